@@ -1,0 +1,48 @@
+#!/usr/bin/env bash
+# Build the REAL reference (danshapero/sigma, Fortran 2003) from the sources
+# where they lie under /root/reference, with amdflang.  TEST INFRASTRUCTURE
+# ONLY: outputs go to oracle/_ref/ (git-ignored); no reference source is copied.
+#
+# Only the modules on / below the hot path are compiled, in the order of
+# /root/reference/src/CMakeLists.txt:1-40.  Not compiled: eigensolver.f90
+# (needs LAPACK dstev), wrapper.f90 (dead code), sigma.f90 (umbrella).
+# util.f90 holds one off-path routine (`determinant`, util.f90:59) that calls
+# LAPACK dgetrf; the image has no LAPACK, no stand-in is written, and the
+# symbol is simply left unresolved in the shared object (never called on the
+# matvec / solver path; lazy binding).
+set -euo pipefail
+REF=${SIGMA_REFERENCE:-/root/reference}
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/_ref"
+FC=${FC:-/opt/rocm/bin/amdflang}
+[ -d "$REF/src" ] || { echo "reference sources not present at $REF - skipping"; exit 0; }
+command -v "$FC" >/dev/null || { echo "no Fortran compiler ($FC) - skipping"; exit 0; }
+mkdir -p "$OUT/obj"
+SRCS="types.f90 util.f90 vectors.f90
+ linear_operator/linear_operator_interface.f90 linear_operator/linear_operator_sums.f90
+ linear_operator/linear_operator_products.f90 linear_operator/linear_operator_adjoints.f90
+ linear_operator/linear_operators.f90
+ graph/graph_interfaces.f90 graph/formats/coo_graphs.f90 graph/formats/cs_graphs.f90
+ graph/formats/ellpack_graphs.f90 graph/formats/ll_graphs.f90 graph/graph_factory.f90
+ graph/permutations.f90 graph/graphs.f90
+ matrix/sparse_matrix_interfaces.f90 matrix/formats/default_sparse_matrix_kernels.f90
+ matrix/formats/default_matrices.f90 matrix/formats/cs_matrices.f90
+ matrix/formats/ellpack_matrices.f90 matrix/sparse_matrix_factory.f90
+ matrix/sparse_matrix_composites.f90 matrix/sparse_matrix_algebra.f90
+ matrix/sparse_matrices.f90
+ solver/bicgstab_solvers.f90 solver/cg_solvers.f90 solver/jacobi_solvers.f90
+ solver/ldu_solvers.f90"
+cd "$OUT/obj"
+OBJS=""
+for s in $SRCS; do
+  o="$(basename "${s%.f90}").o"
+  if [ ! -f "$o" ] || [ "$REF/src/$s" -nt "$o" ]; then
+    "$FC" -O2 -fPIC -c "$REF/src/$s" -o "$o"
+  fi
+  OBJS="$OBJS $o"
+done
+# the driver is OUR code (oracle/ref_driver.f90); it only `use`s reference modules
+"$FC" -O2 -fPIC -c "$HERE/ref_driver.f90" -o ref_driver.o
+"$FC" -O2 -o "$OUT/sigma_ref_driver" ref_driver.o $OBJS \
+    -Wl,-z,execstack -Wl,--unresolved-symbols=ignore-all
+echo "built $OUT/sigma_ref_driver"

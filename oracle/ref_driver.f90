@@ -1,0 +1,219 @@
+!==========================================================================!
+! ref_driver -- TEST INFRASTRUCTURE ONLY (never shipped, never measured as   !
+! the product).  This program is OUR code: it `use`s the modules of the     !
+! real reference (danshapero/sigma, compiled in place from /root/reference  !
+! by oracle/build_ref.sh) and drives the hot path named in SURVEY.md §8:    !
+!                                                                          !
+!   ll_graph%add_edge -> convert_graph_type -> A%set_value    (§3 D)       !
+!   A%matvec                      linear_operator_interface.f90:185-194    !
+!   cg / bicgstab %solve          cg_solvers.f90:116-194,                   !
+!                                 bicgstab_solvers.f90:124-237             !
+!   jacobi / ldu %setup, %solve   jacobi_solvers.f90:37-81,                 !
+!                                 ldu_solvers.f90:95-176                   !
+!                                                                          !
+! It reads one problem file (written by oracle/make_golden.py), runs it    !
+! through the reference and dumps every array as a raw little-endian file  !
+! `<outprefix>.<name>.<i4|f8>`, which make_golden.py packs into the        !
+! committed fixtures under tests/golden/.                                   !
+!                                                                          !
+! Problem file (unformatted stream, int32 / float64):                      !
+!   n, m, ne, fmt(1=csr,2=ellpack), nsolve                                  !
+!   ei(ne), ej(ne)      edges in INSERTION order (1-based)                  !
+!   ev(ne)              value given to set_value(ei,ej)                     !
+!   x(m)                matvec input                                        !
+!   b(n)                right-hand side                                     !
+!   nsolve x { solver(1=cg,2=bicgstab), pc(0,1=jacobi,2=ldu), tol(f8) }     !
+!==========================================================================!
+program ref_driver
+
+use types, only: dp
+use graphs
+use sparse_matrices
+use linear_operator_interface
+use cg_solvers
+use bicgstab_solvers
+use jacobi_solvers
+use ldu_solvers
+
+implicit none
+
+    character(len=512) :: infile, outprefix
+    integer :: n, m, ne, fmt, nsolve, k, s, its
+    integer, allocatable :: ei(:), ej(:), skind(:), pkind(:)
+    real(dp), allocatable :: ev(:), x(:), b(:), y(:), u(:), z(:), tols(:)
+    class(graph_interface), pointer :: g
+    type(csr_matrix), target :: Acsr
+    type(ellpack_matrix), target :: Aell
+    class(sparse_matrix_interface), pointer :: A
+    class(linear_solver), pointer :: solver, pc
+    character(len=16) :: tag
+    real(dp) :: t0, t1
+
+    call getarg(1, infile)
+    call getarg(2, outprefix)
+
+    open(unit=21, file=trim(infile), access='stream', form='unformatted', &
+        & status='old')
+    read(21) n, m, ne, fmt, nsolve
+    allocate(ei(ne), ej(ne), ev(ne), x(m), b(n), y(n), u(n), z(n))
+    allocate(skind(nsolve), pkind(nsolve), tols(nsolve))
+    read(21) ei
+    read(21) ej
+    read(21) ev
+    read(21) x
+    read(21) b
+    do s = 1, nsolve
+        read(21) skind(s), pkind(s), tols(s)
+    enddo
+    close(21)
+
+    !------------------------------------------------------------------!
+    ! Graph: same call sequence as test/solver_test_jacobi.f90:73-101   !
+    !------------------------------------------------------------------!
+    allocate(ll_graph :: g)
+    call g%init(n, m)
+    do k = 1, ne
+        call g%add_edge(ei(k), ej(k))
+    enddo
+
+    if (fmt == 1) then
+        call convert_graph_type(g, "compressed sparse")
+        call Acsr%init(n, m)
+        call Acsr%set_graph(g)
+        call Acsr%zero()
+        A => Acsr
+    else
+        call convert_graph_type(g, "ellpack")
+        call Aell%init(n, m)
+        call Aell%set_graph(g)
+        call Aell%zero()
+        A => Aell
+    endif
+
+    do k = 1, ne
+        call A%set_value(ei(k), ej(k), ev(k))
+    enddo
+
+    !------------------------------------------------------------------!
+    ! Index arrays + values exactly as the reference holds them         !
+    !------------------------------------------------------------------!
+    if (fmt == 1) then
+        call dump_i4('ptr', Acsr%g%ptr, size(Acsr%g%ptr))
+        call dump_i4('node', Acsr%g%node, size(Acsr%g%node))
+        call dump_f8('val', Acsr%val, size(Acsr%val))
+    else
+        call dump_i4('max_d', [Aell%g%max_d], 1)
+        call dump_i4('degrees', Aell%g%degrees, size(Aell%g%degrees))
+        call dump_i4('node', reshape(Aell%g%node, [size(Aell%g%node)]), &
+            & size(Aell%g%node))
+        call dump_f8('val', reshape(Aell%val, [size(Aell%val)]), &
+            & size(Aell%val))
+    endif
+
+    !------------------------------------------------------------------!
+    ! y = A x   and   y2 = y + A x  (matvec, then matvec_add on top)    !
+    !------------------------------------------------------------------!
+    y = -7.0_dp     ! garbage on purpose: matvec must overwrite
+    call A%matvec(x, y)
+    call dump_f8('y', y, n)
+    call A%matvec_add(x, y)
+    call dump_f8('y_add', y, n)
+
+    !------------------------------------------------------------------!
+    ! Solves                                                            !
+    !------------------------------------------------------------------!
+    do s = 1, nsolve
+        write(tag, '(a,i0)') 's', s
+
+        if (skind(s) == 1) then
+            solver => cg(tols(s))
+        else
+            solver => bicgstab(tols(s))
+        endif
+        call solver%setup(A)
+
+        nullify(pc)
+        if (pkind(s) == 1) then
+            pc => jacobi()
+        elseif (pkind(s) == 2) then
+            pc => ldu(incomplete = .true., level = 0)
+        endif
+
+        if (associated(pc)) then
+            call pc%setup(A)
+            ! one stand-alone preconditioner apply z = M^{-1} b
+            z = 0.0_dp
+            call pc%solve(A, z, b)
+            call dump_f8(trim(tag)//'_pcz', z, n)
+            select type(pc)
+                type is(jacobi_solver)
+                    call dump_f8(trim(tag)//'_idiag', pc%idiag, n)
+                type is(sparse_ldu_solver)
+                    call dump_i4(trim(tag)//'_Lptr', pc%L%g%ptr, n + 1)
+                    call dump_i4(trim(tag)//'_Lnode', pc%L%g%node, &
+                        & size(pc%L%g%node))
+                    call dump_f8(trim(tag)//'_Lval', pc%L%val, &
+                        & size(pc%L%val))
+                    call dump_i4(trim(tag)//'_Uptr', pc%U%g%ptr, n + 1)
+                    call dump_i4(trim(tag)//'_Unode', pc%U%g%node, &
+                        & size(pc%U%g%node))
+                    call dump_f8(trim(tag)//'_Uval', pc%U%val, &
+                        & size(pc%U%val))
+                    call dump_f8(trim(tag)//'_D', pc%D, n)
+            end select
+        endif
+
+        u = 0.0_dp
+        call cpu_time(t0)
+        if (associated(pc)) then
+            call solver%solve(A, u, b, pc)
+        else
+            call solver%solve(A, u, b)
+        endif
+        call cpu_time(t1)
+
+        its = -1
+        select type(solver)
+            type is(cg_solver)
+                its = solver%iterations
+            type is(bicgstab_solver)
+                its = solver%iterations
+        end select
+
+        call dump_f8(trim(tag)//'_u', u, n)
+        call dump_i4(trim(tag)//'_iterations', [its], 1)
+        print '(a,i0,a,i0,a,i0,a,i0,a,es10.3)', 'solve ', s, ': solver=', &
+            & skind(s), ' pc=', pkind(s), ' iterations=', its, &
+            & ' seconds=', t1 - t0
+
+        call solver%destroy()
+        deallocate(solver)
+        if (associated(pc)) then
+            call pc%destroy()
+            deallocate(pc)
+        endif
+    enddo
+
+contains
+
+    subroutine dump_i4(name, arr, cnt)
+        character(len=*), intent(in) :: name
+        integer, intent(in) :: cnt
+        integer, intent(in) :: arr(cnt)
+        open(unit=22, file=trim(outprefix)//'.'//name//'.i4', &
+            & access='stream', form='unformatted', status='replace')
+        write(22) arr
+        close(22)
+    end subroutine dump_i4
+
+    subroutine dump_f8(name, arr, cnt)
+        character(len=*), intent(in) :: name
+        integer, intent(in) :: cnt
+        real(dp), intent(in) :: arr(cnt)
+        open(unit=22, file=trim(outprefix)//'.'//name//'.f8', &
+            & access='stream', form='unformatted', status='replace')
+        write(22) arr
+        close(22)
+    end subroutine dump_f8
+
+end program ref_driver
