@@ -1,0 +1,178 @@
+/*
+ * sigma_hip.h -- C ABI of the MI355X-native SpMV + Krylov path for SiGMA.
+ *
+ * This is the drop-in boundary.  The reference (danshapero/sigma) has
+ * no usable FFI for this path: src/wrapper.f90 is dead code that wraps graph edits only
+ * (src/wrapper.f90:100-303, excluded at src/CMakeLists.txt:39-40).  What the Fortran
+ * host binds with ISO_C_BINDING is therefore the set of type-bound procedures that make
+ * up the path; every entry point below names the one it replaces.  Conventions follow
+ * src/wrapper.f90: opaque handles (type(c_ptr)), `integer(c_int), value` scalars, and
+ * index arrays are handed over EXACTLY as the Fortran holds them -- 1-based int32
+ * (src/graph/formats/cs_graphs.f90:16, src/graph/formats/ellpack_graphs.f90:14) --
+ * conversion to the device layout is this library's job.
+ *
+ * Errors: the reference prints and calls exit(1) (src/solver/cg_solvers.f90:61-65).
+ * Here every function returns an int status (0 = ok) and sgm_last_error() holds the
+ * message; sigma_amd/fortran/sigma_hip.f90 turns nonzero into print + exit(1).
+ *
+ * `where` arguments say where the caller's arrays live: SGM_HOST (copied across PCIe
+ * inside the call) or SGM_DEVICE (HBM pointers, e.g. from sgm_malloc or a torch tensor).
+ * All calls are synchronous on return unless sgm_set_async(1) was called.
+ * Not thread-safe (the reference is single-threaded); one process drives one GPU.
+ */
+#ifndef SIGMA_HIP_H
+#define SIGMA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sgm_mat_s *sgm_mat;       /* class(sparse_matrix_interface) leaf: csr_matrix / ellpack_matrix */
+typedef struct sgm_pc_s *sgm_pc;         /* class(linear_solver) used as preconditioner: jacobi / ldu      */
+typedef struct sgm_solver_s *sgm_solver; /* class(linear_solver): cg / bicgstab / gmres                    */
+typedef struct sgm_comm_s *sgm_comm;     /* row-partition communicator (RCCL over xGMI); no reference analogue */
+
+enum {
+    SGM_OK = 0,
+    SGM_ERR_BAD_ARG = 1,
+    SGM_ERR_DIMS = 2,          /* non-square matrix handed to a solver: cg_solvers.f90:61-65 */
+    SGM_ERR_HIP = 3,
+    SGM_ERR_RCCL = 4,
+    SGM_ERR_NOT_CONVERGED = 5, /* only when a max_iter extension is set and hit */
+    SGM_ERR_NO_DEVICE = 6,
+    SGM_ERR_ALLOC = 7,
+    SGM_ERR_UNSUPPORTED = 8
+};
+enum { SGM_HOST = 0, SGM_DEVICE = 1 };
+enum { SGM_FMT_CSR = 1, SGM_FMT_ELL = 2 };
+enum { SGM_SOLVER_CG = 1, SGM_SOLVER_BICGSTAB = 2, SGM_SOLVER_GMRES = 3 };
+enum { SGM_PC_JACOBI = 1, SGM_PC_ILDU0 = 2 };
+
+/* ---- runtime -------------------------------------------------------------------- */
+int sgm_init(int device);                 /* hipSetDevice + stream; fails loudly without a GPU */
+int sgm_finalize(void);
+const char *sgm_last_error(void);
+int sgm_set_stream(void *hip_stream);     /* adopt the caller's hipStream_t (NULL = library stream) */
+int sgm_set_async(int on);                /* 1: calls return without hipStreamSynchronize */
+int sgm_synchronize(void);
+int sgm_malloc(void **p, size_t bytes);   /* HBM buffer for hosts without a device allocator */
+int sgm_free(void *p);
+int sgm_memcpy(void *dst, const void *src, size_t bytes, int kind); /* 0 h2d, 1 d2h, 2 d2d */
+
+/* ---- matrices -------------------------------------------------------------------- *
+ * sgm_csr_create    <- csr_matrix: g%ptr(n+1), g%node(nnz), val(nnz)
+ *                      src/matrix/formats/cs_matrices.f90:32-38,112-151; cs_graphs.f90:16
+ * sgm_ell_create    <- ellpack_matrix: g%node(max_d,n), val(max_d,n) column-major,
+ *                      padding = last neighbour / 0.0
+ *                      src/matrix/formats/ellpack_matrices.f90:28-33; ellpack_graphs.f90:14,164
+ * sgm_*_set_values  <- re-upload after host-side set_value/add_value
+ *                      (test/solver_test_jacobi.f90:240-274 edits A, then re-runs setup)
+ * sgm_mat_matvec    <- A%matvec(x,y): y = 0 ; matvec_add
+ *                      src/linear_operator/linear_operator_interface.f90:185-194
+ * sgm_mat_matvec_add<- csr_matvec_add cs_matrices.f90:600-622 /
+ *                      ellpack_matvec_add ellpack_matrices.f90:640-665
+ * sgm_mat_destroy   <- A%destroy()
+ * Results are bit-identical to the reference loops: per row, products are rounded
+ * individually and added left to right in stored order (no FMA, no reassociation).   */
+int sgm_csr_create(sgm_mat *out, int32_t nrow, int32_t ncol, int64_t nnz,
+                   const int32_t *ptr_1based, const int32_t *node_1based,
+                   const double *val, int where);
+int sgm_csr_set_values(sgm_mat A, const double *val, int where);
+int sgm_ell_create(sgm_mat *out, int32_t nrow, int32_t ncol, int32_t max_d,
+                   const int32_t *node_1based_colmajor, const double *val_colmajor,
+                   int where);
+int sgm_ell_set_values(sgm_mat A, const double *val_colmajor, int where);
+int sgm_mat_matvec(sgm_mat A, const double *x, double *y, int where);
+int sgm_mat_matvec_add(sgm_mat A, const double *x, double *y, int where);
+int sgm_mat_info(sgm_mat A, int32_t *nrow, int32_t *ncol, int64_t *nnz, int32_t *fmt,
+                 int64_t *x_len /* entries matvec reads from x: ncol, or owned+halo when distributed */);
+int sgm_mat_destroy(sgm_mat A);
+
+/* ---- vector statements inline in the solvers (SURVEY §2a "dot", "axpy family") ---- *
+ * dot_product(a,b)  cg_solvers.f90:131,135,140 ; y = y + alpha*x  cg_solvers.f90:137-138 */
+int sgm_dot(int64_t n, const double *a, const double *b, double *result, int where);
+int sgm_axpy(int64_t n, double alpha, const double *x, double *y, int where);
+
+/* ---- preconditioners --------------------------------------------------------------- *
+ * sgm_jacobi_create <- jacobi() + jacobi_setup      src/solver/jacobi_solvers.f90:23-63
+ * sgm_ildu0_create  <- ldu(incomplete,level=0) + sparse_ldu_setup
+ *                      src/solver/ldu_solvers.f90:73-130 (pattern :397-440, factorization
+ *                      :275-387 run on the host once; factors + level sets live in HBM)
+ * sgm_pc_setup      <- pc%setup(A) again after the values changed
+ * sgm_pc_apply      <- pc%solve(A, z, r): jacobi_solve :68-81 / ldu_solve :160-176
+ * sgm_pc_get        <- read back idiag / L,D,U for parity checks ("idiag","Lptr","Lnode",
+ *                      "Lval","Uptr","Unode","Uval","D"; 1-based like the reference)       */
+int sgm_jacobi_create(sgm_pc *out, sgm_mat A);
+int sgm_ildu0_create(sgm_pc *out, sgm_mat A);
+int sgm_pc_setup(sgm_pc pc, sgm_mat A);
+int sgm_pc_apply(sgm_pc pc, const double *r, double *z, int where);
+int sgm_pc_get(sgm_pc pc, const char *name, void *out_host, size_t bytes, size_t *needed);
+int sgm_pc_destroy(sgm_pc pc);
+
+/* ---- solvers ------------------------------------------------------------------------ *
+ * sgm_cg_create       <- cg(tolerance)            src/solver/cg_solvers.f90:36-47
+ * sgm_bicgstab_create <- bicgstab(tolerance)      src/solver/bicgstab_solvers.f90:37-48
+ * sgm_gmres_create    <- NO reference counterpart; GMRES(restart), MGS Arnoldi,
+ *                        same tolerance / iterations conventions as cg
+ * sgm_solver_setup    <- solver%setup(A): square check, work vectors, iterations = 0
+ *                        cg_solvers.f90:52-90
+ * sgm_solver_solve    <- solver%solve(A,x,b[,pc]): cg_solve :116-150, cg_solve_pc :155-194,
+ *                        bicgstab_solve :124-177, bicgstab_solve_pc :182-237.
+ *                        ABSOLUTE tolerance on sqrt(res2), initial guess from x, no
+ *                        iteration cap unless sgm_solver_set_max_iter (an extension) is
+ *                        called; `iterations` accumulates across solves like the reference.
+ *                        The whole loop is device-resident: x and b cross the boundary once.
+ * sgm_solver_destroy  <- solver%destroy()          cg_solvers.f90:199-212                 */
+int sgm_cg_create(sgm_solver *out, double tolerance);
+int sgm_bicgstab_create(sgm_solver *out, double tolerance);
+int sgm_gmres_create(sgm_solver *out, double tolerance, int32_t restart);
+int sgm_solver_setup(sgm_solver s, sgm_mat A);
+int sgm_solver_set_max_iter(sgm_solver s, int64_t max_iter /* <= 0: unbounded */);
+int sgm_solver_set_history(sgm_solver s, int64_t capacity); /* record res2 per iteration */
+int sgm_solver_solve(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc pc_or_null,
+                     int where);
+int sgm_solver_info(sgm_solver s, int64_t *iterations, double *res2, int32_t *converged,
+                    int64_t *last_solve_iterations);
+int sgm_solver_get_history(sgm_solver s, double *out_host, int64_t capacity, int64_t *count);
+int sgm_solver_destroy(sgm_solver s);
+
+/* ---- row-partitioned multi-GPU (nothing in the reference) ---------------- *
+ * One process per GPU.  Rank r owns the contiguous global rows
+ * [row_starts[r], row_starts[r+1]) of A and the same slice of every vector.
+ * sgm_comm_unique_id / sgm_comm_init: RCCL bootstrap (the 128-byte id is broadcast by the
+ * host, e.g. over torch.distributed/gloo or MPI).
+ * sgm_csr_create_dist: this rank's rows with GLOBAL 1-based column ids; builds the sorted
+ * unique halo list, renumbers columns to [owned | halo] and exchanges the send lists.
+ * A distributed matrix reads x of length x_len = owned + halo (sgm_mat_info): the owned
+ * part is the caller's, the halo part is filled by the library (ncclSend/ncclRecv with
+ * the neighbour ranks) in every matvec.  Dots inside the solvers become
+ * ncclAllReduce(sum, fp64); row sums stay bit-identical to the 1-GPU result.
+ * sgm_csr_create_partitioned: the same partition / halo / reduction machinery with all P
+ * row blocks inside ONE process on ONE GPU (exchanges are device gathers): x, y, b are
+ * plain global-length vectors.  It exists so that the multi-GPU logic is exercised by
+ * `pytest -m gpu` on a single-GPU box.
+ * sgm_halo_plan_host: the host-only index work of the two calls above (no HIP call), so it
+ * can be checked bit-for-bit without a GPU: sorted unique halo list (global, 1-based) and
+ * the renumbered node array (1-based: 1..n_own owned, n_own+1.. halo, in halo-list order). */
+int sgm_comm_unique_id(void *id128);
+int sgm_comm_init(sgm_comm *out, int rank, int nranks, const void *id128);
+int sgm_comm_destroy(sgm_comm c);
+int sgm_csr_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts /* nranks+1, 0-based */,
+                        int64_t nnz_local, const int32_t *ptr_1based_local,
+                        const int32_t *node_1based_global, const double *val, int where);
+int sgm_csr_create_partitioned(sgm_mat *out, int32_t nparts, const int64_t *row_starts /* nparts+1 */,
+                               int32_t nrow, int32_t ncol, int64_t nnz,
+                               const int32_t *ptr_1based, const int32_t *node_1based,
+                               const double *val /* host arrays */);
+int sgm_halo_plan_host(int32_t n_own, int64_t col_begin /* first owned global column, 0-based */,
+                       int64_t nnz, const int32_t *node_1based_global,
+                       int32_t *node_1based_local_out, int32_t *halo_cols_out /* capacity nnz */,
+                       int32_t *n_halo_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIGMA_HIP_H */

@@ -1,0 +1,496 @@
+"""sigma_amd -- MI355X-native SpMV + Krylov path for SiGMA (danshapero/sigma).
+
+This package is the thin host side above the C ABI of ``libsigma_hip.so``
+(include/sigma_hip.h): it mirrors the reference's operator / solver interface for the
+hot path -- same names, argument meaning and error behaviour --
+
+    A = csr_matrix(n, m, ptr, node, val)       cs_matrices.f90:32-151  (1-based arrays)
+    A = ellpack_matrix(n, m, node, val)        ellpack_matrices.f90:28-105
+    A.matvec(x, y); A.matvec_add(x, y)         linear_operator_interface.f90:185-194
+    solver = cg(tolerance)                     cg_solvers.f90:36-47
+    solver = bicgstab(tolerance)               bicgstab_solvers.f90:37-48
+    pc = jacobi(); pc = ldu(incomplete, level) jacobi_solvers.f90:23-31, ldu_solvers.f90:73-86
+    solver.setup(A); pc.setup(A)
+    solver.solve(A, x, b[, pc])                generic solve: linear_solve / linear_solve_pc
+    solver.iterations, solver.tolerance, solver.nn, solver.initialized
+    solver.destroy(); A.destroy()
+
+All arithmetic happens in hand-written HIP kernels for gfx950; there is NO CPU fallback:
+importing works anywhere (so the build and symbol checks run on a CPU box), but any
+compute call without a GPU raises SigmaError.  Vectors may be numpy arrays (copied over
+PCIe inside the call) or CUDA/HIP torch tensors (used in place in HBM).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsigma_hip.so")
+
+SGM_HOST, SGM_DEVICE = 0, 1
+FMT_CSR, FMT_ELL = 1, 2
+
+_lib = None
+
+
+class SigmaError(RuntimeError):
+    """Nonzero status from libsigma_hip.so (the reference would print and exit(1))."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"[sigma_hip status {code}] {msg}")
+        self.code = code
+
+
+def build(force=False):
+    """Compile libsigma_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    import subprocess
+    src = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", src, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", src, "-j4"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded C-ABI library.  Fails loudly when the HIP extension is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SigmaError(-1, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                 "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.sgm_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _ck(rc):
+    if rc != 0:
+        raise SigmaError(rc, lib().sgm_last_error().decode(errors="replace"))
+
+
+def init(device=0):
+    _ck(lib().sgm_init(C.c_int(device)))
+
+
+def set_stream(stream_ptr):
+    _ck(lib().sgm_set_stream(C.c_void_p(stream_ptr)))
+
+
+def set_async(on):
+    _ck(lib().sgm_set_async(C.c_int(1 if on else 0)))
+
+
+def synchronize():
+    _ck(lib().sgm_synchronize())
+
+
+def use_torch_stream():
+    """Launch on torch's current HIP stream so torch.cuda.Event brackets our kernels."""
+    import torch
+    set_stream(torch.cuda.current_stream().cuda_stream)
+
+
+# ------------------------------------------------------------------------------------ #
+def _is_torch(a):
+    return hasattr(a, "data_ptr") and hasattr(a, "is_cuda")
+
+
+def _arg(a, dtype, writable=False):
+    """(pointer, where, keepalive) for a numpy array or a device torch tensor."""
+    if _is_torch(a):
+        import torch
+        want = {np.float64: torch.float64, np.int32: torch.int32, np.int64: torch.int64}[dtype]
+        if a.dtype != want or not a.is_contiguous():
+            raise TypeError(f"torch tensor must be contiguous {want}")
+        if not a.is_cuda:
+            return _arg(a.numpy(), dtype, writable)
+        return C.c_void_p(a.data_ptr()), SGM_DEVICE, a
+    arr = np.asarray(a)
+    if arr.dtype != dtype or not arr.flags.c_contiguous or (writable and not arr.flags.writeable):
+        if writable:
+            raise TypeError(f"output array must be a contiguous writable {np.dtype(dtype)} numpy array")
+        arr = np.ascontiguousarray(arr, dtype)
+    return C.c_void_p(arr.ctypes.data), SGM_HOST, arr
+
+
+def _same_where(*ws):
+    if len(set(ws)) != 1:
+        raise TypeError("all vectors of one call must live in the same place (host or device)")
+    return ws[0]
+
+
+class _Matrix:
+    """linear_operator face (nrow, ncol, matvec, matvec_add, destroy)."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        self.nrow = self.ncol = 0
+        self.solver = None       # linear_operator%solver / %pc (linear_operator_interface.f90:29)
+        self.pc = None
+
+    # -- linear_operator_interface.f90:185-194 ------------------------------------------
+    def matvec(self, x, y):
+        px, wx, _k1 = _arg(x, np.float64)
+        py, wy, _k2 = _arg(y, np.float64, writable=True)
+        _ck(lib().sgm_mat_matvec(self._h, px, py, C.c_int(_same_where(wx, wy))))
+        return y
+
+    def matvec_add(self, x, y):
+        px, wx, _k1 = _arg(x, np.float64)
+        py, wy, _k2 = _arg(y, np.float64, writable=True)
+        _ck(lib().sgm_mat_matvec_add(self._h, px, py, C.c_int(_same_where(wx, wy))))
+        return y
+
+    @property
+    def x_len(self):
+        n = C.c_int64(0)
+        _ck(lib().sgm_mat_info(self._h, None, None, None, None, C.byref(n)))
+        return n.value
+
+    # -- linear_operator_interface.f90:213-280: A%solve facade ---------------------------
+    def set_solver(self, solver):
+        self.solver = solver
+        solver.setup(self)
+
+    def set_preconditioner(self, pc):
+        self.pc = pc
+        pc.setup(self)
+
+    def solve(self, x, b):
+        if self.solver is None:
+            raise SigmaError(1, "A%solve: no solver set (linear_operator_interface.f90:213-233)")
+        return self.solver.solve(self, x, b, self.pc)
+
+    def destroy(self):
+        if self._h:
+            _ck(lib().sgm_mat_destroy(self._h))
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class csr_matrix(_Matrix):
+    """csr_matrix (cs_matrices.f90:112-151): g%ptr(n+1), g%node(nnz), val(nnz), 1-based."""
+
+    def __init__(self, nrow, ncol, ptr, node, val):
+        super().__init__()
+        pp, w1, _k1 = _arg(ptr, np.int32)
+        pn, w2, _k2 = _arg(node, np.int32)
+        pv, w3, _k3 = _arg(val, np.float64)
+        self.nrow, self.ncol = int(nrow), int(ncol)
+        self.nnz = int(len(val))
+        _ck(lib().sgm_csr_create(C.byref(self._h), C.c_int32(nrow), C.c_int32(ncol), C.c_int64(self.nnz),
+                                 pp, pn, pv, C.c_int(_same_where(w1, w2, w3))))
+
+    def set_values(self, val):
+        pv, w, _k = _arg(val, np.float64)
+        _ck(lib().sgm_csr_set_values(self._h, pv, C.c_int(w)))
+
+
+class partitioned_csr_matrix(_Matrix):
+    """The multi-GPU row partition with all P row blocks on one GPU (test vehicle)."""
+
+    def __init__(self, nrow, ncol, ptr, node, val, row_starts):
+        super().__init__()
+        ptr = np.ascontiguousarray(ptr, np.int32)
+        node = np.ascontiguousarray(node, np.int32)
+        val = np.ascontiguousarray(val, np.float64)
+        rs = np.ascontiguousarray(row_starts, np.int64)
+        self.nrow, self.ncol, self.nnz = int(nrow), int(ncol), int(len(val))
+        _ck(lib().sgm_csr_create_partitioned(C.byref(self._h), C.c_int32(len(rs) - 1), C.c_void_p(rs.ctypes.data),
+                                             C.c_int32(nrow), C.c_int32(ncol), C.c_int64(self.nnz),
+                                             C.c_void_p(ptr.ctypes.data), C.c_void_p(node.ctypes.data),
+                                             C.c_void_p(val.ctypes.data)))
+
+
+class dist_csr_matrix(_Matrix):
+    """This rank's row block of a matrix partitioned over processes (RCCL)."""
+
+    def __init__(self, comm, row_starts, ptr_local, node_global, val):
+        super().__init__()
+        rs = np.ascontiguousarray(row_starts, np.int64)
+        pp, w1, _k1 = _arg(ptr_local, np.int32)
+        pn, w2, _k2 = _arg(node_global, np.int32)
+        pv, w3, _k3 = _arg(val, np.float64)
+        self.nrow = self.ncol = int(rs[-1])
+        self.n_local = int(rs[comm.rank + 1] - rs[comm.rank])
+        self.nnz = int(len(val))
+        _ck(lib().sgm_csr_create_dist(C.byref(self._h), comm._h, C.c_void_p(rs.ctypes.data), C.c_int64(self.nnz),
+                                      pp, pn, pv, C.c_int(_same_where(w1, w2, w3))))
+
+
+class ellpack_matrix(_Matrix):
+    """ellpack_matrix (ellpack_matrices.f90:28-105): node(max_d,n), val(max_d,n) in Fortran
+    order, i.e. a C array of shape (n, max_d); padding = last neighbour / 0.0."""
+
+    def __init__(self, nrow, ncol, node, val):
+        super().__init__()
+        if _is_torch(node):
+            max_d = int(node.shape[1])
+        else:
+            node = np.ascontiguousarray(node, np.int32)
+            val = np.ascontiguousarray(val, np.float64)
+            max_d = int(node.shape[1]) if node.ndim == 2 else int(node.size // max(nrow, 1))
+        pn, w1, _k1 = _arg(node, np.int32)
+        pv, w2, _k2 = _arg(val, np.float64)
+        self.nrow, self.ncol, self.max_d = int(nrow), int(ncol), max_d
+        _ck(lib().sgm_ell_create(C.byref(self._h), C.c_int32(nrow), C.c_int32(ncol), C.c_int32(max_d), pn, pv,
+                                 C.c_int(_same_where(w1, w2))))
+
+    def set_values(self, val):
+        pv, w, _k = _arg(val, np.float64)
+        _ck(lib().sgm_ell_set_values(self._h, pv, C.c_int(w)))
+
+
+# ------------------------------------------------------------------------------------ #
+class _Preconditioner:
+    """linear_solver used as a preconditioner (setup / solve / destroy)."""
+    _create = None
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        self.nn = 0
+        self.initialized = False
+
+    def setup(self, A):
+        if not self._h:
+            _ck(getattr(lib(), self._create)(C.byref(self._h), A._h))
+        else:
+            _ck(lib().sgm_pc_setup(self._h, A._h))
+        self.nn = A.nrow
+        self.initialized = True
+
+    def solve(self, A, x, b):
+        """pc%solve(A, x, b): x = M^-1 b."""
+        pb, wb, _k1 = _arg(b, np.float64)
+        px, wx, _k2 = _arg(x, np.float64, writable=True)
+        _ck(lib().sgm_pc_apply(self._h, pb, px, C.c_int(_same_where(wb, wx))))
+        return x
+
+    def get(self, name, dtype):
+        need = C.c_size_t(0)
+        _ck(lib().sgm_pc_get(self._h, name.encode(), None, C.c_size_t(0), C.byref(need)))
+        out = np.zeros(need.value // np.dtype(dtype).itemsize, dtype)
+        _ck(lib().sgm_pc_get(self._h, name.encode(), C.c_void_p(out.ctypes.data), C.c_size_t(out.nbytes), None))
+        return out
+
+    def destroy(self):
+        if self._h:
+            _ck(lib().sgm_pc_destroy(self._h))
+            self._h = C.c_void_p()
+        self.initialized = False
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class jacobi_solver(_Preconditioner):
+    _create = "sgm_jacobi_create"
+
+    @property
+    def idiag(self):
+        return self.get("idiag", np.float64)
+
+
+class sparse_ldu_solver(_Preconditioner):
+    _create = "sgm_ildu0_create"
+
+
+def jacobi():
+    """jacobi() factory (jacobi_solvers.f90:23-31)."""
+    return jacobi_solver()
+
+
+def ldu(incomplete=True, level=0):
+    """ldu(incomplete, level) factory (ldu_solvers.f90:73-86).  Like the reference
+    (ldu_set_params :143-151) the arguments are accepted and forced to ILDU(0)."""
+    return sparse_ldu_solver()
+
+
+class _Solver:
+    """linear_solver (linear_operator_interface.f90:61-73)."""
+
+    def __init__(self, tolerance):
+        self._h = C.c_void_p()
+        self.tolerance = 1.0e-16 if tolerance is None else float(tolerance)   # cg_solvers.f90:106
+        self.nn = 0
+        self.initialized = False
+        self._max_iter = 0
+        self._hist = 0
+
+    def _create(self):
+        raise NotImplementedError
+
+    def setup(self, A):
+        if not self._h:
+            self._create()
+            if self._max_iter:
+                _ck(lib().sgm_solver_set_max_iter(self._h, C.c_int64(self._max_iter)))
+            if self._hist:
+                _ck(lib().sgm_solver_set_history(self._h, C.c_int64(self._hist)))
+        _ck(lib().sgm_solver_setup(self._h, A._h))
+        self.nn = A.nrow
+        self.initialized = True
+
+    def set_max_iter(self, max_iter):
+        """Extension: the reference has no iteration cap.  <= 0 = unbounded."""
+        self._max_iter = int(max_iter)
+        if self._h:
+            _ck(lib().sgm_solver_set_max_iter(self._h, C.c_int64(self._max_iter)))
+
+    def set_history(self, capacity):
+        self._hist = int(capacity)
+        if self._h:
+            _ck(lib().sgm_solver_set_history(self._h, C.c_int64(self._hist)))
+
+    def solve(self, A, x, b, pc=None, check=True):
+        """solver%solve(A, x, b[, pc]): x holds the initial guess on entry, the solution on
+        exit.  With set_max_iter, hitting the cap raises unless check=False."""
+        px, wx, _k1 = _arg(x, np.float64, writable=True)
+        pb, wb, _k2 = _arg(b, np.float64)
+        rc = lib().sgm_solver_solve(self._h, A._h, px, pb, pc._h if pc is not None else None,
+                                    C.c_int(_same_where(wx, wb)))
+        if rc == 5 and not check:
+            return x
+        _ck(rc)
+        return x
+
+    def _info(self):
+        it, last = C.c_int64(0), C.c_int64(0)
+        r, cv = C.c_double(0.0), C.c_int32(0)
+        _ck(lib().sgm_solver_info(self._h, C.byref(it), C.byref(r), C.byref(cv), C.byref(last)))
+        return it.value, r.value, cv.value, last.value
+
+    @property
+    def iterations(self):
+        return self._info()[0] if self._h else 0
+
+    @property
+    def last_iterations(self):
+        return self._info()[3]
+
+    @property
+    def res2(self):
+        return self._info()[1]
+
+    @property
+    def converged(self):
+        return bool(self._info()[2])
+
+    @property
+    def history(self):
+        cnt = C.c_int64(0)
+        _ck(lib().sgm_solver_get_history(self._h, None, C.c_int64(0), C.byref(cnt)))
+        out = np.zeros(cnt.value, np.float64)
+        if cnt.value:
+            _ck(lib().sgm_solver_get_history(self._h, C.c_void_p(out.ctypes.data), C.c_int64(cnt.value), None))
+        return out
+
+    def destroy(self):
+        if self._h:
+            _ck(lib().sgm_solver_destroy(self._h))
+            self._h = C.c_void_p()
+        self.initialized = False
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class cg_solver(_Solver):
+    def _create(self):
+        _ck(lib().sgm_cg_create(C.byref(self._h), C.c_double(self.tolerance)))
+
+
+class bicgstab_solver(_Solver):
+    def _create(self):
+        _ck(lib().sgm_bicgstab_create(C.byref(self._h), C.c_double(self.tolerance)))
+
+
+class gmres_solver(_Solver):
+    def __init__(self, tolerance, restart):
+        super().__init__(tolerance)
+        self.restart = int(restart)
+
+    def _create(self):
+        _ck(lib().sgm_gmres_create(C.byref(self._h), C.c_double(self.tolerance), C.c_int32(self.restart)))
+
+
+def cg(tolerance=None):
+    """cg(tolerance) factory (cg_solvers.f90:36-47); default tolerance 1e-16 (:106)."""
+    return cg_solver(tolerance)
+
+
+def bicgstab(tolerance=None):
+    """bicgstab(tolerance) factory (bicgstab_solvers.f90:37-48)."""
+    return bicgstab_solver(tolerance)
+
+
+def gmres(tolerance=None, restart=30):
+    """GMRES(restart).  Not in the reference; conventions follow cg."""
+    return gmres_solver(tolerance, restart)
+
+
+# ------------------------------------------------------------------------------------ #
+class Comm:
+    """RCCL communicator for the row partition (one process per GPU)."""
+
+    def __init__(self, rank, nranks, unique_id):
+        self._h = C.c_void_p()
+        self.rank, self.nranks = int(rank), int(nranks)
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        _ck(lib().sgm_comm_init(C.byref(self._h), C.c_int(rank), C.c_int(nranks), buf))
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * 128)()
+        _ck(lib().sgm_comm_unique_id(buf))
+        return bytes(buf)
+
+    def destroy(self):
+        if self._h:
+            _ck(lib().sgm_comm_destroy(self._h))
+            self._h = C.c_void_p()
+
+
+def halo_plan_host(n_own, col_begin, node_global):
+    """Host-only index work of the row partition (no GPU needed): returns
+    (node_local 1-based, halo_cols sorted unique global 1-based)."""
+    node = np.ascontiguousarray(node_global, np.int32)
+    out = np.zeros(len(node), np.int32)
+    halo = np.zeros(max(len(node), 1), np.int32)
+    nh = C.c_int32(0)
+    _ck(lib().sgm_halo_plan_host(C.c_int32(n_own), C.c_int64(col_begin), C.c_int64(len(node)),
+                                 C.c_void_p(node.ctypes.data), C.c_void_p(out.ctypes.data),
+                                 C.c_void_p(halo.ctypes.data), C.byref(nh)))
+    return out, halo[:nh.value].copy()
+
+
+def dot(a, b):
+    pa, wa, _k1 = _arg(a, np.float64)
+    pb, wb, _k2 = _arg(b, np.float64)
+    n = a.numel() if _is_torch(a) else len(a)
+    r = C.c_double(0.0)
+    _ck(lib().sgm_dot(C.c_int64(n), pa, pb, C.byref(r), C.c_int(_same_where(wa, wb))))
+    return r.value
+
+
+def axpy(alpha, x, y):
+    px, wx, _k1 = _arg(x, np.float64)
+    py, wy, _k2 = _arg(y, np.float64, writable=True)
+    n = x.numel() if _is_torch(x) else len(x)
+    _ck(lib().sgm_axpy(C.c_int64(n), C.c_double(alpha), px, py, C.c_int(_same_where(wx, wy))))
+    return y

@@ -1,0 +1,182 @@
+// Internal declarations of libsigma_hip.so (gfx950 / CDNA4 only).
+// Public surface: include/sigma_hip.h.  Nothing here includes or links oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sigma_hip.h"
+
+namespace sgm {
+
+// ------------------------------------------------------------------ errors
+extern std::string g_err;
+int fail(int code, const char *fmt, ...);
+
+#define SGM_HIP(call)                                                              \
+    do {                                                                           \
+        hipError_t e__ = (call);                                                   \
+        if (e__ != hipSuccess)                                                     \
+            return sgm::fail(SGM_ERR_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__,   \
+                             #call, hipGetErrorString(e__));                       \
+    } while (0)
+#define SGM_TRY(call)                        \
+    do {                                     \
+        int rc__ = (call);                   \
+        if (rc__ != SGM_OK) return rc__;     \
+    } while (0)
+
+// ------------------------------------------------------------------ runtime
+struct Runtime {
+    bool ready = false;
+    int device = -1;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool async = false;
+    int num_cu = 256;
+};
+extern Runtime g_rt;
+int require_init();
+int finish();   // hipStreamSynchronize unless async
+
+template <class T>
+int dalloc(T **p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+    if (e != hipSuccess)
+        return fail(SGM_ERR_ALLOC, "hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
+    return SGM_OK;
+}
+inline void dfree(void *p) { if (p) (void)hipFree(p); }
+
+// ------------------------------------------------------------------ launch geometry
+constexpr int kBlock = 256;          // 4 waves of 64
+constexpr int kMaxGrid = 2048;       // 256 CUs x 8 resident 256-thread blocks
+constexpr int kTile = 2048;          // nnz products staged in LDS per tile (16 KiB)
+constexpr int kSlots = 32;           // device scalar slots per solver part
+
+inline int vec_grid(int64_t n)
+{
+    int64_t g = (n + 4 * kBlock - 1) / (4 * kBlock);     // >= 4 elements per thread
+    if (g < 1) g = 1;
+    if (g > kMaxGrid) g = kMaxGrid;
+    return (int)g;
+}
+
+// A scalar that lives on the device as `count` partial sums (count == 1: already
+// reduced, e.g. after an all-reduce).  Every consumer block re-reduces the partials in
+// the same fixed order, so all blocks see the same bits and no host round trip or
+// atomic is needed between a dot product and its consumers.
+struct ScalarRef {
+    const double *ptr;
+    int count;
+};
+
+// ------------------------------------------------------------------ matrices
+struct HaloNbr {
+    int peer = -1;                 // rank (RCCL) or part index (local)
+    int32_t send_count = 0;        // my owned entries the peer needs
+    int32_t *send_idx = nullptr;   // device: local owned indices, in the peer's halo order
+    double *send_buf = nullptr;    // device staging (RCCL only)
+    int32_t recv_offset = 0;       // offset inside my halo region
+    int32_t recv_count = 0;
+};
+
+struct Part {
+    int32_t n = 0;                 // owned rows
+    int32_t ncol_own = 0;          // owned columns (== n for the square partitions used)
+    int32_t n_halo = 0;
+    int64_t nnz = 0;
+    int64_t row_begin = 0;         // first owned global row
+    // CSR (device, 0-based; col indexes [owned | halo]); val/col padded by 2 entries
+    int32_t *rowptr = nullptr;
+    int32_t *col = nullptr;
+    double *val = nullptr;
+    // ELLPACK (device, slot-major: entry (slot k, row i) at k*n + i)
+    int32_t max_d = 0;
+    int32_t *ecol = nullptr;
+    double *eval = nullptr;
+    std::vector<HaloNbr> nbrs;
+    double *xext = nullptr;        // owned+halo staging for plain-vector matvec (multi-part only)
+    int64_t xlen() const { return (int64_t)ncol_own + n_halo; }
+};
+
+}  // namespace sgm
+
+struct sgm_comm_s {
+    int rank = 0, nranks = 1;
+    void *nccl = nullptr;          // ncclComm_t
+};
+
+struct sgm_mat_s {
+    int32_t fmt = 0;
+    int32_t nrow = 0, ncol = 0;    // global
+    int64_t nnz = 0;               // global (local sum when distributed)
+    std::vector<sgm::Part> parts;  // 1 unless created with sgm_csr_create_partitioned
+    sgm_comm comm = nullptr;       // RCCL communicator when distributed over processes
+    bool distributed() const { return comm != nullptr || parts.size() > 1; }
+    // host copies kept for host-side setup work (ILDU factorisation, Jacobi); 1-based
+    std::vector<int32_t> h_ptr, h_node;
+    std::vector<double> h_val;
+    bool host_copy = false;
+};
+
+namespace sgm {
+
+// exchange the halo part of an extended vector set (one pointer per local part)
+int halo_exchange(sgm_mat A, double *const *xext);
+// sum `count` scalar slots across parts / ranks (in place, every part gets the total)
+int allreduce_slots(sgm_mat A, double *const *slot_ptrs, int count);
+
+// y = [y +] A x on every part; optional fused dots: partial sums of w[i]*y[i] (dot_w) and
+// y[i]*y[i] (dot_yy) per block into partials arrays (kMaxGrid doubles each).
+struct SpmvDots {
+    const double *const *w = nullptr;   // per part; nullptr = no w.y dot
+    double *const *part_wy = nullptr;   // per part partial arrays
+    double *const *part_yy = nullptr;   // per part partial arrays or nullptr
+};
+int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
+               const SpmvDots *dots, const int *flag_done, int *grid_out);
+
+int spmv_grid(const Part &p);
+
+}  // namespace sgm
+
+// ====================================================================== device helpers
+#if defined(__HIPCC__)
+namespace sgm {
+
+// Deterministic block-wide sum; every thread returns the same bits.
+template <int BLOCK>
+__device__ inline double block_sum(double v, double *red /* BLOCK/64 doubles of LDS */)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    double s = red[0];
+#pragma unroll
+    for (int w = 1; w < BLOCK / 64; ++w) s += red[w];
+    return s;
+}
+
+template <int BLOCK>
+__device__ inline double load_scalar(ScalarRef r, double *red)
+{
+    if (r.count == 1) return r.ptr[0];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < r.count; i += BLOCK) v += r.ptr[i];
+    return block_sum<BLOCK>(v, red);
+}
+
+}  // namespace sgm
+#endif

@@ -1,0 +1,497 @@
+// Preconditioners for gfx950: Jacobi (jacobi_solvers.f90:37-81) and ILDU(0)
+// (ldu_solvers.f90:95-176, :208-265, :275-440).
+//
+// Jacobi: idiag(i) = 1/A(i,i) is extracted on the device by a row scan (the reference
+// calls A%get_value(i,i) per row, cs_matrices.f90:709-724); apply is one elementwise pass.
+//
+// ILDU(0): the factorisation runs once on the HOST (the reference's algorithm is a
+// sequential IKJ sweep built on get/set/add_value row scans; it is setup, not the hot
+// path) and keeps the reference's arithmetic order, so L-I, D, U-I are bit-identical.
+// The APPLY is the hot part: x=b ; (I+L)^-1 ; x/D ; (I+U)^-1, each triangular solve a
+// row recurrence (ldu_solvers.f90:227-236).  Rows are grouped into dependency LEVELS at
+// setup; rows of one level are independent, each lane does its row's
+// z = z - val(k)*x(node(k)) left to right, so the result is bit-identical to the
+// sequential sweep.  Wide levels get one launch each; runs of narrow levels are executed
+// by ONE workgroup that walks the levels with a barrier in between (no launch per level).
+#include "sgm_internal.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace sgm {
+struct Staged {
+    double *dev = nullptr;
+    bool owned = false;
+    ~Staged() { if (owned) dfree(dev); }
+};
+int stage_in(Staged &s, const double *v, int64_t n, int where, bool copy);
+int stage_out(const Staged &s, double *v, int64_t n, int where);
+}  // namespace sgm
+using namespace sgm;
+
+namespace {
+
+constexpr int kTrsvBlock = 1024;
+constexpr int kNarrow = 2048;        // levels with <= this many rows are walked by one workgroup
+
+struct TriFactor {                   // strictly triangular CSR factor on the device (0-based)
+    int32_t *rowptr = nullptr, *col = nullptr;
+    double *val = nullptr;
+    int32_t *order = nullptr;        // rows sorted by level
+    std::vector<int32_t> level_ptr;  // host: offsets into order per level
+    int32_t *level_ptr_dev = nullptr;
+    struct Launch { int32_t l0, l1; bool narrow; };
+    std::vector<Launch> schedule;
+};
+
+struct PartPC {
+    double *idiag = nullptr;
+};
+
+}  // namespace
+
+struct sgm_pc_s {
+    int kind = 0;
+    int32_t n = 0;
+    std::vector<PartPC> parts;       // jacobi
+    // ildu (single part)
+    TriFactor L, U;
+    double *D = nullptr;
+    std::vector<int32_t> hLptr, hLnode, hUptr, hUnode;      // 1-based, as the reference holds them
+    std::vector<double> hLval, hUval, hD, hidiag;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------ kernels
+__global__ void k_jacobi_setup_csr(int32_t n, const int32_t *__restrict__ rowptr,
+                                   const int32_t *__restrict__ col, const double *__restrict__ val,
+                                   double *__restrict__ idiag)
+{
+    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double z = 0.0;                                   // get_value: 0 when the entry is absent
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
+        if (col[k] == i) z = val[k];
+    idiag[i] = 1.0 / z;
+}
+__global__ void k_jacobi_setup_ell(int32_t n, int32_t max_d, const int32_t *__restrict__ ecol,
+                                   const double *__restrict__ eval, double *__restrict__ idiag)
+{
+    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // ellpack get_value scans the first degrees(i) slots (ellpack_matrices.f90:232-235);
+    // padding repeats the last real neighbour with val 0, real neighbours are unique, so
+    // the FIRST hit is the real slot.
+    double z = 0.0;
+    for (int32_t k = 0; k < max_d; ++k)
+        if (ecol[(int64_t)k * n + i] == i) { z = eval[(int64_t)k * n + i]; break; }
+    idiag[i] = 1.0 / z;
+}
+__global__ void k_scale_by(int64_t n, const double *__restrict__ d, const double *__restrict__ r,
+                           double *__restrict__ z, const int *flag)
+{
+    if (flag && *flag) return;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) z[i] = d[i] * r[i];       // x = idiag * b
+}
+__global__ void k_div_by(int64_t n, const double *__restrict__ d, double *__restrict__ x, const int *flag)
+{
+    if (flag && *flag) return;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) x[i] = x[i] / d[i];       // x = x / D
+}
+__global__ void k_copy(int64_t n, const double *__restrict__ s, double *__restrict__ d, const int *flag)
+{
+    if (flag && *flag) return;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) d[i] = s[i];
+}
+
+__device__ inline void trsv_row(int32_t row, const int32_t *rowptr, const int32_t *col, const double *val,
+                                double *x)
+{
+    double z = x[row];
+    for (int32_t k = rowptr[row]; k < rowptr[row + 1]; ++k) z = z - val[k] * x[col[k]];
+    x[row] = z;
+}
+// one wide level
+__global__ void k_trsv_level(const int32_t *__restrict__ order, int32_t begin, int32_t end,
+                             const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                             const double *__restrict__ val, double *x, const int *flag)
+{
+    if (flag && *flag) return;
+    const int32_t t = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < end) trsv_row(order[t], rowptr, col, val, x);
+}
+// a run of narrow levels [l0, l1) walked by ONE workgroup; the x entries written in level
+// l are read in level l+1 by the same workgroup (barrier + workgroup-scope ordering).
+__global__ __launch_bounds__(kTrsvBlock) void k_trsv_narrow(const int32_t *__restrict__ order,
+                                                            const int32_t *__restrict__ level_ptr, int32_t l0,
+                                                            int32_t l1, const int32_t *__restrict__ rowptr,
+                                                            const int32_t *__restrict__ col,
+                                                            const double *__restrict__ val, double *x,
+                                                            const int *flag)
+{
+    if (flag && *flag) return;
+    for (int32_t l = l0; l < l1; ++l) {
+        const int32_t b = level_ptr[l], e = level_ptr[l + 1];
+        for (int32_t t = b + threadIdx.x; t < e; t += kTrsvBlock) trsv_row(order[t], rowptr, col, val, x);
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------- host factorisation
+// Row-scan accessors with the reference's semantics (cs_matrices.f90:709-724, :840-895).
+struct HostCsr {
+    std::vector<int32_t> *ptr, *node;
+    std::vector<double> *val;
+    double get(int32_t i, int32_t j) const
+    {
+        double z = 0.0;
+        for (int32_t k = (*ptr)[i - 1]; k < (*ptr)[i]; ++k)
+            if ((*node)[k - 1] == j) z = (*val)[k - 1];
+        return z;
+    }
+    void set(int32_t i, int32_t j, double z)
+    {
+        for (int32_t k = (*ptr)[i - 1]; k < (*ptr)[i]; ++k)
+            if ((*node)[k - 1] == j) (*val)[k - 1] = z;
+    }
+    void add(int32_t i, int32_t j, double z)
+    {
+        for (int32_t k = (*ptr)[i - 1]; k < (*ptr)[i]; ++k)
+            if ((*node)[k - 1] == j) (*val)[k - 1] = (*val)[k - 1] + z;
+    }
+};
+
+// incomplete_ldu_sparsity_pattern, level 0 (ldu_solvers.f90:397-440): entries of A in
+// stored order; i>j -> L, j>i -> U.
+void ildu_pattern(sgm_pc pc, int32_t n, const std::vector<int32_t> &ptr, const std::vector<int32_t> &node)
+{
+    pc->hLptr.assign(n + 1, 1);
+    pc->hUptr.assign(n + 1, 1);
+    pc->hLnode.clear();
+    pc->hUnode.clear();
+    for (int32_t i = 1; i <= n; ++i) {
+        for (int32_t k = ptr[i - 1]; k < ptr[i]; ++k) {
+            const int32_t j = node[k - 1];
+            if (i > j) pc->hLnode.push_back(j);
+            if (j > i) pc->hUnode.push_back(j);
+        }
+        pc->hLptr[i] = (int32_t)pc->hLnode.size() + 1;
+        pc->hUptr[i] = (int32_t)pc->hUnode.size() + 1;
+    }
+}
+
+// sparse_static_pattern_ldu_factorization (ldu_solvers.f90:275-387), same statement order.
+void ildu_factor(sgm_pc pc, int32_t n, const std::vector<int32_t> &ptr, const std::vector<int32_t> &node,
+                 const std::vector<double> &val)
+{
+    pc->hLval.assign(pc->hLnode.size(), 0.0);
+    pc->hUval.assign(pc->hUnode.size(), 0.0);
+    pc->hD.assign(n, 0.0);
+    HostCsr L{&pc->hLptr, &pc->hLnode, &pc->hLval}, U{&pc->hUptr, &pc->hUnode, &pc->hUval};
+    std::vector<double> &D = pc->hD;
+    for (int32_t i = 1; i <= n; ++i)
+        for (int32_t k = ptr[i - 1]; k < ptr[i]; ++k) {
+            const int32_t j = node[k - 1];
+            if (i > j) L.set(i, j, val[k - 1]);
+            else if (j > i) U.set(i, j, val[k - 1]);
+            else D[i - 1] = val[k - 1];
+        }
+    for (int32_t i = 1; i <= n; ++i) {
+        const int32_t lb = pc->hLptr[i - 1] - 1, dl = pc->hLptr[i] - pc->hLptr[i - 1];
+        const int32_t ub = pc->hUptr[i - 1] - 1, du = pc->hUptr[i] - pc->hUptr[i - 1];
+        for (int32_t a = 0; a < dl; ++a) {
+            const int32_t k = pc->hLnode[lb + a];
+            double Lik = L.get(i, k);
+            const double Uki = U.get(k, i);
+            L.set(i, k, Lik / D[k - 1]);
+            Lik = Lik / D[k - 1];
+            for (int32_t c = 0; c < dl; ++c) {
+                const int32_t j = pc->hLnode[lb + c];
+                if (j > k) {
+                    const double Ukj = U.get(k, j);
+                    L.add(i, j, -Lik * D[k - 1] * Ukj);
+                }
+            }
+            D[i - 1] = D[i - 1] - Lik * D[k - 1] * Uki;
+            for (int32_t c = 0; c < du; ++c) {
+                const int32_t j = pc->hUnode[ub + c];
+                const double Ukj = U.get(k, j);
+                U.add(i, j, -Lik * D[k - 1] * Ukj);
+            }
+        }
+        for (int32_t c = 0; c < du; ++c) {
+            const int32_t k = pc->hUnode[ub + c];
+            const double Uik = U.get(i, k);
+            U.set(i, k, Uik / D[i - 1]);
+        }
+    }
+}
+
+void free_tri(TriFactor &T)
+{
+    dfree(T.rowptr); dfree(T.col); dfree(T.val); dfree(T.order); dfree(T.level_ptr_dev);
+    T = TriFactor();
+}
+
+// upload a strictly triangular factor and build its level schedule.  lower: rows depend on
+// smaller rows (forward sweep 1..n); upper: on larger rows (backward sweep n..1).
+int upload_tri(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const std::vector<int32_t> &node1,
+               const std::vector<double> &val, bool lower, bool pattern_changed)
+{
+    const size_t nnz = node1.size();
+    if (pattern_changed) {
+        free_tri(T);
+        std::vector<int32_t> rp(n + 1), cl(std::max<size_t>(nnz, 1));
+        for (int32_t i = 0; i <= n; ++i) rp[i] = ptr1[i] - 1;
+        for (size_t k = 0; k < nnz; ++k) cl[k] = node1[k] - 1;
+        std::vector<int32_t> level(n, 0);
+        int32_t nlev = 0;
+        auto visit = [&](int32_t i) {
+            int32_t lv = 0;
+            for (int32_t k = rp[i]; k < rp[i + 1]; ++k) lv = std::max(lv, level[cl[k]] + 1);
+            level[i] = lv;
+            nlev = std::max(nlev, lv + 1);
+        };
+        if (lower) for (int32_t i = 0; i < n; ++i) visit(i);
+        else for (int32_t i = n - 1; i >= 0; --i) visit(i);
+        T.level_ptr.assign(nlev + 1, 0);
+        for (int32_t i = 0; i < n; ++i) T.level_ptr[level[i] + 1]++;
+        for (int32_t l = 0; l < nlev; ++l) T.level_ptr[l + 1] += T.level_ptr[l];
+        std::vector<int32_t> order(std::max(n, 1)), cursor(T.level_ptr.begin(), T.level_ptr.end() - 1);
+        for (int32_t i = 0; i < n; ++i) order[cursor[level[i]]++] = i;
+        // schedule: wide levels alone, runs of narrow levels together
+        for (int32_t l = 0; l < nlev;) {
+            const int32_t sz = T.level_ptr[l + 1] - T.level_ptr[l];
+            if (sz > kNarrow) { T.schedule.push_back({l, l + 1, false}); ++l; continue; }
+            int32_t e = l;
+            while (e < nlev && T.level_ptr[e + 1] - T.level_ptr[e] <= kNarrow) ++e;
+            T.schedule.push_back({l, e, true});
+            l = e;
+        }
+        SGM_TRY(dalloc(&T.rowptr, (size_t)n + 1));
+        SGM_TRY(dalloc(&T.col, nnz));
+        SGM_TRY(dalloc(&T.val, nnz));
+        SGM_TRY(dalloc(&T.order, (size_t)n));
+        SGM_TRY(dalloc(&T.level_ptr_dev, T.level_ptr.size()));
+        SGM_HIP(hipMemcpy(T.rowptr, rp.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
+        if (nnz) SGM_HIP(hipMemcpy(T.col, cl.data(), nnz * 4, hipMemcpyHostToDevice));
+        if (n) SGM_HIP(hipMemcpy(T.order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        SGM_HIP(hipMemcpy(T.level_ptr_dev, T.level_ptr.data(), T.level_ptr.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (nnz) SGM_HIP(hipMemcpy(T.val, val.data(), nnz * 8, hipMemcpyHostToDevice));
+    return SGM_OK;
+}
+
+void trsv(const TriFactor &T, double *x, const int *flag)
+{
+    hipStream_t st = g_rt.stream;
+    for (const auto &L : T.schedule) {
+        if (L.narrow) {
+            hipLaunchKernelGGL(k_trsv_narrow, dim3(1), dim3(kTrsvBlock), 0, st, T.order, T.level_ptr_dev, L.l0, L.l1,
+                               T.rowptr, T.col, T.val, x, flag);
+        } else {
+            const int32_t b = T.level_ptr[L.l0], e = T.level_ptr[L.l1];
+            hipLaunchKernelGGL(k_trsv_level, dim3((e - b + kBlock - 1) / kBlock), dim3(kBlock), 0, st, T.order, b, e,
+                               T.rowptr, T.col, T.val, x, flag);
+        }
+    }
+}
+
+int download_csr(sgm_mat A, std::vector<int32_t> &ptr1, std::vector<int32_t> &node1, std::vector<double> &val)
+{
+    const Part &p = A->parts[0];
+    ptr1.resize((size_t)p.n + 1);
+    node1.resize((size_t)p.nnz);
+    val.resize((size_t)p.nnz);
+    SGM_HIP(hipStreamSynchronize(g_rt.stream));
+    SGM_HIP(hipMemcpy(ptr1.data(), p.rowptr, ptr1.size() * 4, hipMemcpyDeviceToHost));
+    if (p.nnz) {
+        SGM_HIP(hipMemcpy(node1.data(), p.col, node1.size() * 4, hipMemcpyDeviceToHost));
+        SGM_HIP(hipMemcpy(val.data(), p.val, val.size() * 8, hipMemcpyDeviceToHost));
+    }
+    for (auto &v : ptr1) v += 1;
+    for (auto &v : node1) v += 1;
+    return SGM_OK;
+}
+
+}  // namespace
+
+namespace sgm {
+
+int pc_kind(sgm_pc pc) { return pc ? pc->kind : 0; }
+const double *pc_idiag(sgm_pc pc, size_t part) { return pc->parts[part].idiag; }
+
+int pc_apply_parts(sgm_pc pc, sgm_mat A, const double *const *r, double *const *z, const int *const *flags)
+{
+    hipStream_t st = g_rt.stream;
+    if (pc->kind == SGM_PC_JACOBI) {
+        for (size_t ip = 0; ip < A->parts.size(); ++ip) {
+            const int64_t n = A->parts[ip].n;
+            hipLaunchKernelGGL(k_scale_by, dim3(vec_grid(n)), dim3(kBlock), 0, st, n, pc->parts[ip].idiag, r[ip], z[ip],
+                               flags ? flags[ip] : nullptr);
+        }
+    } else {
+        const int64_t n = pc->n;
+        const int *flag = flags ? flags[0] : nullptr;
+        hipLaunchKernelGGL(k_copy, dim3(vec_grid(n)), dim3(kBlock), 0, st, n, r[0], z[0], flag);   // x = b
+        trsv(pc->L, z[0], flag);
+        hipLaunchKernelGGL(k_div_by, dim3(vec_grid(n)), dim3(kBlock), 0, st, n, pc->D, z[0], flag);
+        trsv(pc->U, z[0], flag);
+    }
+    SGM_HIP(hipGetLastError());
+    return SGM_OK;
+}
+
+}  // namespace sgm
+
+extern "C" {
+
+int sgm_pc_setup(sgm_pc pc, sgm_mat A)
+{
+    SGM_TRY(require_init());
+    if (!pc || !A) return fail(SGM_ERR_BAD_ARG, "sgm_pc_setup: null argument");
+    if (A->nrow != A->ncol)      // jacobi_solvers.f90:46-50, ldu_solvers.f90:104-108
+        return fail(SGM_ERR_DIMS, "Cannot make a %s solver for a non-square matrix",
+                    pc->kind == SGM_PC_JACOBI ? "Jacobi" : "LDU");
+    hipStream_t st = g_rt.stream;
+    if (pc->kind == SGM_PC_JACOBI) {
+        if (pc->parts.size() != A->parts.size()) {
+            for (auto &pp : pc->parts) dfree(pp.idiag);
+            pc->parts.assign(A->parts.size(), PartPC());
+        }
+        pc->n = A->nrow;
+        for (size_t ip = 0; ip < A->parts.size(); ++ip) {
+            const Part &p = A->parts[ip];
+            if (!pc->parts[ip].idiag) SGM_TRY(dalloc(&pc->parts[ip].idiag, (size_t)p.n + 2));
+            const int grid = (p.n + kBlock - 1) / kBlock;
+            if (!grid) continue;
+            if (A->fmt == SGM_FMT_CSR)
+                hipLaunchKernelGGL(k_jacobi_setup_csr, dim3(grid), dim3(kBlock), 0, st, p.n, p.rowptr, p.col, p.val,
+                                   pc->parts[ip].idiag);
+            else
+                hipLaunchKernelGGL(k_jacobi_setup_ell, dim3(grid), dim3(kBlock), 0, st, p.n, p.max_d, p.ecol, p.eval,
+                                   pc->parts[ip].idiag);
+        }
+        SGM_HIP(hipGetLastError());
+        return finish();
+    }
+    // ILDU(0)
+    if (A->fmt != SGM_FMT_CSR || A->distributed())
+        return fail(SGM_ERR_UNSUPPORTED, "ILDU(0) needs a single-GPU CSR matrix");
+    std::vector<int32_t> ptr1, node1;
+    std::vector<double> val;
+    SGM_TRY(download_csr(A, ptr1, node1, val));
+    const int32_t n = A->nrow;
+    const bool fresh = pc->n != n || pc->hLptr.empty();      // ldu_solvers.f90:117-125: pattern once
+    if (fresh) ildu_pattern(pc, n, ptr1, node1);
+    pc->n = n;
+    ildu_factor(pc, n, ptr1, node1, val);
+    SGM_TRY(upload_tri(pc->L, n, pc->hLptr, pc->hLnode, pc->hLval, true, fresh));
+    SGM_TRY(upload_tri(pc->U, n, pc->hUptr, pc->hUnode, pc->hUval, false, fresh));
+    if (fresh) { dfree(pc->D); SGM_TRY(dalloc(&pc->D, (size_t)n)); }
+    if (n) SGM_HIP(hipMemcpy(pc->D, pc->hD.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    return SGM_OK;
+}
+
+int sgm_jacobi_create(sgm_pc *out, sgm_mat A)
+{
+    if (!out) return fail(SGM_ERR_BAD_ARG, "sgm_jacobi_create: null out pointer");
+    sgm_pc pc = new sgm_pc_s;
+    pc->kind = SGM_PC_JACOBI;
+    int rc = sgm_pc_setup(pc, A);
+    if (rc != SGM_OK) { sgm_pc_destroy(pc); return rc; }
+    *out = pc;
+    return SGM_OK;
+}
+
+int sgm_ildu0_create(sgm_pc *out, sgm_mat A)
+{
+    if (!out) return fail(SGM_ERR_BAD_ARG, "sgm_ildu0_create: null out pointer");
+    sgm_pc pc = new sgm_pc_s;
+    pc->kind = SGM_PC_ILDU0;
+    int rc = sgm_pc_setup(pc, A);
+    if (rc != SGM_OK) { sgm_pc_destroy(pc); return rc; }
+    *out = pc;
+    return SGM_OK;
+}
+
+int sgm_pc_apply(sgm_pc pc, const double *r, double *z, int where)
+{
+    SGM_TRY(require_init());
+    if (!pc || !r || !z) return fail(SGM_ERR_BAD_ARG, "sgm_pc_apply: null argument");
+    if (pc->kind == SGM_PC_JACOBI && pc->parts.size() != 1)
+        return fail(SGM_ERR_UNSUPPORTED, "sgm_pc_apply: stand-alone apply needs a single-part matrix");
+    Staged sr, sz;
+    SGM_TRY(stage_in(sr, r, pc->n, where, true));
+    SGM_TRY(stage_in(sz, z, pc->n, where, false));
+    // a throw-away matrix view with the right part count for pc_apply_parts
+    sgm_mat_s view;
+    view.parts.resize(1);
+    view.parts[0].n = pc->n;
+    const double *rs[1] = {sr.dev};
+    double *zs[1] = {sz.dev};
+    SGM_TRY(pc_apply_parts(pc, &view, rs, zs, nullptr));
+    SGM_TRY(stage_out(sz, z, pc->n, where));
+    return finish();
+}
+
+int sgm_pc_get(sgm_pc pc, const char *name, void *out, size_t bytes, size_t *needed)
+{
+    if (!pc || !name) return fail(SGM_ERR_BAD_ARG, "sgm_pc_get: null argument");
+    const void *src = nullptr;
+    size_t sz = 0;
+    std::string nm(name);
+    static const char kEmpty = 0;
+    if (pc->kind == SGM_PC_JACOBI && nm == "idiag") {
+        if (pc->parts.size() != 1) return fail(SGM_ERR_UNSUPPORTED, "sgm_pc_get(idiag): single-part only");
+        pc->hidiag.resize((size_t)pc->n);
+        SGM_HIP(hipStreamSynchronize(g_rt.stream));
+        if (pc->n) SGM_HIP(hipMemcpy(pc->hidiag.data(), pc->parts[0].idiag, (size_t)pc->n * 8, hipMemcpyDeviceToHost));
+        src = pc->hidiag.data(); sz = pc->hidiag.size() * 8;
+    } else if (pc->kind == SGM_PC_ILDU0) {
+        if (nm == "Lptr") { src = pc->hLptr.data(); sz = pc->hLptr.size() * 4; }
+        else if (nm == "Lnode") { src = pc->hLnode.data(); sz = pc->hLnode.size() * 4; }
+        else if (nm == "Lval") { src = pc->hLval.data(); sz = pc->hLval.size() * 8; }
+        else if (nm == "Uptr") { src = pc->hUptr.data(); sz = pc->hUptr.size() * 4; }
+        else if (nm == "Unode") { src = pc->hUnode.data(); sz = pc->hUnode.size() * 4; }
+        else if (nm == "Uval") { src = pc->hUval.data(); sz = pc->hUval.size() * 8; }
+        else if (nm == "D") { src = pc->hD.data(); sz = pc->hD.size() * 8; }
+        else if (nm == "levels") {
+            static int32_t lv[2];
+            lv[0] = (int32_t)pc->L.level_ptr.size() - 1;
+            lv[1] = (int32_t)pc->U.level_ptr.size() - 1;
+            src = lv; sz = sizeof lv;
+        }
+    }
+    const bool known = nm == "idiag" || nm == "Lptr" || nm == "Lnode" || nm == "Lval" || nm == "Uptr" ||
+                       nm == "Unode" || nm == "Uval" || nm == "D" || nm == "levels";
+    if (!known || (!src && sz)) return fail(SGM_ERR_BAD_ARG, "sgm_pc_get: unknown array '%s'", name);
+    if (!src) src = &kEmpty;
+    if (needed) *needed = sz;
+    if (out && sz) {
+        if (bytes < sz) return fail(SGM_ERR_BAD_ARG, "sgm_pc_get: buffer too small (%zu < %zu)", bytes, sz);
+        memcpy(out, src, sz);
+    }
+    return SGM_OK;
+}
+
+int sgm_pc_destroy(sgm_pc pc)
+{
+    if (!pc) return SGM_OK;
+    for (auto &pp : pc->parts) dfree(pp.idiag);
+    free_tri(pc->L);
+    free_tri(pc->U);
+    dfree(pc->D);
+    delete pc;
+    return SGM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,124 @@
+// Runtime plumbing of libsigma_hip.so: device selection, stream, errors, HBM buffers.
+#include "sgm_internal.hpp"
+
+namespace sgm {
+
+std::string g_err;
+Runtime g_rt;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+int require_init()
+{
+    if (g_rt.ready) return SGM_OK;
+    return sgm_init(-1);
+}
+
+int finish()
+{
+    if (g_rt.async) return SGM_OK;
+    SGM_HIP(hipStreamSynchronize(g_rt.stream));
+    return SGM_OK;
+}
+
+}  // namespace sgm
+
+using namespace sgm;
+
+extern "C" {
+
+int sgm_init(int device)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(SGM_ERR_NO_DEVICE,
+                    "sgm_init: no HIP device visible (%s); this library has no CPU path",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0) {
+        if (g_rt.ready) return SGM_OK;
+        device = 0;
+    }
+    if (device >= count) return fail(SGM_ERR_BAD_ARG, "sgm_init: device %d of %d", device, count);
+    if (g_rt.ready && g_rt.device == device) return SGM_OK;
+    SGM_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SGM_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        fprintf(stderr, "[sigma_hip] warning: built for gfx950, running on %s\n", prop.gcnArchName);
+    g_rt.num_cu = prop.multiProcessorCount;
+    if (!g_rt.own_stream) SGM_HIP(hipStreamCreateWithFlags(&g_rt.own_stream, hipStreamNonBlocking));
+    g_rt.stream = g_rt.own_stream;
+    g_rt.device = device;
+    g_rt.ready = true;
+    return SGM_OK;
+}
+
+int sgm_finalize(void)
+{
+    if (!g_rt.ready) return SGM_OK;
+    (void)hipStreamSynchronize(g_rt.stream);
+    if (g_rt.own_stream) (void)hipStreamDestroy(g_rt.own_stream);
+    g_rt = Runtime();
+    return SGM_OK;
+}
+
+const char *sgm_last_error(void) { return g_err.c_str(); }
+
+int sgm_set_stream(void *s)
+{
+    SGM_TRY(require_init());
+    g_rt.stream = s ? (hipStream_t)s : g_rt.own_stream;
+    return SGM_OK;
+}
+
+int sgm_set_async(int on)
+{
+    g_rt.async = on != 0;
+    return SGM_OK;
+}
+
+int sgm_synchronize(void)
+{
+    SGM_TRY(require_init());
+    SGM_HIP(hipStreamSynchronize(g_rt.stream));
+    return SGM_OK;
+}
+
+int sgm_malloc(void **p, size_t bytes)
+{
+    SGM_TRY(require_init());
+    if (!p) return fail(SGM_ERR_BAD_ARG, "sgm_malloc: null out pointer");
+    char *q = nullptr;
+    SGM_TRY(dalloc(&q, bytes));
+    *p = q;
+    return SGM_OK;
+}
+
+int sgm_free(void *p)
+{
+    if (p) SGM_HIP(hipFree(p));
+    return SGM_OK;
+}
+
+int sgm_memcpy(void *dst, const void *src, size_t bytes, int kind)
+{
+    SGM_TRY(require_init());
+    hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice
+                      : kind == 1 ? hipMemcpyDeviceToHost
+                                  : hipMemcpyDeviceToDevice;
+    SGM_HIP(hipMemcpyAsync(dst, src, bytes, k, g_rt.stream));
+    if (kind != 2) SGM_HIP(hipStreamSynchronize(g_rt.stream));
+    return finish();
+}
+
+}  // extern "C"

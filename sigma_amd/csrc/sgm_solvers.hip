@@ -1,0 +1,1106 @@
+// Device-resident Krylov loops for gfx950: CG / PCG (cg_solvers.f90:116-194), BiCGStab /
+// preconditioned BiCGStab (bicgstab_solvers.f90:124-237) and GMRES(m) (no reference
+// counterpart), plus the dot / axpy statements they are made of.
+//
+// Design: the whole `do while (dsqrt(res2) > tolerance)` loop runs on the GPU.
+//  * Every dot product is produced as <= 2048 per-workgroup partial sums (fixed grid,
+//    xor-butterfly wave reduction + fixed-order LDS sum).  Every CONSUMER workgroup
+//    re-reduces the partials in the same order (ScalarRef), so alpha/beta/omega are
+//    computed redundantly but bit-identically by all workgroups: no host round trip, no
+//    atomics, no grid barrier between a dot and the update that needs it.
+//  * The loop condition is a device flag written by the kernel that learns the new
+//    res2; all later kernels of the batch exit at once when it is set, so the host only
+//    polls once per batch and `iterations` still equals the reference's count exactly.
+//  * Fusion (bytes per CG iteration: B_csr + 72 n): p.q is folded into the
+//    SpMV epilogue; x/r update + r.r (or the Jacobi apply + r.z) is one pass; the p
+//    update is one pass.
+//  * Multi-GPU / multi-partition: the same kernels run per row block; a dot is then
+//    reduced to one slot per part and summed across parts (ncclAllReduce or k_sum_parts).
+// Compiled with -ffp-contract=off: a*b+c is never fused, like the reference build.
+#include "sgm_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace sgm {
+
+struct Staged {
+    double *dev = nullptr;
+    bool owned = false;
+    ~Staged() { if (owned) dfree(dev); }
+};
+int stage_in(Staged &s, const double *v, int64_t n, int where, bool copy);
+int stage_out(const Staged &s, double *v, int64_t n, int where);
+int pc_apply_parts(sgm_pc pc, sgm_mat A, const double *const *r, double *const *z, const int *const *flags);
+int pc_kind(sgm_pc pc);
+const double *pc_idiag(sgm_pc pc, size_t part);
+
+// ------------------------------------------------------------------ generic fused kernel
+// F provides: bool prepare(double* red) (block-uniform; false = nothing to do),
+//             void pair(int64_t i2) (elements 2*i2, 2*i2+1), void single(int64_t i),
+//             void finish(double* red).
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_elem(int64_t n, F f, const int *flag)
+{
+    __shared__ double red[kBlock / 64];
+    if (flag && *flag) return;
+    if (!f.prepare(red)) return;
+    const int64_t gtid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t n2 = n >> 1;
+    for (int64_t i = gtid; i < n2; i += stride) f.pair(i);
+    if ((n & 1) && gtid == 0) f.single(n - 1);
+    f.finish(red);
+}
+
+#define D2(p) reinterpret_cast<double2 *>(p)
+#define CD2(p) reinterpret_cast<const double2 *>(p)
+
+__device__ inline void put_partial(double v, double *part, double *red)
+{
+    const double t = block_sum<kBlock>(v, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// dst = src
+struct FCopy {
+    double *dst; const double *src;
+    __device__ bool prepare(double *) { return true; }
+    __device__ void pair(int64_t i) { D2(dst)[i] = CD2(src)[i]; }
+    __device__ void single(int64_t i) { dst[i] = src[i]; }
+    __device__ void finish(double *) {}
+};
+// dst = value
+struct FFill {
+    double *dst; double v;
+    __device__ bool prepare(double *) { return true; }
+    __device__ void pair(int64_t i) { D2(dst)[i] = make_double2(v, v); }
+    __device__ void single(int64_t i) { dst[i] = v; }
+    __device__ void finish(double *) {}
+};
+// up to two dots: a.b -> part0, c.d -> part1 (c == nullptr: one dot)
+struct FDot2 {
+    const double *a, *b, *c, *d; double *part0, *part1;
+    double s0 = 0.0, s1 = 0.0;
+    __device__ bool prepare(double *) { return true; }
+    __device__ void pair(int64_t i)
+    {
+        const double2 x = CD2(a)[i], y = CD2(b)[i];
+        s0 += x.x * y.x; s0 += x.y * y.y;
+        if (c) { const double2 u = CD2(c)[i], w = CD2(d)[i]; s1 += u.x * w.x; s1 += u.y * w.y; }
+    }
+    __device__ void single(int64_t i) { s0 += a[i] * b[i]; if (c) s1 += c[i] * d[i]; }
+    __device__ void finish(double *red) { put_partial(s0, part0, red); if (c) put_partial(s1, part1, red); }
+};
+// y = y + alpha * x  (host scalar)
+struct FAxpy {
+    double *y; const double *x; double alpha;
+    __device__ bool prepare(double *) { return true; }
+    __device__ void pair(int64_t i)
+    {
+        double2 a = D2(y)[i]; const double2 b = CD2(x)[i];
+        a.x = a.x + alpha * b.x; a.y = a.y + alpha * b.y; D2(y)[i] = a;
+    }
+    __device__ void single(int64_t i) { y[i] = y[i] + alpha * x[i]; }
+    __device__ void finish(double *) {}
+};
+
+// ---- CG -----------------------------------------------------------------------------
+// r = b - q ; [p = r ; partial r.r]          cg_solvers.f90:129-131
+struct FCgInit {
+    const double *b, *q; double *r, *p; double *part; bool with_p;
+    double s = 0.0;
+    __device__ bool prepare(double *) { return true; }
+    __device__ void pair(int64_t i)
+    {
+        const double2 bb = CD2(b)[i], qq = CD2(q)[i];
+        double2 rr; rr.x = bb.x - qq.x; rr.y = bb.y - qq.y;
+        D2(r)[i] = rr;
+        if (with_p) { D2(p)[i] = rr; s += rr.x * rr.x; s += rr.y * rr.y; }
+    }
+    __device__ void single(int64_t i)
+    {
+        const double rr = b[i] - q[i]; r[i] = rr;
+        if (with_p) { p[i] = rr; s += rr * rr; }
+    }
+    __device__ void finish(double *red) { if (with_p) put_partial(s, part, red); }
+};
+// p = z ; partial r.z                          cg_solvers.f90:172-173
+struct FCopyDot {
+    double *p; const double *z, *r; double *part; double s = 0.0;
+    __device__ bool prepare(double *) { return true; }
+    __device__ void pair(int64_t i)
+    {
+        const double2 zz = CD2(z)[i], rr = CD2(r)[i];
+        D2(p)[i] = zz; s += rr.x * zz.x; s += rr.y * zz.y;
+    }
+    __device__ void single(int64_t i) { p[i] = z[i]; s += r[i] * z[i]; }
+    __device__ void finish(double *red) { put_partial(s, part, red); }
+};
+// alpha = res2/dpr ; x = x+alpha*p ; r = r-alpha*q ; then
+//   MODE 0: partial r.r   MODE 1: z = idiag*r, partial r.z   MODE 2: nothing (generic pc follows)
+// cg_solvers.f90:136-140 / :180-185 with jacobi_solve jacobi_solvers.f90:77 folded in
+template <int MODE>
+struct FCgXR {
+    ScalarRef res2, dpr;
+    const double *p, *q; double *x, *r; const double *idiag; double *z; double *part;
+    double alpha = 0.0, s = 0.0;
+    __device__ bool prepare(double *red)
+    {
+        const double a = load_scalar<kBlock>(res2, red);
+        const double b = load_scalar<kBlock>(dpr, red);
+        alpha = a / b;
+        return true;
+    }
+    __device__ void one(double pv, double qv, double &xv, double &rv, double idv, double &zv)
+    {
+        xv = xv + alpha * pv;
+        rv = rv - alpha * qv;
+        if (MODE == 0) s += rv * rv;
+        if (MODE == 1) { zv = idv * rv; s += rv * zv; }
+    }
+    __device__ void pair(int64_t i)
+    {
+        const double2 pp = CD2(p)[i], qq = CD2(q)[i];
+        double2 xx = D2(x)[i], rr = D2(r)[i], zz = make_double2(0, 0), dd = make_double2(0, 0);
+        if (MODE == 1) dd = CD2(idiag)[i];
+        one(pp.x, qq.x, xx.x, rr.x, dd.x, zz.x);
+        one(pp.y, qq.y, xx.y, rr.y, dd.y, zz.y);
+        D2(x)[i] = xx; D2(r)[i] = rr;
+        if (MODE == 1) D2(z)[i] = zz;
+    }
+    __device__ void single(int64_t i)
+    {
+        double xv = x[i], rv = r[i], zv = 0.0;
+        one(p[i], q[i], xv, rv, MODE == 1 ? idiag[i] : 0.0, zv);
+        x[i] = xv; r[i] = rv;
+        if (MODE == 1) z[i] = zv;
+    }
+    __device__ void finish(double *red) { if (MODE != 2) put_partial(s, part, red); }
+};
+// beta = dnew/res2 ; p = z + beta*p ; bookkeeping: iterations++, history, loop condition
+// cg_solvers.f90:141-145
+struct FCgP {
+    ScalarRef res2, dnew; const double *z; double *p;
+    double tol; int *flag; int64_t *iters; double *history; int64_t hist_cap; double *res_out;
+    double beta = 0.0;
+    __device__ bool prepare(double *red)
+    {
+        const double a = load_scalar<kBlock>(res2, red);
+        const double d = load_scalar<kBlock>(dnew, red);
+        beta = d / a;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const int64_t it = *iters;
+            if (history && it < hist_cap) history[it] = d;
+            *iters = it + 1;
+            *res_out = d;
+            if (!(sqrt(d) > tol)) *flag = 1;
+        }
+        return true;
+    }
+    __device__ void pair(int64_t i)
+    {
+        const double2 zz = CD2(z)[i]; double2 pp = D2(p)[i];
+        pp.x = zz.x + beta * pp.x; pp.y = zz.y + beta * pp.y; D2(p)[i] = pp;
+    }
+    __device__ void single(int64_t i) { p[i] = z[i] + beta * p[i]; }
+    __device__ void finish(double *) {}
+};
+
+// one block: res = sum(ref) ; flag = !(sqrt(res) > tol)   (the loop test before iteration 1)
+__global__ __launch_bounds__(kBlock) void k_check(ScalarRef ref, double tol, int *flag, double *res_out)
+{
+    __shared__ double red[kBlock / 64];
+    if (*flag) return;
+    const double d = load_scalar<kBlock>(ref, red);
+    if (threadIdx.x == 0) {
+        *res_out = d;
+        if (!(sqrt(d) > tol)) *flag = 1;
+    }
+}
+// one block: slot = sum(partials)
+__global__ __launch_bounds__(kBlock) void k_reduce(const double *part, int count, double *slot)
+{
+    __shared__ double red[kBlock / 64];
+    ScalarRef r{part, count};
+    const double d = load_scalar<kBlock>(r, red);
+    if (threadIdx.x == 0) *slot = d;
+}
+
+// ---- BiCGStab -------------------------------------------------------------------------
+struct BiScalars {          // dot results of the CURRENT (cur) and PREVIOUS (old) iteration
+    ScalarRef rr, rho, rho_old, r0v_old, st_old, tt_old, r0v, st, tt;
+    int first;              // iteration 1: rho_old = alpha = omega = 1 (bicgstab_solvers.f90:144-147)
+    int nan_guard;          // plain variant only (:165)
+};
+__device__ inline double bi_omega(double st, double tt, int guard)
+{
+    double om = st / tt;
+    if (guard && isnan(om)) om = 0.0;
+    return om;
+}
+// loop test + rho/beta + p = r + beta*(p - omega*v)     bicgstab_solvers.f90:154-157
+struct FBiP {
+    BiScalars S; const double *r, *v; double *p;
+    double tol; int *flag; int64_t *iters; double *history; int64_t hist_cap; double *res_out;
+    double beta = 0.0, omega = 1.0;
+    __device__ bool prepare(double *red)
+    {
+        const double res2 = load_scalar<kBlock>(S.rr, red);
+        const bool stop = !(sqrt(res2) > tol);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const int64_t it = *iters;
+            *res_out = res2;
+            if (!S.first && history && it - 1 < hist_cap && it >= 1) history[it - 1] = res2;
+            if (stop) *flag = 1; else *iters = it + 1;
+        }
+        if (stop) return false;
+        const double rho = load_scalar<kBlock>(S.rho, red);
+        double rho_old = 1.0, alpha = 1.0;
+        omega = 1.0;
+        if (!S.first) {
+            rho_old = load_scalar<kBlock>(S.rho_old, red);
+            alpha = rho_old / load_scalar<kBlock>(S.r0v_old, red);
+            const double st = load_scalar<kBlock>(S.st_old, red);
+            const double tt = load_scalar<kBlock>(S.tt_old, red);
+            omega = bi_omega(st, tt, S.nan_guard);
+        }
+        beta = rho / rho_old * alpha / omega;
+        return true;
+    }
+    __device__ void pair(int64_t i)
+    {
+        const double2 rr = CD2(r)[i], vv = CD2(v)[i]; double2 pp = D2(p)[i];
+        pp.x = rr.x + beta * (pp.x - omega * vv.x);
+        pp.y = rr.y + beta * (pp.y - omega * vv.y);
+        D2(p)[i] = pp;
+    }
+    __device__ void single(int64_t i) { p[i] = r[i] + beta * (p[i] - omega * v[i]); }
+    __device__ void finish(double *) {}
+};
+// alpha = rho / (r0.v) ; s = r - alpha*v                 bicgstab_solvers.f90:160-161
+struct FBiS {
+    ScalarRef rho, r0v; const double *r, *v; double *s; double alpha = 0.0;
+    __device__ bool prepare(double *red)
+    {
+        const double a = load_scalar<kBlock>(rho, red);
+        alpha = a / load_scalar<kBlock>(r0v, red);
+        return true;
+    }
+    __device__ void pair(int64_t i)
+    {
+        const double2 rr = CD2(r)[i], vv = CD2(v)[i]; double2 ss;
+        ss.x = rr.x - alpha * vv.x; ss.y = rr.y - alpha * vv.y; D2(s)[i] = ss;
+    }
+    __device__ void single(int64_t i) { s[i] = r[i] - alpha * v[i]; }
+    __device__ void finish(double *) {}
+};
+// omega ; x = x + alpha*p + omega*s ; r = s - omega*t ; partial r.r and r0.r
+// bicgstab_solvers.f90:164-169 (+ rho of the next iteration, :155)
+struct FBiXR {
+    ScalarRef rho, r0v, st, tt; int nan_guard;
+    const double *p, *s, *t, *r0; double *x, *r; double *part_rr, *part_rho;
+    double alpha = 0.0, omega = 0.0, srr = 0.0, srho = 0.0;
+    __device__ bool prepare(double *red)
+    {
+        const double a = load_scalar<kBlock>(rho, red);
+        alpha = a / load_scalar<kBlock>(r0v, red);
+        const double b = load_scalar<kBlock>(st, red);
+        omega = bi_omega(b, load_scalar<kBlock>(tt, red), nan_guard);
+        return true;
+    }
+    __device__ void one(double pv, double sv, double tv, double r0v_, double &xv, double &rv)
+    {
+        xv = xv + alpha * pv + omega * sv;
+        rv = sv - omega * tv;
+        srr += rv * rv;
+        srho += r0v_ * rv;
+    }
+    __device__ void pair(int64_t i)
+    {
+        const double2 pp = CD2(p)[i], ss = CD2(s)[i], tt_ = CD2(t)[i], r00 = CD2(r0)[i];
+        double2 xx = D2(x)[i], rr;
+        one(pp.x, ss.x, tt_.x, r00.x, xx.x, rr.x);
+        one(pp.y, ss.y, tt_.y, r00.y, xx.y, rr.y);
+        D2(x)[i] = xx; D2(r)[i] = rr;
+    }
+    __device__ void single(int64_t i)
+    {
+        double xv = x[i], rv;
+        one(p[i], s[i], t[i], r0[i], xv, rv);
+        x[i] = xv; r[i] = rv;
+    }
+    __device__ void finish(double *red) { put_partial(srr, part_rr, red); put_partial(srho, part_rho, red); }
+};
+// r0 = src ; r = r0 ; v = 0 ; p = 0 ; partial r.r (twice: res2 and rho)   :140-152
+struct FBiInit {
+    const double *b, *q; bool sub; double *r0, *r, *v, *p; double *part_rr, *part_rho; double s = 0.0;
+    __device__ bool prepare(double *) { return true; }
+    __device__ void one(int64_t i)
+    {
+        const double w = sub ? b[i] - q[i] : b[i];
+        r0[i] = w; r[i] = w; v[i] = 0.0; p[i] = 0.0; s += w * w;
+    }
+    __device__ void pair(int64_t i) { one(2 * i); one(2 * i + 1); }
+    __device__ void single(int64_t i) { one(i); }
+    __device__ void finish(double *red)
+    {
+        const double t = block_sum<kBlock>(s, red);
+        if (threadIdx.x == 0) { part_rr[blockIdx.x] = t; part_rho[blockIdx.x] = t; }
+    }
+};
+
+// ---- GMRES(m) --------------------------------------------------------------------------
+constexpr int kGmresMaxRestart = 64;
+struct GmresState {                 // lives in device memory, one per part (all parts hold the same values)
+    double H[(kGmresMaxRestart + 1) * kGmresMaxRestart];   // column-major, R after rotations
+    double cs[kGmresMaxRestart], sn[kGmresMaxRestart], g[kGmresMaxRestart + 1], y[kGmresMaxRestart];
+    int j;                          // Arnoldi steps done in this cycle
+};
+// w = w - h_prev*v_prev (if v_prev) ; partial w.v_cur (v_cur == nullptr: partial w.w)
+struct FMgs {
+    double *w; const double *v_prev, *v_cur; ScalarRef h_prev; double *part; double h = 0.0, s = 0.0;
+    __device__ bool prepare(double *red)
+    {
+        if (v_prev) h = load_scalar<kBlock>(h_prev, red);
+        return true;
+    }
+    __device__ void one(int64_t i)
+    {
+        double wv = w[i];
+        if (v_prev) { wv = wv - h * v_prev[i]; w[i] = wv; }
+        s += wv * (v_cur ? v_cur[i] : wv);
+    }
+    __device__ void pair(int64_t i) { one(2 * i); one(2 * i + 1); }
+    __device__ void single(int64_t i) { one(i); }
+    __device__ void finish(double *red) { put_partial(s, part, red); }
+};
+// dst = src / sqrt(sum(nrm2))      (v_{j+1} = w / h_{j+1,j} ; v_1 = r / beta)
+struct FScaleInv {
+    double *dst; const double *src; ScalarRef nrm2; double d = 1.0;
+    __device__ bool prepare(double *red) { d = sqrt(load_scalar<kBlock>(nrm2, red)); return true; }
+    __device__ void pair(int64_t i)
+    {
+        const double2 a = CD2(src)[i]; double2 o; o.x = a.x / d; o.y = a.y / d; D2(dst)[i] = o;
+    }
+    __device__ void single(int64_t i) { dst[i] = src[i] / d; }
+    __device__ void finish(double *) {}
+};
+// start of a cycle: beta = sqrt(sum) ; g = (beta,0,...) ; j = 0 ; loop test
+__global__ __launch_bounds__(kBlock) void k_gmres_start(ScalarRef nrm2, GmresState *G, double tol, int *flag,
+                                                        double *res_out)
+{
+    __shared__ double red[kBlock / 64];
+    const double d = load_scalar<kBlock>(nrm2, red);
+    if (threadIdx.x == 0) {
+        const double beta = sqrt(d);
+        G->j = 0;
+        G->g[0] = beta;
+        *res_out = beta * beta;
+        if (!(beta > tol)) *flag = 1;
+    }
+}
+// after the Gram-Schmidt sweep of step j: column j of H from the partial arrays, previous
+// rotations, new rotation, residual estimate, loop test
+__global__ __launch_bounds__(kBlock) void k_gmres_givens(const double *parts, int stride, int count,
+                                                         int in_slots, const double *slots, int m,
+                                                         GmresState *G, double tol, int *flag, int64_t *iters,
+                                                         double *history, int64_t hist_cap, double *res_out)
+{
+    __shared__ double red[kBlock / 64];
+    if (*flag) return;
+    const int j = G->j;
+    __shared__ double hcol[kGmresMaxRestart + 2];
+    for (int i = 0; i <= j + 1; ++i) {          // h_0..h_j and the squared norm at j+1
+        ScalarRef r = in_slots ? ScalarRef{slots + i, 1} : ScalarRef{parts + (size_t)i * stride, count};
+        const double d = load_scalar<kBlock>(r, red);
+        if (threadIdx.x == 0) hcol[i] = d;
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    double *H = G->H + (size_t)j * (m + 1);
+    for (int i = 0; i <= j; ++i) H[i] = hcol[i];
+    H[j + 1] = sqrt(hcol[j + 1]);
+    for (int i = 0; i < j; ++i) {
+        const double h0 = H[i], h1 = H[i + 1];
+        H[i] = G->cs[i] * h0 + G->sn[i] * h1;
+        H[i + 1] = -G->sn[i] * h0 + G->cs[i] * h1;
+    }
+    const double h0 = H[j], h1 = H[j + 1];
+    const double d = sqrt(h0 * h0 + h1 * h1);
+    G->cs[j] = h0 / d;
+    G->sn[j] = h1 / d;
+    H[j] = d;
+    H[j + 1] = 0.0;
+    G->g[j + 1] = -G->sn[j] * G->g[j];
+    G->g[j] = G->cs[j] * G->g[j];
+    const double res = fabs(G->g[j + 1]);
+    const int64_t it = *iters;
+    if (history && it < hist_cap) history[it] = res * res;
+    *iters = it + 1;
+    *res_out = res * res;
+    G->j = j + 1;
+    if (!(res > tol)) *flag = 1;
+}
+// end of a cycle: back substitution for y (k = G->j columns)
+__global__ void k_gmres_solve_y(GmresState *G, int m)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int k = G->j;
+    for (int i = k - 1; i >= 0; --i) {
+        double s = G->g[i];
+        for (int l = i + 1; l < k; ++l) s = s - G->H[i + (size_t)l * (m + 1)] * G->y[l];
+        G->y[i] = s / G->H[i + (size_t)i * (m + 1)];
+    }
+}
+// x = x + sum_i y_i v_i   (one pass over x, k passes over V)
+struct FGmresUpdate {
+    double *x; const double *V; int64_t ldv; const GmresState *G; int k = 0;
+    __device__ bool prepare(double *) { k = G->j; return k > 0; }
+    __device__ void one(int64_t i)
+    {
+        double xv = x[i];
+        for (int c = 0; c < k; ++c) xv = xv + G->y[c] * V[(size_t)c * ldv + i];
+        x[i] = xv;
+    }
+    __device__ void pair(int64_t i) { one(2 * i); one(2 * i + 1); }
+    __device__ void single(int64_t i) { one(i); }
+    __device__ void finish(double *) {}
+};
+
+template <class F>
+static inline void launch_elem(int64_t n, const F &f, const int *flag)
+{
+    hipLaunchKernelGGL((k_elem<F>), dim3(vec_grid(n)), dim3(kBlock), 0, g_rt.stream, n, f, flag);
+}
+
+}  // namespace sgm
+
+using namespace sgm;
+
+// ======================================================================================
+// solver object
+// ======================================================================================
+namespace {
+constexpr int kNumPartials = 40;     // partial arrays per part (GMRES needs restart+2)
+
+struct PartWork {
+    int64_t n = 0, next = 0;         // owned length, extended (owned+halo) length
+    std::vector<double *> vec;       // work vectors, each `next` long
+    double *partials = nullptr;      // kNumPartials x kMaxGrid
+    double *slots = nullptr;         // kNumPartials reduced scalars (multi-part only)
+    int *flag = nullptr;             // device: loop finished
+    int64_t *iters = nullptr;        // device: iterations of the current solve
+    double *res = nullptr;           // device: last res2
+    double *history = nullptr;
+    GmresState *gmres = nullptr;
+    double *V = nullptr;             // GMRES basis, (restart+1) x next
+    int count[kNumPartials] = {0};   // producer grid of each partial array
+};
+}  // namespace
+
+struct sgm_solver_s {
+    int kind = 0;
+    double tolerance = 1e-16;        // cg_set_params default, cg_solvers.f90:106
+    int32_t restart = 30;
+    int64_t max_iter = 0;
+    int64_t hist_cap = 0;
+    bool initialized = false;
+    int32_t nn = 0;
+    int64_t iterations = 0;          // accumulates across solves (cg_solvers.f90:72,145)
+    int64_t last_iterations = 0;
+    double res2 = 0.0;
+    int32_t converged = 0;
+    std::vector<PartWork> work;
+    std::vector<double> history;
+    bool multi = false;
+};
+
+namespace {
+
+int num_work_vectors(int kind) { return kind == SGM_SOLVER_CG ? 4 : kind == SGM_SOLVER_BICGSTAB ? 8 : 3; }
+
+void free_work(sgm_solver s)
+{
+    for (auto &w : s->work) {
+        for (double *v : w.vec) dfree(v);
+        dfree(w.partials); dfree(w.slots); dfree(w.flag); dfree(w.iters); dfree(w.res);
+        dfree(w.history); dfree(w.gmres); dfree(w.V);
+    }
+    s->work.clear();
+}
+
+// ScalarRef of partial array k on part ip
+ScalarRef ref(sgm_solver s, size_t ip, int k)
+{
+    PartWork &w = s->work[ip];
+    if (s->multi) return ScalarRef{w.slots + k, 1};
+    return ScalarRef{w.partials + (size_t)k * kMaxGrid, w.count[k]};
+}
+double *part(sgm_solver s, size_t ip, int k) { return s->work[ip].partials + (size_t)k * kMaxGrid; }
+
+// after the producers of partial arrays ks[] ran on every part: make the totals visible
+int finish_dots(sgm_solver s, sgm_mat A, const int *ks, int nk)
+{
+    if (!s->multi) return SGM_OK;
+    // slots ks[] must be contiguous for the all-reduce: callers pass consecutive ids
+    for (size_t ip = 0; ip < s->work.size(); ++ip)
+        for (int t = 0; t < nk; ++t)
+            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, g_rt.stream, part(s, ip, ks[t]),
+                               s->work[ip].count[ks[t]], s->work[ip].slots + ks[t]);
+    std::vector<double *> ptrs(s->work.size());
+    for (size_t ip = 0; ip < s->work.size(); ++ip) ptrs[ip] = s->work[ip].slots + ks[0];
+    return allreduce_slots(A, ptrs.data(), ks[nk - 1] - ks[0] + 1);
+}
+
+struct Views {       // per-part pointer tables for spmv_parts / pc
+    std::vector<const double *> cx;
+    std::vector<double *> y;
+    std::vector<const double *> w;
+    std::vector<double *> p0, p1;
+    std::vector<const int *> flags;
+};
+
+int read_state(sgm_solver s, int *flag, int64_t *iters, double *res)
+{
+    PartWork &w = s->work[0];
+    SGM_HIP(hipMemcpyAsync(flag, w.flag, sizeof(int), hipMemcpyDeviceToHost, g_rt.stream));
+    SGM_HIP(hipMemcpyAsync(iters, w.iters, sizeof(int64_t), hipMemcpyDeviceToHost, g_rt.stream));
+    SGM_HIP(hipMemcpyAsync(res, w.res, sizeof(double), hipMemcpyDeviceToHost, g_rt.stream));
+    SGM_HIP(hipStreamSynchronize(g_rt.stream));
+    return SGM_OK;
+}
+
+// ---------------------------------------------------------------------------------- CG
+enum { C_PQ = 0, C_RR0 = 1, C_RR1 = 2 };
+enum { V_P = 0, V_Q = 1, V_R = 2, V_Z = 3 };
+
+int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sgm_pc pc)
+{
+    const size_t P = s->work.size();
+    const int pk = pc ? pc_kind(pc) : 0;
+    Views v;
+    v.cx.resize(P); v.y.resize(P); v.w.resize(P); v.p0.resize(P); v.flags.resize(P);
+    auto W = [&](size_t ip, int k) { return s->work[ip].vec[k]; };
+    int grid = 0;
+
+    // q = A x  (x staged into p: a distributed matvec needs the halo slots)
+    for (size_t ip = 0; ip < P; ++ip) {
+        launch_elem(s->work[ip].n, FCopy{W(ip, V_P), x[ip]}, nullptr);
+        v.cx[ip] = W(ip, V_P); v.y[ip] = W(ip, V_Q); v.flags[ip] = s->work[ip].flag;
+    }
+    SGM_TRY(spmv_parts(A, v.cx.data(), v.y.data(), false, nullptr, nullptr, &grid));
+    if (pk == 0) {
+        for (size_t ip = 0; ip < P; ++ip) {
+            const int64_t n = s->work[ip].n;
+            s->work[ip].count[C_RR0] = vec_grid(n);
+            launch_elem(n, FCgInit{b[ip], W(ip, V_Q), W(ip, V_R), W(ip, V_P), part(s, ip, C_RR0), true}, nullptr);
+        }
+    } else {
+        std::vector<const double *> rr(P); std::vector<double *> zz(P);
+        for (size_t ip = 0; ip < P; ++ip) {
+            launch_elem(s->work[ip].n, FCgInit{b[ip], W(ip, V_Q), W(ip, V_R), nullptr, nullptr, false}, nullptr);
+            rr[ip] = W(ip, V_R); zz[ip] = W(ip, V_Z);
+        }
+        SGM_TRY(pc_apply_parts(pc, A, rr.data(), zz.data(), nullptr));
+        for (size_t ip = 0; ip < P; ++ip) {
+            const int64_t n = s->work[ip].n;
+            s->work[ip].count[C_RR0] = vec_grid(n);
+            launch_elem(n, FCopyDot{W(ip, V_P), W(ip, V_Z), W(ip, V_R), part(s, ip, C_RR0)}, nullptr);
+        }
+    }
+    { const int ks[1] = {C_RR0}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+    for (size_t ip = 0; ip < P; ++ip)
+        hipLaunchKernelGGL(k_check, dim3(1), dim3(kBlock), 0, g_rt.stream, ref(s, ip, C_RR0), s->tolerance,
+                           s->work[ip].flag, s->work[ip].res);
+
+    int64_t k = 0;
+    int flag = 0; int64_t iters = 0; double res = 0.0;
+    const int64_t batch_max = pk == SGM_PC_ILDU0 ? 1 : 16;
+    for (;;) {
+        int64_t batch = batch_max;
+        if (s->max_iter > 0) batch = std::min<int64_t>(batch, s->max_iter - k);
+        for (int64_t bi = 0; bi < batch; ++bi, ++k) {
+            const int cur = (k & 1) ? C_RR1 : C_RR0, nxt = (k & 1) ? C_RR0 : C_RR1;
+            // q = A p, partial p.q
+            SpmvDots dots;
+            for (size_t ip = 0; ip < P; ++ip) {
+                v.cx[ip] = W(ip, V_P); v.y[ip] = W(ip, V_Q); v.w[ip] = W(ip, V_P); v.p0[ip] = part(s, ip, C_PQ);
+            }
+            dots.w = v.w.data(); dots.part_wy = v.p0.data();
+            // all parts share one flag value; spmv takes part 0's flag for every launch on
+            // this device (identical contents)
+            SGM_TRY(spmv_parts(A, v.cx.data(), v.y.data(), false, &dots, s->work[0].flag, &grid));
+            for (size_t ip = 0; ip < P; ++ip) s->work[ip].count[C_PQ] = spmv_grid(A->parts[ip]);
+            { const int ks[1] = {C_PQ}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+            for (size_t ip = 0; ip < P; ++ip) {
+                PartWork &w = s->work[ip];
+                w.count[nxt] = vec_grid(w.n);
+                if (pk == 0)
+                    launch_elem(w.n, FCgXR<0>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_P), W(ip, V_Q), x[ip],
+                                              W(ip, V_R), nullptr, nullptr, part(s, ip, nxt)}, w.flag);
+                else if (pk == SGM_PC_JACOBI)
+                    launch_elem(w.n, FCgXR<1>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_P), W(ip, V_Q), x[ip],
+                                              W(ip, V_R), pc_idiag(pc, ip), W(ip, V_Z), part(s, ip, nxt)}, w.flag);
+                else
+                    launch_elem(w.n, FCgXR<2>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_P), W(ip, V_Q), x[ip],
+                                              W(ip, V_R), nullptr, nullptr, nullptr}, w.flag);
+            }
+            if (pk != 0 && pk != SGM_PC_JACOBI) {
+                std::vector<const double *> rr(P); std::vector<double *> zz(P);
+                for (size_t ip = 0; ip < P; ++ip) { rr[ip] = W(ip, V_R); zz[ip] = W(ip, V_Z); }
+                SGM_TRY(pc_apply_parts(pc, A, rr.data(), zz.data(), v.flags.data()));
+                for (size_t ip = 0; ip < P; ++ip) {
+                    PartWork &w = s->work[ip];
+                    launch_elem(w.n, FDot2{W(ip, V_R), W(ip, V_Z), nullptr, nullptr, part(s, ip, nxt), nullptr}, w.flag);
+                }
+            }
+            { const int ks[1] = {nxt}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+            for (size_t ip = 0; ip < P; ++ip) {
+                PartWork &w = s->work[ip];
+                launch_elem(w.n, FCgP{ref(s, ip, cur), ref(s, ip, nxt), pk == 0 ? W(ip, V_R) : W(ip, V_Z), W(ip, V_P),
+                                      s->tolerance, w.flag, w.iters, ip == 0 ? w.history : nullptr, s->hist_cap,
+                                      w.res}, w.flag);
+            }
+        }
+        SGM_HIP(hipGetLastError());
+        SGM_TRY(read_state(s, &flag, &iters, &res));
+        if (flag || (s->max_iter > 0 && k >= s->max_iter)) break;
+    }
+    s->last_iterations = iters;
+    s->res2 = res;
+    s->converged = flag;
+    return SGM_OK;
+}
+
+// ---------------------------------------------------------------------------- BiCGStab
+// partial arrays: parity-indexed dot results
+enum { B_RR = 0, B_RHO = 2, B_R0V = 4, B_ST = 6, B_TT = 8 };     // +parity
+enum { W_P = 0, W_Q = 1, W_R = 2, W_R0 = 3, W_V = 4, W_S = 5, W_T = 6, W_Z = 7 };
+
+int run_bicgstab(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sgm_pc pc)
+{
+    const size_t P = s->work.size();
+    const int pk = pc ? pc_kind(pc) : 0;
+    Views v;
+    v.cx.resize(P); v.y.resize(P); v.w.resize(P); v.p0.resize(P); v.p1.resize(P); v.flags.resize(P);
+    auto W = [&](size_t ip, int k) { return s->work[ip].vec[k]; };
+    int grid = 0;
+    for (size_t ip = 0; ip < P; ++ip) v.flags[ip] = s->work[ip].flag;
+
+    for (size_t ip = 0; ip < P; ++ip) {
+        launch_elem(s->work[ip].n, FCopy{W(ip, W_P), x[ip]}, nullptr);
+        v.cx[ip] = W(ip, W_P); v.y[ip] = W(ip, W_Q);
+    }
+    SGM_TRY(spmv_parts(A, v.cx.data(), v.y.data(), false, nullptr, nullptr, &grid));
+    if (pk) {   // z = b - q ; r0 = M^-1 z
+        std::vector<const double *> zz(P); std::vector<double *> r0(P);
+        for (size_t ip = 0; ip < P; ++ip) {
+            launch_elem(s->work[ip].n, FCgInit{b[ip], W(ip, W_Q), W(ip, W_Z), nullptr, nullptr, false}, nullptr);
+            zz[ip] = W(ip, W_Z); r0[ip] = W(ip, W_R0);
+        }
+        SGM_TRY(pc_apply_parts(pc, A, zz.data(), r0.data(), nullptr));
+    }
+    for (size_t ip = 0; ip < P; ++ip) {
+        const int64_t n = s->work[ip].n;
+        s->work[ip].count[B_RR] = s->work[ip].count[B_RHO] = vec_grid(n);
+        launch_elem(n, FBiInit{pk ? W(ip, W_R0) : b[ip], W(ip, W_Q), pk == 0, W(ip, W_R0), W(ip, W_R), W(ip, W_V),
+                               W(ip, W_P), part(s, ip, B_RR), part(s, ip, B_RHO)}, nullptr);
+    }
+    { const int ks[3] = {B_RR, B_RR + 1, B_RHO}; SGM_TRY(finish_dots(s, A, ks, 3)); }
+
+    int64_t k = 0;
+    int flag = 0; int64_t iters = 0; double res = 0.0;
+    const int64_t batch_max = pk == SGM_PC_ILDU0 ? 1 : 16;
+    auto enqueue_test = [&](int cur) {   // loop test only (no p update): used after the last batch
+        for (size_t ip = 0; ip < P; ++ip)
+            hipLaunchKernelGGL(k_check, dim3(1), dim3(kBlock), 0, g_rt.stream, ref(s, ip, B_RR + cur), s->tolerance,
+                               s->work[ip].flag, s->work[ip].res);
+    };
+    for (;;) {
+        int64_t batch = batch_max;
+        if (s->max_iter > 0) batch = std::min<int64_t>(batch, s->max_iter - k);
+        for (int64_t bi = 0; bi < batch; ++bi, ++k) {
+            const int c = (int)(k & 1), o = c ^ 1;
+            for (size_t ip = 0; ip < P; ++ip) {
+                PartWork &w = s->work[ip];
+                BiScalars S{ref(s, ip, B_RR + c), ref(s, ip, B_RHO + c), ref(s, ip, B_RHO + o), ref(s, ip, B_R0V + o),
+                            ref(s, ip, B_ST + o), ref(s, ip, B_TT + o), ref(s, ip, B_R0V + c), ref(s, ip, B_ST + c),
+                            ref(s, ip, B_TT + c), k == 0, pk == 0};
+                launch_elem(w.n, FBiP{S, W(ip, W_R), W(ip, W_V), W(ip, W_P), s->tolerance, w.flag, w.iters,
+                                      ip == 0 ? w.history : nullptr, s->hist_cap, w.res}, w.flag);
+            }
+            // v = [M^-1] A p ; r0.v
+            SpmvDots dots;
+            for (size_t ip = 0; ip < P; ++ip) {
+                v.cx[ip] = W(ip, W_P); v.y[ip] = pk ? W(ip, W_Z) : W(ip, W_V);
+                v.w[ip] = W(ip, W_R0); v.p0[ip] = part(s, ip, B_R0V + c);
+            }
+            dots.w = v.w.data(); dots.part_wy = v.p0.data();
+            SGM_TRY(spmv_parts(A, v.cx.data(), v.y.data(), false, pk ? nullptr : &dots, s->work[0].flag, &grid));
+            for (size_t ip = 0; ip < P; ++ip) s->work[ip].count[B_R0V + c] = spmv_grid(A->parts[ip]);
+            if (pk) {
+                std::vector<const double *> zz(P); std::vector<double *> vv(P);
+                for (size_t ip = 0; ip < P; ++ip) { zz[ip] = W(ip, W_Z); vv[ip] = W(ip, W_V); }
+                SGM_TRY(pc_apply_parts(pc, A, zz.data(), vv.data(), v.flags.data()));
+                for (size_t ip = 0; ip < P; ++ip) {
+                    PartWork &w = s->work[ip];
+                    w.count[B_R0V + c] = vec_grid(w.n);
+                    launch_elem(w.n, FDot2{W(ip, W_R0), W(ip, W_V), nullptr, nullptr, part(s, ip, B_R0V + c), nullptr},
+                                w.flag);
+                }
+            }
+            { const int ks[1] = {B_R0V + c}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+            for (size_t ip = 0; ip < P; ++ip) {
+                PartWork &w = s->work[ip];
+                launch_elem(w.n, FBiS{ref(s, ip, B_RHO + c), ref(s, ip, B_R0V + c), W(ip, W_R), W(ip, W_V), W(ip, W_S)},
+                            w.flag);
+            }
+            // t = [M^-1] A s ; s.t , t.t
+            for (size_t ip = 0; ip < P; ++ip) {
+                v.cx[ip] = W(ip, W_S); v.y[ip] = pk ? W(ip, W_Z) : W(ip, W_T);
+                v.w[ip] = W(ip, W_S); v.p0[ip] = part(s, ip, B_ST + c); v.p1[ip] = part(s, ip, B_TT + c);
+            }
+            dots.w = v.w.data(); dots.part_wy = v.p0.data(); dots.part_yy = v.p1.data();
+            SGM_TRY(spmv_parts(A, v.cx.data(), v.y.data(), false, pk ? nullptr : &dots, s->work[0].flag, &grid));
+            for (size_t ip = 0; ip < P; ++ip) s->work[ip].count[B_ST + c] = s->work[ip].count[B_TT + c] = spmv_grid(A->parts[ip]);
+            if (pk) {
+                std::vector<const double *> zz(P); std::vector<double *> tt(P);
+                for (size_t ip = 0; ip < P; ++ip) { zz[ip] = W(ip, W_Z); tt[ip] = W(ip, W_T); }
+                SGM_TRY(pc_apply_parts(pc, A, zz.data(), tt.data(), v.flags.data()));
+                for (size_t ip = 0; ip < P; ++ip) {
+                    PartWork &w = s->work[ip];
+                    w.count[B_ST + c] = w.count[B_TT + c] = vec_grid(w.n);
+                    launch_elem(w.n, FDot2{W(ip, W_S), W(ip, W_T), W(ip, W_T), W(ip, W_T), part(s, ip, B_ST + c),
+                                           part(s, ip, B_TT + c)}, w.flag);
+                }
+            }
+            // ST/TT ids are not adjacent for one parity: two calls keep slots contiguous
+            { const int ks[1] = {B_ST + c}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+            { const int ks[1] = {B_TT + c}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+            for (size_t ip = 0; ip < P; ++ip) {
+                PartWork &w = s->work[ip];
+                w.count[B_RR + o] = w.count[B_RHO + o] = vec_grid(w.n);
+                launch_elem(w.n, FBiXR{ref(s, ip, B_RHO + c), ref(s, ip, B_R0V + c), ref(s, ip, B_ST + c),
+                                       ref(s, ip, B_TT + c), pk == 0, W(ip, W_P), W(ip, W_S), W(ip, W_T), W(ip, W_R0),
+                                       x[ip], W(ip, W_R), part(s, ip, B_RR + o), part(s, ip, B_RHO + o)}, w.flag);
+            }
+            { const int ks[1] = {B_RR + o}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+            { const int ks[1] = {B_RHO + o}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+        }
+        // the loop test of the NEXT iteration decides whether we are done (k_check only ever
+        // sets the flag, so an earlier in-batch stop is kept)
+        enqueue_test((int)(k & 1));
+        SGM_HIP(hipGetLastError());
+        SGM_TRY(read_state(s, &flag, &iters, &res));
+        if (flag || (s->max_iter > 0 && k >= s->max_iter)) break;
+    }
+    if (s->hist_cap && iters >= 1 && iters <= s->hist_cap)    // res2 after the last iteration
+        SGM_HIP(hipMemcpy(s->work[0].history + (iters - 1), s->work[0].res, 8, hipMemcpyDeviceToDevice));
+    s->last_iterations = iters;
+    s->res2 = res;
+    s->converged = flag;
+    return SGM_OK;
+}
+
+// ------------------------------------------------------------------------------- GMRES
+enum { G_W = 0, G_T = 1, G_X = 2 };     // work vectors: w, tmp, (x staging unused)
+
+int run_gmres(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sgm_pc pc)
+{
+    const size_t P = s->work.size();
+    const int m = s->restart;
+    Views v;
+    v.cx.resize(P); v.y.resize(P); v.flags.resize(P);
+    auto W = [&](size_t ip, int k) { return s->work[ip].vec[k]; };
+    auto Vc = [&](size_t ip, int c) { return s->work[ip].V + (size_t)c * s->work[ip].next; };
+    int grid = 0;
+    for (size_t ip = 0; ip < P; ++ip) v.flags[ip] = s->work[ip].flag;
+    const int NRM = m + 1;       // partial array ids: 0..m = h column (h_0..h_j, norm at j+1) ; NRM also start norm
+    int64_t done_steps = 0;
+    int flag = 0; int64_t iters = 0; double res = 0.0;
+
+    auto apply_A = [&](int srcV, int src_col, double *const *dst_w) -> int {
+        // dst_w = [M^-1] A src   (src is a column of V or the x staging in W)
+        for (size_t ip = 0; ip < P; ++ip) {
+            v.cx[ip] = srcV ? Vc(ip, src_col) : W(ip, G_X);
+            v.y[ip] = pc ? W(ip, G_T) : dst_w[ip];
+        }
+        SGM_TRY(spmv_parts(A, v.cx.data(), v.y.data(), false, nullptr, s->work[0].flag, &grid));
+        if (pc) {
+            std::vector<const double *> tt(P);
+            for (size_t ip = 0; ip < P; ++ip) tt[ip] = W(ip, G_T);
+            SGM_TRY(pc_apply_parts(pc, A, tt.data(), dst_w, v.flags.data()));
+        }
+        return SGM_OK;
+    };
+    std::vector<double *> wv(P);
+    for (size_t ip = 0; ip < P; ++ip) wv[ip] = W(ip, G_W);
+
+    for (;;) {
+        // r = M^-1 (b - A x) ; beta ; v_0 = r / beta
+        for (size_t ip = 0; ip < P; ++ip) launch_elem(s->work[ip].n, FCopy{W(ip, G_X), x[ip]}, s->work[ip].flag);
+        if (pc) {
+            for (size_t ip = 0; ip < P; ++ip) { v.cx[ip] = W(ip, G_X); v.y[ip] = W(ip, G_W); }
+            SGM_TRY(spmv_parts(A, v.cx.data(), v.y.data(), false, nullptr, s->work[0].flag, &grid));
+            std::vector<const double *> tt(P);
+            for (size_t ip = 0; ip < P; ++ip) {
+                launch_elem(s->work[ip].n, FCgInit{b[ip], W(ip, G_W), W(ip, G_T), nullptr, nullptr, false}, s->work[ip].flag);
+                tt[ip] = W(ip, G_T);
+            }
+            SGM_TRY(pc_apply_parts(pc, A, tt.data(), wv.data(), v.flags.data()));
+        } else {
+            for (size_t ip = 0; ip < P; ++ip) { v.cx[ip] = W(ip, G_X); v.y[ip] = W(ip, G_T); }
+            SGM_TRY(spmv_parts(A, v.cx.data(), v.y.data(), false, nullptr, s->work[0].flag, &grid));
+            for (size_t ip = 0; ip < P; ++ip)
+                launch_elem(s->work[ip].n, FCgInit{b[ip], W(ip, G_T), W(ip, G_W), nullptr, nullptr, false}, s->work[ip].flag);
+        }
+        for (size_t ip = 0; ip < P; ++ip) {
+            PartWork &w = s->work[ip];
+            w.count[NRM] = vec_grid(w.n);
+            launch_elem(w.n, FMgs{W(ip, G_W), nullptr, nullptr, ScalarRef{nullptr, 0}, part(s, ip, NRM)}, w.flag);
+        }
+        { const int ks[1] = {NRM}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+        for (size_t ip = 0; ip < P; ++ip) {
+            PartWork &w = s->work[ip];
+            hipLaunchKernelGGL(k_gmres_start, dim3(1), dim3(kBlock), 0, g_rt.stream, ref(s, ip, NRM), w.gmres,
+                               s->tolerance, w.flag, w.res);
+            launch_elem(w.n, FScaleInv{Vc(ip, 0), W(ip, G_W), ref(s, ip, NRM)}, w.flag);
+        }
+        int steps = m;
+        if (s->max_iter > 0) steps = (int)std::min<int64_t>(m, s->max_iter - done_steps);
+        for (int j = 0; j < steps; ++j) {
+            SGM_TRY(apply_A(1, j, wv.data()));
+            // modified Gram-Schmidt: h_i = w.v_i ; w -= h_i v_i, fused as
+            //   pass i: [w -= h_{i-1} v_{i-1}] ; partial w.v_i        (i = 0..j)
+            //   pass j+1: w -= h_j v_j ; partial w.w
+            for (int i = 0; i <= j + 1; ++i) {
+                for (size_t ip = 0; ip < P; ++ip) {
+                    PartWork &w = s->work[ip];
+                    w.count[i] = vec_grid(w.n);
+                    launch_elem(w.n, FMgs{W(ip, G_W), i ? Vc(ip, i - 1) : nullptr, i <= j ? Vc(ip, i) : nullptr,
+                                          i ? ref(s, ip, i - 1) : ScalarRef{nullptr, 0}, part(s, ip, i)}, w.flag);
+                }
+                { const int ks[1] = {i}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+            }
+            for (size_t ip = 0; ip < P; ++ip) {
+                PartWork &w = s->work[ip];
+                // v_{j+1} = w / h_{j+1,j} must use the norm BEFORE the rotation -> scale first
+                launch_elem(w.n, FScaleInv{Vc(ip, j + 1), W(ip, G_W), ref(s, ip, j + 1)}, w.flag);
+                hipLaunchKernelGGL(k_gmres_givens, dim3(1), dim3(kBlock), 0, g_rt.stream, w.partials, kMaxGrid,
+                                   w.count[0], s->multi ? 1 : 0, w.slots, m, w.gmres, s->tolerance, w.flag, w.iters,
+                                   ip == 0 ? w.history : nullptr, s->hist_cap, w.res);
+            }
+        }
+        done_steps += steps;
+        // x = x + V y  (always: also when the loop test fired mid-cycle)
+        for (size_t ip = 0; ip < P; ++ip) {
+            PartWork &w = s->work[ip];
+            hipLaunchKernelGGL(k_gmres_solve_y, dim3(1), dim3(64), 0, g_rt.stream, w.gmres, m);
+            launch_elem(w.n, FGmresUpdate{x[ip], w.V, w.next, w.gmres}, nullptr);
+        }
+        SGM_HIP(hipGetLastError());
+        SGM_TRY(read_state(s, &flag, &iters, &res));
+        if (flag || (s->max_iter > 0 && done_steps >= s->max_iter)) break;
+    }
+    s->last_iterations = iters;
+    s->res2 = res;
+    s->converged = flag;
+    return SGM_OK;
+}
+
+}  // namespace
+
+// ======================================================================================
+// C ABI
+// ======================================================================================
+extern "C" {
+
+static int solver_create(sgm_solver *out, int kind, double tol, int32_t restart)
+{
+    if (!out) return fail(SGM_ERR_BAD_ARG, "solver create: null out pointer");
+    sgm_solver s = new sgm_solver_s;
+    s->kind = kind;
+    s->tolerance = tol;
+    s->restart = restart;
+    *out = s;
+    return SGM_OK;
+}
+int sgm_cg_create(sgm_solver *out, double tolerance) { return solver_create(out, SGM_SOLVER_CG, tolerance, 0); }
+int sgm_bicgstab_create(sgm_solver *out, double tolerance) { return solver_create(out, SGM_SOLVER_BICGSTAB, tolerance, 0); }
+int sgm_gmres_create(sgm_solver *out, double tolerance, int32_t restart)
+{
+    if (restart < 1 || restart > kNumPartials - 2 || restart > kGmresMaxRestart)
+        return fail(SGM_ERR_BAD_ARG, "sgm_gmres_create: restart must be in 1..%d", kNumPartials - 2);
+    return solver_create(out, SGM_SOLVER_GMRES, tolerance, restart);
+}
+
+int sgm_solver_setup(sgm_solver s, sgm_mat A)
+{
+    SGM_TRY(require_init());
+    if (!s || !A) return fail(SGM_ERR_BAD_ARG, "sgm_solver_setup: null argument");
+    if (A->nrow != A->ncol)     // cg_solvers.f90:61-65
+        return fail(SGM_ERR_DIMS, "Cannot make a %s solver for a non-square matrix",
+                    s->kind == SGM_SOLVER_CG ? "CG" : s->kind == SGM_SOLVER_BICGSTAB ? "BiCGStab" : "GMRES");
+    s->nn = A->nrow;
+    s->iterations = 0;          // cg_solvers.f90:72
+    s->multi = A->distributed();
+    bool realloc = !s->initialized || s->work.size() != A->parts.size();
+    for (size_t ip = 0; !realloc && ip < A->parts.size(); ++ip)
+        realloc = s->work[ip].n != A->parts[ip].n || s->work[ip].next != A->parts[ip].xlen();
+    if (realloc) {
+        free_work(s);
+        s->work.resize(A->parts.size());
+        for (size_t ip = 0; ip < A->parts.size(); ++ip) {
+            PartWork &w = s->work[ip];
+            w.n = A->parts[ip].n;
+            w.next = std::max<int64_t>(A->parts[ip].xlen(), w.n);
+            w.vec.resize(num_work_vectors(s->kind));
+            for (auto &p : w.vec) SGM_TRY(dalloc(&p, (size_t)w.next + 2));
+            SGM_TRY(dalloc(&w.partials, (size_t)kNumPartials * kMaxGrid));
+            SGM_TRY(dalloc(&w.slots, (size_t)kNumPartials));
+            SGM_TRY(dalloc(&w.flag, 1));
+            SGM_TRY(dalloc(&w.iters, 1));
+            SGM_TRY(dalloc(&w.res, 1));
+            if (s->kind == SGM_SOLVER_GMRES) {
+                SGM_TRY(dalloc(&w.gmres, 1));
+                SGM_TRY(dalloc(&w.V, (size_t)(s->restart + 1) * w.next + 2));
+            }
+        }
+        s->initialized = true;
+    }
+    for (auto &w : s->work) {   // cg_solvers.f90:84-88: zero the work vectors on every setup
+        for (auto &p : w.vec) SGM_HIP(hipMemsetAsync(p, 0, ((size_t)w.next + 2) * 8, g_rt.stream));
+        SGM_HIP(hipMemsetAsync(w.partials, 0, (size_t)kNumPartials * kMaxGrid * 8, g_rt.stream));
+        SGM_HIP(hipMemsetAsync(w.slots, 0, (size_t)kNumPartials * 8, g_rt.stream));
+    }
+    return finish();
+}
+
+int sgm_solver_set_max_iter(sgm_solver s, int64_t max_iter)
+{
+    if (!s) return fail(SGM_ERR_BAD_ARG, "null solver");
+    s->max_iter = max_iter > 0 ? max_iter : 0;
+    return SGM_OK;
+}
+
+int sgm_solver_set_history(sgm_solver s, int64_t capacity)
+{
+    if (!s) return fail(SGM_ERR_BAD_ARG, "null solver");
+    s->hist_cap = capacity > 0 ? capacity : 0;
+    for (auto &w : s->work) { dfree(w.history); w.history = nullptr; }
+    return SGM_OK;
+}
+
+int sgm_solver_solve(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc pc, int where)
+{
+    SGM_TRY(require_init());
+    if (!s || !A || !x || !b) return fail(SGM_ERR_BAD_ARG, "sgm_solver_solve: null argument");
+    if (!s->initialized) return fail(SGM_ERR_BAD_ARG, "sgm_solver_solve: solver%%setup(A) has not been called");
+    if (A->nrow != s->nn || s->work.size() != A->parts.size())
+        return fail(SGM_ERR_DIMS, "sgm_solver_solve: matrix does not match the one given to setup");
+    const size_t P = A->parts.size();
+    // the caller's vectors: global length for a single / in-process-partitioned matrix,
+    // owned slice for a matrix distributed over processes
+    const int64_t nvec = A->comm ? A->parts[0].n : A->nrow;
+    Staged sx, sb;
+    SGM_TRY(stage_in(sx, x, nvec, where, true));
+    SGM_TRY(stage_in(sb, b, nvec, where, true));
+    std::vector<double *> xs(P);
+    std::vector<const double *> bs(P);
+    for (size_t ip = 0; ip < P; ++ip) {
+        const int64_t off = A->comm ? 0 : A->parts[ip].row_begin;
+        if (off & 1) return fail(SGM_ERR_UNSUPPORTED, "partition boundaries must be even rows (16-B vector access)");
+        xs[ip] = sx.dev + off;
+        bs[ip] = sb.dev + off;
+        PartWork &w = s->work[ip];
+        SGM_HIP(hipMemsetAsync(w.flag, 0, sizeof(int), g_rt.stream));
+        SGM_HIP(hipMemsetAsync(w.iters, 0, sizeof(int64_t), g_rt.stream));
+        if (s->hist_cap && !w.history && ip == 0) {
+            SGM_TRY(dalloc(&w.history, (size_t)s->hist_cap));
+        }
+        if (w.history) SGM_HIP(hipMemsetAsync(w.history, 0, (size_t)s->hist_cap * 8, g_rt.stream));
+    }
+    int rc;
+    if (s->kind == SGM_SOLVER_CG) rc = run_cg(s, A, xs.data(), bs.data(), pc);
+    else if (s->kind == SGM_SOLVER_BICGSTAB) rc = run_bicgstab(s, A, xs.data(), bs.data(), pc);
+    else rc = run_gmres(s, A, xs.data(), bs.data(), pc);
+    if (rc != SGM_OK) return rc;
+    s->iterations += s->last_iterations;
+    if (s->hist_cap) {
+        const int64_t cnt = std::min<int64_t>(s->last_iterations, s->hist_cap);
+        s->history.resize((size_t)cnt);
+        if (cnt) SGM_HIP(hipMemcpy(s->history.data(), s->work[0].history, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+    }
+    SGM_TRY(stage_out(sx, x, nvec, where));
+    SGM_TRY(finish());
+    if (s->max_iter > 0 && !s->converged) {
+        fail(SGM_ERR_NOT_CONVERGED, "solver stopped at max_iter=%lld with sqrt(res2)=%g > %g",
+             (long long)s->max_iter, std::sqrt(s->res2), s->tolerance);
+        return SGM_ERR_NOT_CONVERGED;
+    }
+    return SGM_OK;
+}
+
+int sgm_solver_info(sgm_solver s, int64_t *iterations, double *res2, int32_t *converged, int64_t *last)
+{
+    if (!s) return fail(SGM_ERR_BAD_ARG, "null solver");
+    if (iterations) *iterations = s->iterations;
+    if (res2) *res2 = s->res2;
+    if (converged) *converged = s->converged;
+    if (last) *last = s->last_iterations;
+    return SGM_OK;
+}
+
+int sgm_solver_get_history(sgm_solver s, double *out, int64_t capacity, int64_t *count)
+{
+    if (!s) return fail(SGM_ERR_BAD_ARG, "null solver");
+    const int64_t c = std::min<int64_t>((int64_t)s->history.size(), capacity);
+    if (out && c) memcpy(out, s->history.data(), (size_t)c * 8);
+    if (count) *count = (int64_t)s->history.size();
+    return SGM_OK;
+}
+
+int sgm_solver_destroy(sgm_solver s)
+{
+    if (!s) return SGM_OK;
+    free_work(s);
+    delete s;
+    return SGM_OK;
+}
+
+// ---- exported vector statements ------------------------------------------------------
+int sgm_dot(int64_t n, const double *a, const double *b, double *result, int where)
+{
+    SGM_TRY(require_init());
+    if (n < 0 || !a || !b || !result) return fail(SGM_ERR_BAD_ARG, "sgm_dot: bad argument");
+    Staged sa, sb2;
+    SGM_TRY(stage_in(sa, a, n, where, true));
+    SGM_TRY(stage_in(sb2, b, n, where, true));
+    double *partials = nullptr, *slot = nullptr;
+    SGM_TRY(dalloc(&partials, (size_t)kMaxGrid));
+    SGM_TRY(dalloc(&slot, 1));
+    const int grid = vec_grid(n);
+    launch_elem(n, FDot2{sa.dev, sb2.dev, nullptr, nullptr, partials, nullptr}, nullptr);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, g_rt.stream, partials, grid, slot);
+    SGM_HIP(hipMemcpyAsync(result, slot, 8, hipMemcpyDeviceToHost, g_rt.stream));
+    SGM_HIP(hipStreamSynchronize(g_rt.stream));
+    dfree(partials);
+    dfree(slot);
+    return SGM_OK;
+}
+
+int sgm_axpy(int64_t n, double alpha, const double *x, double *y, int where)
+{
+    SGM_TRY(require_init());
+    if (n < 0 || !x || !y) return fail(SGM_ERR_BAD_ARG, "sgm_axpy: bad argument");
+    Staged sx, sy;
+    SGM_TRY(stage_in(sx, x, n, where, true));
+    SGM_TRY(stage_in(sy, y, n, where, true));
+    launch_elem(n, FAxpy{sy.dev, sx.dev, alpha}, nullptr);
+    SGM_HIP(hipGetLastError());
+    SGM_TRY(stage_out(sy, y, n, where));
+    return finish();
+}
+
+}  // extern "C"

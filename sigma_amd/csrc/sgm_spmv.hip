@@ -1,0 +1,483 @@
+// Sparse matrix-vector products for gfx950: CSR (cs_matrices.f90:600-622) and ELLPACK
+// (ellpack_matrices.f90:640-665), plus the matrix handles of the C ABI.
+//
+// Numerics contract (bit-identical to the reference loops): for every row the products
+// val(k)*x(node(k)) are rounded individually (this file is compiled with
+// -ffp-contract=off, so no v_fma_f64 is formed) and added to a scalar LEFT TO RIGHT in
+// stored order; `matvec` returns 0.0 + z like `y = 0; y(i) = y(i) + z`
+// (linear_operator_interface.f90:191-192).
+//
+// CSR kernel ("stream" form): a 256-thread workgroup owns 256 consecutive rows.  The
+// nnz range of those rows is contiguous in val/col, so it is streamed in tiles of 2048
+// entries with 16-byte (val) / 8-byte (col) coalesced loads by ALL lanes regardless of
+// row lengths; each lane multiplies its two entries by the gathered x values and parks
+// the products in LDS (16 KiB).  After the barrier lane i walks row i's products in LDS
+// in order.  HBM sees only wide streaming reads; the x gather is served by L2 (the
+// workgroup -> row-block map keeps consecutive row blocks on one XCD).
+// Algorithmic bytes per SpMV: 12*nnz + 4*(n+1) + 8*m + 8*n.
+#include "sgm_internal.hpp"
+
+#include <algorithm>
+
+namespace sgm {
+
+// ---------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------
+__global__ void k_dec1(int32_t *a, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) a[i] -= 1;
+}
+
+__global__ void k_ell_transpose(const int32_t *__restrict__ node, const double *__restrict__ val,
+                                int32_t *__restrict__ ecol, double *__restrict__ eval,
+                                int32_t n, int32_t max_d)
+{
+    // in: (max_d, n) column-major = row i contiguous; out: slot-major [k*n + i]
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)n * max_d;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < total; t += stride) {
+        const int32_t k = (int32_t)(t / n), i = (int32_t)(t % n);
+        if (node) ecol[t] = node[(int64_t)i * max_d + k] - 1;
+        if (val) eval[t] = val[(int64_t)i * max_d + k];
+    }
+}
+
+// Work-group -> row-block map.  Blocks b and b+8 share an XCD (round-robin dispatch), so
+// the blocks of one XCD take CONSECUTIVE row blocks inside each sweep of the grid: the x
+// entries they gather (own rows +- the stencil reach) stay in that XCD's 4 MiB L2.
+// Bijective because the grid is a multiple of 8.  Placement only changes speed.
+__device__ inline int64_t rowblock_of(int it, int b, int grid)
+{
+    const int per = grid >> 3;
+    return (int64_t)it * grid + (int64_t)(b & 7) * per + (b >> 3);
+}
+
+template <bool ADD, bool DOT_W, bool DOT_YY>
+__global__ __launch_bounds__(kBlock) void k_csr_spmv(
+    int32_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
+    const double *__restrict__ w, double *__restrict__ part_wy, double *__restrict__ part_yy,
+    const int *__restrict__ flag_done)
+{
+    __shared__ double prod[kTile];
+    __shared__ double red[kBlock / 64];
+    if (flag_done && *flag_done) return;
+
+    const int tid = threadIdx.x;
+    const int64_t nrb = ((int64_t)n + kBlock - 1) / kBlock;
+    double dwy = 0.0, dyy = 0.0;
+
+    for (int it = 0;; ++it) {
+        const int64_t rb = rowblock_of(it, blockIdx.x, gridDim.x);
+        if ((int64_t)it * gridDim.x >= nrb) break;
+        if (rb >= nrb) continue;          // uniform per block
+        const int32_t r0 = (int32_t)(rb * kBlock);
+        const int32_t r1 = min(r0 + kBlock, n);
+        const int32_t row = r0 + tid;
+        int32_t k = 0, ke = 0;
+        if (row < n) {
+            k = rowptr[row];
+            ke = rowptr[row + 1];
+        }
+        const int32_t s = rowptr[r0] & ~1;    // tile starts are even: 16-B aligned val loads
+        const int32_t e = rowptr[r1];
+        double z = 0.0;
+
+        for (int32_t ts = s; ts < e; ts += kTile) {
+            const int32_t te = min(ts + kTile, e);
+            // ---- phase 1: all lanes stream val/col and gather x (2 entries per lane)
+            constexpr int VPT = kTile / (2 * kBlock);
+            double2 v[VPT];
+            int2 c[VPT];
+#pragma unroll
+            for (int m = 0; m < VPT; ++m) {
+                const int32_t j = ts + 2 * tid + 2 * kBlock * m;
+                if (j < te) {     // arrays are padded by 2 entries: j+1 is always readable
+                    v[m] = *reinterpret_cast<const double2 *>(val + j);
+                    c[m] = *reinterpret_cast<const int2 *>(col + j);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < VPT; ++m) {
+                const int32_t j = ts + 2 * tid + 2 * kBlock * m;
+                if (j < te) {
+                    const double x0 = x[c[m].x], x1 = x[c[m].y];
+                    double2 p;
+                    p.x = v[m].x * x0;
+                    p.y = v[m].y * x1;
+                    *reinterpret_cast<double2 *>(prod + (j - ts)) = p;
+                }
+            }
+            __syncthreads();
+            // ---- phase 2: lane i adds row i's products left to right
+            const int32_t kend = min(ke, te);
+            for (; k < kend; ++k) z = z + prod[k - ts];
+            __syncthreads();
+        }
+        if (row < n) {
+            const double yi = ADD ? y[row] + z : 0.0 + z;
+            y[row] = yi;
+            if (DOT_W) dwy += w[row] * yi;
+            if (DOT_YY) dyy += yi * yi;
+        }
+    }
+    if (DOT_W) {
+        const double t = block_sum<kBlock>(dwy, red);
+        if (tid == 0) part_wy[blockIdx.x] = t;
+    }
+    if (DOT_YY) {
+        const double t = block_sum<kBlock>(dyy, red);
+        if (tid == 0) part_yy[blockIdx.x] = t;
+    }
+}
+
+// ELLPACK, slot-major device layout: lane i owns row i and walks ALL max_d slots in
+// order (padding slots multiply 0.0 by x(last neighbour), exactly like the reference,
+// so a non-finite x entry propagates the same way).
+template <bool ADD, bool DOT_W, bool DOT_YY>
+__global__ __launch_bounds__(kBlock) void k_ell_spmv(
+    int32_t n, int32_t max_d, const int32_t *__restrict__ ecol, const double *__restrict__ eval,
+    const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ w,
+    double *__restrict__ part_wy, double *__restrict__ part_yy, const int *__restrict__ flag_done)
+{
+    __shared__ double red[kBlock / 64];
+    if (flag_done && *flag_done) return;
+    double dwy = 0.0, dyy = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        double z = 0.0;
+        int32_t k = 0;
+        constexpr int U = 8;
+        for (; k + U <= max_d; k += U) {
+            int32_t c[U];
+            double v[U], xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                c[u] = ecol[(int64_t)(k + u) * n + i];
+                v[u] = eval[(int64_t)(k + u) * n + i];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv[u] = x[c[u]];
+#pragma unroll
+            for (int u = 0; u < U; ++u) z = z + v[u] * xv[u];
+        }
+        for (; k < max_d; ++k) z = z + eval[(int64_t)k * n + i] * x[ecol[(int64_t)k * n + i]];
+        const double yi = ADD ? y[i] + z : 0.0 + z;
+        y[i] = yi;
+        if (DOT_W) dwy += w[i] * yi;
+        if (DOT_YY) dyy += yi * yi;
+    }
+    if (DOT_W) {
+        const double t = block_sum<kBlock>(dwy, red);
+        if (threadIdx.x == 0) part_wy[blockIdx.x] = t;
+    }
+    if (DOT_YY) {
+        const double t = block_sum<kBlock>(dyy, red);
+        if (threadIdx.x == 0) part_yy[blockIdx.x] = t;
+    }
+}
+
+__global__ void k_gather(double *__restrict__ dst, const double *__restrict__ src,
+                         const int32_t *__restrict__ idx, int32_t count)
+{
+    int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count) dst[t] = src[idx[t]];
+}
+
+// ---------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------
+int spmv_grid(const Part &p)
+{
+    int64_t nrb = ((int64_t)p.n + kBlock - 1) / kBlock;
+    int64_t g = ((nrb + 7) / 8) * 8;
+    if (g > kMaxGrid) g = kMaxGrid;
+    if (g < 8) g = 8;
+    return (int)g;
+}
+
+template <bool ADD>
+static void launch_csr(const Part &p, int grid, const double *x, double *y, const double *w,
+                       double *pwy, double *pyy, const int *flag)
+{
+    hipStream_t st = g_rt.stream;
+#define L(DW, DY)                                                                         \
+    hipLaunchKernelGGL((k_csr_spmv<ADD, DW, DY>), dim3(grid), dim3(kBlock), 0, st, p.n,   \
+                       p.rowptr, p.col, p.val, x, y, w, pwy, pyy, flag)
+    if (w && pyy) L(true, true);
+    else if (w) L(true, false);
+    else if (pyy) L(false, true);
+    else L(false, false);
+#undef L
+}
+
+template <bool ADD>
+static void launch_ell(const Part &p, int grid, const double *x, double *y, const double *w,
+                       double *pwy, double *pyy, const int *flag)
+{
+    hipStream_t st = g_rt.stream;
+#define L(DW, DY)                                                                         \
+    hipLaunchKernelGGL((k_ell_spmv<ADD, DW, DY>), dim3(grid), dim3(kBlock), 0, st, p.n,   \
+                       p.max_d, p.ecol, p.eval, x, y, w, pwy, pyy, flag)
+    if (w && pyy) L(true, true);
+    else if (w) L(true, false);
+    else if (pyy) L(false, true);
+    else L(false, false);
+#undef L
+}
+
+int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
+               const SpmvDots *dots, const int *flag_done, int *grid_out)
+{
+    if (A->distributed()) SGM_TRY(halo_exchange(A, const_cast<double *const *>(x)));
+    for (size_t ip = 0; ip < A->parts.size(); ++ip) {
+        const Part &p = A->parts[ip];
+        const int grid = spmv_grid(p);
+        if (grid_out) *grid_out = grid;
+        const double *w = dots && dots->w ? dots->w[ip] : nullptr;
+        double *pwy = dots && dots->part_wy ? dots->part_wy[ip] : nullptr;
+        double *pyy = dots && dots->part_yy ? dots->part_yy[ip] : nullptr;
+        if (A->fmt == SGM_FMT_CSR) {
+            if (add) launch_csr<true>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done);
+            else launch_csr<false>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done);
+        } else {
+            if (add) launch_ell<true>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done);
+            else launch_ell<false>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done);
+        }
+    }
+    SGM_HIP(hipGetLastError());
+    return SGM_OK;
+}
+
+// Upload one CSR row block.  ptr1 is 1-based local (n+1), node1 is 1-based and already
+// renumbered to [owned | halo]; `where` says where the three arrays live.
+int build_csr_part(Part &p, int32_t n, int32_t ncol_own, int32_t n_halo, int64_t nnz,
+                   const int32_t *ptr1, const int32_t *node1, const double *val, int where)
+{
+    p.n = n;
+    p.ncol_own = ncol_own;
+    p.n_halo = n_halo;
+    p.nnz = nnz;
+    SGM_TRY(dalloc(&p.rowptr, (size_t)n + 1));
+    SGM_TRY(dalloc(&p.col, (size_t)nnz + 2));
+    SGM_TRY(dalloc(&p.val, (size_t)nnz + 2));
+    hipStream_t st = g_rt.stream;
+    const hipMemcpyKind kind = where == SGM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    SGM_HIP(hipMemsetAsync(p.col + nnz, 0, 2 * sizeof(int32_t), st));
+    SGM_HIP(hipMemsetAsync(p.val + nnz, 0, 2 * sizeof(double), st));
+    SGM_HIP(hipMemcpyAsync(p.rowptr, ptr1, ((size_t)n + 1) * sizeof(int32_t), kind, st));
+    if (nnz) {
+        SGM_HIP(hipMemcpyAsync(p.col, node1, (size_t)nnz * sizeof(int32_t), kind, st));
+        SGM_HIP(hipMemcpyAsync(p.val, val, (size_t)nnz * sizeof(double), kind, st));
+    }
+    hipLaunchKernelGGL(k_dec1, dim3(vec_grid(n + 1)), dim3(kBlock), 0, st, p.rowptr, (int64_t)n + 1);
+    if (nnz) hipLaunchKernelGGL(k_dec1, dim3(vec_grid(nnz)), dim3(kBlock), 0, st, p.col, nnz);
+    SGM_HIP(hipGetLastError());
+    SGM_HIP(hipStreamSynchronize(st));   // host staging buffers may go away after return
+    return SGM_OK;
+}
+
+void free_part(Part &p)
+{
+    dfree(p.rowptr); dfree(p.col); dfree(p.val); dfree(p.ecol); dfree(p.eval); dfree(p.xext);
+    for (auto &nb : p.nbrs) { dfree(nb.send_idx); dfree(nb.send_buf); }
+    p = Part();
+}
+
+// Stage a caller vector on the device if it lives on the host (or is not 16-B aligned).
+struct Staged {
+    double *dev = nullptr;
+    bool owned = false;
+    ~Staged() { if (owned) dfree(dev); }
+};
+int stage_in(Staged &s, const double *v, int64_t n, int where, bool copy)
+{
+    if (where == SGM_DEVICE && (reinterpret_cast<uintptr_t>(v) & 15) == 0) {
+        s.dev = const_cast<double *>(v);
+        return SGM_OK;
+    }
+    SGM_TRY(dalloc(&s.dev, (size_t)n));
+    s.owned = true;
+    if (copy)
+        SGM_HIP(hipMemcpyAsync(s.dev, v, (size_t)n * 8,
+                               where == SGM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                               g_rt.stream));
+    return SGM_OK;
+}
+int stage_out(const Staged &s, double *v, int64_t n, int where)
+{
+    if (!s.owned) return SGM_OK;
+    SGM_HIP(hipMemcpyAsync(v, s.dev, (size_t)n * 8,
+                           where == SGM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
+                           g_rt.stream));
+    SGM_HIP(hipStreamSynchronize(g_rt.stream));
+    return SGM_OK;
+}
+
+static int matvec_impl(sgm_mat A, const double *x, double *y, int where, bool add)
+{
+    SGM_TRY(require_init());
+    if (!A || !x || !y) return fail(SGM_ERR_BAD_ARG, "matvec: null argument");
+    const size_t P = A->parts.size();
+    if (P == 1) {
+        Part &p = A->parts[0];
+        Staged sx, sy;
+        SGM_TRY(stage_in(sx, x, p.xlen(), where, true));
+        SGM_TRY(stage_in(sy, y, p.n, where, add));
+        const double *xs[1] = {sx.dev};
+        double *ys[1] = {sy.dev};
+        SGM_TRY(spmv_parts(A, xs, ys, add, nullptr, nullptr, nullptr));
+        SGM_TRY(stage_out(sy, y, p.n, where));
+        return finish();
+    }
+    // in-process row partition: x and y are plain global-length vectors
+    Staged sx, sy;
+    SGM_TRY(stage_in(sx, x, A->ncol, where, true));
+    SGM_TRY(stage_in(sy, y, A->nrow, where, add));
+    std::vector<const double *> xs(P);
+    std::vector<double *> ys(P);
+    for (size_t ip = 0; ip < P; ++ip) {
+        Part &p = A->parts[ip];
+        SGM_HIP(hipMemcpyAsync(p.xext, sx.dev + p.row_begin, (size_t)p.ncol_own * 8,
+                               hipMemcpyDeviceToDevice, g_rt.stream));
+        xs[ip] = p.xext;
+        ys[ip] = sy.dev + p.row_begin;
+    }
+    SGM_TRY(spmv_parts(A, xs.data(), ys.data(), add, nullptr, nullptr, nullptr));
+    SGM_TRY(stage_out(sy, y, A->nrow, where));
+    return finish();
+}
+
+}  // namespace sgm
+
+using namespace sgm;
+
+extern "C" {
+
+int sgm_csr_create(sgm_mat *out, int32_t nrow, int32_t ncol, int64_t nnz, const int32_t *ptr,
+                   const int32_t *node, const double *val, int where)
+{
+    SGM_TRY(require_init());
+    if (!out || nrow < 0 || ncol < 0 || nnz < 0 || !ptr || (nnz && (!node || !val)))
+        return fail(SGM_ERR_BAD_ARG, "sgm_csr_create: bad argument");
+    if (nnz > INT32_MAX - 4) return fail(SGM_ERR_UNSUPPORTED, "sgm_csr_create: nnz exceeds int32 ptr");
+    sgm_mat A = new sgm_mat_s;
+    A->fmt = SGM_FMT_CSR;
+    A->nrow = nrow;
+    A->ncol = ncol;
+    A->nnz = nnz;
+    A->parts.resize(1);
+    int rc = build_csr_part(A->parts[0], nrow, ncol, 0, nnz, ptr, node, val, where);
+    if (rc != SGM_OK) { sgm_mat_destroy(A); return rc; }
+    *out = A;
+    return SGM_OK;
+}
+
+int sgm_csr_set_values(sgm_mat A, const double *val, int where)
+{
+    SGM_TRY(require_init());
+    if (!A || A->fmt != SGM_FMT_CSR || !val) return fail(SGM_ERR_BAD_ARG, "sgm_csr_set_values: bad argument");
+    int64_t off = 0;
+    for (auto &p : A->parts) {
+        SGM_HIP(hipMemcpyAsync(p.val, val + off, (size_t)p.nnz * 8,
+                               where == SGM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                               g_rt.stream));
+        off += p.nnz;
+    }
+    SGM_HIP(hipStreamSynchronize(g_rt.stream));
+    return SGM_OK;
+}
+
+int sgm_ell_create(sgm_mat *out, int32_t nrow, int32_t ncol, int32_t max_d, const int32_t *node,
+                   const double *val, int where)
+{
+    SGM_TRY(require_init());
+    if (!out || nrow < 0 || ncol < 0 || max_d < 0 || (nrow && max_d && (!node || !val)))
+        return fail(SGM_ERR_BAD_ARG, "sgm_ell_create: bad argument");
+    sgm_mat A = new sgm_mat_s;
+    A->fmt = SGM_FMT_ELL;
+    A->nrow = nrow;
+    A->ncol = ncol;
+    A->nnz = (int64_t)nrow * max_d;
+    A->parts.resize(1);
+    Part &p = A->parts[0];
+    p.n = nrow;
+    p.ncol_own = ncol;
+    p.max_d = max_d;
+    const size_t total = (size_t)nrow * max_d;
+    int rc = dalloc(&p.ecol, total);
+    if (rc == SGM_OK) rc = dalloc(&p.eval, total);
+    if (rc != SGM_OK) { sgm_mat_destroy(A); return rc; }
+    *out = A;
+    if (total == 0) return SGM_OK;
+    int32_t *tn = nullptr;
+    if (where == SGM_HOST) {
+        SGM_TRY(dalloc(&tn, total));
+        SGM_HIP(hipMemcpyAsync(tn, node, total * 4, hipMemcpyHostToDevice, g_rt.stream));
+        hipLaunchKernelGGL(k_ell_transpose, dim3(vec_grid(total)), dim3(kBlock), 0, g_rt.stream, tn,
+                           (const double *)nullptr, p.ecol, p.eval, nrow, max_d);
+        SGM_HIP(hipStreamSynchronize(g_rt.stream));
+        dfree(tn);
+    } else {
+        hipLaunchKernelGGL(k_ell_transpose, dim3(vec_grid(total)), dim3(kBlock), 0, g_rt.stream, node,
+                           (const double *)nullptr, p.ecol, p.eval, nrow, max_d);
+    }
+    return sgm_ell_set_values(A, val, where);
+}
+
+int sgm_ell_set_values(sgm_mat A, const double *val, int where)
+{
+    SGM_TRY(require_init());
+    if (!A || A->fmt != SGM_FMT_ELL || !val) return fail(SGM_ERR_BAD_ARG, "sgm_ell_set_values: bad argument");
+    Part &p = A->parts[0];
+    const size_t total = (size_t)p.n * p.max_d;
+    if (!total) return SGM_OK;
+    double *tv = nullptr;
+    const double *src = val;
+    if (where == SGM_HOST) {
+        SGM_TRY(dalloc(&tv, total));
+        SGM_HIP(hipMemcpyAsync(tv, val, total * 8, hipMemcpyHostToDevice, g_rt.stream));
+        src = tv;
+    }
+    hipLaunchKernelGGL(k_ell_transpose, dim3(vec_grid(total)), dim3(kBlock), 0, g_rt.stream,
+                       (const int32_t *)nullptr, src, p.ecol, p.eval, p.n, p.max_d);
+    SGM_HIP(hipGetLastError());
+    SGM_HIP(hipStreamSynchronize(g_rt.stream));
+    dfree(tv);
+    return SGM_OK;
+}
+
+int sgm_mat_matvec(sgm_mat A, const double *x, double *y, int where)
+{
+    return matvec_impl(A, x, y, where, false);
+}
+
+int sgm_mat_matvec_add(sgm_mat A, const double *x, double *y, int where)
+{
+    return matvec_impl(A, x, y, where, true);
+}
+
+int sgm_mat_info(sgm_mat A, int32_t *nrow, int32_t *ncol, int64_t *nnz, int32_t *fmt, int64_t *x_len)
+{
+    if (!A) return fail(SGM_ERR_BAD_ARG, "sgm_mat_info: null matrix");
+    if (nrow) *nrow = A->nrow;
+    if (ncol) *ncol = A->ncol;
+    if (nnz) *nnz = A->nnz;
+    if (fmt) *fmt = A->fmt;
+    if (x_len) *x_len = A->comm ? A->parts[0].xlen() : A->ncol;
+    return SGM_OK;
+}
+
+int sgm_mat_destroy(sgm_mat A)
+{
+    if (!A) return SGM_OK;
+    for (auto &p : A->parts) free_part(p);
+    delete A;
+    return SGM_OK;
+}
+
+}  // extern "C"

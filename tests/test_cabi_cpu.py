@@ -1,0 +1,94 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/sigma_hip.h declares, fails loudly without a GPU, and its host-only index work
+(halo planning) is bit-exact against a numpy restatement."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import sigma_amd as sg
+from sigma_amd import problems as P
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "sigma_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sgm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    sg.build()
+    L = sg.lib()
+    names = declared_symbols()
+    assert len(names) >= 40
+    for nm in names:
+        assert hasattr(L, nm), f"{nm} declared in include/sigma_hip.h but not exported"
+
+
+def test_no_torch_types_in_the_abi():
+    txt = open(os.path.join(ROOT, "include", "sigma_hip.h")).read()
+    assert "torch" not in re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    assert 'extern "C"' in txt
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_has_gpu(), reason="GPU present: the loud-failure path cannot be seen")
+def test_product_fails_loudly_without_gpu():
+    ptr, node, val = P.poisson2d_csr(4, 4)
+    with pytest.raises(sg.SigmaError) as e:
+        sg.csr_matrix(16, 16, ptr, node, val)
+    assert e.value.code == 6 and "no CPU path" in str(e.value)
+
+
+def test_product_never_imports_the_oracle():
+    import sys
+    for fn in os.listdir(os.path.join(ROOT, "sigma_amd")):
+        if fn.endswith(".py"):
+            src = open(os.path.join(ROOT, "sigma_amd", fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src and "liborc" not in src
+    for fn in os.listdir(os.path.join(ROOT, "sigma_amd", "csrc")):
+        if not fn.endswith((".hip", ".hpp", ".cpp", ".h", "Makefile")):
+            continue
+        src = open(os.path.join(ROOT, "sigma_amd", "csrc", fn)).read()
+        assert "oracle/" not in src.replace("links oracle/", "") and "liborc" not in src
+
+
+def numpy_halo_plan(n_own, col_begin, node):
+    node = node.astype(np.int64)
+    own = (node > col_begin) & (node <= col_begin + n_own)
+    halo = np.unique(node[~own])
+    local = np.where(own, node - col_begin, n_own + 1 + np.searchsorted(halo, node))
+    return local.astype(np.int32), halo.astype(np.int32)
+
+
+@pytest.mark.parametrize("nparts", [2, 3, 4, 8])
+def test_halo_plan_bit_exact(nparts):
+    for (ptr, node, val), n in ((P.poisson2d_csr(37, 29), 37 * 29), (P.laplace3d_csr(9, 8, 11), 9 * 8 * 11)):
+        starts = (np.arange(nparts + 1) * n // nparts) // 2 * 2
+        starts[-1] = n
+        for p in range(nparts):
+            r0, r1 = starts[p], starts[p + 1]
+            seg = node[ptr[r0] - 1: ptr[r1] - 1]
+            loc, halo = sg.halo_plan_host(r1 - r0, r0, seg)
+            loc_np, halo_np = numpy_halo_plan(r1 - r0, r0, seg)
+            assert np.array_equal(loc, loc_np)
+            assert np.array_equal(halo, halo_np)
+    # random columns, including none outside the owned range
+    rs = np.random.RandomState(0)
+    node = rs.randint(1, 1001, size=5000).astype(np.int32)
+    loc, halo = sg.halo_plan_host(1000, 0, node)
+    assert len(halo) == 0 and np.array_equal(loc, node)
+    loc, halo = sg.halo_plan_host(100, 450, node)
+    loc_np, halo_np = numpy_halo_plan(100, 450, node)
+    assert np.array_equal(loc, loc_np) and np.array_equal(halo, halo_np)

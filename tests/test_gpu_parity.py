@@ -1,0 +1,470 @@
+"""Parity tests proper (run with -m gpu on an MI355X): the HIP path, called through the
+C ABI, against (1) the committed golden fixtures produced by the real reference and
+(2) the CPU oracle on the same seeded inputs.
+
+Bars: index work / stored values / matvec / preconditioner factors and applies are
+BIT-EXACT; Krylov solutions within 1e-12 relative of the reference's with the same
+iteration count (+-1; dot products are summed in a different order than the compiler's
+dot_product, which is the only source of difference)."""
+import numpy as np
+import pytest
+
+from conftest import golden_names
+import sigma_amd as sg
+from sigma_amd import problems as P
+
+pytestmark = pytest.mark.gpu
+
+CG, BICGSTAB = 1, 2
+
+
+@pytest.fixture(scope="module")
+def orc():
+    import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    sg.init(0)
+
+
+def hip_matrix(g):
+    n, m = int(g["n"]), int(g["m"])
+    if int(g["fmt"]) == 1:
+        return sg.csr_matrix(n, m, g["ref_ptr"], g["ref_node"], g["ref_val"])
+    md = int(g["ref_max_d"][0])
+    return sg.ellpack_matrix(n, m, g["ref_node"].reshape(n, md), g["ref_val"].reshape(n, md))
+
+
+def hip_from_oracle(A):
+    if A.fmt == 1:
+        return sg.csr_matrix(A.n, A.m, A.ptr, A.node, A.val)
+    return sg.ellpack_matrix(A.n, A.m, A.node, A.val)
+
+
+# ------------------------------------------------------------------------------ matvec
+@pytest.mark.parametrize("name", golden_names())
+def test_matvec_golden_bit_exact(golden, name):
+    g = golden(name)
+    A = hip_matrix(g)
+    y = np.full(int(g["n"]), -7.0)           # garbage: matvec must overwrite
+    A.matvec(g["x"], y)
+    assert np.array_equal(y, g["ref_y"])
+    A.matvec_add(g["x"], y)
+    assert np.array_equal(y, g["ref_y_add"])
+
+
+@pytest.mark.parametrize("name", ["poisson2d_32x24", "random_ell32_padded_512"])
+def test_matvec_device_tensors(golden, name):
+    import torch
+    g = golden(name)
+    A = hip_matrix(g)
+    x = torch.from_numpy(g["x"]).cuda()
+    y = torch.full((int(g["n"]),), -7.0, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    A.matvec(x, y)
+    assert np.array_equal(y.cpu().numpy(), g["ref_y"])
+    # unaligned device views are staged, not mis-read
+    xx = torch.zeros(int(g["m"]) + 1, dtype=torch.float64, device="cuda")
+    xx[1:] = x
+    torch.cuda.synchronize()
+    A.matvec(xx[1:], y)
+    assert np.array_equal(y.cpu().numpy(), g["ref_y"])
+
+
+def _cases(orc):
+    rs = np.random.RandomState(11)
+    out = []
+    out.append(("poisson2d_257x129", orc.CsrMatrix(257 * 129, 257 * 129, *P.poisson2d_csr(257, 129))))
+    out.append(("laplace3d_33x31x29", orc.CsrMatrix(33 * 31 * 29, 33 * 31 * 29, *P.laplace3d_csr(33, 31, 29))))
+    out.append(("tridiag_100001", orc.CsrMatrix(100001, 100001, *P.tridiag_csr(100001, 2.0, -0.75, -1.25))))
+    n = 20000
+    e = P.random_regular_ell(n, 32, 99)
+    out.append(("random_csr32", orc.CsrMatrix.from_edges(n, n, *e)))
+    out.append(("random_ell32", orc.EllMatrix.from_edges(n, n, *e)))
+    e = P.random_regular_ell(n, 32, 5, dmin=20)
+    out.append(("random_ell_padded", orc.EllMatrix.from_edges(n, n, *e)))
+    # ragged: empty rows, rows longer than one 2048-entry LDS tile, rows straddling tiles
+    n, m = 3000, 4000
+    deg = rs.randint(0, 12, size=n)
+    deg[rs.randint(0, n, 40)] = 0
+    deg[[7, 1500, 2999]] = [5000, 2049, 3333]
+    deg[[0, 1, 2]] = [0, 0, 1]
+    ptr = np.concatenate([[1], 1 + np.cumsum(deg)]).astype(np.int32)
+    node = rs.randint(1, m + 1, size=int(deg.sum())).astype(np.int32)
+    val = rs.standard_normal(int(deg.sum()))
+    out.append(("ragged_rect", orc.CsrMatrix(n, m, ptr, node, val)))
+    # a single row / a single entry / an all-empty matrix
+    out.append(("one_entry", orc.CsrMatrix(1, 1, np.array([1, 2], np.int32), np.array([1], np.int32), np.array([3.5]))))
+    out.append(("all_empty", orc.CsrMatrix(5, 5, np.ones(6, np.int32), np.zeros(0, np.int32), np.zeros(0))))
+    return out
+
+
+def test_matvec_vs_oracle_bit_exact(orc):
+    rs = np.random.RandomState(3)
+    for name, A in _cases(orc):
+        H = hip_from_oracle(A)
+        for x in (P.test_vector(A.m), rs.standard_normal(A.m) * 1e3):
+            y_ref = A.matvec(x)
+            y = np.full(A.n, np.nan)
+            H.matvec(x, y)
+            assert np.array_equal(y, y_ref), name
+            y0 = rs.standard_normal(A.n)
+            y_ref = A.matvec_add(x, y0.copy())
+            y = y0.copy()
+            H.matvec_add(x, y)
+            assert np.array_equal(y, y_ref), name
+        H.destroy()
+
+
+def test_matvec_signed_zero_and_nonfinite(orc):
+    """0 + z keeps the reference's +0.0 for an all-cancelling / empty row; 0*Inf in an
+    ELLPACK padding slot is NaN in the reference too."""
+    A = orc.CsrMatrix(2, 2, np.array([1, 3, 3], np.int32), np.array([1, 2], np.int32), np.array([-1.0, 0.0]))
+    x = np.array([0.0, 5.0])
+    H = hip_from_oracle(A)
+    y = np.full(2, 1.0)
+    H.matvec(x, y)
+    yr = A.matvec(x)
+    assert np.array_equal(np.signbit(y), np.signbit(yr)) and np.array_equal(y, yr)
+    e = P.random_regular_ell(200, 8, 1, dmin=3)
+    E = orc.EllMatrix.from_edges(200, 200, *e)
+    x = P.test_vector(200)
+    x[17] = np.inf
+    HE = hip_from_oracle(E)
+    y = np.zeros(200)
+    HE.matvec(x, y)
+    yr = E.matvec(x)
+    assert np.array_equal(np.isnan(y), np.isnan(yr))
+    ok = ~np.isnan(yr)
+    assert np.array_equal(y[ok], yr[ok])
+
+
+def test_set_values_reupload(orc):
+    ptr, node, val = P.poisson2d_csr(40, 30)
+    H = sg.csr_matrix(1200, 1200, ptr, node, val)
+    val2 = val * np.linspace(1, 2, len(val))
+    H.set_values(val2)
+    x = P.test_vector(1200)
+    y = np.zeros(1200)
+    H.matvec(x, y)
+    assert np.array_equal(y, orc.CsrMatrix(1200, 1200, ptr, node, val2).matvec(x))
+
+
+# ---------------------------------------------------------------------- vector statements
+def test_dot_axpy(orc):
+    rs = np.random.RandomState(5)
+    for n in (1, 2, 3, 255, 256, 257, 4097, 1000003):
+        a, b = rs.standard_normal(n), rs.standard_normal(n)
+        d = sg.dot(a, b)
+        ref = float(np.dot(a, b))
+        assert abs(d - ref) <= 1e-12 * max(1.0, np.abs(a * b).sum())
+        y = b.copy()
+        sg.axpy(0.37, a, y)
+        assert np.array_equal(y, b + 0.37 * a)       # one rounding per op, no FMA
+
+
+# --------------------------------------------------------------------- preconditioners
+@pytest.mark.parametrize("name", golden_names())
+def test_preconditioners_golden_bit_exact(golden, name):
+    g = golden(name)
+    if not len(g["solves"]):
+        pytest.skip("no solves in this fixture")
+    A = hip_matrix(g)
+    n = int(g["n"])
+    for s, (skind, pkind, tol) in enumerate(g["solves"], 1):
+        if int(pkind) == 1:
+            pc = sg.jacobi()
+            pc.setup(A)
+            assert np.array_equal(pc.idiag, g[f"ref_s{s}_idiag"])
+            z = np.zeros(n)
+            pc.solve(A, z, g["b"])
+            assert np.array_equal(z, g[f"ref_s{s}_pcz"])
+        elif int(pkind) == 2:
+            pc = sg.ldu(incomplete=True, level=0)
+            pc.setup(A)
+            for nm, dt in (("Lptr", np.int32), ("Lnode", np.int32), ("Uptr", np.int32), ("Unode", np.int32),
+                           ("Lval", np.float64), ("Uval", np.float64), ("D", np.float64)):
+                assert np.array_equal(pc.get(nm, dt), g[f"ref_s{s}_{nm}"]), nm
+            z = np.zeros(n)
+            pc.solve(A, z, g["b"])
+            assert np.array_equal(z, g[f"ref_s{s}_pcz"])
+
+
+def test_ildu_apply_many_levels_vs_oracle(orc):
+    """5-point grid 300x200: 499 dependency levels, wide and narrow level runs."""
+    ptr, node, val = P.poisson2d_csr(300, 200)
+    n = 60000
+    A = orc.CsrMatrix(n, n, ptr, node, val)
+    ref = orc.Ildu(A)
+    H = hip_from_oracle(A)
+    pc = sg.ldu()
+    pc.setup(H)
+    assert np.array_equal(pc.get("Lval", np.float64), ref.Lval)
+    assert np.array_equal(pc.get("D", np.float64), ref.D)
+    lv = pc.get("levels", np.int32)
+    assert lv[0] == 499 and lv[1] == 499
+    b = P.test_vector(n)
+    z = np.zeros(n)
+    pc.solve(H, z, b)
+    assert np.array_equal(z, ref.solve(b))
+    # a level wider than the narrow-run threshold: 3000 x 3 grid, levels up to 3 rows only;
+    # use a block-diagonal trick instead: many independent tridiagonals = few, WIDE levels
+    nb, bl = 5000, 4
+    ei, ej, ev = [], [], []
+    for t in range(nb):
+        e = P.tridiag_edges(bl, 2.0, -1.0, -1.0)
+        ei.append(e[0] + t * bl); ej.append(e[1] + t * bl); ev.append(e[2] * (1 + t % 3))
+    A = orc.CsrMatrix.from_edges(nb * bl, nb * bl, np.concatenate(ei), np.concatenate(ej), np.concatenate(ev))
+    ref = orc.Ildu(A)
+    H = hip_from_oracle(A)
+    pc = sg.ldu()
+    pc.setup(H)
+    assert pc.get("levels", np.int32)[0] == bl
+    b = P.test_vector(nb * bl)
+    z = np.zeros(nb * bl)
+    pc.solve(H, z, b)
+    assert np.array_equal(z, ref.solve(b))
+
+
+# --------------------------------------------------------------------------------- solvers
+def _solve(A, g, skind, pkind, tol, hist=0):
+    pc = {0: lambda: None, 1: sg.jacobi, 2: sg.ldu}[int(pkind)]()
+    if pc is not None:
+        pc.setup(A)
+    solver = sg.cg(tol) if int(skind) == CG else sg.bicgstab(tol)
+    if hist:
+        solver.set_history(hist)
+    solver.setup(A)
+    u = np.zeros(int(g["n"]))
+    solver.solve(A, u, g["b"], pc)
+    return u, solver
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_solvers_golden(golden, name):
+    g = golden(name)
+    if not len(g["solves"]):
+        pytest.skip("no solves in this fixture")
+    A = hip_matrix(g)
+    for s, (skind, pkind, tol) in enumerate(g["solves"], 1):
+        u, solver = _solve(A, g, skind, pkind, tol)
+        uref = g[f"ref_s{s}_u"]
+        itref = int(g[f"ref_s{s}_iterations"][0])
+        rel = np.abs(u - uref).max() / np.abs(uref).max()
+        long_bicg = int(skind) == BICGSTAB and itref > 500
+        assert rel <= (1e-9 if long_bicg else 1e-12), (name, s, rel)
+        assert abs(solver.iterations - itref) <= (0.05 * itref if long_bicg else 1), (name, s, solver.iterations, itref)
+        assert solver.converged
+        assert np.sqrt(solver.res2) <= tol
+
+
+def test_reference_known_answers(golden):
+    # test/solver_test_diffusion_1d.f90:104-115: ELLPACK n=127, cg(1e-16): 64 iterations, err <= 1e-14
+    g = golden("diffusion1d_ell_127")
+    u, solver = _solve(hip_matrix(g), g, CG, 0, 1e-16)
+    assert solver.iterations == 64
+    assert np.abs(u - g["analytic"]).max() <= 1e-14
+    # test/solver_test_advection_diffusion_1d.f90:111-122: bicgstab(1e-12), err <= 1e-8
+    g = golden("advdiff1d_ell_1024")
+    u, solver = _solve(hip_matrix(g), g, BICGSTAB, 0, 1e-12)
+    assert np.abs(u - g["analytic"]).max() <= 1e-8
+
+
+def test_solver_semantics(golden, orc):
+    g = golden("poisson2d_32x24")
+    A = hip_matrix(g)
+    n = int(g["n"])
+    solver = sg.cg(1e-12)
+    solver.setup(A)
+    u = np.zeros(n)
+    solver.solve(A, u, g["b"])
+    it1 = solver.iterations
+    # iterations accumulate across solves (cg_solvers.f90:72,145); initial guess is used
+    u2 = u.copy()
+    solver.solve(A, u2, g["b"])
+    assert solver.iterations == it1 and solver.last_iterations == 0 and np.array_equal(u, u2)
+    u3 = np.zeros(n)
+    solver.solve(A, u3, g["b"])
+    assert solver.iterations == 2 * it1
+    solver.setup(A)                      # setup zeroes the counter
+    assert solver.iterations == 0
+    # max_iter is an extension: hitting it reports NOT_CONVERGED
+    solver.set_max_iter(5)
+    with pytest.raises(sg.SigmaError) as e:
+        solver.solve(A, np.zeros(n), g["b"])
+    assert e.value.code == 5 and solver.last_iterations == 5
+    # non-square matrices are refused like cg_setup does (cg_solvers.f90:61-65)
+    R = sg.csr_matrix(2, 3, np.array([1, 2, 3], np.int32), np.array([1, 3], np.int32), np.array([1.0, 2.0]))
+    with pytest.raises(sg.SigmaError) as e:
+        sg.cg().setup(R)
+    assert e.value.code == 2 and "non-square" in str(e.value)
+    # A%solve facade (linear_operator_interface.f90:213-280)
+    A.set_solver(sg.cg(1e-12))
+    A.set_preconditioner(sg.jacobi())
+    u4 = np.zeros(n)
+    A.solve(u4, g["b"])
+    assert np.abs(u4 - g["ref_s2_u"]).max() / np.abs(g["ref_s2_u"]).max() <= 1e-12
+
+
+def test_residual_history_vs_oracle(orc):
+    """res2 after every iteration, first 50 iterations, relative difference <= 1e-12
+    (C2-mini and C5-mini; SURVEY §8d parity gates)."""
+    for (ptr, node, val), n in ((P.poisson2d_csr(96, 80), 96 * 80), (P.laplace3d_csr(20, 18, 16), 20 * 18 * 16)):
+        A = orc.CsrMatrix(n, n, ptr, node, val)
+        b = np.full(n, 1.0 / n)
+        for fn, mk in ((orc.cg, sg.cg), (orc.bicgstab, sg.bicgstab)):
+            xr, itr, _, hr = fn(A, b, tol=1e-30, max_iter=50, history=50)
+            H = hip_from_oracle(A)
+            s = mk(1e-30)
+            s.set_max_iter(50)
+            s.set_history(50)
+            s.setup(H)
+            x = np.zeros(n)
+            s.solve(H, x, b, check=False)
+            h = s.history
+            assert len(h) == 50 == len(hr)
+            assert np.abs(h - hr).max() / 1.0 <= 1e-12 * np.abs(hr).max()
+            assert (np.abs(h - hr) / hr).max() <= (1e-12 if fn is orc.cg else 1e-9)
+            assert np.abs(x - xr).max() / np.abs(xr).max() <= 1e-12
+
+
+def test_gmres(golden, orc):
+    """GMRES(30) has no reference counterpart: checked against the oracle's textbook GMRES,
+    the analytic solution and the reference's BiCGStab solution."""
+    g = golden("advdiff1d_csr_1024")
+    A = hip_matrix(g)
+    Ao = orc.CsrMatrix(1024, 1024, g["ref_ptr"], g["ref_node"], g["ref_val"])
+    s = sg.gmres(1e-12, 30)
+    s.setup(A)
+    u = np.zeros(1024)
+    s.solve(A, u, g["b"])
+    uo, ito, _, _ = orc.gmres(Ao, g["b"], tol=1e-12, restart=30)
+    assert abs(s.iterations - ito) <= max(2, 0.02 * ito)
+    assert np.abs(u - g["analytic"]).max() <= 1e-8
+    assert np.abs(u - g["ref_s1_u"]).max() / np.abs(g["ref_s1_u"]).max() <= 1e-7
+    # a fixed number of steps reproduces the oracle's iterate closely (same MGS order)
+    s2 = sg.gmres(1e-30, 30)
+    s2.set_max_iter(75)
+    s2.set_history(75)
+    s2.setup(A)
+    u = np.zeros(1024)
+    s2.solve(A, u, g["b"], check=False)
+    uo, ito, _, ho = orc.gmres(Ao, g["b"], tol=1e-30, restart=30, max_iter=75, history=75)
+    assert s2.last_iterations == 75 == ito
+    assert np.abs(u - uo).max() / np.abs(uo).max() <= 1e-10
+    assert (np.abs(s2.history - ho) / ho).max() <= 1e-9
+    # preconditioned, on the skew-perturbed random matrix
+    g = golden("random_skew_128")
+    A = hip_matrix(g)
+    pc = sg.jacobi()
+    pc.setup(A)
+    s = sg.gmres(1e-13, 30)
+    s.setup(A)
+    u = np.zeros(128)
+    s.solve(A, u, g["b"], pc)
+    assert np.abs(u - g["ref_s2_u"]).max() / np.abs(g["ref_s2_u"]).max() <= 1e-11
+
+
+# ------------------------------------------------------------ row partition on one GPU
+@pytest.mark.parametrize("nparts", [2, 3, 8])
+def test_partitioned_matvec_bit_exact_and_cg(orc, nparts):
+    for (ptr, node, val), n in ((P.poisson2d_csr(64, 50), 3200), (P.laplace3d_csr(12, 10, 14), 1680)):
+        A = orc.CsrMatrix(n, n, ptr, node, val)
+        starts = (np.arange(nparts + 1) * n // nparts) // 2 * 2
+        starts[-1] = n
+        H = sg.partitioned_csr_matrix(n, n, ptr, node, val, starts)
+        x = P.test_vector(n)
+        y = np.zeros(n)
+        H.matvec(x, y)
+        assert np.array_equal(y, A.matvec(x))          # same per-row order: bit-exact
+        b = np.full(n, 1.0 / n)
+        for pc_mk, opc in ((None, None), (sg.jacobi, orc.Jacobi)):
+            ur, itr, _, _ = orc.cg(A, b, tol=1e-13, pc=opc(A) if opc else None)
+            s = sg.cg(1e-13)
+            s.setup(H)
+            pc = pc_mk() if pc_mk else None
+            if pc:
+                pc.setup(H)
+            u = np.zeros(n)
+            s.solve(H, u, b, pc)
+            assert abs(s.iterations - itr) <= 1
+            assert np.abs(u - ur).max() / np.abs(ur).max() <= 1e-12
+        ur, itr, _, _ = orc.bicgstab(A, b, tol=1e-13)
+        s = sg.bicgstab(1e-13)
+        s.setup(H)
+        u = np.zeros(n)
+        s.solve(H, u, b)
+        assert abs(s.iterations - itr) <= 2
+        assert np.abs(u - ur).max() / np.abs(ur).max() <= 1e-11
+
+
+def test_rccl_single_rank(orc):
+    """RCCL binding with a 1-rank communicator: bootstrap, distributed create, matvec, CG."""
+    comm = sg.Comm(0, 1, sg.Comm.unique_id())
+    ptr, node, val = P.poisson2d_csr(48, 40)
+    n = 1920
+    A = orc.CsrMatrix(n, n, ptr, node, val)
+    H = sg.dist_csr_matrix(comm, np.array([0, n]), ptr, node, val)
+    assert H.x_len == n
+    x = P.test_vector(n)
+    y = np.zeros(n)
+    H.matvec(x, y)
+    assert np.array_equal(y, A.matvec(x))
+    b = np.full(n, 1.0 / n)
+    ur, itr, _, _ = orc.cg(A, b, tol=1e-13)
+    s = sg.cg(1e-13)
+    s.setup(H)
+    u = np.zeros(n)
+    s.solve(H, u, b)
+    assert abs(s.iterations - itr) <= 1 and np.abs(u - ur).max() / np.abs(ur).max() <= 1e-12
+    H.destroy()
+    comm.destroy()
+
+
+# ------------------------------------------------------- full benchmark size (BASELINE C2)
+def test_full_size_properties():
+    """5-point Poisson at nx=ny=3162 (n = 9,998,244): properties that do not need the
+    oracle -- exact row sums for x = 1, sampled rows recomputed on the host in the stored
+    order (bit-exact), linearity in exact arithmetic cases, and CG monotonic energy."""
+    import torch
+    nx = ny = 3162
+    n = nx * ny
+    ptr, node, val = P.poisson2d_csr(nx, ny)
+    A = sg.csr_matrix(n, n, ptr, node, val)
+    ones = np.ones(n)
+    y = np.zeros(n)
+    A.matvec(ones, y)
+    expect = 4.0 - np.diff(ptr) + 1.0            # 4 - (#neighbours) ; #neighbours = rowlen - 1
+    assert np.array_equal(y, expect)
+    x = P.test_vector(n)
+    A.matvec(x, y)
+    rs = np.random.RandomState(0)
+    rows = np.unique(np.concatenate([rs.randint(0, n, 20000), [0, 1, nx - 1, nx, n - nx, n - 1]]))
+    for r in rows:
+        z = 0.0
+        for k in range(ptr[r] - 1, ptr[r + 1] - 1):
+            z = z + val[k] * x[node[k] - 1]
+        assert y[r] == 0.0 + z
+    # scaling x by a power of two scales y exactly
+    y2 = np.zeros(n)
+    A.matvec(4.0 * x, y2)
+    assert np.array_equal(y2, 4.0 * y)
+    # device-resident CG for a fixed number of iterations: res2 history is finite and the
+    # A-norm error functional decreases
+    xb = torch.zeros(n, dtype=torch.float64, device="cuda")
+    b = torch.full((n,), 1.0 / n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    s = sg.cg(1e-30)
+    s.set_max_iter(40)
+    s.set_history(40)
+    s.setup(A)
+    s.solve(A, xb, b, check=False)
+    h = s.history
+    assert len(h) == 40 and np.all(np.isfinite(h)) and h[-1] < h[0]
+    Ax = torch.zeros_like(xb)
+    A.matvec(xb, Ax)
+    torch.cuda.synchronize()
+    phi = 0.5 * float(torch.dot(xb, Ax)) - float(torch.dot(b, xb))
+    assert phi < 0.0
