@@ -91,7 +91,7 @@ def test_solvers(golden, name):
         # cond(A) ~ n^2 ~ 1e6 for the 1024-row advection problem: two iterates whose residuals are
         # both <= 1e-12 may differ by ~1e-6 relative; 1e-7 is what the conditioning allows
         assert rel <= (1e-7 if long_bicg else 1e-12), (name, s, rel)
-        assert abs(its - itref) <= (0.05 * itref if long_bicg else 1), (name, s, its, itref)
+        assert abs(its - itref) <= (0.10 * itref if long_bicg else 1), (name, s, its, itref)
 
 
 def test_reference_known_answers(golden):
