@@ -58,7 +58,7 @@ inline void dfree(void *p) { if (p) (void)hipFree(p); }
 
 // ------------------------------------------------------------------ launch geometry
 constexpr int kBlock = 256;          // 4 waves of 64
-constexpr int kMaxGrid = 2048;       // 256 CUs x 8 resident 256-thread blocks
+constexpr int kMaxGrid = 4096;       // partial-sum slots per dot (>= the largest grid)
 constexpr int kTile = 2048;          // nnz products staged in LDS per tile (16 KiB)
 constexpr int kSlots = 32;           // device scalar slots per solver part
 
@@ -66,7 +66,7 @@ inline int vec_grid(int64_t n)
 {
     int64_t g = (n + 4 * kBlock - 1) / (4 * kBlock);     // >= 4 elements per thread
     if (g < 1) g = 1;
-    if (g > kMaxGrid) g = kMaxGrid;
+    if (g > 2048) g = 2048;            // 256 CUs x 8 resident 256-thread blocks
     return (int)g;
 }
 

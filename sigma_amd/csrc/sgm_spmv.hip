@@ -18,6 +18,7 @@
 #include "sgm_internal.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace sgm {
 
@@ -56,27 +57,38 @@ __device__ inline int64_t rowblock_of(int it, int b, int grid)
     return (int64_t)it * grid + (int64_t)(b & 7) * per + (b >> 3);
 }
 
-template <bool ADD, bool DOT_W, bool DOT_YY>
-__global__ __launch_bounds__(kBlock) void k_csr_spmv(
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+template <class T>
+__device__ inline T ld_stream(const T *p, bool nt)
+{
+    return nt ? __builtin_nontemporal_load(p) : *p;
+}
+
+// BLOCK threads own BLOCK consecutive rows; TILE = 2*BLOCK*VPT products are staged per pass.
+template <int BLOCK, int VPT, bool NT, bool ADD, bool DOT_W, bool DOT_YY>
+__global__ __launch_bounds__(BLOCK) void k_csr_spmv(
     int32_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ w, double *__restrict__ part_wy, double *__restrict__ part_yy,
-    const int *__restrict__ flag_done)
+    const int *__restrict__ flag_done, int remap)
 {
-    __shared__ double prod[kTile];
-    __shared__ double red[kBlock / 64];
+    constexpr int TILE = 2 * BLOCK * VPT;
+    __shared__ double prod[TILE];
+    __shared__ double red[BLOCK / 64];
     if (flag_done && *flag_done) return;
 
     const int tid = threadIdx.x;
-    const int64_t nrb = ((int64_t)n + kBlock - 1) / kBlock;
+    const int64_t nrb = ((int64_t)n + BLOCK - 1) / BLOCK;
     double dwy = 0.0, dyy = 0.0;
 
     for (int it = 0;; ++it) {
-        const int64_t rb = rowblock_of(it, blockIdx.x, gridDim.x);
         if ((int64_t)it * gridDim.x >= nrb) break;
+        const int64_t rb = remap ? rowblock_of(it, blockIdx.x, gridDim.x) : (int64_t)it * gridDim.x + blockIdx.x;
         if (rb >= nrb) continue;          // uniform per block
-        const int32_t r0 = (int32_t)(rb * kBlock);
-        const int32_t r1 = min(r0 + kBlock, n);
+        const int32_t r0 = (int32_t)(rb * BLOCK);
+        const int32_t r1 = min(r0 + BLOCK, n);
         const int32_t row = r0 + tid;
         int32_t k = 0, ke = 0;
         if (row < n) {
@@ -87,29 +99,28 @@ __global__ __launch_bounds__(kBlock) void k_csr_spmv(
         const int32_t e = rowptr[r1];
         double z = 0.0;
 
-        for (int32_t ts = s; ts < e; ts += kTile) {
-            const int32_t te = min(ts + kTile, e);
+        for (int32_t ts = s; ts < e; ts += TILE) {
+            const int32_t te = min(ts + TILE, e);
             // ---- phase 1: all lanes stream val/col and gather x (2 entries per lane)
-            constexpr int VPT = kTile / (2 * kBlock);
-            double2 v[VPT];
-            int2 c[VPT];
+            f64x2 v[VPT];
+            i32x2 c[VPT];
 #pragma unroll
             for (int m = 0; m < VPT; ++m) {
-                const int32_t j = ts + 2 * tid + 2 * kBlock * m;
+                const int32_t j = ts + 2 * tid + 2 * BLOCK * m;
                 if (j < te) {     // arrays are padded by 2 entries: j+1 is always readable
-                    v[m] = *reinterpret_cast<const double2 *>(val + j);
-                    c[m] = *reinterpret_cast<const int2 *>(col + j);
+                    v[m] = ld_stream(reinterpret_cast<const f64x2 *>(val + j), NT);
+                    c[m] = ld_stream(reinterpret_cast<const i32x2 *>(col + j), NT);
                 }
             }
 #pragma unroll
             for (int m = 0; m < VPT; ++m) {
-                const int32_t j = ts + 2 * tid + 2 * kBlock * m;
+                const int32_t j = ts + 2 * tid + 2 * BLOCK * m;
                 if (j < te) {
                     const double x0 = x[c[m].x], x1 = x[c[m].y];
-                    double2 p;
+                    f64x2 p;
                     p.x = v[m].x * x0;
                     p.y = v[m].y * x1;
-                    *reinterpret_cast<double2 *>(prod + (j - ts)) = p;
+                    *reinterpret_cast<f64x2 *>(prod + (j - ts)) = p;
                 }
             }
             __syncthreads();
@@ -120,17 +131,17 @@ __global__ __launch_bounds__(kBlock) void k_csr_spmv(
         }
         if (row < n) {
             const double yi = ADD ? y[row] + z : 0.0 + z;
-            y[row] = yi;
+            if (NT) __builtin_nontemporal_store(yi, y + row); else y[row] = yi;
             if (DOT_W) dwy += w[row] * yi;
             if (DOT_YY) dyy += yi * yi;
         }
     }
     if (DOT_W) {
-        const double t = block_sum<kBlock>(dwy, red);
+        const double t = block_sum<BLOCK>(dwy, red);
         if (tid == 0) part_wy[blockIdx.x] = t;
     }
     if (DOT_YY) {
-        const double t = block_sum<kBlock>(dyy, red);
+        const double t = block_sum<BLOCK>(dyy, red);
         if (tid == 0) part_yy[blockIdx.x] = t;
     }
 }
@@ -191,28 +202,62 @@ __global__ void k_gather(double *__restrict__ dst, const double *__restrict__ sr
 // ---------------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------------
+// Launch configuration of the CSR kernel.  SGM_SPMV_CFG="block,vpt,nt,maxgrid,remap"
+// overrides the default (tuning aid; results do not depend on it).
+struct SpmvCfg { int block = 256, vpt = 2, nt = 1, maxgrid = 2048, remap = 1; };
+static SpmvCfg &spmv_cfg()
+{
+    static SpmvCfg c;
+    static bool init = false;
+    if (!init) {
+        init = true;
+        if (const char *e = getenv("SGM_SPMV_CFG"))
+            sscanf(e, "%d,%d,%d,%d,%d", &c.block, &c.vpt, &c.nt, &c.maxgrid, &c.remap);
+        if (c.maxgrid > kMaxGrid) c.maxgrid = kMaxGrid;
+        if (c.maxgrid < 8) c.maxgrid = 8;
+    }
+    return c;
+}
+
 int spmv_grid(const Part &p)
 {
-    int64_t nrb = ((int64_t)p.n + kBlock - 1) / kBlock;
+    const SpmvCfg &c = spmv_cfg();
+    int64_t nrb = ((int64_t)p.n + c.block - 1) / c.block;
     int64_t g = ((nrb + 7) / 8) * 8;
-    if (g > kMaxGrid) g = kMaxGrid;
+    if (g > c.maxgrid) g = c.maxgrid / 8 * 8;
     if (g < 8) g = 8;
     return (int)g;
+}
+
+template <int BLOCK, int VPT, bool NT, bool ADD>
+static void launch_csr_cfg(const Part &p, int grid, const double *x, double *y, const double *w,
+                           double *pwy, double *pyy, const int *flag, int remap)
+{
+    hipStream_t st = g_rt.stream;
+#define L(DW, DY)                                                                                  \
+    hipLaunchKernelGGL((k_csr_spmv<BLOCK, VPT, NT, ADD, DW, DY>), dim3(grid), dim3(BLOCK), 0, st,  \
+                       p.n, p.rowptr, p.col, p.val, x, y, w, pwy, pyy, flag, remap)
+    if (w && pyy) L(true, true);
+    else if (w) L(true, false);
+    else if (pyy) L(false, true);
+    else L(false, false);
+#undef L
 }
 
 template <bool ADD>
 static void launch_csr(const Part &p, int grid, const double *x, double *y, const double *w,
                        double *pwy, double *pyy, const int *flag)
 {
-    hipStream_t st = g_rt.stream;
-#define L(DW, DY)                                                                         \
-    hipLaunchKernelGGL((k_csr_spmv<ADD, DW, DY>), dim3(grid), dim3(kBlock), 0, st, p.n,   \
-                       p.rowptr, p.col, p.val, x, y, w, pwy, pyy, flag)
-    if (w && pyy) L(true, true);
-    else if (w) L(true, false);
-    else if (pyy) L(false, true);
-    else L(false, false);
-#undef L
+    const SpmvCfg &c = spmv_cfg();
+#define CFG(B, V)                                                                              \
+    if (c.block == B && c.vpt == V) {                                                          \
+        if (c.nt) launch_csr_cfg<B, V, true, ADD>(p, grid, x, y, w, pwy, pyy, flag, c.remap);  \
+        else launch_csr_cfg<B, V, false, ADD>(p, grid, x, y, w, pwy, pyy, flag, c.remap);      \
+        return;                                                                                \
+    }
+    CFG(256, 2) CFG(256, 4) CFG(256, 8) CFG(512, 2) CFG(512, 4) CFG(512, 8) CFG(1024, 2) CFG(1024, 4)
+#undef CFG
+    launch_csr_cfg<256, 2, true, ADD>(p, grid, x, y, w, pwy, pyy, flag, c.remap);
 }
 
 template <bool ADD>
