@@ -92,3 +92,11 @@ def test_halo_plan_bit_exact(nparts):
     loc, halo = sg.halo_plan_host(100, 450, node)
     loc_np, halo_np = numpy_halo_plan(100, 450, node)
     assert np.array_equal(loc, loc_np) and np.array_equal(halo, halo_np)
+
+
+def test_fortran_shim_binds_only_declared_symbols():
+    """Every bind(c) name in the Fortran host layer is declared in include/sigma_hip.h."""
+    src = open(os.path.join(ROOT, "sigma_amd", "fortran", "sigma_hip.f90")).read()
+    names = set(re.findall(r"bind\(c,\s*name='(sgm_[a-z0-9_]+)'\)", src))
+    assert len(names) >= 20
+    assert names <= set(declared_symbols())

@@ -487,3 +487,18 @@ def test_full_size_properties():
     s.solve(A, x20, b, check=False)
     phi20 = phi(x20)
     assert phi40 < phi20 < 0.0
+
+
+# ------------------------------------------------------------- Fortran ISO_C_BINDING host layer
+def test_fortran_host_layer():
+    """sigma_amd/fortran: the reference's two deterministic solver tests re-written against
+    the sigma_hip Fortran module (same thresholds, exit code = verdict, like CTest)."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sigma_amd", "fortran",
+                       "solver_test_diffusion_1d_hip")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran example not built (no amdflang at build time)")
+    r = subprocess.run([exe, "-v"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all sigma_hip Fortran checks passed" in r.stdout
