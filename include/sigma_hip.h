@@ -58,6 +58,11 @@ const char *sgm_last_error(void);
 int sgm_set_stream(void *hip_stream);     /* adopt the caller's hipStream_t (NULL = library stream) */
 int sgm_set_async(int on);                /* 1: calls return without hipStreamSynchronize */
 int sgm_synchronize(void);
+/* options: "csr_offset_dict" (default 1): CSR matrices whose column-minus-row offsets take
+ * at most 255 distinct values (every stencil / banded matrix) get a second device copy of
+ * the column indices as 1-byte dictionary codes, and matvec streams 9 instead of 12 bytes
+ * per stored entry.  Results are bit-identical either way; 0 forces the int32 kernel.  */
+int sgm_set_option(const char *name, int value);
 int sgm_malloc(void **p, size_t bytes);   /* HBM buffer for hosts without a device allocator */
 int sgm_free(void *p);
 int sgm_memcpy(void *dst, const void *src, size_t bytes, int kind); /* 0 h2d, 1 d2h, 2 d2d */

@@ -32,6 +32,11 @@ int fail(int code, const char *fmt, ...);
     } while (0)
 
 // ------------------------------------------------------------------ runtime
+struct Options {
+    int csr_offset_dict = 1;       // use the 1-byte column code kernel when a matrix allows it
+};
+extern Options g_opt;
+
 struct Runtime {
     bool ready = false;
     int device = -1;
@@ -99,6 +104,11 @@ struct Part {
     int32_t *rowptr = nullptr;
     int32_t *col = nullptr;
     double *val = nullptr;
+    // offset-dictionary form of col (built when the matrix has <= 255 distinct col-row
+    // offsets, e.g. any stencil / banded matrix): col(k) = row + dict[code(k)], 1 byte/nnz
+    uint8_t *code = nullptr;
+    int32_t *dict = nullptr;       // 256 entries
+    int32_t ndict = 0;
     // ELLPACK (device, slot-major: entry (slot k, row i) at k*n + i)
     int32_t max_d = 0;
     int32_t *ecol = nullptr;

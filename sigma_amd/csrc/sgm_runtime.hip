@@ -5,6 +5,7 @@ namespace sgm {
 
 std::string g_err;
 Runtime g_rt;
+Options g_opt;
 
 int fail(int code, const char *fmt, ...)
 {
@@ -92,6 +93,13 @@ int sgm_synchronize(void)
     SGM_TRY(require_init());
     SGM_HIP(hipStreamSynchronize(g_rt.stream));
     return SGM_OK;
+}
+
+int sgm_set_option(const char *name, int value)
+{
+    if (!name) return fail(SGM_ERR_BAD_ARG, "sgm_set_option: null name");
+    if (!strcmp(name, "csr_offset_dict")) { g_opt.csr_offset_dict = value; return SGM_OK; }
+    return fail(SGM_ERR_BAD_ARG, "sgm_set_option: unknown option '%s'", name);
 }
 
 int sgm_malloc(void **p, size_t bytes)
