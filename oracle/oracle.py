@@ -242,6 +242,12 @@ def gmres(A, b, x0=None, pc=None, tol=1e-16, max_iter=0, restart=30, history=0):
                   extra=(C.c_int32(restart),))
 
 
+def set_dot_mode(mode):
+    """0: left-to-right dot products; 1: four interleaved partial sums (a vectorising
+    compiler's dot_product).  Both are valid restatements of the Fortran intrinsic."""
+    lib().orc_set_dot_mode(C.c_int(mode))
+
+
 def time_csr_matvec(A, x, reps):
     y = np.zeros(A.n, F8)
     x = np.ascontiguousarray(x, F8)

@@ -219,10 +219,28 @@ static double op_get_value(const orc_op *A, const int32_t *degrees, int32_t i, i
 /* ------------------------------------------------------------------------ */
 /* dot / axpy statements (inline in the reference solvers)       */
 /* ------------------------------------------------------------------------ */
+/* Fortran intrinsic dot_product: the summation order is the COMPILER'S choice.  Mode 0 is
+ * the plain left-to-right sum; mode 1 is the order a 4-lane vectorising compiler produces
+ * (four interleaved partial sums, combined at the end).  Both are valid restatements of
+ * `dot_product`; tests use the gap between them to calibrate how far two correct
+ * implementations of the same recurrence may drift apart. */
+static int g_dot_mode = 0;
+ORC_API void orc_set_dot_mode(int mode) { g_dot_mode = mode; }
 static double dot(int32_t n, const double *a, const double *b)
 {
-    /* Fortran intrinsic dot_product: summation order is compiler-chosen; the
-     * oracle uses the plain left-to-right sum. */
+    if (g_dot_mode == 1) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int32_t i = 0;
+        for (; i + 4 <= n; i += 4) {
+            s0 = s0 + a[i] * b[i];
+            s1 = s1 + a[i + 1] * b[i + 1];
+            s2 = s2 + a[i + 2] * b[i + 2];
+            s3 = s3 + a[i + 3] * b[i + 3];
+        }
+        double s = (s0 + s1) + (s2 + s3);
+        for (; i < n; i++) s = s + a[i] * b[i];
+        return s;
+    }
     double s = 0.0;
     for (int32_t i = 0; i < n; i++) s = s + a[i] * b[i];
     return s;

@@ -88,6 +88,11 @@ def synchronize():
     _ck(lib().sgm_synchronize())
 
 
+def set_option(name, value):
+    """sgm_set_option: "csr_offset_dict" 1/0 (1-byte column codes for stencil-like matrices)."""
+    _ck(lib().sgm_set_option(name.encode(), C.c_int(int(value))))
+
+
 def use_torch_stream():
     """Launch on torch's current HIP stream so torch.cuda.Event brackets our kernels."""
     import torch

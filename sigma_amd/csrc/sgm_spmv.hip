@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace sgm {
 
@@ -146,6 +147,116 @@ __global__ __launch_bounds__(BLOCK) void k_csr_spmv(
     }
 }
 
+// CSR with dictionary-coded column offsets ("offset-dict" form).  Matrices from structured
+// grids have very few distinct (column - row) offsets (5 for the 5-point, 7 for the 7-point
+// stencil, also after the [owned | halo] renumbering of a slab partition), so the column of
+// entry k is stored as a 1-byte code: col(k) = row + dict[code(k)].  HBM traffic drops from
+// 12 to 9 bytes per stored entry.  Because the offset is relative to the ROW, the gather is
+// done by the lane that owns the row: val and codes are streamed into LDS with wide
+// coalesced loads by all lanes, then lane i walks row i left to right -- up to 8 entries'
+// x values are requested at once, the adds stay in stored order (bit-identical results).
+// For stencil rows lane l and lane l+1 gather neighbouring x entries: coalesced 512-B reads.
+template <int BLOCK, int VPT, bool ADD, bool DOT_W, bool DOT_YY>
+__global__ __launch_bounds__(BLOCK) void k_csr_do(
+    int32_t n, const int32_t *__restrict__ rowptr, const uint8_t *__restrict__ code,
+    const int32_t *__restrict__ dict, const double *__restrict__ val, const double *__restrict__ x,
+    double *__restrict__ y, const double *__restrict__ w, double *__restrict__ part_wy,
+    double *__restrict__ part_yy, const int *__restrict__ flag_done, int remap)
+{
+    constexpr int TILE = 2 * BLOCK * VPT;
+    constexpr int U = 8;
+    constexpr int CPT = (TILE / 4 + BLOCK - 1) / BLOCK;      // 4-byte code words per lane per tile
+    __shared__ double vl[TILE];
+    __shared__ uint32_t cl4[TILE / 4];
+    __shared__ int32_t dl[256];
+    __shared__ double red[BLOCK / 64];
+    if (flag_done && *flag_done) return;
+    const uint8_t *cl = reinterpret_cast<const uint8_t *>(cl4);
+
+    const int tid = threadIdx.x;
+    for (int t = tid; t < 256; t += BLOCK) dl[t] = dict[t];
+    const int64_t nrb = ((int64_t)n + BLOCK - 1) / BLOCK;
+    double dwy = 0.0, dyy = 0.0;
+
+    for (int it = 0;; ++it) {
+        if ((int64_t)it * gridDim.x >= nrb) break;
+        const int64_t rb = remap ? rowblock_of(it, blockIdx.x, gridDim.x) : (int64_t)it * gridDim.x + blockIdx.x;
+        if (rb >= nrb) continue;
+        const int32_t r0 = (int32_t)(rb * BLOCK);
+        const int32_t r1 = min(r0 + BLOCK, n);
+        const int32_t row = r0 + tid;
+        int32_t k = 0, ke = 0;
+        if (row < n) {
+            k = rowptr[row];
+            ke = rowptr[row + 1];
+        }
+        const int32_t s = rowptr[r0] & ~3;    // tiles start at multiples of 4 entries: aligned 4-B code loads
+        const int32_t e = rowptr[r1];
+        double z = 0.0;
+
+        for (int32_t ts = s; ts < e; ts += TILE) {
+            const int32_t te = min(ts + TILE, e);
+            // ---- phase 1: stream val (16 B / lane) and codes (4 B / lane) into LDS
+            f64x2 v[VPT];
+#pragma unroll
+            for (int m = 0; m < VPT; ++m) {
+                const int32_t j = ts + 2 * tid + 2 * BLOCK * m;
+                if (j < te) v[m] = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + j));
+            }
+            uint32_t c4[CPT];
+#pragma unroll
+            for (int m = 0; m < CPT; ++m) {
+                const int32_t q = tid + BLOCK * m;
+                if (q < TILE / 4 && ts + 4 * q < te)
+                    c4[m] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(code + ts) + q);
+            }
+            __syncthreads();       // the previous tile's phase 2 is done with the LDS buffers
+#pragma unroll
+            for (int m = 0; m < VPT; ++m) {
+                const int32_t j = ts + 2 * tid + 2 * BLOCK * m;
+                if (j < te) *reinterpret_cast<f64x2 *>(vl + (j - ts)) = v[m];
+            }
+#pragma unroll
+            for (int m = 0; m < CPT; ++m) {
+                const int32_t q = tid + BLOCK * m;
+                if (q < TILE / 4 && ts + 4 * q < te) cl4[q] = c4[m];
+            }
+            __syncthreads();
+            // ---- phase 2: lane i gathers for row i (8 requests in flight), adds in order
+            const int32_t kend = min(ke, te);
+            while (k < kend) {
+                const int cnt = min(kend - k, U);
+                double xv[U], vv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (u < cnt) {
+                        const int o = k + u - ts;
+                        xv[u] = x[row + dl[cl[o]]];
+                        vv[u] = vl[o];
+                    }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (u < cnt) z = z + vv[u] * xv[u];
+                k += cnt;
+            }
+        }
+        if (row < n) {
+            const double yi = ADD ? y[row] + z : 0.0 + z;
+            __builtin_nontemporal_store(yi, y + row);
+            if (DOT_W) dwy += w[row] * yi;
+            if (DOT_YY) dyy += yi * yi;
+        }
+    }
+    if (DOT_W) {
+        const double t = block_sum<BLOCK>(dwy, red);
+        if (tid == 0) part_wy[blockIdx.x] = t;
+    }
+    if (DOT_YY) {
+        const double t = block_sum<BLOCK>(dyy, red);
+        if (tid == 0) part_yy[blockIdx.x] = t;
+    }
+}
+
 // ELLPACK, slot-major device layout: lane i owns row i and walks ALL max_d slots in
 // order (padding slots multiply 0.0 by x(last neighbour), exactly like the reference,
 // so a non-finite x entry propagates the same way).
@@ -204,7 +315,7 @@ __global__ void k_gather(double *__restrict__ dst, const double *__restrict__ sr
 // ---------------------------------------------------------------------------------
 // Launch configuration of the CSR kernel.  SGM_SPMV_CFG="block,vpt,nt,maxgrid,remap"
 // overrides the default (tuning aid; results do not depend on it).
-struct SpmvCfg { int block = 256, vpt = 2, nt = 1, maxgrid = 2048, remap = 1; };
+struct SpmvCfg { int block = 256, vpt = 2, nt = 1, maxgrid = 0, remap = 1, do_vpt = 0; };   // 0 = automatic
 static SpmvCfg &spmv_cfg()
 {
     static SpmvCfg c;
@@ -212,19 +323,42 @@ static SpmvCfg &spmv_cfg()
     if (!init) {
         init = true;
         if (const char *e = getenv("SGM_SPMV_CFG"))
-            sscanf(e, "%d,%d,%d,%d,%d", &c.block, &c.vpt, &c.nt, &c.maxgrid, &c.remap);
+            sscanf(e, "%d,%d,%d,%d,%d,%d", &c.block, &c.vpt, &c.nt, &c.maxgrid, &c.remap, &c.do_vpt);
         if (c.maxgrid > kMaxGrid) c.maxgrid = kMaxGrid;
-        if (c.maxgrid < 8) c.maxgrid = 8;
     }
     return c;
 }
 
+static bool use_offset_dict(const Part &p) { return p.code && g_opt.csr_offset_dict; }
+
+// tile (= 2*BLOCK*VPT entries) of the offset-dict kernel: the smallest one that holds a whole
+// row block of average density, so that a row block is one load phase + one gather phase
+static int do_vpt_for(const Part &p)
+{
+    const SpmvCfg &c = spmv_cfg();
+    if (c.do_vpt) return c.do_vpt;
+    const double per_block = (double)p.nnz / (p.n > 0 ? p.n : 1) * c.block + 4;
+    return per_block <= 4.0 * c.block ? 2 : per_block <= 6.0 * c.block ? 3 : 4;
+}
+
+// Persistent grid: exactly the number of workgroups that are resident at once (LDS- or
+// wave-limited), rounded down to a multiple of 8 for the XCD map -- a larger grid only adds
+// a tail, a smaller one leaves CUs idle (measured: 7-point, 19.5 KiB LDS: 1536 beats 2048).
 int spmv_grid(const Part &p)
 {
     const SpmvCfg &c = spmv_cfg();
-    int64_t nrb = ((int64_t)p.n + c.block - 1) / c.block;
+    const int64_t nrb = ((int64_t)p.n + c.block - 1) / c.block;
     int64_t g = ((nrb + 7) / 8) * 8;
-    if (g > c.maxgrid) g = c.maxgrid / 8 * 8;
+    int64_t cap = c.maxgrid;
+    if (cap <= 0) {
+        const int tile = 2 * c.block * (use_offset_dict(p) ? do_vpt_for(p) : c.vpt);
+        const int lds = use_offset_dict(p) ? tile * 9 + 1024 + 64 : tile * 8 + 64;
+        int per_cu = (160 * 1024) / ((lds + 1023) / 1024 * 1024);
+        per_cu = std::min(per_cu, 2048 / c.block);
+        cap = (int64_t)per_cu * g_rt.num_cu;
+    }
+    if (cap > kMaxGrid) cap = kMaxGrid;
+    if (g > cap) g = cap / 8 * 8;
     if (g < 8) g = 8;
     return (int)g;
 }
@@ -261,6 +395,32 @@ static void launch_csr(const Part &p, int grid, const double *x, double *y, cons
 }
 
 template <bool ADD>
+static void launch_csr_do(const Part &p, int grid, const double *x, double *y, const double *w,
+                          double *pwy, double *pyy, const int *flag)
+{
+    const SpmvCfg &c = spmv_cfg();
+    hipStream_t st = g_rt.stream;
+#define L(B, V, DW, DY)                                                                          \
+    hipLaunchKernelGGL((k_csr_do<B, V, ADD, DW, DY>), dim3(grid), dim3(B), 0, st, p.n, p.rowptr, \
+                       p.code, p.dict, p.val, x, y, w, pwy, pyy, flag, c.remap)
+#define LV(B, V)                                \
+    {                                           \
+        if (w && pyy) L(B, V, true, true);      \
+        else if (w) L(B, V, true, false);       \
+        else if (pyy) L(B, V, false, true);     \
+        else L(B, V, false, false);             \
+    }
+    const int vpt = do_vpt_for(p);
+    if (c.block == 512) {
+        if (vpt == 2) LV(512, 2) else if (vpt == 3) LV(512, 3) else LV(512, 4)
+    } else {
+        if (vpt == 2) LV(256, 2) else if (vpt == 3) LV(256, 3) else LV(256, 4)
+    }
+#undef LV
+#undef L
+}
+
+template <bool ADD>
 static void launch_ell(const Part &p, int grid, const double *x, double *y, const double *w,
                        double *pwy, double *pyy, const int *flag)
 {
@@ -286,7 +446,10 @@ int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
         const double *w = dots && dots->w ? dots->w[ip] : nullptr;
         double *pwy = dots && dots->part_wy ? dots->part_wy[ip] : nullptr;
         double *pyy = dots && dots->part_yy ? dots->part_yy[ip] : nullptr;
-        if (A->fmt == SGM_FMT_CSR) {
+        if (A->fmt == SGM_FMT_CSR && use_offset_dict(p)) {
+            if (add) launch_csr_do<true>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done);
+            else launch_csr_do<false>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done);
+        } else if (A->fmt == SGM_FMT_CSR) {
             if (add) launch_csr<true>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done);
             else launch_csr<false>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done);
         } else {
@@ -295,6 +458,58 @@ int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
         }
     }
     SGM_HIP(hipGetLastError());
+    return SGM_OK;
+}
+
+// Offset dictionary of a row block (host index work at setup): distinct (col - row) values in
+// order of first appearance; gives up (p.code stays null) beyond 255 distinct offsets.
+// ptr1/node1: optional 1-based host copies (otherwise the device arrays are read back).
+static int build_offset_dict(Part &p, const int32_t *ptr1, const int32_t *node1)
+{
+    const int64_t nnz = p.nnz;
+    const int32_t n = p.n;
+    if (nnz == 0 || n == 0) return SGM_OK;
+    std::vector<int32_t> hp, hc;
+    const bool host = ptr1 && node1;
+    if (!host) {
+        hp.resize((size_t)n + 1);
+        hc.resize((size_t)nnz);
+        SGM_HIP(hipMemcpy(hp.data(), p.rowptr, hp.size() * 4, hipMemcpyDeviceToHost));
+        SGM_HIP(hipMemcpy(hc.data(), p.col, hc.size() * 4, hipMemcpyDeviceToHost));
+    }
+    const int32_t base = host ? 1 : 0;
+    const int32_t *ptr = host ? ptr1 : hp.data();
+    const int32_t *col = host ? node1 : hc.data();
+    constexpr int HS = 1024;                            // open-addressing table, <= 255 live keys
+    int32_t key[HS];
+    int16_t slot[HS];
+    for (int i = 0; i < HS; ++i) slot[i] = -1;
+    std::vector<int32_t> dict;
+    std::vector<uint8_t> code((size_t)nnz + 32, 0);
+    for (int32_t i = 0; i < n; ++i) {
+        for (int64_t k = ptr[i] - base; k < ptr[i + 1] - base; ++k) {
+            const int32_t off = (col[k] - base) - i;
+            uint32_t h = ((uint32_t)off * 2654435761u) >> 22;      // 10 bits
+            for (;;) {
+                if (slot[h] < 0) {
+                    if (dict.size() == 255) return SGM_OK;          // too many offsets: int32 kernel
+                    slot[h] = (int16_t)dict.size();
+                    key[h] = off;
+                    dict.push_back(off);
+                    break;
+                }
+                if (key[h] == off) break;
+                h = (h + 1) & (HS - 1);
+            }
+            code[(size_t)k] = (uint8_t)slot[h];
+        }
+    }
+    p.ndict = (int32_t)dict.size();
+    dict.resize(256, 0);
+    SGM_TRY(dalloc(&p.code, code.size()));
+    SGM_TRY(dalloc(&p.dict, (size_t)256));
+    SGM_HIP(hipMemcpy(p.code, code.data(), code.size(), hipMemcpyHostToDevice));
+    SGM_HIP(hipMemcpy(p.dict, dict.data(), 256 * 4, hipMemcpyHostToDevice));
     return SGM_OK;
 }
 
@@ -323,12 +538,12 @@ int build_csr_part(Part &p, int32_t n, int32_t ncol_own, int32_t n_halo, int64_t
     if (nnz) hipLaunchKernelGGL(k_dec1, dim3(vec_grid(nnz)), dim3(kBlock), 0, st, p.col, nnz);
     SGM_HIP(hipGetLastError());
     SGM_HIP(hipStreamSynchronize(st));   // host staging buffers may go away after return
-    return SGM_OK;
+    return build_offset_dict(p, where == SGM_HOST ? ptr1 : nullptr, where == SGM_HOST ? node1 : nullptr);
 }
 
 void free_part(Part &p)
 {
-    dfree(p.rowptr); dfree(p.col); dfree(p.val); dfree(p.ecol); dfree(p.eval); dfree(p.xext);
+    dfree(p.rowptr); dfree(p.col); dfree(p.val); dfree(p.code); dfree(p.dict); dfree(p.ecol); dfree(p.eval); dfree(p.xext);
     for (auto &nb : p.nbrs) { dfree(nb.send_idx); dfree(nb.send_buf); }
     p = Part();
 }

@@ -53,6 +53,7 @@ int main(int argc, char **argv)
     }
     const int64_t nnz = node.size();
     CK(sgm_init(0));
+    if (const char *d = getenv("SGM_CSR_DO")) CK(sgm_set_option("csr_offset_dict", atoi(d)));
     sgm_mat A;
     CK(sgm_csr_create(&A, (int32_t)n, (int32_t)n, nnz, ptr.data(), node.data(), val.data(), SGM_HOST));
     std::vector<double> hx(n);
@@ -87,8 +88,8 @@ int main(int argc, char **argv)
     unsigned long long h = 1469598103934665603ull;
     for (int64_t i = 0; i < n; ++i) { unsigned long long b; memcpy(&b, &hy[i], 8); h = (h ^ b) * 1099511628211ull; }
     const char *cfg = getenv("SGM_SPMV_CFG");
-    printf("cfg=%-18s n=%lld nnz=%lld  avg %.2f us  med %.2f us  min %.2f us  -> %.0f GB/s avg, %.0f GB/s best (%.1f%% / %.1f%% of 8 TB/s)  y-hash %016llx\n",
-           cfg ? cfg : "default", (long long)n, (long long)nnz, 1e3 * tot / reps, 1e3 * ms[reps / 2], 1e3 * ms[0],
+    printf("do=%s cfg=%-18s n=%lld nnz=%lld  avg %.2f us  med %.2f us  min %.2f us  -> %.0f GB/s avg, %.0f GB/s best (%.1f%% / %.1f%% of 8 TB/s)  y-hash %016llx\n",
+           getenv("SGM_CSR_DO") ? getenv("SGM_CSR_DO") : "1", cfg ? cfg : "default", (long long)n, (long long)nnz, 1e3 * tot / reps, 1e3 * ms[reps / 2], 1e3 * ms[0],
            bytes / (1e-3 * tot / reps) / 1e9, bytes / (1e-3 * ms[0]) / 1e9, bytes / (1e-3 * tot / reps) / 8e10,
            bytes / (1e-3 * ms[0]) / 8e10, h);
     return 0;
