@@ -153,7 +153,7 @@ struct SpmvDots {
     double *const *part_yy = nullptr;   // per part partial arrays or nullptr
 };
 int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
-               const SpmvDots *dots, const int *flag_done, int *grid_out);
+               const SpmvDots *dots, const int *flag_done, int *grid_out, int gen = 0x7fffffff);
 
 int spmv_grid(const Part &p);
 

@@ -20,7 +20,10 @@
 #include "sgm_internal.hpp"
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
+#include <cstdlib>
+#include <type_traits>
 
 namespace sgm {
 
@@ -39,11 +42,16 @@ const double *pc_idiag(sgm_pc pc, size_t part);
 // F provides: bool prepare(double* red) (block-uniform; false = nothing to do),
 //             void pair(int64_t i2) (elements 2*i2, 2*i2+1), void single(int64_t i),
 //             void finish(double* red).
+// Stop flag protocol: *flag == 0: keep going.  A kernel of "generation" gen is skipped when
+// *flag != 0 && gen >= *flag.  The CG p/x-update kernel of iteration k (generation k+1) sets
+// flag = k+2 when the new res2 meets the tolerance: every kernel of iterations > k is skipped,
+// while all workgroups of the setting kernel itself still run (they carry the last x update).
+// Kernels that do not take part in this (gen = INT_MAX) stop on any nonzero flag.
 template <class F>
-__global__ __launch_bounds__(kBlock) void k_elem(int64_t n, F f, const int *flag)
+__global__ __launch_bounds__(kBlock) void k_elem(int64_t n, F f, const int *flag, int gen)
 {
     __shared__ double red[kBlock / 64];
-    if (flag && *flag) return;
+    if (flag) { const int st = *flag; if (st && gen >= st) return; }
     if (!f.prepare(red)) return;
     const int64_t gtid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -64,6 +72,7 @@ __device__ inline void put_partial(double v, double *part, double *red)
 
 // dst = src
 struct FCopy {
+    static constexpr bool kDot = false;
     double *dst; const double *src;
     __device__ bool prepare(double *) { return true; }
     __device__ void pair(int64_t i) { D2(dst)[i] = CD2(src)[i]; }
@@ -72,6 +81,7 @@ struct FCopy {
 };
 // dst = value
 struct FFill {
+    static constexpr bool kDot = false;
     double *dst; double v;
     __device__ bool prepare(double *) { return true; }
     __device__ void pair(int64_t i) { D2(dst)[i] = make_double2(v, v); }
@@ -94,6 +104,7 @@ struct FDot2 {
 };
 // y = y + alpha * x  (host scalar)
 struct FAxpy {
+    static constexpr bool kDot = false;
     double *y; const double *x; double alpha;
     __device__ bool prepare(double *) { return true; }
     __device__ void pair(int64_t i)
@@ -137,13 +148,16 @@ struct FCopyDot {
     __device__ void single(int64_t i) { p[i] = z[i]; s += r[i] * z[i]; }
     __device__ void finish(double *red) { put_partial(s, part, red); }
 };
-// alpha = res2/dpr ; x = x+alpha*p ; r = r-alpha*q ; then
+// alpha = res2/dpr ; r = r-alpha*q ; then
 //   MODE 0: partial r.r   MODE 1: z = idiag*r, partial r.z   MODE 2: nothing (generic pc follows)
-// cg_solvers.f90:136-140 / :180-185 with jacobi_solve jacobi_solvers.f90:77 folded in
+// cg_solvers.f90:138-140 / :181-185 with jacobi_solve jacobi_solvers.f90:77 folded in.
+// (x = x+alpha*p, :137, is carried out by FCgPX: p is read there anyway, which saves one pass
+// over p per iteration; the operations and their operands are the reference's.)
 template <int MODE>
-struct FCgXR {
+struct FCgR {
+    static constexpr bool kDot = MODE != 2;
     ScalarRef res2, dpr;
-    const double *p, *q; double *x, *r; const double *idiag; double *z; double *part;
+    const double *q; double *r; const double *idiag; double *z; double *part;
     double alpha = 0.0, s = 0.0;
     __device__ bool prepare(double *red)
     {
@@ -152,58 +166,67 @@ struct FCgXR {
         alpha = a / b;
         return true;
     }
-    __device__ void one(double pv, double qv, double &xv, double &rv, double idv, double &zv)
+    __device__ void one(double qv, double &rv, double idv, double &zv)
     {
-        xv = xv + alpha * pv;
         rv = rv - alpha * qv;
         if (MODE == 0) s += rv * rv;
         if (MODE == 1) { zv = idv * rv; s += rv * zv; }
     }
     __device__ void pair(int64_t i)
     {
-        const double2 pp = CD2(p)[i], qq = CD2(q)[i];
-        double2 xx = D2(x)[i], rr = D2(r)[i], zz = make_double2(0, 0), dd = make_double2(0, 0);
+        const double2 qq = CD2(q)[i];
+        double2 rr = D2(r)[i], zz = make_double2(0, 0), dd = make_double2(0, 0);
         if (MODE == 1) dd = CD2(idiag)[i];
-        one(pp.x, qq.x, xx.x, rr.x, dd.x, zz.x);
-        one(pp.y, qq.y, xx.y, rr.y, dd.y, zz.y);
-        D2(x)[i] = xx; D2(r)[i] = rr;
+        one(qq.x, rr.x, dd.x, zz.x);
+        one(qq.y, rr.y, dd.y, zz.y);
+        D2(r)[i] = rr;
         if (MODE == 1) D2(z)[i] = zz;
     }
     __device__ void single(int64_t i)
     {
-        double xv = x[i], rv = r[i], zv = 0.0;
-        one(p[i], q[i], xv, rv, MODE == 1 ? idiag[i] : 0.0, zv);
-        x[i] = xv; r[i] = rv;
+        double rv = r[i], zv = 0.0;
+        one(q[i], rv, MODE == 1 ? idiag[i] : 0.0, zv);
+        r[i] = rv;
         if (MODE == 1) z[i] = zv;
     }
     __device__ void finish(double *red) { if (MODE != 2) put_partial(s, part, red); }
 };
-// beta = dnew/res2 ; p = z + beta*p ; bookkeeping: iterations++, history, loop condition
-// cg_solvers.f90:141-145
-struct FCgP {
-    ScalarRef res2, dnew; const double *z; double *p;
-    double tol; int *flag; int64_t *iters; double *history; int64_t hist_cap; double *res_out;
-    double beta = 0.0;
+// alpha = res2/dpr ; beta = dnew/res2 ; x = x + alpha*p ; p = z + beta*p ;
+// bookkeeping: iterations++, history, loop condition        cg_solvers.f90:137,141-145
+struct FCgPX {
+    static constexpr bool kDot = false;
+    ScalarRef res2, dpr, dnew; const double *z; double *p, *x;
+    double tol; int *flag; int stop_value; int64_t *iters; double *history; int64_t hist_cap; double *res_out;
+    double alpha = 0.0, beta = 0.0;
     __device__ bool prepare(double *red)
     {
         const double a = load_scalar<kBlock>(res2, red);
+        const double b = load_scalar<kBlock>(dpr, red);
         const double d = load_scalar<kBlock>(dnew, red);
+        alpha = a / b;
         beta = d / a;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             const int64_t it = *iters;
             if (history && it < hist_cap) history[it] = d;
             *iters = it + 1;
             *res_out = d;
-            if (!(sqrt(d) > tol)) *flag = 1;
+            if (!(sqrt(d) > tol)) *flag = stop_value;
         }
         return true;
     }
     __device__ void pair(int64_t i)
     {
-        const double2 zz = CD2(z)[i]; double2 pp = D2(p)[i];
-        pp.x = zz.x + beta * pp.x; pp.y = zz.y + beta * pp.y; D2(p)[i] = pp;
+        const double2 zz = CD2(z)[i]; double2 pp = D2(p)[i], xx = D2(x)[i];
+        xx.x = xx.x + alpha * pp.x; xx.y = xx.y + alpha * pp.y;
+        pp.x = zz.x + beta * pp.x; pp.y = zz.y + beta * pp.y;
+        D2(x)[i] = xx; D2(p)[i] = pp;
     }
-    __device__ void single(int64_t i) { p[i] = z[i] + beta * p[i]; }
+    __device__ void single(int64_t i)
+    {
+        const double pv = p[i];
+        x[i] = x[i] + alpha * pv;
+        p[i] = z[i] + beta * pv;
+    }
     __device__ void finish(double *) {}
 };
 
@@ -241,6 +264,7 @@ __device__ inline double bi_omega(double st, double tt, int guard)
 }
 // loop test + rho/beta + p = r + beta*(p - omega*v)     bicgstab_solvers.f90:154-157
 struct FBiP {
+    static constexpr bool kDot = false;
     BiScalars S; const double *r, *v; double *p;
     double tol; int *flag; int64_t *iters; double *history; int64_t hist_cap; double *res_out;
     double beta = 0.0, omega = 1.0;
@@ -280,6 +304,7 @@ struct FBiP {
 };
 // alpha = rho / (r0.v) ; s = r - alpha*v                 bicgstab_solvers.f90:160-161
 struct FBiS {
+    static constexpr bool kDot = false;
     ScalarRef rho, r0v; const double *r, *v; double *s; double alpha = 0.0;
     __device__ bool prepare(double *red)
     {
@@ -377,6 +402,7 @@ struct FMgs {
 };
 // dst = src / sqrt(sum(nrm2))      (v_{j+1} = w / h_{j+1,j} ; v_1 = r / beta)
 struct FScaleInv {
+    static constexpr bool kDot = false;
     double *dst; const double *src; ScalarRef nrm2; double d = 1.0;
     __device__ bool prepare(double *red) { d = sqrt(load_scalar<kBlock>(nrm2, red)); return true; }
     __device__ void pair(int64_t i)
@@ -455,6 +481,7 @@ __global__ void k_gmres_solve_y(GmresState *G, int m)
 }
 // x = x + sum_i y_i v_i   (one pass over x, k passes over V)
 struct FGmresUpdate {
+    static constexpr bool kDot = false;
     double *x; const double *V; int64_t ldv; const GmresState *G; int k = 0;
     __device__ bool prepare(double *) { k = G->j; return k > 0; }
     __device__ void one(int64_t i)
@@ -468,10 +495,45 @@ struct FGmresUpdate {
     __device__ void finish(double *) {}
 };
 
-template <class F>
-static inline void launch_elem(int64_t n, const F &f, const int *flag)
+// Grid policy of the vector kernels.  Kernels that leave partial sums need grid <= kMaxGrid;
+// pure update kernels take one pass over a large grid (a copy-like stream runs ~30 % faster
+// that way on MI355X than as a small persistent grid: tools/stream_bench.cpp).
+// SGM_VEC_CFG="dot_grid,nodot_grid" overrides (tuning aid).
+struct VecCfg { int dot_grid = 2048, nodot_grid = 2048; };
+static VecCfg &vec_cfg()
 {
-    hipLaunchKernelGGL((k_elem<F>), dim3(vec_grid(n)), dim3(kBlock), 0, g_rt.stream, n, f, flag);
+    static VecCfg c;
+    static bool init = false;
+    if (!init) {
+        init = true;
+        if (const char *e = getenv("SGM_VEC_CFG")) sscanf(e, "%d,%d", &c.dot_grid, &c.nodot_grid);
+        if (c.dot_grid > kMaxGrid) c.dot_grid = kMaxGrid;
+    }
+    return c;
+}
+int dot_grid(int64_t n)
+{
+    int64_t g = (n + 4 * kBlock - 1) / (4 * kBlock);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(g, vec_cfg().dot_grid));
+}
+static int nodot_grid(int64_t n)
+{
+    int64_t g = (n / 2 + kBlock - 1) / kBlock;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(g, vec_cfg().nodot_grid));
+}
+
+template <class T, class = void> struct has_kdot : std::false_type {};
+template <class T> struct has_kdot<T, std::void_t<decltype(T::kDot)>> : std::true_type {};
+template <class F> constexpr bool leaves_partials()
+{
+    if constexpr (has_kdot<F>::value) return F::kDot; else return true;
+}
+
+template <class F>
+static inline void launch_elem(int64_t n, const F &f, const int *flag, int gen = INT32_MAX)
+{
+    const int grid = leaves_partials<F>() ? dot_grid(n) : nodot_grid(n);
+    hipLaunchKernelGGL((k_elem<F>), dim3(grid), dim3(kBlock), 0, g_rt.stream, n, f, flag, gen);
 }
 
 }  // namespace sgm
@@ -593,7 +655,7 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
     if (pk == 0) {
         for (size_t ip = 0; ip < P; ++ip) {
             const int64_t n = s->work[ip].n;
-            s->work[ip].count[C_RR0] = vec_grid(n);
+            s->work[ip].count[C_RR0] = dot_grid(n);
             launch_elem(n, FCgInit{b[ip], W(ip, V_Q), W(ip, V_R), W(ip, V_P), part(s, ip, C_RR0), true}, nullptr);
         }
     } else {
@@ -605,7 +667,7 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
         SGM_TRY(pc_apply_parts(pc, A, rr.data(), zz.data(), nullptr));
         for (size_t ip = 0; ip < P; ++ip) {
             const int64_t n = s->work[ip].n;
-            s->work[ip].count[C_RR0] = vec_grid(n);
+            s->work[ip].count[C_RR0] = dot_grid(n);
             launch_elem(n, FCopyDot{W(ip, V_P), W(ip, V_Z), W(ip, V_R), part(s, ip, C_RR0)}, nullptr);
         }
     }
@@ -630,21 +692,23 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
             dots.w = v.w.data(); dots.part_wy = v.p0.data();
             // all parts share one flag value; spmv takes part 0's flag for every launch on
             // this device (identical contents)
-            SGM_TRY(spmv_parts(A, v.cx.data(), v.y.data(), false, &dots, s->work[0].flag, &grid));
+            SGM_TRY(spmv_parts(A, v.cx.data(), v.y.data(), false, &dots, s->work[0].flag, &grid,
+                               (int)std::min<int64_t>(k + 1, INT32_MAX - 2)));
             for (size_t ip = 0; ip < P; ++ip) s->work[ip].count[C_PQ] = spmv_grid(A->parts[ip]);
             { const int ks[1] = {C_PQ}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+            const int gen = (int)std::min<int64_t>(k + 1, INT32_MAX - 2);
             for (size_t ip = 0; ip < P; ++ip) {
                 PartWork &w = s->work[ip];
-                w.count[nxt] = vec_grid(w.n);
+                w.count[nxt] = dot_grid(w.n);
                 if (pk == 0)
-                    launch_elem(w.n, FCgXR<0>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_P), W(ip, V_Q), x[ip],
-                                              W(ip, V_R), nullptr, nullptr, part(s, ip, nxt)}, w.flag);
+                    launch_elem(w.n, FCgR<0>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_Q), W(ip, V_R), nullptr, nullptr,
+                                             part(s, ip, nxt)}, w.flag, gen);
                 else if (pk == SGM_PC_JACOBI)
-                    launch_elem(w.n, FCgXR<1>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_P), W(ip, V_Q), x[ip],
-                                              W(ip, V_R), pc_idiag(pc, ip), W(ip, V_Z), part(s, ip, nxt)}, w.flag);
+                    launch_elem(w.n, FCgR<1>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_Q), W(ip, V_R), pc_idiag(pc, ip),
+                                             W(ip, V_Z), part(s, ip, nxt)}, w.flag, gen);
                 else
-                    launch_elem(w.n, FCgXR<2>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_P), W(ip, V_Q), x[ip],
-                                              W(ip, V_R), nullptr, nullptr, nullptr}, w.flag);
+                    launch_elem(w.n, FCgR<2>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_Q), W(ip, V_R), nullptr, nullptr,
+                                             nullptr}, w.flag, gen);
             }
             if (pk != 0 && pk != SGM_PC_JACOBI) {
                 std::vector<const double *> rr(P); std::vector<double *> zz(P);
@@ -652,15 +716,15 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
                 SGM_TRY(pc_apply_parts(pc, A, rr.data(), zz.data(), v.flags.data()));
                 for (size_t ip = 0; ip < P; ++ip) {
                     PartWork &w = s->work[ip];
-                    launch_elem(w.n, FDot2{W(ip, V_R), W(ip, V_Z), nullptr, nullptr, part(s, ip, nxt), nullptr}, w.flag);
+                    launch_elem(w.n, FDot2{W(ip, V_R), W(ip, V_Z), nullptr, nullptr, part(s, ip, nxt), nullptr}, w.flag, gen);
                 }
             }
             { const int ks[1] = {nxt}; SGM_TRY(finish_dots(s, A, ks, 1)); }
             for (size_t ip = 0; ip < P; ++ip) {
                 PartWork &w = s->work[ip];
-                launch_elem(w.n, FCgP{ref(s, ip, cur), ref(s, ip, nxt), pk == 0 ? W(ip, V_R) : W(ip, V_Z), W(ip, V_P),
-                                      s->tolerance, w.flag, w.iters, ip == 0 ? w.history : nullptr, s->hist_cap,
-                                      w.res}, w.flag);
+                launch_elem(w.n, FCgPX{ref(s, ip, cur), ref(s, ip, C_PQ), ref(s, ip, nxt), pk == 0 ? W(ip, V_R) : W(ip, V_Z),
+                                       W(ip, V_P), x[ip], s->tolerance, w.flag, gen + 1, w.iters,
+                                       ip == 0 ? w.history : nullptr, s->hist_cap, w.res}, w.flag, gen);
             }
         }
         SGM_HIP(hipGetLastError());
@@ -703,7 +767,7 @@ int run_bicgstab(sgm_solver s, sgm_mat A, double *const *x, const double *const 
     }
     for (size_t ip = 0; ip < P; ++ip) {
         const int64_t n = s->work[ip].n;
-        s->work[ip].count[B_RR] = s->work[ip].count[B_RHO] = vec_grid(n);
+        s->work[ip].count[B_RR] = s->work[ip].count[B_RHO] = dot_grid(n);
         launch_elem(n, FBiInit{pk ? W(ip, W_R0) : b[ip], W(ip, W_Q), pk == 0, W(ip, W_R0), W(ip, W_R), W(ip, W_V),
                                W(ip, W_P), part(s, ip, B_RR), part(s, ip, B_RHO)}, nullptr);
     }
@@ -745,7 +809,7 @@ int run_bicgstab(sgm_solver s, sgm_mat A, double *const *x, const double *const 
                 SGM_TRY(pc_apply_parts(pc, A, zz.data(), vv.data(), v.flags.data()));
                 for (size_t ip = 0; ip < P; ++ip) {
                     PartWork &w = s->work[ip];
-                    w.count[B_R0V + c] = vec_grid(w.n);
+                    w.count[B_R0V + c] = dot_grid(w.n);
                     launch_elem(w.n, FDot2{W(ip, W_R0), W(ip, W_V), nullptr, nullptr, part(s, ip, B_R0V + c), nullptr},
                                 w.flag);
                 }
@@ -770,7 +834,7 @@ int run_bicgstab(sgm_solver s, sgm_mat A, double *const *x, const double *const 
                 SGM_TRY(pc_apply_parts(pc, A, zz.data(), tt.data(), v.flags.data()));
                 for (size_t ip = 0; ip < P; ++ip) {
                     PartWork &w = s->work[ip];
-                    w.count[B_ST + c] = w.count[B_TT + c] = vec_grid(w.n);
+                    w.count[B_ST + c] = w.count[B_TT + c] = dot_grid(w.n);
                     launch_elem(w.n, FDot2{W(ip, W_S), W(ip, W_T), W(ip, W_T), W(ip, W_T), part(s, ip, B_ST + c),
                                            part(s, ip, B_TT + c)}, w.flag);
                 }
@@ -780,7 +844,7 @@ int run_bicgstab(sgm_solver s, sgm_mat A, double *const *x, const double *const 
             { const int ks[1] = {B_TT + c}; SGM_TRY(finish_dots(s, A, ks, 1)); }
             for (size_t ip = 0; ip < P; ++ip) {
                 PartWork &w = s->work[ip];
-                w.count[B_RR + o] = w.count[B_RHO + o] = vec_grid(w.n);
+                w.count[B_RR + o] = w.count[B_RHO + o] = dot_grid(w.n);
                 launch_elem(w.n, FBiXR{ref(s, ip, B_RHO + c), ref(s, ip, B_R0V + c), ref(s, ip, B_ST + c),
                                        ref(s, ip, B_TT + c), pk == 0, W(ip, W_P), W(ip, W_S), W(ip, W_T), W(ip, W_R0),
                                        x[ip], W(ip, W_R), part(s, ip, B_RR + o), part(s, ip, B_RHO + o)}, w.flag);
@@ -857,7 +921,7 @@ int run_gmres(sgm_solver s, sgm_mat A, double *const *x, const double *const *b,
         }
         for (size_t ip = 0; ip < P; ++ip) {
             PartWork &w = s->work[ip];
-            w.count[NRM] = vec_grid(w.n);
+            w.count[NRM] = dot_grid(w.n);
             launch_elem(w.n, FMgs{W(ip, G_W), nullptr, nullptr, ScalarRef{nullptr, 0}, part(s, ip, NRM)}, w.flag);
         }
         { const int ks[1] = {NRM}; SGM_TRY(finish_dots(s, A, ks, 1)); }
@@ -877,7 +941,7 @@ int run_gmres(sgm_solver s, sgm_mat A, double *const *x, const double *const *b,
             for (int i = 0; i <= j + 1; ++i) {
                 for (size_t ip = 0; ip < P; ++ip) {
                     PartWork &w = s->work[ip];
-                    w.count[i] = vec_grid(w.n);
+                    w.count[i] = dot_grid(w.n);
                     launch_elem(w.n, FMgs{W(ip, G_W), i ? Vc(ip, i - 1) : nullptr, i <= j ? Vc(ip, i) : nullptr,
                                           i ? ref(s, ip, i - 1) : ScalarRef{nullptr, 0}, part(s, ip, i)}, w.flag);
                 }
@@ -1080,7 +1144,7 @@ int sgm_dot(int64_t n, const double *a, const double *b, double *result, int whe
     double *partials = nullptr, *slot = nullptr;
     SGM_TRY(dalloc(&partials, (size_t)kMaxGrid));
     SGM_TRY(dalloc(&slot, 1));
-    const int grid = vec_grid(n);
+    const int grid = dot_grid(n);
     launch_elem(n, FDot2{sa.dev, sb2.dev, nullptr, nullptr, partials, nullptr}, nullptr);
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, g_rt.stream, partials, grid, slot);
     SGM_HIP(hipMemcpyAsync(result, slot, 8, hipMemcpyDeviceToHost, g_rt.stream));

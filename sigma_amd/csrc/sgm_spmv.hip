@@ -73,12 +73,12 @@ __global__ __launch_bounds__(BLOCK) void k_csr_spmv(
     int32_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ w, double *__restrict__ part_wy, double *__restrict__ part_yy,
-    const int *__restrict__ flag_done, int remap)
+    const int *__restrict__ flag_done, int gen, int remap)
 {
     constexpr int TILE = 2 * BLOCK * VPT;
     __shared__ double prod[TILE];
     __shared__ double red[BLOCK / 64];
-    if (flag_done && *flag_done) return;
+    if (flag_done) { const int st = *flag_done; if (st && gen >= st) return; }
 
     const int tid = threadIdx.x;
     const int64_t nrb = ((int64_t)n + BLOCK - 1) / BLOCK;
@@ -92,9 +92,12 @@ __global__ __launch_bounds__(BLOCK) void k_csr_spmv(
         const int32_t r1 = min(r0 + BLOCK, n);
         const int32_t row = r0 + tid;
         int32_t k = 0, ke = 0;
+        double wv = 0.0, y0 = 0.0;          // requested now, consumed after the row sum
         if (row < n) {
             k = rowptr[row];
             ke = rowptr[row + 1];
+            if (DOT_W) wv = w[row];
+            if (ADD) y0 = y[row];
         }
         const int32_t s = rowptr[r0] & ~1;    // tile starts are even: 16-B aligned val loads
         const int32_t e = rowptr[r1];
@@ -131,9 +134,9 @@ __global__ __launch_bounds__(BLOCK) void k_csr_spmv(
             __syncthreads();
         }
         if (row < n) {
-            const double yi = ADD ? y[row] + z : 0.0 + z;
+            const double yi = ADD ? y0 + z : 0.0 + z;
             if (NT) __builtin_nontemporal_store(yi, y + row); else y[row] = yi;
-            if (DOT_W) dwy += w[row] * yi;
+            if (DOT_W) dwy += wv * yi;
             if (DOT_YY) dyy += yi * yi;
         }
     }
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
     int32_t n, const int32_t *__restrict__ rowptr, const uint8_t *__restrict__ code,
     const int32_t *__restrict__ dict, const double *__restrict__ val, const double *__restrict__ x,
     double *__restrict__ y, const double *__restrict__ w, double *__restrict__ part_wy,
-    double *__restrict__ part_yy, const int *__restrict__ flag_done, int remap)
+    double *__restrict__ part_yy, const int *__restrict__ flag_done, int gen, int remap)
 {
     constexpr int TILE = 2 * BLOCK * VPT;
     constexpr int U = 8;
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
     __shared__ uint32_t cl4[TILE / 4];
     __shared__ int32_t dl[256];
     __shared__ double red[BLOCK / 64];
-    if (flag_done && *flag_done) return;
+    if (flag_done) { const int st = *flag_done; if (st && gen >= st) return; }
     const uint8_t *cl = reinterpret_cast<const uint8_t *>(cl4);
 
     const int tid = threadIdx.x;
@@ -186,9 +189,12 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
         const int32_t r1 = min(r0 + BLOCK, n);
         const int32_t row = r0 + tid;
         int32_t k = 0, ke = 0;
+        double wv = 0.0, y0 = 0.0;          // requested now, consumed after the row sum
         if (row < n) {
             k = rowptr[row];
             ke = rowptr[row + 1];
+            if (DOT_W) wv = w[row];
+            if (ADD) y0 = y[row];
         }
         const int32_t s = rowptr[r0] & ~3;    // tiles start at multiples of 4 entries: aligned 4-B code loads
         const int32_t e = rowptr[r1];
@@ -241,9 +247,9 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
             }
         }
         if (row < n) {
-            const double yi = ADD ? y[row] + z : 0.0 + z;
+            const double yi = ADD ? y0 + z : 0.0 + z;
             __builtin_nontemporal_store(yi, y + row);
-            if (DOT_W) dwy += w[row] * yi;
+            if (DOT_W) dwy += wv * yi;
             if (DOT_YY) dyy += yi * yi;
         }
     }
@@ -264,10 +270,10 @@ template <bool ADD, bool DOT_W, bool DOT_YY>
 __global__ __launch_bounds__(kBlock) void k_ell_spmv(
     int32_t n, int32_t max_d, const int32_t *__restrict__ ecol, const double *__restrict__ eval,
     const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ w,
-    double *__restrict__ part_wy, double *__restrict__ part_yy, const int *__restrict__ flag_done)
+    double *__restrict__ part_wy, double *__restrict__ part_yy, const int *__restrict__ flag_done, int gen)
 {
     __shared__ double red[kBlock / 64];
-    if (flag_done && *flag_done) return;
+    if (flag_done) { const int st = *flag_done; if (st && gen >= st) return; }
     double dwy = 0.0, dyy = 0.0;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
@@ -329,6 +335,7 @@ static SpmvCfg &spmv_cfg()
     return c;
 }
 
+static int resident_per_cu(bool dict, int block, int vpt);
 static bool use_offset_dict(const Part &p) { return p.code && g_opt.csr_offset_dict; }
 
 // tile (= 2*BLOCK*VPT entries) of the offset-dict kernel: the smallest one that holds a whole
@@ -350,13 +357,8 @@ int spmv_grid(const Part &p)
     const int64_t nrb = ((int64_t)p.n + c.block - 1) / c.block;
     int64_t g = ((nrb + 7) / 8) * 8;
     int64_t cap = c.maxgrid;
-    if (cap <= 0) {
-        const int tile = 2 * c.block * (use_offset_dict(p) ? do_vpt_for(p) : c.vpt);
-        const int lds = use_offset_dict(p) ? tile * 9 + 1024 + 64 : tile * 8 + 64;
-        int per_cu = (160 * 1024) / ((lds + 1023) / 1024 * 1024);
-        per_cu = std::min(per_cu, 2048 / c.block);
-        cap = (int64_t)per_cu * g_rt.num_cu;
-    }
+    if (cap <= 0) cap = (int64_t)resident_per_cu(use_offset_dict(p), c.block, use_offset_dict(p) ? do_vpt_for(p) : c.vpt) *
+                        g_rt.num_cu;
     if (cap > kMaxGrid) cap = kMaxGrid;
     if (g > cap) g = cap / 8 * 8;
     if (g < 8) g = 8;
@@ -365,12 +367,12 @@ int spmv_grid(const Part &p)
 
 template <int BLOCK, int VPT, bool NT, bool ADD>
 static void launch_csr_cfg(const Part &p, int grid, const double *x, double *y, const double *w,
-                           double *pwy, double *pyy, const int *flag, int remap)
+                           double *pwy, double *pyy, const int *flag, int gen, int remap)
 {
     hipStream_t st = g_rt.stream;
 #define L(DW, DY)                                                                                  \
     hipLaunchKernelGGL((k_csr_spmv<BLOCK, VPT, NT, ADD, DW, DY>), dim3(grid), dim3(BLOCK), 0, st,  \
-                       p.n, p.rowptr, p.col, p.val, x, y, w, pwy, pyy, flag, remap)
+                       p.n, p.rowptr, p.col, p.val, x, y, w, pwy, pyy, flag, gen, remap)
     if (w && pyy) L(true, true);
     else if (w) L(true, false);
     else if (pyy) L(false, true);
@@ -380,29 +382,29 @@ static void launch_csr_cfg(const Part &p, int grid, const double *x, double *y, 
 
 template <bool ADD>
 static void launch_csr(const Part &p, int grid, const double *x, double *y, const double *w,
-                       double *pwy, double *pyy, const int *flag)
+                       double *pwy, double *pyy, const int *flag, int gen)
 {
     const SpmvCfg &c = spmv_cfg();
 #define CFG(B, V)                                                                              \
     if (c.block == B && c.vpt == V) {                                                          \
-        if (c.nt) launch_csr_cfg<B, V, true, ADD>(p, grid, x, y, w, pwy, pyy, flag, c.remap);  \
-        else launch_csr_cfg<B, V, false, ADD>(p, grid, x, y, w, pwy, pyy, flag, c.remap);      \
+        if (c.nt) launch_csr_cfg<B, V, true, ADD>(p, grid, x, y, w, pwy, pyy, flag, gen, c.remap);  \
+        else launch_csr_cfg<B, V, false, ADD>(p, grid, x, y, w, pwy, pyy, flag, gen, c.remap);      \
         return;                                                                                \
     }
     CFG(256, 2) CFG(256, 4) CFG(256, 8) CFG(512, 2) CFG(512, 4) CFG(512, 8) CFG(1024, 2) CFG(1024, 4)
 #undef CFG
-    launch_csr_cfg<256, 2, true, ADD>(p, grid, x, y, w, pwy, pyy, flag, c.remap);
+    launch_csr_cfg<256, 2, true, ADD>(p, grid, x, y, w, pwy, pyy, flag, gen, c.remap);
 }
 
 template <bool ADD>
 static void launch_csr_do(const Part &p, int grid, const double *x, double *y, const double *w,
-                          double *pwy, double *pyy, const int *flag)
+                          double *pwy, double *pyy, const int *flag, int gen)
 {
     const SpmvCfg &c = spmv_cfg();
     hipStream_t st = g_rt.stream;
 #define L(B, V, DW, DY)                                                                          \
     hipLaunchKernelGGL((k_csr_do<B, V, ADD, DW, DY>), dim3(grid), dim3(B), 0, st, p.n, p.rowptr, \
-                       p.code, p.dict, p.val, x, y, w, pwy, pyy, flag, c.remap)
+                       p.code, p.dict, p.val, x, y, w, pwy, pyy, flag, gen, c.remap)
 #define LV(B, V)                                \
     {                                           \
         if (w && pyy) L(B, V, true, true);      \
@@ -422,12 +424,12 @@ static void launch_csr_do(const Part &p, int grid, const double *x, double *y, c
 
 template <bool ADD>
 static void launch_ell(const Part &p, int grid, const double *x, double *y, const double *w,
-                       double *pwy, double *pyy, const int *flag)
+                       double *pwy, double *pyy, const int *flag, int gen)
 {
     hipStream_t st = g_rt.stream;
 #define L(DW, DY)                                                                         \
     hipLaunchKernelGGL((k_ell_spmv<ADD, DW, DY>), dim3(grid), dim3(kBlock), 0, st, p.n,   \
-                       p.max_d, p.ecol, p.eval, x, y, w, pwy, pyy, flag)
+                       p.max_d, p.ecol, p.eval, x, y, w, pwy, pyy, flag, gen)
     if (w && pyy) L(true, true);
     else if (w) L(true, false);
     else if (pyy) L(false, true);
@@ -435,8 +437,31 @@ static void launch_ell(const Part &p, int grid, const double *x, double *y, cons
 #undef L
 }
 
+// Workgroups of one kernel variant that fit on a CU at once (occupancy API, cached).
+static int resident_per_cu(bool dict, int block, int vpt)
+{
+    static int cache[2][3][5] = {};
+    const int bi = block == 256 ? 0 : block == 512 ? 1 : 2;
+    int &slot = cache[dict ? 1 : 0][bi][vpt < 5 ? vpt : 4];
+    if (slot) return slot;
+    const void *fn = nullptr;
+#define PICK_DO(B, V) if (block == B && vpt == V) fn = (const void *)k_csr_do<B, V, false, false, false>;
+#define PICK_ST(B, V) if (block == B && vpt == V) fn = (const void *)k_csr_spmv<B, V, true, false, false, false>;
+    if (dict) { PICK_DO(256, 2) PICK_DO(256, 3) PICK_DO(256, 4) PICK_DO(512, 2) PICK_DO(512, 3) PICK_DO(512, 4) }
+    else { PICK_ST(256, 2) PICK_ST(256, 4) PICK_ST(256, 8) PICK_ST(512, 2) PICK_ST(512, 4) PICK_ST(512, 8) PICK_ST(1024, 2) PICK_ST(1024, 4) }
+#undef PICK_DO
+#undef PICK_ST
+    int nb = 0;
+    if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, block, 0) != hipSuccess || nb < 1)
+        nb = 2048 / block;
+    // every variant with dots / ADD uses a few more registers; stay one short of the edge
+    // only when the API answer is LDS-limited (it is exact for LDS)
+    slot = nb;
+    return slot;
+}
+
 int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
-               const SpmvDots *dots, const int *flag_done, int *grid_out)
+               const SpmvDots *dots, const int *flag_done, int *grid_out, int gen)
 {
     if (A->distributed()) SGM_TRY(halo_exchange(A, const_cast<double *const *>(x)));
     for (size_t ip = 0; ip < A->parts.size(); ++ip) {
@@ -447,14 +472,14 @@ int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
         double *pwy = dots && dots->part_wy ? dots->part_wy[ip] : nullptr;
         double *pyy = dots && dots->part_yy ? dots->part_yy[ip] : nullptr;
         if (A->fmt == SGM_FMT_CSR && use_offset_dict(p)) {
-            if (add) launch_csr_do<true>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done);
-            else launch_csr_do<false>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done);
+            if (add) launch_csr_do<true>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done, gen);
+            else launch_csr_do<false>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done, gen);
         } else if (A->fmt == SGM_FMT_CSR) {
-            if (add) launch_csr<true>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done);
-            else launch_csr<false>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done);
+            if (add) launch_csr<true>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done, gen);
+            else launch_csr<false>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done, gen);
         } else {
-            if (add) launch_ell<true>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done);
-            else launch_ell<false>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done);
+            if (add) launch_ell<true>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done, gen);
+            else launch_ell<false>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done, gen);
         }
     }
     SGM_HIP(hipGetLastError());

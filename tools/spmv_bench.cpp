@@ -70,17 +70,25 @@ int main(int argc, char **argv)
     hipStreamSynchronize(st);
     std::vector<hipEvent_t> ev(reps + 1);
     for (auto &e : ev) hipEventCreate(&e);
+    // SGM_BENCH_FLUSH=1: stream 1 GiB through the caches between matvecs (cold Infinity Cache,
+    // the state a matvec finds inside a Krylov iteration)
+    const bool flush = getenv("SGM_BENCH_FLUSH") != nullptr;
+    void *fl = nullptr;
+    if (flush) hipMalloc(&fl, 1ull << 30);
+    std::vector<hipEvent_t> ev0(reps);
+    for (auto &e : ev0) hipEventCreate(&e);
     hipEventRecord(ev[0], st);
     for (int r = 0; r < reps; ++r) {
+        if (flush) hipMemsetAsync(fl, r, 1ull << 30, st);
+        hipEventRecord(ev0[r], st);
         CK(sgm_mat_matvec(A, x, y, SGM_DEVICE));
         hipEventRecord(ev[r + 1], st);
     }
     hipStreamSynchronize(st);
     std::vector<float> ms(reps);
-    for (int r = 0; r < reps; ++r) hipEventElapsedTime(&ms[r], ev[r], ev[r + 1]);
+    float tot = 0;
+    for (int r = 0; r < reps; ++r) { hipEventElapsedTime(&ms[r], ev0[r], ev[r + 1]); tot += ms[r]; }
     std::sort(ms.begin(), ms.end());
-    float tot;
-    hipEventElapsedTime(&tot, ev[0], ev[reps]);
     const double bytes = 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n;
     // checksum so that variants can be compared bit for bit
     std::vector<double> hy(n);
@@ -92,5 +100,34 @@ int main(int argc, char **argv)
            getenv("SGM_CSR_DO") ? getenv("SGM_CSR_DO") : "1", cfg ? cfg : "default", (long long)n, (long long)nnz, 1e3 * tot / reps, 1e3 * ms[reps / 2], 1e3 * ms[0],
            bytes / (1e-3 * tot / reps) / 1e9, bytes / (1e-3 * ms[0]) / 1e9, bytes / (1e-3 * tot / reps) / 8e10,
            bytes / (1e-3 * ms[0]) / 8e10, h);
+    // ---- CG: fixed iteration count, device-resident vectors
+    if (getenv("SGM_BENCH_CG")) {
+        const int its = atoi(getenv("SGM_BENCH_CG"));
+        sgm_solver sv;
+        CK(sgm_cg_create(&sv, 1e-300));
+        CK(sgm_solver_set_max_iter(sv, its));
+        CK(sgm_solver_setup(sv, A));
+        double *u, *b;
+        CK(sgm_malloc((void **)&u, n * 8));
+        CK(sgm_malloc((void **)&b, n * 8));
+        std::vector<double> hb(n, 1.0 / n), hz(n, 0.0);
+        CK(sgm_memcpy(b, hb.data(), n * 8, 0));
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(sgm_memcpy(u, hz.data(), n * 8, 0));
+            hipStreamSynchronize(st);
+            hipEventRecord(ev[0], st);
+            int rc = sgm_solver_solve(sv, A, u, b, nullptr, SGM_DEVICE);
+            hipEventRecord(ev[1], st);
+            hipStreamSynchronize(st);
+            if (rc != 0 && rc != SGM_ERR_NOT_CONVERGED) { fprintf(stderr, "solve: %s\n", sgm_last_error()); return 1; }
+            float t; hipEventElapsedTime(&t, ev[0], ev[1]);
+            int64_t it, last; double r2; int32_t cv;
+            sgm_solver_info(sv, &it, &r2, &cv, &last);
+            const double cgb = bytes + 72.0 * n;
+            printf("  CG rep %d: %lld its  %.2f us/iter  %.0f iters/s  %.0f GB/s on B_csr+72n (%.1f%% of 8 TB/s)  res2 %.17g\n", rep,
+                   (long long)last, 1e3 * t / last, last / (1e-3 * t), cgb * last / (1e-3 * t) / 1e9,
+                   cgb * last / (1e-3 * t) / 8e10, r2);
+        }
+    }
     return 0;
 }
