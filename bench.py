@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--ny", type=int, default=3162)
     ap.add_argument("--cg-steps", type=int, default=100)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the RCCL row-partition code path even with one rank (testing aid)")
     args = ap.parse_args()
 
     import torch
@@ -63,21 +65,35 @@ def main():
     torch.cuda.set_stream(stream)
     sg.use_torch_stream()
     sg.set_async(True)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        # torch.distributed is the CONTROL plane only (bootstrap of the RCCL id, barriers, the
+        # max-over-ranks of the timings) and runs over gloo on the host, so that the data
+        # plane -- the library's own RCCL communicator (halo send/recv + dot all-reduces on the
+        # launch stream) -- is the only RCCL communicator of the process.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def barrier():
-        if world > 1:
+        torch.cuda.synchronize()
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(v):
+        if not use_dist:
+            return v
+        t = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     # ---- synthetic matrix: this rank's nx*ny rows of the nx x (world*ny) 5-point grid ----
     nx, ny = args.nx, args.ny
     n_loc = nx * ny
     n_glob = n_loc * world
     ptr, node, val = P.poisson2d_csr(nx, ny * world) if world == 1 else (None, None, None)
-    if world == 1:
+    if not use_dist:
         A = sg.csr_matrix(n_loc, n_loc, torch.from_numpy(ptr).to(dev), torch.from_numpy(node).to(dev),
                           torch.from_numpy(val).to(dev))
         nnz = len(val)
@@ -107,10 +123,7 @@ def main():
         A.matvec(x, y)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt)
     ms_per_step = 1e3 * dt / args.steps
     value = bytes_rank * world * args.steps / dt / 1e9
 
@@ -131,7 +144,7 @@ def main():
     variants = {"offset_dict_u8_codes (default for stencil-like matrices)":
                 {"kernel": "k_csr_do", "avg_launch_ms": 1e3 * k_avg, "GB/s_algorithmic": achieved,
                  "stored_bytes_per_nnz": 9}}
-    if world == 1:
+    if not use_dist:
         sg.set_option("csr_offset_dict", 0)
         for _ in range(5):
             A.matvec(x, y)
@@ -156,10 +169,7 @@ def main():
         s.solve(A, u, bvec, check=False)
         barrier()
         dtc = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dtc], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dtc = float(t.item())
+        dtc = max_over_ranks(dtc)
         its = s.last_iterations
         cg_bytes = (bytes_rank + 72 * n_loc) * world     # SURVEY §8d fused floor B_csr + 72 n
         cg = {"iters_per_s": its / dtc, "iterations": its, "ms_per_iter": 1e3 * dtc / its,
@@ -207,7 +217,8 @@ def main():
             "spmv_variants": variants, "cg": cg, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
+        barrier()
         dist.destroy_process_group()
 
 

@@ -159,16 +159,17 @@ __global__ __launch_bounds__(BLOCK) void k_csr_spmv(
 // coalesced loads by all lanes, then lane i walks row i left to right -- up to 8 entries'
 // x values are requested at once, the adds stay in stored order (bit-identical results).
 // For stencil rows lane l and lane l+1 gather neighbouring x entries: coalesced 512-B reads.
-template <int BLOCK, int VPT, bool ADD, bool DOT_W, bool DOT_YY>
+template <int BLOCK, int TILE, bool ADD, bool DOT_W, bool DOT_YY>
 __global__ __launch_bounds__(BLOCK) void k_csr_do(
     int32_t n, const int32_t *__restrict__ rowptr, const uint8_t *__restrict__ code,
     const int32_t *__restrict__ dict, const double *__restrict__ val, const double *__restrict__ x,
     double *__restrict__ y, const double *__restrict__ w, double *__restrict__ part_wy,
     double *__restrict__ part_yy, const int *__restrict__ flag_done, int gen, int remap)
 {
-    constexpr int TILE = 2 * BLOCK * VPT;
+    constexpr int VPT = (TILE + 2 * BLOCK - 1) / (2 * BLOCK);  // 16-byte val loads per lane per tile
     constexpr int U = 8;
     constexpr int CPT = (TILE / 4 + BLOCK - 1) / BLOCK;      // 4-byte code words per lane per tile
+    static_assert(TILE % 4 == 0, "tiles are whole 4-byte code words");
     __shared__ double vl[TILE];
     __shared__ uint32_t cl4[TILE / 4];
     __shared__ int32_t dl[256];
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
 // ELLPACK, slot-major device layout: lane i owns row i and walks ALL max_d slots in
 // order (padding slots multiply 0.0 by x(last neighbour), exactly like the reference,
 // so a non-finite x entry propagates the same way).
-template <bool ADD, bool DOT_W, bool DOT_YY>
+template <int U, bool NT, bool ADD, bool DOT_W, bool DOT_YY>
 __global__ __launch_bounds__(kBlock) void k_ell_spmv(
     int32_t n, int32_t max_d, const int32_t *__restrict__ ecol, const double *__restrict__ eval,
     const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ w,
@@ -278,15 +279,17 @@ __global__ __launch_bounds__(kBlock) void k_ell_spmv(
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         double z = 0.0;
+        double wv = 0.0, y0 = 0.0;
+        if (DOT_W) wv = w[i];
+        if (ADD) y0 = y[i];
         int32_t k = 0;
-        constexpr int U = 8;
         for (; k + U <= max_d; k += U) {
             int32_t c[U];
             double v[U], xv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                c[u] = ecol[(int64_t)(k + u) * n + i];
-                v[u] = eval[(int64_t)(k + u) * n + i];
+                c[u] = ld_stream(ecol + (int64_t)(k + u) * n + i, NT);
+                v[u] = ld_stream(eval + (int64_t)(k + u) * n + i, NT);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) xv[u] = x[c[u]];
@@ -294,9 +297,9 @@ __global__ __launch_bounds__(kBlock) void k_ell_spmv(
             for (int u = 0; u < U; ++u) z = z + v[u] * xv[u];
         }
         for (; k < max_d; ++k) z = z + eval[(int64_t)k * n + i] * x[ecol[(int64_t)k * n + i]];
-        const double yi = ADD ? y[i] + z : 0.0 + z;
+        const double yi = ADD ? y0 + z : 0.0 + z;
         y[i] = yi;
-        if (DOT_W) dwy += w[i] * yi;
+        if (DOT_W) dwy += wv * yi;
         if (DOT_YY) dyy += yi * yi;
     }
     if (DOT_W) {
@@ -335,17 +338,26 @@ static SpmvCfg &spmv_cfg()
     return c;
 }
 
-static int resident_per_cu(bool dict, int block, int vpt);
+static int resident_per_cu(bool dict, int block, int v);
+int ell_grid(const Part &p);
 static bool use_offset_dict(const Part &p) { return p.code && g_opt.csr_offset_dict; }
 
-// tile (= 2*BLOCK*VPT entries) of the offset-dict kernel: the smallest one that holds a whole
-// row block of average density, so that a row block is one load phase + one gather phase
-static int do_vpt_for(const Part &p)
+// (BLOCK, TILE) instantiations of the offset-dict kernel.  TILE = entries staged in LDS per
+// pass (9 bytes each); the launcher picks the smallest one that holds a whole row block of
+// average density (+ alignment slack), so that a row block is one load phase + one gather
+// phase and the LDS footprint stays small enough for 8 workgroups per CU.
+#define SGM_DO_VARIANTS(X) X(256, 1024) X(256, 1536) X(256, 1920) X(256, 2048) X(512, 2048) X(512, 3072) X(512, 3840)
+static int do_tile_for(const Part &p)
 {
     const SpmvCfg &c = spmv_cfg();
-    if (c.do_vpt) return c.do_vpt;
+    static const int t256[] = {1024, 1536, 1920, 2048}, t512[] = {2048, 3072, 3840};
+    const int *tiles = c.block == 512 ? t512 : t256;
+    const int nt = c.block == 512 ? 3 : 4;
+    if (c.do_vpt) return tiles[std::min(std::max(c.do_vpt - 1, 0), nt - 1)];     // tuning override: 1..nt
     const double per_block = (double)p.nnz / (p.n > 0 ? p.n : 1) * c.block + 4;
-    return per_block <= 4.0 * c.block ? 2 : per_block <= 6.0 * c.block ? 3 : 4;
+    for (int i = 0; i < nt; ++i)
+        if (per_block <= tiles[i]) return tiles[i];
+    return tiles[nt - 1];
 }
 
 // Persistent grid: exactly the number of workgroups that are resident at once (LDS- or
@@ -353,11 +365,12 @@ static int do_vpt_for(const Part &p)
 // a tail, a smaller one leaves CUs idle (measured: 7-point, 19.5 KiB LDS: 1536 beats 2048).
 int spmv_grid(const Part &p)
 {
+    if (p.ecol) return ell_grid(p);
     const SpmvCfg &c = spmv_cfg();
     const int64_t nrb = ((int64_t)p.n + c.block - 1) / c.block;
     int64_t g = ((nrb + 7) / 8) * 8;
     int64_t cap = c.maxgrid;
-    if (cap <= 0) cap = (int64_t)resident_per_cu(use_offset_dict(p), c.block, use_offset_dict(p) ? do_vpt_for(p) : c.vpt) *
+    if (cap <= 0) cap = (int64_t)resident_per_cu(use_offset_dict(p), c.block, use_offset_dict(p) ? do_tile_for(p) : c.vpt) *
                         g_rt.num_cu;
     if (cap > kMaxGrid) cap = kMaxGrid;
     if (g > cap) g = cap / 8 * 8;
@@ -402,24 +415,40 @@ static void launch_csr_do(const Part &p, int grid, const double *x, double *y, c
 {
     const SpmvCfg &c = spmv_cfg();
     hipStream_t st = g_rt.stream;
-#define L(B, V, DW, DY)                                                                          \
-    hipLaunchKernelGGL((k_csr_do<B, V, ADD, DW, DY>), dim3(grid), dim3(B), 0, st, p.n, p.rowptr, \
+    const int tile = do_tile_for(p);
+#define L(B, T, DW, DY)                                                                          \
+    hipLaunchKernelGGL((k_csr_do<B, T, ADD, DW, DY>), dim3(grid), dim3(B), 0, st, p.n, p.rowptr, \
                        p.code, p.dict, p.val, x, y, w, pwy, pyy, flag, gen, c.remap)
-#define LV(B, V)                                \
-    {                                           \
-        if (w && pyy) L(B, V, true, true);      \
-        else if (w) L(B, V, true, false);       \
-        else if (pyy) L(B, V, false, true);     \
-        else L(B, V, false, false);             \
+#define LV(B, T)                                \
+    if (c.block == B && tile == T) {            \
+        if (w && pyy) L(B, T, true, true);      \
+        else if (w) L(B, T, true, false);       \
+        else if (pyy) L(B, T, false, true);     \
+        else L(B, T, false, false);             \
+        return;                                 \
     }
-    const int vpt = do_vpt_for(p);
-    if (c.block == 512) {
-        if (vpt == 2) LV(512, 2) else if (vpt == 3) LV(512, 3) else LV(512, 4)
-    } else {
-        if (vpt == 2) LV(256, 2) else if (vpt == 3) LV(256, 3) else LV(256, 4)
-    }
+    SGM_DO_VARIANTS(LV)
 #undef LV
 #undef L
+}
+
+// SGM_ELL_CFG="U,nt,grid": slots in flight per lane, nontemporal matrix loads, grid cap (tuning aid)
+struct EllCfg { int u = 8, nt = 1, grid = 2048; };
+static EllCfg &ell_cfg()
+{
+    static EllCfg c;
+    static bool init = false;
+    if (!init) {
+        init = true;
+        if (const char *e = getenv("SGM_ELL_CFG")) sscanf(e, "%d,%d,%d", &c.u, &c.nt, &c.grid);
+        if (c.grid > kMaxGrid) c.grid = kMaxGrid;
+    }
+    return c;
+}
+int ell_grid(const Part &p)
+{
+    int64_t g = ((int64_t)p.n + kBlock - 1) / kBlock;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(g, ell_cfg().grid));
 }
 
 template <bool ADD>
@@ -427,37 +456,44 @@ static void launch_ell(const Part &p, int grid, const double *x, double *y, cons
                        double *pwy, double *pyy, const int *flag, int gen)
 {
     hipStream_t st = g_rt.stream;
-#define L(DW, DY)                                                                         \
-    hipLaunchKernelGGL((k_ell_spmv<ADD, DW, DY>), dim3(grid), dim3(kBlock), 0, st, p.n,   \
+    const EllCfg &c = ell_cfg();
+#define L(UU, NTT, DW, DY)                                                                          \
+    hipLaunchKernelGGL((k_ell_spmv<UU, NTT, ADD, DW, DY>), dim3(grid), dim3(kBlock), 0, st, p.n,     \
                        p.max_d, p.ecol, p.eval, x, y, w, pwy, pyy, flag, gen)
-    if (w && pyy) L(true, true);
-    else if (w) L(true, false);
-    else if (pyy) L(false, true);
-    else L(false, false);
+#define LV(UU, NTT)                              \
+    {                                            \
+        if (w && pyy) L(UU, NTT, true, true);    \
+        else if (w) L(UU, NTT, true, false);     \
+        else if (pyy) L(UU, NTT, false, true);   \
+        else L(UU, NTT, false, false);           \
+    }
+    if (c.u >= 16) { if (c.nt) LV(16, true) else LV(16, false) }
+    else if (c.u <= 4) { if (c.nt) LV(4, true) else LV(4, false) }
+    else { if (c.nt) LV(8, true) else LV(8, false) }
+#undef LV
 #undef L
 }
 
 // Workgroups of one kernel variant that fit on a CU at once (occupancy API, cached).
-static int resident_per_cu(bool dict, int block, int vpt)
+// `v` is the TILE for the offset-dict kernel and VPT for the int32 kernel.
+static int resident_per_cu(bool dict, int block, int v)
 {
-    static int cache[2][3][5] = {};
-    const int bi = block == 256 ? 0 : block == 512 ? 1 : 2;
-    int &slot = cache[dict ? 1 : 0][bi][vpt < 5 ? vpt : 4];
-    if (slot) return slot;
+    static std::vector<std::pair<int, int>> cache;
+    const int key = (dict ? 1 << 30 : 0) | (block << 16) | v;
+    for (auto &kv : cache)
+        if (kv.first == key) return kv.second;
     const void *fn = nullptr;
-#define PICK_DO(B, V) if (block == B && vpt == V) fn = (const void *)k_csr_do<B, V, false, false, false>;
-#define PICK_ST(B, V) if (block == B && vpt == V) fn = (const void *)k_csr_spmv<B, V, true, false, false, false>;
-    if (dict) { PICK_DO(256, 2) PICK_DO(256, 3) PICK_DO(256, 4) PICK_DO(512, 2) PICK_DO(512, 3) PICK_DO(512, 4) }
-    else { PICK_ST(256, 2) PICK_ST(256, 4) PICK_ST(256, 8) PICK_ST(512, 2) PICK_ST(512, 4) PICK_ST(512, 8) PICK_ST(1024, 2) PICK_ST(1024, 4) }
+#define PICK_DO(B, T) if (dict && block == B && v == T) fn = (const void *)k_csr_do<B, T, false, false, false>;
+#define PICK_ST(B, V) if (!dict && block == B && v == V) fn = (const void *)k_csr_spmv<B, V, true, false, false, false>;
+    SGM_DO_VARIANTS(PICK_DO)
+    PICK_ST(256, 2) PICK_ST(256, 4) PICK_ST(256, 8) PICK_ST(512, 2) PICK_ST(512, 4) PICK_ST(512, 8) PICK_ST(1024, 2) PICK_ST(1024, 4)
 #undef PICK_DO
 #undef PICK_ST
     int nb = 0;
     if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, block, 0) != hipSuccess || nb < 1)
         nb = 2048 / block;
-    // every variant with dots / ADD uses a few more registers; stay one short of the edge
-    // only when the API answer is LDS-limited (it is exact for LDS)
-    slot = nb;
-    return slot;
+    cache.emplace_back(key, nb);
+    return nb;
 }
 
 int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
