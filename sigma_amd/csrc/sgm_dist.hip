@@ -21,6 +21,7 @@ namespace sgm {
 int build_csr_part(Part &p, int32_t n, int32_t ncol_own, int32_t n_halo, int64_t nnz,
                    const int32_t *ptr1, const int32_t *node1, const double *val, int where);
 void free_part(Part &p);
+void set_interior_range(Part &p, const int32_t *ptr1, const int32_t *node1);
 __global__ void k_gather(double *__restrict__ dst, const double *__restrict__ src,
                          const int32_t *__restrict__ idx, int32_t count);
 
@@ -76,9 +77,8 @@ static int load_rccl()
     } while (0)
 
 // ------------------------------------------------------------------ halo exchange
-int halo_exchange(sgm_mat A, double *const *xext)
+int halo_exchange(sgm_mat A, double *const *xext, hipStream_t st)
 {
-    hipStream_t st = g_rt.stream;
     if (A->comm) {
         Part &p = A->parts[0];
         if (p.nbrs.empty()) return SGM_OK;
@@ -227,6 +227,7 @@ int sgm_csr_create_partitioned(sgm_mat *out, int32_t nparts, const int64_t *row_
         if (rc == SGM_OK) rc = dalloc(&p.xext, (size_t)p.xlen());
         if (rc != SGM_OK) { sgm_mat_destroy(A); return rc; }
         p.row_begin = r0;
+        set_interior_range(p, lptr.data(), lnode.data());
     }
     // send lists: part q sends to part p the entries of p's halo that q owns, in p's halo order
     for (int ip = 0; ip < nparts; ++ip) {
@@ -335,6 +336,7 @@ int sgm_csr_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts, 
     }
     if (rc != SGM_OK) { sgm_mat_destroy(A); return rc; }
     p.row_begin = r0;
+    set_interior_range(p, ptr_h, lnode.data());
     { std::vector<int32_t>().swap(hnode); std::vector<int32_t>().swap(lnode); }
 
     // who needs what: want[q] = number of my halo entries owned by rank q

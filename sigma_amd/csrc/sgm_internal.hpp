@@ -42,6 +42,8 @@ struct Runtime {
     int device = -1;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t comm_stream = nullptr;      // halo exchange, overlapped with interior rows
+    hipEvent_t ev_x_ready = nullptr, ev_halo_done = nullptr;
     bool async = false;
     int num_cu = 256;
 };
@@ -98,6 +100,7 @@ struct Part {
     int32_t n = 0;                 // owned rows
     int32_t ncol_own = 0;          // owned columns (== n for the square partitions used)
     int32_t n_halo = 0;
+    int32_t int_lo = 0, int_hi = 0; // interior rows [int_lo, int_hi): only owned columns (when n_halo > 0)
     int64_t nnz = 0;
     int64_t row_begin = 0;         // first owned global row
     // CSR (device, 0-based; col indexes [owned | halo]); val/col padded by 2 entries
@@ -141,7 +144,7 @@ struct sgm_mat_s {
 namespace sgm {
 
 // exchange the halo part of an extended vector set (one pointer per local part)
-int halo_exchange(sgm_mat A, double *const *xext);
+int halo_exchange(sgm_mat A, double *const *xext, hipStream_t st);
 // sum `count` scalar slots across parts / ranks (in place, every part gets the total)
 int allreduce_slots(sgm_mat A, double *const *slot_ptrs, int count);
 

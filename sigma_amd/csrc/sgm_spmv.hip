@@ -363,19 +363,50 @@ static int do_tile_for(const Part &p)
 // Persistent grid: exactly the number of workgroups that are resident at once (LDS- or
 // wave-limited), rounded down to a multiple of 8 for the XCD map -- a larger grid only adds
 // a tail, a smaller one leaves CUs idle (measured: 7-point, 19.5 KiB LDS: 1536 beats 2048).
-int spmv_grid(const Part &p)
+static int grid_for_rows(const Part &p, int64_t rows, int64_t limit)
 {
-    if (p.ecol) return ell_grid(p);
     const SpmvCfg &c = spmv_cfg();
-    const int64_t nrb = ((int64_t)p.n + c.block - 1) / c.block;
+    const int64_t nrb = (rows + c.block - 1) / c.block;
     int64_t g = ((nrb + 7) / 8) * 8;
     int64_t cap = c.maxgrid;
     if (cap <= 0) cap = (int64_t)resident_per_cu(use_offset_dict(p), c.block, use_offset_dict(p) ? do_tile_for(p) : c.vpt) *
                         g_rt.num_cu;
-    if (cap > kMaxGrid) cap = kMaxGrid;
+    if (cap > limit) cap = limit;
     if (g > cap) g = cap / 8 * 8;
     if (g < 8) g = 8;
     return (int)g;
+}
+
+// Row ranges of one SpMV.  A part with halo columns is split so that the rows that touch
+// only owned columns ("interior", one contiguous run of row blocks found at setup) can run
+// while the halo exchange is still in flight; the head / tail ranges follow it.
+struct RowRange { int32_t lo, hi; int grid, part_off; };
+static int spmv_ranges(const Part &p, RowRange out[3])
+{
+    int nr = 0, off = 0;
+    auto add = [&](int32_t lo, int32_t hi) {       // grids sum to <= kMaxGrid partial slots
+        if (hi <= lo) return;
+        out[nr] = RowRange{lo, hi, grid_for_rows(p, hi - lo, nr == 0 ? kMaxGrid / 2 : kMaxGrid / 4), off};
+        off += out[nr].grid;
+        ++nr;
+    };
+    if (p.n_halo == 0 || p.int_hi <= p.int_lo) {
+        add(0, p.n > 0 ? p.n : 1);
+        if (nr) out[0].hi = p.n;
+        return nr;
+    }
+    add(p.int_lo, p.int_hi);      // interior first: it is launched before the halo has arrived
+    add(0, p.int_lo);
+    add(p.int_hi, p.n);
+    return nr;
+}
+
+int spmv_grid(const Part &p)       // = number of partial sums one SpMV leaves per fused dot
+{
+    if (p.ecol) return ell_grid(p);
+    RowRange r[3];
+    const int nr = spmv_ranges(p, r);
+    return nr ? r[nr - 1].part_off + r[nr - 1].grid : 8;
 }
 
 template <int BLOCK, int VPT, bool NT, bool ADD>
@@ -496,30 +527,97 @@ static int resident_per_cu(bool dict, int block, int v)
     return nb;
 }
 
+static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const double *x, double *y, bool add,
+                         const double *w, double *pwy, double *pyy, const int *flag_done, int gen)
+{
+    // a row range is the same kernel on shifted pointers: rowptr entries stay absolute offsets
+    // into val/col/code; the offset-dict kernel forms columns as row + offset, so x shifts too
+    Part v;
+    v.n = r.hi - r.lo;
+    v.nnz = p.nnz; v.n_halo = p.n_halo; v.ncol_own = p.ncol_own;
+    v.rowptr = p.rowptr + r.lo; v.col = p.col; v.val = p.val; v.code = p.code; v.dict = p.dict;
+    const bool dict = use_offset_dict(p);
+    const double *xs = dict ? x + r.lo : x;
+    double *ys = y + r.lo;
+    const double *ws = w ? w + r.lo : nullptr;
+    double *pw = pwy ? pwy + r.part_off : nullptr, *py = pyy ? pyy + r.part_off : nullptr;
+    if (dict) {
+        if (add) launch_csr_do<true>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
+        else launch_csr_do<false>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
+    } else {
+        if (add) launch_csr<true>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
+        else launch_csr<false>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
+    }
+}
+
 int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
                const SpmvDots *dots, const int *flag_done, int *grid_out, int gen)
 {
-    if (A->distributed()) SGM_TRY(halo_exchange(A, const_cast<double *const *>(x)));
-    for (size_t ip = 0; ip < A->parts.size(); ++ip) {
-        const Part &p = A->parts[ip];
-        const int grid = spmv_grid(p);
-        if (grid_out) *grid_out = grid;
-        const double *w = dots && dots->w ? dots->w[ip] : nullptr;
-        double *pwy = dots && dots->part_wy ? dots->part_wy[ip] : nullptr;
-        double *pyy = dots && dots->part_yy ? dots->part_yy[ip] : nullptr;
-        if (A->fmt == SGM_FMT_CSR && use_offset_dict(p)) {
-            if (add) launch_csr_do<true>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done, gen);
-            else launch_csr_do<false>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done, gen);
-        } else if (A->fmt == SGM_FMT_CSR) {
-            if (add) launch_csr<true>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done, gen);
-            else launch_csr<false>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done, gen);
-        } else {
-            if (add) launch_ell<true>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done, gen);
-            else launch_ell<false>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done, gen);
+    const size_t P = A->parts.size();
+    bool exchange = false;
+    if (A->distributed())
+        for (const Part &p : A->parts) exchange = exchange || !p.nbrs.empty();
+    if (exchange) {
+        // halo exchange on the communication stream, overlapped with the interior rows
+        if (!g_rt.comm_stream) {
+            SGM_HIP(hipStreamCreateWithFlags(&g_rt.comm_stream, hipStreamNonBlocking));
+            SGM_HIP(hipEventCreateWithFlags(&g_rt.ev_x_ready, hipEventDisableTiming));
+            SGM_HIP(hipEventCreateWithFlags(&g_rt.ev_halo_done, hipEventDisableTiming));
+        }
+        SGM_HIP(hipEventRecord(g_rt.ev_x_ready, g_rt.stream));
+        SGM_HIP(hipStreamWaitEvent(g_rt.comm_stream, g_rt.ev_x_ready, 0));
+        SGM_TRY(halo_exchange(A, const_cast<double *const *>(x), g_rt.comm_stream));
+        SGM_HIP(hipEventRecord(g_rt.ev_halo_done, g_rt.comm_stream));
+    }
+    for (int pass = 0; pass < 2; ++pass) {          // pass 0: ranges that need no halo; pass 1: the rest
+        if (pass == 1 && exchange) SGM_HIP(hipStreamWaitEvent(g_rt.stream, g_rt.ev_halo_done, 0));
+        for (size_t ip = 0; ip < P; ++ip) {
+            const Part &p = A->parts[ip];
+            const double *w = dots && dots->w ? dots->w[ip] : nullptr;
+            double *pwy = dots && dots->part_wy ? dots->part_wy[ip] : nullptr;
+            double *pyy = dots && dots->part_yy ? dots->part_yy[ip] : nullptr;
+            if (A->fmt != SGM_FMT_CSR) {
+                if (pass == 1) continue;
+                const int grid = ell_grid(p);
+                if (grid_out) *grid_out = grid;
+                if (add) launch_ell<true>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done, gen);
+                else launch_ell<false>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done, gen);
+                continue;
+            }
+            RowRange r[3];
+            const int nr = spmv_ranges(p, r);
+            if (grid_out) *grid_out = spmv_grid(p);
+            const bool split = nr > 1;              // r[0] is the interior range
+            for (int k = 0; k < nr; ++k) {
+                const bool needs_halo = !(split && k == 0) && p.n_halo > 0;
+                if ((pass == 1) != needs_halo) continue;
+                launch_range(A, p, r[k], x[ip], y[ip], add, w, pwy, pyy, flag_done, gen);
+            }
         }
     }
     SGM_HIP(hipGetLastError());
     return SGM_OK;
+}
+
+// Longest run of row blocks whose rows reference owned columns only (host index work at
+// setup; ptr1/node1 are the part's 1-based local arrays).
+void set_interior_range(Part &p, const int32_t *ptr1, const int32_t *node1)
+{
+    p.int_lo = 0;
+    p.int_hi = 0;
+    if (p.n_halo == 0 || p.n == 0) return;
+    const int B = spmv_cfg().block;
+    const int32_t nb = (p.n + B - 1) / B;
+    int32_t best_lo = 0, best_len = 0, run_lo = 0, run_len = 0;
+    for (int32_t b = 0; b < nb; ++b) {
+        const int32_t r0 = b * B, r1 = std::min(r0 + B, p.n);
+        bool halo = false;
+        for (int64_t k = ptr1[r0] - 1; k < ptr1[r1] - 1 && !halo; ++k) halo = node1[k] > p.ncol_own;
+        if (halo) { run_len = 0; run_lo = b + 1; continue; }
+        if (++run_len > best_len) { best_len = run_len; best_lo = run_lo; }
+    }
+    p.int_lo = best_lo * B;
+    p.int_hi = std::min<int32_t>((best_lo + best_len) * B, p.n);
 }
 
 // Offset dictionary of a row block (host index work at setup): distinct (col - row) values in

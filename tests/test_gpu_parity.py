@@ -444,6 +444,42 @@ def test_partitioned_matvec_bit_exact_and_cg(orc, nparts):
         assert np.abs(u - ur).max() / np.abs(ur).max() <= 1e-11
 
 
+@pytest.mark.parametrize("dict_opt", [1, 0])
+def test_partitioned_overlap_split_bit_exact(orc, dict_opt):
+    """Row blocks with halo columns are split into interior rows (run while the halo
+    exchange is in flight on a second stream) and head/tail rows; both CSR kernels (offset
+    dictionary and int32 columns) must reproduce the serial rows bit for bit, also with the
+    fused dot epilogues used by the solvers."""
+    sg.set_option("csr_offset_dict", dict_opt)
+    try:
+        for (ptr, node, val), n in ((P.poisson2d_csr(300, 200), 60000), (P.laplace3d_csr(30, 28, 40), 33600)):
+            A = orc.CsrMatrix(n, n, ptr, node, val)
+            for nparts in (2, 5):
+                starts = (np.arange(nparts + 1) * n // nparts) // 2 * 2
+                starts[-1] = n
+                H = sg.partitioned_csr_matrix(n, n, ptr, node, val, starts)
+                x = np.random.RandomState(nparts).standard_normal(n)
+                y = np.zeros(n)
+                H.matvec(x, y)
+                assert np.array_equal(y, A.matvec(x))
+                y0 = np.random.RandomState(1).standard_normal(n)
+                y = y0.copy()
+                H.matvec_add(x, y)
+                assert np.array_equal(y, A.matvec_add(x, y0.copy()))
+                b = np.full(n, 1.0 / n)
+                ur, itr, _, hr = orc.cg(A, b, tol=1e-30, max_iter=30, history=30)
+                s = sg.cg(1e-30)
+                s.set_max_iter(30)
+                s.set_history(30)
+                s.setup(H)
+                u = np.zeros(n)
+                s.solve(H, u, b, check=False)
+                assert (np.abs(s.history - hr) / hr).max() <= 1e-11
+                assert np.abs(u - ur).max() / np.abs(ur).max() <= 1e-12
+    finally:
+        sg.set_option("csr_offset_dict", 1)
+
+
 def test_rccl_single_rank(orc):
     """RCCL binding with a 1-rank communicator: bootstrap, distributed create, matvec, CG."""
     comm = sg.Comm(0, 1, sg.Comm.unique_id())
