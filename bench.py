@@ -41,6 +41,10 @@ def main():
     ap.add_argument("--ny", type=int, default=3162)
     ap.add_argument("--cg-steps", type=int, default=100)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c5"],
+                    help="c2: 5-point 2-D Poisson, nx*ny rows PER GPU (weak scaling, the BASELINE metric); "
+                         "c5: 7-point 3-D Laplacian m^3 (default 464^3) split in z-slabs over the GPUs (strong scaling)")
+    ap.add_argument("--c5-edge", type=int, default=464, help="grid edge m of the c5 workload (m^3 rows)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the RCCL row-partition code path even with one rank (testing aid)")
     args = ap.parse_args()
@@ -81,6 +85,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def sum_over_ranks(v):
+        if not use_dist:
+            return v
+        t = torch.tensor([float(v)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
     def max_over_ranks(v):
         if not use_dist:
             return v
@@ -88,26 +99,43 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    # ---- synthetic matrix: this rank's nx*ny rows of the nx x (world*ny) 5-point grid ----
+    # ---- synthetic matrix ------------------------------------------------------------------
     nx, ny = args.nx, args.ny
-    n_loc = nx * ny
-    n_glob = n_loc * world
-    ptr, node, val = P.poisson2d_csr(nx, ny * world) if world == 1 else (None, None, None)
+    ptr = node = val = None
+    if args.workload == "c2":
+        # this rank's nx*ny rows of the nx x (world*ny) 5-point grid (weak scaling)
+        n_loc = nx * ny
+        n_glob = n_loc * world
+        i0 = rank * n_loc
+        starts = np.arange(world + 1, dtype=np.int64) * n_loc
+        if not use_dist:
+            ptr, node, val = P.poisson2d_csr(nx, ny)
+            arrays = (torch.from_numpy(ptr).to(dev), torch.from_numpy(node).to(dev), torch.from_numpy(val).to(dev))
+        else:
+            arrays = local_rows_poisson2d(nx, ny, world, rank)
+        workload = (f"5-point 2D Poisson CSR, {nx}x{ny} rows per GPU", "weak")
+    else:
+        # z-slabs of the m^3 7-point grid (strong scaling), generated on the device
+        m = args.c5_edge
+        zs = [(m * r) // world for r in range(world + 1)]
+        starts = np.array([z * m * m for z in zs], dtype=np.int64)
+        i0, n_loc, n_glob = int(starts[rank]), int(starts[rank + 1] - starts[rank]), m ** 3
+        arrays = local_rows_laplace3d(m, int(zs[rank]), int(zs[rank + 1]), dev)
+        workload = (f"7-point 3D Laplacian CSR {m}^3 split in z-slabs over {world} GPU(s)", "strong")
+    nnz = int(arrays[2].numel() if hasattr(arrays[2], "numel") else len(arrays[2]))
     if not use_dist:
-        A = sg.csr_matrix(n_loc, n_loc, torch.from_numpy(ptr).to(dev), torch.from_numpy(node).to(dev),
-                          torch.from_numpy(val).to(dev))
-        nnz = len(val)
+        if args.workload == "c5":   # global == local numbering on one GPU
+            A = sg.csr_matrix(n_loc, n_loc, *arrays)
+        else:
+            A = sg.csr_matrix(n_loc, n_loc, *arrays)
         x_len = n_loc
     else:
-        # local rows of the global grid, built directly (same generator, rows sliced)
-        ptr_l, node_l, val_l = local_rows_poisson2d(nx, ny, world, rank)
         uid = [sg.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         comm = sg.Comm(rank, world, uid[0])
-        starts = np.arange(world + 1, dtype=np.int64) * n_loc
-        A = sg.dist_csr_matrix(comm, starts, ptr_l, node_l, val_l)
-        nnz = len(val_l)
+        A = sg.dist_csr_matrix(comm, starts, *arrays)
         x_len = A.x_len
+    del arrays
     x = torch.zeros(x_len, dtype=torch.float64, device=dev)
     i0 = rank * n_loc
     x[:n_loc] = torch.sin(0.001 * torch.arange(i0 + 1, i0 + n_loc + 1, dtype=torch.float64, device=dev))
@@ -125,7 +153,8 @@ def main():
     dt = time.perf_counter() - t0
     dt = max_over_ranks(dt)
     ms_per_step = 1e3 * dt / args.steps
-    value = bytes_rank * world * args.steps / dt / 1e9
+    bytes_all = sum_over_ranks(bytes_rank)
+    value = bytes_all * args.steps / dt / 1e9
 
     # ---- dominant kernel with HIP events on the launch stream -----------------------------
     def time_kernel(mat, reps=50):
@@ -171,7 +200,7 @@ def main():
         dtc = time.perf_counter() - t0
         dtc = max_over_ranks(dtc)
         its = s.last_iterations
-        cg_bytes = (bytes_rank + 72 * n_loc) * world     # SURVEY §8d fused floor B_csr + 72 n
+        cg_bytes = sum_over_ranks(bytes_rank + 72 * n_loc)     # SURVEY §8d fused floor B_csr + 72 n
         cg = {"iters_per_s": its / dtc, "iterations": its, "ms_per_iter": 1e3 * dtc / its,
               "bytes_per_iter": cg_bytes, "GB/s": cg_bytes * its / dtc / 1e9,
               "frac_of_hbm_peak": cg_bytes * its / dtc / 1e9 / (HBM_PEAK_GBS * world),
@@ -179,7 +208,7 @@ def main():
 
     # ---- CPU baseline: the oracle (1 thread, like the reference) on a bounded sample -------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu and ptr is not None:
         import oracle as orc
         # the SAME matrix as the GPU workload (800 MB per matvec: far beyond any host cache)
         Ao = orc.CsrMatrix(n_loc, n_loc, ptr, node, val)
@@ -194,7 +223,7 @@ def main():
     # come from the committed rocprofv3 --pmc passes over this same command (profiles/)
     traffic, traffic_src = None, None
     tf = os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")
-    if os.path.exists(tf) and world == 1 and (nx, ny) == (3162, 3162):
+    if os.path.exists(tf) and world == 1 and (nx, ny) == (3162, 3162) and args.workload == "c2":
         tj = json.load(open(tf))
         traffic, traffic_src = tj.get("hbm_traffic_bytes"), "profiles/r01/pmc_hbm_traffic.json"
 
@@ -202,10 +231,10 @@ def main():
         out = {
             "metric": "SpMV GB/s (achieved HBM) + CG iters/sec on 5-pt Laplacian, N=1e7",
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": workload[1], "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"5-point 2D Poisson CSR, {nx}x{ny} rows per GPU (n={n_loc}/GPU, nnz={nnz}/GPU), "
-                                   "fp64 SpMV y=A*x", "rows_per_gpu": n_loc, "nnz_per_gpu": int(nnz),
+            "config": {"workload": f"{workload[0]} (rank 0: n={n_loc}, nnz={nnz}), fp64 SpMV y=A*x",
+                       "rows_per_gpu": n_loc, "nnz_per_gpu": int(nnz),
                        "parallelism": f"row-partition x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -220,6 +249,24 @@ def main():
     if use_dist:
         barrier()
         dist.destroy_process_group()
+
+
+def local_rows_laplace3d(m, z0, z1, dev):
+    """Rows of the planes [z0, z1) of the m^3 7-point grid, built on the device: local 1-based
+    ptr, GLOBAL 1-based node, val; entry order -z,-y,-x,C,+x,+y,+z like problems.laplace3d_csr."""
+    import torch
+    pl = m * m
+    k = torch.arange(z0 * pl, z1 * pl, device=dev, dtype=torch.int64)
+    i, j, l = k % m, (k // m) % m, k // pl
+    one = torch.ones_like(k, dtype=torch.bool)
+    offs = [(-pl, l > 0, -1.0), (-m, j > 0, -1.0), (-1, i > 0, -1.0), (0, one, 6.0), (1, i < m - 1, -1.0),
+            (m, j < m - 1, -1.0), (pl, l < m - 1, -1.0)]
+    mask = torch.stack([mk for _, mk, _ in offs], dim=1)
+    ptr = torch.ones(k.numel() + 1, dtype=torch.int64, device=dev)
+    ptr[1:] += torch.cumsum(mask.sum(dim=1), 0)
+    cols = torch.stack([k + 1 + o for o, _, _ in offs], dim=1)[mask].to(torch.int32)
+    vals = torch.tensor([v for _, _, v in offs], dtype=torch.float64, device=dev).expand(k.numel(), -1)[mask].contiguous()
+    return ptr.to(torch.int32), cols, vals
 
 
 def local_rows_poisson2d(nx, ny, world, rank):

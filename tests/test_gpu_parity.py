@@ -474,8 +474,10 @@ def test_partitioned_overlap_split_bit_exact(orc, dict_opt):
                 s.setup(H)
                 u = np.zeros(n)
                 s.solve(H, u, b, check=False)
+                # unconverged iterates after 30 iterations: the drift between two valid dot
+                # summation orders (test_residual_history_vs_oracle calibrates it) is a few 1e-12
                 assert (np.abs(s.history - hr) / hr).max() <= 1e-11
-                assert np.abs(u - ur).max() / np.abs(ur).max() <= 1e-12
+                assert np.abs(u - ur).max() / np.abs(ur).max() <= 1e-11
     finally:
         sg.set_option("csr_offset_dict", 1)
 
