@@ -66,8 +66,6 @@ inline void dfree(void *p) { if (p) (void)hipFree(p); }
 // ------------------------------------------------------------------ launch geometry
 constexpr int kBlock = 256;          // 4 waves of 64
 constexpr int kMaxGrid = 4096;       // partial-sum slots per dot (>= the largest grid)
-constexpr int kTile = 2048;          // nnz products staged in LDS per tile (16 KiB)
-constexpr int kSlots = 32;           // device scalar slots per solver part
 
 inline int vec_grid(int64_t n)
 {
@@ -135,10 +133,6 @@ struct sgm_mat_s {
     std::vector<sgm::Part> parts;  // 1 unless created with sgm_csr_create_partitioned
     sgm_comm comm = nullptr;       // RCCL communicator when distributed over processes
     bool distributed() const { return comm != nullptr || parts.size() > 1; }
-    // host copies kept for host-side setup work (ILDU factorisation, Jacobi); 1-based
-    std::vector<int32_t> h_ptr, h_node;
-    std::vector<double> h_val;
-    bool host_copy = false;
 };
 
 namespace sgm {

@@ -79,15 +79,6 @@ struct FCopy {
     __device__ void single(int64_t i) { dst[i] = src[i]; }
     __device__ void finish(double *) {}
 };
-// dst = value
-struct FFill {
-    static constexpr bool kDot = false;
-    double *dst; double v;
-    __device__ bool prepare(double *) { return true; }
-    __device__ void pair(int64_t i) { D2(dst)[i] = make_double2(v, v); }
-    __device__ void single(int64_t i) { dst[i] = v; }
-    __device__ void finish(double *) {}
-};
 // up to two dots: a.b -> part0, c.d -> part1 (c == nullptr: one dot)
 struct FDot2 {
     const double *a, *b, *c, *d; double *part0, *part1;

@@ -7,14 +7,16 @@
 // stored order; `matvec` returns 0.0 + z like `y = 0; y(i) = y(i) + z`
 // (linear_operator_interface.f90:191-192).
 //
-// CSR kernel ("stream" form): a 256-thread workgroup owns 256 consecutive rows.  The
-// nnz range of those rows is contiguous in val/col, so it is streamed in tiles of 2048
-// entries with 16-byte (val) / 8-byte (col) coalesced loads by ALL lanes regardless of
-// row lengths; each lane multiplies its two entries by the gathered x values and parks
-// the products in LDS (16 KiB).  After the barrier lane i walks row i's products in LDS
-// in order.  HBM sees only wide streaming reads; the x gather is served by L2 (the
-// workgroup -> row-block map keeps consecutive row blocks on one XCD).
-// Algorithmic bytes per SpMV: 12*nnz + 4*(n+1) + 8*m + 8*n.
+// Two CSR kernels share one structure: a 256-thread workgroup owns 256 consecutive rows of
+// a persistent grid sweep; the nnz range of those rows is contiguous in val/col, so it is
+// streamed in LDS-sized tiles with 16-byte coalesced (nontemporal) loads by ALL lanes
+// regardless of row lengths, and after a barrier lane i adds row i's terms in stored order.
+//   k_csr_spmv  int32 columns (any matrix): the x gather happens while streaming (two
+//               entries per lane), products are parked in LDS.                12 B / entry
+//   k_csr_do    1-byte dictionary-coded column offsets (stencil-like matrices): val and
+//               codes are parked in LDS, the row's owner gathers x.            9 B / entry
+// The x gather is served by L2 (the workgroup -> row-block map keeps consecutive row blocks
+// on one XCD).  Algorithmic bytes per SpMV: 12*nnz + 4*(n+1) + 8*m + 8*n.
 #include "sgm_internal.hpp"
 
 #include <algorithm>
@@ -52,9 +54,14 @@ __global__ void k_ell_transpose(const int32_t *__restrict__ node, const double *
 // the blocks of one XCD take CONSECUTIVE row blocks inside each sweep of the grid: the x
 // entries they gather (own rows +- the stencil reach) stay in that XCD's 4 MiB L2.
 // Bijective because the grid is a multiple of 8.  Placement only changes speed.
-__device__ inline int64_t rowblock_of(int it, int b, int grid)
+__device__ inline int64_t rowblock_of(int it, int b, int grid, int64_t nrb = 0, int mode = 1)
 {
     const int per = grid >> 3;
+    if (mode == 2) {        // XCD-major: every XCD walks its own contiguous eighth of the rows
+        const int64_t chunk = (nrb + 7) / 8;
+        const int64_t local = (int64_t)it * per + (b >> 3);
+        return local < chunk ? (int64_t)(b & 7) * chunk + local : nrb;
+    }
     return (int64_t)it * grid + (int64_t)(b & 7) * per + (b >> 3);
 }
 
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_spmv(
 
     for (int it = 0;; ++it) {
         if ((int64_t)it * gridDim.x >= nrb) break;
-        const int64_t rb = remap ? rowblock_of(it, blockIdx.x, gridDim.x) : (int64_t)it * gridDim.x + blockIdx.x;
+        const int64_t rb = remap ? rowblock_of(it, blockIdx.x, gridDim.x, nrb, remap) : (int64_t)it * gridDim.x + blockIdx.x;
         if (rb >= nrb) continue;          // uniform per block
         const int32_t r0 = (int32_t)(rb * BLOCK);
         const int32_t r1 = min(r0 + BLOCK, n);
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
 
     for (int it = 0;; ++it) {
         if ((int64_t)it * gridDim.x >= nrb) break;
-        const int64_t rb = remap ? rowblock_of(it, blockIdx.x, gridDim.x) : (int64_t)it * gridDim.x + blockIdx.x;
+        const int64_t rb = remap ? rowblock_of(it, blockIdx.x, gridDim.x, nrb, remap) : (int64_t)it * gridDim.x + blockIdx.x;
         if (rb >= nrb) continue;
         const int32_t r0 = (int32_t)(rb * BLOCK);
         const int32_t r1 = min(r0 + BLOCK, n);

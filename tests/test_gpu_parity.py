@@ -444,6 +444,33 @@ def test_partitioned_matvec_bit_exact_and_cg(orc, nparts):
         assert np.abs(u - ur).max() / np.abs(ur).max() <= 1e-11
 
 
+def test_partitioned_gmres_and_pbicgstab(orc):
+    """The remaining solver/preconditioner combinations on a 3-way in-process row partition."""
+    g_edges = P.random_spd_edges(400, seed=9, skew=True)
+    A = orc.CsrMatrix.from_edges(400, 400, *g_edges)
+    starts = np.array([0, 134, 266, 400])
+    H = sg.partitioned_csr_matrix(400, 400, A.ptr, A.node, A.val, starts)
+    b = P.test_vector(400)
+    ur, itr, _, _ = orc.gmres(A, b, tol=1e-12, restart=30)
+    s = sg.gmres(1e-12, 30)
+    s.setup(H)
+    u = np.zeros(400)
+    s.solve(H, u, b)
+    assert abs(s.iterations - itr) <= 2 and np.abs(u - ur).max() / np.abs(ur).max() <= 1e-10
+    ur, itr, _, _ = orc.bicgstab(A, b, tol=1e-12, pc=orc.Jacobi(A))
+    s = sg.bicgstab(1e-12)
+    s.setup(H)
+    pc = sg.jacobi()
+    pc.setup(H)
+    u = np.zeros(400)
+    s.solve(H, u, b, pc)
+    assert abs(s.iterations - itr) <= 2 and np.abs(u - ur).max() / np.abs(ur).max() <= 1e-10
+    # ILDU(0) is refused on a partitioned matrix (global dependency chain), loudly
+    with pytest.raises(sg.SigmaError) as e:
+        sg.ldu().setup(H)
+    assert e.value.code == 8
+
+
 @pytest.mark.parametrize("dict_opt", [1, 0])
 def test_partitioned_overlap_split_bit_exact(orc, dict_opt):
     """Row blocks with halo columns are split into interior rows (run while the halo

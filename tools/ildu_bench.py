@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""ILDU(0)-PCG vs Jacobi-PCG vs CG on a 2-D Poisson grid: iterations and time (one GPU)."""
+import sys, os, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import sigma_amd as sg
+from sigma_amd import problems as P
+nx = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+n = nx * nx
+ptr, node, val = P.poisson2d_csr(nx, nx)
+sg.init(0)
+A = sg.csr_matrix(n, n, ptr, node, val)
+b = np.full(n, 1.0 / n)
+for name, mk in (("cg", None), ("jacobi", sg.jacobi), ("ildu0", sg.ldu)):
+    pc = mk() if mk else None
+    t0 = time.time()
+    if pc:
+        pc.setup(A)
+    tset = time.time() - t0
+    s = sg.cg(1e-8)
+    s.setup(A)
+    u = np.zeros(n)
+    t0 = time.time()
+    s.solve(A, u, b, pc)
+    dt = time.time() - t0
+    extra = {}
+    if name == "ildu0":
+        extra["levels"] = pc.get("levels", np.int32).tolist()
+    print(json.dumps({"grid": nx, "pc": name, "setup_s": tset, "iterations": s.iterations, "solve_s": dt,
+                      "ms_per_iter": 1e3 * dt / max(s.iterations, 1), **extra}), flush=True)
