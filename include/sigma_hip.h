@@ -92,6 +92,15 @@ int sgm_ell_create(sgm_mat *out, int32_t nrow, int32_t ncol, int32_t max_d,
 int sgm_ell_set_values(sgm_mat A, const double *val_colmajor, int where);
 int sgm_mat_matvec(sgm_mat A, const double *x, double *y, int where);
 int sgm_mat_matvec_add(sgm_mat A, const double *x, double *y, int where);
+/* sgm_mat_matvec_t     <- A%matvec_t(x,y): y = 0 ; matvec_t_add
+ *                         src/linear_operator/linear_operator_interface.f90:199-208
+ * sgm_mat_matvec_t_add <- csc_matvec_add (the csr transpose kernel) cs_matrices.f90:627-647 /
+ *                         ellpack_matvec_t_add ellpack_matrices.f90:670-693
+ * x has nrow entries, y has ncol.  The reference scatters y(node(k)) += val(k)*x(j); here an
+ * explicit transpose is built on first use so that every y(i) is summed in that same order
+ * (bit-identical, no atomics).  Single-GPU matrices only.                               */
+int sgm_mat_matvec_t(sgm_mat A, const double *x, double *y, int where);
+int sgm_mat_matvec_t_add(sgm_mat A, const double *x, double *y, int where);
 int sgm_mat_info(sgm_mat A, int32_t *nrow, int32_t *ncol, int64_t *nnz, int32_t *fmt,
                  int64_t *x_len /* entries matvec reads from x: ncol, or owned+halo when distributed */);
 int sgm_mat_destroy(sgm_mat A);

@@ -101,6 +101,15 @@ class CsrMatrix:
                          _p(self.node), _p(self.val), _p(x), _p(y))
         return y
 
+    def matvec_t_add(self, x, y):
+        x = np.ascontiguousarray(x, F8)
+        lib().orc_csr_matvec_t_add(C.c_int32(self.n), _p(self.ptr), _p(self.node), _p(self.val),
+                                   _p(x), _p(y))
+        return y
+
+    def matvec_t(self, x):       # linear_operator_interface.f90:199-208: y = 0 ; matvec_t_add
+        return self.matvec_t_add(x, np.zeros(self.m, F8))
+
 
 class EllMatrix:
     """ellpack_matrix restatement: node/val as Fortran (max_d, n) column-major, kept
@@ -141,6 +150,15 @@ class EllMatrix:
         lib().orc_matvec(C.c_int32(2), C.c_int32(self.n), C.c_int32(self.max_d), None,
                          _p(self.node), _p(self.val), _p(x), _p(y))
         return y
+
+    def matvec_t_add(self, x, y):
+        x = np.ascontiguousarray(x, F8)
+        lib().orc_ell_matvec_t_add(C.c_int32(self.n), C.c_int32(self.max_d), _p(self.node),
+                                   _p(self.val), _p(x), _p(y))
+        return y
+
+    def matvec_t(self, x):
+        return self.matvec_t_add(x, np.zeros(self.m, F8))
 
 
 class Jacobi:

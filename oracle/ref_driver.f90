@@ -40,7 +40,7 @@ implicit none
     character(len=512) :: infile, outprefix
     integer :: n, m, ne, fmt, nsolve, k, s, its
     integer, allocatable :: ei(:), ej(:), skind(:), pkind(:)
-    real(dp), allocatable :: ev(:), x(:), b(:), y(:), u(:), z(:), tols(:)
+    real(dp), allocatable :: ev(:), x(:), b(:), y(:), u(:), z(:), tols(:), yt(:)
     class(graph_interface), pointer :: g
     type(csr_matrix), target :: Acsr
     type(ellpack_matrix), target :: Aell
@@ -118,6 +118,19 @@ implicit none
     call dump_f8('y', y, n)
     call A%matvec_add(x, y)
     call dump_f8('y_add', y, n)
+
+    !------------------------------------------------------------------!
+    ! transpose products: yt = A^T b ; yt = yt + A^T b                  !
+    ! (linear_operator_interface.f90:199-208 -> csc_matvec_add          !
+    !  cs_matrices.f90:627-647 / ellpack_matvec_t_add                   !
+    !  ellpack_matrices.f90:670-693)                                    !
+    !------------------------------------------------------------------!
+    allocate(yt(m))
+    yt = -7.0_dp
+    call A%matvec_t(b, yt)
+    call dump_f8('yt', yt, m)
+    call A%matvec_t_add(b, yt)
+    call dump_f8('yt_add', yt, m)
 
     !------------------------------------------------------------------!
     ! Solves                                                            !

@@ -174,6 +174,36 @@ ORC_API void orc_ell_matvec_add(int32_t n, int32_t max_d, const int32_t *node,
     }
 }
 
+/* csc_matvec_add applied to a csr_matrix = the transpose product
+ * (src/matrix/formats/cs_matrices.f90:627-647, bound as csr matvec_t_add_impl):
+ * for j: z = x(j); for k in row j: y(node(k)) = y(node(k)) + val(k)*z */
+ORC_API void orc_csr_matvec_t_add(int32_t n, const int32_t *ptr, const int32_t *node,
+                                  const double *val, const double *x, double *y)
+{
+    for (int32_t j = 1; j <= n; j++) {
+        double z = x[j - 1];
+        for (int32_t k = ptr[j - 1]; k <= ptr[j] - 1; k++) {
+            int32_t i = node[k - 1];
+            y[i - 1] = y[i - 1] + val[k - 1] * z;
+        }
+    }
+}
+
+/* ellpack_matvec_t_add (src/matrix/formats/ellpack_matrices.f90:670-693): all max_d slots */
+ORC_API void orc_ell_matvec_t_add(int32_t n, int32_t max_d, const int32_t *node,
+                                  const double *val, const double *x, double *y)
+{
+    for (int32_t j = 1; j <= n; j++) {
+        double z = x[j - 1];
+        const int32_t *row = node + (size_t)(j - 1) * max_d;
+        const double *vrow = val + (size_t)(j - 1) * max_d;
+        for (int32_t k = 0; k < max_d; k++) {
+            int32_t i = row[k];
+            y[i - 1] = y[i - 1] + vrow[k] * z;
+        }
+    }
+}
+
 /* A generic operator handle for the solvers: fmt 1 = CSR, 2 = ELLPACK. */
 typedef struct {
     int32_t fmt, n, max_d;

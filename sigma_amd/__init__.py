@@ -150,6 +150,19 @@ class _Matrix:
         _ck(lib().sgm_mat_matvec_add(self._h, px, py, C.c_int(_same_where(wx, wy))))
         return y
 
+    # -- linear_operator_interface.f90:199-208 ------------------------------------------
+    def matvec_t(self, x, y):
+        px, wx, _k1 = _arg(x, np.float64)
+        py, wy, _k2 = _arg(y, np.float64, writable=True)
+        _ck(lib().sgm_mat_matvec_t(self._h, px, py, C.c_int(_same_where(wx, wy))))
+        return y
+
+    def matvec_t_add(self, x, y):
+        px, wx, _k1 = _arg(x, np.float64)
+        py, wy, _k2 = _arg(y, np.float64, writable=True)
+        _ck(lib().sgm_mat_matvec_t_add(self._h, px, py, C.c_int(_same_where(wx, wy))))
+        return y
+
     @property
     def x_len(self):
         n = C.c_int64(0)

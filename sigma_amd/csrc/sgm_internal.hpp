@@ -133,6 +133,11 @@ struct sgm_mat_s {
     std::vector<sgm::Part> parts;  // 1 unless created with sgm_csr_create_partitioned
     sgm_comm comm = nullptr;       // RCCL communicator when distributed over processes
     bool distributed() const { return comm != nullptr || parts.size() > 1; }
+    // explicit transpose for matvec_t (built on first use; rows sorted by (source row, slot) so
+    // that every y(i) receives its terms in the reference's order)
+    sgm_mat_s *T = nullptr;
+    int32_t *tperm = nullptr;      // device: position in this matrix's val/eval of each entry of T
+    bool t_stale = true;
 };
 
 namespace sgm {
@@ -150,7 +155,8 @@ struct SpmvDots {
     double *const *part_yy = nullptr;   // per part partial arrays or nullptr
 };
 int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
-               const SpmvDots *dots, const int *flag_done, int *grid_out, int gen = 0x7fffffff);
+               const SpmvDots *dots, const int *flag_done, int *grid_out, int gen = 0x7fffffff,
+               bool chain = false);
 
 int spmv_grid(const Part &p);
 

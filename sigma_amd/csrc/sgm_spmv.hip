@@ -88,12 +88,14 @@ __global__ __launch_bounds__(BLOCK) void k_csr_spmv(
     if (flag_done) { const int st = *flag_done; if (st && gen >= st) return; }
 
     const int tid = threadIdx.x;
+    const bool chain = (remap & 256) != 0;      // launch flag bits above the XCD-map mode
+    const int rmode = remap & 255;
     const int64_t nrb = ((int64_t)n + BLOCK - 1) / BLOCK;
     double dwy = 0.0, dyy = 0.0;
 
     for (int it = 0;; ++it) {
         if ((int64_t)it * gridDim.x >= nrb) break;
-        const int64_t rb = remap ? rowblock_of(it, blockIdx.x, gridDim.x, nrb, remap) : (int64_t)it * gridDim.x + blockIdx.x;
+        const int64_t rb = rmode ? rowblock_of(it, blockIdx.x, gridDim.x, nrb, rmode) : (int64_t)it * gridDim.x + blockIdx.x;
         if (rb >= nrb) continue;          // uniform per block
         const int32_t r0 = (int32_t)(rb * BLOCK);
         const int32_t r1 = min(r0 + BLOCK, n);
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_spmv(
         }
         const int32_t s = rowptr[r0] & ~1;    // tile starts are even: 16-B aligned val loads
         const int32_t e = rowptr[r1];
-        double z = 0.0;
+        double z = (ADD && chain) ? y0 : 0.0;   // chain: the row sum continues from y(i) (transpose products)
 
         for (int32_t ts = s; ts < e; ts += TILE) {
             const int32_t te = min(ts + TILE, e);
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_spmv(
             __syncthreads();
         }
         if (row < n) {
-            const double yi = ADD ? y0 + z : 0.0 + z;
+            const double yi = ADD ? (chain ? z : y0 + z) : 0.0 + z;
             if (NT) __builtin_nontemporal_store(yi, y + row); else y[row] = yi;
             if (DOT_W) dwy += wv * yi;
             if (DOT_YY) dyy += yi * yi;
@@ -185,13 +187,15 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
     const uint8_t *cl = reinterpret_cast<const uint8_t *>(cl4);
 
     const int tid = threadIdx.x;
+    const bool chain = (remap & 256) != 0;      // launch flag bits above the XCD-map mode
+    const int rmode = remap & 255;
     for (int t = tid; t < 256; t += BLOCK) dl[t] = dict[t];
     const int64_t nrb = ((int64_t)n + BLOCK - 1) / BLOCK;
     double dwy = 0.0, dyy = 0.0;
 
     for (int it = 0;; ++it) {
         if ((int64_t)it * gridDim.x >= nrb) break;
-        const int64_t rb = remap ? rowblock_of(it, blockIdx.x, gridDim.x, nrb, remap) : (int64_t)it * gridDim.x + blockIdx.x;
+        const int64_t rb = rmode ? rowblock_of(it, blockIdx.x, gridDim.x, nrb, rmode) : (int64_t)it * gridDim.x + blockIdx.x;
         if (rb >= nrb) continue;
         const int32_t r0 = (int32_t)(rb * BLOCK);
         const int32_t r1 = min(r0 + BLOCK, n);
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
         }
         const int32_t s = rowptr[r0] & ~3;    // tiles start at multiples of 4 entries: aligned 4-B code loads
         const int32_t e = rowptr[r1];
-        double z = 0.0;
+        double z = (ADD && chain) ? y0 : 0.0;   // chain: the row sum continues from y(i) (transpose products)
 
         for (int32_t ts = s; ts < e; ts += TILE) {
             const int32_t te = min(ts + TILE, e);
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
             }
         }
         if (row < n) {
-            const double yi = ADD ? y0 + z : 0.0 + z;
+            const double yi = ADD ? (chain ? z : y0 + z) : 0.0 + z;
             __builtin_nontemporal_store(yi, y + row);
             if (DOT_W) dwy += wv * yi;
             if (DOT_YY) dyy += yi * yi;
@@ -278,17 +282,18 @@ template <int U, bool NT, bool ADD, bool DOT_W, bool DOT_YY>
 __global__ __launch_bounds__(kBlock) void k_ell_spmv(
     int32_t n, int32_t max_d, const int32_t *__restrict__ ecol, const double *__restrict__ eval,
     const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ w,
-    double *__restrict__ part_wy, double *__restrict__ part_yy, const int *__restrict__ flag_done, int gen)
+    double *__restrict__ part_wy, double *__restrict__ part_yy, const int *__restrict__ flag_done, int gen,
+    int chain)
 {
     __shared__ double red[kBlock / 64];
     if (flag_done) { const int st = *flag_done; if (st && gen >= st) return; }
     double dwy = 0.0, dyy = 0.0;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        double z = 0.0;
         double wv = 0.0, y0 = 0.0;
         if (DOT_W) wv = w[i];
         if (ADD) y0 = y[i];
+        double z = (ADD && chain) ? y0 : 0.0;
         int32_t k = 0;
         for (; k + U <= max_d; k += U) {
             int32_t c[U];
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void k_ell_spmv(
             for (int u = 0; u < U; ++u) z = z + v[u] * xv[u];
         }
         for (; k < max_d; ++k) z = z + eval[(int64_t)k * n + i] * x[ecol[(int64_t)k * n + i]];
-        const double yi = ADD ? y0 + z : 0.0 + z;
+        const double yi = ADD ? (chain ? z : y0 + z) : 0.0 + z;
         y[i] = yi;
         if (DOT_W) dwy += wv * yi;
         if (DOT_YY) dyy += yi * yi;
@@ -329,6 +334,8 @@ __global__ void k_gather(double *__restrict__ dst, const double *__restrict__ sr
 // ---------------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------------
+static int g_launch_flags = 0;        // 256: chained accumulation (see k_csr_* `chain`)
+
 // Launch configuration of the CSR kernel.  SGM_SPMV_CFG="block,vpt,nt,maxgrid,remap"
 // overrides the default (tuning aid; results do not depend on it).
 struct SpmvCfg { int block = 256, vpt = 2, nt = 1, maxgrid = 0, remap = 1, do_vpt = 0; };   // 0 = automatic
@@ -438,13 +445,13 @@ static void launch_csr(const Part &p, int grid, const double *x, double *y, cons
     const SpmvCfg &c = spmv_cfg();
 #define CFG(B, V)                                                                              \
     if (c.block == B && c.vpt == V) {                                                          \
-        if (c.nt) launch_csr_cfg<B, V, true, ADD>(p, grid, x, y, w, pwy, pyy, flag, gen, c.remap);  \
-        else launch_csr_cfg<B, V, false, ADD>(p, grid, x, y, w, pwy, pyy, flag, gen, c.remap);      \
+        if (c.nt) launch_csr_cfg<B, V, true, ADD>(p, grid, x, y, w, pwy, pyy, flag, gen, c.remap | g_launch_flags);  \
+        else launch_csr_cfg<B, V, false, ADD>(p, grid, x, y, w, pwy, pyy, flag, gen, c.remap | g_launch_flags);      \
         return;                                                                                \
     }
     CFG(256, 2) CFG(256, 4) CFG(256, 8) CFG(512, 2) CFG(512, 4) CFG(512, 8) CFG(1024, 2) CFG(1024, 4)
 #undef CFG
-    launch_csr_cfg<256, 2, true, ADD>(p, grid, x, y, w, pwy, pyy, flag, gen, c.remap);
+    launch_csr_cfg<256, 2, true, ADD>(p, grid, x, y, w, pwy, pyy, flag, gen, c.remap | g_launch_flags);
 }
 
 template <bool ADD>
@@ -456,7 +463,7 @@ static void launch_csr_do(const Part &p, int grid, const double *x, double *y, c
     const int tile = do_tile_for(p);
 #define L(B, T, DW, DY)                                                                          \
     hipLaunchKernelGGL((k_csr_do<B, T, ADD, DW, DY>), dim3(grid), dim3(B), 0, st, p.n, p.rowptr, \
-                       p.code, p.dict, p.val, x, y, w, pwy, pyy, flag, gen, c.remap)
+                       p.code, p.dict, p.val, x, y, w, pwy, pyy, flag, gen, c.remap | g_launch_flags)
 #define LV(B, T)                                \
     if (c.block == B && tile == T) {            \
         if (w && pyy) L(B, T, true, true);      \
@@ -497,7 +504,7 @@ static void launch_ell(const Part &p, int grid, const double *x, double *y, cons
     const EllCfg &c = ell_cfg();
 #define L(UU, NTT, DW, DY)                                                                          \
     hipLaunchKernelGGL((k_ell_spmv<UU, NTT, ADD, DW, DY>), dim3(grid), dim3(kBlock), 0, st, p.n,     \
-                       p.max_d, p.ecol, p.eval, x, y, w, pwy, pyy, flag, gen)
+                       p.max_d, p.ecol, p.eval, x, y, w, pwy, pyy, flag, gen, g_launch_flags & 256)
 #define LV(UU, NTT)                              \
     {                                            \
         if (w && pyy) L(UU, NTT, true, true);    \
@@ -558,9 +565,10 @@ static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const doub
 }
 
 int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
-               const SpmvDots *dots, const int *flag_done, int *grid_out, int gen)
+               const SpmvDots *dots, const int *flag_done, int *grid_out, int gen, bool chain)
 {
     const size_t P = A->parts.size();
+    g_launch_flags = chain ? 256 : 0;
     bool exchange = false;
     if (A->distributed())
         for (const Part &p : A->parts) exchange = exchange || !p.nbrs.empty();
@@ -602,6 +610,7 @@ int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
             }
         }
     }
+    g_launch_flags = 0;
     SGM_HIP(hipGetLastError());
     return SGM_OK;
 }
@@ -744,6 +753,97 @@ int stage_out(const Staged &s, double *v, int64_t n, int where)
     return SGM_OK;
 }
 
+__global__ void k_gather_perm(double *__restrict__ dst, const double *__restrict__ src,
+                              const int32_t *__restrict__ perm, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = src[perm[i]];
+}
+
+// Transpose products (linear_operator_interface.f90:199-208 -> csc_matvec_add
+// cs_matrices.f90:627-647 / ellpack_matvec_t_add ellpack_matrices.f90:670-693).  The reference
+// scatters y(node(k)) += val(k)*x(j) for j = 1..n, k in stored order; a scatter needs atomics
+// on a GPU and would lose the summation order.  Instead A^T is built once (host counting
+// sort, stable in (j, k)), so y(i) is a ROW SUM over the same terms in the same order and the
+// ordinary SpMV kernels apply (for matvec_t_add the sum is chained onto y(i), bit for bit
+// like the scatter).  ELLPACK padding slots are kept (they add val=0 * x(j) like the reference).
+static int ensure_transpose(sgm_mat A)
+{
+    if (A->distributed()) return fail(SGM_ERR_UNSUPPORTED, "matvec_t: not available on a row-partitioned matrix");
+    Part &p = A->parts[0];
+    const bool ell = A->fmt == SGM_FMT_ELL;
+    const int64_t nnz = ell ? (int64_t)p.n * p.max_d : p.nnz;
+    if (!A->T) {
+        std::vector<int32_t> hp, hc((size_t)std::max<int64_t>(nnz, 1));
+        SGM_HIP(hipStreamSynchronize(g_rt.stream));
+        if (!ell) {
+            hp.resize((size_t)p.n + 1);
+            SGM_HIP(hipMemcpy(hp.data(), p.rowptr, hp.size() * 4, hipMemcpyDeviceToHost));
+            if (nnz) SGM_HIP(hipMemcpy(hc.data(), p.col, (size_t)nnz * 4, hipMemcpyDeviceToHost));
+        } else if (nnz) {
+            SGM_HIP(hipMemcpy(hc.data(), p.ecol, (size_t)nnz * 4, hipMemcpyDeviceToHost));
+        }
+        const int32_t nt = A->ncol;                        // rows of A^T
+        std::vector<int32_t> tptr((size_t)nt + 1, 0), tnode((size_t)std::max<int64_t>(nnz, 1)), perm(tnode.size());
+        for (int64_t k = 0; k < nnz; ++k) tptr[(size_t)hc[k] + 1]++;
+        for (int32_t c = 0; c < nt; ++c) tptr[c + 1] += tptr[c];
+        std::vector<int32_t> cur(tptr.begin(), tptr.end() - 1);
+        for (int32_t j = 0; j < p.n; ++j) {
+            if (!ell) {
+                for (int32_t k = hp[j]; k < hp[j + 1]; ++k) {
+                    const int32_t pos = cur[hc[k]]++;
+                    tnode[pos] = j + 1;
+                    perm[pos] = k;
+                }
+            } else {
+                for (int32_t k = 0; k < p.max_d; ++k) {
+                    const int64_t src = (int64_t)k * p.n + j;          // slot-major device layout
+                    const int32_t pos = cur[hc[src]]++;
+                    tnode[pos] = j + 1;
+                    perm[pos] = (int32_t)src;
+                }
+            }
+        }
+        for (auto &v : tptr) v += 1;
+        std::vector<double> zeros((size_t)std::max<int64_t>(nnz, 1), 0.0);
+        sgm_mat T = new sgm_mat_s;
+        T->fmt = SGM_FMT_CSR;
+        T->nrow = A->ncol;
+        T->ncol = A->nrow;
+        T->nnz = nnz;
+        T->parts.resize(1);
+        int rc = build_csr_part(T->parts[0], T->nrow, T->ncol, 0, nnz, tptr.data(), tnode.data(), zeros.data(), SGM_HOST);
+        if (rc == SGM_OK) rc = dalloc(&A->tperm, (size_t)std::max<int64_t>(nnz, 1));
+        if (rc != SGM_OK) { sgm_mat_destroy(T); return rc; }
+        if (nnz) SGM_HIP(hipMemcpy(A->tperm, perm.data(), (size_t)nnz * 4, hipMemcpyHostToDevice));
+        A->T = T;
+        A->t_stale = true;
+    }
+    if (A->t_stale && nnz) {
+        hipLaunchKernelGGL(k_gather_perm, dim3(vec_grid(nnz)), dim3(kBlock), 0, g_rt.stream, A->T->parts[0].val,
+                           (const double *)(ell ? p.eval : p.val), (const int32_t *)A->tperm, nnz);
+        SGM_HIP(hipGetLastError());
+    }
+    A->t_stale = false;
+    return SGM_OK;
+}
+
+static int matvec_t_impl(sgm_mat A, const double *x, double *y, int where, bool add)
+{
+    SGM_TRY(require_init());
+    if (!A || !x || !y) return fail(SGM_ERR_BAD_ARG, "matvec_t: null argument");
+    SGM_TRY(ensure_transpose(A));
+    Staged sx, sy;
+    SGM_TRY(stage_in(sx, x, A->nrow, where, true));
+    SGM_TRY(stage_in(sy, y, A->ncol, where, add));
+    const double *xs[1] = {sx.dev};
+    double *ys[1] = {sy.dev};
+    SGM_TRY(spmv_parts(A->T, xs, ys, add, nullptr, nullptr, nullptr, 0x7fffffff, /*chain=*/add));
+    SGM_TRY(stage_out(sy, y, A->ncol, where));
+    return finish();
+}
+
 static int matvec_impl(sgm_mat A, const double *x, double *y, int where, bool add)
 {
     SGM_TRY(require_init());
@@ -807,6 +907,7 @@ int sgm_csr_set_values(sgm_mat A, const double *val, int where)
 {
     SGM_TRY(require_init());
     if (!A || A->fmt != SGM_FMT_CSR || !val) return fail(SGM_ERR_BAD_ARG, "sgm_csr_set_values: bad argument");
+    A->t_stale = true;
     int64_t off = 0;
     for (auto &p : A->parts) {
         SGM_HIP(hipMemcpyAsync(p.val, val + off, (size_t)p.nnz * 8,
@@ -860,6 +961,7 @@ int sgm_ell_set_values(sgm_mat A, const double *val, int where)
     SGM_TRY(require_init());
     if (!A || A->fmt != SGM_FMT_ELL || !val) return fail(SGM_ERR_BAD_ARG, "sgm_ell_set_values: bad argument");
     Part &p = A->parts[0];
+    A->t_stale = true;
     const size_t total = (size_t)p.n * p.max_d;
     if (!total) return SGM_OK;
     double *tv = nullptr;
@@ -887,6 +989,16 @@ int sgm_mat_matvec_add(sgm_mat A, const double *x, double *y, int where)
     return matvec_impl(A, x, y, where, true);
 }
 
+int sgm_mat_matvec_t(sgm_mat A, const double *x, double *y, int where)
+{
+    return matvec_t_impl(A, x, y, where, false);
+}
+
+int sgm_mat_matvec_t_add(sgm_mat A, const double *x, double *y, int where)
+{
+    return matvec_t_impl(A, x, y, where, true);
+}
+
 int sgm_mat_info(sgm_mat A, int32_t *nrow, int32_t *ncol, int64_t *nnz, int32_t *fmt, int64_t *x_len)
 {
     if (!A) return fail(SGM_ERR_BAD_ARG, "sgm_mat_info: null matrix");
@@ -902,6 +1014,8 @@ int sgm_mat_destroy(sgm_mat A)
 {
     if (!A) return SGM_OK;
     for (auto &p : A->parts) free_part(p);
+    if (A->T) sgm_mat_destroy(A->T);
+    dfree(A->tperm);
     delete A;
     return SGM_OK;
 }

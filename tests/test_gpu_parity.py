@@ -121,6 +121,43 @@ def test_matvec_vs_oracle_bit_exact(orc):
         H.destroy()
 
 
+@pytest.mark.parametrize("name", golden_names())
+def test_matvec_t_golden_bit_exact(golden, name):
+    """Transpose products (csc_matvec_add cs_matrices.f90:627-647, ellpack_matvec_t_add
+    ellpack_matrices.f90:670-693) against the reference's own outputs."""
+    g = golden(name)
+    A = hip_matrix(g)
+    yt = np.full(int(g["m"]), -7.0)
+    A.matvec_t(g["b"], yt)
+    assert np.array_equal(yt, g["ref_yt"])
+    A.matvec_t_add(g["b"], yt)
+    assert np.array_equal(yt, g["ref_yt_add"])
+
+
+def test_matvec_t_vs_oracle_bit_exact(orc):
+    rs = np.random.RandomState(4)
+    for name, A in _cases(orc):
+        H = hip_from_oracle(A)
+        x = rs.standard_normal(A.n)
+        y = np.full(A.m, np.nan)
+        H.matvec_t(x, y)
+        assert np.array_equal(y, A.matvec_t(x)), name
+        y0 = rs.standard_normal(A.m)
+        y = y0.copy()
+        H.matvec_t_add(x, y)
+        assert np.array_equal(y, A.matvec_t_add(x, y0.copy())), name
+    # values changed after the transpose was built: set_values must refresh it
+    ptr, node, val = P.poisson2d_csr(50, 40)
+    H = sg.csr_matrix(2000, 2000, ptr, node, val)
+    x = P.test_vector(2000)
+    y = np.zeros(2000)
+    H.matvec_t(x, y)
+    val2 = val * np.linspace(1, 3, len(val))
+    H.set_values(val2)
+    H.matvec_t(x, y)
+    assert np.array_equal(y, orc.CsrMatrix(2000, 2000, ptr, node, val2).matvec_t(x))
+
+
 def test_offset_dict_and_int32_kernels_agree(orc):
     """Stencil matrices take the 1-byte offset-dictionary kernel by default; forcing the
     int32-column kernel must give the same bits (and both equal the oracle)."""

@@ -48,6 +48,16 @@ def test_matvec_bit_exact(golden, name):
     assert np.array_equal(y, g["ref_y_add"])
 
 
+@pytest.mark.parametrize("name", golden_names())
+def test_transpose_matvec_bit_exact(golden, name):
+    g = golden(name)
+    A = build(g)
+    yt = A.matvec_t(g["b"])
+    assert np.array_equal(yt, g["ref_yt"])
+    A.matvec_t_add(g["b"], yt)
+    assert np.array_equal(yt, g["ref_yt_add"])
+
+
 def _pc(A, kind):
     return {0: lambda A: None, 1: orc.Jacobi, 2: orc.Ildu}[kind](A)
 
