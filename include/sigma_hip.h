@@ -47,7 +47,7 @@ enum {
     SGM_ERR_UNSUPPORTED = 8
 };
 enum { SGM_HOST = 0, SGM_DEVICE = 1 };
-enum { SGM_FMT_CSR = 1, SGM_FMT_ELL = 2 };
+enum { SGM_FMT_CSR = 1, SGM_FMT_ELL = 2, SGM_FMT_COMPOSITE = 3 };
 enum { SGM_SOLVER_CG = 1, SGM_SOLVER_BICGSTAB = 2, SGM_SOLVER_GMRES = 3 };
 enum { SGM_PC_JACOBI = 1, SGM_PC_ILDU0 = 2 };
 
@@ -101,6 +101,16 @@ int sgm_mat_matvec_add(sgm_mat A, const double *x, double *y, int where);
  * (bit-identical, no atomics).  Single-GPU matrices only.                               */
 int sgm_mat_matvec_t(sgm_mat A, const double *x, double *y, int where);
 int sgm_mat_matvec_t_add(sgm_mat A, const double *x, double *y, int where);
+/* sgm_composite_create <- type(sparse_matrix), the block "matrix of matrices"
+ *                         src/matrix/sparse_matrix_composites.f90:41-162; matvec_add = loop over
+ *                         the blocks `C%matvec_add(x(j1:j2), y(i1:i2))`, :1076-1099 (row blocks
+ *                         outer, column blocks inner), matvec_t_add :1104-1127 (column blocks
+ *                         outer).  row_ptr/col_ptr are the 1-based block offsets (nrb+1 / ncb+1
+ *                         entries); blocks[it*ncb + jt] are leaf handles (NULL = empty block) that
+ *                         stay owned by the caller.  The handle works with matvec(_t)(_add) and
+ *                         with the unpreconditioned solvers.                               */
+int sgm_composite_create(sgm_mat *out, int32_t nrb, int32_t ncb, const int32_t *row_ptr_1based,
+                         const int32_t *col_ptr_1based, const sgm_mat *blocks);
 int sgm_mat_info(sgm_mat A, int32_t *nrow, int32_t *ncol, int64_t *nnz, int32_t *fmt,
                  int64_t *x_len /* entries matvec reads from x: ncol, or owned+halo when distributed */);
 int sgm_mat_destroy(sgm_mat A);

@@ -245,6 +245,52 @@ class dist_csr_matrix(_Matrix):
                                       pp, pn, pv, C.c_int(_same_where(w1, w2, w3))))
 
 
+class sparse_matrix(_Matrix):
+    """The composite "matrix of matrices" (sparse_matrix_composites.f90:41-162): row_ptr /
+    col_ptr are the 1-based block offsets, set_submatrix(it, jt, B) places a leaf (1-based
+    block indices); build() freezes the layout.  matvec_add loops over the blocks like
+    composite_matvec_add (:1076-1099)."""
+
+    def __init__(self, row_ptr, col_ptr):
+        super().__init__()
+        self.row_ptr = np.ascontiguousarray(row_ptr, np.int32)
+        self.col_ptr = np.ascontiguousarray(col_ptr, np.int32)
+        self.num_row_mats, self.num_col_mats = len(self.row_ptr) - 1, len(self.col_ptr) - 1
+        self.nrow, self.ncol = int(self.row_ptr[-1] - 1), int(self.col_ptr[-1] - 1)
+        self.sub_mats = [[None] * self.num_col_mats for _ in range(self.num_row_mats)]
+
+    def set_submatrix(self, it, jt, B):
+        self.sub_mats[it - 1][jt - 1] = B
+        if self._h:
+            self.destroy()
+
+    def _build(self):
+        if self._h:
+            return
+        arr = (C.c_void_p * (self.num_row_mats * self.num_col_mats))()
+        for i, row in enumerate(self.sub_mats):
+            for j, B in enumerate(row):
+                arr[i * self.num_col_mats + j] = B._h if B is not None else None
+        _ck(lib().sgm_composite_create(C.byref(self._h), C.c_int32(self.num_row_mats), C.c_int32(self.num_col_mats),
+                                       C.c_void_p(self.row_ptr.ctypes.data), C.c_void_p(self.col_ptr.ctypes.data), arr))
+
+    def matvec(self, x, y):
+        self._build()
+        return super().matvec(x, y)
+
+    def matvec_add(self, x, y):
+        self._build()
+        return super().matvec_add(x, y)
+
+    def matvec_t(self, x, y):
+        self._build()
+        return super().matvec_t(x, y)
+
+    def matvec_t_add(self, x, y):
+        self._build()
+        return super().matvec_t_add(x, y)
+
+
 class ellpack_matrix(_Matrix):
     """ellpack_matrix (ellpack_matrices.f90:28-105): node(max_d,n), val(max_d,n) in Fortran
     order, i.e. a C array of shape (n, max_d); padding = last neighbour / 0.0."""
@@ -351,6 +397,8 @@ class _Solver:
         raise NotImplementedError
 
     def setup(self, A):
+        if hasattr(A, "_build"):
+            A._build()
         if not self._h:
             self._create()
             if self._max_iter:

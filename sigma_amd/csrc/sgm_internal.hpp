@@ -116,6 +116,7 @@ struct Part {
     double *eval = nullptr;
     std::vector<HaloNbr> nbrs;
     double *xext = nullptr;        // owned+halo staging for plain-vector matvec (multi-part only)
+    int dot_grid_override = 0;     // composite matrices: grid of the separate dot kernel
     int64_t xlen() const { return (int64_t)ncol_own + n_halo; }
 };
 
@@ -135,6 +136,9 @@ struct sgm_mat_s {
     bool distributed() const { return comm != nullptr || parts.size() > 1; }
     // explicit transpose for matvec_t (built on first use; rows sorted by (source row, slot) so
     // that every y(i) receives its terms in the reference's order)
+    // composite ("matrix of matrices", sparse_matrix_composites.f90:41-162): blocks are not owned
+    std::vector<int32_t> blk_row_ptr, blk_col_ptr;      // 0-based offsets, nrb+1 / ncb+1
+    std::vector<sgm_mat_s *> blocks;                    // nrb x ncb, row-major, may hold nullptr
     sgm_mat_s *T = nullptr;
     int32_t *tperm = nullptr;      // device: position in this matrix's val/eval of each entry of T
     bool t_stale = true;

@@ -362,6 +362,8 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
         return fail(SGM_ERR_DIMS, "Cannot make a %s solver for a non-square matrix",
                     pc->kind == SGM_PC_JACOBI ? "Jacobi" : "LDU");
     hipStream_t st = g_rt.stream;
+    if (A->fmt == SGM_FMT_COMPOSITE)
+        return fail(SGM_ERR_UNSUPPORTED, "preconditioners need a leaf (CSR / ELLPACK) matrix, not a composite");
     if (pc->kind == SGM_PC_JACOBI) {
         if (pc->parts.size() != A->parts.size()) {
             for (auto &pp : pc->parts) dfree(pp.idiag);

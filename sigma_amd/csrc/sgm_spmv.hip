@@ -417,6 +417,7 @@ static int spmv_ranges(const Part &p, RowRange out[3])
 
 int spmv_grid(const Part &p)       // = number of partial sums one SpMV leaves per fused dot
 {
+    if (p.dot_grid_override) return p.dot_grid_override;
     if (p.ecol) return ell_grid(p);
     RowRange r[3];
     const int nr = spmv_ranges(p, r);
@@ -564,9 +565,13 @@ static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const doub
     }
 }
 
+static int composite_spmv(sgm_mat A, const double *x, double *y, bool add, const SpmvDots *dots,
+                          const int *flag_done, int *grid_out, int gen);
+
 int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
                const SpmvDots *dots, const int *flag_done, int *grid_out, int gen, bool chain)
 {
+    if (A->fmt == SGM_FMT_COMPOSITE) return composite_spmv(A, x[0], y[0], add, dots, flag_done, grid_out, gen);
     const size_t P = A->parts.size();
     g_launch_flags = chain ? 256 : 0;
     bool exchange = false;
@@ -611,6 +616,53 @@ int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
         }
     }
     g_launch_flags = 0;
+    SGM_HIP(hipGetLastError());
+    return SGM_OK;
+}
+
+// partial sums of w.y and y.y (composite matrices cannot fuse them into one leaf kernel)
+__global__ __launch_bounds__(kBlock) void k_dot_wy_yy(int64_t n, const double *__restrict__ w,
+                                                      const double *__restrict__ y, double *part_wy,
+                                                      double *part_yy, const int *flag_done, int gen)
+{
+    __shared__ double red[kBlock / 64];
+    if (flag_done) { const int st = *flag_done; if (st && gen >= st) return; }
+    double a = 0.0, b = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const double yi = y[i];
+        if (w) a += w[i] * yi;
+        b += yi * yi;
+    }
+    if (part_wy) { const double t = block_sum<kBlock>(a, red); if (threadIdx.x == 0) part_wy[blockIdx.x] = t; }
+    if (part_yy) { const double t = block_sum<kBlock>(b, red); if (threadIdx.x == 0) part_yy[blockIdx.x] = t; }
+}
+
+// composite_matvec_add (sparse_matrix_composites.f90:1076-1099): for every row block, the
+// column blocks in order, each `C%matvec_add(x(j1:j2), y(i1:i2))` -- one leaf launch per block
+// on shifted pointers (the leaf kernels read x and write y with 8-byte accesses, so block
+// boundaries need no alignment).
+static int composite_spmv(sgm_mat A, const double *x, double *y, bool add, const SpmvDots *dots,
+                          const int *flag_done, int *grid_out, int gen)
+{
+    const int nrb = (int)A->blk_row_ptr.size() - 1, ncb = (int)A->blk_col_ptr.size() - 1;
+    if (!add) SGM_HIP(hipMemsetAsync(y, 0, (size_t)A->nrow * 8, g_rt.stream));     // y = 0 (matvec)
+    for (int it = 0; it < nrb; ++it)
+        for (int jt = 0; jt < ncb; ++jt) {
+            sgm_mat C = A->blocks[(size_t)it * ncb + jt];
+            if (!C) continue;
+            const double *xs[1] = {x + A->blk_col_ptr[jt]};
+            double *ys[1] = {y + A->blk_row_ptr[it]};
+            SGM_TRY(spmv_parts(C, xs, ys, true, nullptr, flag_done, nullptr, gen, false));
+        }
+    if (dots && (dots->part_wy || dots->part_yy)) {
+        const int grid = A->parts[0].dot_grid_override;
+        hipLaunchKernelGGL(k_dot_wy_yy, dim3(grid), dim3(kBlock), 0, g_rt.stream, (int64_t)A->nrow,
+                           dots->w ? dots->w[0] : nullptr, (const double *)y,
+                           dots->part_wy ? dots->part_wy[0] : nullptr, dots->part_yy ? dots->part_yy[0] : nullptr,
+                           flag_done, gen);
+    }
+    if (grid_out) *grid_out = A->parts[0].dot_grid_override;
     SGM_HIP(hipGetLastError());
     return SGM_OK;
 }
@@ -833,6 +885,25 @@ static int matvec_t_impl(sgm_mat A, const double *x, double *y, int where, bool 
 {
     SGM_TRY(require_init());
     if (!A || !x || !y) return fail(SGM_ERR_BAD_ARG, "matvec_t: null argument");
+    if (A->fmt == SGM_FMT_COMPOSITE) {
+        // composite_matvec_t_add (sparse_matrix_composites.f90:1104-1127): column blocks outer
+        Staged sx, sy;
+        SGM_TRY(stage_in(sx, x, A->nrow, where, true));
+        SGM_TRY(stage_in(sy, y, A->ncol, where, add));
+        if (!add) SGM_HIP(hipMemsetAsync(sy.dev, 0, (size_t)A->ncol * 8, g_rt.stream));
+        const int nrb = (int)A->blk_row_ptr.size() - 1, ncb = (int)A->blk_col_ptr.size() - 1;
+        for (int jt = 0; jt < ncb; ++jt)
+            for (int it = 0; it < nrb; ++it) {
+                sgm_mat C = A->blocks[(size_t)it * ncb + jt];
+                if (!C) continue;
+                SGM_TRY(ensure_transpose(C));
+                const double *xs[1] = {sx.dev + A->blk_row_ptr[it]};
+                double *ys[1] = {sy.dev + A->blk_col_ptr[jt]};
+                SGM_TRY(spmv_parts(C->T, xs, ys, true, nullptr, nullptr, nullptr, 0x7fffffff, true));
+            }
+        SGM_TRY(stage_out(sy, y, A->ncol, where));
+        return finish();
+    }
     SGM_TRY(ensure_transpose(A));
     Staged sx, sy;
     SGM_TRY(stage_in(sx, x, A->nrow, where, true));
@@ -987,6 +1058,39 @@ int sgm_mat_matvec(sgm_mat A, const double *x, double *y, int where)
 int sgm_mat_matvec_add(sgm_mat A, const double *x, double *y, int where)
 {
     return matvec_impl(A, x, y, where, true);
+}
+
+int sgm_composite_create(sgm_mat *out, int32_t nrb, int32_t ncb, const int32_t *row_ptr, const int32_t *col_ptr,
+                         const sgm_mat *blocks)
+{
+    SGM_TRY(require_init());
+    if (!out || nrb < 1 || ncb < 1 || !row_ptr || !col_ptr || !blocks)
+        return fail(SGM_ERR_BAD_ARG, "sgm_composite_create: bad argument");
+    sgm_mat A = new sgm_mat_s;
+    A->fmt = SGM_FMT_COMPOSITE;
+    for (int i = 0; i <= nrb; ++i) A->blk_row_ptr.push_back(row_ptr[i] - 1);
+    for (int j = 0; j <= ncb; ++j) A->blk_col_ptr.push_back(col_ptr[j] - 1);
+    A->nrow = A->blk_row_ptr[nrb];
+    A->ncol = A->blk_col_ptr[ncb];
+    A->blocks.assign(blocks, blocks + (size_t)nrb * ncb);
+    for (int it = 0; it < nrb; ++it)
+        for (int jt = 0; jt < ncb; ++jt) {
+            sgm_mat C = A->blocks[(size_t)it * ncb + jt];
+            if (!C) continue;
+            if (C->distributed() || C->fmt == SGM_FMT_COMPOSITE || C->nrow != A->blk_row_ptr[it + 1] - A->blk_row_ptr[it] ||
+                C->ncol != A->blk_col_ptr[jt + 1] - A->blk_col_ptr[jt]) {
+                delete A;
+                return fail(SGM_ERR_DIMS, "sgm_composite_create: block (%d,%d) does not fit its slot", it + 1, jt + 1);
+            }
+            A->nnz += C->nnz;
+        }
+    A->parts.resize(1);
+    A->parts[0].n = A->nrow;
+    A->parts[0].ncol_own = A->ncol;
+    int64_t g = ((int64_t)A->nrow + 4 * kBlock - 1) / (4 * kBlock);
+    A->parts[0].dot_grid_override = (int)std::max<int64_t>(1, std::min<int64_t>(g, 2048));
+    *out = A;
+    return SGM_OK;
 }
 
 int sgm_mat_matvec_t(sgm_mat A, const double *x, double *y, int where)

@@ -104,6 +104,24 @@ interface
         integer(c_int), value :: where
         integer(c_int) :: rc
     end function
+    function sgm_mat_matvec_t(A, x, y, where) &
+            & bind(c, name='sgm_mat_matvec_t') result(rc)
+        import :: c_ptr, c_int, c_double
+        type(c_ptr), value :: A
+        real(c_double), intent(in) :: x(*)
+        real(c_double), intent(inout) :: y(*)
+        integer(c_int), value :: where
+        integer(c_int) :: rc
+    end function
+    function sgm_mat_matvec_t_add(A, x, y, where) &
+            & bind(c, name='sgm_mat_matvec_t_add') result(rc)
+        import :: c_ptr, c_int, c_double
+        type(c_ptr), value :: A
+        real(c_double), intent(in) :: x(*)
+        real(c_double), intent(inout) :: y(*)
+        integer(c_int), value :: where
+        integer(c_int) :: rc
+    end function
     function sgm_mat_destroy(A) bind(c, name='sgm_mat_destroy') result(rc)
         import :: c_ptr, c_int
         type(c_ptr), value :: A
@@ -211,6 +229,8 @@ contains
     procedure :: upload => hip_csr_upload
     procedure :: matvec => hip_csr_matvec
     procedure :: matvec_add => hip_csr_matvec_add
+    procedure :: matvec_t => hip_csr_matvec_t
+    procedure :: matvec_t_add => hip_csr_matvec_t_add
     procedure :: destroy => hip_csr_destroy
 end type hip_csr_matrix
 
@@ -380,6 +400,22 @@ subroutine hip_csr_matvec_add(A, x, y)  ! cs_matrices.f90:600-622
     real(dp), intent(inout) :: y(:)
     call A%upload()
     call hip_check(sgm_mat_matvec_add(A%handle, x, y, SGM_HOST))
+end subroutine
+
+subroutine hip_csr_matvec_t(A, x, y)    ! linear_operator_interface.f90:199-208
+    class(hip_csr_matrix), intent(inout) :: A
+    real(dp), intent(in) :: x(:)
+    real(dp), intent(out) :: y(:)
+    call A%upload()
+    call hip_check(sgm_mat_matvec_t(A%handle, x, y, SGM_HOST))
+end subroutine
+
+subroutine hip_csr_matvec_t_add(A, x, y)  ! csc_matvec_add, cs_matrices.f90:627-647
+    class(hip_csr_matrix), intent(inout) :: A
+    real(dp), intent(in) :: x(:)
+    real(dp), intent(inout) :: y(:)
+    call A%upload()
+    call hip_check(sgm_mat_matvec_t_add(A%handle, x, y, SGM_HOST))
 end subroutine
 
 subroutine hip_csr_destroy(A)

@@ -101,6 +101,17 @@ implicit none
     enddo
     call B%set_value(nn, nn, 2.0_dp)
 
+    ! B is symmetric: B^T f and B f agree to rounding (different summation order per entry)
+    call B%matvec(f, u)
+    call B%matvec_t(f, v)
+    if (maxval(dabs(u - v)) > 1.0d-18) then
+        print *, 'matvec_t differs from matvec on a symmetric matrix:', maxval(dabs(u - v))
+        call exit(1)
+    endif
+    do i = 1, nn
+        v(i) = i * dx * (1.0_dp - i * dx)
+    enddo
+
     solver => hip_cg(1.d-16)
     pc => hip_jacobi()
     call solver%setup(B)

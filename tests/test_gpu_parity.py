@@ -158,6 +158,96 @@ def test_matvec_t_vs_oracle_bit_exact(orc):
     assert np.array_equal(y, orc.CsrMatrix(2000, 2000, ptr, node, val2).matvec_t(x))
 
 
+def test_composite_block_matrix(orc):
+    """sparse_matrix composite (sparse_matrix_composites.f90:1076-1127): a 3 x 2 block layout
+    with one empty block, CSR and ELLPACK leaves; matvec / matvec_add / matvec_t(_add) against
+    the same block loops over the oracle's leaf kernels (bit-exact), and CG on a 2 x 2 SPD
+    composite against the oracle CG on the assembled matrix."""
+    rs = np.random.RandomState(21)
+    rows, cols = [300, 257, 130], [401, 286]
+    rp = np.concatenate([[1], 1 + np.cumsum(rows)]).astype(np.int32)
+    cp = np.concatenate([[1], 1 + np.cumsum(cols)]).astype(np.int32)
+    S = sg.sparse_matrix(rp, cp)
+    leaves = {}
+    for it, nr in enumerate(rows):
+        for jt, nc in enumerate(cols):
+            if (it, jt) == (1, 1):
+                continue                                   # empty block
+            deg = rs.randint(0, 7, size=nr)
+            ptr = np.concatenate([[1], 1 + np.cumsum(deg)]).astype(np.int32)
+            node = rs.randint(1, nc + 1, size=int(deg.sum())).astype(np.int32)
+            val = rs.standard_normal(int(deg.sum()))
+            if (it + jt) % 2 == 0:
+                Ao = orc.CsrMatrix(nr, nc, ptr, node, val)
+            else:                                          # an ELLPACK leaf
+                ei = np.repeat(np.arange(1, nr + 1), 3).astype(np.int32)
+                ej = np.stack([rs.permutation(nc)[:3] + 1 for _ in range(nr)]).ravel().astype(np.int32)
+                Ao = orc.EllMatrix.from_edges(nr, nc, ei, ej, rs.standard_normal(3 * nr))
+            H = hip_from_oracle(Ao)
+            leaves[(it, jt)] = (Ao, H)
+            S.set_submatrix(it + 1, jt + 1, H)
+    n, m = sum(rows), sum(cols)
+
+    def ref_matvec_add(x, y):
+        for it in range(len(rows)):
+            for jt in range(len(cols)):
+                if (it, jt) in leaves:
+                    yy = y[rp[it] - 1:rp[it + 1] - 1]
+                    leaves[(it, jt)][0].matvec_add(x[cp[jt] - 1:cp[jt + 1] - 1].copy(), yy)
+        return y
+
+    def ref_matvec_t_add(x, y):
+        for jt in range(len(cols)):
+            for it in range(len(rows)):
+                if (it, jt) in leaves:
+                    yy = y[cp[jt] - 1:cp[jt + 1] - 1]
+                    leaves[(it, jt)][0].matvec_t_add(x[rp[it] - 1:rp[it + 1] - 1].copy(), yy)
+        return y
+
+    x, xt = rs.standard_normal(m), rs.standard_normal(n)
+    y = np.full(n, -3.0)
+    S.matvec(x, y)
+    assert np.array_equal(y, ref_matvec_add(x, np.zeros(n)))
+    y0 = rs.standard_normal(n)
+    y = y0.copy()
+    S.matvec_add(x, y)
+    assert np.array_equal(y, ref_matvec_add(x, y0.copy()))
+    yt = np.full(m, 5.0)
+    S.matvec_t(xt, yt)
+    assert np.array_equal(yt, ref_matvec_t_add(xt, np.zeros(m)))
+    y0 = rs.standard_normal(m)
+    yt = y0.copy()
+    S.matvec_t_add(xt, yt)
+    assert np.array_equal(yt, ref_matvec_t_add(xt, y0.copy()))
+
+    # CG through a 2 x 2 composite of the 5-point matrix (the Lanczos test's B%solve shape)
+    nx, ny = 40, 30
+    ptr, node, val = P.poisson2d_csr(nx, ny)
+    nn = nx * ny
+    import scipy.sparse as sp
+    M = sp.csr_matrix((val, node - 1, ptr - 1), shape=(nn, nn))
+    h = 620
+    S2 = sg.sparse_matrix(np.array([1, h + 1, nn + 1], np.int32), np.array([1, h + 1, nn + 1], np.int32))
+    keep = []
+    for it, (a, b_) in enumerate(((0, h), (h, nn))):
+        for jt, (c, d) in enumerate(((0, h), (h, nn))):
+            B = M[a:b_, c:d].tocsr()
+            B.sort_indices()
+            Hb = sg.csr_matrix(b_ - a, d - c, (B.indptr + 1).astype(np.int32), (B.indices + 1).astype(np.int32), B.data)
+            keep.append(Hb)
+            S2.set_submatrix(it + 1, jt + 1, Hb)
+    b = np.full(nn, 1.0 / nn)
+    ur, itr, _, _ = orc.cg(orc.CsrMatrix(nn, nn, ptr, node, val), b, tol=1e-13)
+    s = sg.cg(1e-13)
+    s.setup(S2)
+    u = np.zeros(nn)
+    s.solve(S2, u, b)
+    assert abs(s.iterations - itr) <= 1 and np.abs(u - ur).max() / np.abs(ur).max() <= 1e-12
+    with pytest.raises(sg.SigmaError) as e:
+        sg.jacobi().setup(S2)
+    assert e.value.code == 8
+
+
 def test_offset_dict_and_int32_kernels_agree(orc):
     """Stencil matrices take the 1-byte offset-dictionary kernel by default; forcing the
     int32-column kernel must give the same bits (and both equal the oracle)."""
