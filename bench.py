@@ -174,14 +174,17 @@ def main():
                 {"kernel": "k_csr_do", "avg_launch_ms": 1e3 * k_avg, "GB/s_algorithmic": achieved,
                  "stored_bytes_per_nnz": 9}}
     if not use_dist:
-        sg.set_option("csr_offset_dict", 0)
-        for _ in range(5):
-            A.matvec(x, y)
-        k32 = time_kernel(A)
+        for label, kern, ro in (("int32_columns, row-owner gather (general kernel, rows <= 32 entries)", "k_csr_do<CW=4>", 1),
+                                ("int32_columns, streaming gather (general kernel, any row length)", "k_csr_spmv", 0)):
+            sg.set_option("csr_offset_dict", 0)
+            sg.set_option("csr_row_owner", ro)
+            for _ in range(5):
+                A.matvec(x, y)
+            k32 = time_kernel(A)
+            variants[label] = {"kernel": kern, "avg_launch_ms": 1e3 * k32, "GB/s_algorithmic": bytes_rank / k32 / 1e9,
+                               "frac_of_hbm_peak": bytes_rank / k32 / 1e9 / HBM_PEAK_GBS, "stored_bytes_per_nnz": 12}
         sg.set_option("csr_offset_dict", 1)
-        variants["int32_columns (general CSR kernel)"] = {
-            "kernel": "k_csr_spmv", "avg_launch_ms": 1e3 * k32, "GB/s_algorithmic": bytes_rank / k32 / 1e9,
-            "stored_bytes_per_nnz": 12}
+        sg.set_option("csr_row_owner", 1)
 
     # ---- CG iterations/s (device-resident loop, fixed iteration count) -------------------
     cg = None

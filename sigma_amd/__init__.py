@@ -89,7 +89,8 @@ def synchronize():
 
 
 def set_option(name, value):
-    """sgm_set_option: "csr_offset_dict" 1/0 (1-byte column codes for stencil-like matrices)."""
+    """sgm_set_option: "csr_offset_dict" 1/0 (1-byte column codes for stencil-like matrices),
+    "csr_row_owner" 1/0 (row-owner gather for int32-column matrices with rows <= 32 entries)."""
     _ck(lib().sgm_set_option(name.encode(), C.c_int(int(value))))
 
 

@@ -34,6 +34,7 @@ int fail(int code, const char *fmt, ...);
 // ------------------------------------------------------------------ runtime
 struct Options {
     int csr_offset_dict = 1;       // use the 1-byte column code kernel when a matrix allows it
+    int csr_row_owner = 1;         // int32 columns, rows <= 32 entries: gather by the row's owner lane
 };
 extern Options g_opt;
 
@@ -110,6 +111,7 @@ struct Part {
     uint8_t *code = nullptr;
     int32_t *dict = nullptr;       // 256 entries
     int32_t ndict = 0;
+    int32_t max_row = 0;           // longest row (entries); picks the row-owner kernel for short rows
     // ELLPACK (device, slot-major: entry (slot k, row i) at k*n + i)
     int32_t max_d = 0;
     int32_t *ecol = nullptr;

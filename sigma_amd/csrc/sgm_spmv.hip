@@ -168,7 +168,10 @@ __global__ __launch_bounds__(BLOCK) void k_csr_spmv(
 // coalesced loads by all lanes, then lane i walks row i left to right -- up to 8 entries'
 // x values are requested at once, the adds stay in stored order (bit-identical results).
 // For stencil rows lane l and lane l+1 gather neighbouring x entries: coalesced 512-B reads.
-template <int BLOCK, int TILE, bool ADD, bool DOT_W, bool DOT_YY>
+// CW = bytes per stored column: 1 = dictionary code (col = row + dict[code]); 4 = the int32
+// column itself ("row-owner" form of the general kernel, used when rows are short: the lane
+// that owns a row gathers for it, which keeps stencil-like gathers coalesced; 12 B / entry).
+template <int BLOCK, int TILE, int CW, bool ADD, bool DOT_W, bool DOT_YY>
 __global__ __launch_bounds__(BLOCK) void k_csr_do(
     int32_t n, const int32_t *__restrict__ rowptr, const uint8_t *__restrict__ code,
     const int32_t *__restrict__ dict, const double *__restrict__ val, const double *__restrict__ x,
@@ -180,8 +183,8 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
     constexpr int CPT = (TILE / 4 + BLOCK - 1) / BLOCK;      // 4-byte code words per lane per tile
     static_assert(TILE % 4 == 0, "tiles are whole 4-byte code words");
     __shared__ double vl[TILE];
-    __shared__ uint32_t cl4[TILE / 4];
-    __shared__ int32_t dl[256];
+    __shared__ uint32_t cl4[TILE * CW / 4];
+    __shared__ int32_t dl[CW == 1 ? 256 : 1];
     __shared__ double red[BLOCK / 64];
     if (flag_done) { const int st = *flag_done; if (st && gen >= st) return; }
     const uint8_t *cl = reinterpret_cast<const uint8_t *>(cl4);
@@ -189,7 +192,9 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
     const int tid = threadIdx.x;
     const bool chain = (remap & 256) != 0;      // launch flag bits above the XCD-map mode
     const int rmode = remap & 255;
-    for (int t = tid; t < 256; t += BLOCK) dl[t] = dict[t];
+    if (CW == 1)
+        for (int t = tid; t < 256; t += BLOCK) dl[t] = dict[t];
+    const int32_t *col32 = reinterpret_cast<const int32_t *>(code);
     const int64_t nrb = ((int64_t)n + BLOCK - 1) / BLOCK;
     double dwy = 0.0, dyy = 0.0;
 
@@ -222,11 +227,20 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
                 if (j < te) v[m] = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + j));
             }
             uint32_t c4[CPT];
+            i32x2 c8[VPT];
+            if (CW == 1) {
 #pragma unroll
-            for (int m = 0; m < CPT; ++m) {
-                const int32_t q = tid + BLOCK * m;
-                if (q < TILE / 4 && ts + 4 * q < te)
-                    c4[m] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(code + ts) + q);
+                for (int m = 0; m < CPT; ++m) {
+                    const int32_t q = tid + BLOCK * m;
+                    if (q < TILE / 4 && ts + 4 * q < te)
+                        c4[m] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(code + ts) + q);
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < VPT; ++m) {
+                    const int32_t j = ts + 2 * tid + 2 * BLOCK * m;
+                    if (j < te) c8[m] = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(col32 + j));
+                }
             }
             __syncthreads();       // the previous tile's phase 2 is done with the LDS buffers
 #pragma unroll
@@ -234,10 +248,18 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
                 const int32_t j = ts + 2 * tid + 2 * BLOCK * m;
                 if (j < te) *reinterpret_cast<f64x2 *>(vl + (j - ts)) = v[m];
             }
+            if (CW == 1) {
 #pragma unroll
-            for (int m = 0; m < CPT; ++m) {
-                const int32_t q = tid + BLOCK * m;
-                if (q < TILE / 4 && ts + 4 * q < te) cl4[q] = c4[m];
+                for (int m = 0; m < CPT; ++m) {
+                    const int32_t q = tid + BLOCK * m;
+                    if (q < TILE / 4 && ts + 4 * q < te) cl4[q] = c4[m];
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < VPT; ++m) {
+                    const int32_t j = ts + 2 * tid + 2 * BLOCK * m;
+                    if (j < te) *reinterpret_cast<i32x2 *>(cl4 + (j - ts)) = c8[m];
+                }
             }
             __syncthreads();
             // ---- phase 2: lane i gathers for row i (8 requests in flight), adds in order
@@ -249,7 +271,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
                 for (int u = 0; u < U; ++u)
                     if (u < cnt) {
                         const int o = k + u - ts;
-                        xv[u] = x[row + dl[cl[o]]];
+                        xv[u] = CW == 1 ? x[row + dl[cl[o]]] : x[(int32_t)cl4[o]];
                         vv[u] = vl[o];
                     }
 #pragma unroll
@@ -355,6 +377,11 @@ static SpmvCfg &spmv_cfg()
 static int resident_per_cu(bool dict, int block, int v);
 int ell_grid(const Part &p);
 static bool use_offset_dict(const Part &p) { return p.code && g_opt.csr_offset_dict; }
+// k_csr_do serves both the dictionary form and, for short rows, plain int32 columns
+static bool use_row_owner(const Part &p)
+{
+    return use_offset_dict(p) || (g_opt.csr_row_owner && p.max_row > 0 && p.max_row <= 32);
+}
 
 // (BLOCK, TILE) instantiations of the offset-dict kernel.  TILE = entries staged in LDS per
 // pass (9 bytes each); the launcher picks the smallest one that holds a whole row block of
@@ -383,7 +410,7 @@ static int grid_for_rows(const Part &p, int64_t rows, int64_t limit)
     const int64_t nrb = (rows + c.block - 1) / c.block;
     int64_t g = ((nrb + 7) / 8) * 8;
     int64_t cap = c.maxgrid;
-    if (cap <= 0) cap = (int64_t)resident_per_cu(use_offset_dict(p), c.block, use_offset_dict(p) ? do_tile_for(p) : c.vpt) *
+    if (cap <= 0) cap = (int64_t)resident_per_cu(use_row_owner(p), c.block, use_row_owner(p) ? do_tile_for(p) : c.vpt) *
                         g_rt.num_cu;
     if (cap > limit) cap = limit;
     if (g > cap) g = cap / 8 * 8;
@@ -462,9 +489,17 @@ static void launch_csr_do(const Part &p, int grid, const double *x, double *y, c
     const SpmvCfg &c = spmv_cfg();
     hipStream_t st = g_rt.stream;
     const int tile = do_tile_for(p);
-#define L(B, T, DW, DY)                                                                          \
-    hipLaunchKernelGGL((k_csr_do<B, T, ADD, DW, DY>), dim3(grid), dim3(B), 0, st, p.n, p.rowptr, \
-                       p.code, p.dict, p.val, x, y, w, pwy, pyy, flag, gen, c.remap | g_launch_flags)
+    const bool dict = use_offset_dict(p);
+#define L(B, T, DW, DY)                                                                                 \
+    do {                                                                                                \
+        if (dict)                                                                                       \
+            hipLaunchKernelGGL((k_csr_do<B, T, 1, ADD, DW, DY>), dim3(grid), dim3(B), 0, st, p.n, p.rowptr, \
+                               p.code, p.dict, p.val, x, y, w, pwy, pyy, flag, gen, c.remap | g_launch_flags); \
+        else                                                                                            \
+            hipLaunchKernelGGL((k_csr_do<B, T, 4, ADD, DW, DY>), dim3(grid), dim3(B), 0, st, p.n, p.rowptr, \
+                               reinterpret_cast<const uint8_t *>(p.col), p.dict, p.val, x, y, w, pwy, pyy, flag, \
+                               gen, c.remap | g_launch_flags);                                          \
+    } while (0)
 #define LV(B, T)                                \
     if (c.block == B && tile == T) {            \
         if (w && pyy) L(B, T, true, true);      \
@@ -529,7 +564,7 @@ static int resident_per_cu(bool dict, int block, int v)
     for (auto &kv : cache)
         if (kv.first == key) return kv.second;
     const void *fn = nullptr;
-#define PICK_DO(B, T) if (dict && block == B && v == T) fn = (const void *)k_csr_do<B, T, false, false, false>;
+#define PICK_DO(B, T) if (dict && block == B && v == T) fn = (const void *)k_csr_do<B, T, 4, false, false, false>;
 #define PICK_ST(B, V) if (!dict && block == B && v == V) fn = (const void *)k_csr_spmv<B, V, true, false, false, false>;
     SGM_DO_VARIANTS(PICK_DO)
     PICK_ST(256, 2) PICK_ST(256, 4) PICK_ST(256, 8) PICK_ST(512, 2) PICK_ST(512, 4) PICK_ST(512, 8) PICK_ST(1024, 2) PICK_ST(1024, 4)
@@ -551,12 +586,13 @@ static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const doub
     v.n = r.hi - r.lo;
     v.nnz = p.nnz; v.n_halo = p.n_halo; v.ncol_own = p.ncol_own;
     v.rowptr = p.rowptr + r.lo; v.col = p.col; v.val = p.val; v.code = p.code; v.dict = p.dict;
+    v.max_row = p.max_row;
     const bool dict = use_offset_dict(p);
     const double *xs = dict ? x + r.lo : x;
     double *ys = y + r.lo;
     const double *ws = w ? w + r.lo : nullptr;
     double *pw = pwy ? pwy + r.part_off : nullptr, *py = pyy ? pyy + r.part_off : nullptr;
-    if (dict) {
+    if (use_row_owner(p)) {
         if (add) launch_csr_do<true>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
         else launch_csr_do<false>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
     } else {
@@ -707,6 +743,8 @@ static int build_offset_dict(Part &p, const int32_t *ptr1, const int32_t *node1)
     const int32_t base = host ? 1 : 0;
     const int32_t *ptr = host ? ptr1 : hp.data();
     const int32_t *col = host ? node1 : hc.data();
+    p.max_row = 0;
+    for (int32_t i = 0; i < n; ++i) p.max_row = std::max(p.max_row, ptr[i + 1] - ptr[i]);
     constexpr int HS = 1024;                            // open-addressing table, <= 255 live keys
     int32_t key[HS];
     int16_t slot[HS];

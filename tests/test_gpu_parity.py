@@ -249,21 +249,28 @@ def test_composite_block_matrix(orc):
 
 
 def test_offset_dict_and_int32_kernels_agree(orc):
-    """Stencil matrices take the 1-byte offset-dictionary kernel by default; forcing the
-    int32-column kernel must give the same bits (and both equal the oracle)."""
+    """Three CSR kernels, one result: 1-byte offset-dictionary codes (default for stencil-like
+    matrices), int32 columns gathered by the row's owner lane (rows <= 32 entries), int32
+    columns gathered while streaming (any row length).  All must equal the oracle bit for bit."""
     rs = np.random.RandomState(8)
-    for name, A in _cases(orc)[:3]:
+    for name, A in _cases(orc)[:4]:
         x = rs.standard_normal(A.m)
         y_ref = A.matvec(x)
-        for opt in (1, 0):
-            sg.set_option("csr_offset_dict", opt)
+        yt_ref = A.matvec_t(rs.standard_normal(A.n) * 0 + 1.0)
+        for dict_opt, ro_opt in ((1, 1), (0, 1), (0, 0)):
+            sg.set_option("csr_offset_dict", dict_opt)
+            sg.set_option("csr_row_owner", ro_opt)
             try:
                 H = hip_from_oracle(A)
                 y = np.zeros(A.n)
                 H.matvec(x, y)
+                yt = np.zeros(A.m)
+                H.matvec_t(np.ones(A.n), yt)
             finally:
                 sg.set_option("csr_offset_dict", 1)
-            assert np.array_equal(y, y_ref), (name, opt)
+                sg.set_option("csr_row_owner", 1)
+            assert np.array_equal(y, y_ref), (name, dict_opt, ro_opt)
+            assert np.array_equal(yt, yt_ref), (name, dict_opt, ro_opt)
 
 
 def test_matvec_signed_zero_and_nonfinite(orc):

@@ -54,6 +54,7 @@ int main(int argc, char **argv)
     const int64_t nnz = node.size();
     CK(sgm_init(0));
     if (const char *d = getenv("SGM_CSR_DO")) CK(sgm_set_option("csr_offset_dict", atoi(d)));
+    if (const char *d = getenv("SGM_CSR_RO")) CK(sgm_set_option("csr_row_owner", atoi(d)));
     sgm_mat A;
     CK(sgm_csr_create(&A, (int32_t)n, (int32_t)n, nnz, ptr.data(), node.data(), val.data(), SGM_HOST));
     std::vector<double> hx(n);
