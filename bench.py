@@ -241,7 +241,7 @@ def main():
                        "parallelism": f"row-partition x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_csr_do<256,3>", "algorithmic_bytes_per_launch": bytes_rank,
+                         "kernel": "k_csr_do<256,1536,CW=1>", "algorithmic_bytes_per_launch": bytes_rank,
                          "avg_launch_ms": 1e3 * k_avg, "traffic_source": traffic_src,
                          "note": "achieved = algorithmic bytes (12 nnz + 4(n+1) + 16 n, the reference's int32/fp64 "
                                  "arrays) / measured launch time; the kernel streams 1-byte column codes, so the "
