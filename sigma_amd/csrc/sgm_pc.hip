@@ -16,6 +16,7 @@
 #include "sgm_internal.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace sgm {
@@ -270,9 +271,10 @@ int upload_tri(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const 
         // schedule: wide levels alone, runs of narrow levels together
         for (int32_t l = 0; l < nlev;) {
             const int32_t sz = T.level_ptr[l + 1] - T.level_ptr[l];
-            if (sz > kNarrow) { T.schedule.push_back({l, l + 1, false}); ++l; continue; }
+            static const int narrow = getenv("SGM_TRSV_NARROW") ? atoi(getenv("SGM_TRSV_NARROW")) : kNarrow;
+            if (sz > narrow) { T.schedule.push_back({l, l + 1, false}); ++l; continue; }
             int32_t e = l;
-            while (e < nlev && T.level_ptr[e + 1] - T.level_ptr[e] <= kNarrow) ++e;
+            while (e < nlev && T.level_ptr[e + 1] - T.level_ptr[e] <= narrow) ++e;
             T.schedule.push_back({l, e, true});
             l = e;
         }

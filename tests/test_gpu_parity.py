@@ -469,6 +469,51 @@ def test_solver_semantics(golden, orc):
     assert np.abs(u4 - g["ref_s2_u"]).max() / np.abs(g["ref_s2_u"]).max() <= 1e-12
 
 
+def test_solver_edge_cases(orc):
+    """Zero right-hand side (the loop is never entered, cg_solvers.f90:133), a 1 x 1 system,
+    odd sizes (vector kernels have a scalar tail), a non-zero initial guess, and the
+    BiCGStab omega NaN guard (bicgstab_solvers.f90:165: exact solve in the first step)."""
+    ptr, node, val = P.poisson2d_csr(17, 13)              # n = 221, odd
+    n = 221
+    A = orc.CsrMatrix(n, n, ptr, node, val)
+    H = hip_from_oracle(A)
+    for mk in (sg.cg, sg.bicgstab, lambda t: sg.gmres(t, 30)):
+        s = mk(1e-14)
+        s.setup(H)
+        u = np.zeros(n)
+        s.solve(H, u, np.zeros(n))
+        assert s.iterations == 0 and s.converged and not u.any()
+    x0 = P.test_vector(n)
+    b = A.matvec(np.ones(n))
+    for ofn, mk in ((orc.cg, sg.cg), (orc.bicgstab, sg.bicgstab)):
+        ur, itr, _, _ = ofn(A, b, x0=x0, tol=1e-13)
+        s = mk(1e-13)
+        s.setup(H)
+        u = x0.copy()
+        s.solve(H, u, b)
+        assert abs(s.iterations - itr) <= 1 and np.abs(u - ur).max() <= 1e-12
+        assert np.abs(u - 1.0).max() <= 1e-11
+    one = orc.CsrMatrix(1, 1, np.array([1, 2], np.int32), np.array([1], np.int32), np.array([4.0]))
+    H1 = hip_from_oracle(one)
+    for ofn, mk in ((orc.cg, sg.cg), (orc.bicgstab, sg.bicgstab)):
+        ur, itr, _, _ = ofn(one, np.array([2.0]), tol=1e-15)
+        s = mk(1e-15)
+        s.setup(H1)
+        u = np.zeros(1)
+        s.solve(H1, u, np.array([2.0]))
+        assert s.iterations == itr and u[0] == ur[0] == 0.5
+    # identity matrix: BiCGStab solves exactly in one step, s = 0, t = 0 -> omega = 0/0 = NaN -> 0
+    I = orc.CsrMatrix(64, 64, np.arange(1, 66, dtype=np.int32), np.arange(1, 65, dtype=np.int32), np.ones(64))
+    HI = hip_from_oracle(I)
+    bb = P.test_vector(64)
+    ur, itr, _, _ = orc.bicgstab(I, bb, tol=1e-15)
+    s = sg.bicgstab(1e-15)
+    s.setup(HI)
+    u = np.zeros(64)
+    s.solve(HI, u, bb)
+    assert s.iterations == itr == 1 and np.array_equal(u, ur) and np.all(np.isfinite(u))
+
+
 def test_residual_history_vs_oracle(orc):
     """res2 after every iteration, first 50 iterations, relative difference <= 1e-12
     (C2-mini and C5-mini; SURVEY §8d parity gates)."""
