@@ -491,7 +491,9 @@ def test_solver_edge_cases(orc):
         s.setup(H)
         u = x0.copy()
         s.solve(H, u, b)
-        assert abs(s.iterations - itr) <= 1 and np.abs(u - ur).max() <= 1e-12
+        # BiCGStab's residual is not monotone: the count at which it first dips below the
+        # tolerance moves by a few iterations with the rounding of the dots
+        assert abs(s.iterations - itr) <= (1 if ofn is orc.cg else 3) and np.abs(u - ur).max() <= 1e-12
         assert np.abs(u - 1.0).max() <= 1e-11
     one = orc.CsrMatrix(1, 1, np.array([1, 2], np.int32), np.array([1], np.int32), np.array([4.0]))
     H1 = hip_from_oracle(one)
