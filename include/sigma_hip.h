@@ -103,6 +103,20 @@ int sgm_mat_matvec_add(sgm_mat A, const double *x, double *y, int where);
  * (bit-identical, no atomics).  Single-GPU matrices only.                               */
 int sgm_mat_matvec_t(sgm_mat A, const double *x, double *y, int where);
 int sgm_mat_matvec_t_add(sgm_mat A, const double *x, double *y, int where);
+/* sgm_csr_from_edges / sgm_ell_from_edges <- the assembly sequence of the reference's tests
+ *   g%add_edge(i,j)... ; convert_graph_type(g, "compressed sparse" | "ellpack") ; A%set_graph(g) ;
+ *   A%set_value(i,j,z)...        (test/solver_test_jacobi.f90:73-128)
+ * i.e. ll_graphs.f90:355-370 (repeated edges ignored) + cs_graphs.f90:109-197 /
+ * ellpack_graphs.f90:105-170 + cs_matrices.f90:840-863 (the last value written wins).
+ * The edge list (1-based, INSERTION order) is turned into the same ptr/node/val (or
+ * node(max_d,n)/val/degrees) arrays on the device -- bit-identical index work.
+ * sgm_mat_get reads a leaf matrix back in the reference's layout: "ptr","node","val" (CSR),
+ * "max_d","degrees","node","val" (ELLPACK, (max_d,n) Fortran order).                     */
+int sgm_csr_from_edges(sgm_mat *out, int32_t nrow, int32_t ncol, int64_t ne, const int32_t *ei_1based,
+                       const int32_t *ej_1based, const double *ev, int where);
+int sgm_ell_from_edges(sgm_mat *out, int32_t nrow, int32_t ncol, int64_t ne, const int32_t *ei_1based,
+                       const int32_t *ej_1based, const double *ev, int where);
+int sgm_mat_get(sgm_mat A, const char *name, void *out_host, size_t bytes, size_t *needed);
 /* sgm_composite_create <- type(sparse_matrix), the block "matrix of matrices"
  *                         src/matrix/sparse_matrix_composites.f90:41-162; matvec_add = loop over
  *                         the blocks `C%matvec_add(x(j1:j2), y(i1:i2))`, :1076-1099 (row blocks

@@ -184,6 +184,30 @@ class _Matrix:
             raise SigmaError(1, "A%solve: no solver set (linear_operator_interface.f90:213-233)")
         return self.solver.solve(self, x, b, self.pc)
 
+    def get(self, name, dtype):
+        """Read a leaf matrix back in the reference's layout (sgm_mat_get)."""
+        need = C.c_size_t(0)
+        _ck(lib().sgm_mat_get(self._h, name.encode(), None, C.c_size_t(0), C.byref(need)))
+        out = np.zeros(need.value // np.dtype(dtype).itemsize, dtype)
+        _ck(lib().sgm_mat_get(self._h, name.encode(), C.c_void_p(out.ctypes.data), C.c_size_t(out.nbytes), None))
+        return out
+
+    @classmethod
+    def from_edges(cls, nrow, ncol, ei, ej, ev):
+        """Assemble on the device from an edge list in insertion order (1-based), like
+        g%add_edge ... convert_graph_type ... A%set_value (sgm_csr/ell_from_edges)."""
+        self = cls.__new__(cls)
+        _Matrix.__init__(self)
+        pi, w1, _k1 = _arg(ei, np.int32)
+        pj, w2, _k2 = _arg(ej, np.int32)
+        pv, w3, _k3 = _arg(ev, np.float64)
+        ne = ei.numel() if _is_torch(ei) else len(ei)
+        self.nrow, self.ncol = int(nrow), int(ncol)
+        fn = lib().sgm_csr_from_edges if cls is csr_matrix else lib().sgm_ell_from_edges
+        _ck(fn(C.byref(self._h), C.c_int32(nrow), C.c_int32(ncol), C.c_int64(ne), pi, pj, pv,
+               C.c_int(_same_where(w1, w2, w3))))
+        return self
+
     def destroy(self):
         if self._h:
             _ck(lib().sgm_mat_destroy(self._h))

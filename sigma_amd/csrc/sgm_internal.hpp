@@ -116,6 +116,7 @@ struct Part {
     int32_t max_d = 0;
     int32_t *ecol = nullptr;
     double *eval = nullptr;
+    int32_t *edeg = nullptr;       // degrees(n), only when built by sgm_ell_from_edges
     std::vector<HaloNbr> nbrs;
     double *xext = nullptr;        // owned+halo staging for plain-vector matvec (multi-part only)
     int dot_grid_override = 0;     // composite matrices: grid of the separate dot kernel

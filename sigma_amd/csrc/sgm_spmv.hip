@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 namespace sgm {
@@ -45,7 +46,9 @@ __global__ void k_ell_transpose(const int32_t *__restrict__ node, const double *
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; t < total; t += stride) {
         const int32_t k = (int32_t)(t / n), i = (int32_t)(t % n);
-        if (node) ecol[t] = node[(int64_t)i * max_d + k] - 1;
+        // an empty row keeps node = 0 in the reference (it then reads x(0): README.md:71-73);
+        // clamp so that the padding product 0.0 * x(1) stays inside the vector
+        if (node) ecol[t] = max(node[(int64_t)i * max_d + k] - 1, 0);
         if (val) eval[t] = val[(int64_t)i * max_d + k];
     }
 }
@@ -808,7 +811,7 @@ int build_csr_part(Part &p, int32_t n, int32_t ncol_own, int32_t n_halo, int64_t
 
 void free_part(Part &p)
 {
-    dfree(p.rowptr); dfree(p.col); dfree(p.val); dfree(p.code); dfree(p.dict); dfree(p.ecol); dfree(p.eval); dfree(p.xext);
+    dfree(p.rowptr); dfree(p.col); dfree(p.val); dfree(p.code); dfree(p.dict); dfree(p.ecol); dfree(p.eval); dfree(p.edeg); dfree(p.xext);
     for (auto &nb : p.nbrs) { dfree(nb.send_idx); dfree(nb.send_buf); }
     p = Part();
 }
@@ -1139,6 +1142,61 @@ int sgm_mat_matvec_t(sgm_mat A, const double *x, double *y, int where)
 int sgm_mat_matvec_t_add(sgm_mat A, const double *x, double *y, int where)
 {
     return matvec_t_impl(A, x, y, where, true);
+}
+
+int sgm_mat_get(sgm_mat A, const char *name, void *out, size_t bytes, size_t *needed)
+{
+    SGM_TRY(require_init());
+    if (!A || !name) return fail(SGM_ERR_BAD_ARG, "sgm_mat_get: null argument");
+    if (A->distributed() || A->fmt == SGM_FMT_COMPOSITE)
+        return fail(SGM_ERR_UNSUPPORTED, "sgm_mat_get: leaf single-GPU matrices only");
+    const Part &p = A->parts[0];
+    const std::string nm(name);
+    std::vector<int32_t> vi;
+    std::vector<double> vd;
+    SGM_HIP(hipStreamSynchronize(g_rt.stream));
+    const bool ell = A->fmt == SGM_FMT_ELL;
+    if (!ell && nm == "ptr") {
+        vi.resize((size_t)p.n + 1);
+        SGM_HIP(hipMemcpy(vi.data(), p.rowptr, vi.size() * 4, hipMemcpyDeviceToHost));
+        for (auto &v : vi) v += 1;
+    } else if (!ell && nm == "node") {
+        vi.resize((size_t)p.nnz);
+        if (p.nnz) SGM_HIP(hipMemcpy(vi.data(), p.col, vi.size() * 4, hipMemcpyDeviceToHost));
+        for (auto &v : vi) v += 1;
+    } else if (!ell && nm == "val") {
+        vd.resize((size_t)p.nnz);
+        if (p.nnz) SGM_HIP(hipMemcpy(vd.data(), p.val, vd.size() * 8, hipMemcpyDeviceToHost));
+    } else if (ell && nm == "max_d") {
+        vi.assign(1, p.max_d);
+    } else if (ell && nm == "degrees" && p.edeg) {
+        vi.resize((size_t)p.n);
+        if (p.n) SGM_HIP(hipMemcpy(vi.data(), p.edeg, vi.size() * 4, hipMemcpyDeviceToHost));
+    } else if (ell && (nm == "node" || nm == "val")) {
+        const size_t total = (size_t)p.n * p.max_d;       // back to the reference's (max_d, n) order
+        if (nm == "node") {
+            std::vector<int32_t> t(total);
+            if (total) SGM_HIP(hipMemcpy(t.data(), p.ecol, total * 4, hipMemcpyDeviceToHost));
+            vi.resize(total);
+            for (int32_t i = 0; i < p.n; ++i)
+                for (int32_t k = 0; k < p.max_d; ++k) vi[(size_t)i * p.max_d + k] = t[(size_t)k * p.n + i] + 1;
+        } else {
+            std::vector<double> t(total);
+            if (total) SGM_HIP(hipMemcpy(t.data(), p.eval, total * 8, hipMemcpyDeviceToHost));
+            vd.resize(total);
+            for (int32_t i = 0; i < p.n; ++i)
+                for (int32_t k = 0; k < p.max_d; ++k) vd[(size_t)i * p.max_d + k] = t[(size_t)k * p.n + i];
+        }
+    } else {
+        return fail(SGM_ERR_BAD_ARG, "sgm_mat_get: unknown array '%s' for this format", name);
+    }
+    const size_t sz = vi.size() * 4 + vd.size() * 8;
+    if (needed) *needed = sz;
+    if (out && sz) {
+        if (bytes < sz) return fail(SGM_ERR_BAD_ARG, "sgm_mat_get: buffer too small (%zu < %zu)", bytes, sz);
+        memcpy(out, vi.empty() ? (const void *)vd.data() : (const void *)vi.data(), sz);
+    }
+    return SGM_OK;
 }
 
 int sgm_mat_info(sgm_mat A, int32_t *nrow, int32_t *ncol, int64_t *nnz, int32_t *fmt, int64_t *x_len)
