@@ -179,6 +179,14 @@ int sgm_solver_info(sgm_solver s, int64_t *iterations, double *res2, int32_t *co
 int sgm_solver_get_history(sgm_solver s, double *out_host, int64_t capacity, int64_t *count);
 int sgm_solver_destroy(sgm_solver s);
 
+/* ---- Lanczos ------------------------------------------------------------------------- *
+ * sgm_lanczos <- lanczos(A, T, Q)  src/eigensolver.f90:27-90 (what eigensolve :160-208 feeds to
+ * LAPACK dstev): nsteps Lanczos steps with full re-orthogonalisation.  T_host: 3 x nsteps,
+ * column-major (T(2,:) diagonal, T(1,:) = T(3,:) off-diagonal); Q_out (optional): n x nsteps
+ * column-major Lanczos vectors.  q1 is the start vector (the reference draws it from a
+ * time-seeded RNG); it is normalised inside.                                              */
+int sgm_lanczos(sgm_mat A, int32_t nsteps, const double *q1, double *T_host, double *Q_out, int where);
+
 /* ---- row-partitioned multi-GPU (nothing in the reference) ---------------- *
  * One process per GPU.  Rank r owns the contiguous global rows
  * [row_starts[r], row_starts[r+1]) of A and the same slice of every vector.

@@ -260,6 +260,17 @@ def gmres(A, b, x0=None, pc=None, tol=1e-16, max_iter=0, restart=30, history=0):
                   extra=(C.c_int32(restart),))
 
 
+def lanczos(A, nsteps, q1):
+    """lanczos(A, T, Q) (eigensolver.f90:27-90) with the start vector given: returns
+    (T[3, nsteps] as the reference indexes it, Q[n, nsteps])."""
+    T = np.zeros((nsteps, 3), F8)
+    Q = np.zeros((nsteps, A.n), F8)
+    q1 = np.ascontiguousarray(q1, F8)
+    lib().orc_lanczos(C.c_int32(A.fmt), C.c_int32(A.n), C.c_int32(A.max_d), _p(A.ptr), _p(A.node),
+                      _p(A.val), C.c_int32(nsteps), _p(q1), _p(T), _p(Q))
+    return T.T.copy(), Q.T.copy()
+
+
 def set_dot_mode(mode):
     """0: left-to-right dot products; 1: four interleaved partial sums (a vectorising
     compiler's dot_product).  Both are valid restatements of the Fortran intrinsic."""

@@ -667,6 +667,45 @@ ORC_API int64_t orc_gmres(const orc_solve_args *a, int32_t m, double *x, const d
     return it;
 }
 
+/* lanczos(A, T, Q) (src/eigensolver.f90:27-90) with the start vector handed in instead of
+ * the time-seeded random_number (:45-49).  T: 3 x n column-major, Q: nrow x n column-major.
+ * `sum(a*b)` is the Fortran intrinsic: order unspecified, restated with dot().           */
+ORC_API void orc_lanczos(int32_t fmt, int32_t nrow, int32_t max_d, const int32_t *ptr,
+                         const int32_t *node, const double *val, int32_t n, const double *q1,
+                         double *T, double *Q)
+{
+    orc_op A = {fmt, nrow, max_d, ptr, node, val};
+    double *w = calloc(nrow, 8);
+    double alpha, beta = 0.0;
+    memset(T, 0, (size_t)3 * n * 8);
+    memset(Q, 0, (size_t)nrow * n * 8);
+#define QC(i) (Q + (size_t)((i) - 1) * nrow)
+    double nrm = sqrt(dot(nrow, q1, q1));
+    for (int32_t l = 0; l < nrow; l++) QC(1)[l] = q1[l] / nrm;
+    op_matvec(&A, QC(1), w);
+    alpha = dot(nrow, QC(1), w);
+    for (int32_t l = 0; l < nrow; l++) w[l] = w[l] - alpha * QC(1)[l];
+    beta = sqrt(dot(nrow, w, w));
+    for (int32_t l = 0; l < nrow; l++) QC(2)[l] = w[l] / beta;
+    T[1] = alpha; T[2] = beta; T[0] = beta;
+    for (int32_t i = 2; i <= n - 1; i++) {
+        op_matvec(&A, QC(i), w);
+        alpha = dot(nrow, QC(i), w);
+        for (int32_t l = 0; l < nrow; l++) w[l] = w[l] - alpha * QC(i)[l] - beta * QC(i - 1)[l];
+        for (int32_t k = 1; k <= i - 2; k++) {
+            double h = dot(nrow, QC(k), w);
+            for (int32_t l = 0; l < nrow; l++) w[l] = w[l] - h * QC(k)[l];
+        }
+        beta = sqrt(dot(nrow, w, w));
+        for (int32_t l = 0; l < nrow; l++) QC(i + 1)[l] = w[l] / beta;
+        T[3 * (i - 1) + 1] = alpha; T[3 * (i - 1) + 2] = beta; T[3 * (i - 1) + 0] = beta;
+    }
+    op_matvec(&A, QC(n), w);
+    T[3 * (n - 1) + 1] = dot(nrow, QC(n), w);
+#undef QC
+    free(w);
+}
+
 /* ------------------------------------------------------------------------ */
 /* Timing helpers for bench.py's cpu_baseline leg ("port", 1 thread: the     */
 /* reference has no threading, CMakeLists.txt:17-20).                       */

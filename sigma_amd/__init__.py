@@ -557,6 +557,22 @@ class Comm:
             self._h = C.c_void_p()
 
 
+def lanczos(A, nsteps, q1, want_Q=True):
+    """lanczos(A, T, Q) (src/eigensolver.f90:27-90) on the device with the start vector q1:
+    returns (T[3, nsteps], Q[n, nsteps] or None).  The eigenvalues of the tridiagonal
+    (diag T[1], off-diagonal T[2][:-1]) are what eigensolve :160-208 gets from dstev."""
+    if hasattr(A, "_build"):
+        A._build()
+    pq, w, _k = _arg(q1, np.float64)
+    T = np.zeros((nsteps, 3), np.float64)
+    Q = np.zeros((nsteps, A.nrow), np.float64) if want_Q else None
+    if w != SGM_HOST:
+        raise TypeError("lanczos: pass the start vector as a numpy array")
+    _ck(lib().sgm_lanczos(A._h, C.c_int32(nsteps), pq, C.c_void_p(T.ctypes.data),
+                          C.c_void_p(Q.ctypes.data) if want_Q else None, C.c_int(SGM_HOST)))
+    return T.T.copy(), (Q.T.copy() if want_Q else None)
+
+
 def halo_plan_host(n_own, col_begin, node_global):
     """Host-only index work of the row partition (no GPU needed): returns
     (node_local 1-based, halo_cols sorted unique global 1-based)."""

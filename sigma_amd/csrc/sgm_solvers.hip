@@ -504,6 +504,41 @@ struct FGmresUpdate {
     __device__ void finish(double *) {}
 };
 
+// ---- Lanczos (src/eigensolver.f90:27-90) -------------------------------------------------
+// w = w - alpha*q_i - beta*q_{i-1}   (eigensolver.f90:69; beta = sqrt(sum(nrm2)), q_prev may be null)
+struct FLanczosW {
+    static constexpr bool kDot = false;
+    double *w; const double *qi, *qprev; ScalarRef alpha, nrm2; double a = 0.0, b = 0.0;
+    __device__ bool prepare(double *red)
+    {
+        a = load_scalar<kBlock>(alpha, red);
+        if (qprev) b = sqrt(load_scalar<kBlock>(nrm2, red));
+        return true;
+    }
+    __device__ void one(int64_t i)
+    {
+        double wv = w[i] - a * qi[i];
+        if (qprev) wv = wv - b * qprev[i];
+        w[i] = wv;
+    }
+    template <bool NT> __device__ void pair(int64_t i) { one(2 * i); one(2 * i + 1); }
+    __device__ void single(int64_t i) { one(i); }
+    __device__ void finish(double *) {}
+};
+// T(2,i) = alpha ; T(3,i) = T(1,i) = beta      (eigensolver.f90:78-80)
+__global__ __launch_bounds__(kBlock) void k_lanczos_record(ScalarRef alpha, ScalarRef nrm2, int has_beta,
+                                                           double *T3 /* 3 x n, column-major */, int col)
+{
+    __shared__ double red[kBlock / 64];
+    const double a = load_scalar<kBlock>(alpha, red);
+    double b = 0.0;
+    if (has_beta) b = sqrt(load_scalar<kBlock>(nrm2, red));
+    if (threadIdx.x == 0) {
+        T3[3 * col + 1] = a;
+        if (has_beta) { T3[3 * col + 2] = b; T3[3 * col + 0] = b; }
+    }
+}
+
 // Grid policy of the vector kernels.  Kernels that leave partial sums need grid <= kMaxGrid;
 // pure update kernels take one pass over a large grid (a copy-like stream runs ~30 % faster
 // that way on MI355X than as a small persistent grid: tools/stream_bench.cpp).
@@ -1146,6 +1181,74 @@ int sgm_solver_destroy(sgm_solver s)
 }
 
 // ---- exported vector statements ------------------------------------------------------
+// sgm_lanczos <- lanczos(A, T, Q)  src/eigensolver.f90:27-90: n = nsteps Lanczos steps with full
+// re-orthogonalisation against q_1..q_{i-2}; T is the 3 x n band (T(2,:) diagonal, T(1,:)=T(3,:)
+// off-diagonal), Q the n_rows x n Lanczos vectors.  The reference draws q_1 from a time-seeded
+// RNG (util.f90:72-102); here the caller supplies it (it is normalised like eigensolver.f90:49).
+int sgm_lanczos(sgm_mat A, int32_t nsteps, const double *q1, double *T_host, double *Q_out, int where)
+{
+    SGM_TRY(require_init());
+    if (!A || nsteps < 2 || !q1 || !T_host) return fail(SGM_ERR_BAD_ARG, "sgm_lanczos: bad argument");
+    if (A->nrow != A->ncol) return fail(SGM_ERR_DIMS, "sgm_lanczos: square matrices only");
+    if (A->distributed()) return fail(SGM_ERR_UNSUPPORTED, "sgm_lanczos: single-GPU matrices only");
+    const int64_t n = A->nrow, ld = n + (n & 1);          // even leading dimension: 16-B aligned columns
+    double *Q = nullptr, *w = nullptr, *parts = nullptr, *T3 = nullptr;
+    SGM_TRY(dalloc(&Q, (size_t)ld * nsteps + 2));
+    SGM_TRY(dalloc(&w, (size_t)ld + 2));
+    SGM_TRY(dalloc(&parts, (size_t)4 * kMaxGrid));
+    SGM_TRY(dalloc(&T3, (size_t)3 * nsteps));
+    hipStream_t st = g_rt.stream;
+    SGM_HIP(hipMemsetAsync(T3, 0, (size_t)3 * nsteps * 8, st));
+    SGM_HIP(hipMemsetAsync(Q, 0, ((size_t)ld * nsteps + 2) * 8, st));
+    double *P_ALPHA = parts, *P_NRM = parts + kMaxGrid, *P_H[2] = {parts + 2 * kMaxGrid, parts + 3 * kMaxGrid};
+    auto q = [&](int i) { return Q + (size_t)(i - 1) * ld; };          // 1-based like the reference
+    const int gd = dot_grid(n);
+    {   // q_1 = q1 / sqrt(sum(q1*q1))
+        Staged s1;
+        SGM_TRY(stage_in(s1, q1, n, where, true));
+        launch_elem(n, FDot2{s1.dev, s1.dev, nullptr, nullptr, P_NRM, nullptr}, nullptr);
+        launch_elem(n, FScaleInv{q(1), s1.dev, ScalarRef{P_NRM, gd}}, nullptr);
+        SGM_HIP(hipStreamSynchronize(st));
+    }
+    const Part &p0 = A->parts[0];
+    for (int i = 1; i <= nsteps; ++i) {
+        // w = A q_i ; alpha = sum(q_i * w)
+        const double *xs[1] = {q(i)};
+        double *ys[1] = {w};
+        const double *ws[1] = {q(i)};
+        double *pw[1] = {P_ALPHA};
+        SpmvDots dots;
+        dots.w = ws; dots.part_wy = pw;
+        SGM_TRY(spmv_parts(A, xs, ys, false, &dots, nullptr, nullptr));
+        const ScalarRef alpha{P_ALPHA, spmv_grid(p0)};
+        if (i == nsteps) {                                   // eigensolver.f90:87-88
+            hipLaunchKernelGGL(k_lanczos_record, dim3(1), dim3(kBlock), 0, st, alpha, alpha, 0, T3, i - 1);
+            break;
+        }
+        // w = w - alpha q_i - beta q_{i-1}   (beta of the previous step = sqrt(P_NRM))
+        launch_elem(n, FLanczosW{w, q(i), i > 1 ? q(i - 1) : nullptr, alpha, ScalarRef{P_NRM, gd}}, nullptr);
+        // full re-orthogonalisation: for k = 1..i-2: w = w - sum(q_k*w) q_k  (fused like the GMRES MGS
+        // sweep), then beta^2 = sum(w*w)
+        const int nre = i - 2 > 0 ? i - 2 : 0;
+        for (int k = 1; k <= nre + 1; ++k) {
+            const double *vprev = k > 1 ? q(k - 1) : nullptr;
+            const double *vcur = k <= nre ? q(k) : nullptr;
+            double *out = k <= nre ? P_H[k & 1] : P_NRM;
+            launch_elem(n, FMgs{w, vprev, vcur, ScalarRef{P_H[(k - 1) & 1], gd}, out}, nullptr);
+        }
+        launch_elem(n, FScaleInv{q(i + 1), w, ScalarRef{P_NRM, gd}}, nullptr);
+        hipLaunchKernelGGL(k_lanczos_record, dim3(1), dim3(kBlock), 0, st, alpha, ScalarRef{P_NRM, gd}, 1, T3, i - 1);
+    }
+    SGM_HIP(hipGetLastError());
+    SGM_HIP(hipMemcpyAsync(T_host, T3, (size_t)3 * nsteps * 8, hipMemcpyDeviceToHost, st));
+    if (Q_out)
+        SGM_HIP(hipMemcpy2DAsync(Q_out, (size_t)n * 8, Q, (size_t)ld * 8, (size_t)n * 8, nsteps,
+                                 where == SGM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    dfree(Q); dfree(w); dfree(parts); dfree(T3);
+    return SGM_OK;
+}
+
 int sgm_dot(int64_t n, const double *a, const double *b, double *result, int where)
 {
     SGM_TRY(require_init());

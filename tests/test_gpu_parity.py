@@ -646,6 +646,37 @@ def test_gmres(golden, orc):
     assert np.abs(u - g["ref_s2_u"]).max() / np.abs(g["ref_s2_u"]).max() <= 1e-11
 
 
+# ------------------------------------------------------------------------------- Lanczos
+def test_lanczos_vs_oracle_and_spectrum(orc):
+    """lanczos (src/eigensolver.f90:27-90, restated in the oracle; the reference's own run
+    needs LAPACK and a time-seeded start vector, so it is pinned by the restatement and by the
+    analytic spectrum of the 5-point Laplacian): T and Q against the oracle for the same start
+    vector, Q orthonormal, extreme Ritz values against 4 - 2cos(i pi/(nx+1)) - 2cos(j pi/(ny+1))."""
+    nx, ny = 40, 30
+    n = nx * ny
+    A = orc.CsrMatrix(n, n, *P.poisson2d_csr(nx, ny))
+    H = hip_from_oracle(A)
+    q1 = 2 * np.random.RandomState(12).random_sample(n) - 1
+    m = 60
+    T, Q = sg.lanczos(H, m, q1)
+    To, Qo = orc.lanczos(A, m, q1)
+    assert np.abs(T[1] - To[1]).max() <= 1e-9 and np.abs(T[2] - To[2]).max() <= 1e-9
+    assert np.array_equal(T[0], T[2])
+    assert np.abs(Q[:, :10] - Qo[:, :10]).max() <= 1e-10
+    assert np.abs(Q.T @ Q - np.eye(m)).max() <= 1e-10          # full re-orthogonalisation
+    import scipy.linalg as sl
+    ritz = sl.eigvalsh_tridiagonal(T[1], T[2][:-1])
+    lam = (4 - 2 * np.cos(np.arange(1, nx + 1) * np.pi / (nx + 1))[:, None]
+           - 2 * np.cos(np.arange(1, ny + 1) * np.pi / (ny + 1))[None, :]).ravel()
+    ritz_o = sl.eigvalsh_tridiagonal(To[1], To[2][:-1])
+    assert np.abs(ritz - ritz_o).max() <= 1e-9
+    assert abs(ritz[-1] - lam.max()) <= 1e-4 and abs(ritz[0] - lam.min()) <= 1e-3     # 60 steps of 1200
+    # ELLPACK operator, composite operator
+    E = orc.EllMatrix.from_edges(n, n, *P.poisson2d_edges(nx, ny))
+    T2, _ = sg.lanczos(hip_from_oracle(E), 20, q1, want_Q=False)
+    assert np.abs(T2[1] - To[1][:20])[:19].max() <= 1e-9
+
+
 # ------------------------------------------------------------ row partition on one GPU
 @pytest.mark.parametrize("nparts", [2, 3, 8])
 def test_partitioned_matvec_bit_exact_and_cg(orc, nparts):
