@@ -62,6 +62,7 @@ int sgm_synchronize(void);
  * at most 255 distinct values (every stencil / banded matrix) get a second device copy of
  * the column indices as 1-byte dictionary codes, and matvec streams 9 instead of 12 bytes
  * per stored entry.  Results are bit-identical either way; 0 forces the int32 kernels.
+ * "ell_offset_dict" (default 1): the same for ELLPACK matrices with max_d <= 16.
  * "csr_row_owner" (default 1): int32-column matrices whose rows hold <= 32 entries use the
  * row-owner gather kernel; 0 forces the balanced streaming-gather kernel (any row length).  */
 int sgm_set_option(const char *name, int value);

@@ -34,6 +34,7 @@ int fail(int code, const char *fmt, ...);
 // ------------------------------------------------------------------ runtime
 struct Options {
     int csr_offset_dict = 1;       // use the 1-byte column code kernel when a matrix allows it
+    int ell_offset_dict = 1;       // ELLPACK twin of csr_offset_dict (max_d <= 16)
     int csr_row_owner = 1;         // int32 columns, rows <= 32 entries: gather by the row's owner lane
 };
 extern Options g_opt;
@@ -117,6 +118,8 @@ struct Part {
     int32_t *ecol = nullptr;
     double *eval = nullptr;
     int32_t *edeg = nullptr;       // degrees(n), only when built by sgm_ell_from_edges
+    uint8_t *ecode = nullptr;      // ELLPACK offset-dictionary codes, row-major n x emdp (emdp = max_d rounded up)
+    int32_t emdp = 0;
     std::vector<HaloNbr> nbrs;
     double *xext = nullptr;        // owned+halo staging for plain-vector matvec (multi-part only)
     int dot_grid_override = 0;     // composite matrices: grid of the separate dot kernel

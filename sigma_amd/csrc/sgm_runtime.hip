@@ -100,6 +100,7 @@ int sgm_set_option(const char *name, int value)
     if (!name) return fail(SGM_ERR_BAD_ARG, "sgm_set_option: null name");
     if (!strcmp(name, "csr_offset_dict")) { g_opt.csr_offset_dict = value; return SGM_OK; }
     if (!strcmp(name, "csr_row_owner")) { g_opt.csr_row_owner = value; return SGM_OK; }
+    if (!strcmp(name, "ell_offset_dict")) { g_opt.ell_offset_dict = value; return SGM_OK; }
     return fail(SGM_ERR_BAD_ARG, "sgm_set_option: unknown option '%s'", name);
 }
 

@@ -349,6 +349,59 @@ __global__ __launch_bounds__(kBlock) void k_ell_spmv(
     }
 }
 
+// ELLPACK with dictionary-coded column offsets (max_d <= 16, <= 255 distinct col-row offsets):
+// the MDP code bytes of a row are one 4/8/16-byte load, val stays slot-major (8-B coalesced
+// loads), lane i gathers x(i + dict[code]) for its own row -- adjacent lanes read adjacent x
+// entries for stencil-like matrices.  9 instead of 12 bytes per slot; all max_d slots are
+// walked in order (padding included), so the result is bit-identical to k_ell_spmv.
+template <int MDP, bool ADD, bool DOT_W, bool DOT_YY>
+__global__ __launch_bounds__(kBlock) void k_ell_do(
+    int32_t n, int32_t max_d, const uint8_t *__restrict__ ecode, const int32_t *__restrict__ dict,
+    const double *__restrict__ eval, const double *__restrict__ x, double *__restrict__ y,
+    const double *__restrict__ w, double *__restrict__ part_wy, double *__restrict__ part_yy,
+    const int *__restrict__ flag_done, int gen, int chain)
+{
+    __shared__ double red[kBlock / 64];
+    __shared__ int32_t dl[256];
+    if (flag_done) { const int st = *flag_done; if (st && gen >= st) return; }
+    for (int t = threadIdx.x; t < 256; t += kBlock) dl[t] = dict[t];
+    __syncthreads();
+    double dwy = 0.0, dyy = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        uint32_t cw[MDP / 4];
+        const uint32_t *cp = reinterpret_cast<const uint32_t *>(ecode + i * MDP);
+#pragma unroll
+        for (int q = 0; q < MDP / 4; ++q) cw[q] = __builtin_nontemporal_load(cp + q);
+        double wv = 0.0, y0 = 0.0;
+        if (DOT_W) wv = w[i];
+        if (ADD) y0 = y[i];
+        double v[MDP], xv[MDP];
+#pragma unroll
+        for (int k = 0; k < MDP; ++k)
+            if (k < max_d) {
+                v[k] = __builtin_nontemporal_load(eval + (int64_t)k * n + i);
+                xv[k] = x[i + dl[(cw[k >> 2] >> (8 * (k & 3))) & 255]];
+            }
+        double z = (ADD && chain) ? y0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < MDP; ++k)
+            if (k < max_d) z = z + v[k] * xv[k];
+        const double yi = ADD ? (chain ? z : y0 + z) : 0.0 + z;
+        y[i] = yi;
+        if (DOT_W) dwy += wv * yi;
+        if (DOT_YY) dyy += yi * yi;
+    }
+    if (DOT_W) {
+        const double t = block_sum<kBlock>(dwy, red);
+        if (threadIdx.x == 0) part_wy[blockIdx.x] = t;
+    }
+    if (DOT_YY) {
+        const double t = block_sum<kBlock>(dyy, red);
+        if (threadIdx.x == 0) part_yy[blockIdx.x] = t;
+    }
+}
+
 __global__ void k_gather(double *__restrict__ dst, const double *__restrict__ src,
                          const int32_t *__restrict__ idx, int32_t count)
 {
@@ -541,6 +594,22 @@ static void launch_ell(const Part &p, int grid, const double *x, double *y, cons
 {
     hipStream_t st = g_rt.stream;
     const EllCfg &c = ell_cfg();
+    if (p.ecode && g_opt.ell_offset_dict) {
+#define LD(M, DW, DY)                                                                                   \
+    hipLaunchKernelGGL((k_ell_do<M, ADD, DW, DY>), dim3(grid), dim3(kBlock), 0, st, p.n, p.max_d, p.ecode, \
+                       p.dict, p.eval, x, y, w, pwy, pyy, flag, gen, g_launch_flags & 256)
+#define LDV(M)                                   \
+    {                                            \
+        if (w && pyy) LD(M, true, true);         \
+        else if (w) LD(M, true, false);          \
+        else if (pyy) LD(M, false, true);        \
+        else LD(M, false, false);                \
+    }
+        if (p.emdp == 4) LDV(4) else if (p.emdp == 8) LDV(8) else LDV(16)
+#undef LDV
+#undef LD
+        return;
+    }
 #define L(UU, NTT, DW, DY)                                                                          \
     hipLaunchKernelGGL((k_ell_spmv<UU, NTT, ADD, DW, DY>), dim3(grid), dim3(kBlock), 0, st, p.n,     \
                        p.max_d, p.ecol, p.eval, x, y, w, pwy, pyy, flag, gen, g_launch_flags & 256)
@@ -781,6 +850,49 @@ static int build_offset_dict(Part &p, const int32_t *ptr1, const int32_t *node1)
     return SGM_OK;
 }
 
+// ELLPACK twin of build_offset_dict: codes for ALL max_d slots of every row (padding slots
+// carry the last neighbour, so their offsets are already in the dictionary), row-major with
+// the row padded to 4 / 8 / 16 bytes.  Skipped for max_d > 16 or > 255 distinct offsets.
+static int build_ell_offset_dict(Part &p)
+{
+    if (p.n == 0 || p.max_d == 0 || p.max_d > 16) return SGM_OK;
+    const size_t total = (size_t)p.n * p.max_d;
+    std::vector<int32_t> hc(total);
+    SGM_HIP(hipStreamSynchronize(g_rt.stream));
+    SGM_HIP(hipMemcpy(hc.data(), p.ecol, total * 4, hipMemcpyDeviceToHost));
+    const int mdp = p.max_d <= 4 ? 4 : p.max_d <= 8 ? 8 : 16;
+    std::vector<uint8_t> code((size_t)p.n * mdp + 16, 0);
+    std::vector<int32_t> dict;
+    constexpr int HS = 1024;
+    int32_t key[HS];
+    int16_t slot[HS];
+    for (int i = 0; i < HS; ++i) slot[i] = -1;
+    for (int32_t i = 0; i < p.n; ++i)
+        for (int32_t k = 0; k < p.max_d; ++k) {
+            const int32_t off = hc[(size_t)k * p.n + i] - i;
+            uint32_t h = ((uint32_t)off * 2654435761u) >> 22;
+            for (;;) {
+                if (slot[h] < 0) {
+                    if (dict.size() == 255) return SGM_OK;
+                    slot[h] = (int16_t)dict.size();
+                    key[h] = off;
+                    dict.push_back(off);
+                    break;
+                }
+                if (key[h] == off) break;
+                h = (h + 1) & (HS - 1);
+            }
+            code[(size_t)i * mdp + k] = (uint8_t)slot[h];
+        }
+    dict.resize(256, 0);
+    SGM_TRY(dalloc(&p.ecode, code.size()));
+    if (!p.dict) SGM_TRY(dalloc(&p.dict, (size_t)256));
+    SGM_HIP(hipMemcpy(p.ecode, code.data(), code.size(), hipMemcpyHostToDevice));
+    SGM_HIP(hipMemcpy(p.dict, dict.data(), 256 * 4, hipMemcpyHostToDevice));
+    p.emdp = mdp;
+    return SGM_OK;
+}
+
 // Upload one CSR row block.  ptr1 is 1-based local (n+1), node1 is 1-based and already
 // renumbered to [owned | halo]; `where` says where the three arrays live.
 int build_csr_part(Part &p, int32_t n, int32_t ncol_own, int32_t n_halo, int64_t nnz,
@@ -811,7 +923,7 @@ int build_csr_part(Part &p, int32_t n, int32_t ncol_own, int32_t n_halo, int64_t
 
 void free_part(Part &p)
 {
-    dfree(p.rowptr); dfree(p.col); dfree(p.val); dfree(p.code); dfree(p.dict); dfree(p.ecol); dfree(p.eval); dfree(p.edeg); dfree(p.xext);
+    dfree(p.rowptr); dfree(p.col); dfree(p.val); dfree(p.code); dfree(p.dict); dfree(p.ecol); dfree(p.eval); dfree(p.edeg); dfree(p.ecode); dfree(p.xext);
     for (auto &nb : p.nbrs) { dfree(nb.send_idx); dfree(nb.send_buf); }
     p = Part();
 }
@@ -1065,6 +1177,7 @@ int sgm_ell_create(sgm_mat *out, int32_t nrow, int32_t ncol, int32_t max_d, cons
         hipLaunchKernelGGL(k_ell_transpose, dim3(vec_grid(total)), dim3(kBlock), 0, g_rt.stream, node,
                            (const double *)nullptr, p.ecol, p.eval, nrow, max_d);
     }
+    SGM_TRY(build_ell_offset_dict(p));
     return sgm_ell_set_values(A, val, where);
 }
 

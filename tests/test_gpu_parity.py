@@ -327,6 +327,25 @@ def test_offset_dict_and_int32_kernels_agree(orc):
             assert np.array_equal(yt, yt_ref), (name, dict_opt, ro_opt)
 
 
+@pytest.mark.parametrize("name", [n for n in golden_names() if "_ell_" in n])
+def test_ell_offset_dict_and_plain_kernels_agree(golden, name):
+    """ELLPACK matrices with max_d <= 16 and few distinct offsets take the 1-byte code kernel;
+    the plain int32 slot-major kernel must give the same bits (both equal the reference)."""
+    g = golden(name)
+    for opt in (1, 0):
+        sg.set_option("ell_offset_dict", opt)
+        try:
+            A = hip_matrix(g)
+            y = np.zeros(int(g["n"]))
+            A.matvec(g["x"], y)
+            yt = np.zeros(int(g["m"]))
+            A.matvec_t(g["b"], yt)
+        finally:
+            sg.set_option("ell_offset_dict", 1)
+        assert np.array_equal(y, g["ref_y"]), opt
+        assert np.array_equal(yt, g["ref_yt"]), opt
+
+
 def test_matvec_signed_zero_and_nonfinite(orc):
     """0 + z keeps the reference's +0.0 for an all-cancelling / empty row; 0*Inf in an
     ELLPACK padding slot is NaN in the reference too."""
