@@ -656,7 +656,8 @@ static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const doub
     // into val/col/code; the offset-dict kernel forms columns as row + offset, so x shifts too
     Part v;
     v.n = r.hi - r.lo;
-    v.nnz = p.nnz; v.n_halo = p.n_halo; v.ncol_own = p.ncol_own;
+    v.nnz = (int64_t)((double)p.nnz * v.n / (p.n > 0 ? p.n : 1));   // same row density => same tile choice as the full part
+    v.n_halo = p.n_halo; v.ncol_own = p.ncol_own;
     v.rowptr = p.rowptr + r.lo; v.col = p.col; v.val = p.val; v.code = p.code; v.dict = p.dict;
     v.max_row = p.max_row;
     const bool dict = use_offset_dict(p);
