@@ -11,8 +11,13 @@
 // row recurrence (ldu_solvers.f90:227-236).  Rows are grouped into dependency LEVELS at
 // setup; rows of one level are independent, each lane does its row's
 // z = z - val(k)*x(node(k)) left to right, so the result is bit-identical to the
-// sequential sweep.  Wide levels get one launch each; runs of narrow levels are executed
-// by ONE workgroup that walks the levels with a barrier in between (no launch per level).
+// sequential sweep.  The solve runs in "position space": vectors are permuted into level
+// order (xp[pos]), every row is a 64-byte record {count, first 4 (dependency position, value)}
+// so that ONE independent load brings a row and can be issued a level ahead, and
+// dependencies are positions.  Wide levels get one launch each; runs of narrow levels
+// (<= 4096 rows) are walked by ONE 1024-thread workgroup that keeps the last 8192 results in
+// an LDS ring: a level then costs LDS reads + a barrier instead of four dependent global
+// round trips (3.9 us -> see DESIGN.md).
 #include "sgm_internal.hpp"
 
 #include <algorithm>
@@ -33,14 +38,28 @@ using namespace sgm;
 namespace {
 
 constexpr int kTrsvBlock = 1024;
-constexpr int kNarrow = 2048;        // levels with <= this many rows are walked by one workgroup
+constexpr int kNarrow = 4096;        // levels with <= this many rows are walked by one workgroup (4 rows per lane)
+constexpr int kRing = 8192;          // LDS ring of recent results (64 KiB): covers two narrow levels
+constexpr int kInline = 4;           // dependencies stored inside the row record
 
-struct TriFactor {                   // strictly triangular CSR factor on the device (0-based)
-    int32_t *rowptr = nullptr, *col = nullptr;
-    double *val = nullptr;
-    int32_t *order = nullptr;        // rows sorted by level
-    std::vector<int32_t> level_ptr;  // host: offsets into order per level
+struct TrsvRec {                     // one row of a triangular factor, in level order (64 bytes)
+    int32_t cnt, k0;                 // entries of the row; offset of its entries in pq / pv
+    int32_t q[kInline];              // position (in level order) of the first dependencies
+    double v[kInline];               // their values
+    int32_t pad[2];
+};
+static_assert(sizeof(TrsvRec) == 64, "TrsvRec is one 64-byte record");
+
+struct TriFactor {                   // strictly triangular factor on the device, level order
+    int32_t *order = nullptr;        // device: pos -> row
+    TrsvRec *recs = nullptr;         // device: n records
+    int32_t *pq = nullptr;           // device: dependency positions of ALL entries, rows in level order
+    double *pv = nullptr;            // device: their values
     int32_t *level_ptr_dev = nullptr;
+    std::vector<int32_t> level_ptr;  // host: offsets into the level order per level
+    std::vector<int32_t> h_order, h_pos, h_src;      // host: pos -> row, row -> pos, level-order entry -> factor entry
+    std::vector<TrsvRec> h_recs;
+    std::vector<int32_t> h_pq;
     struct Launch { int32_t l0, l1; bool narrow; };
     std::vector<Launch> schedule;
 };
@@ -58,6 +77,8 @@ struct sgm_pc_s {
     // ildu (single part)
     TriFactor L, U;
     double *D = nullptr;
+    double *xpL = nullptr, *xpU = nullptr, *Dp = nullptr;   // level-order work vectors, D in U's level order
+    int32_t *mapLU = nullptr;                                // U position -> L position of the same row
     std::vector<int32_t> hLptr, hLnode, hUptr, hUnode;      // 1-based, as the reference holds them
     std::vector<double> hLval, hUval, hD, hidiag;
 };
@@ -112,37 +133,113 @@ __global__ void k_copy(int64_t n, const double *__restrict__ s, double *__restri
     for (; i < n; i += stride) d[i] = s[i];
 }
 
-__device__ inline void trsv_row(int32_t row, const int32_t *rowptr, const int32_t *col, const double *val,
-                                double *x)
-{
-    double z = x[row];
-    for (int32_t k = rowptr[row]; k < rowptr[row + 1]; ++k) z = z - val[k] * x[col[k]];
-    x[row] = z;
-}
-// one wide level
-__global__ void k_trsv_level(const int32_t *__restrict__ order, int32_t begin, int32_t end,
-                             const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                             const double *__restrict__ val, double *x, const int *flag)
+__global__ void k_perm_gather(int64_t n, double *__restrict__ xp, const double *__restrict__ src,
+                              const int32_t *__restrict__ order, const int *flag)
 {
     if (flag && *flag) return;
-    const int32_t t = begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < end) trsv_row(order[t], rowptr, col, val, x);
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; p < n; p += stride) xp[p] = src[order[p]];            // x = b, in level order
 }
-// a run of narrow levels [l0, l1) walked by ONE workgroup; the x entries written in level
-// l are read in level l+1 by the same workgroup (barrier + workgroup-scope ordering).
-__global__ __launch_bounds__(kTrsvBlock) void k_trsv_narrow(const int32_t *__restrict__ order,
-                                                            const int32_t *__restrict__ level_ptr, int32_t l0,
-                                                            int32_t l1, const int32_t *__restrict__ rowptr,
-                                                            const int32_t *__restrict__ col,
-                                                            const double *__restrict__ val, double *x,
-                                                            const int *flag)
+__global__ void k_lu_transition(int64_t n, double *__restrict__ xpU, const double *__restrict__ xpL,
+                                const int32_t *__restrict__ mapLU, const double *__restrict__ Dp, const int *flag)
 {
     if (flag && *flag) return;
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; p < n; p += stride) xpU[p] = xpL[mapLU[p]] / Dp[p];   // x = x / D, re-ordered for the U sweep
+}
+__global__ void k_perm_scatter(int64_t n, double *__restrict__ dst, const double *__restrict__ xp,
+                               const int32_t *__restrict__ order, const int *flag)
+{
+    if (flag && *flag) return;
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; p < n; p += stride) dst[order[p]] = xp[p];
+}
+
+// one wide level: one lane per row, dependencies read from global memory
+__global__ void k_trsv_wide(const TrsvRec *__restrict__ recs, const int32_t *__restrict__ pq,
+                            const double *__restrict__ pv, int32_t begin, int32_t end, double *xp, const int *flag)
+{
+    if (flag && *flag) return;
+    const int32_t p = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= end) return;
+    const TrsvRec r = recs[p];
+    double z = xp[p];
+#pragma unroll
+    for (int j = 0; j < kInline; ++j)
+        if (j < r.cnt) z = z - r.v[j] * xp[r.q[j]];
+    for (int32_t k = r.k0 + kInline; k < r.k0 + r.cnt; ++k) z = z - pv[k] * xp[pq[k]];
+    xp[p] = z;
+}
+
+// a run of narrow levels [l0, l1) walked by ONE workgroup.  The records and right-hand sides of
+// level l+1 are requested before level l is computed (independent loads); results of the
+// current run live in an LDS ring indexed by position, so the dependencies of the next level
+// are LDS reads; anything older than the ring (or produced before this run) is read from xp,
+// which the per-level workgroup fence + barrier keeps valid.
+__global__ __launch_bounds__(kTrsvBlock) void k_trsv_walk(const TrsvRec *__restrict__ recs,
+                                                          const int32_t *__restrict__ pq,
+                                                          const double *__restrict__ pv,
+                                                          const int32_t *__restrict__ level_ptr, int32_t l0,
+                                                          int32_t l1, double *xp, const int *flag)
+{
+    __shared__ double ring[kRing];
+    if (flag && *flag) return;
+    constexpr int RPT = kNarrow / kTrsvBlock;
+    const int32_t base = level_ptr[l0];
+    TrsvRec pre[RPT];
+    double z0pre[RPT];
+    auto fetch = [&](int32_t l) {
+        const int32_t b = level_ptr[l], e = level_ptr[l + 1];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int32_t p = b + threadIdx.x + r * kTrsvBlock;
+            if (p < e) {
+                pre[r] = recs[p];
+                z0pre[r] = xp[p];          // the right-hand side entry: only this row ever writes it
+            }
+        }
+    };
+    fetch(l0);
+    int32_t fpos = base;      // every position < fpos is visible in xp (written before a workgroup fence)
     for (int32_t l = l0; l < l1; ++l) {
         const int32_t b = level_ptr[l], e = level_ptr[l + 1];
-        for (int32_t t = b + threadIdx.x; t < e; t += kTrsvBlock) trsv_row(order[t], rowptr, col, val, x);
-        __threadfence_block();
-        __syncthreads();
+        if (e - fpos > kRing) {
+            // the ring is about to lose positions that were never fenced: make all stores of this
+            // run visible in xp first (rare: once per ~2 narrow levels at most, usually far less)
+            __threadfence_block();
+            __syncthreads();
+            fpos = b;
+        }
+        TrsvRec cur[RPT];
+        double z0[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) { cur[r] = pre[r]; z0[r] = z0pre[r]; }
+        if (l + 1 < l1) fetch(l + 1);
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int32_t p = b + threadIdx.x + r * kTrsvBlock;
+            if (p >= e) continue;
+            double z = z0[r];
+#pragma unroll
+            for (int j = 0; j < kInline; ++j)
+                if (j < cur[r].cnt) {
+                    const int32_t q = cur[r].q[j];
+                    const double xv = q >= fpos ? ring[q & (kRing - 1)] : xp[q];
+                    z = z - cur[r].v[j] * xv;
+                }
+            for (int32_t k = cur[r].k0 + kInline; k < cur[r].k0 + cur[r].cnt; ++k) {
+                const int32_t q = pq[k];
+                const double xv = q >= fpos ? ring[q & (kRing - 1)] : xp[q];
+                z = z - pv[k] * xv;
+            }
+            ring[p & (kRing - 1)] = z;
+            xp[p] = z;                       // drains in the background; readers use the ring
+        }
+        // level barrier on the LDS ring only: the global stores above stay in flight
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
 
@@ -238,26 +335,23 @@ void ildu_factor(sgm_pc pc, int32_t n, const std::vector<int32_t> &ptr, const st
 
 void free_tri(TriFactor &T)
 {
-    dfree(T.rowptr); dfree(T.col); dfree(T.val); dfree(T.order); dfree(T.level_ptr_dev);
+    dfree(T.order); dfree(T.recs); dfree(T.pq); dfree(T.pv); dfree(T.level_ptr_dev);
     T = TriFactor();
 }
 
-// upload a strictly triangular factor and build its level schedule.  lower: rows depend on
-// smaller rows (forward sweep 1..n); upper: on larger rows (backward sweep n..1).
+// upload a strictly triangular factor in level order.  lower: rows depend on smaller rows
+// (forward sweep 1..n); upper: on larger rows (backward sweep n..1).
 int upload_tri(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const std::vector<int32_t> &node1,
                const std::vector<double> &val, bool lower, bool pattern_changed)
 {
     const size_t nnz = node1.size();
     if (pattern_changed) {
         free_tri(T);
-        std::vector<int32_t> rp(n + 1), cl(std::max<size_t>(nnz, 1));
-        for (int32_t i = 0; i <= n; ++i) rp[i] = ptr1[i] - 1;
-        for (size_t k = 0; k < nnz; ++k) cl[k] = node1[k] - 1;
         std::vector<int32_t> level(n, 0);
         int32_t nlev = 0;
         auto visit = [&](int32_t i) {
             int32_t lv = 0;
-            for (int32_t k = rp[i]; k < rp[i + 1]; ++k) lv = std::max(lv, level[cl[k]] + 1);
+            for (int32_t k = ptr1[i] - 1; k < ptr1[i + 1] - 1; ++k) lv = std::max(lv, level[node1[k] - 1] + 1);
             level[i] = lv;
             nlev = std::max(nlev, lv + 1);
         };
@@ -266,43 +360,74 @@ int upload_tri(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const 
         T.level_ptr.assign(nlev + 1, 0);
         for (int32_t i = 0; i < n; ++i) T.level_ptr[level[i] + 1]++;
         for (int32_t l = 0; l < nlev; ++l) T.level_ptr[l + 1] += T.level_ptr[l];
-        std::vector<int32_t> order(std::max(n, 1)), cursor(T.level_ptr.begin(), T.level_ptr.end() - 1);
-        for (int32_t i = 0; i < n; ++i) order[cursor[level[i]]++] = i;
+        T.h_order.assign(std::max(n, 1), 0);
+        T.h_pos.assign(std::max(n, 1), 0);
+        std::vector<int32_t> cursor(T.level_ptr.begin(), T.level_ptr.end() - 1);
+        for (int32_t i = 0; i < n; ++i) {
+            const int32_t p = cursor[level[i]]++;
+            T.h_order[p] = i;
+            T.h_pos[i] = p;
+        }
+        // rows in level order: dependency POSITIONS in stored order
+        T.h_recs.assign(std::max(n, 1), TrsvRec());
+        T.h_pq.assign(std::max<size_t>(nnz, 1), 0);
+        T.h_src.assign(std::max<size_t>(nnz, 1), 0);
+        int32_t kk = 0;
+        for (int32_t p = 0; p < n; ++p) {
+            const int32_t i = T.h_order[p];
+            TrsvRec &r = T.h_recs[p];
+            r.cnt = ptr1[i + 1] - ptr1[i];
+            r.k0 = kk;
+            for (int32_t k = ptr1[i] - 1; k < ptr1[i + 1] - 1; ++k, ++kk) {
+                T.h_pq[kk] = T.h_pos[node1[k] - 1];
+                T.h_src[kk] = k;
+                if (kk - r.k0 < kInline) r.q[kk - r.k0] = T.h_pq[kk];
+            }
+        }
         // schedule: wide levels alone, runs of narrow levels together
+        static const int narrow = getenv("SGM_TRSV_NARROW") ? std::min(atoi(getenv("SGM_TRSV_NARROW")), kNarrow) : kNarrow;
         for (int32_t l = 0; l < nlev;) {
             const int32_t sz = T.level_ptr[l + 1] - T.level_ptr[l];
-            static const int narrow = getenv("SGM_TRSV_NARROW") ? atoi(getenv("SGM_TRSV_NARROW")) : kNarrow;
             if (sz > narrow) { T.schedule.push_back({l, l + 1, false}); ++l; continue; }
             int32_t e = l;
             while (e < nlev && T.level_ptr[e + 1] - T.level_ptr[e] <= narrow) ++e;
             T.schedule.push_back({l, e, true});
             l = e;
         }
-        SGM_TRY(dalloc(&T.rowptr, (size_t)n + 1));
-        SGM_TRY(dalloc(&T.col, nnz));
-        SGM_TRY(dalloc(&T.val, nnz));
         SGM_TRY(dalloc(&T.order, (size_t)n));
+        SGM_TRY(dalloc(&T.recs, (size_t)n));
+        SGM_TRY(dalloc(&T.pq, nnz));
+        SGM_TRY(dalloc(&T.pv, nnz));
         SGM_TRY(dalloc(&T.level_ptr_dev, T.level_ptr.size()));
-        SGM_HIP(hipMemcpy(T.rowptr, rp.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
-        if (nnz) SGM_HIP(hipMemcpy(T.col, cl.data(), nnz * 4, hipMemcpyHostToDevice));
-        if (n) SGM_HIP(hipMemcpy(T.order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        if (n) SGM_HIP(hipMemcpy(T.order, T.h_order.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        if (nnz) SGM_HIP(hipMemcpy(T.pq, T.h_pq.data(), nnz * 4, hipMemcpyHostToDevice));
         SGM_HIP(hipMemcpy(T.level_ptr_dev, T.level_ptr.data(), T.level_ptr.size() * 4, hipMemcpyHostToDevice));
     }
-    if (nnz) SGM_HIP(hipMemcpy(T.val, val.data(), nnz * 8, hipMemcpyHostToDevice));
+    // values (every setup): level-order copy + the inline part of the records
+    std::vector<double> hv(std::max<size_t>(nnz, 1));
+    for (size_t kk = 0; kk < nnz; ++kk) hv[kk] = val[T.h_src[kk]];
+    for (int32_t p = 0; p < n; ++p) {
+        TrsvRec &r = T.h_recs[p];
+        for (int j = 0; j < kInline && j < r.cnt; ++j) r.v[j] = hv[r.k0 + j];
+    }
+    if (nnz) SGM_HIP(hipMemcpy(T.pv, hv.data(), nnz * 8, hipMemcpyHostToDevice));
+    if (n) SGM_HIP(hipMemcpy(T.recs, T.h_recs.data(), (size_t)n * sizeof(TrsvRec), hipMemcpyHostToDevice));
     return SGM_OK;
 }
 
-void trsv(const TriFactor &T, double *x, const int *flag)
+// triangular solve in position space: xp holds the right-hand side on entry, the solution on exit
+void trsv(const TriFactor &T, double *xp, const int *flag)
 {
     hipStream_t st = g_rt.stream;
     for (const auto &L : T.schedule) {
         if (L.narrow) {
-            hipLaunchKernelGGL(k_trsv_narrow, dim3(1), dim3(kTrsvBlock), 0, st, T.order, T.level_ptr_dev, L.l0, L.l1,
-                               T.rowptr, T.col, T.val, x, flag);
+            hipLaunchKernelGGL(k_trsv_walk, dim3(1), dim3(kTrsvBlock), 0, st, (const TrsvRec *)T.recs,
+                               (const int32_t *)T.pq, (const double *)T.pv, (const int32_t *)T.level_ptr_dev, L.l0, L.l1,
+                               xp, flag);
         } else {
             const int32_t b = T.level_ptr[L.l0], e = T.level_ptr[L.l1];
-            hipLaunchKernelGGL(k_trsv_level, dim3((e - b + kBlock - 1) / kBlock), dim3(kBlock), 0, st, T.order, b, e,
-                               T.rowptr, T.col, T.val, x, flag);
+            hipLaunchKernelGGL(k_trsv_wide, dim3((e - b + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
+                               (const TrsvRec *)T.recs, (const int32_t *)T.pq, (const double *)T.pv, b, e, xp, flag);
         }
     }
 }
@@ -343,10 +468,14 @@ int pc_apply_parts(sgm_pc pc, sgm_mat A, const double *const *r, double *const *
     } else {
         const int64_t n = pc->n;
         const int *flag = flags ? flags[0] : nullptr;
-        hipLaunchKernelGGL(k_copy, dim3(vec_grid(n)), dim3(kBlock), 0, st, n, r[0], z[0], flag);   // x = b
-        trsv(pc->L, z[0], flag);
-        hipLaunchKernelGGL(k_div_by, dim3(vec_grid(n)), dim3(kBlock), 0, st, n, pc->D, z[0], flag);
-        trsv(pc->U, z[0], flag);
+        const int g = vec_grid(n);
+        hipLaunchKernelGGL(k_perm_gather, dim3(g), dim3(kBlock), 0, st, n, pc->xpL, r[0], (const int32_t *)pc->L.order, flag);
+        trsv(pc->L, pc->xpL, flag);                                             // (I+L) x = b
+        hipLaunchKernelGGL(k_lu_transition, dim3(g), dim3(kBlock), 0, st, n, pc->xpU, (const double *)pc->xpL,
+                           (const int32_t *)pc->mapLU, (const double *)pc->Dp, flag);                       // x = x / D
+        trsv(pc->U, pc->xpU, flag);                                             // (I+U) x = x
+        hipLaunchKernelGGL(k_perm_scatter, dim3(g), dim3(kBlock), 0, st, n, z[0], (const double *)pc->xpU,
+                           (const int32_t *)pc->U.order, flag);
     }
     SGM_HIP(hipGetLastError());
     return SGM_OK;
@@ -400,8 +529,23 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
     ildu_factor(pc, n, ptr1, node1, val);
     SGM_TRY(upload_tri(pc->L, n, pc->hLptr, pc->hLnode, pc->hLval, true, fresh));
     SGM_TRY(upload_tri(pc->U, n, pc->hUptr, pc->hUnode, pc->hUval, false, fresh));
-    if (fresh) { dfree(pc->D); SGM_TRY(dalloc(&pc->D, (size_t)n)); }
-    if (n) SGM_HIP(hipMemcpy(pc->D, pc->hD.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    if (fresh) {
+        dfree(pc->D); dfree(pc->xpL); dfree(pc->xpU); dfree(pc->Dp); dfree(pc->mapLU);
+        SGM_TRY(dalloc(&pc->D, (size_t)n));
+        SGM_TRY(dalloc(&pc->xpL, (size_t)n));
+        SGM_TRY(dalloc(&pc->xpU, (size_t)n));
+        SGM_TRY(dalloc(&pc->Dp, (size_t)n));
+        SGM_TRY(dalloc(&pc->mapLU, (size_t)n));
+        std::vector<int32_t> map((size_t)std::max(n, 1));
+        for (int32_t p = 0; p < n; ++p) map[p] = pc->L.h_pos[pc->U.h_order[p]];
+        if (n) SGM_HIP(hipMemcpy(pc->mapLU, map.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    }
+    std::vector<double> dp((size_t)std::max(n, 1));
+    for (int32_t p = 0; p < n; ++p) dp[p] = pc->hD[pc->U.h_order[p]];
+    if (n) {
+        SGM_HIP(hipMemcpy(pc->D, pc->hD.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+        SGM_HIP(hipMemcpy(pc->Dp, dp.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    }
     return SGM_OK;
 }
 
@@ -493,7 +637,7 @@ int sgm_pc_destroy(sgm_pc pc)
     for (auto &pp : pc->parts) dfree(pp.idiag);
     free_tri(pc->L);
     free_tri(pc->U);
-    dfree(pc->D);
+    dfree(pc->D); dfree(pc->xpL); dfree(pc->xpU); dfree(pc->Dp); dfree(pc->mapLU);
     delete pc;
     return SGM_OK;
 }
