@@ -64,7 +64,12 @@ int sgm_synchronize(void);
  * per stored entry.  Results are bit-identical either way; 0 forces the int32 kernels.
  * "ell_offset_dict" (default 1): the same for ELLPACK matrices with max_d <= 16.
  * "csr_row_owner" (default 1): int32-column matrices whose rows hold <= 32 entries use the
- * row-owner gather kernel; 0 forces the balanced streaming-gather kernel (any row length).  */
+ * row-owner gather kernel; 0 forces the balanced streaming-gather kernel (any row length).
+ * "csr_sliced" (default 0): offset-dictionary matrices whose rows hold <= 8 entries from <= 15
+ * distinct offsets (1-D/2-D/3-D stencils) also keep their values in slices of 256 rows,
+ * slot-major, plus one 32-bit word of 4-bit codes per row: every load is coalesced and
+ * independent, no row pointers are read (8 W + 4 bytes per row of width W).  Measured equal to
+ * the 1-byte-code kernel within noise, hence opt-in.                      */
 int sgm_set_option(const char *name, int value);
 int sgm_malloc(void **p, size_t bytes);   /* HBM buffer for hosts without a device allocator */
 int sgm_free(void *p);
@@ -130,6 +135,9 @@ int sgm_composite_create(sgm_mat *out, int32_t nrb, int32_t ncb, const int32_t *
                          const int32_t *col_ptr_1based, const sgm_mat *blocks);
 int sgm_mat_info(sgm_mat A, int32_t *nrow, int32_t *ncol, int64_t *nnz, int32_t *fmt,
                  int64_t *x_len /* entries matvec reads from x: ncol, or owned+halo when distributed */);
+/* name of the SpMV kernel variant the matrix runs with under the current options
+ * (diagnostics for benches and tests; e.g. "k_csr_sl<W=5>", "k_csr_do<256,1536,CW=1>") */
+int sgm_mat_kernel(sgm_mat A, char *buf, int len);
 int sgm_mat_destroy(sgm_mat A);
 
 /* ---- vector statements inline in the solvers (SURVEY §2a "dot", "axpy family") ---- *

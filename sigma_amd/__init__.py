@@ -90,7 +90,9 @@ def synchronize():
 
 def set_option(name, value):
     """sgm_set_option: "csr_offset_dict" 1/0 (1-byte column codes for stencil-like matrices),
-    "csr_row_owner" 1/0 (row-owner gather for int32-column matrices with rows <= 32 entries)."""
+    "csr_row_owner" 1/0 (row-owner gather for int32-column matrices with rows <= 32 entries),
+    "csr_sliced" 1/0 (opt-in: slot-major slices + 4-bit codes for rows <= 8 entries / <= 15 offsets),
+    "ell_offset_dict" 1/0."""
     _ck(lib().sgm_set_option(name.encode(), C.c_int(int(value))))
 
 
@@ -169,6 +171,13 @@ class _Matrix:
         n = C.c_int64(0)
         _ck(lib().sgm_mat_info(self._h, None, None, None, None, C.byref(n)))
         return n.value
+
+    @property
+    def kernel(self):
+        """Name of the SpMV kernel variant this matrix runs with under the current options."""
+        buf = C.create_string_buffer(64)
+        _ck(lib().sgm_mat_kernel(self._h, buf, C.c_int(64)))
+        return buf.value.decode()
 
     # -- linear_operator_interface.f90:213-280: A%solve facade ---------------------------
     def set_solver(self, solver):

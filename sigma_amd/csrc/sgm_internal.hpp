@@ -36,6 +36,7 @@ struct Options {
     int csr_offset_dict = 1;       // use the 1-byte column code kernel when a matrix allows it
     int ell_offset_dict = 1;       // ELLPACK twin of csr_offset_dict (max_d <= 16)
     int csr_row_owner = 1;         // int32 columns, rows <= 32 entries: gather by the row's owner lane
+    int csr_sliced = 0;            // rows <= 8 entries, <= 15 offsets: slot-major slices + 4-bit codes (k_csr_sl); opt-in
 };
 extern Options g_opt;
 
@@ -113,6 +114,12 @@ struct Part {
     int32_t *dict = nullptr;       // 256 entries
     int32_t ndict = 0;
     int32_t max_row = 0;           // longest row (entries); picks the row-owner kernel for short rows
+    // sliced form (rows <= 8 entries, <= 15 distinct offsets, little padding): slices of 256
+    // rows, values slot-major inside a slice (entry (slot u, row r) at ((r/256)*sw + u)*256 + r%256),
+    // the row's column offsets as 8 four-bit dictionary codes in one word (15 = no entry)
+    double *sval = nullptr;
+    uint32_t *scode = nullptr;
+    int32_t sw = 0;                // slots per row in sval (3, 5, 7 or 8)
     // ELLPACK (device, slot-major: entry (slot k, row i) at k*n + i)
     int32_t max_d = 0;
     int32_t *ecol = nullptr;

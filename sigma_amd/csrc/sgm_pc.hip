@@ -19,6 +19,7 @@
 // an LDS ring: a level then costs LDS reads + a barrier instead of four dependent global
 // round trips (3.9 us -> see DESIGN.md).
 #include "sgm_internal.hpp"
+#include <type_traits>
 
 #include <algorithm>
 #include <cstdlib>
@@ -56,11 +57,15 @@ struct TriFactor {                   // strictly triangular factor on the device
     int32_t *pq = nullptr;           // device: dependency positions of ALL entries, rows in level order
     double *pv = nullptr;            // device: their values
     int32_t *level_ptr_dev = nullptr;
+    uint64_t *dq = nullptr;          // device: ring-walker copy, 4 x 16-bit position deltas per row (0 = none)
+    double *dv = nullptr;            // device: ring-walker copy, kInline value slots, slot-major (slot*n + pos)
+    std::vector<uint64_t> h_dq;
+    size_t nstride = 0;              // entries per value slot of dv (n + padding)
     std::vector<int32_t> level_ptr;  // host: offsets into the level order per level
     std::vector<int32_t> h_order, h_pos, h_src;      // host: pos -> row, row -> pos, level-order entry -> factor entry
     std::vector<TrsvRec> h_recs;
     std::vector<int32_t> h_pq;
-    struct Launch { int32_t l0, l1; bool narrow; };
+    struct Launch { int32_t l0, l1; bool narrow; int rpt; bool ring; int c; };    // c: most dependencies of a row in the run   // rpt: rows per lane of the walker (1, 2, 4); ring: k_trsv_walk_ring applies
     std::vector<Launch> schedule;
 };
 
@@ -174,72 +179,208 @@ __global__ void k_trsv_wide(const TrsvRec *__restrict__ recs, const int32_t *__r
     xp[p] = z;
 }
 
-// a run of narrow levels [l0, l1) walked by ONE workgroup.  The records and right-hand sides of
-// level l+1 are requested before level l is computed (independent loads); results of the
-// current run live in an LDS ring indexed by position, so the dependencies of the next level
-// are LDS reads; anything older than the ring (or produced before this run) is read from xp,
-// which the per-level workgroup fence + barrier keeps valid.
+// a run of narrow levels [l0, l1) walked by ONE workgroup.  The row records and right-hand
+// sides are independent of the solve, so they are requested D levels ahead (registers; one
+// HBM round trip is ~2 us, one level's arithmetic a fraction of that); results of the current
+// run live in an LDS ring indexed by position, so the dependencies of the next level are LDS
+// reads; anything older than the ring (or produced before this run) is read from xp, which
+// the workgroup fence + barrier before a ring wrap keeps valid.  RPT = rows per lane and
+// level (levels of up to RPT*1024 rows); RPT*D records are in flight per lane.
+template <int RPT, int D>
 __global__ __launch_bounds__(kTrsvBlock) void k_trsv_walk(const TrsvRec *__restrict__ recs,
                                                           const int32_t *__restrict__ pq,
                                                           const double *__restrict__ pv,
                                                           const int32_t *__restrict__ level_ptr, int32_t l0,
-                                                          int32_t l1, double *xp, const int *flag)
+                                                          int32_t l1, int32_t n, double *xp, const int *flag)
 {
+    // Every prefetch load and every result store is issued by ALL lanes on EVERY level (lanes
+    // without a row use a clamped record and the scratch slots xp[n + lane]): the compiler can
+    // then count the younger requests exactly and waits for a prefetched record with
+    // s_waitcnt vmcnt(k > 0); a conditional load or store in the loop would turn every wait
+    // into vmcnt(0), i.e. one HBM round trip per level.
     __shared__ double ring[kRing];
     if (flag && *flag) return;
-    constexpr int RPT = kNarrow / kTrsvBlock;
-    const int32_t base = level_ptr[l0];
-    TrsvRec pre[RPT];
-    double z0pre[RPT];
-    auto fetch = [&](int32_t l) {
-        const int32_t b = level_ptr[l], e = level_ptr[l + 1];
+    const int tid = threadIdx.x;
+    TrsvRec pre[D][RPT];
+    double z0pre[D][RPT];
+    int32_t lb[D], le[D];
+    // a level's bounds are a scalar load: requested at the top of a step (overlaps the LDS
+    // reads), consumed by the row requests at its end
+    auto bounds = [&](int32_t l, int32_t &b, int32_t &e) {
+        const int32_t lc = min(l, l1 - 1);           // past the run: an empty level (requests are clamped)
+        b = level_ptr[lc];
+        e = level_ptr[lc + 1];
+        if (l >= l1) b = e;
+    };
+    auto fetch = [&](int slot, int32_t b, int32_t e) {
+        lb[slot] = b;
+        le[slot] = e;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            const int32_t p = b + threadIdx.x + r * kTrsvBlock;
-            if (p < e) {
-                pre[r] = recs[p];
-                z0pre[r] = xp[p];          // the right-hand side entry: only this row ever writes it
-            }
+            const int32_t p = b + tid + r * kTrsvBlock;
+            const bool ok = p < e;
+            pre[slot][r] = recs[ok ? p : n - 1];
+            z0pre[slot][r] = xp[ok ? p : n + tid + r * kTrsvBlock];   // right-hand side: only this row ever writes it
         }
     };
-    fetch(l0);
-    int32_t fpos = base;      // every position < fpos is visible in xp (written before a workgroup fence)
-    for (int32_t l = l0; l < l1; ++l) {
-        const int32_t b = level_ptr[l], e = level_ptr[l + 1];
-        if (e - fpos > kRing) {
-            // the ring is about to lose positions that were never fenced: make all stores of this
-            // run visible in xp first (rare: once per ~2 narrow levels at most, usually far less)
-            __threadfence_block();
-            __syncthreads();
-            fpos = b;
-        }
-        TrsvRec cur[RPT];
-        double z0[RPT];
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) { cur[r] = pre[r]; z0[r] = z0pre[r]; }
-        if (l + 1 < l1) fetch(l + 1);
+    for (int j = 0; j < D; ++j) {
+        int32_t b, e;
+        bounds(l0 + j, b, e);
+        fetch(j, b, e);
+    }
+    int32_t fpos = level_ptr[l0];   // every position < fpos is visible in xp (written before a workgroup fence)
+    for (int32_t l = l0; l < l1; l += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {                // levels past l1 are empty: same instruction stream
+            const int32_t b = lb[j], e = le[j];
+            int32_t nb, ne;
+            bounds(l + j + D, nb, ne);
+            if (e - fpos > kRing) {
+                // the ring is about to lose positions that were never fenced: make all stores of
+                // this run visible in xp first (rare: once per ~2 widest levels at most)
+                __threadfence_block();
+                __syncthreads();
+                fpos = b;
+            }
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const int32_t p = b + tid + r * kTrsvBlock;
+                const bool ok = p < e;
+                const int32_t cnt = ok ? pre[j][r].cnt : 0;
+                double z = z0pre[j][r];
+                bool fast = cnt <= kInline;
+#pragma unroll
+                for (int i = 0; i < kInline; ++i) fast = fast & ((i >= cnt) | (pre[j][r].q[i] >= fpos));
+                if (fast) {                          // every dependency is in the LDS ring: no memory wait
+#pragma unroll
+                    for (int i = 0; i < kInline; ++i) {
+                        const double t = z - pre[j][r].v[i] * ring[pre[j][r].q[i] & (kRing - 1)];
+                        z = i < cnt ? t : z;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < kInline; ++i)      // (static indices: the records stay in registers)
+                        if (i < cnt) {
+                            const int32_t q = pre[j][r].q[i];
+                            const double xv = q >= fpos ? ring[q & (kRing - 1)] : xp[q];
+                            z = z - pre[j][r].v[i] * xv;
+                        }
+                    for (int32_t k = pre[j][r].k0 + kInline; k < pre[j][r].k0 + cnt; ++k) {
+                        const int32_t q = pq[k];
+                        const double xv = q >= fpos ? ring[q & (kRing - 1)] : xp[q];
+                        z = z - pv[k] * xv;
+                    }
+                }
+                if (ok) ring[p & (kRing - 1)] = z;
+                xp[ok ? p : n + tid + r * kTrsvBlock] = z;     // drains in the background; readers use the ring
+            }
+            // slot j is free again: request level l+j+D into the same registers (issued after the
+            // last use, so the compiler needs no second register set and no copies at the back-edge)
+            fetch(j, nb, ne);
+            // level barrier on the LDS ring only: the global stores above stay in flight
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+}
+
+// The same walk for runs whose rows all have <= kInline dependencies, every one of them within
+// kRing positions below the end of the row's own level (checked on the host at setup; true for
+// grid-like factors).  The ring is pre-loaded with the kRing results that precede the run, so
+// EVERY dependency is an LDS read: no fence, no branch, and no memory request inside the loop
+// other than the D-level-ahead prefetch and the result store -- the loop is one straight
+// instruction stream, which lets the compiler wait for a prefetched row with an exact
+// s_waitcnt vmcnt(k).  One workgroup on one CU is bound by the CU's memory pipeline (measured:
+// 64-byte records, one per lane = 64 cache lines per load instruction, ~0.9 us per 1000-row
+// level), so these runs read a structure-of-arrays copy instead: per row ONE 8-byte word of
+// four 16-bit ring slots (position & (kRing-1); kRing = "no entry", a slot that holds 0.0 and
+// is paired with the value 0.0) and C values, slot-major -- every load is a coalesced 8 bytes
+// per lane, C + 3 memory instructions and ~3 ALU instructions per dependency.
+template <int RPT, int D, int C>
+__global__ __launch_bounds__(kTrsvBlock) void k_trsv_walk_ring(const uint64_t *__restrict__ dq,
+                                                               const double *__restrict__ dv, uint32_t nstride,
+                                                               const int32_t *__restrict__ level_ptr, int32_t l0,
+                                                               int32_t l1, int32_t n, double *xp, const int *flag)
+{
+    // ring[kRing] is a constant 0.0 (the slot absent dependencies point at, with value 0.0:
+    // z - 0.0*0.0 == z for every z, so they need no branch); ring[kRing+1+lane]: parking
+    __shared__ double ring[kRing + 1 + kTrsvBlock];
+    if (flag && *flag) return;
+    const uint32_t tid = threadIdx.x;
+    {
+        const int32_t base = level_ptr[l0];
+        for (int32_t q = base - 1 - (int32_t)tid; q >= 0 && q >= base - kRing; q -= kTrsvBlock) ring[q & (kRing - 1)] = xp[q];
+        if (tid == 0) ring[kRing] = 0.0;
+    }
+    // byte offsets fit 32 bits (checked on the host): scalar base + 32-bit lane offset addressing
+    const char *dqb = reinterpret_cast<const char *>(dq);
+    const char *dvb[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) dvb[i] = reinterpret_cast<const char *>(dv + (size_t)i * nstride);
+    char *xpb = reinterpret_cast<char *>(xp);
+    const uint32_t park_ring = (kRing + 1 + tid) * 8u;
+    // (C <= 2 reads only the low half of the slot word: a half-used 64-bit register pair would
+    //  hand its idle half to the register allocator, and a write to it must wait for the load)
+    using WQ = typename std::conditional<(C <= 2), uint32_t, uint64_t>::type;
+    WQ wq[D][RPT];
+    double wv[D][RPT][C], z0pre[D][RPT];
+    int32_t lb[D], le[D];
+    auto bounds = [&](int32_t l, int32_t &b, int32_t &e) {
+        const int32_t lc = min(l, l1 - 1);           // past the run: an empty level
+        b = level_ptr[lc];
+        e = level_ptr[lc + 1];
+        if (l >= l1) b = e;
+    };
+    auto fetch = [&](int slot, int32_t b, int32_t e) {
+        lb[slot] = b;
+        le[slot] = e;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            const int32_t p = b + threadIdx.x + r * kTrsvBlock;
-            if (p >= e) continue;
-            double z = z0[r];
+            // lanes past the level's end read the rows that follow (the arrays are padded by
+            // kNarrow entries); what they compute lands in the parking slots
+            const uint32_t off = ((uint32_t)b + tid + r * kTrsvBlock) * 8u;
+            wq[slot][r] = *reinterpret_cast<const WQ *>(dqb + off);
 #pragma unroll
-            for (int j = 0; j < kInline; ++j)
-                if (j < cur[r].cnt) {
-                    const int32_t q = cur[r].q[j];
-                    const double xv = q >= fpos ? ring[q & (kRing - 1)] : xp[q];
-                    z = z - cur[r].v[j] * xv;
-                }
-            for (int32_t k = cur[r].k0 + kInline; k < cur[r].k0 + cur[r].cnt; ++k) {
-                const int32_t q = pq[k];
-                const double xv = q >= fpos ? ring[q & (kRing - 1)] : xp[q];
-                z = z - pv[k] * xv;
-            }
-            ring[p & (kRing - 1)] = z;
-            xp[p] = z;                       // drains in the background; readers use the ring
+            for (int i = 0; i < C; ++i) wv[slot][r][i] = *reinterpret_cast<const double *>(dvb[i] + off);
+            z0pre[slot][r] = *reinterpret_cast<const double *>(xpb + off);
         }
-        // level barrier on the LDS ring only: the global stores above stay in flight
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        int32_t b, e;
+        bounds(l0 + j, b, e);
+        fetch(j, b, e);
+    }
+    __syncthreads();
+    const char *ringb = reinterpret_cast<const char *>(ring);
+    for (int32_t l = l0; l < l1; l += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {                // levels past l1 are empty: same instruction stream
+            const int32_t b = lb[j], e = le[j];
+            int32_t nb, ne;
+            bounds(l + j + D, nb, ne);
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const uint32_t p = (uint32_t)b + tid + r * kTrsvBlock;
+                const bool ok = p < (uint32_t)e;
+                double z = z0pre[j][r];
+#pragma unroll
+                for (int i = 0; i < C; ++i) {
+                    const uint32_t slot = (uint32_t)(wq[j][r] >> (16 * i)) & 0xffffu;     // ring slot of the dependency
+                    z = z - wv[j][r][i] * *reinterpret_cast<const double *>(ringb + slot * 8u);
+                }
+                *reinterpret_cast<double *>(const_cast<char *>(ringb) + (ok ? (p & (kRing - 1)) * 8u : park_ring)) = z;
+                *reinterpret_cast<double *>(xpb + (ok ? p : (uint32_t)n + tid + r * kTrsvBlock) * 8u) = z;
+            }
+            // slot j is free again: request level l+j+D into the same registers (issued after the
+            // last use, so the compiler needs no second register set and no copies at the back-edge)
+            fetch(j, nb, ne);
+            // level barrier on the LDS ring only: the global stores above stay in flight
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // keep the next level's address arithmetic below this point: hoisted above, it would
+            // pull the wait for that level's (still in flight) row up here
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
@@ -335,7 +476,7 @@ void ildu_factor(sgm_pc pc, int32_t n, const std::vector<int32_t> &ptr, const st
 
 void free_tri(TriFactor &T)
 {
-    dfree(T.order); dfree(T.recs); dfree(T.pq); dfree(T.pv); dfree(T.level_ptr_dev);
+    dfree(T.order); dfree(T.recs); dfree(T.pq); dfree(T.pv); dfree(T.level_ptr_dev); dfree(T.dq); dfree(T.dv);
     T = TriFactor();
 }
 
@@ -388,12 +529,42 @@ int upload_tri(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const 
         static const int narrow = getenv("SGM_TRSV_NARROW") ? std::min(atoi(getenv("SGM_TRSV_NARROW")), kNarrow) : kNarrow;
         for (int32_t l = 0; l < nlev;) {
             const int32_t sz = T.level_ptr[l + 1] - T.level_ptr[l];
-            if (sz > narrow) { T.schedule.push_back({l, l + 1, false}); ++l; continue; }
+            if (sz > narrow) { T.schedule.push_back({l, l + 1, false, 0, false, 0}); ++l; continue; }
+            // runs are cut by width class (rows per lane 1 / 2 / 4): narrower levels leave
+            // registers for a deeper record prefetch
+            auto cls = [&](int32_t lev) { const int32_t w = T.level_ptr[lev + 1] - T.level_ptr[lev];
+                                          return w <= kTrsvBlock ? 1 : w <= 2 * kTrsvBlock ? 2 : 4; };
+            const int c = cls(l);
             int32_t e = l;
-            while (e < nlev && T.level_ptr[e + 1] - T.level_ptr[e] <= narrow) ++e;
-            T.schedule.push_back({l, e, true});
+            while (e < nlev && T.level_ptr[e + 1] - T.level_ptr[e] <= narrow && cls(e) == c) ++e;
+            // all dependencies inline and within the ring's reach?  (see k_trsv_walk_ring)
+            bool ring_ok = true;
+            int cmax = 0;
+            for (int32_t lev = l; lev < e && ring_ok; ++lev)
+                for (int32_t p = T.level_ptr[lev]; p < T.level_ptr[lev + 1] && ring_ok; ++p) {
+                    const TrsvRec &r = T.h_recs[p];
+                    ring_ok = r.cnt <= kInline;
+                    cmax = std::max(cmax, r.cnt);
+                    for (int32_t k = r.k0; k < r.k0 + r.cnt && ring_ok; ++k)
+                        ring_ok = T.h_pq[k] >= T.level_ptr[lev + 1] - kRing && T.h_pq[k] < p;
+                }
+            T.schedule.push_back({l, e, true, c, ring_ok, cmax});
             l = e;
         }
+        // ring-walker copy of the structure: 16-bit ring slots (only read in ring runs), padded
+        // by kNarrow rows so that lanes past a level's end read valid memory
+        T.nstride = (size_t)n + kNarrow;
+        T.h_dq.assign(T.nstride, 0);
+        for (int32_t p = 0; p < n; ++p) {
+            const TrsvRec &r = T.h_recs[p];
+            uint64_t w = 0;
+            for (int j = 0; j < kInline; ++j)
+                w |= (uint64_t)(j < r.cnt ? (r.q[j] & (kRing - 1)) : kRing) << (16 * j);
+            T.h_dq[p] = w;
+        }
+        SGM_TRY(dalloc(&T.dq, T.nstride));
+        SGM_TRY(dalloc(&T.dv, T.nstride * kInline));
+        SGM_HIP(hipMemcpy(T.dq, T.h_dq.data(), T.h_dq.size() * 8, hipMemcpyHostToDevice));
         SGM_TRY(dalloc(&T.order, (size_t)n));
         SGM_TRY(dalloc(&T.recs, (size_t)n));
         SGM_TRY(dalloc(&T.pq, nnz));
@@ -412,18 +583,48 @@ int upload_tri(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const 
     }
     if (nnz) SGM_HIP(hipMemcpy(T.pv, hv.data(), nnz * 8, hipMemcpyHostToDevice));
     if (n) SGM_HIP(hipMemcpy(T.recs, T.h_recs.data(), (size_t)n * sizeof(TrsvRec), hipMemcpyHostToDevice));
+    if (n) {
+        std::vector<double> sv(T.nstride * kInline, 0.0);
+        for (int32_t p = 0; p < n; ++p)
+            for (int j = 0; j < kInline && j < T.h_recs[p].cnt; ++j) sv[(size_t)j * T.nstride + p] = T.h_recs[p].v[j];
+        SGM_HIP(hipMemcpy(T.dv, sv.data(), sv.size() * 8, hipMemcpyHostToDevice));
+    }
     return SGM_OK;
 }
 
 // triangular solve in position space: xp holds the right-hand side on entry, the solution on exit
 void trsv(const TriFactor &T, double *xp, const int *flag)
 {
+    const int32_t n = (int32_t)T.h_order.size();
     hipStream_t st = g_rt.stream;
     for (const auto &L : T.schedule) {
         if (L.narrow) {
-            hipLaunchKernelGGL(k_trsv_walk, dim3(1), dim3(kTrsvBlock), 0, st, (const TrsvRec *)T.recs,
-                               (const int32_t *)T.pq, (const double *)T.pv, (const int32_t *)T.level_ptr_dev, L.l0, L.l1,
-                               xp, flag);
+            static const int depth = getenv("SGM_TRSV_DEPTH") ? atoi(getenv("SGM_TRSV_DEPTH")) : 0;   // tuning aid
+#define WALK(R, DD)                                                                                          \
+    hipLaunchKernelGGL((k_trsv_walk<R, DD>), dim3(1), dim3(kTrsvBlock), 0, st, (const TrsvRec *)T.recs,       \
+                       (const int32_t *)T.pq, (const double *)T.pv, (const int32_t *)T.level_ptr_dev, L.l0, L.l1, \
+                       n, xp, flag)
+#define RING(R, DD, CC)                                                                                      \
+    hipLaunchKernelGGL((k_trsv_walk_ring<R, DD, CC>), dim3(1), dim3(kTrsvBlock), 0, st, (const uint64_t *)T.dq, \
+                       (const double *)T.dv, (uint32_t)T.nstride, (const int32_t *)T.level_ptr_dev, L.l0, L.l1, n, xp,    \
+                       flag)
+#define RINGC(R, DD)                                                          \
+    do {                                                                      \
+        if (L.c <= 2) RING(R, DD, 2); else if (L.c == 3) RING(R, DD, 3); else RING(R, DD, 4); \
+    } while (0)
+            static const bool no_ring = getenv("SGM_TRSV_NO_RING") != nullptr;                       // tuning aid
+            if (L.ring && !no_ring && T.nstride < (size_t)500000000) {       // (32-bit byte offsets)
+                if (L.rpt == 1) {
+                    if (depth == 1) RINGC(1, 1); else if (depth == 2) RINGC(1, 2); else if (depth == 8) RINGC(1, 8); else RINGC(1, 4);
+                } else if (L.rpt == 2) {
+                    if (depth == 1) RINGC(2, 1); else RINGC(2, 2);
+                } else RINGC(4, 1);
+            } else if (L.rpt == 1) WALK(1, 2);
+            else if (L.rpt == 2) WALK(2, 1);
+            else WALK(4, 1);
+#undef RINGC
+#undef RING
+#undef WALK
         } else {
             const int32_t b = T.level_ptr[L.l0], e = T.level_ptr[L.l1];
             hipLaunchKernelGGL(k_trsv_wide, dim3((e - b + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
@@ -532,8 +733,8 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
     if (fresh) {
         dfree(pc->D); dfree(pc->xpL); dfree(pc->xpU); dfree(pc->Dp); dfree(pc->mapLU);
         SGM_TRY(dalloc(&pc->D, (size_t)n));
-        SGM_TRY(dalloc(&pc->xpL, (size_t)n));
-        SGM_TRY(dalloc(&pc->xpU, (size_t)n));
+        SGM_TRY(dalloc(&pc->xpL, (size_t)n + kNarrow));     // + scratch slots of the level walker
+        SGM_TRY(dalloc(&pc->xpU, (size_t)n + kNarrow));
         SGM_TRY(dalloc(&pc->Dp, (size_t)n));
         SGM_TRY(dalloc(&pc->mapLU, (size_t)n));
         std::vector<int32_t> map((size_t)std::max(n, 1));

@@ -300,6 +300,92 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
     }
 }
 
+// Sliced form of the offset-dict kernel, for matrices whose rows hold <= 8 entries drawn from
+// <= 15 distinct (column - row) offsets (1-D/2-D/3-D stencils, also after the [owned | halo]
+// renumbering of a slab).  At upload the values are re-laid in slices of 256 rows, slot-major
+// inside a slice, and the row's column offsets become eight 4-bit dictionary codes in ONE
+// 32-bit word (code 15 = no entry; a row's entries fill slots 0.. in stored order).  Lane i
+// then reads everything row i needs with independent, fully coalesced loads -- W values
+// (512 contiguous bytes per wave and slot), one code word, W x entries -- no LDS staging, no
+// barrier, no row pointers: every load of a row block is in flight at once, which is what
+// the streaming (cache-cold) regime wants.  HBM bytes per row: 8 W + 4 (+ x, y) instead of
+// 9 nnz_row + 4.  The products are rounded one by one and added in stored order, exactly like
+// the other kernels (bit-identical results).
+template <int W, bool ADD, bool DOT_W, bool DOT_YY>
+__global__ __launch_bounds__(256) void k_csr_sl(
+    int32_t n, const uint32_t *__restrict__ scode, const int32_t *__restrict__ dict,
+    const double *__restrict__ sval, const double *__restrict__ x, double *__restrict__ y,
+    const double *__restrict__ w, double *__restrict__ part_wy, double *__restrict__ part_yy,
+    const int *__restrict__ flag_done, int gen, int remap)
+{
+    constexpr int BLOCK = 256;
+    __shared__ int32_t dl[16];
+    __shared__ double red[BLOCK / 64];
+    if (flag_done) { const int st = *flag_done; if (st && gen >= st) return; }
+    const int tid = threadIdx.x;
+    const bool chain = (remap & 256) != 0;
+    const int rmode = remap & 255;
+    if (tid < 16) dl[tid] = dict[tid];
+    __syncthreads();
+    const int64_t nrb = ((int64_t)n + BLOCK - 1) / BLOCK;
+    double dwy = 0.0, dyy = 0.0;
+
+    for (int it = 0;; ++it) {
+        if ((int64_t)it * gridDim.x >= nrb) break;
+        const int64_t rb = rmode ? rowblock_of(it, blockIdx.x, gridDim.x, nrb, rmode) : (int64_t)it * gridDim.x + blockIdx.x;
+        if (rb >= nrb) continue;
+        const int32_t row = (int32_t)(rb * BLOCK) + tid;
+        uint32_t cw = 0xffffffffu;
+        double wv = 0.0, y0 = 0.0;
+        if (row < n) {
+            cw = __builtin_nontemporal_load(scode + row);
+            if (DOT_W) wv = w[row];
+            if (ADD) y0 = y[row];
+        }
+        const double *vb = sval + rb * (int64_t)(W * BLOCK) + tid;     // slices are whole: no bounds
+        double v[W], xv[W];
+#pragma unroll
+        for (int u = 0; u < W; ++u) v[u] = __builtin_nontemporal_load(vb + u * BLOCK);
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            const uint32_t c = (cw >> (4 * u)) & 15u;
+            xv[u] = c != 15u ? x[row + dl[c]] : 0.0;
+        }
+        double z = (ADD && chain) ? y0 : 0.0;
+#pragma unroll
+        for (int u = 0; u < W; ++u)
+            if (((cw >> (4 * u)) & 15u) != 15u) z = z + v[u] * xv[u];
+        if (row < n) {
+            const double yi = ADD ? (chain ? z : y0 + z) : 0.0 + z;
+            __builtin_nontemporal_store(yi, y + row);
+            if (DOT_W) dwy += wv * yi;
+            if (DOT_YY) dyy += yi * yi;
+        }
+    }
+    if (DOT_W) {
+        const double t = block_sum<BLOCK>(dwy, red);
+        if (tid == 0) part_wy[blockIdx.x] = t;
+    }
+    if (DOT_YY) {
+        const double t = block_sum<BLOCK>(dyy, red);
+        if (tid == 0) part_yy[blockIdx.x] = t;
+    }
+}
+
+// values in CSR order -> sliced layout (at upload and after every value update)
+__global__ __launch_bounds__(256) void k_sl_pack(int32_t n, int32_t W, const int32_t *__restrict__ rowptr,
+                                                 const double *__restrict__ val, double *__restrict__ sval)
+{
+    const int64_t nrb = ((int64_t)n + 255) / 256;
+    for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+        const int64_t row = rb * 256 + threadIdx.x;
+        int32_t k = 0, ke = 0;
+        if (row < n) { k = rowptr[row]; ke = rowptr[row + 1]; }
+        double *dst = sval + rb * (int64_t)W * 256 + threadIdx.x;
+        for (int u = 0; u < W; ++u) dst[(int64_t)u * 256] = k + u < ke ? val[k + u] : 0.0;
+    }
+}
+
 // ELLPACK, slot-major device layout: lane i owns row i and walks ALL max_d slots in
 // order (padding slots multiply 0.0 by x(last neighbour), exactly like the reference,
 // so a non-finite x entry propagates the same way).
@@ -433,6 +519,8 @@ static SpmvCfg &spmv_cfg()
 static int resident_per_cu(bool dict, int block, int v);
 int ell_grid(const Part &p);
 static bool use_offset_dict(const Part &p) { return p.code && g_opt.csr_offset_dict; }
+static bool use_sliced(const Part &p) { return p.scode && g_opt.csr_sliced && g_opt.csr_offset_dict; }
+static int resident_sl(int W);
 // k_csr_do serves both the dictionary form and, for short rows, plain int32 columns
 static bool use_row_owner(const Part &p)
 {
@@ -463,9 +551,11 @@ static int do_tile_for(const Part &p)
 static int grid_for_rows(const Part &p, int64_t rows, int64_t limit)
 {
     const SpmvCfg &c = spmv_cfg();
-    const int64_t nrb = (rows + c.block - 1) / c.block;
+    const int blk = use_sliced(p) ? 256 : c.block;
+    const int64_t nrb = (rows + blk - 1) / blk;
     int64_t g = ((nrb + 7) / 8) * 8;
     int64_t cap = c.maxgrid;
+    if (cap <= 0 && use_sliced(p)) cap = (int64_t)resident_sl(p.sw) * g_rt.num_cu;
     if (cap <= 0) cap = (int64_t)resident_per_cu(use_row_owner(p), c.block, use_row_owner(p) ? do_tile_for(p) : c.vpt) *
                         g_rt.num_cu;
     if (cap > limit) cap = limit;
@@ -569,6 +659,43 @@ static void launch_csr_do(const Part &p, int grid, const double *x, double *y, c
 #undef L
 }
 
+#define SGM_SL_WIDTHS(X) X(3) X(5) X(7) X(8)
+template <bool ADD>
+static void launch_csr_sl(const Part &p, int grid, const double *x, double *y, const double *w,
+                          double *pwy, double *pyy, const int *flag, int gen)
+{
+    const SpmvCfg &c = spmv_cfg();
+    hipStream_t st = g_rt.stream;
+#define L(WW, DW, DY)                                                                                   \
+    hipLaunchKernelGGL((k_csr_sl<WW, ADD, DW, DY>), dim3(grid), dim3(256), 0, st, p.n, p.scode, p.dict, \
+                       p.sval, x, y, w, pwy, pyy, flag, gen, c.remap | g_launch_flags)
+#define LV(WW)                                \
+    if (p.sw == WW) {                         \
+        if (w && pyy) L(WW, true, true);      \
+        else if (w) L(WW, true, false);       \
+        else if (pyy) L(WW, false, true);     \
+        else L(WW, false, false);             \
+        return;                               \
+    }
+    SGM_SL_WIDTHS(LV)
+#undef LV
+#undef L
+}
+
+static int resident_sl(int W)
+{
+    static int cache[9] = {0};
+    if (W < 0 || W > 8) return 8;
+    if (cache[W]) return cache[W];
+    const void *fn = nullptr;
+#define PICK(WW) if (W == WW) fn = (const void *)k_csr_sl<WW, false, false, false>;
+    SGM_SL_WIDTHS(PICK)
+#undef PICK
+    int nb = 0;
+    if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) != hipSuccess || nb < 1) nb = 8;
+    return cache[W] = nb;
+}
+
 // SGM_ELL_CFG="U,nt,grid": slots in flight per lane, nontemporal matrix loads, grid cap (tuning aid)
 struct EllCfg { int u = 8, nt = 1, grid = 2048; };
 static EllCfg &ell_cfg()
@@ -660,12 +787,17 @@ static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const doub
     v.n_halo = p.n_halo; v.ncol_own = p.ncol_own;
     v.rowptr = p.rowptr + r.lo; v.col = p.col; v.val = p.val; v.code = p.code; v.dict = p.dict;
     v.max_row = p.max_row;
+    const bool sliced = use_sliced(p);      // range starts are multiples of 256 rows (set_interior_range)
+    if (sliced) { v.sval = p.sval + (int64_t)r.lo * p.sw; v.scode = p.scode + r.lo; v.sw = p.sw; }
     const bool dict = use_offset_dict(p);
     const double *xs = dict ? x + r.lo : x;
     double *ys = y + r.lo;
     const double *ws = w ? w + r.lo : nullptr;
     double *pw = pwy ? pwy + r.part_off : nullptr, *py = pyy ? pyy + r.part_off : nullptr;
-    if (use_row_owner(p)) {
+    if (sliced) {
+        if (add) launch_csr_sl<true>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
+        else launch_csr_sl<false>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
+    } else if (use_row_owner(p)) {
         if (add) launch_csr_do<true>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
         else launch_csr_do<false>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
     } else {
@@ -797,6 +929,17 @@ void set_interior_range(Part &p, const int32_t *ptr1, const int32_t *node1)
     p.int_hi = std::min<int32_t>((best_lo + best_len) * B, p.n);
 }
 
+// refresh the sliced copy of the values (no-op for parts without one)
+int pack_sliced(Part &p)
+{
+    if (!p.scode || p.n == 0) return SGM_OK;
+    const int64_t nrb = ((int64_t)p.n + 255) / 256;
+    hipLaunchKernelGGL(k_sl_pack, dim3((unsigned)std::min<int64_t>(nrb, 65536)), dim3(256), 0, g_rt.stream, p.n, p.sw,
+                       (const int32_t *)p.rowptr, (const double *)p.val, p.sval);
+    SGM_HIP(hipGetLastError());
+    return SGM_OK;
+}
+
 // Offset dictionary of a row block (host index work at setup): distinct (col - row) values in
 // order of first appearance; gives up (p.code stays null) beyond 255 distinct offsets.
 // ptr1/node1: optional 1-based host copies (otherwise the device arrays are read back).
@@ -848,6 +991,24 @@ static int build_offset_dict(Part &p, const int32_t *ptr1, const int32_t *node1)
     SGM_TRY(dalloc(&p.dict, (size_t)256));
     SGM_HIP(hipMemcpy(p.code, code.data(), code.size(), hipMemcpyHostToDevice));
     SGM_HIP(hipMemcpy(p.dict, dict.data(), 256 * 4, hipMemcpyHostToDevice));
+    // sliced form (opt-in, built only while the option is on): short rows, few offsets, little padding
+    const int W = p.max_row <= 3 ? 3 : p.max_row <= 5 ? 5 : p.max_row <= 7 ? 7 : 8;
+    if (g_opt.csr_sliced && p.ndict <= 15 && p.max_row >= 1 && p.max_row <= 8 && (double)W * n <= 1.25 * (double)nnz) {
+        const size_t rows_padded = ((size_t)n + 255) / 256 * 256;
+        std::vector<uint32_t> sc(rows_padded, 0xffffffffu);
+        for (int32_t i = 0; i < n; ++i) {
+            uint32_t cw = 0xffffffffu;
+            int u = 0;
+            for (int64_t k = ptr[i] - base; k < ptr[i + 1] - base; ++k, ++u)
+                cw = (cw & ~(15u << (4 * u))) | ((uint32_t)code[(size_t)k] << (4 * u));
+            sc[(size_t)i] = cw;
+        }
+        SGM_TRY(dalloc(&p.scode, rows_padded));
+        SGM_TRY(dalloc(&p.sval, rows_padded * W));
+        SGM_HIP(hipMemcpy(p.scode, sc.data(), rows_padded * 4, hipMemcpyHostToDevice));
+        p.sw = W;
+        SGM_TRY(pack_sliced(p));
+    }
     return SGM_OK;
 }
 
@@ -924,7 +1085,7 @@ int build_csr_part(Part &p, int32_t n, int32_t ncol_own, int32_t n_halo, int64_t
 
 void free_part(Part &p)
 {
-    dfree(p.rowptr); dfree(p.col); dfree(p.val); dfree(p.code); dfree(p.dict); dfree(p.ecol); dfree(p.eval); dfree(p.edeg); dfree(p.ecode); dfree(p.xext);
+    dfree(p.rowptr); dfree(p.col); dfree(p.val); dfree(p.code); dfree(p.dict); dfree(p.sval); dfree(p.scode); dfree(p.ecol); dfree(p.eval); dfree(p.edeg); dfree(p.ecode); dfree(p.xext);
     for (auto &nb : p.nbrs) { dfree(nb.send_idx); dfree(nb.send_buf); }
     p = Part();
 }
@@ -1030,6 +1191,7 @@ static int ensure_transpose(sgm_mat A)
         hipLaunchKernelGGL(k_gather_perm, dim3(vec_grid(nnz)), dim3(kBlock), 0, g_rt.stream, A->T->parts[0].val,
                            (const double *)(ell ? p.eval : p.val), (const int32_t *)A->tperm, nnz);
         SGM_HIP(hipGetLastError());
+        SGM_TRY(pack_sliced(A->T->parts[0]));
     }
     A->t_stale = false;
     return SGM_OK;
@@ -1139,6 +1301,7 @@ int sgm_csr_set_values(sgm_mat A, const double *val, int where)
                                where == SGM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
                                g_rt.stream));
         off += p.nnz;
+        SGM_TRY(pack_sliced(p));
     }
     SGM_HIP(hipStreamSynchronize(g_rt.stream));
     return SGM_OK;
@@ -1321,6 +1484,25 @@ int sgm_mat_info(sgm_mat A, int32_t *nrow, int32_t *ncol, int64_t *nnz, int32_t 
     if (nnz) *nnz = A->nnz;
     if (fmt) *fmt = A->fmt;
     if (x_len) *x_len = A->comm ? A->parts[0].xlen() : A->ncol;
+    return SGM_OK;
+}
+
+int sgm_mat_kernel(sgm_mat A, char *buf, int len)
+{
+    if (!A || !buf || len < 1) return fail(SGM_ERR_BAD_ARG, "sgm_mat_kernel: bad argument");
+    char name[64];
+    if (A->fmt == SGM_FMT_COMPOSITE) snprintf(name, sizeof name, "composite");
+    else {
+        const Part &p = A->parts[0];
+        if (A->fmt == SGM_FMT_ELL) {
+            if (p.ecode && g_opt.ell_offset_dict) snprintf(name, sizeof name, "k_ell_do<MDP=%d>", p.emdp);
+            else snprintf(name, sizeof name, "k_ell_spmv");
+        } else if (use_sliced(p)) snprintf(name, sizeof name, "k_csr_sl<W=%d>", p.sw);
+        else if (use_offset_dict(p)) snprintf(name, sizeof name, "k_csr_do<256,%d,CW=1>", do_tile_for(p));
+        else if (use_row_owner(p)) snprintf(name, sizeof name, "k_csr_do<256,%d,CW=4>", do_tile_for(p));
+        else snprintf(name, sizeof name, "k_csr_spmv");
+    }
+    snprintf(buf, (size_t)len, "%s", name);
     return SGM_OK;
 }
 

@@ -302,29 +302,111 @@ def test_composite_block_matrix(orc):
     assert e.value.code == 8
 
 
+def _kernel_options(dict_opt, sl_opt, ro_opt):
+    sg.set_option("csr_offset_dict", dict_opt)
+    sg.set_option("csr_sliced", sl_opt)
+    sg.set_option("csr_row_owner", ro_opt)
+
+
+KERNEL_COMBOS = ((1, 1, 1, "k_csr_sl"), (1, 0, 1, "CW=1"), (0, 0, 1, "CW=4"), (0, 0, 0, "k_csr_spmv"))
+
+
 def test_offset_dict_and_int32_kernels_agree(orc):
-    """Three CSR kernels, one result: 1-byte offset-dictionary codes (default for stencil-like
-    matrices), int32 columns gathered by the row's owner lane (rows <= 32 entries), int32
-    columns gathered while streaming (any row length).  All must equal the oracle bit for bit."""
+    """Four CSR kernels, one result: sliced 4-bit codes (rows <= 8 entries, <= 15 offsets),
+    1-byte offset-dictionary codes (other stencil-like matrices), int32 columns gathered by
+    the row's owner lane (rows <= 32 entries), int32 columns gathered while streaming (any row
+    length).  All must equal the oracle bit for bit."""
     rs = np.random.RandomState(8)
     for name, A in _cases(orc)[:4]:
         x = rs.standard_normal(A.m)
         y_ref = A.matvec(x)
         yt_ref = A.matvec_t(rs.standard_normal(A.n) * 0 + 1.0)
-        for dict_opt, ro_opt in ((1, 1), (0, 1), (0, 0)):
-            sg.set_option("csr_offset_dict", dict_opt)
-            sg.set_option("csr_row_owner", ro_opt)
+        seen = set()
+        for dict_opt, sl_opt, ro_opt, _tag in KERNEL_COMBOS:
+            _kernel_options(dict_opt, sl_opt, ro_opt)
             try:
                 H = hip_from_oracle(A)
+                seen.add(H.kernel)
                 y = np.zeros(A.n)
                 H.matvec(x, y)
                 yt = np.zeros(A.m)
                 H.matvec_t(np.ones(A.n), yt)
             finally:
-                sg.set_option("csr_offset_dict", 1)
-                sg.set_option("csr_row_owner", 1)
-            assert np.array_equal(y, y_ref), (name, dict_opt, ro_opt)
-            assert np.array_equal(yt, yt_ref), (name, dict_opt, ro_opt)
+                _kernel_options(1, 0, 1)
+            assert np.array_equal(y, y_ref), (name, dict_opt, sl_opt, ro_opt)
+            assert np.array_equal(yt, yt_ref), (name, dict_opt, sl_opt, ro_opt)
+        # the stencils exercise all four kernels; the random matrix has no dictionary
+        assert len(seen) == (2 if name.startswith("random") else 4), (name, seen)
+
+
+def _banded_short_rows(n, seed, wmax=8, noffs=15):
+    """Rows of <= wmax entries at columns row + {0..noffs-1} (rectangular n x (n+noffs-1)):
+    mostly full rows, some shorter, some empty; duplicates inside a row allowed."""
+    rs = np.random.RandomState(seed)
+    deg = np.full(n, wmax)
+    short = rs.rand(n) < 0.10
+    deg[short] = rs.randint(0, wmax, size=int(short.sum()))
+    deg[[0, n // 2, n - 1]] = [0, 1, wmax]
+    ptr = np.concatenate([[1], 1 + np.cumsum(deg)]).astype(np.int32)
+    rows = np.repeat(np.arange(n), deg)
+    node = (rows + rs.randint(0, noffs, size=rows.size) + 1).astype(np.int32)
+    val = rs.standard_normal(rows.size)
+    return ptr, node, val
+
+
+@pytest.mark.parametrize("n,wmax", [(1, 3), (255, 3), (256, 5), (257, 7), (70001, 8), (33333, 5)])
+def test_sliced_kernel_ragged_rows_nonfinite_and_updates(orc, n, wmax):
+    """k_csr_sl on rows of 0..W entries, slices that end mid-block, duplicate columns, Inf/NaN in
+    x (a missing slot must not contribute 0*Inf), y += A x, chained transpose sums, and a value
+    update (the sliced copy is re-packed): always the oracle's bits."""
+    ptr, node, val = _banded_short_rows(n, 100 + n, wmax=wmax)
+    m = n + 14
+    A = orc.CsrMatrix(n, m, ptr, node, val)
+    sg.set_option("csr_sliced", 1)          # opt-in kernel
+    try:
+        _sliced_checks(orc, A, n, m, ptr, node, val)
+    finally:
+        sg.set_option("csr_sliced", 0)
+
+
+def _sliced_checks(orc, A, n, m, ptr, node, val):
+    H = sg.csr_matrix(n, m, ptr, node, val)
+    assert H.kernel.startswith("k_csr_sl"), H.kernel
+    rs = np.random.RandomState(n)
+    x = rs.standard_normal(m)
+    y0 = rs.standard_normal(n)
+    y = y0.copy()
+    H.matvec_add(x, y)
+    assert np.array_equal(y, A.matvec_add(x, y0.copy()))
+    xb = x.copy()
+    xb[rs.randint(0, m, 5)] = np.inf
+    xb[rs.randint(0, m, 3)] = np.nan
+    yb = np.zeros(n)
+    H.matvec(xb, yb)
+    assert np.array_equal(yb, A.matvec(xb), equal_nan=True)
+    xt = rs.standard_normal(n)
+    t0 = rs.standard_normal(m)
+    t = t0.copy()
+    H.matvec_t_add(xt, t)
+    assert np.array_equal(t, A.matvec_t_add(xt, t0.copy()))
+    val2 = rs.standard_normal(val.size)
+    H.set_values(val2)
+    A2 = orc.CsrMatrix(n, m, ptr, node, val2)
+    y = np.zeros(n)
+    H.matvec(x, y)
+    assert np.array_equal(y, A2.matvec(x))
+    t = np.zeros(m)
+    H.matvec_t(xt, t)
+    assert np.array_equal(t, A2.matvec_t(xt))
+    # the 1-byte-code kernel on the same handle agrees
+    sg.set_option("csr_sliced", 0)
+    try:
+        assert "CW=1" in H.kernel
+        y1 = np.zeros(n)
+        H.matvec(x, y1)
+    finally:
+        sg.set_option("csr_sliced", 1)
+    assert np.array_equal(y1, y)
 
 
 @pytest.mark.parametrize("name", [n for n in golden_names() if "_ell_" in n])

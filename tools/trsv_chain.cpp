@@ -1,0 +1,112 @@
+// Calibration (not part of the product): what does one level of the ring walker cost, and which
+// part of the per-level dependency chain is it?  Synthetic factor: L levels of w rows, every row
+// has 2 dependencies in the previous level.  ./trsv_chain <levels> <w>
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+
+constexpr int kRing = 8192, kB = 1024, D = 4;
+enum { SLOAD = 1, GLOAD = 2, LDSR = 4, BARRIER = 8, GSTORE = 16, LDSW = 32 };
+
+template <int F>
+__global__ __launch_bounds__(kB) void walk(const uint32_t *__restrict__ dq, const double *__restrict__ dv, uint32_t nstride,
+                                           const int32_t *__restrict__ level_ptr, int32_t nlev, int32_t w, int32_t n, double *xp)
+{
+    __shared__ double ring[kRing + 1 + kB];
+    const uint32_t tid = threadIdx.x;
+    for (int i = tid; i < kRing + 1 + kB; i += kB) ring[i] = 0.0;
+    const char *dqb = (const char *)dq, *dv0 = (const char *)dv, *dv1 = (const char *)(dv + nstride);
+    char *xpb = (char *)xp;
+    const char *ringb = (const char *)ring;
+    const uint32_t park = (kRing + 1 + tid) * 8u;
+    uint32_t wq[D]; double v0[D], v1[D], z0[D]; int32_t lb[D], le[D];
+    auto bounds = [&](int32_t l, int32_t &b, int32_t &e) {
+        const int32_t lc = min(l, nlev - 1);
+        if (F & SLOAD) { b = level_ptr[lc]; e = level_ptr[lc + 1]; } else { b = lc * w; e = b + w; }
+        if (l >= nlev) b = e;
+    };
+    auto fetch = [&](int s, int32_t b, int32_t e) {
+        lb[s] = b; le[s] = e;
+        const uint32_t off = ((uint32_t)b + tid) * 8u;
+        if (F & GLOAD) {
+            wq[s] = *(const uint32_t *)(dqb + off); v0[s] = *(const double *)(dv0 + off); v1[s] = *(const double *)(dv1 + off);
+            z0[s] = *(const double *)(xpb + off);
+        } else { wq[s] = ((b + tid) & 8191u) | (((b + tid + 1) & 8191u) << 16); v0[s] = 0.25; v1[s] = 0.25; z0[s] = 1.0; }
+    };
+#pragma unroll
+    for (int j = 0; j < D; ++j) { int32_t b, e; bounds(j, b, e); fetch(j, b, e); }
+    __syncthreads();
+    for (int32_t l = 0; l < nlev; l += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int32_t b = lb[j], e = le[j];
+            int32_t nb, ne;
+            bounds(l + j + D, nb, ne);
+            const uint32_t p = (uint32_t)b + tid;
+            const bool ok = p < (uint32_t)e;
+            double z = z0[j];
+            const uint32_t s0 = wq[j] & 0xffffu, s1 = wq[j] >> 16;
+            const double x0 = (F & LDSR) ? *(const double *)(ringb + s0 * 8u) : 0.5;
+            const double x1 = (F & LDSR) ? *(const double *)(ringb + s1 * 8u) : 0.5;
+            z = z - v0[j] * x0;
+            z = z - v1[j] * x1;
+            if (F & LDSW) *(double *)(const_cast<char *>(ringb) + (ok ? (p & (kRing - 1)) * 8u : park)) = z;
+            if (F & GSTORE) *(double *)(xpb + (ok ? p : (uint32_t)n + tid) * 8u) = z;
+            else if (z == 1.2345e-300) xp[0] = z;
+            fetch(j, nb, ne);
+            if (F & BARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int F>
+void run(const char *label, int threads, uint32_t *dq, double *dv, uint32_t ns, int32_t *lp, int nlev, int w, int n, double *xp)
+{
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int r = 0; r < 2; ++r) walk<F><<<1, threads>>>(dq, dv, ns, lp, nlev, w, n, xp);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    const int reps = 5;
+    for (int r = 0; r < reps; ++r) walk<F><<<1, threads>>>(dq, dv, ns, lp, nlev, w, n, xp);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-44s %4d thr: %7.1f ns/level\n", label, threads, ms * 1e6 / reps / nlev);
+}
+
+int main(int argc, char **argv)
+{
+    const int nlev = argc > 1 ? atoi(argv[1]) : 2000, w = argc > 2 ? atoi(argv[2]) : 1000;
+    const int n = nlev * w;
+    const uint32_t ns = n + 4096;
+    std::vector<int32_t> lp(nlev + 1);
+    for (int l = 0; l <= nlev; ++l) lp[l] = l * w;
+    std::vector<uint32_t> q(2 * (size_t)ns, 8192u | (8192u << 16));
+    for (int l = 1; l < nlev; ++l)
+        for (int i = 0; i < w; ++i) {
+            const uint32_t p = l * w + i, a = (l - 1) * w + i, b = (l - 1) * w + (i + 1) % w;
+            q[2 * (size_t)p] = (a & 8191u) | ((b & 8191u) << 16);
+        }
+    std::vector<double> v(2 * (size_t)ns, 0.25), x(ns, 1.0);
+    uint32_t *dq; double *dv, *xp; int32_t *dlp;
+    hipMalloc(&dq, q.size() * 4); hipMalloc(&dv, v.size() * 8); hipMalloc(&xp, (size_t)ns * 8); hipMalloc(&dlp, lp.size() * 4);
+    hipMemcpy(dq, q.data(), q.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dv, v.data(), v.size() * 8, hipMemcpyHostToDevice);
+    hipMemcpy(xp, x.data(), x.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dlp, lp.data(), lp.size() * 4, hipMemcpyHostToDevice);
+    constexpr int ALL = SLOAD | GLOAD | LDSR | BARRIER | GSTORE | LDSW;
+    for (int thr : {1024, 256}) {
+        run<ALL>("all", thr, dq, dv, ns, dlp, nlev, w, n, xp);
+        run<ALL & ~SLOAD>("no s_load (bounds by arithmetic)", thr, dq, dv, ns, dlp, nlev, w, n, xp);
+        run<ALL & ~GLOAD>("no global loads", thr, dq, dv, ns, dlp, nlev, w, n, xp);
+        run<ALL & ~GSTORE>("no global store", thr, dq, dv, ns, dlp, nlev, w, n, xp);
+        run<ALL & ~(GLOAD | GSTORE)>("no global loads/stores", thr, dq, dv, ns, dlp, nlev, w, n, xp);
+        run<ALL & ~(GLOAD | GSTORE | SLOAD)>("no global, no s_load", thr, dq, dv, ns, dlp, nlev, w, n, xp);
+        run<ALL & ~LDSR>("no LDS reads", thr, dq, dv, ns, dlp, nlev, w, n, xp);
+        run<ALL & ~BARRIER>("no barrier (wrong results)", thr, dq, dv, ns, dlp, nlev, w, n, xp);
+        run<BARRIER>("barrier only", thr, dq, dv, ns, dlp, nlev, w, n, xp);
+        run<BARRIER | LDSR | LDSW>("barrier + LDS only", thr, dq, dv, ns, dlp, nlev, w, n, xp);
+    }
+    return 0;
+}
