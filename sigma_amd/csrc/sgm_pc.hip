@@ -57,6 +57,7 @@ struct TriFactor {                   // strictly triangular factor on the device
     int32_t *pq = nullptr;           // device: dependency positions of ALL entries, rows in level order
     double *pv = nullptr;            // device: their values
     int32_t *level_ptr_dev = nullptr;
+    uint32_t *dq32 = nullptr;        // device: low halves of dq, contiguous (runs with <= 2 dependencies per row)
     uint64_t *dq = nullptr;          // device: ring-walker copy, 4 x 16-bit position deltas per row (0 = none)
     double *dv = nullptr;            // device: ring-walker copy, kInline value slots, slot-major (slot*n + pos)
     std::vector<uint64_t> h_dq;
@@ -65,7 +66,9 @@ struct TriFactor {                   // strictly triangular factor on the device
     std::vector<int32_t> h_order, h_pos, h_src;      // host: pos -> row, row -> pos, level-order entry -> factor entry
     std::vector<TrsvRec> h_recs;
     std::vector<int32_t> h_pq;
-    struct Launch { int32_t l0, l1; bool narrow; int rpt; bool ring; int c; };    // c: most dependencies of a row in the run   // rpt: rows per lane of the walker (1, 2, 4); ring: k_trsv_walk_ring applies
+    // cls: 0..2 = 256/512/1024 threads (one row per lane), 3/4 = 2/4 rows per lane; ring: k_trsv_walk_ring
+    // applies; c: most dependencies of a row in the run
+    struct Launch { int32_t l0, l1; bool narrow; int cls; bool ring; int c; };
     std::vector<Launch> schedule;
 };
 
@@ -296,34 +299,38 @@ __global__ __launch_bounds__(kTrsvBlock) void k_trsv_walk(const TrsvRec *__restr
 // four 16-bit ring slots (position & (kRing-1); kRing = "no entry", a slot that holds 0.0 and
 // is paired with the value 0.0) and C values, slot-major -- every load is a coalesced 8 bytes
 // per lane, C + 3 memory instructions and ~3 ALU instructions per dependency.
-template <int RPT, int D, int C>
-__global__ __launch_bounds__(kTrsvBlock) void k_trsv_walk_ring(const uint64_t *__restrict__ dq,
-                                                               const double *__restrict__ dv, uint32_t nstride,
-                                                               const int32_t *__restrict__ level_ptr, int32_t l0,
-                                                               int32_t l1, int32_t n, double *xp, const int *flag)
+// A = adjacent rows per lane (1 or 2): with A = 2 a lane owns rows 2t and 2t+1 of the level and
+// every load moves 16 bytes per lane -- half the memory instructions for the same bytes.
+template <class T, int A> struct alignas(sizeof(T)) RowPack { T v[A]; };
+template <int TB, int RPT, int D, int C, int A>
+__global__ __launch_bounds__(TB) void k_trsv_walk_ring(const uint64_t *__restrict__ dq,
+                                                       const uint32_t *__restrict__ dq32,
+                                                       const double *__restrict__ dv, uint32_t nstride,
+                                                       const int32_t *__restrict__ level_ptr, int32_t l0,
+                                                       int32_t l1, int32_t n, double *xp, const int *flag)
 {
     // ring[kRing] is a constant 0.0 (the slot absent dependencies point at, with value 0.0:
-    // z - 0.0*0.0 == z for every z, so they need no branch); ring[kRing+1+lane]: parking
-    __shared__ double ring[kRing + 1 + kTrsvBlock];
+    // z - 0.0*0.0 == z for every z, so they need no branch); ring[kRing+1+..]: parking
+    __shared__ double ring[kRing + 1 + 2 * kTrsvBlock];
     if (flag && *flag) return;
     const uint32_t tid = threadIdx.x;
     {
         const int32_t base = level_ptr[l0];
-        for (int32_t q = base - 1 - (int32_t)tid; q >= 0 && q >= base - kRing; q -= kTrsvBlock) ring[q & (kRing - 1)] = xp[q];
+        for (int32_t q = base - 1 - (int32_t)tid; q >= 0 && q >= base - kRing; q -= TB) ring[q & (kRing - 1)] = xp[q];
         if (tid == 0) ring[kRing] = 0.0;
     }
     // byte offsets fit 32 bits (checked on the host): scalar base + 32-bit lane offset addressing
-    const char *dqb = reinterpret_cast<const char *>(dq);
+    // (C <= 2 reads the 32-bit copy of the slot words: of a 64-bit word only the low half would
+    //  be used, the register allocator would re-use the idle half, and a write to a register
+    //  with a load in flight has to wait for that load)
+    using WQ = typename std::conditional<(C <= 2), uint32_t, uint64_t>::type;
+    const char *dqb = C <= 2 ? reinterpret_cast<const char *>(dq32) : reinterpret_cast<const char *>(dq);
     const char *dvb[C];
 #pragma unroll
     for (int i = 0; i < C; ++i) dvb[i] = reinterpret_cast<const char *>(dv + (size_t)i * nstride);
     char *xpb = reinterpret_cast<char *>(xp);
-    const uint32_t park_ring = (kRing + 1 + tid) * 8u;
-    // (C <= 2 reads only the low half of the slot word: a half-used 64-bit register pair would
-    //  hand its idle half to the register allocator, and a write to it must wait for the load)
-    using WQ = typename std::conditional<(C <= 2), uint32_t, uint64_t>::type;
-    WQ wq[D][RPT];
-    double wv[D][RPT][C], z0pre[D][RPT];
+    RowPack<WQ, A> wq[D][RPT];
+    RowPack<double, A> wv[D][RPT][C], z0pre[D][RPT];
     int32_t lb[D], le[D];
     auto bounds = [&](int32_t l, int32_t &b, int32_t &e) {
         const int32_t lc = min(l, l1 - 1);           // past the run: an empty level
@@ -338,11 +345,11 @@ __global__ __launch_bounds__(kTrsvBlock) void k_trsv_walk_ring(const uint64_t *_
         for (int r = 0; r < RPT; ++r) {
             // lanes past the level's end read the rows that follow (the arrays are padded by
             // kNarrow entries); what they compute lands in the parking slots
-            const uint32_t off = ((uint32_t)b + tid + r * kTrsvBlock) * 8u;
-            wq[slot][r] = *reinterpret_cast<const WQ *>(dqb + off);
+            const uint32_t off = ((uint32_t)b + A * (tid + r * TB)) * 8u;
+            wq[slot][r] = *reinterpret_cast<const RowPack<WQ, A> *>(dqb + (C <= 2 ? off / 2 : off));
 #pragma unroll
-            for (int i = 0; i < C; ++i) wv[slot][r][i] = *reinterpret_cast<const double *>(dvb[i] + off);
-            z0pre[slot][r] = *reinterpret_cast<const double *>(xpb + off);
+            for (int i = 0; i < C; ++i) wv[slot][r][i] = *reinterpret_cast<const RowPack<double, A> *>(dvb[i] + off);
+            z0pre[slot][r] = *reinterpret_cast<const RowPack<double, A> *>(xpb + off);
         }
     };
 #pragma unroll
@@ -360,18 +367,23 @@ __global__ __launch_bounds__(kTrsvBlock) void k_trsv_walk_ring(const uint64_t *_
             int32_t nb, ne;
             bounds(l + j + D, nb, ne);
 #pragma unroll
-            for (int r = 0; r < RPT; ++r) {
-                const uint32_t p = (uint32_t)b + tid + r * kTrsvBlock;
-                const bool ok = p < (uint32_t)e;
-                double z = z0pre[j][r];
+            for (int r = 0; r < RPT; ++r)
 #pragma unroll
-                for (int i = 0; i < C; ++i) {
-                    const uint32_t slot = (uint32_t)(wq[j][r] >> (16 * i)) & 0xffffu;     // ring slot of the dependency
-                    z = z - wv[j][r][i] * *reinterpret_cast<const double *>(ringb + slot * 8u);
+                for (int a = 0; a < A; ++a) {
+                    const uint32_t lane_row = A * (tid + r * TB) + a;      // < A * RPT * TB <= 2 * kTrsvBlock ... kNarrow
+                    const uint32_t p = (uint32_t)b + lane_row;
+                    const bool ok = p < (uint32_t)e;
+                    double z = z0pre[j][r].v[a];
+#pragma unroll
+                    for (int i = 0; i < C; ++i) {
+                        const uint32_t slot = (uint32_t)(wq[j][r].v[a] >> (16 * i)) & 0xffffu;     // ring slot of the dependency
+                        z = z - wv[j][r][i].v[a] * *reinterpret_cast<const double *>(ringb + slot * 8u);
+                    }
+                    // rows past the level's end: results go to parking slots nobody reads
+                    const uint32_t park = A * tid + a;
+                    *reinterpret_cast<double *>(const_cast<char *>(ringb) + (ok ? (p & (kRing - 1)) : kRing + 1 + park) * 8u) = z;
+                    *reinterpret_cast<double *>(xpb + (ok ? p : (uint32_t)n + lane_row) * 8u) = z;
                 }
-                *reinterpret_cast<double *>(const_cast<char *>(ringb) + (ok ? (p & (kRing - 1)) * 8u : park_ring)) = z;
-                *reinterpret_cast<double *>(xpb + (ok ? p : (uint32_t)n + tid + r * kTrsvBlock) * 8u) = z;
-            }
             // slot j is free again: request level l+j+D into the same registers (issued after the
             // last use, so the compiler needs no second register set and no copies at the back-edge)
             fetch(j, nb, ne);
@@ -476,7 +488,7 @@ void ildu_factor(sgm_pc pc, int32_t n, const std::vector<int32_t> &ptr, const st
 
 void free_tri(TriFactor &T)
 {
-    dfree(T.order); dfree(T.recs); dfree(T.pq); dfree(T.pv); dfree(T.level_ptr_dev); dfree(T.dq); dfree(T.dv);
+    dfree(T.order); dfree(T.recs); dfree(T.pq); dfree(T.pv); dfree(T.level_ptr_dev); dfree(T.dq); dfree(T.dq32); dfree(T.dv);
     T = TriFactor();
 }
 
@@ -527,16 +539,30 @@ int upload_tri(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const 
         }
         // schedule: wide levels alone, runs of narrow levels together
         static const int narrow = getenv("SGM_TRSV_NARROW") ? std::min(atoi(getenv("SGM_TRSV_NARROW")), kNarrow) : kNarrow;
+        std::vector<int8_t> lev_cls(nlev, 0);
+        {
+            std::vector<int8_t> raw(nlev, 0);
+            for (int32_t l = 0; l < nlev; ++l) {
+                const int32_t w = T.level_ptr[l + 1] - T.level_ptr[l];
+                raw[l] = w <= 256 ? 0 : w <= 512 ? 1 : w <= kTrsvBlock ? 2 : w <= 2 * kTrsvBlock ? 3 : w <= narrow ? 4 : 5;
+            }
+            for (int32_t l = 0; l < nlev; ++l) {          // window maximum over narrow neighbours
+                int8_t m = raw[l];
+                if (m < 5) {
+                    for (int32_t k = l - 1; k >= std::max(0, l - 8) && raw[k] < 5; --k) m = std::max(m, raw[k]);
+                    for (int32_t k = l + 1; k <= std::min(nlev - 1, l + 8) && raw[k] < 5; ++k) m = std::max(m, raw[k]);
+                }
+                lev_cls[l] = m;
+            }
+        }
         for (int32_t l = 0; l < nlev;) {
             const int32_t sz = T.level_ptr[l + 1] - T.level_ptr[l];
             if (sz > narrow) { T.schedule.push_back({l, l + 1, false, 0, false, 0}); ++l; continue; }
-            // runs are cut by width class (rows per lane 1 / 2 / 4): narrower levels leave
-            // registers for a deeper record prefetch
-            auto cls = [&](int32_t lev) { const int32_t w = T.level_ptr[lev + 1] - T.level_ptr[lev];
-                                          return w <= kTrsvBlock ? 1 : w <= 2 * kTrsvBlock ? 2 : 4; };
-            const int c = cls(l);
+            // runs are cut by width class: 256 / 512 / 1024 threads with one row per lane, then 2 and
+            // 4 rows per lane (classes 0..4, smoothed so that a run is at least ~16 levels long)
+            const int c = lev_cls[l];
             int32_t e = l;
-            while (e < nlev && T.level_ptr[e + 1] - T.level_ptr[e] <= narrow && cls(e) == c) ++e;
+            while (e < nlev && T.level_ptr[e + 1] - T.level_ptr[e] <= narrow && lev_cls[e] == c) ++e;
             // all dependencies inline and within the ring's reach?  (see k_trsv_walk_ring)
             bool ring_ok = true;
             int cmax = 0;
@@ -565,6 +591,12 @@ int upload_tri(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const 
         SGM_TRY(dalloc(&T.dq, T.nstride));
         SGM_TRY(dalloc(&T.dv, T.nstride * kInline));
         SGM_HIP(hipMemcpy(T.dq, T.h_dq.data(), T.h_dq.size() * 8, hipMemcpyHostToDevice));
+        {
+            std::vector<uint32_t> lo(T.nstride);
+            for (size_t p = 0; p < T.nstride; ++p) lo[p] = (uint32_t)T.h_dq[p];
+            SGM_TRY(dalloc(&T.dq32, T.nstride));
+            SGM_HIP(hipMemcpy(T.dq32, lo.data(), lo.size() * 4, hipMemcpyHostToDevice));
+        }
         SGM_TRY(dalloc(&T.order, (size_t)n));
         SGM_TRY(dalloc(&T.recs, (size_t)n));
         SGM_TRY(dalloc(&T.pq, nnz));
@@ -599,28 +631,37 @@ void trsv(const TriFactor &T, double *xp, const int *flag)
     hipStream_t st = g_rt.stream;
     for (const auto &L : T.schedule) {
         if (L.narrow) {
-            static const int depth = getenv("SGM_TRSV_DEPTH") ? atoi(getenv("SGM_TRSV_DEPTH")) : 0;   // tuning aid
 #define WALK(R, DD)                                                                                          \
     hipLaunchKernelGGL((k_trsv_walk<R, DD>), dim3(1), dim3(kTrsvBlock), 0, st, (const TrsvRec *)T.recs,       \
                        (const int32_t *)T.pq, (const double *)T.pv, (const int32_t *)T.level_ptr_dev, L.l0, L.l1, \
                        n, xp, flag)
-#define RING(R, DD, CC)                                                                                      \
-    hipLaunchKernelGGL((k_trsv_walk_ring<R, DD, CC>), dim3(1), dim3(kTrsvBlock), 0, st, (const uint64_t *)T.dq, \
-                       (const double *)T.dv, (uint32_t)T.nstride, (const int32_t *)T.level_ptr_dev, L.l0, L.l1, n, xp,    \
+#define RING(TT, R, DD, CC, AA)                                                                              \
+    hipLaunchKernelGGL((k_trsv_walk_ring<TT, R, DD, CC, AA>), dim3(1), dim3(TT), 0, st, (const uint64_t *)T.dq, \
+                       (const uint32_t *)T.dq32, (const double *)T.dv, (uint32_t)T.nstride, (const int32_t *)T.level_ptr_dev, L.l0, L.l1, n, xp, \
                        flag)
-#define RINGC(R, DD)                                                          \
+#define RINGC(TT, R, DD, AA)                                                  \
     do {                                                                      \
-        if (L.c <= 2) RING(R, DD, 2); else if (L.c == 3) RING(R, DD, 3); else RING(R, DD, 4); \
+        if (L.c <= 2) RING(TT, R, DD, 2, AA); else if (L.c == 3) RING(TT, R, DD, 3, AA); else RING(TT, R, DD, 4, AA); \
     } while (0)
-            static const bool no_ring = getenv("SGM_TRSV_NO_RING") != nullptr;                       // tuning aid
+            static const bool no_ring = getenv("SGM_TRSV_NO_RING") != nullptr;                       // tuning aids
+            static const bool no_pair = getenv("SGM_TRSV_NO_PAIR") != nullptr;
             if (L.ring && !no_ring && T.nstride < (size_t)500000000) {       // (32-bit byte offsets)
-                if (L.rpt == 1) {
-                    if (depth == 1) RINGC(1, 1); else if (depth == 2) RINGC(1, 2); else if (depth == 8) RINGC(1, 8); else RINGC(1, 4);
-                } else if (L.rpt == 2) {
-                    if (depth == 1) RINGC(2, 1); else RINGC(2, 2);
-                } else RINGC(4, 1);
-            } else if (L.rpt == 1) WALK(1, 2);
-            else if (L.rpt == 2) WALK(2, 1);
+                // class = widest level of the run: <= 256, 512, 1024, 2048, 4096 rows
+                if (no_pair) {
+                    if (L.cls == 0) RINGC(256, 1, 4, 1);
+                    else if (L.cls == 1) RINGC(512, 1, 4, 1);
+                    else if (L.cls == 2) RINGC(1024, 1, 4, 1);
+                    else if (L.cls == 3) RINGC(1024, 2, 2, 1);
+                    else RINGC(1024, 4, 1, 1);
+                } else {
+                    if (L.cls == 0) RINGC(256, 1, 4, 1);
+                    else if (L.cls == 1) RINGC(256, 1, 4, 2);
+                    else if (L.cls == 2) RINGC(512, 1, 4, 2);
+                    else if (L.cls == 3) RINGC(1024, 1, 2, 2);
+                    else RINGC(1024, 2, 1, 2);
+                }
+            } else if (L.cls <= 2) WALK(1, 2);
+            else if (L.cls == 3) WALK(2, 1);
             else WALK(4, 1);
 #undef RINGC
 #undef RING

@@ -8,7 +8,8 @@
 #include <vector>
 
 constexpr int kRing = 8192, kB = 1024, D = 4;
-enum { SLOAD = 1, GLOAD = 2, LDSR = 4, BARRIER = 8, GSTORE = 16, LDSW = 32 };
+enum { SLOAD = 1, GLOAD = 2, LDSR = 4, BARRIER = 8, GSTORE = 16, LDSW = 32, TOPLOAD = 64, PACK = 128 };
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 template <int F>
 __global__ __launch_bounds__(kB) void walk(const uint32_t *__restrict__ dq, const double *__restrict__ dv, uint32_t nstride,
@@ -30,7 +31,12 @@ __global__ __launch_bounds__(kB) void walk(const uint32_t *__restrict__ dq, cons
     auto fetch = [&](int s, int32_t b, int32_t e) {
         lb[s] = b; le[s] = e;
         const uint32_t off = ((uint32_t)b + tid) * 8u;
-        if (F & GLOAD) {
+        if ((F & GLOAD) && (F & PACK)) {
+            // (synthetic: both 16-byte records are read from the value array; the point is the instruction mix)
+            const f64x2 a = *(const f64x2 *)(dv0 + 2 * off), c = *(const f64x2 *)(dv0 + 2 * off + 16 * 1024);
+            v0[s] = a.x; v1[s] = a.y; z0[s] = c.x; wq[s] = ((b + tid) & 8191u) | (((b + tid + 1) & 8191u) << 16);
+            if (c.y == 1.2345e-300) wq[s] = 0;
+        } else if (F & GLOAD) {
             wq[s] = *(const uint32_t *)(dqb + off); v0[s] = *(const double *)(dv0 + off); v1[s] = *(const double *)(dv1 + off);
             z0[s] = *(const double *)(xpb + off);
         } else { wq[s] = ((b + tid) & 8191u) | (((b + tid + 1) & 8191u) << 16); v0[s] = 0.25; v1[s] = 0.25; z0[s] = 1.0; }
@@ -43,7 +49,10 @@ __global__ __launch_bounds__(kB) void walk(const uint32_t *__restrict__ dq, cons
         for (int j = 0; j < D; ++j) {
             const int32_t b = lb[j], e = le[j];
             int32_t nb, ne;
-            bounds(l + j + D, nb, ne);
+            if (F & TOPLOAD) {      // refill the slot the PREVIOUS level used, right after the barrier
+                bounds(l + j - 1 + D, nb, ne);
+                if (l + j > 0) fetch((j + D - 1) % D, nb, ne);
+            } else bounds(l + j + D, nb, ne);
             const uint32_t p = (uint32_t)b + tid;
             const bool ok = p < (uint32_t)e;
             double z = z0[j];
@@ -55,12 +64,105 @@ __global__ __launch_bounds__(kB) void walk(const uint32_t *__restrict__ dq, cons
             if (F & LDSW) *(double *)(const_cast<char *>(ringb) + (ok ? (p & (kRing - 1)) * 8u : park)) = z;
             if (F & GSTORE) *(double *)(xpb + (ok ? p : (uint32_t)n + tid) * 8u) = z;
             else if (z == 1.2345e-300) xp[0] = z;
-            fetch(j, nb, ne);
+            if (!(F & TOPLOAD)) fetch(j, nb, ne);
             if (F & BARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+}
+
+
+// walker + L2 warmer in one launch: workgroup 0 walks; workgroup `hb` (same XCD when workgroups
+// are dealt round-robin over the 8 XCDs) reads the row arrays a bounded distance ahead of the
+// walker's published position so that the walker's requests hit the XCD's L2
+template <int F>
+__global__ __launch_bounds__(kB) void walk_helped(const uint32_t *__restrict__ dq, const double *__restrict__ dv, uint32_t nstride,
+                                                  const int32_t *__restrict__ level_ptr, int32_t nlev, int32_t w, int32_t n, double *xp,
+                                                  int hb, int *progress, uint32_t ahead)
+{
+    if (blockIdx.x != 0 && (int)blockIdx.x != hb) return;
+    if ((int)blockIdx.x == hb) {
+        const uint32_t tid = threadIdx.x;
+        uint32_t done = 0;                      // rows warmed so far
+        double acc = 0.0;
+        for (;;) {
+            const int pos = __builtin_nontemporal_load(progress);        // walker's row position, -1 = finished
+            if (pos < 0) break;
+            const uint32_t target = min((uint32_t)pos + ahead, (uint32_t)n);
+            while (done < target) {
+                const uint32_t i = done + tid;                           // 1024 rows per pass
+                if (i < (uint32_t)n) {
+                    acc += (double)dq[i] + dv[i] + dv[(size_t)nstride + i] + xp[i];
+                }
+                done += kB;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (acc == 1.2345e-300) xp[n + 1] = acc;
+        return;
+    }
+    __shared__ double ring[kRing + 1 + kB];
+    const uint32_t tid = threadIdx.x;
+    for (int i = tid; i < kRing + 1 + kB; i += kB) ring[i] = 0.0;
+    const char *dqb = (const char *)dq, *dv0 = (const char *)dv, *dv1 = (const char *)(dv + nstride);
+    char *xpb = (char *)xp;
+    const char *ringb = (const char *)ring;
+    const uint32_t park = (kRing + 1 + tid) * 8u;
+    uint32_t wq[D]; double v0[D], v1[D], z0[D]; int32_t lb[D], le[D];
+    auto bounds = [&](int32_t l, int32_t &b, int32_t &e) {
+        const int32_t lc = min(l, nlev - 1);
+        b = level_ptr[lc]; e = level_ptr[lc + 1];
+        if (l >= nlev) b = e;
+    };
+    auto fetch = [&](int s, int32_t b, int32_t e) {
+        lb[s] = b; le[s] = e;
+        const uint32_t off = ((uint32_t)b + tid) * 8u;
+        wq[s] = *(const uint32_t *)(dqb + off); v0[s] = *(const double *)(dv0 + off); v1[s] = *(const double *)(dv1 + off);
+        z0[s] = *(const double *)(xpb + off);
+    };
+#pragma unroll
+    for (int j = 0; j < D; ++j) { int32_t b, e; bounds(j, b, e); fetch(j, b, e); }
+    __syncthreads();
+    for (int32_t l = 0; l < nlev; l += D) {
+        if (tid == 0) __builtin_nontemporal_store((int)lb[0], progress);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int32_t b = lb[j], e = le[j];
+            int32_t nb, ne;
+            bounds(l + j + D, nb, ne);
+            const uint32_t p = (uint32_t)b + tid;
+            const bool ok = p < (uint32_t)e;
+            double z = z0[j];
+            const uint32_t s0 = wq[j] & 0xffffu, s1 = wq[j] >> 16;
+            z = z - v0[j] * *(const double *)(ringb + s0 * 8u);
+            z = z - v1[j] * *(const double *)(ringb + s1 * 8u);
+            *(double *)(const_cast<char *>(ringb) + (ok ? (p & (kRing - 1)) * 8u : park)) = z;
+            *(double *)(xpb + (ok ? p : (uint32_t)n + tid) * 8u) = z;
+            fetch(j, nb, ne);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (tid == 0) __builtin_nontemporal_store(-1, progress);
+}
+
+void run_helped(int hb, uint32_t ahead, uint32_t *dq, double *dv, uint32_t ns, int32_t *lp, int nlev, int w, int n, double *xp, int *progress)
+{
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int grid = hb + 1;
+    for (int r = 0; r < 2; ++r) { hipMemset(progress, 0, 4); walk_helped<0><<<grid, kB>>>(dq, dv, ns, lp, nlev, w, n, xp, hb, progress, ahead); }
+    hipDeviceSynchronize();
+    float tot = 0;
+    const int reps = 5;
+    for (int r = 0; r < reps; ++r) {
+        hipMemset(progress, 0, 4);
+        hipEventRecord(e0);
+        walk_helped<0><<<grid, kB>>>(dq, dv, ns, lp, nlev, w, n, xp, hb, progress, ahead);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); tot += ms;
+    }
+    printf("helped: helper workgroup %2d, %7u rows ahead: %7.1f ns/level\n", hb, ahead, tot * 1e6 / reps / nlev);
 }
 
 template <int F>
@@ -96,8 +198,11 @@ int main(int argc, char **argv)
     hipMemcpy(dq, q.data(), q.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dv, v.data(), v.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(xp, x.data(), x.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dlp, lp.data(), lp.size() * 4, hipMemcpyHostToDevice);
     constexpr int ALL = SLOAD | GLOAD | LDSR | BARRIER | GSTORE | LDSW;
-    for (int thr : {1024, 256}) {
+    for (int thr : {1024, 512, 256}) {
         run<ALL>("all", thr, dq, dv, ns, dlp, nlev, w, n, xp);
+        run<ALL | TOPLOAD>("all, refill at the top of the level", thr, dq, dv, ns, dlp, nlev, w, n, xp);
+        run<ALL | PACK>("all, two 16-byte loads instead of four", thr, dq, dv, ns, dlp, nlev, w, n, xp);
+        run<ALL | PACK | TOPLOAD>("all, 16-byte loads, refill at top", thr, dq, dv, ns, dlp, nlev, w, n, xp);
         run<ALL & ~SLOAD>("no s_load (bounds by arithmetic)", thr, dq, dv, ns, dlp, nlev, w, n, xp);
         run<ALL & ~GLOAD>("no global loads", thr, dq, dv, ns, dlp, nlev, w, n, xp);
         run<ALL & ~GSTORE>("no global store", thr, dq, dv, ns, dlp, nlev, w, n, xp);
@@ -108,5 +213,9 @@ int main(int argc, char **argv)
         run<BARRIER>("barrier only", thr, dq, dv, ns, dlp, nlev, w, n, xp);
         run<BARRIER | LDSR | LDSW>("barrier + LDS only", thr, dq, dv, ns, dlp, nlev, w, n, xp);
     }
+    int *progress; hipMalloc(&progress, 64);
+    for (int hb : {8})
+        for (uint32_t ahead : {32768u})
+            run_helped(hb, ahead, dq, dv, ns, dlp, nlev, w, n, xp, progress);
     return 0;
 }
