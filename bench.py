@@ -223,6 +223,12 @@ def main():
                "sample": f"the full workload matrix (n={Ao.n}, nnz={Ao.nnz}), {reps} matvecs of "
                          f"oracle/sigma_oracle.c (csr_matvec_add restatement), {sec * 1e3:.1f} ms each; "
                          f"host has {os.cpu_count()} logical cores, the reference is single-threaded"}
+        # the REAL reference (compiled in place by oracle/build_ref.sh; the binary travels with
+        # the snapshot, the sources do not), timed on a bounded sample of the same workload
+        ref = reference_cpu_baseline()
+        if ref:
+            ref["port_on_full_workload"] = {"GB/s": cpu["value"], "sample": cpu["sample"]}
+            cpu = ref
 
     # HBM bytes per launch from the PMC counters cannot be collected inside this process; they
     # come from the committed rocprofv3 --pmc passes over this same command (profiles/)
@@ -254,6 +260,52 @@ def main():
     if use_dist:
         barrier()
         dist.destroy_process_group()
+
+
+def reference_cpu_baseline(nx_mv=2000, reps=20, nx_cg=600):
+    """cpu_baseline of kind "reference": oracle/_ref/sigma_ref_driver (our driver program linked
+    against the reference's own modules) times A%matvec on the nx_mv^2 5-point Laplacian and one
+    unpreconditioned CG solve on nx_cg^2 -- about 15 s of one host core."""
+    import struct
+    import subprocess
+    import tempfile
+    from sigma_amd import problems as P
+    drv = os.path.join(ROOT, "oracle", "_ref", "sigma_ref_driver")
+    if not os.path.exists(drv):
+        return None
+
+    def run(nx, solves, mode):
+        n = nx * nx
+        ei, ej, ev = P.poisson2d_edges(nx, nx)
+        with tempfile.TemporaryDirectory() as td:
+            inp = os.path.join(td, "in.bin")
+            with open(inp, "wb") as f:
+                f.write(struct.pack("<5i", n, n, len(ei), 1, len(solves)))
+                f.write(np.asarray(ei, "<i4").tobytes())
+                f.write(np.asarray(ej, "<i4").tobytes())
+                f.write(np.asarray(ev, "<f8").tobytes())
+                f.write(np.asarray(P.test_vector(n), "<f8").tobytes())
+                f.write(np.full(n, 1.0 / n, "<f8").tobytes())
+                for (sk, pk, tol) in solves:
+                    f.write(struct.pack("<iid", sk, pk, tol))
+            out = subprocess.run([drv, inp, os.path.join(td, "o"), mode], capture_output=True, text=True, timeout=300)
+        return n, len(ei), out.stdout
+
+    try:
+        n, nnz, txt = run(nx_mv, [], f"time:{reps}")
+        sec = float(txt.split("matvec_seconds_each=")[1].split()[0])
+        n2, _, txt2 = run(nx_cg, [(1, 0, 1e-8)], "time:1")
+        line = [ln for ln in txt2.splitlines() if ln.startswith("solve 1:")][0]
+        its = int(line.split("iterations=")[1].split()[0])
+        cg_sec = float(line.split("seconds=")[1].split()[0])
+    except Exception as e:        # a baseline leg must never take the bench line down
+        sys.stderr.write(f"[bench] reference baseline skipped: {e}\n")
+        return None
+    return {"value": spmv_bytes(n, n, nnz) / sec / 1e9, "unit": "GB/s", "cores": 1, "kind": "reference",
+            "sample": f"danshapero/sigma itself (amdflang -O2, oracle/build_ref.sh): csr A%matvec on the "
+                      f"{nx_mv}^2 5-point Laplacian (n={n}, nnz={nnz}), {reps} calls, {sec * 1e3:.2f} ms each; "
+                      f"cg%solve on {nx_cg}^2 to 1e-8: {its} iterations in {cg_sec:.2f} s",
+            "cg_iters_per_s": its / cg_sec if cg_sec > 0 else None, "cg_n": n2}
 
 
 def local_rows_laplace3d(m, z0, z1, dev):

@@ -16,6 +16,11 @@
 ! `<outprefix>.<name>.<i4|f8>`, which make_golden.py packs into the        !
 ! committed fixtures under tests/golden/.                                   !
 !                                                                          !
+! With a third argument `time:<reps>` nothing is dumped: the driver times  !
+! <reps> calls of A%matvec and the solves of the problem file and prints   !
+! `matvec_seconds_each=` / `solve ... seconds=` lines (bench.py's           !
+! cpu_baseline of kind "reference").                                       !
+!                                                                          !
 ! Problem file (unformatted stream, int32 / float64):                      !
 !   n, m, ne, fmt(1=csr,2=ellpack), nsolve                                  !
 !   ei(ne), ej(ne)      edges in INSERTION order (1-based)                  !
@@ -37,7 +42,10 @@ use ldu_solvers
 
 implicit none
 
-    character(len=512) :: infile, outprefix
+    character(len=512) :: infile, outprefix, mode
+    logical :: timing
+    integer :: reps, rep
+    integer(8) :: c0, c1, crate
     integer :: n, m, ne, fmt, nsolve, k, s, its
     integer, allocatable :: ei(:), ej(:), skind(:), pkind(:)
     real(dp), allocatable :: ev(:), x(:), b(:), y(:), u(:), z(:), tols(:), yt(:)
@@ -51,6 +59,15 @@ implicit none
 
     call getarg(1, infile)
     call getarg(2, outprefix)
+    timing = .false.
+    reps = 0
+    if (command_argument_count() >= 3) then
+        call getarg(3, mode)
+        if (mode(1:5) == 'time:') then
+            timing = .true.
+            read(mode(6:), *) reps
+        endif
+    endif
 
     open(unit=21, file=trim(infile), access='stream', form='unformatted', &
         & status='old')
@@ -94,10 +111,25 @@ implicit none
         call A%set_value(ei(k), ej(k), ev(k))
     enddo
 
+    if (timing) then
+        y = 0.0_dp
+        call A%matvec(x, y)
+        call system_clock(c0, crate)
+        do rep = 1, reps
+            call A%matvec(x, y)
+        enddo
+        call system_clock(c1)
+        print '(a,es12.5,a,i0,a,es12.5)', 'matvec_seconds_each=', &
+            & dble(c1 - c0) / dble(crate) / max(reps, 1), ' reps=', reps, &
+            & ' checksum=', sum(y)
+    endif
+
     !------------------------------------------------------------------!
     ! Index arrays + values exactly as the reference holds them         !
     !------------------------------------------------------------------!
-    if (fmt == 1) then
+    if (timing) then
+        continue
+    elseif (fmt == 1) then
         call dump_i4('ptr', Acsr%g%ptr, size(Acsr%g%ptr))
         call dump_i4('node', Acsr%g%node, size(Acsr%g%node))
         call dump_f8('val', Acsr%val, size(Acsr%val))
@@ -177,13 +209,15 @@ implicit none
         endif
 
         u = 0.0_dp
-        call cpu_time(t0)
+        call system_clock(c0, crate)
         if (associated(pc)) then
             call solver%solve(A, u, b, pc)
         else
             call solver%solve(A, u, b)
         endif
-        call cpu_time(t1)
+        call system_clock(c1)
+        t0 = 0.0_dp
+        t1 = dble(c1 - c0) / dble(crate)
 
         its = -1
         select type(solver)
@@ -213,6 +247,7 @@ contains
         character(len=*), intent(in) :: name
         integer, intent(in) :: cnt
         integer, intent(in) :: arr(cnt)
+        if (timing) return
         open(unit=22, file=trim(outprefix)//'.'//name//'.i4', &
             & access='stream', form='unformatted', status='replace')
         write(22) arr
@@ -223,6 +258,7 @@ contains
         character(len=*), intent(in) :: name
         integer, intent(in) :: cnt
         real(dp), intent(in) :: arr(cnt)
+        if (timing) return
         open(unit=22, file=trim(outprefix)//'.'//name//'.f8', &
             & access='stream', form='unformatted', status='replace')
         write(22) arr
