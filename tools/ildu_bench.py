@@ -6,12 +6,15 @@ import numpy as np
 import sigma_amd as sg
 from sigma_amd import problems as P
 nx = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+only = sys.argv[2].split(",") if len(sys.argv) > 2 else ["cg", "jacobi", "ildu0"]
 n = nx * nx
 ptr, node, val = P.poisson2d_csr(nx, nx)
 sg.init(0)
 A = sg.csr_matrix(n, n, ptr, node, val)
 b = np.full(n, 1.0 / n)
 for name, mk in (("cg", None), ("jacobi", sg.jacobi), ("ildu0", sg.ldu)):
+    if name not in only:
+        continue
     pc = mk() if mk else None
     t0 = time.time()
     if pc:
