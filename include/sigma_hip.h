@@ -135,6 +135,29 @@ int sgm_composite_create(sgm_mat *out, int32_t nrb, int32_t ncb, const int32_t *
                          const int32_t *col_ptr_1based, const sgm_mat *blocks);
 int sgm_mat_info(sgm_mat A, int32_t *nrow, int32_t *ncol, int64_t *nnz, int32_t *fmt,
                  int64_t *x_len /* entries matvec reads from x: ncol, or owned+halo when distributed */);
+/* ---- re-orderings ------------------------------------------------- *
+ * Graph = the matrix's own cs_graph (neighbours of i = the columns of row i in stored order).
+ * sgm_graph_bfs_order          breadth_first_search(p, g)   src/graph/permutations.f90:22-78
+ *                              p(i) = visiting number from vertex 1, -1 if never reached
+ * sgm_graph_greedy_coloring    greedy_coloring(colors, g)   permutations.f90:83-157
+ * sgm_graph_greedy_color_order greedy_color_ordering(p, ptrs, num_colors, g)  :162-205
+ *                              p(i) = new index when vertices are sorted by colour; ptrs
+ *                              (num_colors+1 entries, may be NULL) = first index per colour;
+ *                              fails where the reference would index out of bounds (a vertex
+ *                              not reachable from vertex 1)
+ * Outputs are HOST arrays of nrow int32 (1-based values, like the reference's).  These are
+ * sequential, order-dependent algorithms: they run on the host over a copy of the index arrays.
+ * sgm_mat_left_permute(A, p)   A%left_permute(p)   cs_matrices.f90:471-478: row i -> row p(i)
+ * sgm_mat_right_permute(A, p)  A%right_permute(p)  cs_matrices.f90:483-490: column j -> p(j)
+ *                              device kernels; entries keep their stored order inside a row, so
+ *                              row sums are bit-identical to the reference's permuted matrix.
+ *                              Preconditioners set up before a permutation must be set up again. */
+int sgm_graph_bfs_order(sgm_mat A, int32_t *p_out);
+int sgm_graph_greedy_coloring(sgm_mat A, int32_t *colors_out, int32_t *num_colors);
+int sgm_graph_greedy_color_order(sgm_mat A, int32_t *p_out, int32_t *ptrs_out, int32_t ptrs_len,
+                                 int32_t *num_colors);
+int sgm_mat_left_permute(sgm_mat A, const int32_t *p, int where);
+int sgm_mat_right_permute(sgm_mat A, const int32_t *p, int where);
 /* name of the SpMV kernel variant the matrix runs with under the current options
  * (diagnostics for benches and tests; e.g. "k_csr_sl<W=5>", "k_csr_do<256,1536,CW=1>") */
 int sgm_mat_kernel(sgm_mat A, char *buf, int len);

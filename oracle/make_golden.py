@@ -34,7 +34,7 @@ NOPC, JACOBI, LDU = 0, 1, 2
 CSR, ELL = 1, 2
 
 
-def run_reference(n, m, fmt, edges, x, b, solves):
+def run_reference(n, m, fmt, edges, x, b, solves, mode=None):
     ei, ej, ev = edges
     with tempfile.TemporaryDirectory() as td:
         inp = os.path.join(td, "in.bin")
@@ -47,12 +47,15 @@ def run_reference(n, m, fmt, edges, x, b, solves):
             f.write(np.asarray(b, "<f8").tobytes())
             for (s, pc, tol) in solves:
                 f.write(struct.pack("<iid", s, pc, tol))
-        out = subprocess.run([DRIVER, inp, os.path.join(td, "o")], check=True,
+        out = subprocess.run([DRIVER, inp, os.path.join(td, "o")] + ([mode] if mode else []), check=True,
                              capture_output=True, text=True, timeout=600)
         sys.stdout.write(out.stdout)
         res = {}
         for fn in sorted(os.listdir(td)):
             if not fn.startswith("o."):
+                continue
+            if fn == "o.matrix.txt":        # A%to_file output, kept byte for byte
+                res["ref_matrix_txt"] = np.frombuffer(open(os.path.join(td, fn), "rb").read(), dtype=np.uint8)
                 continue
             _, name, ext = fn.split(".")
             res["ref_" + name] = np.fromfile(os.path.join(td, fn),
@@ -60,9 +63,14 @@ def run_reference(n, m, fmt, edges, x, b, solves):
     return res
 
 
-def case(name, n, m, fmt, edges, x, b, solves, extra=None):
+ONLY = sys.argv[1] if len(sys.argv) > 1 else None      # name prefix filter, e.g. `make_golden.py perm_`
+
+
+def case(name, n, m, fmt, edges, x, b, solves, extra=None, mode=None):
+    if ONLY and not name.startswith(ONLY):
+        return
     print(f"== {name}: n={n} ne={len(edges[0])} fmt={'csr' if fmt == CSR else 'ell'}")
-    res = run_reference(n, m, fmt, edges, x, b, solves)
+    res = run_reference(n, m, fmt, edges, x, b, solves, mode)
     res.update(n=np.int32(n), m=np.int32(m), fmt=np.int32(fmt),
                ei=np.asarray(edges[0], np.int32), ej=np.asarray(edges[1], np.int32),
                ev=np.asarray(edges[2], np.float64), x=np.asarray(x, np.float64),
@@ -145,5 +153,23 @@ def main():
         case(f"duplicates_{tag}_16", 16, 16, fmt, (ei, ej, ev), P.test_vector(16), f, [])
 
 
+def perm_cases():
+    """Reorderings (permutations.f90) + symmetric permutation by the colour ordering; the
+    solves run on the PERMUTED matrix (ref_driver mode `perm`)."""
+    nx, ny = 32, 24
+    n = nx * ny
+    case("perm_poisson2d_32x24", n, n, CSR, P.poisson2d_edges(nx, ny), P.test_vector(n), np.full(n, 1.0 / n),
+         [(CG, NOPC, 1e-12), (CG, LDU, 1e-12), (BICGSTAB, LDU, 1e-12)], mode="perm")
+    nx, ny, nz = 8, 7, 6
+    n = nx * ny * nz
+    case("perm_laplace3d_8x7x6", n, n, CSR, P.laplace3d_edges(nx, ny, nz), P.test_vector(n), np.full(n, 1.0 / n),
+         [(CG, LDU, 1e-13)], mode="perm")
+    n = 128
+    rs = np.random.RandomState(17)
+    case("perm_random_spd_128", n, n, CSR, P.random_spd_edges(n, seed=3, skew=False), rs.random_sample(n),
+         rs.random_sample(n), [(CG, LDU, 1e-14)], mode="perm")
+
+
 if __name__ == "__main__":
     main()
+    perm_cases()

@@ -271,6 +271,46 @@ def lanczos(A, nsteps, q1):
     return T.T.copy(), Q.T.copy()
 
 
+def bfs_order(A):
+    """breadth_first_search(p, g) (permutations.f90:22-78) on the matrix graph: p(i) = visiting number."""
+    p = np.zeros(A.n, I4)
+    lib().orc_bfs_order(C.c_int32(A.n), _p(A.ptr), _p(A.node), _p(p))
+    return p
+
+
+def greedy_coloring(A):
+    """greedy_coloring(colors, g) (permutations.f90:83-157)."""
+    c = np.zeros(A.n, I4)
+    lib().orc_greedy_coloring(C.c_int32(A.n), _p(A.ptr), _p(A.node), _p(c))
+    return c
+
+
+def greedy_color_ordering(A):
+    """greedy_color_ordering(p, ptrs, num_colors, g) (permutations.f90:162-205):
+    returns (p, ptrs[:num_colors+1], num_colors)."""
+    p = np.zeros(A.n, I4)
+    ptrs = np.zeros(A.n + 2, I4)
+    lib().orc_greedy_color_ordering.restype = C.c_int32
+    nc = lib().orc_greedy_color_ordering(C.c_int32(A.n), _p(A.ptr), _p(A.node), _p(p), _p(ptrs))
+    if nc < 0:
+        raise ValueError("greedy_color_ordering: the graph is not connected from vertex 1")
+    return p, ptrs[:nc + 1].copy(), int(nc)
+
+
+def permuted(A, p_left=None, p_right=None):
+    """A%left_permute(p_left) then A%right_permute(p_right) (cs_matrices.f90:471-490) as a new CsrMatrix."""
+    ptr, node, val = A.ptr.copy(), A.node.copy(), A.val.copy()
+    if p_left is not None:
+        p_left = np.ascontiguousarray(p_left, I4)
+        ptr2, node2, val2 = np.zeros_like(ptr), np.zeros_like(node), np.zeros_like(val)
+        lib().orc_csr_left_permute(C.c_int32(A.n), _p(ptr), _p(node), _p(val), _p(p_left), _p(ptr2), _p(node2), _p(val2))
+        ptr, node, val = ptr2, node2, val2
+    if p_right is not None:
+        p_right = np.ascontiguousarray(p_right, I4)
+        lib().orc_csr_right_permute(C.c_int64(len(node)), _p(node), _p(p_right))
+    return CsrMatrix(A.n, A.m, ptr, node, val)
+
+
 def set_dot_mode(mode):
     """0: left-to-right dot products; 1: four interleaved partial sums (a vectorising
     compiler's dot_product).  Both are valid restatements of the Fortran intrinsic."""

@@ -39,12 +39,14 @@ use cg_solvers
 use bicgstab_solvers
 use jacobi_solvers
 use ldu_solvers
+use permutations
 
 implicit none
 
     character(len=512) :: infile, outprefix, mode
-    logical :: timing
-    integer :: reps, rep
+    logical :: timing, perm_mode
+    integer :: reps, rep, ncol
+    integer, allocatable :: pp(:), cptrs(:)
     integer(8) :: c0, c1, crate
     integer :: n, m, ne, fmt, nsolve, k, s, its
     integer, allocatable :: ei(:), ej(:), skind(:), pkind(:)
@@ -60,9 +62,11 @@ implicit none
     call getarg(1, infile)
     call getarg(2, outprefix)
     timing = .false.
+    perm_mode = .false.
     reps = 0
     if (command_argument_count() >= 3) then
         call getarg(3, mode)
+        if (mode(1:4) == 'perm') perm_mode = .true.
         if (mode(1:5) == 'time:') then
             timing = .true.
             read(mode(6:), *) reps
@@ -163,6 +167,35 @@ implicit none
     call dump_f8('yt', yt, m)
     call A%matvec_t_add(b, yt)
     call dump_f8('yt_add', yt, m)
+
+    !------------------------------------------------------------------!
+    ! Reorderings of the matrix graph (permutations.f90) and the         !
+    ! symmetric permutation of the matrix by the colour ordering         !
+    ! (cs_matrices.f90:471-490).  From here on A is the permuted matrix: !
+    ! the solves below run on it.                                        !
+    !------------------------------------------------------------------!
+    if (perm_mode .and. fmt == 1) then
+        ! text dump of the matrix as assembled (sparse_matrix_interfaces.f90:601-653)
+        call A%to_file(trim(outprefix)//'.matrix.txt')
+        allocate(pp(n), cptrs(n + 2))
+        call breadth_first_search(pp, Acsr%g)
+        call dump_i4('bfs_p', pp, n)
+        call greedy_coloring(pp, Acsr%g)
+        call dump_i4('colors', pp, n)
+        cptrs = 0
+        call greedy_color_ordering(pp, cptrs, ncol, Acsr%g)
+        call dump_i4('color_p', pp, n)
+        call dump_i4('color_ptrs', cptrs, ncol + 1)
+        call dump_i4('num_colors', [ncol], 1)
+        call Acsr%left_permute(pp)
+        call Acsr%right_permute(pp)
+        call dump_i4('perm_ptr', Acsr%g%ptr, size(Acsr%g%ptr))
+        call dump_i4('perm_node', Acsr%g%node, size(Acsr%g%node))
+        call dump_f8('perm_val', Acsr%val, size(Acsr%val))
+        y = -7.0_dp
+        call A%matvec(x, y)
+        call dump_f8('perm_y', y, n)
+    endif
 
     !------------------------------------------------------------------!
     ! Solves                                                            !

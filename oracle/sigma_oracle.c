@@ -729,3 +729,122 @@ ORC_API double orc_time_csr_matvec(int32_t n, const int32_t *ptr, const int32_t 
     for (int32_t r = 0; r < reps; r++) op_matvec(&A, x, y);
     return (now_s() - t0) / reps;
 }
+
+/* ------------------------------------------------------------------------ */
+/* Reorderings of the matrix graph (src/graph/permutations.f90) and the      */
+/* permutation of a CSR matrix (cs_graphs.f90:499-571 +                      */
+/* default_sparse_matrix_kernels.f90:234-277).  All arrays 1-based like the  */
+/* reference's; the graph is the cs_graph of the matrix (neighbours of i =   */
+/* node(ptr(i) .. ptr(i+1)-1) in stored order, cs_graphs.f90 get_neighbors). */
+/* ------------------------------------------------------------------------ */
+
+/* breadth_first_search (permutations.f90:22-78): FIFO from vertex 1; p(i) = visiting
+ * number (1..), -1 for vertices the search never reaches.  Returns the count visited. */
+ORC_API int32_t orc_bfs_order(int32_t n, const int32_t *ptr, const int32_t *node, int32_t *p)
+{
+    int32_t *queue = malloc((size_t)(n > 0 ? n : 1) * 4);
+    int32_t head = 0, tail = 0, num = 0;
+    for (int32_t i = 0; i < n; i++) p[i] = -1;
+    if (n > 0) queue[tail++] = 1;
+    while (tail > head) {
+        num++;
+        const int32_t i = queue[head++];
+        p[i - 1] = num;
+        for (int32_t k = ptr[i - 1]; k < ptr[i]; k++) {
+            const int32_t j = node[k - 1];
+            if (p[j - 1] == -1) {
+                queue[tail++] = j;
+                p[j - 1] = 0;
+            }
+        }
+    }
+    free(queue);
+    return num;
+}
+
+/* greedy_coloring (permutations.f90:83-157): vertices in FIFO order from vertex 1; a vertex
+ * takes, among the colours already in use that none of its neighbours has, the one with the
+ * FEWEST vertices so far (first such in colour order), else a new colour.  colors(i) in
+ * 1..used, -1 for unreached vertices.  Returns the number of colours used. */
+ORC_API int32_t orc_greedy_coloring(int32_t n, const int32_t *ptr, const int32_t *node,
+                                    int32_t *colors)
+{
+    int32_t d = 0;
+    for (int32_t i = 0; i < n; i++) if (ptr[i + 1] - ptr[i] > d) d = ptr[i + 1] - ptr[i];
+    int32_t *queue = malloc((size_t)(n > 0 ? n : 1) * 4);
+    int32_t *neighbor_colors = calloc((size_t)d + 2, 4), *color_totals = calloc((size_t)d + 2, 4);
+    int32_t head = 0, tail = 0, used = 0;
+    for (int32_t i = 0; i < n; i++) colors[i] = -1;
+    if (n > 0) { queue[tail++] = 1; colors[0] = 0; }
+    while (tail > head) {
+        for (int32_t k = 0; k <= d; k++) neighbor_colors[k] = 0;
+        const int32_t i = queue[head++];
+        for (int32_t k = ptr[i - 1]; k < ptr[i]; k++) {
+            const int32_t j = node[k - 1];
+            const int32_t c = colors[j - 1];
+            if (c > 0) neighbor_colors[c - 1]++;
+            else if (c == -1) { queue[tail++] = j; colors[j - 1] = 0; }
+        }
+        int32_t color = 0, min_occupancy = n + 1;
+        for (int32_t k = 1; k <= used; k++)
+            if (color_totals[k - 1] > 0 && color_totals[k - 1] < min_occupancy &&
+                neighbor_colors[k - 1] == 0) {
+                color = k;
+                min_occupancy = color_totals[k - 1];
+            }
+        if (color == 0) color = ++used;
+        colors[i - 1] = color;
+        color_totals[color - 1]++;
+    }
+    free(queue); free(neighbor_colors); free(color_totals);
+    return used;
+}
+
+/* greedy_color_ordering (permutations.f90:162-205): p(i) = new index of vertex i when the
+ * vertices are sorted by colour (stable in i); ptrs(c) = first new index of colour c
+ * (num_colors + 1 entries).  The graph must be connected (the reference indexes ptrs(0)
+ * for an unreached vertex).  Returns num_colors, or -1 if some vertex was not reached. */
+ORC_API int32_t orc_greedy_color_ordering(int32_t n, const int32_t *ptr, const int32_t *node,
+                                          int32_t *p, int32_t *ptrs)
+{
+    const int32_t nc = orc_greedy_coloring(n, ptr, node, p);
+    for (int32_t i = 0; i < n; i++) if (p[i] < 1) return -1;
+    for (int32_t c = 0; c <= nc; c++) ptrs[c] = 0;
+    for (int32_t i = 0; i < n; i++) ptrs[p[i]]++;            /* ptrs(p(i)+1) += 1 */
+    ptrs[0] = 1;
+    for (int32_t c = 1; c <= nc; c++) ptrs[c] += ptrs[c - 1];
+    int32_t *added = calloc((size_t)nc + 1, 4);
+    for (int32_t i = 0; i < n; i++) {
+        const int32_t c = p[i];
+        p[i] = ptrs[c - 1] + added[c - 1];
+        added[c - 1]++;
+    }
+    free(added);
+    return nc;
+}
+
+/* cs_matrix%left_permute (cs_matrices.f90:471-478 -> graph_leftperm -> cs_graph_left_permute
+ * cs_graphs.f90:499-550): row i becomes row p(i); the entries of a row keep their order. */
+ORC_API void orc_csr_left_permute(int32_t n, const int32_t *ptr, const int32_t *node,
+                                  const double *val, const int32_t *p, int32_t *ptr2,
+                                  int32_t *node2, double *val2)
+{
+    for (int32_t i = 0; i <= n; i++) ptr2[i] = 0;
+    for (int32_t i = 0; i < n; i++) ptr2[p[i]] = ptr[i + 1] - ptr[i];     /* ptr(p(i)+1) */
+    ptr2[0] = 1;
+    for (int32_t i = 0; i < n; i++) ptr2[i + 1] += ptr2[i];
+    for (int32_t i = 0; i < n; i++) {
+        const int32_t d = ptr[i + 1] - ptr[i];
+        for (int32_t k = 0; k < d; k++) {
+            node2[ptr2[p[i] - 1] - 1 + k] = node[ptr[i] - 1 + k];
+            val2[ptr2[p[i] - 1] - 1 + k] = val[ptr[i] - 1 + k];
+        }
+    }
+}
+
+/* cs_matrix%right_permute (cs_graph_right_permute cs_graphs.f90:555-571): column j becomes
+ * column p(j), in place; values do not move. */
+ORC_API void orc_csr_right_permute(int64_t nnz, int32_t *node, const int32_t *p)
+{
+    for (int64_t k = 0; k < nnz; k++) node[k] = p[node[k] - 1];
+}

@@ -172,6 +172,37 @@ class _Matrix:
         _ck(lib().sgm_mat_info(self._h, None, None, None, None, C.byref(n)))
         return n.value
 
+    # -- src/graph/permutations.f90 + cs_matrices.f90:471-490 -----------------------------
+    def bfs_order(self):
+        """breadth_first_search(p, g) on the matrix graph: p(i) = visiting number (1-based), -1 unreached."""
+        p = np.zeros(self.nrow, np.int32)
+        _ck(lib().sgm_graph_bfs_order(self._h, p.ctypes.data_as(C.c_void_p)))
+        return p
+
+    def greedy_coloring(self):
+        """greedy_coloring(colors, g): returns (colors, num_colors)."""
+        c = np.zeros(self.nrow, np.int32)
+        nc = C.c_int32(0)
+        _ck(lib().sgm_graph_greedy_coloring(self._h, c.ctypes.data_as(C.c_void_p), C.byref(nc)))
+        return c, nc.value
+
+    def greedy_color_ordering(self):
+        """greedy_color_ordering(p, ptrs, num_colors, g): returns (p, ptrs[:num_colors+1], num_colors)."""
+        p = np.zeros(self.nrow, np.int32)
+        ptrs = np.zeros(self.nrow + 2, np.int32)
+        nc = C.c_int32(0)
+        _ck(lib().sgm_graph_greedy_color_order(self._h, p.ctypes.data_as(C.c_void_p), ptrs.ctypes.data_as(C.c_void_p),
+                                               C.c_int32(len(ptrs)), C.byref(nc)))
+        return p, ptrs[:nc.value + 1].copy(), nc.value
+
+    def left_permute(self, p):
+        pp, w, _k = _arg(p, np.int32)
+        _ck(lib().sgm_mat_left_permute(self._h, pp, C.c_int(w)))
+
+    def right_permute(self, p):
+        pp, w, _k = _arg(p, np.int32)
+        _ck(lib().sgm_mat_right_permute(self._h, pp, C.c_int(w)))
+
     @property
     def kernel(self):
         """Name of the SpMV kernel variant this matrix runs with under the current options."""
@@ -216,6 +247,33 @@ class _Matrix:
         _ck(fn(C.byref(self._h), C.c_int32(nrow), C.c_int32(ncol), C.c_int64(ne), pi, pj, pv,
                C.c_int(_same_where(w1, w2, w3))))
         return self
+
+    # -- sparse_matrix_to_file (sparse_matrix_interfaces.f90:601-653): text dump -----------
+    def to_file(self, filename, trans=False):
+        """`nrow ncol nnz`, then one `i j value` line per stored entry in stored order (rows in
+        order, a row's entries as they lie in memory); `trans` swaps i/j and the dimensions like the
+        reference.  Values are written with 17 significant digits (they read back bit for bit)."""
+        if not isinstance(self, csr_matrix):
+            raise SigmaError(7, "to_file: CSR matrices only")
+        ptr, node, val = self.get("ptr", np.int32), self.get("node", np.int32), self.get("val", np.float64)
+        rows = np.repeat(np.arange(1, self.nrow + 1, dtype=np.int64), np.diff(ptr))
+        a, b = (node, rows) if trans else (rows, node)
+        dims = (self.ncol, self.nrow) if trans else (self.nrow, self.ncol)
+        with open(filename, "w") as f:
+            f.write(f" {dims[0]} {dims[1]} {len(val)}\n")
+            f.writelines(f" {int(i)} {int(j)} {float(v)!r}\n" for i, j, v in zip(a, b, val))
+
+    @classmethod
+    def from_file(cls, filename):
+        """Read a file written by to_file (or by the reference's A%to_file): the entries are
+        inserted in file order, so a CSR matrix written and read back has identical arrays."""
+        with open(filename) as f:
+            nrow, ncol, nnz = (int(t) for t in f.readline().split())
+            data = np.loadtxt(f, dtype=np.float64, ndmin=2) if nnz else np.zeros((0, 3))
+        if data.shape[0] != nnz:
+            raise SigmaError(2, f"from_file: header says {nnz} entries, file holds {data.shape[0]}")
+        return cls.from_edges(nrow, ncol, data[:, 0].astype(np.int32), data[:, 1].astype(np.int32),
+                              np.ascontiguousarray(data[:, 2]))
 
     def destroy(self):
         if self._h:

@@ -1083,6 +1083,23 @@ int build_csr_part(Part &p, int32_t n, int32_t ncol_own, int32_t n_halo, int64_t
     return build_offset_dict(p, where == SGM_HOST ? ptr1 : nullptr, where == SGM_HOST ? node1 : nullptr);
 }
 
+// after a change of the index arrays (matrix permutation): drop and rebuild the derived formats
+int rebuild_csr_formats(Part &p)
+{
+    dfree(p.code); dfree(p.dict); dfree(p.sval); dfree(p.scode);
+    p.code = nullptr; p.dict = nullptr; p.sval = nullptr; p.scode = nullptr;
+    p.ndict = 0; p.sw = 0; p.max_row = 0;
+    return build_offset_dict(p, nullptr, nullptr);
+}
+int sgm_invalidate_transpose(sgm_mat A)
+{
+    if (A->T) { sgm_mat_destroy(A->T); A->T = nullptr; }
+    dfree(A->tperm);
+    A->tperm = nullptr;
+    A->t_stale = true;
+    return SGM_OK;
+}
+
 void free_part(Part &p)
 {
     dfree(p.rowptr); dfree(p.col); dfree(p.val); dfree(p.code); dfree(p.dict); dfree(p.sval); dfree(p.scode); dfree(p.ecol); dfree(p.eval); dfree(p.edeg); dfree(p.ecode); dfree(p.xext);

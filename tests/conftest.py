@@ -24,4 +24,10 @@ def golden():
 
 
 def golden_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+    """Fixtures whose solves ran on the matrix as assembled (the `perm_*` ones re-order it first)."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and not f.startswith("perm_"))
+
+
+def perm_golden_names():
+    """Fixtures of the re-ordering path: permutations.f90 + symmetric permutation, solves on the permuted matrix."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f.startswith("perm_"))

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""ILDU(0)-PCG vs Jacobi-PCG vs CG on a 2-D Poisson grid: iterations and time (one GPU)."""
+"""ILDU(0)-PCG vs Jacobi-PCG vs CG on a 2-D Poisson grid: iterations and time (one GPU).
+  python tools/ildu_bench.py <nx> [cg,jacobi,ildu0] [colour]
+`colour`: the matrix is first re-ordered by the reference's own greedy_color_ordering
+(permutations.f90) and permuted symmetrically -- ILDU(0) then has as many dependency levels as colours."""
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,6 +15,20 @@ ptr, node, val = P.poisson2d_csr(nx, nx)
 sg.init(0)
 A = sg.csr_matrix(n, n, ptr, node, val)
 b = np.full(n, 1.0 / n)
+colour = len(sys.argv) > 3 and sys.argv[3] == "colour"
+if colour:
+    t0 = time.time()
+    p, ptrs, nc = A.greedy_color_ordering()
+    t1 = time.time()
+    A.left_permute(p)
+    A.right_permute(p)
+    sg.synchronize()
+    t2 = time.time()
+    bp = np.empty(n)
+    bp[p - 1] = b
+    b = bp
+    print(json.dumps({"grid": nx, "reordering": "greedy_color_ordering", "colours": nc, "ordering_s": t1 - t0,
+                      "permute_s": t2 - t1}), flush=True)
 for name, mk in (("cg", None), ("jacobi", sg.jacobi), ("ildu0", sg.ldu)):
     if name not in only:
         continue
