@@ -172,7 +172,10 @@ int sgm_axpy(int64_t n, double alpha, const double *x, double *y, int where);
  * sgm_jacobi_create <- jacobi() + jacobi_setup      src/solver/jacobi_solvers.f90:23-63
  * sgm_ildu0_create  <- ldu(incomplete,level=0) + sparse_ldu_setup
  *                      src/solver/ldu_solvers.f90:73-130 (pattern :397-440, factorization
- *                      :275-387 run on the host once; factors + level sets live in HBM)
+ *                      :275-387 run on the host once; factors + level sets live in HBM);
+ *                      on a row-partitioned matrix: ILDU(0) of each part's diagonal block
+ *                      (block-Jacobi, no exchange in the apply; iteration counts differ
+ *                      from the one-part factorisation)
  * sgm_pc_setup      <- pc%setup(A) again after the values changed
  * sgm_pc_apply      <- pc%solve(A, z, r): jacobi_solve :68-81 / ldu_solve :160-176
  * sgm_pc_get        <- read back idiag / L,D,U for parity checks ("idiag","Lptr","Lnode",

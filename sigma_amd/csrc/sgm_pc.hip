@@ -78,17 +78,24 @@ struct PartPC {
 
 }  // namespace
 
-struct sgm_pc_s {
-    int kind = 0;
+// ILDU(0) of one diagonal block (the whole matrix on one GPU; with a row partition, the owned
+// rows x owned columns of each part: block-Jacobi ILDU)
+struct IlduState {
     int32_t n = 0;
-    std::vector<PartPC> parts;       // jacobi
-    // ildu (single part)
     TriFactor L, U;
     double *D = nullptr;
     double *xpL = nullptr, *xpU = nullptr, *Dp = nullptr;   // level-order work vectors, D in U's level order
     int32_t *mapLU = nullptr;                                // U position -> L position of the same row
     std::vector<int32_t> hLptr, hLnode, hUptr, hUnode;      // 1-based, as the reference holds them
-    std::vector<double> hLval, hUval, hD, hidiag;
+    std::vector<double> hLval, hUval, hD;
+};
+
+struct sgm_pc_s {
+    int kind = 0;
+    int32_t n = 0;
+    std::vector<PartPC> parts;       // jacobi
+    std::vector<IlduState> ild;      // ildu: one block per part
+    std::vector<double> hidiag;
 };
 
 namespace {
@@ -422,7 +429,7 @@ struct HostCsr {
 
 // incomplete_ldu_sparsity_pattern, level 0 (ldu_solvers.f90:397-440): entries of A in
 // stored order; i>j -> L, j>i -> U.
-void ildu_pattern(sgm_pc pc, int32_t n, const std::vector<int32_t> &ptr, const std::vector<int32_t> &node)
+void ildu_pattern(IlduState *pc, int32_t n, const std::vector<int32_t> &ptr, const std::vector<int32_t> &node)
 {
     pc->hLptr.assign(n + 1, 1);
     pc->hUptr.assign(n + 1, 1);
@@ -440,7 +447,7 @@ void ildu_pattern(sgm_pc pc, int32_t n, const std::vector<int32_t> &ptr, const s
 }
 
 // sparse_static_pattern_ldu_factorization (ldu_solvers.f90:275-387), same statement order.
-void ildu_factor(sgm_pc pc, int32_t n, const std::vector<int32_t> &ptr, const std::vector<int32_t> &node,
+void ildu_factor(IlduState *pc, int32_t n, const std::vector<int32_t> &ptr, const std::vector<int32_t> &node,
                  const std::vector<double> &val)
 {
     pc->hLval.assign(pc->hLnode.size(), 0.0);
@@ -484,6 +491,15 @@ void ildu_factor(sgm_pc pc, int32_t n, const std::vector<int32_t> &ptr, const st
             U.set(i, k, Uik / D[i - 1]);
         }
     }
+}
+
+void free_tri(TriFactor &T);
+void free_ildu(IlduState &S)
+{
+    free_tri(S.L);
+    free_tri(S.U);
+    dfree(S.D); dfree(S.xpL); dfree(S.xpU); dfree(S.Dp); dfree(S.mapLU);
+    S = IlduState();
 }
 
 void free_tri(TriFactor &T)
@@ -674,20 +690,29 @@ void trsv(const TriFactor &T, double *xp, const int *flag)
     }
 }
 
-int download_csr(sgm_mat A, std::vector<int32_t> &ptr1, std::vector<int32_t> &node1, std::vector<double> &val)
+// rows of one part restricted to its owned columns (1-based host copy).  For a single-part
+// matrix this is the matrix itself; for a row partition it is the diagonal block (halo columns,
+// numbered >= ncol_own, are dropped).
+int download_block(const Part &p, std::vector<int32_t> &ptr1, std::vector<int32_t> &node1, std::vector<double> &val)
 {
-    const Part &p = A->parts[0];
-    ptr1.resize((size_t)p.n + 1);
-    node1.resize((size_t)p.nnz);
-    val.resize((size_t)p.nnz);
+    std::vector<int32_t> hp((size_t)p.n + 1), hc((size_t)p.nnz);
+    std::vector<double> hv((size_t)p.nnz);
     SGM_HIP(hipStreamSynchronize(g_rt.stream));
-    SGM_HIP(hipMemcpy(ptr1.data(), p.rowptr, ptr1.size() * 4, hipMemcpyDeviceToHost));
+    SGM_HIP(hipMemcpy(hp.data(), p.rowptr, hp.size() * 4, hipMemcpyDeviceToHost));
     if (p.nnz) {
-        SGM_HIP(hipMemcpy(node1.data(), p.col, node1.size() * 4, hipMemcpyDeviceToHost));
-        SGM_HIP(hipMemcpy(val.data(), p.val, val.size() * 8, hipMemcpyDeviceToHost));
+        SGM_HIP(hipMemcpy(hc.data(), p.col, hc.size() * 4, hipMemcpyDeviceToHost));
+        SGM_HIP(hipMemcpy(hv.data(), p.val, hv.size() * 8, hipMemcpyDeviceToHost));
     }
-    for (auto &v : ptr1) v += 1;
-    for (auto &v : node1) v += 1;
+    ptr1.assign((size_t)p.n + 1, 1);
+    node1.clear();
+    val.clear();
+    node1.reserve(hc.size());
+    val.reserve(hv.size());
+    for (int32_t i = 0; i < p.n; ++i) {
+        for (int32_t k = hp[i]; k < hp[i + 1]; ++k)
+            if (hc[k] < p.ncol_own) { node1.push_back(hc[k] + 1); val.push_back(hv[k]); }
+        ptr1[i + 1] = (int32_t)node1.size() + 1;
+    }
     return SGM_OK;
 }
 
@@ -708,16 +733,19 @@ int pc_apply_parts(sgm_pc pc, sgm_mat A, const double *const *r, double *const *
                                flags ? flags[ip] : nullptr);
         }
     } else {
-        const int64_t n = pc->n;
-        const int *flag = flags ? flags[0] : nullptr;
-        const int g = vec_grid(n);
-        hipLaunchKernelGGL(k_perm_gather, dim3(g), dim3(kBlock), 0, st, n, pc->xpL, r[0], (const int32_t *)pc->L.order, flag);
-        trsv(pc->L, pc->xpL, flag);                                             // (I+L) x = b
-        hipLaunchKernelGGL(k_lu_transition, dim3(g), dim3(kBlock), 0, st, n, pc->xpU, (const double *)pc->xpL,
-                           (const int32_t *)pc->mapLU, (const double *)pc->Dp, flag);                       // x = x / D
-        trsv(pc->U, pc->xpU, flag);                                             // (I+U) x = x
-        hipLaunchKernelGGL(k_perm_scatter, dim3(g), dim3(kBlock), 0, st, n, z[0], (const double *)pc->xpU,
-                           (const int32_t *)pc->U.order, flag);
+        for (size_t ip = 0; ip < pc->ild.size(); ++ip) {      // block-Jacobi over the parts: no exchange
+            const IlduState *S = &pc->ild[ip];
+            const int64_t n = S->n;
+            const int *flag = flags ? flags[ip] : nullptr;
+            const int g = vec_grid(n);
+            hipLaunchKernelGGL(k_perm_gather, dim3(g), dim3(kBlock), 0, st, n, S->xpL, r[ip], (const int32_t *)S->L.order, flag);
+            trsv(S->L, S->xpL, flag);                                             // (I+L) x = b
+            hipLaunchKernelGGL(k_lu_transition, dim3(g), dim3(kBlock), 0, st, n, S->xpU, (const double *)S->xpL,
+                               (const int32_t *)S->mapLU, (const double *)S->Dp, flag);                     // x = x / D
+            trsv(S->U, S->xpU, flag);                                             // (I+U) x = x
+            hipLaunchKernelGGL(k_perm_scatter, dim3(g), dim3(kBlock), 0, st, n, z[ip], (const double *)S->xpU,
+                               (const int32_t *)S->U.order, flag);
+        }
     }
     SGM_HIP(hipGetLastError());
     return SGM_OK;
@@ -758,35 +786,44 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
         SGM_HIP(hipGetLastError());
         return finish();
     }
-    // ILDU(0)
-    if (A->fmt != SGM_FMT_CSR || A->distributed())
-        return fail(SGM_ERR_UNSUPPORTED, "ILDU(0) needs a single-GPU CSR matrix");
-    std::vector<int32_t> ptr1, node1;
-    std::vector<double> val;
-    SGM_TRY(download_csr(A, ptr1, node1, val));
-    const int32_t n = A->nrow;
-    const bool fresh = pc->n != n || pc->hLptr.empty();      // ldu_solvers.f90:117-125: pattern once
-    if (fresh) ildu_pattern(pc, n, ptr1, node1);
-    pc->n = n;
-    ildu_factor(pc, n, ptr1, node1, val);
-    SGM_TRY(upload_tri(pc->L, n, pc->hLptr, pc->hLnode, pc->hLval, true, fresh));
-    SGM_TRY(upload_tri(pc->U, n, pc->hUptr, pc->hUnode, pc->hUval, false, fresh));
-    if (fresh) {
-        dfree(pc->D); dfree(pc->xpL); dfree(pc->xpU); dfree(pc->Dp); dfree(pc->mapLU);
-        SGM_TRY(dalloc(&pc->D, (size_t)n));
-        SGM_TRY(dalloc(&pc->xpL, (size_t)n + kNarrow));     // + scratch slots of the level walker
-        SGM_TRY(dalloc(&pc->xpU, (size_t)n + kNarrow));
-        SGM_TRY(dalloc(&pc->Dp, (size_t)n));
-        SGM_TRY(dalloc(&pc->mapLU, (size_t)n));
-        std::vector<int32_t> map((size_t)std::max(n, 1));
-        for (int32_t p = 0; p < n; ++p) map[p] = pc->L.h_pos[pc->U.h_order[p]];
-        if (n) SGM_HIP(hipMemcpy(pc->mapLU, map.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    // ILDU(0); on a row partition: of every part's diagonal block (block-Jacobi ILDU -- exact
+    // parity with the reference holds for one part, more parts change the iteration counts)
+    if (A->fmt != SGM_FMT_CSR)
+        return fail(SGM_ERR_UNSUPPORTED, "ILDU(0) needs a CSR matrix");
+    if (pc->ild.size() != A->parts.size()) {
+        for (auto &S : pc->ild) free_ildu(S);
+        pc->ild.assign(A->parts.size(), IlduState());
     }
-    std::vector<double> dp((size_t)std::max(n, 1));
-    for (int32_t p = 0; p < n; ++p) dp[p] = pc->hD[pc->U.h_order[p]];
-    if (n) {
-        SGM_HIP(hipMemcpy(pc->D, pc->hD.data(), (size_t)n * 8, hipMemcpyHostToDevice));
-        SGM_HIP(hipMemcpy(pc->Dp, dp.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    pc->n = A->nrow;
+    for (size_t ip = 0; ip < A->parts.size(); ++ip) {
+        IlduState *S = &pc->ild[ip];
+        std::vector<int32_t> ptr1, node1;
+        std::vector<double> val;
+        SGM_TRY(download_block(A->parts[ip], ptr1, node1, val));
+        const int32_t n = A->parts[ip].n;
+        const bool fresh = S->n != n || S->hLptr.empty();      // ldu_solvers.f90:117-125: pattern once
+        if (fresh) ildu_pattern(S, n, ptr1, node1);
+        S->n = n;
+        ildu_factor(S, n, ptr1, node1, val);
+        SGM_TRY(upload_tri(S->L, n, S->hLptr, S->hLnode, S->hLval, true, fresh));
+        SGM_TRY(upload_tri(S->U, n, S->hUptr, S->hUnode, S->hUval, false, fresh));
+        if (fresh) {
+            dfree(S->D); dfree(S->xpL); dfree(S->xpU); dfree(S->Dp); dfree(S->mapLU);
+            SGM_TRY(dalloc(&S->D, (size_t)n));
+            SGM_TRY(dalloc(&S->xpL, (size_t)n + kNarrow));     // + scratch slots of the level walker
+            SGM_TRY(dalloc(&S->xpU, (size_t)n + kNarrow));
+            SGM_TRY(dalloc(&S->Dp, (size_t)n));
+            SGM_TRY(dalloc(&S->mapLU, (size_t)n));
+            std::vector<int32_t> map((size_t)std::max(n, 1));
+            for (int32_t p = 0; p < n; ++p) map[p] = S->L.h_pos[S->U.h_order[p]];
+            if (n) SGM_HIP(hipMemcpy(S->mapLU, map.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        }
+        std::vector<double> dp((size_t)std::max(n, 1));
+        for (int32_t p = 0; p < n; ++p) dp[p] = S->hD[S->U.h_order[p]];
+        if (n) {
+            SGM_HIP(hipMemcpy(S->D, S->hD.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+            SGM_HIP(hipMemcpy(S->Dp, dp.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+        }
     }
     return SGM_OK;
 }
@@ -847,17 +884,19 @@ int sgm_pc_get(sgm_pc pc, const char *name, void *out, size_t bytes, size_t *nee
         if (pc->n) SGM_HIP(hipMemcpy(pc->hidiag.data(), pc->parts[0].idiag, (size_t)pc->n * 8, hipMemcpyDeviceToHost));
         src = pc->hidiag.data(); sz = pc->hidiag.size() * 8;
     } else if (pc->kind == SGM_PC_ILDU0) {
-        if (nm == "Lptr") { src = pc->hLptr.data(); sz = pc->hLptr.size() * 4; }
-        else if (nm == "Lnode") { src = pc->hLnode.data(); sz = pc->hLnode.size() * 4; }
-        else if (nm == "Lval") { src = pc->hLval.data(); sz = pc->hLval.size() * 8; }
-        else if (nm == "Uptr") { src = pc->hUptr.data(); sz = pc->hUptr.size() * 4; }
-        else if (nm == "Unode") { src = pc->hUnode.data(); sz = pc->hUnode.size() * 4; }
-        else if (nm == "Uval") { src = pc->hUval.data(); sz = pc->hUval.size() * 8; }
-        else if (nm == "D") { src = pc->hD.data(); sz = pc->hD.size() * 8; }
+        if (pc->ild.size() != 1) return fail(SGM_ERR_UNSUPPORTED, "sgm_pc_get: single-part ILDU only");
+        const IlduState *S = &pc->ild[0];
+        if (nm == "Lptr") { src = S->hLptr.data(); sz = S->hLptr.size() * 4; }
+        else if (nm == "Lnode") { src = S->hLnode.data(); sz = S->hLnode.size() * 4; }
+        else if (nm == "Lval") { src = S->hLval.data(); sz = S->hLval.size() * 8; }
+        else if (nm == "Uptr") { src = S->hUptr.data(); sz = S->hUptr.size() * 4; }
+        else if (nm == "Unode") { src = S->hUnode.data(); sz = S->hUnode.size() * 4; }
+        else if (nm == "Uval") { src = S->hUval.data(); sz = S->hUval.size() * 8; }
+        else if (nm == "D") { src = S->hD.data(); sz = S->hD.size() * 8; }
         else if (nm == "levels") {
             static int32_t lv[2];
-            lv[0] = (int32_t)pc->L.level_ptr.size() - 1;
-            lv[1] = (int32_t)pc->U.level_ptr.size() - 1;
+            lv[0] = (int32_t)S->L.level_ptr.size() - 1;
+            lv[1] = (int32_t)S->U.level_ptr.size() - 1;
             src = lv; sz = sizeof lv;
         }
     }
@@ -877,9 +916,7 @@ int sgm_pc_destroy(sgm_pc pc)
 {
     if (!pc) return SGM_OK;
     for (auto &pp : pc->parts) dfree(pp.idiag);
-    free_tri(pc->L);
-    free_tri(pc->U);
-    dfree(pc->D); dfree(pc->xpL); dfree(pc->xpU); dfree(pc->Dp); dfree(pc->mapLU);
+    for (auto &S : pc->ild) free_ildu(S);
     delete pc;
     return SGM_OK;
 }
