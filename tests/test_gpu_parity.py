@@ -538,6 +538,29 @@ def test_ildu_apply_many_levels_vs_oracle(orc):
     assert np.array_equal(z, ref.solve(b))
 
 
+@pytest.mark.parametrize("nx,ny", [(300, 300), (700, 600), (1500, 1100), (2500, 2100), (5000, 4200)])
+def test_ildu_ring_walker_every_width_class_vs_oracle(orc, nx, ny):
+    """The LDS-ring level walker picks its thread count / rows per lane from the widest level of
+    a run (<= 256, 512, 1024, 2048, 4096 rows; wider levels get one launch each): grids whose
+    anti-diagonals reach each class, apply compared bit for bit with the oracle's sequential sweeps."""
+    n = nx * ny
+    ptr, node, val = P.poisson2d_csr(nx, ny)
+    A = orc.CsrMatrix(n, n, ptr, node, val)
+    ref = orc.Ildu(A)
+    H = hip_from_oracle(A)
+    pc = sg.ldu()
+    pc.setup(H)
+    assert list(pc.get("levels", np.int32)) == [nx + ny - 1, nx + ny - 1]
+    b = np.random.RandomState(nx).standard_normal(n)
+    z = np.zeros(n)
+    pc.solve(H, z, b)
+    assert np.array_equal(z, ref.solve(b))
+    # a second apply (the work vectors and the prefetch scratch slots are reused)
+    b2 = P.test_vector(n)
+    pc.solve(H, z, b2)
+    assert np.array_equal(z, ref.solve(b2))
+
+
 # ------------------------------------------------------------------------- re-orderings
 @pytest.mark.parametrize("name", perm_golden_names())
 def test_reorderings_and_permuted_matrix_golden_bit_exact(golden, name):
