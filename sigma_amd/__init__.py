@@ -76,8 +76,13 @@ def init(device=0):
     _ck(lib().sgm_init(C.c_int(device)))
 
 
+_adopted_stream = None      # hipStream_t the library launches on when it is not its own
+
+
 def set_stream(stream_ptr):
+    global _adopted_stream
     _ck(lib().sgm_set_stream(C.c_void_p(stream_ptr)))
+    _adopted_stream = stream_ptr or None
 
 
 def set_async(on):
@@ -116,6 +121,11 @@ def _arg(a, dtype, writable=False):
             raise TypeError(f"torch tensor must be contiguous {want}")
         if not a.is_cuda:
             return _arg(a.numpy(), dtype, writable)
+        # the library launches on its own stream unless it adopted torch's (use_torch_stream): a
+        # tensor torch is still producing on another stream must be finished before we read it
+        cur = torch.cuda.current_stream(a.device)
+        if cur.cuda_stream != _adopted_stream:
+            cur.synchronize()
         return C.c_void_p(a.data_ptr()), SGM_DEVICE, a
     arr = np.asarray(a)
     if arr.dtype != dtype or not arr.flags.c_contiguous or (writable and not arr.flags.writeable):

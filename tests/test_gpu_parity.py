@@ -1129,6 +1129,102 @@ def test_full_size_properties():
     assert phi40 < phi20 < 0.0
 
 
+def _torch_rowsum_in_stored_order(cols, vals, mask, x):
+    """y(i) = ((0 + v0*x[c0]) + v1*x[c1]) + ... over the row's slots in stored order, one torch
+    elementwise op per step (separate kernels: products rounded, then added -- no FMA): an
+    independent evaluation of the reference's loop for matrices laid out as (row, slot) tables."""
+    import torch
+    z = torch.zeros(cols.shape[0], dtype=torch.float64, device=x.device)
+    for k in range(cols.shape[1]):
+        prod = vals[:, k] * x[cols[:, k]]
+        z = torch.where(mask[:, k], z + prod, z) if mask is not None else z + prod
+    return z
+
+
+def test_full_size_c3_tridiagonal_spmv_and_krylov_residuals():
+    """BASELINE C3: 1-D advection-diffusion, n = 1e7.  Every row of the SpMV bit-exact against a
+    torch evaluation in stored order; BiCGStab and GMRES(30) for a fixed 30 iterations: the
+    recursive residual the solver reports equals the true residual b - A u recomputed by SpMV."""
+    import torch
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from bench_configs import stencil_csr_torch
+    dev = torch.device("cuda", 0)
+    n = 10_000_000
+    dx = 1.0 / (n + 1)
+    lo, up = -1.0 - 0.5 * dx / 2, -1.0 + 0.5 * dx / 2
+    ptr, node, val = P.tridiag_csr(n, 2.0, up, lo)
+    A = sg.csr_matrix(n, n, ptr, node, val)
+    x = torch.sin(0.001 * torch.arange(1, n + 1, dtype=torch.float64, device=dev))
+    y = torch.zeros(n, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()            # the library launches on its own stream
+    A.matvec(x, y)
+    torch.cuda.synchronize()
+    # row tables in the stored order of tridiag_csr: row 1 = (1,1),(1,2); row i = (i,i-1),(i,i),(i,i+1)
+    tp, tn, tv = (torch.from_numpy(a).to(dev) for a in (ptr.astype(np.int64), node.astype(np.int64), val))
+    start = tp[:-1] - 1
+    ln = tp[1:] - tp[:-1]
+    cols = torch.stack([tn[torch.clamp(start + k, max=tn.numel() - 1)] - 1 for k in range(3)], dim=1)
+    vals = torch.stack([tv[torch.clamp(start + k, max=tn.numel() - 1)] for k in range(3)], dim=1)
+    mask = torch.stack([ln > k for k in range(3)], dim=1)
+    assert torch.equal(y, _torch_rowsum_in_stored_order(cols, vals, mask, x))
+    b = torch.full((n,), 2.0 * dx * dx, dtype=torch.float64, device=dev)
+    for mk in (lambda: sg.bicgstab(1e-300), lambda: sg.gmres(1e-300, 30)):
+        s = mk()
+        s.set_max_iter(30)
+        s.setup(A)
+        u = torch.zeros(n, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        s.solve(A, u, b, check=False)
+        Au = torch.zeros_like(u)
+        torch.cuda.synchronize()
+        A.matvec(u, Au)
+        torch.cuda.synchronize()
+        true_res2 = float(torch.dot(b - Au, b - Au))
+        assert s.last_iterations == 30 and np.isfinite(s.res2)
+        assert abs(true_res2 - s.res2) <= 1e-6 * max(true_res2, s.res2), (true_res2, s.res2)
+
+
+def test_full_size_c5_mini_and_c4_every_row_bit_exact():
+    """BASELINE C5 geometry (7-point, z-slab sized 464 x 464 x 58 = one of eight ranks' rows at
+    full cross-section) and C4 (ELLPACK random digraph, degree 32, n = 5e6 at 1/4 size): every
+    row bit-exact against the torch evaluation in stored order."""
+    import torch
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from bench_configs import laplace3d_torch
+    dev = torch.device("cuda", 0)
+    nx, ny, nz = 464, 464, 58
+    n = nx * ny * nz
+    ptr, node, val = laplace3d_torch(nx, ny, nz, dev)
+    A = sg.csr_matrix(n, n, ptr, node, val)
+    x = torch.sin(0.001 * torch.arange(1, n + 1, dtype=torch.float64, device=dev))
+    y = torch.zeros(n, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()            # the library launches on its own stream
+    A.matvec(x, y)
+    torch.cuda.synchronize()
+    tp, tn = ptr.to(torch.int64), node.to(torch.int64)
+    start, ln = tp[:-1] - 1, tp[1:] - tp[:-1]
+    cols = torch.stack([tn[torch.clamp(start + k, max=tn.numel() - 1)] - 1 for k in range(7)], dim=1)
+    vals = torch.stack([val[torch.clamp(start + k, max=tn.numel() - 1)] for k in range(7)], dim=1)
+    mask = torch.stack([ln > k for k in range(7)], dim=1)
+    assert torch.equal(y, _torch_rowsum_in_stored_order(cols, vals, mask, x))
+    del A, cols, vals, mask, ptr, node, val
+    # C4 at a quarter of the rows (the generator is a sequential 64-bit LCG on the host)
+    n = 1_250_000
+    ei, ej, ev = P.random_regular_ell(n, 32, 12345)
+    enode, eval_ = ej.reshape(n, 32), ev.reshape(n, 32)
+    E = sg.ellpack_matrix(n, n, enode, eval_)
+    x = torch.sin(0.001 * torch.arange(1, n + 1, dtype=torch.float64, device=dev))
+    y = torch.zeros(n, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    E.matvec(x, y)
+    torch.cuda.synchronize()
+    cols = torch.from_numpy(enode.astype(np.int64) - 1).to(dev)
+    vals = torch.from_numpy(np.ascontiguousarray(eval_)).to(dev)
+    assert torch.equal(y, _torch_rowsum_in_stored_order(cols, vals, None, x))
+
+
 # ------------------------------------------------------------- Fortran ISO_C_BINDING host layer
 def test_fortran_host_layer():
     """sigma_amd/fortran: the reference's two deterministic solver tests re-written against
