@@ -125,13 +125,21 @@ __global__ void k_jacobi_setup_ell(int32_t n, int32_t max_d, const int32_t *__re
         if (ecol[(int64_t)k * n + i] == i) { z = eval[(int64_t)k * n + i]; break; }
     idiag[i] = 1.0 / z;
 }
+// (vectors are 16-byte aligned: 16-byte accesses for the pairs, the odd tail element alone)
 __global__ void k_scale_by(int64_t n, const double *__restrict__ d, const double *__restrict__ r,
                            double *__restrict__ z, const int *flag)
 {
     if (flag && *flag) return;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) z[i] = d[i] * r[i];       // x = idiag * b
+    const int64_t n2 = n >> 1;
+    const double2 *d2 = reinterpret_cast<const double2 *>(d), *r2 = reinterpret_cast<const double2 *>(r);
+    double2 *z2 = reinterpret_cast<double2 *>(z);
+    for (int64_t i = gtid; i < n2; i += stride) {            // x = idiag * b
+        const double2 a = d2[i], b = r2[i];
+        z2[i] = make_double2(a.x * b.x, a.y * b.y);
+    }
+    if ((n & 1) && gtid == 0) z[n - 1] = d[n - 1] * r[n - 1];
 }
 __global__ void k_div_by(int64_t n, const double *__restrict__ d, double *__restrict__ x, const int *flag)
 {
