@@ -122,6 +122,54 @@ interface
         integer(c_int), value :: where
         integer(c_int) :: rc
     end function
+    function sgm_mat_left_permute(A, p, where) &
+            & bind(c, name='sgm_mat_left_permute') result(rc)
+        import
+        type(c_ptr), value :: A
+        integer(c_int32_t), intent(in) :: p(*)
+        integer(c_int), value :: where
+        integer(c_int) :: rc
+    end function
+    function sgm_mat_right_permute(A, p, where) &
+            & bind(c, name='sgm_mat_right_permute') result(rc)
+        import
+        type(c_ptr), value :: A
+        integer(c_int32_t), intent(in) :: p(*)
+        integer(c_int), value :: where
+        integer(c_int) :: rc
+    end function
+    function sgm_graph_bfs_order(A, p) bind(c, name='sgm_graph_bfs_order') result(rc)
+        import
+        type(c_ptr), value :: A
+        integer(c_int32_t), intent(out) :: p(*)
+        integer(c_int) :: rc
+    end function
+    function sgm_graph_greedy_coloring(A, colors, num_colors) &
+            & bind(c, name='sgm_graph_greedy_coloring') result(rc)
+        import
+        type(c_ptr), value :: A
+        integer(c_int32_t), intent(out) :: colors(*)
+        integer(c_int32_t), intent(out) :: num_colors
+        integer(c_int) :: rc
+    end function
+    function sgm_graph_greedy_color_order(A, p, ptrs, ptrs_len, num_colors) &
+            & bind(c, name='sgm_graph_greedy_color_order') result(rc)
+        import
+        type(c_ptr), value :: A
+        integer(c_int32_t), intent(out) :: p(*), ptrs(*)
+        integer(c_int32_t), value :: ptrs_len
+        integer(c_int32_t), intent(out) :: num_colors
+        integer(c_int) :: rc
+    end function
+    function sgm_mat_get(A, name, out, bytes, needed) bind(c, name='sgm_mat_get') result(rc)
+        import
+        type(c_ptr), value :: A
+        character(kind=c_char), intent(in) :: name(*)
+        type(c_ptr), value :: out
+        integer(c_size_t), value :: bytes
+        type(c_ptr), value :: needed
+        integer(c_int) :: rc
+    end function
     function sgm_mat_destroy(A) bind(c, name='sgm_mat_destroy') result(rc)
         import :: c_ptr, c_int
         type(c_ptr), value :: A
@@ -231,6 +279,8 @@ contains
     procedure :: matvec_add => hip_csr_matvec_add
     procedure :: matvec_t => hip_csr_matvec_t
     procedure :: matvec_t_add => hip_csr_matvec_t_add
+    procedure :: left_permute => hip_csr_left_permute
+    procedure :: right_permute => hip_csr_right_permute
     procedure :: destroy => hip_csr_destroy
 end type hip_csr_matrix
 
@@ -416,6 +466,66 @@ subroutine hip_csr_matvec_t_add(A, x, y)  ! csc_matvec_add, cs_matrices.f90:627-
     real(dp), intent(inout) :: y(:)
     call A%upload()
     call hip_check(sgm_mat_matvec_t_add(A%handle, x, y, SGM_HOST))
+end subroutine
+
+! cs_matrices.f90:471-490: the permutation runs on the device; the host copies of the arrays
+! (kept for get_value / set_value) are refreshed from it
+subroutine hip_csr_left_permute(A, p)
+    class(hip_csr_matrix), intent(inout), target :: A
+    integer, intent(in) :: p(:)
+    call A%upload()
+    call hip_check(sgm_mat_left_permute(A%handle, int(p, c_int32_t), SGM_HOST))
+    call hip_csr_download(A)
+end subroutine
+
+subroutine hip_csr_right_permute(A, p)
+    class(hip_csr_matrix), intent(inout), target :: A
+    integer, intent(in) :: p(:)
+    call A%upload()
+    call hip_check(sgm_mat_right_permute(A%handle, int(p, c_int32_t), SGM_HOST))
+    call hip_csr_download(A)
+end subroutine
+
+subroutine hip_csr_download(A)
+    class(hip_csr_matrix), intent(inout), target :: A
+    call hip_check(sgm_mat_get(A%handle, 'ptr'//c_null_char, c_loc(A%ptr), &
+        & int(4 * size(A%ptr), c_size_t), c_null_ptr))
+    call hip_check(sgm_mat_get(A%handle, 'node'//c_null_char, c_loc(A%node), &
+        & int(4 * size(A%node), c_size_t), c_null_ptr))
+    call hip_check(sgm_mat_get(A%handle, 'val'//c_null_char, c_loc(A%val), &
+        & int(8 * size(A%val), c_size_t), c_null_ptr))
+    A%values_dirty = .false.
+end subroutine
+
+! src/graph/permutations.f90 on the matrix graph (the routines take the matrix, which owns it)
+subroutine hip_breadth_first_search(p, A)              ! permutations.f90:22-78
+    integer, intent(out) :: p(:)
+    class(hip_csr_matrix), intent(inout) :: A
+    integer(c_int32_t) :: p32(size(p))
+    call A%upload()
+    call hip_check(sgm_graph_bfs_order(A%handle, p32))
+    p = p32
+end subroutine
+
+subroutine hip_greedy_coloring(colors, A)              ! permutations.f90:83-157
+    integer, intent(out) :: colors(:)
+    class(hip_csr_matrix), intent(inout) :: A
+    integer(c_int32_t) :: c32(size(colors)), nc
+    call A%upload()
+    call hip_check(sgm_graph_greedy_coloring(A%handle, c32, nc))
+    colors = c32
+end subroutine
+
+subroutine hip_greedy_color_ordering(p, ptrs, num_colors, A)   ! permutations.f90:162-205
+    integer, intent(out) :: p(:), ptrs(:), num_colors
+    class(hip_csr_matrix), intent(inout) :: A
+    integer(c_int32_t) :: p32(size(p)), t32(size(ptrs)), nc
+    call A%upload()
+    t32 = 0
+    call hip_check(sgm_graph_greedy_color_order(A%handle, p32, t32, int(size(ptrs), c_int32_t), nc))
+    p = p32
+    ptrs = t32
+    num_colors = nc
 end subroutine
 
 subroutine hip_csr_destroy(A)

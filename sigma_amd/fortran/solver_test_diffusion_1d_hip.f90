@@ -17,8 +17,9 @@ implicit none
     type(hip_csr_matrix) :: B
     type(hip_linear_solver), pointer :: solver, pc
     real(dp), allocatable :: u(:), v(:), f(:)
-    integer, allocatable :: ptr(:), node(:)
-    integer :: i, nn, k
+    integer, allocatable :: ptr(:), node(:), pp(:), cptrs(:)
+    real(dp), allocatable :: fp(:), up(:)
+    integer :: i, nn, k, ncol
     real(dp) :: dx, misfit, c, x
     character(len=16) :: arg
     logical :: verbose
@@ -127,6 +128,45 @@ implicit none
     call solver%destroy()
     call pc%destroy()
     deallocate(solver, pc)
+
+    !------------------------------------------------------------------!
+    ! the same system after greedy_color_ordering (permutations.f90)    !
+    ! and a symmetric permutation: ILDU(0)-preconditioned CG             !
+    !------------------------------------------------------------------!
+    allocate(pp(nn), cptrs(nn + 2), fp(nn), up(nn))
+    call hip_greedy_color_ordering(pp, cptrs, ncol, B)
+    if (ncol /= 2 .or. cptrs(1) /= 1 .or. cptrs(3) /= nn + 1) then
+        print *, 'a tridiagonal graph takes two colours; got', ncol, cptrs(1:3)
+        call exit(1)
+    endif
+    call B%left_permute(pp)
+    call B%right_permute(pp)
+    do i = 1, nn
+        fp(pp(i)) = f(i)
+        if (B%get_value(pp(i), pp(i)) /= 2.0_dp) then
+            print *, 'permuted diagonal entry is wrong at', i
+            call exit(1)
+        endif
+    enddo
+    solver => hip_cg(1.d-16)
+    pc => hip_ldu(incomplete = .true., level = 0)
+    call solver%setup(B)
+    call pc%setup(B)
+    up = 0.0_dp
+    call solver%solve(B, up, fp, pc)
+    do i = 1, nn
+        u(i) = up(pp(i))
+    enddo
+    misfit = maxval(dabs(u - v))
+    if (verbose) print *, 'colour-ordered ILDU-PCG iterations:', solver%iterations, ' error:', misfit
+    if (misfit > 1.0e-14) then
+        print *, 'ILDU-preconditioned CG on the colour-ordered matrix failed. Error found:', misfit
+        call exit(1)
+    endif
+    call solver%destroy()
+    call pc%destroy()
+    deallocate(solver, pc, pp, cptrs, fp, up)
+
     call B%destroy()
     call A%destroy()
     deallocate(u, v, f)
