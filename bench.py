@@ -223,11 +223,19 @@ def main():
                "sample": f"the full workload matrix (n={Ao.n}, nnz={Ao.nnz}), {reps} matvecs of "
                          f"oracle/sigma_oracle.c (csr_matvec_add restatement), {sec * 1e3:.1f} ms each; "
                          f"host has {os.cpu_count()} logical cores, the reference is single-threaded"}
+        # SURVEY 8(d) "(ii) all cores": the same row loop under one OpenMP pragma (rows bit-identical)
+        sec_omp, nthreads, y_omp = orc.time_csr_matvec_omp(Ao, P.test_vector(n_loc), reps)
+        cpu["all_cores_openmp"] = {"GB/s": spmv_bytes(Ao.n, Ao.n, Ao.nnz) / sec_omp / 1e9, "threads": nthreads,
+                                   "ms_per_matvec": 1e3 * sec_omp,
+                                   "note": "arrays are numpy allocations first touched by one thread (one NUMA node); "
+                                           "the thread count is the pod's OpenMP default, not a tuned placement",
+                                   "rows_equal_single_thread": bool(np.array_equal(y_omp, Ao.matvec(P.test_vector(n_loc))))}
         # the REAL reference (compiled in place by oracle/build_ref.sh; the binary travels with
         # the snapshot, the sources do not), timed on a bounded sample of the same workload
         ref = reference_cpu_baseline()
         if ref:
-            ref["port_on_full_workload"] = {"GB/s": cpu["value"], "sample": cpu["sample"]}
+            ref["port_on_full_workload"] = {"GB/s": cpu["value"], "sample": cpu["sample"],
+                                            "all_cores_openmp": cpu["all_cores_openmp"]}
             cpu = ref
 
     # HBM bytes per launch from the PMC counters cannot be collected inside this process; they

@@ -322,3 +322,14 @@ def time_csr_matvec(A, x, reps):
     x = np.ascontiguousarray(x, F8)
     return lib().orc_time_csr_matvec(C.c_int32(A.n), _p(A.ptr), _p(A.node), _p(A.val),
                                      _p(x), _p(y), C.c_int32(reps))
+
+
+def time_csr_matvec_omp(A, x, reps):
+    """All host cores (OpenMP over rows; bit-identical rows): returns (seconds per matvec, threads)."""
+    y = np.zeros(A.n, F8)
+    x = np.ascontiguousarray(x, F8)
+    nt = C.c_int32(0)
+    lib().orc_time_csr_matvec_omp.restype = C.c_double
+    sec = lib().orc_time_csr_matvec_omp(C.c_int32(A.n), _p(A.ptr), _p(A.node), _p(A.val), _p(x), _p(y),
+                                        C.c_int32(reps), C.byref(nt))
+    return sec, int(nt.value), y
