@@ -7,6 +7,11 @@ os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "bench.json"))
 ks = max(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime)
 shutil.copy(ks, os.path.join(dst, "kernel_stats.csv"))
+cfgs = glob.glob(os.path.join(src, "stats_configs", "*", "*kernel_stats.csv"))
+if cfgs:     # tools/bench_configs.py --configs c3,c4,c5 (one process, all three configs)
+    shutil.copy(max(cfgs, key=os.path.getmtime), os.path.join(dst, "kernel_stats_configs_c3_c4_c5.csv"))
+    if os.path.exists(os.path.join(src, "configs.jsonl")):
+        shutil.copy(os.path.join(src, "configs.jsonl"), os.path.join(dst, "configs_c3_c4_c5.jsonl"))
 ild = glob.glob(os.path.join(src, "stats_ildu", "*", "*kernel_stats.csv"))
 if ild:      # ILDU(0)-PCG on the 1000^2 grid (tools/ildu_bench.py 1000 ildu0)
     shutil.copy(max(ild, key=os.path.getmtime), os.path.join(dst, "kernel_stats_ildu_pcg_1000x1000.csv"))

@@ -10,3 +10,6 @@ timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- 
 # ILDU(0)-PCG on the 1000^2 grid: per-kernel times of the level walkers
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ildu -- python tools/ildu_bench.py 1000 ildu0 > $OUT/stats_ildu.log 2>&1
 cat $OUT/bench.json
+# secondary configs of BASELINE.json (C3 BiCGStab/GMRES, C4 ELLPACK, C5 464^3 on one GPU): per-kernel times
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_configs -- python tools/bench_configs.py --configs c3,c4,c5 > $OUT/configs.log 2>&1
+grep '^{' $OUT/configs.log > $OUT/configs.jsonl
