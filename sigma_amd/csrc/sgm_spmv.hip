@@ -182,7 +182,10 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
     double *__restrict__ part_yy, const int *__restrict__ flag_done, int gen, int remap)
 {
     constexpr int VPT = (TILE + 2 * BLOCK - 1) / (2 * BLOCK);  // 16-byte val loads per lane per tile
-    constexpr int U = 8;
+    // x requests in flight per lane = the row length the tile was chosen for (TILE / BLOCK entries per
+    // row): a longer unroll only costs registers, and the fused-dot variants must stay within 64 VGPRs
+    // to keep 8 waves per SIMD like the plain kernel the persistent grid is sized for
+    constexpr int U = TILE <= 4 * BLOCK ? 4 : TILE <= 6 * BLOCK ? 6 : 8;
     constexpr int CPT = (TILE / 4 + BLOCK - 1) / BLOCK;      // 4-byte code words per lane per tile
     static_assert(TILE % 4 == 0, "tiles are whole 4-byte code words");
     __shared__ double vl[TILE];
@@ -209,11 +212,10 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
         const int32_t r1 = min(r0 + BLOCK, n);
         const int32_t row = r0 + tid;
         int32_t k = 0, ke = 0;
-        double wv = 0.0, y0 = 0.0;          // requested now, consumed after the row sum
+        double y0 = 0.0;                    // requested now, consumed after the row sum
         if (row < n) {
             k = rowptr[row];
             ke = rowptr[row + 1];
-            if (DOT_W) wv = w[row];
             if (ADD) y0 = y[row];
         }
         const int32_t s = rowptr[r0] & ~3;    // tiles start at multiples of 4 entries: aligned 4-B code loads
@@ -286,7 +288,10 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
         if (row < n) {
             const double yi = ADD ? (chain ? z : y0 + z) : 0.0 + z;
             __builtin_nontemporal_store(yi, y + row);
-            if (DOT_W) dwy += wv * yi;
+            // w(row) is read here, not with the row pointers: held across the row sum it costs the two
+            // registers that push the fused variants over 64 VGPRs (7 instead of 8 waves per SIMD, and
+            // a persistent grid sized for 8 then runs a second round); w is x or was just gathered: an L2 hit
+            if (DOT_W) dwy += w[row] * yi;
             if (DOT_YY) dyy += yi * yi;
         }
     }
@@ -516,7 +521,7 @@ static SpmvCfg &spmv_cfg()
     return c;
 }
 
-static int resident_per_cu(bool dict, int block, int v);
+static int resident_per_cu(bool dict, int block, int v, int cw = 4);
 int ell_grid(const Part &p);
 static bool use_offset_dict(const Part &p) { return p.code && g_opt.csr_offset_dict; }
 static bool use_sliced(const Part &p) { return p.scode && g_opt.csr_sliced && g_opt.csr_offset_dict; }
@@ -556,8 +561,8 @@ static int grid_for_rows(const Part &p, int64_t rows, int64_t limit)
     int64_t g = ((nrb + 7) / 8) * 8;
     int64_t cap = c.maxgrid;
     if (cap <= 0 && use_sliced(p)) cap = (int64_t)resident_sl(p.sw) * g_rt.num_cu;
-    if (cap <= 0) cap = (int64_t)resident_per_cu(use_row_owner(p), c.block, use_row_owner(p) ? do_tile_for(p) : c.vpt) *
-                        g_rt.num_cu;
+    if (cap <= 0) cap = (int64_t)resident_per_cu(use_row_owner(p), c.block, use_row_owner(p) ? do_tile_for(p) : c.vpt,
+                                                 use_offset_dict(p) ? 1 : 4) * g_rt.num_cu;
     if (cap > limit) cap = limit;
     if (g > cap) g = cap / 8 * 8;
     if (g < 8) g = 8;
@@ -756,14 +761,19 @@ static void launch_ell(const Part &p, int grid, const double *x, double *y, cons
 
 // Workgroups of one kernel variant that fit on a CU at once (occupancy API, cached).
 // `v` is the TILE for the offset-dict kernel and VPT for the int32 kernel.
-static int resident_per_cu(bool dict, int block, int v)
+// The fused-dot variants of one (BLOCK, TILE, CW) family have the same occupancy as the plain kernel
+// (checked at build time with -Rpass-analysis=kernel-resource-usage: 8 waves/SIMD for tiles <= 1536,
+// 7 for the 1-byte-code kernel with larger tiles), so one grid serves every epilogue.
+static int resident_per_cu(bool dict, int block, int v, int cw)
 {
     static std::vector<std::pair<int, int>> cache;
-    const int key = (dict ? 1 << 30 : 0) | (block << 16) | v;
+    const int key = (dict ? 1 << 30 : 0) | (cw == 1 ? 1 << 29 : 0) | (block << 16) | v;
     for (auto &kv : cache)
         if (kv.first == key) return kv.second;
     const void *fn = nullptr;
-#define PICK_DO(B, T) if (dict && block == B && v == T) fn = (const void *)k_csr_do<B, T, 4, false, false, false>;
+#define PICK_DO(B, T)                                                                                   \
+    if (dict && block == B && v == T)                                                                   \
+        fn = cw == 1 ? (const void *)k_csr_do<B, T, 1, false, true, false> : (const void *)k_csr_do<B, T, 4, false, true, false>;
 #define PICK_ST(B, V) if (!dict && block == B && v == V) fn = (const void *)k_csr_spmv<B, V, true, false, false, false>;
     SGM_DO_VARIANTS(PICK_DO)
     PICK_ST(256, 2) PICK_ST(256, 4) PICK_ST(256, 8) PICK_ST(512, 2) PICK_ST(512, 4) PICK_ST(512, 8) PICK_ST(1024, 2) PICK_ST(1024, 4)
