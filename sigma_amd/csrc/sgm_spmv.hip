@@ -717,7 +717,11 @@ static EllCfg &ell_cfg()
 int ell_grid(const Part &p)
 {
     int64_t g = ((int64_t)p.n + kBlock - 1) / kBlock;
-    return (int)std::max<int64_t>(1, std::min<int64_t>(g, ell_cfg().grid));
+    int64_t cap = ell_cfg().grid;
+    // k_ell_do<16> holds 16 values + 16 x entries per lane: 77-88 VGPRs, 5 waves/SIMD with the fused
+    // dots -- a grid-stride launch sized for 8 resident workgroups per CU would run a second round
+    if (p.ecode && g_opt.ell_offset_dict && p.emdp == 16) cap = std::min<int64_t>(cap, (int64_t)5 * g_rt.num_cu);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
 }
 
 template <bool ADD>

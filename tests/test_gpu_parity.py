@@ -409,6 +409,51 @@ def _sliced_checks(orc, A, n, m, ptr, node, val):
     assert np.array_equal(y1, y)
 
 
+def test_ell_wide_dictionary_kernel_nine_point_stencil(orc):
+    """ELLPACK with 9..16 slots per row takes k_ell_do<16> (16 values + 16 x entries per lane, its
+    own grid size): 9-point stencil on a 301 x 257 grid, boundary rows padded, with the fused
+    dots of a CG solve; bit-exact against the oracle, same bits from the plain slot-major kernel."""
+    nx, ny = 301, 257
+    n = nx * ny
+    k = np.arange(n)
+    i, j = k % nx, k // nx
+    ei, ej, ev = [], [], []
+    for dj in (-1, 0, 1):
+        for di in (-1, 0, 1):
+            ok = (i + di >= 0) & (i + di < nx) & (j + dj >= 0) & (j + dj < ny)
+            ei.append(k[ok] + 1)
+            ej.append(k[ok] + di + dj * nx + 1)
+            ev.append(np.full(int(ok.sum()), 8.0 if (di == 0 and dj == 0) else -1.0 / (1 + abs(di) + abs(dj))))
+    order = np.argsort(np.concatenate(ei), kind="stable")          # row-major, insertion order kept inside a row
+    ei, ej, ev = (np.concatenate(a)[order] for a in (ei, ej, ev))
+    A = orc.EllMatrix.from_edges(n, n, ei.astype(np.int32), ej.astype(np.int32), ev)
+    assert A.max_d == 9
+    x = P.test_vector(n)
+    outs = []
+    for opt in (1, 0):
+        sg.set_option("ell_offset_dict", opt)
+        try:
+            H = sg.ellpack_matrix(n, n, A.node, A.val)
+            assert ("k_ell_do<MDP=16>" in H.kernel) == bool(opt), H.kernel
+            y = np.zeros(n)
+            H.matvec(x, y)
+            y2 = y.copy()
+            H.matvec_add(x, y2)
+            b = np.full(n, 1.0 / n)
+            s = sg.cg(1e-12)
+            s.setup(H)
+            u = np.zeros(n)
+            s.solve(H, u, b)
+            outs.append((y, y2, u, s.iterations))
+        finally:
+            sg.set_option("ell_offset_dict", 1)
+    assert np.array_equal(outs[0][0], A.matvec(x)) and np.array_equal(outs[1][0], outs[0][0])
+    assert np.array_equal(outs[0][1], A.matvec_add(x, A.matvec(x))) and np.array_equal(outs[1][1], outs[0][1])
+    ur, itr, _, _ = orc.cg(A, np.full(n, 1.0 / n), tol=1e-12)
+    for _, _, u, its in outs:
+        assert abs(its - itr) <= 1 and np.abs(u - ur).max() / np.abs(ur).max() <= 1e-11
+
+
 @pytest.mark.parametrize("name", [n for n in golden_names() if "_ell_" in n])
 def test_ell_offset_dict_and_plain_kernels_agree(golden, name):
     """ELLPACK matrices with max_d <= 16 and few distinct offsets take the 1-byte code kernel;
