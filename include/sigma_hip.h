@@ -145,8 +145,9 @@ int sgm_mat_info(sgm_mat A, int32_t *nrow, int32_t *ncol, int64_t *nnz, int32_t 
  *                              (num_colors+1 entries, may be NULL) = first index per colour;
  *                              fails where the reference would index out of bounds (a vertex
  *                              not reachable from vertex 1)
- * Outputs are HOST arrays of nrow int32 (1-based values, like the reference's).  These are
- * sequential, order-dependent algorithms: they run on the host over a copy of the index arrays.
+ * Outputs are HOST arrays of nrow int32 (1-based values, like the reference's).  The
+ * breadth-first numbering runs on the device (level-synchronous, same FIFO order); the colouring
+ * is order- and tally-dependent and runs on the host over a copy of the index arrays.
  * sgm_mat_left_permute(A, p)   A%left_permute(p)   cs_matrices.f90:471-478: row i -> row p(i)
  * sgm_mat_right_permute(A, p)  A%right_permute(p)  cs_matrices.f90:483-490: column j -> p(j)
  *                              device kernels; entries keep their stored order inside a row, so

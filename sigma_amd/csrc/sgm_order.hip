@@ -3,10 +3,11 @@
 //   cs_matrix%left_permute / %right_permute   src/matrix/formats/cs_matrices.f90:471-490
 //       -> graph_leftperm / graph_rightperm   default_sparse_matrix_kernels.f90:234-277
 //       -> cs_graph_left_permute / _right_permute   src/graph/formats/cs_graphs.f90:499-571
-// The three graph routines are queue-driven sequential algorithms whose result depends on the
-// visiting order (the colouring also on running per-colour tallies), so they run on the host
-// over a downloaded copy of the index arrays -- index work at setup, bit-exact, like the ILDU
-// factorisation.  The permutation of the matrix itself is device work: row lengths scattered to
+// The breadth-first numbering runs on the device (level-synchronous; the FIFO order of the
+// reference is reproduced exactly, see k_bfs_*).  The greedy colouring is order-dependent AND
+// depends on running per-colour tallies (every decision reads the global state left by the previous
+// one), so it runs on the host over a downloaded copy of the index arrays -- index work at setup,
+// bit-exact, like the ILDU factorisation.  The permutation of the matrix itself is device work: row lengths scattered to
 // their new places, a prefix sum (hipCUB), row segments copied in stored order (so a permuted
 // row sums the same terms in the same order as before), columns renumbered in place; the device
 // formats (offset dictionary ...) are then rebuilt.  What this buys on the hot path: ILDU(0)
@@ -72,6 +73,53 @@ int32_t greedy_coloring_host(int32_t n, const std::vector<int32_t> &ptr, const s
     return used;
 }
 
+// ---- breadth-first numbering, level-synchronous, in the reference's FIFO order ---------------
+// The queue order of breadth_first_search (permutations.f90:44-72) is: level by level; inside a
+// level, by (queue position of the parent that enqueued the vertex, slot of the vertex in the
+// parent's neighbour list), i.e. the FIRST candidate slot that names an unvisited vertex when the
+// frontier's neighbour lists are laid end to end.  That is a parallel computation: expand the
+// frontier (prefix sum of degrees), atomicMin the slot number per vertex, keep the winners in slot
+// order (stream compaction).
+__global__ void k_bfs_degrees(int32_t m, const int32_t *__restrict__ frontier, const int32_t *__restrict__ rowptr,
+                              int32_t *__restrict__ deg)
+{
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < m) { const int32_t u = frontier[r]; deg[r] = rowptr[u + 1] - rowptr[u]; }
+    if (r == m) deg[r] = 0;                      // so that the exclusive sum's last entry is the total
+}
+// one wave per frontier vertex: its neighbour list goes to cand[off .. off+deg); unvisited ones bid
+__global__ void k_bfs_expand(int32_t m, const int32_t *__restrict__ frontier, const int32_t *__restrict__ rowptr,
+                             const int32_t *__restrict__ col, const int32_t *__restrict__ off,
+                             const int32_t *__restrict__ p, int32_t *__restrict__ cand, int32_t *__restrict__ first)
+{
+    const int32_t r = (int32_t)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= m) return;
+    const int32_t u = frontier[r], s0 = rowptr[u], d = rowptr[u + 1] - s0, o = off[r];
+    for (int32_t k = lane; k < d; k += 64) {
+        const int32_t j = col[s0 + k];
+        cand[o + k] = j;
+        if (p[j] == -1) atomicMin(&first[j], o + k);
+    }
+}
+__global__ void k_bfs_flags(int32_t e, const int32_t *__restrict__ cand, const int32_t *__restrict__ p,
+                            const int32_t *__restrict__ first, uint8_t *__restrict__ flag)
+{
+    const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < e) { const int32_t j = cand[s]; flag[s] = p[j] == -1 && first[j] == s; }
+}
+__global__ void k_bfs_number(int32_t m, const int32_t *__restrict__ frontier, int32_t base, int32_t *__restrict__ p)
+{
+    const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < m) p[frontier[t]] = base + t + 1;
+}
+__global__ void k_fill_i32(int64_t n, int32_t *a, int32_t v)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) a[i] = v;
+}
+
 __global__ void k_perm_lengths(int32_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ p1,
                                int32_t *__restrict__ len2)
 {
@@ -134,23 +182,97 @@ extern "C" {
 int sgm_graph_bfs_order(sgm_mat A, int32_t *p_out)
 {
     SGM_TRY(require_init());
-    std::vector<int32_t> ptr, node;
-    SGM_TRY(host_graph(A, "sgm_graph_bfs_order", ptr, node));
-    if (!p_out) return fail(SGM_ERR_BAD_ARG, "sgm_graph_bfs_order: null output");
-    const int32_t n = A->nrow;
-    std::vector<int32_t> queue((size_t)std::max(n, 1));
-    int32_t head = 0, tail = 0, num = 0;
-    for (int32_t i = 0; i < n; ++i) p_out[i] = -1;
-    if (n > 0) queue[tail++] = 0;
-    while (tail > head) {                                   // permutations.f90:44-72
-        const int32_t i = queue[head++];
-        p_out[i] = ++num;
-        for (int32_t k = ptr[i]; k < ptr[i + 1]; ++k) {
-            const int32_t j = node[k];
-            if (p_out[j] == -1) { queue[tail++] = j; p_out[j] = 0; }
+    if (!A || !p_out) return fail(SGM_ERR_BAD_ARG, "sgm_graph_bfs_order: null argument");
+    if (A->fmt != SGM_FMT_CSR || A->distributed())
+        return fail(SGM_ERR_UNSUPPORTED, "sgm_graph_bfs_order: single-GPU CSR matrices only");
+    if (A->nrow != A->ncol) return fail(SGM_ERR_BAD_ARG, "sgm_graph_bfs_order: the matrix graph must be square");
+    const Part &pt = A->parts[0];
+    const int32_t n = pt.n;
+    if (n == 0) return SGM_OK;
+    hipStream_t st = g_rt.stream;
+    const size_t ne = (size_t)std::max<int64_t>(pt.nnz, 1);
+    int32_t *p = nullptr, *first = nullptr, *fr[2] = {nullptr, nullptr}, *deg = nullptr, *off = nullptr, *cand = nullptr, *cnt = nullptr;
+    uint8_t *flag = nullptr;
+    void *tmp = nullptr;
+    size_t tb1 = 0, tb2 = 0;
+    int rc = dalloc(&p, (size_t)n);
+    if (rc == SGM_OK) rc = dalloc(&first, (size_t)n);
+    if (rc == SGM_OK) rc = dalloc(&fr[0], (size_t)n);
+    if (rc == SGM_OK) rc = dalloc(&fr[1], (size_t)n);
+    if (rc == SGM_OK) rc = dalloc(&deg, (size_t)n + 1);
+    if (rc == SGM_OK) rc = dalloc(&off, (size_t)n + 1);
+    if (rc == SGM_OK) rc = dalloc(&cand, ne);
+    if (rc == SGM_OK) rc = dalloc(&flag, ne);
+    if (rc == SGM_OK) rc = dalloc(&cnt, 1);
+    if (rc == SGM_OK) {
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb1, deg, off, n + 1, st);
+        (void)hipcub::DeviceSelect::Flagged(nullptr, tb2, cand, flag, fr[0], cnt, (int)std::min<size_t>(ne, INT32_MAX), st);
+        if (hipMalloc(&tmp, std::max<size_t>(std::max(tb1, tb2), 16)) != hipSuccess) rc = fail(SGM_ERR_HIP, "sgm_graph_bfs_order: workspace");
+    }
+    if (rc == SGM_OK) {
+        hipLaunchKernelGGL(k_fill_i32, dim3(vec_grid(n)), dim3(kBlock), 0, st, (int64_t)n, p, -1);
+        hipLaunchKernelGGL(k_fill_i32, dim3(vec_grid(n)), dim3(kBlock), 0, st, (int64_t)n, first, INT32_MAX);
+        const int32_t zero = 0;
+        (void)hipMemcpyAsync(fr[0], &zero, 4, hipMemcpyHostToDevice, st);          // the queue starts with vertex 1
+        int32_t m = 1, base = 0, levels = 0;
+        int cur = 0;
+        bool on_host = false;
+        hipLaunchKernelGGL(k_bfs_number, dim3(1), dim3(kBlock), 0, st, m, (const int32_t *)fr[0], base, p);
+        base = 1;
+        while (m > 0 && rc == SGM_OK) {
+            hipLaunchKernelGGL(k_bfs_degrees, dim3((m + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, m,
+                               (const int32_t *)fr[cur], (const int32_t *)pt.rowptr, deg);
+            (void)hipcub::DeviceScan::ExclusiveSum(tmp, tb1, deg, off, m + 1, st);
+            int32_t e = 0;
+            (void)hipMemcpyAsync(&e, off + m, 4, hipMemcpyDeviceToHost, st);
+            if (hipStreamSynchronize(st) != hipSuccess) { rc = fail(SGM_ERR_HIP, "sgm_graph_bfs_order: level failed"); break; }
+            if (e == 0) break;
+            hipLaunchKernelGGL(k_bfs_expand, dim3((unsigned)(((int64_t)m * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, m,
+                               (const int32_t *)fr[cur], (const int32_t *)pt.rowptr, (const int32_t *)pt.col,
+                               (const int32_t *)off, (const int32_t *)p, cand, first);
+            hipLaunchKernelGGL(k_bfs_flags, dim3((e + kBlock - 1) / kBlock), dim3(kBlock), 0, st, e, (const int32_t *)cand,
+                               (const int32_t *)p, (const int32_t *)first, flag);
+            (void)hipcub::DeviceSelect::Flagged(tmp, tb2, cand, flag, fr[cur ^ 1], cnt, e, st);
+            int32_t m2 = 0;
+            (void)hipMemcpyAsync(&m2, cnt, 4, hipMemcpyDeviceToHost, st);
+            if (hipStreamSynchronize(st) != hipSuccess) { rc = fail(SGM_ERR_HIP, "sgm_graph_bfs_order: level failed"); break; }
+            cur ^= 1;
+            m = m2;
+            if (m > 0) {
+                hipLaunchKernelGGL(k_bfs_number, dim3((m + kBlock - 1) / kBlock), dim3(kBlock), 0, st, m,
+                                   (const int32_t *)fr[cur], base, p);
+                base += m;
+            }
+            // A level costs two host round trips (~65 us).  Graphs of large diameter (grids: thousands
+            // of levels of a few thousand vertices) are faster in the sequential queue loop: when the
+            // frontiers stay small, the search continues on the host from the current frontier, which
+            // IS the queue at this point (same order, same numbering).
+            ++levels;
+            if (m > 0 && levels >= 16 && (int64_t)base < (int64_t)levels * 4096) { on_host = true; break; }
+        }
+        if (rc == SGM_OK && (hipMemcpy(p_out, p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess || hipGetLastError() != hipSuccess))
+            rc = fail(SGM_ERR_HIP, "sgm_graph_bfs_order: copy back failed");
+        if (rc == SGM_OK && on_host) {
+            std::vector<int32_t> ptr((size_t)n + 1), node((size_t)pt.nnz), queue((size_t)n);
+            bool ok = hipMemcpy(ptr.data(), pt.rowptr, ptr.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+            if (pt.nnz) ok = ok && hipMemcpy(node.data(), pt.col, node.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+            ok = ok && hipMemcpy(queue.data(), fr[cur], (size_t)m * 4, hipMemcpyDeviceToHost) == hipSuccess;
+            if (!ok) rc = fail(SGM_ERR_HIP, "sgm_graph_bfs_order: hand-over to the host failed");
+            // the frontier's vertices are numbered already; they sit in the queue waiting to be expanded
+            int32_t head = 0, tail = m, num = base;
+            while (rc == SGM_OK && tail > head) {                       // permutations.f90:44-72
+                const int32_t i = queue[head++];
+                if (p_out[i] <= 0) p_out[i] = ++num;
+                for (int32_t k = ptr[i]; k < ptr[i + 1]; ++k) {
+                    const int32_t j = node[k];
+                    if (p_out[j] == -1) { queue[tail++] = j; p_out[j] = 0; }
+                }
+            }
         }
     }
-    return SGM_OK;
+    if (tmp) (void)hipFree(tmp);
+    dfree(p); dfree(first); dfree(fr[0]); dfree(fr[1]); dfree(deg); dfree(off); dfree(cand); dfree(flag); dfree(cnt);
+    return rc;
 }
 
 int sgm_graph_greedy_coloring(sgm_mat A, int32_t *colors_out, int32_t *num_colors)
