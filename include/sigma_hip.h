@@ -150,6 +150,7 @@ int sgm_mat_info(sgm_mat A, int32_t *nrow, int32_t *ncol, int64_t *nnz, int32_t 
  * is order- and tally-dependent and runs on the host over a copy of the index arrays.
  * sgm_mat_left_permute(A, p)   A%left_permute(p)   cs_matrices.f90:471-478: row i -> row p(i)
  * sgm_mat_right_permute(A, p)  A%right_permute(p)  cs_matrices.f90:483-490: column j -> p(j)
+ *                              (ELLPACK handles too: ellpack_matrices.f90:601-632)
  *                              device kernels; entries keep their stored order inside a row, so
  *                              row sums are bit-identical to the reference's permuted matrix.
  *                              Preconditioners set up before a permutation must be set up again. */

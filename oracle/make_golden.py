@@ -164,6 +164,10 @@ def perm_cases():
     n = nx * ny * nz
     case("perm_laplace3d_8x7x6", n, n, CSR, P.laplace3d_edges(nx, ny, nz), P.test_vector(n), np.full(n, 1.0 / n),
          [(CG, LDU, 1e-13)], mode="perm")
+    nx, ny = 32, 24
+    n = nx * ny
+    case("perm_poisson2d_ell_32x24", n, n, ELL, P.poisson2d_edges(nx, ny), P.test_vector(n), np.full(n, 1.0 / n),
+         [(CG, NOPC, 1e-12), (CG, JACOBI, 1e-12)], mode="perm")
     n = 128
     rs = np.random.RandomState(17)
     case("perm_random_spd_128", n, n, CSR, P.random_spd_edges(n, seed=3, skew=False), rs.random_sample(n),

@@ -311,6 +311,32 @@ def permuted(A, p_left=None, p_right=None):
     return CsrMatrix(A.n, A.m, ptr, node, val)
 
 
+def ell_graph_as_csr(E):
+    """The neighbour lists of an ELLPACK graph (the first degrees(i) slots of row i) as a CsrMatrix,
+    for the graph routines above (they only look at ptr/node)."""
+    deg = E.degrees.astype(np.int64)
+    ptr = np.concatenate([[1], 1 + np.cumsum(deg)]).astype(I4)
+    mask = np.arange(E.max_d)[None, :] < deg[:, None]
+    node = np.ascontiguousarray(E.node.reshape(E.n, E.max_d)[mask], I4)
+    return CsrMatrix(E.n, E.m, ptr, node, np.ones(len(node), F8))
+
+
+def ell_permuted(E, p_left=None, p_right=None):
+    """ellpack left/right permute (ellpack_matrices.f90:601-632): returns (node, val, degrees) as (n, max_d) arrays."""
+    node = np.ascontiguousarray(E.node.reshape(E.n, E.max_d), I4).copy()
+    val = np.ascontiguousarray(E.val.reshape(E.n, E.max_d), F8).copy()
+    deg = np.ascontiguousarray(E.degrees, I4).copy()
+    if p_left is not None:
+        p_left = np.ascontiguousarray(p_left, I4)
+        n2, v2, d2 = np.zeros_like(node), np.zeros_like(val), np.zeros_like(deg)
+        lib().orc_ell_left_permute(C.c_int32(E.n), C.c_int32(E.max_d), _p(node), _p(val), _p(deg), _p(p_left), _p(n2), _p(v2), _p(d2))
+        node, val, deg = n2, v2, d2
+    if p_right is not None:
+        p_right = np.ascontiguousarray(p_right, I4)
+        lib().orc_ell_right_permute(C.c_int32(E.n), C.c_int32(E.max_d), _p(node), _p(p_right))
+    return node, val, deg
+
+
 def set_dot_mode(mode):
     """0: left-to-right dot products; 1: four interleaved partial sums (a vectorising
     compiler's dot_product).  Both are valid restatements of the Fortran intrinsic."""

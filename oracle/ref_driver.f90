@@ -195,6 +195,24 @@ implicit none
         y = -7.0_dp
         call A%matvec(x, y)
         call dump_f8('perm_y', y, n)
+    elseif (perm_mode .and. fmt == 2) then
+        ! the same for an ELLPACK matrix (ellpack_graphs.f90:486-541, ellpack_matrices.f90:601-632)
+        allocate(pp(n), cptrs(n + 2))
+        call breadth_first_search(pp, Aell%g)
+        call dump_i4('bfs_p', pp, n)
+        cptrs = 0
+        call greedy_color_ordering(pp, cptrs, ncol, Aell%g)
+        call dump_i4('color_p', pp, n)
+        call dump_i4('color_ptrs', cptrs, ncol + 1)
+        call dump_i4('num_colors', [ncol], 1)
+        call Aell%left_permute(pp)
+        call Aell%right_permute(pp)
+        call dump_i4('perm_degrees', Aell%g%degrees, size(Aell%g%degrees))
+        call dump_i4('perm_node', reshape(Aell%g%node, [size(Aell%g%node)]), size(Aell%g%node))
+        call dump_f8('perm_val', reshape(Aell%val, [size(Aell%val)]), size(Aell%val))
+        y = -7.0_dp
+        call A%matvec(x, y)
+        call dump_f8('perm_y', y, n)
     endif
 
     !------------------------------------------------------------------!

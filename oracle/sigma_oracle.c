@@ -877,3 +877,25 @@ ORC_API void orc_csr_right_permute(int64_t nnz, int32_t *node, const int32_t *p)
 {
     for (int64_t k = 0; k < nnz; k++) node[k] = p[node[k] - 1];
 }
+
+/* ellpack_matrix%left_permute (ellpack_matrices.f90:601-619 + ellpack_graph_left_permute
+ * ellpack_graphs.f90:486-518): column i of node/val(max_d, n) moves to column p(i), degrees too. */
+ORC_API void orc_ell_left_permute(int32_t n, int32_t max_d, const int32_t *node, const double *val,
+                                  const int32_t *degrees, const int32_t *p, int32_t *node2,
+                                  double *val2, int32_t *degrees2)
+{
+    for (int32_t i = 0; i < n; i++) {
+        for (int32_t k = 0; k < max_d; k++) {
+            node2[(size_t)(p[i] - 1) * max_d + k] = node[(size_t)i * max_d + k];
+            val2[(size_t)(p[i] - 1) * max_d + k] = val[(size_t)i * max_d + k];
+        }
+        degrees2[p[i] - 1] = degrees[i];
+    }
+}
+
+/* ellpack_graph_right_permute (ellpack_graphs.f90:523-541): every nonzero neighbour j -> p(j). */
+ORC_API void orc_ell_right_permute(int32_t n, int32_t max_d, int32_t *node, const int32_t *p)
+{
+    for (size_t k = 0; k < (size_t)n * max_d; k++)
+        if (node[k] != 0) node[k] = p[node[k] - 1];
+}

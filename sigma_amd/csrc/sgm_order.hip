@@ -21,6 +21,7 @@
 
 namespace sgm {
 int rebuild_csr_formats(Part &p);          // sgm_spmv.hip
+int rebuild_ell_formats(Part &p);          // sgm_spmv.hip
 int sgm_invalidate_transpose(sgm_mat A);   // sgm_spmv.hip
 }
 using namespace sgm;
@@ -145,6 +146,27 @@ __global__ void k_perm_cols(int64_t nnz, int32_t *__restrict__ col, const int32_
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; k < nnz; k += stride) col[k] = p1[col[k]] - 1;
+}
+// ELLPACK, slot-major device layout (slot k of row i at k*n + i): row i -> row p(i) in every slot
+__global__ void k_ell_perm_rows(int32_t n, int32_t max_d, const int32_t *__restrict__ p1, const int32_t *__restrict__ ecol,
+                                const double *__restrict__ eval, const int32_t *__restrict__ edeg,
+                                int32_t *__restrict__ ecol2, double *__restrict__ eval2, int32_t *__restrict__ edeg2)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t d = p1[i] - 1;
+    for (int32_t k = 0; k < max_d; ++k) {
+        ecol2[(int64_t)k * n + d] = ecol[(int64_t)k * n + i];
+        eval2[(int64_t)k * n + d] = eval[(int64_t)k * n + i];
+    }
+    if (edeg) edeg2[d] = edeg[i];
+}
+// ellpack_graph_right_permute: every real neighbour j -> p(j) (a 0 in the reference = -1 here stays)
+__global__ void k_ell_perm_cols(int64_t total, int32_t *__restrict__ ecol, const int32_t *__restrict__ p1)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; k < total; k += stride) { const int32_t c = ecol[k]; if (c >= 0) ecol[k] = p1[c] - 1; }
 }
 __global__ void k_check_perm(int32_t n, const int32_t *__restrict__ p1, int32_t *__restrict__ seen, int *bad)
 {
@@ -316,13 +338,34 @@ int sgm_mat_left_permute(sgm_mat A, const int32_t *p, int where)
 {
     SGM_TRY(require_init());
     if (!A || !p) return fail(SGM_ERR_BAD_ARG, "sgm_mat_left_permute: null argument");
-    if (A->fmt != SGM_FMT_CSR || A->distributed())
-        return fail(SGM_ERR_UNSUPPORTED, "sgm_mat_left_permute: single-GPU CSR matrices only");
+    if ((A->fmt != SGM_FMT_CSR && A->fmt != SGM_FMT_ELL) || A->distributed())
+        return fail(SGM_ERR_UNSUPPORTED, "sgm_mat_left_permute: single-GPU CSR / ELLPACK matrices only");
     Part &pt = A->parts[0];
     const int32_t n = pt.n;
     hipStream_t st = g_rt.stream;
     int32_t *dp = nullptr;
     SGM_TRY(stage_perm("sgm_mat_left_permute", n, p, where, &dp));
+    if (A->fmt == SGM_FMT_ELL) {         // ellpack_matrices.f90:601-619
+        const size_t total = (size_t)n * pt.max_d;
+        int32_t *ecol2 = nullptr, *edeg2 = nullptr;
+        double *eval2 = nullptr;
+        int rc = dalloc(&ecol2, std::max<size_t>(total, 1));
+        if (rc == SGM_OK) rc = dalloc(&eval2, std::max<size_t>(total, 1));
+        if (rc == SGM_OK && pt.edeg) rc = dalloc(&edeg2, (size_t)std::max(n, 1));
+        if (rc == SGM_OK && n) {
+            hipLaunchKernelGGL(k_ell_perm_rows, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, pt.max_d,
+                               (const int32_t *)dp, (const int32_t *)pt.ecol, (const double *)pt.eval,
+                               (const int32_t *)pt.edeg, ecol2, eval2, edeg2);
+            if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess)
+                rc = fail(SGM_ERR_HIP, "sgm_mat_left_permute: kernel failed");
+        }
+        dfree(dp);
+        if (rc != SGM_OK) { dfree(ecol2); dfree(eval2); dfree(edeg2); return rc; }
+        dfree(pt.ecol); dfree(pt.eval); dfree(pt.edeg);
+        pt.ecol = ecol2; pt.eval = eval2; pt.edeg = edeg2;
+        SGM_TRY(sgm_invalidate_transpose(A));
+        return rebuild_ell_formats(pt);
+    }
     int32_t *len2 = nullptr, *rowptr2 = nullptr, *col2 = nullptr;
     double *val2 = nullptr;
     void *tmp = nullptr;
@@ -361,11 +404,20 @@ int sgm_mat_right_permute(sgm_mat A, const int32_t *p, int where)
 {
     SGM_TRY(require_init());
     if (!A || !p) return fail(SGM_ERR_BAD_ARG, "sgm_mat_right_permute: null argument");
-    if (A->fmt != SGM_FMT_CSR || A->distributed())
-        return fail(SGM_ERR_UNSUPPORTED, "sgm_mat_right_permute: single-GPU CSR matrices only");
+    if ((A->fmt != SGM_FMT_CSR && A->fmt != SGM_FMT_ELL) || A->distributed())
+        return fail(SGM_ERR_UNSUPPORTED, "sgm_mat_right_permute: single-GPU CSR / ELLPACK matrices only");
     Part &pt = A->parts[0];
     int32_t *dp = nullptr;
     SGM_TRY(stage_perm("sgm_mat_right_permute", A->ncol, p, where, &dp));
+    if (A->fmt == SGM_FMT_ELL) {         // ellpack_graphs.f90:523-541
+        const int64_t total = (int64_t)pt.n * pt.max_d;
+        if (total) hipLaunchKernelGGL(k_ell_perm_cols, dim3(vec_grid(total)), dim3(kBlock), 0, g_rt.stream, total, pt.ecol, (const int32_t *)dp);
+        const bool ok = hipStreamSynchronize(g_rt.stream) == hipSuccess && hipGetLastError() == hipSuccess;
+        dfree(dp);
+        if (!ok) return fail(SGM_ERR_HIP, "sgm_mat_right_permute: kernel failed");
+        SGM_TRY(sgm_invalidate_transpose(A));
+        return rebuild_ell_formats(pt);
+    }
     if (pt.nnz) hipLaunchKernelGGL(k_perm_cols, dim3(vec_grid(pt.nnz)), dim3(kBlock), 0, g_rt.stream, pt.nnz, pt.col, (const int32_t *)dp);
     const bool ok = hipStreamSynchronize(g_rt.stream) == hipSuccess && hipGetLastError() == hipSuccess;
     dfree(dp);

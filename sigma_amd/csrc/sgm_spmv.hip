@@ -1105,6 +1105,12 @@ int rebuild_csr_formats(Part &p)
     p.ndict = 0; p.sw = 0; p.max_row = 0;
     return build_offset_dict(p, nullptr, nullptr);
 }
+int rebuild_ell_formats(Part &p)
+{
+    dfree(p.ecode); dfree(p.dict);
+    p.ecode = nullptr; p.dict = nullptr; p.emdp = 0;
+    return build_ell_offset_dict(p);
+}
 int sgm_invalidate_transpose(sgm_mat A)
 {
     if (A->T) { sgm_mat_destroy(A->T); A->T = nullptr; }

@@ -28,6 +28,8 @@ def golden_names():
     return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and not f.startswith("perm_"))
 
 
-def perm_golden_names():
-    """Fixtures of the re-ordering path: permutations.f90 + symmetric permutation, solves on the permuted matrix."""
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f.startswith("perm_"))
+def perm_golden_names(ell=False):
+    """Fixtures of the re-ordering path: permutations.f90 + symmetric permutation, solves on the
+    permuted matrix (CSR ones by default, the ELLPACK ones with ell=True)."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN)
+                  if f.endswith(".npz") and f.startswith("perm_") and (("_ell_" in f) == ell))

@@ -191,3 +191,21 @@ def test_solves_on_the_permuted_matrix(golden, name):
         ref_u, ref_its = g[f"ref_s{k}_u"], int(g[f"ref_s{k}_iterations"][0])
         assert abs(its - ref_its) <= 1, (k, its, ref_its)
         assert np.abs(u - ref_u).max() / np.abs(ref_u).max() <= 1e-12, k
+
+
+@pytest.mark.parametrize("name", perm_golden_names(ell=True))
+def test_ellpack_reorderings_and_permutation_bit_exact(golden, name):
+    """The same on an ELLPACK matrix: BFS / colour ordering over the first degrees(i) slots, then
+    ellpack left/right permute (ellpack_matrices.f90:601-632), against the reference's output."""
+    g = golden(name)
+    E = build(g)
+    G = orc.ell_graph_as_csr(E)
+    assert np.array_equal(orc.bfs_order(G), g["ref_bfs_p"])
+    p, ptrs, nc = orc.greedy_color_ordering(G)
+    assert nc == int(g["ref_num_colors"][0]) and np.array_equal(p, g["ref_color_p"]) and np.array_equal(ptrs, g["ref_color_ptrs"])
+    node, val, deg = orc.ell_permuted(E, p, p)
+    assert np.array_equal(node.ravel(), g["ref_perm_node"])
+    assert np.array_equal(val.ravel(), g["ref_perm_val"])
+    assert np.array_equal(deg, g["ref_perm_degrees"])
+    B = orc.EllMatrix(E.n, E.m, E.max_d, node, val, deg)
+    assert np.array_equal(B.matvec(g["x"]), g["ref_perm_y"])
