@@ -169,24 +169,30 @@ def main():
         return float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e-3
 
     k_avg = time_kernel(A)
+    main_kernel = A.kernel
     achieved = bytes_rank / k_avg / 1e9
-    # the same matrix through the general int32-column kernel (what a matrix without a small
-    # offset dictionary gets), for comparison; not part of `value`
-    variants = {"offset_dict_u8_codes (default for stencil-like matrices)":
-                {"kernel": "k_csr_do", "avg_launch_ms": 1e3 * k_avg, "GB/s_algorithmic": achieved,
-                 "stored_bytes_per_nnz": 9}}
+    # the same matrix through the other CSR kernels (what matrices that do not qualify for the
+    # default form get), for comparison; not part of `value`
+    variants = {"sliced 4-bit codes, 2 rows per lane (default for rows <= 8 entries / <= 15 offsets)":
+                {"kernel": main_kernel, "avg_launch_ms": 1e3 * k_avg, "GB/s_algorithmic": achieved,
+                 "frac_of_hbm_peak": achieved / HBM_PEAK_GBS}}
     if not use_dist:
-        for label, kern, ro in (("int32_columns, row-owner gather (general kernel, rows <= 32 entries)", "k_csr_do<CW=4>", 1),
-                                ("int32_columns, streaming gather (general kernel, any row length)", "k_csr_spmv", 0)):
-            sg.set_option("csr_offset_dict", 0)
-            sg.set_option("csr_row_owner", ro)
+        for label, opts in (("offset_dict_u8_codes, LDS-staged row-owner kernel (stencil-like matrices with longer rows / more offsets)",
+                             {"csr_sliced": 0}),
+                            ("int32_columns, row-owner gather (general kernel, rows <= 32 entries)",
+                             {"csr_offset_dict": 0, "csr_row_owner": 1}),
+                            ("int32_columns, streaming gather (general kernel, any row length)",
+                             {"csr_offset_dict": 0, "csr_row_owner": 0})):
+            for k, v in opts.items():
+                sg.set_option(k, v)
             for _ in range(5):
                 A.matvec(x, y)
-            k32 = time_kernel(A)
-            variants[label] = {"kernel": kern, "avg_launch_ms": 1e3 * k32, "GB/s_algorithmic": bytes_rank / k32 / 1e9,
-                               "frac_of_hbm_peak": bytes_rank / k32 / 1e9 / HBM_PEAK_GBS, "stored_bytes_per_nnz": 12}
-        sg.set_option("csr_offset_dict", 1)
-        sg.set_option("csr_row_owner", 1)
+            kv = time_kernel(A)
+            variants[label] = {"kernel": A.kernel, "avg_launch_ms": 1e3 * kv, "GB/s_algorithmic": bytes_rank / kv / 1e9,
+                               "frac_of_hbm_peak": bytes_rank / kv / 1e9 / HBM_PEAK_GBS}
+            sg.set_option("csr_offset_dict", 1)
+            sg.set_option("csr_row_owner", 1)
+            sg.set_option("csr_sliced", 1)
 
     # ---- CG iterations/s (device-resident loop, fixed iteration count) -------------------
     cg = None
@@ -244,7 +250,9 @@ def main():
     tf = os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")
     if os.path.exists(tf) and world == 1 and (nx, ny) == (3162, 3162) and args.workload == "c2":
         tj = json.load(open(tf))
-        traffic, traffic_src = tj.get("hbm_traffic_bytes"), "profiles/r01/pmc_hbm_traffic.json"
+        # only if the committed counters belong to the kernel that ran here
+        if main_kernel.split("<")[0] in tj.get("dominant_kernel", ""):
+            traffic, traffic_src = tj.get("hbm_traffic_bytes"), "profiles/r01/pmc_hbm_traffic.json"
 
     if rank == 0:
         out = {
@@ -257,11 +265,11 @@ def main():
                        "parallelism": f"row-partition x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_csr_do<256,1536,CW=1>", "algorithmic_bytes_per_launch": bytes_rank,
+                         "kernel": main_kernel, "algorithmic_bytes_per_launch": bytes_rank,
                          "avg_launch_ms": 1e3 * k_avg, "traffic_source": traffic_src,
                          "note": "achieved = algorithmic bytes (12 nnz + 4(n+1) + 16 n, the reference's int32/fp64 "
-                                 "arrays) / measured launch time; the kernel streams 1-byte column codes, so the "
-                                 "HBM bytes it really moves (`traffic`) are below the algorithmic count"},
+                                 "arrays) / measured launch time; the kernel streams 4-bit column codes and no row pointers, "
+                                 "so the HBM bytes it really moves (`traffic`) are below the algorithmic count"},
             "spmv_variants": variants, "cg": cg, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

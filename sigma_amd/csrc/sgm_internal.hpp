@@ -36,7 +36,7 @@ struct Options {
     int csr_offset_dict = 1;       // use the 1-byte column code kernel when a matrix allows it
     int ell_offset_dict = 1;       // ELLPACK twin of csr_offset_dict (max_d <= 16)
     int csr_row_owner = 1;         // int32 columns, rows <= 32 entries: gather by the row's owner lane
-    int csr_sliced = 0;            // rows <= 8 entries, <= 15 offsets: slot-major slices + 4-bit codes (k_csr_sl); opt-in
+    int csr_sliced = 1;            // rows <= 8 entries, <= 15 offsets: slot-major slices + 4-bit codes (k_csr_sl)
 };
 extern Options g_opt;
 

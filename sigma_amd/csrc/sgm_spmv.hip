@@ -306,16 +306,19 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
 }
 
 // Sliced form of the offset-dict kernel, for matrices whose rows hold <= 8 entries drawn from
-// <= 15 distinct (column - row) offsets (1-D/2-D/3-D stencils, also after the [owned | halo]
-// renumbering of a slab).  At upload the values are re-laid in slices of 256 rows, slot-major
-// inside a slice, and the row's column offsets become eight 4-bit dictionary codes in ONE
-// 32-bit word (code 15 = no entry; a row's entries fill slots 0.. in stored order).  Lane i
-// then reads everything row i needs with independent, fully coalesced loads -- W values
-// (512 contiguous bytes per wave and slot), one code word, W x entries -- no LDS staging, no
-// barrier, no row pointers: every load of a row block is in flight at once, which is what
-// the streaming (cache-cold) regime wants.  HBM bytes per row: 8 W + 4 (+ x, y) instead of
-// 9 nnz_row + 4.  The products are rounded one by one and added in stored order, exactly like
-// the other kernels (bit-identical results).
+// <= 15 distinct (column - row) offsets (1-D/2-D/3-D stencils).  At upload the values are re-laid
+// in slices of 512 rows, slot-major inside a slice, and a row's column offsets become eight 4-bit
+// dictionary codes in ONE 32-bit word (code 15 = no entry; a row's entries fill slots 0.. in
+// stored order).  A lane owns the two adjacent rows 2t, 2t+1 of a slice and reads everything
+// they need with independent, fully coalesced 16-byte loads (W value pairs, one pair of code
+// words) plus 2 W gathers of x -- no LDS staging, no barrier, no row pointers; y leaves as one
+// 16-byte store.  HBM bytes per row: 8 W + 4 (+ x, y) instead of 9 nnz_row + 4.  Row blocks go
+// round-robin over the workgroups (it * grid + block), grid = min(slices, 4096): measured against
+// the LDS-staged kernel (tools/sl_ablate.cpp and bench): the 16-byte accesses and the plain map are
+// worth 10-17 % each way of the comparison.  Products are rounded one by one and added in stored
+// order per row, exactly like the other kernels (bit-identical results).
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+constexpr int kSlRows = 512;       // rows per slice = 2 x workgroup size
 template <int W, bool ADD, bool DOT_W, bool DOT_YY>
 __global__ __launch_bounds__(256) void k_csr_sl(
     int32_t n, const uint32_t *__restrict__ scode, const int32_t *__restrict__ dict,
@@ -329,42 +332,50 @@ __global__ __launch_bounds__(256) void k_csr_sl(
     if (flag_done) { const int st = *flag_done; if (st && gen >= st) return; }
     const int tid = threadIdx.x;
     const bool chain = (remap & 256) != 0;
-    const int rmode = remap & 255;
     if (tid < 16) dl[tid] = dict[tid];
     __syncthreads();
-    const int64_t nrb = ((int64_t)n + BLOCK - 1) / BLOCK;
+    const int64_t nsl = ((int64_t)n + kSlRows - 1) / kSlRows;
     double dwy = 0.0, dyy = 0.0;
 
-    for (int it = 0;; ++it) {
-        if ((int64_t)it * gridDim.x >= nrb) break;
-        const int64_t rb = rmode ? rowblock_of(it, blockIdx.x, gridDim.x, nrb, rmode) : (int64_t)it * gridDim.x + blockIdx.x;
-        if (rb >= nrb) continue;
-        const int32_t row = (int32_t)(rb * BLOCK) + tid;
-        uint32_t cw = 0xffffffffu;
-        double wv = 0.0, y0 = 0.0;
-        if (row < n) {
-            cw = __builtin_nontemporal_load(scode + row);
-            if (DOT_W) wv = w[row];
-            if (ADD) y0 = y[row];
-        }
-        const double *vb = sval + rb * (int64_t)(W * BLOCK) + tid;     // slices are whole: no bounds
-        double v[W], xv[W];
+    for (int64_t sl = blockIdx.x; sl < nsl; sl += gridDim.x) {
+        const int32_t row = (int32_t)(sl * kSlRows) + 2 * tid;          // even: 16-byte aligned pairs
+        // (the code array is padded to whole slices with "no entry" words: rows >= n do nothing)
+        const u32x2 cw = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(scode + row));
+        const f64x2 *vb = reinterpret_cast<const f64x2 *>(sval + sl * (int64_t)(W * kSlRows)) + tid;
+        f64x2 v[W];
 #pragma unroll
         for (int u = 0; u < W; ++u) v[u] = __builtin_nontemporal_load(vb + u * BLOCK);
+        f64x2 y0 = {0.0, 0.0};
+        if (ADD) {
+            if (row + 1 < n) y0 = *reinterpret_cast<const f64x2 *>(y + row);
+            else if (row < n) y0.x = y[row];
+        }
+        double xa[W], xb[W];
 #pragma unroll
         for (int u = 0; u < W; ++u) {
-            const uint32_t c = (cw >> (4 * u)) & 15u;
-            xv[u] = c != 15u ? x[row + dl[c]] : 0.0;
+            const uint32_t ca = (cw.x >> (4 * u)) & 15u, cb = (cw.y >> (4 * u)) & 15u;
+            xa[u] = ca != 15u ? x[row + dl[ca]] : 0.0;
+            xb[u] = cb != 15u ? x[row + 1 + dl[cb]] : 0.0;
         }
-        double z = (ADD && chain) ? y0 : 0.0;
+        f64x2 z;
+        z.x = (ADD && chain) ? y0.x : 0.0;
+        z.y = (ADD && chain) ? y0.y : 0.0;
 #pragma unroll
-        for (int u = 0; u < W; ++u)
-            if (((cw >> (4 * u)) & 15u) != 15u) z = z + v[u] * xv[u];
-        if (row < n) {
-            const double yi = ADD ? (chain ? z : y0 + z) : 0.0 + z;
-            __builtin_nontemporal_store(yi, y + row);
-            if (DOT_W) dwy += wv * yi;
-            if (DOT_YY) dyy += yi * yi;
+        for (int u = 0; u < W; ++u) {
+            if (((cw.x >> (4 * u)) & 15u) != 15u) z.x = z.x + v[u].x * xa[u];
+            if (((cw.y >> (4 * u)) & 15u) != 15u) z.y = z.y + v[u].y * xb[u];
+        }
+        f64x2 yi;
+        yi.x = ADD ? (chain ? z.x : y0.x + z.x) : 0.0 + z.x;
+        yi.y = ADD ? (chain ? z.y : y0.y + z.y) : 0.0 + z.y;
+        if (row + 1 < n) {
+            __builtin_nontemporal_store(yi, reinterpret_cast<f64x2 *>(y + row));
+            if (DOT_W) { const f64x2 wv = *reinterpret_cast<const f64x2 *>(w + row); dwy += wv.x * yi.x; dwy += wv.y * yi.y; }
+            if (DOT_YY) { dyy += yi.x * yi.x; dyy += yi.y * yi.y; }
+        } else if (row < n) {
+            __builtin_nontemporal_store(yi.x, y + row);
+            if (DOT_W) dwy += w[row] * yi.x;
+            if (DOT_YY) dyy += yi.x * yi.x;
         }
     }
     if (DOT_W) {
@@ -381,14 +392,15 @@ __global__ __launch_bounds__(256) void k_csr_sl(
 __global__ __launch_bounds__(256) void k_sl_pack(int32_t n, int32_t W, const int32_t *__restrict__ rowptr,
                                                  const double *__restrict__ val, double *__restrict__ sval)
 {
-    const int64_t nrb = ((int64_t)n + 255) / 256;
-    for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
-        const int64_t row = rb * 256 + threadIdx.x;
-        int32_t k = 0, ke = 0;
-        if (row < n) { k = rowptr[row]; ke = rowptr[row + 1]; }
-        double *dst = sval + rb * (int64_t)W * 256 + threadIdx.x;
-        for (int u = 0; u < W; ++u) dst[(int64_t)u * 256] = k + u < ke ? val[k + u] : 0.0;
-    }
+    const int64_t nsl = ((int64_t)n + kSlRows - 1) / kSlRows;
+    for (int64_t sl = blockIdx.x; sl < nsl; sl += gridDim.x)
+        for (int r = threadIdx.x; r < kSlRows; r += blockDim.x) {
+            const int64_t row = sl * kSlRows + r;
+            int32_t k = 0, ke = 0;
+            if (row < n) { k = rowptr[row]; ke = rowptr[row + 1]; }
+            double *dst = sval + sl * (int64_t)W * kSlRows + r;
+            for (int u = 0; u < W; ++u) dst[(int64_t)u * kSlRows] = k + u < ke ? val[k + u] : 0.0;
+        }
 }
 
 // ELLPACK, slot-major device layout: lane i owns row i and walks ALL max_d slots in
@@ -525,7 +537,6 @@ static int resident_per_cu(bool dict, int block, int v, int cw = 4);
 int ell_grid(const Part &p);
 static bool use_offset_dict(const Part &p) { return p.code && g_opt.csr_offset_dict; }
 static bool use_sliced(const Part &p) { return p.scode && g_opt.csr_sliced && g_opt.csr_offset_dict; }
-static int resident_sl(int W);
 // k_csr_do serves both the dictionary form and, for short rows, plain int32 columns
 static bool use_row_owner(const Part &p)
 {
@@ -556,11 +567,11 @@ static int do_tile_for(const Part &p)
 static int grid_for_rows(const Part &p, int64_t rows, int64_t limit)
 {
     const SpmvCfg &c = spmv_cfg();
-    const int blk = use_sliced(p) ? 256 : c.block;
+    const int blk = use_sliced(p) ? kSlRows : c.block;
     const int64_t nrb = (rows + blk - 1) / blk;
     int64_t g = ((nrb + 7) / 8) * 8;
     int64_t cap = c.maxgrid;
-    if (cap <= 0 && use_sliced(p)) cap = (int64_t)resident_sl(p.sw) * g_rt.num_cu;
+    if (cap <= 0 && use_sliced(p)) cap = kMaxGrid;          // round-robin slices, not a persistent resident grid
     if (cap <= 0) cap = (int64_t)resident_per_cu(use_row_owner(p), c.block, use_row_owner(p) ? do_tile_for(p) : c.vpt,
                                                  use_offset_dict(p) ? 1 : 4) * g_rt.num_cu;
     if (cap > limit) cap = limit;
@@ -583,6 +594,10 @@ static int spmv_ranges(const Part &p, RowRange out[3])
         ++nr;
     };
     if (p.n_halo == 0 || p.int_hi <= p.int_lo) {
+        if (use_sliced(p)) {           // one range, all kMaxGrid partial slots are its own
+            out[0] = RowRange{0, p.n, grid_for_rows(p, p.n > 0 ? p.n : 1, kMaxGrid), 0};
+            return 1;
+        }
         add(0, p.n > 0 ? p.n : 1);
         if (nr) out[0].hi = p.n;
         return nr;
@@ -687,20 +702,6 @@ static void launch_csr_sl(const Part &p, int grid, const double *x, double *y, c
 #undef L
 }
 
-static int resident_sl(int W)
-{
-    static int cache[9] = {0};
-    if (W < 0 || W > 8) return 8;
-    if (cache[W]) return cache[W];
-    const void *fn = nullptr;
-#define PICK(WW) if (W == WW) fn = (const void *)k_csr_sl<WW, false, false, false>;
-    SGM_SL_WIDTHS(PICK)
-#undef PICK
-    int nb = 0;
-    if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) != hipSuccess || nb < 1) nb = 8;
-    return cache[W] = nb;
-}
-
 // SGM_ELL_CFG="U,nt,grid": slots in flight per lane, nontemporal matrix loads, grid cap (tuning aid)
 struct EllCfg { int u = 8, nt = 1, grid = 2048; };
 static EllCfg &ell_cfg()
@@ -801,7 +802,7 @@ static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const doub
     v.n_halo = p.n_halo; v.ncol_own = p.ncol_own;
     v.rowptr = p.rowptr + r.lo; v.col = p.col; v.val = p.val; v.code = p.code; v.dict = p.dict;
     v.max_row = p.max_row;
-    const bool sliced = use_sliced(p);      // range starts are multiples of 256 rows (set_interior_range)
+    const bool sliced = use_sliced(p);      // range starts are multiples of the 512-row slices (set_interior_range)
     if (sliced) { v.sval = p.sval + (int64_t)r.lo * p.sw; v.scode = p.scode + r.lo; v.sw = p.sw; }
     const bool dict = use_offset_dict(p);
     const double *xs = dict ? x + r.lo : x;
@@ -929,7 +930,9 @@ void set_interior_range(Part &p, const int32_t *ptr1, const int32_t *node1)
     p.int_lo = 0;
     p.int_hi = 0;
     if (p.n_halo == 0 || p.n == 0) return;
-    const int B = spmv_cfg().block;
+    // ranges are cut at row-block boundaries of the kernel that will run them (512-row slices for the
+    // sliced kernel; a multiple of the other kernels' 256-row blocks, so they can run the ranges too)
+    const int B = p.scode ? std::max(kSlRows, spmv_cfg().block) : spmv_cfg().block;
     const int32_t nb = (p.n + B - 1) / B;
     int32_t best_lo = 0, best_len = 0, run_lo = 0, run_len = 0;
     for (int32_t b = 0; b < nb; ++b) {
@@ -947,8 +950,8 @@ void set_interior_range(Part &p, const int32_t *ptr1, const int32_t *node1)
 int pack_sliced(Part &p)
 {
     if (!p.scode || p.n == 0) return SGM_OK;
-    const int64_t nrb = ((int64_t)p.n + 255) / 256;
-    hipLaunchKernelGGL(k_sl_pack, dim3((unsigned)std::min<int64_t>(nrb, 65536)), dim3(256), 0, g_rt.stream, p.n, p.sw,
+    const int64_t nsl = ((int64_t)p.n + kSlRows - 1) / kSlRows;
+    hipLaunchKernelGGL(k_sl_pack, dim3((unsigned)std::min<int64_t>(nsl, 65536)), dim3(256), 0, g_rt.stream, p.n, p.sw,
                        (const int32_t *)p.rowptr, (const double *)p.val, p.sval);
     SGM_HIP(hipGetLastError());
     return SGM_OK;
@@ -1008,7 +1011,7 @@ static int build_offset_dict(Part &p, const int32_t *ptr1, const int32_t *node1)
     // sliced form (opt-in, built only while the option is on): short rows, few offsets, little padding
     const int W = p.max_row <= 3 ? 3 : p.max_row <= 5 ? 5 : p.max_row <= 7 ? 7 : 8;
     if (g_opt.csr_sliced && p.ndict <= 15 && p.max_row >= 1 && p.max_row <= 8 && (double)W * n <= 1.25 * (double)nnz) {
-        const size_t rows_padded = ((size_t)n + 255) / 256 * 256;
+        const size_t rows_padded = ((size_t)n + kSlRows - 1) / kSlRows * kSlRows;
         std::vector<uint32_t> sc(rows_padded, 0xffffffffu);
         for (int32_t i = 0; i < n; ++i) {
             uint32_t cw = 0xffffffffu;

@@ -34,7 +34,7 @@ for k, v in out["kernels"].items():
         v["hbm_read_bytes_corrected"] = 2 * v["FETCH_SIZE"]["mean_KB"] * 1024
         v["hbm_write_bytes"] = v["WRITE_SIZE"]["mean_KB"] * 1024
         v["hbm_traffic_bytes"] = v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"]
-main = [k for k in out["kernels"] if "k_csr_do" in k]
+main = [k for k in out["kernels"] if "k_csr_sl" in k] or [k for k in out["kernels"] if "k_csr_do" in k]
 if main:
     out["hbm_traffic_bytes"] = out["kernels"][main[0]]["hbm_traffic_bytes"]
     out["dominant_kernel"] = main[0]

@@ -8,10 +8,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import sigma_amd as sg
 from sigma_amd import problems as P
-nx = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+nx = int(sys.argv[1]) if len(sys.argv) > 1 else 1000       # negative: |nx|^3 7-point grid instead of nx^2 5-point
 only = sys.argv[2].split(",") if len(sys.argv) > 2 else ["cg", "jacobi", "ildu0"]
-n = nx * nx
-ptr, node, val = P.poisson2d_csr(nx, nx)
+if nx < 0:
+    m3 = -nx
+    n = m3 ** 3
+    ptr, node, val = P.laplace3d_csr(m3, m3, m3)
+else:
+    n = nx * nx
+    ptr, node, val = P.poisson2d_csr(nx, nx)
 sg.init(0)
 A = sg.csr_matrix(n, n, ptr, node, val)
 b = np.full(n, 1.0 / n)

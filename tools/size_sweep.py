@@ -57,7 +57,7 @@ def main():
             out[name] = {"us": round(t * 1e6, 1), "frac_alg": round(alg / t / 8e12, 3),
                          "stored_TBs": round(stored / t / 1e12, 2)}
         sg.set_option("csr_offset_dict", 1)
-        sg.set_option("csr_sliced", 0)
+        sg.set_option("csr_sliced", 1)
         print(json.dumps(out), flush=True)
         del A, x, y
         torch.cuda.empty_cache()

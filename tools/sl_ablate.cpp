@@ -182,6 +182,77 @@ void run2(const char *label, int grid, int32_t n, uint32_t *sc, int32_t *dict, d
     printf("%-34s grid %5d: %8.1f us  %6.2f TB/s moved (%.0f MB)\n", label, grid, t * 1e6, bytes / t / 1e12, bytes / 1e6);
 }
 
+
+// two adjacent rows per lane AND software-pipelined: the next row block's codes and values are
+// requested before the current block's x values are consumed
+template <int W, int F>
+__global__ __launch_bounds__(256) void k2p(int32_t n, const uint32_t *__restrict__ scode, const int32_t *__restrict__ dict,
+                                           const double *__restrict__ sval, const double *__restrict__ x, double *__restrict__ y)
+{
+    __shared__ int32_t dl[16];
+    const int tid = threadIdx.x;
+    if (tid < 16) dl[tid] = dict[tid];
+    __syncthreads();
+    const int64_t nrb = ((int64_t)n + 511) / 512;
+    int64_t rb = (F & NOMAP) ? (int64_t)blockIdx.x : rowblock_of(0, blockIdx.x, gridDim.x);
+    if (rb >= nrb) return;
+    u32x2 cw = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(scode + rb * 512 + 2 * tid));
+    f64x2 v[W];
+    {
+        const f64x2 *vb = reinterpret_cast<const f64x2 *>(sval + rb * (int64_t)(W * 512)) + tid;
+#pragma unroll
+        for (int u = 0; u < W; ++u) v[u] = __builtin_nontemporal_load(vb + u * 256);
+    }
+    for (int it = 0;; ++it) {
+        const int32_t row = (int32_t)(rb * 512) + 2 * tid;
+        double xa[W], xb[W];
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            const uint32_t ca = (cw.x >> (4 * u)) & 15u, cb = (cw.y >> (4 * u)) & 15u;
+            xa[u] = x[row + dl[ca]];
+            xb[u] = x[row + 1 + dl[cb]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int64_t rbn = (F & NOMAP) ? (int64_t)(it + 1) * gridDim.x + blockIdx.x : rowblock_of(it + 1, blockIdx.x, gridDim.x);
+        const bool more = rbn < nrb;
+        u32x2 cwn = {0xffffffffu, 0xffffffffu};
+        f64x2 vn[W];
+        if (more) {
+            cwn = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(scode + rbn * 512 + 2 * tid));
+            const f64x2 *vb = reinterpret_cast<const f64x2 *>(sval + rbn * (int64_t)(W * 512)) + tid;
+#pragma unroll
+            for (int u = 0; u < W; ++u) vn[u] = __builtin_nontemporal_load(vb + u * 256);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f64x2 z = {0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < W; ++u) { z.x = z.x + v[u].x * xa[u]; z.y = z.y + v[u].y * xb[u]; }
+        __builtin_nontemporal_store(z, reinterpret_cast<f64x2 *>(y + row));
+        if (!more) break;
+        rb = rbn; cw = cwn;
+#pragma unroll
+        for (int u = 0; u < W; ++u) v[u] = vn[u];
+    }
+}
+
+template <int W, int F>
+void run2p(const char *label, int grid, int32_t n, uint32_t *sc, int32_t *dict, double *sv, double *x, double *y, int plane)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int r = 0; r < 3; ++r) k2p<W, F><<<grid, 256>>>(n, sc, dict, sv, x + plane, y);
+    hipDeviceSynchronize();
+    const int reps = 10;
+    hipEventRecord(e0);
+    for (int r = 0; r < reps; ++r) k2p<W, F><<<grid, 256>>>(n, sc, dict, sv, x + plane, y);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double t = ms * 1e-3 / reps;
+    const double bytes = (double)n * (8.0 * W + 4 + 8 + 8);
+    printf("%-34s grid %5d: %8.1f us  %6.2f TB/s moved (%.0f MB)\n", label, grid, t * 1e6, bytes / t / 1e12, bytes / 1e6);
+}
+
 template <int W, int F>
 void run(const char *label, int grid, int32_t n, uint32_t *sc, int32_t *dict, double *sv, double *x, double *y, int plane)
 {
@@ -223,6 +294,8 @@ void all(int grid, int32_t n, uint32_t *sc, int32_t *dict, double *sv, double *x
     run2<W, LC | GX | ST>("2rows: all", grid, n, sc, dict, sv, x, y, plane);
     run2<W, LC | GX | ST | NOMAP>("2rows: all, plain map", grid, n, sc, dict, sv, x, y, plane);
     run2<W, LC | GX | ST | STPLAIN>("2rows: all, plain store", grid, n, sc, dict, sv, x, y, plane);
+    run2p<W, 0>("2rows pipelined", grid, n, sc, dict, sv, x, y, plane);
+    run2p<W, NOMAP>("2rows pipelined, plain map", grid, n, sc, dict, sv, x, y, plane);
     runp<W, 0>("all, pipelined", grid, n, sc, dict, sv, x, y, plane);
     runp<W, NOMAP>("all, pipelined, plain map", grid, n, sc, dict, sv, x, y, plane);
 }
@@ -244,7 +317,7 @@ int main(int argc, char **argv)
     hipMemcpy(dict, d.data(), 64, hipMemcpyHostToDevice);
     std::vector<uint32_t> h(np, 0x76543210u);
     hipMemcpy(sc, h.data(), np * 4, hipMemcpyHostToDevice);
-    for (int grid : {2048, argc > 5 ? atoi(argv[5]) : 4096}) {
+    for (int grid : {1024, 2048, argc > 5 ? atoi(argv[5]) : 4096}) {
         if (W == 3) all<3>(grid, n, sc, dict, sv, x, y, plane);
         else if (W == 5) all<5>(grid, n, sc, dict, sv, x, y, plane);
         else all<7>(grid, n, sc, dict, sv, x, y, plane);
