@@ -403,6 +403,19 @@ __global__ __launch_bounds__(256) void k_sl_pack(int32_t n, int32_t W, const int
         }
 }
 
+// the same for an ELLPACK matrix (slot-major eval, stride n): all max_d slots of a row are entries
+__global__ __launch_bounds__(256) void k_sl_pack_ell(int32_t n, int32_t W, int32_t max_d, const double *__restrict__ eval,
+                                                     double *__restrict__ sval)
+{
+    const int64_t nsl = ((int64_t)n + kSlRows - 1) / kSlRows;
+    for (int64_t sl = blockIdx.x; sl < nsl; sl += gridDim.x)
+        for (int r = threadIdx.x; r < kSlRows; r += blockDim.x) {
+            const int64_t row = sl * kSlRows + r;
+            double *dst = sval + sl * (int64_t)W * kSlRows + r;
+            for (int u = 0; u < W; ++u) dst[(int64_t)u * kSlRows] = (row < n && u < max_d) ? eval[(int64_t)u * n + row] : 0.0;
+        }
+}
+
 // ELLPACK, slot-major device layout: lane i owns row i and walks ALL max_d slots in
 // order (padding slots multiply 0.0 by x(last neighbour), exactly like the reference,
 // so a non-finite x entry propagates the same way).
@@ -715,8 +728,13 @@ static EllCfg &ell_cfg()
     }
     return c;
 }
+static bool use_sliced_ell(const Part &p) { return p.ecol && p.scode && g_opt.csr_sliced && g_opt.ell_offset_dict; }
 int ell_grid(const Part &p)
 {
+    if (use_sliced_ell(p)) {           // k_csr_sl: 512-row slices round-robin over <= kMaxGrid workgroups
+        const int64_t nsl = ((int64_t)p.n + kSlRows - 1) / kSlRows;
+        return (int)std::max<int64_t>(1, std::min<int64_t>(nsl, kMaxGrid));
+    }
     int64_t g = ((int64_t)p.n + kBlock - 1) / kBlock;
     int64_t cap = ell_cfg().grid;
     // k_ell_do<16> holds 16 values + 16 x entries per lane: 77-88 VGPRs, 5 waves/SIMD with the fused
@@ -729,6 +747,10 @@ template <bool ADD>
 static void launch_ell(const Part &p, int grid, const double *x, double *y, const double *w,
                        double *pwy, double *pyy, const int *flag, int gen)
 {
+    if (use_sliced_ell(p)) {           // structured ELLPACK in the sliced form: the CSR kernel as it is
+        launch_csr_sl<ADD>(p, grid, x, y, w, pwy, pyy, flag, gen);
+        return;
+    }
     hipStream_t st = g_rt.stream;
     const EllCfg &c = ell_cfg();
     if (p.ecode && g_opt.ell_offset_dict) {
@@ -951,8 +973,12 @@ int pack_sliced(Part &p)
 {
     if (!p.scode || p.n == 0) return SGM_OK;
     const int64_t nsl = ((int64_t)p.n + kSlRows - 1) / kSlRows;
-    hipLaunchKernelGGL(k_sl_pack, dim3((unsigned)std::min<int64_t>(nsl, 65536)), dim3(256), 0, g_rt.stream, p.n, p.sw,
-                       (const int32_t *)p.rowptr, (const double *)p.val, p.sval);
+    if (p.ecol)
+        hipLaunchKernelGGL(k_sl_pack_ell, dim3((unsigned)std::min<int64_t>(nsl, 65536)), dim3(256), 0, g_rt.stream, p.n, p.sw,
+                           p.max_d, (const double *)p.eval, p.sval);
+    else
+        hipLaunchKernelGGL(k_sl_pack, dim3((unsigned)std::min<int64_t>(nsl, 65536)), dim3(256), 0, g_rt.stream, p.n, p.sw,
+                           (const int32_t *)p.rowptr, (const double *)p.val, p.sval);
     SGM_HIP(hipGetLastError());
     return SGM_OK;
 }
@@ -1069,6 +1095,25 @@ static int build_ell_offset_dict(Part &p)
     SGM_HIP(hipMemcpy(p.ecode, code.data(), code.size(), hipMemcpyHostToDevice));
     SGM_HIP(hipMemcpy(p.dict, dict.data(), 256 * 4, hipMemcpyHostToDevice));
     p.emdp = mdp;
+    // sliced form (see k_csr_sl): every one of the max_d slots is an entry (padding slots keep their
+    // 0.0 * x(last neighbour) term, like the reference), so the CSR kernel applies as it is
+    const int ndict = (int)std::count_if(slot, slot + HS, [](int16_t v) { return v >= 0; });
+    if (g_opt.csr_sliced && ndict <= 15 && p.max_d >= 1 && p.max_d <= 8) {
+        const int W = p.max_d <= 3 ? 3 : p.max_d <= 5 ? 5 : p.max_d <= 7 ? 7 : 8;
+        const size_t rows_padded = ((size_t)p.n + kSlRows - 1) / kSlRows * kSlRows;
+        std::vector<uint32_t> sc(rows_padded, 0xffffffffu);
+        for (int32_t i = 0; i < p.n; ++i) {
+            uint32_t cw = 0xffffffffu;
+            for (int32_t k = 0; k < p.max_d; ++k)
+                cw = (cw & ~(15u << (4 * k))) | ((uint32_t)code[(size_t)i * mdp + k] << (4 * k));
+            sc[(size_t)i] = cw;
+        }
+        SGM_TRY(dalloc(&p.scode, rows_padded));
+        SGM_TRY(dalloc(&p.sval, rows_padded * W));
+        SGM_HIP(hipMemcpy(p.scode, sc.data(), rows_padded * 4, hipMemcpyHostToDevice));
+        p.sw = W;
+        SGM_TRY(pack_sliced(p));
+    }
     return SGM_OK;
 }
 
@@ -1110,8 +1155,8 @@ int rebuild_csr_formats(Part &p)
 }
 int rebuild_ell_formats(Part &p)
 {
-    dfree(p.ecode); dfree(p.dict);
-    p.ecode = nullptr; p.dict = nullptr; p.emdp = 0;
+    dfree(p.ecode); dfree(p.dict); dfree(p.sval); dfree(p.scode);
+    p.ecode = nullptr; p.dict = nullptr; p.emdp = 0; p.sval = nullptr; p.scode = nullptr; p.sw = 0;
     return build_ell_offset_dict(p);
 }
 int sgm_invalidate_transpose(sgm_mat A)
@@ -1403,6 +1448,7 @@ int sgm_ell_set_values(sgm_mat A, const double *val, int where)
     hipLaunchKernelGGL(k_ell_transpose, dim3(vec_grid(total)), dim3(kBlock), 0, g_rt.stream,
                        (const int32_t *)nullptr, src, p.ecol, p.eval, p.n, p.max_d);
     SGM_HIP(hipGetLastError());
+    SGM_TRY(pack_sliced(p));
     SGM_HIP(hipStreamSynchronize(g_rt.stream));
     dfree(tv);
     return SGM_OK;
@@ -1535,7 +1581,8 @@ int sgm_mat_kernel(sgm_mat A, char *buf, int len)
     else {
         const Part &p = A->parts[0];
         if (A->fmt == SGM_FMT_ELL) {
-            if (p.ecode && g_opt.ell_offset_dict) snprintf(name, sizeof name, "k_ell_do<MDP=%d>", p.emdp);
+            if (use_sliced_ell(p)) snprintf(name, sizeof name, "k_csr_sl<W=%d>", p.sw);
+            else if (p.ecode && g_opt.ell_offset_dict) snprintf(name, sizeof name, "k_ell_do<MDP=%d>", p.emdp);
             else snprintf(name, sizeof name, "k_ell_spmv");
         } else if (use_sliced(p)) snprintf(name, sizeof name, "k_csr_sl<W=%d>", p.sw);
         else if (use_offset_dict(p)) snprintf(name, sizeof name, "k_csr_do<256,%d,CW=1>", do_tile_for(p));

@@ -452,21 +452,37 @@ def test_ell_wide_dictionary_kernel_nine_point_stencil(orc):
 
 @pytest.mark.parametrize("name", [n for n in golden_names() if "_ell_" in n])
 def test_ell_offset_dict_and_plain_kernels_agree(golden, name):
-    """ELLPACK matrices with max_d <= 16 and few distinct offsets take the 1-byte code kernel;
-    the plain int32 slot-major kernel must give the same bits (both equal the reference)."""
+    """Structured ELLPACK matrices take the sliced 4-bit-code kernel (max_d <= 8, <= 15 offsets) or the
+    1-byte code kernel (max_d <= 16); the plain int32 slot-major kernel must give the same bits (all
+    equal the reference), also y += A x, after a value update, and for the transpose."""
     g = golden(name)
-    for opt in (1, 0):
+    n, m = int(g["n"]), int(g["m"])
+    seen = set()
+    for opt, sl in ((1, 1), (1, 0), (0, 1)):
         sg.set_option("ell_offset_dict", opt)
+        sg.set_option("csr_sliced", sl)
         try:
             A = hip_matrix(g)
-            y = np.zeros(int(g["n"]))
+            seen.add(A.kernel.split("<")[0])
+            y = np.zeros(n)
             A.matvec(g["x"], y)
-            yt = np.zeros(int(g["m"]))
+            y2 = y.copy()
+            A.matvec_add(g["x"], y2)
+            yt = np.zeros(m)
             A.matvec_t(g["b"], yt)
+            md = int(g["ref_max_d"][0])
+            A.set_values((2.0 * g["ref_val"]).reshape(n, md))      # doubled values: doubled rows, exactly
+            y3 = np.zeros(n)
+            A.matvec(g["x"], y3)
         finally:
             sg.set_option("ell_offset_dict", 1)
-        assert np.array_equal(y, g["ref_y"]), opt
-        assert np.array_equal(yt, g["ref_yt"]), opt
+            sg.set_option("csr_sliced", 1)
+        assert np.array_equal(y, g["ref_y"]), (opt, sl)
+        assert np.array_equal(y2, g["ref_y_add"]), (opt, sl)
+        assert np.array_equal(yt, g["ref_yt"]), (opt, sl)
+        assert np.array_equal(y3, 2.0 * g["ref_y"]), (opt, sl)
+    if int(g["ref_max_d"][0]) <= 8:
+        assert seen == {"k_csr_sl", "k_ell_do", "k_ell_spmv"}, seen
 
 
 def test_matvec_signed_zero_and_nonfinite(orc):
