@@ -119,6 +119,7 @@ struct Part {
     // the row's column offsets as 8 four-bit dictionary codes in one word (15 = no entry)
     double *sval = nullptr;
     uint32_t *scode = nullptr;
+    int32_t *scol = nullptr;       // sliced form WITHOUT a dictionary: the int32 column of every slot (-1 = no entry), same layout as sval
     int32_t sw = 0;                // slots per row in sval (3, 5, 7 or 8)
     // ELLPACK (device, slot-major: entry (slot k, row i) at k*n + i)
     int32_t max_d = 0;

@@ -388,6 +388,101 @@ __global__ __launch_bounds__(256) void k_csr_sl(
     }
 }
 
+// The sliced form for matrices WITHOUT an offset dictionary (arbitrary columns) whose rows are short
+// (<= 16 entries) and of similar length: the int32 column of every slot is stored beside the value,
+// slot-major in the same 512-row slices (-1 = no entry); 12 bytes per slot like plain CSR, but every
+// load is a coalesced 8/16 bytes per lane and there is no row pointer, no LDS, no barrier.  Slots are
+// walked in chunks of 8 (registers).
+template <int W, bool ADD, bool DOT_W, bool DOT_YY>
+__global__ __launch_bounds__(256) void k_csr_sl32(
+    int32_t n, const int32_t *__restrict__ scol, const double *__restrict__ sval,
+    const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ w,
+    double *__restrict__ part_wy, double *__restrict__ part_yy, const int *__restrict__ flag_done, int gen, int remap)
+{
+    constexpr int BLOCK = 256;
+    __shared__ double red[BLOCK / 64];
+    if (flag_done) { const int st = *flag_done; if (st && gen >= st) return; }
+    const int tid = threadIdx.x;
+    const bool chain = (remap & 256) != 0;
+    const int64_t nsl = ((int64_t)n + kSlRows - 1) / kSlRows;
+    double dwy = 0.0, dyy = 0.0;
+
+    for (int64_t sl = blockIdx.x; sl < nsl; sl += gridDim.x) {
+        const int32_t row = (int32_t)(sl * kSlRows) + 2 * tid;
+        const f64x2 *vb = reinterpret_cast<const f64x2 *>(sval + sl * (int64_t)(W * kSlRows)) + tid;
+        const i32x2 *cb = reinterpret_cast<const i32x2 *>(scol + sl * (int64_t)(W * kSlRows)) + tid;
+        f64x2 y0 = {0.0, 0.0};
+        if (ADD) {
+            if (row + 1 < n) y0 = *reinterpret_cast<const f64x2 *>(y + row);
+            else if (row < n) y0.x = y[row];
+        }
+        f64x2 z;
+        z.x = (ADD && chain) ? y0.x : 0.0;
+        z.y = (ADD && chain) ? y0.y : 0.0;
+#pragma unroll
+        for (int c0 = 0; c0 < W; c0 += 8) {
+            constexpr int CH = 8;
+            f64x2 v[CH];
+            i32x2 cc[CH];
+            double xa[CH], xb[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if (c0 + u < W) {
+                    v[u] = __builtin_nontemporal_load(vb + (c0 + u) * BLOCK);
+                    cc[u] = __builtin_nontemporal_load(cb + (c0 + u) * BLOCK);
+                }
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if (c0 + u < W) {
+                    xa[u] = cc[u].x >= 0 ? x[cc[u].x] : 0.0;
+                    xb[u] = cc[u].y >= 0 ? x[cc[u].y] : 0.0;
+                }
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if (c0 + u < W) {
+                    if (cc[u].x >= 0) z.x = z.x + v[u].x * xa[u];
+                    if (cc[u].y >= 0) z.y = z.y + v[u].y * xb[u];
+                }
+            if (W > 8) __builtin_amdgcn_sched_barrier(0);       // one chunk's registers at a time
+        }
+        f64x2 yi;
+        yi.x = ADD ? (chain ? z.x : y0.x + z.x) : 0.0 + z.x;
+        yi.y = ADD ? (chain ? z.y : y0.y + z.y) : 0.0 + z.y;
+        if (row + 1 < n) {
+            __builtin_nontemporal_store(yi, reinterpret_cast<f64x2 *>(y + row));
+            if (DOT_W) { const f64x2 wv = *reinterpret_cast<const f64x2 *>(w + row); dwy += wv.x * yi.x; dwy += wv.y * yi.y; }
+            if (DOT_YY) { dyy += yi.x * yi.x; dyy += yi.y * yi.y; }
+        } else if (row < n) {
+            __builtin_nontemporal_store(yi.x, y + row);
+            if (DOT_W) dwy += w[row] * yi.x;
+            if (DOT_YY) dyy += yi.x * yi.x;
+        }
+    }
+    if (DOT_W) {
+        const double t = block_sum<BLOCK>(dwy, red);
+        if (tid == 0) part_wy[blockIdx.x] = t;
+    }
+    if (DOT_YY) {
+        const double t = block_sum<BLOCK>(dyy, red);
+        if (tid == 0) part_yy[blockIdx.x] = t;
+    }
+}
+
+// columns in CSR order -> sliced layout (-1 where a row has no entry in the slot; whole slices)
+__global__ __launch_bounds__(256) void k_sl_pack_cols(int32_t n, int32_t W, const int32_t *__restrict__ rowptr,
+                                                      const int32_t *__restrict__ col, int32_t *__restrict__ scol)
+{
+    const int64_t nsl = ((int64_t)n + kSlRows - 1) / kSlRows;
+    for (int64_t sl = blockIdx.x; sl < nsl; sl += gridDim.x)
+        for (int r = threadIdx.x; r < kSlRows; r += blockDim.x) {
+            const int64_t row = sl * kSlRows + r;
+            int32_t k = 0, ke = 0;
+            if (row < n) { k = rowptr[row]; ke = rowptr[row + 1]; }
+            int32_t *dst = scol + sl * (int64_t)W * kSlRows + r;
+            for (int u = 0; u < W; ++u) dst[(int64_t)u * kSlRows] = k + u < ke ? col[k + u] : -1;
+        }
+}
+
 // values in CSR order -> sliced layout (at upload and after every value update)
 __global__ __launch_bounds__(256) void k_sl_pack(int32_t n, int32_t W, const int32_t *__restrict__ rowptr,
                                                  const double *__restrict__ val, double *__restrict__ sval)
@@ -550,6 +645,8 @@ static int resident_per_cu(bool dict, int block, int v, int cw = 4);
 int ell_grid(const Part &p);
 static bool use_offset_dict(const Part &p) { return p.code && g_opt.csr_offset_dict; }
 static bool use_sliced(const Part &p) { return p.scode && g_opt.csr_sliced && g_opt.csr_offset_dict; }
+static bool use_sliced32(const Part &p) { return p.scol && g_opt.csr_sliced && !p.ecol; }
+static bool any_sliced(const Part &p) { return use_sliced(p) || use_sliced32(p); }
 // k_csr_do serves both the dictionary form and, for short rows, plain int32 columns
 static bool use_row_owner(const Part &p)
 {
@@ -580,11 +677,11 @@ static int do_tile_for(const Part &p)
 static int grid_for_rows(const Part &p, int64_t rows, int64_t limit)
 {
     const SpmvCfg &c = spmv_cfg();
-    const int blk = use_sliced(p) ? kSlRows : c.block;
+    const int blk = any_sliced(p) ? kSlRows : c.block;
     const int64_t nrb = (rows + blk - 1) / blk;
     int64_t g = ((nrb + 7) / 8) * 8;
     int64_t cap = c.maxgrid;
-    if (cap <= 0 && use_sliced(p)) cap = kMaxGrid;          // round-robin slices, not a persistent resident grid
+    if (cap <= 0 && any_sliced(p)) cap = kMaxGrid;          // round-robin slices, not a persistent resident grid
     if (cap <= 0) cap = (int64_t)resident_per_cu(use_row_owner(p), c.block, use_row_owner(p) ? do_tile_for(p) : c.vpt,
                                                  use_offset_dict(p) ? 1 : 4) * g_rt.num_cu;
     if (cap > limit) cap = limit;
@@ -607,7 +704,7 @@ static int spmv_ranges(const Part &p, RowRange out[3])
         ++nr;
     };
     if (p.n_halo == 0 || p.int_hi <= p.int_lo) {
-        if (use_sliced(p)) {           // one range, all kMaxGrid partial slots are its own
+        if (any_sliced(p)) {           // one range, all kMaxGrid partial slots are its own
             out[0] = RowRange{0, p.n, grid_for_rows(p, p.n > 0 ? p.n : 1, kMaxGrid), 0};
             return 1;
         }
@@ -711,6 +808,28 @@ static void launch_csr_sl(const Part &p, int grid, const double *x, double *y, c
         return;                               \
     }
     SGM_SL_WIDTHS(LV)
+#undef LV
+#undef L
+}
+
+#define SGM_SL32_WIDTHS(X) X(3) X(5) X(7) X(8) X(12) X(16)
+template <bool ADD>
+static void launch_csr_sl32(const Part &p, int grid, const double *x, double *y, const double *w,
+                            double *pwy, double *pyy, const int *flag, int gen)
+{
+    hipStream_t st = g_rt.stream;
+#define L(WW, DW, DY)                                                                                     \
+    hipLaunchKernelGGL((k_csr_sl32<WW, ADD, DW, DY>), dim3(grid), dim3(256), 0, st, p.n, p.scol, p.sval, x, y, \
+                       w, pwy, pyy, flag, gen, g_launch_flags)
+#define LV(WW)                                \
+    if (p.sw == WW) {                         \
+        if (w && pyy) L(WW, true, true);      \
+        else if (w) L(WW, true, false);       \
+        else if (pyy) L(WW, false, true);     \
+        else L(WW, false, false);             \
+        return;                               \
+    }
+    SGM_SL32_WIDTHS(LV)
 #undef LV
 #undef L
 }
@@ -824,8 +943,9 @@ static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const doub
     v.n_halo = p.n_halo; v.ncol_own = p.ncol_own;
     v.rowptr = p.rowptr + r.lo; v.col = p.col; v.val = p.val; v.code = p.code; v.dict = p.dict;
     v.max_row = p.max_row;
-    const bool sliced = use_sliced(p);      // range starts are multiples of the 512-row slices (set_interior_range)
+    const bool sliced = use_sliced(p), sliced32 = !sliced && use_sliced32(p);   // range starts are multiples of the 512-row slices
     if (sliced) { v.sval = p.sval + (int64_t)r.lo * p.sw; v.scode = p.scode + r.lo; v.sw = p.sw; }
+    if (sliced32) { v.sval = p.sval + (int64_t)r.lo * p.sw; v.scol = p.scol + (int64_t)r.lo * p.sw; v.sw = p.sw; }
     const bool dict = use_offset_dict(p);
     const double *xs = dict ? x + r.lo : x;
     double *ys = y + r.lo;
@@ -834,6 +954,9 @@ static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const doub
     if (sliced) {
         if (add) launch_csr_sl<true>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
         else launch_csr_sl<false>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
+    } else if (sliced32) {            // absolute columns: x is not shifted
+        if (add) launch_csr_sl32<true>(v, r.grid, x, ys, ws, pw, py, flag_done, gen);
+        else launch_csr_sl32<false>(v, r.grid, x, ys, ws, pw, py, flag_done, gen);
     } else if (use_row_owner(p)) {
         if (add) launch_csr_do<true>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
         else launch_csr_do<false>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
@@ -954,7 +1077,7 @@ void set_interior_range(Part &p, const int32_t *ptr1, const int32_t *node1)
     if (p.n_halo == 0 || p.n == 0) return;
     // ranges are cut at row-block boundaries of the kernel that will run them (512-row slices for the
     // sliced kernel; a multiple of the other kernels' 256-row blocks, so they can run the ranges too)
-    const int B = p.scode ? std::max(kSlRows, spmv_cfg().block) : spmv_cfg().block;
+    const int B = (p.scode || p.scol) ? std::max(kSlRows, spmv_cfg().block) : spmv_cfg().block;
     const int32_t nb = (p.n + B - 1) / B;
     int32_t best_lo = 0, best_len = 0, run_lo = 0, run_len = 0;
     for (int32_t b = 0; b < nb; ++b) {
@@ -971,7 +1094,7 @@ void set_interior_range(Part &p, const int32_t *ptr1, const int32_t *node1)
 // refresh the sliced copy of the values (no-op for parts without one)
 int pack_sliced(Part &p)
 {
-    if (!p.scode || p.n == 0) return SGM_OK;
+    if ((!p.scode && !p.scol) || p.n == 0) return SGM_OK;
     const int64_t nsl = ((int64_t)p.n + kSlRows - 1) / kSlRows;
     if (p.ecol)
         hipLaunchKernelGGL(k_sl_pack_ell, dim3((unsigned)std::min<int64_t>(nsl, 65536)), dim3(256), 0, g_rt.stream, p.n, p.sw,
@@ -1004,6 +1127,20 @@ static int build_offset_dict(Part &p, const int32_t *ptr1, const int32_t *node1)
     const int32_t *col = host ? node1 : hc.data();
     p.max_row = 0;
     for (int32_t i = 0; i < n; ++i) p.max_row = std::max(p.max_row, ptr[i + 1] - ptr[i]);
+    // without a dictionary (option off at creation, or more than 255 offsets): try the int32 sliced form
+    auto sliced32 = [&]() -> int {
+        const int W = p.max_row <= 3 ? 3 : p.max_row <= 5 ? 5 : p.max_row <= 7 ? 7 : p.max_row <= 8 ? 8 : p.max_row <= 12 ? 12 : 16;
+        if (!g_opt.csr_sliced || p.max_row < 1 || p.max_row > 16 || (double)W * n > 1.25 * (double)nnz) return SGM_OK;
+        const size_t rows_padded = ((size_t)n + kSlRows - 1) / kSlRows * kSlRows;
+        SGM_TRY(dalloc(&p.scol, rows_padded * W));
+        SGM_TRY(dalloc(&p.sval, rows_padded * W));
+        p.sw = W;
+        hipLaunchKernelGGL(k_sl_pack_cols, dim3((unsigned)std::min<size_t>(rows_padded / kSlRows, 65536)), dim3(256), 0, g_rt.stream,
+                           n, W, (const int32_t *)p.rowptr, (const int32_t *)p.col, p.scol);
+        SGM_HIP(hipGetLastError());
+        return pack_sliced(p);
+    };
+    if (!g_opt.csr_offset_dict) return sliced32();
     constexpr int HS = 1024;                            // open-addressing table, <= 255 live keys
     int32_t key[HS];
     int16_t slot[HS];
@@ -1016,7 +1153,7 @@ static int build_offset_dict(Part &p, const int32_t *ptr1, const int32_t *node1)
             uint32_t h = ((uint32_t)off * 2654435761u) >> 22;      // 10 bits
             for (;;) {
                 if (slot[h] < 0) {
-                    if (dict.size() == 255) return SGM_OK;          // too many offsets: int32 kernel
+                    if (dict.size() == 255) return sliced32();      // too many offsets: int32 kernels
                     slot[h] = (int16_t)dict.size();
                     key[h] = off;
                     dict.push_back(off);
@@ -1148,8 +1285,8 @@ int build_csr_part(Part &p, int32_t n, int32_t ncol_own, int32_t n_halo, int64_t
 // after a change of the index arrays (matrix permutation): drop and rebuild the derived formats
 int rebuild_csr_formats(Part &p)
 {
-    dfree(p.code); dfree(p.dict); dfree(p.sval); dfree(p.scode);
-    p.code = nullptr; p.dict = nullptr; p.sval = nullptr; p.scode = nullptr;
+    dfree(p.code); dfree(p.dict); dfree(p.sval); dfree(p.scode); dfree(p.scol);
+    p.code = nullptr; p.dict = nullptr; p.sval = nullptr; p.scode = nullptr; p.scol = nullptr;
     p.ndict = 0; p.sw = 0; p.max_row = 0;
     return build_offset_dict(p, nullptr, nullptr);
 }
@@ -1170,7 +1307,7 @@ int sgm_invalidate_transpose(sgm_mat A)
 
 void free_part(Part &p)
 {
-    dfree(p.rowptr); dfree(p.col); dfree(p.val); dfree(p.code); dfree(p.dict); dfree(p.sval); dfree(p.scode); dfree(p.ecol); dfree(p.eval); dfree(p.edeg); dfree(p.ecode); dfree(p.xext);
+    dfree(p.rowptr); dfree(p.col); dfree(p.val); dfree(p.code); dfree(p.dict); dfree(p.sval); dfree(p.scode); dfree(p.scol); dfree(p.ecol); dfree(p.eval); dfree(p.edeg); dfree(p.ecode); dfree(p.xext);
     for (auto &nb : p.nbrs) { dfree(nb.send_idx); dfree(nb.send_buf); }
     p = Part();
 }
@@ -1585,6 +1722,7 @@ int sgm_mat_kernel(sgm_mat A, char *buf, int len)
             else if (p.ecode && g_opt.ell_offset_dict) snprintf(name, sizeof name, "k_ell_do<MDP=%d>", p.emdp);
             else snprintf(name, sizeof name, "k_ell_spmv");
         } else if (use_sliced(p)) snprintf(name, sizeof name, "k_csr_sl<W=%d>", p.sw);
+        else if (use_sliced32(p)) snprintf(name, sizeof name, "k_csr_sl32<W=%d>", p.sw);
         else if (use_offset_dict(p)) snprintf(name, sizeof name, "k_csr_do<256,%d,CW=1>", do_tile_for(p));
         else if (use_row_owner(p)) snprintf(name, sizeof name, "k_csr_do<256,%d,CW=4>", do_tile_for(p));
         else snprintf(name, sizeof name, "k_csr_spmv");

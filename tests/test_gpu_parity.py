@@ -308,14 +308,14 @@ def _kernel_options(dict_opt, sl_opt, ro_opt):
     sg.set_option("csr_row_owner", ro_opt)
 
 
-KERNEL_COMBOS = ((1, 1, 1, "k_csr_sl"), (1, 0, 1, "CW=1"), (0, 0, 1, "CW=4"), (0, 0, 0, "k_csr_spmv"))
+KERNEL_COMBOS = ((1, 1, 1, "k_csr_sl"), (1, 0, 1, "CW=1"), (0, 1, 1, "k_csr_sl32"), (0, 0, 1, "CW=4"), (0, 0, 0, "k_csr_spmv"))
 
 
 def test_offset_dict_and_int32_kernels_agree(orc):
-    """Four CSR kernels, one result: sliced 4-bit codes (rows <= 8 entries, <= 15 offsets),
-    1-byte offset-dictionary codes (other stencil-like matrices), int32 columns gathered by
-    the row's owner lane (rows <= 32 entries), int32 columns gathered while streaming (any row
-    length).  All must equal the oracle bit for bit."""
+    """Five CSR kernels, one result: sliced 4-bit codes (rows <= 8 entries, <= 15 offsets),
+    1-byte offset-dictionary codes (other stencil-like matrices), sliced int32 columns (short rows
+    without a dictionary), int32 columns gathered by the row's owner lane (rows <= 32 entries), int32
+    columns gathered while streaming (any row length).  All must equal the oracle bit for bit."""
     rs = np.random.RandomState(8)
     for name, A in _cases(orc)[:4]:
         x = rs.standard_normal(A.m)
@@ -336,7 +336,7 @@ def test_offset_dict_and_int32_kernels_agree(orc):
             assert np.array_equal(y, y_ref), (name, dict_opt, sl_opt, ro_opt)
             assert np.array_equal(yt, yt_ref), (name, dict_opt, sl_opt, ro_opt)
         # the stencils exercise all four kernels; the random matrix has no dictionary
-        assert len(seen) == (2 if name.startswith("random") else 4), (name, seen)
+        assert len(seen) == (2 if name.startswith("random") else 5), (name, seen)
 
 
 def _banded_short_rows(n, seed, wmax=8, noffs=15):
@@ -352,6 +352,56 @@ def _banded_short_rows(n, seed, wmax=8, noffs=15):
     node = (rows + rs.randint(0, noffs, size=rows.size) + 1).astype(np.int32)
     val = rs.standard_normal(rows.size)
     return ptr, node, val
+
+
+@pytest.mark.parametrize("n,wmax", [(1, 3), (511, 5), (513, 8), (40001, 12), (70003, 16)])
+def test_sliced_int32_kernel_short_rows_without_dictionary(orc, n, wmax):
+    """Rows of 0..16 entries at ARBITRARY columns (more than 255 distinct offsets: no dictionary):
+    k_csr_sl32 keeps the int32 column of every slot in the sliced layout.  Same checks as the 4-bit
+    form: ragged rows, slices ending mid-block, Inf/NaN in x, y += A x, chained transpose, value
+    update, and the plain int32 kernels on the same data."""
+    rs = np.random.RandomState(7 * n + wmax)
+    m = max(n, 400)
+    deg = np.full(n, wmax)
+    short = rs.rand(n) < 0.10
+    deg[short] = rs.randint(0, wmax, size=int(short.sum()))
+    deg[[0, n // 2, n - 1]] = [0 if n > 2 else wmax, 1 if n > 2 else wmax, wmax]
+    ptr = np.concatenate([[1], 1 + np.cumsum(deg)]).astype(np.int32)
+    node = rs.randint(1, m + 1, size=int(deg.sum())).astype(np.int32)
+    val = rs.standard_normal(node.size)
+    A = orc.CsrMatrix(n, m, ptr, node, val)
+    H = sg.csr_matrix(n, m, ptr, node, val)
+    if n > 300:
+        assert H.kernel.startswith("k_csr_sl32"), H.kernel
+    x = rs.standard_normal(m)
+    y0 = rs.standard_normal(n)
+    y = y0.copy()
+    H.matvec_add(x, y)
+    assert np.array_equal(y, A.matvec_add(x, y0.copy()))
+    xb = x.copy()
+    xb[rs.randint(0, m, 5)] = np.inf
+    xb[rs.randint(0, m, 3)] = np.nan
+    yb = np.zeros(n)
+    H.matvec(xb, yb)
+    assert np.array_equal(yb, A.matvec(xb), equal_nan=True)
+    xt = rs.standard_normal(n)
+    t0 = rs.standard_normal(m)
+    t = t0.copy()
+    H.matvec_t_add(xt, t)
+    assert np.array_equal(t, A.matvec_t_add(xt, t0.copy()))
+    val2 = rs.standard_normal(val.size)
+    H.set_values(val2)
+    A2 = orc.CsrMatrix(n, m, ptr, node, val2)
+    y = np.zeros(n)
+    H.matvec(x, y)
+    assert np.array_equal(y, A2.matvec(x))
+    sg.set_option("csr_sliced", 0)
+    try:
+        y1 = np.zeros(n)
+        H.matvec(x, y1)
+    finally:
+        sg.set_option("csr_sliced", 1)
+    assert np.array_equal(y1, y)
 
 
 @pytest.mark.parametrize("n,wmax", [(1, 3), (255, 3), (256, 5), (257, 7), (70001, 8), (33333, 5)])
