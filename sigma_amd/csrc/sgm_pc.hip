@@ -57,6 +57,7 @@ struct TriFactor {                   // strictly triangular factor on the device
     int32_t *pq = nullptr;           // device: dependency positions of ALL entries, rows in level order
     double *pv = nullptr;            // device: their values
     int32_t *level_ptr_dev = nullptr;
+    int32_t *wq = nullptr;           // device: dependency POSITIONS, kInline slots, slot-major (-1 = none): wide levels
     uint32_t *dq32 = nullptr;        // device: low halves of dq, contiguous (runs with <= 2 dependencies per row)
     uint64_t *dq = nullptr;          // device: ring-walker copy, 4 x 16-bit position deltas per row (0 = none)
     double *dv = nullptr;            // device: ring-walker copy, kInline value slots, slot-major (slot*n + pos)
@@ -194,6 +195,27 @@ __global__ void k_trsv_wide(const TrsvRec *__restrict__ recs, const int32_t *__r
     for (int j = 0; j < kInline; ++j)
         if (j < r.cnt) z = z - r.v[j] * xp[r.q[j]];
     for (int32_t k = r.k0 + kInline; k < r.k0 + r.cnt; ++k) z = z - pv[k] * xp[pq[k]];
+    xp[p] = z;
+}
+
+// the same on the structure-of-arrays copy (all rows of the level have <= kInline dependencies):
+// positions and values slot-major, every load coalesced (the 64-byte records cost one cache line per
+// lane and load instruction)
+template <int C>
+__global__ void k_trsv_wide_soa(const int32_t *__restrict__ wq, const double *__restrict__ dv, uint32_t nstride,
+                                int32_t begin, int32_t end, double *xp, const int *flag)
+{
+    if (flag && *flag) return;
+    const int32_t p = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= end) return;
+    double z = xp[p];
+    int32_t q[C];
+    double v[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { q[c] = wq[(size_t)c * nstride + p]; v[c] = dv[(size_t)c * nstride + p]; }
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+        if (q[c] >= 0) z = z - v[c] * xp[q[c]];
     xp[p] = z;
 }
 
@@ -512,7 +534,7 @@ void free_ildu(IlduState &S)
 
 void free_tri(TriFactor &T)
 {
-    dfree(T.order); dfree(T.recs); dfree(T.pq); dfree(T.pv); dfree(T.level_ptr_dev); dfree(T.dq); dfree(T.dq32); dfree(T.dv);
+    dfree(T.order); dfree(T.recs); dfree(T.pq); dfree(T.pv); dfree(T.level_ptr_dev); dfree(T.dq); dfree(T.dq32); dfree(T.dv); dfree(T.wq);
     T = TriFactor();
 }
 
@@ -581,7 +603,13 @@ int upload_tri(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const 
         }
         for (int32_t l = 0; l < nlev;) {
             const int32_t sz = T.level_ptr[l + 1] - T.level_ptr[l];
-            if (sz > narrow) { T.schedule.push_back({l, l + 1, false, 0, false, 0}); ++l; continue; }
+            if (sz > narrow) {
+                int cm = 0;
+                for (int32_t p = T.level_ptr[l]; p < T.level_ptr[l + 1]; ++p) cm = std::max(cm, T.h_recs[p].cnt);
+                T.schedule.push_back({l, l + 1, false, 0, false, cm});      // c: most dependencies of a row of the level
+                ++l;
+                continue;
+            }
             // runs are cut by width class: 256 / 512 / 1024 threads with one row per lane, then 2 and
             // 4 rows per lane (classes 0..4, smoothed so that a run is at least ~16 levels long)
             const int c = lev_cls[l];
@@ -620,6 +648,13 @@ int upload_tri(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const 
             for (size_t p = 0; p < T.nstride; ++p) lo[p] = (uint32_t)T.h_dq[p];
             SGM_TRY(dalloc(&T.dq32, T.nstride));
             SGM_HIP(hipMemcpy(T.dq32, lo.data(), lo.size() * 4, hipMemcpyHostToDevice));
+        }
+        {
+            std::vector<int32_t> wq(T.nstride * kInline, -1);
+            for (int32_t p = 0; p < n; ++p)
+                for (int j = 0; j < kInline && j < T.h_recs[p].cnt; ++j) wq[(size_t)j * T.nstride + p] = T.h_recs[p].q[j];
+            SGM_TRY(dalloc(&T.wq, wq.size()));
+            SGM_HIP(hipMemcpy(T.wq, wq.data(), wq.size() * 4, hipMemcpyHostToDevice));
         }
         SGM_TRY(dalloc(&T.order, (size_t)n));
         SGM_TRY(dalloc(&T.recs, (size_t)n));
@@ -692,8 +727,16 @@ void trsv(const TriFactor &T, double *xp, const int *flag)
 #undef WALK
         } else {
             const int32_t b = T.level_ptr[L.l0], e = T.level_ptr[L.l1];
-            hipLaunchKernelGGL(k_trsv_wide, dim3((e - b + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
-                               (const TrsvRec *)T.recs, (const int32_t *)T.pq, (const double *)T.pv, b, e, xp, flag);
+            const dim3 g((e - b + kBlock - 1) / kBlock);
+#define WSOA(CC) hipLaunchKernelGGL((k_trsv_wide_soa<CC>), g, dim3(kBlock), 0, st, (const int32_t *)T.wq, \
+                                    (const double *)T.dv, (uint32_t)T.nstride, b, e, xp, flag)
+            if (L.c <= 2 && T.nstride < (size_t)500000000) WSOA(2);
+            else if (L.c == 3 && T.nstride < (size_t)500000000) WSOA(3);
+            else if (L.c == 4 && T.nstride < (size_t)500000000) WSOA(4);
+            else
+                hipLaunchKernelGGL(k_trsv_wide, g, dim3(kBlock), 0, st, (const TrsvRec *)T.recs, (const int32_t *)T.pq,
+                                   (const double *)T.pv, b, e, xp, flag);
+#undef WSOA
         }
     }
 }
