@@ -1109,24 +1109,92 @@ int pack_sliced(Part &p)
 // Offset dictionary of a row block (host index work at setup): distinct (col - row) values in
 // order of first appearance; gives up (p.code stays null) beyond 255 distinct offsets.
 // ptr1/node1: optional 1-based host copies (otherwise the device arrays are read back).
-static int build_offset_dict(Part &p, const int32_t *ptr1, const int32_t *node1)
+__global__ void k_fill32(int64_t n, int32_t *a, int32_t v)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) a[i] = v;
+}
+
+// ---- offset dictionary + sliced codes, built on the device ---------------------------------------
+// pass 1: the set of distinct (col - row) offsets (open-addressing table of 1024 slots in global
+// memory, atomicCAS insert; more than 255 live keys = overflow) and the longest row
+constexpr int kDictSlots = 1024;
+constexpr int32_t kDictEmpty = INT32_MIN;
+__global__ __launch_bounds__(256) void k_dict_collect(int32_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                      int32_t *table, int *count, int *max_row)
+{
+    __shared__ int32_t seen[64];            // the offsets this workgroup inserted last: most entries repeat them
+    if (threadIdx.x < 64) seen[threadIdx.x] = kDictEmpty;
+    __syncthreads();
+    int mr = 0;
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int32_t s0 = rowptr[i], e = rowptr[i + 1];
+        mr = max(mr, e - s0);
+        for (int32_t k = s0; k < e; ++k) {
+            const int32_t off = col[k] - i;
+            const uint32_t hs = ((uint32_t)off * 2654435761u) >> 26;          // 6 bits: workgroup filter
+            if (seen[hs] == off) continue;
+            if (*(volatile int *)count > 255) break;                          // overflow already: nothing more to learn
+            uint32_t h = ((uint32_t)off * 2654435761u) >> 22;                // 10 bits
+            for (int probe = 0; probe < kDictSlots; ++probe) {
+                const int32_t prev = atomicCAS(&table[h], kDictEmpty, off);
+                if (prev == kDictEmpty) { atomicAdd(count, 1); break; }
+                if (prev == off) break;
+                h = (h + 1) & (kDictSlots - 1);
+            }
+            seen[hs] = off;                                                   // benign race: a filter only
+        }
+    }
+    atomicMax(max_row, mr);
+}
+// pass 2: 1-byte code of every entry (binary search in the sorted dictionary, held in LDS) and, when
+// asked for, the row's word of 4-bit codes (15 = no entry)
+__global__ __launch_bounds__(256) void k_dict_encode(int32_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                     const int32_t *__restrict__ dict, int ndict, uint8_t *__restrict__ code,
+                                                     uint32_t *__restrict__ scode)
+{
+    __shared__ int32_t dl[256];
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) dl[t] = t < ndict ? dict[t] : INT32_MAX;
+    __syncthreads();
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int32_t s0 = rowptr[i], e = rowptr[i + 1];
+        uint32_t cw = 0xffffffffu;
+        for (int32_t k = s0; k < e; ++k) {
+            const int32_t off = col[k] - i;
+            int lo = 0, hi = ndict - 1;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (dl[mid] < off) lo = mid + 1; else hi = mid; }
+            code[k] = (uint8_t)lo;
+            if (scode && k - s0 < 8) cw = (cw & ~(15u << (4 * (k - s0)))) | ((uint32_t)lo << (4 * (k - s0)));
+        }
+        if (scode) scode[i] = cw;
+    }
+}
+
+// Offset dictionary of a row block (index work at setup, on the device): the distinct (col - row)
+// values in ascending order; gives up (p.code stays null) beyond 255 distinct offsets.
+static int build_offset_dict(Part &p, const int32_t *, const int32_t *)
 {
     const int64_t nnz = p.nnz;
     const int32_t n = p.n;
     if (nnz == 0 || n == 0) return SGM_OK;
-    std::vector<int32_t> hp, hc;
-    const bool host = ptr1 && node1;
-    if (!host) {
-        hp.resize((size_t)n + 1);
-        hc.resize((size_t)nnz);
-        SGM_HIP(hipMemcpy(hp.data(), p.rowptr, hp.size() * 4, hipMemcpyDeviceToHost));
-        SGM_HIP(hipMemcpy(hc.data(), p.col, hc.size() * 4, hipMemcpyDeviceToHost));
-    }
-    const int32_t base = host ? 1 : 0;
-    const int32_t *ptr = host ? ptr1 : hp.data();
-    const int32_t *col = host ? node1 : hc.data();
-    p.max_row = 0;
-    for (int32_t i = 0; i < n; ++i) p.max_row = std::max(p.max_row, ptr[i + 1] - ptr[i]);
+    hipStream_t st = g_rt.stream;
+    int32_t *table = nullptr;
+    int *cnt = nullptr;             // [0] distinct offsets, [1] longest row
+    SGM_TRY(dalloc(&table, (size_t)kDictSlots));
+    SGM_TRY(dalloc(&cnt, 2));
+    hipLaunchKernelGGL(k_fill32, dim3(kDictSlots / 256), dim3(256), 0, st, (int64_t)kDictSlots, table, kDictEmpty);
+    SGM_HIP(hipMemsetAsync(cnt, 0, 2 * sizeof(int), st));
+    const int grid = (int)std::min<int64_t>(((int64_t)n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_dict_collect, dim3(grid), dim3(256), 0, st, n, (const int32_t *)p.rowptr, (const int32_t *)p.col, table,
+                       cnt, cnt + 1);
+    std::vector<int32_t> htab(kDictSlots);
+    int hcnt[2] = {0, 0};
+    SGM_HIP(hipMemcpyAsync(htab.data(), table, kDictSlots * 4, hipMemcpyDeviceToHost, st));
+    SGM_HIP(hipMemcpyAsync(hcnt, cnt, sizeof hcnt, hipMemcpyDeviceToHost, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    dfree(table); dfree(cnt);
+    p.max_row = hcnt[1];
     // without a dictionary (option off at creation, or more than 255 offsets): try the int32 sliced form
     auto sliced32 = [&]() -> int {
         const int W = p.max_row <= 3 ? 3 : p.max_row <= 5 ? 5 : p.max_row <= 7 ? 7 : p.max_row <= 8 ? 8 : p.max_row <= 12 ? 12 : 16;
@@ -1140,55 +1208,33 @@ static int build_offset_dict(Part &p, const int32_t *ptr1, const int32_t *node1)
         SGM_HIP(hipGetLastError());
         return pack_sliced(p);
     };
-    if (!g_opt.csr_offset_dict) return sliced32();
-    constexpr int HS = 1024;                            // open-addressing table, <= 255 live keys
-    int32_t key[HS];
-    int16_t slot[HS];
-    for (int i = 0; i < HS; ++i) slot[i] = -1;
+    if (!g_opt.csr_offset_dict || hcnt[0] > 255) return sliced32();
     std::vector<int32_t> dict;
-    std::vector<uint8_t> code((size_t)nnz + 32, 0);
-    for (int32_t i = 0; i < n; ++i) {
-        for (int64_t k = ptr[i] - base; k < ptr[i + 1] - base; ++k) {
-            const int32_t off = (col[k] - base) - i;
-            uint32_t h = ((uint32_t)off * 2654435761u) >> 22;      // 10 bits
-            for (;;) {
-                if (slot[h] < 0) {
-                    if (dict.size() == 255) return sliced32();      // too many offsets: int32 kernels
-                    slot[h] = (int16_t)dict.size();
-                    key[h] = off;
-                    dict.push_back(off);
-                    break;
-                }
-                if (key[h] == off) break;
-                h = (h + 1) & (HS - 1);
-            }
-            code[(size_t)k] = (uint8_t)slot[h];
-        }
-    }
+    for (int32_t v : htab) if (v != kDictEmpty) dict.push_back(v);
+    std::sort(dict.begin(), dict.end());
     p.ndict = (int32_t)dict.size();
     dict.resize(256, 0);
-    SGM_TRY(dalloc(&p.code, code.size()));
+    SGM_TRY(dalloc(&p.code, (size_t)nnz + 32));
     SGM_TRY(dalloc(&p.dict, (size_t)256));
-    SGM_HIP(hipMemcpy(p.code, code.data(), code.size(), hipMemcpyHostToDevice));
-    SGM_HIP(hipMemcpy(p.dict, dict.data(), 256 * 4, hipMemcpyHostToDevice));
-    // sliced form (opt-in, built only while the option is on): short rows, few offsets, little padding
+    SGM_HIP(hipMemcpyAsync(p.dict, dict.data(), 256 * 4, hipMemcpyHostToDevice, st));
+    SGM_HIP(hipMemsetAsync(p.code + nnz, 0, 32, st));
+    // sliced form: short rows, few offsets, little padding
     const int W = p.max_row <= 3 ? 3 : p.max_row <= 5 ? 5 : p.max_row <= 7 ? 7 : 8;
-    if (g_opt.csr_sliced && p.ndict <= 15 && p.max_row >= 1 && p.max_row <= 8 && (double)W * n <= 1.25 * (double)nnz) {
-        const size_t rows_padded = ((size_t)n + kSlRows - 1) / kSlRows * kSlRows;
-        std::vector<uint32_t> sc(rows_padded, 0xffffffffu);
-        for (int32_t i = 0; i < n; ++i) {
-            uint32_t cw = 0xffffffffu;
-            int u = 0;
-            for (int64_t k = ptr[i] - base; k < ptr[i + 1] - base; ++k, ++u)
-                cw = (cw & ~(15u << (4 * u))) | ((uint32_t)code[(size_t)k] << (4 * u));
-            sc[(size_t)i] = cw;
-        }
+    const bool sliced = g_opt.csr_sliced && p.ndict <= 15 && p.max_row >= 1 && p.max_row <= 8 && (double)W * n <= 1.25 * (double)nnz;
+    size_t rows_padded = 0;
+    if (sliced) {
+        rows_padded = ((size_t)n + kSlRows - 1) / kSlRows * kSlRows;
         SGM_TRY(dalloc(&p.scode, rows_padded));
         SGM_TRY(dalloc(&p.sval, rows_padded * W));
-        SGM_HIP(hipMemcpy(p.scode, sc.data(), rows_padded * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_fill32, dim3(vec_grid(rows_padded)), dim3(256), 0, st, (int64_t)rows_padded,
+                           reinterpret_cast<int32_t *>(p.scode), (int32_t)-1);
         p.sw = W;
-        SGM_TRY(pack_sliced(p));
     }
+    hipLaunchKernelGGL(k_dict_encode, dim3(grid), dim3(256), 0, st, n, (const int32_t *)p.rowptr, (const int32_t *)p.col,
+                       (const int32_t *)p.dict, p.ndict, p.code, sliced ? p.scode : nullptr);
+    SGM_HIP(hipGetLastError());
+    if (sliced) SGM_TRY(pack_sliced(p));
+    SGM_HIP(hipStreamSynchronize(st));       // `dict` (host staging of the upload) goes out of scope
     return SGM_OK;
 }
 
