@@ -1241,62 +1241,97 @@ static int build_offset_dict(Part &p, const int32_t *, const int32_t *)
 // ELLPACK twin of build_offset_dict: codes for ALL max_d slots of every row (padding slots
 // carry the last neighbour, so their offsets are already in the dictionary), row-major with
 // the row padded to 4 / 8 / 16 bytes.  Skipped for max_d > 16 or > 255 distinct offsets.
+// (device kernels of the ELLPACK twin: offsets of ALL max_d slots, slot-major columns)
+__global__ __launch_bounds__(256) void k_ell_dict_collect(int32_t n, int32_t max_d, const int32_t *__restrict__ ecol, int32_t *table,
+                                                          int *count)
+{
+    __shared__ int32_t seen[64];
+    if (threadIdx.x < 64) seen[threadIdx.x] = kDictEmpty;
+    __syncthreads();
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        for (int32_t k = 0; k < max_d; ++k) {
+            const int32_t off = ecol[(int64_t)k * n + i] - i;
+            const uint32_t hs = ((uint32_t)off * 2654435761u) >> 26;
+            if (seen[hs] == off) continue;
+            if (*(volatile int *)count > 255) return;
+            uint32_t h = ((uint32_t)off * 2654435761u) >> 22;
+            for (int probe = 0; probe < kDictSlots; ++probe) {
+                const int32_t prev = atomicCAS(&table[h], kDictEmpty, off);
+                if (prev == kDictEmpty) { atomicAdd(count, 1); break; }
+                if (prev == off) break;
+                h = (h + 1) & (kDictSlots - 1);
+            }
+            seen[hs] = off;
+        }
+}
+__global__ __launch_bounds__(256) void k_ell_dict_encode(int32_t n, int32_t max_d, int32_t mdp, const int32_t *__restrict__ ecol,
+                                                         const int32_t *__restrict__ dict, int ndict, uint8_t *__restrict__ ecode,
+                                                         uint32_t *__restrict__ scode)
+{
+    __shared__ int32_t dl[256];
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) dl[t] = t < ndict ? dict[t] : INT32_MAX;
+    __syncthreads();
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t cw = 0xffffffffu;
+        for (int32_t k = 0; k < max_d; ++k) {
+            const int32_t off = ecol[(int64_t)k * n + i] - i;
+            int lo = 0, hi = ndict - 1;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (dl[mid] < off) lo = mid + 1; else hi = mid; }
+            ecode[(int64_t)i * mdp + k] = (uint8_t)lo;
+            if (scode && k < 8) cw = (cw & ~(15u << (4 * k))) | ((uint32_t)lo << (4 * k));
+        }
+        if (scode) scode[i] = cw;
+    }
+}
+
 static int build_ell_offset_dict(Part &p)
 {
     if (p.n == 0 || p.max_d == 0 || p.max_d > 16) return SGM_OK;
-    const size_t total = (size_t)p.n * p.max_d;
-    std::vector<int32_t> hc(total);
-    SGM_HIP(hipStreamSynchronize(g_rt.stream));
-    SGM_HIP(hipMemcpy(hc.data(), p.ecol, total * 4, hipMemcpyDeviceToHost));
-    const int mdp = p.max_d <= 4 ? 4 : p.max_d <= 8 ? 8 : 16;
-    std::vector<uint8_t> code((size_t)p.n * mdp + 16, 0);
+    hipStream_t st = g_rt.stream;
+    int32_t *table = nullptr;
+    int *cnt = nullptr;
+    SGM_TRY(dalloc(&table, (size_t)kDictSlots));
+    SGM_TRY(dalloc(&cnt, 1));
+    hipLaunchKernelGGL(k_fill32, dim3(kDictSlots / 256), dim3(256), 0, st, (int64_t)kDictSlots, table, kDictEmpty);
+    SGM_HIP(hipMemsetAsync(cnt, 0, sizeof(int), st));
+    const int grid = (int)std::min<int64_t>(((int64_t)p.n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_ell_dict_collect, dim3(grid), dim3(256), 0, st, p.n, p.max_d, (const int32_t *)p.ecol, table, cnt);
+    std::vector<int32_t> htab(kDictSlots);
+    int hcnt = 0;
+    SGM_HIP(hipMemcpyAsync(htab.data(), table, kDictSlots * 4, hipMemcpyDeviceToHost, st));
+    SGM_HIP(hipMemcpyAsync(&hcnt, cnt, sizeof hcnt, hipMemcpyDeviceToHost, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    dfree(table); dfree(cnt);
+    if (hcnt > 255) return SGM_OK;              // too many offsets: the int32 slot-major kernel
     std::vector<int32_t> dict;
-    constexpr int HS = 1024;
-    int32_t key[HS];
-    int16_t slot[HS];
-    for (int i = 0; i < HS; ++i) slot[i] = -1;
-    for (int32_t i = 0; i < p.n; ++i)
-        for (int32_t k = 0; k < p.max_d; ++k) {
-            const int32_t off = hc[(size_t)k * p.n + i] - i;
-            uint32_t h = ((uint32_t)off * 2654435761u) >> 22;
-            for (;;) {
-                if (slot[h] < 0) {
-                    if (dict.size() == 255) return SGM_OK;
-                    slot[h] = (int16_t)dict.size();
-                    key[h] = off;
-                    dict.push_back(off);
-                    break;
-                }
-                if (key[h] == off) break;
-                h = (h + 1) & (HS - 1);
-            }
-            code[(size_t)i * mdp + k] = (uint8_t)slot[h];
-        }
+    for (int32_t v : htab) if (v != kDictEmpty) dict.push_back(v);
+    std::sort(dict.begin(), dict.end());
+    const int ndict = (int)dict.size();
     dict.resize(256, 0);
-    SGM_TRY(dalloc(&p.ecode, code.size()));
+    const int mdp = p.max_d <= 4 ? 4 : p.max_d <= 8 ? 8 : 16;
+    const size_t code_bytes = (size_t)p.n * mdp + 16;
+    SGM_TRY(dalloc(&p.ecode, code_bytes));
     if (!p.dict) SGM_TRY(dalloc(&p.dict, (size_t)256));
-    SGM_HIP(hipMemcpy(p.ecode, code.data(), code.size(), hipMemcpyHostToDevice));
-    SGM_HIP(hipMemcpy(p.dict, dict.data(), 256 * 4, hipMemcpyHostToDevice));
+    SGM_HIP(hipMemsetAsync(p.ecode, 0, code_bytes, st));
+    SGM_HIP(hipMemcpyAsync(p.dict, dict.data(), 256 * 4, hipMemcpyHostToDevice, st));
     p.emdp = mdp;
     // sliced form (see k_csr_sl): every one of the max_d slots is an entry (padding slots keep their
     // 0.0 * x(last neighbour) term, like the reference), so the CSR kernel applies as it is
-    const int ndict = (int)std::count_if(slot, slot + HS, [](int16_t v) { return v >= 0; });
-    if (g_opt.csr_sliced && ndict <= 15 && p.max_d >= 1 && p.max_d <= 8) {
+    const bool sliced = g_opt.csr_sliced && ndict <= 15 && p.max_d >= 1 && p.max_d <= 8;
+    if (sliced) {
         const int W = p.max_d <= 3 ? 3 : p.max_d <= 5 ? 5 : p.max_d <= 7 ? 7 : 8;
         const size_t rows_padded = ((size_t)p.n + kSlRows - 1) / kSlRows * kSlRows;
-        std::vector<uint32_t> sc(rows_padded, 0xffffffffu);
-        for (int32_t i = 0; i < p.n; ++i) {
-            uint32_t cw = 0xffffffffu;
-            for (int32_t k = 0; k < p.max_d; ++k)
-                cw = (cw & ~(15u << (4 * k))) | ((uint32_t)code[(size_t)i * mdp + k] << (4 * k));
-            sc[(size_t)i] = cw;
-        }
         SGM_TRY(dalloc(&p.scode, rows_padded));
         SGM_TRY(dalloc(&p.sval, rows_padded * W));
-        SGM_HIP(hipMemcpy(p.scode, sc.data(), rows_padded * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_fill32, dim3(vec_grid(rows_padded)), dim3(256), 0, st, (int64_t)rows_padded,
+                           reinterpret_cast<int32_t *>(p.scode), (int32_t)-1);
         p.sw = W;
-        SGM_TRY(pack_sliced(p));
     }
+    hipLaunchKernelGGL(k_ell_dict_encode, dim3(grid), dim3(256), 0, st, p.n, p.max_d, mdp, (const int32_t *)p.ecol,
+                       (const int32_t *)p.dict, ndict, p.ecode, sliced ? p.scode : nullptr);
+    SGM_HIP(hipGetLastError());
+    if (sliced) SGM_TRY(pack_sliced(p));
+    SGM_HIP(hipStreamSynchronize(st));
     return SGM_OK;
 }
 
