@@ -19,6 +19,8 @@
 // on one XCD).  Algorithmic bytes per SpMV: 12*nnz + 4*(n+1) + 8*m + 8*n.
 #include "sgm_internal.hpp"
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 #include <cstdlib>
 #include <string>
@@ -1438,6 +1440,53 @@ __global__ void k_gather_perm(double *__restrict__ dst, const double *__restrict
 // sort, stable in (j, k)), so y(i) is a ROW SUM over the same terms in the same order and the
 // ordinary SpMV kernels apply (for matvec_t_add the sum is chained onto y(i), bit for bit
 // like the scatter).  ELLPACK padding slots are kept (they add val=0 * x(j) like the reference).
+// keys (= column of the entry) and source indices of all entries in (row j, slot k) order
+__global__ void k_tr_keys_csr(int32_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                              int32_t *__restrict__ key, int32_t *__restrict__ src, int32_t *__restrict__ rowid,
+                              int32_t *__restrict__ count)
+{
+    const int32_t j = (int32_t)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j >= n) return;
+    for (int32_t k = rowptr[j] + lane; k < rowptr[j + 1]; k += 64) {
+        key[k] = col[k];
+        src[k] = k;
+        rowid[k] = j + 1;                        // 1-based row of A = column index in A^T
+        atomicAdd(&count[col[k]], 1);
+    }
+}
+__global__ void k_tr_keys_ell(int32_t n, int32_t max_d, const int32_t *__restrict__ ecol, int32_t *__restrict__ key,
+                              int32_t *__restrict__ src, int32_t *__restrict__ rowid, int32_t *__restrict__ count)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // t = j*max_d + k
+    if (t >= (int64_t)n * max_d) return;
+    const int32_t j = (int32_t)(t / max_d), k = (int32_t)(t % max_d);
+    const int64_t s = (int64_t)k * n + j;                                   // slot-major device layout
+    const int32_t c = ecol[s];
+    key[t] = c;
+    src[t] = (int32_t)s;
+    rowid[t] = j + 1;
+    atomicAdd(&count[c], 1);
+}
+__global__ void k_tr_gather_rows(int64_t nnz, int64_t stride_t, int32_t max_d, int32_t n_src, const int32_t *__restrict__ src_sorted,
+                                 const int32_t *__restrict__ rowid, int32_t *__restrict__ tnode)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < nnz; i += stride) {
+        const int32_t s = src_sorted[i];
+        // CSR: rowid is indexed by the entry; ELLPACK: by t = j*max_d + k with s = k*n + j
+        tnode[i] = max_d ? rowid[(int64_t)(s % n_src) * max_d + s / n_src] : rowid[s];
+    }
+    (void)stride_t;
+}
+__global__ void k_inc1(int64_t n, int32_t *a)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) a[i] += 1;
+}
+
 static int ensure_transpose(sgm_mat A)
 {
     if (A->distributed()) return fail(SGM_ERR_UNSUPPORTED, "matvec_t: not available on a row-partitioned matrix");
@@ -1445,48 +1494,63 @@ static int ensure_transpose(sgm_mat A)
     const bool ell = A->fmt == SGM_FMT_ELL;
     const int64_t nnz = ell ? (int64_t)p.n * p.max_d : p.nnz;
     if (!A->T) {
-        std::vector<int32_t> hp, hc((size_t)std::max<int64_t>(nnz, 1));
-        SGM_HIP(hipStreamSynchronize(g_rt.stream));
-        if (!ell) {
-            hp.resize((size_t)p.n + 1);
-            SGM_HIP(hipMemcpy(hp.data(), p.rowptr, hp.size() * 4, hipMemcpyDeviceToHost));
-            if (nnz) SGM_HIP(hipMemcpy(hc.data(), p.col, (size_t)nnz * 4, hipMemcpyDeviceToHost));
-        } else if (nnz) {
-            SGM_HIP(hipMemcpy(hc.data(), p.ecol, (size_t)nnz * 4, hipMemcpyDeviceToHost));
-        }
+        // A^T on the device: a STABLE radix sort of the entries by column (hipCUB) keeps them in
+        // (row j, slot k) order inside every column, which is the order the reference's scatter adds
+        // them in; the column histogram's prefix sum is A^T's row pointer.
+        hipStream_t st = g_rt.stream;
         const int32_t nt = A->ncol;                        // rows of A^T
-        std::vector<int32_t> tptr((size_t)nt + 1, 0), tnode((size_t)std::max<int64_t>(nnz, 1)), perm(tnode.size());
-        for (int64_t k = 0; k < nnz; ++k) tptr[(size_t)hc[k] + 1]++;
-        for (int32_t c = 0; c < nt; ++c) tptr[c + 1] += tptr[c];
-        std::vector<int32_t> cur(tptr.begin(), tptr.end() - 1);
-        for (int32_t j = 0; j < p.n; ++j) {
-            if (!ell) {
-                for (int32_t k = hp[j]; k < hp[j + 1]; ++k) {
-                    const int32_t pos = cur[hc[k]]++;
-                    tnode[pos] = j + 1;
-                    perm[pos] = k;
+        const size_t m = (size_t)std::max<int64_t>(nnz, 1);
+        int32_t *key = nullptr, *src = nullptr, *rowid = nullptr, *key2 = nullptr, *src2 = nullptr, *tptr = nullptr, *tnode = nullptr;
+        double *zeros = nullptr;
+        void *tmp = nullptr;
+        size_t tb_sort = 0, tb_scan = 0;
+        int rc = dalloc(&key, m);
+        if (rc == SGM_OK) rc = dalloc(&src, m);
+        if (rc == SGM_OK) rc = dalloc(&rowid, m);
+        if (rc == SGM_OK) rc = dalloc(&key2, m);
+        if (rc == SGM_OK) rc = dalloc(&src2, m);
+        if (rc == SGM_OK) rc = dalloc(&tptr, (size_t)nt + 2);
+        if (rc == SGM_OK) rc = dalloc(&tnode, m);
+        if (rc == SGM_OK) rc = dalloc(&zeros, m);
+        if (rc == SGM_OK) {
+            int end_bit = 1;
+            while (end_bit < 31 && (1ll << end_bit) <= (int64_t)nt) ++end_bit;
+            (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb_sort, key, key2, src, src2, (int)std::min<int64_t>(nnz, INT32_MAX), 0, end_bit, st);
+            (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb_scan, tptr, tptr, nt + 1, st);
+            if (hipMalloc(&tmp, std::max<size_t>(std::max(tb_sort, tb_scan), 16)) != hipSuccess) rc = fail(SGM_ERR_HIP, "matvec_t: sort workspace");
+            if (rc == SGM_OK) {
+                (void)hipMemsetAsync(tptr, 0, ((size_t)nt + 2) * 4, st);
+                (void)hipMemsetAsync(zeros, 0, m * 8, st);
+                if (nnz) {
+                    if (!ell)
+                        hipLaunchKernelGGL(k_tr_keys_csr, dim3((unsigned)(((int64_t)p.n * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                                           p.n, (const int32_t *)p.rowptr, (const int32_t *)p.col, key, src, rowid, tptr);
+                    else
+                        hipLaunchKernelGGL(k_tr_keys_ell, dim3((unsigned)((nnz + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, p.n, p.max_d,
+                                           (const int32_t *)p.ecol, key, src, rowid, tptr);
+                    (void)hipcub::DeviceRadixSort::SortPairs(tmp, tb_sort, key, key2, src, src2, (int)nnz, 0, end_bit, st);
+                    hipLaunchKernelGGL(k_tr_gather_rows, dim3(vec_grid(nnz)), dim3(kBlock), 0, st, nnz, (int64_t)0, ell ? p.max_d : 0, p.n,
+                                       (const int32_t *)src2, (const int32_t *)rowid, tnode);
                 }
-            } else {
-                for (int32_t k = 0; k < p.max_d; ++k) {
-                    const int64_t src = (int64_t)k * p.n + j;          // slot-major device layout
-                    const int32_t pos = cur[hc[src]]++;
-                    tnode[pos] = j + 1;
-                    perm[pos] = (int32_t)src;
-                }
+                (void)hipcub::DeviceScan::ExclusiveSum(tmp, tb_scan, tptr, tptr, nt + 1, st);
+                hipLaunchKernelGGL(k_inc1, dim3(vec_grid(nt + 1)), dim3(kBlock), 0, st, (int64_t)nt + 1, tptr);     // 1-based, like the reference
+                if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(SGM_ERR_HIP, "matvec_t: transpose build failed");
             }
         }
-        for (auto &v : tptr) v += 1;
-        std::vector<double> zeros((size_t)std::max<int64_t>(nnz, 1), 0.0);
-        sgm_mat T = new sgm_mat_s;
-        T->fmt = SGM_FMT_CSR;
-        T->nrow = A->ncol;
-        T->ncol = A->nrow;
-        T->nnz = nnz;
-        T->parts.resize(1);
-        int rc = build_csr_part(T->parts[0], T->nrow, T->ncol, 0, nnz, tptr.data(), tnode.data(), zeros.data(), SGM_HOST);
-        if (rc == SGM_OK) rc = dalloc(&A->tperm, (size_t)std::max<int64_t>(nnz, 1));
-        if (rc != SGM_OK) { sgm_mat_destroy(T); return rc; }
-        if (nnz) SGM_HIP(hipMemcpy(A->tperm, perm.data(), (size_t)nnz * 4, hipMemcpyHostToDevice));
+        sgm_mat T = nullptr;
+        if (rc == SGM_OK) {
+            T = new sgm_mat_s;
+            T->fmt = SGM_FMT_CSR;
+            T->nrow = A->ncol;
+            T->ncol = A->nrow;
+            T->nnz = nnz;
+            T->parts.resize(1);
+            rc = build_csr_part(T->parts[0], T->nrow, T->ncol, 0, nnz, tptr, tnode, zeros, SGM_DEVICE);
+        }
+        if (tmp) (void)hipFree(tmp);
+        dfree(key); dfree(src); dfree(rowid); dfree(key2); dfree(tptr); dfree(tnode); dfree(zeros);
+        if (rc != SGM_OK) { dfree(src2); if (T) sgm_mat_destroy(T); return rc; }
+        A->tperm = src2;                                   // entry of A behind every entry of A^T
         A->T = T;
         A->t_stale = true;
     }
