@@ -1436,7 +1436,7 @@ __global__ void k_gather_perm(double *__restrict__ dst, const double *__restrict
 // Transpose products (linear_operator_interface.f90:199-208 -> csc_matvec_add
 // cs_matrices.f90:627-647 / ellpack_matvec_t_add ellpack_matrices.f90:670-693).  The reference
 // scatters y(node(k)) += val(k)*x(j) for j = 1..n, k in stored order; a scatter needs atomics
-// on a GPU and would lose the summation order.  Instead A^T is built once (host counting
+// on a GPU and would lose the summation order.  Instead A^T is built once (device radix
 // sort, stable in (j, k)), so y(i) is a ROW SUM over the same terms in the same order and the
 // ordinary SpMV kernels apply (for matvec_t_add the sum is chained onto y(i), bit for bit
 // like the scatter).  ELLPACK padding slots are kept (they add val=0 * x(j) like the reference).
