@@ -354,6 +354,108 @@ def _banded_short_rows(n, seed, wmax=8, noffs=15):
     return ptr, node, val
 
 
+def _random_csr(rs, kind):
+    """Random CSR arrays (1-based) of a given flavour; duplicates inside a row are allowed."""
+    n = int(rs.choice([1, 2, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1000, 2049, 3001]))
+    m = int(rs.choice([n, n, max(1, n // 2), n + 17]))
+    if kind == "banded":                  # few offsets, short rows: 4-bit sliced form
+        w = int(rs.choice([1, 2, 3, 5, 7, 8]))
+        offs = np.sort(rs.choice(np.arange(-9, 10), size=min(w + 2, 15), replace=False))
+        deg = np.where(rs.rand(n) < 0.9, w, rs.randint(0, w + 1, size=n))
+        rows = np.repeat(np.arange(n), deg)
+        cols = rows + offs[rs.randint(0, len(offs), size=rows.size)]
+        cols = np.clip(cols, 0, m - 1)
+    elif kind == "many_offsets":          # more than 15 but fewer than 256 offsets: 1-byte codes
+        deg = rs.randint(0, 12, size=n)
+        rows = np.repeat(np.arange(n), deg)
+        cols = np.clip(rows + rs.randint(-60, 61, size=rows.size), 0, m - 1)
+    elif kind == "short_random":          # arbitrary columns, rows <= 16: int32 sliced form
+        w = int(rs.choice([3, 6, 8, 11, 16]))
+        deg = np.where(rs.rand(n) < 0.9, w, rs.randint(0, w + 1, size=n))
+        rows = np.repeat(np.arange(n), deg)
+        cols = rs.randint(0, m, size=rows.size)
+    else:                                 # ragged: empty rows and long rows
+        deg = rs.randint(0, 6, size=n)
+        deg[rs.randint(0, n, size=max(1, n // 50))] = rs.randint(40, 3000)
+        rows = np.repeat(np.arange(n), deg)
+        cols = rs.randint(0, m, size=rows.size)
+    ptr = np.concatenate([[1], 1 + np.cumsum(deg)]).astype(np.int32)
+    return n, m, ptr, (cols + 1).astype(np.int32), rs.standard_normal(rows.size)
+
+
+@pytest.mark.parametrize("kind", ["banded", "many_offsets", "short_random", "ragged"])
+def test_randomised_matrices_every_kernel_vs_oracle(orc, kind):
+    """Seeded random matrices of four flavours (sizes around the 64 / 256 / 512-row block edges,
+    rectangular, empty and duplicate entries), every kernel combination: matvec, y += A x and both
+    transpose products equal the oracle bit for bit."""
+    rs = np.random.RandomState({"banded": 1, "many_offsets": 2, "short_random": 3, "ragged": 4}[kind])
+    kernels = set()
+    for _trial in range(12):
+        n, m, ptr, node, val = _random_csr(rs, kind)
+        A = orc.CsrMatrix(n, m, ptr, node, val)
+        x, y0 = rs.standard_normal(m), rs.standard_normal(n)
+        xt, t0 = rs.standard_normal(n), rs.standard_normal(m)
+        y_ref, ya_ref = A.matvec(x), A.matvec_add(x, y0.copy())
+        t_ref, ta_ref = A.matvec_t(xt), A.matvec_t_add(xt, t0.copy())
+        for dict_opt, sl_opt, ro_opt, _tag in KERNEL_COMBOS:
+            _kernel_options(dict_opt, sl_opt, ro_opt)
+            try:
+                H = sg.csr_matrix(n, m, ptr, node, val)
+                kernels.add(H.kernel.split("<")[0] + ("CW4" if "CW=4" in H.kernel else ""))
+                y = np.zeros(n)
+                H.matvec(x, y)
+                ya = y0.copy()
+                H.matvec_add(x, ya)
+                t = np.zeros(m)
+                H.matvec_t(xt, t)
+                ta = t0.copy()
+                H.matvec_t_add(xt, ta)
+            finally:
+                _kernel_options(1, 1, 1)
+            key = (kind, _trial, n, m, dict_opt, sl_opt, ro_opt)
+            assert np.array_equal(y, y_ref), key
+            assert np.array_equal(ya, ya_ref), key
+            assert np.array_equal(t, t_ref), key
+            assert np.array_equal(ta, ta_ref), key
+    expect = {"banded": "k_csr_sl", "many_offsets": "k_csr_do", "short_random": "k_csr_sl32", "ragged": "k_csr_spmv"}[kind]
+    assert expect in kernels, (kind, kernels)
+
+
+@pytest.mark.parametrize("nparts", [2, 3, 5])
+def test_randomised_partitions_vs_oracle(orc, nparts):
+    """Row partitions of seeded random banded / short-row matrices (halo lists, interior and boundary
+    ranges cut at slice boundaries, every kernel combination): matvec and y += A x bit for bit."""
+    rs = np.random.RandomState(100 + nparts)
+    for trial in range(6):
+        n = int(rs.choice([2000, 5121, 12000, 30001]))
+        w = int(rs.choice([3, 5, 8]))
+        reach = int(rs.choice([1, 40, 700]))
+        offs = np.unique(np.concatenate([[0], rs.randint(-reach, reach + 1, size=w + 3)]))
+        deg = np.where(rs.rand(n) < 0.9, w, rs.randint(0, w + 1, size=n))
+        rows = np.repeat(np.arange(n), deg)
+        cols = np.clip(rows + offs[rs.randint(0, len(offs), size=rows.size)], 0, n - 1)
+        if trial % 2:                     # arbitrary columns near the row: no dictionary
+            cols = np.clip(rows + rs.randint(-reach - 300, reach + 301, size=rows.size), 0, n - 1)
+        ptr = np.concatenate([[1], 1 + np.cumsum(deg)]).astype(np.int32)
+        node, val = (cols + 1).astype(np.int32), rs.standard_normal(rows.size)
+        A = orc.CsrMatrix(n, n, ptr, node, val)
+        starts = np.sort(np.concatenate([[0, n], rs.choice(np.arange(2, n - 2, 2), size=nparts - 1, replace=False)]))
+        x, y0 = rs.standard_normal(n), rs.standard_normal(n)
+        y_ref, ya_ref = A.matvec(x), A.matvec_add(x, y0.copy())
+        for dict_opt, sl_opt, ro_opt, _tag in KERNEL_COMBOS:
+            _kernel_options(dict_opt, sl_opt, ro_opt)
+            try:
+                H = sg.partitioned_csr_matrix(n, n, ptr, node, val, starts)
+                y = np.zeros(n)
+                H.matvec(x, y)
+                ya = y0.copy()
+                H.matvec_add(x, ya)
+            finally:
+                _kernel_options(1, 1, 1)
+            assert np.array_equal(y, y_ref), (trial, n, list(starts), dict_opt, sl_opt, ro_opt)
+            assert np.array_equal(ya, ya_ref), (trial, n, list(starts), dict_opt, sl_opt, ro_opt)
+
+
 @pytest.mark.parametrize("n,wmax", [(1, 3), (511, 5), (513, 8), (40001, 12), (70003, 16)])
 def test_sliced_int32_kernel_short_rows_without_dictionary(orc, n, wmax):
     """Rows of 0..16 entries at ARBITRARY columns (more than 255 distinct offsets: no dictionary):
