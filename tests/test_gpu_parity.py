@@ -421,6 +421,53 @@ def test_randomised_matrices_every_kernel_vs_oracle(orc, kind):
     assert expect in kernels, (kind, kernels)
 
 
+@pytest.mark.parametrize("max_d", [1, 3, 4, 5, 8, 9, 16, 20])
+def test_randomised_ellpack_every_kernel_vs_oracle(orc, max_d):
+    """Seeded random ELLPACK matrices (banded with few offsets, or arbitrary columns; rows of 1..max_d
+    neighbours, padded the reference's way by EllMatrix.from_edges) through the sliced kernel, the
+    1-byte-code kernel and the plain slot-major kernel: matvec, y += A x, both transpose products."""
+    rs = np.random.RandomState(50 + max_d)
+    for trial in range(6):
+        n = int(rs.choice([1, 64, 257, 512, 1000, 4097]))
+        banded = trial % 2 == 0
+        deg = np.where(rs.rand(n) < 0.8, max_d, rs.randint(1, max_d + 1, size=n))
+        deg[rs.randint(0, n)] = max_d
+        ei, ej = [], []
+        for i in range(n):
+            pool = np.clip(i + np.arange(-12, 13), 0, n - 1) if banded else np.arange(n)
+            pool = np.unique(pool)
+            k = min(int(deg[i]), len(pool))
+            cols = rs.choice(pool, size=k, replace=False)
+            ei.append(np.full(k, i + 1)); ej.append(cols + 1)
+        ei, ej = np.concatenate(ei).astype(np.int32), np.concatenate(ej).astype(np.int32)
+        ev = rs.standard_normal(ei.size)
+        A = orc.EllMatrix.from_edges(n, n, ei, ej, ev)
+        x, y0 = rs.standard_normal(n), rs.standard_normal(n)
+        y_ref, ya_ref = A.matvec(x), A.matvec_add(x, y0.copy())
+        t_ref, ta_ref = A.matvec_t(x), A.matvec_t_add(x, y0.copy())
+        for opt, sl in ((1, 1), (1, 0), (0, 1)):
+            sg.set_option("ell_offset_dict", opt)
+            sg.set_option("csr_sliced", sl)
+            try:
+                H = sg.ellpack_matrix(n, n, A.node, A.val)
+                y = np.zeros(n)
+                H.matvec(x, y)
+                ya = y0.copy()
+                H.matvec_add(x, ya)
+                t = np.zeros(n)
+                H.matvec_t(x, t)
+                ta = y0.copy()
+                H.matvec_t_add(x, ta)
+            finally:
+                sg.set_option("ell_offset_dict", 1)
+                sg.set_option("csr_sliced", 1)
+            key = (max_d, trial, n, banded, opt, sl)
+            assert np.array_equal(y, y_ref), key
+            assert np.array_equal(ya, ya_ref), key
+            assert np.array_equal(t, t_ref), key
+            assert np.array_equal(ta, ta_ref), key
+
+
 @pytest.mark.parametrize("nparts", [2, 3, 5])
 def test_randomised_partitions_vs_oracle(orc, nparts):
     """Row partitions of seeded random banded / short-row matrices (halo lists, interior and boundary
