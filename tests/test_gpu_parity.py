@@ -817,6 +817,51 @@ def test_ildu_ring_walker_every_width_class_vs_oracle(orc, nx, ny):
     assert np.array_equal(z, ref.solve(b2))
 
 
+@pytest.mark.parametrize("flavour", ["banded", "blocks", "arrowhead", "sparse_random"])
+def test_randomised_ildu_factor_and_apply_vs_oracle(orc, flavour):
+    """Seeded random structurally-symmetric, diagonally dominant matrices: long narrow dependency
+    chains (banded), many independent blocks (few wide levels), rows with more than four lower
+    entries (the generic walker and the record overflow path), irregular sparsity -- factors and two
+    applies bit for bit against the oracle's sequential sweeps."""
+    rs = np.random.RandomState({"banded": 11, "blocks": 12, "arrowhead": 13, "sparse_random": 14}[flavour])
+    for trial in range(4):
+        n = int(rs.choice([300, 2000, 9000, 30000]))
+        if flavour == "banded":
+            offs = np.unique(rs.randint(1, 6, size=3))
+            pairs = [(i, i - o) for o in offs for i in range(o, n) if rs.rand() < 0.9]
+        elif flavour == "blocks":
+            bl = int(rs.choice([3, 5, 8]))
+            pairs = [(i, i - 1) for i in range(1, n) if i % bl and rs.rand() < 0.95]
+        elif flavour == "arrowhead":      # every row couples to up to 7 earlier rows nearby
+            pairs = [(i, j) for i in range(1, n) for j in set(rs.randint(max(0, i - 40), i, size=min(i, 7)).tolist())]
+        else:
+            m = 3 * n
+            a, b = rs.randint(0, n, size=m), rs.randint(0, n, size=m)
+            pairs = list({(max(i, j), min(i, j)) for i, j in zip(a, b) if i != j})
+        lo = np.array(pairs, dtype=np.int64).reshape(-1, 2)
+        v = -rs.rand(len(lo)) - 0.1
+        rows = np.concatenate([lo[:, 0], lo[:, 1], np.arange(n)])
+        cols = np.concatenate([lo[:, 1], lo[:, 0], np.arange(n)])
+        vals = np.concatenate([v, v, np.zeros(n)])
+        order = rs.permutation(len(rows))                 # insertion order is arbitrary
+        rows, cols, vals = rows[order], cols[order], vals[order]
+        dsum = np.zeros(n)
+        np.add.at(dsum, rows, np.abs(vals))
+        vals[rows == cols] = dsum[rows[rows == cols]] + 1.0 + rs.rand(n)[rows[rows == cols]]
+        A = orc.CsrMatrix.from_edges(n, n, (rows + 1).astype(np.int32), (cols + 1).astype(np.int32), vals)
+        ref = orc.Ildu(A)
+        H = hip_from_oracle(A)
+        pc = sg.ldu()
+        pc.setup(H)
+        assert np.array_equal(pc.get("D", np.float64), ref.D)
+        assert np.array_equal(pc.get("Lval", np.float64), ref.Lval) and np.array_equal(pc.get("Uval", np.float64), ref.Uval)
+        for k in range(2):
+            b = rs.standard_normal(n)
+            z = np.zeros(n)
+            pc.solve(H, z, b)
+            assert np.array_equal(z, ref.solve(b)), (flavour, trial, n, k)
+
+
 # ------------------------------------------------------------------------- re-orderings
 @pytest.mark.parametrize("name", perm_golden_names())
 def test_reorderings_and_permuted_matrix_golden_bit_exact(golden, name):
