@@ -68,7 +68,7 @@ inline void dfree(void *p) { if (p) (void)hipFree(p); }
 
 // ------------------------------------------------------------------ launch geometry
 constexpr int kBlock = 256;          // 4 waves of 64
-constexpr int kMaxGrid = 4096;       // partial-sum slots per dot (>= the largest grid)
+constexpr int kMaxGrid = 8192;       // partial-sum slots per dot (>= the largest grid)
 
 inline int vec_grid(int64_t n)
 {

@@ -683,7 +683,9 @@ static int grid_for_rows(const Part &p, int64_t rows, int64_t limit)
     const int64_t nrb = (rows + blk - 1) / blk;
     int64_t g = ((nrb + 7) / 8) * 8;
     int64_t cap = c.maxgrid;
-    if (cap <= 0 && any_sliced(p)) cap = kMaxGrid;          // round-robin slices, not a persistent resident grid
+    // round-robin slices, not a persistent resident grid: 4096 workgroups; 8192 from 65536 slices on
+    // (n >= 3.3e7: 464^3 1.54 -> 1.42 ms; below that the consumers' re-reduction of more partials costs more)
+    if (cap <= 0 && any_sliced(p)) cap = nrb >= 65536 ? kMaxGrid : kMaxGrid / 2;
     if (cap <= 0) cap = (int64_t)resident_per_cu(use_row_owner(p), c.block, use_row_owner(p) ? do_tile_for(p) : c.vpt,
                                                  use_offset_dict(p) ? 1 : 4) * g_rt.num_cu;
     if (cap > limit) cap = limit;
@@ -701,7 +703,7 @@ static int spmv_ranges(const Part &p, RowRange out[3])
     int nr = 0, off = 0;
     auto add = [&](int32_t lo, int32_t hi) {       // grids sum to <= kMaxGrid partial slots
         if (hi <= lo) return;
-        out[nr] = RowRange{lo, hi, grid_for_rows(p, hi - lo, nr == 0 ? kMaxGrid / 2 : kMaxGrid / 4), off};
+        out[nr] = RowRange{lo, hi, grid_for_rows(p, hi - lo, nr == 0 ? kMaxGrid / 4 : kMaxGrid / 8), off};
         off += out[nr].grid;
         ++nr;
     };
@@ -854,7 +856,7 @@ int ell_grid(const Part &p)
 {
     if (use_sliced_ell(p)) {           // k_csr_sl: 512-row slices round-robin over <= kMaxGrid workgroups
         const int64_t nsl = ((int64_t)p.n + kSlRows - 1) / kSlRows;
-        return (int)std::max<int64_t>(1, std::min<int64_t>(nsl, kMaxGrid));
+        return (int)std::max<int64_t>(1, std::min<int64_t>(nsl, nsl >= 65536 ? kMaxGrid : kMaxGrid / 2));
     }
     int64_t g = ((int64_t)p.n + kBlock - 1) / kBlock;
     int64_t cap = ell_cfg().grid;
