@@ -683,9 +683,9 @@ static int grid_for_rows(const Part &p, int64_t rows, int64_t limit)
     const int64_t nrb = (rows + blk - 1) / blk;
     int64_t g = ((nrb + 7) / 8) * 8;
     int64_t cap = c.maxgrid;
-    // round-robin slices, not a persistent resident grid: 4096 workgroups; 8192 from 65536 slices on
-    // (n >= 3.3e7: 464^3 1.54 -> 1.42 ms; below that the consumers' re-reduction of more partials costs more)
-    if (cap <= 0 && any_sliced(p)) cap = nrb >= 65536 ? kMaxGrid : kMaxGrid / 2;
+    // round-robin slices, not a persistent resident grid: 4096 workgroups; 8192 from 32768 slices on
+    // (n >= 1.7e7: 464^3 1.54 -> 1.45 ms, 300^3 355 -> 345 us; below that the consumers' re-reduction of more partials costs more)
+    if (cap <= 0 && any_sliced(p)) cap = nrb >= 32768 ? kMaxGrid : kMaxGrid / 2;
     if (cap <= 0) cap = (int64_t)resident_per_cu(use_row_owner(p), c.block, use_row_owner(p) ? do_tile_for(p) : c.vpt,
                                                  use_offset_dict(p) ? 1 : 4) * g_rt.num_cu;
     if (cap > limit) cap = limit;
@@ -856,7 +856,7 @@ int ell_grid(const Part &p)
 {
     if (use_sliced_ell(p)) {           // k_csr_sl: 512-row slices round-robin over <= kMaxGrid workgroups
         const int64_t nsl = ((int64_t)p.n + kSlRows - 1) / kSlRows;
-        return (int)std::max<int64_t>(1, std::min<int64_t>(nsl, nsl >= 65536 ? kMaxGrid : kMaxGrid / 2));
+        return (int)std::max<int64_t>(1, std::min<int64_t>(nsl, nsl >= 32768 ? kMaxGrid : kMaxGrid / 2));
     }
     int64_t g = ((int64_t)p.n + kBlock - 1) / kBlock;
     int64_t cap = ell_cfg().grid;
