@@ -553,7 +553,7 @@ def test_sliced_int32_kernel_short_rows_without_dictionary(orc, n, wmax):
     assert np.array_equal(y1, y)
 
 
-@pytest.mark.parametrize("n,wmax", [(1, 3), (255, 3), (256, 5), (257, 7), (70001, 8), (33333, 5)])
+@pytest.mark.parametrize("n,wmax", [(1, 3), (255, 3), (256, 5), (257, 7), (70001, 8), (33333, 5), (262147, 5), (1048573, 3)])
 def test_sliced_kernel_ragged_rows_nonfinite_and_updates(orc, n, wmax):
     """k_csr_sl on rows of 0..W entries, slices that end mid-block, duplicate columns, Inf/NaN in
     x (a missing slot must not contribute 0*Inf), y += A x, chained transpose sums, and a value
