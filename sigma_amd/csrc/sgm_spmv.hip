@@ -420,7 +420,13 @@ __global__ __launch_bounds__(256) void k_csr_sl32(
     const int64_t nsl = ((int64_t)n + kSlRows - 1) / kSlRows;
     double dwy = 0.0, dyy = 0.0;
 
-    for (int64_t sl = blockIdx.x; sl < nsl; sl += gridDim.x) {
+    int64_t first = blockIdx.x;             // XCD-block-cyclic slices, see k_csr_sl
+    if ((remap & 255) >= 3) {
+        const int G = (remap & 255) == 3 ? 8 : (remap & 255) == 4 ? 2 : 32;
+        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        first = (int64_t)(loc / G) * (8 * G) + xcd * G + loc % G;
+    }
+    for (int64_t sl = first; sl < nsl; sl += gridDim.x) {
         const int32_t row = (int32_t)(sl * kSlRows) + 2 * tid;
         const f64x2 *vb = reinterpret_cast<const f64x2 *>(sval + sl * (int64_t)(W * kSlRows)) + tid;
         const i32x2 *cb = reinterpret_cast<const i32x2 *>(scol + sl * (int64_t)(W * kSlRows)) + tid;
@@ -838,9 +844,12 @@ static void launch_csr_sl32(const Part &p, int grid, const double *x, double *y,
                             double *pwy, double *pyy, const int *flag, int gen)
 {
     hipStream_t st = g_rt.stream;
+    const SpmvCfg &c = spmv_cfg();
+    int mode = c.remap == 1 ? (grid <= kMaxGrid / 2 ? 5 : 0) : (c.remap >= 3 ? c.remap : 0);
+    if (mode >= 3 && grid % (8 * (mode == 3 ? 8 : mode == 4 ? 2 : 32)) != 0) mode = 0;
 #define L(WW, DW, DY)                                                                                     \
     hipLaunchKernelGGL((k_csr_sl32<WW, ADD, DW, DY>), dim3(grid), dim3(256), 0, st, p.n, p.scol, p.sval, x, y, \
-                       w, pwy, pyy, flag, gen, g_launch_flags)
+                       w, pwy, pyy, flag, gen, mode | g_launch_flags)
 #define LV(WW)                                \
     if (p.sw == WW) {                         \
         if (w && pyy) L(WW, true, true);      \
