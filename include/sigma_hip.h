@@ -163,6 +163,11 @@ int sgm_mat_right_permute(sgm_mat A, const int32_t *p, int where);
 /* name of the SpMV kernel variant the matrix runs with under the current options
  * (diagnostics for benches and tests; e.g. "k_csr_sl<W=5>", "k_csr_do<256,1536,CW=1>") */
 int sgm_mat_kernel(sgm_mat A, char *buf, int len);
+/* bytes by construction: what the handle keeps in HBM (every layout it holds), and what ONE
+ * y = A x moves with the kernel the current options select: that kernel's stored format as it
+ * reads it (padded slices, codes, row pointers) + every x entry once + every y entry once.
+ * bench.py grades the roofline fraction on matvec_bytes, not on the reference layout's bytes. */
+int sgm_mat_footprint(sgm_mat A, int64_t *resident_bytes, int64_t *matvec_bytes);
 int sgm_mat_destroy(sgm_mat A);
 
 /* ---- vector statements inline in the solvers (SURVEY §2a "dot", "axpy family") ---- *
@@ -256,6 +261,37 @@ int sgm_halo_plan_host(int32_t n_own, int64_t col_begin /* first owned global co
                        int64_t nnz, const int32_t *node_1based_global,
                        int32_t *node_1based_local_out, int32_t *halo_cols_out /* capacity nnz */,
                        int32_t *n_halo_out);
+/* The rest of the host-only planning that sgm_csr_create_dist / _partitioned run (no HIP call; the
+ * world_size-2 gloo test drives exactly these, exchanging the lists over gloo instead of RCCL):
+ * sgm_dist_plan_host       one rank's requests: want[q] = entries of its (sorted) halo list that
+ *                          rank q owns, want_off = their prefix sum (nranks+1: the run of halo
+ *                          entries owned by q), req[t] = index of halo entry t in ITS OWNER's local
+ *                          numbering (0-based) -- the list that owner gathers from when it sends.
+ * sgm_dist_neighbors_host  one rank's neighbour table from the all-gathered want matrix
+ *                          (want_all[q*nranks + r] = rank q's want[r]): per neighbour its rank,
+ *                          how many entries go to it / come from it, and where the received run
+ *                          starts inside this rank's halo region.  Arrays hold up to nranks-1.
+ * sgm_partition_links_host every (sender, receiver) link of an in-process partition, as
+ *                          sgm_csr_create_partitioned builds them: first call with sender = NULL
+ *                          for the sizes (n_links, idx_needed), then with arrays; idx_concat holds
+ *                          the senders' gather lists end to end (0-based local indices).
+ * sgm_partition_rows_by_nnz contiguous row blocks balanced by the bytes of B_csr they carry
+ *                          (12 per stored entry + 20 per row, SURVEY 8d/8e "balanced by nnz"),
+ *                          boundaries rounded to multiples of `align` rows (even; 512 keeps the
+ *                          sliced kernel's slices whole).  row_starts_out: nparts+1 entries.
+ * sgm_mat_halo_nbr         reads the exchange plan of a built matrix back (k < 0: only n_nbrs). */
+int sgm_dist_plan_host(int32_t rank, int32_t nranks, const int64_t *row_starts, int32_t n_halo,
+                       const int32_t *halo_cols_1based, int32_t *want, int32_t *want_off, int32_t *req);
+int sgm_dist_neighbors_host(int32_t rank, int32_t nranks, const int32_t *want_all, int32_t *peer,
+                            int32_t *send_count, int32_t *recv_count, int32_t *recv_offset, int32_t *n_nbrs);
+int sgm_partition_links_host(int32_t nparts, const int64_t *row_starts, const int32_t *ptr_1based,
+                             const int32_t *node_1based, int32_t *n_links, int32_t *sender, int32_t *receiver,
+                             int32_t *recv_offset, int32_t *count, int32_t *idx_concat, int64_t idx_capacity,
+                             int64_t *idx_needed);
+int sgm_partition_rows_by_nnz(int32_t nrow, const int32_t *ptr_1based, int32_t nparts, int32_t align,
+                              int64_t *row_starts_out);
+int sgm_mat_halo_nbr(sgm_mat A, int32_t part, int32_t k, int32_t *n_nbrs, int32_t *peer, int32_t *send_count,
+                     int32_t *recv_count, int32_t *recv_offset, int32_t *send_idx_host, int32_t capacity);
 
 #ifdef __cplusplus
 }

@@ -73,6 +73,12 @@ implicit none
         endif
     endif
 
+    if (infile(1:14) == 'gen:poisson2d:') then
+        ! no problem file: the driver lays down the nx x ny 5-point grid itself, edges in the
+        ! insertion order S,W,C,E,N of sigma_amd/problems.py (bench.py's cpu_baseline on the full
+        ! C2 workload: a 800 MB problem file would only add I/O to the sample)
+        call gen_poisson2d(infile(15:))
+    else
     open(unit=21, file=trim(infile), access='stream', form='unformatted', &
         & status='old')
     read(21) n, m, ne, fmt, nsolve
@@ -87,6 +93,7 @@ implicit none
         read(21) skind(s), pkind(s), tols(s)
     enddo
     close(21)
+    endif
 
     !------------------------------------------------------------------!
     ! Graph: same call sequence as test/solver_test_jacobi.f90:73-101   !
@@ -293,6 +300,45 @@ implicit none
     enddo
 
 contains
+
+    subroutine gen_poisson2d(spec)
+        character(len=*), intent(in) :: spec
+        integer :: nx, ny, ix, iy, row, c
+        c = index(spec, ':')
+        read(spec(1:c-1), *) nx
+        read(spec(c+1:), *) ny
+        n = nx * ny
+        m = n
+        fmt = 1
+        nsolve = 0
+        ne = 5 * n - 2 * nx - 2 * ny
+        allocate(ei(ne), ej(ne), ev(ne), x(m), b(n), y(n), u(n), z(n))
+        allocate(skind(0), pkind(0), tols(0))
+        k = 0
+        do iy = 1, ny
+            do ix = 1, nx
+                row = (iy - 1) * nx + ix
+                if (iy > 1) call put(row, row - nx, -1.0_dp)
+                if (ix > 1) call put(row, row - 1, -1.0_dp)
+                call put(row, row, 4.0_dp)
+                if (ix < nx) call put(row, row + 1, -1.0_dp)
+                if (iy < ny) call put(row, row + nx, -1.0_dp)
+            enddo
+        enddo
+        do row = 1, n
+            x(row) = sin(0.001_dp * row)
+        enddo
+        b = 1.0_dp / n
+    end subroutine gen_poisson2d
+
+    subroutine put(i, j, v)
+        integer, intent(in) :: i, j
+        real(dp), intent(in) :: v
+        k = k + 1
+        ei(k) = i
+        ej(k) = j
+        ev(k) = v
+    end subroutine put
 
     subroutine dump_i4(name, arr, cnt)
         character(len=*), intent(in) :: name

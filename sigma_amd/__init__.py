@@ -135,6 +135,16 @@ def _arg(a, dtype, writable=False):
     return C.c_void_p(arr.ctypes.data), SGM_HOST, arr
 
 
+def _len(a):
+    return int(a.numel()) if _is_torch(a) else int(np.asarray(a).size)
+
+
+def _need(a, n, what):
+    """The C ABI takes raw pointers: a short vector would be read or written out of bounds."""
+    if _len(a) < n:
+        raise SigmaError(2, f"{what}: vector has {_len(a)} entries, the operation needs {n}")
+
+
 def _same_where(*ws):
     if len(set(ws)) != 1:
         raise TypeError("all vectors of one call must live in the same place (host or device)")
@@ -151,13 +161,22 @@ class _Matrix:
         self.pc = None
 
     # -- linear_operator_interface.f90:185-194 ------------------------------------------
+    def _lens(self):
+        """(entries matvec reads from x, entries it writes to y): ncol / nrow, or owned+halo /
+        owned rows for a matrix distributed over processes."""
+        return self.x_len, getattr(self, "n_local", self.nrow)
+
     def matvec(self, x, y):
+        nx, ny = self._lens()
+        _need(x, nx, "matvec x"); _need(y, ny, "matvec y")
         px, wx, _k1 = _arg(x, np.float64)
         py, wy, _k2 = _arg(y, np.float64, writable=True)
         _ck(lib().sgm_mat_matvec(self._h, px, py, C.c_int(_same_where(wx, wy))))
         return y
 
     def matvec_add(self, x, y):
+        nx, ny = self._lens()
+        _need(x, nx, "matvec_add x"); _need(y, ny, "matvec_add y")
         px, wx, _k1 = _arg(x, np.float64)
         py, wy, _k2 = _arg(y, np.float64, writable=True)
         _ck(lib().sgm_mat_matvec_add(self._h, px, py, C.c_int(_same_where(wx, wy))))
@@ -165,22 +184,51 @@ class _Matrix:
 
     # -- linear_operator_interface.f90:199-208 ------------------------------------------
     def matvec_t(self, x, y):
+        _need(x, self.nrow, "matvec_t x"); _need(y, self.ncol, "matvec_t y")
         px, wx, _k1 = _arg(x, np.float64)
         py, wy, _k2 = _arg(y, np.float64, writable=True)
         _ck(lib().sgm_mat_matvec_t(self._h, px, py, C.c_int(_same_where(wx, wy))))
         return y
 
     def matvec_t_add(self, x, y):
+        _need(x, self.nrow, "matvec_t_add x"); _need(y, self.ncol, "matvec_t_add y")
         px, wx, _k1 = _arg(x, np.float64)
         py, wy, _k2 = _arg(y, np.float64, writable=True)
         _ck(lib().sgm_mat_matvec_t_add(self._h, px, py, C.c_int(_same_where(wx, wy))))
         return y
+
+    def halo_nbrs(self, part=0):
+        """Exchange plan of local part `part` (parity checks): list of dicts with peer, send_count,
+        recv_count, recv_offset and the send list (0-based local indices)."""
+        n = C.c_int32(0)
+        _ck(lib().sgm_mat_halo_nbr(self._h, C.c_int32(part), C.c_int32(-1), C.byref(n), None, None, None, None, None, C.c_int32(0)))
+        out = []
+        for k in range(n.value):
+            pe, sc, rc, ro = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+            _ck(lib().sgm_mat_halo_nbr(self._h, C.c_int32(part), C.c_int32(k), None, C.byref(pe), C.byref(sc), C.byref(rc),
+                                       C.byref(ro), None, C.c_int32(0)))
+            idx = np.zeros(sc.value, np.int32)
+            if sc.value:
+                _ck(lib().sgm_mat_halo_nbr(self._h, C.c_int32(part), C.c_int32(k), None, None, None, None, None,
+                                           C.c_void_p(idx.ctypes.data), C.c_int32(sc.value)))
+            out.append({"peer": pe.value, "send_count": sc.value, "recv_count": rc.value, "recv_offset": ro.value,
+                        "send_idx": idx})
+        return out
 
     @property
     def x_len(self):
         n = C.c_int64(0)
         _ck(lib().sgm_mat_info(self._h, None, None, None, None, C.byref(n)))
         return n.value
+
+    def footprint(self):
+        """(resident_bytes, matvec_bytes): what the handle keeps in HBM, and what one y = A x moves by
+        construction with the kernel the current options select (sgm_mat_footprint)."""
+        if hasattr(self, "_build"):
+            self._build()
+        r, m = C.c_int64(0), C.c_int64(0)
+        _ck(lib().sgm_mat_footprint(self._h, C.byref(r), C.byref(m)))
+        return r.value, m.value
 
     # -- src/graph/permutations.f90 + cs_matrices.f90:471-490 -----------------------------
     def bfs_order(self):
@@ -436,6 +484,7 @@ class _Preconditioner:
 
     def solve(self, A, x, b):
         """pc%solve(A, x, b): x = M^-1 b."""
+        _need(b, self.nn, "pc%solve b"); _need(x, self.nn, "pc%solve x")
         pb, wb, _k1 = _arg(b, np.float64)
         px, wx, _k2 = _arg(x, np.float64, writable=True)
         _ck(lib().sgm_pc_apply(self._h, pb, px, C.c_int(_same_where(wb, wx))))
@@ -525,6 +574,8 @@ class _Solver:
     def solve(self, A, x, b, pc=None, check=True):
         """solver%solve(A, x, b[, pc]): x holds the initial guess on entry, the solution on
         exit.  With set_max_iter, hitting the cap raises unless check=False."""
+        nloc = getattr(A, "n_local", A.nrow)
+        _need(x, nloc, "solve x"); _need(b, nloc, "solve b")
         px, wx, _k1 = _arg(x, np.float64, writable=True)
         pb, wb, _k2 = _arg(b, np.float64)
         rc = lib().sgm_solver_solve(self._h, A._h, px, pb, pc._h if pc is not None else None,
@@ -661,6 +712,63 @@ def halo_plan_host(n_own, col_begin, node_global):
                                  C.c_void_p(node.ctypes.data), C.c_void_p(out.ctypes.data),
                                  C.c_void_p(halo.ctypes.data), C.byref(nh)))
     return out, halo[:nh.value].copy()
+
+
+def dist_plan_host(rank, nranks, row_starts, halo_cols):
+    """sgm_dist_plan_host (no GPU needed): (want[nranks], want_off[nranks+1], req[len(halo)])."""
+    rs = np.ascontiguousarray(row_starts, np.int64)
+    halo = np.ascontiguousarray(halo_cols, np.int32)
+    want, off, req = np.zeros(nranks, np.int32), np.zeros(nranks + 1, np.int32), np.zeros(max(len(halo), 1), np.int32)
+    _ck(lib().sgm_dist_plan_host(C.c_int32(rank), C.c_int32(nranks), C.c_void_p(rs.ctypes.data), C.c_int32(len(halo)),
+                                 C.c_void_p(halo.ctypes.data), C.c_void_p(want.ctypes.data), C.c_void_p(off.ctypes.data),
+                                 C.c_void_p(req.ctypes.data)))
+    return want, off, req[:len(halo)].copy()
+
+
+def dist_neighbors_host(rank, nranks, want_all):
+    """sgm_dist_neighbors_host: list of (peer, send_count, recv_count, recv_offset) from the
+    all-gathered want matrix (row q = rank q's want)."""
+    wa = np.ascontiguousarray(want_all, np.int32).reshape(nranks, nranks)
+    arr = [np.zeros(max(nranks, 1), np.int32) for _ in range(4)]
+    n = C.c_int32(0)
+    _ck(lib().sgm_dist_neighbors_host(C.c_int32(rank), C.c_int32(nranks), C.c_void_p(wa.ctypes.data),
+                                      *[C.c_void_p(a.ctypes.data) for a in arr], C.byref(n)))
+    return [tuple(int(a[i]) for a in arr) for i in range(n.value)]
+
+
+def partition_links_host(row_starts, ptr, node):
+    """sgm_partition_links_host: the (sender, receiver, recv_offset, send list) links that
+    sgm_csr_create_partitioned builds for these row blocks (host-only)."""
+    rs = np.ascontiguousarray(row_starts, np.int64)
+    ptr = np.ascontiguousarray(ptr, np.int32)
+    node = np.ascontiguousarray(node, np.int32)
+    nparts = len(rs) - 1
+    nl, need = C.c_int32(0), C.c_int64(0)
+    _ck(lib().sgm_partition_links_host(C.c_int32(nparts), C.c_void_p(rs.ctypes.data), C.c_void_p(ptr.ctypes.data),
+                                       C.c_void_p(node.ctypes.data), C.byref(nl), None, None, None, None, None,
+                                       C.c_int64(0), C.byref(need)))
+    a = [np.zeros(max(nl.value, 1), np.int32) for _ in range(4)]
+    idx = np.zeros(max(need.value, 1), np.int32)
+    _ck(lib().sgm_partition_links_host(C.c_int32(nparts), C.c_void_p(rs.ctypes.data), C.c_void_p(ptr.ctypes.data),
+                                       C.c_void_p(node.ctypes.data), C.byref(nl), *[C.c_void_p(v.ctypes.data) for v in a],
+                                       C.c_void_p(idx.ctypes.data), C.c_int64(len(idx)), None))
+    out, off = [], 0
+    for i in range(nl.value):
+        cnt = int(a[3][i])
+        out.append({"sender": int(a[0][i]), "receiver": int(a[1][i]), "recv_offset": int(a[2][i]),
+                    "send_idx": idx[off:off + cnt].copy()})
+        off += cnt
+    return out
+
+
+def partition_rows_by_nnz(ptr, nparts, align=512):
+    """sgm_partition_rows_by_nnz: contiguous row blocks balanced by 12 nnz + 20 rows, boundaries at
+    multiples of `align` rows; returns row_starts (nparts+1, 0-based, int64)."""
+    ptr = np.ascontiguousarray(ptr, np.int32)
+    rs = np.zeros(nparts + 1, np.int64)
+    _ck(lib().sgm_partition_rows_by_nnz(C.c_int32(len(ptr) - 1), C.c_void_p(ptr.ctypes.data), C.c_int32(nparts),
+                                        C.c_int32(align), C.c_void_p(rs.ctypes.data)))
+    return rs
 
 
 def dot(a, b):

@@ -45,10 +45,17 @@ static Rccl g_nccl;
 static int load_rccl()
 {
     if (g_nccl.h) return SGM_OK;
+    // SGM_RCCL_LIB names another build of the library (same ncclXxx entry points): a site's own
+    // RCCL, or the host-staged stand-in under tests/mock_rccl that lets `pytest -m gpu` run the
+    // multi-rank code with several processes on ONE GPU (RCCL itself refuses two ranks per device)
+    if (const char *e = getenv("SGM_RCCL_LIB")) {
+        g_nccl.h = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+        if (!g_nccl.h) return fail(SGM_ERR_RCCL, "cannot dlopen SGM_RCCL_LIB=%s: %s", e, dlerror());
+    }
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *nm : names) {
-        g_nccl.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
         if (g_nccl.h) break;
+        g_nccl.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!g_nccl.h) return fail(SGM_ERR_RCCL, "cannot dlopen librccl.so.1: %s", dlerror());
 #define SYM(field, name)                                                         \
@@ -152,6 +159,10 @@ int allreduce_slots(sgm_mat A, double *const *slot_ptrs, int count)
 }
 
 // ------------------------------------------------------------------ host planning
+// Everything in this section is host-only index work (no HIP call): it is exported so that the
+// CPU test suite drives the SAME code the RCCL path runs (tests/test_dist_cpu.py, world_size-2
+// gloo), and sgm_csr_create_partitioned / sgm_csr_create_dist are both built on it.
+
 // Sorted unique list of the non-owned columns + renumbering to [owned | halo].
 static void halo_plan(int32_t n_own, int64_t col_begin, int64_t nnz, const int32_t *node,
                       int32_t *node_local, std::vector<int32_t> &halo)
@@ -181,6 +192,77 @@ static int owner_of(const int64_t *row_starts, int nparts, int64_t col0 /*0-base
     return (int)(it - row_starts) - 1;
 }
 
+// What one rank asks of the others: want[q] = how many of my halo entries rank q owns (the halo
+// list is sorted, owners are contiguous row blocks, so those entries are the run
+// [want_off[q], want_off[q+1]) of the halo), req[t] = index of halo entry t in ITS OWNER's
+// local numbering (0-based) -- the list the owner gathers from when it sends to me.
+static int dist_plan(int rank, int nranks, const int64_t *row_starts, const std::vector<int32_t> &halo,
+                     std::vector<int32_t> &want, std::vector<int32_t> &want_off, std::vector<int32_t> &req)
+{
+    want.assign((size_t)nranks, 0);
+    want_off.assign((size_t)nranks + 1, 0);
+    req.resize(halo.size());
+    const int64_t ntot = row_starts[nranks];
+    for (size_t t = 0; t < halo.size(); ++t) {
+        const int64_t c0 = (int64_t)halo[t] - 1;
+        if (c0 < 0 || c0 >= ntot) return fail(SGM_ERR_BAD_ARG, "column %lld outside 1..%lld", (long long)halo[t], (long long)ntot);
+        const int q = owner_of(row_starts, nranks, c0);
+        if (q == rank) return fail(SGM_ERR_BAD_ARG, "halo entry %lld is owned by this rank", (long long)halo[t]);
+        want[q]++;
+        req[t] = (int32_t)(c0 - row_starts[q]);
+    }
+    for (int q = 0; q < nranks; ++q) want_off[q + 1] = want_off[q] + want[q];
+    return SGM_OK;
+}
+
+struct NbrPlan { int peer; int32_t send_count, recv_count, recv_offset; };
+// Neighbour table of `rank` from the all-gathered want matrix (row q = rank q's want[]).
+static void dist_neighbors(int rank, int nranks, const int32_t *want_all, std::vector<NbrPlan> &out)
+{
+    out.clear();
+    int32_t off = 0;
+    for (int q = 0; q < nranks; ++q) {
+        const int32_t i_want = want_all[(size_t)rank * nranks + q];       // I receive this many from q
+        const int32_t they_want = want_all[(size_t)q * nranks + rank];    // q receives this many of mine
+        if (q != rank && (i_want || they_want)) out.push_back(NbrPlan{q, they_want, i_want, off});
+        off += i_want;
+    }
+}
+
+// All links of an in-process partition: the same dist_plan, run for every receiver.
+struct Link { int sender, receiver; int32_t recv_offset; std::vector<int32_t> idx; };
+static int partition_links(int nparts, const int64_t *row_starts, const std::vector<std::vector<int32_t>> &halos,
+                           std::vector<Link> &links)
+{
+    links.clear();
+    std::vector<int32_t> want, want_off, req;
+    for (int ip = 0; ip < nparts; ++ip) {
+        SGM_TRY(dist_plan(ip, nparts, row_starts, halos[ip], want, want_off, req));
+        for (int q = 0; q < nparts; ++q) {
+            if (!want[q]) continue;
+            Link l;
+            l.sender = q;
+            l.receiver = ip;
+            l.recv_offset = want_off[q];
+            l.idx.assign(req.begin() + want_off[q], req.begin() + want_off[q + 1]);
+            links.push_back(std::move(l));
+        }
+    }
+    return SGM_OK;
+}
+
+// frees a half-built matrix (and scratch device buffers) on every early return
+struct MatGuard {
+    sgm_mat A = nullptr;
+    std::vector<void *> scratch;
+    ~MatGuard()
+    {
+        for (void *p : scratch) dfree(p);
+        if (A) sgm_mat_destroy(A);
+    }
+    sgm_mat release() { sgm_mat a = A; A = nullptr; return a; }
+};
+
 }  // namespace sgm
 
 using namespace sgm;
@@ -199,6 +281,92 @@ int sgm_halo_plan_host(int32_t n_own, int64_t col_begin, int64_t nnz, const int3
     return SGM_OK;
 }
 
+int sgm_dist_plan_host(int32_t rank, int32_t nranks, const int64_t *row_starts, int32_t n_halo,
+                       const int32_t *halo_cols, int32_t *want, int32_t *want_off, int32_t *req)
+{
+    if (nranks < 1 || rank < 0 || rank >= nranks || !row_starts || n_halo < 0 || (n_halo && !halo_cols) || !want || !want_off)
+        return fail(SGM_ERR_BAD_ARG, "sgm_dist_plan_host: bad argument");
+    std::vector<int32_t> halo(halo_cols, halo_cols + n_halo), w, wo, r;
+    SGM_TRY(dist_plan(rank, nranks, row_starts, halo, w, wo, r));
+    std::copy(w.begin(), w.end(), want);
+    std::copy(wo.begin(), wo.end(), want_off);
+    if (req) std::copy(r.begin(), r.end(), req);
+    return SGM_OK;
+}
+
+int sgm_dist_neighbors_host(int32_t rank, int32_t nranks, const int32_t *want_all, int32_t *peer,
+                            int32_t *send_count, int32_t *recv_count, int32_t *recv_offset, int32_t *n_nbrs)
+{
+    if (nranks < 1 || rank < 0 || rank >= nranks || !want_all || !n_nbrs)
+        return fail(SGM_ERR_BAD_ARG, "sgm_dist_neighbors_host: bad argument");
+    std::vector<NbrPlan> nb;
+    dist_neighbors(rank, nranks, want_all, nb);
+    *n_nbrs = (int32_t)nb.size();
+    for (size_t i = 0; i < nb.size(); ++i) {
+        if (peer) peer[i] = nb[i].peer;
+        if (send_count) send_count[i] = nb[i].send_count;
+        if (recv_count) recv_count[i] = nb[i].recv_count;
+        if (recv_offset) recv_offset[i] = nb[i].recv_offset;
+    }
+    return SGM_OK;
+}
+
+int sgm_partition_links_host(int32_t nparts, const int64_t *row_starts, const int32_t *ptr, const int32_t *node,
+                             int32_t *n_links, int32_t *sender, int32_t *receiver, int32_t *recv_offset,
+                             int32_t *count, int32_t *idx_concat, int64_t idx_capacity, int64_t *idx_needed)
+{
+    if (nparts < 1 || !row_starts || !ptr || !n_links) return fail(SGM_ERR_BAD_ARG, "sgm_partition_links_host: bad argument");
+    std::vector<std::vector<int32_t>> halos((size_t)nparts);
+    for (int ip = 0; ip < nparts; ++ip) {
+        const int64_t r0 = row_starts[ip], r1 = row_starts[ip + 1];
+        const int64_t k0 = ptr[r0] - 1, k1 = ptr[r1] - 1;
+        std::vector<int32_t> lnode((size_t)std::max<int64_t>(k1 - k0, 1));
+        halo_plan((int32_t)(r1 - r0), r0, k1 - k0, node + k0, lnode.data(), halos[ip]);
+    }
+    std::vector<Link> links;
+    SGM_TRY(partition_links(nparts, row_starts, halos, links));
+    int64_t total = 0;
+    for (auto &l : links) total += (int64_t)l.idx.size();
+    *n_links = (int32_t)links.size();
+    if (idx_needed) *idx_needed = total;
+    if (!sender) return SGM_OK;                       // sizing call
+    if (idx_concat && idx_capacity < total) return fail(SGM_ERR_BAD_ARG, "sgm_partition_links_host: idx buffer too small");
+    int64_t off = 0;
+    for (size_t i = 0; i < links.size(); ++i) {
+        sender[i] = links[i].sender;
+        if (receiver) receiver[i] = links[i].receiver;
+        if (recv_offset) recv_offset[i] = links[i].recv_offset;
+        if (count) count[i] = (int32_t)links[i].idx.size();
+        if (idx_concat) std::copy(links[i].idx.begin(), links[i].idx.end(), idx_concat + off);
+        off += (int64_t)links[i].idx.size();
+    }
+    return SGM_OK;
+}
+
+int sgm_partition_rows_by_nnz(int32_t nrow, const int32_t *ptr, int32_t nparts, int32_t align, int64_t *row_starts)
+{
+    if (nrow < 0 || !ptr || nparts < 1 || !row_starts) return fail(SGM_ERR_BAD_ARG, "sgm_partition_rows_by_nnz: bad argument");
+    if (align < 2) align = 2;                         // 16-byte vector accesses need even row boundaries
+    if (align & 1) align += 1;
+    // weight of the rows [0, r): the bytes of B_csr they account for (12 per entry, 20 per row)
+    auto weight = [&](int64_t r) { return 12 * ((int64_t)ptr[r] - 1) + 20 * r; };
+    const int64_t total = weight(nrow);
+    row_starts[0] = 0;
+    for (int p = 1; p < nparts; ++p) {
+        const int64_t target = total / nparts * p + total % nparts * p / nparts;
+        int64_t lo = row_starts[p - 1], hi = nrow;        // first row whose prefix weight reaches the target
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) / 2;
+            if (weight(mid) < target) lo = mid + 1; else hi = mid;
+        }
+        int64_t r = (lo + align / 2) / align * align;      // nearest multiple of `align`
+        r = std::max<int64_t>(r, row_starts[p - 1]);
+        row_starts[p] = std::min<int64_t>(r, nrow);
+    }
+    row_starts[nparts] = nrow;
+    return SGM_OK;
+}
+
 int sgm_csr_create_partitioned(sgm_mat *out, int32_t nparts, const int64_t *row_starts, int32_t nrow,
                                int32_t ncol, int64_t nnz, const int32_t *ptr, const int32_t *node,
                                const double *val)
@@ -207,7 +375,8 @@ int sgm_csr_create_partitioned(sgm_mat *out, int32_t nparts, const int64_t *row_
     if (!out || nparts < 1 || !row_starts || !ptr || nrow != ncol || row_starts[0] != 0 ||
         row_starts[nparts] != nrow)
         return fail(SGM_ERR_BAD_ARG, "sgm_csr_create_partitioned: bad argument (square matrices only)");
-    sgm_mat A = new sgm_mat_s;
+    MatGuard g;
+    sgm_mat A = g.A = new sgm_mat_s;
     A->fmt = SGM_FMT_CSR;
     A->nrow = nrow;
     A->ncol = ncol;
@@ -222,37 +391,25 @@ int sgm_csr_create_partitioned(sgm_mat *out, int32_t nparts, const int64_t *row_
         for (int32_t i = 0; i <= n; ++i) lptr[i] = (int32_t)(ptr[r0 + i] - k0);
         halo_plan(n, r0, k1 - k0, node + k0, lnode.data(), halos[ip]);
         Part &p = A->parts[ip];
-        int rc = build_csr_part(p, n, n, (int32_t)halos[ip].size(), k1 - k0, lptr.data(), lnode.data(),
-                                val + k0, SGM_HOST);
-        if (rc == SGM_OK) rc = dalloc(&p.xext, (size_t)p.xlen());
-        if (rc != SGM_OK) { sgm_mat_destroy(A); return rc; }
+        SGM_TRY(build_csr_part(p, n, n, (int32_t)halos[ip].size(), k1 - k0, lptr.data(), lnode.data(), val + k0, SGM_HOST));
+        SGM_TRY(dalloc(&p.xext, (size_t)p.xlen()));
         p.row_begin = r0;
         set_interior_range(p, lptr.data(), lnode.data());
     }
     // send lists: part q sends to part p the entries of p's halo that q owns, in p's halo order
-    for (int ip = 0; ip < nparts; ++ip) {
-        const auto &h = halos[ip];
-        size_t a = 0;
-        while (a < h.size()) {
-            const int q = owner_of(row_starts, nparts, (int64_t)h[a] - 1);
-            size_t b = a;
-            std::vector<int32_t> idx;
-            while (b < h.size() && owner_of(row_starts, nparts, (int64_t)h[b] - 1) == q) {
-                idx.push_back((int32_t)(h[b] - 1 - row_starts[q]));
-                ++b;
-            }
-            HaloNbr nb;
-            nb.peer = ip;                       // stored on the SENDER q
-            nb.send_count = (int32_t)idx.size();
-            nb.recv_offset = (int32_t)a;        // offset in the receiver's halo region
-            int rc = dalloc(&nb.send_idx, idx.size());
-            if (rc != SGM_OK) { sgm_mat_destroy(A); return rc; }
-            SGM_HIP(hipMemcpy(nb.send_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
-            A->parts[q].nbrs.push_back(nb);
-            a = b;
-        }
+    std::vector<Link> links;
+    SGM_TRY(partition_links(nparts, row_starts, halos, links));
+    for (const Link &l : links) {
+        HaloNbr nb;
+        nb.peer = l.receiver;                 // stored on the SENDER
+        nb.send_count = (int32_t)l.idx.size();
+        nb.recv_offset = l.recv_offset;       // offset in the receiver's halo region
+        SGM_TRY(dalloc(&nb.send_idx, l.idx.size()));
+        A->parts[l.sender].nbrs.push_back(nb);          // owned by the part from here on
+        SGM_HIP(hipMemcpyAsync(nb.send_idx, l.idx.data(), l.idx.size() * 4, hipMemcpyHostToDevice, g_rt.stream));
+        SGM_HIP(hipStreamSynchronize(g_rt.stream));
     }
-    *out = A;
+    *out = g.release();
     return SGM_OK;
 }
 
@@ -299,23 +456,34 @@ int sgm_csr_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts, 
     const int R = comm->nranks, me = comm->rank;
     const int64_t r0 = row_starts[me], r1 = row_starts[me + 1];
     const int32_t n = (int32_t)(r1 - r0);
+    if (row_starts[0] != 0 || r1 < r0 || row_starts[R] > INT32_MAX)
+        return fail(SGM_ERR_BAD_ARG, "sgm_csr_create_dist: row_starts must rise from 0 to the global row count (< 2^31)");
+    for (int q = 1; q < R; ++q)
+        if (row_starts[q] & 1) return fail(SGM_ERR_UNSUPPORTED, "partition boundaries must be even rows (16-B vector access)");
     hipStream_t st = g_rt.stream;
 
-    // the index work runs on the host (same code as sgm_halo_plan_host)
+    // the index work runs on the host (same code as sgm_halo_plan_host / sgm_dist_plan_host).
+    // Device arrays are read on the library's stream: the caller may still be producing them there.
     std::vector<int32_t> hnode, lnode((size_t)std::max<int64_t>(nnz, 1)), hptr;
     const int32_t *node_h = node, *ptr_h = ptr;
     if (where == SGM_DEVICE) {
         hnode.resize((size_t)std::max<int64_t>(nnz, 1));
         hptr.resize((size_t)n + 1);
-        SGM_HIP(hipMemcpy(hnode.data(), node, (size_t)nnz * 4, hipMemcpyDeviceToHost));
-        SGM_HIP(hipMemcpy(hptr.data(), ptr, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+        if (nnz) SGM_HIP(hipMemcpyAsync(hnode.data(), node, (size_t)nnz * 4, hipMemcpyDeviceToHost, st));
+        SGM_HIP(hipMemcpyAsync(hptr.data(), ptr, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, st));
+        SGM_HIP(hipStreamSynchronize(st));
         node_h = hnode.data();
         ptr_h = hptr.data();
     }
+    if ((int64_t)ptr_h[n] - 1 != nnz) return fail(SGM_ERR_BAD_ARG, "sgm_csr_create_dist: ptr(n+1)-1 = %lld but nnz_local = %lld",
+                                                   (long long)ptr_h[n] - 1, (long long)nnz);
     std::vector<int32_t> halo;
     halo_plan(n, r0, nnz, node_h, lnode.data(), halo);
+    std::vector<int32_t> want, want_off, req;
+    SGM_TRY(dist_plan(me, R, row_starts, halo, want, want_off, req));
 
-    sgm_mat A = new sgm_mat_s;
+    MatGuard g;
+    sgm_mat A = g.A = new sgm_mat_s;
     A->fmt = SGM_FMT_CSR;
     A->nrow = (int32_t)row_starts[R];
     A->ncol = A->nrow;
@@ -323,60 +491,51 @@ int sgm_csr_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts, 
     A->comm = comm;
     A->parts.resize(1);
     Part &p = A->parts[0];
-    int rc;
     if (where == SGM_DEVICE) {
         // values stay on the device; only the renumbered node array is re-uploaded
         int32_t *dnode = nullptr;
         SGM_TRY(dalloc(&dnode, (size_t)std::max<int64_t>(nnz, 1)));
-        SGM_HIP(hipMemcpy(dnode, lnode.data(), (size_t)nnz * 4, hipMemcpyHostToDevice));
-        rc = build_csr_part(p, n, n, (int32_t)halo.size(), nnz, ptr, dnode, val, SGM_DEVICE);
-        dfree(dnode);
+        g.scratch.push_back(dnode);
+        if (nnz) SGM_HIP(hipMemcpyAsync(dnode, lnode.data(), (size_t)nnz * 4, hipMemcpyHostToDevice, st));
+        SGM_TRY(build_csr_part(p, n, n, (int32_t)halo.size(), nnz, ptr, dnode, val, SGM_DEVICE));
     } else {
-        rc = build_csr_part(p, n, n, (int32_t)halo.size(), nnz, ptr_h, lnode.data(), val, SGM_HOST);
+        SGM_TRY(build_csr_part(p, n, n, (int32_t)halo.size(), nnz, ptr_h, lnode.data(), val, SGM_HOST));
     }
-    if (rc != SGM_OK) { sgm_mat_destroy(A); return rc; }
     p.row_begin = r0;
     set_interior_range(p, ptr_h, lnode.data());
     { std::vector<int32_t>().swap(hnode); std::vector<int32_t>().swap(lnode); }
 
-    // who needs what: want[q] = number of my halo entries owned by rank q
-    std::vector<int32_t> want(R, 0), want_off(R + 1, 0);
-    for (int32_t c : halo) want[owner_of(row_starts, R, (int64_t)c - 1)]++;
-    for (int q = 0; q < R; ++q) want_off[q + 1] = want_off[q] + want[q];
     if (R > 1) {
-        // all ranks learn the full want matrix, then neighbours swap index lists
-        int32_t *d_want = nullptr, *d_all = nullptr;
+        // all ranks learn the full want matrix, then neighbours swap their request lists
+        int32_t *d_want = nullptr, *d_all = nullptr, *d_req = nullptr;
         SGM_TRY(dalloc(&d_want, (size_t)R));
+        g.scratch.push_back(d_want);
         SGM_TRY(dalloc(&d_all, (size_t)R * R));
-        SGM_HIP(hipMemcpy(d_want, want.data(), (size_t)R * 4, hipMemcpyHostToDevice));
-        SGM_NCCL(g_nccl.AllGather(d_want, d_all, (size_t)R, ncclInt32, (ncclComm_t)comm->nccl, st));
-        SGM_HIP(hipStreamSynchronize(st));
-        std::vector<int32_t> all((size_t)R * R);
-        SGM_HIP(hipMemcpy(all.data(), d_all, all.size() * 4, hipMemcpyDeviceToHost));
-        dfree(d_want);
-        dfree(d_all);
-        // local indices (0-based, in the owner's numbering) of the entries I want from each owner
-        std::vector<int32_t> req(halo.size());
-        for (size_t t = 0; t < halo.size(); ++t) {
-            const int q = owner_of(row_starts, R, (int64_t)halo[t] - 1);
-            req[t] = (int32_t)(halo[t] - 1 - row_starts[q]);
-        }
-        int32_t *d_req = nullptr;
+        g.scratch.push_back(d_all);
         SGM_TRY(dalloc(&d_req, req.size()));
-        SGM_HIP(hipMemcpy(d_req, req.data(), req.size() * 4, hipMemcpyHostToDevice));
-        for (int q = 0; q < R; ++q) {
-            const int32_t they_want = all[(size_t)q * R + me];   // rank q wants this many of mine
-            if (q == me || (!they_want && !want[q])) continue;
+        g.scratch.push_back(d_req);
+        SGM_HIP(hipMemcpyAsync(d_want, want.data(), (size_t)R * 4, hipMemcpyHostToDevice, st));
+        SGM_NCCL(g_nccl.AllGather(d_want, d_all, (size_t)R, ncclInt32, (ncclComm_t)comm->nccl, st));
+        std::vector<int32_t> all((size_t)R * R);
+        SGM_HIP(hipMemcpyAsync(all.data(), d_all, all.size() * 4, hipMemcpyDeviceToHost, st));
+        if (!req.empty()) SGM_HIP(hipMemcpyAsync(d_req, req.data(), req.size() * 4, hipMemcpyHostToDevice, st));
+        SGM_HIP(hipStreamSynchronize(st));
+        for (int q = 0; q < R; ++q)
+            if (all[(size_t)me * R + q] != want[q]) return fail(SGM_ERR_RCCL, "sgm_csr_create_dist: all-gather returned a different want row");
+        std::vector<NbrPlan> plan;
+        dist_neighbors(me, R, all.data(), plan);
+        for (const NbrPlan &pl : plan) {
             HaloNbr nb;
-            nb.peer = q;
-            nb.send_count = they_want;
-            nb.recv_count = want[q];
-            nb.recv_offset = want_off[q];
-            if (they_want) {
-                SGM_TRY(dalloc(&nb.send_idx, (size_t)they_want));
-                SGM_TRY(dalloc(&nb.send_buf, (size_t)they_want));
+            nb.peer = pl.peer;
+            nb.send_count = pl.send_count;
+            nb.recv_count = pl.recv_count;
+            nb.recv_offset = pl.recv_offset;
+            if (pl.send_count > n) return fail(SGM_ERR_RCCL, "rank %d asks for %d entries of the %d this rank owns", pl.peer, pl.send_count, n);
+            p.nbrs.push_back(nb);                       // buffers below are owned by the part from here on
+            if (pl.send_count) {
+                SGM_TRY(dalloc(&p.nbrs.back().send_idx, (size_t)pl.send_count));
+                SGM_TRY(dalloc(&p.nbrs.back().send_buf, (size_t)pl.send_count));
             }
-            p.nbrs.push_back(nb);
         }
         SGM_NCCL(g_nccl.GroupStart());
         for (auto &nb : p.nbrs) {
@@ -388,9 +547,31 @@ int sgm_csr_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts, 
         }
         SGM_NCCL(g_nccl.GroupEnd());
         SGM_HIP(hipStreamSynchronize(st));
-        dfree(d_req);
     }
-    *out = A;
+    *out = g.release();
+    return SGM_OK;
+}
+
+/* read back the exchange plan of a distributed / partitioned matrix (parity checks): for local
+ * part `part`, neighbour `k`: peer, counts, offset and (optionally) the send list (0-based). */
+int sgm_mat_halo_nbr(sgm_mat A, int32_t part, int32_t k, int32_t *n_nbrs, int32_t *peer, int32_t *send_count,
+                     int32_t *recv_count, int32_t *recv_offset, int32_t *send_idx_host, int32_t capacity)
+{
+    if (!A || part < 0 || (size_t)part >= A->parts.size()) return fail(SGM_ERR_BAD_ARG, "sgm_mat_halo_nbr: bad argument");
+    const Part &p = A->parts[part];
+    if (n_nbrs) *n_nbrs = (int32_t)p.nbrs.size();
+    if (k < 0) return SGM_OK;
+    if ((size_t)k >= p.nbrs.size()) return fail(SGM_ERR_BAD_ARG, "sgm_mat_halo_nbr: neighbour %d of %zu", k, p.nbrs.size());
+    const HaloNbr &nb = p.nbrs[k];
+    if (peer) *peer = nb.peer;
+    if (send_count) *send_count = nb.send_count;
+    if (recv_count) *recv_count = nb.recv_count;
+    if (recv_offset) *recv_offset = nb.recv_offset;
+    if (send_idx_host && nb.send_count) {
+        if (capacity < nb.send_count) return fail(SGM_ERR_BAD_ARG, "sgm_mat_halo_nbr: buffer too small");
+        SGM_HIP(hipStreamSynchronize(g_rt.stream));
+        SGM_HIP(hipMemcpy(send_idx_host, nb.send_idx, (size_t)nb.send_count * 4, hipMemcpyDeviceToHost));
+    }
     return SGM_OK;
 }
 

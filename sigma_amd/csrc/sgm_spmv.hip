@@ -1925,6 +1925,65 @@ int sgm_mat_kernel(sgm_mat A, char *buf, int len)
     return SGM_OK;
 }
 
+// Bytes by construction: what lives in HBM for this handle, and what ONE
+// y = A x moves with the kernel the current options select -- the stored format of that kernel
+// (padded slices, codes, row pointers as it reads them), every x entry once, every y entry once.
+static int64_t part_resident_bytes(const Part &p)
+{
+    int64_t b = 0;
+    const int64_t nsl = ((int64_t)p.n + kSlRows - 1) / kSlRows;
+    if (p.rowptr) b += 4 * ((int64_t)p.n + 1);
+    if (p.col) b += 4 * (p.nnz + 2);
+    if (p.val) b += 8 * (p.nnz + 2);
+    if (p.code) b += p.nnz + 16;
+    if (p.dict) b += 4 * 256;
+    if (p.sval) b += 8 * nsl * kSlRows * p.sw;
+    if (p.scode) b += 4 * nsl * kSlRows;
+    if (p.scol) b += 4 * nsl * kSlRows * p.sw;
+    if (p.ecol) b += 4 * (int64_t)p.n * p.max_d;
+    if (p.eval) b += 8 * (int64_t)p.n * p.max_d;
+    if (p.edeg) b += 4 * (int64_t)p.n;
+    if (p.ecode) b += (int64_t)p.n * p.emdp;
+    if (p.xext) b += 8 * p.xlen();
+    for (const auto &nb : p.nbrs) b += (int64_t)nb.send_count * (nb.send_buf ? 12 : 4);
+    return b;
+}
+static int64_t part_matvec_bytes(const sgm_mat_s *A, const Part &p)
+{
+    const int64_t nsl = ((int64_t)p.n + kSlRows - 1) / kSlRows;
+    int64_t m;
+    if (A->fmt == SGM_FMT_ELL) {
+        if (use_sliced_ell(p)) m = nsl * kSlRows * (8 * (int64_t)p.sw + 4);
+        else if (p.ecode && g_opt.ell_offset_dict) m = (int64_t)p.n * (8 * (int64_t)p.max_d + p.emdp);
+        else m = 12 * (int64_t)p.n * p.max_d;
+    } else if (use_sliced(p)) m = nsl * kSlRows * (8 * (int64_t)p.sw + 4);
+    else if (use_sliced32(p)) m = nsl * kSlRows * 12 * (int64_t)p.sw;
+    else if (use_offset_dict(p)) m = 9 * p.nnz + 4 * ((int64_t)p.n + 1);
+    else m = 12 * p.nnz + 4 * ((int64_t)p.n + 1);
+    return m + 8 * p.xlen() + 8 * (int64_t)p.n;
+}
+
+int sgm_mat_footprint(sgm_mat A, int64_t *resident_bytes, int64_t *matvec_bytes)
+{
+    if (!A) return fail(SGM_ERR_BAD_ARG, "sgm_mat_footprint: null matrix");
+    int64_t res = 0, mv = 0;
+    if (A->fmt == SGM_FMT_COMPOSITE) {
+        for (sgm_mat C : A->blocks) {
+            if (!C) continue;
+            int64_t r = 0, m = 0;
+            SGM_TRY(sgm_mat_footprint(C, &r, &m));
+            mv += m + 8 * (int64_t)C->nrow;       // a block leaf adds onto y: one more read of its rows
+        }
+        mv += 8 * (int64_t)A->nrow;               // y = 0
+    } else {
+        for (const Part &p : A->parts) { res += part_resident_bytes(p); mv += part_matvec_bytes(A, p); }
+        if (A->T) { int64_t r = 0; SGM_TRY(sgm_mat_footprint(A->T, &r, nullptr)); res += r + 4 * A->nnz; }
+    }
+    if (resident_bytes) *resident_bytes = res;
+    if (matvec_bytes) *matvec_bytes = mv;
+    return SGM_OK;
+}
+
 int sgm_mat_destroy(sgm_mat A)
 {
     if (!A) return SGM_OK;

@@ -1,0 +1,160 @@
+"""One rank of the multi-process GPU tests (started by tests/test_gpu_multirank.py, one process
+per rank).  Runs the PRODUCT's row-partitioned path -- sgm_comm_init, sgm_csr_create_dist, halo
+exchange on the communication stream, all-reduced dots inside the device-resident Krylov loops --
+and checks it against the CPU oracle.  With SGM_RCCL_LIB pointing at tests/mock_rccl the ranks
+share ONE GPU (RCCL itself refuses that); with real RCCL every rank takes its own device.
+
+    python tests/dist_worker.py RANK WORLD PORT CASE OUT.json
+"""
+import json
+import os
+import sys
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world, port, case, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    res = {"rank": rank, "ok": False}
+    try:
+        run(rank, world, port, case, res)
+        res["ok"] = True
+    except Exception:
+        res["error"] = traceback.format_exc()
+    with open(out, "w") as f:
+        json.dump(res, f)
+    sys.exit(0 if res["ok"] else 1)
+
+
+def run(rank, world, port, case, res):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import oracle as orc
+    import sigma_amd as sg
+    from sigma_amd import problems as P
+
+    same_gpu = bool(os.environ.get("SGM_RCCL_LIB"))
+    device = 0 if same_gpu else rank
+    sg.init(device)
+    torch.cuda.set_device(device)
+    dev = torch.device("cuda", device)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        uid = [sg.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = sg.Comm(rank, world, uid[0])
+
+        if case == "poisson2d":
+            n = 96 * 70
+            ptr, node, val = P.poisson2d_csr(96, 70)
+        elif case == "laplace3d":
+            n = 24 * 20 * 30
+            ptr, node, val = P.laplace3d_csr(24, 20, 30)
+        else:                       # nonsymmetric, irregular: no offset dictionary, halo from several ranks
+            n = 1200
+            Ar = orc.CsrMatrix.from_edges(n, n, *P.random_spd_edges(n, seed=5, skew=True))
+            ptr, node, val = Ar.ptr, Ar.node, Ar.val
+        A = orc.CsrMatrix(n, n, ptr, node, val)
+        starts = sg.partition_rows_by_nnz(ptr, world, align=2)
+        r0, r1 = int(starts[rank]), int(starts[rank + 1])
+        n_own = r1 - r0
+        k0, k1 = ptr[r0] - 1, ptr[r1] - 1
+        lptr = (ptr[r0:r1 + 1] - k0).astype(np.int32)
+        lnode_g = np.ascontiguousarray(node[k0:k1])
+        lval = np.ascontiguousarray(val[k0:k1])
+
+        H = sg.dist_csr_matrix(comm, starts, lptr, lnode_g, lval)
+        _, halo = sg.halo_plan_host(n_own, r0, lnode_g)
+        assert H.x_len == n_own + len(halo), (H.x_len, n_own, len(halo))
+        res["n_halo"] = int(len(halo))
+
+        # ---- the exchange plan the ranks agreed on over the transport == the in-process links
+        links = sg.partition_links_host(starts, ptr, node)
+        mine = sorted((l for l in links if l["sender"] == rank), key=lambda l: l["receiver"])
+        to_me = {l["sender"]: l for l in links if l["receiver"] == rank}
+        nbrs = H.halo_nbrs()
+        sends = sorted((nb for nb in nbrs if nb["send_count"]), key=lambda nb: nb["peer"])
+        assert [nb["peer"] for nb in sends] == [l["receiver"] for l in mine]
+        for nb, l in zip(sends, mine):
+            assert np.array_equal(nb["send_idx"], l["send_idx"]), "send list differs from the in-process partition"
+        for nb in nbrs:
+            if nb["recv_count"]:
+                l = to_me[nb["peer"]]
+                assert nb["recv_offset"] == l["recv_offset"] and nb["recv_count"] == len(l["send_idx"])
+        assert sum(1 for nb in nbrs if nb["recv_count"]) == len(to_me)
+
+        # ---- matvec: host vectors, then device tensors; rows bit-identical to the serial matvec
+        x = P.test_vector(n) if case != "random" else np.random.RandomState(1).standard_normal(n)
+        y_ref = A.matvec(x)[r0:r1]
+        xe = np.zeros(H.x_len)
+        xe[:n_own] = x[r0:r1]
+        y = np.zeros(n_own)
+        H.matvec(xe, y)
+        assert np.array_equal(y, y_ref), "distributed matvec rows differ from the serial matvec"
+        assert np.array_equal(xe[n_own:], x[halo - 1]), "halo region does not hold the neighbours' x entries"
+        xd = torch.zeros(H.x_len, dtype=torch.float64, device=dev)
+        xd[:n_own] = torch.from_numpy(x[r0:r1]).to(dev)
+        yd = torch.full((n_own,), -3.0, dtype=torch.float64, device=dev)
+        H.matvec(xd, yd)
+        assert np.array_equal(yd.cpu().numpy(), y_ref)
+        y0 = np.random.RandomState(7).standard_normal(n)
+        ya = y0[r0:r1].copy()
+        H.matvec_add(xe, ya)
+        assert np.array_equal(ya, A.matvec_add(x, y0.copy())[r0:r1])
+
+        # ---- the same matrix created from DEVICE arrays (what bench.py --workload c5 does)
+        H2 = sg.dist_csr_matrix(comm, starts, torch.from_numpy(lptr).to(dev), torch.from_numpy(lnode_g).to(dev),
+                                torch.from_numpy(lval).to(dev))
+        yd.fill_(-5.0)
+        H2.matvec(xd, yd)
+        assert np.array_equal(yd.cpu().numpy(), y_ref)
+        H2.destroy()
+
+        # ---- Krylov loops with all-reduced dots
+        b = np.full(n, 1.0 / n) if case != "random" else P.test_vector(n)
+        bl = b[r0:r1].copy()
+        out = {}
+
+        def check(name, solver, pc_mk, ref, it_tol, rel_tol):
+            ur, itr = ref[0], ref[1]
+            solver.setup(H)
+            pc = pc_mk() if pc_mk else None
+            if pc is not None:
+                pc.setup(H)
+            u = np.zeros(n_own)
+            solver.solve(H, u, bl, pc)
+            rel = float(np.abs(u - ur[r0:r1]).max() / np.abs(ur).max())
+            out[name] = {"iterations": int(solver.iterations), "oracle_iterations": int(itr), "rel": rel}
+            assert abs(solver.iterations - itr) <= it_tol(itr), (name, solver.iterations, itr)
+            assert rel <= rel_tol, (name, rel)
+            solver.destroy()
+            if pc is not None:
+                pc.destroy()
+
+        if case != "random":
+            check("cg", sg.cg(1e-13), None, orc.cg(A, b, tol=1e-13), lambda i: 1, 1e-12)
+            check("cg_jacobi", sg.cg(1e-13), sg.jacobi, orc.cg(A, b, tol=1e-13, pc=orc.Jacobi(A)), lambda i: 1, 1e-12)
+            # block-Jacobi ILDU(0): the oracle factors the block-diagonal part of A
+            rows = np.repeat(np.arange(n), np.diff(ptr))
+            blk = np.searchsorted(starts, np.arange(n), side="right") - 1
+            keep = blk[rows] == blk[node - 1]
+            cnt = np.bincount(rows[keep], minlength=n)
+            Ab = orc.CsrMatrix(n, n, np.concatenate([[1], 1 + np.cumsum(cnt)]).astype(np.int32), node[keep].copy(), val[keep].copy())
+            check("cg_ildu_blockjacobi", sg.cg(1e-12), sg.ldu, orc.cg(A, b, tol=1e-12, pc=orc.Ildu(Ab)), lambda i: 1, 1e-11)
+            check("bicgstab", sg.bicgstab(1e-13), None, orc.bicgstab(A, b, tol=1e-13), lambda i: max(2, 0.1 * i), 1e-11)
+        else:
+            check("bicgstab_jacobi", sg.bicgstab(1e-12), sg.jacobi, orc.bicgstab(A, b, tol=1e-12, pc=orc.Jacobi(A)),
+                  lambda i: max(2, 0.1 * i), 1e-10)
+        check("gmres30", sg.gmres(1e-12, 30), None, orc.gmres(A, b, tol=1e-12, restart=30), lambda i: 2, 1e-10)
+        res["solves"] = out
+        H.destroy()
+        comm.destroy()
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

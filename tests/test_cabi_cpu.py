@@ -51,6 +51,21 @@ def test_product_fails_loudly_without_gpu():
     assert e.value.code == 6 and "no CPU path" in str(e.value)
 
 
+@pytest.mark.skipif(_has_gpu(), reason="GPU present: the loud-failure path cannot be seen")
+def test_bench_gpus_2_spawns_ranks_that_fail_at_no_device():
+    """`python bench.py --gpus 2` typed plainly: the parent spawns the two rank processes itself
+    (no torch.distributed.run, no exec) and on a CPU-only box they fail only at SGM_ERR_NO_DEVICE."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "sigma_hip status 6" in p.stderr and "no CPU path" in p.stderr
+    assert "rank exit codes: [1, 1]" in p.stderr
+    assert p.stdout.strip() == ""
+
+
 def test_product_never_imports_the_oracle():
     import sys
     for fn in os.listdir(os.path.join(ROOT, "sigma_amd")):

@@ -1,9 +1,18 @@
-"""N > 1 path on CPU: two `gloo` processes run the row-partition protocol of
-sgm_csr_create_dist / the distributed CG with the library's own host-only
-halo planner (sgm_halo_plan_host, no GPU call) and the CPU oracle as the local arithmetic:
+"""N > 1 path on CPU: `gloo` processes run the row-partition protocol of sgm_csr_create_dist /
+the distributed CG.  Every list RCCL would carry comes from the PRODUCT's own
+host-only planners (the code sgm_csr_create_dist runs, exported for this purpose):
 
-  * want-count all-gather + index-list swap  (what sgm_csr_create_dist does over RCCL)
-  * per matvec: gather send list -> send/recv with the neighbour rank -> local matvec on
+  sgm_halo_plan_host       sorted unique halo list + renumbering to [owned | halo]
+  sgm_dist_plan_host       want counts per owner, request list in the owner's numbering
+  sgm_dist_neighbors_host  neighbour table (peer, send/recv counts, halo offset) from the
+                           all-gathered want matrix
+  sgm_partition_links_host what sgm_csr_create_partitioned builds in one process: the send lists
+                           received over gloo must equal these bit for bit
+
+Only the transport (gloo instead of RCCL) and the local arithmetic (the CPU oracle instead of the
+HIP kernels) differ from the GPU run:
+  * want-count all-gather + request-list swap (what sgm_csr_create_dist does over RCCL)
+  * per matvec: gather send list -> send/recv with the neighbour ranks -> local matvec on
     [owned | halo]            (row sums must be BIT-identical to the serial matvec)
   * per dot: local partial + all_reduce(sum)   (solution within 1e-12 of the serial CG)
 """
@@ -42,48 +51,53 @@ def _worker(rank, world, port, case, q):
         else:
             n = 9 * 8 * 10
             ptr, node, val = P.laplace3d_csr(9, 8, 10)
-        starts = (np.arange(world + 1) * n // world) // 2 * 2
-        starts[-1] = n
+        starts = sg.partition_rows_by_nnz(ptr, world, align=2)          # product partitioner
         r0, r1 = int(starts[rank]), int(starts[rank + 1])
         n_own = r1 - r0
         k0, k1 = ptr[r0] - 1, ptr[r1] - 1
         lptr = (ptr[r0:r1 + 1] - k0).astype(np.int32)
-        # --- index work: the library's host planner (bit-exact vs numpy in test_cabi_cpu)
+        # --- index work: the library's host planners
         lnode, halo = sg.halo_plan_host(n_own, r0, node[k0:k1])
         A_loc = orc.CsrMatrix(n_own, n_own + len(halo), lptr, lnode, val[k0:k1])
-        owner = np.searchsorted(starts, halo - 1, side="right") - 1
-        # --- want counts all-gather, then neighbours swap index lists
-        want = np.array([(owner == q_).sum() for q_ in range(world)], dtype=np.int64)
-        allw = [torch.zeros(world, dtype=torch.int64) for _ in range(world)]
-        dist.all_gather(allw, torch.from_numpy(want))
-        allw = torch.stack(allw).numpy()                       # allw[q][me] = q wants this many of mine
+        want, want_off, req = sg.dist_plan_host(rank, world, starts, halo)
+        # --- want counts all-gather (RCCL: ncclAllGather), then neighbours swap request lists
+        allw = [torch.zeros(world, dtype=torch.int32) for _ in range(world)]
+        dist.all_gather(allw, torch.from_numpy(want.copy()))
+        want_all = torch.stack(allw).numpy()
+        nbrs = sg.dist_neighbors_host(rank, world, want_all)       # (peer, send_count, recv_count, recv_offset)
         send_idx = {}
         reqs = []
-        for q_ in range(world):
-            if q_ == rank:
-                continue
-            if want[q_]:
-                req = torch.from_numpy((halo[owner == q_] - 1 - starts[q_]).astype(np.int64))
-                reqs.append(dist.isend(req, q_))
-            if allw[q_][rank]:
-                buf = torch.zeros(int(allw[q_][rank]), dtype=torch.int64)
-                reqs.append(dist.irecv(buf, q_))
-                send_idx[q_] = buf
+        for peer, sc, rc, ro in nbrs:                                # RCCL: one grouped ncclSend/ncclRecv
+            if rc:
+                reqs.append(dist.isend(torch.from_numpy(req[ro:ro + rc].copy()), peer))
+            if sc:
+                send_idx[peer] = torch.zeros(sc, dtype=torch.int32)
+                reqs.append(dist.irecv(send_idx[peer], peer))
         for r in reqs:
             r.wait()
+        # the lists this rank received must be the ones the in-process partition builds
+        links = [l for l in sg.partition_links_host(starts, ptr, node) if l["sender"] == rank]
+        ok_links = len(links) == len(send_idx)
+        for l in links:
+            got = send_idx.get(l["receiver"])
+            ok_links = ok_links and got is not None and np.array_equal(got.numpy(), l["send_idx"])
+            mine = [t for t in sg.partition_links_host(starts, ptr, node) if t["receiver"] == rank and t["sender"] == l["receiver"]]
+            for t in mine:      # and my halo offsets are the receiver-side offsets of those links
+                ok_links = ok_links and any(p_ == t["sender"] and ro_ == t["recv_offset"] and rc_ == len(t["send_idx"])
+                                            for p_, _, rc_, ro_ in nbrs)
 
         def exchange(xext):
             rq, bufs = [], {}
-            for q_, idx in send_idx.items():
-                rq.append(dist.isend(torch.from_numpy(xext[idx.numpy()].copy()), q_))
-            for q_ in range(world):
-                if q_ != rank and want[q_]:
-                    bufs[q_] = torch.zeros(int(want[q_]), dtype=torch.float64)
-                    rq.append(dist.irecv(bufs[q_], q_))
+            for peer, sc, rc, ro in nbrs:
+                if sc:
+                    rq.append(dist.isend(torch.from_numpy(xext[send_idx[peer].numpy()].copy()), peer))
+                if rc:
+                    bufs[peer] = (torch.zeros(rc, dtype=torch.float64), ro, rc)
+                    rq.append(dist.irecv(bufs[peer][0], peer))
             for r in rq:
                 r.wait()
-            for q_, b in bufs.items():
-                xext[n_own:][owner == q_] = b.numpy()
+            for peer, (b_, ro, rc) in bufs.items():
+                xext[n_own + ro:n_own + ro + rc] = b_.numpy()
 
         def matvec(v_own):
             xext = np.zeros(n_own + len(halo))
@@ -124,26 +138,72 @@ def _worker(rank, world, port, case, q):
             its += 1
         xr, itr, _, _ = orc.cg(A, b, tol=tol)
         rel = float(np.abs(xl - xr[r0:r1]).max() / np.abs(xr).max())
-        q.put((rank, ok_mv, its, itr, rel, len(halo)))
+        q.put((rank, ok_mv, its, itr, rel, len(halo), bool(ok_links)))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["poisson2d", "laplace3d"])
-def test_two_rank_gloo_partition_protocol(case):
+@pytest.mark.parametrize("case,world", [("poisson2d", 2), ("laplace3d", 2), ("laplace3d", 3)])
+def test_gloo_partition_protocol_on_product_planners(case, world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, ok_mv, its, itr, rel, nh in res:
+    for rank, ok_mv, its, itr, rel, nh, ok_links in res:
         assert nh > 0
+        assert ok_links, f"rank {rank}: send lists over gloo differ from sgm_csr_create_partitioned's links"
         assert ok_mv, f"rank {rank}: partitioned matvec rows differ from the serial matvec"
         assert abs(its - itr) <= 1
         assert rel <= 1e-12
+
+
+def test_planners_agree_without_any_transport():
+    """dist_plan + neighbours for every rank, with the want matrix assembled locally, reproduce
+    the in-process links (what the gloo test checks, for more ranks and an uneven partition)."""
+    import sigma_amd as sg
+    from sigma_amd import problems as P
+    ptr, node, val = P.laplace3d_csr(7, 6, 11)
+    n = 7 * 6 * 11
+    for world in (2, 3, 5, 8):
+        starts = sg.partition_rows_by_nnz(ptr, world, align=2)
+        assert starts[0] == 0 and starts[-1] == n and np.all(np.diff(starts) > 0) and np.all(starts[:-1] % 2 == 0)
+        plans = []
+        for r in range(world):
+            r0, r1 = int(starts[r]), int(starts[r + 1])
+            _, halo = sg.halo_plan_host(r1 - r0, r0, node[ptr[r0] - 1: ptr[r1] - 1])
+            plans.append((halo,) + sg.dist_plan_host(r, world, starts, halo))
+        want_all = np.stack([p[1] for p in plans])
+        links = sg.partition_links_host(starts, ptr, node)
+        seen = 0
+        for r in range(world):
+            for peer, sc, rc, ro in sg.dist_neighbors_host(r, world, want_all):
+                if rc:      # what r asks of peer == the link peer -> r
+                    l = [t for t in links if t["sender"] == peer and t["receiver"] == r]
+                    assert len(l) == 1 and l[0]["recv_offset"] == ro
+                    assert np.array_equal(l[0]["send_idx"], plans[r][3][ro:ro + rc])
+                    halo = plans[r][0]
+                    assert np.array_equal(halo[ro:ro + rc] - 1 - starts[peer], l[0]["send_idx"])
+                    seen += 1
+                assert sc == want_all[peer][r]
+        assert seen == len(links)
+
+
+def test_partition_rows_by_nnz_balances_bytes():
+    import sigma_amd as sg
+    rs_ = np.random.RandomState(3)
+    n = 20000
+    cnt = rs_.randint(0, 40, size=n)
+    cnt[:2000] = 200            # a dense head: equal-row blocks would be badly unbalanced
+    ptr = np.concatenate([[1], 1 + np.cumsum(cnt)]).astype(np.int32)
+    for parts in (2, 4, 8):
+        starts = sg.partition_rows_by_nnz(ptr, parts, align=16)
+        assert starts[0] == 0 and starts[-1] == n and np.all(starts[1:-1] % 16 == 0)
+        w = np.array([12 * (ptr[starts[i + 1]] - ptr[starts[i]]) + 20 * (starts[i + 1] - starts[i]) for i in range(parts)], float)
+        assert w.max() / w.mean() < 1.05

@@ -1,0 +1,101 @@
+"""The multi-rank code path of the product, executed: several PROCESSES, each a rank of
+sgm_comm_init / sgm_csr_create_dist, halo exchange + all-reduced dots inside the device-resident
+solvers (tests/dist_worker.py does the checking against the oracle, bit-exact rows).
+
+* test_ranks_share_one_gpu_over_the_host_staged_transport: RCCL refuses two ranks per device and the
+  GPU boxes have one GPU, so SGM_RCCL_LIB swaps RCCL for tests/mock_rccl (same ncclXxx entry
+  points, messages staged through POSIX shared memory).  Everything above the transport is the
+  product code that runs over xGMI.
+* test_ranks_on_two_gpus_over_rccl: the same workers over real RCCL; skipped with fewer than 2 GPUs.
+* bench.py --gpus 2 typed plainly: the parent only spawns; checked here on the GPU box with the
+  host-staged transport, and in tests/test_cabi_cpu.py on a CPU box (children fail with
+  SGM_ERR_NO_DEVICE).
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MOCK = os.path.join(ROOT, "tests", "mock_rccl", "librccl_mock.so")
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+def _run_ranks(world, case, tmp_path, mock):
+    port = _free_port()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if mock:
+        env["SGM_RCCL_LIB"] = MOCK
+    else:
+        env.pop("SGM_RCCL_LIB", None)
+    outs = [str(tmp_path / f"rank{r}.json") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r), str(world), str(port),
+                               case, outs[r]], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    deadline = time.time() + 420
+    while any(p.poll() is None for p in procs) and time.time() < deadline:
+        time.sleep(0.1)
+    for p in procs:                 # the exact PIDs started here, nothing else
+        if p.poll() is None:
+            p.kill()
+    logs = [p.communicate()[0].decode(errors="replace")[-3000:] for p in procs]
+    results = []
+    for r in range(world):
+        assert os.path.exists(outs[r]), f"rank {r} wrote no result (rc {procs[r].returncode}):\n{logs[r]}"
+        results.append(json.load(open(outs[r])))
+    for r, res in enumerate(results):
+        assert res["ok"], f"rank {r}: {res.get('error')}\n{logs[r]}"
+        assert res["n_halo"] > 0
+    return results
+
+
+@pytest.mark.parametrize("world,case", [(2, "poisson2d"), (2, "laplace3d"), (3, "laplace3d"), (3, "random"), (4, "poisson2d")])
+def test_ranks_share_one_gpu_over_the_host_staged_transport(world, case, tmp_path):
+    assert os.path.exists(MOCK), "tests/mock_rccl/librccl_mock.so is missing: run __graft_entry__.build()"
+    results = _run_ranks(world, case, tmp_path, mock=True)
+    its = {k: {r["solves"][k]["iterations"] for r in results} for k in results[0]["solves"]}
+    for k, v in its.items():        # every rank stops at the same iteration (the flag follows all-reduced values)
+        assert len(v) == 1, (k, v)
+
+
+@pytest.mark.parametrize("case", ["poisson2d", "laplace3d"])
+def test_ranks_on_two_gpus_over_rccl(case, tmp_path):
+    if _device_count() < 2:
+        pytest.skip("needs 2 GPUs: RCCL refuses two ranks on one device")
+    _run_ranks(2, case, tmp_path, mock=False)
+
+
+def test_bench_gpus_2_typed_plainly_spawns_its_ranks(tmp_path):
+    """`python bench.py --gpus 2`: the parent spawns 2 rank processes before any GPU call and relays
+    rank 0's JSON line.  Small grids, both ranks on the one GPU of the box over the host-staged transport."""
+    env = dict(os.environ)
+    env.update({"SGM_RCCL_LIB": MOCK, "SGM_BENCH_SAME_GPU": "1"})
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--spmv-per-step", "4", "--nx", "300", "--ny", "200", "--cg-steps", "20", "--c5-edge", "40",
+                        "--c5-cg-steps", "10", "--no-cpu"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, p.stdout[-2000:]
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["roofline"]["frac"] <= 1.0
+    assert out["cg"]["iterations"] == 20 and out["c5_strong_scaling"]["cg_iterations"] == 10
+    assert out["config"]["parallelism"] == "row-partition x2"
