@@ -1,59 +1,3 @@
-# INTEGRATION — binding libsigma_hip.so from SiGMA (Fortran 2003, ISO_C_BINDING)
-
-The drop-in boundary is `include/sigma_hip.h` (C ABI, `sigma_amd/libsigma_hip.so`).  The
-reference has no FFI for the matvec / solver path (`src/wrapper.f90` wraps graph edits only and
-is excluded from the build, `src/CMakeLists.txt:39-40`), so the binding below is what a
-maintainer adds to `src/`.
-
-**It is a compiled file, not a sketch.**  `oracle/hip_binding.f90` is quoted verbatim in §1
-(`tools/sync_integration_md.py` keeps the two identical, `tests/test_cabi_cpu.py` checks it).
-`oracle/build_ref.sh` compiles it with amdflang against the reference's own `.mod` files
-(`oracle/_ref/obj/`) and links `oracle/hip_binding_test.f90` with the reference's objects and
-`libsigma_hip.so` into `oracle/_ref/hip_binding_test`:
-
-* CPU suite (`-m "not gpu"`): the program links and, with no GPU, ends at its first product with
-  the reference's error behaviour — message, `Terminating.`, `exit(1)`.
-* GPU suite (`-m gpu`, the binary travels with the snapshot): the reference's two deterministic
-  solver tests (`test/solver_test_diffusion_1d.f90:50-120`,
-  `test/solver_test_advection_diffusion_1d.f90:55-122`, same thresholds) pass with the
-  reference's graph / matrix machinery on the host and every product / solve on the device:
-  `A%matvec` through `hip_ellpack_matrix` is bit-identical to `ellpack_matvec_add`; the
-  reference's OWN `cg()` loop over the device matvec takes its 64 iterations; `hip_cg()`,
-  `hip_bicgstab()`, `hip_jacobi()`, `hip_ldu()`, the `A%set_solver / A%solve` facade and a value
-  edit after setup (`scalar_multiply`, then `pc%setup` again) all meet the reference's bars.
-
-A stand-alone twin without any dependency on the reference's modules (it builds on the GPU box
-too) is `sigma_amd/fortran/sigma_hip.f90` + `solver_test_diffusion_1d_hip.f90`.
-
-## 1. The binding: `hip_matrices`, `hip_solvers`
-
-What it overrides, and why that is enough:
-
-* `hip_csr_matrix` **extends `csr_matrix`** (`src/matrix/formats/cs_matrices.f90:112-151`),
-  `hip_ellpack_matrix` **extends `ellpack_matrix`** (`ellpack_matrices.f90:28-105`).
-  `matvec_add` / `matvec_t_add` are ordinary overridable bindings (`cs_matrices.f90:66-67`,
-  interface `linear_operator_interface.f90:82-87`); everything else of the library —
-  `A%matvec` (`:185-194`), operator sums / products / adjoints, the reference's own CG and
-  BiCGStab loops, `generalized_lanczos`, composite blocks — reaches the device through them.
-  The arrays go over exactly as the reference holds them: `A%g%ptr`, `A%g%node` (1-based int32,
-  `cs_graphs.f90:16`), `A%val`; ELLPACK: `g%node(max_d,n)`, `val(max_d,n)` with their padding.
-* `matvec_add` takes the matrix `intent(in)`, so the device handle sits behind a pointer
-  component (`hip_device_copy`) whose target may be brought up to date from inside it.  The
-  mutators (`set_value`, `add_value`, `set/add_multiple_values`, `zero`, `scalar_multiply`,
-  `left/right_permute`, `set_graph`, `copy_graph`, `copy_matrix`) call the reference's own code
-  and mark the copy stale; host code that writes `A%val(:)` directly calls `A%values_changed()`.
-* `hip_krylov_solver` / `hip_preconditioner` **extend `linear_solver`**
-  (`linear_operator_interface.f90:61-73`) with `setup`, `linear_solve`, `linear_solve_pc`,
-  `destroy` and the public fields callers read (`iterations`, `tolerance`, `nn`, `initialized`,
-  `cg_solvers.f90:10-28`); factories `hip_cg(tol)`, `hip_bicgstab(tol)`, `hip_gmres(tol, restart)`,
-  `hip_jacobi()`, `hip_ldu()` return `class(linear_solver), pointer` like `cg()`
-  (`cg_solvers.f90:36-47`).  A hip solver handed a non-hip operator or preconditioner stops with
-  a message (there is no CPU fallback inside the binding; `cg()` remains available for those).
-* Errors: every C function returns an `int`; `hip_check` turns nonzero into the reference's
-  print + `call exit(1)` (`cg_solvers.f90:61-65`) with the text of `sgm_last_error()`.
-
-<!-- BEGIN oracle/hip_binding.f90 -->
-```fortran
 !==========================================================================!
 ! hip_binding.f90 -- the REFERENCE-SIDE binding of libsigma_hip.so.        !
 !                                                                          !
@@ -951,42 +895,3 @@ end subroutine hip_pc_destroy
 
 
 end module hip_solvers
-```
-<!-- END oracle/hip_binding.f90 -->
-
-## 2. The rest of the surface (same pattern, see `include/sigma_hip.h`)
-
-| reference call | C entry point |
-|---|---|
-| `type(sparse_matrix)` composite: `set_submatrix`, block `matvec_add` (`sparse_matrix_composites.f90:1076-1127`) | with hip leaves the reference's own block loop already runs on the device; `sgm_composite_create(nrb, ncb, row_ptr, col_ptr, blocks)` gives ONE handle for the device-resident solvers |
-| `g%add_edge` … `convert_graph_type` … `A%set_value` (assembly, `test/solver_test_jacobi.f90:73-128`) | `sgm_csr_from_edges` / `sgm_ell_from_edges` (edge list in insertion order + values), `sgm_mat_get` to read `ptr/node/val` back |
-| `breadth_first_search`, `greedy_coloring`, `greedy_color_ordering` (`src/graph/permutations.f90`) on `A%g`; `A%left_permute(p)`, `A%right_permute(p)` (`cs_matrices.f90:471-490`) | `sgm_graph_bfs_order`, `sgm_graph_greedy_coloring`, `sgm_graph_greedy_color_order` (host int32 outputs, 1-based); `sgm_mat_left_permute`, `sgm_mat_right_permute` (device; set preconditioners up again afterwards) |
-| `lanczos`, `generalized_lanczos` (`src/eigensolver.f90:27-155`) | `sgm_lanczos`, `sgm_generalized_lanczos` (T and Q come back; `dstev` stays with LAPACK on the host) |
-| `A%to_file(filename, trans)` (`sparse_matrix_interfaces.f90:601-653`) | host-side only: `sgm_mat_get` the three arrays and write `i j val` lines (`sigma_amd.csr_matrix.to_file / from_file`) |
-
-`sgm_set_option(name, value)` switches device formats without changing results (all variants are
-bit-identical and covered by `tests/test_gpu_parity.py`); `sgm_mat_kernel(A, buf, len)` names the
-SpMV kernel a handle runs with; `sgm_mat_footprint` reports resident bytes and bytes moved per
-product.
-
-## 3. Build
-
-```
-make -C sigma_amd/csrc                 # hipcc --offload-arch=gfx950 -> sigma_amd/libsigma_hip.so
-amdflang -O2 -c hip_binding.f90        # needs the reference's .mod files on the include path
-amdflang -o my_test my_test.f90 hip_binding.o -L<sigma build> -lsigma -Lsigma_amd -lsigma_hip
-```
-In CMake terms (`src/CMakeLists.txt:41`): add the file to the library and
-`target_link_libraries(sigma sigma_hip)`.  `oracle/build_ref.sh` is the recipe used here.
-
-## 4. Other hosts
-
-* C / C++: include `include/sigma_hip.h`, link `-lsigma_hip` (`tools/spmv_bench.cpp` is a
-  40-line example: create, matvec on device buffers, CG).
-* Python: `sigma_amd/__init__.py` is the ctypes binding used by the tests and `bench.py`
-  (numpy arrays = host, CUDA torch tensors = device pointers).
-* Multi-GPU: one process per GPU; `sgm_comm_unique_id` on rank 0, broadcast the 128 bytes with
-  whatever the host has (MPI, `torch.distributed`), `sgm_comm_init`, then
-  `sgm_csr_create_dist(comm, row_starts, local ptr, GLOBAL node, val)`
-  (`sgm_partition_rows_by_nnz` picks balanced `row_starts`); vectors are `[owned | halo]`
-  (`sgm_mat_info(...,&x_len)`), solver calls are collective.

@@ -174,6 +174,22 @@ def perm_cases():
          rs.random_sample(n), [(CG, LDU, 1e-14)], mode="perm")
 
 
+def eig_cases():
+    """lanczos / generalized_lanczos (src/eigensolver.f90:27-155, ref_driver mode `eig:<nsteps>`).
+    The reference draws its start vector from a TIME-SEEDED generator (util.f90:72-102), so these
+    two fixtures hold a different Q(:,1) every time they are regenerated; the tests feed the
+    fixture's own Q(:,1) back as the start vector and compare T and Q from there."""
+    nx, ny = 16, 12
+    n = nx * ny
+    case("eig_poisson2d_16x12", n, n, CSR, P.poisson2d_edges(nx, ny), P.test_vector(n), np.full(n, 1.0 / n), [],
+         mode="eig:12", extra=dict(nsteps=np.int32(12), time_seeded_start_vector=np.int32(1)))
+    nx, ny, nz = 6, 5, 4
+    n = nx * ny * nz
+    case("eig_laplace3d_6x5x4", n, n, CSR, P.laplace3d_edges(nx, ny, nz), P.test_vector(n), np.full(n, 1.0 / n), [],
+         mode="eig:10", extra=dict(nsteps=np.int32(10), time_seeded_start_vector=np.int32(1)))
+
+
 if __name__ == "__main__":
     main()
     perm_cases()
+    eig_cases()

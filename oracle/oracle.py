@@ -271,6 +271,17 @@ def lanczos(A, nsteps, q1):
     return T.T.copy(), Q.T.copy()
 
 
+def generalized_lanczos(A, B, nsteps, q1, tol=1e-14):
+    """generalized_lanczos(A, B, T, Q) (eigensolver.f90:95-155), B%solve = CG(tol), start vector
+    given: returns (T[3, nsteps], Q[n, nsteps]).  CSR operands."""
+    T = np.zeros((nsteps, 3), F8)
+    Q = np.zeros((nsteps, A.n), F8)
+    q1 = np.ascontiguousarray(q1, F8)
+    lib().orc_generalized_lanczos(C.c_int32(A.n), _p(A.ptr), _p(A.node), _p(A.val), _p(B.ptr), _p(B.node), _p(B.val),
+                                  C.c_double(tol), C.c_int32(nsteps), _p(q1), _p(T), _p(Q))
+    return T.T.copy(), Q.T.copy()
+
+
 def bfs_order(A):
     """breadth_first_search(p, g) (permutations.f90:22-78) on the matrix graph: p(i) = visiting number."""
     p = np.zeros(A.n, I4)

@@ -40,11 +40,16 @@ use bicgstab_solvers
 use jacobi_solvers
 use ldu_solvers
 use permutations
+use eigensolver
 
 implicit none
 
     character(len=512) :: infile, outprefix, mode
-    logical :: timing, perm_mode
+    logical :: timing, perm_mode, eig_mode
+    integer :: nsteps
+    real(dp), allocatable :: Tl(:,:), Ql(:,:)
+    type(csr_matrix), target :: Bcsr
+    class(linear_solver), pointer :: bsolver
     integer :: reps, rep, ncol
     integer, allocatable :: pp(:), cptrs(:)
     integer(8) :: c0, c1, crate
@@ -63,10 +68,15 @@ implicit none
     call getarg(2, outprefix)
     timing = .false.
     perm_mode = .false.
+    eig_mode = .false.
     reps = 0
     if (command_argument_count() >= 3) then
         call getarg(3, mode)
         if (mode(1:4) == 'perm') perm_mode = .true.
+        if (mode(1:4) == 'eig:') then
+            eig_mode = .true.
+            read(mode(5:), *) nsteps
+        endif
         if (mode(1:5) == 'time:') then
             timing = .true.
             read(mode(6:), *) reps
@@ -220,6 +230,36 @@ implicit none
         y = -7.0_dp
         call A%matvec(x, y)
         call dump_f8('perm_y', y, n)
+    endif
+
+    !------------------------------------------------------------------!
+    ! Lanczos (src/eigensolver.f90:27-90) and generalized Lanczos        !
+    ! (:95-155) with B = a diagonally dominant matrix on A's graph and   !
+    ! B%solve = the reference's CG.  Q(:,1) of each dump is the          !
+    ! (time-seeded) start vector the run used.                           !
+    !------------------------------------------------------------------!
+    if (eig_mode .and. fmt == 1) then
+        allocate(Tl(3, nsteps), Ql(n, nsteps))
+        call lanczos(A, Tl, Ql)
+        call dump_f8('lanczos_T', reshape(Tl, [3 * nsteps]), 3 * nsteps)
+        call dump_f8('lanczos_Q', reshape(Ql, [n * nsteps]), n * nsteps)
+
+        call Bcsr%init(n, m)
+        call Bcsr%set_graph(g)
+        call Bcsr%zero()
+        do k = 1, ne
+            if (ei(k) == ej(k)) then
+                call Bcsr%set_value(ei(k), ej(k), 1.0_dp + mod(ei(k), 7) / 16.0_dp)
+            else
+                call Bcsr%set_value(ei(k), ej(k), -1.0_dp / 16.0_dp)
+            endif
+        enddo
+        call dump_f8('B_val', Bcsr%val, size(Bcsr%val))
+        bsolver => cg(1.0d-14)
+        call Bcsr%set_solver(bsolver)
+        call generalized_lanczos(A, Bcsr, Tl, Ql)
+        call dump_f8('glanczos_T', reshape(Tl, [3 * nsteps]), 3 * nsteps)
+        call dump_f8('glanczos_Q', reshape(Ql, [n * nsteps]), n * nsteps)
     endif
 
     !------------------------------------------------------------------!

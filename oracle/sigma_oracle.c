@@ -706,6 +706,51 @@ ORC_API void orc_lanczos(int32_t fmt, int32_t nrow, int32_t max_d, const int32_t
     free(w);
 }
 
+/* generalized_lanczos(A, B, T, Q) (src/eigensolver.f90:95-155): Lanczos for A x = lambda B x;
+ * every step solves B w = v with B's solver -- here the unpreconditioned CG restatement with
+ * absolute tolerance `tol`, started from the CURRENT content of w (= A q_i, the reference's
+ * `call B%solve(w, v)` hands w over as the initial guess).  No re-orthogonalisation (:131-148).
+ * The start vector replaces the time-seeded random_number (:120-122); it is normalised in the
+ * B-norm like :123-124.  T: 3 x n column-major, Q: nrow x n column-major. */
+ORC_API void orc_generalized_lanczos(int32_t nrow, const int32_t *Aptr, const int32_t *Anode, const double *Aval,
+                                     const int32_t *Bptr, const int32_t *Bnode, const double *Bval, double tol,
+                                     int32_t n, const double *q1, double *T, double *Q)
+{
+    orc_op A = {1, nrow, 0, Aptr, Anode, Aval}, B = {1, nrow, 0, Bptr, Bnode, Bval};
+    orc_solve_args sa;
+    memset(&sa, 0, sizeof sa);
+    sa.fmt = 1; sa.n = nrow; sa.ptr = Bptr; sa.node = Bnode; sa.val = Bval; sa.tol = tol;
+    double *w = calloc(nrow, 8), *v = calloc(nrow, 8), *z = calloc((size_t)nrow * (n + 1), 8);
+    double alpha = 0.0, beta = 0.0;
+    memset(T, 0, (size_t)3 * n * 8);
+    memset(Q, 0, (size_t)nrow * n * 8);
+#define QC(i) (Q + (size_t)((i) - 1) * nrow)
+#define ZC(i) (z + (size_t)(i) * nrow)              /* z(:, 0:n) */
+    op_matvec(&B, q1, w);
+    {
+        const double nrm = sqrt(dot(nrow, w, q1));
+        for (int32_t l = 0; l < nrow; l++) QC(1)[l] = q1[l] / nrm;
+    }
+    op_matvec(&B, QC(1), ZC(1));
+    for (int32_t i = 1; i <= n - 1; i++) {
+        op_matvec(&A, QC(i), w);
+        for (int32_t l = 0; l < nrow; l++) v[l] = w[l] - beta * ZC(i - 1)[l];
+        alpha = dot(nrow, v, QC(i));
+        for (int32_t l = 0; l < nrow; l++) v[l] = v[l] - alpha * ZC(i)[l];
+        orc_cg(&sa, w, v, NULL);                     /* call B%solve(w, v) */
+        beta = sqrt(dot(nrow, w, v));
+        for (int32_t l = 0; l < nrow; l++) QC(i + 1)[l] = w[l] / beta;
+        for (int32_t l = 0; l < nrow; l++) ZC(i + 1)[l] = v[l] / beta;
+        T[3 * (i - 1) + 1] = alpha; T[3 * (i - 1) + 2] = beta; T[3 * (i - 1) + 0] = beta;
+    }
+    op_matvec(&A, QC(n), v);
+    for (int32_t l = 0; l < nrow; l++) v[l] = v[l] - beta * ZC(n)[l];
+    T[3 * (n - 1) + 1] = dot(nrow, QC(n), v);       /* the loop index is n after the loop (:151) */
+#undef QC
+#undef ZC
+    free(w); free(v); free(z);
+}
+
 /* ------------------------------------------------------------------------ */
 /* Timing helpers for bench.py's cpu_baseline leg ("port", 1 thread: the     */
 /* reference has no threading, CMakeLists.txt:17-20).                       */

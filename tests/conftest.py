@@ -25,7 +25,12 @@ def golden():
 
 def golden_names():
     """Fixtures whose solves ran on the matrix as assembled (the `perm_*` ones re-order it first)."""
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and not f.startswith("perm_"))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and not f.startswith(("perm_", "eig_", "comp_")))
+
+
+def eig_golden_names():
+    """Fixtures of lanczos / generalized_lanczos (time-seeded start vector kept in the fixture)."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f.startswith("eig_"))
 
 
 def perm_golden_names(ell=False):

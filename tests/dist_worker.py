@@ -94,12 +94,13 @@ def run(rank, world, port, case, res):
         y = np.zeros(n_own)
         H.matvec(xe, y)
         assert np.array_equal(y, y_ref), "distributed matvec rows differ from the serial matvec"
-        assert np.array_equal(xe[n_own:], x[halo - 1]), "halo region does not hold the neighbours' x entries"
         xd = torch.zeros(H.x_len, dtype=torch.float64, device=dev)
         xd[:n_own] = torch.from_numpy(x[r0:r1]).to(dev)
         yd = torch.full((n_own,), -3.0, dtype=torch.float64, device=dev)
         H.matvec(xd, yd)
         assert np.array_equal(yd.cpu().numpy(), y_ref)
+        # a device vector is used in place: its halo region now holds the neighbours' x entries
+        assert np.array_equal(xd[n_own:].cpu().numpy(), x[halo - 1]), "halo region does not hold the neighbours' x entries"
         y0 = np.random.RandomState(7).standard_normal(n)
         ya = y0[r0:r1].copy()
         H.matvec_add(xe, ya)

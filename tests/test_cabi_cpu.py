@@ -115,3 +115,25 @@ def test_fortran_shim_binds_only_declared_symbols():
     names = set(re.findall(r"bind\(c,\s*name='(sgm_[a-z0-9_]+)'\)", src))
     assert len(names) >= 20
     assert names <= set(declared_symbols())
+
+
+REF_BINDING_TEST = os.path.join(ROOT, "oracle", "_ref", "hip_binding_test")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BINDING_TEST), reason="oracle/_ref not built (no reference sources / compiler here)")
+@pytest.mark.skipif(_has_gpu(), reason="GPU present: the loud-failure path cannot be seen")
+def test_reference_side_binding_links_and_dies_like_the_reference_without_a_gpu():
+    """oracle/hip_binding.f90 -- types that EXTEND the reference's csr_matrix / ellpack_matrix /
+    linear_solver -- compiled against the reference's own modules and linked with libsigma_hip.so
+    (oracle/build_ref.sh).  Without a GPU its first product ends the program the way the
+    reference ends on errors: a message and exit(1) (cg_solvers.f90:61-65)."""
+    import subprocess
+    p = subprocess.run([REF_BINDING_TEST], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 1
+    assert "sigma_hip status" in p.stdout and "Terminating." in p.stdout and "no HIP device" in p.stdout
+
+
+def test_integration_md_quotes_the_compiled_binding_verbatim():
+    src = open(os.path.join(ROOT, "oracle", "hip_binding.f90")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert src.strip() in doc, "INTEGRATION.md must carry oracle/hip_binding.f90 verbatim (tools/sync_integration_md.py)"

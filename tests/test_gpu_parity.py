@@ -1570,3 +1570,23 @@ def test_fortran_host_layer():
     r = subprocess.run([exe, "-v"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all sigma_hip Fortran checks passed" in r.stdout
+
+
+def test_reference_side_binding_runs_the_references_own_tests():
+    """oracle/_ref/hip_binding_test (built in the reference container by oracle/build_ref.sh; the
+    binary travels, the reference sources do not): the reference's graph / matrix code on the host,
+    hip_csr_matrix / hip_ellpack_matrix EXTENDING its types, the reference's own cg() loop over the
+    device matvec, hip_cg / hip_bicgstab / hip_jacobi / hip_ldu behind linear_solver, the A%solve
+    facade -- with the thresholds of test/solver_test_diffusion_1d.f90 and
+    test/solver_test_advection_diffusion_1d.f90."""
+    import os
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(ROOT, "oracle", "_ref", "hip_binding_test")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/hip_binding_test was not built")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "bit-identical to the reference" in p.stdout and "all passed" in p.stdout
+    its = [int(ln.split("iterations")[1].split()[0]) for ln in p.stdout.splitlines() if "reference cg() on hip matrix" in ln]
+    assert its == [64]          # the reference's own count on this problem (SURVEY 8c)

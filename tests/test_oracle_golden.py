@@ -11,7 +11,7 @@ Also re-checks the known answers of the reference's own tests
 import numpy as np
 import pytest
 
-from conftest import golden_names, perm_golden_names
+from conftest import eig_golden_names, golden_names, perm_golden_names
 import oracle as orc
 
 CG, BICGSTAB = 1, 2
@@ -209,3 +209,25 @@ def test_ellpack_reorderings_and_permutation_bit_exact(golden, name):
     assert np.array_equal(deg, g["ref_perm_degrees"])
     B = orc.EllMatrix(E.n, E.m, E.max_d, node, val, deg)
     assert np.array_equal(B.matvec(g["x"]), g["ref_perm_y"])
+
+
+@pytest.mark.parametrize("name", eig_golden_names())
+def test_lanczos_and_generalized_lanczos_vs_the_reference(golden, name):
+    """lanczos / generalized_lanczos (eigensolver.f90:27-155) run by the reference itself
+    (oracle/ref_driver.f90, mode eig:<n>); the fixture's Q(:,1) is the time-seeded start vector
+    of that run and is fed back as the oracle's.  B%solve in the reference run = cg(1e-14)."""
+    g = golden(name)
+    n, ns = int(g["n"]), int(g["nsteps"])
+    A = orc.CsrMatrix.from_edges(n, n, g["ei"], g["ej"], g["ev"])
+    assert np.array_equal(A.val, g["ref_val"])
+    T, Q = g["ref_lanczos_T"].reshape(ns, 3).T, g["ref_lanczos_Q"].reshape(ns, n).T
+    To, Qo = orc.lanczos(A, ns, Q[:, 0].copy())
+    assert np.abs(To - T).max() <= 1e-12 and np.abs(Qo - Q).max() <= 1e-12
+    assert np.array_equal(T[0], T[2]) and T[0, -1] == 0.0
+    B = orc.CsrMatrix(n, n, A.ptr, A.node, g["ref_B_val"])
+    T, Q = g["ref_glanczos_T"].reshape(ns, 3).T, g["ref_glanczos_Q"].reshape(ns, n).T
+    To, Qo = orc.generalized_lanczos(A, B, ns, Q[:, 0].copy(), 1e-14)
+    assert np.abs(To - T).max() <= 1e-11 and np.abs(Qo - Q).max() <= 1e-11
+    # the vectors are B-orthonormal: Q^T B Q = I
+    BQ = np.stack([B.matvec(Q[:, k].copy()) for k in range(ns)], axis=1)
+    assert np.abs(Q.T @ BQ - np.eye(ns)).max() <= 1e-8
