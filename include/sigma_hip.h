@@ -229,6 +229,14 @@ int sgm_solver_destroy(sgm_solver s);
  * time-seeded RNG); it is normalised inside.                                              */
 int sgm_lanczos(sgm_mat A, int32_t nsteps, const double *q1, double *T_host, double *Q_out, int where);
 
+/* sgm_generalized_lanczos <- generalized_lanczos(A, B, T, Q)  src/eigensolver.f90:95-155: Lanczos for
+ * A x = lambda B x.  Every step solves B w = v with `solver_for_B` (set up for B by the caller, like
+ * B%set_solver; optional preconditioner), started from w = A q_i as the reference's
+ * `call B%solve(w, v)` does (:140).  No re-orthogonalisation (the reference has none here); q1 is
+ * normalised in the B-norm (:123-124).  T_host / Q_out as in sgm_lanczos.                  */
+int sgm_generalized_lanczos(sgm_mat A, sgm_mat B, sgm_solver solver_for_B, sgm_pc pc_or_null, int32_t nsteps,
+                            const double *q1, double *T_host, double *Q_out, int where);
+
 /* ---- row-partitioned multi-GPU (nothing in the reference) ---------------- *
  * One process per GPU.  Rank r owns the contiguous global rows
  * [row_starts[r], row_starts[r+1]) of A and the same slice of every vector.

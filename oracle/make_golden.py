@@ -189,7 +189,24 @@ def eig_cases():
          mode="eig:10", extra=dict(nsteps=np.int32(10), time_seeded_start_vector=np.int32(1)))
 
 
+def comp_cases():
+    """The composite `sparse_matrix` (sparse_matrix_composites.f90): the same entries split into a
+    2 x 2 block matrix at row/column nb1 (ref_driver mode `comp:<nb1>`); y, y_add, yt, yt_add and
+    the solves (CG, CG + Jacobi: jacobi_setup reads the composite through get_value) are the
+    composite's.  The blocks' own ptr/node/val are in the fixture as ref_blk<it><jt>_*."""
+    nx, ny = 32, 24
+    n = nx * ny
+    case("comp_poisson2d_32x24", n, n, CSR, P.poisson2d_edges(nx, ny), P.test_vector(n), np.full(n, 1.0 / n),
+         [(CG, NOPC, 1e-12), (CG, JACOBI, 1e-12), (BICGSTAB, JACOBI, 1e-12)], mode="comp:401",
+         extra=dict(nb1=np.int32(401)))
+    n = 128
+    rs = np.random.RandomState(27)
+    case("comp_random_spd_128", n, n, CSR, P.random_spd_edges(n, seed=3, skew=False), rs.random_sample(n),
+         rs.random_sample(n), [(CG, NOPC, 1e-14), (CG, JACOBI, 1e-14)], mode="comp:50", extra=dict(nb1=np.int32(50)))
+
+
 if __name__ == "__main__":
     main()
     perm_cases()
     eig_cases()
+    comp_cases()

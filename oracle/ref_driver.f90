@@ -45,7 +45,12 @@ use eigensolver
 implicit none
 
     character(len=512) :: infile, outprefix, mode
-    logical :: timing, perm_mode, eig_mode
+    logical :: timing, perm_mode, eig_mode, comp_mode
+    integer :: nb1, it, jt, bi, bj, r0(3), nbe
+    type(sparse_matrix), target :: Scomp
+    class(graph_interface), pointer :: gb
+    type(csr_matrix), pointer :: Cb
+    character(len=8) :: btag
     integer :: nsteps
     real(dp), allocatable :: Tl(:,:), Ql(:,:)
     type(csr_matrix), target :: Bcsr
@@ -69,10 +74,15 @@ implicit none
     timing = .false.
     perm_mode = .false.
     eig_mode = .false.
+    comp_mode = .false.
     reps = 0
     if (command_argument_count() >= 3) then
         call getarg(3, mode)
         if (mode(1:4) == 'perm') perm_mode = .true.
+        if (mode(1:5) == 'comp:') then
+            comp_mode = .true.
+            read(mode(6:), *) nb1
+        endif
         if (mode(1:4) == 'eig:') then
             eig_mode = .true.
             read(mode(5:), *) nsteps
@@ -161,6 +171,52 @@ implicit none
             & size(Aell%g%node))
         call dump_f8('val', reshape(Aell%val, [size(Aell%val)]), &
             & size(Aell%val))
+    endif
+
+    !------------------------------------------------------------------!
+    ! comp:<nb1> -- the same entries as a 2 x 2 composite `sparse_matrix` !
+    ! (sparse_matrix_composites.f90:41-162): rows / columns split at nb1, !
+    ! every block a csr_matrix built from the edges that fall into it, in !
+    ! the insertion order of the edge list.  From here on A is the        !
+    ! composite: the products and solves below go through                 !
+    ! composite_matvec_add (:1076-1099) / composite_matvec_t_add          !
+    ! (:1104-1127) and composite_mat_get_value (:465-485).                !
+    !------------------------------------------------------------------!
+    if (comp_mode .and. fmt == 1) then
+        r0 = [0, nb1, n]
+        call Scomp%set_dimensions(n, m)
+        call Scomp%set_block_sizes([nb1, n - nb1], [nb1, m - nb1])
+        do it = 1, 2
+            do jt = 1, 2
+                allocate(ll_graph :: gb)
+                call gb%init(r0(it + 1) - r0(it), r0(jt + 1) - r0(jt))
+                nbe = 0
+                do k = 1, ne
+                    if (ei(k) > r0(it) .and. ei(k) <= r0(it + 1) .and. ej(k) > r0(jt) .and. ej(k) <= r0(jt + 1)) then
+                        call gb%add_edge(ei(k) - r0(it), ej(k) - r0(jt))
+                        nbe = nbe + 1
+                    endif
+                enddo
+                call convert_graph_type(gb, "compressed sparse")
+                allocate(Cb)
+                call Cb%init(r0(it + 1) - r0(it), r0(jt + 1) - r0(jt))
+                call Cb%set_graph(gb)
+                call Cb%zero()
+                do k = 1, ne
+                    if (ei(k) > r0(it) .and. ei(k) <= r0(it + 1) .and. ej(k) > r0(jt) .and. ej(k) <= r0(jt + 1)) then
+                        call Cb%set_value(ei(k) - r0(it), ej(k) - r0(jt), ev(k))
+                    endif
+                enddo
+                write(btag, '(a,i0,i0)') 'blk', it, jt
+                call dump_i4(trim(btag)//'_ptr', Cb%g%ptr, size(Cb%g%ptr))
+                call dump_i4(trim(btag)//'_node', Cb%g%node, size(Cb%g%node))
+                call dump_f8(trim(btag)//'_val', Cb%val, size(Cb%val))
+                call Scomp%set_submatrix(it, jt, Cb)
+            enddo
+        enddo
+        call dump_i4('comp_row_ptr', Scomp%row_ptr, 3)
+        call dump_i4('comp_col_ptr', Scomp%col_ptr, 3)
+        A => Scomp
     endif
 
     !------------------------------------------------------------------!

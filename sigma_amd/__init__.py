@@ -475,6 +475,8 @@ class _Preconditioner:
         self.initialized = False
 
     def setup(self, A):
+        if hasattr(A, "_build"):
+            A._build()
         if not self._h:
             _ck(getattr(lib(), self._create)(C.byref(self._h), A._h))
         else:
@@ -698,6 +700,28 @@ def lanczos(A, nsteps, q1, want_Q=True):
         raise TypeError("lanczos: pass the start vector as a numpy array")
     _ck(lib().sgm_lanczos(A._h, C.c_int32(nsteps), pq, C.c_void_p(T.ctypes.data),
                           C.c_void_p(Q.ctypes.data) if want_Q else None, C.c_int(SGM_HOST)))
+    return T.T.copy(), (Q.T.copy() if want_Q else None)
+
+
+def generalized_lanczos(A, B, nsteps, q1, want_Q=True):
+    """generalized_lanczos(A, B, T, Q) (src/eigensolver.f90:95-155) on the device: Lanczos for
+    A x = lambda B x with the start vector q1.  Like the reference it uses the solver (and
+    preconditioner) set on B with B.set_solver / B.set_preconditioner for the per-step solve
+    `B%solve(w, v)`.  Returns (T[3, nsteps], Q[n, nsteps] or None)."""
+    for M in (A, B):
+        if hasattr(M, "_build"):
+            M._build()
+    if B.solver is None:
+        raise SigmaError(1, "generalized_lanczos: B has no solver set (eigensolver.f90:101-103 assumes B%set_solver)")
+    pq, w, _k = _arg(q1, np.float64)
+    if w != SGM_HOST:
+        raise TypeError("generalized_lanczos: pass the start vector as a numpy array")
+    _need(q1, A.nrow, "generalized_lanczos q1")
+    T = np.zeros((nsteps, 3), np.float64)
+    Q = np.zeros((nsteps, A.nrow), np.float64) if want_Q else None
+    _ck(lib().sgm_generalized_lanczos(A._h, B._h, B.solver._h, B.pc._h if B.pc is not None else None, C.c_int32(nsteps), pq,
+                                      C.c_void_p(T.ctypes.data), C.c_void_p(Q.ctypes.data) if want_Q else None,
+                                      C.c_int(SGM_HOST)))
     return T.T.copy(), (Q.T.copy() if want_Q else None)
 
 

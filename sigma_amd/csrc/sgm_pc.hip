@@ -102,29 +102,40 @@ struct sgm_pc_s {
 namespace {
 
 // ------------------------------------------------------------------------------ kernels
-__global__ void k_jacobi_setup_csr(int32_t n, const int32_t *__restrict__ rowptr,
+// rows [row0, row0 + count) of a leaf; the diagonal of global row i sits at local column
+// (local row) + dcol of this leaf (dcol = 0 for a plain matrix; row-block minus column-block
+// offset for a block of a composite, composite_mat_get_value sparse_matrix_composites.f90:465-485)
+__global__ void k_jacobi_setup_csr(int32_t count, int32_t row0, int32_t dcol, const int32_t *__restrict__ rowptr,
                                    const int32_t *__restrict__ col, const double *__restrict__ val,
                                    double *__restrict__ idiag)
 {
-    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const int32_t i = row0 + t, want = i + dcol;
     double z = 0.0;                                   // get_value: 0 when the entry is absent
     for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
-        if (col[k] == i) z = val[k];
-    idiag[i] = 1.0 / z;
+        if (col[k] == want) z = val[k];
+    idiag[t] = 1.0 / z;
 }
-__global__ void k_jacobi_setup_ell(int32_t n, int32_t max_d, const int32_t *__restrict__ ecol,
-                                   const double *__restrict__ eval, double *__restrict__ idiag)
+__global__ void k_jacobi_setup_ell(int32_t count, int32_t row0, int32_t dcol, int32_t n, int32_t max_d,
+                                   const int32_t *__restrict__ ecol, const double *__restrict__ eval,
+                                   double *__restrict__ idiag)
 {
-    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const int32_t i = row0 + t, want = i + dcol;
     // ellpack get_value scans the first degrees(i) slots (ellpack_matrices.f90:232-235);
     // padding repeats the last real neighbour with val 0, real neighbours are unique, so
     // the FIRST hit is the real slot.
     double z = 0.0;
     for (int32_t k = 0; k < max_d; ++k)
-        if (ecol[(int64_t)k * n + i] == i) { z = eval[(int64_t)k * n + i]; break; }
-    idiag[i] = 1.0 / z;
+        if (ecol[(int64_t)k * n + i] == want) { z = eval[(int64_t)k * n + i]; break; }
+    idiag[t] = 1.0 / z;
+}
+__global__ void k_fill_inf(int32_t count, double *idiag)
+{
+    int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count) idiag[t] = 1.0 / 0.0;
 }
 // (vectors are 16-byte aligned: 16-byte accesses for the pairs, the odd tail element alone)
 __global__ void k_scale_by(int64_t n, const double *__restrict__ d, const double *__restrict__ r,
@@ -814,8 +825,46 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
         return fail(SGM_ERR_DIMS, "Cannot make a %s solver for a non-square matrix",
                     pc->kind == SGM_PC_JACOBI ? "Jacobi" : "LDU");
     hipStream_t st = g_rt.stream;
-    if (A->fmt == SGM_FMT_COMPOSITE)
-        return fail(SGM_ERR_UNSUPPORTED, "preconditioners need a leaf (CSR / ELLPACK) matrix, not a composite");
+    auto jacobi_rows = [&](const Part &p, int32_t fmt, int32_t row0, int32_t count, int32_t dcol, double *out) {
+        const int grid = (count + kBlock - 1) / kBlock;
+        if (!grid) return;
+        if (fmt == SGM_FMT_CSR)
+            hipLaunchKernelGGL(k_jacobi_setup_csr, dim3(grid), dim3(kBlock), 0, st, count, row0, dcol, p.rowptr, p.col, p.val, out);
+        else
+            hipLaunchKernelGGL(k_jacobi_setup_ell, dim3(grid), dim3(kBlock), 0, st, count, row0, dcol, p.n, p.max_d, p.ecol,
+                               p.eval, out);
+    };
+    if (A->fmt == SGM_FMT_COMPOSITE) {
+        // jacobi_setup only needs A%get_value(i,i) (jacobi_solvers.f90:59-61), which a composite answers
+        // from the block that owns (i,i) (sparse_matrix_composites.f90:465-485).  ILDU on a composite has no
+        // reference behaviour to match: its pattern pass walks the composite's get_edges cursor, whose block
+        // advance skips block (2,1) and runs past the last column block (sparse_matrix_composites.f90:724-727).
+        if (pc->kind != SGM_PC_JACOBI)
+            return fail(SGM_ERR_UNSUPPORTED, "ILDU(0) needs a leaf CSR matrix, not a composite (the reference's own "
+                                             "pattern pass is broken on composites)");
+        if (pc->parts.size() != 1) {
+            for (auto &pp : pc->parts) dfree(pp.idiag);
+            pc->parts.assign(1, PartPC());
+        }
+        pc->n = A->nrow;
+        if (!pc->parts[0].idiag) SGM_TRY(dalloc(&pc->parts[0].idiag, (size_t)A->nrow + 2));
+        const int nrb = (int)A->blk_row_ptr.size() - 1, ncb = (int)A->blk_col_ptr.size() - 1;
+        for (int it = 0; it < nrb; ++it)
+            for (int jt = 0; jt < ncb; ++jt) {
+                const int32_t lo = std::max(A->blk_row_ptr[it], A->blk_col_ptr[jt]);
+                const int32_t hi = std::min(A->blk_row_ptr[it + 1], A->blk_col_ptr[jt + 1]);
+                if (hi <= lo) continue;               // this block holds no diagonal entry
+                sgm_mat C = A->blocks[(size_t)it * ncb + jt];
+                double *out = pc->parts[0].idiag + lo;
+                if (!C) {
+                    hipLaunchKernelGGL(k_fill_inf, dim3((hi - lo + kBlock - 1) / kBlock), dim3(kBlock), 0, st, hi - lo, out);
+                    continue;
+                }
+                jacobi_rows(C->parts[0], C->fmt, lo - A->blk_row_ptr[it], hi - lo, A->blk_row_ptr[it] - A->blk_col_ptr[jt], out);
+            }
+        SGM_HIP(hipGetLastError());
+        return finish();
+    }
     if (pc->kind == SGM_PC_JACOBI) {
         if (pc->parts.size() != A->parts.size()) {
             for (auto &pp : pc->parts) dfree(pp.idiag);
@@ -825,14 +874,7 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
         for (size_t ip = 0; ip < A->parts.size(); ++ip) {
             const Part &p = A->parts[ip];
             if (!pc->parts[ip].idiag) SGM_TRY(dalloc(&pc->parts[ip].idiag, (size_t)p.n + 2));
-            const int grid = (p.n + kBlock - 1) / kBlock;
-            if (!grid) continue;
-            if (A->fmt == SGM_FMT_CSR)
-                hipLaunchKernelGGL(k_jacobi_setup_csr, dim3(grid), dim3(kBlock), 0, st, p.n, p.rowptr, p.col, p.val,
-                                   pc->parts[ip].idiag);
-            else
-                hipLaunchKernelGGL(k_jacobi_setup_ell, dim3(grid), dim3(kBlock), 0, st, p.n, p.max_d, p.ecol, p.eval,
-                                   pc->parts[ip].idiag);
+            jacobi_rows(p, A->fmt, 0, p.n, 0, pc->parts[ip].idiag);
         }
         SGM_HIP(hipGetLastError());
         return finish();

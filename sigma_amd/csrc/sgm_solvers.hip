@@ -575,6 +575,52 @@ __global__ __launch_bounds__(kBlock) void k_lanczos_record(ScalarRef alpha, Scal
     }
 }
 
+// ---- generalized Lanczos (src/eigensolver.f90:95-155) ---------------------------------------
+// v = w - beta*z_prev (beta = sqrt(sum(nrm2)); z_prev may be null) ; partial sum(v*q)   (:133-134, :150-151)
+struct FGlV {
+    const double *w, *zprev, *q; double *v; ScalarRef nrm2; double *part; double b = 0.0, s = 0.0;
+    __device__ bool prepare(double *red)
+    {
+        if (zprev) b = sqrt(load_scalar<kBlock>(nrm2, red));
+        return true;
+    }
+    __device__ void one(int64_t i)
+    {
+        double vv = w[i];
+        if (zprev) vv = vv - b * zprev[i];
+        v[i] = vv;
+        s += vv * q[i];
+    }
+    template <bool NT> __device__ void pair(int64_t i)
+    {
+        double2 vv = ld2<NT>(w, i);
+        if (zprev) {
+            const double2 zz = ld2<NT>(zprev, i);
+            vv.x = vv.x - b * zz.x;
+            vv.y = vv.y - b * zz.y;
+        }
+        st2<NT>(v, i, vv);
+        const double2 qq = ld2<NT>(q, i);
+        s += vv.x * qq.x;
+        s += vv.y * qq.y;
+    }
+    __device__ void single(int64_t i) { one(i); }
+    __device__ void finish(double *red) { put_partial(s, part, red); }
+};
+// y = y - a*x   (a = a device scalar)                                                   (:135)
+struct FSubScaled {
+    static constexpr bool kDot = false;
+    double *y; const double *x; ScalarRef a; double av = 0.0;
+    __device__ bool prepare(double *red) { av = load_scalar<kBlock>(a, red); return true; }
+    template <bool NT> __device__ void pair(int64_t i)
+    {
+        double2 yy = ld2<NT>(y, i); const double2 xx = ld2<NT>(x, i);
+        yy.x = yy.x - av * xx.x; yy.y = yy.y - av * xx.y; st2<NT>(y, i, yy);
+    }
+    __device__ void single(int64_t i) { y[i] = y[i] - av * x[i]; }
+    __device__ void finish(double *) {}
+};
+
 // Grid policy of the vector kernels.  Kernels that leave partial sums need grid <= kMaxGrid;
 // pure update kernels take one pass over a large grid (a copy-like stream runs ~30 % faster
 // that way on MI355X than as a small persistent grid: tools/stream_bench.cpp).
@@ -1282,6 +1328,85 @@ int sgm_lanczos(sgm_mat A, int32_t nsteps, const double *q1, double *T_host, dou
                                  where == SGM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
     SGM_HIP(hipStreamSynchronize(st));
     dfree(Q); dfree(w); dfree(parts); dfree(T3);
+    return SGM_OK;
+}
+
+// sgm_generalized_lanczos <- generalized_lanczos(A, B, T, Q)  src/eigensolver.f90:95-155: Lanczos for
+// A x = lambda B x.  Every step solves B w = v with the solver the caller set up for B (the reference
+// reads B%solver / B%pc, :140), started from the current w = A q_i exactly like `call B%solve(w, v)`.
+// No re-orthogonalisation (the reference has none here).  q1 replaces the time-seeded start vector
+// and is normalised in the B-norm (:123-124).
+int sgm_generalized_lanczos(sgm_mat A, sgm_mat B, sgm_solver solver, sgm_pc pc, int32_t nsteps, const double *q1,
+                            double *T_host, double *Q_out, int where)
+{
+    SGM_TRY(require_init());
+    if (!A || !B || !solver || nsteps < 2 || !q1 || !T_host) return fail(SGM_ERR_BAD_ARG, "sgm_generalized_lanczos: bad argument");
+    if (A->nrow != A->ncol || B->nrow != B->ncol || A->nrow != B->nrow)
+        return fail(SGM_ERR_DIMS, "sgm_generalized_lanczos: A and B must be square and of one size");
+    if (A->distributed() || B->distributed()) return fail(SGM_ERR_UNSUPPORTED, "sgm_generalized_lanczos: single-GPU matrices only");
+    if (!solver->initialized || solver->nn != B->nrow)
+        return fail(SGM_ERR_BAD_ARG, "sgm_generalized_lanczos: the solver has not been set up for B (B%%set_solver)");
+    const int64_t n = A->nrow, ld = n + (n & 1);
+    struct Bufs {
+        double *Q = nullptr, *Z = nullptr, *w = nullptr, *v = nullptr, *parts = nullptr, *T3 = nullptr;
+        ~Bufs() { dfree(Q); dfree(Z); dfree(w); dfree(v); dfree(parts); dfree(T3); }
+    } m;
+    SGM_TRY(dalloc(&m.Q, (size_t)ld * nsteps + 2));
+    SGM_TRY(dalloc(&m.Z, (size_t)ld * (nsteps + 1) + 2));        // z(:, 0:n), column 0 stays zero
+    SGM_TRY(dalloc(&m.w, (size_t)ld + 2));
+    SGM_TRY(dalloc(&m.v, (size_t)ld + 2));
+    SGM_TRY(dalloc(&m.parts, (size_t)2 * kMaxGrid));
+    SGM_TRY(dalloc(&m.T3, (size_t)3 * nsteps));
+    hipStream_t st = g_rt.stream;
+    SGM_HIP(hipMemsetAsync(m.T3, 0, (size_t)3 * nsteps * 8, st));
+    SGM_HIP(hipMemsetAsync(m.Q, 0, ((size_t)ld * nsteps + 2) * 8, st));
+    SGM_HIP(hipMemsetAsync(m.Z, 0, ((size_t)ld * (nsteps + 1) + 2) * 8, st));
+    SGM_HIP(hipMemsetAsync(m.w, 0, ((size_t)ld + 2) * 8, st));
+    SGM_HIP(hipMemsetAsync(m.v, 0, ((size_t)ld + 2) * 8, st));
+    double *P_ALPHA = m.parts, *P_B2 = m.parts + kMaxGrid;
+    auto q = [&](int i) { return m.Q + (size_t)(i - 1) * ld; };      // 1-based like the reference
+    auto z = [&](int i) { return m.Z + (size_t)i * ld; };            // 0-based: z(:, 0:n)
+    const int gd = dot_grid(n);
+    auto apply = [&](sgm_mat M, const double *x, double *y) -> int {
+        const double *xs[1] = {x};
+        double *ys[1] = {y};
+        return spmv_parts(M, xs, ys, false, nullptr, nullptr, nullptr);
+    };
+    {   // q_1 = q1 / sqrt(sum((B q1) * q1)) ; z_1 = B q_1
+        Staged s1;
+        SGM_TRY(stage_in(s1, q1, n, where, true));
+        SGM_TRY(apply(B, s1.dev, m.w));
+        launch_elem(n, FDot2{m.w, s1.dev, nullptr, nullptr, P_B2, nullptr}, nullptr);
+        launch_elem(n, FScaleInv{q(1), s1.dev, ScalarRef{P_B2, gd}}, nullptr);
+        SGM_TRY(apply(B, q(1), z(1)));
+        SGM_HIP(hipStreamSynchronize(st));
+    }
+    for (int i = 1; i <= nsteps - 1; ++i) {
+        SGM_TRY(apply(A, q(i), m.w));                                                   // w = A q_i
+        launch_elem(n, FGlV{m.w, i > 1 ? z(i - 1) : nullptr, q(i), m.v, ScalarRef{P_B2, gd}, P_ALPHA}, nullptr);
+        launch_elem(n, FSubScaled{m.v, z(i), ScalarRef{P_ALPHA, gd}}, nullptr);            // v = v - alpha z_i
+        SGM_HIP(hipGetLastError());
+        // call B%solve(w, v): the solver's own loop, x = w in place (initial guess A q_i), b = v
+        const int rc = sgm_solver_solve(solver, B, m.w, m.v, pc, SGM_DEVICE);
+        if (rc != SGM_OK) return rc;
+        // alpha was consumed before the solve; record it with the NEW beta = sqrt(sum(w*v))
+        launch_elem(n, FDot2{m.w, m.v, nullptr, nullptr, P_B2, nullptr}, nullptr);
+        hipLaunchKernelGGL(k_lanczos_record, dim3(1), dim3(kBlock), 0, st, ScalarRef{P_ALPHA, gd}, ScalarRef{P_B2, gd}, 1,
+                           m.T3, i - 1);
+        launch_elem(n, FScaleInv{q(i + 1), m.w, ScalarRef{P_B2, gd}}, nullptr);
+        launch_elem(n, FScaleInv{z(i + 1), m.v, ScalarRef{P_B2, gd}}, nullptr);
+    }
+    // v = A q_n - beta z_n ; T(2,n) = sum(q_n * v)
+    SGM_TRY(apply(A, q(nsteps), m.w));
+    launch_elem(n, FGlV{m.w, z(nsteps), q(nsteps), m.v, ScalarRef{P_B2, gd}, P_ALPHA}, nullptr);
+    hipLaunchKernelGGL(k_lanczos_record, dim3(1), dim3(kBlock), 0, st, ScalarRef{P_ALPHA, gd}, ScalarRef{P_ALPHA, gd}, 0, m.T3,
+                       nsteps - 1);
+    SGM_HIP(hipGetLastError());
+    SGM_HIP(hipMemcpyAsync(T_host, m.T3, (size_t)3 * nsteps * 8, hipMemcpyDeviceToHost, st));
+    if (Q_out)
+        SGM_HIP(hipMemcpy2DAsync(Q_out, (size_t)n * 8, m.Q, (size_t)ld * 8, (size_t)n * 8, nsteps,
+                                 where == SGM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+    SGM_HIP(hipStreamSynchronize(st));
     return SGM_OK;
 }
 

@@ -38,3 +38,8 @@ def perm_golden_names(ell=False):
     permuted matrix (CSR ones by default, the ELLPACK ones with ell=True)."""
     return sorted(f[:-4] for f in os.listdir(GOLDEN)
                   if f.endswith(".npz") and f.startswith("perm_") and (("_ell_" in f) == ell))
+
+
+def comp_golden_names():
+    """Fixtures of the composite `sparse_matrix` (2 x 2 blocks; products and solves on the composite)."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f.startswith("comp_"))

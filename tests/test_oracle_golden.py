@@ -11,7 +11,7 @@ Also re-checks the known answers of the reference's own tests
 import numpy as np
 import pytest
 
-from conftest import eig_golden_names, golden_names, perm_golden_names
+from conftest import comp_golden_names, eig_golden_names, golden_names, perm_golden_names
 import oracle as orc
 
 CG, BICGSTAB = 1, 2
@@ -231,3 +231,50 @@ def test_lanczos_and_generalized_lanczos_vs_the_reference(golden, name):
     # the vectors are B-orthonormal: Q^T B Q = I
     BQ = np.stack([B.matvec(Q[:, k].copy()) for k in range(ns)], axis=1)
     assert np.abs(Q.T @ BQ - np.eye(ns)).max() <= 1e-8
+
+
+def composite_blocks(g):
+    """Oracle leaves of a comp_* fixture + the block offsets (0-based)."""
+    rp, cp = g["ref_comp_row_ptr"] - 1, g["ref_comp_col_ptr"] - 1
+    blocks = [[orc.CsrMatrix(int(rp[i + 1] - rp[i]), int(cp[j + 1] - cp[j]), g[f"ref_blk{i + 1}{j + 1}_ptr"],
+                             g[f"ref_blk{i + 1}{j + 1}_node"], g[f"ref_blk{i + 1}{j + 1}_val"]) for j in range(2)]
+              for i in range(2)]
+    return rp, cp, blocks
+
+
+@pytest.mark.parametrize("name", comp_golden_names())
+def test_composite_block_loops_bit_exact(golden, name):
+    """composite_matvec_add / composite_matvec_t_add (sparse_matrix_composites.f90:1076-1127) run by the
+    reference on a 2 x 2 composite of csr leaves: the block loops over oracle leaves reproduce y, y_add,
+    yt, yt_add bit for bit, and get_value through the owning block gives the reference's Jacobi idiag."""
+    g = golden(name)
+    n = int(g["n"])
+    rp, cp, B = composite_blocks(g)
+    for i in range(2):
+        for j in range(2):      # every block = the edges that fall into it, in the list's insertion order
+            sel = (g["ei"] > rp[i]) & (g["ei"] <= rp[i + 1]) & (g["ej"] > cp[j]) & (g["ej"] <= cp[j + 1])
+            L = orc.CsrMatrix.from_edges(B[i][j].n, B[i][j].m, g["ei"][sel] - rp[i], g["ej"][sel] - cp[j], g["ev"][sel])
+            assert np.array_equal(L.ptr, B[i][j].ptr) and np.array_equal(L.node, B[i][j].node) and np.array_equal(L.val, B[i][j].val)
+
+    def matvec_add(x, y):
+        for i in range(2):
+            for j in range(2):
+                B[i][j].matvec_add(x[cp[j]:cp[j + 1]].copy(), y[rp[i]:rp[i + 1]])
+        return y
+
+    def matvec_t_add(x, y):
+        for j in range(2):
+            for i in range(2):
+                B[i][j].matvec_t_add(x[rp[i]:rp[i + 1]].copy(), y[cp[j]:cp[j + 1]])
+        return y
+
+    y = matvec_add(g["x"], np.zeros(n))
+    assert np.array_equal(y, g["ref_y"])
+    assert np.array_equal(matvec_add(g["x"], y), g["ref_y_add"])
+    yt = matvec_t_add(g["b"], np.zeros(n))
+    assert np.array_equal(yt, g["ref_yt"])
+    assert np.array_equal(matvec_t_add(g["b"], yt), g["ref_yt_add"])
+    # jacobi_setup on the composite: idiag(i) = 1 / A%get_value(i,i), answered by the diagonal blocks here
+    idiag = np.concatenate([orc.Jacobi(B[0][0]).idiag, orc.Jacobi(B[1][1]).idiag])
+    assert np.array_equal(idiag, g["ref_s2_idiag"])
+    assert np.array_equal(idiag * g["b"], g["ref_s2_pcz"])

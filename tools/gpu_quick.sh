@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r02
-timeout 1500 python -m pytest tests/test_gpu_multirank.py -x -q -m gpu > gpurun_out/r02/multirank.log 2>&1; echo multirank=$?
-tail -25 gpurun_out/r02/multirank.log
-./oracle/_ref/hip_binding_test; echo binding=$?
+timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "composite or lanczos or binding" > gpurun_out/r02/quick.log 2>&1; echo quick=$?
+tail -25 gpurun_out/r02/quick.log
