@@ -254,8 +254,10 @@ def bicgstab(A, b, x0=None, pc=None, tol=1e-16, max_iter=0, history=0):
     return _solve(lib().orc_bicgstab, A, b, x0, pc, tol, max_iter, history)
 
 
-def gmres(A, b, x0=None, pc=None, tol=1e-16, max_iter=0, restart=30, history=0):
-    """Returns (x, iterations, |residual|, history-of-res^2).  No reference counterpart."""
+def gmres(A, b, x0=None, pc=None, tol=1e-16, max_iter=0, restart=30, history=0, orth="mgs"):
+    """Returns (x, iterations, |residual|, history-of-res^2).  No reference counterpart.
+    orth: "mgs" (modified Gram-Schmidt) or "cgs2" (classical Gram-Schmidt twice)."""
+    lib().orc_set_gmres_orth(C.c_int(1 if orth == "cgs2" else 0))
     return _solve(lib().orc_gmres, A, b, x0, pc, tol, max_iter, history,
                   extra=(C.c_int32(restart),))
 

@@ -593,6 +593,11 @@ ORC_API int64_t orc_bicgstab(const orc_solve_args *a, double *x, const double *b
  * Conventions borrowed from cg_solve: absolute tolerance on the (preconditioned)
  * residual norm, initial guess taken from x, iterations = number of inner
  * (Arnoldi) steps, counted across restarts; max_iter <= 0 = unbounded. */
+/* Arnoldi orthogonalisation of orc_gmres: 0 = modified Gram-Schmidt, 1 = CGS-2 (classical Gram-Schmidt
+ * applied twice).  No reference constrains the choice (the reference has no GMRES). */
+static int g_gmres_orth = 0;
+ORC_API void orc_set_gmres_orth(int mode) { g_gmres_orth = mode; }
+
 ORC_API int64_t orc_gmres(const orc_solve_args *a, int32_t m, double *x, const double *b,
                           double *res_out)
 {
@@ -601,6 +606,7 @@ ORC_API int64_t orc_gmres(const orc_solve_args *a, int32_t m, double *x, const d
     double *V = calloc((size_t)n * (m + 1), 8), *w = calloc(n, 8), *tmp = calloc(n, 8);
     double *H = calloc((size_t)(m + 1) * m, 8);        /* H[i + j*(m+1)] */
     double *cs = calloc(m, 8), *sn = calloc(m, 8), *g = calloc(m + 1, 8), *yv = calloc(m, 8);
+    double *hc = calloc(m + 1, 8);
     int64_t it = 0;
     double res = 0.0;
     int done = 0;
@@ -622,11 +628,23 @@ ORC_API int64_t orc_gmres(const orc_solve_args *a, int32_t m, double *x, const d
             double *vj = V + (size_t)j * n;
             op_matvec(&A, vj, tmp);
             if (a->pc_kind) pc_solve(&pc, w, tmp); else memcpy(w, tmp, (size_t)n * 8);
-            for (int32_t i = 0; i <= j; i++) {
-                double *vi = V + (size_t)i * n;
-                double h = dot(n, w, vi);
-                H[i + (size_t)j * (m + 1)] = h;
-                for (int32_t l = 0; l < n; l++) w[l] = w[l] - h * vi[l];
+            if (g_gmres_orth == 0) {        /* modified Gram-Schmidt */
+                for (int32_t i = 0; i <= j; i++) {
+                    double *vi = V + (size_t)i * n;
+                    double h = dot(n, w, vi);
+                    H[i + (size_t)j * (m + 1)] = h;
+                    for (int32_t l = 0; l < n; l++) w[l] = w[l] - h * vi[l];
+                }
+            } else {                        /* CGS-2: classical Gram-Schmidt twice, h = h1 + h2 */
+                for (int32_t i = 0; i <= j; i++) H[i + (size_t)j * (m + 1)] = 0.0;
+                for (int pass = 0; pass < 2; pass++) {
+                    for (int32_t i = 0; i <= j; i++) hc[i] = dot(n, w, V + (size_t)i * n);
+                    for (int32_t i = 0; i <= j; i++) {
+                        const double *vi = V + (size_t)i * n;
+                        for (int32_t l = 0; l < n; l++) w[l] = w[l] - hc[i] * vi[l];
+                        H[i + (size_t)j * (m + 1)] = pass ? H[i + (size_t)j * (m + 1)] + hc[i] : hc[i];
+                    }
+                }
             }
             double hn = sqrt(dot(n, w, w));
             H[(j + 1) + (size_t)j * (m + 1)] = hn;
@@ -663,7 +681,7 @@ ORC_API int64_t orc_gmres(const orc_solve_args *a, int32_t m, double *x, const d
         }
     }
     if (res_out) *res_out = res;
-    free(V); free(w); free(tmp); free(H); free(cs); free(sn); free(g); free(yv);
+    free(V); free(w); free(tmp); free(H); free(cs); free(sn); free(g); free(yv); free(hc);
     return it;
 }
 

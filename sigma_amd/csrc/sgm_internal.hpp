@@ -37,6 +37,7 @@ struct Options {
     int ell_offset_dict = 1;       // ELLPACK twin of csr_offset_dict (max_d <= 16)
     int csr_row_owner = 1;         // int32 columns, rows <= 32 entries: gather by the row's owner lane
     int csr_sliced = 1;            // rows <= 8 entries, <= 15 offsets: slot-major slices + 4-bit codes (k_csr_sl)
+    int gmres_cgs2 = 1;            // GMRES: blocked CGS-2 orthogonalisation (3 passes per step) instead of modified Gram-Schmidt
 };
 extern Options g_opt;
 

@@ -62,6 +62,7 @@ int sgm_init(int device)
     g_rt.device = device;
     g_rt.ready = true;
     if (const char *e = getenv("SGM_CSR_SLICED")) g_opt.csr_sliced = atoi(e);      // tuning aid (see sgm_set_option)
+    if (const char *e = getenv("SGM_GMRES_CGS2")) g_opt.gmres_cgs2 = atoi(e);
     return SGM_OK;
 }
 
@@ -103,6 +104,7 @@ int sgm_set_option(const char *name, int value)
     if (!strcmp(name, "csr_row_owner")) { g_opt.csr_row_owner = value; return SGM_OK; }
     if (!strcmp(name, "csr_sliced")) { g_opt.csr_sliced = value; return SGM_OK; }
     if (!strcmp(name, "ell_offset_dict")) { g_opt.ell_offset_dict = value; return SGM_OK; }
+    if (!strcmp(name, "gmres_cgs2")) { g_opt.gmres_cgs2 = value; return SGM_OK; }
     return fail(SGM_ERR_BAD_ARG, "sgm_set_option: unknown option '%s'", name);
 }
 

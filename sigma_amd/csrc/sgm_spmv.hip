@@ -656,20 +656,27 @@ static SpmvCfg &spmv_cfg()
         if (const char *e = getenv("SGM_SPMV_CFG"))
             sscanf(e, "%d,%d,%d,%d,%d,%d", &c.block, &c.vpt, &c.nt, &c.maxgrid, &c.remap, &c.do_vpt);
         if (c.maxgrid > kMaxGrid) c.maxgrid = kMaxGrid;
+        // only instantiated (block, vpt) pairs: anything else would launch a kernel of another shape
+        if (c.block != 256 && c.block != 512 && c.block != 1024) c.block = 256;
+        if (c.vpt != 2 && c.vpt != 4 && c.vpt != 8) c.vpt = 2;
+        if (c.block == 1024 && c.vpt == 8) c.vpt = 4;
     }
     return c;
 }
 
 static int resident_per_cu(bool dict, int block, int v, int cw = 4);
 int ell_grid(const Part &p);
-static bool use_offset_dict(const Part &p) { return p.code && g_opt.csr_offset_dict; }
+// k_csr_do exists for 256- and 512-thread workgroups only; with any other SGM_SPMV_CFG block size the
+// matrices it would serve take the streaming kernel (which has the 1024-thread variants) instead
+static bool do_block_ok() { const int b = spmv_cfg().block; return b == 256 || b == 512; }
+static bool use_offset_dict(const Part &p) { return p.code && g_opt.csr_offset_dict && do_block_ok(); }
 static bool use_sliced(const Part &p) { return p.scode && g_opt.csr_sliced && g_opt.csr_offset_dict; }
 static bool use_sliced32(const Part &p) { return p.scol && g_opt.csr_sliced && !p.ecol; }
 static bool any_sliced(const Part &p) { return use_sliced(p) || use_sliced32(p); }
 // k_csr_do serves both the dictionary form and, for short rows, plain int32 columns
 static bool use_row_owner(const Part &p)
 {
-    return use_offset_dict(p) || (g_opt.csr_row_owner && p.max_row > 0 && p.max_row <= 32);
+    return use_offset_dict(p) || (do_block_ok() && g_opt.csr_row_owner && p.max_row > 0 && p.max_row <= 32);
 }
 
 // (BLOCK, TILE) instantiations of the offset-dict kernel.  TILE = entries staged in LDS per

@@ -1237,9 +1237,19 @@ def test_residual_history_vs_oracle(orc):
                 assert np.abs(x - xr).max() / np.abs(xr).max() <= max(1e-12, 4 * np.abs(xv - xr).max() / np.abs(xr).max())
 
 
-def test_gmres(golden, orc):
-    """GMRES(30) has no reference counterpart: checked against the oracle's textbook GMRES,
-    the analytic solution and the reference's BiCGStab solution."""
+@pytest.mark.parametrize("orth", ["cgs2", "mgs"])
+def test_gmres(golden, orc, orth):
+    """GMRES(30) has no reference counterpart: checked against the oracle's textbook GMRES (same
+    Arnoldi orthogonalisation: blocked CGS-2, the default, or modified Gram-Schmidt), the analytic
+    solution and the reference's BiCGStab solution."""
+    sg.set_option("gmres_cgs2", 1 if orth == "cgs2" else 0)
+    try:
+        _gmres_checks(golden, orc, orth)
+    finally:
+        sg.set_option("gmres_cgs2", 1)
+
+
+def _gmres_checks(golden, orc, orth):
     g = golden("advdiff1d_csr_1024")
     A = hip_matrix(g)
     Ao = orc.CsrMatrix(1024, 1024, g["ref_ptr"], g["ref_node"], g["ref_val"])
@@ -1247,7 +1257,7 @@ def test_gmres(golden, orc):
     s.setup(A)
     u = np.zeros(1024)
     s.solve(A, u, g["b"])
-    uo, ito, _, _ = orc.gmres(Ao, g["b"], tol=1e-12, restart=30)
+    uo, ito, _, _ = orc.gmres(Ao, g["b"], tol=1e-12, restart=30, orth=orth)
     assert abs(s.iterations - ito) <= max(2, 0.02 * ito)
     assert np.abs(u - g["analytic"]).max() <= 1e-8
     assert np.abs(u - g["ref_s1_u"]).max() / np.abs(g["ref_s1_u"]).max() <= 1e-7
@@ -1258,7 +1268,7 @@ def test_gmres(golden, orc):
     s2.setup(A)
     u = np.zeros(1024)
     s2.solve(A, u, g["b"], check=False)
-    uo, ito, _, ho = orc.gmres(Ao, g["b"], tol=1e-30, restart=30, max_iter=75, history=75)
+    uo, ito, _, ho = orc.gmres(Ao, g["b"], tol=1e-30, restart=30, max_iter=75, history=75, orth=orth)
     assert s2.last_iterations == 75 == ito
     assert np.abs(u - uo).max() / np.abs(uo).max() <= 1e-10
     assert (np.abs(s2.history - ho) / ho).max() <= 1e-9
@@ -1272,6 +1282,22 @@ def test_gmres(golden, orc):
     u = np.zeros(128)
     s.solve(A, u, g["b"], pc)
     assert np.abs(u - g["ref_s2_u"]).max() / np.abs(g["ref_s2_u"]).max() <= 1e-11
+    # every width class of the blocked kernels (4 / 8 / 16 / 32 vectors), odd length, restart 3..32
+    n = 2001
+    Ar = orc.CsrMatrix.from_edges(n, n, *P.advection_diffusion_1d(n)[0])
+    Hr = sg.csr_matrix(n, n, Ar.ptr, Ar.node, Ar.val)
+    b = P.test_vector(n)
+    for restart in (3, 7, 13, 32):
+        uo, ito, _, ho = orc.gmres(Ar, b, tol=1e-30, restart=restart, max_iter=2 * restart + 1, history=80, orth=orth)
+        s3 = sg.gmres(1e-30, restart)
+        s3.set_max_iter(2 * restart + 1)
+        s3.set_history(80)
+        s3.setup(Hr)
+        u = np.zeros(n)
+        s3.solve(Hr, u, b, check=False)
+        assert s3.last_iterations == ito == 2 * restart + 1
+        assert np.abs(u - uo).max() / np.abs(uo).max() <= 1e-10, restart
+        assert (np.abs(s3.history - ho[:len(s3.history)]) / ho[:len(s3.history)]).max() <= 1e-8, restart
 
 
 # ------------------------------------------------------------------------------- Lanczos
