@@ -37,6 +37,9 @@ struct Options {
     int ell_offset_dict = 1;       // ELLPACK twin of csr_offset_dict (max_d <= 16)
     int csr_row_owner = 1;         // int32 columns, rows <= 32 entries: gather by the row's owner lane
     int csr_sliced = 1;            // rows <= 8 entries, <= 15 offsets: slot-major slices + 4-bit codes (k_csr_sl)
+    int ell_colblock = 1;          // ELLPACK with random columns: column-blocked two-phase product (0 never, 1 automatic, 2 always)
+    int ell_colblock_cols = 16384; // its column block (x entries staged in LDS per workgroup; even, <= 16384)
+    int ell_colblock_chunks = 8;   // workgroups per column block in the multiply phase
     int gmres_cgs2 = 1;            // GMRES: blocked CGS-2 orthogonalisation (3 passes per step) instead of modified Gram-Schmidt
 };
 extern Options g_opt;
@@ -129,6 +132,15 @@ struct Part {
     int32_t *edeg = nullptr;       // degrees(n), only when built by sgm_ell_from_edges
     uint8_t *ecode = nullptr;      // ELLPACK offset-dictionary codes, row-major n x emdp (emdp = max_d rounded up)
     int32_t emdp = 0;
+    // column-blocked two-phase form of an ELLPACK matrix with random columns (sgm_ellcb.hip)
+    int32_t *cb_perm = nullptr;    // sorted position -> entry i*max_d + k
+    double *cb_sval = nullptr;     // values in (column block, row, slot) order
+    uint16_t *cb_lcol = nullptr;   // column inside its block
+    int32_t *cb_bstart = nullptr;  // nb+1: where every column block starts in the sorted order
+    uint16_t *cb_lpos = nullptr;   // slot-major: position of entry (k, i) in its tile's LDS image
+    void *cb_fdesc = nullptr;      // ntiles x nb run descriptors {sorted position, length | LDS base << 16}
+    double *cb_P = nullptr;        // products val * x in sorted order (written by phase 1)
+    int32_t cb_cols = 0, cb_nb = 0, cb_R = 0, cb_ntiles = 0;
     std::vector<HaloNbr> nbrs;
     double *xext = nullptr;        // owned+halo staging for plain-vector matvec (multi-part only)
     int dot_grid_override = 0;     // composite matrices: grid of the separate dot kernel

@@ -1,6 +1,8 @@
 // Runtime plumbing of libsigma_hip.so: device selection, stream, errors, HBM buffers.
 #include "sgm_internal.hpp"
 
+#include <algorithm>
+
 namespace sgm {
 
 std::string g_err;
@@ -104,6 +106,9 @@ int sgm_set_option(const char *name, int value)
     if (!strcmp(name, "csr_row_owner")) { g_opt.csr_row_owner = value; return SGM_OK; }
     if (!strcmp(name, "csr_sliced")) { g_opt.csr_sliced = value; return SGM_OK; }
     if (!strcmp(name, "ell_offset_dict")) { g_opt.ell_offset_dict = value; return SGM_OK; }
+    if (!strcmp(name, "ell_colblock")) { g_opt.ell_colblock = value; return SGM_OK; }
+    if (!strcmp(name, "ell_colblock_cols")) { g_opt.ell_colblock_cols = std::min(16384, std::max(2, value)) & ~1; return SGM_OK; }
+    if (!strcmp(name, "ell_colblock_chunks")) { g_opt.ell_colblock_chunks = std::max(1, value); return SGM_OK; }
     if (!strcmp(name, "gmres_cgs2")) { g_opt.gmres_cgs2 = value; return SGM_OK; }
     return fail(SGM_ERR_BAD_ARG, "sgm_set_option: unknown option '%s'", name);
 }

@@ -666,6 +666,16 @@ static SpmvCfg &spmv_cfg()
 
 static int resident_per_cu(bool dict, int block, int v, int cw = 4);
 int ell_grid(const Part &p);
+// sgm_ellcb.hip: column-blocked two-phase product for ELLPACK matrices with random columns
+bool use_ell_colblock(const Part &p);
+int ell_colblock_grid(const Part &p);
+int build_ell_colblock(Part &p);
+int refresh_ell_colblock_values(Part &p);
+void free_ell_colblock(Part &p);
+int launch_ell_colblock(const Part &p, int grid, const double *x, double *y, bool add, bool chain, const double *w,
+                        double *pwy, double *pyy, const int *flag, int gen);
+int64_t ell_colblock_resident_bytes(const Part &p);
+int64_t ell_colblock_matvec_bytes(const Part &p);
 // k_csr_do exists for 256- and 512-thread workgroups only; with any other SGM_SPMV_CFG block size the
 // matrices it would serve take the streaming kernel (which has the 1024-thread variants) instead
 static bool do_block_ok() { const int b = spmv_cfg().block; return b == 256 || b == 512; }
@@ -886,6 +896,7 @@ static EllCfg &ell_cfg()
 static bool use_sliced_ell(const Part &p) { return p.ecol && p.scode && g_opt.csr_sliced && g_opt.ell_offset_dict; }
 int ell_grid(const Part &p)
 {
+    if (use_ell_colblock(p)) return ell_colblock_grid(p);
     if (use_sliced_ell(p)) {           // k_csr_sl: 512-row slices round-robin over <= kMaxGrid workgroups
         const int64_t nsl = ((int64_t)p.n + kSlRows - 1) / kSlRows;
         return (int)std::max<int64_t>(1, std::min<int64_t>(nsl, nsl >= 32768 ? kMaxGrid : kMaxGrid / 2));
@@ -902,6 +913,10 @@ template <bool ADD>
 static void launch_ell(const Part &p, int grid, const double *x, double *y, const double *w,
                        double *pwy, double *pyy, const int *flag, int gen)
 {
+    if (use_ell_colblock(p)) {         // random columns: products through LDS-resident x blocks, then ordered row sums
+        (void)launch_ell_colblock(p, grid, x, y, ADD, (g_launch_flags & 256) != 0, w, pwy, pyy, flag, gen);
+        return;
+    }
     if (use_sliced_ell(p)) {           // structured ELLPACK in the sliced form: the CSR kernel as it is
         launch_csr_sl<ADD>(p, grid, x, y, w, pwy, pyy, flag, gen);
         return;
@@ -1433,7 +1448,9 @@ int rebuild_ell_formats(Part &p)
 {
     dfree(p.ecode); dfree(p.dict); dfree(p.sval); dfree(p.scode);
     p.ecode = nullptr; p.dict = nullptr; p.emdp = 0; p.sval = nullptr; p.scode = nullptr; p.sw = 0;
-    return build_ell_offset_dict(p);
+    SGM_TRY(build_ell_offset_dict(p));
+    SGM_TRY(build_ell_colblock(p));
+    return refresh_ell_colblock_values(p);
 }
 int sgm_invalidate_transpose(sgm_mat A)
 {
@@ -1448,6 +1465,7 @@ void free_part(Part &p)
 {
     dfree(p.rowptr); dfree(p.col); dfree(p.val); dfree(p.code); dfree(p.dict); dfree(p.sval); dfree(p.scode); dfree(p.scol); dfree(p.ecol); dfree(p.eval); dfree(p.edeg); dfree(p.ecode); dfree(p.xext);
     for (auto &nb : p.nbrs) { dfree(nb.send_idx); dfree(nb.send_buf); }
+    free_ell_colblock(p);
     p = Part();
 }
 
@@ -1765,6 +1783,7 @@ int sgm_ell_create(sgm_mat *out, int32_t nrow, int32_t ncol, int32_t max_d, cons
                            (const double *)nullptr, p.ecol, p.eval, nrow, max_d);
     }
     SGM_TRY(build_ell_offset_dict(p));
+    SGM_TRY(build_ell_colblock(p));
     return sgm_ell_set_values(A, val, where);
 }
 
@@ -1787,6 +1806,7 @@ int sgm_ell_set_values(sgm_mat A, const double *val, int where)
                        (const int32_t *)nullptr, src, p.ecol, p.eval, p.n, p.max_d);
     SGM_HIP(hipGetLastError());
     SGM_TRY(pack_sliced(p));
+    SGM_TRY(refresh_ell_colblock_values(p));
     SGM_HIP(hipStreamSynchronize(g_rt.stream));
     dfree(tv);
     return SGM_OK;
@@ -1919,7 +1939,8 @@ int sgm_mat_kernel(sgm_mat A, char *buf, int len)
     else {
         const Part &p = A->parts[0];
         if (A->fmt == SGM_FMT_ELL) {
-            if (use_sliced_ell(p)) snprintf(name, sizeof name, "k_csr_sl<W=%d>", p.sw);
+            if (use_ell_colblock(p)) snprintf(name, sizeof name, "k_ellcb<cols=%d,R=%d>", p.cb_cols, p.cb_R);
+            else if (use_sliced_ell(p)) snprintf(name, sizeof name, "k_csr_sl<W=%d>", p.sw);
             else if (p.ecode && g_opt.ell_offset_dict) snprintf(name, sizeof name, "k_ell_do<MDP=%d>", p.emdp);
             else snprintf(name, sizeof name, "k_ell_spmv");
         } else if (use_sliced(p)) snprintf(name, sizeof name, "k_csr_sl<W=%d>", p.sw);
@@ -1952,6 +1973,7 @@ static int64_t part_resident_bytes(const Part &p)
     if (p.edeg) b += 4 * (int64_t)p.n;
     if (p.ecode) b += (int64_t)p.n * p.emdp;
     if (p.xext) b += 8 * p.xlen();
+    b += ell_colblock_resident_bytes(p);
     for (const auto &nb : p.nbrs) b += (int64_t)nb.send_count * (nb.send_buf ? 12 : 4);
     return b;
 }
@@ -1960,6 +1982,7 @@ static int64_t part_matvec_bytes(const sgm_mat_s *A, const Part &p)
     const int64_t nsl = ((int64_t)p.n + kSlRows - 1) / kSlRows;
     int64_t m;
     if (A->fmt == SGM_FMT_ELL) {
+        if (use_ell_colblock(p)) return ell_colblock_matvec_bytes(p);
         if (use_sliced_ell(p)) m = nsl * kSlRows * (8 * (int64_t)p.sw + 4);
         else if (p.ecode && g_opt.ell_offset_dict) m = (int64_t)p.n * (8 * (int64_t)p.max_d + p.emdp);
         else m = 12 * (int64_t)p.n * p.max_d;

@@ -526,6 +526,72 @@ def test_randomised_ellpack_every_kernel_vs_oracle(orc, max_d):
             assert np.array_equal(ta, ta_ref), key
 
 
+@pytest.mark.parametrize("n,max_d,dmin,cols,chunks", [(3000, 32, None, 64, 3), (1000, 7, 3, 16, 1), (70001, 32, 24, 2048, 8),
+                                                       (513, 9, None, 2, 2), (5000, 100, 60, 256, 2), (20000, 16, None, 16384, 8)])
+def test_ell_column_blocked_two_phase_vs_oracle(orc, n, max_d, dmin, cols, chunks):
+    """k_ellcb (sgm_ellcb.hip): the two-phase product for ELLPACK matrices with random columns -- products
+    through LDS-resident column blocks of x, then row sums in slot order from an LDS image of the tile's
+    products.  Forced on (option ell_colblock = 2) for small matrices with small column blocks so that many
+    blocks, chunks, odd run boundaries, padded rows (0 * x(last) terms), partial tiles and every tile height
+    (R = 64 / 128 / 192 / 256 by max_d) are exercised: bit-exact against the oracle, like k_ell_spmv."""
+    sg.set_option("ell_colblock", 2)
+    sg.set_option("ell_colblock_cols", cols)
+    sg.set_option("ell_colblock_chunks", chunks)
+    try:
+        ei, ej, ev = P.random_regular_ell(n, max_d, 777 + n, dmin=dmin)
+        A = orc.EllMatrix.from_edges(n, n, ei, ej, ev)
+        H = sg.ellpack_matrix(n, n, A.node, A.val)
+        assert H.kernel.startswith("k_ellcb"), H.kernel
+        rs = np.random.RandomState(n)
+        x, y0 = rs.standard_normal(n), rs.standard_normal(n)
+        y = np.full(n, -9.0)
+        H.matvec(x, y)
+        assert np.array_equal(y, A.matvec(x))
+        ya = y0.copy()
+        H.matvec_add(x, ya)
+        assert np.array_equal(ya, A.matvec_add(x, y0.copy()))
+        # the same handle with the plain kernel (option off): identical bits
+        sg.set_option("ell_colblock", 0)
+        assert H.kernel == "k_ell_spmv"
+        y2 = np.zeros(n)
+        H.matvec(x, y2)
+        assert np.array_equal(y2, y)
+        sg.set_option("ell_colblock", 2)
+        # non-finite x entries propagate like the reference (also through padding slots)
+        xn = x.copy()
+        xn[rs.randint(0, n, 5)] = np.inf
+        xn[rs.randint(0, n, 5)] = np.nan
+        H.matvec(xn, y)
+        assert np.array_equal(y, A.matvec(xn), equal_nan=True)
+        # value update (re-sorted copy of the values), transpose products through the same handle
+        v2 = A.val * 1.5 + 0.25 * (A.val != 0)
+        H.set_values(v2)
+        A2 = orc.EllMatrix(n, n, A.max_d, A.node, v2, A.degrees)
+        H.matvec(x, y)
+        assert np.array_equal(y, A2.matvec(x))
+        t = np.zeros(n)
+        H.matvec_t(x, t)
+        assert np.array_equal(t, A2.matvec_t(x))
+        # fused dot epilogues (w.y and y.y partial sums of the second phase) inside BiCGStab
+        b = P.test_vector(n)
+        ur, itr, _, hr = orc.bicgstab(A2, b, tol=1e-30, max_iter=4, history=4)
+        s = sg.bicgstab(1e-30)
+        s.set_max_iter(4)
+        s.set_history(4)
+        s.setup(H)
+        u = np.zeros(n)
+        s.solve(H, u, b, check=False)
+        assert s.last_iterations == 4
+        # (BiCGStab on a random nonsymmetric matrix does not converge: the residual grows and two valid dot
+        # orders drift apart quickly, so only the first two steps are compared)
+        fin = np.isfinite(hr) & (hr > 0)
+        assert (np.abs(s.history[fin] - hr[fin]) / hr[fin])[:2].max() <= 1e-9
+    finally:
+        sg.set_option("ell_colblock", 1)
+        sg.set_option("ell_colblock_cols", 16384)
+        sg.set_option("ell_colblock_chunks", 8)
+
+
 @pytest.mark.parametrize("nparts", [2, 3, 5])
 def test_randomised_partitions_vs_oracle(orc, nparts):
     """Row partitions of seeded random banded / short-row matrices (halo lists, interior and boundary
@@ -1687,6 +1753,94 @@ def test_full_size_c5_mini_and_c4_every_row_bit_exact():
     cols = torch.from_numpy(enode.astype(np.int64) - 1).to(dev)
     vals = torch.from_numpy(np.ascontiguousarray(eval_)).to(dev)
     assert torch.equal(y, _torch_rowsum_in_stored_order(cols, vals, None, x))
+
+
+def test_full_size_c4_ellpack_every_row_bit_exact_both_kernels():
+    """BASELINE C4 at FULL size: ELLPACK random digraph, degree 32, n = 5,000,000 (160 M stored entries).
+    The column-blocked two-phase kernel (what `create` picks for it) and the plain slot-major kernel
+    give identical bits, and every row equals the torch evaluation in stored order."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 5_000_000
+    ei, ej, ev = P.random_regular_ell(n, 32, 12345)
+    enode, eval_ = ej.reshape(n, 32), ev.reshape(n, 32)
+    del ei
+    E = sg.ellpack_matrix(n, n, enode, eval_)
+    assert E.kernel.startswith("k_ellcb"), E.kernel
+    x = torch.sin(0.001 * torch.arange(1, n + 1, dtype=torch.float64, device=dev))
+    y = torch.zeros(n, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    E.matvec(x, y)
+    torch.cuda.synchronize()
+    cols = torch.from_numpy(enode.astype(np.int64) - 1).to(dev)
+    vals = torch.from_numpy(np.ascontiguousarray(eval_)).to(dev)
+    ref = _torch_rowsum_in_stored_order(cols, vals, None, x)
+    assert torch.equal(y, ref)
+    del cols, vals
+    sg.set_option("ell_colblock", 0)
+    try:
+        assert E.kernel == "k_ell_spmv"
+        y2 = torch.zeros(n, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        E.matvec(x, y2)
+        torch.cuda.synchronize()
+        assert torch.equal(y2, ref)
+    finally:
+        sg.set_option("ell_colblock", 1)
+
+
+def test_full_size_c5_464_cubed_every_row_bit_exact_and_cg_energy():
+    """BASELINE C5 at FULL size on one GPU: 7-point 464^3 (n = 99,897,344, nnz = 697,989,632).  Every row of
+    y = A x equals the torch evaluation in stored order (checked slab by slab to bound memory); exact row
+    sums for x = 1 (0 inside, positive on the boundary); 20 CG iterations decrease the energy norm."""
+    import torch
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from bench_configs import laplace3d_torch
+    dev = torch.device("cuda", 0)
+    m = 464
+    n = m ** 3
+    ptr, node, val = laplace3d_torch(m, m, m, dev)
+    torch.cuda.synchronize()
+    A = sg.csr_matrix(n, n, ptr, node, val)
+    assert A.kernel == "k_csr_sl<W=7>"
+    x = torch.sin(0.001 * torch.arange(1, n + 1, dtype=torch.float64, device=dev))
+    y = torch.zeros(n, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    A.matvec(x, y)
+    torch.cuda.synchronize()
+    tp = ptr.to(torch.int64)
+    slab = 16 * m * m
+    for r0 in range(0, n, slab):
+        r1 = min(n, r0 + slab)
+        start, ln = tp[r0:r1] - 1, tp[r0 + 1:r1 + 1] - tp[r0:r1]
+        idx = [torch.clamp(start + k, max=node.numel() - 1) for k in range(7)]
+        cols = torch.stack([node[i].to(torch.int64) - 1 for i in idx], dim=1)
+        vals = torch.stack([val[i] for i in idx], dim=1)
+        mask = torch.stack([ln > k for k in range(7)], dim=1)
+        assert torch.equal(y[r0:r1], _torch_rowsum_in_stored_order(cols, vals, mask, x)), r0
+    del cols, vals, mask, idx, tp
+    ones = torch.ones(n, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    A.matvec(ones, y)
+    torch.cuda.synchronize()
+    assert float(y.min()) == 0.0 and float(y.max()) == 3.0           # 6 - (number of neighbours): corners 3
+    assert int((y != 0).sum()) == n - (m - 2) ** 3
+    del ptr, node, val, ones
+    b = torch.full((n,), 1.0 / n, dtype=torch.float64, device=dev)
+    u = torch.zeros(n, dtype=torch.float64, device=dev)
+    s = sg.cg(1e-300)
+    s.set_max_iter(20)
+    s.set_history(20)
+    s.setup(A)
+    torch.cuda.synchronize()
+    s.solve(A, u, b, check=False)
+    torch.cuda.synchronize()
+    assert s.last_iterations == 20 and np.all(np.isfinite(s.history))
+    A.matvec(u, y)
+    torch.cuda.synchronize()
+    energy = 0.5 * float(torch.dot(u, y)) - float(torch.dot(b, u))
+    assert energy < 0.0                                              # below the energy of u = 0
 
 
 # ------------------------------------------------------------- Fortran ISO_C_BINDING host layer

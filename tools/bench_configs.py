@@ -135,14 +135,25 @@ def main():
         node = ej.reshape(n, 32)        # no padding: every row has exactly 32 slots, insertion order
         val = ev.reshape(n, 32)
         gen_s = time.time() - t0
+        torch.cuda.synchronize()
+        t0 = time.time()
         A = sg.ellpack_matrix(n, n, node, val)
+        torch.cuda.synchronize()
+        create_s = time.time() - t0
         x = torch.sin(0.001 * torch.arange(1, n + 1, dtype=torch.float64, device=dev))
         y = torch.zeros(n, dtype=torch.float64, device=dev)
-        t = timed(lambda: A.matvec(x, y), 30)
         bell = 12 * n * 32 + 16 * n
-        print(json.dumps({"config": "C4 ELLPACK random digraph degree 32", "n": n, "max_d": 32, "gen_s": gen_s,
-                          "spmv_us": t * 1e6, "spmv_GBs": bell / t / 1e9, "spmv_frac": bell / t / 1e9 / PEAK}),
-              flush=True)
+        out = {"config": "C4 ELLPACK random digraph degree 32", "n": n, "max_d": 32, "gen_s": gen_s, "create_s": create_s,
+               "algorithmic_bytes": bell, "resident_bytes": A.footprint()[0]}
+        for opt, label in ((1, "default"), (0, "ell_colblock=0")):
+            sg.set_option("ell_colblock", opt)
+            t = timed(lambda: A.matvec(x, y), 30)
+            mv = A.footprint()[1]
+            out[label] = {"kernel": A.kernel, "spmv_us": t * 1e6, "moved_bytes": mv, "GBs_moved": mv / t / 1e9,
+                          "frac_of_hbm_peak_moved": mv / t / 1e9 / PEAK, "effective_GBs_on_reference_bytes": bell / t / 1e9,
+                          "effective_frac": bell / t / 1e9 / PEAK}
+        sg.set_option("ell_colblock", 1)
+        print(json.dumps(out), flush=True)
         del A
 
     if "c5" in todo:
