@@ -589,7 +589,7 @@ def test_ell_column_blocked_two_phase_vs_oracle(orc, n, max_d, dmin, cols, chunk
     finally:
         sg.set_option("ell_colblock", 1)
         sg.set_option("ell_colblock_cols", 16384)
-        sg.set_option("ell_colblock_chunks", 8)
+        sg.set_option("ell_colblock_chunks", 16)
 
 
 @pytest.mark.parametrize("nparts", [2, 3, 5])
