@@ -22,7 +22,6 @@ a compressed layout, and it is never called "achieved HBM".
 N > 1 is weak scaling for the C2 line: every rank owns nx*ny rows of an nx x (N*ny) grid.
 """
 import argparse
-import glob
 import hashlib
 import json
 import os
@@ -47,8 +46,8 @@ def csrc_sha1():
     """Fingerprint of the kernel sources; PMC summaries under profiles/ carry the one they were
     collected with, and `traffic` is only quoted when it matches what runs now."""
     h = hashlib.sha1()
-    for f in sorted(glob.glob(os.path.join(ROOT, "sigma_amd", "csrc", "*.h*"))):
-        h.update(open(f, "rb").read())
+    for f in ("sgm_spmv.hip", "sgm_internal.hpp"):          # the SpMV kernels and the header they share
+        h.update(open(os.path.join(ROOT, "sigma_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
 

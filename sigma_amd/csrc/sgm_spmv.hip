@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void k_csr_sl(
     // launcher only asks for it when the grid is a multiple of 8 G (the map is then a permutation).
     int64_t first = blockIdx.x;
     if ((remap & 255) >= 3) {
-        const int G = (remap & 255) == 3 ? 8 : (remap & 255) == 4 ? 2 : 32;
+        const int G = (remap & 255) == 3 ? 8 : (remap & 255) == 4 ? 2 : (remap & 255) == 6 ? 64 : (remap & 255) == 7 ? 128 : 32;
         const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
         first = (int64_t)(loc / G) * (8 * G) + xcd * G + loc % G;
     }
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void k_csr_sl32(
 
     int64_t first = blockIdx.x;             // XCD-block-cyclic slices, see k_csr_sl
     if ((remap & 255) >= 3) {
-        const int G = (remap & 255) == 3 ? 8 : (remap & 255) == 4 ? 2 : 32;
+        const int G = (remap & 255) == 3 ? 8 : (remap & 255) == 4 ? 2 : (remap & 255) == 6 ? 64 : (remap & 255) == 7 ? 128 : 32;
         const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
         first = (int64_t)(loc / G) * (8 * G) + xcd * G + loc % G;
     }
@@ -838,7 +838,7 @@ static void launch_csr_sl(const Part &p, int grid, const double *x, double *y, c
     // (measured: 300^3 363 vs 358 us) and wherever the grid is not a multiple of 8 G; SGM_SPMV_CFG's
     // remap field overrides (0 = round-robin, 3/4/5 = G 8/2/32)
     int mode = c.remap == 1 ? (grid <= kMaxGrid / 2 ? 5 : 0) : (c.remap >= 3 ? c.remap : 0);
-    if (mode >= 3 && grid % (8 * (mode == 3 ? 8 : mode == 4 ? 2 : 32)) != 0) mode = 0;
+    if (mode >= 3 && grid % (8 * (mode == 3 ? 8 : mode == 4 ? 2 : mode == 6 ? 64 : mode == 7 ? 128 : 32)) != 0) mode = 0;
 #define L(WW, DW, DY)                                                                                   \
     hipLaunchKernelGGL((k_csr_sl<WW, ADD, DW, DY>), dim3(grid), dim3(256), 0, st, p.n, p.scode, p.dict, \
                        p.sval, x, y, w, pwy, pyy, flag, gen, mode | g_launch_flags)
@@ -863,7 +863,7 @@ static void launch_csr_sl32(const Part &p, int grid, const double *x, double *y,
     hipStream_t st = g_rt.stream;
     const SpmvCfg &c = spmv_cfg();
     int mode = c.remap == 1 ? (grid <= kMaxGrid / 2 ? 5 : 0) : (c.remap >= 3 ? c.remap : 0);
-    if (mode >= 3 && grid % (8 * (mode == 3 ? 8 : mode == 4 ? 2 : 32)) != 0) mode = 0;
+    if (mode >= 3 && grid % (8 * (mode == 3 ? 8 : mode == 4 ? 2 : mode == 6 ? 64 : mode == 7 ? 128 : 32)) != 0) mode = 0;
 #define L(WW, DW, DY)                                                                                     \
     hipLaunchKernelGGL((k_csr_sl32<WW, ADD, DW, DY>), dim3(grid), dim3(256), 0, st, p.n, p.scol, p.sval, x, y, \
                        w, pwy, pyy, flag, gen, mode | g_launch_flags)

@@ -1,15 +1,21 @@
-# Round profile: kernel stats + HBM counters of the bench command (run on the GPU box).
+# Round profile (run on the GPU box): the bench line, kernel stats + HBM counters of the bench command,
+# and the per-kernel times of the other BASELINE configs.  tools/collect_profiles.py condenses it into profiles/<tag>/.
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_round
 rm -rf $OUT; mkdir -p $OUT
-timeout 600 python bench.py --steps 200 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err; echo bench=$?
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --steps 50 --warmup 5 --cg-steps 30 --no-cpu > $OUT/stats.log 2>&1
-timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python bench.py --steps 5 --warmup 1 --cg-steps 0 --no-cpu > $OUT/pmc1.log 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python bench.py --steps 5 --warmup 1 --cg-steps 0 --no-cpu > $OUT/pmc2.log 2>&1
-# ILDU(0)-PCG on the 1000^2 grid: per-kernel times of the level walkers
+timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo bench=$?
+BARGS="--steps 2 --warmup 1 --spmv-per-step 64 --cg-steps 30 --no-cpu --no-c5"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py $BARGS > $OUT/stats.log 2>&1
+PARGS="--steps 1 --warmup 1 --spmv-per-step 4 --cg-steps 0 --no-cpu --no-c5 --no-variants"
+timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python bench.py $PARGS > $OUT/pmc1.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python bench.py $PARGS > $OUT/pmc2.log 2>&1
+# ILDU(0)-PCG on the 1000^2 grid: per-kernel times of the triangular solves
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ildu -- python tools/ildu_bench.py 1000 ildu0 > $OUT/stats_ildu.log 2>&1
-cat $OUT/bench.json
-# secondary configs of BASELINE.json (C3 BiCGStab/GMRES, C4 ELLPACK, C5 464^3 on one GPU): per-kernel times
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_configs -- python tools/bench_configs.py --configs c3,c4,c5 > $OUT/configs.log 2>&1
-grep '^{' $OUT/configs.log > $OUT/configs.jsonl
+# C3 GMRES(30): blocked CGS-2 vs modified Gram-Schmidt (launch counts per step come out of the Calls column)
+SGM_GMRES_CGS2=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_cgs2 -- python tools/bench_configs.py --configs c3 > $OUT/c3_cgs2.log 2>&1
+SGM_GMRES_CGS2=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_mgs -- python tools/bench_configs.py --configs c3 > $OUT/c3_mgs.log 2>&1
+# C4 / C5: per-kernel times
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_configs -- python tools/bench_configs.py --configs c4,c5 > $OUT/configs.log 2>&1
+grep -h '^{' $OUT/c3_cgs2.log $OUT/c3_mgs.log $OUT/configs.log > $OUT/configs.jsonl
+cat $OUT/bench.json | cut -c1-600
