@@ -261,6 +261,11 @@ int sgm_comm_destroy(sgm_comm c);
 int sgm_csr_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts /* nranks+1, 0-based */,
                         int64_t nnz_local, const int32_t *ptr_1based_local,
                         const int32_t *node_1based_global, const double *val, int where);
+/* sgm_ell_create_dist: this rank's rows of an ELLPACK matrix (node / val as (max_d, n_local) column-major,
+ * GLOBAL 1-based columns, padding as the reference keeps it).  Held as fixed-length CSR rows whose padding
+ * slots are stored entries, so the row sums equal ellpack_matvec_add's (ellpack_matrices.f90:640-665). */
+int sgm_ell_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts, int32_t max_d,
+                        const int32_t *node_1based_global_colmajor, const double *val_colmajor, int where);
 int sgm_csr_create_partitioned(sgm_mat *out, int32_t nparts, const int64_t *row_starts /* nparts+1 */,
                                int32_t nrow, int32_t ncol, int64_t nnz,
                                const int32_t *ptr_1based, const int32_t *node_1based,

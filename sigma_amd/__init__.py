@@ -395,6 +395,23 @@ class dist_csr_matrix(_Matrix):
                                       pp, pn, pv, C.c_int(_same_where(w1, w2, w3))))
 
 
+class dist_ellpack_matrix(_Matrix):
+    """This rank's rows of an ELLPACK matrix partitioned over processes (sgm_ell_create_dist): node / val
+    as C arrays of shape (n_local, max_d) = the reference's (max_d, n_local), GLOBAL 1-based columns."""
+
+    def __init__(self, comm, row_starts, node_global, val):
+        super().__init__()
+        rs = np.ascontiguousarray(row_starts, np.int64)
+        max_d = int(node_global.shape[1])
+        pn, w1, _k1 = _arg(node_global, np.int32)
+        pv, w2, _k2 = _arg(val, np.float64)
+        self.nrow = self.ncol = int(rs[-1])
+        self.n_local = int(rs[comm.rank + 1] - rs[comm.rank])
+        self.max_d = max_d
+        _ck(lib().sgm_ell_create_dist(C.byref(self._h), comm._h, C.c_void_p(rs.ctypes.data), C.c_int32(max_d), pn, pv,
+                                      C.c_int(_same_where(w1, w2))))
+
+
 class sparse_matrix(_Matrix):
     """The composite "matrix of matrices" (sparse_matrix_composites.f90:41-162): row_ptr /
     col_ptr are the 1-based block offsets, set_submatrix(it, jt, B) places a leaf (1-based

@@ -552,6 +552,37 @@ int sgm_csr_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts, 
     return SGM_OK;
 }
 
+/* ELLPACK rows of a partitioned matrix (ellpack_matvec_add, ellpack_matrices.f90:640-665, sums ALL max_d
+ * slots of a row in order, padding included): held as CSR rows of fixed length max_d whose padding slots
+ * are stored entries (value 0.0, column = the row's last neighbour), so the row sums -- and a 0 * Inf in a
+ * padding slot -- come out exactly as the reference's.  node / val: (max_d, n_local) column-major like the
+ * reference holds them, GLOBAL 1-based columns.  A slot of an empty row (node 0 in the reference, which then
+ * reads x(0)) points at the row's own column. */
+int sgm_ell_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts, int32_t max_d, const int32_t *node,
+                        const double *val, int where)
+{
+    SGM_TRY(require_init());
+    if (!out || !comm || !row_starts || max_d < 0) return fail(SGM_ERR_BAD_ARG, "sgm_ell_create_dist: bad argument");
+    const int64_t r0 = row_starts[comm->rank], r1 = row_starts[comm->rank + 1];
+    const int32_t n = (int32_t)(r1 - r0);
+    const int64_t nnz = (int64_t)n * max_d;
+    if (nnz >= INT32_MAX) return fail(SGM_ERR_UNSUPPORTED, "sgm_ell_create_dist: n_local * max_d exceeds int32");
+    if (nnz && (!node || !val)) return fail(SGM_ERR_BAD_ARG, "sgm_ell_create_dist: null arrays");
+    std::vector<int32_t> hnode((size_t)std::max<int64_t>(nnz, 1)), hptr((size_t)n + 1);
+    std::vector<double> hval((size_t)std::max<int64_t>(nnz, 1));
+    if (nnz) {
+        const hipMemcpyKind kind = where == SGM_HOST ? hipMemcpyHostToHost : hipMemcpyDeviceToHost;
+        SGM_HIP(hipMemcpyAsync(hnode.data(), node, (size_t)nnz * 4, kind, g_rt.stream));
+        SGM_HIP(hipMemcpyAsync(hval.data(), val, (size_t)nnz * 8, kind, g_rt.stream));
+        SGM_HIP(hipStreamSynchronize(g_rt.stream));
+    }
+    for (int32_t i = 0; i <= n; ++i) hptr[i] = 1 + i * max_d;
+    for (int32_t i = 0; i < n; ++i)
+        for (int32_t k = 0; k < max_d; ++k)
+            if (hnode[(size_t)i * max_d + k] <= 0) hnode[(size_t)i * max_d + k] = (int32_t)(r0 + i + 1);
+    return sgm_csr_create_dist(out, comm, row_starts, nnz, hptr.data(), hnode.data(), hval.data(), SGM_HOST);
+}
+
 /* read back the exchange plan of a distributed / partitioned matrix (parity checks): for local
  * part `part`, neighbour `k`: peer, counts, offset and (optionally) the send list (0-based). */
 int sgm_mat_halo_nbr(sgm_mat A, int32_t part, int32_t k, int32_t *n_nbrs, int32_t *peer, int32_t *send_count,

@@ -475,11 +475,32 @@ __global__ __launch_bounds__(TB) void k_trsv_walk_ring(const uint64_t *__restric
 //       dependency contributes an exact 0.0, whatever its operand holds)
 // Coefficients, codes and right-hand sides do not depend on the solve: they are requested DEPTH steps
 // ahead (static register slots, every lane loads on every step so the waits stay exact).
-constexpr int kGridDepth = 4;
+// The chain of a step is: shift the previous results one lane up (DPP wave_shr, no LDS), two products, two
+// subtractions.  Nothing in it may wait for memory, so the tile's data goes through LDS in chunks of CH steps:
+// while chunk c is being solved out of LDS, chunk c+1 sits in LDS already and the global loads of chunk c+2 are in
+// flight into registers (one vmcnt wait per chunk, not per step).
+constexpr int kGridChunk = 32;       // steps per chunk; a tile's step count S is a multiple of it
+constexpr int kGridBurst = 8;        // steps whose operands are pulled from LDS into registers at a time
+constexpr size_t kGridLds = (size_t)2 * kGridChunk * (3 * 64 * 8 + 64 + 8);
+__device__ inline double shift_up_one_lane(double v)
+{
+    // lane l receives lane l-1's value (wave_shr:1 crosses the 16-lane DPP rows on gfx9); lane 0 keeps its own
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int slo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    const int shi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(shi, slo);
+}
+template <int CH, int SB>
 __global__ __launch_bounds__(64) void k_trsv_grid(int32_t d, int32_t ib_lo, int32_t NI, int32_t BH, int32_t S,
                                                   const double *__restrict__ cS, const double *__restrict__ cW,
                                                   const uint8_t *__restrict__ code, double *xp, const int *flag)
 {
+    extern __shared__ double lds_grid[];
+    double (*lS)[CH][64] = reinterpret_cast<double (*)[CH][64]>(lds_grid);
+    double (*lW)[CH][64] = reinterpret_cast<double (*)[CH][64]>(lds_grid + 2 * CH * 64);
+    double (*lR)[CH][64] = reinterpret_cast<double (*)[CH][64]>(lds_grid + 4 * CH * 64);
+    double (*lE)[CH] = reinterpret_cast<double (*)[CH]>(lds_grid + 6 * CH * 64);
+    uint8_t (*lC)[CH][64] = reinterpret_cast<uint8_t (*)[CH][64]>(lds_grid + 6 * CH * 64 + 2 * CH);
     if (flag && *flag) return;
     const int lane = threadIdx.x;
     const int32_t ib = ib_lo + blockIdx.x, jb = d - ib;
@@ -489,41 +510,75 @@ __global__ __launch_bounds__(64) void k_trsv_grid(int32_t d, int32_t ib_lo, int3
     double up_top = 0.0;
     if (jb > 0) up_top = xp[base - (int64_t)NI * tile + (int64_t)(BH - 1 + lane) * 64 + lane];
     // lane 63 of the left tile, 63 steps ahead: + (step + 63) * 64.  Without a left tile the load goes to this
-    // tile's own lane 63 (always issued: a conditional load would force vmcnt(0) waits); its value is never
-    // used, because column 0 has no r-1 dependency.
+    // tile's own lane 63; its value is never used, because column 0 has no r-1 dependency.
     const int64_t lbase = (ib > 0 ? base - tile : base) + 63;
-    double pcS[kGridDepth], pcW[kGridDepth], prh[kGridDepth], ped[kGridDepth];
-    uint32_t pco[kGridDepth];
-    auto fetch = [&](int slot, int32_t t) {
-        const int32_t tc = min(t, S - 1);                      // past the tile: repeat the last step's addresses
-        const int64_t p = base + (int64_t)tc * 64 + lane;
-        pcS[slot] = cS[p];
-        pcW[slot] = cW[p];
-        pco[slot] = code[p];
-        prh[slot] = xp[p];
-        // (the last 63 steps of a tile have no row in lane 0: the clamped address stays inside the left tile)
-        ped[slot] = xp[lbase + (int64_t)min(tc + 63, S - 1) * 64];
+    double rS[CH], rW[CH], rR[CH], rE[CH];
+    uint32_t rC[CH];
+    auto load_chunk = [&](int32_t c) {                      // global -> registers (chunks past the tile: the last one again)
+        const int32_t t0 = min(c * CH, S - CH);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int64_t p = base + (int64_t)(t0 + j) * 64 + lane;
+            rS[j] = cS[p];
+            rW[j] = cW[p];
+            rC[j] = code[p];
+            rR[j] = xp[p];
+            rE[j] = xp[lbase + (int64_t)min(t0 + j + 63, S - 1) * 64];
+        }
     };
+    auto stash_chunk = [&](int buf) {                       // registers -> LDS
 #pragma unroll
-    for (int j = 0; j < kGridDepth; ++j) fetch(j, j);
+        for (int j = 0; j < CH; ++j) {
+            lS[buf][j][lane] = rS[j];
+            lW[buf][j][lane] = rW[j];
+            lR[buf][j][lane] = rR[j];
+            lC[buf][j][lane] = (uint8_t)rC[j];
+            if (lane == 0) lE[buf][j] = rE[j];
+        }
+    };
+    double aS[2][SB], aW[2][SB], aR[2][SB], aE[2][SB];
+    uint32_t aC[2][SB];
+    const int32_t nch = S / CH;
+    load_chunk(0);
+    stash_chunk(0);
+    load_chunk(1);
     double prev = 0.0;
-    for (int32_t t0 = 0; t0 < S; t0 += kGridDepth) {
+    for (int32_t c = 0; c < nch; ++c) {
+        const int buf = c & 1;
+        stash_chunk(buf ^ 1);                               // chunk c+1 (its loads were issued one chunk ago)
+        load_chunk(c + 2);
 #pragma unroll
-        for (int j = 0; j < kGridDepth; ++j) {
-            const int32_t t = t0 + j;
-            const uint32_t c = pco[j];
-            const double lft = __shfl_up(prev, 1, 64);
-            const double left = lane == 0 ? ped[j] : lft;
-            const double upv = t == lane ? up_top : prev;
-            const double pS = (c & 1u) ? pcS[j] * upv : 0.0;
-            const double pW = (c & 2u) ? pcW[j] * left : 0.0;
-            const bool wfirst = (c & 4u) != 0;
-            double z = prh[j];
-            z = z - (wfirst ? pW : pS);
-            z = z - (wfirst ? pS : pW);
-            xp[base + (int64_t)t * 64 + lane] = z;          // (S is a multiple of the depth: always inside the tile)
-            prev = z;
-            fetch(j, t + kGridDepth);
+        for (int u = 0; u < SB; ++u) {
+            aS[0][u] = lS[buf][u][lane]; aW[0][u] = lW[buf][u][lane]; aR[0][u] = lR[buf][u][lane];
+            aE[0][u] = lE[buf][u]; aC[0][u] = lC[buf][u][lane];
+        }
+#pragma unroll
+        for (int sb = 0; sb < CH / SB; ++sb) {
+            const int set = sb & 1;
+            if (sb + 1 < CH / SB) {                         // operands of the next burst: requested before this burst's chain
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int j = (sb + 1) * SB + u;
+                    aS[set ^ 1][u] = lS[buf][j][lane]; aW[set ^ 1][u] = lW[buf][j][lane]; aR[set ^ 1][u] = lR[buf][j][lane];
+                    aE[set ^ 1][u] = lE[buf][j]; aC[set ^ 1][u] = lC[buf][j][lane];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int32_t t = c * CH + sb * SB + u;
+                const uint32_t cc = aC[set][u];
+                const double lft = shift_up_one_lane(prev);
+                const double left = lane == 0 ? aE[set][u] : lft;
+                const double upv = t == lane ? up_top : prev;
+                const double pS = (cc & 1u) ? aS[set][u] * upv : 0.0;
+                const double pW = (cc & 2u) ? aW[set][u] * left : 0.0;
+                const bool wfirst = (cc & 4u) != 0;
+                double z = aR[set][u];
+                z = z - (wfirst ? pW : pS);
+                z = z - (wfirst ? pS : pW);
+                xp[base + (int64_t)t * 64 + lane] = z;
+                prev = z;
+            }
         }
     }
 }
@@ -851,7 +906,7 @@ int build_grid(GridTri &G, int32_t n, int32_t w, const std::vector<int32_t> &ptr
     G.BH = bh_env > 0 ? bh_env : 256;
     if (G.BH > G.nj) G.BH = std::max(1, G.nj);
     G.NJ = (G.nj + G.BH - 1) / G.BH;
-    G.S = (G.BH + 63 + kGridDepth - 1) / kGridDepth * kGridDepth;
+    G.S = std::max(2 * kGridChunk, (G.BH + 63 + kGridChunk - 1) / kGridChunk * kGridChunk);
     G.NP = (int64_t)G.NI * G.NJ * G.S * 64;
     if (G.NP >= INT32_MAX) return SGM_OK;                     // (positions are int32)
     std::vector<int32_t> hrow((size_t)G.NP, -1);
@@ -904,8 +959,13 @@ void trsv_grid(const GridTri &G, double *xp, const int *flag)
     hipStream_t st = g_rt.stream;
     for (int32_t d = 0; d <= G.NI + G.NJ - 2; ++d) {
         const int32_t lo = std::max(0, d - (G.NJ - 1)), hi = std::min(G.NI - 1, d);
-        hipLaunchKernelGGL(k_trsv_grid, dim3(hi - lo + 1), dim3(64), 0, st, d, lo, G.NI, G.BH, G.S, (const double *)G.cS,
-                           (const double *)G.cW, (const uint8_t *)G.code, xp, flag);
+        static bool attr = false;
+        if (!attr) {            // more than 64 KiB of LDS per workgroup needs the attribute
+            (void)hipFuncSetAttribute((const void *)k_trsv_grid<kGridChunk, kGridBurst>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGridLds);
+            attr = true;
+        }
+        hipLaunchKernelGGL((k_trsv_grid<kGridChunk, kGridBurst>), dim3(hi - lo + 1), dim3(64), kGridLds, st, d, lo, G.NI, G.BH, G.S,
+                           (const double *)G.cS, (const double *)G.cW, (const uint8_t *)G.code, xp, flag);
     }
 }
 

@@ -114,6 +114,21 @@ def run(rank, world, port, case, res):
         assert np.array_equal(yd.cpu().numpy(), y_ref)
         H2.destroy()
 
+        # ---- ELLPACK rows (padding slots included) through the same machinery: sgm_ell_create_dist
+        ne = 4000
+        E = orc.EllMatrix.from_edges(ne, ne, *P.random_regular_ell(ne, 12, 99, dmin=7))
+        es = sg.partition_rows_by_nnz(np.arange(1, 12 * ne + 2, 12, dtype=np.int32), world, align=2)
+        e0, e1 = int(es[rank]), int(es[rank + 1])
+        He = sg.dist_ellpack_matrix(comm, es, np.ascontiguousarray(E.node.reshape(ne, -1)[e0:e1]),
+                                    np.ascontiguousarray(E.val.reshape(ne, -1)[e0:e1]))
+        xe_full = np.random.RandomState(3).standard_normal(ne)
+        xel = np.zeros(He.x_len)
+        xel[:e1 - e0] = xe_full[e0:e1]
+        ye = np.zeros(e1 - e0)
+        He.matvec(xel, ye)
+        assert np.array_equal(ye, E.matvec(xe_full)[e0:e1]), "distributed ELLPACK rows differ from ellpack_matvec_add"
+        He.destroy()
+
         # ---- Krylov loops with all-reduced dots
         b = np.full(n, 1.0 / n) if case != "random" else P.test_vector(n)
         bl = b[r0:r1].copy()
