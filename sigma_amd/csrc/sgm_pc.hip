@@ -73,24 +73,6 @@ struct TriFactor {                   // strictly triangular factor on the device
     std::vector<Launch> schedule;
 };
 
-// A strictly triangular factor whose rows depend only on the previous row (r-1) and on the row one
-// grid line back (r-w): ILDU(0) factors of 5-point / banded matrices in natural order.  Rows are
-// re-laid in SKEWED tiles of 64 columns x BH grid lines: lane l of the wave that owns a tile handles
-// column i0+l and, at step t, grid line t-l, so that the (i-1, j) neighbour is lane l-1's result of
-// the previous step (one DPP shift) and the (i, j-1) neighbour the lane's own -- no LDS, no barrier,
-// every load and store of a step is one coalesced 512-byte access of the skewed layout
-// (position = tile base + step * 64 + lane).  See k_trsv_grid.
-struct GridTri {
-    bool on = false;
-    int32_t w = 0, nj = 0, NI = 0, NJ = 0, BH = 0, S = 0;      // grid width / lines, tiles, lines per tile, steps per tile
-    int64_t NP = 0;                                             // positions (incl. padding)
-    double *cS = nullptr, *cW = nullptr;                        // device: coefficient of the r-w / r-1 dependency per position
-    uint8_t *code = nullptr;                                    // device: bit0 has r-w, bit1 has r-1, bit2 r-1 comes FIRST in stored order
-    int32_t *row = nullptr;                                     // device: position -> row (-1 = padding)
-    std::vector<int32_t> h_pos;                                 // host: row -> position
-    std::vector<int32_t> h_srcS, h_srcW;                        // host: position -> entry of the factor's val array (-1 = none)
-};
-
 struct PartPC {
     double *idiag = nullptr;
 };
@@ -107,10 +89,6 @@ struct IlduState {
     int32_t *mapLU = nullptr;                                // U position -> L position of the same row
     std::vector<int32_t> hLptr, hLnode, hUptr, hUnode;      // 1-based, as the reference holds them
     std::vector<double> hLval, hUval, hD;
-    // grid-skew path (both factors grid-like, see GridTri): position-space vectors and the L -> U hand-over
-    GridTri gL, gU;
-    double *gxL = nullptr, *gxU = nullptr, *gDp = nullptr;
-    int32_t *gmapLU = nullptr;
 };
 
 struct sgm_pc_s {
@@ -466,148 +444,6 @@ __global__ __launch_bounds__(TB) void k_trsv_walk_ring(const uint64_t *__restric
     }
 }
 
-// ---- grid-skew triangular solve (GridTri) -----------------------------------------------------
-// One launch per tile anti-diagonal d (tiles (ib, jb) with ib + jb = d are independent); one WAVE per
-// tile.  Position space: xp[tile base + step * 64 + lane].  At step t lane l holds row (i0 + l, j0 + t - l):
-//   up   = its own result of step t-1            (first line of the tile: read from the tile above)
-//   left = lane l-1's result of step t-1         (lane 0: read from the tile to the left, 63 steps ahead there)
-//   z = rhs - c1*x1 - c2*x2 in the row's STORED order (products rounded one by one; an absent
-//       dependency contributes an exact 0.0, whatever its operand holds)
-// Coefficients, codes and right-hand sides do not depend on the solve: they are requested DEPTH steps
-// ahead (static register slots, every lane loads on every step so the waits stay exact).
-// The chain of a step is: shift the previous results one lane up (DPP wave_shr, no LDS), two products, two
-// subtractions.  Nothing in it may wait for memory, so the tile's data goes through LDS in chunks of CH steps:
-// while chunk c is being solved out of LDS, chunk c+1 sits in LDS already and the global loads of chunk c+2 are in
-// flight into registers (one vmcnt wait per chunk, not per step).
-constexpr int kGridChunk = 32;       // steps per chunk; a tile's step count S is a multiple of it
-constexpr int kGridBurst = 8;        // steps whose operands are pulled from LDS into registers at a time
-constexpr size_t kGridLds = (size_t)2 * kGridChunk * (3 * 64 * 8 + 64 + 8);
-__device__ inline double shift_up_one_lane(double v)
-{
-    // lane l receives lane l-1's value (wave_shr:1 crosses the 16-lane DPP rows on gfx9); lane 0 keeps its own
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const int slo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
-    const int shi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
-    return __hiloint2double(shi, slo);
-}
-template <int CH, int SB>
-__global__ __launch_bounds__(64) void k_trsv_grid(int32_t d, int32_t ib_lo, int32_t NI, int32_t BH, int32_t S,
-                                                  const double *__restrict__ cS, const double *__restrict__ cW,
-                                                  const uint8_t *__restrict__ code, double *xp, const int *flag)
-{
-    extern __shared__ double lds_grid[];
-    double (*lS)[CH][64] = reinterpret_cast<double (*)[CH][64]>(lds_grid);
-    double (*lW)[CH][64] = reinterpret_cast<double (*)[CH][64]>(lds_grid + 2 * CH * 64);
-    double (*lR)[CH][64] = reinterpret_cast<double (*)[CH][64]>(lds_grid + 4 * CH * 64);
-    double (*lE)[CH] = reinterpret_cast<double (*)[CH]>(lds_grid + 6 * CH * 64);
-    uint8_t (*lC)[CH][64] = reinterpret_cast<uint8_t (*)[CH][64]>(lds_grid + 6 * CH * 64 + 2 * CH);
-    if (flag && *flag) return;
-    const int lane = threadIdx.x;
-    const int32_t ib = ib_lo + blockIdx.x, jb = d - ib;
-    const int64_t tile = (int64_t)S * 64;
-    const int64_t base = ((int64_t)jb * NI + ib) * tile;
-    // the tile above: line BH-1 of column lane sits at step BH-1+lane there
-    double up_top = 0.0;
-    if (jb > 0) up_top = xp[base - (int64_t)NI * tile + (int64_t)(BH - 1 + lane) * 64 + lane];
-    // lane 63 of the left tile, 63 steps ahead: + (step + 63) * 64.  Without a left tile the load goes to this
-    // tile's own lane 63; its value is never used, because column 0 has no r-1 dependency.
-    const int64_t lbase = (ib > 0 ? base - tile : base) + 63;
-    double rS[CH], rW[CH], rR[CH], rE[CH];
-    uint32_t rC[CH];
-    auto load_chunk = [&](int32_t c) {                      // global -> registers (chunks past the tile: the last one again)
-        const int32_t t0 = min(c * CH, S - CH);
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const int64_t p = base + (int64_t)(t0 + j) * 64 + lane;
-            rS[j] = cS[p];
-            rW[j] = cW[p];
-            rC[j] = code[p];
-            rR[j] = xp[p];
-            rE[j] = xp[lbase + (int64_t)min(t0 + j + 63, S - 1) * 64];
-        }
-    };
-    auto stash_chunk = [&](int buf) {                       // registers -> LDS
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            lS[buf][j][lane] = rS[j];
-            lW[buf][j][lane] = rW[j];
-            lR[buf][j][lane] = rR[j];
-            lC[buf][j][lane] = (uint8_t)rC[j];
-            if (lane == 0) lE[buf][j] = rE[j];
-        }
-    };
-    double aS[2][SB], aW[2][SB], aR[2][SB], aE[2][SB];
-    uint32_t aC[2][SB];
-    const int32_t nch = S / CH;
-    load_chunk(0);
-    stash_chunk(0);
-    load_chunk(1);
-    double prev = 0.0;
-    for (int32_t c = 0; c < nch; ++c) {
-        const int buf = c & 1;
-        stash_chunk(buf ^ 1);                               // chunk c+1 (its loads were issued one chunk ago)
-        load_chunk(c + 2);
-#pragma unroll
-        for (int u = 0; u < SB; ++u) {
-            aS[0][u] = lS[buf][u][lane]; aW[0][u] = lW[buf][u][lane]; aR[0][u] = lR[buf][u][lane];
-            aE[0][u] = lE[buf][u]; aC[0][u] = lC[buf][u][lane];
-        }
-#pragma unroll
-        for (int sb = 0; sb < CH / SB; ++sb) {
-            const int set = sb & 1;
-            if (sb + 1 < CH / SB) {                         // operands of the next burst: requested before this burst's chain
-#pragma unroll
-                for (int u = 0; u < SB; ++u) {
-                    const int j = (sb + 1) * SB + u;
-                    aS[set ^ 1][u] = lS[buf][j][lane]; aW[set ^ 1][u] = lW[buf][j][lane]; aR[set ^ 1][u] = lR[buf][j][lane];
-                    aE[set ^ 1][u] = lE[buf][j]; aC[set ^ 1][u] = lC[buf][j][lane];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < SB; ++u) {
-                const int32_t t = c * CH + sb * SB + u;
-                const uint32_t cc = aC[set][u];
-                const double lft = shift_up_one_lane(prev);
-                const double left = lane == 0 ? aE[set][u] : lft;
-                const double upv = t == lane ? up_top : prev;
-                const double pS = (cc & 1u) ? aS[set][u] * upv : 0.0;
-                const double pW = (cc & 2u) ? aW[set][u] * left : 0.0;
-                const bool wfirst = (cc & 4u) != 0;
-                double z = aR[set][u];
-                z = z - (wfirst ? pW : pS);
-                z = z - (wfirst ? pS : pW);
-                xp[base + (int64_t)t * 64 + lane] = z;
-                prev = z;
-            }
-        }
-    }
-}
-// position-space gather / hand-over / scatter of the grid path (padding positions hold 0)
-__global__ void k_grid_gather(int64_t np, double *__restrict__ xp, const double *__restrict__ src,
-                              const int32_t *__restrict__ row, const int *flag)
-{
-    if (flag && *flag) return;
-    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; p < np; p += stride) { const int32_t r = row[p]; xp[p] = r >= 0 ? src[r] : 0.0; }
-}
-__global__ void k_grid_transition(int64_t np, double *__restrict__ xpU, const double *__restrict__ xpL,
-                                  const int32_t *__restrict__ mapLU, const double *__restrict__ Dp, const int *flag)
-{
-    if (flag && *flag) return;
-    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; p < np; p += stride) { const int32_t q = mapLU[p]; xpU[p] = q >= 0 ? xpL[q] / Dp[p] : 0.0; }   // x = x / D
-}
-__global__ void k_grid_scatter(int64_t np, double *__restrict__ dst, const double *__restrict__ xp,
-                               const int32_t *__restrict__ row, const int *flag)
-{
-    if (flag && *flag) return;
-    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; p < np; p += stride) { const int32_t r = row[p]; if (r >= 0) dst[r] = xp[p]; }
-}
-
 // --------------------------------------------------------------------- host factorisation
 // Row-scan accessors with the reference's semantics (cs_matrices.f90:709-724, :840-895).
 struct HostCsr {
@@ -699,14 +535,11 @@ void ildu_factor(IlduState *pc, int32_t n, const std::vector<int32_t> &ptr, cons
 }
 
 void free_tri(TriFactor &T);
-void free_grid(GridTri &G);
 void free_ildu(IlduState &S)
 {
     free_tri(S.L);
     free_tri(S.U);
     dfree(S.D); dfree(S.xpL); dfree(S.xpU); dfree(S.Dp); dfree(S.mapLU);
-    free_grid(S.gL); free_grid(S.gU);
-    dfree(S.gxL); dfree(S.gxU); dfree(S.gDp); dfree(S.gmapLU);
     S = IlduState();
 }
 
@@ -861,114 +694,6 @@ int upload_tri(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const 
     return SGM_OK;
 }
 
-// ---- grid-skew path: host side ----------------------------------------------------------------
-void free_grid(GridTri &G)
-{
-    dfree(G.cS); dfree(G.cW); dfree(G.code); dfree(G.row);
-    G = GridTri();
-}
-
-// Is the factor grid-like?  lower: deps of row r within {r-1, r-w}, the r-1 one never across a grid
-// line (r % w != 0); upper: {r+1, r+w}, (r+1) % w != 0.  Returns w (0 = no).
-int32_t grid_width(int32_t n, const std::vector<int32_t> &ptr1, const std::vector<int32_t> &node1, bool lower)
-{
-    int32_t w = 0;
-    for (int32_t r = 0; r < n; ++r)
-        for (int32_t k = ptr1[r] - 1; k < ptr1[r + 1] - 1; ++k) {
-            const int32_t dlt = lower ? r - (node1[k] - 1) : (node1[k] - 1) - r;
-            if (dlt <= 0) return 0;
-            if (dlt == 1) continue;
-            if (!w) w = dlt;
-            if (dlt != w) return 0;
-        }
-    if (w < 2) return 0;
-    for (int32_t r = 0; r < n; ++r) {
-        if (ptr1[r + 1] - ptr1[r] > 2) return 0;
-        for (int32_t k = ptr1[r] - 1; k < ptr1[r + 1] - 1; ++k) {
-            const int32_t c = node1[k] - 1;
-            if (lower && c == r - 1 && r % w == 0) return 0;
-            if (!lower && c == r + 1 && (r + 1) % w == 0) return 0;
-        }
-        if (ptr1[r + 1] - ptr1[r] == 2 && node1[ptr1[r] - 1] == node1[ptr1[r]]) return 0;
-    }
-    return w;
-}
-
-// index work of the skewed layout (once per pattern).  The upper factor is the lower one of the
-// reversed numbering: i' = w-1-i, j' = nj-1-j.
-int build_grid(GridTri &G, int32_t n, int32_t w, const std::vector<int32_t> &ptr1, const std::vector<int32_t> &node1, bool lower)
-{
-    free_grid(G);
-    static const int bh_env = getenv("SGM_TRSV_GRID_BH") ? atoi(getenv("SGM_TRSV_GRID_BH")) : 0;
-    G.w = w;
-    G.nj = (n + w - 1) / w;
-    G.NI = (w + 63) / 64;
-    G.BH = bh_env > 0 ? bh_env : 256;
-    if (G.BH > G.nj) G.BH = std::max(1, G.nj);
-    G.NJ = (G.nj + G.BH - 1) / G.BH;
-    G.S = std::max(2 * kGridChunk, (G.BH + 63 + kGridChunk - 1) / kGridChunk * kGridChunk);
-    G.NP = (int64_t)G.NI * G.NJ * G.S * 64;
-    if (G.NP >= INT32_MAX) return SGM_OK;                     // (positions are int32)
-    std::vector<int32_t> hrow((size_t)G.NP, -1);
-    std::vector<uint8_t> hcode((size_t)G.NP, 0);
-    G.h_pos.assign(std::max(n, 1), 0);
-    G.h_srcS.assign((size_t)G.NP, -1);
-    G.h_srcW.assign((size_t)G.NP, -1);
-    for (int32_t r = 0; r < n; ++r) {
-        int32_t i = r % w, j = r / w;
-        if (!lower) { i = w - 1 - i; j = G.nj - 1 - j; }
-        const int32_t ib = i / 64, l = i % 64, jb = j / G.BH, jl = j % G.BH;
-        const int64_t p = ((int64_t)jb * G.NI + ib) * G.S * 64 + (int64_t)(jl + l) * 64 + l;
-        G.h_pos[r] = (int32_t)p;
-        hrow[p] = r;
-        uint8_t c = 0;
-        int seen = 0;
-        for (int32_t k = ptr1[r] - 1; k < ptr1[r + 1] - 1; ++k, ++seen) {
-            const int32_t dlt = lower ? r - (node1[k] - 1) : (node1[k] - 1) - r;
-            if (dlt == 1) { c |= 2; G.h_srcW[p] = k; if (seen == 0) c |= 4; }
-            else { c |= 1; G.h_srcS[p] = k; }
-        }
-        hcode[p] = c;
-    }
-    SGM_TRY(dalloc(&G.cS, (size_t)G.NP));
-    SGM_TRY(dalloc(&G.cW, (size_t)G.NP));
-    SGM_TRY(dalloc(&G.code, (size_t)G.NP));
-    SGM_TRY(dalloc(&G.row, (size_t)G.NP));
-    SGM_HIP(hipMemcpy(G.code, hcode.data(), (size_t)G.NP, hipMemcpyHostToDevice));
-    SGM_HIP(hipMemcpy(G.row, hrow.data(), (size_t)G.NP * 4, hipMemcpyHostToDevice));
-    G.on = true;
-    return SGM_OK;
-}
-
-// coefficients in the skewed layout (every setup)
-int refresh_grid_values(GridTri &G, const std::vector<double> &val)
-{
-    if (!G.on) return SGM_OK;
-    std::vector<double> a((size_t)G.NP, 0.0), b((size_t)G.NP, 0.0);
-    for (int64_t p = 0; p < G.NP; ++p) {
-        if (G.h_srcS[p] >= 0) a[p] = val[G.h_srcS[p]];
-        if (G.h_srcW[p] >= 0) b[p] = val[G.h_srcW[p]];
-    }
-    SGM_HIP(hipMemcpy(G.cS, a.data(), (size_t)G.NP * 8, hipMemcpyHostToDevice));
-    SGM_HIP(hipMemcpy(G.cW, b.data(), (size_t)G.NP * 8, hipMemcpyHostToDevice));
-    return SGM_OK;
-}
-
-void trsv_grid(const GridTri &G, double *xp, const int *flag)
-{
-    hipStream_t st = g_rt.stream;
-    for (int32_t d = 0; d <= G.NI + G.NJ - 2; ++d) {
-        const int32_t lo = std::max(0, d - (G.NJ - 1)), hi = std::min(G.NI - 1, d);
-        static bool attr = false;
-        if (!attr) {            // more than 64 KiB of LDS per workgroup needs the attribute
-            (void)hipFuncSetAttribute((const void *)k_trsv_grid<kGridChunk, kGridBurst>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGridLds);
-            attr = true;
-        }
-        hipLaunchKernelGGL((k_trsv_grid<kGridChunk, kGridBurst>), dim3(hi - lo + 1), dim3(64), kGridLds, st, d, lo, G.NI, G.BH, G.S,
-                           (const double *)G.cS, (const double *)G.cW, (const uint8_t *)G.code, xp, flag);
-    }
-}
-
 // triangular solve in position space: xp holds the right-hand side on entry, the solution on exit
 void trsv(const TriFactor &T, double *xp, const int *flag)
 {
@@ -1074,17 +799,6 @@ int pc_apply_parts(sgm_pc pc, sgm_mat A, const double *const *r, double *const *
             const IlduState *S = &pc->ild[ip];
             const int64_t n = S->n;
             const int *flag = flags ? flags[ip] : nullptr;
-            if (S->gL.on && S->gU.on && g_opt.ildu_grid) {           // grid-like factors: skewed-tile wavefronts
-                const int gl = vec_grid(S->gL.NP), gu = vec_grid(S->gU.NP);
-                hipLaunchKernelGGL(k_grid_gather, dim3(gl), dim3(kBlock), 0, st, S->gL.NP, S->gxL, r[ip], (const int32_t *)S->gL.row, flag);
-                trsv_grid(S->gL, S->gxL, flag);                                       // (I+L) x = b
-                hipLaunchKernelGGL(k_grid_transition, dim3(gu), dim3(kBlock), 0, st, S->gU.NP, S->gxU, (const double *)S->gxL,
-                                   (const int32_t *)S->gmapLU, (const double *)S->gDp, flag);       // x = x / D
-                trsv_grid(S->gU, S->gxU, flag);                                       // (I+U) x = x
-                hipLaunchKernelGGL(k_grid_scatter, dim3(gu), dim3(kBlock), 0, st, S->gU.NP, z[ip], (const double *)S->gxU,
-                                   (const int32_t *)S->gU.row, flag);
-                continue;
-            }
             const int g = vec_grid(n);
             hipLaunchKernelGGL(k_perm_gather, dim3(g), dim3(kBlock), 0, st, n, S->xpL, r[ip], (const int32_t *)S->L.order, flag);
             trsv(S->L, S->xpL, flag);                                             // (I+L) x = b
@@ -1196,32 +910,6 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             std::vector<int32_t> map((size_t)std::max(n, 1));
             for (int32_t p = 0; p < n; ++p) map[p] = S->L.h_pos[S->U.h_order[p]];
             if (n) SGM_HIP(hipMemcpy(S->mapLU, map.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-        }
-        if (fresh) {        // grid-like factors get the skewed-tile layout as well (the level-scheduled one stays: option off)
-            free_grid(S->gL); free_grid(S->gU);
-            dfree(S->gxL); dfree(S->gxU); dfree(S->gDp); dfree(S->gmapLU);
-            S->gxL = S->gxU = S->gDp = nullptr; S->gmapLU = nullptr;
-            const int32_t wl = grid_width(n, S->hLptr, S->hLnode, true), wu = grid_width(n, S->hUptr, S->hUnode, false);
-            if (wl >= 64 && wl == wu && (n + wl - 1) / wl >= 16) {
-                SGM_TRY(build_grid(S->gL, n, wl, S->hLptr, S->hLnode, true));
-                SGM_TRY(build_grid(S->gU, n, wl, S->hUptr, S->hUnode, false));
-                if (S->gL.on && S->gU.on) {
-                    SGM_TRY(dalloc(&S->gxL, (size_t)S->gL.NP));
-                    SGM_TRY(dalloc(&S->gxU, (size_t)S->gU.NP));
-                    SGM_TRY(dalloc(&S->gDp, (size_t)S->gU.NP));
-                    SGM_TRY(dalloc(&S->gmapLU, (size_t)S->gU.NP));
-                    std::vector<int32_t> map((size_t)S->gU.NP, -1);
-                    for (int32_t r = 0; r < n; ++r) map[S->gU.h_pos[r]] = S->gL.h_pos[r];
-                    SGM_HIP(hipMemcpy(S->gmapLU, map.data(), map.size() * 4, hipMemcpyHostToDevice));
-                } else { free_grid(S->gL); free_grid(S->gU); }
-            }
-        }
-        if (S->gL.on && S->gU.on) {
-            SGM_TRY(refresh_grid_values(S->gL, S->hLval));
-            SGM_TRY(refresh_grid_values(S->gU, S->hUval));
-            std::vector<double> gd((size_t)S->gU.NP, 1.0);
-            for (int32_t r = 0; r < n; ++r) gd[S->gU.h_pos[r]] = S->hD[r];
-            SGM_HIP(hipMemcpy(S->gDp, gd.data(), gd.size() * 8, hipMemcpyHostToDevice));
         }
         std::vector<double> dp((size_t)std::max(n, 1));
         for (int32_t p = 0; p < n; ++p) dp[p] = S->hD[S->U.h_order[p]];
