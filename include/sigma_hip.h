@@ -106,7 +106,9 @@ int sgm_mat_matvec_add(sgm_mat A, const double *x, double *y, int where);
  *                         ellpack_matvec_t_add ellpack_matrices.f90:670-693
  * x has nrow entries, y has ncol.  The reference scatters y(node(k)) += val(k)*x(j); here an
  * explicit transpose is built on first use so that every y(i) is summed in that same order
- * (bit-identical, no atomics).  Single-GPU matrices only.                               */
+ * (bit-identical, no atomics).  On a matrix distributed over processes (sgm_csr_create_dist) the call is
+ * collective: A^T is built once as another distributed matrix (every entry travels to the rank owning its
+ * column), x = this rank's owned rows, y = its owned columns.  Not available on in-process partitions.   */
 int sgm_mat_matvec_t(sgm_mat A, const double *x, double *y, int where);
 int sgm_mat_matvec_t_add(sgm_mat A, const double *x, double *y, int where);
 /* sgm_csr_from_edges / sgm_ell_from_edges <- the assembly sequence of the reference's tests

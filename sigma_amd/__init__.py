@@ -184,14 +184,14 @@ class _Matrix:
 
     # -- linear_operator_interface.f90:199-208 ------------------------------------------
     def matvec_t(self, x, y):
-        _need(x, self.nrow, "matvec_t x"); _need(y, self.ncol, "matvec_t y")
+        _need(x, getattr(self, "n_local", self.nrow), "matvec_t x"); _need(y, getattr(self, "n_local", self.ncol), "matvec_t y")
         px, wx, _k1 = _arg(x, np.float64)
         py, wy, _k2 = _arg(y, np.float64, writable=True)
         _ck(lib().sgm_mat_matvec_t(self._h, px, py, C.c_int(_same_where(wx, wy))))
         return y
 
     def matvec_t_add(self, x, y):
-        _need(x, self.nrow, "matvec_t_add x"); _need(y, self.ncol, "matvec_t_add y")
+        _need(x, getattr(self, "n_local", self.nrow), "matvec_t_add x"); _need(y, getattr(self, "n_local", self.ncol), "matvec_t_add y")
         px, wx, _k1 = _arg(x, np.float64)
         py, wy, _k2 = _arg(y, np.float64, writable=True)
         _ck(lib().sgm_mat_matvec_t_add(self._h, px, py, C.c_int(_same_where(wx, wy))))
@@ -740,6 +740,30 @@ def generalized_lanczos(A, B, nsteps, q1, want_Q=True):
                                       C.c_void_p(T.ctypes.data), C.c_void_p(Q.ctypes.data) if want_Q else None,
                                       C.c_int(SGM_HOST)))
     return T.T.copy(), (Q.T.copy() if want_Q else None)
+
+
+def _ritz(T, Q, normalise_sign):
+    """The LAPACK tail of eigensolve (src/eigensolver.f90:174-186): dstev('V') on the tridiagonal, V = Q Z.
+    Host side (scipy's LAPACK), like the reference's."""
+    from scipy.linalg import eigh_tridiagonal
+    lam, Z = eigh_tridiagonal(T[1], T[2][:-1])
+    V = Q @ Z
+    if normalise_sign:                                   # V(:,i) = V(1,i) / |V(1,i)| * V(:,i)   (:182-184)
+        V = V * (V[0] / np.abs(V[0]))
+    return lam, V
+
+
+def eigensolve(A, n, q1):
+    """eigensolve(A, lambda, V) (src/eigensolver.f90:160-188): n Lanczos steps on the device, the
+    tridiagonal eigenproblem on the host.  Returns (lambda[n] ascending, V[nrow, n])."""
+    T, Q = lanczos(A, n, q1)
+    return _ritz(T, Q, True)
+
+
+def generalized_eigensolve(A, B, n, q1):
+    """generalized_eigensolve(A, B, lambda, V) (src/eigensolver.f90:193-208); B needs a solver set."""
+    T, Q = generalized_lanczos(A, B, n, q1)
+    return _ritz(T, Q, False)
 
 
 def halo_plan_host(n_own, col_begin, node_global):

@@ -489,6 +489,8 @@ int sgm_csr_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts, 
     A->ncol = A->nrow;
     A->nnz = nnz;
     A->comm = comm;
+    A->row_starts.assign(row_starts, row_starts + R + 1);
+    A->halo_cols = halo;
     A->parts.resize(1);
     Part &p = A->parts[0];
     if (where == SGM_DEVICE) {
@@ -582,6 +584,177 @@ int sgm_ell_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts, 
             if (hnode[(size_t)i * max_d + k] <= 0) hnode[(size_t)i * max_d + k] = (int32_t)(r0 + i + 1);
     return sgm_csr_create_dist(out, comm, row_starts, nnz, hptr.data(), hnode.data(), hval.data(), SGM_HOST);
 }
+
+}  // extern "C"
+
+namespace sgm {
+
+struct Staged {
+    double *dev = nullptr;
+    bool owned = false;
+    ~Staged() { if (owned) dfree(dev); }
+};
+int stage_in(Staged &s, const double *v, int64_t n, int where, bool copy);
+int stage_out(const Staged &s, double *v, int64_t n, int where);
+
+// A^T of a matrix distributed over processes, as ANOTHER distributed matrix: every stored entry
+// (row j, column i, value) travels once to the rank that owns column i (counts by all-gather, then one
+// grouped send/recv of three arrays per peer).  Ranks own ascending row blocks and send their entries in
+// (row, slot) order, so the receiver's concatenation in rank order followed by a STABLE sort by column
+// leaves every column's entries in global (row j, slot k) order -- the order the reference's scatter
+// y(node(k)) += val(k) x(j) adds them in (cs_matrices.f90:627-647).  The product is then a row sum of
+// A^T (chained onto y for matvec_t_add), with A^T's own halo exchange for the x entries of other ranks.
+static int ensure_transpose_dist(sgm_mat A)
+{
+    if (A->T && !A->t_stale) return SGM_OK;
+    if (A->T) { sgm_mat_destroy(A->T); A->T = nullptr; }
+    const Part &p = A->parts[0];
+    sgm_comm comm = A->comm;
+    const int R = comm->nranks, me = comm->rank;
+    const int64_t *rs = A->row_starts.data();
+    const int64_t r0 = rs[me];
+    const int32_t n = p.n;
+    hipStream_t st = g_rt.stream;
+    std::vector<int32_t> hptr((size_t)n + 1), hcol((size_t)std::max<int64_t>(p.nnz, 1));
+    std::vector<double> hval((size_t)std::max<int64_t>(p.nnz, 1));
+    SGM_HIP(hipMemcpyAsync(hptr.data(), p.rowptr, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, st));
+    if (p.nnz) {
+        SGM_HIP(hipMemcpyAsync(hcol.data(), p.col, (size_t)p.nnz * 4, hipMemcpyDeviceToHost, st));
+        SGM_HIP(hipMemcpyAsync(hval.data(), p.val, (size_t)p.nnz * 8, hipMemcpyDeviceToHost, st));
+    }
+    SGM_HIP(hipStreamSynchronize(st));
+    // entries bucketed by the owner of their column, each bucket in (row, slot) order
+    std::vector<int32_t> cnt(R, 0), off(R + 1, 0), owner((size_t)std::max<int64_t>(p.nnz, 1));
+    for (int64_t k = 0; k < p.nnz; ++k) {
+        const int32_t c = hcol[k];
+        const int64_t g0 = c < n ? r0 + c : (int64_t)A->halo_cols[c - n] - 1;        // global column, 0-based
+        const int q = c < n ? me : owner_of(rs, R, g0);
+        owner[k] = q;
+        hcol[k] = (int32_t)(g0 - rs[q]);                                           // column in its owner's numbering
+        cnt[q]++;
+    }
+    for (int q = 0; q < R; ++q) off[q + 1] = off[q] + cnt[q];
+    const size_t ns = (size_t)std::max<int64_t>(p.nnz, 1);
+    std::vector<int32_t> si(ns), sj(ns), cur(off.begin(), off.end() - 1);
+    std::vector<double> sv(ns);
+    for (int32_t jl = 0; jl < n; ++jl)
+        for (int32_t k = hptr[jl]; k < hptr[jl + 1]; ++k) {
+            const int32_t d = cur[owner[k]]++;
+            si[d] = hcol[k];
+            sj[d] = (int32_t)(r0 + jl + 1);                                        // global row, 1-based: A^T's column
+            sv[d] = hval[k];
+        }
+    // counts of every rank, then the entries
+    struct Scratch { std::vector<void *> v; ~Scratch() { for (void *q : v) dfree(q); } } sc;
+    auto dev = [&](size_t bytes, void **out) -> int {
+        char *q = nullptr;
+        SGM_TRY(dalloc(&q, bytes ? bytes : 1));
+        sc.v.push_back(q);
+        *out = q;
+        return SGM_OK;
+    };
+    int32_t *d_cnt = nullptr, *d_all = nullptr;
+    SGM_TRY(dev((size_t)R * 4, (void **)&d_cnt));
+    SGM_TRY(dev((size_t)R * R * 4, (void **)&d_all));
+    SGM_HIP(hipMemcpyAsync(d_cnt, cnt.data(), (size_t)R * 4, hipMemcpyHostToDevice, st));
+    SGM_NCCL(g_nccl.AllGather(d_cnt, d_all, (size_t)R, ncclInt32, (ncclComm_t)comm->nccl, st));
+    std::vector<int32_t> all((size_t)R * R);
+    SGM_HIP(hipMemcpyAsync(all.data(), d_all, all.size() * 4, hipMemcpyDeviceToHost, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    std::vector<int64_t> roff(R + 1, 0);
+    for (int q = 0; q < R; ++q) roff[q + 1] = roff[q] + all[(size_t)q * R + me];     // what rank q sends to me
+    const int64_t nr = roff[R];
+    if (nr >= INT32_MAX) return fail(SGM_ERR_UNSUPPORTED, "matvec_t: the transposed row block exceeds int32 entries");
+    int32_t *dsi = nullptr, *dsj = nullptr, *dri = nullptr, *drj = nullptr;
+    double *dsv = nullptr, *drv = nullptr;
+    SGM_TRY(dev(ns * 4, (void **)&dsi));
+    SGM_TRY(dev(ns * 4, (void **)&dsj));
+    SGM_TRY(dev(ns * 8, (void **)&dsv));
+    SGM_TRY(dev((size_t)nr * 4, (void **)&dri));
+    SGM_TRY(dev((size_t)nr * 4, (void **)&drj));
+    SGM_TRY(dev((size_t)nr * 8, (void **)&drv));
+    SGM_HIP(hipMemcpyAsync(dsi, si.data(), ns * 4, hipMemcpyHostToDevice, st));
+    SGM_HIP(hipMemcpyAsync(dsj, sj.data(), ns * 4, hipMemcpyHostToDevice, st));
+    SGM_HIP(hipMemcpyAsync(dsv, sv.data(), ns * 8, hipMemcpyHostToDevice, st));
+    if (R > 1) {
+        SGM_NCCL(g_nccl.GroupStart());
+        for (int q = 0; q < R; ++q) {
+            if (q == me) continue;
+            if (cnt[q]) {
+                SGM_NCCL(g_nccl.Send(dsi + off[q], (size_t)cnt[q], ncclInt32, q, (ncclComm_t)comm->nccl, st));
+                SGM_NCCL(g_nccl.Send(dsj + off[q], (size_t)cnt[q], ncclInt32, q, (ncclComm_t)comm->nccl, st));
+                SGM_NCCL(g_nccl.Send(dsv + off[q], (size_t)cnt[q], ncclFloat64, q, (ncclComm_t)comm->nccl, st));
+            }
+            const size_t rc = (size_t)(roff[q + 1] - roff[q]);
+            if (rc) {
+                SGM_NCCL(g_nccl.Recv(dri + roff[q], rc, ncclInt32, q, (ncclComm_t)comm->nccl, st));
+                SGM_NCCL(g_nccl.Recv(drj + roff[q], rc, ncclInt32, q, (ncclComm_t)comm->nccl, st));
+                SGM_NCCL(g_nccl.Recv(drv + roff[q], rc, ncclFloat64, q, (ncclComm_t)comm->nccl, st));
+            }
+        }
+        SGM_NCCL(g_nccl.GroupEnd());
+    }
+    if (cnt[me]) {
+        SGM_HIP(hipMemcpyAsync(dri + roff[me], dsi + off[me], (size_t)cnt[me] * 4, hipMemcpyDeviceToDevice, st));
+        SGM_HIP(hipMemcpyAsync(drj + roff[me], dsj + off[me], (size_t)cnt[me] * 4, hipMemcpyDeviceToDevice, st));
+        SGM_HIP(hipMemcpyAsync(drv + roff[me], dsv + off[me], (size_t)cnt[me] * 8, hipMemcpyDeviceToDevice, st));
+    }
+    std::vector<int32_t> ri((size_t)std::max<int64_t>(nr, 1)), rj((size_t)std::max<int64_t>(nr, 1));
+    std::vector<double> rv((size_t)std::max<int64_t>(nr, 1));
+    if (nr) {
+        SGM_HIP(hipMemcpyAsync(ri.data(), dri, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
+        SGM_HIP(hipMemcpyAsync(rj.data(), drj, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
+        SGM_HIP(hipMemcpyAsync(rv.data(), drv, (size_t)nr * 8, hipMemcpyDeviceToHost, st));
+    }
+    SGM_HIP(hipStreamSynchronize(st));
+    // stable counting sort by local column = row of A^T
+    std::vector<int32_t> tptr((size_t)n + 1, 0), tnode((size_t)std::max<int64_t>(nr, 1));
+    std::vector<double> tval((size_t)std::max<int64_t>(nr, 1));
+    for (int64_t e = 0; e < nr; ++e) {
+        if (ri[e] < 0 || ri[e] >= n) return fail(SGM_ERR_RCCL, "matvec_t: received an entry for column %d of %d", ri[e], n);
+        tptr[ri[e] + 1]++;
+    }
+    for (int32_t i = 0; i < n; ++i) tptr[i + 1] += tptr[i];
+    {
+        std::vector<int32_t> fill(tptr.begin(), tptr.end() - 1);
+        for (int64_t e = 0; e < nr; ++e) {
+            const int32_t d = fill[ri[e]]++;
+            tnode[d] = rj[e];
+            tval[d] = rv[e];
+        }
+    }
+    for (auto &v : tptr) v += 1;                                                  // 1-based like the reference's ptr
+    sgm_mat T = nullptr;
+    SGM_TRY(sgm_csr_create_dist(&T, comm, rs, nr, tptr.data(), tnode.data(), tval.data(), SGM_HOST));
+    if (!T->parts[0].xext) {
+        const int rc = dalloc(&T->parts[0].xext, (size_t)T->parts[0].xlen() + 2);
+        if (rc != SGM_OK) { sgm_mat_destroy(T); return rc; }
+    }
+    A->T = T;
+    A->t_stale = false;
+    return SGM_OK;
+}
+
+int matvec_t_dist(sgm_mat A, const double *x, double *y, int where, bool add)
+{
+    if (A->fmt != SGM_FMT_CSR) return fail(SGM_ERR_UNSUPPORTED, "matvec_t: CSR matrices only when distributed");
+    SGM_TRY(ensure_transpose_dist(A));
+    sgm_mat T = A->T;
+    Part &pt = T->parts[0];
+    const hipMemcpyKind kind = where == SGM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    SGM_HIP(hipMemcpyAsync(pt.xext, x, (size_t)pt.n * 8, kind, g_rt.stream));     // owned rows; A^T's halo is filled by the exchange
+    Staged sy;
+    SGM_TRY(stage_in(sy, y, pt.n, where, add));
+    const double *xs[1] = {pt.xext};
+    double *ys[1] = {sy.dev};
+    SGM_TRY(spmv_parts(T, xs, ys, add, nullptr, nullptr, nullptr, 0x7fffffff, /*chain=*/add));
+    SGM_TRY(stage_out(sy, y, pt.n, where));
+    return finish();
+}
+
+}  // namespace sgm
+
+extern "C" {
 
 /* read back the exchange plan of a distributed / partitioned matrix (parity checks): for local
  * part `part`, neighbour `k`: peer, counts, offset and (optionally) the send list (0-based). */

@@ -160,6 +160,8 @@ struct sgm_mat_s {
     int64_t nnz = 0;               // global (local sum when distributed)
     std::vector<sgm::Part> parts;  // 1 unless created with sgm_csr_create_partitioned
     sgm_comm comm = nullptr;       // RCCL communicator when distributed over processes
+    std::vector<int64_t> row_starts;   // distributed: the row partition (nranks+1, 0-based)
+    std::vector<int32_t> halo_cols;    // distributed: global 1-based column of every halo slot
     bool distributed() const { return comm != nullptr || parts.size() > 1; }
     // explicit transpose for matvec_t (built on first use; rows sorted by (source row, slot) so
     // that every y(i) receives its terms in the reference's order)
@@ -173,6 +175,8 @@ struct sgm_mat_s {
 
 namespace sgm {
 
+// y = [y +] A^T x on a matrix distributed over processes (sgm_dist.hip): x = owned rows, y = owned columns
+int matvec_t_dist(sgm_mat A, const double *x, double *y, int where, bool add);
 // exchange the halo part of an extended vector set (one pointer per local part)
 int halo_exchange(sgm_mat A, double *const *xext, hipStream_t st);
 // sum `count` scalar slots across parts / ranks (in place, every part gets the total)

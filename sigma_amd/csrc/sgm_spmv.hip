@@ -1642,6 +1642,7 @@ static int matvec_t_impl(sgm_mat A, const double *x, double *y, int where, bool 
 {
     SGM_TRY(require_init());
     if (!A || !x || !y) return fail(SGM_ERR_BAD_ARG, "matvec_t: null argument");
+    if (A->comm) return matvec_t_dist(A, x, y, where, add);
     if (A->fmt == SGM_FMT_COMPOSITE) {
         // composite_matvec_t_add (sparse_matrix_composites.f90:1104-1127): column blocks outer
         Staged sx, sy;

@@ -106,6 +106,20 @@ def run(rank, world, port, case, res):
         H.matvec_add(xe, ya)
         assert np.array_equal(ya, A.matvec_add(x, y0.copy())[r0:r1])
 
+        # ---- transpose products: A^T built once as another distributed matrix (entries travel to the owner of
+        #      their column); every y(i) sums the reference scatter's terms in the reference's order
+        xt = np.random.RandomState(11).standard_normal(n)
+        t_ref = A.matvec_t(xt)
+        t = np.full(n_own, -2.0)
+        H.matvec_t(xt[r0:r1].copy(), t)
+        assert np.array_equal(t, t_ref[r0:r1]), "distributed matvec_t differs from csc_matvec_add"
+        ta = y0[r0:r1].copy()
+        H.matvec_t_add(xt[r0:r1].copy(), ta)
+        assert np.array_equal(ta, A.matvec_t_add(xt, y0.copy())[r0:r1])
+        td = torch.zeros(n_own, dtype=torch.float64, device=dev)
+        H.matvec_t(torch.from_numpy(xt[r0:r1].copy()).to(dev), td)
+        assert np.array_equal(td.cpu().numpy(), t_ref[r0:r1])
+
         # ---- the same matrix created from DEVICE arrays (what bench.py --workload c5 does)
         H2 = sg.dist_csr_matrix(comm, starts, torch.from_numpy(lptr).to(dev), torch.from_numpy(lnode_g).to(dev),
                                 torch.from_numpy(lval).to(dev))

@@ -117,9 +117,15 @@ ncclResult_t run_ops()
     const double t0 = now();
     for (;;) {
         bool all = true, moved = false;
-        for (auto &o : g_ops) {
+        for (size_t oi = 0; oi < g_ops.size(); ++oi) {
+            Op &o = g_ops[oi];
             if (o.done == o.bytes) continue;
             all = false;
+            // several messages to / from one peer share a ring: they move strictly in issue order
+            bool earlier = false;
+            for (size_t e = 0; e < oi && !earlier; ++e)
+                earlier = g_ops[e].send == o.send && g_ops[e].peer == o.peer && g_ops[e].c == o.c && g_ops[e].done < g_ops[e].bytes;
+            if (earlier) continue;
             Ring &r = o.send ? o.c->ring(o.c->rank, o.peer) : o.c->ring(o.peer, o.c->rank);
             const uint64_t head = r.head.load(std::memory_order_acquire), tail = r.tail.load(std::memory_order_acquire);
             size_t chunk = o.send ? kRing - (size_t)(head - tail) : (size_t)(head - tail);
