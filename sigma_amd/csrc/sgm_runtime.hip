@@ -65,6 +65,7 @@ int sgm_init(int device)
     g_rt.ready = true;
     if (const char *e = getenv("SGM_CSR_SLICED")) g_opt.csr_sliced = atoi(e);      // tuning aid (see sgm_set_option)
     if (const char *e = getenv("SGM_GMRES_CGS2")) g_opt.gmres_cgs2 = atoi(e);
+    if (const char *e = getenv("SGM_ILDU_STRIPS")) g_opt.ildu_strips = atoi(e);
     return SGM_OK;
 }
 
@@ -109,6 +110,7 @@ int sgm_set_option(const char *name, int value)
     if (!strcmp(name, "ell_colblock")) { g_opt.ell_colblock = value; return SGM_OK; }
     if (!strcmp(name, "ell_colblock_cols")) { g_opt.ell_colblock_cols = std::min(16384, std::max(2, value)) & ~1; return SGM_OK; }
     if (!strcmp(name, "ell_colblock_chunks")) { g_opt.ell_colblock_chunks = std::max(1, value); return SGM_OK; }
+    if (!strcmp(name, "ildu_strips")) { g_opt.ildu_strips = value; return SGM_OK; }
     if (!strcmp(name, "gmres_cgs2")) { g_opt.gmres_cgs2 = value; return SGM_OK; }
     return fail(SGM_ERR_BAD_ARG, "sgm_set_option: unknown option '%s'", name);
 }

@@ -36,6 +36,7 @@ int stage_in(Staged &s, const double *v, int64_t n, int where, bool copy);
 int stage_out(const Staged &s, double *v, int64_t n, int where);
 int pc_apply_parts(sgm_pc pc, sgm_mat A, const double *const *r, double *const *z, const int *const *flags);
 int pc_kind(sgm_pc pc);
+bool pc_apply_is_short(sgm_pc pc);
 const double *pc_idiag(sgm_pc pc, size_t part);
 
 // ------------------------------------------------------------------ generic fused kernel
@@ -923,7 +924,7 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
 
     int64_t k = 0;
     int flag = 0; int64_t iters = 0; double res = 0.0;
-    const int64_t batch_max = pk == SGM_PC_ILDU0 ? 1 : 16;
+    const int64_t batch_max = pc_apply_is_short(pc) ? 16 : 1;
     for (;;) {
         int64_t batch = batch_max;
         if (s->max_iter > 0) batch = std::min<int64_t>(batch, s->max_iter - k);
@@ -1020,7 +1021,7 @@ int run_bicgstab(sgm_solver s, sgm_mat A, double *const *x, const double *const 
 
     int64_t k = 0;
     int flag = 0; int64_t iters = 0; double res = 0.0;
-    const int64_t batch_max = pk == SGM_PC_ILDU0 ? 1 : 16;
+    const int64_t batch_max = pc_apply_is_short(pc) ? 16 : 1;
     auto enqueue_test = [&](int cur) {   // loop test only (no p update): used after the last batch
         for (size_t ip = 0; ip < P; ++ip)
             hipLaunchKernelGGL(k_check, dim3(1), dim3(kBlock), 0, g_rt.stream, ref(s, ip, B_RR + cur), s->tolerance,

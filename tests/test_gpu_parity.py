@@ -941,6 +941,82 @@ def test_ildu_ring_walker_every_width_class_vs_oracle(orc, nx, ny):
     assert np.array_equal(z, ref.solve(b2))
 
 
+def _grid_like_matrix(n, w, order, seed, holes=0.0):
+    """Diagonally dominant matrix whose rows touch r-w, r-1, r, r+1, r+w (no r-1 / r+1 across a grid line), rows
+    stored in the given slot order; `holes` removes a fraction of the off-diagonal pairs symmetrically."""
+    rs = np.random.RandomState(seed)
+    offs_by_order = {"sw": (-w, -1, 0, 1, w), "ws": (-1, -w, 0, w, 1)}
+    keep_s = rs.rand(n) >= holes            # pair (r, r-w)
+    keep_w = rs.rand(n) >= holes            # pair (r, r-1)
+    ei, ej = [], []
+    for r in range(n):
+        mixed = order == "mixed"
+        offs = offs_by_order["sw" if (not mixed and order == "sw") or (mixed and r % 3) else "ws"]
+        for o in offs:
+            c = r + o
+            if c < 0 or c >= n:
+                continue
+            if o == -1 and (r % w == 0 or not keep_w[r]):
+                continue
+            if o == 1 and ((r + 1) % w == 0 or not keep_w[r + 1]):
+                continue
+            if o == -w and not keep_s[r]:
+                continue
+            if o == w and not keep_s[r + w]:
+                continue
+            ei.append(r + 1); ej.append(c + 1)
+    ei, ej = np.array(ei, np.int32), np.array(ej, np.int32)
+    lo, hi = np.minimum(ei, ej).astype(np.int64), np.maximum(ei, ej).astype(np.int64)
+    sym = ((lo * 2654435761 + hi * 40503) % 1000) / 1000.0            # the same value for (r, c) and (c, r): SPD by dominance
+    ev = np.where(ei == ej, 4.5 + sym, -0.5 - 0.5 * sym)
+    return ei, ej, ev
+
+
+@pytest.mark.parametrize("n,w,order,holes", [(64 * 70, 70, "sw", 0.0), (100 * 131 + 57, 131, "ws", 0.0), (257 * 300, 257, "mixed", 0.1),
+                                            (640 * 64, 640, "sw", 0.3)])
+def test_ildu_strip_pipeline_vs_level_walkers_and_oracle(orc, n, w, order, holes):
+    """The strip-pipelined triangular solves (one launch per sweep, neighbouring strips handing edge values to each
+    other inside it) against the level-scheduled walkers and the oracle, bit for bit: strips narrower than a wave,
+    a partial last grid line, both stored orders of a row's two terms and rows mixing them, missing terms."""
+    ei, ej, ev = _grid_like_matrix(n, w, order, seed=n % 97, holes=holes)
+    A = orc.CsrMatrix.from_edges(n, n, ei, ej, ev)
+    H = hip_from_oracle(A)
+    opc = orc.Ildu(A)
+    pc = sg.ldu()
+    pc.setup(H)
+    strips = pc.get("strips", np.int32)
+    assert strips[0] == (w + 63) // 64 and strips[1] >= (n + w - 1) // w + 63, strips
+    assert (strips[2], strips[3]) == {"sw": (0, 1), "ws": (1, 0), "mixed": (2, 2)}[order]    # U sees the same row order from the other side
+    rs = np.random.RandomState(5)
+    for trial in range(3):
+        r = rs.standard_normal(n)
+        z = np.zeros(n)
+        pc.solve(H, z, r)
+        assert np.array_equal(z, opc.solve(r)), trial
+    sg.set_option("ildu_strips", 0)
+    try:
+        assert pc.get("strips", np.int32)[0] == 0
+        z2 = np.zeros(n)
+        pc.solve(H, z2, r)
+        assert np.array_equal(z2, z)
+    finally:
+        sg.set_option("ildu_strips", 1)
+    # inside a solver (16 iterations queued per look at the stop flag) and after a value update
+    b = P.test_vector(n)
+    ur, itr, _, _ = orc.cg(A, b, tol=1e-12, pc=opc)
+    s = sg.cg(1e-12)
+    s.setup(H)
+    u = np.zeros(n)
+    s.solve(H, u, b, pc)
+    assert abs(s.iterations - itr) <= 1 and np.abs(u - ur).max() / np.abs(ur).max() <= 1e-11
+    H.set_values(A.val * 1.25)
+    pc.setup(H)
+    A2 = orc.CsrMatrix(n, n, A.ptr, A.node, A.val * 1.25)
+    z = np.zeros(n)
+    pc.solve(H, z, r)
+    assert np.array_equal(z, orc.Ildu(A2).solve(r))
+
+
 @pytest.mark.parametrize("flavour", ["banded", "blocks", "arrowhead", "sparse_random"])
 def test_randomised_ildu_factor_and_apply_vs_oracle(orc, flavour):
     """Seeded random structurally-symmetric, diagonally dominant matrices: long narrow dependency
