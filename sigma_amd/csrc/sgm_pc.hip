@@ -528,6 +528,7 @@ __global__ __launch_bounds__(192) void k_trsv_strip(int32_t NI, int32_t S, const
         };
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j) fetch(j, j);
+        const long long clk0 = wall_clock64();
         double prev = 0.0;
         double eE[CH];                       // lane 0's left neighbours of the current chunk (read out of the ring at its start)
         double *ow = &out_scratch[lane];     // where this lane's results of the current chunk go in LDS
@@ -577,6 +578,12 @@ __global__ __launch_bounds__(192) void k_trsv_strip(int32_t NI, int32_t S, const
                     __hip_atomic_store(&out_count, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
+        // diagnostics (sgm_pc_get "strip_clocks"): start / end of this strip's chain in the two unused tail slots of its edge row
+        if (lane == 0) {
+            long long *tail = reinterpret_cast<long long *>(edge + (int64_t)ib * (S + 64) + S + 62);
+            tail[0] = clk0;
+            tail[1] = wall_clock64();
+        }
         return;
     }
     // ---- helper waves: wave 1 forwards this strip's edge values, wave 2 fetches the left strip's
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(192) void k_trsv_strip(int32_t NI, int32_t S, const
                 spins = 0;
                 continue;
             }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(4);            // (the helpers share the CU's LDS and memory pipeline with the chain wave: poll gently)
             if (++spins > kStripSpinLimit || __hip_atomic_load(&lds_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
                 if (lane == 0) __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return;
@@ -612,7 +619,9 @@ __global__ __launch_bounds__(192) void k_trsv_strip(int32_t NI, int32_t S, const
     int32_t got = 0;                 // steps of left-edge values copied into the ring; lane 0 at step t needs the left strip's step t + 63
     while (got < S) {
         // never more than a ring ahead of what the chain has consumed (it has produced out_count steps)
-        const int32_t room = __hip_atomic_load(&out_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + kStripRing - 2 * CH;
+        const int32_t done = __hip_atomic_load(&out_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int32_t room = done + kStripRing - 2 * CH;
+        if (got - done > 128) { __builtin_amdgcn_s_sleep(32); continue; }       // comfortably ahead of the chain: stay out of its way
         if (got < room) {
             int32_t left_known = __hip_atomic_load(progress + ib - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             left_known = __builtin_amdgcn_readfirstlane(left_known);
@@ -1021,8 +1030,15 @@ void trsv_grid(const GridTri &G, double *xp, const int *flag)
     static const int xcd_env = getenv("SGM_STRIP_XCD") ? atoi(getenv("SGM_STRIP_XCD")) : -1;
     static const int depth = getenv("SGM_STRIP_DEPTH") ? atoi(getenv("SGM_STRIP_DEPTH")) : kStripDepth;
     const int one_xcd = xcd_env > 0 ? 1 : 0;             // (measured: 0.83 vs 0.87 ms at 1000^2, 2.06 vs 1.85 at 2000^2: within noise, off)
-#define STRIP_K(DD, OO) hipLaunchKernelGGL((k_trsv_strip<DD, kStripChunk, OO>), dim3(one_xcd ? G.NI * 8 : G.NI), dim3(192), 0, st, G.NI, G.S, \
-                                          (const StripRec *)G.rec, xp, G.edge, G.progress, flag, one_xcd)
+    // 96 KiB of (unused) dynamic LDS per workgroup: at most ONE strip per CU, so that no two chain waves share a SIMD
+    static const size_t lds_pad = getenv("SGM_STRIP_LDS") ? (size_t)atoi(getenv("SGM_STRIP_LDS")) : (size_t)96 * 1024;
+#define STRIP_K(DD, OO)                                                                                                          \
+    do {                                                                                                                         \
+        static bool attr = false;                                                                                                \
+        if (!attr) { (void)hipFuncSetAttribute((const void *)k_trsv_strip<DD, kStripChunk, OO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pad); attr = true; } \
+        hipLaunchKernelGGL((k_trsv_strip<DD, kStripChunk, OO>), dim3(one_xcd ? G.NI * 8 : G.NI), dim3(192), lds_pad, st, G.NI, G.S, \
+                           (const StripRec *)G.rec, xp, G.edge, G.progress, flag, one_xcd);                                      \
+    } while (0)
     if (depth >= 32) { if (G.order == 0) STRIP_K(32, 0); else if (G.order == 1) STRIP_K(32, 1); else STRIP_K(32, 2); }
     else { if (G.order == 0) STRIP_K(16, 0); else if (G.order == 1) STRIP_K(16, 1); else STRIP_K(16, 2); }
 #undef STRIP_K
@@ -1415,6 +1431,14 @@ int sgm_pc_get(sgm_pc pc, const char *name, void *out, size_t bytes, size_t *nee
             sv[0] = on ? S->gL.NI : 0; sv[1] = on ? S->gL.S : 0; sv[2] = on ? S->gL.order : 0; sv[3] = on ? S->gU.order : 0;
             src = sv; sz = sizeof sv;
         }
+        else if (nm == "strip_clocks" && S->grid_ok) {     // per strip of the L sweep: chain start, end (100 MHz ticks)
+            static std::vector<long long> ck;
+            ck.assign((size_t)2 * S->gL.NI, 0);
+            SGM_HIP(hipStreamSynchronize(g_rt.stream));
+            for (int32_t i = 0; i < S->gL.NI; ++i)
+                SGM_HIP(hipMemcpy(&ck[2 * i], S->gL.edge + (int64_t)i * (S->gL.S + 64) + S->gL.S + 62, 16, hipMemcpyDeviceToHost));
+            src = ck.data(); sz = ck.size() * 8;
+        }
         else if (nm == "levels") {
             static int32_t lv[2];
             lv[0] = (int32_t)S->L.level_ptr.size() - 1;
@@ -1422,7 +1446,7 @@ int sgm_pc_get(sgm_pc pc, const char *name, void *out, size_t bytes, size_t *nee
             src = lv; sz = sizeof lv;
         }
     }
-    const bool known = nm == "strips" || nm == "idiag" || nm == "Lptr" || nm == "Lnode" || nm == "Lval" || nm == "Uptr" ||
+    const bool known = nm == "strips" || nm == "strip_clocks" || nm == "idiag" || nm == "Lptr" || nm == "Lnode" || nm == "Lval" || nm == "Uptr" ||
                        nm == "Unode" || nm == "Uval" || nm == "D" || nm == "levels";
     if (!known || (!src && sz)) return fail(SGM_ERR_BAD_ARG, "sgm_pc_get: unknown array '%s'", name);
     if (!src) src = &kEmpty;
