@@ -198,13 +198,14 @@ __global__ __launch_bounds__(TPB) void k_ellcb_mul(int32_t ncol, int32_t cb, int
 }
 
 // ------------------------------------------------------------------------------ phase 2
-// TPB = R threads; a workgroup walks tiles t = blockIdx.x, + gridDim.x, ...
+// A workgroup walks tiles t = blockIdx.x, + gridDim.x, ...
 // Copy of the tile's nb runs into the LDS image: every wave takes a contiguous share of the runs,
 // fetches their descriptors 64 at a time with ONE coalesced load (a lane per run) and then moves two
 // runs per wave instruction (a half-wave each; runs average 27 entries), eight instructions in flight.
 // The 2-byte image positions of the lane's own row are requested before the copy, so their latency
 // hides behind it.
-template <int TPB, int MAXD, bool ADD, bool DOT_W, bool DOT_YY>
+// R rows per tile, TPB = CM * R threads: all TPB / 64 waves copy runs, the first R threads own the rows.
+template <int R, int TPB, int MAXD, bool ADD, bool DOT_W, bool DOT_YY>
 __global__ __launch_bounds__(TPB) void k_ellcb_sum(int32_t n, int32_t max_d, int32_t nb, int32_t ntiles,
                                                    const int2 *__restrict__ fdesc, const uint16_t *__restrict__ lpos,
                                                    const double *__restrict__ P, double *__restrict__ y,
@@ -221,8 +222,8 @@ __global__ __launch_bounds__(TPB) void k_ellcb_sum(int32_t n, int32_t max_d, int
     const int32_t per = (nb + NW - 1) / NW, bw0 = wave * per, bw1 = min(nb, bw0 + per);
     double dwy = 0.0, dyy = 0.0;
     for (int32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int32_t i = t * TPB + threadIdx.x;
-        const bool live = i < n;
+        const int32_t i = t * R + (int32_t)threadIdx.x;
+        const bool live = (int)threadIdx.x < R && i < n;
         // positions of this lane's row (slots 0..MAXD-1 in registers; longer rows re-read them later)
         uint16_t pz[MAXD];
 #pragma unroll
@@ -396,15 +397,16 @@ int build_ell_colblock(Part &p)
     return SGM_OK;
 }
 
-template <int TPB, bool ADD>
+template <int R, bool ADD>
 static void launch_sum(const Part &p, int grid, double *y, const double *w, double *pwy, double *pyy, const int *flag, int gen,
                        int chain)
 {
     hipStream_t st = g_rt.stream;
     const size_t lds = (size_t)p.cb_R * p.max_d * 8;
-    constexpr int MAXD = 8192 / TPB;                 // the longest row a tile of TPB rows allows (R * max_d <= 8192)
+    constexpr int MAXD = 8192 / R;                   // the longest row a tile of R rows allows (R * max_d <= 8192)
+    constexpr int TPB = 2 * R;                       // twice as many waves copy runs as there are rows (C4: 696 -> see DESIGN)
 #define L(DW, DY)                                                                                                     \
-    hipLaunchKernelGGL((k_ellcb_sum<TPB, MAXD, ADD, DW, DY>), dim3(grid), dim3(TPB), lds, st, p.n, p.max_d, p.cb_nb, p.cb_ntiles, \
+    hipLaunchKernelGGL((k_ellcb_sum<R, TPB, MAXD, ADD, DW, DY>), dim3(grid), dim3(TPB), lds, st, p.n, p.max_d, p.cb_nb, p.cb_ntiles, \
                        (const int2 *)p.cb_fdesc, (const uint16_t *)p.cb_lpos, (const double *)p.cb_P, y, w, pwy, pyy, flag, \
                        gen, chain)
     if (w && pyy) L(true, true);
