@@ -99,7 +99,10 @@ __global__ void k_csr_to_ell(int32_t nrow, int32_t max_d, const int32_t *__restr
 __global__ void k_max_deg(int32_t nrow, const int32_t *__restrict__ ptr, int32_t *out)
 {
     int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < nrow) atomicMax(out, ptr[r + 1] - ptr[r]);
+    int32_t d = r < nrow ? ptr[r + 1] - ptr[r] : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) d = max(d, __shfl_xor(d, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, d);          // one atomic per wave, not per row
 }
 
 // device CSR arrays (1-based, exactly what cs_graph_build + set_value produce) from an edge list

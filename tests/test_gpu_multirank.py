@@ -99,3 +99,22 @@ def test_bench_gpus_2_typed_plainly_spawns_its_ranks(tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["roofline"]["frac"] <= 1.0
     assert out["cg"]["iterations"] == 20 and out["c5_strong_scaling"]["cg_iterations"] == 10
     assert out["config"]["parallelism"] == "row-partition x2"
+
+
+def test_bench_under_torch_distributed_run_like_the_driver_launches_it(tmp_path):
+    """The driver's N > 1 launch line: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` (every process is a rank; nothing is spawned by bench.py).
+    Both ranks on the one GPU of the box over the host-staged transport, small grids."""
+    env = dict(os.environ)
+    env.update({"SGM_RCCL_LIB": MOCK, "SGM_BENCH_SAME_GPU": "1"})
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps",
+                        "2", "--warmup", "1", "--spmv-per-step", "4", "--nx", "300", "--ny", "200", "--cg-steps", "20",
+                        "--c5-edge", "40", "--c5-cg-steps", "10", "--no-cpu"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, p.stdout[-2000:]
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["cg"]["iterations"] == 20 and out["c5_strong_scaling"]["cg_iterations"] == 10

@@ -1507,7 +1507,7 @@ def test_lanczos_and_generalized_lanczos_vs_reference_fixture(golden, orc, name)
 
 def test_eigensolve_and_generalized_eigensolve_ritz_pairs():
     """eigensolve / generalized_eigensolve (eigensolver.f90:160-208): Lanczos on the device + the
-    LAPACK tail on the host.  The extreme Ritz pairs of 60 steps are converged eigenpairs:
+    LAPACK tail on the host.  The extreme Ritz pairs of 200 steps (n = 600) are converged eigenpairs:
     A v = lambda v (resp. A v = lambda B v) to 1e-8, first components positive after eigensolve's
     sign normalisation, Ritz values inside the analytic spectrum of the 5-point Laplacian."""
     nx, ny = 30, 20
@@ -1515,11 +1515,11 @@ def test_eigensolve_and_generalized_eigensolve_ritz_pairs():
     ptr, node, val = P.poisson2d_csr(nx, ny)
     A = sg.csr_matrix(n, n, ptr, node, val)
     q1 = np.random.RandomState(2).random_sample(n) * 2 - 1
-    lam, V = sg.eigensolve(A, 60, q1)
+    lam, V = sg.eigensolve(A, 200, q1)
     assert np.all(np.diff(lam) >= 0) and np.all(V[0] > 0)
     exact = np.sort([4 - 2 * np.cos(np.pi * i / (nx + 1)) - 2 * np.cos(np.pi * j / (ny + 1))
                      for i in range(1, nx + 1) for j in range(1, ny + 1)])
-    assert abs(lam[0] - exact[0]) <= 1e-8 and abs(lam[-1] - exact[-1]) <= 1e-8
+    assert abs(lam[0] - exact[0]) <= 1e-7 and abs(lam[-1] - exact[-1]) <= 1e-7
     for k in (0, -1):
         y = np.zeros(n)
         A.matvec(np.ascontiguousarray(V[:, k]), y)
@@ -1527,7 +1527,7 @@ def test_eigensolve_and_generalized_eigensolve_ritz_pairs():
     rows = np.repeat(np.arange(1, n + 1), np.diff(ptr))
     B = sg.csr_matrix(n, n, ptr, node, np.where(rows == node, 1.0 + (rows % 7) / 16.0, -1.0 / 16.0))
     B.set_solver(sg.cg(1e-14))
-    lam, V = sg.generalized_eigensolve(A, B, 60, q1)
+    lam, V = sg.generalized_eigensolve(A, B, 120, q1)
     for k in (0, -1):
         y, z = np.zeros(n), np.zeros(n)
         A.matvec(np.ascontiguousarray(V[:, k]), y)
