@@ -54,6 +54,31 @@ def build(force=False):
     return LIB_PATH
 
 
+def _share_torch_hip_runtime():
+    """One HIP/HSA runtime per process.  A torch wheel carries its own libamdhip64.so.7 and a
+    libhsa-runtime64.so its other libraries ask for by a name the system copy does not answer to,
+    so `import torch` AFTER this library has pulled in /opt/rocm's runtime starts a second HSA
+    runtime and torch then finds no GPU.  When torch is installed but not yet imported, load its
+    libamdhip64 first; the dynamic linker then hands the same copy to libsigma_hip.so (same
+    soname), exactly as when torch was imported first.  SGM_HIP_RUNTIME=system skips this."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("SGM_HIP_RUNTIME", "") == "system":
+        return
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """The loaded C-ABI library.  Fails loudly when the HIP extension is missing."""
     global _lib
@@ -61,6 +86,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise SigmaError(-1, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                  "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.sgm_last_error.restype = C.c_char_p
         _lib = L

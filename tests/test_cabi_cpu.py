@@ -137,3 +137,20 @@ def test_integration_md_quotes_the_compiled_binding_verbatim():
     src = open(os.path.join(ROOT, "oracle", "hip_binding.f90")).read()
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert src.strip() in doc, "INTEGRATION.md must carry oracle/hip_binding.f90 verbatim (tools/sync_integration_md.py)"
+
+
+def test_one_hip_runtime_per_process_whichever_side_loads_first():
+    """Loading libsigma_hip.so before `import torch` must not leave two HIP/HSA runtimes mapped
+    (the second one finds no GPU: torch then reports "No HIP GPUs are available")."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import sigma_amd as sg; sg.lib(); import torch\n"
+            "libs = sorted(set(l.split()[-1] for l in open('/proc/self/maps')\n"
+            "              if 'libamdhip64' in l or 'libhsa-runtime64' in l))\n"
+            "print('\\n'.join(libs))\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-400:]
+    libs = out.stdout.split()
+    assert sum("libamdhip64" in l for l in libs) == 1, libs
+    assert sum("libhsa-runtime64" in l for l in libs) == 1, libs

@@ -6,6 +6,8 @@ Bars: index work / stored values / matvec / preconditioner factors and applies a
 BIT-EXACT; Krylov solutions within 1e-12 relative of the reference's with the same
 iteration count (+-1; dot products are summed in a different order than the compiler's
 dot_product, which is the only source of difference)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1982,3 +1984,26 @@ def test_reference_side_binding_runs_the_references_own_tests():
     assert "bit-identical to the reference" in p.stdout and "all passed" in p.stdout
     its = [int(ln.split("iterations")[1].split()[0]) for ln in p.stdout.splitlines() if "reference cg() on hip matrix" in ln]
     assert its == [64]          # the reference's own count on this problem
+
+
+@pytest.mark.gpu
+def test_torch_imported_after_the_library_still_sees_the_gpu():
+    """A fresh process that uses the library first and imports torch afterwards (the order a
+    numpy-only caller that later hands over device tensors would hit)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np, sigma_amd as sg\n"
+            "from sigma_amd import problems as P\n"
+            "sg.init(0)\n"
+            "ptr, node, val = P.poisson2d_csr(40, 30)\n"
+            "A = sg.csr_matrix(1200, 1200, ptr, node, val)\n"
+            "import torch\n"
+            "x = torch.ones(1200, dtype=torch.float64, device='cuda')\n"
+            "y = torch.zeros(1200, dtype=torch.float64, device='cuda')\n"
+            "A.matvec(x, y); sg.synchronize()\n"
+            "print(float(y.abs().sum()))\n" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-600:]
+    assert float(out.stdout.split()[-1]) > 0.0

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "eigensolve or lanczos" 2>&1 | tail -15
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -m gpu -k "$1" 2>&1 | tail -8
