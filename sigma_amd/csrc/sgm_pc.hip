@@ -117,6 +117,9 @@ struct IlduState {
     double *gxL = nullptr, *gxU = nullptr, *gDp = nullptr;
     int32_t *gmapLU = nullptr;
     bool grid_ok = false;                                   // the strip path reproduced the level-scheduled apply at setup
+    // slab-pipeline path (3-D grid factors, sgm_trsv3.hip); slab_ok: it reproduced the level-scheduled apply at setup
+    Slab3 *slab = nullptr;
+    bool slab_ok = false;
 };
 
 struct sgm_pc_s {
@@ -648,20 +651,24 @@ __global__ __launch_bounds__(192) void k_trsv_strip(int32_t NI, int32_t S, const
     }
 }
 // position-space gather / hand-over / scatter of the strip path (padding positions hold 0)
+// (gather and transition also clear the progress words of the sweep that follows)
 __global__ void k_grid_gather(int64_t np, StripRec *__restrict__ rec, const double *__restrict__ src,
-                              const int32_t *__restrict__ row, const int *flag)
+                              const int32_t *__restrict__ row, int32_t *__restrict__ progress, int32_t nprog, const int *flag)
 {
     if (flag && *flag) return;
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q = p; q < nprog; q += stride) progress[q] = 0;
     for (; p < np; p += stride) { const int32_t r = row[p]; rec[p].rhs = r >= 0 ? src[r] : 0.0; }
 }
 __global__ void k_grid_transition(int64_t np, StripRec *__restrict__ recU, const double *__restrict__ xpL,
-                                  const int32_t *__restrict__ mapLU, const double *__restrict__ Dp, const int *flag)
+                                  const int32_t *__restrict__ mapLU, const double *__restrict__ Dp, int32_t *__restrict__ progress,
+                                  int32_t nprog, const int *flag)
 {
     if (flag && *flag) return;
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q = p; q < nprog; q += stride) progress[q] = 0;
     for (; p < np; p += stride) { const int32_t q = mapLU[p]; recU[p].rhs = q >= 0 ? xpL[q] / Dp[p] : 0.0; }   // x = x / D
 }
 __global__ void k_grid_scatter(int64_t np, double *__restrict__ dst, const double *__restrict__ xp,
@@ -772,6 +779,7 @@ void free_ildu(IlduState &S)
     dfree(S.D); dfree(S.xpL); dfree(S.xpU); dfree(S.Dp); dfree(S.mapLU);
     free_grid(S.gL); free_grid(S.gU);
     dfree(S.gxL); dfree(S.gxU); dfree(S.gDp); dfree(S.gmapLU);
+    slab3_free(S.slab);
     S = IlduState();
 }
 
@@ -1026,7 +1034,6 @@ int refresh_grid_values(GridTri &G, const std::vector<double> &val)
 void trsv_grid(const GridTri &G, double *xp, const int *flag)
 {
     hipStream_t st = g_rt.stream;
-    (void)hipMemsetAsync(G.progress, 0, ((size_t)G.NI + 1) * 4, st);
     static const int xcd_env = getenv("SGM_STRIP_XCD") ? atoi(getenv("SGM_STRIP_XCD")) : -1;
     static const int depth = getenv("SGM_STRIP_DEPTH") ? atoi(getenv("SGM_STRIP_DEPTH")) : kStripDepth;
     const int one_xcd = xcd_env > 0 ? 1 : 0;             // (measured: 0.83 vs 0.87 ms at 1000^2, 2.06 vs 1.85 at 2000^2: within noise, off)
@@ -1049,10 +1056,11 @@ void apply_grid(const IlduState *S, const double *r, double *z, const int *flag)
 {
     hipStream_t st = g_rt.stream;
     const int gl = vec_grid(S->gL.NP), gu = vec_grid(S->gU.NP);
-    hipLaunchKernelGGL(k_grid_gather, dim3(gl), dim3(kBlock), 0, st, S->gL.NP, S->gL.rec, r, (const int32_t *)S->gL.row, flag);
+    hipLaunchKernelGGL(k_grid_gather, dim3(gl), dim3(kBlock), 0, st, S->gL.NP, S->gL.rec, r, (const int32_t *)S->gL.row, S->gL.progress,
+                       S->gL.NI + 1, flag);
     trsv_grid(S->gL, S->gxL, flag);                                       // (I+L) x = b
     hipLaunchKernelGGL(k_grid_transition, dim3(gu), dim3(kBlock), 0, st, S->gU.NP, S->gU.rec, (const double *)S->gxL,
-                       (const int32_t *)S->gmapLU, (const double *)S->gDp, flag);       // x = x / D
+                       (const int32_t *)S->gmapLU, (const double *)S->gDp, S->gU.progress, S->gU.NI + 1, flag);       // x = x / D
     trsv_grid(S->gU, S->gxU, flag);                                       // (I+U) x = x
     hipLaunchKernelGGL(k_grid_scatter, dim3(gu), dim3(kBlock), 0, st, S->gU.NP, z, (const double *)S->gxU,
                        (const int32_t *)S->gU.row, flag);
@@ -1170,7 +1178,7 @@ bool pc_apply_is_short(sgm_pc pc)
     if (!pc || pc->kind == SGM_PC_JACOBI) return true;
     if (!g_opt.ildu_strips) return false;
     for (const auto &S : pc->ild)
-        if (!S.grid_ok) return false;
+        if (!S.grid_ok && !S.slab_ok) return false;
     return true;
 }
 const double *pc_idiag(sgm_pc pc, size_t part) { return pc->parts[part].idiag; }
@@ -1190,6 +1198,10 @@ int pc_apply_parts(sgm_pc pc, sgm_mat A, const double *const *r, double *const *
             const int *flag = flags ? flags[ip] : nullptr;
             if (S->grid_ok && g_opt.ildu_strips) {                 // grid-like factors: one strip-pipelined launch per sweep
                 apply_grid(S, r[ip], z[ip], flag);
+                continue;
+            }
+            if (S->slab_ok && g_opt.ildu_strips) {                 // 3-D grid factors: one slab-pipelined launch per sweep
+                slab3_apply(S->slab, r[ip], z[ip], flag);
                 continue;
             }
             apply_levels(S, r[ip], z[ip], flag);
@@ -1316,7 +1328,13 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
                     SGM_HIP(hipMemcpy(S->gmapLU, map.data(), map.size() * 4, hipMemcpyHostToDevice));
                 } else { free_grid(S->gL); free_grid(S->gU); }
             }
+            slab3_free(S->slab);
+            S->slab = nullptr;
+            S->slab_ok = false;
+            if (g_opt.ildu_strips && !(S->gL.on && S->gU.on))
+                SGM_TRY(slab3_build(&S->slab, n, S->hLptr, S->hLnode, S->hUptr, S->hUnode));
         }
+        if (S->slab) SGM_TRY(slab3_refresh(S->slab, S->hLval, S->hUval, S->hD));
         const bool have_grid = S->gL.on && S->gU.on;
         if (have_grid) {
             SGM_TRY(refresh_grid_values(S->gL, S->hLval));
@@ -1331,7 +1349,7 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             SGM_HIP(hipMemcpy(S->D, S->hD.data(), (size_t)n * 8, hipMemcpyHostToDevice));
             SGM_HIP(hipMemcpy(S->Dp, dp.data(), (size_t)n * 8, hipMemcpyHostToDevice));
         }
-        if (have_grid && fresh) {
+        if ((have_grid || S->slab) && fresh) {
             // the strip pipeline hands data between workgroups inside one launch: before it is trusted with this
             // pattern it must reproduce the level-scheduled apply bit for bit on a test vector (and raise no abort)
             std::vector<double> rt((size_t)n), za((size_t)n), zb((size_t)n);
@@ -1345,16 +1363,22 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             apply_levels(S, dr, dz, nullptr);
             (void)hipMemcpyAsync(za.data(), dz, (size_t)n * 8, hipMemcpyDeviceToHost, st2);
             (void)hipMemsetAsync(dz, 0, (size_t)n * 8, st2);
-            apply_grid(S, dr, dz, nullptr);
+            if (have_grid) apply_grid(S, dr, dz, nullptr);
+            else slab3_apply(S->slab, dr, dz, nullptr);
             (void)hipMemcpyAsync(zb.data(), dz, (size_t)n * 8, hipMemcpyDeviceToHost, st2);
             int32_t abL = 0, abU = 0;
-            (void)hipMemcpyAsync(&abL, S->gL.progress + S->gL.NI, 4, hipMemcpyDeviceToHost, st2);
-            (void)hipMemcpyAsync(&abU, S->gU.progress + S->gU.NI, 4, hipMemcpyDeviceToHost, st2);
+            if (have_grid) {
+                (void)hipMemcpyAsync(&abL, S->gL.progress + S->gL.NI, 4, hipMemcpyDeviceToHost, st2);
+                (void)hipMemcpyAsync(&abU, S->gU.progress + S->gU.NI, 4, hipMemcpyDeviceToHost, st2);
+            }
             const hipError_t e = hipStreamSynchronize(st2);
+            if (!have_grid && e == hipSuccess) (void)slab3_aborted(S->slab, &abL, &abU);
             dfree(dr); dfree(dz);
-            S->grid_ok = e == hipSuccess && !abL && !abU && memcmp(za.data(), zb.data(), (size_t)n * 8) == 0;
-            if (!S->grid_ok)
-                fprintf(stderr, "[sigma_hip] ILDU strip pipeline disabled for this matrix (self-check: abort %d/%d)\n", abL, abU);
+            const bool same = e == hipSuccess && !abL && !abU && memcmp(za.data(), zb.data(), (size_t)n * 8) == 0;
+            if (have_grid) S->grid_ok = same; else S->slab_ok = same;
+            if (!same)
+                fprintf(stderr, "[sigma_hip] ILDU %s pipeline disabled for this matrix (self-check: abort %d/%d)\n",
+                        have_grid ? "strip" : "slab", abL, abU);
         }
     }
     return SGM_OK;
@@ -1439,6 +1463,18 @@ int sgm_pc_get(sgm_pc pc, const char *name, void *out, size_t bytes, size_t *nee
                 SGM_HIP(hipMemcpy(&ck[2 * i], S->gL.edge + (int64_t)i * (S->gL.S + 64) + S->gL.S + 62, 16, hipMemcpyDeviceToHost));
             src = ck.data(); sz = ck.size() * 8;
         }
+        else if (nm == "slabs") {           // slab pipeline in use: {strips, line groups, lines per group, steps, order of L, of U}; zeros = off
+            static int32_t sv[6];
+            memset(sv, 0, sizeof sv);
+            if (S->slab_ok && g_opt.ildu_strips) slab3_info(S->slab, sv);
+            src = sv; sz = sizeof sv;
+        }
+        else if (nm == "slab_clocks" && S->slab_ok) {
+            static std::vector<long long> ck;
+            SGM_HIP(hipStreamSynchronize(g_rt.stream));
+            SGM_TRY(slab3_clocks(S->slab, ck));
+            src = ck.data(); sz = ck.size() * 8;
+        }
         else if (nm == "levels") {
             static int32_t lv[2];
             lv[0] = (int32_t)S->L.level_ptr.size() - 1;
@@ -1446,7 +1482,7 @@ int sgm_pc_get(sgm_pc pc, const char *name, void *out, size_t bytes, size_t *nee
             src = lv; sz = sizeof lv;
         }
     }
-    const bool known = nm == "strips" || nm == "strip_clocks" || nm == "idiag" || nm == "Lptr" || nm == "Lnode" || nm == "Lval" || nm == "Uptr" ||
+    const bool known = nm == "strips" || nm == "strip_clocks" || nm == "slabs" || nm == "slab_clocks" || nm == "idiag" || nm == "Lptr" || nm == "Lnode" || nm == "Lval" || nm == "Uptr" ||
                        nm == "Unode" || nm == "Uval" || nm == "D" || nm == "levels";
     if (!known || (!src && sz)) return fail(SGM_ERR_BAD_ARG, "sgm_pc_get: unknown array '%s'", name);
     if (!src) src = &kEmpty;

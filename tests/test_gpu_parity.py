@@ -974,6 +974,86 @@ def _grid_like_matrix(n, w, order, seed, holes=0.0):
     return ei, ej, ev
 
 
+def _grid3_like_matrix(n, w, h, order, seed, holes=0.0):
+    """3-D twin of _grid_like_matrix: rows touch r-wh, r-w, r-1, r, r+1, r+w, r+wh (no +-1 across a grid line, no +-w
+    across a plane); `order`: "asc" (ascending columns), "desc" (the lower terms nearest-first) or "mixed" (a per-row
+    choice among four slot orders); `holes` removes a fraction of the off-diagonal pairs symmetrically."""
+    rs = np.random.RandomState(seed)
+    wh = w * h
+    orders = {"asc": (-wh, -w, -1, 0, 1, w, wh), "desc": (-1, -w, -wh, 0, wh, w, 1),
+              "m2": (-w, -wh, -1, 0, w, 1, wh), "m3": (-1, -wh, -w, 0, 1, wh, w)}
+    keep = {1: rs.rand(n) >= holes, w: rs.rand(n) >= holes, wh: rs.rand(n) >= holes}      # pair (r, r-d) by its later row
+    pick = rs.randint(0, 4, n)
+    ei, ej = [], []
+    for r in range(n):
+        offs = orders[order] if order != "mixed" else orders[("asc", "desc", "m2", "m3")[pick[r]]]
+        for o in offs:
+            c = r + o
+            if c < 0 or c >= n:
+                continue
+            hi = max(r, c)
+            d = abs(o)
+            if d and not keep[d][hi]:
+                continue
+            if d == 1 and hi % w == 0:
+                continue
+            if d == w and (hi // w) % h == 0:
+                continue
+            ei.append(r + 1); ej.append(c + 1)
+    ei, ej = np.array(ei, np.int32), np.array(ej, np.int32)
+    lo, hi = np.minimum(ei, ej).astype(np.int64), np.maximum(ei, ej).astype(np.int64)
+    sym = ((lo * 2654435761 + hi * 40503) % 1000) / 1000.0
+    ev = np.where(ei == ej, 6.5 + sym, -0.5 - 0.5 * sym)
+    return ei, ej, ev
+
+
+@pytest.mark.parametrize("w,h,nk,tail,order,holes", [(100, 20, 12, 0, "asc", 0.0), (64, 16, 9, 0, "desc", 0.0), (70, 33, 17, 1234, "mixed", 0.1),
+                                                       (130, 24, 10, 0, "asc", 0.3), (40, 9, 8, 77, "asc", 0.0), (200, 12, 9, 0, "mixed", 0.0)])
+def test_ildu_slab_pipeline_vs_level_walkers_and_oracle(orc, w, h, nk, tail, order, holes):
+    """The slab-pipelined triangular solves for 3-D grid factors (one launch per sweep; strips of a workgroup hand
+    lane-63 results to each other in LDS, line groups hand whole result vectors to the next workgroup through memory)
+    against the level walkers and the oracle, bit for bit: strips narrower than a wave, padded line groups, a partial
+    last plane, every stored order of a row's three terms, missing terms, one to four strips per workgroup."""
+    n = w * h * nk + tail
+    ei, ej, ev = _grid3_like_matrix(n, w, h, order, seed=n % 89, holes=holes)
+    A = orc.CsrMatrix.from_edges(n, n, ei, ej, ev)
+    H = hip_from_oracle(A)
+    opc = orc.Ildu(A)
+    pc = sg.ldu()
+    pc.setup(H)
+    slabs = pc.get("slabs", np.int32)
+    assert slabs[0] == (w + 63) // 64 and slabs[1] * slabs[2] >= h and slabs[1] >= 1, slabs
+    reg = 10 if (holes == 0.0 and tail == 0 and order != "mixed") else 0         # +10: the variant that reads no presence codes
+    assert (slabs[4], slabs[5]) == tuple(v + reg for v in {"asc": (0, 1), "desc": (1, 0), "mixed": (2, 2)}[order]), slabs
+    rs = np.random.RandomState(6)
+    for trial in range(3):
+        r = rs.standard_normal(n)
+        z = np.zeros(n)
+        pc.solve(H, z, r)
+        assert np.array_equal(z, opc.solve(r)), trial
+    sg.set_option("ildu_strips", 0)
+    try:
+        assert pc.get("slabs", np.int32)[0] == 0
+        z2 = np.zeros(n)
+        pc.solve(H, z2, r)
+        assert np.array_equal(z2, z)
+    finally:
+        sg.set_option("ildu_strips", 1)
+    b = P.test_vector(n)
+    ur, itr, _, _ = orc.cg(A, b, tol=1e-12, pc=opc)
+    s = sg.cg(1e-12)
+    s.setup(H)
+    u = np.zeros(n)
+    s.solve(H, u, b, pc)
+    assert abs(s.iterations - itr) <= 1 and np.abs(u - ur).max() / np.abs(ur).max() <= 1e-11
+    H.set_values(A.val * 1.25)
+    pc.setup(H)
+    A2 = orc.CsrMatrix(n, n, A.ptr, A.node, A.val * 1.25)
+    z = np.zeros(n)
+    pc.solve(H, z, r)
+    assert np.array_equal(z, orc.Ildu(A2).solve(r))
+
+
 @pytest.mark.parametrize("n,w,order,holes", [(64 * 70, 70, "sw", 0.0), (100 * 131 + 57, 131, "ws", 0.0), (257 * 300, 257, "mixed", 0.1),
                                             (640 * 64, 640, "sw", 0.3)])
 def test_ildu_strip_pipeline_vs_level_walkers_and_oracle(orc, n, w, order, holes):
