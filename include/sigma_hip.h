@@ -263,6 +263,14 @@ int sgm_comm_destroy(sgm_comm c);
 int sgm_csr_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts /* nranks+1, 0-based */,
                         int64_t nnz_local, const int32_t *ptr_1based_local,
                         const int32_t *node_1based_global, const double *val, int where);
+/* sgm_csr_create_dist_rect: rows partitioned by row_starts, x (the columns) by col_starts -- an off-diagonal block
+ * of a composite (sparse_matrix_composites.f90:41-162) whose block rows / columns have partitions of their own.
+ * matvec reads x as [this rank's col_starts slice | halo].  A composite of such leaves (every leaf on the same
+ * communicator, block row i partitioned like block column i) is itself a distributed operator: its vectors are
+ * the concatenation of this rank's slices of the block vectors.                                               */
+int sgm_csr_create_dist_rect(sgm_mat *out, sgm_comm comm, const int64_t *row_starts, const int64_t *col_starts,
+                             int64_t nnz_local, const int32_t *ptr_1based_local,
+                             const int32_t *node_1based_global, const double *val, int where);
 /* sgm_ell_create_dist: this rank's rows of an ELLPACK matrix (node / val as (max_d, n_local) column-major,
  * GLOBAL 1-based columns, padding as the reference keeps it).  Held as fixed-length CSR rows whose padding
  * slots are stored entries, so the row sums equal ellpack_matvec_add's (ellpack_matrices.f90:640-665). */

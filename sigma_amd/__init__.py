@@ -210,14 +210,14 @@ class _Matrix:
 
     # -- linear_operator_interface.f90:199-208 ------------------------------------------
     def matvec_t(self, x, y):
-        _need(x, getattr(self, "n_local", self.nrow), "matvec_t x"); _need(y, getattr(self, "n_local", self.ncol), "matvec_t y")
+        _need(x, getattr(self, "n_local", self.nrow), "matvec_t x"); _need(y, getattr(self, "nc_local", self.ncol), "matvec_t y")
         px, wx, _k1 = _arg(x, np.float64)
         py, wy, _k2 = _arg(y, np.float64, writable=True)
         _ck(lib().sgm_mat_matvec_t(self._h, px, py, C.c_int(_same_where(wx, wy))))
         return y
 
     def matvec_t_add(self, x, y):
-        _need(x, getattr(self, "n_local", self.nrow), "matvec_t_add x"); _need(y, getattr(self, "n_local", self.ncol), "matvec_t_add y")
+        _need(x, getattr(self, "n_local", self.nrow), "matvec_t_add x"); _need(y, getattr(self, "nc_local", self.ncol), "matvec_t_add y")
         px, wx, _k1 = _arg(x, np.float64)
         py, wy, _k2 = _arg(y, np.float64, writable=True)
         _ck(lib().sgm_mat_matvec_t_add(self._h, px, py, C.c_int(_same_where(wx, wy))))
@@ -406,19 +406,22 @@ class partitioned_csr_matrix(_Matrix):
 
 
 class dist_csr_matrix(_Matrix):
-    """This rank's row block of a matrix partitioned over processes (RCCL)."""
+    """This rank's row block of a matrix partitioned over processes (RCCL).  col_starts: the partition of x when it
+    is not the rows' (sgm_csr_create_dist_rect: an off-diagonal block of a composite)."""
 
-    def __init__(self, comm, row_starts, ptr_local, node_global, val):
+    def __init__(self, comm, row_starts, ptr_local, node_global, val, col_starts=None):
         super().__init__()
         rs = np.ascontiguousarray(row_starts, np.int64)
+        cs = rs if col_starts is None else np.ascontiguousarray(col_starts, np.int64)
         pp, w1, _k1 = _arg(ptr_local, np.int32)
         pn, w2, _k2 = _arg(node_global, np.int32)
         pv, w3, _k3 = _arg(val, np.float64)
-        self.nrow = self.ncol = int(rs[-1])
+        self.nrow, self.ncol = int(rs[-1]), int(cs[-1])
         self.n_local = int(rs[comm.rank + 1] - rs[comm.rank])
+        self.nc_local = int(cs[comm.rank + 1] - cs[comm.rank])
         self.nnz = int(len(val))
-        _ck(lib().sgm_csr_create_dist(C.byref(self._h), comm._h, C.c_void_p(rs.ctypes.data), C.c_int64(self.nnz),
-                                      pp, pn, pv, C.c_int(_same_where(w1, w2, w3))))
+        _ck(lib().sgm_csr_create_dist_rect(C.byref(self._h), comm._h, C.c_void_p(rs.ctypes.data), C.c_void_p(cs.ctypes.data),
+                                           C.c_int64(self.nnz), pp, pn, pv, C.c_int(_same_where(w1, w2, w3))))
 
 
 class dist_ellpack_matrix(_Matrix):
@@ -432,7 +435,7 @@ class dist_ellpack_matrix(_Matrix):
         pn, w1, _k1 = _arg(node_global, np.int32)
         pv, w2, _k2 = _arg(val, np.float64)
         self.nrow = self.ncol = int(rs[-1])
-        self.n_local = int(rs[comm.rank + 1] - rs[comm.rank])
+        self.n_local = self.nc_local = int(rs[comm.rank + 1] - rs[comm.rank])
         self.max_d = max_d
         _ck(lib().sgm_ell_create_dist(C.byref(self._h), comm._h, C.c_void_p(rs.ctypes.data), C.c_int32(max_d), pn, pv,
                                       C.c_int(_same_where(w1, w2))))
@@ -466,6 +469,12 @@ class sparse_matrix(_Matrix):
                 arr[i * self.num_col_mats + j] = B._h if B is not None else None
         _ck(lib().sgm_composite_create(C.byref(self._h), C.c_int32(self.num_row_mats), C.c_int32(self.num_col_mats),
                                        C.c_void_p(self.row_ptr.ctypes.data), C.c_void_p(self.col_ptr.ctypes.data), arr))
+        leaves = [B for row in self.sub_mats for B in row if B is not None]
+        if leaves and hasattr(leaves[0], "n_local"):
+            # over distributed leaves the vectors are this rank's slices of the block vectors, concatenated
+            self.n_local = sum(next(B.n_local for B in row if B is not None) for row in self.sub_mats)
+            self.nc_local = sum(next(self.sub_mats[i][j].nc_local for i in range(self.num_row_mats) if self.sub_mats[i][j] is not None)
+                                for j in range(self.num_col_mats))
 
     def matvec(self, x, y):
         self._build()
@@ -524,7 +533,7 @@ class _Preconditioner:
             _ck(getattr(lib(), self._create)(C.byref(self._h), A._h))
         else:
             _ck(lib().sgm_pc_setup(self._h, A._h))
-        self.nn = A.nrow
+        self.nn = getattr(A, "n_local", A.nrow)
         self.initialized = True
 
     def solve(self, A, x, b):

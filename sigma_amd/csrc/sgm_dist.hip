@@ -451,15 +451,24 @@ int sgm_comm_destroy(sgm_comm c)
 int sgm_csr_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts, int64_t nnz,
                         const int32_t *ptr, const int32_t *node, const double *val, int where)
 {
+    return sgm_csr_create_dist_rect(out, comm, row_starts, row_starts, nnz, ptr, node, val, where);
+}
+
+// rows partitioned by row_starts, x (the columns) by col_starts: an off-diagonal block of a composite whose
+// block rows / block columns have partitions of their own
+int sgm_csr_create_dist_rect(sgm_mat *out, sgm_comm comm, const int64_t *row_starts, const int64_t *col_starts, int64_t nnz,
+                             const int32_t *ptr, const int32_t *node, const double *val, int where)
+{
     SGM_TRY(require_init());
-    if (!out || !comm || !row_starts || !ptr) return fail(SGM_ERR_BAD_ARG, "sgm_csr_create_dist: bad argument");
+    if (!out || !comm || !row_starts || !col_starts || !ptr) return fail(SGM_ERR_BAD_ARG, "sgm_csr_create_dist: bad argument");
     const int R = comm->nranks, me = comm->rank;
     const int64_t r0 = row_starts[me], r1 = row_starts[me + 1];
-    const int32_t n = (int32_t)(r1 - r0);
-    if (row_starts[0] != 0 || r1 < r0 || row_starts[R] > INT32_MAX)
-        return fail(SGM_ERR_BAD_ARG, "sgm_csr_create_dist: row_starts must rise from 0 to the global row count (< 2^31)");
+    const int64_t c0 = col_starts[me], c1 = col_starts[me + 1];
+    const int32_t n = (int32_t)(r1 - r0), nc = (int32_t)(c1 - c0);
+    if (row_starts[0] != 0 || r1 < r0 || row_starts[R] > INT32_MAX || col_starts[0] != 0 || c1 < c0 || col_starts[R] > INT32_MAX)
+        return fail(SGM_ERR_BAD_ARG, "sgm_csr_create_dist: row_starts / col_starts must rise from 0 to the global count (< 2^31)");
     for (int q = 1; q < R; ++q)
-        if (row_starts[q] & 1) return fail(SGM_ERR_UNSUPPORTED, "partition boundaries must be even rows (16-B vector access)");
+        if ((row_starts[q] | col_starts[q]) & 1) return fail(SGM_ERR_UNSUPPORTED, "partition boundaries must be even rows (16-B vector access)");
     hipStream_t st = g_rt.stream;
 
     // the index work runs on the host (same code as sgm_halo_plan_host / sgm_dist_plan_host).
@@ -478,18 +487,19 @@ int sgm_csr_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts, 
     if ((int64_t)ptr_h[n] - 1 != nnz) return fail(SGM_ERR_BAD_ARG, "sgm_csr_create_dist: ptr(n+1)-1 = %lld but nnz_local = %lld",
                                                    (long long)ptr_h[n] - 1, (long long)nnz);
     std::vector<int32_t> halo;
-    halo_plan(n, r0, nnz, node_h, lnode.data(), halo);
+    halo_plan(nc, c0, nnz, node_h, lnode.data(), halo);
     std::vector<int32_t> want, want_off, req;
-    SGM_TRY(dist_plan(me, R, row_starts, halo, want, want_off, req));
+    SGM_TRY(dist_plan(me, R, col_starts, halo, want, want_off, req));
 
     MatGuard g;
     sgm_mat A = g.A = new sgm_mat_s;
     A->fmt = SGM_FMT_CSR;
     A->nrow = (int32_t)row_starts[R];
-    A->ncol = A->nrow;
+    A->ncol = (int32_t)col_starts[R];
     A->nnz = nnz;
     A->comm = comm;
     A->row_starts.assign(row_starts, row_starts + R + 1);
+    A->col_starts.assign(col_starts, col_starts + R + 1);
     A->halo_cols = halo;
     A->parts.resize(1);
     Part &p = A->parts[0];
@@ -499,9 +509,9 @@ int sgm_csr_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts, 
         SGM_TRY(dalloc(&dnode, (size_t)std::max<int64_t>(nnz, 1)));
         g.scratch.push_back(dnode);
         if (nnz) SGM_HIP(hipMemcpyAsync(dnode, lnode.data(), (size_t)nnz * 4, hipMemcpyHostToDevice, st));
-        SGM_TRY(build_csr_part(p, n, n, (int32_t)halo.size(), nnz, ptr, dnode, val, SGM_DEVICE));
+        SGM_TRY(build_csr_part(p, n, nc, (int32_t)halo.size(), nnz, ptr, dnode, val, SGM_DEVICE));
     } else {
-        SGM_TRY(build_csr_part(p, n, n, (int32_t)halo.size(), nnz, ptr_h, lnode.data(), val, SGM_HOST));
+        SGM_TRY(build_csr_part(p, n, nc, (int32_t)halo.size(), nnz, ptr_h, lnode.data(), val, SGM_HOST));
     }
     p.row_begin = r0;
     set_interior_range(p, ptr_h, lnode.data());
@@ -532,7 +542,7 @@ int sgm_csr_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts, 
             nb.send_count = pl.send_count;
             nb.recv_count = pl.recv_count;
             nb.recv_offset = pl.recv_offset;
-            if (pl.send_count > n) return fail(SGM_ERR_RCCL, "rank %d asks for %d entries of the %d this rank owns", pl.peer, pl.send_count, n);
+            if (pl.send_count > nc) return fail(SGM_ERR_RCCL, "rank %d asks for %d entries of the %d this rank owns", pl.peer, pl.send_count, nc);
             p.nbrs.push_back(nb);                       // buffers below are owned by the part from here on
             if (pl.send_count) {
                 SGM_TRY(dalloc(&p.nbrs.back().send_idx, (size_t)pl.send_count));
@@ -611,9 +621,9 @@ static int ensure_transpose_dist(sgm_mat A)
     const Part &p = A->parts[0];
     sgm_comm comm = A->comm;
     const int R = comm->nranks, me = comm->rank;
-    const int64_t *rs = A->row_starts.data();
-    const int64_t r0 = rs[me];
-    const int32_t n = p.n;
+    const int64_t *rs = A->row_starts.data(), *cs = A->col_starts.data();      // A^T: rows by cs, x by rs
+    const int64_t r0 = rs[me], c0 = cs[me];
+    const int32_t n = p.n, nc = p.ncol_own;
     hipStream_t st = g_rt.stream;
     std::vector<int32_t> hptr((size_t)n + 1), hcol((size_t)std::max<int64_t>(p.nnz, 1));
     std::vector<double> hval((size_t)std::max<int64_t>(p.nnz, 1));
@@ -627,10 +637,10 @@ static int ensure_transpose_dist(sgm_mat A)
     std::vector<int32_t> cnt(R, 0), off(R + 1, 0), owner((size_t)std::max<int64_t>(p.nnz, 1));
     for (int64_t k = 0; k < p.nnz; ++k) {
         const int32_t c = hcol[k];
-        const int64_t g0 = c < n ? r0 + c : (int64_t)A->halo_cols[c - n] - 1;        // global column, 0-based
-        const int q = c < n ? me : owner_of(rs, R, g0);
+        const int64_t g0 = c < nc ? c0 + c : (int64_t)A->halo_cols[c - nc] - 1;      // global column, 0-based
+        const int q = c < nc ? me : owner_of(cs, R, g0);
         owner[k] = q;
-        hcol[k] = (int32_t)(g0 - rs[q]);                                           // column in its owner's numbering
+        hcol[k] = (int32_t)(g0 - cs[q]);                                           // column in its owner's numbering
         cnt[q]++;
     }
     for (int q = 0; q < R; ++q) off[q + 1] = off[q] + cnt[q];
@@ -708,13 +718,13 @@ static int ensure_transpose_dist(sgm_mat A)
     }
     SGM_HIP(hipStreamSynchronize(st));
     // stable counting sort by local column = row of A^T
-    std::vector<int32_t> tptr((size_t)n + 1, 0), tnode((size_t)std::max<int64_t>(nr, 1));
+    std::vector<int32_t> tptr((size_t)nc + 1, 0), tnode((size_t)std::max<int64_t>(nr, 1));
     std::vector<double> tval((size_t)std::max<int64_t>(nr, 1));
     for (int64_t e = 0; e < nr; ++e) {
-        if (ri[e] < 0 || ri[e] >= n) return fail(SGM_ERR_RCCL, "matvec_t: received an entry for column %d of %d", ri[e], n);
+        if (ri[e] < 0 || ri[e] >= nc) return fail(SGM_ERR_RCCL, "matvec_t: received an entry for column %d of %d", ri[e], nc);
         tptr[ri[e] + 1]++;
     }
-    for (int32_t i = 0; i < n; ++i) tptr[i + 1] += tptr[i];
+    for (int32_t i = 0; i < nc; ++i) tptr[i + 1] += tptr[i];
     {
         std::vector<int32_t> fill(tptr.begin(), tptr.end() - 1);
         for (int64_t e = 0; e < nr; ++e) {
@@ -725,7 +735,7 @@ static int ensure_transpose_dist(sgm_mat A)
     }
     for (auto &v : tptr) v += 1;                                                  // 1-based like the reference's ptr
     sgm_mat T = nullptr;
-    SGM_TRY(sgm_csr_create_dist(&T, comm, rs, nr, tptr.data(), tnode.data(), tval.data(), SGM_HOST));
+    SGM_TRY(sgm_csr_create_dist_rect(&T, comm, cs, rs, nr, tptr.data(), tnode.data(), tval.data(), SGM_HOST));
     if (!T->parts[0].xext) {
         const int rc = dalloc(&T->parts[0].xext, (size_t)T->parts[0].xlen() + 2);
         if (rc != SGM_OK) { sgm_mat_destroy(T); return rc; }
@@ -742,7 +752,7 @@ int matvec_t_dist(sgm_mat A, const double *x, double *y, int where, bool add)
     sgm_mat T = A->T;
     Part &pt = T->parts[0];
     const hipMemcpyKind kind = where == SGM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-    SGM_HIP(hipMemcpyAsync(pt.xext, x, (size_t)pt.n * 8, kind, g_rt.stream));     // owned rows; A^T's halo is filled by the exchange
+    SGM_HIP(hipMemcpyAsync(pt.xext, x, (size_t)pt.ncol_own * 8, kind, g_rt.stream));     // A's owned rows; A^T's halo is filled by the exchange
     Staged sy;
     SGM_TRY(stage_in(sy, y, pt.n, where, add));
     const double *xs[1] = {pt.xext};

@@ -162,6 +162,7 @@ struct sgm_mat_s {
     std::vector<sgm::Part> parts;  // 1 unless created with sgm_csr_create_partitioned
     sgm_comm comm = nullptr;       // RCCL communicator when distributed over processes
     std::vector<int64_t> row_starts;   // distributed: the row partition (nranks+1, 0-based)
+    std::vector<int64_t> col_starts;   // distributed: the partition of x (== row_starts unless created by sgm_csr_create_dist_rect)
     std::vector<int32_t> halo_cols;    // distributed: global 1-based column of every halo slot
     bool distributed() const { return comm != nullptr || parts.size() > 1; }
     // explicit transpose for matvec_t (built on first use; rows sorted by (source row, slot) so

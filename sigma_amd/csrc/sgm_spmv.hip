@@ -1098,18 +1098,27 @@ static int composite_spmv(sgm_mat A, const double *x, double *y, bool add, const
                           const int *flag_done, int *grid_out, int gen)
 {
     const int nrb = (int)A->blk_row_ptr.size() - 1, ncb = (int)A->blk_col_ptr.size() - 1;
-    if (!add) SGM_HIP(hipMemsetAsync(y, 0, (size_t)A->nrow * 8, g_rt.stream));     // y = 0 (matvec)
+    // over distributed leaves (sgm_csr_create_dist_rect) the block offsets are LOCAL: x and y are the concatenation
+    // of this rank's slices of the block vectors; a leaf reads [its slice of x_j | halo] out of its own staging vector
+    const int64_t nloc = A->parts[0].n;
+    if (!add) SGM_HIP(hipMemsetAsync(y, 0, (size_t)nloc * 8, g_rt.stream));     // y = 0 (matvec)
     for (int it = 0; it < nrb; ++it)
         for (int jt = 0; jt < ncb; ++jt) {
             sgm_mat C = A->blocks[(size_t)it * ncb + jt];
             if (!C) continue;
             const double *xs[1] = {x + A->blk_col_ptr[jt]};
             double *ys[1] = {y + A->blk_row_ptr[it]};
+            if (C->comm) {
+                Part &cp = C->parts[0];
+                if (!cp.xext) SGM_TRY(dalloc(&cp.xext, (size_t)cp.xlen() + 2));
+                SGM_HIP(hipMemcpyAsync(cp.xext, xs[0], (size_t)cp.ncol_own * 8, hipMemcpyDeviceToDevice, g_rt.stream));
+                xs[0] = cp.xext;
+            }
             SGM_TRY(spmv_parts(C, xs, ys, true, nullptr, flag_done, nullptr, gen, false));
         }
     if (dots && (dots->part_wy || dots->part_yy)) {
         const int grid = A->parts[0].dot_grid_override;
-        hipLaunchKernelGGL(k_dot_wy_yy, dim3(grid), dim3(kBlock), 0, g_rt.stream, (int64_t)A->nrow,
+        hipLaunchKernelGGL(k_dot_wy_yy, dim3(grid), dim3(kBlock), 0, g_rt.stream, nloc,
                            dots->w ? dots->w[0] : nullptr, (const double *)y,
                            dots->part_wy ? dots->part_wy[0] : nullptr, dots->part_yy ? dots->part_yy[0] : nullptr,
                            flag_done, gen);
@@ -1685,26 +1694,31 @@ static int matvec_t_impl(sgm_mat A, const double *x, double *y, int where, bool 
 {
     SGM_TRY(require_init());
     if (!A || !x || !y) return fail(SGM_ERR_BAD_ARG, "matvec_t: null argument");
-    if (A->comm) return matvec_t_dist(A, x, y, where, add);
     if (A->fmt == SGM_FMT_COMPOSITE) {
         // composite_matvec_t_add (sparse_matrix_composites.f90:1104-1127): column blocks outer
+        const int64_t nr = A->parts[0].n, nc = A->parts[0].ncol_own;        // (local lengths over distributed leaves)
         Staged sx, sy;
-        SGM_TRY(stage_in(sx, x, A->nrow, where, true));
-        SGM_TRY(stage_in(sy, y, A->ncol, where, add));
-        if (!add) SGM_HIP(hipMemsetAsync(sy.dev, 0, (size_t)A->ncol * 8, g_rt.stream));
+        SGM_TRY(stage_in(sx, x, nr, where, true));
+        SGM_TRY(stage_in(sy, y, nc, where, add));
+        if (!add) SGM_HIP(hipMemsetAsync(sy.dev, 0, (size_t)nc * 8, g_rt.stream));
         const int nrb = (int)A->blk_row_ptr.size() - 1, ncb = (int)A->blk_col_ptr.size() - 1;
         for (int jt = 0; jt < ncb; ++jt)
             for (int it = 0; it < nrb; ++it) {
                 sgm_mat C = A->blocks[(size_t)it * ncb + jt];
                 if (!C) continue;
+                if (C->comm) {          // A^T of the leaf is a distributed matrix of its own (sgm_dist.hip)
+                    SGM_TRY(matvec_t_dist(C, sx.dev + A->blk_row_ptr[it], sy.dev + A->blk_col_ptr[jt], SGM_DEVICE, true));
+                    continue;
+                }
                 SGM_TRY(ensure_transpose(C));
                 const double *xs[1] = {sx.dev + A->blk_row_ptr[it]};
                 double *ys[1] = {sy.dev + A->blk_col_ptr[jt]};
                 SGM_TRY(spmv_parts(C->T, xs, ys, true, nullptr, nullptr, nullptr, 0x7fffffff, true));
             }
-        SGM_TRY(stage_out(sy, y, A->ncol, where));
+        SGM_TRY(stage_out(sy, y, nc, where));
         return finish();
     }
+    if (A->comm) return matvec_t_dist(A, x, y, where, add);
     SGM_TRY(ensure_transpose(A));
     Staged sx, sy;
     SGM_TRY(stage_in(sx, x, A->nrow, where, true));
@@ -1879,21 +1893,57 @@ int sgm_composite_create(sgm_mat *out, int32_t nrb, int32_t ncb, const int32_t *
     A->nrow = A->blk_row_ptr[nrb];
     A->ncol = A->blk_col_ptr[ncb];
     A->blocks.assign(blocks, blocks + (size_t)nrb * ncb);
+    sgm_comm comm = nullptr;
+    bool any_local = false;
     for (int it = 0; it < nrb; ++it)
         for (int jt = 0; jt < ncb; ++jt) {
             sgm_mat C = A->blocks[(size_t)it * ncb + jt];
             if (!C) continue;
-            if (C->distributed() || C->fmt == SGM_FMT_COMPOSITE || C->nrow != A->blk_row_ptr[it + 1] - A->blk_row_ptr[it] ||
+            if (C->parts.size() != 1 || C->fmt == SGM_FMT_COMPOSITE || C->nrow != A->blk_row_ptr[it + 1] - A->blk_row_ptr[it] ||
                 C->ncol != A->blk_col_ptr[jt + 1] - A->blk_col_ptr[jt]) {
                 delete A;
                 return fail(SGM_ERR_DIMS, "sgm_composite_create: block (%d,%d) does not fit its slot", it + 1, jt + 1);
             }
+            if (C->comm) { if (comm && comm != C->comm) { delete A; return fail(SGM_ERR_BAD_ARG, "sgm_composite_create: leaves on different communicators"); } comm = C->comm; }
+            else any_local = true;
             A->nnz += C->nnz;
         }
+    int64_t nloc_r = A->nrow, nloc_c = A->ncol;
+    if (comm) {
+        // Leaves distributed over processes: block row i must be partitioned the same way in all its leaves, block
+        // column j likewise, and (so that the operator maps a vector layout onto itself) block row i like block
+        // column i.  The block offsets become the LOCAL ones: this rank's slices of the block vectors, concatenated.
+        const int me = comm->rank;
+        auto bad = [&](const char *why) { delete A; return fail(SGM_ERR_UNSUPPORTED, "sgm_composite_create over distributed leaves: %s", why); };
+        if (any_local) return bad("every leaf must be distributed (sgm_csr_create_dist / _rect / sgm_ell_create_dist)");
+        if (nrb != ncb) return bad("needs as many block rows as block columns");
+        std::vector<const std::vector<int64_t> *> rpart(nrb, nullptr), cpart(ncb, nullptr);
+        for (int it = 0; it < nrb; ++it)
+            for (int jt = 0; jt < ncb; ++jt) {
+                sgm_mat C = A->blocks[(size_t)it * ncb + jt];
+                if (!C) continue;
+                if (rpart[it] && *rpart[it] != C->row_starts) return bad("the leaves of a block row are partitioned differently");
+                if (cpart[jt] && *cpart[jt] != C->col_starts) return bad("the leaves of a block column are partitioned differently");
+                rpart[it] = &C->row_starts;
+                cpart[jt] = &C->col_starts;
+            }
+        std::vector<int32_t> lr(1, 0), lc(1, 0);
+        for (int it = 0; it < nrb; ++it) {
+            if (!rpart[it] || !cpart[it]) return bad("a block row or column without any leaf has no partition");
+            if (*rpart[it] != *cpart[it]) return bad("block row i must be partitioned like block column i");
+            lr.push_back(lr.back() + (int32_t)((*rpart[it])[me + 1] - (*rpart[it])[me]));
+            lc.push_back(lc.back() + (int32_t)((*cpart[it])[me + 1] - (*cpart[it])[me]));
+        }
+        A->blk_row_ptr = lr;
+        A->blk_col_ptr = lc;
+        A->comm = comm;
+        nloc_r = lr.back();
+        nloc_c = lc.back();
+    }
     A->parts.resize(1);
-    A->parts[0].n = A->nrow;
-    A->parts[0].ncol_own = A->ncol;
-    int64_t g = ((int64_t)A->nrow + 4 * kBlock - 1) / (4 * kBlock);
+    A->parts[0].n = (int32_t)nloc_r;
+    A->parts[0].ncol_own = (int32_t)nloc_c;
+    int64_t g = (nloc_r + 4 * kBlock - 1) / (4 * kBlock);
     A->parts[0].dot_grid_override = (int)std::max<int64_t>(1, std::min<int64_t>(g, 2048));
     *out = A;
     return SGM_OK;

@@ -47,6 +47,10 @@ def run(rank, world, port, case, res):
         dist.broadcast_object_list(uid, src=0)
         comm = sg.Comm(rank, world, uid[0])
 
+        if case == "composite":
+            run_composite(rank, world, comm, dev, res)
+            comm.destroy()
+            return
         if case == "poisson2d":
             n = 96 * 70
             ptr, node, val = P.poisson2d_csr(96, 70)
@@ -184,6 +188,98 @@ def run(rank, world, port, case, res):
         comm.destroy()
     finally:
         dist.destroy_process_group()
+
+
+def run_composite(rank, world, comm, dev, res):
+    """A 2 x 2 composite (sparse_matrix_composites.f90:41-162) whose four leaves are each distributed over the
+    ranks -- block row i with a partition of its own, the off-diagonal leaves rectangular
+    (sgm_csr_create_dist_rect) -- against the serial block loops of the oracle's leaves, bit for bit, and
+    CG / Jacobi-PCG on it against the oracle's solves of the assembled matrix."""
+    import numpy as np
+    import scipy.sparse as sp
+    import torch
+    import oracle as orc
+    import sigma_amd as sg
+    from sigma_amd import problems as P
+
+    nx, ny = 96, 70
+    n = nx * ny
+    ptr, node, val = P.poisson2d_csr(nx, ny)
+    A = orc.CsrMatrix(n, n, ptr, node, val)
+    Asp = sp.csr_matrix((val, node - 1, ptr - 1), shape=(n, n))
+    Asp.sort_indices()
+    m = 3362                                             # block boundary (not a grid line)
+    cuts = [0, m, n]
+    parts = []                                           # row partition of block row i (even boundaries)
+    for i in range(2):
+        sub = Asp[cuts[i]:cuts[i + 1]]
+        parts.append(sg.partition_rows_by_nnz((sub.indptr + 1).astype(np.int32), world, align=2))
+    leaves_o, leaves_d = [[None, None], [None, None]], [[None, None], [None, None]]
+    for i in range(2):
+        for j in range(2):
+            B = Asp[cuts[i]:cuts[i + 1], cuts[j]:cuts[j + 1]].tocsr()
+            B.sort_indices()
+            nr, nc = B.shape
+            leaves_o[i][j] = orc.CsrMatrix(nr, nc, (B.indptr + 1).astype(np.int32), (B.indices + 1).astype(np.int32), B.data.copy())
+            r0, r1 = int(parts[i][rank]), int(parts[i][rank + 1])
+            L = B[r0:r1]
+            leaves_d[i][j] = sg.dist_csr_matrix(comm, parts[i], (L.indptr + 1).astype(np.int32), (L.indices + 1).astype(np.int32),
+                                                L.data.copy(), col_starts=parts[j])
+    S = sg.sparse_matrix(np.array([1, m + 1, n + 1], np.int32), np.array([1, m + 1, n + 1], np.int32))
+    for i in range(2):
+        for j in range(2):
+            S.set_submatrix(i + 1, j + 1, leaves_d[i][j])
+
+    def local(v):
+        return np.concatenate([v[cuts[i] + int(parts[i][rank]):cuts[i] + int(parts[i][rank + 1])] for i in range(2)])
+
+    rs = np.random.RandomState(4)
+    x = rs.standard_normal(n)
+    xs = [x[:m], x[m:]]
+    # composite_matvec_add: row blocks outer, column blocks inner, y(i1:i2) += leaf * x(j1:j2)
+    y0 = rs.standard_normal(n)
+    yref = np.zeros(n)
+    yaref = y0.copy()
+    for i in range(2):
+        for j in range(2):
+            yref[cuts[i]:cuts[i + 1]] = leaves_o[i][j].matvec_add(xs[j], yref[cuts[i]:cuts[i + 1]].copy())
+            yaref[cuts[i]:cuts[i + 1]] = leaves_o[i][j].matvec_add(xs[j], yaref[cuts[i]:cuts[i + 1]].copy())
+    xl = local(x)
+    y = np.full(len(xl), -7.0)
+    S.matvec(xl, y)
+    assert np.array_equal(y, local(yref)), "composite over distributed leaves: matvec differs from the serial block loops"
+    ya = local(y0)
+    S.matvec_add(xl, ya)
+    assert np.array_equal(ya, local(yaref))
+    yd = torch.zeros(len(xl), dtype=torch.float64, device=dev)
+    S.matvec(torch.from_numpy(xl).to(dev), yd)
+    assert np.array_equal(yd.cpu().numpy(), local(yref))
+    # composite_matvec_t_add: column blocks outer, y(j1:j2) += leaf^T * x(i1:i2)
+    tref = np.zeros(n)
+    for j in range(2):
+        for i in range(2):
+            tref[cuts[j]:cuts[j + 1]] = leaves_o[i][j].matvec_t_add(xs[i], tref[cuts[j]:cuts[j + 1]].copy())
+    t = np.full(len(xl), 3.0)
+    S.matvec_t(xl, t)
+    assert np.array_equal(t, local(tref)), "composite over distributed leaves: matvec_t differs from the serial block loops"
+    # Krylov loops: all-reduced dots, Jacobi from the diagonal leaves
+    b = np.full(n, 1.0 / n)
+    out = {}
+    for name, mk_pc, opc in (("cg", None, None), ("cg_jacobi", sg.jacobi, orc.Jacobi(A))):
+        ur, itr, _, _ = orc.cg(A, b, tol=1e-13, pc=opc)
+        s = sg.cg(1e-13)
+        s.setup(S)
+        pc = mk_pc() if mk_pc else None
+        if pc is not None:
+            pc.setup(S)
+        u = np.zeros(len(xl))
+        s.solve(S, u, local(b), pc)
+        rel = float(np.abs(u - local(ur)).max() / np.abs(ur).max())
+        out[name] = {"iterations": int(s.iterations), "oracle_iterations": int(itr), "rel": rel}
+        assert abs(s.iterations - itr) <= 2 and rel <= 1e-11, (name, s.iterations, itr, rel)
+    res["solves"] = out
+    res["n_local"] = int(len(xl))
+    res["n_halo"] = int(sum(leaves_d[i][j].x_len - leaves_d[i][j].nc_local for i in range(2) for j in range(2)))
 
 
 if __name__ == "__main__":
