@@ -13,7 +13,7 @@ def newest(pattern):
     return max(f, key=os.path.getmtime) if f else None
 
 
-for sub, name in (("stats", "kernel_stats.csv"), ("stats_ildu", "kernel_stats_ildu_pcg_1000x1000.csv"),
+for sub, name in (("stats", "kernel_stats.csv"), ("stats_ildu", "kernel_stats_ildu_pcg_1000x1000.csv"), ("stats_ildu3", "kernel_stats_ildu_100cubed.csv"),
                   ("stats_c3_cgs2", "kernel_stats_c3_gmres_cgs2.csv"), ("stats_c3_mgs", "kernel_stats_c3_gmres_mgs.csv"),
                   ("stats_configs", "kernel_stats_configs_c4_c5.csv")):
     f = newest(os.path.join(sub, "*", "*kernel_stats.csv"))

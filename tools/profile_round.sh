@@ -12,6 +12,8 @@ timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- 
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python bench.py $PARGS > $OUT/pmc2.log 2>&1
 # ILDU(0)-PCG on the 1000^2 grid: per-kernel times of the triangular solves
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ildu -- python tools/ildu_bench.py 1000 ildu0 > $OUT/stats_ildu.log 2>&1
+# ILDU(0)-PCG on the 100^3 grid: the slab-pipelined triangular solves
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ildu3 -- python tools/ildu_bench.py -100 ildu0 > $OUT/stats_ildu3.log 2>&1 < /dev/null
 # C3 GMRES(30): blocked CGS-2 vs modified Gram-Schmidt (launch counts per step come out of the Calls column)
 SGM_GMRES_CGS2=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_cgs2 -- python tools/bench_configs.py --configs c3 > $OUT/c3_cgs2.log 2>&1
 SGM_GMRES_CGS2=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_mgs -- python tools/bench_configs.py --configs c3 > $OUT/c3_mgs.log 2>&1
