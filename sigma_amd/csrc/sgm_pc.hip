@@ -502,7 +502,7 @@ __device__ inline double dpp_shift_up(double v, double lane0)
     return __hiloint2double(shi, slo);
 }
 // ORDER: 0 = every row subtracts its r-w term first, 1 = every row its r-1 term first, 2 = per-row flag (bit 2)
-template <int DEPTH, int CH, int ORDER>
+template <int DEPTH, int CH, int ORDER, int LA = DEPTH>
 __global__ __launch_bounds__(192) void k_trsv_strip(int32_t NI, int32_t S, const StripRec *__restrict__ rec, double *__restrict__ xp,
                                                     double *edge, int32_t *progress, const int *flag, int one_xcd)
 {
@@ -530,7 +530,8 @@ __global__ __launch_bounds__(192) void k_trsv_strip(int32_t NI, int32_t S, const
             rb[slot] = R[(int64_t)tc * 128 + 1];
         };
 #pragma unroll
-        for (int j = 0; j < DEPTH; ++j) fetch(j, j);
+        // look-ahead LA steps of the DEPTH register slots: two loads and a store per step, and vmcnt counts to 63
+        for (int j = 0; j < LA; ++j) fetch(j, j);
         const long long clk0 = wall_clock64();
         double prev = 0.0;
         double eE[CH];                       // lane 0's left neighbours of the current chunk (read out of the ring at its start)
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(192) void k_trsv_strip(int32_t NI, int32_t S, const
                 __builtin_nontemporal_store(z, X + (int64_t)t * 64);
                 ow[j % CH] = z;                         // lane 63: the out ring; the other lanes: scratch
                 prev = z;
-                fetch(j, t + DEPTH);
+                fetch((j + LA) % DEPTH, t + LA);
                 if (j % CH == CH - 1 && lane == 0)
                     __hip_atomic_store(&out_count, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -1039,15 +1040,18 @@ void trsv_grid(const GridTri &G, double *xp, const int *flag)
     const int one_xcd = xcd_env > 0 ? 1 : 0;             // (measured: 0.83 vs 0.87 ms at 1000^2, 2.06 vs 1.85 at 2000^2: within noise, off)
     // 96 KiB of (unused) dynamic LDS per workgroup: at most ONE strip per CU, so that no two chain waves share a SIMD
     static const size_t lds_pad = getenv("SGM_STRIP_LDS") ? (size_t)atoi(getenv("SGM_STRIP_LDS")) : (size_t)96 * 1024;
-#define STRIP_K(DD, OO)                                                                                                          \
+#define STRIP_K(DD, OO, LL)                                                                                                      \
     do {                                                                                                                         \
         static bool attr = false;                                                                                                \
-        if (!attr) { (void)hipFuncSetAttribute((const void *)k_trsv_strip<DD, kStripChunk, OO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pad); attr = true; } \
-        hipLaunchKernelGGL((k_trsv_strip<DD, kStripChunk, OO>), dim3(one_xcd ? G.NI * 8 : G.NI), dim3(192), lds_pad, st, G.NI, G.S, \
+        if (!attr) { (void)hipFuncSetAttribute((const void *)k_trsv_strip<DD, kStripChunk, OO, LL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pad); attr = true; } \
+        hipLaunchKernelGGL((k_trsv_strip<DD, kStripChunk, OO, LL>), dim3(one_xcd ? G.NI * 8 : G.NI), dim3(192), lds_pad, st, G.NI, G.S, \
                            (const StripRec *)G.rec, xp, G.edge, G.progress, flag, one_xcd);                                      \
     } while (0)
-    if (depth >= 32) { if (G.order == 0) STRIP_K(32, 0); else if (G.order == 1) STRIP_K(32, 1); else STRIP_K(32, 2); }
-    else { if (G.order == 0) STRIP_K(16, 0); else if (G.order == 1) STRIP_K(16, 1); else STRIP_K(16, 2); }
+    // look-ahead (SGM_STRIP_DEPTH): 32 register slots with 20 steps in flight (3 memory operations per step, vmcnt counts to 63),
+    // 32 with all 32 in flight (the compiler then drains the queue once per trip of the unrolled loop), or 16
+    if (depth == 20) { if (G.order == 0) STRIP_K(32, 0, 20); else if (G.order == 1) STRIP_K(32, 1, 20); else STRIP_K(32, 2, 20); }
+    else if (depth >= 32) { if (G.order == 0) STRIP_K(32, 0, 32); else if (G.order == 1) STRIP_K(32, 1, 32); else STRIP_K(32, 2, 32); }
+    else { if (G.order == 0) STRIP_K(16, 0, 16); else if (G.order == 1) STRIP_K(16, 1, 16); else STRIP_K(16, 2, 16); }
 #undef STRIP_K
 }
 
