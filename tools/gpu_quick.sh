@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_gpu_multirank.py -q -x -m gpu -k "host_staged" 2>&1 | tail -25
+for g in 3162 -160 -200; do timeout 900 python tools/ildu_bench.py $g ildu0 2>&1 | grep -v amdgpu | tail -1 | cut -c1-330; done
