@@ -1054,6 +1054,43 @@ def test_ildu_slab_pipeline_vs_level_walkers_and_oracle(orc, w, h, nk, tail, ord
     assert np.array_equal(z, orc.Ildu(A2).solve(r))
 
 
+@pytest.mark.parametrize("shape", [(1000, 1000, 1), (100, 100, 100), (192, 96, 40)])
+def test_ildu_pipelines_at_size_vs_oracle(orc, shape):
+    """The strip pipeline on the 1000^2 5-point grid and the slab pipeline on the 100^3 / 192x96x40 7-point grids
+    (the sizes DESIGN quotes): ILDU(0) applies bit-identical to the oracle's sequential sweeps and to the level
+    walkers, and ILDU-PCG stopping at the oracle's iteration count."""
+    nx, ny, nz = shape
+    n = nx * ny * nz
+    ptr, node, val = P.poisson2d_csr(nx, ny) if nz == 1 else P.laplace3d_csr(nx, ny, nz)
+    A = orc.CsrMatrix(n, n, ptr, node, val)
+    H = sg.csr_matrix(n, n, ptr, node, val)
+    opc = orc.Ildu(A)
+    pc = sg.ldu()
+    pc.setup(H)
+    assert pc.get("strips" if nz == 1 else "slabs", np.int32)[0] == (nx + 63) // 64
+    rs = np.random.RandomState(8)
+    r = rs.standard_normal(n)
+    zo = opc.solve(r)
+    for trial in range(3):
+        z = np.zeros(n)
+        pc.solve(H, z, r)
+        assert np.array_equal(z, zo), trial
+    sg.set_option("ildu_strips", 0)
+    try:
+        z2 = np.zeros(n)
+        pc.solve(H, z2, r)
+    finally:
+        sg.set_option("ildu_strips", 1)
+    assert np.array_equal(z2, zo)
+    b = np.full(n, 1.0 / n)
+    ur, itr, _, _ = orc.cg(A, b, tol=1e-8, pc=opc)
+    s = sg.cg(1e-8)
+    s.setup(H)
+    u = np.zeros(n)
+    s.solve(H, u, b, pc)
+    assert abs(s.iterations - itr) <= 1 and np.abs(u - ur).max() / np.abs(ur).max() <= 1e-9, (s.iterations, itr)
+
+
 @pytest.mark.parametrize("n,w,order,holes", [(64 * 70, 70, "sw", 0.0), (100 * 131 + 57, 131, "ws", 0.0), (257 * 300, 257, "mixed", 0.1),
                                             (640 * 64, 640, "sw", 0.3)])
 def test_ildu_strip_pipeline_vs_level_walkers_and_oracle(orc, n, w, order, holes):
