@@ -123,7 +123,8 @@ def set_option(name, value):
     """sgm_set_option: "csr_offset_dict" 1/0 (1-byte column codes for stencil-like matrices),
     "csr_row_owner" 1/0 (row-owner gather for int32-column matrices with rows <= 32 entries),
     "csr_sliced" 1/0 (slot-major slices + 4-bit codes for rows <= 8 entries / <= 15 offsets; default on),
-    "ell_offset_dict" 1/0."""
+    "ell_offset_dict" 1/0, "ell_colblock" 0/1/2, "ell_colblock_cols", "ell_colblock_chunks", "ell_colblock_rows" 0/256/512,
+    "ildu_strips" 1/0, "gmres_cgs2" 1/0."""
     _ck(lib().sgm_set_option(name.encode(), C.c_int(int(value))))
 
 

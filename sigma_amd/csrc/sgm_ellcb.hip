@@ -88,7 +88,7 @@ __global__ void k_ellcb_runs(int32_t ntiles, int32_t nb, int32_t R, int32_t max_
         return lo;
     };
     const int32_t a = first_row_at_least((int64_t)t * R), z = first_row_at_least((int64_t)(t + 1) * R);
-    fdesc[id] = make_int2(a, z - a);       // len <= R * max_d <= 8192; the base is filled in by k_ellcb_bases
+    fdesc[id] = make_int2(a, z - a);       // len <= R * max_d <= 16384; the base is filled in by k_ellcb_bases
 }
 // LDS base of every run of a tile (exclusive prefix sum over the column blocks)
 __global__ void k_ellcb_bases(int32_t ntiles, int32_t nb, int2 *__restrict__ fdesc)
@@ -205,7 +205,8 @@ __global__ __launch_bounds__(TPB) void k_ellcb_mul(int32_t ncol, int32_t cb, int
 // The 2-byte image positions of the lane's own row are requested before the copy, so their latency
 // hides behind it.
 // R rows per tile, TPB = CM * R threads: all TPB / 64 waves copy runs, the first R threads own the rows.
-template <int R, int TPB, int MAXD, bool ADD, bool DOT_W, bool DOT_YY>
+// FULLW: one run per wave instruction (64 lanes; tiles of 512 rows, runs average 54 entries) instead of two half-wave runs.
+template <int R, int TPB, int MAXD, bool ADD, bool DOT_W, bool DOT_YY, bool FULLW = false>
 __global__ __launch_bounds__(TPB) void k_ellcb_sum(int32_t n, int32_t max_d, int32_t nb, int32_t ntiles,
                                                    const int2 *__restrict__ fdesc, const uint16_t *__restrict__ lpos,
                                                    const double *__restrict__ P, double *__restrict__ y,
@@ -217,7 +218,9 @@ __global__ __launch_bounds__(TPB) void k_ellcb_sum(int32_t n, int32_t max_d, int
     __shared__ double red[TPB / 64];
     if (flag_done) { const int st = *flag_done; if (st && gen >= st) return; }
     constexpr int NW = TPB / 64;
-    const int lane = threadIdx.x & 63, half = lane >> 5, q = lane & 31;
+    const int lane = threadIdx.x & 63, half = FULLW ? 0 : lane >> 5, q = FULLW ? lane : lane & 31;
+    constexpr int RW = FULLW ? 64 : 32;          // lanes per run
+    constexpr int RPI = FULLW ? 1 : 2;           // runs per wave instruction
     const int wave = threadIdx.x >> 6;
     const int32_t per = (nb + NW - 1) / NW, bw0 = wave * per, bw1 = min(nb, bw0 + per);
     double dwy = 0.0, dyy = 0.0;
@@ -234,12 +237,12 @@ __global__ __launch_bounds__(TPB) void k_ellcb_sum(int32_t n, int32_t max_d, int
             const int32_t cnt = min(64, bw1 - b0);
             int2 d = make_int2(0, 0);
             if (lane < cnt) d = D[b0 + lane];
-            for (int32_t f0 = 0; f0 < cnt; f0 += 16) {          // 8 instructions x 2 runs in flight
+            for (int32_t f0 = 0; f0 < cnt; f0 += 8 * RPI) {     // 8 instructions x RPI runs in flight
                 double v[8];
                 int32_t o[8], l[8], g[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int src = f0 + 2 * u + half;          // (runs beyond cnt carry len 0)
+                    const int src = f0 + RPI * u + half;        // (runs beyond cnt carry len 0)
                     g[u] = __shfl(d.x, src, 64);
                     const uint32_t lb = (uint32_t)__shfl(d.y, src, 64);
                     l[u] = (int32_t)(lb & 0xffffu);
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(TPB) void k_ellcb_sum(int32_t n, int32_t max_d, int
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     if (q < l[u]) img[o[u] + q] = v[u];
-                    for (int32_t r = q + 32; r < l[u]; r += 32) img[o[u] + r] = P[g[u] + r];    // runs longer than a half-wave
+                    for (int32_t r = q + RW; r < l[u]; r += RW) img[o[u] + r] = P[g[u] + r];    // runs longer than RW lanes
                 }
             }
         }
@@ -352,7 +355,12 @@ int build_ell_colblock(Part &p)
     const int64_t total = (int64_t)p.n * p.max_d;
     const int32_t cb = c.cb, nb = (p.ncol_own + cb - 1) / cb;
     if (nb > 65535) return SGM_OK;
-    int32_t R = std::min(256, 8192 / p.max_d) / 64 * 64;          // tile image <= 64 KiB, whole waves
+    // tile image <= 64 KiB (two workgroups per CU) -- or, option ell_colblock_rows = 512 (automatic for rows <= 32 slots:
+    // runs twice as long, one 1024-thread workgroup per CU with a 128 KiB image) -- whole waves
+    static const int rows_env = getenv("SGM_ELLCB_ROWS") ? atoi(getenv("SGM_ELLCB_ROWS")) : 0;      // tuning aid
+    const int want_rows = rows_env ? rows_env : g_opt.ell_colblock_rows;
+    int32_t R = std::min(256, 8192 / p.max_d) / 64 * 64;
+    if ((want_rows == 512 || (want_rows == 0 && p.max_d >= 16)) && p.max_d <= 32) R = 512;
     if (R < 64) return SGM_OK;
     const int32_t ntiles = (p.n + R - 1) / R;
     p.cb_cols = cb; p.cb_nb = nb; p.cb_R = R; p.cb_ntiles = ntiles;
@@ -403,12 +411,17 @@ static void launch_sum(const Part &p, int grid, double *y, const double *w, doub
 {
     hipStream_t st = g_rt.stream;
     const size_t lds = (size_t)p.cb_R * p.max_d * 8;
-    constexpr int MAXD = 8192 / R;                   // the longest row a tile of R rows allows (R * max_d <= 8192)
-    constexpr int TPB = 2 * R;                       // twice as many waves copy runs as there are rows (C4: 696 -> see DESIGN)
+    constexpr bool BIG = R == 512;                   // 128 KiB image, 1024 threads, whole-wave runs
+    constexpr int MAXD = (BIG ? 16384 : 8192) / R;   // the longest row a tile of R rows allows
+    constexpr int TPB = BIG ? 1024 : 2 * R;          // twice as many waves copy runs as there are rows (C4: 696 -> see DESIGN)
 #define L(DW, DY)                                                                                                     \
-    hipLaunchKernelGGL((k_ellcb_sum<R, TPB, MAXD, ADD, DW, DY>), dim3(grid), dim3(TPB), lds, st, p.n, p.max_d, p.cb_nb, p.cb_ntiles, \
-                       (const int2 *)p.cb_fdesc, (const uint16_t *)p.cb_lpos, (const double *)p.cb_P, y, w, pwy, pyy, flag, \
-                       gen, chain)
+    do {                                                                                                              \
+        static bool attr = false;                                                                                     \
+        if (BIG && !attr) { (void)hipFuncSetAttribute((const void *)k_ellcb_sum<R, TPB, MAXD, ADD, DW, DY, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 32 * 8); attr = true; } \
+        hipLaunchKernelGGL((k_ellcb_sum<R, TPB, MAXD, ADD, DW, DY, BIG>), dim3(grid), dim3(TPB), lds, st, p.n, p.max_d, p.cb_nb, p.cb_ntiles, \
+                           (const int2 *)p.cb_fdesc, (const uint16_t *)p.cb_lpos, (const double *)p.cb_P, y, w, pwy, pyy, flag, \
+                           gen, chain);                                                                               \
+    } while (0)
     if (w && pyy) L(true, true);
     else if (w) L(true, false);
     else if (pyy) L(false, true);
@@ -435,7 +448,7 @@ int launch_ell_colblock(const Part &p, int grid, const double *x, double *y, boo
         if (add) launch_sum<RR, true>(p, grid, y, w, pwy, pyy, flag, gen, chain ? 1 : 0);                        \
         else launch_sum<RR, false>(p, grid, y, w, pwy, pyy, flag, gen, 0);                                      \
     }
-    R_CASE(64) R_CASE(128) R_CASE(192) R_CASE(256)
+    R_CASE(64) R_CASE(128) R_CASE(192) R_CASE(256) R_CASE(512)
 #undef R_CASE
     SGM_HIP(hipGetLastError());
     return SGM_OK;

@@ -39,6 +39,7 @@ struct Options {
     int csr_sliced = 1;            // rows <= 8 entries, <= 15 offsets: slot-major slices + 4-bit codes (k_csr_sl)
     int ell_colblock = 1;          // ELLPACK with random columns: column-blocked two-phase product (0 never, 1 automatic, 2 always)
     int ell_colblock_cols = 16384; // its column block (x entries staged in LDS per workgroup; even, <= 16384)
+    int ell_colblock_rows = 0;     // rows per tile of its sum phase: 0 automatic, 256 or 512
     int ell_colblock_chunks = 16;  // workgroups per column block in the multiply phase (C4 sweep: 4 / 8 / 16 -> 1.32 / 1.31 / 1.27 ms)
     int ildu_strips = 1;           // ILDU(0) factors of grid-like matrices (deps r-1, r-w): strip-pipelined triangular solves
     int gmres_cgs2 = 1;            // GMRES: blocked CGS-2 orthogonalisation (3 passes per step) instead of modified Gram-Schmidt

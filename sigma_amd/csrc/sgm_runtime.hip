@@ -109,6 +109,7 @@ int sgm_set_option(const char *name, int value)
     if (!strcmp(name, "ell_offset_dict")) { g_opt.ell_offset_dict = value; return SGM_OK; }
     if (!strcmp(name, "ell_colblock")) { g_opt.ell_colblock = value; return SGM_OK; }
     if (!strcmp(name, "ell_colblock_cols")) { g_opt.ell_colblock_cols = std::min(16384, std::max(2, value)) & ~1; return SGM_OK; }
+    if (!strcmp(name, "ell_colblock_rows")) { g_opt.ell_colblock_rows = value == 512 ? 512 : value == 256 ? 256 : 0; return SGM_OK; }
     if (!strcmp(name, "ell_colblock_chunks")) { g_opt.ell_colblock_chunks = std::max(1, value); return SGM_OK; }
     if (!strcmp(name, "ildu_strips")) { g_opt.ildu_strips = value; return SGM_OK; }
     if (!strcmp(name, "gmres_cgs2")) { g_opt.gmres_cgs2 = value; return SGM_OK; }

@@ -528,22 +528,27 @@ def test_randomised_ellpack_every_kernel_vs_oracle(orc, max_d):
             assert np.array_equal(ta, ta_ref), key
 
 
-@pytest.mark.parametrize("n,max_d,dmin,cols,chunks", [(3000, 32, None, 64, 3), (1000, 7, 3, 16, 1), (70001, 32, 24, 2048, 8),
-                                                       (513, 9, None, 2, 2), (5000, 100, 60, 256, 2), (20000, 16, None, 16384, 8)])
-def test_ell_column_blocked_two_phase_vs_oracle(orc, n, max_d, dmin, cols, chunks):
+@pytest.mark.parametrize("n,max_d,dmin,cols,chunks,rows", [(3000, 32, None, 64, 3, 0), (1000, 7, 3, 16, 1, 0), (70001, 32, 24, 2048, 8, 256),
+                                                            (513, 9, None, 2, 2, 0), (5000, 100, 60, 256, 2, 0), (20000, 16, None, 16384, 8, 0),
+                                                            (70001, 32, 24, 2048, 8, 512), (4000, 40, 20, 128, 2, 0), (3000, 32, None, 64, 3, 256)])
+def test_ell_column_blocked_two_phase_vs_oracle(orc, n, max_d, dmin, cols, chunks, rows):
     """k_ellcb (sgm_ellcb.hip): the two-phase product for ELLPACK matrices with random columns -- products
     through LDS-resident column blocks of x, then row sums in slot order from an LDS image of the tile's
     products.  Forced on (option ell_colblock = 2) for small matrices with small column blocks so that many
-    blocks, chunks, odd run boundaries, padded rows (0 * x(last) terms), partial tiles and every tile height
-    (R = 64 / 128 / 192 / 256 by max_d) are exercised: bit-exact against the oracle, like k_ell_spmv."""
+    blocks, chunks, odd run boundaries, padded rows (0 * x(last) terms), partial tiles and the tile heights
+    (R = 64 / 192 / 256 by max_d; 512 with whole-wave runs for rows of 16..32 slots, or 256 on request) are exercised:
+    bit-exact against the oracle, like k_ell_spmv."""
     sg.set_option("ell_colblock", 2)
     sg.set_option("ell_colblock_cols", cols)
     sg.set_option("ell_colblock_chunks", chunks)
+    sg.set_option("ell_colblock_rows", rows)
     try:
         ei, ej, ev = P.random_regular_ell(n, max_d, 777 + n, dmin=dmin)
         A = orc.EllMatrix.from_edges(n, n, ei, ej, ev)
         H = sg.ellpack_matrix(n, n, A.node, A.val)
         assert H.kernel.startswith("k_ellcb"), H.kernel
+        want_r = 512 if (rows != 256 and 16 <= max_d <= 32) else min(256, 8192 // max_d) // 64 * 64
+        assert H.kernel.endswith(f"R={want_r}>"), (H.kernel, want_r)
         rs = np.random.RandomState(n)
         x, y0 = rs.standard_normal(n), rs.standard_normal(n)
         y = np.full(n, -9.0)
@@ -592,6 +597,7 @@ def test_ell_column_blocked_two_phase_vs_oracle(orc, n, max_d, dmin, cols, chunk
         sg.set_option("ell_colblock", 1)
         sg.set_option("ell_colblock_cols", 16384)
         sg.set_option("ell_colblock_chunks", 16)
+        sg.set_option("ell_colblock_rows", 0)
 
 
 @pytest.mark.parametrize("nparts", [2, 3, 5])
