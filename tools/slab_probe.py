@@ -29,7 +29,7 @@ for nx, ny, nz in shapes:
     st = pc.get("slabs", np.int32)
     out = {"grid": [nx, ny, nz], "slabs": st.tolist(), "apply_us": dt * 1e6}
     if st[0]:
-        ck = pc.get("slab_clocks", np.int64).reshape(-1, 2)
+        ck = pc.get("slab_clocks", np.int64)[:2 * int(st[0]) * int(st[1])].reshape(-1, 2)      # chain start / end per (group, strip)
         t0c = ck[:, 0].min()
         rows = [(round((a - t0c) / 100.0, 1), round((b - t0c) / 100.0, 1)) for a, b in ck]
         print("   chain start/end us per (group, strip):", rows[:8], "...", rows[-4:])
