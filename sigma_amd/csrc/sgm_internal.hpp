@@ -59,6 +59,8 @@ struct Runtime {
 extern Runtime g_rt;
 int require_init();
 int finish();   // hipStreamSynchronize unless async
+// pageable host <-> device, chunked through pinned buffers (synchronous)
+int copy_big(void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
 
 template <class T>
 int dalloc(T **p, size_t count)

@@ -19,6 +19,8 @@
 // an LDS ring: a level then costs LDS reads + a barrier instead of four dependent global
 // round trips (3.9 us -> see DESIGN.md).
 #include "sgm_internal.hpp"
+
+#include <chrono>
 #include <type_traits>
 
 #include <algorithm>
@@ -120,6 +122,8 @@ struct IlduState {
     // slab-pipeline path (3-D grid factors, sgm_trsv3.hip); slab_ok: it reproduced the level-scheduled apply at setup
     Slab3 *slab = nullptr;
     bool slab_ok = false;
+    // the level-scheduled structures are built on first need when a pipelined path serves the pattern
+    bool levels_ready = false, levels_pattern = false;
 };
 
 struct sgm_pc_s {
@@ -1010,7 +1014,7 @@ int build_grid(GridTri &G, int32_t n, int32_t w, const std::vector<int32_t> &ptr
     SGM_TRY(dalloc(&G.row, (size_t)G.NP));
     SGM_TRY(dalloc(&G.edge, (size_t)G.NI * (G.S + 64)));
     SGM_TRY(dalloc(&G.progress, (size_t)G.NI + 1));
-    SGM_HIP(hipMemcpy(G.row, hrow.data(), (size_t)G.NP * 4, hipMemcpyHostToDevice));
+    SGM_TRY(copy_big(G.row, hrow.data(), (size_t)G.NP * 4, hipMemcpyHostToDevice));
     SGM_HIP(hipMemset(G.edge, 0, (size_t)G.NI * (G.S + 64) * 8));
     G.on = true;
     return SGM_OK;
@@ -1028,7 +1032,7 @@ int refresh_grid_values(GridTri &G, const std::vector<double> &val)
         if (G.order == 2) h[p].code = G.h_code[p];             // flag word
         else h[p].code = ((G.h_code[p] & 1) ? 0xffffffffull : 0ull) | ((G.h_code[p] & 2) ? 0xffffffff00000000ull : 0ull);   // AND masks
     }
-    SGM_HIP(hipMemcpy(G.rec, h.data(), (size_t)G.NP * sizeof(StripRec), hipMemcpyHostToDevice));
+    SGM_TRY(copy_big(G.rec, h.data(), (size_t)G.NP * sizeof(StripRec), hipMemcpyHostToDevice));
     return SGM_OK;
 }
 
@@ -1068,6 +1072,55 @@ void apply_grid(const IlduState *S, const double *r, double *z, const int *flag)
     trsv_grid(S->gU, S->gxU, flag);                                       // (I+U) x = x
     hipLaunchKernelGGL(k_grid_scatter, dim3(gu), dim3(kBlock), 0, st, S->gU.NP, z, (const double *)S->gxU,
                        (const int32_t *)S->gU.row, flag);
+}
+
+// The level-scheduled structures of both factors (index work when the pattern is new, values always) and the work
+// vectors of apply_levels.  At setup when no pipelined path serves the pattern, otherwise on first need.
+int ensure_levels(IlduState *S)
+{
+    if (S->levels_ready) return SGM_OK;
+    const int32_t n = S->n;
+    const bool fresh = !S->levels_pattern;
+    SGM_TRY(upload_tri(S->L, n, S->hLptr, S->hLnode, S->hLval, true, fresh));
+    SGM_TRY(upload_tri(S->U, n, S->hUptr, S->hUnode, S->hUval, false, fresh));
+    if (fresh) {
+        dfree(S->D); dfree(S->xpL); dfree(S->xpU); dfree(S->Dp); dfree(S->mapLU);
+        S->D = S->xpL = S->xpU = S->Dp = nullptr; S->mapLU = nullptr;
+        SGM_TRY(dalloc(&S->D, (size_t)n));
+        SGM_TRY(dalloc(&S->xpL, (size_t)n + kNarrow));     // + scratch slots of the level walker
+        SGM_TRY(dalloc(&S->xpU, (size_t)n + kNarrow));
+        SGM_TRY(dalloc(&S->Dp, (size_t)n));
+        SGM_TRY(dalloc(&S->mapLU, (size_t)n));
+        std::vector<int32_t> map((size_t)std::max(n, 1));
+        for (int32_t p = 0; p < n; ++p) map[p] = S->L.h_pos[S->U.h_order[p]];
+        if (n) SGM_HIP(hipMemcpy(S->mapLU, map.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    }
+    std::vector<double> dp((size_t)std::max(n, 1));
+    for (int32_t p = 0; p < n; ++p) dp[p] = S->hD[S->U.h_order[p]];
+    if (n) {
+        SGM_HIP(hipMemcpy(S->D, S->hD.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+        SGM_HIP(hipMemcpy(S->Dp, dp.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    }
+    S->levels_pattern = true;
+    S->levels_ready = true;
+    return SGM_OK;
+}
+
+// ldu_solve on the host factors, row by row in stored order: the yardstick of the setup self-check only
+void host_sweeps(const IlduState *S, const double *r, double *x)
+{
+    const int32_t n = S->n;
+    for (int32_t i = 0; i < n; ++i) {
+        double z = r[i];
+        for (int32_t k = S->hLptr[i] - 1; k < S->hLptr[i + 1] - 1; ++k) z = z - S->hLval[k] * x[S->hLnode[k] - 1];
+        x[i] = z;
+    }
+    for (int32_t i = 0; i < n; ++i) x[i] = x[i] / S->hD[i];
+    for (int32_t i = n - 1; i >= 0; --i) {
+        double z = x[i];
+        for (int32_t k = S->hUptr[i] - 1; k < S->hUptr[i + 1] - 1; ++k) z = z - S->hUval[k] * x[S->hUnode[k] - 1];
+        x[i] = z;
+    }
 }
 
 void trsv(const TriFactor &T, double *xp, const int *flag);
@@ -1149,13 +1202,26 @@ void trsv(const TriFactor &T, double *xp, const int *flag)
 // numbered >= ncol_own, are dropped).
 int download_block(const Part &p, std::vector<int32_t> &ptr1, std::vector<int32_t> &node1, std::vector<double> &val)
 {
+    SGM_HIP(hipStreamSynchronize(g_rt.stream));
+    if (p.n_halo == 0) {          // the whole part is its own diagonal block: straight into the 1-based arrays
+        ptr1.resize((size_t)p.n + 1);
+        node1.resize((size_t)p.nnz);
+        val.resize((size_t)p.nnz);
+        SGM_TRY(copy_big(ptr1.data(), p.rowptr, ptr1.size() * 4, hipMemcpyDeviceToHost));
+        if (p.nnz) {
+            SGM_TRY(copy_big(node1.data(), p.col, node1.size() * 4, hipMemcpyDeviceToHost));
+            SGM_TRY(copy_big(val.data(), p.val, val.size() * 8, hipMemcpyDeviceToHost));
+        }
+        for (auto &v : ptr1) v += 1;
+        for (auto &v : node1) v += 1;
+        return SGM_OK;
+    }
     std::vector<int32_t> hp((size_t)p.n + 1), hc((size_t)p.nnz);
     std::vector<double> hv((size_t)p.nnz);
-    SGM_HIP(hipStreamSynchronize(g_rt.stream));
-    SGM_HIP(hipMemcpy(hp.data(), p.rowptr, hp.size() * 4, hipMemcpyDeviceToHost));
+    SGM_TRY(copy_big(hp.data(), p.rowptr, hp.size() * 4, hipMemcpyDeviceToHost));
     if (p.nnz) {
-        SGM_HIP(hipMemcpy(hc.data(), p.col, hc.size() * 4, hipMemcpyDeviceToHost));
-        SGM_HIP(hipMemcpy(hv.data(), p.val, hv.size() * 8, hipMemcpyDeviceToHost));
+        SGM_TRY(copy_big(hc.data(), p.col, hc.size() * 4, hipMemcpyDeviceToHost));
+        SGM_TRY(copy_big(hv.data(), p.val, hv.size() * 8, hipMemcpyDeviceToHost));
     }
     ptr1.assign((size_t)p.n + 1, 1);
     node1.clear();
@@ -1208,6 +1274,7 @@ int pc_apply_parts(sgm_pc pc, sgm_mat A, const double *const *r, double *const *
                 slab3_apply(S->slab, r[ip], z[ip], flag);
                 continue;
             }
+            SGM_TRY(ensure_levels(&pc->ild[ip]));              // (built on first need when a pipelined path served the pattern so far)
             apply_levels(S, r[ip], z[ip], flag);
         }
     }
@@ -1294,26 +1361,29 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
         IlduState *S = &pc->ild[ip];
         std::vector<int32_t> ptr1, node1;
         std::vector<double> val;
+        static const bool timing = getenv("SGM_PC_TIMING") != nullptr;       // phase times of the setup on stderr (tuning aid)
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto t_prev = now();
+        auto lap = [&](const char *what) {
+            if (!timing) return;
+            (void)hipStreamSynchronize(g_rt.stream);
+            const auto t = now();
+            fprintf(stderr, "[sigma_hip] ildu setup: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+            t_prev = t;
+        };
         SGM_TRY(download_block(A->parts[ip], ptr1, node1, val));
+        lap("download");
         const int32_t n = A->parts[ip].n;
         const bool fresh = S->n != n || S->hLptr.empty();      // ldu_solvers.f90:117-125: pattern once
         if (fresh) ildu_pattern(S, n, ptr1, node1);
+        lap("pattern (host)");
         S->n = n;
         ildu_factor(S, n, ptr1, node1, val);
-        SGM_TRY(upload_tri(S->L, n, S->hLptr, S->hLnode, S->hLval, true, fresh));
-        SGM_TRY(upload_tri(S->U, n, S->hUptr, S->hUnode, S->hUval, false, fresh));
-        if (fresh) {
-            dfree(S->D); dfree(S->xpL); dfree(S->xpU); dfree(S->Dp); dfree(S->mapLU);
-            SGM_TRY(dalloc(&S->D, (size_t)n));
-            SGM_TRY(dalloc(&S->xpL, (size_t)n + kNarrow));     // + scratch slots of the level walker
-            SGM_TRY(dalloc(&S->xpU, (size_t)n + kNarrow));
-            SGM_TRY(dalloc(&S->Dp, (size_t)n));
-            SGM_TRY(dalloc(&S->mapLU, (size_t)n));
-            std::vector<int32_t> map((size_t)std::max(n, 1));
-            for (int32_t p = 0; p < n; ++p) map[p] = S->L.h_pos[S->U.h_order[p]];
-            if (n) SGM_HIP(hipMemcpy(S->mapLU, map.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-        }
-        if (fresh) {        // grid-like factors get the strip layout as well (the level-scheduled one stays)
+        lap("factorisation (host)");
+        // (the level-scheduled structures: ensure_levels, below or on first need)
+        S->levels_ready = false;
+        if (fresh) S->levels_pattern = false;
+        if (fresh) {        // grid-like factors get the strip layout
             free_grid(S->gL); free_grid(S->gU);
             dfree(S->gxL); dfree(S->gxU); dfree(S->gDp); dfree(S->gmapLU);
             S->gxL = S->gxU = S->gDp = nullptr; S->gmapLU = nullptr;
@@ -1329,7 +1399,7 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
                     SGM_TRY(dalloc(&S->gmapLU, (size_t)S->gU.NP));
                     std::vector<int32_t> map((size_t)S->gU.NP, -1);
                     for (int32_t r = 0; r < n; ++r) map[S->gU.h_pos[r]] = S->gL.h_pos[r];
-                    SGM_HIP(hipMemcpy(S->gmapLU, map.data(), map.size() * 4, hipMemcpyHostToDevice));
+                    SGM_TRY(copy_big(S->gmapLU, map.data(), map.size() * 4, hipMemcpyHostToDevice));
                 } else { free_grid(S->gL); free_grid(S->gU); }
             }
             slab3_free(S->slab);
@@ -1338,6 +1408,7 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             if (g_opt.ildu_strips && !(S->gL.on && S->gU.on))
                 SGM_TRY(slab3_build(&S->slab, n, S->hLptr, S->hLnode, S->hUptr, S->hUnode));
         }
+        lap("strip / slab index work");
         if (S->slab) SGM_TRY(slab3_refresh(S->slab, S->hLval, S->hUval, S->hD));
         const bool have_grid = S->gL.on && S->gU.on;
         if (have_grid) {
@@ -1345,27 +1416,27 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             SGM_TRY(refresh_grid_values(S->gU, S->hUval));
             std::vector<double> gd((size_t)S->gU.NP, 1.0);
             for (int32_t r = 0; r < n; ++r) gd[S->gU.h_pos[r]] = S->hD[r];
-            SGM_HIP(hipMemcpy(S->gDp, gd.data(), gd.size() * 8, hipMemcpyHostToDevice));
+            SGM_TRY(copy_big(S->gDp, gd.data(), gd.size() * 8, hipMemcpyHostToDevice));
         }
-        std::vector<double> dp((size_t)std::max(n, 1));
-        for (int32_t p = 0; p < n; ++p) dp[p] = S->hD[S->U.h_order[p]];
-        if (n) {
-            SGM_HIP(hipMemcpy(S->D, S->hD.data(), (size_t)n * 8, hipMemcpyHostToDevice));
-            SGM_HIP(hipMemcpy(S->Dp, dp.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+        if (!have_grid && !S->slab) {         // no pipelined path for this pattern: the level walkers serve it
+            SGM_TRY(ensure_levels(S));
+            lap("level schedules + upload");
         }
+        lap("strip / slab records");
         if ((have_grid || S->slab) && fresh) {
-            // the strip pipeline hands data between workgroups inside one launch: before it is trusted with this
-            // pattern it must reproduce the level-scheduled apply bit for bit on a test vector (and raise no abort)
+            // the pipelines hand data between workgroups inside one launch: before one is trusted with this pattern it
+            // must reproduce the row-by-row sweeps of ldu_solve (ldu_solvers.f90:160-176, :208-265; run here on the host
+            // factors, in stored order) bit for bit on a test vector, and raise no abort.  This decides which DEVICE path
+            // serves the pattern; no result ever comes from the host sweep.
             std::vector<double> rt((size_t)n), za((size_t)n), zb((size_t)n);
             for (int32_t i = 0; i < n; ++i) rt[i] = 1.0 + 0.25 * (i % 7) - 0.125 * (i % 3);
+            host_sweeps(S, rt.data(), za.data());
             double *dr = nullptr, *dz = nullptr;
             SGM_TRY(dalloc(&dr, (size_t)n));
             int rc = dalloc(&dz, (size_t)n);
             if (rc != SGM_OK) { dfree(dr); return rc; }
             hipStream_t st2 = g_rt.stream;
             (void)hipMemcpyAsync(dr, rt.data(), (size_t)n * 8, hipMemcpyHostToDevice, st2);
-            apply_levels(S, dr, dz, nullptr);
-            (void)hipMemcpyAsync(za.data(), dz, (size_t)n * 8, hipMemcpyDeviceToHost, st2);
             (void)hipMemsetAsync(dz, 0, (size_t)n * 8, st2);
             if (have_grid) apply_grid(S, dr, dz, nullptr);
             else slab3_apply(S->slab, dr, dz, nullptr);
@@ -1383,6 +1454,11 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             if (!same)
                 fprintf(stderr, "[sigma_hip] ILDU %s pipeline disabled for this matrix (self-check: abort %d/%d)\n",
                         have_grid ? "strip" : "slab", abL, abU);
+            lap("self-check");
+            if (!same) {
+                SGM_TRY(ensure_levels(S));
+                lap("level schedules + upload");
+            }
         }
     }
     return SGM_OK;
@@ -1480,6 +1556,7 @@ int sgm_pc_get(sgm_pc pc, const char *name, void *out, size_t bytes, size_t *nee
             src = ck.data(); sz = ck.size() * 8;
         }
         else if (nm == "levels") {
+            SGM_TRY(ensure_levels(&pc->ild[0]));
             static int32_t lv[2];
             lv[0] = (int32_t)S->L.level_ptr.size() - 1;
             lv[1] = (int32_t)S->U.level_ptr.size() - 1;

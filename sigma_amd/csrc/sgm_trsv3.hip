@@ -471,8 +471,8 @@ int build_tri(SlabTri &G, int32_t n, int32_t w, int32_t h, const std::vector<int
     SGM_TRY(dalloc(&G.row, (size_t)G.NP));
     SGM_TRY(dalloc(&G.progress, (size_t)G.NB * G.NI + 1));
     SGM_TRY(dalloc(&G.clk, ((size_t)G.NB * G.NI * (2 + G.S / 16) + (size_t)G.NB * 512)));
-    SGM_HIP(hipMemcpy(G.row, hrow.data(), (size_t)G.NP * 4, hipMemcpyHostToDevice));
-    SGM_HIP(hipMemcpy(G.code, G.h_code.data(), (size_t)G.NP * 4, hipMemcpyHostToDevice));
+    SGM_TRY(copy_big(G.row, hrow.data(), (size_t)G.NP * 4, hipMemcpyHostToDevice));
+    SGM_TRY(copy_big(G.code, G.h_code.data(), (size_t)G.NP * 4, hipMemcpyHostToDevice));
     SGM_HIP(hipMemset(G.clk, 0, ((size_t)G.NB * G.NI * (2 + G.S / 16) + (size_t)G.NB * 512) * 8));
     G.on = true;
     return SGM_OK;
@@ -487,7 +487,7 @@ int refresh_tri(SlabTri &G, const std::vector<double> &val)
         hrec[4 * p + 2] = G.h_src[2][p] >= 0 ? val[G.h_src[2][p]] : 0.0;
         hrec[4 * p + 3] = 0.0;
     }
-    SGM_HIP(hipMemcpy(G.rec, hrec.data(), hrec.size() * 8, hipMemcpyHostToDevice));
+    SGM_TRY(copy_big(G.rec, hrec.data(), hrec.size() * 8, hipMemcpyHostToDevice));
     return SGM_OK;
 }
 
@@ -588,7 +588,7 @@ int slab3_refresh(Slab3 *S, const std::vector<double> &Lval, const std::vector<d
     SGM_TRY(refresh_tri(S->U, Uval));
     std::vector<double> gd((size_t)S->U.NP, 1.0);
     for (int32_t r = 0; r < S->n; ++r) gd[S->U.h_pos[r]] = D[r];
-    SGM_HIP(hipMemcpy(S->Dp, gd.data(), gd.size() * 8, hipMemcpyHostToDevice));
+    SGM_TRY(copy_big(S->Dp, gd.data(), gd.size() * 8, hipMemcpyHostToDevice));
     return SGM_OK;
 }
 
