@@ -207,3 +207,43 @@ def test_partition_rows_by_nnz_balances_bytes():
         assert starts[0] == 0 and starts[-1] == n and np.all(starts[1:-1] % 16 == 0)
         w = np.array([12 * (ptr[starts[i + 1]] - ptr[starts[i]]) + 20 * (starts[i + 1] - starts[i]) for i in range(parts)], float)
         assert w.max() / w.mean() < 1.05
+
+
+def test_rectangular_leaf_planners_without_any_transport():
+    """An off-diagonal block of a composite (sgm_csr_create_dist_rect): rows partitioned by one list, x by another.
+    The same planners, fed the COLUMN partition, give every rank its halo and the owners their request lists;
+    the rows computed on [owned slice of x | halo] equal the serial block product bit for bit."""
+    import scipy.sparse as sp
+    import oracle as orc
+    import sigma_amd as sg
+    from sigma_amd import problems as P
+    ptr, node, val = P.laplace3d_csr(9, 8, 10)
+    n = 720
+    Asp = sp.csr_matrix((val, node - 1, ptr - 1), shape=(n, n))
+    m = 302
+    B = Asp[:m, m:].tocsr()                      # 302 x 418: rows of block row 1, columns of block column 2
+    B.sort_indices()
+    Bo = orc.CsrMatrix(m, n - m, (B.indptr + 1).astype(np.int32), (B.indices + 1).astype(np.int32), B.data.copy())
+    x = np.random.RandomState(2).standard_normal(n - m)
+    y_ref = Bo.matvec(x)
+    for world in (2, 3, 5):
+        rs = sg.partition_rows_by_nnz((Asp[:m].indptr + 1).astype(np.int32), world, align=2)
+        cs = sg.partition_rows_by_nnz((Asp[m:].indptr + 1).astype(np.int32), world, align=2)
+        assert rs[-1] == m and cs[-1] == n - m and not np.array_equal(rs, cs)
+        asked = {q: [] for q in range(world)}
+        for r in range(world):
+            L = B[int(rs[r]):int(rs[r + 1])]
+            c0, nc = int(cs[r]), int(cs[r + 1] - cs[r])
+            lnode, halo = sg.halo_plan_host(nc, c0, (L.indices + 1).astype(np.int32))
+            assert np.all((halo - 1 < c0) | (halo - 1 >= c0 + nc)) and np.all(np.diff(halo) > 0)
+            want, want_off, req = sg.dist_plan_host(r, world, cs, halo)
+            assert want[r] == 0 and want.sum() == len(halo)
+            for q in range(world):
+                mine = req[want_off[q]:want_off[q] + want[q]]
+                glob = halo[want_off[q]:want_off[q] + want[q]] - 1
+                assert np.all((glob >= cs[q]) & (glob < cs[q + 1])), "a halo column was asked of the wrong owner"
+                assert np.array_equal(mine, (glob - cs[q]).astype(np.int32))
+                asked[q].append(len(mine))
+            xext = np.concatenate([x[c0:c0 + nc], x[halo - 1]])
+            A_loc = orc.CsrMatrix(L.shape[0], nc + len(halo), (L.indptr + 1).astype(np.int32), lnode, L.data.copy())
+            assert np.array_equal(A_loc.matvec(xext), y_ref[int(rs[r]):int(rs[r + 1])]), (world, r)
