@@ -91,7 +91,7 @@ struct GridTri {
     int64_t NP = 0;                                             // positions (incl. padding) = NI * S * 64
     StripRec *rec = nullptr;                                    // device
     int32_t *row = nullptr;                                     // device: position -> row (-1 = padding)
-    double *edge = nullptr;                                     // device: NI x (S + 64): lane 63's result of every step
+    double *edge = nullptr;                                     // device: NI x (S + 72): lane 63's result of every step (kEdgeEmpty = not yet), 2 clocks
     int32_t *progress = nullptr;                                // device: NI + 1: steps whose edge values are published; [NI] = abort
     std::vector<int32_t> h_pos;                                 // host: row -> position
     std::vector<int32_t> h_srcS, h_srcW;                        // host: position -> entry of the factor's val array (-1 = none)
@@ -496,6 +496,9 @@ constexpr int kStripDepth = 32;          // records in flight per lane (16: 0.91
 constexpr int kStripChunk = 8;           // steps between LDS hand-offs
 constexpr int kStripRing = 512;          // edge values the LDS rings hold (steps)
 constexpr int kStripSpinLimit = 1 << 22;
+constexpr int kEdgePad = 72;             // an edge row: S + 64 values (a strip reads its left neighbour's step t + 63), 2 clocks
+// "not yet written": a SIGNALLING NaN no subtraction can produce (arithmetic quiets NaNs), so the edge values are their own flags
+constexpr unsigned long long kEdgeEmpty = 0x7FF4A5A5A5A5A5A5ull;
 typedef double f64x2s __attribute__((ext_vector_type(2)));
 __device__ inline double dpp_shift_up(double v, double lane0)
 {
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(192) void k_trsv_strip(int32_t NI, int32_t S, const
         }
         // diagnostics (sgm_pc_get "strip_clocks"): start / end of this strip's chain in the two unused tail slots of its edge row
         if (lane == 0) {
-            long long *tail = reinterpret_cast<long long *>(edge + (int64_t)ib * (S + 64) + S + 62);
+            long long *tail = reinterpret_cast<long long *>(edge + (int64_t)ib * (S + kEdgePad) + S + 64);
             tail[0] = clk0;
             tail[1] = wall_clock64();
         }
@@ -596,19 +599,20 @@ __global__ __launch_bounds__(192) void k_trsv_strip(int32_t NI, int32_t S, const
     }
     // ---- helper waves: wave 1 forwards this strip's edge values, wave 2 fetches the left strip's
     const bool forwarder = threadIdx.x < 128;
-    double *my_edge = edge + (int64_t)ib * (S + 64);
-    const double *left_edge = edge + (int64_t)(ib > 0 ? ib - 1 : 0) * (S + 64);
+    double *my_edge = edge + (int64_t)ib * (S + kEdgePad);
+    const double *left_edge = edge + (int64_t)(ib > 0 ? ib - 1 : 0) * (S + kEdgePad);
     int spins = 0;
     if (forwarder) {
-        int32_t sent = 0;            // steps of this strip's edge values published
+        // edge values are their own flags (kEdgeEmpty until written, reset before every sweep): no progress word, no wait
+        // for the stores to be acknowledged
+        int32_t sent = 0;            // steps of this strip's edge values stored
         while (sent < S) {
-            const int32_t made = __hip_atomic_load(&out_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int32_t made = min(__hip_atomic_load(&out_count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP), S);
             if (made > sent) {
                 for (int32_t q = sent + lane; q < made; q += 64)
                     __hip_atomic_store(my_edge + q, out_ring[q & (kStripRing - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) {
-                    __hip_atomic_store(progress + ib, made, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(progress + ib, made, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // (diagnostics only)
                     __hip_atomic_store(&out_sent, made, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 sent = made;
@@ -621,6 +625,8 @@ __global__ __launch_bounds__(192) void k_trsv_strip(int32_t NI, int32_t S, const
                 return;
             }
         }
+        // the right strip reads 63 entries past the last step (padding rows there: any value that is not kEdgeEmpty)
+        __hip_atomic_store(my_edge + S + lane, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     if (ib == 0) return;
@@ -630,15 +636,17 @@ __global__ __launch_bounds__(192) void k_trsv_strip(int32_t NI, int32_t S, const
         const int32_t done = __hip_atomic_load(&out_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const int32_t room = done + kStripRing - 2 * CH;
         if (got - done > 128) { __builtin_amdgcn_s_sleep(32); continue; }       // comfortably ahead of the chain: stay out of its way
-        if (got < room) {
-            int32_t left_known = __hip_atomic_load(progress + ib - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            left_known = __builtin_amdgcn_readfirstlane(left_known);
-            int32_t upto = min(min(left_known - 63, S), room);      // steps t < upto are served by left steps < left_known
-            if (left_known >= S) upto = min(S, room);
-            if (upto > got) {
-                for (int32_t q = got + lane; q < upto; q += 64)
-                    in_ring[q & (kStripRing - 1)] = __hip_atomic_load(left_edge + q + 63, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                got = upto;
+        const int32_t cnt = min(64, min(S, room) - got);
+        if (cnt > 0) {
+            // ONE memory round trip per look: load the next entries and keep the leading ones that have been written
+            double v = 0.0;
+            if (lane < cnt) v = __hip_atomic_load(left_edge + got + 63 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool ok = lane >= cnt || (unsigned long long)__double_as_longlong(v) != kEdgeEmpty;
+            const unsigned long long miss = ~__ballot(ok);
+            const int32_t nvalid = miss ? min(cnt, (int32_t)__builtin_ctzll(miss)) : cnt;
+            if (nvalid > 0) {
+                if (lane < nvalid) in_ring[(got + lane) & (kStripRing - 1)] = v;
+                got += nvalid;
                 if (lane == 0) __hip_atomic_store(&in_avail, got >= S ? S + kStripRing : got, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 spins = 0;
                 continue;
@@ -658,22 +666,25 @@ __global__ __launch_bounds__(192) void k_trsv_strip(int32_t NI, int32_t S, const
 // position-space gather / hand-over / scatter of the strip path (padding positions hold 0)
 // (gather and transition also clear the progress words of the sweep that follows)
 __global__ void k_grid_gather(int64_t np, StripRec *__restrict__ rec, const double *__restrict__ src,
-                              const int32_t *__restrict__ row, int32_t *__restrict__ progress, int32_t nprog, const int *flag)
+                              const int32_t *__restrict__ row, int32_t *__restrict__ progress, int32_t nprog,
+                              unsigned long long *__restrict__ edge, int64_t nedge, const int *flag)
 {
     if (flag && *flag) return;
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t q = p; q < nprog; q += stride) progress[q] = 0;
+    for (int64_t q = p; q < nedge; q += stride) edge[q] = kEdgeEmpty;
     for (; p < np; p += stride) { const int32_t r = row[p]; rec[p].rhs = r >= 0 ? src[r] : 0.0; }
 }
 __global__ void k_grid_transition(int64_t np, StripRec *__restrict__ recU, const double *__restrict__ xpL,
                                   const int32_t *__restrict__ mapLU, const double *__restrict__ Dp, int32_t *__restrict__ progress,
-                                  int32_t nprog, const int *flag)
+                                  int32_t nprog, unsigned long long *__restrict__ edge, int64_t nedge, const int *flag)
 {
     if (flag && *flag) return;
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t q = p; q < nprog; q += stride) progress[q] = 0;
+    for (int64_t q = p; q < nedge; q += stride) edge[q] = kEdgeEmpty;
     for (; p < np; p += stride) { const int32_t q = mapLU[p]; recU[p].rhs = q >= 0 ? xpL[q] / Dp[p] : 0.0; }   // x = x / D
 }
 __global__ void k_grid_scatter(int64_t np, double *__restrict__ dst, const double *__restrict__ xp,
@@ -1012,10 +1023,10 @@ int build_grid(GridTri &G, int32_t n, int32_t w, const std::vector<int32_t> &ptr
     }
     SGM_TRY(dalloc(&G.rec, (size_t)G.NP));
     SGM_TRY(dalloc(&G.row, (size_t)G.NP));
-    SGM_TRY(dalloc(&G.edge, (size_t)G.NI * (G.S + 64)));
+    SGM_TRY(dalloc(&G.edge, (size_t)G.NI * (G.S + kEdgePad)));
     SGM_TRY(dalloc(&G.progress, (size_t)G.NI + 1));
     SGM_TRY(copy_big(G.row, hrow.data(), (size_t)G.NP * 4, hipMemcpyHostToDevice));
-    SGM_HIP(hipMemset(G.edge, 0, (size_t)G.NI * (G.S + 64) * 8));
+    SGM_HIP(hipMemset(G.edge, 0, (size_t)G.NI * (G.S + kEdgePad) * 8));
     G.on = true;
     return SGM_OK;
 }
@@ -1065,10 +1076,11 @@ void apply_grid(const IlduState *S, const double *r, double *z, const int *flag)
     hipStream_t st = g_rt.stream;
     const int gl = vec_grid(S->gL.NP), gu = vec_grid(S->gU.NP);
     hipLaunchKernelGGL(k_grid_gather, dim3(gl), dim3(kBlock), 0, st, S->gL.NP, S->gL.rec, r, (const int32_t *)S->gL.row, S->gL.progress,
-                       S->gL.NI + 1, flag);
+                       S->gL.NI + 1, reinterpret_cast<unsigned long long *>(S->gL.edge), (int64_t)S->gL.NI * (S->gL.S + kEdgePad), flag);
     trsv_grid(S->gL, S->gxL, flag);                                       // (I+L) x = b
     hipLaunchKernelGGL(k_grid_transition, dim3(gu), dim3(kBlock), 0, st, S->gU.NP, S->gU.rec, (const double *)S->gxL,
-                       (const int32_t *)S->gmapLU, (const double *)S->gDp, S->gU.progress, S->gU.NI + 1, flag);       // x = x / D
+                       (const int32_t *)S->gmapLU, (const double *)S->gDp, S->gU.progress, S->gU.NI + 1,
+                       reinterpret_cast<unsigned long long *>(S->gU.edge), (int64_t)S->gU.NI * (S->gU.S + kEdgePad), flag);       // x = x / D
     trsv_grid(S->gU, S->gxU, flag);                                       // (I+U) x = x
     hipLaunchKernelGGL(k_grid_scatter, dim3(gu), dim3(kBlock), 0, st, S->gU.NP, z, (const double *)S->gxU,
                        (const int32_t *)S->gU.row, flag);
@@ -1540,7 +1552,7 @@ int sgm_pc_get(sgm_pc pc, const char *name, void *out, size_t bytes, size_t *nee
             ck.assign((size_t)2 * S->gL.NI, 0);
             SGM_HIP(hipStreamSynchronize(g_rt.stream));
             for (int32_t i = 0; i < S->gL.NI; ++i)
-                SGM_HIP(hipMemcpy(&ck[2 * i], S->gL.edge + (int64_t)i * (S->gL.S + 64) + S->gL.S + 62, 16, hipMemcpyDeviceToHost));
+                SGM_HIP(hipMemcpy(&ck[2 * i], S->gL.edge + (int64_t)i * (S->gL.S + kEdgePad) + S->gL.S + 64, 16, hipMemcpyDeviceToHost));
             src = ck.data(); sz = ck.size() * 8;
         }
         else if (nm == "slabs") {           // slab pipeline in use: {strips, line groups, lines per group, steps, order of L, of U}; zeros = off
