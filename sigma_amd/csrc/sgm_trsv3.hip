@@ -33,6 +33,8 @@ constexpr int kPadPos = 32 * 64;           // positions of padding behind the re
 constexpr int kEdgeRing = 512;            // lane-63 results a chain wave keeps for the wave to its right
 constexpr int kSlabSpinLimit = 1 << 22;
 constexpr int kBig = 1 << 29;
+// "not yet written": a SIGNALLING NaN no subtraction can produce (arithmetic quiets NaNs) -- the forwarded results are their own flags
+constexpr unsigned long long kEmpty = 0x7FF4A5A5A5A5A5A5ull;
 typedef double f64x2s __attribute__((ext_vector_type(2)));
 
 struct SlabTri {
@@ -249,13 +251,13 @@ __global__ __launch_bounds__(TPB) void k_trsv_slab(int32_t NI, int32_t NB, int32
             }
             if (all) return;
             if (any) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every strip's stores are performed: publish
+                // (no wait for the stores to be acknowledged, no flag: a result is kEmpty in memory until it has landed)
                 if (lane == 0 && npass < 128) { htrace[2 * npass] = wall_clock64(); htrace[2 * npass + 1] = made[0]; ++npass; }
 #pragma unroll
                 for (int a = 0; a < kSlabMaxNI; ++a) {
                     if (a >= NI || made[a] <= sent[a]) continue;
                     if (lane == 0) {
-                        __hip_atomic_store(progress + (int64_t)b * NI + a, made[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(progress + (int64_t)b * NI + a, made[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (diagnostics only)
                         lds_st(&os[a], made[a]);
                     }
                     sent[a] = made[a];
@@ -273,87 +275,118 @@ __global__ __launch_bounds__(TPB) void k_trsv_slab(int32_t NI, int32_t NB, int32
     // ---------------------------------------------------------------------- fetcher: upstream results -> inb
     if (b == 0) return;
     long long *htrace = clk + (int64_t)NB * NI * (2 + S / 16) + (int64_t)b * 512 + 256;
-    // One memory round trip per pass: the pass loads the entries the PREVIOUS pass's look at the upstream progress words
-    // allowed (<= kBatch per strip, every strip's loads in flight together) and, in the same flight, those words again.
+    // One memory round trip per pass: load the next kBatch entries of every strip (all loads in flight together) and keep
+    // the leading ones whose 64 values have all landed (kEmpty = not yet; the gather / hand-over kernels reset the arrays).
     // (Tried: laying consecutive groups onto ONE XCD and reading the upstream results through its L2 with sc0 loads --
     // the producer's sc1 write-through stores do not refresh the L2 line, the reader sees stale data for ~100 us; and a
     // whole sweep's record traffic through one XCD's fabric port halves the chain rate.  Memory (sc1) it is.)
     {
         constexpr int kScope = __HIP_MEMORY_SCOPE_AGENT;
-        constexpr int kBatch = 16;
-        int32_t got[kSlabMaxNI], known[kSlabMaxNI];
+        constexpr int NIM = TPB == 256 ? 2 : kSlabMaxNI;       // strips per workgroup of this variant
+        constexpr int kBatch = 16;                             // entries per strip per request (32: slower -- the pass itself gets longer)
+        constexpr bool DBL = false;                            // (a second request in flight per strip: slower -- 614 vs 530 us at 100^3 -- the speculative loads come back empty and are asked again)
+        int32_t got[NIM], next[NIM];                           // entries in inb / first entry not yet requested
+        int32_t baseA[NIM], uptoA[NIM], baseB[NIM], uptoB[NIM];
+        double vA[NIM][kBatch], vB[DBL ? NIM : 1][kBatch];
         int npass = 0;
 #pragma unroll
-        for (int a = 0; a < kSlabMaxNI; ++a) { got[a] = 0; known[a] = 0; }
-        for (;;) {
-            bool all = true, any = false;
-            int32_t upto[kSlabMaxNI], seen[kSlabMaxNI];
-            double v[kSlabMaxNI][kBatch];
+        for (int a = 0; a < NIM; ++a) { got[a] = 0; next[a] = 0; baseA[a] = baseB[a] = -1; uptoA[a] = uptoB[a] = 0; }
+        auto issue = [&](auto &v, int32_t (&base)[NIM], int32_t (&upto)[NIM]) {
 #pragma unroll
-            for (int a = 0; a < kSlabMaxNI; ++a) {
-                upto[a] = 0;
-                seen[a] = 0;
-                if (a >= NI || got[a] >= S) continue;
-                all = false;
+            for (int a = 0; a < NIM; ++a) {
+                base[a] = -1;
+                if (a >= NI || next[a] >= S) continue;
                 // entry q overwrites q - R, consumed once the chain has completed step q - R - HB + 1; stay clear of it
                 const int32_t room = min(ld_relaxed(&oc[a + 1]), S) + R - 1;
-                upto[a] = min(min(min(known[a], S), room), got[a] + kBatch);
+                const int32_t up = min(min(S, room), next[a] + kBatch);
+                if (up <= next[a]) continue;
+                base[a] = next[a];
+                upto[a] = up;
                 const double *src = xp + (((int64_t)(b - 1) * NI + a) * S) * 64 + lane;
-                if (upto[a] > got[a]) {
-#pragma unroll
-                    for (int u = 0; u < kBatch; ++u)
-                        v[a][u] = __hip_atomic_load(src + (int64_t)min(got[a] + u, upto[a] - 1) * 64, __ATOMIC_RELAXED, kScope);
-                }
-                seen[a] = __hip_atomic_load(progress + (int64_t)(b - 1) * NI + a, __ATOMIC_RELAXED, kScope);
-            }
-            if (all) return;
-#pragma unroll
-            for (int a = 0; a < kSlabMaxNI; ++a) {
-                if (a >= NI) continue;
-                const int32_t sn = __builtin_amdgcn_readfirstlane(seen[a]);
-                if (sn > known[a]) { known[a] = sn; any = true; }
-                if (upto[a] <= got[a]) continue;
-                double *dst = inb + (size_t)a * R * 64 + lane;
 #pragma unroll
                 for (int u = 0; u < kBatch; ++u)
-                    if (got[a] + u < upto[a]) dst[(size_t)((got[a] + u) & (R - 1)) * 64] = v[a][u];
-                got[a] = upto[a];
+                    v[a][u] = __hip_atomic_load(src + (int64_t)min(base[a] + u, up - 1) * 64, __ATOMIC_RELAXED, kScope);
+                next[a] = up;
+            }
+        };
+        auto consume = [&](auto &v, int32_t (&base)[NIM], int32_t (&upto)[NIM]) {
+            bool any = false;
+#pragma unroll
+            for (int a = 0; a < NIM; ++a) {
+                if (a >= NI || base[a] < 0) continue;
+                if (base[a] != got[a]) { next[a] = got[a]; continue; }       // behind a request that landed only partly: dropped
+                double *dst = inb + (size_t)a * R * 64 + lane;
+                int32_t nvalid = 0;
+                bool open = true;
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const bool landed = __ballot((unsigned long long)__double_as_longlong(v[a][u]) != kEmpty) == ~0ull;
+                    open = open && landed && base[a] + u < upto[a];
+                    if (open) { dst[(size_t)((base[a] + u) & (R - 1)) * 64] = v[a][u]; ++nvalid; }
+                }
+                if (base[a] + nvalid < upto[a]) next[a] = got[a] + nvalid;    // ask again from the first entry that had not landed
+                if (!nvalid) continue;
+                got[a] += nvalid;
                 if (lane == 0) lds_st(&ia[a], got[a] >= S ? kBig : got[a]);
                 if (a == 0 && lane == 0 && npass < 128) { htrace[2 * npass] = wall_clock64(); htrace[2 * npass + 1] = got[0]; ++npass; }
                 any = true;
             }
-            if (any) { spins = 0; continue; }
+            return any;
+        };
+        auto done = [&]() {
+            bool all = true;
+#pragma unroll
+            for (int a = 0; a < NIM; ++a) if (a < NI && got[a] < S) all = false;
+            return all;
+        };
+        auto stalled = [&](bool any) {
+            if (any) { spins = 0; return false; }
             __builtin_amdgcn_s_sleep(1);
             if (++spins > kSlabSpinLimit || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || ld_relaxed(lds_abort)) {
                 if (lane == 0) {
                     __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(lds_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                return;
+                return true;
             }
+            return false;
+        };
+        issue(vA, baseA, uptoA);
+        for (;;) {
+            if constexpr (DBL) issue(vB, baseB, uptoB);
+            bool any = consume(vA, baseA, uptoA);
+            if (done()) return;
+            issue(vA, baseA, uptoA);
+            if constexpr (DBL) {
+                any = consume(vB, baseB, uptoB) || any;
+                if (done()) return;
+            }
+            if (stalled(any)) return;
         }
     }
 }
 
 // position-space gather / hand-over / scatter (padding positions hold 0); rhs = second half of a record's second pair
 // (both also clear the progress words of the sweep that follows)
+// and mark the sweep's result array "not yet written"
 __global__ void k_slab_gather(int64_t np, f64x2s *__restrict__ rec, const double *__restrict__ src, const int32_t *__restrict__ row,
-                              int32_t *__restrict__ progress, int32_t nprog, const int *flag)
+                              int32_t *__restrict__ progress, int32_t nprog, unsigned long long *__restrict__ xres, const int *flag)
 {
     if (flag && *flag) return;
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t q = p; q < nprog; q += stride) progress[q] = 0;
-    for (; p < np; p += stride) { const int32_t r = row[p]; rec[2 * p + 1].y = r >= 0 ? src[r] : 0.0; }
+    for (; p < np; p += stride) { const int32_t r = row[p]; rec[2 * p + 1].y = r >= 0 ? src[r] : 0.0; xres[p] = kEmpty; }
 }
 __global__ void k_slab_transition(int64_t np, f64x2s *__restrict__ recU, const double *__restrict__ xL, const int32_t *__restrict__ mapLU,
-                                  const double *__restrict__ Dp, int32_t *__restrict__ progress, int32_t nprog, const int *flag)
+                                  const double *__restrict__ Dp, int32_t *__restrict__ progress, int32_t nprog,
+                                  unsigned long long *__restrict__ xres, const int *flag)
 {
     if (flag && *flag) return;
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t q = p; q < nprog; q += stride) progress[q] = 0;
-    for (; p < np; p += stride) { const int32_t q = mapLU[p]; recU[2 * p + 1].y = q >= 0 ? xL[q] / Dp[p] : 0.0; }   // x = x / D
+    for (; p < np; p += stride) { const int32_t q = mapLU[p]; recU[2 * p + 1].y = q >= 0 ? xL[q] / Dp[p] : 0.0; xres[p] = kEmpty; }   // x = x / D
 }
 __global__ void k_slab_scatter(int64_t np, double *__restrict__ dst, const double *__restrict__ xp, const int32_t *__restrict__ row, const int *flag)
 {
@@ -598,10 +631,11 @@ void slab3_apply(const Slab3 *S, const double *r, double *z, const int *flag)
     hipStream_t st = g_rt.stream;
     const int gl = vec_grid(S->L.NP), gu = vec_grid(S->U.NP);
     hipLaunchKernelGGL(k_slab_gather, dim3(gl), dim3(kBlock), 0, st, S->L.NP, S->L.rec, r, (const int32_t *)S->L.row, S->L.progress,
-                       S->L.NB * S->L.NI + 1, flag);
+                       S->L.NB * S->L.NI + 1, reinterpret_cast<unsigned long long *>(S->xL), flag);
     trsv_slab(S->L, S->xL, flag);
     hipLaunchKernelGGL(k_slab_transition, dim3(gu), dim3(kBlock), 0, st, S->U.NP, S->U.rec, (const double *)S->xL,
-                       (const int32_t *)S->mapLU, (const double *)S->Dp, S->U.progress, S->U.NB * S->U.NI + 1, flag);
+                       (const int32_t *)S->mapLU, (const double *)S->Dp, S->U.progress, S->U.NB * S->U.NI + 1,
+                       reinterpret_cast<unsigned long long *>(S->xU), flag);
     trsv_slab(S->U, S->xU, flag);
     hipLaunchKernelGGL(k_slab_scatter, dim3(gu), dim3(kBlock), 0, st, S->U.NP, z, (const double *)S->xU, (const int32_t *)S->U.row, flag);
 }
