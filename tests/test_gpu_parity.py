@@ -1060,6 +1060,29 @@ def test_ildu_slab_pipeline_vs_level_walkers_and_oracle(orc, w, h, nk, tail, ord
     assert np.array_equal(z, orc.Ildu(A2).solve(r))
 
 
+@pytest.mark.parametrize("shape", [(200, 150, 1), (70, 40, 30), (130, 24, 16)])
+def test_ildu_pipelines_propagate_non_finite_entries_like_the_sequential_sweeps(orc, shape):
+    """Inf / NaN in the right-hand side spread along the factor's dependencies only, exactly as in the row-by-row
+    sweeps: the pipelines' padding rows and absent terms (coefficient +0.0) must never turn them into NaNs elsewhere."""
+    nx, ny, nz = shape
+    n = nx * ny * nz
+    ptr, node, val = P.poisson2d_csr(nx, ny) if nz == 1 else P.laplace3d_csr(nx, ny, nz)
+    A = orc.CsrMatrix(n, n, ptr, node, val)
+    H = sg.csr_matrix(n, n, ptr, node, val)
+    opc = orc.Ildu(A)
+    pc = sg.ldu()
+    pc.setup(H)
+    assert pc.get("strips" if nz == 1 else "slabs", np.int32)[0] > 0
+    rs = np.random.RandomState(12)
+    for trial, where in enumerate(([n // 2], [n - 1], [0, n // 3, n - 7], [nx - 1, nx * ny - 1 if nz > 1 else n // 5])):
+        r = rs.standard_normal(n)
+        r[where] = [np.inf, -np.inf, np.nan][trial % 3]
+        z = np.zeros(n)
+        pc.solve(H, z, r)
+        zo = opc.solve(r)
+        assert np.array_equal(np.isnan(z), np.isnan(zo)) and np.array_equal(z, zo, equal_nan=True), trial
+
+
 @pytest.mark.parametrize("shape", [(1000, 1000, 1), (100, 100, 100), (192, 96, 40)])
 def test_ildu_pipelines_at_size_vs_oracle(orc, shape):
     """The strip pipeline on the 1000^2 5-point grid and the slab pipeline on the 100^3 / 192x96x40 7-point grids
