@@ -486,10 +486,9 @@ __global__ __launch_bounds__(TB) void k_trsv_walk_ring(const uint64_t *__restric
 //                dependency contributes an exact 0.0 whatever its operand holds).  Its only vector-memory traffic is
 //                the 32-byte records DEPTH steps ahead (static register slots: exact vmcnt waits) and the result
 //                store; lane 0's left neighbours come out of an LDS ring, lane 63's results go into another.
-//   helper wave  talks to the neighbours: polls the left strip's published progress, copies that strip's edge
-//                values into the LDS ring; forwards this strip's edge values to memory and publishes its progress.
-//                All of it with sc1 (agent-scope relaxed) accesses + `s_waitcnt vmcnt(0)` before the flag store,
-//                the hand-off recipe that is valid across XCDs.
+//   helper waves talk to the neighbours: one forwards this strip's edge values to memory, one loads the left strip's
+//                into the LDS ring -- sc1 (agent-scope relaxed) accesses, valid across XCDs.  The edge values are their
+//                own flags (kEdgeEmpty until written): a hand-off costs one memory round trip.
 // Strip ib only ever waits for strip ib-1 -- a workgroup with a smaller index, dispatched no later -- so the launch
 // cannot deadlock; every wait loop is bounded all the same and raises the abort word instead of hanging.
 constexpr int kStripDepth = 32;          // records in flight per lane (16: 0.91 / 1.81 ms per PCG iteration at 1000^2 / 2000^2, 32: 0.85 / 1.66)

@@ -15,11 +15,13 @@
 //   * a step subtracts the three products in the row's STORED order, each rounded on its own; an absent
 //     term contributes an exact 0.0 whatever its operand holds  =>  bit-identical to the sequential sweep;
 //   * workgroup b only waits for workgroup b-1: two helper waves per workgroup forward the chain waves'
-//     result rings to memory / fetch the upstream ones, with sc1 (agent-scope) accesses and
-//     `s_waitcnt vmcnt(0)` before the progress store -- the hand-off recipe that is valid across XCDs.
-//     Every wait loop is bounded and raises an abort word instead of hanging.
-// The path is only trusted with a pattern after it reproduced the level-scheduled apply bit for bit
-// on a test vector at setup (sgm_pc.hip).
+//     result rings to memory / fetch the upstream ones, with sc1 (agent-scope) accesses, valid across
+//     XCDs.  The results are their own flags: the result arrays hold a signalling-NaN pattern until
+//     written (no subtraction can produce one; the gather / hand-over kernels reset them before every
+//     sweep), so a hand-off costs ONE memory round trip.  Every wait loop is bounded and raises an
+//     abort word instead of hanging.
+// The path is only trusted with a pattern after it reproduced the row-by-row sweeps bit for bit on a
+// test vector at setup (sgm_pc.hip).
 #include "sgm_internal.hpp"
 
 #include <algorithm>
@@ -47,7 +49,7 @@ struct SlabTri {
     f64x2s *rec = nullptr;                 // device: 2 per position {c_back, c_up}, {c_left, rhs}
     int32_t *code = nullptr;               // device: bit0 has back, bit1 has up, bit2 has left; bits 3.. three 2-bit source ids in stored order
     int32_t *row = nullptr;                // device: position -> row (-1 = padding)
-    int32_t *progress = nullptr;           // device: NB*NI published steps, [NB*NI] = abort word
+    int32_t *progress = nullptr;           // device: NB*NI forwarded steps (diagnostics), [NB*NI] = abort word
     long long *clk = nullptr;              // device: 2 per (b, a): chain start / end
     std::vector<int32_t> h_pos;            // row -> position
     std::vector<int32_t> h_src[3];         // position -> entry of the factor's val array per source (-1 = none)
@@ -82,7 +84,7 @@ __device__ inline void lds_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC
 // The rings are two halves of DEPTH steps and the step loop is unrolled DEPTH times, so every ring access of a step has a
 // static offset from one of two base registers that swap once per DEPTH steps.
 // The chain waves only WRITE LDS: the forwarder wave stores their results to memory (the solution in position space,
-// which is also what the next workgroup's fetcher reads) and publishes the progress.
+// which is also what the next workgroup's fetcher reads).
 // REG: every row has exactly the dependencies its grid position implies -- then an absent term's coefficient (+0.0)
 // always meets an operand that is +0.0 (zeroed rings, padding rows), the product is +0.0, and no presence codes are read.
 constexpr int kSlabMaxNI = 4;
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(TPB) void k_trsv_slab(int32_t NI, int32_t NB, int32
     }
     int spins = 0;
     if (wv == NI) {
-        // ------------------------------------------------------------------ forwarder: result rings -> memory (+ progress)
+        // ------------------------------------------------------------------ forwarder: result rings -> memory
         int32_t sent[kSlabMaxNI];
         long long *htrace = clk + (int64_t)NB * NI * (2 + S / 16) + (int64_t)b * 512;       // diagnostics: (clock, steps forwarded) per pass
         int npass = 0;
