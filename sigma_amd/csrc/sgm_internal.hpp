@@ -128,6 +128,8 @@ struct Part {
     double *sval = nullptr;
     uint32_t *scode = nullptr;
     int32_t *scol = nullptr;       // sliced form WITHOUT a dictionary: the int32 column of every slot (-1 = no entry), same layout as sval
+    uint8_t *sbcode = nullptr;     // sliced form for rows of 9..32 entries with a dictionary (k_csr_slb): 1-byte codes (255 = no entry),
+                                   // per slice and chunk of 8 slots the 8 bytes of every row: ((slice * sw/8 + chunk) * 512 + row) * 8 + slot % 8
     int32_t sw = 0;                // slots per row in sval (3, 5, 7 or 8)
     // ELLPACK (device, slot-major: entry (slot k, row i) at k*n + i)
     int32_t max_d = 0;

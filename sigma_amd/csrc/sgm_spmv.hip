@@ -19,6 +19,8 @@
 // on one XCD).  Algorithmic bytes per SpMV: 12*nnz + 4*(n+1) + 8*m + 8*n.
 #include "sgm_internal.hpp"
 
+#include <type_traits>
+
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -143,8 +145,20 @@ __global__ __launch_bounds__(BLOCK) void k_csr_spmv(
             }
             __syncthreads();
             // ---- phase 2: lane i adds row i's products left to right
+            // (eight independent LDS reads, then the adds in stored order: a long row is a serial chain of adds, but it
+            // need not be a serial chain of LDS round trips as well)
             const int32_t kend = min(ke, te);
-            for (; k < kend; ++k) z = z + prod[k - ts];
+            while (k < kend) {
+                const int cnt = min(kend - k, 8);
+                double pv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (u < cnt) pv[u] = prod[k + u - ts];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (u < cnt) z = z + pv[u];
+                k += cnt;
+            }
             __syncthreads();
         }
         if (row < n) {
@@ -487,6 +501,124 @@ __global__ __launch_bounds__(256) void k_csr_sl32(
     }
 }
 
+// The sliced form for rows of 9..32 entries drawn from <= 255 distinct (column - row) offsets (27- / 19-point stencils,
+// 2-D 9-point, block-structured FEM): values slot-major in the same 512-row slices, W = the longest row rounded up to 8,
+// and ONE BYTE per slot for the column -- per chunk of 8 slots the 8 codes of a row sit together, so a lane reads the
+// codes of its two rows with one 16-byte load per chunk.  9 bytes per slot instead of CSR's 12, every load a coalesced
+// 16 bytes per lane, no row pointer, no barrier; the dictionary (<= 255 offsets) is looked up in LDS.  Slots are walked
+// in stored order: bit-identical to csr_matvec_add.
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+// W = value slots per row (compile time: a run-time W costs 10 %): the instantiated widths below, the smallest one that
+// holds the longest row; code bytes come in chunks of 8 per row.
+#define SGM_SLB_WIDTHS(X) X(9) X(12) X(15) X(16) X(19) X(20) X(24) X(25) X(27) X(28) X(32)
+template <int W, bool ADD, bool DOT_W, bool DOT_YY>
+__global__ __launch_bounds__(256) void k_csr_slb(
+    int32_t n, const uint8_t *__restrict__ sbcode, const int32_t *__restrict__ dict, const double *__restrict__ sval,
+    const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ w,
+    double *__restrict__ part_wy, double *__restrict__ part_yy, const int *__restrict__ flag_done, int gen, int remap)
+{
+    constexpr int BLOCK = 256;
+    constexpr int NCH = (W + 7) / 8;
+    static_assert(W >= 9 && W <= 32, "rows of 9..32 entries");
+    __shared__ int32_t dl[256];
+    __shared__ double red[BLOCK / 64];
+    if (flag_done) { const int st = *flag_done; if (st && gen >= st) return; }
+    const int tid = threadIdx.x;
+    dl[tid] = dict[tid];
+    __syncthreads();
+    const bool chain = (remap & 256) != 0;
+    const int64_t nsl = ((int64_t)n + kSlRows - 1) / kSlRows;
+    double dwy = 0.0, dyy = 0.0;
+
+    int64_t first = blockIdx.x;             // XCD-block-cyclic slices, see k_csr_sl
+    if ((remap & 255) >= 3) {
+        const int G = (remap & 255) == 3 ? 8 : (remap & 255) == 4 ? 2 : (remap & 255) == 6 ? 64 : (remap & 255) == 7 ? 128 : 32;
+        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        first = (int64_t)(loc / G) * (8 * G) + xcd * G + loc % G;
+    }
+    for (int64_t sl = first; sl < nsl; sl += gridDim.x) {
+        const int32_t row = (int32_t)(sl * kSlRows) + 2 * tid;
+        const f64x2 *vb = reinterpret_cast<const f64x2 *>(sval + sl * (int64_t)W * kSlRows) + tid;
+        const u32x4s *cb = reinterpret_cast<const u32x4s *>(sbcode + sl * (int64_t)(NCH * 8 * kSlRows)) + tid;      // 16 bytes: rows 2t, 2t+1
+        f64x2 y0 = {0.0, 0.0};
+        if (ADD) {
+            if (row + 1 < n) y0 = *reinterpret_cast<const f64x2 *>(y + row);
+            else if (row < n) y0.x = y[row];
+        }
+        f64x2 z;
+        z.x = (ADD && chain) ? y0.x : 0.0;
+        z.y = (ADD && chain) ? y0.y : 0.0;
+        // chunks of 8 slots.  Unrolled over all chunks the compiler keeps every slot live (237 VGPRs at W = 27, two waves
+        // per SIMD) -- which still wins up to W = 28: all of a wave's loads are in flight at once; beyond that a rolled loop
+        auto chunk = [&](int c, auto cnt_tag) {
+            constexpr int CNT = decltype(cnt_tag)::value;
+            f64x2 v[CNT];
+            double xa[CNT], xb[CNT];
+            const u32x4s cw = __builtin_nontemporal_load(cb + c * BLOCK);
+#pragma unroll
+            for (int u = 0; u < CNT; ++u) v[u] = __builtin_nontemporal_load(vb + (c * 8 + u) * BLOCK);
+#pragma unroll
+            for (int u = 0; u < CNT; ++u) {
+                const uint32_t ca = ((u < 4 ? cw.x : cw.y) >> (8 * (u & 3))) & 255u;
+                const uint32_t cbv = ((u < 4 ? cw.z : cw.w) >> (8 * (u & 3))) & 255u;
+                xa[u] = ca != 255u ? x[row + dl[ca]] : 0.0;
+                xb[u] = cbv != 255u ? x[row + 1 + dl[cbv]] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < CNT; ++u) {
+                const uint32_t ca = ((u < 4 ? cw.x : cw.y) >> (8 * (u & 3))) & 255u;
+                const uint32_t cbv = ((u < 4 ? cw.z : cw.w) >> (8 * (u & 3))) & 255u;
+                if (ca != 255u) z.x = z.x + v[u].x * xa[u];
+                if (cbv != 255u) z.y = z.y + v[u].y * xb[u];
+            }
+        };
+        if (W > 28) {       // (measured on the 160^3 27-point matrix, rolled vs unrolled: W = 32: 249 vs 281 us; 28: 237 vs 224; 27: 229 vs 218)
+#pragma unroll 1
+            for (int c = 0; c < W / 8; ++c) chunk(c, std::integral_constant<int, 8>{});
+        } else {
+#pragma unroll
+            for (int c = 0; c < W / 8; ++c) chunk(c, std::integral_constant<int, 8>{});
+        }
+        if (W % 8) chunk(W / 8, std::integral_constant<int, (W % 8 ? W % 8 : 8)>{});
+        f64x2 yi;
+        yi.x = ADD ? (chain ? z.x : y0.x + z.x) : 0.0 + z.x;
+        yi.y = ADD ? (chain ? z.y : y0.y + z.y) : 0.0 + z.y;
+        if (row + 1 < n) {
+            __builtin_nontemporal_store(yi, reinterpret_cast<f64x2 *>(y + row));
+            if (DOT_W) { const f64x2 wv = *reinterpret_cast<const f64x2 *>(w + row); dwy += wv.x * yi.x; dwy += wv.y * yi.y; }
+            if (DOT_YY) { dyy += yi.x * yi.x; dyy += yi.y * yi.y; }
+        } else if (row < n) {
+            __builtin_nontemporal_store(yi.x, y + row);
+            if (DOT_W) dwy += w[row] * yi.x;
+            if (DOT_YY) dyy += yi.x * yi.x;
+        }
+    }
+    if (DOT_W) {
+        const double t = block_sum<BLOCK>(dwy, red);
+        if (tid == 0) part_wy[blockIdx.x] = t;
+    }
+    if (DOT_YY) {
+        const double t = block_sum<BLOCK>(dyy, red);
+        if (tid == 0) part_yy[blockIdx.x] = t;
+    }
+}
+
+// 1-byte codes in CSR order -> the chunked sliced layout of k_csr_slb (255 where a row has no entry in the slot)
+__global__ __launch_bounds__(256) void k_slb_pack_codes(int32_t n, int32_t W, const int32_t *__restrict__ rowptr,
+                                                        const uint8_t *__restrict__ code, uint8_t *__restrict__ sbcode)
+{
+    const int64_t nsl = ((int64_t)n + kSlRows - 1) / kSlRows;
+    for (int64_t sl = blockIdx.x; sl < nsl; sl += gridDim.x)
+        for (int r = threadIdx.x; r < kSlRows; r += blockDim.x) {
+            const int64_t row = sl * kSlRows + r;
+            int32_t k = 0, ke = 0;
+            if (row < n) { k = rowptr[row]; ke = rowptr[row + 1]; }
+            const int WC = (W + 7) / 8 * 8;          // code bytes per row
+            uint8_t *dst = sbcode + sl * (int64_t)WC * kSlRows + (int64_t)r * 8;
+            for (int u = 0; u < WC; ++u) dst[(int64_t)(u >> 3) * kSlRows * 8 + (u & 7)] = (u < W && k + u < ke) ? code[k + u] : (uint8_t)255;
+        }
+}
+
 // columns in CSR order -> sliced layout (-1 where a row has no entry in the slot; whole slices)
 __global__ __launch_bounds__(256) void k_sl_pack_cols(int32_t n, int32_t W, const int32_t *__restrict__ rowptr,
                                                       const int32_t *__restrict__ col, int32_t *__restrict__ scol)
@@ -682,7 +814,8 @@ static bool do_block_ok() { const int b = spmv_cfg().block; return b == 256 || b
 static bool use_offset_dict(const Part &p) { return p.code && g_opt.csr_offset_dict && do_block_ok(); }
 static bool use_sliced(const Part &p) { return p.scode && g_opt.csr_sliced && g_opt.csr_offset_dict; }
 static bool use_sliced32(const Part &p) { return p.scol && g_opt.csr_sliced && !p.ecol; }
-static bool any_sliced(const Part &p) { return use_sliced(p) || use_sliced32(p); }
+static bool use_slicedb(const Part &p) { return p.sbcode && g_opt.csr_sliced && g_opt.csr_offset_dict; }
+static bool any_sliced(const Part &p) { return use_sliced(p) || use_sliced32(p) || use_slicedb(p); }
 // k_csr_do serves both the dictionary form and, for short rows, plain int32 columns
 static bool use_row_owner(const Part &p)
 {
@@ -880,6 +1013,30 @@ static void launch_csr_sl32(const Part &p, int grid, const double *x, double *y,
 #undef L
 }
 
+template <bool ADD>
+static void launch_csr_slb(const Part &p, int grid, const double *x, double *y, const double *w,
+                           double *pwy, double *pyy, const int *flag, int gen)
+{
+    hipStream_t st = g_rt.stream;
+    const SpmvCfg &c = spmv_cfg();
+    int mode = c.remap == 1 ? (grid <= kMaxGrid / 2 ? 5 : 0) : (c.remap >= 3 ? c.remap : 0);
+    if (mode >= 3 && grid % (8 * (mode == 3 ? 8 : mode == 4 ? 2 : mode == 6 ? 64 : mode == 7 ? 128 : 32)) != 0) mode = 0;
+#define L(WW, DW, DY)                                                                                     \
+    hipLaunchKernelGGL((k_csr_slb<WW, ADD, DW, DY>), dim3(grid), dim3(256), 0, st, p.n, p.sbcode, p.dict, p.sval, x, y, \
+                       w, pwy, pyy, flag, gen, mode | g_launch_flags)
+#define LV(WW)                                \
+    if (p.sw == WW) {                         \
+        if (w && pyy) L(WW, true, true);      \
+        else if (w) L(WW, true, false);       \
+        else if (pyy) L(WW, false, true);     \
+        else L(WW, false, false);             \
+        return;                               \
+    }
+    SGM_SLB_WIDTHS(LV)
+#undef LV
+#undef L
+}
+
 // SGM_ELL_CFG="U,nt,grid": slots in flight per lane, nontemporal matrix loads, grid cap (tuning aid)
 struct EllCfg { int u = 8, nt = 1, grid = 2048; };
 static EllCfg &ell_cfg()
@@ -994,8 +1151,9 @@ static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const doub
     v.n_halo = p.n_halo; v.ncol_own = p.ncol_own;
     v.rowptr = p.rowptr + r.lo; v.col = p.col; v.val = p.val; v.code = p.code; v.dict = p.dict;
     v.max_row = p.max_row;
-    const bool sliced = use_sliced(p), sliced32 = !sliced && use_sliced32(p);   // range starts are multiples of the 512-row slices
+    const bool sliced = use_sliced(p), slicedb = !sliced && use_slicedb(p), sliced32 = !sliced && !slicedb && use_sliced32(p);   // range starts are multiples of the 512-row slices
     if (sliced) { v.sval = p.sval + (int64_t)r.lo * p.sw; v.scode = p.scode + r.lo; v.sw = p.sw; }
+    if (slicedb) { v.sval = p.sval + (int64_t)r.lo * p.sw; v.sbcode = p.sbcode + (int64_t)r.lo * ((p.sw + 7) / 8 * 8); v.sw = p.sw; }
     if (sliced32) { v.sval = p.sval + (int64_t)r.lo * p.sw; v.scol = p.scol + (int64_t)r.lo * p.sw; v.sw = p.sw; }
     const bool dict = use_offset_dict(p);
     const double *xs = dict ? x + r.lo : x;
@@ -1005,6 +1163,9 @@ static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const doub
     if (sliced) {
         if (add) launch_csr_sl<true>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
         else launch_csr_sl<false>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
+    } else if (slicedb) {
+        if (add) launch_csr_slb<true>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
+        else launch_csr_slb<false>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
     } else if (sliced32) {            // absolute columns: x is not shifted
         if (add) launch_csr_sl32<true>(v, r.grid, x, ys, ws, pw, py, flag_done, gen);
         else launch_csr_sl32<false>(v, r.grid, x, ys, ws, pw, py, flag_done, gen);
@@ -1137,7 +1298,7 @@ void set_interior_range(Part &p, const int32_t *ptr1, const int32_t *node1)
     if (p.n_halo == 0 || p.n == 0) return;
     // ranges are cut at row-block boundaries of the kernel that will run them (512-row slices for the
     // sliced kernel; a multiple of the other kernels' 256-row blocks, so they can run the ranges too)
-    const int B = (p.scode || p.scol) ? std::max(kSlRows, spmv_cfg().block) : spmv_cfg().block;
+    const int B = (p.scode || p.scol || p.sbcode) ? std::max(kSlRows, spmv_cfg().block) : spmv_cfg().block;
     const int32_t nb = (p.n + B - 1) / B;
     int32_t best_lo = 0, best_len = 0, run_lo = 0, run_len = 0;
     for (int32_t b = 0; b < nb; ++b) {
@@ -1154,7 +1315,7 @@ void set_interior_range(Part &p, const int32_t *ptr1, const int32_t *node1)
 // refresh the sliced copy of the values (no-op for parts without one)
 int pack_sliced(Part &p)
 {
-    if ((!p.scode && !p.scol) || p.n == 0) return SGM_OK;
+    if ((!p.scode && !p.scol && !p.sbcode) || p.n == 0) return SGM_OK;
     const int64_t nsl = ((int64_t)p.n + kSlRows - 1) / kSlRows;
     if (p.ecol)
         hipLaunchKernelGGL(k_sl_pack_ell, dim3((unsigned)std::min<int64_t>(nsl, 65536)), dim3(256), 0, g_rt.stream, p.n, p.sw,
@@ -1330,6 +1491,23 @@ static int build_offset_dict(Part &p, const int32_t *, const int32_t *)
                        (const int32_t *)p.dict, p.ndict, p.code, sliced ? p.scode : nullptr);
     SGM_HIP(hipGetLastError());
     if (sliced) SGM_TRY(pack_sliced(p));
+    // longer rows (9..32 entries), <= 255 offsets, little padding: slot-major slices with 1-byte codes (k_csr_slb)
+    int Wb = 0;                                               // value slots: the smallest instantiated width that holds the longest row
+#define PICK(WW) if (!Wb && p.max_row <= WW) Wb = WW;
+    SGM_SLB_WIDTHS(PICK)
+#undef PICK
+    if (const char *e = getenv("SGM_SLB_W")) { const int f = atoi(e); if (f >= p.max_row && f <= 32) Wb = f; }      // tuning aid (an instantiated width)
+    const int Wc = (Wb + 7) / 8 * 8;                          // code bytes per row in eights
+    if (!sliced && g_opt.csr_sliced && Wb && p.ndict <= 255 && p.max_row > 8 && (double)Wb * n <= 1.35 * (double)nnz) {
+        rows_padded = ((size_t)n + kSlRows - 1) / kSlRows * kSlRows;
+        SGM_TRY(dalloc(&p.sbcode, rows_padded * Wc));
+        SGM_TRY(dalloc(&p.sval, rows_padded * Wb));
+        p.sw = Wb;
+        hipLaunchKernelGGL(k_slb_pack_codes, dim3((unsigned)std::min<size_t>(rows_padded / kSlRows, 65536)), dim3(256), 0, st, n, Wb,
+                           (const int32_t *)p.rowptr, (const uint8_t *)p.code, p.sbcode);
+        SGM_HIP(hipGetLastError());
+        SGM_TRY(pack_sliced(p));
+    }
     SGM_HIP(hipStreamSynchronize(st));       // `dict` (host staging of the upload) goes out of scope
     return SGM_OK;
 }
@@ -1491,8 +1669,8 @@ int build_csr_part(Part &p, int32_t n, int32_t ncol_own, int32_t n_halo, int64_t
 // after a change of the index arrays (matrix permutation): drop and rebuild the derived formats
 int rebuild_csr_formats(Part &p)
 {
-    dfree(p.code); dfree(p.dict); dfree(p.sval); dfree(p.scode); dfree(p.scol);
-    p.code = nullptr; p.dict = nullptr; p.sval = nullptr; p.scode = nullptr; p.scol = nullptr;
+    dfree(p.code); dfree(p.dict); dfree(p.sval); dfree(p.scode); dfree(p.scol); dfree(p.sbcode);
+    p.code = nullptr; p.dict = nullptr; p.sval = nullptr; p.scode = nullptr; p.scol = nullptr; p.sbcode = nullptr;
     p.ndict = 0; p.sw = 0; p.max_row = 0;
     return build_offset_dict(p, nullptr, nullptr);
 }
@@ -1515,7 +1693,7 @@ int sgm_invalidate_transpose(sgm_mat A)
 
 void free_part(Part &p)
 {
-    dfree(p.rowptr); dfree(p.col); dfree(p.val); dfree(p.code); dfree(p.dict); dfree(p.sval); dfree(p.scode); dfree(p.scol); dfree(p.ecol); dfree(p.eval); dfree(p.edeg); dfree(p.ecode); dfree(p.xext);
+    dfree(p.rowptr); dfree(p.col); dfree(p.val); dfree(p.code); dfree(p.dict); dfree(p.sval); dfree(p.scode); dfree(p.scol); dfree(p.sbcode); dfree(p.ecol); dfree(p.eval); dfree(p.edeg); dfree(p.ecode); dfree(p.xext);
     for (auto &nb : p.nbrs) { dfree(nb.send_idx); dfree(nb.send_buf); }
     free_ell_colblock(p);
     p = Part();
@@ -2038,6 +2216,7 @@ int sgm_mat_kernel(sgm_mat A, char *buf, int len)
             else if (p.ecode && g_opt.ell_offset_dict) snprintf(name, sizeof name, "k_ell_do<MDP=%d>", p.emdp);
             else snprintf(name, sizeof name, "k_ell_spmv");
         } else if (use_sliced(p)) snprintf(name, sizeof name, "k_csr_sl<W=%d>", p.sw);
+        else if (use_slicedb(p)) snprintf(name, sizeof name, "k_csr_slb<W=%d>", p.sw);
         else if (use_sliced32(p)) snprintf(name, sizeof name, "k_csr_sl32<W=%d>", p.sw);
         else if (use_offset_dict(p)) snprintf(name, sizeof name, "k_csr_do<256,%d,CW=1>", do_tile_for(p));
         else if (use_row_owner(p)) snprintf(name, sizeof name, "k_csr_do<256,%d,CW=4>", do_tile_for(p));
@@ -2062,6 +2241,7 @@ static int64_t part_resident_bytes(const Part &p)
     if (p.sval) b += 8 * nsl * kSlRows * p.sw;
     if (p.scode) b += 4 * nsl * kSlRows;
     if (p.scol) b += 4 * nsl * kSlRows * p.sw;
+    if (p.sbcode) b += nsl * kSlRows * ((p.sw + 7) / 8 * 8);
     if (p.ecol) b += 4 * (int64_t)p.n * p.max_d;
     if (p.eval) b += 8 * (int64_t)p.n * p.max_d;
     if (p.edeg) b += 4 * (int64_t)p.n;
@@ -2081,6 +2261,7 @@ static int64_t part_matvec_bytes(const sgm_mat_s *A, const Part &p)
         else if (p.ecode && g_opt.ell_offset_dict) m = (int64_t)p.n * (8 * (int64_t)p.max_d + p.emdp);
         else m = 12 * (int64_t)p.n * p.max_d;
     } else if (use_sliced(p)) m = nsl * kSlRows * (8 * (int64_t)p.sw + 4);
+    else if (use_slicedb(p)) m = nsl * kSlRows * (8 * (int64_t)p.sw + (p.sw + 7) / 8 * 8);
     else if (use_sliced32(p)) m = nsl * kSlRows * 12 * (int64_t)p.sw;
     else if (use_offset_dict(p)) m = 9 * p.nnz + 4 * ((int64_t)p.n + 1);
     else m = 12 * p.nnz + 4 * ((int64_t)p.n + 1);

@@ -685,6 +685,118 @@ def test_sliced_int32_kernel_short_rows_without_dictionary(orc, n, wmax):
     assert np.array_equal(y1, y)
 
 
+def _stencil_csr_3d(nx, ny, nz, reach):
+    """CSR of a (2 reach + 1)^3-point stencil (reach 1: 27 points) with distinct values per offset, columns ascending."""
+    n = nx * ny * nz
+    idx = np.arange(n)
+    i, j, k = idx % nx, (idx // nx) % ny, idx // (nx * ny)
+    cols, vals, oks = [], [], []
+    t = 0
+    for dk in range(-reach, reach + 1):
+        for dj in range(-reach, reach + 1):
+            for di in range(-reach, reach + 1):
+                ok = (i + di >= 0) & (i + di < nx) & (j + dj >= 0) & (j + dj < ny) & (k + dk >= 0) & (k + dk < nz)
+                cols.append(idx + di + dj * nx + dk * nx * ny); oks.append(ok)
+                vals.append(np.full(n, 27.5 if (di, dj, dk) == (0, 0, 0) else -1.0 + 0.013 * t)); t += 1
+    C, V, M = np.stack(cols, 1), np.stack(vals, 1), np.stack(oks, 1)
+    ptr = np.concatenate([[1], 1 + np.cumsum(M.sum(1))]).astype(np.int32)
+    return n, ptr, (C[M] + 1).astype(np.int32), V[M].copy()
+
+
+@pytest.mark.parametrize("kind", ["27pt", "27pt_one_slice", "9pt_2d", "banded_ragged", "19_to_32_wide"])
+def test_sliced_byte_coded_kernel_rows_of_9_to_32_entries(orc, kind):
+    """k_csr_slb: rows of 9..32 entries from <= 255 distinct offsets (27-point and 2-D 9-point stencils, a ragged
+    banded matrix) -- slot-major slices with 1-byte codes.  Ragged rows, slices ending mid-block, Inf/NaN in x,
+    y += A x, chained transposes, a value update, CG with the fused dots, a row partition, and the other kernels on
+    the same data: always the oracle's bits."""
+    rs = np.random.RandomState(len(kind))
+    if kind == "27pt":
+        n, ptr, node, val = _stencil_csr_3d(23, 17, 11, 1)
+    elif kind == "27pt_one_slice":
+        n, ptr, node, val = _stencil_csr_3d(8, 7, 6, 1)
+    elif kind == "19_to_32_wide":
+        n, ptr, node, val = _stencil_csr_3d(40, 30, 9, 1)
+        keep = np.ones(node.size, bool)          # drop some entries: rows of 19..27 entries, W = 28
+        rows_ = np.repeat(np.arange(n), np.diff(ptr))
+        drop = (np.abs(node - 1 - rows_) > 40 * 30) & (rs.rand(node.size) < 0.3)
+        keep[drop] = False
+        cnt = np.bincount(rows_[keep], minlength=n)
+        ptr = np.concatenate([[1], 1 + np.cumsum(cnt)]).astype(np.int32)
+        node, val = node[keep].copy(), val[keep].copy()
+    elif kind == "9pt_2d":
+        n, ptr, node, val = _stencil_csr_3d(70, 51, 1, 1)
+    else:
+        n = 20011
+        offs = np.sort(rs.choice(np.arange(-400, 401), 120, replace=False))
+        deg = rs.randint(20, 31, n)
+        deg[rs.rand(n) < 0.05] = rs.randint(0, 9)
+        rows, cols = [], []
+        for r in range(n):
+            o = np.sort(rs.choice(offs, deg[r], replace=False))
+            c = r + o
+            c = c[(c >= 0) & (c < n)]
+            rows.append(len(c)); cols.append(c)
+        ptr = np.concatenate([[1], 1 + np.cumsum(rows)]).astype(np.int32)
+        node = (np.concatenate(cols) + 1).astype(np.int32)
+        val = rs.standard_normal(node.size)
+        val[::7] += 3.0
+    A = orc.CsrMatrix(n, n, ptr, node, val)
+    H = sg.csr_matrix(n, n, ptr, node, val)
+    if kind != "27pt_one_slice":         # (a grid that small is mostly boundary: too much padding, the LDS-staged kernel serves it)
+        assert H.kernel.startswith("k_csr_slb"), H.kernel
+    x = rs.standard_normal(n)
+    y0 = rs.standard_normal(n)
+    y = np.full(n, -3.0)
+    H.matvec(x, y)
+    assert np.array_equal(y, A.matvec(x))
+    ya = y0.copy()
+    H.matvec_add(x, ya)
+    assert np.array_equal(ya, A.matvec_add(x, y0.copy()))
+    xb = x.copy()
+    xb[rs.randint(0, n, 5)] = np.inf
+    xb[rs.randint(0, n, 3)] = np.nan
+    yb = np.zeros(n)
+    H.matvec(xb, yb)
+    assert np.array_equal(yb, A.matvec(xb), equal_nan=True)
+    t0 = rs.standard_normal(n)
+    t = t0.copy()
+    H.matvec_t_add(x, t)
+    assert np.array_equal(t, A.matvec_t_add(x, t0.copy()))
+    # the other kernels on the same handle
+    for opts in ({"csr_sliced": 0}, {"csr_sliced": 0, "csr_offset_dict": 0}, {"csr_sliced": 0, "csr_offset_dict": 0, "csr_row_owner": 0}):
+        for k_, v_ in opts.items():
+            sg.set_option(k_, v_)
+        try:
+            assert not H.kernel.startswith("k_csr_slb")
+            y1 = np.zeros(n)
+            H.matvec(x, y1)
+        finally:
+            for k_ in opts:
+                sg.set_option(k_, 1)
+        assert np.array_equal(y1, y), opts
+    # in-process row partition (ranges cut at slice boundaries, halo columns renumbered)
+    if n > 2000:
+        starts = sg.partition_rows_by_nnz(ptr, 3, align=2)
+        Hp = sg.partitioned_csr_matrix(n, n, ptr, node, val, starts)
+        yp = np.zeros(n)
+        Hp.matvec(x, yp)
+        assert np.array_equal(yp, y)
+    # value update, then CG with the dots fused into the product (SPD only for the stencils)
+    val2 = val * 1.5
+    H.set_values(val2)
+    A2 = orc.CsrMatrix(n, n, ptr, node, val2)
+    H.matvec(x, y)
+    assert np.array_equal(y, A2.matvec(x))
+    if kind != "banded_ragged":
+        b = P.test_vector(n)
+        ur, itr, _, _ = orc.cg(A2, b, tol=1e-12)
+        sv = sg.cg(1e-12)
+        sv.setup(H)
+        u = np.zeros(n)
+        sv.solve(H, u, b)
+        assert abs(sv.iterations - itr) <= 1 and np.abs(u - ur).max() / np.abs(ur).max() <= 1e-11
+
+
 @pytest.mark.parametrize("n,wmax", [(1, 3), (255, 3), (256, 5), (257, 7), (70001, 8), (33333, 5), (262147, 5), (1048573, 3)])
 def test_sliced_kernel_ragged_rows_nonfinite_and_updates(orc, n, wmax):
     """k_csr_sl on rows of 0..W entries, slices that end mid-block, duplicate columns, Inf/NaN in
