@@ -63,14 +63,26 @@ int sgm_synchronize(void);
  * the column indices as 1-byte dictionary codes, and matvec streams 9 instead of 12 bytes
  * per stored entry.  Results are bit-identical either way; 0 forces the int32 kernels.
  * "ell_offset_dict" (default 1): the same for ELLPACK matrices with max_d <= 16.
- * "csr_row_owner" (default 1): int32-column matrices whose rows hold <= 32 entries use the
- * row-owner gather kernel; 0 forces the balanced streaming-gather kernel (any row length).
+ * "csr_row_owner" (default 1): int32-column matrices whose rows hold <= 64 entries use the
+ * row-owner gather kernel; 0 forces the kernels for longer rows.
+ * "csr_row_groups" (default 1): int32-column matrices with longer rows (averaging <= 128 entries)
+ * use the row-grouped gather kernel (several gather lanes per row, sums by the row's owner);
+ * 0 forces the balanced streaming-gather kernel (any row length).
  * "csr_sliced" (default 1): offset-dictionary matrices whose rows hold <= 8 entries from <= 15
  * distinct offsets (1-D/2-D/3-D stencils) also keep their values in slices of 512 rows,
  * slot-major, plus one 32-bit word of 4-bit codes per row; a lane owns two adjacent rows, every
  * load is 16 bytes wide, coalesced and independent, no row pointers are read (8 W + 4 bytes per
- * row of width W).  5-17 % faster than the 1-byte-code kernel; 0 keeps that.  */
+ * row of width W).  5-17 % faster than the 1-byte-code kernel; 0 keeps that.
+ * "slice_sched" (default 1): sliced matrices most of whose rows carry an offset of >= 32 slices (the
+ * plane stride of a 3-D grid) hand their slices to the workgroups in a band order per XCD, so that the
+ * slices one plane apart -- which read the same x entries -- share one XCD's L2; only the order in
+ * which whole slices are taken changes.  "slice_sched_band" (default 64): its band width in slices.  */
 int sgm_set_option(const char *name, int value);
+/* The schedule itself, host-only (no HIP call; what the library uploads for a row range of n_slices
+ * 512-row slices): tab_out[it * grid + workgroup] = slice or -1, iters_out = entries per workgroup.
+ * tab_out may be NULL to ask for iters_out only; capacity in entries (>= iters * grid).          */
+int sgm_slice_sched_host(int64_t n_slices, int64_t period_rows, int32_t grid, int32_t band_slices,
+                         int32_t *tab_out, int64_t capacity, int32_t *iters_out);
 int sgm_malloc(void **p, size_t bytes);   /* HBM buffer for hosts without a device allocator */
 int sgm_free(void *p);
 int sgm_memcpy(void *dst, const void *src, size_t bytes, int kind); /* 0 h2d, 1 d2h, 2 d2d */

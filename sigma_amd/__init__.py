@@ -121,7 +121,8 @@ def synchronize():
 
 def set_option(name, value):
     """sgm_set_option: "csr_offset_dict" 1/0 (1-byte column codes for stencil-like matrices),
-    "csr_row_owner" 1/0 (row-owner gather for int32-column matrices with rows <= 32 entries),
+    "csr_row_owner" 1/0 (row-owner gather for int32-column matrices with rows <= 64 entries),
+    "csr_row_groups" 1/0 (row-grouped gather for longer rows), "slice_sched" 0/1 (band-ordered slices on 3-D grids),
     "csr_sliced" 1/0 (slot-major slices + 4-bit codes for rows <= 8 entries / <= 15 offsets; default on),
     "ell_offset_dict" 1/0, "ell_colblock" 0/1/2, "ell_colblock_cols", "ell_colblock_chunks", "ell_colblock_rows" 0/256/512,
     "ildu_strips" 1/0, "gmres_cgs2" 1/0."""
@@ -870,6 +871,19 @@ def partition_rows_by_nnz(ptr, nparts, align=512):
     _ck(lib().sgm_partition_rows_by_nnz(C.c_int32(len(ptr) - 1), C.c_void_p(ptr.ctypes.data), C.c_int32(nparts),
                                         C.c_int32(align), C.c_void_p(rs.ctypes.data)))
     return rs
+
+
+def slice_sched_host(n_slices, period_rows, grid, band_slices=64):
+    """sgm_slice_sched_host: the order in which `grid` workgroups take the 512-row slices of a sliced
+    matrix whose rows carry a far offset of `period_rows`; returns the (iters, grid) int32 table
+    (slice or -1)."""
+    it = C.c_int32(0)
+    _ck(lib().sgm_slice_sched_host(C.c_int64(n_slices), C.c_int64(period_rows), C.c_int32(grid), C.c_int32(band_slices),
+                                   None, C.c_int64(0), C.byref(it)))
+    tab = np.empty(it.value * grid, np.int32)
+    _ck(lib().sgm_slice_sched_host(C.c_int64(n_slices), C.c_int64(period_rows), C.c_int32(grid), C.c_int32(band_slices),
+                                   C.c_void_p(tab.ctypes.data), C.c_int64(tab.size), C.byref(it)))
+    return tab.reshape(it.value, grid)
 
 
 def dot(a, b):

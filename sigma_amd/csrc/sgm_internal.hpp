@@ -35,7 +35,8 @@ int fail(int code, const char *fmt, ...);
 struct Options {
     int csr_offset_dict = 1;       // use the 1-byte column code kernel when a matrix allows it
     int ell_offset_dict = 1;       // ELLPACK twin of csr_offset_dict (max_d <= 16)
-    int csr_row_owner = 1;         // int32 columns, rows <= 32 entries: gather by the row's owner lane
+    int csr_row_owner = 1;         // int32 columns, rows <= 64 entries: gather by the row's owner lane
+    int csr_row_groups = 1;        // int32 columns, longer rows (averaging <= 128 entries): Q gather lanes per row, ordered sums by the row's owner (k_csr_rg)
     int csr_sliced = 1;            // rows <= 8 entries, <= 15 offsets: slot-major slices + 4-bit codes (k_csr_sl)
     int ell_colblock = 1;          // ELLPACK with random columns: column-blocked two-phase product (0 never, 1 automatic, 2 always)
     int ell_colblock_cols = 16384; // its column block (x entries staged in LDS per workgroup; even, <= 16384)
@@ -43,6 +44,8 @@ struct Options {
     int ell_colblock_chunks = 16;  // workgroups per column block in the multiply phase (C4 sweep: 4 / 8 / 16 -> 1.32 / 1.31 / 1.27 ms)
     int ildu_strips = 1;           // ILDU(0) factors of grid-like matrices (deps r-1, r-w): strip-pipelined triangular solves
     int gmres_cgs2 = 1;            // GMRES: blocked CGS-2 orthogonalisation (3 passes per step) instead of modified Gram-Schmidt
+    int slice_sched = 0;           // sliced kernels on matrices with a far stencil offset (3-D grids): band-ordered slice schedule per XCD
+    int slice_sched_band = 64;     // its target band width in slices
 };
 extern Options g_opt;
 
@@ -105,6 +108,10 @@ struct HaloNbr {
     int32_t recv_count = 0;
 };
 
+// Slice schedule of the sliced kernels (sgm_spmv.hip, slice_sched): the order in which the workgroups of every XCD
+// take the 512-row slices of one row range; tab[it * grid + workgroup] = slice or -1
+struct SliceSched { int32_t *tab = nullptr; int32_t lo = 0, hi = 0, grid = 0, iters = 0; };
+
 struct Part {
     int32_t n = 0;                 // owned rows
     int32_t ncol_own = 0;          // owned columns (== n for the square partitions used)
@@ -131,6 +138,11 @@ struct Part {
     uint8_t *sbcode = nullptr;     // sliced form for rows of 9..32 entries with a dictionary (k_csr_slb): 1-byte codes (255 = no entry),
                                    // per slice and chunk of 8 slots the 8 bytes of every row: ((slice * sw/8 + chunk) * 512 + row) * 8 + slot % 8
     int32_t sw = 0;                // slots per row in sval (3, 5, 7 or 8)
+    int32_t sched_period = 0;      // rows: the far offset most rows carry (a 3-D grid's plane), 0 = none / near
+    mutable SliceSched sched[3];   // built on first use, one per row range launched (whole part, or interior / head / tail)
+    mutable int nsched = 0;
+    const int32_t *run_sched = nullptr;   // (views of one launch) the schedule to walk, or null = computed maps
+    int32_t run_iters = 0;
     // ELLPACK (device, slot-major: entry (slot k, row i) at k*n + i)
     int32_t max_d = 0;
     int32_t *ecol = nullptr;

@@ -116,6 +116,7 @@ int sgm_init(int device)
     if (const char *e = getenv("SGM_CSR_SLICED")) g_opt.csr_sliced = atoi(e);      // tuning aid (see sgm_set_option)
     if (const char *e = getenv("SGM_GMRES_CGS2")) g_opt.gmres_cgs2 = atoi(e);
     if (const char *e = getenv("SGM_ILDU_STRIPS")) g_opt.ildu_strips = atoi(e);
+    if (const char *e = getenv("SGM_SLICE_SCHED")) sscanf(e, "%d,%d", &g_opt.slice_sched, &g_opt.slice_sched_band);
     return SGM_OK;
 }
 
@@ -156,12 +157,15 @@ int sgm_set_option(const char *name, int value)
     if (!strcmp(name, "csr_offset_dict")) { g_opt.csr_offset_dict = value; return SGM_OK; }
     if (!strcmp(name, "csr_row_owner")) { g_opt.csr_row_owner = value; return SGM_OK; }
     if (!strcmp(name, "csr_sliced")) { g_opt.csr_sliced = value; return SGM_OK; }
+    if (!strcmp(name, "csr_row_groups")) { g_opt.csr_row_groups = value; return SGM_OK; }
     if (!strcmp(name, "ell_offset_dict")) { g_opt.ell_offset_dict = value; return SGM_OK; }
     if (!strcmp(name, "ell_colblock")) { g_opt.ell_colblock = value; return SGM_OK; }
     if (!strcmp(name, "ell_colblock_cols")) { g_opt.ell_colblock_cols = std::min(16384, std::max(2, value)) & ~1; return SGM_OK; }
     if (!strcmp(name, "ell_colblock_rows")) { g_opt.ell_colblock_rows = value == 512 ? 512 : value == 256 ? 256 : 0; return SGM_OK; }
     if (!strcmp(name, "ell_colblock_chunks")) { g_opt.ell_colblock_chunks = std::max(1, value); return SGM_OK; }
     if (!strcmp(name, "ildu_strips")) { g_opt.ildu_strips = value; return SGM_OK; }
+    if (!strcmp(name, "slice_sched")) { g_opt.slice_sched = value; return SGM_OK; }
+    if (!strcmp(name, "slice_sched_band")) { g_opt.slice_sched_band = std::max(8, value); return SGM_OK; }
     if (!strcmp(name, "gmres_cgs2")) { g_opt.gmres_cgs2 = value; return SGM_OK; }
     return fail(SGM_ERR_BAD_ARG, "sgm_set_option: unknown option '%s'", name);
 }

@@ -178,6 +178,145 @@ __global__ __launch_bounds__(BLOCK) void k_csr_spmv(
     }
 }
 
+// General CSR with LONG rows (no dictionary, rows beyond the row-owner kernel's 64 entries: finite-element matrices of
+// higher order, 3-D unstructured meshes).  k_csr_spmv gathers entry-parallel: the 64 lanes of one gather instruction
+// hold 64 consecutive ENTRIES -- of one or two rows, so 64 different x lines, each moved L2 -> L1 for 8 of its 128 bytes
+// (measured on banded rows of 33..64 entries: 2.0-2.2 TB/s of moved bytes, the L2 -> L1 path carrying 16 x as much).
+// k_csr_do lets the lane that owns a row gather for it, so one instruction holds the k-th entries of consecutive rows
+// (neighbouring columns in any matrix with a banded / mesh-local numbering: a handful of lines) -- but a tile of T
+// staged entries holds only T / len rows, and each of those few lanes walks len entries: time grows with the row length.
+// This kernel keeps k_csr_do's streaming (tiles of contiguous entries, every byte fetched once by coalesced 16-byte
+// loads, values and columns parked in LDS) and gives every row of the tile Q = 2^k gather lanes, Q the largest power of
+// two with Q x (rows in the tile) <= 256: lane (r, q) takes entries q, q + Q, ... of row r, so a gather instruction covers
+// 64 / Q consecutive rows x Q consecutive slots.  The products replace the values in LDS; the row's owner lane then
+// adds them in stored order, carrying its sum across tiles (products rounded one by one, left-to-right sums:
+// bit-identical to csr_matvec_add).  The next tile's loads are in flight while this one is gathered and summed.
+template <int BLOCK, int TILE, bool ADD, bool DOT_W, bool DOT_YY>
+__global__ __launch_bounds__(BLOCK) void k_csr_rg(
+    int32_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
+    const double *__restrict__ w, double *__restrict__ part_wy, double *__restrict__ part_yy,
+    const int *__restrict__ flag_done, int gen, int remap)
+{
+    constexpr int VPT = TILE / (2 * BLOCK), U = 8;
+    static_assert(TILE % (2 * BLOCK) == 0, "whole 16-byte value loads per lane");
+    __shared__ double pl[TILE];            // values, then products
+    __shared__ int32_t cl[TILE];
+    __shared__ int32_t rp[BLOCK + 1];
+    __shared__ double red[BLOCK / 64];
+    if (flag_done) { const int st = *flag_done; if (st && gen >= st) return; }
+
+    const int tid = threadIdx.x;
+    const bool chain = (remap & 256) != 0;
+    const int rmode = remap & 255;
+    const int64_t nrb = ((int64_t)n + BLOCK - 1) / BLOCK;
+    double dwy = 0.0, dyy = 0.0;
+
+    for (int it = 0;; ++it) {
+        if ((int64_t)it * gridDim.x >= nrb) break;
+        const int64_t rb = rmode ? rowblock_of(it, blockIdx.x, gridDim.x, nrb, rmode) : (int64_t)it * gridDim.x + blockIdx.x;
+        if (rb >= nrb) continue;          // uniform per block
+        const int32_t r0 = (int32_t)(rb * BLOCK);
+        const int32_t row = r0 + tid;
+        rp[tid] = rowptr[min(row, n)];    // rows past n are empty (the previous block's gathers, the last readers of rp, lie behind a barrier)
+        if (tid == 0) rp[BLOCK] = rowptr[min(r0 + BLOCK, n)];
+        double wv = 0.0, y0 = 0.0;        // requested now, consumed after the row sum
+        if (row < n) {
+            if (DOT_W) wv = w[row];
+            if (ADD) y0 = y[row];
+        }
+        __syncthreads();
+        int32_t k = rp[tid];
+        const int32_t ke = rp[tid + 1];
+        const int32_t s = rp[0] & ~1;     // tile starts are even: 16-byte aligned value loads
+        const int32_t e = rp[BLOCK];
+        double z = (ADD && chain) ? y0 : 0.0;
+
+        f64x2 v[VPT];
+        i32x2 c[VPT];
+        auto fetch = [&](int32_t ts, int32_t te) {
+#pragma unroll
+            for (int m = 0; m < VPT; ++m) {
+                const int32_t j = ts + 2 * tid + 2 * BLOCK * m;
+                if (j < te) {             // arrays are padded by 2 entries: j + 1 is always readable
+                    v[m] = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + j));
+                    c[m] = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(col + j));
+                }
+            }
+        };
+        if (s < e) fetch(s, min(s + TILE, e));
+        for (int32_t ts = s; ts < e; ts += TILE) {
+            const int32_t te = min(ts + TILE, e);
+            if (ts != s) __syncthreads();           // the previous tile's sums are done with the LDS buffers
+#pragma unroll
+            for (int m = 0; m < VPT; ++m) {
+                const int32_t j = ts + 2 * tid + 2 * BLOCK * m;
+                if (j < te) {
+                    *reinterpret_cast<f64x2 *>(pl + (j - ts)) = v[m];
+                    *reinterpret_cast<i32x2 *>(cl + (j - ts)) = c[m];
+                }
+            }
+            __syncthreads();
+            if (ts + TILE < e) fetch(ts + TILE, min(ts + 2 * TILE, e));       // in flight while this tile is gathered and summed
+            // rows of the block with entries in [ts, te): rf = rows that end at or before ts, rl = rows that start before te, - 1
+            int rf = 0, rl = 0;
+#pragma unroll
+            for (int step = BLOCK / 2; step > 0; step >>= 1) {
+                if (rp[rf + step] <= ts) rf += step;          // rp[rf + step] = end of row rf + step - 1
+                if (rp[rl + step] < te) rl += step;           // start of row rl + step
+            }
+            const int R = max(rl - rf + 1, 1);
+            const int Q = BLOCK / R;                          // gather lanes per row (uniform)
+            const int rq = (tid * ((65536 + Q - 1) / Q)) >> 16;        // tid / Q (exact for tid < 65536 / Q ... BLOCK <= 256)
+            const int r = rf + rq, q = tid - rq * Q;
+            if (r <= rl) {
+                const int32_t lo = max(rp[r], ts), hi = min(rp[r + 1], te);
+                for (int32_t kk = lo + q; kk < hi; kk += U * Q) {
+                    double xv[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int32_t j = kk + u * Q;
+                        if (j < hi) xv[u] = x[cl[j - ts]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int32_t j = kk + u * Q;
+                        if (j < hi) pl[j - ts] = pl[j - ts] * xv[u];
+                    }
+                }
+            }
+            __syncthreads();
+            // the owner of row i adds its products left to right (eight LDS reads at a time, the adds in stored order)
+            const int32_t kend = min(ke, te);
+            while (k < kend) {
+                const int cnt = min(kend - k, 8);
+                double pv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (u < cnt) pv[u] = pl[k + u - ts];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (u < cnt) z = z + pv[u];
+                k += cnt;
+            }
+        }
+        if (row < n) {
+            const double yi = ADD ? (chain ? z : y0 + z) : 0.0 + z;
+            __builtin_nontemporal_store(yi, y + row);
+            if (DOT_W) dwy += wv * yi;
+            if (DOT_YY) dyy += yi * yi;
+        }
+    }
+    if (DOT_W) {
+        const double t = block_sum<BLOCK>(dwy, red);
+        if (tid == 0) part_wy[blockIdx.x] = t;
+    }
+    if (DOT_YY) {
+        const double t = block_sum<BLOCK>(dyy, red);
+        if (tid == 0) part_yy[blockIdx.x] = t;
+    }
+}
+
 // CSR with dictionary-coded column offsets ("offset-dict" form).  Matrices from structured
 // grids have very few distinct (column - row) offsets (5 for the 5-point, 7 for the 7-point
 // stencil, also after the [owned | halo] renumbering of a slab partition), so the column of
@@ -340,7 +479,7 @@ __global__ __launch_bounds__(256) void k_csr_sl(
     int32_t n, const uint32_t *__restrict__ scode, const int32_t *__restrict__ dict,
     const double *__restrict__ sval, const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ w, double *__restrict__ part_wy, double *__restrict__ part_yy,
-    const int *__restrict__ flag_done, int gen, int remap)
+    const int *__restrict__ flag_done, int gen, int remap, const int32_t *__restrict__ sched, int sched_iters)
 {
     constexpr int BLOCK = 256;
     __shared__ int32_t dl[16];
@@ -364,7 +503,13 @@ __global__ __launch_bounds__(256) void k_csr_sl(
         const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
         first = (int64_t)(loc / G) * (8 * G) + xcd * G + loc % G;
     }
-    for (int64_t sl = first; sl < nsl; sl += gridDim.x) {
+    // ... or a slice schedule (slice_sched below; matrices with a far offset, 3-D grids): entry it * grid + workgroup of
+    // a table, -1 = nothing left; the next entry is requested (a scalar load) before this slice's work
+    int64_t sl = sched ? sched[blockIdx.x] : first;
+    int sit = 0;
+    while (sl >= 0 && sl < nsl) {
+        int64_t nxt = sl + gridDim.x;
+        if (sched) { ++sit; nxt = sit < sched_iters ? sched[(int64_t)sit * gridDim.x + blockIdx.x] : -1; }
         const int32_t row = (int32_t)(sl * kSlRows) + 2 * tid;          // even: 16-byte aligned pairs
         // (the code array is padded to whole slices with "no entry" words: rows >= n do nothing)
         const u32x2 cw = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(scode + row));
@@ -404,6 +549,7 @@ __global__ __launch_bounds__(256) void k_csr_sl(
             if (DOT_W) dwy += w[row] * yi.x;
             if (DOT_YY) dyy += yi.x * yi.x;
         }
+        sl = nxt;
     }
     if (DOT_W) {
         const double t = block_sum<BLOCK>(dwy, red);
@@ -515,7 +661,8 @@ template <int W, bool ADD, bool DOT_W, bool DOT_YY>
 __global__ __launch_bounds__(256) void k_csr_slb(
     int32_t n, const uint8_t *__restrict__ sbcode, const int32_t *__restrict__ dict, const double *__restrict__ sval,
     const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ w,
-    double *__restrict__ part_wy, double *__restrict__ part_yy, const int *__restrict__ flag_done, int gen, int remap)
+    double *__restrict__ part_wy, double *__restrict__ part_yy, const int *__restrict__ flag_done, int gen, int remap,
+    const int32_t *__restrict__ sched, int sched_iters)
 {
     constexpr int BLOCK = 256;
     constexpr int NCH = (W + 7) / 8;
@@ -536,7 +683,11 @@ __global__ __launch_bounds__(256) void k_csr_slb(
         const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
         first = (int64_t)(loc / G) * (8 * G) + xcd * G + loc % G;
     }
-    for (int64_t sl = first; sl < nsl; sl += gridDim.x) {
+    int64_t sl = sched ? sched[blockIdx.x] : first;        // slice schedule, see k_csr_sl
+    int sit = 0;
+    while (sl >= 0 && sl < nsl) {
+        int64_t nxt = sl + gridDim.x;
+        if (sched) { ++sit; nxt = sit < sched_iters ? sched[(int64_t)sit * gridDim.x + blockIdx.x] : -1; }
         const int32_t row = (int32_t)(sl * kSlRows) + 2 * tid;
         const f64x2 *vb = reinterpret_cast<const f64x2 *>(sval + sl * (int64_t)W * kSlRows) + tid;
         const u32x4s *cb = reinterpret_cast<const u32x4s *>(sbcode + sl * (int64_t)(NCH * 8 * kSlRows)) + tid;      // 16 bytes: rows 2t, 2t+1
@@ -592,6 +743,7 @@ __global__ __launch_bounds__(256) void k_csr_slb(
             if (DOT_W) dwy += w[row] * yi.x;
             if (DOT_YY) dyy += yi.x * yi.x;
         }
+        sl = nxt;
     }
     if (DOT_W) {
         const double t = block_sum<BLOCK>(dwy, red);
@@ -797,6 +949,8 @@ static SpmvCfg &spmv_cfg()
 }
 
 static int resident_per_cu(bool dict, int block, int v, int cw = 4);
+static const SliceSched *slice_sched(const Part &p, int32_t lo, int32_t hi, int grid);
+static void free_slice_sched(Part &p);
 int ell_grid(const Part &p);
 // sgm_ellcb.hip: column-blocked two-phase product for ELLPACK matrices with random columns
 bool use_ell_colblock(const Part &p);
@@ -819,7 +973,25 @@ static bool any_sliced(const Part &p) { return use_sliced(p) || use_sliced32(p) 
 // k_csr_do serves both the dictionary form and, for short rows, plain int32 columns
 static bool use_row_owner(const Part &p)
 {
-    return use_offset_dict(p) || (do_block_ok() && g_opt.csr_row_owner && p.max_row > 0 && p.max_row <= 32);
+    // (rows of 33..64 entries, banded: 809-822 us against 850-890 with k_csr_rg and 1100-1150 with k_csr_spmv; beyond 64 the
+    // few lanes that own a tile's rows walk too long: 64..128 entries 1160 us against 1020 with k_csr_rg)
+    return use_offset_dict(p) || (do_block_ok() && g_opt.csr_row_owner && p.max_row > 0 && p.max_row <= 64);
+}
+
+// long rows without a dictionary: the row-grouped gather kernel (k_csr_rg)
+constexpr int kRgTile = 2048;
+static bool use_row_groups(const Part &p)
+{
+    // (rows averaging more than 128 entries stay with k_csr_spmv: the owner's serial sum over a tile that holds a handful of
+    // rows takes over -- 150..300 entries: 1840 us against 1670)
+    return g_opt.csr_row_groups && !any_sliced(p) && !use_row_owner(p) && p.n > 0 && p.nnz <= 128 * (int64_t)p.n;
+}
+static int row_groups_resident_per_cu()
+{
+    static int nb = 0;
+    if (!nb && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_csr_rg<256, kRgTile, false, true, false>, 256, 0) != hipSuccess || nb < 1))
+        nb = 6;
+    return nb;
 }
 
 // (BLOCK, TILE) instantiations of the offset-dict kernel.  TILE = entries staged in LDS per
@@ -846,13 +1018,14 @@ static int do_tile_for(const Part &p)
 static int grid_for_rows(const Part &p, int64_t rows, int64_t limit)
 {
     const SpmvCfg &c = spmv_cfg();
-    const int blk = any_sliced(p) ? kSlRows : c.block;
+    const int blk = any_sliced(p) ? kSlRows : use_row_groups(p) ? 256 : c.block;
     const int64_t nrb = (rows + blk - 1) / blk;
     int64_t g = ((nrb + 7) / 8) * 8;
     int64_t cap = c.maxgrid;
     // round-robin slices, not a persistent resident grid: 4096 workgroups; 8192 from 32768 slices on
     // (n >= 1.7e7: 464^3 1.54 -> 1.45 ms, 300^3 355 -> 345 us; below that the consumers' re-reduction of more partials costs more)
     if (cap <= 0 && any_sliced(p)) cap = nrb >= 32768 ? kMaxGrid : kMaxGrid / 2;
+    if (cap <= 0 && use_row_groups(p)) cap = (int64_t)row_groups_resident_per_cu() * g_rt.num_cu;
     if (cap <= 0) cap = (int64_t)resident_per_cu(use_row_owner(p), c.block, use_row_owner(p) ? do_tile_for(p) : c.vpt,
                                                  use_offset_dict(p) ? 1 : 4) * g_rt.num_cu;
     if (cap > limit) cap = limit;
@@ -930,6 +1103,22 @@ static void launch_csr(const Part &p, int grid, const double *x, double *y, cons
 }
 
 template <bool ADD>
+static void launch_csr_rg(const Part &p, int grid, const double *x, double *y, const double *w,
+                          double *pwy, double *pyy, const int *flag, int gen)
+{
+    hipStream_t st = g_rt.stream;
+    const int remap = (spmv_cfg().remap == 2 ? 2 : 1) | g_launch_flags;
+#define L(DW, DY)                                                                                       \
+    hipLaunchKernelGGL((k_csr_rg<256, kRgTile, ADD, DW, DY>), dim3(grid), dim3(256), 0, st, p.n, p.rowptr, p.col, p.val, x, y, w, \
+                       pwy, pyy, flag, gen, remap)
+    if (w && pyy) L(true, true);
+    else if (w) L(true, false);
+    else if (pyy) L(false, true);
+    else L(false, false);
+#undef L
+}
+
+template <bool ADD>
 static void launch_csr_do(const Part &p, int grid, const double *x, double *y, const double *w,
                           double *pwy, double *pyy, const int *flag, int gen)
 {
@@ -974,7 +1163,7 @@ static void launch_csr_sl(const Part &p, int grid, const double *x, double *y, c
     if (mode >= 3 && grid % (8 * (mode == 3 ? 8 : mode == 4 ? 2 : mode == 6 ? 64 : mode == 7 ? 128 : 32)) != 0) mode = 0;
 #define L(WW, DW, DY)                                                                                   \
     hipLaunchKernelGGL((k_csr_sl<WW, ADD, DW, DY>), dim3(grid), dim3(256), 0, st, p.n, p.scode, p.dict, \
-                       p.sval, x, y, w, pwy, pyy, flag, gen, mode | g_launch_flags)
+                       p.sval, x, y, w, pwy, pyy, flag, gen, mode | g_launch_flags, p.run_sched, p.run_iters)
 #define LV(WW)                                \
     if (p.sw == WW) {                         \
         if (w && pyy) L(WW, true, true);      \
@@ -1023,7 +1212,7 @@ static void launch_csr_slb(const Part &p, int grid, const double *x, double *y, 
     if (mode >= 3 && grid % (8 * (mode == 3 ? 8 : mode == 4 ? 2 : mode == 6 ? 64 : mode == 7 ? 128 : 32)) != 0) mode = 0;
 #define L(WW, DW, DY)                                                                                     \
     hipLaunchKernelGGL((k_csr_slb<WW, ADD, DW, DY>), dim3(grid), dim3(256), 0, st, p.n, p.sbcode, p.dict, p.sval, x, y, \
-                       w, pwy, pyy, flag, gen, mode | g_launch_flags)
+                       w, pwy, pyy, flag, gen, mode | g_launch_flags, p.run_sched, p.run_iters)
 #define LV(WW)                                \
     if (p.sw == WW) {                         \
         if (w && pyy) L(WW, true, true);      \
@@ -1075,7 +1264,10 @@ static void launch_ell(const Part &p, int grid, const double *x, double *y, cons
         return;
     }
     if (use_sliced_ell(p)) {           // structured ELLPACK in the sliced form: the CSR kernel as it is
-        launch_csr_sl<ADD>(p, grid, x, y, w, pwy, pyy, flag, gen);
+        Part v;
+        v.n = p.n; v.scode = p.scode; v.dict = p.dict; v.sval = p.sval; v.sw = p.sw;
+        if (const SliceSched *ss = slice_sched(p, 0, p.n, grid)) { v.run_sched = ss->tab; v.run_iters = ss->iters; }
+        launch_csr_sl<ADD>(v, grid, x, y, w, pwy, pyy, flag, gen);
         return;
     }
     hipStream_t st = g_rt.stream;
@@ -1140,6 +1332,87 @@ static int resident_per_cu(bool dict, int block, int v, int cw)
     return nb;
 }
 
+// ---- slice schedule ---------------------------------------------------------------------------------
+// A 3-D grid's rows reference x a whole plane away (offset +-D, D >> one slice).  With slices handed out round-robin or
+// block-cyclic, the slices D rows apart -- which read the same x lines -- run on different XCDs, so every x line enters
+// three L2s (464^3: slice s and s + 420.5 land 4 XCDs apart).  The schedule cuts the period D into NB bands (NB a multiple
+// of 8, bands of about `slice_sched_band` slices); band(s) = floor(NB * frac((512 s + 256) / D)), XCD x walks bands
+// x, x + 8, ... one after the other, each in ascending slice order: a slice and its +-D neighbours sit one band width apart
+// in the SAME XCD's sequence, inside or next to the window of slices that XCD has in flight.  Workgroup b (XCD b % 8,
+// the hardware's round-robin) takes positions b / 8, b / 8 + grid / 8, ... of its XCD's sequence: tab[it * grid + b].
+// Only the ORDER of whole slices changes: every row is still summed by one lane in stored order.
+static void slice_sched_table(int64_t nsl, int64_t period_rows, int grid, int band_slices, std::vector<int32_t> &tab, int &iters)
+{
+    const double P = (double)period_rows / kSlRows;
+    const int NB = 8 * std::max(1, (int)std::ceil(P / (8.0 * std::max(1, band_slices))));
+    std::vector<int32_t> band((size_t)nsl);
+    std::vector<int64_t> cnt((size_t)NB + 1, 0);
+    for (int64_t sl = 0; sl < nsl; ++sl) {
+        const double t = ((double)sl * kSlRows + kSlRows / 2) / (double)period_rows;
+        int b = (int)((t - std::floor(t)) * NB);
+        b = std::min(std::max(b, 0), NB - 1);
+        band[(size_t)sl] = b;
+        ++cnt[(size_t)b + 1];
+    }
+    // XCD x's sequence = bands x, x + 8, ... end to end; start[b] = position of band b's first slice inside it
+    std::vector<int64_t> start((size_t)NB, 0), len(8, 0);
+    for (int x = 0; x < 8; ++x)
+        for (int b = x; b < NB; b += 8) { start[(size_t)b] = len[x]; len[x] += cnt[(size_t)b + 1]; }
+    const int64_t L = grid / 8;
+    const int64_t longest = *std::max_element(len.begin(), len.end());
+    iters = (int)((longest + L - 1) / L);
+    tab.assign((size_t)iters * grid, -1);
+    for (int64_t sl = 0; sl < nsl; ++sl) {
+        const int b = band[(size_t)sl], x = b & 7;
+        const int64_t q = start[(size_t)b]++;
+        tab[(size_t)((q / L) * grid + (q % L) * 8 + x)] = (int32_t)sl;
+    }
+}
+
+extern "C" int sgm_slice_sched_host(int64_t n_slices, int64_t period_rows, int32_t grid, int32_t band_slices,
+                                    int32_t *tab_out, int64_t capacity, int32_t *iters_out)
+{
+    if (n_slices < 1 || n_slices > INT32_MAX || period_rows < 1 || grid < 8 || grid % 8 || !iters_out)
+        return fail(SGM_ERR_BAD_ARG, "sgm_slice_sched_host: n_slices %lld, period %lld, grid %d (a multiple of 8)",
+                    (long long)n_slices, (long long)period_rows, grid);
+    std::vector<int32_t> tab;
+    int iters = 0;
+    slice_sched_table(n_slices, period_rows, grid, band_slices, tab, iters);
+    *iters_out = iters;
+    if (tab_out) {
+        if (capacity < (int64_t)tab.size()) return fail(SGM_ERR_BAD_ARG, "sgm_slice_sched_host: capacity %lld < %zu", (long long)capacity, tab.size());
+        memcpy(tab_out, tab.data(), tab.size() * sizeof(int32_t));
+    }
+    return SGM_OK;
+}
+
+// the schedule of one row range of a part (built and uploaded on first use), or null: no far offset, option off,
+// too few slices for it to matter
+static const SliceSched *slice_sched(const Part &p, int32_t lo, int32_t hi, int grid)
+{
+    if (!g_opt.slice_sched || p.sched_period < 32 * kSlRows || grid < 8 || grid % 8) return nullptr;
+    const int64_t nsl = ((int64_t)hi - lo + kSlRows - 1) / kSlRows;
+    if (nsl < 2 * (int64_t)grid || 2 * (int64_t)p.sched_period > (int64_t)hi - lo) return nullptr;
+    for (int i = 0; i < p.nsched; ++i)
+        if (p.sched[i].lo == lo && p.sched[i].hi == hi && p.sched[i].grid == grid) return p.sched[i].tab ? &p.sched[i] : nullptr;
+    if (p.nsched >= 3) return nullptr;
+    SliceSched &ss = p.sched[p.nsched++];
+    ss.lo = lo; ss.hi = hi; ss.grid = grid; ss.tab = nullptr;
+    std::vector<int32_t> tab;
+    int iters = 0;
+    slice_sched_table(nsl, p.sched_period, grid, g_opt.slice_sched_band, tab, iters);
+    int32_t *d = nullptr;
+    if (dalloc(&d, tab.size()) != SGM_OK) return nullptr;
+    if (hipMemcpy(d, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { dfree(d); return nullptr; }
+    ss.tab = d; ss.iters = iters;
+    return &ss;
+}
+static void free_slice_sched(Part &p)
+{
+    for (int i = 0; i < p.nsched; ++i) { dfree(p.sched[i].tab); p.sched[i] = SliceSched(); }
+    p.nsched = 0;
+}
+
 static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const double *x, double *y, bool add,
                          const double *w, double *pwy, double *pyy, const int *flag_done, int gen)
 {
@@ -1152,6 +1425,8 @@ static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const doub
     v.rowptr = p.rowptr + r.lo; v.col = p.col; v.val = p.val; v.code = p.code; v.dict = p.dict;
     v.max_row = p.max_row;
     const bool sliced = use_sliced(p), slicedb = !sliced && use_slicedb(p), sliced32 = !sliced && !slicedb && use_sliced32(p);   // range starts are multiples of the 512-row slices
+    if (sliced || slicedb)
+        if (const SliceSched *ss = slice_sched(p, r.lo, r.hi, r.grid)) { v.run_sched = ss->tab; v.run_iters = ss->iters; }
     if (sliced) { v.sval = p.sval + (int64_t)r.lo * p.sw; v.scode = p.scode + r.lo; v.sw = p.sw; }
     if (slicedb) { v.sval = p.sval + (int64_t)r.lo * p.sw; v.sbcode = p.sbcode + (int64_t)r.lo * ((p.sw + 7) / 8 * 8); v.sw = p.sw; }
     if (sliced32) { v.sval = p.sval + (int64_t)r.lo * p.sw; v.scol = p.scol + (int64_t)r.lo * p.sw; v.sw = p.sw; }
@@ -1172,6 +1447,9 @@ static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const doub
     } else if (use_row_owner(p)) {
         if (add) launch_csr_do<true>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
         else launch_csr_do<false>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
+    } else if (use_row_groups(p)) {
+        if (add) launch_csr_rg<true>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
+        else launch_csr_rg<false>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
     } else {
         if (add) launch_csr<true>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
         else launch_csr<false>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
@@ -1428,6 +1706,33 @@ __global__ __launch_bounds__(256) void k_dict_encode(int32_t n, const int32_t *_
     }
 }
 
+// The far offset most rows carry (a 3-D grid's plane stride, in rows), for the slice schedule: the largest |offset| that
+// at least a quarter of the rows of a 512-row sample from the middle of the part use.  `codes` = the sample's dictionary
+// codes (any order; 255 and codes >= ndict are ignored), `rows` = rows sampled.
+static int32_t far_offset_of_sample(const std::vector<uint8_t> &codes, int64_t rows, const std::vector<int32_t> &dict, int ndict)
+{
+    std::vector<int64_t> freq(256, 0);
+    for (uint8_t c : codes) ++freq[c];
+    int64_t far = 0;
+    for (int c = 0; c < ndict && c < 255; ++c)
+        if (4 * freq[(size_t)c] >= rows) far = std::max<int64_t>(far, std::llabs((long long)dict[(size_t)c]));
+    return (int32_t)std::min<int64_t>(far, INT32_MAX);
+}
+static int detect_sched_period_csr(Part &p, const std::vector<int32_t> &dict)
+{
+    p.sched_period = 0;
+    if (!p.code || p.n < 64 * kSlRows) return SGM_OK;
+    const int32_t R = kSlRows, mid = (p.n / 2) / kSlRows * kSlRows;
+    std::vector<int32_t> rp((size_t)R + 1);
+    SGM_HIP(hipMemcpy(rp.data(), p.rowptr + mid, ((size_t)R + 1) * 4, hipMemcpyDeviceToHost));
+    const int64_t cnt = (int64_t)rp[(size_t)R] - rp[0];
+    if (cnt <= 0) return SGM_OK;
+    std::vector<uint8_t> codes((size_t)cnt);
+    SGM_HIP(hipMemcpy(codes.data(), p.code + rp[0], (size_t)cnt, hipMemcpyDeviceToHost));
+    p.sched_period = far_offset_of_sample(codes, R, dict, p.ndict);
+    return SGM_OK;
+}
+
 // Offset dictionary of a row block (index work at setup, on the device): the distinct (col - row)
 // values in ascending order; gives up (p.code stays null) beyond 255 distinct offsets.
 static int build_offset_dict(Part &p, const int32_t *, const int32_t *)
@@ -1509,6 +1814,7 @@ static int build_offset_dict(Part &p, const int32_t *, const int32_t *)
         SGM_TRY(pack_sliced(p));
     }
     SGM_HIP(hipStreamSynchronize(st));       // `dict` (host staging of the upload) goes out of scope
+    if (p.scode || p.sbcode) SGM_TRY(detect_sched_period_csr(p, dict));
     return SGM_OK;
 }
 
@@ -1635,6 +1941,15 @@ static int build_ell_offset_dict(Part &p)
     SGM_HIP(hipGetLastError());
     if (sliced) SGM_TRY(pack_sliced(p));
     SGM_HIP(hipStreamSynchronize(st));
+    p.sched_period = 0;
+    if (sliced && p.n >= 64 * kSlRows) {       // the slice schedule's period, from a 512-row sample (see far_offset_of_sample)
+        const int32_t mid = (p.n / 2) / kSlRows * kSlRows;
+        std::vector<uint8_t> rows((size_t)kSlRows * mdp), codes;
+        SGM_HIP(hipMemcpy(rows.data(), p.ecode + (size_t)mid * mdp, rows.size(), hipMemcpyDeviceToHost));
+        for (int32_t i = 0; i < kSlRows; ++i)
+            for (int32_t k = 0; k < p.max_d; ++k) codes.push_back(rows[(size_t)i * mdp + k]);
+        p.sched_period = far_offset_of_sample(codes, kSlRows, dict, ndict);
+    }
     return SGM_OK;
 }
 
@@ -1671,13 +1986,15 @@ int rebuild_csr_formats(Part &p)
 {
     dfree(p.code); dfree(p.dict); dfree(p.sval); dfree(p.scode); dfree(p.scol); dfree(p.sbcode);
     p.code = nullptr; p.dict = nullptr; p.sval = nullptr; p.scode = nullptr; p.scol = nullptr; p.sbcode = nullptr;
-    p.ndict = 0; p.sw = 0; p.max_row = 0;
+    p.ndict = 0; p.sw = 0; p.max_row = 0; p.sched_period = 0;
+    free_slice_sched(p);
     return build_offset_dict(p, nullptr, nullptr);
 }
 int rebuild_ell_formats(Part &p)
 {
     dfree(p.ecode); dfree(p.dict); dfree(p.sval); dfree(p.scode);
-    p.ecode = nullptr; p.dict = nullptr; p.emdp = 0; p.sval = nullptr; p.scode = nullptr; p.sw = 0;
+    p.ecode = nullptr; p.dict = nullptr; p.emdp = 0; p.sval = nullptr; p.scode = nullptr; p.sw = 0; p.sched_period = 0;
+    free_slice_sched(p);
     SGM_TRY(build_ell_offset_dict(p));
     SGM_TRY(build_ell_colblock(p));
     return refresh_ell_colblock_values(p);
@@ -1695,6 +2012,7 @@ void free_part(Part &p)
 {
     dfree(p.rowptr); dfree(p.col); dfree(p.val); dfree(p.code); dfree(p.dict); dfree(p.sval); dfree(p.scode); dfree(p.scol); dfree(p.sbcode); dfree(p.ecol); dfree(p.eval); dfree(p.edeg); dfree(p.ecode); dfree(p.xext);
     for (auto &nb : p.nbrs) { dfree(nb.send_idx); dfree(nb.send_buf); }
+    free_slice_sched(p);
     free_ell_colblock(p);
     p = Part();
 }
@@ -2220,6 +2538,7 @@ int sgm_mat_kernel(sgm_mat A, char *buf, int len)
         else if (use_sliced32(p)) snprintf(name, sizeof name, "k_csr_sl32<W=%d>", p.sw);
         else if (use_offset_dict(p)) snprintf(name, sizeof name, "k_csr_do<256,%d,CW=1>", do_tile_for(p));
         else if (use_row_owner(p)) snprintf(name, sizeof name, "k_csr_do<256,%d,CW=4>", do_tile_for(p));
+        else if (use_row_groups(p)) snprintf(name, sizeof name, "k_csr_rg");
         else snprintf(name, sizeof name, "k_csr_spmv");
     }
     snprintf(buf, (size_t)len, "%s", name);

@@ -154,3 +154,30 @@ def test_one_hip_runtime_per_process_whichever_side_loads_first():
     libs = out.stdout.split()
     assert sum("libamdhip64" in l for l in libs) == 1, libs
     assert sum("libhsa-runtime64" in l for l in libs) == 1, libs
+
+
+@pytest.mark.parametrize("nsl,period,grid,band", [(195112, 215296, 8192, 64), (24389, 215296, 4096, 64), (19411, 46225, 4096, 32),
+                                                   (1000, 20000, 64, 16), (17, 999999, 8, 64), (4096, 16384, 2048, 8)])
+def test_slice_schedule_is_a_permutation(nsl, period, grid, band):
+    """sgm_slice_sched_host (host-only; the table the sliced kernels walk when "slice_sched" is on): every slice
+    exactly once, a workgroup's empty entries only at its tail, slices one period apart on the same XCD
+    (workgroup % 8) and about one band apart in its sequence."""
+    t = sg.slice_sched_host(nsl, period, grid, band)
+    assert t.shape[1] == grid
+    v = t[t >= 0]
+    assert np.array_equal(np.sort(v), np.arange(nsl))
+    filled = (t >= 0)
+    assert np.all(filled[:-1] | ~filled[1:])          # once a column is empty it stays empty
+    xcd_of = np.empty(nsl, np.int64)
+    pos_of = np.empty(nsl, np.int64)
+    it, b = np.nonzero(filled)
+    xcd_of[t[it, b]] = b % 8
+    pos_of[t[it, b]] = it * (grid // 8) + b // 8
+    step = period / 512.0
+    if step >= 32 and nsl > 4 * step:
+        s0 = np.arange(0, int(nsl - step - 1))
+        s1 = np.round(s0 + step).astype(np.int64)
+        same = xcd_of[s0] == xcd_of[s1]
+        assert same.mean() > 0.9                       # (band edges: the neighbour one plane up may sit in the next band)
+        d = (pos_of[s1] - pos_of[s0])[same]
+        assert np.median(np.abs(d)) <= 2 * band + 2

@@ -362,28 +362,32 @@ def test_composite_vs_reference_fixture(golden, name):
         assert np.abs(u - ur).max() / np.abs(ur).max() <= max(1e-12, kappa * tol), k
 
 
-def _kernel_options(dict_opt, sl_opt, ro_opt):
+def _kernel_options(dict_opt, sl_opt, ro_opt, rg_opt=1):
     sg.set_option("csr_offset_dict", dict_opt)
     sg.set_option("csr_sliced", sl_opt)
     sg.set_option("csr_row_owner", ro_opt)
+    sg.set_option("csr_row_groups", rg_opt)
 
 
-KERNEL_COMBOS = ((1, 1, 1, "k_csr_sl"), (1, 0, 1, "CW=1"), (0, 1, 1, "k_csr_sl32"), (0, 0, 1, "CW=4"), (0, 0, 0, "k_csr_spmv"))
+# (offset dictionary, sliced forms, row-owner gather, row-grouped gather, the kernel a stencil matrix then takes)
+KERNEL_COMBOS = ((1, 1, 1, 1, "k_csr_sl"), (1, 0, 1, 1, "CW=1"), (0, 1, 1, 1, "k_csr_sl32"), (0, 0, 1, 1, "CW=4"),
+                 (0, 0, 0, 1, "k_csr_rg"), (0, 0, 0, 0, "k_csr_spmv"))
 
 
 def test_offset_dict_and_int32_kernels_agree(orc):
-    """Five CSR kernels, one result: sliced 4-bit codes (rows <= 8 entries, <= 15 offsets),
+    """Six CSR kernels, one result: sliced 4-bit codes (rows <= 8 entries, <= 15 offsets),
     1-byte offset-dictionary codes (other stencil-like matrices), sliced int32 columns (short rows
-    without a dictionary), int32 columns gathered by the row's owner lane (rows <= 32 entries), int32
-    columns gathered while streaming (any row length).  All must equal the oracle bit for bit."""
+    without a dictionary), int32 columns gathered by the row's owner lane (rows <= 64 entries), by
+    several lanes per row with the owner summing (longer rows), or while streaming (any row length).
+    All must equal the oracle bit for bit."""
     rs = np.random.RandomState(8)
     for name, A in _cases(orc)[:4]:
         x = rs.standard_normal(A.m)
         y_ref = A.matvec(x)
         yt_ref = A.matvec_t(rs.standard_normal(A.n) * 0 + 1.0)
         seen = set()
-        for dict_opt, sl_opt, ro_opt, _tag in KERNEL_COMBOS:
-            _kernel_options(dict_opt, sl_opt, ro_opt)
+        for dict_opt, sl_opt, ro_opt, rg_opt, _tag in KERNEL_COMBOS:
+            _kernel_options(dict_opt, sl_opt, ro_opt, rg_opt)
             try:
                 H = hip_from_oracle(A)
                 seen.add(H.kernel)
@@ -393,10 +397,10 @@ def test_offset_dict_and_int32_kernels_agree(orc):
                 H.matvec_t(np.ones(A.n), yt)
             finally:
                 _kernel_options(1, 1, 1)
-            assert np.array_equal(y, y_ref), (name, dict_opt, sl_opt, ro_opt)
-            assert np.array_equal(yt, yt_ref), (name, dict_opt, sl_opt, ro_opt)
-        # the stencils exercise all four kernels; the random matrix has no dictionary
-        assert len(seen) == (2 if name.startswith("random") else 5), (name, seen)
+            assert np.array_equal(y, y_ref), (name, dict_opt, sl_opt, ro_opt, rg_opt)
+            assert np.array_equal(yt, yt_ref), (name, dict_opt, sl_opt, ro_opt, rg_opt)
+        # the stencils exercise all six kernels; the random matrix has no dictionary
+        assert len(seen) == (3 if name.startswith("random") else 6), (name, seen)
 
 
 def _banded_short_rows(n, seed, wmax=8, noffs=15):
@@ -457,8 +461,8 @@ def test_randomised_matrices_every_kernel_vs_oracle(orc, kind):
         xt, t0 = rs.standard_normal(n), rs.standard_normal(m)
         y_ref, ya_ref = A.matvec(x), A.matvec_add(x, y0.copy())
         t_ref, ta_ref = A.matvec_t(xt), A.matvec_t_add(xt, t0.copy())
-        for dict_opt, sl_opt, ro_opt, _tag in KERNEL_COMBOS:
-            _kernel_options(dict_opt, sl_opt, ro_opt)
+        for dict_opt, sl_opt, ro_opt, rg_opt, _tag in KERNEL_COMBOS:
+            _kernel_options(dict_opt, sl_opt, ro_opt, rg_opt)
             try:
                 H = sg.csr_matrix(n, m, ptr, node, val)
                 kernels.add(H.kernel.split("<")[0] + ("CW4" if "CW=4" in H.kernel else ""))
@@ -472,13 +476,15 @@ def test_randomised_matrices_every_kernel_vs_oracle(orc, kind):
                 H.matvec_t_add(xt, ta)
             finally:
                 _kernel_options(1, 1, 1)
-            key = (kind, _trial, n, m, dict_opt, sl_opt, ro_opt)
+            key = (kind, _trial, n, m, dict_opt, sl_opt, ro_opt, rg_opt)
             assert np.array_equal(y, y_ref), key
             assert np.array_equal(ya, ya_ref), key
             assert np.array_equal(t, t_ref), key
             assert np.array_equal(ta, ta_ref), key
     expect = {"banded": "k_csr_sl", "many_offsets": "k_csr_do", "short_random": "k_csr_sl32", "ragged": "k_csr_spmv"}[kind]
     assert expect in kernels, (kind, kernels)
+    if kind == "ragged":
+        assert "k_csr_rg" in kernels, kernels
 
 
 @pytest.mark.parametrize("max_d", [1, 3, 4, 5, 8, 9, 16, 20])
@@ -621,8 +627,8 @@ def test_randomised_partitions_vs_oracle(orc, nparts):
         starts = np.sort(np.concatenate([[0, n], rs.choice(np.arange(2, n - 2, 2), size=nparts - 1, replace=False)]))
         x, y0 = rs.standard_normal(n), rs.standard_normal(n)
         y_ref, ya_ref = A.matvec(x), A.matvec_add(x, y0.copy())
-        for dict_opt, sl_opt, ro_opt, _tag in KERNEL_COMBOS:
-            _kernel_options(dict_opt, sl_opt, ro_opt)
+        for dict_opt, sl_opt, ro_opt, rg_opt, _tag in KERNEL_COMBOS:
+            _kernel_options(dict_opt, sl_opt, ro_opt, rg_opt)
             try:
                 H = sg.partitioned_csr_matrix(n, n, ptr, node, val, starts)
                 y = np.zeros(n)
@@ -633,6 +639,123 @@ def test_randomised_partitions_vs_oracle(orc, nparts):
                 _kernel_options(1, 1, 1)
             assert np.array_equal(y, y_ref), (trial, n, list(starts), dict_opt, sl_opt, ro_opt)
             assert np.array_equal(ya, ya_ref), (trial, n, list(starts), dict_opt, sl_opt, ro_opt)
+
+
+@pytest.mark.parametrize("n,lo,hi", [(700, 70, 120), (5000, 66, 90), (3001, 1, 200), (9000, 33, 64), (2500, 100, 2600)])
+def test_long_row_kernels_vs_oracle(orc, n, lo, hi):
+    """General matrices with LONG rows (arbitrary columns inside a band, no dictionary): the row-owner kernel up to 64
+    entries per row, the row-grouped gather kernel beyond (several gather lanes per row, sums by the row's owner, rows
+    carried across tiles) and the streaming kernel -- matvec, y += A x, both transpose products, Inf/NaN in x, a row
+    partition with halo ranges, and CG with the dots fused into the product, all against the oracle bit for bit."""
+    import scipy.sparse as sp
+    rs = np.random.RandomState(n + lo + hi)
+    band = max(2 * hi, 300)
+    deg = rs.randint(lo, hi + 1, size=n)
+    deg[rs.randint(0, n, size=5)] = 0
+    deg = np.minimum(deg, n)
+    rows = np.repeat(np.arange(n), deg)
+    cols = np.clip(rows + rs.randint(-band, band + 1, size=rows.size), 0, n - 1)
+    B = sp.csr_matrix((rs.standard_normal(rows.size) * 0.01, (rows, cols)), shape=(n, n))
+    B.sum_duplicates()
+    S = (B + B.T).tocsr()                      # symmetric, sorted columns
+    S = (S + sp.diags(np.abs(S).sum(axis=1).A1 + 1.0)).tocsr()        # diagonally dominant: SPD
+    S.sort_indices()
+    ptr, node, val = (S.indptr + 1).astype(np.int32), (S.indices + 1).astype(np.int32), S.data.copy()
+    A = orc.CsrMatrix(n, n, ptr, node, val)
+    x, y0 = rs.standard_normal(n), rs.standard_normal(n)
+    y_ref, ya_ref, t_ref, ta_ref = A.matvec(x), A.matvec_add(x, y0.copy()), A.matvec_t(x), A.matvec_t_add(x, y0.copy())
+    xb = x.copy()
+    xb[rs.randint(0, n, 4)] = np.inf
+    xb[rs.randint(0, n, 2)] = np.nan
+    yb_ref = A.matvec(xb)
+    b = P.test_vector(n)
+    ur, itr, _, _ = orc.cg(A, b, tol=1e-12)
+    starts = sg.partition_rows_by_nnz(ptr, 3, align=2)
+    seen = set()
+    for ro_opt, rg_opt in ((1, 1), (0, 1), (0, 0)):
+        _kernel_options(1, 1, ro_opt, rg_opt)
+        try:
+            H = sg.csr_matrix(n, n, ptr, node, val)
+            seen.add(H.kernel.split("<")[0])
+            y = np.zeros(n)
+            H.matvec(x, y)
+            ya = y0.copy()
+            H.matvec_add(x, ya)
+            t = np.zeros(n)
+            H.matvec_t(x, t)
+            ta = y0.copy()
+            H.matvec_t_add(x, ta)
+            yb = np.zeros(n)
+            H.matvec(xb, yb)
+            Hp = sg.partitioned_csr_matrix(n, n, ptr, node, val, starts)
+            yp = np.zeros(n)
+            Hp.matvec(x, yp)
+            sv = sg.cg(1e-12)
+            sv.setup(H)
+            u = np.zeros(n)
+            sv.solve(H, u, b)
+        finally:
+            _kernel_options(1, 1, 1, 1)
+        key = (n, lo, hi, ro_opt, rg_opt)
+        assert np.array_equal(y, y_ref), key
+        assert np.array_equal(ya, ya_ref), key
+        assert np.array_equal(t, t_ref), key
+        assert np.array_equal(ta, ta_ref), key
+        assert np.array_equal(yb, yb_ref, equal_nan=True), key
+        assert np.array_equal(yp, y_ref), key
+        assert abs(sv.iterations - itr) <= 1 and np.abs(u - ur).max() / np.abs(ur).max() <= 1e-11, key
+    assert "k_csr_spmv" in seen and ("k_csr_rg" in seen or int(S.getnnz(axis=1).mean()) > 128), seen
+
+
+def test_slice_schedule_keeps_results(orc):
+    """"slice_sched" on (off by default): the sliced kernels take their 512-row slices in the band order of
+    sgm_slice_sched_host on a 3-D grid whose plane stride is >= 32 slices; products and y += A x are the same bits
+    as with the computed maps (only the order of whole slices changes); CG agrees to rounding."""
+    import torch
+    nx, ny, nz = 160, 128, 210            # plane = 20480 rows = 40 slices; 8400 slices >= 2 x the 4096-workgroup grid
+    n = nx * ny * nz
+    dev = torch.device("cuda", 0)
+    k = torch.arange(n, device=dev)
+    i, j, l = k % nx, (k // nx) % ny, k // (nx * ny)
+    offs = ((-nx * ny, l > 0), (-nx, j > 0), (-1, i > 0), (0, torch.ones_like(k, dtype=torch.bool)), (1, i < nx - 1), (nx, j < ny - 1), (nx * ny, l < nz - 1))
+    M = torch.stack([m for _o, m in offs], 1)
+    Ccol = torch.stack([k + o for o, _m in offs], 1)
+    V = torch.tensor([-1.0, -1.25, -1.5, 8.0, -1.5, -1.25, -1.0], dtype=torch.float64, device=dev).repeat(n, 1)
+    ptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    ptr[1:] = torch.cumsum(M.sum(1), 0)
+    ptr1, node1, val = (ptr + 1).to(torch.int32), (Ccol[M] + 1).to(torch.int32), V[M].contiguous()
+    x = torch.sin(0.37 * torch.arange(1, n + 1, dtype=torch.float64, device=dev))
+    out = {}
+    for sched in (0, 1):
+        sg.set_option("slice_sched", sched)
+        try:
+            A = sg.csr_matrix(n, n, ptr1, node1, val)
+            assert A.kernel.startswith("k_csr_sl<W=7>")
+            y = torch.zeros(n, dtype=torch.float64, device=dev)
+            A.matvec(x, y)
+            ya = x.clone()
+            A.matvec_add(x, ya)
+            sv = sg.cg(1e-10)
+            sv.setup(A)
+            sv.set_max_iter(25)
+            u = torch.zeros(n, dtype=torch.float64, device=dev)
+            sv.solve(A, u, x, check=False)
+            sg.synchronize()
+            out[sched] = (y.cpu().numpy(), ya.cpu().numpy(), u.cpu().numpy())
+            del A
+        finally:
+            sg.set_option("slice_sched", 0)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    # (the fused p.q partial sums follow the workgroups' slices, so CG's scalars differ in their last bits)
+    assert np.abs(out[0][2] - out[1][2]).max() <= 1e-9 * np.abs(out[0][2]).max()
+    # a sample of rows against the host sum in stored order
+    rs = np.random.RandomState(3)
+    hp, hn, hv, hx = ptr1.cpu().numpy(), node1.cpu().numpy(), val.cpu().numpy(), x.cpu().numpy()
+    for r in rs.randint(0, n, size=300):
+        z = 0.0
+        for kk in range(hp[r] - 1, hp[r + 1] - 1):
+            z = z + hv[kk] * hx[hn[kk] - 1]
+        assert out[1][0][r] == 0.0 + z
 
 
 @pytest.mark.parametrize("n,wmax", [(1, 3), (511, 5), (513, 8), (40001, 12), (70003, 16)])
@@ -763,7 +886,8 @@ def test_sliced_byte_coded_kernel_rows_of_9_to_32_entries(orc, kind):
     H.matvec_t_add(x, t)
     assert np.array_equal(t, A.matvec_t_add(x, t0.copy()))
     # the other kernels on the same handle
-    for opts in ({"csr_sliced": 0}, {"csr_sliced": 0, "csr_offset_dict": 0}, {"csr_sliced": 0, "csr_offset_dict": 0, "csr_row_owner": 0}):
+    for opts in ({"csr_sliced": 0}, {"csr_sliced": 0, "csr_offset_dict": 0}, {"csr_sliced": 0, "csr_offset_dict": 0, "csr_row_owner": 0},
+                 {"csr_sliced": 0, "csr_offset_dict": 0, "csr_row_owner": 0, "csr_row_groups": 0}):
         for k_, v_ in opts.items():
             sg.set_option(k_, v_)
         try:

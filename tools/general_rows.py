@@ -8,7 +8,12 @@ import sigma_amd as sg
 sg.init(0)
 sg.use_torch_stream()
 dev = torch.device("cuda", 0)
-for n, lo, hi, band in ((4_000_000, 33, 64, 4096), (2_000_000, 64, 128, 8192), (8_000_000, 20, 40, 2048), (10_000_000, 5, 5, 3162)):
+CASES = ((4_000_000, 33, 64, 4096), (2_000_000, 64, 128, 8192), (8_000_000, 20, 40, 2048), (6_000_000, 8, 60, 3000), (1_000_000, 150, 300, 20000))
+if os.environ.get("GR_CASES"):          # e.g. GR_CASES=0,2 GR_KERNELS=1 GR_REPS=3 under a profiler
+    CASES = tuple(CASES[int(t)] for t in os.environ["GR_CASES"].split(","))
+KERNELS = tuple(int(t) for t in os.environ.get("GR_KERNELS", "1,0").split(","))
+REPS = int(os.environ.get("GR_REPS", "50"))
+for n, lo, hi, band in CASES:
     g = torch.Generator(device=dev); g.manual_seed(1)
     deg = torch.randint(lo, hi + 1, (n,), device=dev, generator=g, dtype=torch.int64)
     ptr = torch.zeros(n + 1, dtype=torch.int64, device=dev); ptr[1:] = torch.cumsum(deg, 0)
@@ -21,24 +26,31 @@ for n, lo, hi, band in ((4_000_000, 33, 64, 4096), (2_000_000, 64, 128, 8192), (
     col = col.clamp_(0, n - 1)
     val = torch.rand(nnz, device=dev, generator=g, dtype=torch.float64)
     A = sg.csr_matrix(n, n, (ptr + 1).to(torch.int32), (col + 1).to(torch.int32), val)
-    x = torch.rand(n, device=dev, dtype=torch.float64); y = torch.zeros_like(x)
-    for _ in range(5): A.matvec(x, y)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(50): A.matvec(x, y)
-    e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 20.0
+    x = torch.rand(n, device=dev, dtype=torch.float64)
     moved = 12 * nnz + 4 * n + 16 * n
-    # check a few rows against torch in stored order
-    idx = torch.randint(0, n, (2000,), device=dev, generator=g)
-    ok = True
-    for i in idx[:200].tolist():
-        k0, k1 = int(ptr[i]), int(ptr[i + 1])
-        z = 0.0
-        vv = val[k0:k1].cpu().numpy(); xx = x[col[k0:k1]].cpu().numpy()
-        for a, b in zip(vv, xx): z = z + a * b
-        ok = ok and (0.0 + z == float(y[i]))
-    print(json.dumps({"n": n, "nnz_per_row": [lo, hi], "kernel": A.kernel, "us": us, "moved_GB": moved / 1e9, "TBs": moved / us / 1e6,
-                      "frac_of_8TBs": moved / us / 8e6, "rows_bit_exact": bool(ok)}), flush=True)
+    ys = []
+    for rowline in KERNELS:
+        sg.set_option("csr_row_groups", rowline)
+        y = torch.zeros_like(x)
+        for _ in range(min(5, REPS)): A.matvec(x, y)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(REPS): A.matvec(x, y)
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1000.0 / REPS
+        ys.append(y)
+        # check a few rows against a host loop in stored order
+        idx = torch.randint(0, n, (200,), device=dev, generator=g)
+        ok = True
+        for i in idx.tolist():
+            k0, k1 = int(ptr[i]), int(ptr[i + 1])
+            z = 0.0
+            vv = val[k0:k1].cpu().numpy(); xx = x[col[k0:k1]].cpu().numpy()
+            for a, b in zip(vv, xx): z = z + a * b
+            ok = ok and (0.0 + z == float(y[i]))
+        print(json.dumps({"n": n, "nnz_per_row": [lo, hi], "kernel": A.kernel, "us": round(us, 1), "moved_GB": round(moved / 1e9, 3),
+                          "TBs": round(moved / us / 1e6, 3), "frac_of_8TBs": round(moved / us / 8e6, 3), "rows_bit_exact": bool(ok)}), flush=True)
+    if len(ys) > 1: print(json.dumps({"kernels_bit_identical": bool(torch.equal(ys[0], ys[1]))}), flush=True)
+    sg.set_option("csr_row_groups", 1)
     A.destroy()

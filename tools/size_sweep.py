@@ -20,6 +20,10 @@ def build(spec, dev):
         k = torch.arange(n, device=dev)
         one = torch.ones(n, dtype=torch.bool, device=dev)
         return n, stencil_csr_torch(n, [(-1, k > 0, -1.0), (0, one, 2.0), (1, k < n - 1, -1.0)], dev)
+    if kind == "1d7":       # 7 entries per row like the 3-D stencil, but every x entry next door: the footprint without the reach
+        n = int(dims)
+        k = torch.arange(n, device=dev)
+        return n, stencil_csr_torch(n, [(d, (k + d >= 0) & (k + d < n), 6.0 if d == 0 else -1.0) for d in (-3, -2, -1, 0, 1, 2, 3)], dev)
     if kind == "2d":
         nx, ny = (int(t) for t in dims.split("x"))
         n = nx * ny
