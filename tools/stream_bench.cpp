@@ -39,6 +39,24 @@ __global__ __launch_bounds__(256) void k_copy(const f64x2 *__restrict__ a, f64x2
     for (; i < n2; i += stride) b[i] = a[i];
 }
 
+// RPW streamed 16-byte reads per 16-byte streamed write (an SpMV on the 7-point sliced layout reads 68 bytes per 8 written:
+// RPW = 8; a whole CG iteration about 3.4 : 1): what a read-mostly MIX reaches, against read-only and copy
+template <int RPW>
+__global__ __launch_bounds__(256) void k_mix(const f64x2 *__restrict__ a, f64x2 *__restrict__ b, size_t nw)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < nw; i += stride) {
+        f64x2 v[RPW];
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) v[u] = __builtin_nontemporal_load(a + i + u * nw);
+        f64x2 s = v[0];
+#pragma unroll
+        for (int u = 1; u < RPW; ++u) { s.x += v[u].x; s.y += v[u].y; }
+        __builtin_nontemporal_store(s, b + i);
+    }
+}
+
 template <class F>
 double timeit(F f, int reps)
 {
@@ -73,6 +91,15 @@ int main(int argc, char **argv)
         printf("copy  plain U4 grid %6d: %.1f us  %.0f GB/s (r+w)\n", grid, t * 1e6, bytes / t / 1e9);
         t = timeit([&] { k_copy<true, 4><<<grid, 256>>>(a, b, n2 / 2); }, 50);
         printf("copy  nt    U4 grid %6d: %.1f us  %.0f GB/s (r+w)\n", grid, t * 1e6, bytes / t / 1e9);
+    }
+    for (int grid : {2048, 8192}) {
+        double t;
+        size_t nw = n2 / 8;
+        t = timeit([&] { k_mix<8><<<grid, 256>>>(a, b, nw); }, 30);
+        printf("mix 8 reads : 1 write grid %6d: %.1f us  %.0f GB/s (r+w)\n", grid, t * 1e6, nw * 16.0 * 9 / t / 1e9);
+        nw = n2 / 3;
+        t = timeit([&] { k_mix<3><<<grid, 256>>>(a, b, nw); }, 30);
+        printf("mix 3 reads : 1 write grid %6d: %.1f us  %.0f GB/s (r+w)\n", grid, t * 1e6, nw * 16.0 * 4 / t / 1e9);
     }
     return 0;
 }
