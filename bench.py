@@ -303,10 +303,10 @@ def worker(args):
                               {"csr_sliced": 0}),
                              ("int32_columns, row-owner gather (general kernel, rows <= 64 entries)",
                               {"csr_offset_dict": 0, "csr_row_owner": 1}),
-                             ("int32_columns, row-grouped gather (general kernel, longer rows)",
+                             ("int32_columns, line-staged row owner (general kernel, longer rows)",
                               {"csr_offset_dict": 0, "csr_row_owner": 0}),
                              ("int32_columns, streaming gather (general kernel, any row length)",
-                              {"csr_offset_dict": 0, "csr_row_owner": 0, "csr_row_groups": 0})):
+                              {"csr_offset_dict": 0, "csr_row_owner": 0, "csr_row_lines": 0})):
             for k, v in opts.items():
                 sg.set_option(k, v)
             for _ in range(5):
@@ -314,7 +314,7 @@ def worker(args):
             variants[vlabel] = variant_entry(A, time_kernel(A, x, y, reps=50), time_kernel(A, x, y, reps=20, flush=scratch))
             sg.set_option("csr_offset_dict", 1)
             sg.set_option("csr_row_owner", 1)
-            sg.set_option("csr_row_groups", 1)
+            sg.set_option("csr_row_lines", 1)
             sg.set_option("csr_sliced", 1)
         # a handle created WITHOUT the dictionary: short rows take the sliced int32-column kernel
         # (what a matrix with arbitrary columns and rows <= 16 entries gets; 12 B per slot)

@@ -122,7 +122,7 @@ def synchronize():
 def set_option(name, value):
     """sgm_set_option: "csr_offset_dict" 1/0 (1-byte column codes for stencil-like matrices),
     "csr_row_owner" 1/0 (row-owner gather for int32-column matrices with rows <= 64 entries),
-    "csr_row_groups" 1/0 (row-grouped gather for longer rows), "slice_sched" 0/1 (band-ordered slices on 3-D grids),
+    "csr_row_lines" 1/0 (line-staged row-owner kernel for longer rows), "slice_sched" 0/1 (band-ordered slices on 3-D grids),
     "csr_sliced" 1/0 (slot-major slices + 4-bit codes for rows <= 8 entries / <= 15 offsets; default on),
     "ell_offset_dict" 1/0, "ell_colblock" 0/1/2, "ell_colblock_cols", "ell_colblock_chunks", "ell_colblock_rows" 0/256/512,
     "ildu_strips" 1/0, "gmres_cgs2" 1/0."""

@@ -36,7 +36,7 @@ struct Options {
     int csr_offset_dict = 1;       // use the 1-byte column code kernel when a matrix allows it
     int ell_offset_dict = 1;       // ELLPACK twin of csr_offset_dict (max_d <= 16)
     int csr_row_owner = 1;         // int32 columns, rows <= 64 entries: gather by the row's owner lane
-    int csr_row_groups = 1;        // int32 columns, longer rows (averaging <= 128 entries): Q gather lanes per row, ordered sums by the row's owner (k_csr_rg)
+    int csr_row_lines = 1;         // int32 columns, rows longer than that (up to 4096 entries): one 128-byte line of val per row and pass, all rows of a block walked by their owner lanes (k_csr_rl)
     int csr_sliced = 1;            // rows <= 8 entries, <= 15 offsets: slot-major slices + 4-bit codes (k_csr_sl)
     int ell_colblock = 1;          // ELLPACK with random columns: column-blocked two-phase product (0 never, 1 automatic, 2 always)
     int ell_colblock_cols = 16384; // its column block (x entries staged in LDS per workgroup; even, <= 16384)

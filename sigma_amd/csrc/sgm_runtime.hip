@@ -157,7 +157,7 @@ int sgm_set_option(const char *name, int value)
     if (!strcmp(name, "csr_offset_dict")) { g_opt.csr_offset_dict = value; return SGM_OK; }
     if (!strcmp(name, "csr_row_owner")) { g_opt.csr_row_owner = value; return SGM_OK; }
     if (!strcmp(name, "csr_sliced")) { g_opt.csr_sliced = value; return SGM_OK; }
-    if (!strcmp(name, "csr_row_groups")) { g_opt.csr_row_groups = value; return SGM_OK; }
+    if (!strcmp(name, "csr_row_lines")) { g_opt.csr_row_lines = value; return SGM_OK; }
     if (!strcmp(name, "ell_offset_dict")) { g_opt.ell_offset_dict = value; return SGM_OK; }
     if (!strcmp(name, "ell_colblock")) { g_opt.ell_colblock = value; return SGM_OK; }
     if (!strcmp(name, "ell_colblock_cols")) { g_opt.ell_colblock_cols = std::min(16384, std::max(2, value)) & ~1; return SGM_OK; }

@@ -181,124 +181,110 @@ __global__ __launch_bounds__(BLOCK) void k_csr_spmv(
 // General CSR with LONG rows (no dictionary, rows beyond the row-owner kernel's 64 entries: finite-element matrices of
 // higher order, 3-D unstructured meshes).  k_csr_spmv gathers entry-parallel: the 64 lanes of one gather instruction
 // hold 64 consecutive ENTRIES -- of one or two rows, so 64 different x lines, each moved L2 -> L1 for 8 of its 128 bytes
-// (measured on banded rows of 33..64 entries: 2.0-2.2 TB/s of moved bytes, the L2 -> L1 path carrying 16 x as much).
+// (measured on banded rows of 33..300 entries: 1.6-2.6 TB/s of moved bytes, the L2 -> L1 path carrying 16 x as much).
 // k_csr_do lets the lane that owns a row gather for it, so one instruction holds the k-th entries of consecutive rows
 // (neighbouring columns in any matrix with a banded / mesh-local numbering: a handful of lines) -- but a tile of T
 // staged entries holds only T / len rows, and each of those few lanes walks len entries: time grows with the row length.
-// This kernel keeps k_csr_do's streaming (tiles of contiguous entries, every byte fetched once by coalesced 16-byte
-// loads, values and columns parked in LDS) and gives every row of the tile Q = 2^k gather lanes, Q the largest power of
-// two with Q x (rows in the tile) <= 256: lane (r, q) takes entries q, q + Q, ... of row r, so a gather instruction covers
-// 64 / Q consecutive rows x Q consecutive slots.  The products replace the values in LDS; the row's owner lane then
-// adds them in stored order, carrying its sum across tiles (products rounded one by one, left-to-right sums:
-// bit-identical to csr_matvec_add).  The next tile's loads are in flight while this one is gathered and summed.
-template <int BLOCK, int TILE, bool ADD, bool DOT_W, bool DOT_YY>
-__global__ __launch_bounds__(BLOCK) void k_csr_rg(
+// Here a lane owns a row too, and ALL 256 rows of the block are walked at once; what makes that fit in LDS is the
+// staging unit: not "every entry of the row block" but ONE 128-BYTE LINE of `val` (16 entries) per row and pass.  In
+// pass c, row j's entries that lie in line (first line of row j) + c are staged -- eight lanes per row fetch the line's
+// 16-byte pieces and the 8-byte pieces of `col` beside them, only pieces that hold an entry of the row -- and lane j
+// then walks its up-to-16 entries: columns out of LDS, eight x requests in flight, products rounded one by one and
+// added in stored order (bit-identical to csr_matvec_add).  The loads of pass c + 1 are in flight while pass c is
+// summed.  A block takes as many passes as its longest row has lines.  LDS: 256 rows x 17 (16 + 1 against bank
+// conflicts) x 12 B = 52 KiB, three workgroups per CU.  Price: a `val` line that two rows share and the two halves of
+// a `col` line are requested in different passes and L2 keeps neither (PMC, rows of 33..64 entries: 4.04 GB fetched for
+// 2.36 GB needed; plain instead of nontemporal loads change nothing) -- the longer the rows, the smaller that share.
+template <bool ADD, bool DOT_W, bool DOT_YY>
+__global__ __launch_bounds__(256) void k_csr_rl(
     int32_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ w, double *__restrict__ part_wy, double *__restrict__ part_yy,
     const int *__restrict__ flag_done, int gen, int remap)
 {
-    constexpr int VPT = TILE / (2 * BLOCK), U = 8;
-    static_assert(TILE % (2 * BLOCK) == 0, "whole 16-byte value loads per lane");
-    __shared__ double pl[TILE];            // values, then products
-    __shared__ int32_t cl[TILE];
+    constexpr int BLOCK = 256, ST = 17, RPI = BLOCK / 8, NI = BLOCK / RPI;
+    __shared__ double vl[BLOCK * ST];
+    __shared__ int32_t cl[BLOCK * ST];
     __shared__ int32_t rp[BLOCK + 1];
+    __shared__ int wmax[BLOCK / 64];
     __shared__ double red[BLOCK / 64];
     if (flag_done) { const int st = *flag_done; if (st && gen >= st) return; }
-
     const int tid = threadIdx.x;
     const bool chain = (remap & 256) != 0;
     const int rmode = remap & 255;
     const int64_t nrb = ((int64_t)n + BLOCK - 1) / BLOCK;
+    const int sj = tid >> 3, sp = 2 * (tid & 7);
     double dwy = 0.0, dyy = 0.0;
-
     for (int it = 0;; ++it) {
         if ((int64_t)it * gridDim.x >= nrb) break;
         const int64_t rb = rmode ? rowblock_of(it, blockIdx.x, gridDim.x, nrb, rmode) : (int64_t)it * gridDim.x + blockIdx.x;
-        if (rb >= nrb) continue;          // uniform per block
+        if (rb >= nrb) continue;
         const int32_t r0 = (int32_t)(rb * BLOCK);
         const int32_t row = r0 + tid;
-        rp[tid] = rowptr[min(row, n)];    // rows past n are empty (the previous block's gathers, the last readers of rp, lie behind a barrier)
+        rp[tid] = rowptr[min(row, n)];
         if (tid == 0) rp[BLOCK] = rowptr[min(r0 + BLOCK, n)];
-        double wv = 0.0, y0 = 0.0;        // requested now, consumed after the row sum
+        double wv = 0.0, y0 = 0.0;
         if (row < n) {
             if (DOT_W) wv = w[row];
             if (ADD) y0 = y[row];
         }
         __syncthreads();
-        int32_t k = rp[tid];
-        const int32_t ke = rp[tid + 1];
-        const int32_t s = rp[0] & ~1;     // tile starts are even: 16-byte aligned value loads
-        const int32_t e = rp[BLOCK];
-        double z = (ADD && chain) ? y0 : 0.0;
-
-        f64x2 v[VPT];
-        i32x2 c[VPT];
-        auto fetch = [&](int32_t ts, int32_t te) {
+        const int32_t s = rp[tid], e = rp[tid + 1];
+        int np = e > s ? ((e - 1) >> 4) - (s >> 4) + 1 : 0;
 #pragma unroll
-            for (int m = 0; m < VPT; ++m) {
-                const int32_t j = ts + 2 * tid + 2 * BLOCK * m;
-                if (j < te) {             // arrays are padded by 2 entries: j + 1 is always readable
-                    v[m] = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + j));
-                    c[m] = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(col + j));
+        for (int off = 32; off > 0; off >>= 1) np = max(np, __shfl_xor(np, off, 64));
+        if ((tid & 63) == 0) wmax[tid >> 6] = np;
+        int32_t ss[NI], se[NI];
+#pragma unroll
+        for (int m = 0; m < NI; ++m) { ss[m] = rp[sj + RPI * m]; se[m] = rp[sj + RPI * m + 1]; }
+        __syncthreads();
+        int npass = wmax[0];
+#pragma unroll
+        for (int t = 1; t < BLOCK / 64; ++t) npass = max(npass, wmax[t]);
+        f64x2 v[NI];
+        i32x2 cc[NI];
+        auto fetch = [&](int c) {
+#pragma unroll
+            for (int m = 0; m < NI; ++m) {
+                const int32_t base = (((ss[m] >> 4) + c) << 4) + sp;
+                if (base < se[m] && base + 2 > ss[m]) {
+                    v[m] = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + base));
+                    cc[m] = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(col + base));
                 }
             }
         };
-        if (s < e) fetch(s, min(s + TILE, e));
-        for (int32_t ts = s; ts < e; ts += TILE) {
-            const int32_t te = min(ts + TILE, e);
-            if (ts != s) __syncthreads();           // the previous tile's sums are done with the LDS buffers
+        double z = (ADD && chain) ? y0 : 0.0;
+        if (npass > 0) fetch(0);
+        for (int c = 0; c < npass; ++c) {
 #pragma unroll
-            for (int m = 0; m < VPT; ++m) {
-                const int32_t j = ts + 2 * tid + 2 * BLOCK * m;
-                if (j < te) {
-                    *reinterpret_cast<f64x2 *>(pl + (j - ts)) = v[m];
-                    *reinterpret_cast<i32x2 *>(cl + (j - ts)) = c[m];
+            for (int m = 0; m < NI; ++m) {
+                const int32_t base = (((ss[m] >> 4) + c) << 4) + sp;
+                if (base < se[m] && base + 2 > ss[m]) {
+                    const int o = (sj + RPI * m) * ST + sp;
+                    vl[o] = v[m].x; vl[o + 1] = v[m].y;
+                    cl[o] = cc[m].x; cl[o + 1] = cc[m].y;
                 }
             }
             __syncthreads();
-            if (ts + TILE < e) fetch(ts + TILE, min(ts + 2 * TILE, e));       // in flight while this tile is gathered and summed
-            // rows of the block with entries in [ts, te): rf = rows that end at or before ts, rl = rows that start before te, - 1
-            int rf = 0, rl = 0;
+            if (c + 1 < npass) fetch(c + 1);
+            const int32_t line0 = ((s >> 4) + c) << 4;
+            const int qlo = max(s - line0, 0), qhi = min(e - line0, 16);
 #pragma unroll
-            for (int step = BLOCK / 2; step > 0; step >>= 1) {
-                if (rp[rf + step] <= ts) rf += step;          // rp[rf + step] = end of row rf + step - 1
-                if (rp[rl + step] < te) rl += step;           // start of row rl + step
-            }
-            const int R = max(rl - rf + 1, 1);
-            const int Q = BLOCK / R;                          // gather lanes per row (uniform)
-            const int rq = (tid * ((65536 + Q - 1) / Q)) >> 16;        // tid / Q (exact for tid < 65536 / Q ... BLOCK <= 256)
-            const int r = rf + rq, q = tid - rq * Q;
-            if (r <= rl) {
-                const int32_t lo = max(rp[r], ts), hi = min(rp[r + 1], te);
-                for (int32_t kk = lo + q; kk < hi; kk += U * Q) {
-                    double xv[U];
+            for (int h = 0; h < 16; h += 8) {
+                if (qhi > h && qlo < h + 8) {
+                    double xv[8], vv[8];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int32_t j = kk + u * Q;
-                        if (j < hi) xv[u] = x[cl[j - ts]];
-                    }
+                    for (int u = 0; u < 8; ++u)
+                        if (h + u >= qlo && h + u < qhi) {
+                            xv[u] = x[cl[tid * ST + h + u]];
+                            vv[u] = vl[tid * ST + h + u];
+                        }
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int32_t j = kk + u * Q;
-                        if (j < hi) pl[j - ts] = pl[j - ts] * xv[u];
-                    }
+                    for (int u = 0; u < 8; ++u)
+                        if (h + u >= qlo && h + u < qhi) z = z + vv[u] * xv[u];
                 }
             }
             __syncthreads();
-            // the owner of row i adds its products left to right (eight LDS reads at a time, the adds in stored order)
-            const int32_t kend = min(ke, te);
-            while (k < kend) {
-                const int cnt = min(kend - k, 8);
-                double pv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (u < cnt) pv[u] = pl[k + u - ts];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (u < cnt) z = z + pv[u];
-                k += cnt;
-            }
         }
         if (row < n) {
             const double yi = ADD ? (chain ? z : y0 + z) : 0.0 + z;
@@ -307,14 +293,8 @@ __global__ __launch_bounds__(BLOCK) void k_csr_rg(
             if (DOT_YY) dyy += yi * yi;
         }
     }
-    if (DOT_W) {
-        const double t = block_sum<BLOCK>(dwy, red);
-        if (tid == 0) part_wy[blockIdx.x] = t;
-    }
-    if (DOT_YY) {
-        const double t = block_sum<BLOCK>(dyy, red);
-        if (tid == 0) part_yy[blockIdx.x] = t;
-    }
+    if (DOT_W) { const double t = block_sum<BLOCK>(dwy, red); if (tid == 0) part_wy[blockIdx.x] = t; }
+    if (DOT_YY) { const double t = block_sum<BLOCK>(dyy, red); if (tid == 0) part_yy[blockIdx.x] = t; }
 }
 
 // CSR with dictionary-coded column offsets ("offset-dict" form).  Matrices from structured
@@ -973,24 +953,25 @@ static bool any_sliced(const Part &p) { return use_sliced(p) || use_sliced32(p) 
 // k_csr_do serves both the dictionary form and, for short rows, plain int32 columns
 static bool use_row_owner(const Part &p)
 {
-    // (rows of 33..64 entries, banded: 809-822 us against 850-890 with k_csr_rg and 1100-1150 with k_csr_spmv; beyond 64 the
-    // few lanes that own a tile's rows walk too long: 64..128 entries 1160 us against 1020 with k_csr_rg)
+    // (rows of 33..64 entries, banded: 809-822 us against 906 with k_csr_rl and 1100-1150 with k_csr_spmv; beyond 64 the
+    // few lanes that own a tile's rows walk too long: 64..128 entries 1160 us against 890 with k_csr_rl)
     return use_offset_dict(p) || (do_block_ok() && g_opt.csr_row_owner && p.max_row > 0 && p.max_row <= 64);
 }
 
-// long rows without a dictionary: the row-grouped gather kernel (k_csr_rg)
-constexpr int kRgTile = 2048;
-static bool use_row_groups(const Part &p)
+// long rows without a dictionary: the line-staged row-owner kernel (k_csr_rl).  A block takes as many passes as its
+// longest row has lines, so a matrix with a row beyond 4096 entries (an arrow matrix's dense row) stays with the
+// streaming kernel, whose gathers do not wait for one lane.
+// (rows of 64..128 entries, banded: 890 us against 1020 with a row-grouped gather variant -- contiguous tiles, Q gather
+// lanes per row, sums by the owner; in history -- 1160 with k_csr_do and 1180 with k_csr_spmv; 150..300: 1070 against 1670)
+static bool use_row_lines(const Part &p)
 {
-    // (rows averaging more than 128 entries stay with k_csr_spmv: the owner's serial sum over a tile that holds a handful of
-    // rows takes over -- 150..300 entries: 1840 us against 1670)
-    return g_opt.csr_row_groups && !any_sliced(p) && !use_row_owner(p) && p.n > 0 && p.nnz <= 128 * (int64_t)p.n;
+    return g_opt.csr_row_lines && !any_sliced(p) && !use_row_owner(p) && p.n > 0 && p.max_row <= 4096;
 }
-static int row_groups_resident_per_cu()
+static int row_lines_resident_per_cu()
 {
     static int nb = 0;
-    if (!nb && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_csr_rg<256, kRgTile, false, true, false>, 256, 0) != hipSuccess || nb < 1))
-        nb = 6;
+    if (!nb && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_csr_rl<false, true, false>, 256, 0) != hipSuccess || nb < 1))
+        nb = 3;
     return nb;
 }
 
@@ -1018,14 +999,14 @@ static int do_tile_for(const Part &p)
 static int grid_for_rows(const Part &p, int64_t rows, int64_t limit)
 {
     const SpmvCfg &c = spmv_cfg();
-    const int blk = any_sliced(p) ? kSlRows : use_row_groups(p) ? 256 : c.block;
+    const int blk = any_sliced(p) ? kSlRows : use_row_lines(p) ? 256 : c.block;
     const int64_t nrb = (rows + blk - 1) / blk;
     int64_t g = ((nrb + 7) / 8) * 8;
     int64_t cap = c.maxgrid;
     // round-robin slices, not a persistent resident grid: 4096 workgroups; 8192 from 32768 slices on
     // (n >= 1.7e7: 464^3 1.54 -> 1.45 ms, 300^3 355 -> 345 us; below that the consumers' re-reduction of more partials costs more)
     if (cap <= 0 && any_sliced(p)) cap = nrb >= 32768 ? kMaxGrid : kMaxGrid / 2;
-    if (cap <= 0 && use_row_groups(p)) cap = (int64_t)row_groups_resident_per_cu() * g_rt.num_cu;
+    if (cap <= 0 && use_row_lines(p)) cap = (int64_t)row_lines_resident_per_cu() * g_rt.num_cu;
     if (cap <= 0) cap = (int64_t)resident_per_cu(use_row_owner(p), c.block, use_row_owner(p) ? do_tile_for(p) : c.vpt,
                                                  use_offset_dict(p) ? 1 : 4) * g_rt.num_cu;
     if (cap > limit) cap = limit;
@@ -1103,13 +1084,13 @@ static void launch_csr(const Part &p, int grid, const double *x, double *y, cons
 }
 
 template <bool ADD>
-static void launch_csr_rg(const Part &p, int grid, const double *x, double *y, const double *w,
+static void launch_csr_rl(const Part &p, int grid, const double *x, double *y, const double *w,
                           double *pwy, double *pyy, const int *flag, int gen)
 {
     hipStream_t st = g_rt.stream;
     const int remap = (spmv_cfg().remap == 2 ? 2 : 1) | g_launch_flags;
 #define L(DW, DY)                                                                                       \
-    hipLaunchKernelGGL((k_csr_rg<256, kRgTile, ADD, DW, DY>), dim3(grid), dim3(256), 0, st, p.n, p.rowptr, p.col, p.val, x, y, w, \
+    hipLaunchKernelGGL((k_csr_rl<ADD, DW, DY>), dim3(grid), dim3(256), 0, st, p.n, p.rowptr, p.col, p.val, x, y, w, \
                        pwy, pyy, flag, gen, remap)
     if (w && pyy) L(true, true);
     else if (w) L(true, false);
@@ -1447,9 +1428,9 @@ static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const doub
     } else if (use_row_owner(p)) {
         if (add) launch_csr_do<true>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
         else launch_csr_do<false>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
-    } else if (use_row_groups(p)) {
-        if (add) launch_csr_rg<true>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
-        else launch_csr_rg<false>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
+    } else if (use_row_lines(p)) {
+        if (add) launch_csr_rl<true>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
+        else launch_csr_rl<false>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
     } else {
         if (add) launch_csr<true>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
         else launch_csr<false>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
@@ -2538,7 +2519,7 @@ int sgm_mat_kernel(sgm_mat A, char *buf, int len)
         else if (use_sliced32(p)) snprintf(name, sizeof name, "k_csr_sl32<W=%d>", p.sw);
         else if (use_offset_dict(p)) snprintf(name, sizeof name, "k_csr_do<256,%d,CW=1>", do_tile_for(p));
         else if (use_row_owner(p)) snprintf(name, sizeof name, "k_csr_do<256,%d,CW=4>", do_tile_for(p));
-        else if (use_row_groups(p)) snprintf(name, sizeof name, "k_csr_rg");
+        else if (use_row_lines(p)) snprintf(name, sizeof name, "k_csr_rl");
         else snprintf(name, sizeof name, "k_csr_spmv");
     }
     snprintf(buf, (size_t)len, "%s", name);

@@ -11,6 +11,7 @@ dev = torch.device("cuda", 0)
 CASES = ((4_000_000, 33, 64, 4096), (2_000_000, 64, 128, 8192), (8_000_000, 20, 40, 2048), (6_000_000, 8, 60, 3000), (1_000_000, 150, 300, 20000))
 if os.environ.get("GR_CASES"):          # e.g. GR_CASES=0,2 GR_KERNELS=1 GR_REPS=3 under a profiler
     CASES = tuple(CASES[int(t)] for t in os.environ["GR_CASES"].split(","))
+if os.environ.get("GR_OPTS") == "row_owner0": sg.set_option("csr_row_owner", 0)
 KERNELS = tuple(int(t) for t in os.environ.get("GR_KERNELS", "1,0").split(","))
 REPS = int(os.environ.get("GR_REPS", "50"))
 for n, lo, hi, band in CASES:
@@ -30,7 +31,7 @@ for n, lo, hi, band in CASES:
     moved = 12 * nnz + 4 * n + 16 * n
     ys = []
     for rowline in KERNELS:
-        sg.set_option("csr_row_groups", rowline)
+        sg.set_option("csr_row_lines", rowline)
         y = torch.zeros_like(x)
         for _ in range(min(5, REPS)): A.matvec(x, y)
         torch.cuda.synchronize()
@@ -52,5 +53,5 @@ for n, lo, hi, band in CASES:
         print(json.dumps({"n": n, "nnz_per_row": [lo, hi], "kernel": A.kernel, "us": round(us, 1), "moved_GB": round(moved / 1e9, 3),
                           "TBs": round(moved / us / 1e6, 3), "frac_of_8TBs": round(moved / us / 8e6, 3), "rows_bit_exact": bool(ok)}), flush=True)
     if len(ys) > 1: print(json.dumps({"kernels_bit_identical": bool(torch.equal(ys[0], ys[1]))}), flush=True)
-    sg.set_option("csr_row_groups", 1)
+    sg.set_option("csr_row_lines", 1)
     A.destroy()

@@ -9,7 +9,7 @@ from sigma_amd import problems as P
 sg.init(0)
 nx = 3162; n = nx * nx
 ptr, node, val = P.poisson2d_csr(nx, nx)
-for o in ("csr_offset_dict", "csr_row_owner", "csr_row_groups", "csr_sliced"):
+for o in ("csr_offset_dict", "csr_row_owner", "csr_row_lines", "csr_sliced"):
     sg.set_option(o, 0)
 A = sg.csr_matrix(n, n, torch.from_numpy(ptr).cuda(), torch.from_numpy(node).cuda(), torch.from_numpy(val).cuda())
 x = torch.ones(n, dtype=torch.float64, device="cuda"); y = torch.zeros_like(x)

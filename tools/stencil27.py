@@ -25,8 +25,8 @@ node = (C[M] + 1).to(torch.int32); val = V[M].contiguous()
 nnz = int(ptr[-1])
 x = torch.rand(n, device=dev, dtype=torch.float64)
 for opts in ({}, {"csr_offset_dict": 0, "csr_sliced": 0}, {"csr_offset_dict": 0, "csr_sliced": 0, "csr_row_owner": 0},
-             {"csr_offset_dict": 0, "csr_sliced": 0, "csr_row_owner": 0, "csr_row_groups": 0}):
-    for o in ("csr_offset_dict", "csr_sliced", "csr_row_owner", "csr_row_groups"):
+             {"csr_offset_dict": 0, "csr_sliced": 0, "csr_row_owner": 0, "csr_row_lines": 0}):
+    for o in ("csr_offset_dict", "csr_sliced", "csr_row_owner", "csr_row_lines"):
         sg.set_option(o, opts.get(o, 1))
     A = sg.csr_matrix(n, n, (ptr + 1).to(torch.int32), node, val)
     y = torch.zeros_like(x)
