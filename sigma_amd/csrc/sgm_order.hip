@@ -372,11 +372,11 @@ int sgm_mat_left_permute(sgm_mat A, const int32_t *p, int where)
     size_t tmp_bytes = 0;
     int rc = dalloc(&len2, (size_t)n + 1);
     if (rc == SGM_OK) rc = dalloc(&rowptr2, (size_t)n + 1);
-    if (rc == SGM_OK) rc = dalloc(&col2, (size_t)pt.nnz + 2);
+    if (rc == SGM_OK) rc = dalloc(&col2, (size_t)pt.nnz + 4);
     if (rc == SGM_OK) rc = dalloc(&val2, (size_t)pt.nnz + 2);
     if (rc == SGM_OK) {
         (void)hipMemsetAsync(len2, 0, ((size_t)n + 1) * 4, st);
-        (void)hipMemsetAsync(col2 + pt.nnz, 0, 8, st);
+        (void)hipMemsetAsync(col2 + pt.nnz, 0, 16, st);
         (void)hipMemsetAsync(val2 + pt.nnz, 0, 16, st);
         if (n) hipLaunchKernelGGL(k_perm_lengths, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n,
                                   (const int32_t *)pt.rowptr, (const int32_t *)dp, len2);

@@ -74,6 +74,7 @@ __device__ inline int64_t rowblock_of(int it, int b, int grid, int64_t nrb = 0, 
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 template <class T>
 __device__ inline T ld_stream(const T *p, bool nt)
@@ -192,11 +193,12 @@ __global__ __launch_bounds__(BLOCK) void k_csr_spmv(
 // then walks its up-to-16 entries: columns out of LDS, eight x requests in flight, products rounded one by one and
 // added in stored order (bit-identical to csr_matvec_add).  The loads of pass c + 1 are in flight while pass c is
 // summed.  A block takes as many passes as its longest row has lines.  LDS: 256 rows x 17 (16 + 1 against bank
-// conflicts) x 12 B = 52 KiB, three workgroups per CU.  Price: a `val` line that two rows share and the two halves of
-// a `col` line are requested in different passes and L2 keeps neither (PMC, rows of 33..64 entries: 4.04 GB fetched for
-// 2.36 GB needed; plain instead of nontemporal loads change nothing) -- the longer the rows, the smaller that share.
+// conflicts) x 12 B = 52 KiB, three workgroups per CU.  Price: a line that two rows share is requested by both, in
+// different passes, and L2 keeps none of the stream (PMC, rows of 33..64 entries, when `col` still came in 8-byte
+// pieces beside `val`: 4.04 GB fetched for 2.36 GB needed; plain instead of nontemporal loads changed nothing) -- the
+// longer the rows, the smaller that share.
 template <bool ADD, bool DOT_W, bool DOT_YY>
-__global__ __launch_bounds__(256) void k_csr_rl(
+__global__ __launch_bounds__(256, 3) void k_csr_rl(
     int32_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ w, double *__restrict__ part_wy, double *__restrict__ part_yy,
@@ -234,23 +236,26 @@ __global__ __launch_bounds__(256) void k_csr_rl(
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) np = max(np, __shfl_xor(np, off, 64));
         if ((tid & 63) == 0) wmax[tid >> 6] = np;
-        int32_t ss[NI], se[NI];
-#pragma unroll
-        for (int m = 0; m < NI; ++m) { ss[m] = rp[sj + RPI * m]; se[m] = rp[sj + RPI * m + 1]; }
         __syncthreads();
         int npass = wmax[0];
 #pragma unroll
         for (int t = 1; t < BLOCK / 64; ++t) npass = max(npass, wmax[t]);
         f64x2 v[NI];
-        i32x2 cc[NI];
+        i32x4 cq[NI];
+        // `col` comes in whole 128-byte lines (32 entries = two lines of val): the eight lanes of a row fetch the line's
+        // 16-byte pieces when the pass starts an even val line (or the row); lanes 0-3 hold the columns of that pass,
+        // lanes 4-7 keep theirs in registers for the next one
         auto fetch = [&](int c) {
 #pragma unroll
             for (int m = 0; m < NI; ++m) {
-                const int32_t base = (((ss[m] >> 4) + c) << 4) + sp;
-                if (base < se[m] && base + 2 > ss[m]) {
+                const int32_t ss = rp[sj + RPI * m], se = rp[sj + RPI * m + 1];       // the row this lane stages for
+                const int32_t vline = (ss >> 4) + c;
+                const int32_t base = (vline << 4) + sp;
+                if (base < se && base + 2 > ss)           // the pair holds an entry of the row (arrays are padded)
                     v[m] = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + base));
-                    cc[m] = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(col + base));
-                }
+                const int32_t base4 = ((vline >> 1) << 5) + 2 * sp;
+                if ((c == 0 || !(vline & 1)) && base4 < se && base4 + 4 > ss)
+                    cq[m] = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(col + base4));
             }
         };
         double z = (ADD && chain) ? y0 : 0.0;
@@ -258,11 +263,17 @@ __global__ __launch_bounds__(256) void k_csr_rl(
         for (int c = 0; c < npass; ++c) {
 #pragma unroll
             for (int m = 0; m < NI; ++m) {
-                const int32_t base = (((ss[m] >> 4) + c) << 4) + sp;
-                if (base < se[m] && base + 2 > ss[m]) {
+                const int32_t ss = rp[sj + RPI * m], se = rp[sj + RPI * m + 1];
+                const int32_t vline = (ss >> 4) + c;
+                const int32_t base = (vline << 4) + sp;
+                if (base < se && base + 2 > ss) {
                     const int o = (sj + RPI * m) * ST + sp;
                     vl[o] = v[m].x; vl[o + 1] = v[m].y;
-                    cl[o] = cc[m].x; cl[o + 1] = cc[m].y;
+                }
+                const int32_t base4 = ((vline >> 1) << 5) + 2 * sp;
+                if (((tid >> 2) & 1) == (vline & 1) && base4 < se && base4 + 4 > ss) {
+                    const int o = (sj + RPI * m) * ST + 4 * (tid & 3);
+                    cl[o] = cq[m].x; cl[o + 1] = cq[m].y; cl[o + 2] = cq[m].z; cl[o + 3] = cq[m].w;
                 }
             }
             __syncthreads();
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(256) void k_csr_rl(
             const int32_t line0 = ((s >> 4) + c) << 4;
             const int qlo = max(s - line0, 0), qhi = min(e - line0, 16);
 #pragma unroll
-            for (int h = 0; h < 16; h += 8) {
+            for (int h = 0; h < 16; h += 8) {         // (all 16 requests at once: 866 -> 1123 us -- the empty half is skipped here)
                 if (qhi > h && qlo < h + 8) {
                     double xv[8], vv[8];
 #pragma unroll
@@ -1944,11 +1955,11 @@ int build_csr_part(Part &p, int32_t n, int32_t ncol_own, int32_t n_halo, int64_t
     p.n_halo = n_halo;
     p.nnz = nnz;
     SGM_TRY(dalloc(&p.rowptr, (size_t)n + 1));
-    SGM_TRY(dalloc(&p.col, (size_t)nnz + 2));
+    SGM_TRY(dalloc(&p.col, (size_t)nnz + 4));          // k_csr_rl reads whole 16-byte pieces of col
     SGM_TRY(dalloc(&p.val, (size_t)nnz + 2));
     hipStream_t st = g_rt.stream;
     const hipMemcpyKind kind = where == SGM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-    SGM_HIP(hipMemsetAsync(p.col + nnz, 0, 2 * sizeof(int32_t), st));
+    SGM_HIP(hipMemsetAsync(p.col + nnz, 0, 4 * sizeof(int32_t), st));
     SGM_HIP(hipMemsetAsync(p.val + nnz, 0, 2 * sizeof(double), st));
     SGM_HIP(hipMemcpyAsync(p.rowptr, ptr1, ((size_t)n + 1) * sizeof(int32_t), kind, st));
     if (nnz) {
@@ -2534,7 +2545,7 @@ static int64_t part_resident_bytes(const Part &p)
     int64_t b = 0;
     const int64_t nsl = ((int64_t)p.n + kSlRows - 1) / kSlRows;
     if (p.rowptr) b += 4 * ((int64_t)p.n + 1);
-    if (p.col) b += 4 * (p.nnz + 2);
+    if (p.col) b += 4 * (p.nnz + 4);
     if (p.val) b += 8 * (p.nnz + 2);
     if (p.code) b += p.nnz + 16;
     if (p.dict) b += 4 * 256;
