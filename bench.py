@@ -317,7 +317,7 @@ def worker(args):
             sg.set_option("csr_row_lines", 1)
             sg.set_option("csr_sliced", 1)
         # a handle created WITHOUT the dictionary: short rows take the sliced int32-column kernel
-        # (what a matrix with arbitrary columns and rows <= 16 entries gets; 12 B per slot)
+        # (what a matrix with arbitrary columns and rows <= 32 entries of similar length gets; 12 B per slot)
         sg.set_option("csr_offset_dict", 0)
         try:
             A32 = sg.csr_matrix(n_loc, n_loc, A.get("ptr", np.int32), A.get("node", np.int32), A.get("val", np.float64))
@@ -325,7 +325,7 @@ def worker(args):
             sg.set_option("csr_offset_dict", 1)
         for _ in range(5):
             A32.matvec(x, y)
-        variants["int32_columns, sliced (general kernel, rows <= 16 entries of similar length)"] = \
+        variants["int32_columns, sliced (general kernel, rows <= 32 entries of similar length)"] = \
             variant_entry(A32, time_kernel(A32, x, y, reps=50), time_kernel(A32, x, y, reps=20, flush=scratch))
         A32.destroy()
     del scratch

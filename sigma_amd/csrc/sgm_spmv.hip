@@ -7,16 +7,23 @@
 // stored order; `matvec` returns 0.0 + z like `y = 0; y(i) = y(i) + z`
 // (linear_operator_interface.f90:191-192).
 //
-// Two CSR kernels share one structure: a 256-thread workgroup owns 256 consecutive rows of
-// a persistent grid sweep; the nnz range of those rows is contiguous in val/col, so it is
-// streamed in LDS-sized tiles with 16-byte coalesced (nontemporal) loads by ALL lanes
-// regardless of row lengths, and after a barrier lane i adds row i's terms in stored order.
-//   k_csr_spmv  int32 columns (any matrix): the x gather happens while streaming (two
-//               entries per lane), products are parked in LDS.                12 B / entry
-//   k_csr_do    1-byte dictionary-coded column offsets (stencil-like matrices): val and
-//               codes are parked in LDS, the row's owner gathers x.            9 B / entry
-// The x gather is served by L2 (the workgroup -> row-block map keeps consecutive row blocks
-// on one XCD).  Algorithmic bytes per SpMV: 12*nnz + 4*(n+1) + 8*m + 8*n.
+// CSR kernels, picked per matrix at upload (sgm_mat_kernel names the one in use):
+//   k_csr_sl    rows <= 8 entries from <= 15 (column - row) offsets: values re-laid slot-major in
+//               512-row slices + one word of 4-bit dictionary codes per row; a lane owns two rows,
+//               no LDS, no row pointers.                                     8 W + 4 B / row
+//   k_csr_slb   rows of 9..32 entries, <= 255 offsets: the same with 1-byte codes.     9 B / slot
+//   k_csr_sl32  rows <= 32 entries of similar length at arbitrary columns: the same with int32
+//               columns.                                                              12 B / slot
+//   k_csr_do    a 256-thread workgroup owns 256 consecutive rows; the contiguous val / code range of
+//               those rows is streamed into LDS in tiles by ALL lanes, then the row's owner lane
+//               gathers x and adds in stored order: 1-byte codes (other stencil-like matrices,
+//               9 B / entry) or int32 columns (rows <= 64 entries, 12 B / entry)
+//   k_csr_rl    int32 columns, longer rows: one 128-byte line of val per row and pass, all 256 rows
+//               walked by their owner lanes at once.                                 12 B / entry
+//   k_csr_spmv  int32 columns, any row length: the x gather happens while streaming (two entries
+//               per lane), products are parked in LDS, the owner adds them.          12 B / entry
+// The x gather is served by L2 (the workgroup -> row-block / slice maps keep neighbouring rows on one
+// XCD).  Algorithmic bytes per SpMV on the reference layout: 12*nnz + 4*(n+1) + 8*m + 8*n.
 #include "sgm_internal.hpp"
 
 #include <type_traits>
@@ -553,7 +560,7 @@ __global__ __launch_bounds__(256) void k_csr_sl(
 }
 
 // The sliced form for matrices WITHOUT an offset dictionary (arbitrary columns) whose rows are short
-// (<= 16 entries) and of similar length: the int32 column of every slot is stored beside the value,
+// (<= 32 entries) and of similar length: the int32 column of every slot is stored beside the value,
 // slot-major in the same 512-row slices (-1 = no entry); 12 bytes per slot like plain CSR, but every
 // load is a coalesced 8/16 bytes per lane and there is no row pointer, no LDS, no barrier.  Slots are
 // walked in chunks of 8 (registers).
@@ -613,7 +620,7 @@ __global__ __launch_bounds__(256) void k_csr_sl32(
                     if (cc[u].x >= 0) z.x = z.x + v[u].x * xa[u];
                     if (cc[u].y >= 0) z.y = z.y + v[u].y * xb[u];
                 }
-            if (W > 8) __builtin_amdgcn_sched_barrier(0);       // one chunk's registers at a time
+            if (W > 8) __builtin_amdgcn_sched_barrier(0);       // one chunk's registers at a time (all chunks at once, W = 28: 256 VGPRs, 302 -> 320 us)
         }
         f64x2 yi;
         yi.x = ADD ? (chain ? z.x : y0.x + z.x) : 0.0 + z.x;
@@ -1169,7 +1176,7 @@ static void launch_csr_sl(const Part &p, int grid, const double *x, double *y, c
 #undef L
 }
 
-#define SGM_SL32_WIDTHS(X) X(3) X(5) X(7) X(8) X(12) X(16)
+#define SGM_SL32_WIDTHS(X) X(3) X(5) X(7) X(8) X(12) X(16) X(20) X(24) X(28) X(32)
 template <bool ADD>
 static void launch_csr_sl32(const Part &p, int grid, const double *x, double *y, const double *w,
                             double *pwy, double *pyy, const int *flag, int gen)
@@ -1751,8 +1758,9 @@ static int build_offset_dict(Part &p, const int32_t *, const int32_t *)
     p.max_row = hcnt[1];
     // without a dictionary (option off at creation, or more than 255 offsets): try the int32 sliced form
     auto sliced32 = [&]() -> int {
-        const int W = p.max_row <= 3 ? 3 : p.max_row <= 5 ? 5 : p.max_row <= 7 ? 7 : p.max_row <= 8 ? 8 : p.max_row <= 12 ? 12 : 16;
-        if (!g_opt.csr_sliced || p.max_row < 1 || p.max_row > 16 || (double)W * n > 1.25 * (double)nnz) return SGM_OK;
+        const int W = p.max_row <= 3 ? 3 : p.max_row <= 5 ? 5 : p.max_row <= 7 ? 7 : p.max_row <= 8 ? 8 : p.max_row <= 12 ? 12
+                    : p.max_row <= 16 ? 16 : p.max_row <= 20 ? 20 : p.max_row <= 24 ? 24 : p.max_row <= 28 ? 28 : 32;
+        if (!g_opt.csr_sliced || p.max_row < 1 || p.max_row > 32 || (double)W * n > 1.25 * (double)nnz) return SGM_OK;
         const size_t rows_padded = ((size_t)n + kSlRows - 1) / kSlRows * kSlRows;
         SGM_TRY(dalloc(&p.scol, rows_padded * W));
         SGM_TRY(dalloc(&p.sval, rows_padded * W));
