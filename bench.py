@@ -224,6 +224,35 @@ def worker(args):
         y = torch.zeros(n_loc, dtype=torch.float64, device=dev)
         return x, y
 
+    def selfcheck(kind, y, n_loc, i0):
+        """Every local row of one product against its sum evaluated with torch in stored order (the x entries come from
+        the analytic x(i) = sin(0.001 i), so the halo values a rank needs are known to it): bit for bit, on every rank.
+        A product that differs must not be reported as a measurement."""
+        k = torch.arange(i0, i0 + n_loc, device=dev, dtype=torch.int64)
+        if kind == "c2":
+            nx, NY = args.nx, args.ny * world
+            i, j = k % nx, k // nx
+            one = torch.ones_like(k, dtype=torch.bool)
+            offs = [(-nx, j > 0, -1.0), (-1, i > 0, -1.0), (0, one, 4.0), (1, i < nx - 1, -1.0), (nx, j < NY - 1, -1.0)]
+        else:
+            m = args.c5_edge
+            pl = m * m
+            i, j, l = k % m, (k // m) % m, k // pl
+            one = torch.ones_like(k, dtype=torch.bool)
+            offs = [(-pl, l > 0, -1.0), (-m, j > 0, -1.0), (-1, i > 0, -1.0), (0, one, 6.0), (1, i < m - 1, -1.0),
+                    (m, j < m - 1, -1.0), (pl, l < m - 1, -1.0)]
+        z = torch.zeros(n_loc, dtype=torch.float64, device=dev)
+        for o, mask, v in offs:
+            xo = torch.sin(0.001 * (k + (o + 1)).to(torch.float64))
+            z = torch.where(mask, z + v * xo, z)
+        z = 0.0 + z
+        ok = bool(torch.equal(z, y[:n_loc]))
+        if use_dist:
+            t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = bool(t.item() == 1.0)
+        return ok
+
     def time_kernel(mat, x, y, reps=200, flush=None):
         """Average duration of ONE product, HIP events on the launch stream around every launch.
         flush: a scratch tensor rewritten between launches (cold Infinity Cache / L2)."""
@@ -261,6 +290,11 @@ def worker(args):
     resident_rank, moved_rank = A.footprint()
     inner = max(1, args.spmv_per_step)
 
+    A.matvec(x, y)
+    torch.cuda.synchronize()
+    check_main = selfcheck(args.workload, y, n_loc, i0)
+    if not check_main:
+        sys.stderr.write(f"[bench] rank {rank}: the product differs from its row sums in stored order -- not a measurement\n")
     for _ in range(args.warmup):
         for _ in range(inner):
             A.matvec(x, y)
@@ -358,6 +392,11 @@ def worker(args):
     if not args.no_c5 and args.workload == "c2":
         A5, n5, n5g, i5, nnz5, label5, _ = make_matrix("c5")
         x5, y5 = vectors(A5, n5, i5)
+        A5.matvec(x5, y5)
+        torch.cuda.synchronize()
+        check_c5 = selfcheck("c5", y5, n5, i5)
+        if not check_c5:
+            sys.stderr.write(f"[bench] rank {rank}: the C5 product differs from its row sums in stored order\n")
         for _ in range(3):
             A5.matvec(x5, y5)
         barrier()
@@ -376,7 +415,7 @@ def worker(args):
               "cg_iters_per_s": its5 / dtc5, "cg_iterations": its5, "cg_ms_per_iter": 1e3 * dtc5 / its5,
               "cg_GB/s_moved": moved5 * its5 / dtc5 / 1e9,
               "cg_frac_of_hbm_peak": moved5 * its5 / dtc5 / 1e9 / (HBM_PEAK_GBS * world),
-              "cg_final_res2": res25, "scaling": "strong",
+              "cg_final_res2": res25, "scaling": "strong", "product_bit_exact_on_every_rank": check_c5,
               "note": "north_star target: cg_iters_per_s at n_gpus = 8 >= 6 x the n_gpus = 1 figure"}
         A5.destroy()
 
@@ -416,12 +455,17 @@ def worker(args):
                                  "row of its own layout (W = 5) + x once + y once.  cold_* = the same launch after 512 MiB "
                                  "of unrelated writes (nothing of the previous product left in L2 / Infinity Cache)"},
             "spmv_variants": variants or None, "cg": cg, "c5_strong_scaling": c5, "cpu_baseline": cpu,
+            "selfcheck": {"product_bit_exact_on_every_rank": check_main,
+                          "what": "every local row of one timed-workload product == its sum evaluated with torch in stored "
+                                  "order from x(i) = sin(0.001 i), on every rank (halo values included)"},
         }
         print(json.dumps(out), flush=True)
     if use_dist:
         barrier()
         comm.destroy()
         dist.destroy_process_group()
+    if not check_main or (c5 is not None and not c5["product_bit_exact_on_every_rank"]):
+        sys.exit(3)          # a product that differs is not a measurement
 
 
 # ------------------------------------------------------------------------------------------ #

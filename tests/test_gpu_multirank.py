@@ -100,6 +100,9 @@ def test_bench_gpus_2_typed_plainly_spawns_its_ranks(tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["roofline"]["frac"] <= 1.0
     assert out["cg"]["iterations"] == 20 and out["c5_strong_scaling"]["cg_iterations"] == 10
     assert out["config"]["parallelism"] == "row-partition x2"
+    # every local row of both workloads' products, halo rows included, equals its stored-order sum on both ranks
+    assert out["selfcheck"]["product_bit_exact_on_every_rank"] is True
+    assert out["c5_strong_scaling"]["product_bit_exact_on_every_rank"] is True
 
 
 def test_bench_under_torch_distributed_run_like_the_driver_launches_it(tmp_path):
@@ -119,3 +122,4 @@ def test_bench_under_torch_distributed_run_like_the_driver_launches_it(tmp_path)
     assert len(line) == 1, p.stdout[-2000:]
     out = json.loads(line[0])
     assert out["n_gpus"] == 2 and out["cg"]["iterations"] == 20 and out["c5_strong_scaling"]["cg_iterations"] == 10
+    assert out["selfcheck"]["product_bit_exact_on_every_rank"] is True and out["c5_strong_scaling"]["product_bit_exact_on_every_rank"] is True
