@@ -74,6 +74,11 @@ int sgm_synchronize(void);
  * slot-major, plus one 32-bit word of 4-bit codes per row; a lane owns two adjacent rows, every
  * load is 16 bytes wide, coalesced and independent, no row pointers are read (8 W + 4 bytes per
  * row of width W).  5-17 % faster than the 1-byte-code kernel; 0 keeps that.
+ * "cg_small" (default 1): CG (plain or Jacobi-preconditioned) on a single-GPU CSR matrix of at most
+ * 10240 rows (stencil matrices; 4096 otherwise) runs as ONE workgroup -- p in LDS, x and r in registers,
+ * no launch inside the loop; same statements as the launch-per-kernel loop, only the dot products'
+ * summation order differs.  "cg_small_chunk" (default 50000): iterations per launch of that kernel (the
+ * solve continues in the next launch from parked r, p, res2 -- bit-identical to the uncut solve).
  * "slice_sched" (default 1): sliced matrices most of whose rows carry an offset of >= 32 slices (the
  * plane stride of a 3-D grid) hand their slices to the workgroups in a band order per XCD, so that the
  * slices one plane apart -- which read the same x entries -- share one XCD's L2; only the order in

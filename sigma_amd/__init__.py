@@ -125,7 +125,7 @@ def set_option(name, value):
     "csr_row_lines" 1/0 (line-staged row-owner kernel for longer rows), "slice_sched" 0/1 (band-ordered slices on 3-D grids),
     "csr_sliced" 1/0 (slot-major slices + 4-bit codes for rows <= 8 entries / <= 15 offsets; default on),
     "ell_offset_dict" 1/0, "ell_colblock" 0/1/2, "ell_colblock_cols", "ell_colblock_chunks", "ell_colblock_rows" 0/256/512,
-    "ildu_strips" 1/0, "gmres_cgs2" 1/0."""
+    "ildu_strips" 1/0, "gmres_cgs2" 1/0, "cg_small" 1/0 (single-workgroup CG for small systems), "cg_small_chunk"."""
     _ck(lib().sgm_set_option(name.encode(), C.c_int(int(value))))
 
 

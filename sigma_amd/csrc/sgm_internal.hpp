@@ -44,6 +44,8 @@ struct Options {
     int ell_colblock_chunks = 16;  // workgroups per column block in the multiply phase (C4 sweep: 4 / 8 / 16 -> 1.32 / 1.31 / 1.27 ms)
     int ildu_strips = 1;           // ILDU(0) factors of grid-like matrices (deps r-1, r-w): strip-pipelined triangular solves
     int gmres_cgs2 = 1;            // GMRES: blocked CGS-2 orthogonalisation (3 passes per step) instead of modified Gram-Schmidt
+    int cg_small = 1;              // CG (plain or Jacobi) on a CSR matrix of <= 10240 rows: the whole solve in one workgroup (k_cg_small)
+    int cg_small_chunk = 50000;    // its iterations per launch (the solve continues in the next launch from parked r, p)
     int slice_sched = 0;           // sliced kernels on matrices with a far stencil offset (3-D grids): band-ordered slice schedule per XCD
     int slice_sched_band = 64;     // its target band width in slices
 };

@@ -164,6 +164,8 @@ int sgm_set_option(const char *name, int value)
     if (!strcmp(name, "ell_colblock_rows")) { g_opt.ell_colblock_rows = value == 512 ? 512 : value == 256 ? 256 : 0; return SGM_OK; }
     if (!strcmp(name, "ell_colblock_chunks")) { g_opt.ell_colblock_chunks = std::max(1, value); return SGM_OK; }
     if (!strcmp(name, "ildu_strips")) { g_opt.ildu_strips = value; return SGM_OK; }
+    if (!strcmp(name, "cg_small")) { g_opt.cg_small = value; return SGM_OK; }
+    if (!strcmp(name, "cg_small_chunk")) { g_opt.cg_small_chunk = std::max(1, value); return SGM_OK; }
     if (!strcmp(name, "slice_sched")) { g_opt.slice_sched = value; return SGM_OK; }
     if (!strcmp(name, "slice_sched_band")) { g_opt.slice_sched_band = std::max(8, value); return SGM_OK; }
     if (!strcmp(name, "gmres_cgs2")) { g_opt.gmres_cgs2 = value; return SGM_OK; }

@@ -883,8 +883,231 @@ int read_state(sgm_solver s, int *flag, int64_t *iters, double *res)
 enum { C_PQ = 0, C_RR0 = 1, C_RR1 = 2 };
 enum { V_P = 0, V_Q = 1, V_R = 2, V_Z = 3 };
 
+// ---- CG on a small system: the whole solve in ONE workgroup -----------------------------------------
+// Below n ~ 1e5 an iteration of the loop above IS its three launches (about 15 us whatever n is).  A system of up to
+// 10240 rows fits one workgroup: p lives in LDS (what the row sums gather from), x and r (and 1 / diag for Jacobi) in the
+// registers of the row's thread (rows t, t + 1024, ...), q is consumed where it is formed, the two dot products are
+// block sums -- no launch, no grid-wide hand-off inside the loop.  Same statements and operands as FCgR / FCgPX above
+// (cg_solvers.f90:129-145, :170-190 with jacobi_solve folded in): row sums left to right in stored order with
+// individually rounded products, alpha = res2 / dpr, beta = dnew / res2, the loop test `sqrt(res2) > tolerance` before
+// every iteration.  Only the summation order of the dot products differs (compiler-defined in the reference).
+// SL: the matrix is read from its sliced form (512-row slices, slot-major values, one word of 4-bit offset codes per
+// row: sgm_spmv.hip, k_csr_sl) -- coalesced for rows t, t + 1024, ...; `rowptr` then carries the code words, `col` the
+// offset dictionary, `sw` the slots per row.  Otherwise plain CSR arrays (every lane its own row: one CU's address
+// pipe limits that to about 4096 rows).
+template <int RMAX, bool JAC, bool SL>
+__global__ __launch_bounds__(1024) void k_cg_small(
+    int32_t n, int32_t sw, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val,
+    double *__restrict__ x, const double *__restrict__ b, const double *__restrict__ idiag, double tol, int64_t it_end,
+    int resume, double *__restrict__ wr, double *__restrict__ wp,
+    int *flag, int64_t *iters, double *res_out, double *history, int64_t hist_cap)
+{
+    constexpr int BLOCK = 1024;
+    extern __shared__ double pl[];             // p (n entries), then the block-sum scratch
+    double *red = pl + ((n + 1) & ~1);
+    const int tid = threadIdx.x;
+    double xr[RMAX], rr[RMAX];             // (row pointers and 1 / diag are re-read where needed: L1 / L2 hits, not registers)
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+        const int32_t i = tid + u * BLOCK;
+        xr[u] = 0.0; rr[u] = 0.0;
+        if (i < n) { xr[u] = x[i]; pl[i] = xr[u]; }
+    }
+    __syncthreads();
+    // the thread's RMAX row sums side by side: slot e of every row is requested before any of them is used, so a
+    // row's entries are still added left to right but the thread waits for one round trip per SLOT, not per entry
+    // (rows one after the other: 16 us per iteration at n = 1e4, five entries per row)
+    auto row_sums = [&](double (&q)[RMAX]) {
+        if (SL) {
+            uint32_t cw[RMAX];
+#pragma unroll
+            for (int u = 0; u < RMAX; ++u) {
+                const int32_t i = tid + u * BLOCK;
+                q[u] = 0.0;
+                cw[u] = i < n ? (uint32_t)rowptr[i] : 0xffffffffu;
+            }
+            constexpr int H = RMAX > 5 ? (RMAX + 1) / 2 : RMAX;        // rows side by side (all ten: 71-89 registers spilled)
+#pragma unroll
+            for (int h0 = 0; h0 < RMAX; h0 += H)
+                for (int32_t e = 0; e < sw; ++e) {
+                    double v[H];
+#pragma unroll
+                    for (int u = h0; u < h0 + H && u < RMAX; ++u) {
+                        const int32_t i = tid + u * BLOCK;
+                        if (((cw[u] >> (4 * e)) & 15u) != 15u) v[u - h0] = val[((i >> 9) * sw + e) * 512 + (i & 511)];
+                    }
+#pragma unroll
+                    for (int u = h0; u < h0 + H && u < RMAX; ++u) {
+                        const int32_t i = tid + u * BLOCK;
+                        const uint32_t cd = (cw[u] >> (4 * e)) & 15u;
+                        if (cd != 15u) q[u] = q[u] + v[u - h0] * pl[i + col[cd]];
+                    }
+                }
+#pragma unroll
+            for (int u = 0; u < RMAX; ++u) q[u] = 0.0 + q[u];
+            return;
+        }
+        int32_t k0[RMAX], len[RMAX];
+        int32_t longest = 0;
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = tid + u * BLOCK;
+            k0[u] = 0; len[u] = 0; q[u] = 0.0;
+            if (i < n) { k0[u] = rowptr[i]; len[u] = rowptr[i + 1] - k0[u]; }
+            longest = max(longest, len[u]);
+        }
+        for (int32_t e = 0; e < longest; ++e) {
+            double v[RMAX]; int32_t c[RMAX];
+#pragma unroll
+            for (int u = 0; u < RMAX; ++u)
+                if (e < len[u]) { v[u] = val[k0[u] + e]; c[u] = col[k0[u] + e]; }
+#pragma unroll
+            for (int u = 0; u < RMAX; ++u)
+                if (e < len[u]) q[u] = q[u] + v[u] * pl[c[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) q[u] = 0.0 + q[u];          // A%matvec: y = 0 ; y(i) = y(i) + z
+    };
+    double s = 0.0, res2;
+    int64_t it = 0;
+    if (!resume) {
+        // r = b - A x ; z = M^-1 r ; p = z ; res2 = r.z
+        double zr[RMAX];
+        row_sums(zr);
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = tid + u * BLOCK;
+            const double q = zr[u];
+            zr[u] = 0.0;
+            if (i < n) {
+                rr[u] = b[i] - q;
+                zr[u] = JAC ? idiag[i] * rr[u] : rr[u];
+                s += rr[u] * zr[u];
+            }
+        }
+        res2 = block_sum<BLOCK>(s, red);      // (its barriers: every row sum has read x out of LDS)
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = tid + u * BLOCK;
+            if (i < n) pl[i] = zr[u];
+        }
+    } else {                                  // a solve that outlives one launch: r, p, res2 and the count come back from memory
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = tid + u * BLOCK;
+            if (i < n) { rr[u] = wr[i]; pl[i] = wp[i]; }
+        }
+        res2 = *res_out;
+        it = *iters;
+    }
+    __syncthreads();
+    bool conv = !(sqrt(res2) > tol);
+    while (!conv && it < it_end) {
+        double qv[RMAX];
+        row_sums(qv);
+        s = 0.0;
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = tid + u * BLOCK;
+            if (i < n) s += pl[i] * qv[u];
+        }
+        const double dpr = block_sum<BLOCK>(s, red);
+        const double alpha = res2 / dpr;
+        s = 0.0;
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = tid + u * BLOCK;
+            if (i < n) {
+                rr[u] = rr[u] - alpha * qv[u];
+                const double zv = JAC ? idiag[i] * rr[u] : rr[u];
+                s += rr[u] * zv;
+            }
+        }
+        const double dnew = block_sum<BLOCK>(s, red);    // (its barriers: every row sum of this iteration has read p)
+        const double beta = dnew / res2;
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = tid + u * BLOCK;
+            if (i < n) {
+                const double pv = pl[i];
+                const double zv = JAC ? idiag[i] * rr[u] : rr[u];
+                xr[u] = xr[u] + alpha * pv;
+                pl[i] = zv + beta * pv;
+            }
+        }
+        __syncthreads();
+        if (tid == 0 && history && it < hist_cap) history[it] = dnew;
+        ++it;
+        res2 = dnew;
+        conv = !(sqrt(res2) > tol);
+    }
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+        const int32_t i = tid + u * BLOCK;
+        if (i < n) {
+            x[i] = xr[u];
+            if (!conv) { wr[i] = rr[u]; wp[i] = pl[i]; }
+        }
+    }
+    if (tid == 0) { *iters = it; *res_out = res2; *flag = conv ? 1 : 0; }
+}
+
+constexpr int kCgSmallMax = 10240;          // 10 rows per thread (sliced matrices): x, r, q in registers (16 rows: 53-168 spilled)
+constexpr int kCgSmallMaxCsr = 4096;        // plain CSR arrays: 4 rows per thread (10 rows, n = 1e4: 19 us per iteration, one CU's address pipe)
+static bool cg_small_sliced(const Part &p) { return p.scode && p.sval && p.dict && g_opt.csr_sliced && g_opt.csr_offset_dict && p.sw <= 8; }
+static bool cg_small_applies(sgm_solver s, sgm_mat A, sgm_pc pc)
+{
+    if (!g_opt.cg_small || s->multi || A->parts.size() != 1 || A->fmt != SGM_FMT_CSR) return false;
+    const Part &p = A->parts[0];
+    if (p.n < 1 || p.n_halo != 0 || !p.rowptr || !p.col || !p.val) return false;
+    if (p.n > (cg_small_sliced(p) ? kCgSmallMax : kCgSmallMaxCsr)) return false;
+    const int pk = pc ? pc_kind(pc) : 0;
+    return pk == 0 || pk == SGM_PC_JACOBI;
+}
+static int run_cg_small(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc pc)
+{
+    const Part &p = A->parts[0];
+    PartWork &w = s->work[0];
+    const bool jac = pc && pc_kind(pc) == SGM_PC_JACOBI;
+    const bool sliced = cg_small_sliced(p);
+    const size_t lds = ((size_t)((p.n + 1) & ~1) + 16) * sizeof(double);
+    // the reference's loop has no iteration cap; a launch has one (kCgSmallChunk iterations), after which the solve
+    // continues in the next launch from r, p and res2 parked in the solver's work vectors -- the host stays in control
+    const int64_t kCgSmallChunk = std::max(1, g_opt.cg_small_chunk);
+    int flag = 0; int64_t iters = 0; double res = 0.0;
+    for (int resume = 0;; resume = 1) {
+        int64_t it_end = iters + kCgSmallChunk;
+        if (s->max_iter > 0) it_end = std::min<int64_t>(it_end, s->max_iter);
+#define LS(R, J, S)                                                                                                  \
+    do {                                                                                                             \
+        static bool attr = false;                                                                                    \
+        if (!attr) { SGM_HIP(hipFuncSetAttribute((const void *)k_cg_small<R, J, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (kCgSmallMax + 16) * 8)); attr = true; } \
+        hipLaunchKernelGGL((k_cg_small<R, J, S>), dim3(1), dim3(1024), lds, g_rt.stream, p.n, p.sw,                   \
+                           S ? reinterpret_cast<const int32_t *>(p.scode) : (const int32_t *)p.rowptr,                \
+                           S ? (const int32_t *)p.dict : (const int32_t *)p.col, S ? (const double *)p.sval : (const double *)p.val, \
+                           x, b, jac ? pc_idiag(pc, 0) : nullptr,                                                     \
+                           s->tolerance, it_end, resume, w.vec[V_R], w.vec[V_P], w.flag, w.iters, w.res, w.history,   \
+                           s->hist_cap);                                                                              \
+    } while (0)
+        if (sliced) {
+            if (p.n <= 4096) { if (jac) LS(4, true, true); else LS(4, false, true); }
+            else { if (jac) LS(10, true, true); else LS(10, false, true); }
+        } else { if (jac) LS(4, true, false); else LS(4, false, false); }
+#undef LS
+        SGM_HIP(hipGetLastError());
+        SGM_TRY(read_state(s, &flag, &iters, &res));
+        if (flag || (s->max_iter > 0 && iters >= s->max_iter)) break;
+    }
+    s->last_iterations = iters;
+    s->res2 = res;
+    s->converged = flag;
+    return SGM_OK;
+}
+
 int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sgm_pc pc)
 {
+    if (cg_small_applies(s, A, pc)) return run_cg_small(s, A, x[0], b[0], pc);
     const size_t P = s->work.size();
     const int pk = pc ? pc_kind(pc) : 0;
     Views v;

@@ -642,6 +642,74 @@ def test_randomised_partitions_vs_oracle(orc, nparts):
             assert np.array_equal(ya, ya_ref), (trial, n, list(starts), dict_opt, sl_opt, ro_opt)
 
 
+@pytest.mark.parametrize("kind", ["poisson2d_40x30", "poisson2d_100x100", "tridiagonal_10000", "random_spd_3000"])
+def test_single_workgroup_cg_vs_oracle_and_vs_the_launch_loop(orc, kind):
+    """CG / Jacobi-PCG on small systems run as ONE workgroup (k_cg_small; sliced stencil matrices up to 10240 rows,
+    plain CSR up to 4096): iteration count and solution against the oracle, the same against the launch-per-kernel
+    loop (option cg_small 0), residual history, the iteration cap, and a solve cut into launches of 7 iterations
+    (r, p, res2 parked in memory between launches) -- that one bit-identical to the uncut solve."""
+    import scipy.sparse as sp
+    rs = np.random.RandomState(11)
+    if kind.startswith("poisson2d"):
+        nx, ny = (40, 30) if kind.endswith("40x30") else (100, 100)
+        n = nx * ny
+        ptr, node, val = P.poisson2d_csr(nx, ny)
+    elif kind == "tridiagonal_10000":
+        n = 10000
+        S = sp.diags([-np.ones(n - 1), 2.0 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1]).tocsr()
+        ptr, node, val = (S.indptr + 1).astype(np.int32), (S.indices + 1).astype(np.int32), S.data.copy()
+    else:
+        n = 3000
+        B = sp.random(n, n, density=0.002, random_state=rs, format="csr")
+        S = (B + B.T).tocsr()
+        S = (S + sp.diags(np.abs(S).sum(axis=1).A1 + 0.02)).tocsr()       # strictly diagonally dominant: SPD
+        S.sort_indices()
+        ptr, node, val = (S.indptr + 1).astype(np.int32), (S.indices + 1).astype(np.int32), S.data.copy()
+    A = orc.CsrMatrix(n, n, ptr, node, val)
+    H = sg.csr_matrix(n, n, ptr, node, val)
+    b = P.test_vector(n)
+    tol = 1e-11
+    for jac in (False, True):
+        pco = orc.Jacobi(A) if jac else None
+        ur, itr, _, hist_r = orc.cg(A, b, tol=tol, pc=pco, history=4096)
+        res = {}
+        for small, chunk in ((1, 50000), (1, 7), (0, 50000)):
+            sg.set_option("cg_small", small)
+            sg.set_option("cg_small_chunk", chunk)
+            try:
+                pc = None
+                if jac:
+                    pc = sg.jacobi()
+                    pc.setup(H)
+                sv = sg.cg(tol)
+                sv.set_history(4096)
+                sv.setup(H)
+                u = np.zeros(n)
+                sv.solve(H, u, b, pc)
+                res[(small, chunk)] = (u.copy(), sv.iterations, np.array(sv.history))
+                # the iteration cap: stops there, reports not converged
+                sv2 = sg.cg(1e-300)
+                sv2.set_max_iter(9)
+                sv2.setup(H)
+                u2 = np.zeros(n)
+                sv2.solve(H, u2, b, pc, check=False)
+                assert sv2.last_iterations == 9
+            finally:
+                sg.set_option("cg_small", 1)
+                sg.set_option("cg_small_chunk", 50000)
+        for key, (u, its, hist) in res.items():
+            assert abs(its - itr) <= 1, (kind, jac, key, its, itr)
+            assert np.abs(u - ur).max() / np.abs(ur).max() <= 1e-11, (kind, jac, key)
+            m = min(len(hist), len(hist_r), 40)
+            hr = np.array(hist_r[:m])
+            big = hr > 1e-8 * hr[0]            # (below that the two dot-product orders part: rounding of a 1e-16-sized residual)
+            assert big.sum() >= 3 and (np.abs(hist[:m] - hr)[big] / hr[big]).max() <= 1e-9, (kind, jac, key)
+        # cut into launches of 7 iterations: the same arithmetic, the same bits
+        assert res[(1, 7)][1] == res[(1, 50000)][1]
+        assert np.array_equal(res[(1, 7)][0], res[(1, 50000)][0])
+        assert np.array_equal(res[(1, 7)][2], res[(1, 50000)][2])
+
+
 @pytest.mark.parametrize("n,lo,hi", [(700, 70, 120), (5000, 66, 90), (3001, 1, 200), (9000, 33, 64), (2500, 100, 2600), (4000, 10, 25)])
 def test_long_row_kernels_vs_oracle(orc, n, lo, hi):
     """General matrices with LONG rows (arbitrary columns inside a band, no dictionary): the row-owner kernel up to 64
