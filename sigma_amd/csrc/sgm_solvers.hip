@@ -1055,12 +1055,18 @@ __global__ __launch_bounds__(1024) void k_cg_small(
 
 constexpr int kCgSmallMax = 10240;          // 10 rows per thread (sliced matrices): x, r, q in registers (16 rows: 53-168 spilled)
 constexpr int kCgSmallMaxCsr = 4096;        // plain CSR arrays: 4 rows per thread (10 rows, n = 1e4: 19 us per iteration, one CU's address pipe)
-static bool cg_small_sliced(const Part &p) { return p.scode && p.sval && p.dict && g_opt.csr_sliced && g_opt.csr_offset_dict && p.sw <= 8; }
+// (a structured ELLPACK matrix with max_d <= 8 keeps the same sliced form, every slot an entry: its padding slots'
+// 0.0 * x(last neighbour) terms are added like the reference's ellpack_matvec_add does)
+static bool cg_small_sliced(const Part &p)
+{
+    return p.scode && p.sval && p.dict && g_opt.csr_sliced && (p.ecol ? g_opt.ell_offset_dict : g_opt.csr_offset_dict) && p.sw <= 8;
+}
 static bool cg_small_applies(sgm_solver s, sgm_mat A, sgm_pc pc)
 {
-    if (!g_opt.cg_small || s->multi || A->parts.size() != 1 || A->fmt != SGM_FMT_CSR) return false;
+    if (!g_opt.cg_small || s->multi || A->parts.size() != 1 || (A->fmt != SGM_FMT_CSR && A->fmt != SGM_FMT_ELL)) return false;
     const Part &p = A->parts[0];
-    if (p.n < 1 || p.n_halo != 0 || !p.rowptr || !p.col || !p.val) return false;
+    if (p.n < 1 || p.n_halo != 0) return false;
+    if (!cg_small_sliced(p) && (A->fmt != SGM_FMT_CSR || !p.rowptr || !p.col || !p.val)) return false;
     if (p.n > (cg_small_sliced(p) ? kCgSmallMax : kCgSmallMaxCsr)) return false;
     const int pk = pc ? pc_kind(pc) : 0;
     return pk == 0 || pk == SGM_PC_JACOBI;

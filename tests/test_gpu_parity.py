@@ -642,7 +642,8 @@ def test_randomised_partitions_vs_oracle(orc, nparts):
             assert np.array_equal(ya, ya_ref), (trial, n, list(starts), dict_opt, sl_opt, ro_opt)
 
 
-@pytest.mark.parametrize("kind", ["poisson2d_40x30", "poisson2d_100x100", "tridiagonal_10000", "random_spd_3000"])
+@pytest.mark.parametrize("kind", ["poisson2d_40x30", "poisson2d_100x100", "tridiagonal_10000", "random_spd_3000", "ellpack_tridiagonal_127",
+                                  "ellpack_poisson2d_30x20"])
 def test_single_workgroup_cg_vs_oracle_and_vs_the_launch_loop(orc, kind):
     """CG / Jacobi-PCG on small systems run as ONE workgroup (k_cg_small; sliced stencil matrices up to 10240 rows,
     plain CSR up to 4096): iteration count and solution against the oracle, the same against the launch-per-kernel
@@ -650,7 +651,19 @@ def test_single_workgroup_cg_vs_oracle_and_vs_the_launch_loop(orc, kind):
     (r, p, res2 parked in memory between launches) -- that one bit-identical to the uncut solve."""
     import scipy.sparse as sp
     rs = np.random.RandomState(11)
-    if kind.startswith("poisson2d"):
+    H = None
+    if kind.startswith("ellpack"):       # the reference's diffusion test stores its matrix in ELLPACK (padding slots: last neighbour, 0.0)
+        if kind.endswith("127"):
+            n = 127
+            ptr, node, val = P.poisson2d_csr(n, 1)
+            val = np.where(val == 4.0, 2.0, val)
+        else:
+            n = 600
+            ptr, node, val = P.poisson2d_csr(30, 20)
+        ei = np.repeat(np.arange(1, n + 1), np.diff(ptr)).astype(np.int32)
+        A = orc.EllMatrix.from_edges(n, n, ei, node, val)
+        H = sg.ellpack_matrix(n, n, A.node, A.val)
+    elif kind.startswith("poisson2d"):
         nx, ny = (40, 30) if kind.endswith("40x30") else (100, 100)
         n = nx * ny
         ptr, node, val = P.poisson2d_csr(nx, ny)
@@ -665,8 +678,9 @@ def test_single_workgroup_cg_vs_oracle_and_vs_the_launch_loop(orc, kind):
         S = (S + sp.diags(np.abs(S).sum(axis=1).A1 + 0.02)).tocsr()       # strictly diagonally dominant: SPD
         S.sort_indices()
         ptr, node, val = (S.indptr + 1).astype(np.int32), (S.indices + 1).astype(np.int32), S.data.copy()
-    A = orc.CsrMatrix(n, n, ptr, node, val)
-    H = sg.csr_matrix(n, n, ptr, node, val)
+    if H is None:
+        A = orc.CsrMatrix(n, n, ptr, node, val)
+        H = sg.csr_matrix(n, n, ptr, node, val)
     b = P.test_vector(n)
     tol = 1e-11
     for jac in (False, True):
