@@ -383,6 +383,11 @@ def worker(args):
     if rank == 0 and world == 1 and not args.no_cpu and host is not None:
         cpu = cpu_baseline(args, host, n_loc)
 
+    # ---- C1 (BASELINE configs[0], the reference's own CPU-sized case): tridiagonal n = 10,000, CG to 1e-16 ----
+    c1 = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        c1 = c1_leg(sg, P, torch, dev)
+
     kernel_sha = csrc_sha1()
     A.destroy()
     del x, y
@@ -454,7 +459,7 @@ def worker(args):
                          "note": "achieved = moved_bytes_per_launch / avg_launch_ms: the sliced kernel reads 8W+4 bytes per "
                                  "row of its own layout (W = 5) + x once + y once.  cold_* = the same launch after 512 MiB "
                                  "of unrelated writes (nothing of the previous product left in L2 / Infinity Cache)"},
-            "spmv_variants": variants or None, "cg": cg, "c5_strong_scaling": c5, "cpu_baseline": cpu,
+            "spmv_variants": variants or None, "cg": cg, "c5_strong_scaling": c5, "c1_reference_sized": c1, "cpu_baseline": cpu,
             "selfcheck": {"product_bit_exact_on_every_rank": check_main,
                           "what": "every local row of one timed-workload product == its sum evaluated with torch in stored "
                                   "order from x(i) = sin(0.001 i), on every rank (halo values included)"},
@@ -497,6 +502,54 @@ def cpu_baseline(args, host, n_loc):
         ref["port_on_same_matrix"] = port
         return ref
     return port
+
+
+def c1_leg(sg, P, torch, dev, n=10000, tol=1e-16):
+    """BASELINE configs[0]: tridiag(-1, 2, -1), n = 10,000, f = 2 dx^2, CG from u = 0 to an absolute 1e-16 -- the matrix
+    assembled in the reference's insertion order; the device solve (second of two) beside the reference itself solving
+    the same system on one host core (oracle/_ref/sigma_ref_driver), both against the analytic solution."""
+    import struct
+    import tempfile
+    import numpy as np
+    (ei, ej, ev), f, v = P.diffusion_1d(n)
+    A = sg.csr_matrix.from_edges(n, n, ei, ej, ev)          # device-side assembly in the reference's insertion order
+    b = torch.from_numpy(f).to(dev)
+    s = sg.cg(tol)
+    s.setup(A)
+    u = torch.zeros(n, dtype=torch.float64, device=dev)
+    s.solve(A, u, b)
+    torch.cuda.synchronize()
+    u.zero_()
+    t0 = time.perf_counter()
+    s.solve(A, u, b)
+    torch.cuda.synchronize()
+    gpu_s = time.perf_counter() - t0
+    out = {"workload": f"tridiag(-1,2,-1) n={n}, CG from 0 to an absolute {tol:g} (BASELINE configs[0])",
+           "gpu_ms": 1e3 * gpu_s, "gpu_iterations": int(s.last_iterations),
+           "gpu_max_err_vs_analytic": float(np.abs(u.cpu().numpy() - v).max())}
+    s.destroy()
+    A.destroy()
+    drv = os.path.join(ROOT, "oracle", "_ref", "sigma_ref_driver")
+    if os.path.exists(drv):
+        try:
+            with tempfile.TemporaryDirectory() as td:
+                inp = os.path.join(td, "in.bin")
+                with open(inp, "wb") as fh:
+                    fh.write(struct.pack("<5i", n, n, len(ei), 1, 1))
+                    fh.write(np.asarray(ei, "<i4").tobytes())
+                    fh.write(np.asarray(ej, "<i4").tobytes())
+                    fh.write(np.asarray(ev, "<f8").tobytes())
+                    fh.write(np.zeros(n, "<f8").tobytes())
+                    fh.write(np.asarray(f, "<f8").tobytes())
+                    fh.write(struct.pack("<iid", 1, 0, tol))
+                o = subprocess.run([drv, inp, os.path.join(td, "o"), "time:1"], capture_output=True, text=True, timeout=300)
+            line = [ln for ln in o.stdout.splitlines() if ln.startswith("solve 1:")][0]
+            out["reference_cpu_ms"] = 1e3 * float(line.split("seconds=")[1].split()[0])
+            out["reference_iterations"] = int(line.split("iterations=")[1].split()[0])
+            out["reference_kind"] = "danshapero/sigma itself (amdflang -O2), one host core"
+        except Exception as e:        # a baseline leg must never take the bench line down
+            sys.stderr.write(f"[bench] C1 reference leg skipped: {e}\n")
+    return out
 
 
 def reference_cpu_baseline(nx, ny, reps=10, nx_cg=600):
