@@ -1685,14 +1685,23 @@ def _solve(A, g, skind, pkind, tol, hist=0):
     return u, solver
 
 
+@pytest.mark.parametrize("cg_small", [1, 0])
 @pytest.mark.parametrize("name", golden_names())
-def test_solvers_golden(golden, name):
+def test_solvers_golden(golden, name, cg_small):
+    """Every solve the reference ran on the fixture -- with CG both as one workgroup (the small systems of the
+    fixtures qualify) and as the launch-per-kernel loop, each pinned to the reference's iteration count and solution."""
     g = golden(name)
     if not len(g["solves"]):
         pytest.skip("no solves in this fixture")
     A = hip_matrix(g)
     for s, (skind, pkind, tol) in enumerate(g["solves"], 1):
-        u, solver = _solve(A, g, skind, pkind, tol)
+        if cg_small == 0 and int(skind) != CG:
+            continue                      # (BiCGStab has one path)
+        sg.set_option("cg_small", cg_small)
+        try:
+            u, solver = _solve(A, g, skind, pkind, tol)
+        finally:
+            sg.set_option("cg_small", 1)
         uref = g[f"ref_s{s}_u"]
         itref = int(g[f"ref_s{s}_iterations"][0])
         rel = np.abs(u - uref).max() / np.abs(uref).max()
@@ -1712,9 +1721,14 @@ def test_solvers_golden(golden, name):
 def test_reference_known_answers(golden):
     # test/solver_test_diffusion_1d.f90:104-115: ELLPACK n=127, cg(1e-16): 64 iterations, err <= 1e-14
     g = golden("diffusion1d_ell_127")
-    u, solver = _solve(hip_matrix(g), g, CG, 0, 1e-16)
-    assert solver.iterations == 64
-    assert np.abs(u - g["analytic"]).max() <= 1e-14
+    for cg_small in (1, 0):               # one workgroup / launch loop
+        sg.set_option("cg_small", cg_small)
+        try:
+            u, solver = _solve(hip_matrix(g), g, CG, 0, 1e-16)
+        finally:
+            sg.set_option("cg_small", 1)
+        assert solver.iterations == 64
+        assert np.abs(u - g["analytic"]).max() <= 1e-14
     # test/solver_test_advection_diffusion_1d.f90:111-122: bicgstab(1e-12), err <= 1e-8
     g = golden("advdiff1d_ell_1024")
     u, solver = _solve(hip_matrix(g), g, BICGSTAB, 0, 1e-12)
