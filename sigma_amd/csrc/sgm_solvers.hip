@@ -883,6 +883,69 @@ int read_state(sgm_solver s, int *flag, int64_t *iters, double *res)
 enum { C_PQ = 0, C_RR0 = 1, C_RR1 = 2 };
 enum { V_P = 0, V_Q = 1, V_R = 2, V_Z = 3 };
 
+// The RMAX row sums of one thread of a single-workgroup solver (rows tid, tid + 1024, ...), x gathered out of LDS
+// (`pl`), side by side: slot e of every row is requested before any of them is used, so a row's entries are still
+// added left to right but the thread waits for one round trip per SLOT, not per entry (rows one after the other:
+// 16 us per CG iteration at n = 1e4, five entries per row).  SL: sliced form (a0 = code words, a1 = offset
+// dictionary, val = sval); otherwise CSR (a0 = rowptr, a1 = col).
+template <int RMAX, bool SL>
+__device__ inline void small_row_sums(double (&q)[RMAX], const double *pl, int32_t n, int32_t sw,
+                                      const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                      const double *__restrict__ val)
+{
+    constexpr int BLOCK = 1024;
+    const int tid = threadIdx.x;
+    if (SL) {
+        uint32_t cw[RMAX];
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = tid + u * BLOCK;
+            q[u] = 0.0;
+            cw[u] = i < n ? (uint32_t)rowptr[i] : 0xffffffffu;
+        }
+        constexpr int H = RMAX > 5 ? (RMAX + 1) / 2 : RMAX;        // rows side by side (all ten: 71-89 registers spilled)
+#pragma unroll
+        for (int h0 = 0; h0 < RMAX; h0 += H)
+            for (int32_t e = 0; e < sw; ++e) {
+                double v[H];
+#pragma unroll
+                for (int u = h0; u < h0 + H && u < RMAX; ++u) {
+                    const int32_t i = tid + u * BLOCK;
+                    if (((cw[u] >> (4 * e)) & 15u) != 15u) v[u - h0] = val[((i >> 9) * sw + e) * 512 + (i & 511)];
+                }
+#pragma unroll
+                for (int u = h0; u < h0 + H && u < RMAX; ++u) {
+                    const int32_t i = tid + u * BLOCK;
+                    const uint32_t cd = (cw[u] >> (4 * e)) & 15u;
+                    if (cd != 15u) q[u] = q[u] + v[u - h0] * pl[i + col[cd]];
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) q[u] = 0.0 + q[u];
+        return;
+    }
+    int32_t k0[RMAX], len[RMAX];
+    int32_t longest = 0;
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+        const int32_t i = tid + u * BLOCK;
+        k0[u] = 0; len[u] = 0; q[u] = 0.0;
+        if (i < n) { k0[u] = rowptr[i]; len[u] = rowptr[i + 1] - k0[u]; }
+        longest = max(longest, len[u]);
+    }
+    for (int32_t e = 0; e < longest; ++e) {
+        double v[RMAX]; int32_t c[RMAX];
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u)
+            if (e < len[u]) { v[u] = val[k0[u] + e]; c[u] = col[k0[u] + e]; }
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u)
+            if (e < len[u]) q[u] = q[u] + v[u] * pl[c[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) q[u] = 0.0 + q[u];          // A%matvec: y = 0 ; y(i) = y(i) + z
+}
+
 // ---- CG on a small system: the whole solve in ONE workgroup -----------------------------------------
 // Below n ~ 1e5 an iteration of the loop above IS its three launches (about 15 us whatever n is).  A system of up to
 // 10240 rows fits one workgroup: p lives in LDS (what the row sums gather from), x and r (and 1 / diag for Jacobi) in the
@@ -914,60 +977,7 @@ __global__ __launch_bounds__(1024) void k_cg_small(
         if (i < n) { xr[u] = x[i]; pl[i] = xr[u]; }
     }
     __syncthreads();
-    // the thread's RMAX row sums side by side: slot e of every row is requested before any of them is used, so a
-    // row's entries are still added left to right but the thread waits for one round trip per SLOT, not per entry
-    // (rows one after the other: 16 us per iteration at n = 1e4, five entries per row)
-    auto row_sums = [&](double (&q)[RMAX]) {
-        if (SL) {
-            uint32_t cw[RMAX];
-#pragma unroll
-            for (int u = 0; u < RMAX; ++u) {
-                const int32_t i = tid + u * BLOCK;
-                q[u] = 0.0;
-                cw[u] = i < n ? (uint32_t)rowptr[i] : 0xffffffffu;
-            }
-            constexpr int H = RMAX > 5 ? (RMAX + 1) / 2 : RMAX;        // rows side by side (all ten: 71-89 registers spilled)
-#pragma unroll
-            for (int h0 = 0; h0 < RMAX; h0 += H)
-                for (int32_t e = 0; e < sw; ++e) {
-                    double v[H];
-#pragma unroll
-                    for (int u = h0; u < h0 + H && u < RMAX; ++u) {
-                        const int32_t i = tid + u * BLOCK;
-                        if (((cw[u] >> (4 * e)) & 15u) != 15u) v[u - h0] = val[((i >> 9) * sw + e) * 512 + (i & 511)];
-                    }
-#pragma unroll
-                    for (int u = h0; u < h0 + H && u < RMAX; ++u) {
-                        const int32_t i = tid + u * BLOCK;
-                        const uint32_t cd = (cw[u] >> (4 * e)) & 15u;
-                        if (cd != 15u) q[u] = q[u] + v[u - h0] * pl[i + col[cd]];
-                    }
-                }
-#pragma unroll
-            for (int u = 0; u < RMAX; ++u) q[u] = 0.0 + q[u];
-            return;
-        }
-        int32_t k0[RMAX], len[RMAX];
-        int32_t longest = 0;
-#pragma unroll
-        for (int u = 0; u < RMAX; ++u) {
-            const int32_t i = tid + u * BLOCK;
-            k0[u] = 0; len[u] = 0; q[u] = 0.0;
-            if (i < n) { k0[u] = rowptr[i]; len[u] = rowptr[i + 1] - k0[u]; }
-            longest = max(longest, len[u]);
-        }
-        for (int32_t e = 0; e < longest; ++e) {
-            double v[RMAX]; int32_t c[RMAX];
-#pragma unroll
-            for (int u = 0; u < RMAX; ++u)
-                if (e < len[u]) { v[u] = val[k0[u] + e]; c[u] = col[k0[u] + e]; }
-#pragma unroll
-            for (int u = 0; u < RMAX; ++u)
-                if (e < len[u]) q[u] = q[u] + v[u] * pl[c[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < RMAX; ++u) q[u] = 0.0 + q[u];          // A%matvec: y = 0 ; y(i) = y(i) + z
-    };
+    auto row_sums = [&](double (&q)[RMAX]) { small_row_sums<RMAX, SL>(q, pl, n, sw, rowptr, col, val); };
     double s = 0.0, res2;
     int64_t it = 0;
     if (!resume) {

@@ -1696,7 +1696,8 @@ def test_solvers_golden(golden, name, cg_small):
     A = hip_matrix(g)
     for s, (skind, pkind, tol) in enumerate(g["solves"], 1):
         if cg_small == 0 and int(skind) != CG:
-            continue                      # (BiCGStab has one path)
+            continue                      # (BiCGStab has one path: a single-workgroup variant landed 2 iterations from the
+                                          # reference on one fixture -- its dot products sum in another order -- and was dropped)
         sg.set_option("cg_small", cg_small)
         try:
             u, solver = _solve(A, g, skind, pkind, tol)
