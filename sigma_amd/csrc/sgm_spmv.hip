@@ -375,17 +375,19 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
         const int32_t e = rowptr[r1];
         double z = (ADD && chain) ? y0 : 0.0;   // chain: the row sum continues from y(i) (transpose products)
 
-        for (int32_t ts = s; ts < e; ts += TILE) {
-            const int32_t te = min(ts + TILE, e);
-            // ---- phase 1: stream val (16 B / lane) and codes (4 B / lane) into LDS
-            f64x2 v[VPT];
+        // int32 columns on the largest tiles (long rows: several tiles per row block, phase 2 walks for microseconds): the
+        // next tile's loads are requested before this tile is walked (24 more registers; the short-row shapes that must
+        // stay within 64 VGPRs keep the loads where they were)
+        constexpr bool PF = CW == 4 && TILE >= 2048;
+        f64x2 v[VPT];
+        uint32_t c4[CPT];
+        i32x2 c8[VPT];
+        auto fetch = [&](int32_t ts, int32_t te) {
 #pragma unroll
             for (int m = 0; m < VPT; ++m) {
                 const int32_t j = ts + 2 * tid + 2 * BLOCK * m;
                 if (j < te) v[m] = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + j));
             }
-            uint32_t c4[CPT];
-            i32x2 c8[VPT];
             if (CW == 1) {
 #pragma unroll
                 for (int m = 0; m < CPT; ++m) {
@@ -400,6 +402,12 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
                     if (j < te) c8[m] = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(col32 + j));
                 }
             }
+        };
+        if (PF && s < e) fetch(s, min(s + TILE, e));
+        for (int32_t ts = s; ts < e; ts += TILE) {
+            const int32_t te = min(ts + TILE, e);
+            // ---- phase 1: stream val (16 B / lane) and codes (4 B / lane) into LDS
+            if (!PF) fetch(ts, te);
             __syncthreads();       // the previous tile's phase 2 is done with the LDS buffers
 #pragma unroll
             for (int m = 0; m < VPT; ++m) {
@@ -420,6 +428,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
                 }
             }
             __syncthreads();
+            if (PF && ts + TILE < e) fetch(ts + TILE, min(ts + 2 * TILE, e));
             // ---- phase 2: lane i gathers for row i (8 requests in flight), adds in order
             const int32_t kend = min(ke, te);
             while (k < kend) {
@@ -997,13 +1006,15 @@ static int row_lines_resident_per_cu()
 // pass (9 bytes each); the launcher picks the smallest one that holds a whole row block of
 // average density (+ alignment slack), so that a row block is one load phase + one gather
 // phase and the LDS footprint stays small enough for 8 workgroups per CU.
-#define SGM_DO_VARIANTS(X) X(256, 1024) X(256, 1536) X(256, 1920) X(256, 2048) X(512, 2048) X(512, 3072) X(512, 3840)
+#define SGM_DO_VARIANTS(X) X(256, 1024) X(256, 1536) X(256, 1920) X(256, 2048) X(256, 4096) X(512, 2048) X(512, 3072) X(512, 3840)
 static int do_tile_for(const Part &p)
 {
     const SpmvCfg &c = spmv_cfg();
-    static const int t256[] = {1024, 1536, 1920, 2048}, t512[] = {2048, 3072, 3840};
+    static const int t256[] = {1024, 1536, 1920, 2048, 4096}, t512[] = {2048, 3072, 3840};
     const int *tiles = c.block == 512 ? t512 : t256;
-    const int nt = c.block == 512 ? 3 : 4;
+    // (the 4096-entry tile serves int32 columns only -- long rows: 33..64 entries 794 -> 770 us, 20..40 746 -> 719;
+    // the 1-byte-code form keeps its 2048, measured with seven workgroups per CU)
+    const int nt = c.block == 512 ? 3 : (use_offset_dict(p) ? 4 : 5);
     if (c.do_vpt) return tiles[std::min(std::max(c.do_vpt - 1, 0), nt - 1)];     // tuning override: 1..nt
     const double per_block = (double)p.nnz / (p.n > 0 ? p.n : 1) * c.block + 4;
     for (int i = 0; i < nt; ++i)
