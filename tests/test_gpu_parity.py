@@ -753,6 +753,7 @@ def test_long_row_kernels_vs_oracle(orc, n, lo, hi):
     yb_ref = A.matvec(xb)
     b = P.test_vector(n)
     ur, itr, _, _ = orc.cg(A, b, tol=1e-12)
+    ubr, itb, _, _ = orc.bicgstab(A, b, tol=1e-12)
     starts = sg.partition_rows_by_nnz(ptr, 3, align=2)
     seen = set()
     for ro_opt, rg_opt in ((1, 1), (0, 1), (0, 0)):
@@ -777,9 +778,14 @@ def test_long_row_kernels_vs_oracle(orc, n, lo, hi):
             sv.setup(H)
             u = np.zeros(n)
             sv.solve(H, u, b)
+            sb = sg.bicgstab(1e-12)         # (its second product carries s.t and t.t: both fused dots of the kernel)
+            sb.setup(H)
+            ub = np.zeros(n)
+            sb.solve(H, ub, b)
         finally:
             _kernel_options(1, 1, 1, 1)
         key = (n, lo, hi, ro_opt, rg_opt)
+        assert abs(sb.iterations - itb) <= 1 and np.abs(ub - ubr).max() / np.abs(ubr).max() <= 1e-11, (key, sb.iterations, itb)
         assert np.array_equal(y, y_ref), key
         assert np.array_equal(ya, ya_ref), key
         assert np.array_equal(t, t_ref), key
