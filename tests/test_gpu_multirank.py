@@ -67,7 +67,7 @@ def _run_ranks(world, case, tmp_path, mock):
 
 
 @pytest.mark.parametrize("world,case", [(2, "poisson2d"), (2, "laplace3d"), (3, "laplace3d"), (3, "random"), (4, "poisson2d"),
-                                        (2, "composite"), (3, "composite")])
+                                        (3, "longrows"), (2, "composite"), (3, "composite")])
 def test_ranks_share_one_gpu_over_the_host_staged_transport(world, case, tmp_path):
     assert os.path.exists(MOCK), "tests/mock_rccl/librccl_mock.so is missing: run __graft_entry__.build()"
     results = _run_ranks(world, case, tmp_path, mock=True)
