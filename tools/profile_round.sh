@@ -21,3 +21,7 @@ SGM_GMRES_CGS2=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format cs
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_configs -- python tools/bench_configs.py --configs c4,c5 > $OUT/configs.log 2>&1
 grep -h '^{' $OUT/c3_cgs2.log $OUT/c3_mgs.log $OUT/configs.log > $OUT/configs.jsonl
 cat $OUT/bench.json | cut -c1-600
+# the bench line once more, now that this round's PMC passes exist: condense them on the box (profiles/r02/pmc_hbm_traffic.json
+# with the fingerprint of the sources that just ran) so that `roofline.traffic` of the line is this run's own figure
+python tools/collect_profiles.py r02 > /dev/null 2>&1
+timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo bench_with_traffic=$?
