@@ -74,6 +74,15 @@ int sgm_synchronize(void);
  * slot-major, plus one 32-bit word of 4-bit codes per row; a lane owns two adjacent rows, every
  * load is 16 bytes wide, coalesced and independent, no row pointers are read (8 W + 4 bytes per
  * row of width W).  5-17 % faster than the 1-byte-code kernel; 0 keeps that.
+ * "ell_colblock" (default 1): ELLPACK matrices whose columns have no locality (x >= 16 MB, rows of >= 8
+ * slots) take the column-blocked two-phase product (products through LDS-resident x blocks, then ordered
+ * row sums); 0 never, 2 always.  "ell_colblock_cols" (default 16384): x entries per block;
+ * "ell_colblock_chunks" (default 16): workgroups per block in the first phase; "ell_colblock_rows"
+ * (default 0 = automatic, 256 or 512): rows per tile of the second phase.
+ * "ildu_strips" (default 1): ILDU(0) factors of grid-like matrices use the strip- / slab-pipelined
+ * triangular solves; 0 keeps the level-scheduled walkers.
+ * "gmres_cgs2" (default 1): GMRES orthogonalises with blocked classical Gram-Schmidt applied twice (three
+ * passes and three all-reduces per step); 0 = modified Gram-Schmidt.
  * "cg_small" (default 1): CG (plain or Jacobi-preconditioned) on a single-GPU CSR matrix of at most
  * 10240 rows (stencil matrices; 4096 otherwise) runs as ONE workgroup -- p in LDS, x and r in registers,
  * no launch inside the loop; same statements as the launch-per-kernel loop, only the dot products'

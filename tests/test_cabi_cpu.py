@@ -181,3 +181,23 @@ def test_slice_schedule_is_a_permutation(nsl, period, grid, band):
         assert same.mean() > 0.9                       # (band edges: the neighbour one plane up may sit in the next band)
         d = (pos_of[s1] - pos_of[s0])[same]
         assert np.median(np.abs(d)) <= 2 * band + 2
+
+
+def test_every_documented_option_is_accepted_and_unknown_names_are_refused():
+    """The option names in the header's comment and the ones sgm_set_option knows are the same set (no GPU needed:
+    options are plain settings)."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "sigma_hip.h")).read()
+    start = hdr.index("/* options:")
+    block = hdr[start:hdr.index("int sgm_set_option", start)]
+    names = set(re.findall(r'"([a-z_0-9]+)"(?: \(default|: )', block))
+    assert {"csr_offset_dict", "csr_row_owner", "csr_row_lines", "csr_sliced", "cg_small", "slice_sched"} <= names, names
+    src = open(os.path.join(ROOT, "sigma_amd", "csrc", "sgm_runtime.hip")).read()
+    known = set(re.findall(r'!strcmp\(name, "([a-z_0-9]+)"\)', src))
+    assert names == known, (names - known, known - names)
+    lib = sg.lib()
+    for nm in sorted(known):
+        cur = {"ell_colblock_cols": 16384, "ell_colblock_chunks": 16, "slice_sched_band": 64, "cg_small_chunk": 50000,
+               "ell_colblock_rows": 0, "slice_sched": 0}.get(nm, 1)
+        assert lib.sgm_set_option(nm.encode(), cur) == 0, nm          # (set to its default: nothing changes)
+    assert lib.sgm_set_option(b"no_such_option", 1) != 0
