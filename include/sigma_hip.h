@@ -77,8 +77,8 @@ int sgm_synchronize(void);
  * "ell_colblock" (default 1): ELLPACK matrices whose columns have no locality (x >= 16 MB, rows of >= 8
  * slots) take the column-blocked two-phase product (products through LDS-resident x blocks, then ordered
  * row sums); 0 never, 2 always.  "ell_colblock_cols" (default 16384): x entries per block;
- * "ell_colblock_chunks" (default 16): workgroups per block in the first phase; "ell_colblock_rows"
- * (default 0 = automatic, 256 or 512): rows per tile of the second phase.
+ * "ell_colblock_chunks" (default 16): workgroups per block in the first phase;
+ * "ell_colblock_rows" (default 0 = automatic, 256 or 512): rows per tile of the second phase.
  * "ildu_strips" (default 1): ILDU(0) factors of grid-like matrices use the strip- / slab-pipelined
  * triangular solves; 0 keeps the level-scheduled walkers.
  * "gmres_cgs2" (default 1): GMRES orthogonalises with blocked classical Gram-Schmidt applied twice (three
