@@ -45,6 +45,12 @@ interface
         integer(c_int), value :: device
         integer(c_int) :: rc
     end function
+    function sgm_set_option(name, value) bind(c, name='sgm_set_option') result(rc)
+        import :: c_int, c_char
+        character(kind=c_char), intent(in) :: name(*)
+        integer(c_int), value :: value
+        integer(c_int) :: rc
+    end function
     function sgm_last_error() bind(c, name='sgm_last_error') result(msg)
         import :: c_ptr
         type(c_ptr) :: msg
@@ -358,6 +364,18 @@ subroutine hip_check(rc)
     print *, 'Terminating.'
     call exit(1)
 end subroutine hip_check
+
+
+!==========================================================================!
+!==== options of the library (include/sigma_hip.h, sgm_set_option)      ====!
+!==========================================================================!
+subroutine hip_set_option(name, value)
+    ! e.g. call hip_set_option("cg_small", 0): results do not depend on any of them beyond the
+    ! summation order of dot products
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: value
+    call hip_check(sgm_set_option(trim(name) // c_null_char, int(value, c_int)))
+end subroutine hip_set_option
 
 
 !==========================================================================!

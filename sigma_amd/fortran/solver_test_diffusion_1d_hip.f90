@@ -75,6 +75,23 @@ implicit none
     call solver%destroy()
     deallocate(solver)
 
+    ! the same solve as a loop of kernel launches instead of one workgroup
+    ! (library option "cg_small"): same count, same error bound
+    call hip_set_option("cg_small", 0)
+    u = 0.0_dp
+    solver => hip_cg(1.d-16)
+    call solver%setup(A)
+    call solver%solve(A, u, f)
+    call hip_set_option("cg_small", 1)
+    misfit = maxval(dabs(u - v))
+    if (verbose) print *, 'CG (launch loop) iterations:', solver%iterations, ' error:', misfit
+    if (misfit > 1.0e-14 .or. solver%iterations /= 64) then
+        print *, 'CG as a launch loop failed:', solver%iterations, misfit
+        call exit(1)
+    endif
+    call solver%destroy()
+    deallocate(solver)
+
     !------------------------------------------------------------------!
     ! same matrix in CSR + Jacobi-preconditioned CG                     !
     !------------------------------------------------------------------!
