@@ -196,8 +196,8 @@ __global__ __launch_bounds__(BLOCK) void k_csr_spmv(
 // Here a lane owns a row too, and ALL 256 rows of the block are walked at once; what makes that fit in LDS is the
 // staging unit: not "every entry of the row block" but ONE 128-BYTE LINE of `val` (16 entries) per row and pass.  In
 // pass c, row j's entries that lie in line (first line of row j) + c are staged -- eight lanes per row fetch the line's
-// 16-byte pieces and the 8-byte pieces of `col` beside them, only pieces that hold an entry of the row -- and lane j
-// then walks its up-to-16 entries: columns out of LDS, eight x requests in flight, products rounded one by one and
+// 16-byte pieces, only pieces that hold an entry of the row; `col` comes in whole 128-byte lines (32 entries) on every
+// other pass, see `fetch` -- and lane j then walks its up-to-16 entries: columns out of LDS, eight x requests in flight, products rounded one by one and
 // added in stored order (bit-identical to csr_matvec_add).  The loads of pass c + 1 are in flight while pass c is
 // summed.  A block takes as many passes as its longest row has lines.  LDS: 256 rows x 17 (16 + 1 against bank
 // conflicts) x 12 B = 52 KiB, three workgroups per CU.  Price: a line that two rows share is requested by both, in
