@@ -337,8 +337,6 @@ def worker(args):
                               {"csr_sliced": 0}),
                              ("int32_columns, row-owner gather (general kernel, rows <= 64 entries)",
                               {"csr_offset_dict": 0, "csr_row_owner": 1}),
-                             ("int32_columns, line-staged row owner (general kernel, longer rows)",
-                              {"csr_offset_dict": 0, "csr_row_owner": 0}),
                              ("int32_columns, streaming gather (general kernel, any row length)",
                               {"csr_offset_dict": 0, "csr_row_owner": 0, "csr_row_lines": 0})):
             for k, v in opts.items():

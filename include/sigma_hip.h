@@ -65,8 +65,8 @@ int sgm_synchronize(void);
  * "ell_offset_dict" (default 1): the same for ELLPACK matrices with max_d <= 16.
  * "csr_row_owner" (default 1): int32-column matrices whose rows hold <= 64 entries use the
  * row-owner gather kernel; 0 forces the kernels for longer rows.
- * "csr_row_lines" (default 1): int32-column matrices with longer rows (no row beyond 4096 entries)
- * use the line-staged row-owner kernel (one 128-byte line of values per row and pass, every row of a
+ * "csr_row_lines" (default 1): int32-column matrices with longer rows of similar length (mean >= 16
+ * entries, no row beyond 4096 or beyond 4 x the mean) use the line-staged row-owner kernel (one 128-byte line of values per row and pass, every row of a
  * 256-row block walked by its owner lane); 0 forces the balanced streaming-gather kernel (any row
  * length).
  * "csr_sliced" (default 1): offset-dictionary matrices whose rows hold <= 8 entries from <= 15

@@ -992,7 +992,11 @@ static bool use_row_owner(const Part &p)
 // lanes per row, sums by the owner; in history -- 1160 with k_csr_do and 1180 with k_csr_spmv; 150..300: 1070 against 1670)
 static bool use_row_lines(const Part &p)
 {
-    return g_opt.csr_row_lines && !any_sliced(p) && !use_row_owner(p) && p.n > 0 && p.max_row <= 4096;
+    // ... and rows of SIMILAR length, at least a line long on average: every row of a block waits for the block's longest one
+    // (the 5-point matrix forced through it: 491 us against 153 with k_csr_spmv), so a few long rows among short ones
+    // (max > 4 x mean) also stay with the streaming kernel
+    return g_opt.csr_row_lines && !any_sliced(p) && !use_row_owner(p) && p.n > 0 && p.max_row <= 4096 &&
+           p.nnz >= 16 * (int64_t)p.n && (int64_t)p.max_row * p.n <= 4 * p.nnz;
 }
 static int row_lines_resident_per_cu()
 {
@@ -1025,7 +1029,7 @@ static int do_tile_for(const Part &p)
 // Persistent grid: exactly the number of workgroups that are resident at once (LDS- or
 // wave-limited), rounded down to a multiple of 8 for the XCD map -- a larger grid only adds
 // a tail, a smaller one leaves CUs idle (measured: 7-point, 19.5 KiB LDS: 1536 beats 2048).
-static int grid_for_rows(const Part &p, int64_t rows, int64_t limit)
+static int grid_for_rows(const Part &p, int64_t rows, int64_t limit, bool dots = true)
 {
     const SpmvCfg &c = spmv_cfg();
     const int blk = any_sliced(p) ? kSlRows : use_row_lines(p) ? 256 : c.block;
@@ -1034,7 +1038,9 @@ static int grid_for_rows(const Part &p, int64_t rows, int64_t limit)
     int64_t cap = c.maxgrid;
     // round-robin slices, not a persistent resident grid: 4096 workgroups; 8192 from 32768 slices on
     // (n >= 1.7e7: 464^3 1.54 -> 1.45 ms, 300^3 355 -> 345 us; below that the consumers' re-reduction of more partials costs more)
-    if (cap <= 0 && any_sliced(p)) cap = nrb >= 32768 ? kMaxGrid : kMaxGrid / 2;
+    // a product WITHOUT fused dots takes the 8192 grid at every size (C2: 98.5 -> 95.9 us with the block-cyclic map); with
+    // them the 4096 one below 32768 slices (8192 partials per dot cost the CG update kernels more than the product gains)
+    if (cap <= 0 && any_sliced(p)) cap = (nrb >= 32768 || !dots) ? kMaxGrid : kMaxGrid / 2;
     if (cap <= 0 && use_row_lines(p)) cap = (int64_t)row_lines_resident_per_cu() * g_rt.num_cu;
     if (cap <= 0) cap = (int64_t)resident_per_cu(use_row_owner(p), c.block, use_row_owner(p) ? do_tile_for(p) : c.vpt,
                                                  use_offset_dict(p) ? 1 : 4) * g_rt.num_cu;
@@ -1048,7 +1054,7 @@ static int grid_for_rows(const Part &p, int64_t rows, int64_t limit)
 // only owned columns ("interior", one contiguous run of row blocks found at setup) can run
 // while the halo exchange is still in flight; the head / tail ranges follow it.
 struct RowRange { int32_t lo, hi; int grid, part_off; };
-static int spmv_ranges(const Part &p, RowRange out[3])
+static int spmv_ranges(const Part &p, RowRange out[3], bool dots = true)
 {
     int nr = 0, off = 0;
     auto add = [&](int32_t lo, int32_t hi) {       // grids sum to <= kMaxGrid partial slots
@@ -1059,7 +1065,7 @@ static int spmv_ranges(const Part &p, RowRange out[3])
     };
     if (p.n_halo == 0 || p.int_hi <= p.int_lo) {
         if (any_sliced(p)) {           // one range, all kMaxGrid partial slots are its own
-            out[0] = RowRange{0, p.n, grid_for_rows(p, p.n > 0 ? p.n : 1, kMaxGrid), 0};
+            out[0] = RowRange{0, p.n, grid_for_rows(p, p.n > 0 ? p.n : 1, kMaxGrid, dots), 0};
             return 1;
         }
         add(0, p.n > 0 ? p.n : 1);
@@ -1166,10 +1172,10 @@ static void launch_csr_sl(const Part &p, int grid, const double *x, double *y, c
 {
     const SpmvCfg &c = spmv_cfg();
     hipStream_t st = g_rt.stream;
-    // XCD-block-cyclic slices (G = 32) on the 4096-workgroup grids, plain round-robin on the 8192 ones
+    // XCD-block-cyclic slices (G = 32) below 32768 slices, plain round-robin on the 8192 grids above that
     // (measured: 300^3 363 vs 358 us) and wherever the grid is not a multiple of 8 G; SGM_SPMV_CFG's
     // remap field overrides (0 = round-robin, 3/4/5 = G 8/2/32)
-    int mode = c.remap == 1 ? (grid <= kMaxGrid / 2 ? 5 : 0) : (c.remap >= 3 ? c.remap : 0);
+    int mode = c.remap == 1 ? ((grid <= kMaxGrid / 2 || (int64_t)p.n < (int64_t)32768 * kSlRows) ? 5 : 0) : (c.remap >= 3 ? c.remap : 0);
     if (mode >= 3 && grid % (8 * (mode == 3 ? 8 : mode == 4 ? 2 : mode == 6 ? 64 : mode == 7 ? 128 : 32)) != 0) mode = 0;
 #define L(WW, DW, DY)                                                                                   \
     hipLaunchKernelGGL((k_csr_sl<WW, ADD, DW, DY>), dim3(grid), dim3(256), 0, st, p.n, p.scode, p.dict, \
@@ -1194,7 +1200,7 @@ static void launch_csr_sl32(const Part &p, int grid, const double *x, double *y,
 {
     hipStream_t st = g_rt.stream;
     const SpmvCfg &c = spmv_cfg();
-    int mode = c.remap == 1 ? (grid <= kMaxGrid / 2 ? 5 : 0) : (c.remap >= 3 ? c.remap : 0);
+    int mode = c.remap == 1 ? ((grid <= kMaxGrid / 2 || (int64_t)p.n < (int64_t)32768 * kSlRows) ? 5 : 0) : (c.remap >= 3 ? c.remap : 0);
     if (mode >= 3 && grid % (8 * (mode == 3 ? 8 : mode == 4 ? 2 : mode == 6 ? 64 : mode == 7 ? 128 : 32)) != 0) mode = 0;
 #define L(WW, DW, DY)                                                                                     \
     hipLaunchKernelGGL((k_csr_sl32<WW, ADD, DW, DY>), dim3(grid), dim3(256), 0, st, p.n, p.scol, p.sval, x, y, \
@@ -1218,7 +1224,7 @@ static void launch_csr_slb(const Part &p, int grid, const double *x, double *y, 
 {
     hipStream_t st = g_rt.stream;
     const SpmvCfg &c = spmv_cfg();
-    int mode = c.remap == 1 ? (grid <= kMaxGrid / 2 ? 5 : 0) : (c.remap >= 3 ? c.remap : 0);
+    int mode = c.remap == 1 ? ((grid <= kMaxGrid / 2 || (int64_t)p.n < (int64_t)32768 * kSlRows) ? 5 : 0) : (c.remap >= 3 ? c.remap : 0);
     if (mode >= 3 && grid % (8 * (mode == 3 ? 8 : mode == 4 ? 2 : mode == 6 ? 64 : mode == 7 ? 128 : 32)) != 0) mode = 0;
 #define L(WW, DW, DY)                                                                                     \
     hipLaunchKernelGGL((k_csr_slb<WW, ADD, DW, DY>), dim3(grid), dim3(256), 0, st, p.n, p.sbcode, p.dict, p.sval, x, y, \
@@ -1506,7 +1512,7 @@ int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
                 continue;
             }
             RowRange r[3];
-            const int nr = spmv_ranges(p, r);
+            const int nr = spmv_ranges(p, r, dots != nullptr);
             if (grid_out) *grid_out = spmv_grid(p);
             const bool split = nr > 1;              // r[0] is the interior range
             for (int k = 0; k < nr; ++k) {

@@ -371,11 +371,11 @@ def _kernel_options(dict_opt, sl_opt, ro_opt, rg_opt=1):
 
 # (offset dictionary, sliced forms, row-owner gather, line-staged row owner, the kernel a stencil matrix then takes)
 KERNEL_COMBOS = ((1, 1, 1, 1, "k_csr_sl"), (1, 0, 1, 1, "CW=1"), (0, 1, 1, 1, "k_csr_sl32"), (0, 0, 1, 1, "CW=4"),
-                 (0, 0, 0, 1, "k_csr_rl"), (0, 0, 0, 0, "k_csr_spmv"))
+                 (0, 0, 0, 1, "k_csr_rl or k_csr_spmv"), (0, 0, 0, 0, "k_csr_spmv"))
 
 
 def test_offset_dict_and_int32_kernels_agree(orc):
-    """Six CSR kernels, one result: sliced 4-bit codes (rows <= 8 entries, <= 15 offsets),
+    """The CSR kernels, one result: sliced 4-bit codes (rows <= 8 entries, <= 15 offsets),
     1-byte offset-dictionary codes (other stencil-like matrices), sliced int32 columns (short rows
     without a dictionary), int32 columns gathered by the row's owner lane out of a staged tile (rows <= 64
     entries) or line by line (longer rows), or while streaming (any row length).
@@ -400,8 +400,9 @@ def test_offset_dict_and_int32_kernels_agree(orc):
             assert np.array_equal(y, y_ref), (name, dict_opt, sl_opt, ro_opt, rg_opt)
             assert np.array_equal(yt, yt_ref), (name, dict_opt, sl_opt, ro_opt, rg_opt)
         # the stencils exercise all six kernels; the random matrix has no dictionary
-        # (the random matrix, rows of <= 32 entries: sliced int32 form, row owner, row lines, streaming)
-        assert len(seen) == (4 if name.startswith("random") else 6), (name, seen)
+        # (short rows never take the line-staged kernel: with the row owner off they stream; the random matrix, rows of
+        #  <= 32 entries at arbitrary columns: sliced int32 form, row owner, streaming)
+        assert (len(seen) in (3, 4)) if name.startswith("random") else (len(seen) == 5), (name, seen)
 
 
 def _banded_short_rows(n, seed, wmax=8, noffs=15):
@@ -484,8 +485,6 @@ def test_randomised_matrices_every_kernel_vs_oracle(orc, kind):
             assert np.array_equal(ta, ta_ref), key
     expect = {"banded": "k_csr_sl", "many_offsets": "k_csr_do", "short_random": "k_csr_sl32", "ragged": "k_csr_spmv"}[kind]
     assert expect in kernels, (kind, kernels)
-    if kind == "ragged":
-        assert "k_csr_rl" in kernels, kernels
 
 
 @pytest.mark.parametrize("max_d", [1, 3, 4, 5, 8, 9, 16, 20])
@@ -793,7 +792,11 @@ def test_long_row_kernels_vs_oracle(orc, n, lo, hi):
         assert np.array_equal(yb, yb_ref, equal_nan=True), key
         assert np.array_equal(yp, y_ref), key
         assert abs(sv.iterations - itr) <= 1 and np.abs(u - ur).max() / np.abs(ur).max() <= 1e-11, key
-    assert "k_csr_spmv" in seen and "k_csr_rl" in seen, seen
+    # the line-staged kernel serves rows of similar length only (longest <= 4 x mean, mean >= 16): the (2500, 100, 2600) matrix,
+    # whose clipped columns make two rows dense, stays with the streaming kernel
+    lens = S.getnnz(axis=1)
+    uniform = int(lens.max()) * n <= 4 * S.nnz and S.nnz >= 16 * n and lens.max() <= 4096
+    assert "k_csr_spmv" in seen and (("k_csr_rl" in seen) == bool(uniform)), (seen, uniform)
 
 
 def test_slice_schedule_keeps_results(orc):
