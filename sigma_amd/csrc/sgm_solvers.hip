@@ -1165,7 +1165,9 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
     int flag = 0; int64_t iters = 0; double res = 0.0;
     const int64_t batch_max = pc_apply_is_short(pc) ? 16 : 1;
     for (;;) {
-        int64_t batch = batch_max;
+        // the host looks at the stop flag once per batch (a stream synchronisation + three small copies, ~20 us): batches
+        // grow with the iterations already done -- at most an eighth of them run past the stop as early-exit kernels
+        int64_t batch = batch_max > 1 ? std::min<int64_t>(128, std::max<int64_t>(batch_max, k / 8)) : batch_max;
         if (s->max_iter > 0) batch = std::min<int64_t>(batch, s->max_iter - k);
         for (int64_t bi = 0; bi < batch; ++bi, ++k) {
             const int cur = (k & 1) ? C_RR1 : C_RR0, nxt = (k & 1) ? C_RR0 : C_RR1;
@@ -1267,7 +1269,9 @@ int run_bicgstab(sgm_solver s, sgm_mat A, double *const *x, const double *const 
                                s->work[ip].flag, s->work[ip].res);
     };
     for (;;) {
-        int64_t batch = batch_max;
+        // the host looks at the stop flag once per batch (a stream synchronisation + three small copies, ~20 us): batches
+        // grow with the iterations already done -- at most an eighth of them run past the stop as early-exit kernels
+        int64_t batch = batch_max > 1 ? std::min<int64_t>(128, std::max<int64_t>(batch_max, k / 8)) : batch_max;
         if (s->max_iter > 0) batch = std::min<int64_t>(batch, s->max_iter - k);
         for (int64_t bi = 0; bi < batch; ++bi, ++k) {
             const int c = (int)(k & 1), o = c ^ 1;
