@@ -1078,6 +1078,9 @@ static bool cg_small_applies(sgm_solver s, sgm_mat A, sgm_pc pc)
     if (p.n < 1 || p.n_halo != 0) return false;
     if (!cg_small_sliced(p) && (A->fmt != SGM_FMT_CSR || !p.rowptr || !p.col || !p.val)) return false;
     if (p.n > (cg_small_sliced(p) ? kCgSmallMax : kCgSmallMaxCsr)) return false;
+    // one CU takes about 2.5 us + 0.22 us per 1000 stored slots per iteration (5-point 80^2: 11.3 us, 100^2: 14.9; tridiagonal
+    // n = 1e4: 11.0; 7-point 20^3: 16.2); the launch loop 14.3-14.7 whatever the size: beyond ~49k slots the loop it is
+    if ((cg_small_sliced(p) ? (int64_t)p.n * p.sw : p.nnz) > 49152) return false;
     const int pk = pc ? pc_kind(pc) : 0;
     return pk == 0 || pk == SGM_PC_JACOBI;
 }
