@@ -104,6 +104,13 @@ def main():
     case("diffusion1d_csr_2000", 2000, 2000, CSR, edges, P.test_vector(2000), f,
          [(CG, NOPC, 1e-14)], extra=dict(analytic=v))
 
+    # -- BASELINE config C1 at its stated size: tridiag(-1,2,-1), n = 10,000, f = 2 dx^2, CG from 0 to an absolute
+    #    1e-16.  The reference needs 9388 iterations (its sequential dot_product loses the recurrence's
+    #    orthogonality later than n/2 = 5000, where exact arithmetic -- and a tree-order dot -- stops).
+    edges, f, v = P.diffusion_1d(10000)
+    case("diffusion1d_csr_10000", 10000, 10000, CSR, edges, P.test_vector(10000), f,
+         [(CG, NOPC, 1e-16)], extra=dict(analytic=v))
+
     # -- C2 mini: 5-point Poisson 32x24 (non-square on purpose) ------------------
     nx, ny = 32, 24
     n = nx * ny

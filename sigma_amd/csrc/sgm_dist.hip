@@ -158,6 +158,26 @@ int allreduce_slots(sgm_mat A, double *const *slot_ptrs, int count)
     return SGM_OK;
 }
 
+// ------------------------------------------------------------------ dot_order = 1 across ranks
+int seq_chain_recv(sgm_mat A, double *run)
+{
+    if (!A->comm || A->comm->nranks <= 1 || A->comm->rank == 0) return SGM_OK;
+    SGM_NCCL(g_nccl.Recv(run, 1, ncclFloat64, A->comm->rank - 1, (ncclComm_t)A->comm->nccl, g_rt.stream));
+    return SGM_OK;
+}
+int seq_chain_share(sgm_mat A, double *run)
+{
+    if (!A->comm || A->comm->nranks <= 1) return SGM_OK;
+    const int r = A->comm->rank, R = A->comm->nranks;
+    hipStream_t st = g_rt.stream;
+    if (r + 1 < R) {
+        SGM_NCCL(g_nccl.Send(run, 1, ncclFloat64, r + 1, (ncclComm_t)A->comm->nccl, st));
+        SGM_HIP(hipMemsetAsync(run, 0, sizeof(double), st));      // +0.0: total + 0.0 + ... is the total, bit for bit
+    }
+    SGM_NCCL(g_nccl.AllReduce(run, run, 1, ncclFloat64, ncclSum, (ncclComm_t)A->comm->nccl, st));
+    return SGM_OK;
+}
+
 // ------------------------------------------------------------------ host planning
 // Everything in this section is host-only index work (no HIP call): it is exported so that the
 // CPU test suite drives the SAME code the RCCL path runs (tests/test_dist_cpu.py, world_size-2

@@ -48,6 +48,10 @@ struct Options {
     int cg_small_chunk = 50000;    // its iterations per launch (the solve continues in the next launch from parked r, p)
     int slice_sched = 0;           // sliced kernels on matrices with a far stencil offset (3-D grids): band-ordered slice schedule per XCD
     int slice_sched_band = 64;     // its target band width in slices
+    int dot_order = 0;             // dot products of CG / BiCGStab: 0 = tree (per-workgroup partial sums), 1 = the reference's order
+                                   // (one accumulator, first element to last: what amdflang -O2 makes of dot_product) -- validation mode
+    int bicgstab_small = 1;        // BiCGStab (plain or Jacobi) on a CSR matrix of <= 4096 rows: the whole solve in one workgroup
+    int pipeline_spin_limit = 0;   // strip / slab triangular solves: polls before a wait gives up (0 = built-in limit; tests set 1 to force an abort)
 };
 extern Options g_opt;
 
@@ -202,6 +206,12 @@ int matvec_t_dist(sgm_mat A, const double *x, double *y, int where, bool add);
 int halo_exchange(sgm_mat A, double *const *xext, hipStream_t st);
 // sum `count` scalar slots across parts / ranks (in place, every part gets the total)
 int allreduce_slots(sgm_mat A, double *const *slot_ptrs, int count);
+
+// dot_order = 1 across ranks: one running sum (a device double) travels rank 0 -> 1 -> ... -> R-1, every rank continuing it over its
+// own rows in between; seq_chain_recv takes delivery from rank-1 (no-op on rank 0), seq_chain_share passes it on to rank+1
+// and leaves the total (what the last rank holds) in `run` on every rank.
+int seq_chain_recv(sgm_mat A, double *run);
+int seq_chain_share(sgm_mat A, double *run);
 
 // y = [y +] A x on every part; optional fused dots: partial sums of w[i]*y[i] (dot_w) and
 // y[i]*y[i] (dot_yy) per block into partials arrays (kMaxGrid doubles each).

@@ -115,6 +115,7 @@ int sgm_init(int device)
     g_rt.ready = true;
     if (const char *e = getenv("SGM_CSR_SLICED")) g_opt.csr_sliced = atoi(e);      // tuning aid (see sgm_set_option)
     if (const char *e = getenv("SGM_GMRES_CGS2")) g_opt.gmres_cgs2 = atoi(e);
+    if (const char *e = getenv("SGM_DOT_ORDER")) g_opt.dot_order = atoi(e) == 1 ? 1 : 0;
     if (const char *e = getenv("SGM_ILDU_STRIPS")) g_opt.ildu_strips = atoi(e);
     if (const char *e = getenv("SGM_SLICE_SCHED")) sscanf(e, "%d,%d", &g_opt.slice_sched, &g_opt.slice_sched_band);
     return SGM_OK;
@@ -169,6 +170,13 @@ int sgm_set_option(const char *name, int value)
     if (!strcmp(name, "slice_sched")) { g_opt.slice_sched = value; return SGM_OK; }
     if (!strcmp(name, "slice_sched_band")) { g_opt.slice_sched_band = std::max(8, value); return SGM_OK; }
     if (!strcmp(name, "gmres_cgs2")) { g_opt.gmres_cgs2 = value; return SGM_OK; }
+    if (!strcmp(name, "dot_order")) {
+        if (value != 0 && value != 1) return fail(SGM_ERR_BAD_ARG, "sgm_set_option: dot_order is 0 (tree) or 1 (the reference's sequential order)");
+        g_opt.dot_order = value;
+        return SGM_OK;
+    }
+    if (!strcmp(name, "bicgstab_small")) { g_opt.bicgstab_small = value; return SGM_OK; }
+    if (!strcmp(name, "pipeline_spin_limit")) { g_opt.pipeline_spin_limit = std::max(0, value); return SGM_OK; }
     return fail(SGM_ERR_BAD_ARG, "sgm_set_option: unknown option '%s'", name);
 }
 

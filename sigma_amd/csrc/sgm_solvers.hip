@@ -260,8 +260,96 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const double *part, int count
     if (threadIdx.x == 0) *slot = d;
 }
 
+// ---- dot_order = 1: the reference's dot_product order -----------------------------------------------------
+// The pinned reference build (amdflang -O2, x86-64 without FMA) turns `dot_product(a, b)` into ONE accumulator that
+// starts at +0.0 and takes the individually rounded products a(i) * b(i) first element to last
+// (cg_solvers.f90:131,135,140; bicgstab_solvers.f90:152,155,160,164,169).  The tree order above is a legal
+// dot_product too, but only this order makes the iterates bit-identical to the reference's.  The chain is serial by
+// nature -- one dependent fp64 add per element, about 4 ns each -- so this is a VALIDATION mode (n <~ 1e5), not a
+// production one: the products are formed in parallel and parked in LDS, one wave walks them in order.
+//
+// s + v[0] + v[1] + ... + v[cnt-1], left to right, out of LDS; every lane of the wave runs the same chain on the same
+// (broadcast) addresses.  The next 16 values are requested before the current 16 are added, so the chain never waits
+// for an LDS round trip.  `pr` must be 16-byte aligned.
+__device__ inline double seq_chain_lds(const double *pr, int32_t cnt, double s)
+{
+    int32_t j = 0;
+    if (cnt >= 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = pr[u];
+        for (; j + 32 <= cnt; j += 16) {
+            double w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = pr[j + 16 + u];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s = s + v[u];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = w[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s = s + v[u];
+        j += 16;
+    }
+    for (; j < cnt; ++j) s = s + pr[j];
+    return s;
+}
+
+struct SeqDot {
+    const double *a, *b;      // operands (this part's rows)
+    const double *init;       // running sum of the parts / ranks before this one (null: the sum starts here, at +0.0)
+    double *out;              // running sum after this part's rows
+};
+// ND (1 or 2) dot products at once, ONE workgroup: waves 2 and 3 stream the operands (16-byte coalesced loads), form the
+// products and park them in LDS, chunk c + 1 while chain wave d (wave 0, wave 1) walks chunk c of dot d.
+constexpr int kSeqChunk = 1024;
+template <int ND>
+__global__ __launch_bounds__(kBlock) void k_dot_seq(int64_t n, SeqDot d0, SeqDot d1, const int *flag, int gen)
+{
+    __shared__ __attribute__((aligned(16))) double buf[ND][2][kSeqChunk];
+    if (flag) { const int st = *flag; if (st && gen >= st) return; }
+    const int wave = threadIdx.x >> 6;
+    const int64_t nchunks = (n + kSeqChunk - 1) / kSeqChunk;
+    auto fill = [&](int64_t c) {               // waves 2, 3: 128 threads, 8 products per thread and dot
+        const int t = threadIdx.x - 128;
+        const int64_t base = c * kSeqChunk;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const double *a = d ? d1.a : d0.a, *b = d ? d1.b : d0.b;
+            double *dst = buf[d][c & 1];
+#pragma unroll
+            for (int u = 0; u < kSeqChunk / 256; ++u) {
+                const int64_t e = base + 2 * (t + 128 * u);
+                if (e + 1 < n) {
+                    const double2 x = ld2<false>(a, e >> 1), y = ld2<false>(b, e >> 1);
+                    dst[e - base] = x.x * y.x;
+                    dst[e - base + 1] = x.y * y.y;
+                } else if (e < n) {
+                    dst[e - base] = a[e] * b[e];
+                }
+            }
+        }
+    };
+    double s = 0.0;
+    if (wave < ND) { const SeqDot &d = wave ? d1 : d0; if (d.init) s = *d.init; }
+    if (wave >= 2 && nchunks > 0) fill(0);
+    __syncthreads();
+    for (int64_t c = 0; c < nchunks; ++c) {
+        if (wave >= 2) { if (c + 1 < nchunks) fill(c + 1); }
+        else if (wave < ND) s = seq_chain_lds(buf[wave][c & 1], (int32_t)(n - c * kSeqChunk < kSeqChunk ? n - c * kSeqChunk : kSeqChunk), s);
+        __syncthreads();
+    }
+    if (wave < ND && (threadIdx.x & 63) == 0) *(wave ? d1.out : d0.out) = s;
+}
+// the total (the last part's running sum) into another part's slot
+__global__ void k_copy_slot(const double *src, double *dst, const int *flag, int gen)
+{
+    if (flag) { const int st = *flag; if (st && gen >= st) return; }
+    if (threadIdx.x == 0) *dst = *src;
+}
+
 // ---- BiCGStab -------------------------------------------------------------------------
-struct BiScalars {          // dot results of the CURRENT (cur) and PREVIOUS (old) iteration
+struct BiScalars {         // dot results of the CURRENT (cur) and PREVIOUS (old) iteration
     ScalarRef rr, rho, rho_old, r0v_old, st_old, tt_old, r0v, st, tt;
     int first;              // iteration 1: rho_old = alpha = omega = 1 (bicgstab_solvers.f90:144-147)
     int nan_guard;          // plain variant only (:165)
@@ -819,6 +907,7 @@ struct sgm_solver_s {
     int64_t last_iterations = 0;
     double res2 = 0.0;
     int32_t converged = 0;
+    bool seq = false;                // this solve runs with dot_order = 1 (set by sgm_solver_solve from the option)
     std::vector<PartWork> work;
     std::vector<double> history;
     bool multi = false;
@@ -842,14 +931,55 @@ void free_work(sgm_solver s)
 ScalarRef ref(sgm_solver s, size_t ip, int k)
 {
     PartWork &w = s->work[ip];
-    if (s->multi) return ScalarRef{w.slots + k, 1};
+    if (s->multi || s->seq) return ScalarRef{w.slots + k, 1};
     return ScalarRef{w.partials + (size_t)k * kMaxGrid, w.count[k]};
 }
 double *part(sgm_solver s, size_t ip, int k) { return s->work[ip].partials + (size_t)k * kMaxGrid; }
 
 // after the producers of partial arrays ks[] ran on every part: make the totals visible
-int finish_dots(sgm_solver s, sgm_mat A, const int *ks, int nk)
+// dot_order = 1: `vecs[t]` names the two work vectors dot ks[t] is taken over; the partial sums the producers left are
+// ignored and the products are formed again, in order (k_dot_seq).  Across in-process parts the running sum is handed
+// from one part's kernel to the next one's; across ranks it travels rank 0 -> 1 -> ... (seq_chain_recv / _share), so a
+// partitioned solve adds the same products in the same global order as the one-part solve.
+int finish_dots(sgm_solver s, sgm_mat A, const int *ks, int nk, const int (*vecs)[2] = nullptr, bool use_flag = false,
+                int gen = INT32_MAX)
 {
+    if (s->seq) {
+        if (!vecs) return fail(SGM_ERR_UNSUPPORTED, "dot_order = 1: this dot product has no sequential form");
+        const size_t P = s->work.size();
+        const bool ranks = A->comm && A->comm->nranks > 1;
+        for (int t = 0; t < nk;) {
+            const int nd = (!ranks && t + 1 < nk) ? 2 : 1;
+            if (ranks) SGM_TRY(seq_chain_recv(A, s->work[0].slots + ks[t]));
+            for (size_t ip = 0; ip < P; ++ip) {
+                PartWork &w = s->work[ip];
+                SeqDot d[2];
+                for (int u = 0; u < nd; ++u) {
+                    const int k = ks[t + u];
+                    d[u].a = w.vec[vecs[t + u][0]];
+                    d[u].b = w.vec[vecs[t + u][1]];
+                    d[u].init = ip ? s->work[ip - 1].slots + k : (ranks && A->comm->rank > 0 ? w.slots + k : nullptr);
+                    d[u].out = w.slots + k;
+                }
+                if (nd == 1) {
+                    d[1] = d[0];
+                    hipLaunchKernelGGL((k_dot_seq<1>), dim3(1), dim3(kBlock), 0, g_rt.stream, w.n, d[0], d[1],
+                                       use_flag ? (const int *)w.flag : nullptr, gen);
+                } else {
+                    hipLaunchKernelGGL((k_dot_seq<2>), dim3(1), dim3(kBlock), 0, g_rt.stream, w.n, d[0], d[1],
+                                       use_flag ? (const int *)w.flag : nullptr, gen);
+                }
+            }
+            for (size_t ip = 0; ip + 1 < P; ++ip)
+                for (int u = 0; u < nd; ++u)
+                    hipLaunchKernelGGL(k_copy_slot, dim3(1), dim3(64), 0, g_rt.stream,
+                                       (const double *)(s->work[P - 1].slots + ks[t + u]), s->work[ip].slots + ks[t + u],
+                                       use_flag ? (const int *)s->work[ip].flag : nullptr, gen);
+            if (ranks) SGM_TRY(seq_chain_share(A, s->work[0].slots + ks[t]));
+            t += nd;
+        }
+        return SGM_OK;
+    }
     if (!s->multi) return SGM_OK;
     // slots ks[] must be contiguous for the all-reduce: callers pass consecutive ids
     for (size_t ip = 0; ip < s->work.size(); ++ip)
@@ -946,6 +1076,58 @@ __device__ inline void small_row_sums(double (&q)[RMAX], const double *pl, int32
     for (int u = 0; u < RMAX; ++u) q[u] = 0.0 + q[u];          // A%matvec: y = 0 ; y(i) = y(i) + z
 }
 
+// A dot product inside a single-workgroup solver: thread t holds the products of its rows t, t + BLOCK, ... (0.0 beyond n).
+// Tree order (dot_order = 0): the thread's own rows first, then the block sum.  SEQ (dot_order = 1): the products are
+// parked in LDS by row and ONE wave adds them row 0 to row n-1 -- the reference's dot_product order.
+template <int BLOCK, int RMAX, bool SEQ>
+__device__ inline double small_dot(const double (&prod)[RMAX], int32_t n, double *pr, double *red)
+{
+    if (!SEQ) {
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u)
+            if ((int32_t)threadIdx.x + u * BLOCK < n) s += prod[u];
+        return block_sum<BLOCK>(s, red);
+    }
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+        const int32_t i = threadIdx.x + u * BLOCK;
+        if (i < n) pr[i] = prod[u];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const double s = seq_chain_lds(pr, n, 0.0);
+        if (threadIdx.x == 0) red[0] = s;
+    }
+    __syncthreads();
+    return red[0];
+}
+// two at once (BiCGStab's s.t / t.t and r.r / r0.r): SEQ walks them side by side, waves 0 and 1
+template <int BLOCK, int RMAX, bool SEQ>
+__device__ inline void small_dot2(const double (&prod0)[RMAX], const double (&prod1)[RMAX], int32_t n, double *pr0, double *pr1,
+                                  double *red, double &out0, double &out1)
+{
+    if (!SEQ) {
+        out0 = small_dot<BLOCK, RMAX, false>(prod0, n, pr0, red);
+        out1 = small_dot<BLOCK, RMAX, false>(prod1, n, pr1, red);
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+        const int32_t i = threadIdx.x + u * BLOCK;
+        if (i < n) { pr0[i] = prod0[u]; pr1[i] = prod1[u]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int w = threadIdx.x >> 6;
+        const double s = seq_chain_lds(w ? pr1 : pr0, n, 0.0);
+        if ((threadIdx.x & 63) == 0) red[w] = s;
+    }
+    __syncthreads();
+    out0 = red[0];
+    out1 = red[1];
+}
+
 // ---- CG on a small system: the whole solve in ONE workgroup -----------------------------------------
 // Below n ~ 1e5 an iteration of the loop above IS its three launches (about 15 us whatever n is).  A system of up to
 // 10240 rows fits one workgroup: p lives in LDS (what the row sums gather from), x and r (and 1 / diag for Jacobi) in the
@@ -958,16 +1140,20 @@ __device__ inline void small_row_sums(double (&q)[RMAX], const double *pl, int32
 // row: sgm_spmv.hip, k_csr_sl) -- coalesced for rows t, t + 1024, ...; `rowptr` then carries the code words, `col` the
 // offset dictionary, `sw` the slots per row.  Otherwise plain CSR arrays (every lane its own row: one CU's address
 // pipe limits that to about 4096 rows).
-template <int RMAX, bool JAC, bool SL>
+// SEQ (dot_order = 1): both dot products in the reference's order -- the products parked in LDS, one wave adds them first
+// row to last (small_dot) -- which makes the whole solve bit-identical to cg_solve / cg_solve_pc.
+// (x and b carry no __restrict__: sgm_solver_solve hands caller pointers through, and they may alias.)
+template <int RMAX, bool JAC, bool SL, bool SEQ>
 __global__ __launch_bounds__(1024) void k_cg_small(
     int32_t n, int32_t sw, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val,
-    double *__restrict__ x, const double *__restrict__ b, const double *__restrict__ idiag, double tol, int64_t it_end,
+    double *x, const double *b, const double *__restrict__ idiag, double tol, int64_t it_end,
     int resume, double *__restrict__ wr, double *__restrict__ wp,
     int *flag, int64_t *iters, double *res_out, double *history, int64_t hist_cap)
 {
     constexpr int BLOCK = 1024;
-    extern __shared__ double pl[];             // p (n entries), then the block-sum scratch
+    extern __shared__ double pl[];             // p (n entries), the block-sum scratch, then (SEQ) the parked products
     double *red = pl + ((n + 1) & ~1);
+    double *pr = red + 16;
     const int tid = threadIdx.x;
     double xr[RMAX], rr[RMAX];             // (row pointers and 1 / diag are re-read where needed: L1 / L2 hits, not registers)
 #pragma unroll
@@ -978,7 +1164,8 @@ __global__ __launch_bounds__(1024) void k_cg_small(
     }
     __syncthreads();
     auto row_sums = [&](double (&q)[RMAX]) { small_row_sums<RMAX, SL>(q, pl, n, sw, rowptr, col, val); };
-    double s = 0.0, res2;
+    double res2;
+    double prod[RMAX];
     int64_t it = 0;
     if (!resume) {
         // r = b - A x ; z = M^-1 r ; p = z ; res2 = r.z
@@ -989,13 +1176,14 @@ __global__ __launch_bounds__(1024) void k_cg_small(
             const int32_t i = tid + u * BLOCK;
             const double q = zr[u];
             zr[u] = 0.0;
+            prod[u] = 0.0;
             if (i < n) {
                 rr[u] = b[i] - q;
                 zr[u] = JAC ? idiag[i] * rr[u] : rr[u];
-                s += rr[u] * zr[u];
+                prod[u] = rr[u] * zr[u];
             }
         }
-        res2 = block_sum<BLOCK>(s, red);      // (its barriers: every row sum has read x out of LDS)
+        res2 = small_dot<BLOCK, RMAX, SEQ>(prod, n, pr, red);      // (its barriers: every row sum has read x out of LDS)
 #pragma unroll
         for (int u = 0; u < RMAX; ++u) {
             const int32_t i = tid + u * BLOCK;
@@ -1016,25 +1204,24 @@ __global__ __launch_bounds__(1024) void k_cg_small(
     while (!conv && it < it_end) {
         double qv[RMAX];
         row_sums(qv);
-        s = 0.0;
 #pragma unroll
         for (int u = 0; u < RMAX; ++u) {
             const int32_t i = tid + u * BLOCK;
-            if (i < n) s += pl[i] * qv[u];
+            prod[u] = i < n ? pl[i] * qv[u] : 0.0;
         }
-        const double dpr = block_sum<BLOCK>(s, red);
+        const double dpr = small_dot<BLOCK, RMAX, SEQ>(prod, n, pr, red);
         const double alpha = res2 / dpr;
-        s = 0.0;
 #pragma unroll
         for (int u = 0; u < RMAX; ++u) {
             const int32_t i = tid + u * BLOCK;
+            prod[u] = 0.0;
             if (i < n) {
                 rr[u] = rr[u] - alpha * qv[u];
                 const double zv = JAC ? idiag[i] * rr[u] : rr[u];
-                s += rr[u] * zv;
+                prod[u] = rr[u] * zv;
             }
         }
-        const double dnew = block_sum<BLOCK>(s, red);    // (its barriers: every row sum of this iteration has read p)
+        const double dnew = small_dot<BLOCK, RMAX, SEQ>(prod, n, pr, red);    // (its barriers: every row sum of this iteration has read p)
         const double beta = dnew / res2;
 #pragma unroll
         for (int u = 0; u < RMAX; ++u) {
@@ -1065,54 +1252,80 @@ __global__ __launch_bounds__(1024) void k_cg_small(
 
 constexpr int kCgSmallMax = 10240;          // 10 rows per thread (sliced matrices): x, r, q in registers (16 rows: 53-168 spilled)
 constexpr int kCgSmallMaxCsr = 4096;        // plain CSR arrays: 4 rows per thread (10 rows, n = 1e4: 19 us per iteration, one CU's address pipe)
+constexpr int kCgSmallMaxSeq = 10200;       // dot_order = 1: p AND the parked products live in LDS (2 x 10200 doubles + scratch <= 160 KiB)
+constexpr int kBiSmallMax = 4096;           // BiCGStab: seven vectors in registers, 4 rows per thread
 // (a structured ELLPACK matrix with max_d <= 8 keeps the same sliced form, every slot an entry: its padding slots'
 // 0.0 * x(last neighbour) terms are added like the reference's ellpack_matvec_add does)
 static bool cg_small_sliced(const Part &p)
 {
     return p.scode && p.sval && p.dict && g_opt.csr_sliced && (p.ecol ? g_opt.ell_offset_dict : g_opt.csr_offset_dict) && p.sw <= 8;
 }
-static bool cg_small_applies(sgm_solver s, sgm_mat A, sgm_pc pc)
+static bool small_applies(sgm_solver s, sgm_mat A, sgm_pc pc, bool bicg)
 {
-    if (!g_opt.cg_small || s->multi || A->parts.size() != 1 || (A->fmt != SGM_FMT_CSR && A->fmt != SGM_FMT_ELL)) return false;
+    if (!(bicg ? g_opt.bicgstab_small : g_opt.cg_small) || s->multi || A->parts.size() != 1 ||
+        (A->fmt != SGM_FMT_CSR && A->fmt != SGM_FMT_ELL))
+        return false;
     const Part &p = A->parts[0];
     if (p.n < 1 || p.n_halo != 0) return false;
     if (!cg_small_sliced(p) && (A->fmt != SGM_FMT_CSR || !p.rowptr || !p.col || !p.val)) return false;
-    if (p.n > (cg_small_sliced(p) ? kCgSmallMax : kCgSmallMaxCsr)) return false;
+    int32_t nmax = cg_small_sliced(p) ? kCgSmallMax : kCgSmallMaxCsr;
+    if (s->seq) nmax = std::min(nmax, kCgSmallMaxSeq);
+    if (bicg) nmax = std::min(nmax, kBiSmallMax);
+    if (p.n > nmax) return false;
     // one CU takes about 2.5 us + 0.22 us per 1000 stored slots per iteration (5-point 80^2: 11.3 us, 100^2: 14.9; tridiagonal
     // n = 1e4: 11.0; 7-point 20^3: 16.2); the launch loop 14.3-14.7 whatever the size: beyond ~49k slots the loop it is
+    // (BiCGStab: two products per iteration against five launches -- the same break-even)
     if ((cg_small_sliced(p) ? (int64_t)p.n * p.sw : p.nnz) > 49152) return false;
     const int pk = pc ? pc_kind(pc) : 0;
     return pk == 0 || pk == SGM_PC_JACOBI;
 }
-static int run_cg_small(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc pc)
+// more than 64 KiB of dynamic LDS needs the attribute, once per kernel; false = the runtime refused (the caller takes the
+// launch loop instead)
+static bool allow_lds(const void *fn, size_t bytes)
+{
+    static std::vector<std::pair<const void *, size_t>> done;
+    for (auto &d : done)
+        if (d.first == fn && d.second >= bytes) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    done.emplace_back(fn, bytes);
+    return true;
+}
+// returns SGM_OK with *ran = false when the kernel cannot be launched here (LDS request refused)
+static int run_cg_small(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc pc, bool *ran)
 {
     const Part &p = A->parts[0];
     PartWork &w = s->work[0];
     const bool jac = pc && pc_kind(pc) == SGM_PC_JACOBI;
     const bool sliced = cg_small_sliced(p);
-    const size_t lds = ((size_t)((p.n + 1) & ~1) + 16) * sizeof(double);
+    const size_t npad = (size_t)((p.n + 1) & ~1);
+    const size_t lds = ((s->seq ? 2 : 1) * npad + 16) * sizeof(double);
     // the reference's loop has no iteration cap; a launch has one (kCgSmallChunk iterations), after which the solve
     // continues in the next launch from r, p and res2 parked in the solver's work vectors -- the host stays in control
     const int64_t kCgSmallChunk = std::max(1, g_opt.cg_small_chunk);
     int flag = 0; int64_t iters = 0; double res = 0.0;
+    *ran = true;
     for (int resume = 0;; resume = 1) {
         int64_t it_end = iters + kCgSmallChunk;
         if (s->max_iter > 0) it_end = std::min<int64_t>(it_end, s->max_iter);
-#define LS(R, J, S)                                                                                                  \
+#define LS(R, J, S, Q)                                                                                               \
     do {                                                                                                             \
-        static bool attr = false;                                                                                    \
-        if (!attr) { SGM_HIP(hipFuncSetAttribute((const void *)k_cg_small<R, J, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (kCgSmallMax + 16) * 8)); attr = true; } \
-        hipLaunchKernelGGL((k_cg_small<R, J, S>), dim3(1), dim3(1024), lds, g_rt.stream, p.n, p.sw,                   \
+        if (!allow_lds((const void *)k_cg_small<R, J, S, Q>, lds)) { *ran = false; return SGM_OK; }                   \
+        hipLaunchKernelGGL((k_cg_small<R, J, S, Q>), dim3(1), dim3(1024), lds, g_rt.stream, p.n, p.sw,                \
                            S ? reinterpret_cast<const int32_t *>(p.scode) : (const int32_t *)p.rowptr,                \
                            S ? (const int32_t *)p.dict : (const int32_t *)p.col, S ? (const double *)p.sval : (const double *)p.val, \
                            x, b, jac ? pc_idiag(pc, 0) : nullptr,                                                     \
                            s->tolerance, it_end, resume, w.vec[V_R], w.vec[V_P], w.flag, w.iters, w.res, w.history,   \
                            s->hist_cap);                                                                              \
     } while (0)
+#define LSQ(R, J, S) do { if (s->seq) LS(R, J, S, true); else LS(R, J, S, false); } while (0)
         if (sliced) {
-            if (p.n <= 4096) { if (jac) LS(4, true, true); else LS(4, false, true); }
-            else { if (jac) LS(10, true, true); else LS(10, false, true); }
-        } else { if (jac) LS(4, true, false); else LS(4, false, false); }
+            if (p.n <= 4096) { if (jac) LSQ(4, true, true); else LSQ(4, false, true); }
+            else { if (jac) LSQ(10, true, true); else LSQ(10, false, true); }
+        } else { if (jac) LSQ(4, true, false); else LSQ(4, false, false); }
+#undef LSQ
 #undef LS
         SGM_HIP(hipGetLastError());
         SGM_TRY(read_state(s, &flag, &iters, &res));
@@ -1126,7 +1339,11 @@ static int run_cg_small(sgm_solver s, sgm_mat A, double *x, const double *b, sgm
 
 int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sgm_pc pc)
 {
-    if (cg_small_applies(s, A, pc)) return run_cg_small(s, A, x[0], b[0], pc);
+    if (small_applies(s, A, pc, false)) {
+        bool ran = false;
+        SGM_TRY(run_cg_small(s, A, x[0], b[0], pc, &ran));
+        if (ran) return SGM_OK;
+    }
     const size_t P = s->work.size();
     const int pk = pc ? pc_kind(pc) : 0;
     Views v;
@@ -1159,7 +1376,8 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
             launch_elem(n, FCopyDot{W(ip, V_P), W(ip, V_Z), W(ip, V_R), part(s, ip, C_RR0)}, nullptr);
         }
     }
-    { const int ks[1] = {C_RR0}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+    const int vz[1][2] = {{V_R, pk == 0 ? V_R : V_Z}}, vpq[1][2] = {{V_P, V_Q}};     // operands of r.r / r.z and p.q
+    { const int ks[1] = {C_RR0}; SGM_TRY(finish_dots(s, A, ks, 1, vz)); }
     for (size_t ip = 0; ip < P; ++ip)
         hipLaunchKernelGGL(k_check, dim3(1), dim3(kBlock), 0, g_rt.stream, ref(s, ip, C_RR0), s->tolerance,
                            s->work[ip].flag, s->work[ip].res);
@@ -1185,8 +1403,8 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
             SGM_TRY(spmv_parts(A, v.cx.data(), v.y.data(), false, &dots, s->work[0].flag, &grid,
                                (int)std::min<int64_t>(k + 1, INT32_MAX - 2)));
             for (size_t ip = 0; ip < P; ++ip) s->work[ip].count[C_PQ] = spmv_grid(A->parts[ip]);
-            { const int ks[1] = {C_PQ}; SGM_TRY(finish_dots(s, A, ks, 1)); }
             const int gen = (int)std::min<int64_t>(k + 1, INT32_MAX - 2);
+            { const int ks[1] = {C_PQ}; SGM_TRY(finish_dots(s, A, ks, 1, vpq, true, gen)); }
             for (size_t ip = 0; ip < P; ++ip) {
                 PartWork &w = s->work[ip];
                 w.count[nxt] = dot_grid(w.n);
@@ -1209,7 +1427,7 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
                     launch_elem(w.n, FDot2{W(ip, V_R), W(ip, V_Z), nullptr, nullptr, part(s, ip, nxt), nullptr}, w.flag, gen);
                 }
             }
-            { const int ks[1] = {nxt}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+            { const int ks[1] = {nxt}; SGM_TRY(finish_dots(s, A, ks, 1, vz, true, gen)); }
             for (size_t ip = 0; ip < P; ++ip) {
                 PartWork &w = s->work[ip];
                 launch_elem(w.n, FCgPX{ref(s, ip, cur), ref(s, ip, C_PQ), ref(s, ip, nxt), pk == 0 ? W(ip, V_R) : W(ip, V_Z),
@@ -1232,8 +1450,184 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
 enum { B_RR = 0, B_RHO = 2, B_R0V = 4, B_ST = 6, B_TT = 8 };     // +parity
 enum { W_P = 0, W_Q = 1, W_R = 2, W_R0 = 3, W_V = 4, W_S = 5, W_T = 6, W_Z = 7 };
 
+// ---- BiCGStab on a small system: the whole solve in ONE workgroup ---------------------------------------
+// The single-workgroup twin of the launch loop below for the reference's own test sizes
+// (test/solver_test_advection_diffusion_1d.f90:58-122, n = 1024): the vector a product gathers from (p, then s) lives
+// in LDS, x, r, r0, p, v, s and t in the registers of the row's thread (rows t, t + 1024, ...).  Statements and operands
+// are bicgstab_solve's / bicgstab_solve_pc's (bicgstab_solvers.f90:140-173, :199-233, jacobi_solve folded in):
+// beta = rho / rho_old * alpha / omega, p = r + beta * (p - omega * v), alpha = rho / (r0 . v), s = r - alpha * v,
+// omega = (s . t) / (t . t) with the NaN guard of the plain variant, x = x + alpha * p + omega * s, r = s - omega * t.
+// With SEQ every dot product adds its products first row to last -- the solve is then bit-identical to the
+// reference's; in tree order the iteration count may differ by a few (BiCGStab's residual is not monotone).
+template <int RMAX, bool JAC, bool SL, bool SEQ>
+__global__ __launch_bounds__(1024) void k_bicgstab_small(
+    int32_t n, int32_t sw, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val,
+    double *x, const double *b, const double *__restrict__ idiag, double tol, int64_t it_end, int resume,
+    double *__restrict__ wr, double *__restrict__ wr0, double *__restrict__ wp, double *__restrict__ wv,
+    double *__restrict__ scal /* alpha, omega, rho_old, rho across launches */,
+    int *flag, int64_t *iters, double *res_out, double *history, int64_t hist_cap)
+{
+    constexpr int BLOCK = 1024;
+    extern __shared__ double pl[];             // the vector being multiplied (n entries), scratch, then (SEQ) two product arrays
+    const int32_t npad = (n + 1) & ~1;
+    double *red = pl + npad, *pr0 = red + 16, *pr1 = pr0 + npad;
+    const int tid = threadIdx.x;
+    double xr[RMAX], rr[RMAX], r0[RMAX], pp[RMAX], vv[RMAX], prod0[RMAX], prod1[RMAX];
+    auto row_sums = [&](double (&q)[RMAX]) { small_row_sums<RMAX, SL>(q, pl, n, sw, rowptr, col, val); };
+    double alpha = 1.0, omega = 1.0, rho_old = 1.0, rho = 1.0, res2;       // bicgstab_solvers.f90:144-147
+    int64_t it = 0;
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+        const int32_t i = tid + u * BLOCK;
+        xr[u] = 0.0; rr[u] = 0.0; r0[u] = 0.0; pp[u] = 0.0; vv[u] = 0.0;
+        if (i < n) { xr[u] = x[i]; pl[i] = xr[u]; }
+    }
+    __syncthreads();
+    if (!resume) {
+        // r0 = [M^-1] (b - A x) ; r = r0 ; v = p = 0 ; res2 = r.r ; (rho of the first iteration = r0.r: the same products)
+        double q[RMAX];
+        row_sums(q);
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = tid + u * BLOCK;
+            prod0[u] = 0.0;
+            if (i < n) {
+                const double w = b[i] - q[u];
+                r0[u] = JAC ? idiag[i] * w : w;
+                rr[u] = r0[u];
+                prod0[u] = rr[u] * rr[u];
+            }
+        }
+        res2 = small_dot<BLOCK, RMAX, SEQ>(prod0, n, pr0, red);
+        rho = res2;
+    } else {
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = tid + u * BLOCK;
+            if (i < n) { rr[u] = wr[i]; r0[u] = wr0[i]; pp[u] = wp[i]; vv[u] = wv[i]; }
+        }
+        alpha = scal[0]; omega = scal[1]; rho_old = scal[2]; rho = scal[3];
+        res2 = *res_out;
+        it = *iters;
+    }
+    bool conv = !(sqrt(res2) > tol);
+    while (!conv && it < it_end) {
+        const double beta = rho / rho_old * alpha / omega;
+        __syncthreads();                       // every row sum of the previous product has read pl
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = tid + u * BLOCK;
+            if (i < n) { pp[u] = rr[u] + beta * (pp[u] - omega * vv[u]); pl[i] = pp[u]; }
+        }
+        __syncthreads();
+        double q[RMAX], ss[RMAX];
+        row_sums(q);                           // v = [M^-1] A p
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = tid + u * BLOCK;
+            prod0[u] = 0.0;
+            if (i < n) { vv[u] = JAC ? idiag[i] * q[u] : q[u]; prod0[u] = r0[u] * vv[u]; }
+        }
+        const double r0v = small_dot<BLOCK, RMAX, SEQ>(prod0, n, pr0, red);      // (its barriers: the product has read p)
+        alpha = rho / r0v;
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = tid + u * BLOCK;
+            ss[u] = 0.0;
+            if (i < n) { ss[u] = rr[u] - alpha * vv[u]; pl[i] = ss[u]; }
+        }
+        __syncthreads();
+        row_sums(q);                           // t = [M^-1] A s
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = tid + u * BLOCK;
+            prod0[u] = 0.0; prod1[u] = 0.0;
+            if (i < n) {
+                if (JAC) q[u] = idiag[i] * q[u];
+                prod0[u] = ss[u] * q[u];
+                prod1[u] = q[u] * q[u];
+            }
+        }
+        double st, tt;
+        small_dot2<BLOCK, RMAX, SEQ>(prod0, prod1, n, pr0, pr1, red, st, tt);
+        omega = st / tt;
+        if (!JAC && isnan(omega)) omega = 0.0;                                   // bicgstab_solvers.f90:165 (plain variant only)
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = tid + u * BLOCK;
+            prod0[u] = 0.0; prod1[u] = 0.0;
+            if (i < n) {
+                xr[u] = xr[u] + alpha * pp[u] + omega * ss[u];
+                rr[u] = ss[u] - omega * q[u];
+                prod0[u] = rr[u] * rr[u];
+                prod1[u] = r0[u] * rr[u];
+            }
+        }
+        rho_old = rho;
+        small_dot2<BLOCK, RMAX, SEQ>(prod0, prod1, n, pr0, pr1, red, res2, rho);  // res2 = r.r ; rho of the next iteration = r0.r
+        if (tid == 0 && history && it < hist_cap) history[it] = res2;
+        ++it;
+        conv = !(sqrt(res2) > tol);
+    }
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+        const int32_t i = tid + u * BLOCK;
+        if (i < n) {
+            x[i] = xr[u];
+            if (!conv) { wr[i] = rr[u]; wr0[i] = r0[u]; wp[i] = pp[u]; wv[i] = vv[u]; }
+        }
+    }
+    if (tid == 0) {
+        scal[0] = alpha; scal[1] = omega; scal[2] = rho_old; scal[3] = rho;
+        *iters = it; *res_out = res2; *flag = conv ? 1 : 0;
+    }
+}
+
+static int run_bicgstab_small(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc pc, bool *ran)
+{
+    const Part &p = A->parts[0];
+    PartWork &w = s->work[0];
+    const bool jac = pc && pc_kind(pc) == SGM_PC_JACOBI;
+    const bool sliced = cg_small_sliced(p);
+    const size_t npad = (size_t)((p.n + 1) & ~1);
+    const size_t lds = ((s->seq ? 3 : 1) * npad + 16) * sizeof(double);
+    const int64_t chunk = std::max(1, g_opt.cg_small_chunk);
+    int flag = 0; int64_t iters = 0; double res = 0.0;
+    *ran = true;
+    for (int resume = 0;; resume = 1) {
+        int64_t it_end = iters + chunk;
+        if (s->max_iter > 0) it_end = std::min<int64_t>(it_end, s->max_iter);
+#define LS(J, S, Q)                                                                                                  \
+    do {                                                                                                             \
+        if (!allow_lds((const void *)k_bicgstab_small<4, J, S, Q>, lds)) { *ran = false; return SGM_OK; }             \
+        hipLaunchKernelGGL((k_bicgstab_small<4, J, S, Q>), dim3(1), dim3(1024), lds, g_rt.stream, p.n, p.sw,          \
+                           S ? reinterpret_cast<const int32_t *>(p.scode) : (const int32_t *)p.rowptr,                \
+                           S ? (const int32_t *)p.dict : (const int32_t *)p.col, S ? (const double *)p.sval : (const double *)p.val, \
+                           x, b, jac ? pc_idiag(pc, 0) : nullptr, s->tolerance, it_end, resume, w.vec[W_R], w.vec[W_R0], \
+                           w.vec[W_P], w.vec[W_V], w.slots, w.flag, w.iters, w.res, w.history, s->hist_cap);          \
+    } while (0)
+#define LSQ(J, S) do { if (s->seq) LS(J, S, true); else LS(J, S, false); } while (0)
+        if (sliced) { if (jac) LSQ(true, true); else LSQ(false, true); }
+        else { if (jac) LSQ(true, false); else LSQ(false, false); }
+#undef LSQ
+#undef LS
+        SGM_HIP(hipGetLastError());
+        SGM_TRY(read_state(s, &flag, &iters, &res));
+        if (flag || (s->max_iter > 0 && iters >= s->max_iter)) break;
+    }
+    s->last_iterations = iters;
+    s->res2 = res;
+    s->converged = flag;
+    return SGM_OK;
+}
+
 int run_bicgstab(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sgm_pc pc)
 {
+    if (small_applies(s, A, pc, true)) {
+        bool ran = false;
+        SGM_TRY(run_bicgstab_small(s, A, x[0], b[0], pc, &ran));
+        if (ran) return SGM_OK;
+    }
     const size_t P = s->work.size();
     const int pk = pc ? pc_kind(pc) : 0;
     Views v;
@@ -1261,7 +1655,9 @@ int run_bicgstab(sgm_solver s, sgm_mat A, double *const *x, const double *const 
         launch_elem(n, FBiInit{pk ? W(ip, W_R0) : b[ip], W(ip, W_Q), pk == 0, W(ip, W_R0), W(ip, W_R), W(ip, W_V),
                                W(ip, W_P), part(s, ip, B_RR), part(s, ip, B_RHO)}, nullptr);
     }
-    { const int ks[3] = {B_RR, B_RR + 1, B_RHO}; SGM_TRY(finish_dots(s, A, ks, 3)); }
+    const int v_rr_rho[2][2] = {{W_R, W_R}, {W_R0, W_R}}, v_r0v[1][2] = {{W_R0, W_V}}, v_st_tt[2][2] = {{W_S, W_T}, {W_T, W_T}};
+    if (s->seq) { const int ks[2] = {B_RR, B_RHO}; SGM_TRY(finish_dots(s, A, ks, 2, v_rr_rho)); }
+    else { const int ks[3] = {B_RR, B_RR + 1, B_RHO}; SGM_TRY(finish_dots(s, A, ks, 3)); }
 
     int64_t k = 0;
     int flag = 0; int64_t iters = 0; double res = 0.0;
@@ -1306,7 +1702,7 @@ int run_bicgstab(sgm_solver s, sgm_mat A, double *const *x, const double *const 
                                 w.flag);
                 }
             }
-            { const int ks[1] = {B_R0V + c}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+            { const int ks[1] = {B_R0V + c}; SGM_TRY(finish_dots(s, A, ks, 1, v_r0v, true)); }
             for (size_t ip = 0; ip < P; ++ip) {
                 PartWork &w = s->work[ip];
                 launch_elem(w.n, FBiS{ref(s, ip, B_RHO + c), ref(s, ip, B_R0V + c), W(ip, W_R), W(ip, W_V), W(ip, W_S)},
@@ -1332,8 +1728,11 @@ int run_bicgstab(sgm_solver s, sgm_mat A, double *const *x, const double *const 
                 }
             }
             // ST/TT ids are not adjacent for one parity: two calls keep slots contiguous
-            { const int ks[1] = {B_ST + c}; SGM_TRY(finish_dots(s, A, ks, 1)); }
-            { const int ks[1] = {B_TT + c}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+            if (s->seq) { const int ks[2] = {B_ST + c, B_TT + c}; SGM_TRY(finish_dots(s, A, ks, 2, v_st_tt, true)); }
+            else {
+                { const int ks[1] = {B_ST + c}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+                { const int ks[1] = {B_TT + c}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+            }
             for (size_t ip = 0; ip < P; ++ip) {
                 PartWork &w = s->work[ip];
                 w.count[B_RR + o] = w.count[B_RHO + o] = dot_grid(w.n);
@@ -1341,8 +1740,11 @@ int run_bicgstab(sgm_solver s, sgm_mat A, double *const *x, const double *const 
                                        ref(s, ip, B_TT + c), pk == 0, W(ip, W_P), W(ip, W_S), W(ip, W_T), W(ip, W_R0),
                                        x[ip], W(ip, W_R), part(s, ip, B_RR + o), part(s, ip, B_RHO + o)}, w.flag);
             }
-            { const int ks[1] = {B_RR + o}; SGM_TRY(finish_dots(s, A, ks, 1)); }
-            { const int ks[1] = {B_RHO + o}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+            if (s->seq) { const int ks[2] = {B_RR + o, B_RHO + o}; SGM_TRY(finish_dots(s, A, ks, 2, v_rr_rho, true)); }
+            else {
+                { const int ks[1] = {B_RR + o}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+                { const int ks[1] = {B_RHO + o}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+            }
         }
         // the loop test of the NEXT iteration decides whether we are done (k_check only ever
         // sets the flag, so an earlier in-batch stop is kept)
@@ -1624,6 +2026,9 @@ int sgm_solver_solve(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc
         }
         if (w.history) SGM_HIP(hipMemsetAsync(w.history, 0, (size_t)s->hist_cap * 8, g_rt.stream));
     }
+    // dot_order = 1: CG / BiCGStab add their dot products in the reference's order (GMRES has no reference counterpart
+    // and keeps the tree order)
+    s->seq = g_opt.dot_order == 1 && s->kind != SGM_SOLVER_GMRES;
     int rc;
     if (s->kind == SGM_SOLVER_CG) rc = run_cg(s, A, xs.data(), bs.data(), pc);
     else if (s->kind == SGM_SOLVER_BICGSTAB) rc = run_bicgstab(s, A, xs.data(), bs.data(), pc);

@@ -197,6 +197,33 @@ def run(rank, world, port, case, res):
         else:
             check("bicgstab_jacobi", sg.bicgstab(1e-12), sg.jacobi, orc.bicgstab(A, b, tol=1e-12, pc=orc.Jacobi(A)),
                   lambda i: max(2, 0.1 * i), 1e-10)
+        # ---- dot_order = 1: the running sum of every dot travels rank 0 -> 1 -> ... and each rank continues it over its
+        #      own rows: the distributed iterates are BIT-IDENTICAL to the serial ones (the oracle's left-to-right dots)
+        sg.set_option("dot_order", 1)
+        try:
+            def exact(name, solver, pc_mk, ref):
+                ur, itr = ref[0], ref[1]
+                solver.setup(H)
+                pc = pc_mk() if pc_mk else None
+                if pc is not None:
+                    pc.setup(H)
+                u = np.zeros(n_own)
+                solver.solve(H, u, bl, pc)
+                out[name] = {"iterations": int(solver.iterations), "oracle_iterations": int(itr),
+                             "bit_identical": bool(np.array_equal(u, ur[r0:r1]))}
+                assert solver.iterations == itr, (name, solver.iterations, itr)
+                assert np.array_equal(u, ur[r0:r1]), (name, float(np.abs(u - ur[r0:r1]).max()))
+                solver.destroy()
+                if pc is not None:
+                    pc.destroy()
+            if case != "random":
+                exact("seq_cg", sg.cg(1e-13), None, orc.cg(A, b, tol=1e-13))
+                exact("seq_cg_jacobi", sg.cg(1e-13), sg.jacobi, orc.cg(A, b, tol=1e-13, pc=orc.Jacobi(A)))
+                exact("seq_bicgstab", sg.bicgstab(1e-13), None, orc.bicgstab(A, b, tol=1e-13))
+            else:
+                exact("seq_bicgstab_jacobi", sg.bicgstab(1e-12), sg.jacobi, orc.bicgstab(A, b, tol=1e-12, pc=orc.Jacobi(A)))
+        finally:
+            sg.set_option("dot_order", 0)
         check("gmres30", sg.gmres(1e-12, 30), None, orc.gmres(A, b, tol=1e-12, restart=30), lambda i: 2, 1e-9 if case == "longrows" else 1e-10)
         res["solves"] = out
         H.destroy()

@@ -1694,38 +1694,88 @@ def _solve(A, g, skind, pkind, tol, hist=0):
     return u, solver
 
 
-@pytest.mark.parametrize("cg_small", [1, 0])
+@pytest.fixture
+def dot_order_1():
+    """The reference's dot_product order (one accumulator, first element to last): the solvers' iterates are then
+    bit-identical to the reference's, not merely close."""
+    sg.set_option("dot_order", 1)
+    yield
+    sg.set_option("dot_order", 0)
+
+
+C1_NAME = "diffusion1d_csr_10000"     # BASELINE config C1 at its stated size (tolerance 1e-16)
+
+
+@pytest.mark.parametrize("small", [1, 0])
 @pytest.mark.parametrize("name", golden_names())
-def test_solvers_golden(golden, name, cg_small):
-    """Every solve the reference ran on the fixture -- with CG both as one workgroup (the small systems of the
-    fixtures qualify) and as the launch-per-kernel loop, each pinned to the reference's iteration count and solution."""
+def test_solvers_golden_exact_in_reference_dot_order(golden, name, small, dot_order_1):
+    """dot_order = 1: every solve the reference ran on the fixture -- CG, PCG (Jacobi, ILDU), BiCGStab, PBiCGStab; as ONE
+    workgroup (k_cg_small / k_bicgstab_small, where the system qualifies) and as the launch loop with k_dot_seq -- stops
+    at the reference's iteration count and returns the reference's solution BIT FOR BIT (cg_solvers.f90:128-146,
+    :168-190; bicgstab_solvers.f90:140-173, :199-233).  That includes C1 at its stated size: 9388 iterations."""
     g = golden(name)
     if not len(g["solves"]):
         pytest.skip("no solves in this fixture")
     A = hip_matrix(g)
     for s, (skind, pkind, tol) in enumerate(g["solves"], 1):
-        if cg_small == 0 and int(skind) != CG:
-            continue                      # (BiCGStab has one path: a single-workgroup variant landed 2 iterations from the
-                                          # reference on one fixture -- its dot products sum in another order -- and was dropped)
-        sg.set_option("cg_small", cg_small)
+        sg.set_option("cg_small", small)
+        sg.set_option("bicgstab_small", small)
         try:
             u, solver = _solve(A, g, skind, pkind, tol)
         finally:
             sg.set_option("cg_small", 1)
+            sg.set_option("bicgstab_small", 1)
+        itref = int(g[f"ref_s{s}_iterations"][0])
+        assert solver.iterations == itref, (name, s, solver.iterations, itref)
+        assert np.array_equal(u, g[f"ref_s{s}_u"]), (name, s, np.abs(u - g[f"ref_s{s}_u"]).max())
+        assert solver.converged and np.sqrt(solver.res2) <= tol
+    if name == C1_NAME:
+        assert solver.iterations == 9388
+
+
+@pytest.mark.parametrize("cg_small", [1, 0])
+@pytest.mark.parametrize("name", golden_names())
+def test_solvers_golden(golden, name, cg_small):
+    """The default dot order (tree: per-workgroup partial sums, a legal dot_product order but not the pinned build's):
+    every solve the reference ran on the fixture, as one workgroup and as the launch loop, within the stated
+    relaxations of the reference's iteration count and solution.  (The exact gate is the test above.)"""
+    g = golden(name)
+    if not len(g["solves"]):
+        pytest.skip("no solves in this fixture")
+    A = hip_matrix(g)
+    for s, (skind, pkind, tol) in enumerate(g["solves"], 1):
+        sg.set_option("cg_small", cg_small)
+        sg.set_option("bicgstab_small", cg_small)
+        try:
+            u, solver = _solve(A, g, skind, pkind, tol)
+        finally:
+            sg.set_option("cg_small", 1)
+            sg.set_option("bicgstab_small", 1)
         uref = g[f"ref_s{s}_u"]
         itref = int(g[f"ref_s{s}_iterations"][0])
+        assert solver.converged
+        assert np.sqrt(solver.res2) <= tol
+        if name == C1_NAME:
+            # kappa ~ 4e7 driven 16 digits down: the tree-order dots keep the short recurrence orthogonal until n / 2 =
+            # 5000 iterations (what exact arithmetic gives for this symmetric right-hand side); the reference's
+            # sequential sums need 9388.  Both answers are the analytic solution to 3e-14.
+            assert solver.iterations == 5000 and itref == 9388
+            assert np.abs(u - g["analytic"]).max() <= 3e-14 and np.abs(uref - g["analytic"]).max() <= 3e-14
+            continue
         rel = np.abs(u - uref).max() / np.abs(uref).max()
         # Bound: 1e-12 relative (north_star) wherever the conditioning allows it.  Two iterates
         # whose residuals both meet an ABSOLUTE tolerance tol can differ by cond(A)*tol, so the
         # bound is max(1e-12, KAPPA*tol) with the fixture's condition number (1-D: (2(n+1)/pi)^2).
         bound = max(1e-12, KAPPA.get(name, 1e2) * tol)
         assert rel <= bound, (name, s, rel, bound)
-        # BiCGStab's iteration count on the cond~4e5 advection problem moves by several percent
-        # with the rounding of the dots (the reference itself: 1133 plain, 1106 Jacobi)
-        long_bicg = int(skind) == BICGSTAB and itref > 500
-        assert abs(solver.iterations - itref) <= (0.10 * itref if long_bicg else 1), (name, s, solver.iterations, itref)
-        assert solver.converged
-        assert np.sqrt(solver.res2) <= tol
+        # BiCGStab's residual is not monotone: the iteration at which it first dips below the tolerance moves with
+        # the rounding of the dots -- by several percent on the cond~4e5 advection problem (the reference itself:
+        # 1133 plain, 1106 Jacobi), by up to 3 on the short runs (tree order inside one workgroup: 52 against 54)
+        if int(skind) == BICGSTAB:
+            slack = 0.10 * itref if itref > 500 else 3
+        else:
+            slack = 1
+        assert abs(solver.iterations - itref) <= slack, (name, s, solver.iterations, itref)
 
 
 def test_reference_known_answers(golden):
@@ -1868,6 +1918,80 @@ def test_residual_history_vs_oracle(orc):
             #  noise in every implementation: two valid CPU dot orders already differ by ~0.5 % there)
             if fn is orc.cg:
                 assert np.abs(x - xr).max() / np.abs(xr).max() <= max(1e-12, 4 * np.abs(xv - xr).max() / np.abs(xr).max())
+
+
+def test_residual_history_exact_in_reference_dot_order(orc, dot_order_1):
+    """dot_order = 1: res2 after every iteration equals the oracle's (whose left-to-right dots are bit-identical to the
+    compiled reference's on every fixture solve) -- 50 iterations of CG and BiCGStab on C2-mini and C5-mini, plain and
+    Jacobi, one workgroup and launch loop; the iterates too."""
+    for (ptr, node, val), n in ((P.poisson2d_csr(96, 80), 96 * 80), (P.laplace3d_csr(20, 18, 16), 20 * 18 * 16)):
+        A = orc.CsrMatrix(n, n, ptr, node, val)
+        H = hip_from_oracle(A)
+        b = np.full(n, 1.0 / n)
+        for fn, mk in ((orc.cg, sg.cg), (orc.bicgstab, sg.bicgstab)):
+            for pk in (0, 1):
+                pco = orc.Jacobi(A) if pk else None
+                xr, itr, _, hr = fn(A, b, pc=pco, tol=1e-30, max_iter=50, history=50)
+                for small in (1, 0):
+                    sg.set_option("cg_small", small)
+                    sg.set_option("bicgstab_small", small)
+                    try:
+                        pc = sg.jacobi() if pk else None
+                        if pc is not None:
+                            pc.setup(H)
+                        s = mk(1e-30)
+                        s.set_max_iter(50)
+                        s.set_history(50)
+                        s.setup(H)
+                        x = np.zeros(n)
+                        s.solve(H, x, b, pc, check=False)
+                    finally:
+                        sg.set_option("cg_small", 1)
+                        sg.set_option("bicgstab_small", 1)
+                    assert np.array_equal(np.asarray(s.history), hr), (fn.__name__, pk, small)
+                    assert np.array_equal(x, xr), (fn.__name__, pk, small)
+
+
+def test_reference_dot_order_on_partitions_and_odd_sizes(orc, dot_order_1):
+    """dot_order = 1 beyond the one-workgroup sizes and across in-process partitions: the running sum is handed from one
+    part's k_dot_seq to the next, so a P-way partitioned solve adds the same products in the same global order -- iterates
+    bit-identical to the oracle's one-part solve.  Also odd n (scalar tail of the product loads), a non-zero initial guess,
+    ILDU-PCG, and a system large enough for several chunks of the chain (n = 15 x 1024 + 7)."""
+    nx, ny = 139, 111                                    # n = 15429: beyond k_cg_small, odd
+    n = nx * ny
+    ptr, node, val = P.poisson2d_csr(nx, ny)
+    A = orc.CsrMatrix(n, n, ptr, node, val)
+    H = hip_from_oracle(A)
+    b = A.matvec(np.ones(n))
+    x0 = P.test_vector(n)
+    for ofn, mk in ((orc.cg, sg.cg), (orc.bicgstab, sg.bicgstab)):
+        for pk in (0, 1, 2):
+            pco = {0: lambda A: None, 1: orc.Jacobi, 2: orc.Ildu}[pk](A)
+            ur, itr, _, _ = ofn(A, b, x0=x0, pc=pco, tol=1e-11)
+            pc = {0: lambda: None, 1: sg.jacobi, 2: sg.ldu}[pk]()
+            if pc is not None:
+                pc.setup(H)
+            s = mk(1e-11)
+            s.setup(H)
+            u = x0.copy()
+            s.solve(H, u, b, pc)
+            assert s.iterations == itr and np.array_equal(u, ur), (ofn.__name__, pk, s.iterations, itr)
+    # in-process partitions (even row boundaries): CG, Jacobi-PCG, BiCGStab
+    for nparts in (2, 3):
+        starts = np.array([0] + [2 * ((n * k // nparts) // 2) for k in range(1, nparts)] + [n], np.int64)
+        Hp = sg.partitioned_csr_matrix(n, n, ptr, node, val, starts)
+        for ofn, mk in ((orc.cg, sg.cg), (orc.bicgstab, sg.bicgstab)):
+            for pk in (0, 1):
+                pco = orc.Jacobi(A) if pk else None
+                ur, itr, _, _ = ofn(A, b, pc=pco, tol=1e-11)
+                pc = sg.jacobi() if pk else None
+                if pc is not None:
+                    pc.setup(Hp)
+                s = mk(1e-11)
+                s.setup(Hp)
+                u = np.zeros(n)
+                s.solve(Hp, u, b, pc)
+                assert s.iterations == itr and np.array_equal(u, ur), (nparts, ofn.__name__, pk, s.iterations, itr)
 
 
 @pytest.mark.parametrize("orth", ["cgs2", "mgs"])
