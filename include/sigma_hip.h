@@ -88,10 +88,25 @@ int sgm_synchronize(void);
  * no launch inside the loop; same statements as the launch-per-kernel loop, only the dot products'
  * summation order differs.  "cg_small_chunk" (default 50000): iterations per launch of that kernel (the
  * solve continues in the next launch from parked r, p, res2 -- bit-identical to the uncut solve).
- * "slice_sched" (default 1): sliced matrices most of whose rows carry an offset of >= 32 slices (the
+ * "slice_sched" (default 0: measured within noise of the computed slice maps): sliced matrices most of whose rows carry an offset of >= 32 slices (the
  * plane stride of a 3-D grid) hand their slices to the workgroups in a band order per XCD, so that the
  * slices one plane apart -- which read the same x entries -- share one XCD's L2; only the order in
- * which whole slices are taken changes.  "slice_sched_band" (default 64): its band width in slices.  */
+ * which whole slices are taken changes.  "slice_sched_band" (default 64): its band width in slices.
+ * "dot_order" (default 0): how CG / BiCGStab (plain and preconditioned) add up their dot products.  0 = tree order
+ * (per-workgroup partial sums, re-reduced in a fixed order): a legal order for the Fortran intrinsic, deterministic, and
+ * the fast one.  1 = the order the reference build uses (amdflang -O2 on x86-64 turns dot_product into ONE accumulator
+ * fed first element to last, cg_solvers.f90:131,135,140, bicgstab_solvers.f90:152,155,160,164,169): products formed in
+ * parallel, parked in LDS, added by one wave left to right (about 4 ns per element: a VALIDATION mode for n up to ~1e5, not a
+ * production one).  With it every iterate, iteration count and residual is BIT-IDENTICAL to the reference's -- also on
+ * row partitions and across ranks, where the running sum is handed part to part / rank to rank.  GMRES (no reference
+ * counterpart) keeps the tree order.
+ * "bicgstab_small" (default 1): BiCGStab (plain or Jacobi-preconditioned) on a single-GPU CSR / structured ELLPACK matrix of at
+ * most 4096 rows runs as ONE workgroup, like "cg_small" (the reference's own test size, n = 1024: 24.5 -> ~11 us per
+ * iteration); in tree order its iteration count may differ from the launch loop's by a few.
+ * "pipeline_spin_limit" (default 0 = built-in, 2^22 polls): how often a wait inside the strip- / slab-pipelined ILDU sweeps
+ * polls before it gives up.  A sweep that gives up is never returned: sgm_pc_apply and the solvers notice (a sticky
+ * device word read at their next synchronisation), redo the work with the level-scheduled sweeps and retire the pipeline
+ * for that preconditioner (sgm_pc_get "pipeline_retired").  Tests set 1 to force that path.  */
 int sgm_set_option(const char *name, int value);
 /* The schedule itself, host-only (no HIP call; what the library uploads for a row range of n_slices
  * 512-row slices): tab_out[it * grid + workgroup] = slice or -1, iters_out = entries per workgroup.

@@ -132,6 +132,8 @@ struct sgm_pc_s {
     std::vector<PartPC> parts;       // jacobi
     std::vector<IlduState> ild;      // ildu: one block per part
     std::vector<double> hidiag;
+    int32_t *abort_sticky = nullptr; // device: set by a pipelined triangular sweep that gave up; cleared by the host only
+    int retired = 0;                 // pipelines switched off after an abort (diagnostics: sgm_pc_get "pipeline_retired")
 };
 
 namespace {
@@ -495,6 +497,15 @@ constexpr int kStripDepth = 32;          // records in flight per lane (16: 0.91
 constexpr int kStripChunk = 8;           // steps between LDS hand-offs
 constexpr int kStripRing = 512;          // edge values the LDS rings hold (steps)
 constexpr int kStripSpinLimit = 1 << 22;
+// A wait that gives up marks the sweep (abort_word: cleared by the next sweep's gather, read by the setup self-check) AND the
+// preconditioner's sticky word, which only the host clears: the solvers and sgm_pc_apply read it whenever they synchronise
+// anyway, redo the work with the level walkers and retire the pipeline for this handle -- a result the library itself
+// spoiled never reaches the caller (sgm::pc_abort_word / pc_retire_pipelines).
+__device__ inline void raise_abort(int32_t *abort_word, int32_t *sticky)
+{
+    __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sticky) __hip_atomic_store(sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 constexpr int kEdgePad = 72;             // an edge row: S + 64 values (a strip reads its left neighbour's step t + 63), 2 clocks
 // "not yet written": a SIGNALLING NaN no subtraction can produce (arithmetic quiets NaNs), so the edge values are their own flags
 constexpr unsigned long long kEdgeEmpty = 0x7FF4A5A5A5A5A5A5ull;
@@ -510,7 +521,8 @@ __device__ inline double dpp_shift_up(double v, double lane0)
 // ORDER: 0 = every row subtracts its r-w term first, 1 = every row its r-1 term first, 2 = per-row flag (bit 2)
 template <int DEPTH, int CH, int ORDER, int LA = DEPTH>
 __global__ __launch_bounds__(192) void k_trsv_strip(int32_t NI, int32_t S, const StripRec *__restrict__ rec, double *__restrict__ xp,
-                                                    double *edge, int32_t *progress, const int *flag, int one_xcd)
+                                                    double *edge, int32_t *progress, const int *flag, int one_xcd, int spin_limit,
+                                                    int32_t *sticky)
 {
     __shared__ double in_ring[kStripRing], out_ring[kStripRing], out_scratch[64 + CH];
     __shared__ int in_avail, out_count, out_sent, lds_abort; // steps of left-edge values available / produced by the chain / forwarded
@@ -553,8 +565,8 @@ __global__ __launch_bounds__(192) void k_trsv_strip(int32_t NI, int32_t S, const
                     while (__hip_atomic_load(&in_avail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < t + CH ||
                            t + CH - __hip_atomic_load(&out_sent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > kStripRing - CH) {
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > kStripSpinLimit || __hip_atomic_load(&lds_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                            if (lane == 0) __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (++spins > spin_limit || __hip_atomic_load(&lds_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                            if (lane == 0) raise_abort(abort_word, sticky);
                             return;
                         }
                     }
@@ -619,8 +631,8 @@ __global__ __launch_bounds__(192) void k_trsv_strip(int32_t NI, int32_t S, const
                 continue;
             }
             __builtin_amdgcn_s_sleep(4);            // (the helpers share the CU's LDS and memory pipeline with the chain wave: poll gently)
-            if (++spins > kStripSpinLimit || __hip_atomic_load(&lds_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                if (lane == 0) __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++spins > spin_limit || __hip_atomic_load(&lds_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                if (lane == 0) raise_abort(abort_word, sticky);
                 return;
             }
         }
@@ -652,10 +664,10 @@ __global__ __launch_bounds__(192) void k_trsv_strip(int32_t NI, int32_t S, const
             }
         }
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > kStripSpinLimit || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+        if (++spins > spin_limit || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
             __hip_atomic_load(&lds_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
             if (lane == 0) {
-                __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                raise_abort(abort_word, sticky);
                 __hip_atomic_store(&lds_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             return;
@@ -1046,7 +1058,7 @@ int refresh_grid_values(GridTri &G, const std::vector<double> &val)
     return SGM_OK;
 }
 
-void trsv_grid(const GridTri &G, double *xp, const int *flag)
+void trsv_grid(const GridTri &G, double *xp, const int *flag, int spin_limit, int32_t *sticky)
 {
     hipStream_t st = g_rt.stream;
     static const int xcd_env = getenv("SGM_STRIP_XCD") ? atoi(getenv("SGM_STRIP_XCD")) : -1;
@@ -1059,7 +1071,7 @@ void trsv_grid(const GridTri &G, double *xp, const int *flag)
         static bool attr = false;                                                                                                \
         if (!attr) { (void)hipFuncSetAttribute((const void *)k_trsv_strip<DD, kStripChunk, OO, LL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pad); attr = true; } \
         hipLaunchKernelGGL((k_trsv_strip<DD, kStripChunk, OO, LL>), dim3(one_xcd ? G.NI * 8 : G.NI), dim3(192), lds_pad, st, G.NI, G.S, \
-                           (const StripRec *)G.rec, xp, G.edge, G.progress, flag, one_xcd);                                      \
+                           (const StripRec *)G.rec, xp, G.edge, G.progress, flag, one_xcd, spin_limit, sticky);                  \
     } while (0)
     // look-ahead (SGM_STRIP_DEPTH): 32 register slots with 20 steps in flight (3 memory operations per step, vmcnt counts to 63),
     // 32 with all 32 in flight (the compiler then drains the queue once per trip of the unrolled loop), or 16
@@ -1070,17 +1082,17 @@ void trsv_grid(const GridTri &G, double *xp, const int *flag)
 }
 
 // z = (I+U)^-1 D^-1 (I+L)^-1 r through the strip path
-void apply_grid(const IlduState *S, const double *r, double *z, const int *flag)
+void apply_grid(const IlduState *S, const double *r, double *z, const int *flag, int spin_limit, int32_t *sticky)
 {
     hipStream_t st = g_rt.stream;
     const int gl = vec_grid(S->gL.NP), gu = vec_grid(S->gU.NP);
     hipLaunchKernelGGL(k_grid_gather, dim3(gl), dim3(kBlock), 0, st, S->gL.NP, S->gL.rec, r, (const int32_t *)S->gL.row, S->gL.progress,
                        S->gL.NI + 1, reinterpret_cast<unsigned long long *>(S->gL.edge), (int64_t)S->gL.NI * (S->gL.S + kEdgePad), flag);
-    trsv_grid(S->gL, S->gxL, flag);                                       // (I+L) x = b
+    trsv_grid(S->gL, S->gxL, flag, spin_limit, sticky);                                       // (I+L) x = b
     hipLaunchKernelGGL(k_grid_transition, dim3(gu), dim3(kBlock), 0, st, S->gU.NP, S->gU.rec, (const double *)S->gxL,
                        (const int32_t *)S->gmapLU, (const double *)S->gDp, S->gU.progress, S->gU.NI + 1,
                        reinterpret_cast<unsigned long long *>(S->gU.edge), (int64_t)S->gU.NI * (S->gU.S + kEdgePad), flag);       // x = x / D
-    trsv_grid(S->gU, S->gxU, flag);                                       // (I+U) x = x
+    trsv_grid(S->gU, S->gxU, flag, spin_limit, sticky);                                       // (I+U) x = x
     hipLaunchKernelGGL(k_grid_scatter, dim3(gu), dim3(kBlock), 0, st, S->gU.NP, z, (const double *)S->gxU,
                        (const int32_t *)S->gU.row, flag);
 }
@@ -1264,6 +1276,32 @@ bool pc_apply_is_short(sgm_pc pc)
 }
 const double *pc_idiag(sgm_pc pc, size_t part) { return pc->parts[part].idiag; }
 
+// The sticky abort word of a preconditioner whose apply runs through a pipelined triangular solve right now (null otherwise:
+// nothing to watch).  Whoever synchronises after such applies copies it back; nonzero = some sweep gave up and its result --
+// and everything computed from it -- is not to be used.
+int32_t *pc_abort_word(sgm_pc pc)
+{
+    if (!pc || pc->kind != SGM_PC_ILDU0 || !g_opt.ildu_strips || !pc->abort_sticky) return nullptr;
+    for (const auto &S : pc->ild)
+        if (S.grid_ok || S.slab_ok) return pc->abort_sticky;
+    return nullptr;
+}
+// After an abort: the pipelines of this handle are retired (every later apply takes the level walkers, built here if they
+// were never needed) and the word is cleared.  Loud on stderr: it should not happen on a GPU this process owns.
+int pc_retire_pipelines(sgm_pc pc)
+{
+    fprintf(stderr, "[sigma_hip] ILDU pipelined triangular solve gave up waiting (preempted / shared GPU?): result discarded, "
+                    "redone with the level-scheduled solves; the pipeline is retired for this preconditioner\n");
+    for (auto &S : pc->ild) {
+        S.grid_ok = false;
+        S.slab_ok = false;
+        SGM_TRY(ensure_levels(&S));
+    }
+    pc->retired += 1;
+    SGM_HIP(hipMemsetAsync(pc->abort_sticky, 0, sizeof(int32_t), g_rt.stream));
+    return SGM_OK;
+}
+
 int pc_apply_parts(sgm_pc pc, sgm_mat A, const double *const *r, double *const *z, const int *const *flags)
 {
     hipStream_t st = g_rt.stream;
@@ -1277,12 +1315,13 @@ int pc_apply_parts(sgm_pc pc, sgm_mat A, const double *const *r, double *const *
         for (size_t ip = 0; ip < pc->ild.size(); ++ip) {      // block-Jacobi over the parts: no exchange
             const IlduState *S = &pc->ild[ip];
             const int *flag = flags ? flags[ip] : nullptr;
+            const int spin = g_opt.pipeline_spin_limit > 0 ? g_opt.pipeline_spin_limit : kStripSpinLimit;
             if (S->grid_ok && g_opt.ildu_strips) {                 // grid-like factors: one strip-pipelined launch per sweep
-                apply_grid(S, r[ip], z[ip], flag);
+                apply_grid(S, r[ip], z[ip], flag, spin, pc->abort_sticky);
                 continue;
             }
             if (S->slab_ok && g_opt.ildu_strips) {                 // 3-D grid factors: one slab-pipelined launch per sweep
-                slab3_apply(S->slab, r[ip], z[ip], flag);
+                slab3_apply(S->slab, r[ip], z[ip], flag, spin, pc->abort_sticky);
                 continue;
             }
             SGM_TRY(ensure_levels(&pc->ild[ip]));              // (built on first need when a pipelined path served the pattern so far)
@@ -1363,6 +1402,8 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
     // parity with the reference holds for one part, more parts change the iteration counts)
     if (A->fmt != SGM_FMT_CSR)
         return fail(SGM_ERR_UNSUPPORTED, "ILDU(0) needs a CSR matrix");
+    if (!pc->abort_sticky) SGM_TRY(dalloc(&pc->abort_sticky, 1));
+    SGM_HIP(hipMemsetAsync(pc->abort_sticky, 0, sizeof(int32_t), g_rt.stream));
     if (pc->ild.size() != A->parts.size()) {
         for (auto &S : pc->ild) free_ildu(S);
         pc->ild.assign(A->parts.size(), IlduState());
@@ -1449,8 +1490,8 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             hipStream_t st2 = g_rt.stream;
             (void)hipMemcpyAsync(dr, rt.data(), (size_t)n * 8, hipMemcpyHostToDevice, st2);
             (void)hipMemsetAsync(dz, 0, (size_t)n * 8, st2);
-            if (have_grid) apply_grid(S, dr, dz, nullptr);
-            else slab3_apply(S->slab, dr, dz, nullptr);
+            if (have_grid) apply_grid(S, dr, dz, nullptr, kStripSpinLimit, nullptr);
+            else slab3_apply(S->slab, dr, dz, nullptr, kStripSpinLimit, nullptr);
             (void)hipMemcpyAsync(zb.data(), dz, (size_t)n * 8, hipMemcpyDeviceToHost, st2);
             int32_t abL = 0, abU = 0;
             if (have_grid) {
@@ -1513,6 +1554,17 @@ int sgm_pc_apply(sgm_pc pc, const double *r, double *z, int where)
     const double *rs[1] = {sr.dev};
     double *zs[1] = {sz.dev};
     SGM_TRY(pc_apply_parts(pc, &view, rs, zs, nullptr));
+    if (int32_t *ab = pc_abort_word(pc)) {
+        // a pipelined sweep may give up (bounded waits): look before the result leaves -- one 4-byte copy and a
+        // synchronisation against an apply of a millisecond, also in async mode -- and redo it with the level walkers
+        int32_t aborted = 0;
+        SGM_HIP(hipMemcpyAsync(&aborted, ab, sizeof(int32_t), hipMemcpyDeviceToHost, g_rt.stream));
+        SGM_HIP(hipStreamSynchronize(g_rt.stream));
+        if (aborted) {
+            SGM_TRY(pc_retire_pipelines(pc));
+            SGM_TRY(pc_apply_parts(pc, &view, rs, zs, nullptr));
+        }
+    }
     SGM_TRY(stage_out(sz, z, pc->n, where));
     return finish();
 }
@@ -1566,6 +1618,11 @@ int sgm_pc_get(sgm_pc pc, const char *name, void *out, size_t bytes, size_t *nee
             SGM_TRY(slab3_clocks(S->slab, ck));
             src = ck.data(); sz = ck.size() * 8;
         }
+        else if (nm == "pipeline_retired") {     // how often a pipelined sweep gave up and the pipelines were retired (0 = never)
+            static int32_t rv[1];
+            rv[0] = pc->retired;
+            src = rv; sz = sizeof rv;
+        }
         else if (nm == "levels") {
             SGM_TRY(ensure_levels(&pc->ild[0]));
             static int32_t lv[2];
@@ -1574,7 +1631,7 @@ int sgm_pc_get(sgm_pc pc, const char *name, void *out, size_t bytes, size_t *nee
             src = lv; sz = sizeof lv;
         }
     }
-    const bool known = nm == "strips" || nm == "strip_clocks" || nm == "slabs" || nm == "slab_clocks" || nm == "idiag" || nm == "Lptr" || nm == "Lnode" || nm == "Lval" || nm == "Uptr" ||
+    const bool known = nm == "strips" || nm == "strip_clocks" || nm == "slabs" || nm == "slab_clocks" || nm == "pipeline_retired" || nm == "idiag" || nm == "Lptr" || nm == "Lnode" || nm == "Lval" || nm == "Uptr" ||
                        nm == "Unode" || nm == "Uval" || nm == "D" || nm == "levels";
     if (!known || (!src && sz)) return fail(SGM_ERR_BAD_ARG, "sgm_pc_get: unknown array '%s'", name);
     if (!src) src = &kEmpty;
@@ -1591,6 +1648,7 @@ int sgm_pc_destroy(sgm_pc pc)
     if (!pc) return SGM_OK;
     for (auto &pp : pc->parts) dfree(pp.idiag);
     for (auto &S : pc->ild) free_ildu(S);
+    dfree(pc->abort_sticky);
     delete pc;
     return SGM_OK;
 }

@@ -38,6 +38,8 @@ int pc_apply_parts(sgm_pc pc, sgm_mat A, const double *const *r, double *const *
 int pc_kind(sgm_pc pc);
 bool pc_apply_is_short(sgm_pc pc);
 const double *pc_idiag(sgm_pc pc, size_t part);
+int32_t *pc_abort_word(sgm_pc pc);        // sgm_pc.hip: sticky abort word of a pipelined ILDU apply (null: nothing to watch)
+int pc_retire_pipelines(sgm_pc pc);
 
 // ------------------------------------------------------------------ generic fused kernel
 // F provides: bool prepare(double* red) (block-uniform; false = nothing to do),
@@ -908,6 +910,9 @@ struct sgm_solver_s {
     double res2 = 0.0;
     int32_t converged = 0;
     bool seq = false;                // this solve runs with dot_order = 1 (set by sgm_solver_solve from the option)
+    int32_t *abort_dev = nullptr;    // the preconditioner's sticky abort word while its pipelined sweeps are in use (sgm_pc.hip)
+    int32_t aborted = 0;             // ... as last read by read_state: nonzero = this solve's iterates are spoiled, stop and redo
+    double *x_backup = nullptr;      // the caller's initial guess, kept while abort_dev is watched
     std::vector<PartWork> work;
     std::vector<double> history;
     bool multi = false;
@@ -925,6 +930,8 @@ void free_work(sgm_solver s)
         dfree(w.history); dfree(w.gmres); dfree(w.V);
     }
     s->work.clear();
+    dfree(s->x_backup);
+    s->x_backup = nullptr;
 }
 
 // ScalarRef of partial array k on part ip
@@ -1005,6 +1012,7 @@ int read_state(sgm_solver s, int *flag, int64_t *iters, double *res)
     SGM_HIP(hipMemcpyAsync(flag, w.flag, sizeof(int), hipMemcpyDeviceToHost, g_rt.stream));
     SGM_HIP(hipMemcpyAsync(iters, w.iters, sizeof(int64_t), hipMemcpyDeviceToHost, g_rt.stream));
     SGM_HIP(hipMemcpyAsync(res, w.res, sizeof(double), hipMemcpyDeviceToHost, g_rt.stream));
+    if (s->abort_dev) SGM_HIP(hipMemcpyAsync(&s->aborted, s->abort_dev, sizeof(int32_t), hipMemcpyDeviceToHost, g_rt.stream));
     SGM_HIP(hipStreamSynchronize(g_rt.stream));
     return SGM_OK;
 }
@@ -1437,7 +1445,7 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
         }
         SGM_HIP(hipGetLastError());
         SGM_TRY(read_state(s, &flag, &iters, &res));
-        if (flag || (s->max_iter > 0 && k >= s->max_iter)) break;
+        if (flag || s->aborted || (s->max_iter > 0 && k >= s->max_iter)) break;
     }
     s->last_iterations = iters;
     s->res2 = res;
@@ -1751,7 +1759,7 @@ int run_bicgstab(sgm_solver s, sgm_mat A, double *const *x, const double *const 
         enqueue_test((int)(k & 1));
         SGM_HIP(hipGetLastError());
         SGM_TRY(read_state(s, &flag, &iters, &res));
-        if (flag || (s->max_iter > 0 && k >= s->max_iter)) break;
+        if (flag || s->aborted || (s->max_iter > 0 && k >= s->max_iter)) break;
     }
     if (s->hist_cap && iters >= 1 && iters <= s->hist_cap)    // res2 after the last iteration
         SGM_HIP(hipMemcpy(s->work[0].history + (iters - 1), s->work[0].res, 8, hipMemcpyDeviceToDevice));
@@ -1906,7 +1914,7 @@ int run_gmres(sgm_solver s, sgm_mat A, double *const *x, const double *const *b,
         }
         SGM_HIP(hipGetLastError());
         SGM_TRY(read_state(s, &flag, &iters, &res));
-        if (flag || (s->max_iter > 0 && done_steps >= s->max_iter)) break;
+        if (flag || s->aborted || (s->max_iter > 0 && done_steps >= s->max_iter)) break;
     }
     s->last_iterations = iters;
     s->res2 = res;
@@ -2029,11 +2037,36 @@ int sgm_solver_solve(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc
     // dot_order = 1: CG / BiCGStab add their dot products in the reference's order (GMRES has no reference counterpart
     // and keeps the tree order)
     s->seq = g_opt.dot_order == 1 && s->kind != SGM_SOLVER_GMRES;
-    int rc;
-    if (s->kind == SGM_SOLVER_CG) rc = run_cg(s, A, xs.data(), bs.data(), pc);
-    else if (s->kind == SGM_SOLVER_BICGSTAB) rc = run_bicgstab(s, A, xs.data(), bs.data(), pc);
-    else rc = run_gmres(s, A, xs.data(), bs.data(), pc);
-    if (rc != SGM_OK) return rc;
+    // A pipelined ILDU sweep has bounded waits; one that gives up leaves NaN patterns behind and raises the preconditioner's
+    // sticky word.  It is read with every look at the stop flag (read_state); if it was raised the iterates are spoiled:
+    // the pipelines are retired, the initial guess restored and the solve run again with the level-scheduled sweeps --
+    // never `converged` on a NaN the library produced itself.
+    s->abort_dev = pc ? pc_abort_word(pc) : nullptr;
+    s->aborted = 0;
+    if (s->abort_dev) {
+        if (!s->x_backup) SGM_TRY(dalloc(&s->x_backup, (size_t)nvec + 2));
+        SGM_HIP(hipMemcpyAsync(s->x_backup, sx.dev, (size_t)nvec * 8, hipMemcpyDeviceToDevice, g_rt.stream));
+    }
+    int rc = SGM_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (s->kind == SGM_SOLVER_CG) rc = run_cg(s, A, xs.data(), bs.data(), pc);
+        else if (s->kind == SGM_SOLVER_BICGSTAB) rc = run_bicgstab(s, A, xs.data(), bs.data(), pc);
+        else rc = run_gmres(s, A, xs.data(), bs.data(), pc);
+        if (rc != SGM_OK) return rc;
+        if (!s->aborted) break;
+        if (attempt == 1) return fail(SGM_ERR_HIP, "sgm_solver_solve: a triangular sweep aborted again after the pipelines were retired");
+        SGM_TRY(pc_retire_pipelines(pc));
+        s->abort_dev = nullptr;
+        s->aborted = 0;
+        SGM_HIP(hipMemcpyAsync(sx.dev, s->x_backup, (size_t)nvec * 8, hipMemcpyDeviceToDevice, g_rt.stream));
+        for (size_t ip = 0; ip < P; ++ip) {
+            PartWork &w = s->work[ip];
+            SGM_HIP(hipMemsetAsync(w.flag, 0, sizeof(int), g_rt.stream));
+            SGM_HIP(hipMemsetAsync(w.iters, 0, sizeof(int64_t), g_rt.stream));
+            if (w.history) SGM_HIP(hipMemsetAsync(w.history, 0, (size_t)s->hist_cap * 8, g_rt.stream));
+        }
+    }
+    s->abort_dev = nullptr;
     s->iterations += s->last_iterations;
     if (s->hist_cap) {
         const int64_t cnt = std::min<int64_t>(s->last_iterations, s->hist_cap);

@@ -33,7 +33,6 @@ namespace {
 
 constexpr int kPadPos = 32 * 64;           // positions of padding behind the record arrays (the deepest look-ahead)
 constexpr int kEdgeRing = 512;            // lane-63 results a chain wave keeps for the wave to its right
-constexpr int kSlabSpinLimit = 1 << 22;
 constexpr int kBig = 1 << 29;
 // "not yet written": a SIGNALLING NaN no subtraction can produce (arithmetic quiets NaNs) -- the forwarded results are their own flags
 constexpr unsigned long long kEmpty = 0x7FF4A5A5A5A5A5A5ull;
@@ -91,7 +90,7 @@ constexpr int kSlabMaxNI = 4;
 template <int DEPTH, int CH, int HB, int ORDER, bool REG, int TPB>
 __global__ __launch_bounds__(TPB) void k_trsv_slab(int32_t NI, int32_t NB, int32_t S, const f64x2s *__restrict__ rec,
                                                    const int32_t *__restrict__ code, double *xp, int32_t *progress, long long *clk,
-                                                   const int *flag)
+                                                   const int *flag, int spin_limit, int32_t *sticky)
 {
     constexpr int R = 2 * DEPTH;
     static_assert(DEPTH % CH == 0 && DEPTH % HB == 0 && HB >= 2 && HB + CH < R, "ring geometry");
@@ -167,9 +166,9 @@ __global__ __launch_bounds__(TPB) void k_trsv_slab(int32_t NI, int32_t NB, int32
                         const int c3 = lds_ld(&oc[a + 2]);        // (acquire on LDS = s_waitcnt lgkmcnt(0): orders the ring reads below after all four)
                         if ((c0 >= t + CH + 63) & (c1 >= t + CH + HB) & (c2 >= t + CH - R) & (c3 >= t + CH - kEdgeRing - 63)) break;
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > kSlabSpinLimit || ld_relaxed(lds_abort)) {
+                        if (++spins > spin_limit || ld_relaxed(lds_abort)) {
                             if (lane == 0) {
-                                __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                { __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (sticky) __hip_atomic_store(sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                                 __hip_atomic_store(lds_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
                             return;
@@ -268,8 +267,8 @@ __global__ __launch_bounds__(TPB) void k_trsv_slab(int32_t NI, int32_t NB, int32
                 continue;
             }
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > kSlabSpinLimit || ld_relaxed(lds_abort)) {
-                if (lane == 0) __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++spins > spin_limit || ld_relaxed(lds_abort)) {
+                if (lane == 0) { __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (sticky) __hip_atomic_store(sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                 return;
             }
         }
@@ -344,9 +343,9 @@ __global__ __launch_bounds__(TPB) void k_trsv_slab(int32_t NI, int32_t NB, int32
         auto stalled = [&](bool any) {
             if (any) { spins = 0; return false; }
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > kSlabSpinLimit || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || ld_relaxed(lds_abort)) {
+            if (++spins > spin_limit || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || ld_relaxed(lds_abort)) {
                 if (lane == 0) {
-                    __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    { __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (sticky) __hip_atomic_store(sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                     __hip_atomic_store(lds_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 return true;
@@ -532,7 +531,7 @@ size_t slab_lds(int NI, int R, int CH)
 }
 
 template <int DEPTH, int HB, int ORDER, bool REG, int TPB>
-void launch_slab(const SlabTri &G, double *xp, const int *flag)
+void launch_slab(const SlabTri &G, double *xp, const int *flag, int spin, int32_t *sticky)
 {
     constexpr int CH = 8;
     static const size_t pad = getenv("SGM_SLAB_LDS") ? (size_t)atoi(getenv("SGM_SLAB_LDS")) : (size_t)96 * 1024;
@@ -544,34 +543,34 @@ void launch_slab(const SlabTri &G, double *xp, const int *flag)
         attr = lds;
     }
     hipLaunchKernelGGL((k_trsv_slab<DEPTH, CH, HB, ORDER, REG, TPB>), dim3(G.NB), dim3(64 * (G.NI + 2)), lds, g_rt.stream, G.NI, G.NB, G.S,
-                       (const f64x2s *)G.rec, (const int32_t *)G.code, xp, G.progress, G.clk, flag);
+                       (const f64x2s *)G.rec, (const int32_t *)G.code, xp, G.progress, G.clk, flag, spin, sticky);
 }
 
 // look-ahead 32 (and 64-step rings) for one or two strips per workgroup -- one wave per SIMD, 512 registers each --
 // when no presence codes are read (two loads per step: 64 in flight is what vmcnt can count); 16 otherwise
 template <int HB>
-void launch_slab_o(const SlabTri &G, double *xp, const int *flag)
+void launch_slab_o(const SlabTri &G, double *xp, const int *flag, int spin, int32_t *sticky)
 {
     static const int depth_env = getenv("SGM_SLAB_DEPTH") ? atoi(getenv("SGM_SLAB_DEPTH")) : 32;
     const bool deep = G.NI <= 2 && G.regular && G.order != 2 && depth_env >= 32;
     if (G.order == 0) {
-        if (deep) launch_slab<32, HB, 0, true, 256>(G, xp, flag);
-        else if (G.regular) launch_slab<16, HB, 0, true, 384>(G, xp, flag);
-        else launch_slab<16, HB, 0, false, 384>(G, xp, flag);
+        if (deep) launch_slab<32, HB, 0, true, 256>(G, xp, flag, spin, sticky);
+        else if (G.regular) launch_slab<16, HB, 0, true, 384>(G, xp, flag, spin, sticky);
+        else launch_slab<16, HB, 0, false, 384>(G, xp, flag, spin, sticky);
     } else if (G.order == 1) {
-        if (deep) launch_slab<32, HB, 1, true, 256>(G, xp, flag);
-        else if (G.regular) launch_slab<16, HB, 1, true, 384>(G, xp, flag);
-        else launch_slab<16, HB, 1, false, 384>(G, xp, flag);
-    } else launch_slab<16, HB, 2, false, 384>(G, xp, flag);
+        if (deep) launch_slab<32, HB, 1, true, 256>(G, xp, flag, spin, sticky);
+        else if (G.regular) launch_slab<16, HB, 1, true, 384>(G, xp, flag, spin, sticky);
+        else launch_slab<16, HB, 1, false, 384>(G, xp, flag, spin, sticky);
+    } else launch_slab<16, HB, 2, false, 384>(G, xp, flag, spin, sticky);
 }
 
-void trsv_slab(const SlabTri &G, double *xp, const int *flag)
+void trsv_slab(const SlabTri &G, double *xp, const int *flag, int spin, int32_t *sticky)
 {
     switch (G.HB) {
-    case 2: launch_slab_o<2>(G, xp, flag); break;
-    case 4: launch_slab_o<4>(G, xp, flag); break;
-    case 8: launch_slab_o<8>(G, xp, flag); break;
-    default: launch_slab_o<16>(G, xp, flag); break;
+    case 2: launch_slab_o<2>(G, xp, flag, spin, sticky); break;
+    case 4: launch_slab_o<4>(G, xp, flag, spin, sticky); break;
+    case 8: launch_slab_o<8>(G, xp, flag, spin, sticky); break;
+    default: launch_slab_o<16>(G, xp, flag, spin, sticky); break;
     }
 }
 
@@ -628,17 +627,18 @@ int slab3_refresh(Slab3 *S, const std::vector<double> &Lval, const std::vector<d
 }
 
 // z = (I+U)^-1 D^-1 (I+L)^-1 r
-void slab3_apply(const Slab3 *S, const double *r, double *z, const int *flag)
+// (spin_limit: polls before a wait gives up; sticky: the preconditioner's abort word, set -- never cleared -- by a sweep that did)
+void slab3_apply(const Slab3 *S, const double *r, double *z, const int *flag, int spin_limit, int32_t *sticky)
 {
     hipStream_t st = g_rt.stream;
     const int gl = vec_grid(S->L.NP), gu = vec_grid(S->U.NP);
     hipLaunchKernelGGL(k_slab_gather, dim3(gl), dim3(kBlock), 0, st, S->L.NP, S->L.rec, r, (const int32_t *)S->L.row, S->L.progress,
                        S->L.NB * S->L.NI + 1, reinterpret_cast<unsigned long long *>(S->xL), flag);
-    trsv_slab(S->L, S->xL, flag);
+    trsv_slab(S->L, S->xL, flag, spin_limit, sticky);
     hipLaunchKernelGGL(k_slab_transition, dim3(gu), dim3(kBlock), 0, st, S->U.NP, S->U.rec, (const double *)S->xL,
                        (const int32_t *)S->mapLU, (const double *)S->Dp, S->U.progress, S->U.NB * S->U.NI + 1,
                        reinterpret_cast<unsigned long long *>(S->xU), flag);
-    trsv_slab(S->U, S->xU, flag);
+    trsv_slab(S->U, S->xU, flag, spin_limit, sticky);
     hipLaunchKernelGGL(k_slab_scatter, dim3(gu), dim3(kBlock), 0, st, S->U.NP, z, (const double *)S->xU, (const int32_t *)S->U.row, flag);
 }
 

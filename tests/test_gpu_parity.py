@@ -1680,6 +1680,57 @@ def test_colour_ordered_ildu_on_a_large_grid_vs_oracle(orc):
         H.left_permute(bad)
 
 
+def test_pipeline_abort_is_loud_and_recovers(orc):
+    """The strip / slab pipelined triangular solves wait with a bound; a wait that gives up (a preempted or shared GPU)
+    must never hand NaN patterns to the caller as a result.  Forced here with a spin limit of 1: sgm_pc_apply returns the
+    level walkers' bit-exact result, the solvers return the solve the level walkers give (same iterations, same bits),
+    and the pipeline is retired for the handle (ldu_solve semantics: ldu_solvers.f90:160-176)."""
+    cases = (("strips", P.poisson2d_csr(200, 150), 200 * 150), ("slabs", P.laplace3d_csr(64, 16, 10), 64 * 16 * 10))
+    for which, (ptr, node, val), n in cases:
+        A = orc.CsrMatrix(n, n, ptr, node, val)
+        H = hip_from_oracle(A)
+        ref = orc.Ildu(A)
+        r = P.test_vector(n)
+        b = np.full(n, 1.0 / n)
+        # the walkers' solve (pipelines off) is the yardstick for the solver runs
+        sg.set_option("ildu_strips", 0)
+        try:
+            pcw = sg.ldu(); pcw.setup(H)
+            sw = sg.cg(1e-12); sw.setup(H)
+            uw = np.zeros(n); sw.solve(H, uw, b, pcw)
+        finally:
+            sg.set_option("ildu_strips", 1)
+        for mode in ("apply", "cg", "bicgstab"):
+            pc = sg.ldu()
+            pc.setup(H)                                  # (self-check at setup runs with the built-in limit)
+            assert pc.get(which, np.int32)[0] > 0, (which, "pipeline not in use")
+            assert pc.get("pipeline_retired", np.int32)[0] == 0
+            sg.set_option("pipeline_spin_limit", 1)
+            try:
+                if mode == "apply":
+                    z = np.zeros(n)
+                    pc.solve(H, z, r)
+                    assert np.array_equal(z, ref.solve(r)), (which, mode)
+                elif mode == "cg":
+                    s = sg.cg(1e-12); s.setup(H)
+                    u = np.zeros(n); s.solve(H, u, b, pc)
+                    assert s.converged and s.iterations == sw.iterations and np.array_equal(u, uw), (which, mode, s.iterations, sw.iterations)
+                    assert np.all(np.isfinite(u))
+                else:
+                    s = sg.bicgstab(1e-12); s.setup(H)
+                    u = np.zeros(n); s.solve(H, u, b, pc)
+                    ur, itr, _, _ = orc.bicgstab(A, b, pc=ref, tol=1e-12)
+                    assert s.converged and abs(s.iterations - itr) <= 3 and np.abs(u - ur).max() / np.abs(ur).max() <= 1e-10
+            finally:
+                sg.set_option("pipeline_spin_limit", 0)
+            assert pc.get("pipeline_retired", np.int32)[0] == 1, (which, mode)
+            assert pc.get(which, np.int32)[0] == 0, (which, mode, "pipeline still in use after an abort")
+            # the retired handle keeps working (level walkers), bit-exact
+            z = np.zeros(n)
+            pc.solve(H, z, r)
+            assert np.array_equal(z, ref.solve(r))
+
+
 # --------------------------------------------------------------------------------- solvers
 def _solve(A, g, skind, pkind, tol, hist=0):
     pc = {0: lambda: None, 1: sg.jacobi, 2: sg.ldu}[int(pkind)]()
