@@ -22,6 +22,13 @@
 // bit-identical to k_ell_spmv (products rounded individually, added left to right; a padding
 // slot's 0 * x(last) term is kept).  Built at sgm_ell_create when the matrix looks random
 // (option "ell_colblock": 0 never, 1 automatic, 2 always).
+//
+// Row bands (round 3).  The products make a 16-byte round trip per entry (8 B written by phase 1, read by phase 2): 2.56 GB
+// of the 5.2 GB the two phases move on C4.  Sorting by (row band, column block, row, slot) instead and running the phases
+// band by band -- mul(band 0), sum(band 0), mul(band 1), ... -- over ONE product buffer of a band's size keeps that round
+// trip inside the 256 MiB Infinity Cache: a line stays resident while everything loaded or stored between its two uses fits
+// (guide, "Infinity Cache"), i.e. a band's products + the streams of both phases: rows_per_band * max_d * ~20 B <= ~160 MB
+// (C4: 262144 rows, 20 bands, 64 MB of products).  Row sums do not change: only which launch forms a product does.
 #include "sgm_internal.hpp"
 
 #include <hipcub/hipcub.hpp>
@@ -34,14 +41,15 @@ typedef double f64x2c __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------ setup kernels
 // key of entry e = i*max_d + k (row-major: a stable sort by key leaves (row, slot) order inside a block)
-__global__ void k_ellcb_keys(int32_t n, int32_t max_d, int32_t cb, const int32_t *__restrict__ ecol,
+// key = band * nb + column block (band = row / RB)
+__global__ void k_ellcb_keys(int32_t n, int32_t max_d, int32_t cb, int32_t nb, int32_t RB, const int32_t *__restrict__ ecol,
                              uint16_t *__restrict__ key, int32_t *__restrict__ ent)
 {
     const int64_t total = (int64_t)n * max_d;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
         const int32_t i = (int32_t)(e / max_d), k = (int32_t)(e % max_d);
-        key[e] = (uint16_t)(ecol[(int64_t)k * n + i] / cb);
+        key[e] = (uint16_t)((i / RB) * nb + ecol[(int64_t)k * n + i] / cb);
         ent[e] = (int32_t)e;
     }
 }
@@ -73,14 +81,15 @@ __global__ void k_ellcb_gather(int64_t total, int32_t n, int32_t max_d, int32_t 
 // run (t, b): the entries of column block b whose rows lie in tile t = sorted positions
 // [start, start + len); rows ascend inside a block, so both ends are binary searches.
 // Descriptor = {start, len | base << 16}: base = where the run sits in the tile's LDS image.
-__global__ void k_ellcb_runs(int32_t ntiles, int32_t nb, int32_t R, int32_t max_d, const int32_t *__restrict__ bstart,
+__global__ void k_ellcb_runs(int32_t ntiles, int32_t nb, int32_t R, int32_t RB, int32_t max_d, const int32_t *__restrict__ bstart,
                              const int32_t *__restrict__ perm, int2 *__restrict__ fdesc)
 {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= (int64_t)ntiles * nb) return;
     const int32_t t = (int32_t)(id / nb), b = (int32_t)(id % nb);
+    const int32_t kb = (int32_t)(((int64_t)t * R) / RB) * nb + b;       // (band of the tile, column block): RB is a multiple of R
     auto first_row_at_least = [&](int64_t row) {
-        int32_t lo = bstart[b], hi = bstart[b + 1];
+        int32_t lo = bstart[kb], hi = bstart[kb + 1];
         while (lo < hi) {
             const int32_t mid = lo + ((hi - lo) >> 1);
             if ((int64_t)(perm[mid] / max_d) < row) lo = mid + 1; else hi = mid;
@@ -132,69 +141,84 @@ __global__ void k_ellcb_sample(int32_t n, int32_t max_d, int32_t step, const int
 }
 
 // ------------------------------------------------------------------------------ phase 1
-// grid = nb * CH workgroups: workgroup (b, c) multiplies chunk c of column block b's entries.
+// One band: its sorted positions [bstart[0], bstart[nb]) are cut into gridDim.x equal pieces (even boundaries: 16-byte
+// accesses); workgroup p multiplies piece p, walking the column blocks the piece overlaps -- for each the x block goes to
+// LDS, then the block's entries inside the piece are streamed (value 8 B + column-inside-block 2 B), multiplied and
+// their products stored.  `P` is the product buffer shifted so that P[j] belongs to sorted position j (a band's
+// buffer is reused by the next band).  Pieces, not (block, chunk) pairs: any grid -- a multiple of the CU count -- is
+// balanced whatever the number of column blocks.  NT: nontemporal product stores (single-band form; the banded form
+// keeps them plain so that the products wait in the cache for phase 2).
 template <int TPB>
-__global__ __launch_bounds__(TPB) void k_ellcb_mul(int32_t ncol, int32_t cb, int32_t chunks, const int32_t *__restrict__ bstart,
+__global__ __launch_bounds__(TPB) void k_ellcb_mul(int32_t ncol, int32_t cb, int32_t nb, const int32_t *__restrict__ bstart,
                                                    const double *__restrict__ sval, const uint16_t *__restrict__ lcol,
-                                                   const double *__restrict__ x, double *__restrict__ P,
+                                                   const double *__restrict__ x, double *__restrict__ P, int nt,
                                                    const int *__restrict__ flag_done, int gen)
 {
     extern __shared__ double xs[];
     if (flag_done) { const int st = *flag_done; if (st && gen >= st) return; }
-    const int32_t b = blockIdx.x / chunks, c = blockIdx.x % chunks;
-    const int64_t j0b = bstart[b], j1b = bstart[b + 1];
-    // chunk boundaries on even positions (16-byte accesses), the block's own ends as they are
-    const int64_t len = j1b - j0b;
-    int64_t j0 = j0b + (len * c / chunks), j1 = j0b + (len * (c + 1) / chunks);
-    if (c > 0) j0 = (j0 + 1) & ~(int64_t)1;
-    if (c + 1 < chunks) j1 = (j1 + 1) & ~(int64_t)1;
-    if (j1 > j1b) j1 = j1b;
+    const int64_t jlo = bstart[0], jhi = bstart[nb], len = jhi - jlo;
+    const int64_t np = gridDim.x, pc = blockIdx.x;
+    int64_t j0 = jlo + len * pc / np, j1 = jlo + len * (pc + 1) / np;
+    if (pc > 0) j0 = (j0 + 1) & ~(int64_t)1;
+    if (pc + 1 < np) j1 = (j1 + 1) & ~(int64_t)1;
+    if (j1 > jhi) j1 = jhi;
     if (j0 >= j1) return;
-    const int32_t col0 = b * cb, cnt = min(cb, ncol - col0);
-    // x block -> LDS (col0 is even: cb is; 16-byte loads, odd tail alone)
-    {
-        const f64x2c *src = reinterpret_cast<const f64x2c *>(x + col0);
-        f64x2c *dst = reinterpret_cast<f64x2c *>(xs);
-        for (int32_t t = threadIdx.x; t < (cnt >> 1); t += TPB) dst[t] = src[t];
-        if ((cnt & 1) && threadIdx.x == 0) xs[cnt - 1] = x[col0 + cnt - 1];
+    // the column block holding position j0: the last b with bstart[b] <= j0
+    int32_t lo = 0, hi = nb - 1;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi + 1) >> 1;
+        if ((int64_t)bstart[mid] <= j0) lo = mid; else hi = mid - 1;
     }
-    __syncthreads();
-    int64_t ja = j0;
-    if (ja & 1) {                        // odd head: one entry alone
-        if (threadIdx.x == 0) P[ja] = sval[ja] * xs[lcol[ja]];
-        ++ja;
-    }
-    const int64_t npair = (j1 - ja) >> 1;
-    const f64x2c *v2 = reinterpret_cast<const f64x2c *>(sval + ja);
-    const uint32_t *c2 = reinterpret_cast<const uint32_t *>(lcol + ja);
-    f64x2c *p2 = reinterpret_cast<f64x2c *>(P + ja);
-    constexpr int U = 4;
-    int64_t q = threadIdx.x;
-    for (; q + (int64_t)(U - 1) * TPB < npair; q += (int64_t)U * TPB) {
-        f64x2c v[U];
-        uint32_t cc[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            v[u] = __builtin_nontemporal_load(v2 + q + (int64_t)u * TPB);
-            cc[u] = __builtin_nontemporal_load(c2 + q + (int64_t)u * TPB);
+    for (int32_t b = lo; j0 < j1 && b < nb; ++b) {
+        const int64_t jz = min(j1, (int64_t)bstart[b + 1]);
+        if (jz <= j0) continue;
+        const int32_t col0 = b * cb, cnt = min(cb, ncol - col0);
+        __syncthreads();                     // the previous block's gathers are done with xs
+        {   // x block -> LDS (col0 is even: cb is; 16-byte loads, odd tail alone)
+            const f64x2c *src = reinterpret_cast<const f64x2c *>(x + col0);
+            f64x2c *dst = reinterpret_cast<f64x2c *>(xs);
+            for (int32_t t = threadIdx.x; t < (cnt >> 1); t += TPB) dst[t] = src[t];
+            if ((cnt & 1) && threadIdx.x == 0) xs[cnt - 1] = x[col0 + cnt - 1];
         }
+        __syncthreads();
+        int64_t ja = j0;
+        if (ja & 1) {                        // odd head: one entry alone
+            if (threadIdx.x == 0) P[ja] = sval[ja] * xs[lcol[ja]];
+            ++ja;
+        }
+        const int64_t npair = (jz - ja) >> 1;
+        const f64x2c *v2 = reinterpret_cast<const f64x2c *>(sval + ja);
+        const uint32_t *c2 = reinterpret_cast<const uint32_t *>(lcol + ja);
+        f64x2c *p2 = reinterpret_cast<f64x2c *>(P + ja);
+        constexpr int U = 4;
+        int64_t q = threadIdx.x;
+        for (; q + (int64_t)(U - 1) * TPB < npair; q += (int64_t)U * TPB) {
+            f64x2c v[U];
+            uint32_t cc[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < U; ++u) {
+                v[u] = __builtin_nontemporal_load(v2 + q + (int64_t)u * TPB);
+                cc[u] = __builtin_nontemporal_load(c2 + q + (int64_t)u * TPB);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                f64x2c o;
+                o.x = v[u].x * xs[cc[u] & 0xffffu];
+                o.y = v[u].y * xs[cc[u] >> 16];
+                if (nt) __builtin_nontemporal_store(o, p2 + q + (int64_t)u * TPB); else p2[q + (int64_t)u * TPB] = o;
+            }
+        }
+        for (; q < npair; q += TPB) {
+            const f64x2c v = v2[q];
+            const uint32_t cc = c2[q];
             f64x2c o;
-            o.x = v[u].x * xs[cc[u] & 0xffffu];
-            o.y = v[u].y * xs[cc[u] >> 16];
-            __builtin_nontemporal_store(o, p2 + q + (int64_t)u * TPB);
+            o.x = v.x * xs[cc & 0xffffu];
+            o.y = v.y * xs[cc >> 16];
+            p2[q] = o;
         }
+        if (((jz - ja) & 1) && threadIdx.x == 0) P[jz - 1] = sval[jz - 1] * xs[lcol[jz - 1]];
+        j0 = jz;
     }
-    for (; q < npair; q += TPB) {
-        const f64x2c v = v2[q];
-        const uint32_t cc = c2[q];
-        f64x2c o;
-        o.x = v.x * xs[cc & 0xffffu];
-        o.y = v.y * xs[cc >> 16];
-        p2[q] = o;
-    }
-    if (((j1 - ja) & 1) && threadIdx.x == 0) P[j1 - 1] = sval[j1 - 1] * xs[lcol[j1 - 1]];
 }
 
 // ------------------------------------------------------------------------------ phase 2
@@ -207,12 +231,12 @@ __global__ __launch_bounds__(TPB) void k_ellcb_mul(int32_t ncol, int32_t cb, int
 // R rows per tile, TPB = CM * R threads: all TPB / 64 waves copy runs, the first R threads own the rows.
 // FULLW: one run per wave instruction (64 lanes; tiles of 512 rows, runs average 54 entries) instead of two half-wave runs.
 template <int R, int TPB, int MAXD, bool ADD, bool DOT_W, bool DOT_YY, bool FULLW = false>
-__global__ __launch_bounds__(TPB) void k_ellcb_sum(int32_t n, int32_t max_d, int32_t nb, int32_t ntiles,
+__global__ __launch_bounds__(TPB) void k_ellcb_sum(int32_t n, int32_t max_d, int32_t nb, int32_t t0, int32_t ntiles,
                                                    const int2 *__restrict__ fdesc, const uint16_t *__restrict__ lpos,
                                                    const double *__restrict__ P, double *__restrict__ y,
                                                    const double *__restrict__ w, double *__restrict__ part_wy,
                                                    double *__restrict__ part_yy, const int *__restrict__ flag_done, int gen,
-                                                   int chain)
+                                                   int chain, int nt)
 {
     extern __shared__ double img[];
     __shared__ double red[TPB / 64];
@@ -224,7 +248,8 @@ __global__ __launch_bounds__(TPB) void k_ellcb_sum(int32_t n, int32_t max_d, int
     const int wave = threadIdx.x >> 6;
     const int32_t per = (nb + NW - 1) / NW, bw0 = wave * per, bw1 = min(nb, bw0 + per);
     double dwy = 0.0, dyy = 0.0;
-    for (int32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // tiles [t0, ntiles) of this launch (one band); P is shifted so that P[j] belongs to sorted position j
+    for (int32_t t = t0 + blockIdx.x; t < ntiles; t += gridDim.x) {
         const int32_t i = t * R + (int32_t)threadIdx.x;
         const bool live = (int)threadIdx.x < R && i < n;
         // positions of this lane's row (slots 0..MAXD-1 in registers; longer rows re-read them later)
@@ -247,7 +272,7 @@ __global__ __launch_bounds__(TPB) void k_ellcb_sum(int32_t n, int32_t max_d, int
                     const uint32_t lb = (uint32_t)__shfl(d.y, src, 64);
                     l[u] = (int32_t)(lb & 0xffffu);
                     o[u] = (int32_t)(lb >> 16);
-                    v[u] = q < l[u] ? __builtin_nontemporal_load(P + g[u] + q) : 0.0;
+                    v[u] = q < l[u] ? (nt ? __builtin_nontemporal_load(P + g[u] + q) : P[g[u] + q]) : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -302,11 +327,18 @@ void free_ell_colblock(Part &p)
     p.cb_perm = nullptr; p.cb_sval = nullptr; p.cb_lcol = nullptr; p.cb_bstart = nullptr; p.cb_lpos = nullptr;
     p.cb_fdesc = nullptr; p.cb_P = nullptr;
     p.cb_cols = p.cb_nb = p.cb_R = p.cb_ntiles = 0;
+    p.cb_RB = 0; p.cb_nbands = 1;
 }
 
 bool use_ell_colblock(const Part &p) { return p.cb_P != nullptr && g_opt.ell_colblock != 0; }
 
-int ell_colblock_grid(const Part &p) { return std::max(1, std::min(p.cb_ntiles, cb_cfg().grid2)); }
+// workgroups of one band's sum launch; the fused dots leave one partial sum per (band, workgroup)
+static int band_grid(const Part &p)
+{
+    const int tiles_per_band = p.cb_RB / p.cb_R;
+    return std::max(1, std::min(std::min(p.cb_ntiles, tiles_per_band), std::min(cb_cfg().grid2, kMaxGrid / std::max(1, p.cb_nbands))));
+}
+int ell_colblock_grid(const Part &p) { return band_grid(p) * std::max(1, p.cb_nbands); }
 
 // does the matrix qualify, and do its columns look random?
 static int wants_colblock(const Part &p, bool *yes)
@@ -363,7 +395,20 @@ int build_ell_colblock(Part &p)
     if ((want_rows == 512 || (want_rows == 0 && p.max_d >= 16)) && p.max_d <= 32) R = 512;
     if (R < 64) return SGM_OK;
     const int32_t ntiles = (p.n + R - 1) / R;
-    p.cb_cols = cb; p.cb_nb = nb; p.cb_R = R; p.cb_ntiles = ntiles;
+    // row bands: a band's products (8 B per entry) + what both phases stream meanwhile (10 + 2 B per entry) <= ~160 MB
+    int64_t RB = p.n;
+    if (g_opt.ell_colblock_band > 0) RB = g_opt.ell_colblock_band;
+    else if (g_opt.ell_colblock_band == 0) RB = ((int64_t)160 << 20) / ((int64_t)p.max_d * 20);
+    RB = std::max<int64_t>(R, (RB + R - 1) / R * R);
+    if (RB >= p.n) RB = (int64_t)ntiles * R;                 // one band
+    int32_t nbands = (int32_t)(((int64_t)ntiles * R + RB - 1) / RB);
+    while ((int64_t)nbands * nb > 65535) {                   // 16-bit sort keys: fewer, larger bands
+        RB = (RB * 2 + R - 1) / R * R;
+        nbands = (int32_t)(((int64_t)ntiles * R + RB - 1) / RB);
+    }
+    if ((RB * p.max_d) & 1) return SGM_OK;                   // (a band's first sorted position must be even: R is a multiple of 64, so it is)
+    p.cb_cols = cb; p.cb_nb = nb; p.cb_R = R; p.cb_ntiles = ntiles; p.cb_RB = (int32_t)RB; p.cb_nbands = nbands;
+    const int32_t nkeys = nbands * nb;
 
     uint16_t *key = nullptr, *skey = nullptr;
     int32_t *ent = nullptr;
@@ -373,9 +418,9 @@ int build_ell_colblock(Part &p)
     SGM_TRY(dalloc(&skey, (size_t)total));
     SGM_TRY(dalloc(&ent, (size_t)total));
     SGM_TRY(dalloc(&p.cb_perm, (size_t)total + 2));
-    hipLaunchKernelGGL(k_ellcb_keys, dim3(vec_grid(total)), dim3(kBlock), 0, st, p.n, p.max_d, cb, (const int32_t *)p.ecol, key, ent);
+    hipLaunchKernelGGL(k_ellcb_keys, dim3(vec_grid(total)), dim3(kBlock), 0, st, p.n, p.max_d, cb, nb, (int32_t)RB, (const int32_t *)p.ecol, key, ent);
     int bits = 1;
-    while ((1 << bits) < nb) ++bits;
+    while ((1 << bits) < nkeys) ++bits;
     size_t tmp_bytes = 0;
     SGM_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key, skey, ent, p.cb_perm, (int)total, 0, bits, st));
     char *tmpc = nullptr;
@@ -383,8 +428,8 @@ int build_ell_colblock(Part &p)
     tmp = tmpc;
     SGM_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, key, skey, ent, p.cb_perm, (int)total, 0, bits, st));   // stable
 
-    SGM_TRY(dalloc(&p.cb_bstart, (size_t)nb + 1));
-    hipLaunchKernelGGL(k_ellcb_bstart, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, total, nb, (const uint16_t *)skey, p.cb_bstart);
+    SGM_TRY(dalloc(&p.cb_bstart, (size_t)nkeys + 1));
+    hipLaunchKernelGGL(k_ellcb_bstart, dim3((nkeys + 1 + 255) / 256), dim3(256), 0, st, total, nkeys, (const uint16_t *)skey, p.cb_bstart);
     SGM_TRY(dalloc(&p.cb_sval, (size_t)total + 2));
     SGM_TRY(dalloc(&p.cb_lcol, (size_t)total + 2));
     hipLaunchKernelGGL(k_ellcb_gather, dim3(vec_grid(total)), dim3(kBlock), 0, st, total, p.n, p.max_d, cb,
@@ -393,21 +438,21 @@ int build_ell_colblock(Part &p)
     int2 *fdesc = nullptr;
     SGM_TRY(dalloc(&fdesc, (size_t)nruns));
     p.cb_fdesc = fdesc;
-    hipLaunchKernelGGL(k_ellcb_runs, dim3((unsigned)((nruns + 255) / 256)), dim3(256), 0, st, ntiles, nb, R, p.max_d,
+    hipLaunchKernelGGL(k_ellcb_runs, dim3((unsigned)((nruns + 255) / 256)), dim3(256), 0, st, ntiles, nb, R, (int32_t)RB, p.max_d,
                        (const int32_t *)p.cb_bstart, (const int32_t *)p.cb_perm, fdesc);
     hipLaunchKernelGGL(k_ellcb_bases, dim3((ntiles + 255) / 256), dim3(256), 0, st, ntiles, nb, fdesc);
     SGM_TRY(dalloc(&p.cb_lpos, (size_t)total + 2));
     hipLaunchKernelGGL(k_ellcb_lpos, dim3(vec_grid(total)), dim3(kBlock), 0, st, total, p.n, p.max_d, cb, nb, R,
                        (const int32_t *)p.cb_perm, (const int32_t *)p.ecol, (const int2 *)fdesc, p.cb_lpos);
-    SGM_TRY(dalloc(&p.cb_P, (size_t)total + 2));
+    SGM_TRY(dalloc(&p.cb_P, (size_t)std::min<int64_t>(total, RB * p.max_d) + 2));       // ONE band's products
     SGM_HIP(hipGetLastError());
     SGM_HIP(hipStreamSynchronize(st));
     return SGM_OK;
 }
 
 template <int R, bool ADD>
-static void launch_sum(const Part &p, int grid, double *y, const double *w, double *pwy, double *pyy, const int *flag, int gen,
-                       int chain)
+static void launch_sum(const Part &p, int grid, int32_t t0, int32_t t1, const double *Pj, int nt, double *y, const double *w, double *pwy,
+                       double *pyy, const int *flag, int gen, int chain)
 {
     hipStream_t st = g_rt.stream;
     const size_t lds = (size_t)p.cb_R * p.max_d * 8;
@@ -418,9 +463,9 @@ static void launch_sum(const Part &p, int grid, double *y, const double *w, doub
     do {                                                                                                              \
         static bool attr = false;                                                                                     \
         if (BIG && !attr) { (void)hipFuncSetAttribute((const void *)k_ellcb_sum<R, TPB, MAXD, ADD, DW, DY, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 32 * 8); attr = true; } \
-        hipLaunchKernelGGL((k_ellcb_sum<R, TPB, MAXD, ADD, DW, DY, BIG>), dim3(grid), dim3(TPB), lds, st, p.n, p.max_d, p.cb_nb, p.cb_ntiles, \
-                           (const int2 *)p.cb_fdesc, (const uint16_t *)p.cb_lpos, (const double *)p.cb_P, y, w, pwy, pyy, flag, \
-                           gen, chain);                                                                               \
+        hipLaunchKernelGGL((k_ellcb_sum<R, TPB, MAXD, ADD, DW, DY, BIG>), dim3(grid), dim3(TPB), lds, st, p.n, p.max_d, p.cb_nb, t0, t1, \
+                           (const int2 *)p.cb_fdesc, (const uint16_t *)p.cb_lpos, Pj, y, w, pwy, pyy, flag,              \
+                           gen, chain, nt);                                                                           \
     } while (0)
     if (w && pyy) L(true, true);
     else if (w) L(true, false);
@@ -440,16 +485,29 @@ int launch_ell_colblock(const Part &p, int grid, const double *x, double *y, boo
         SGM_HIP(hipFuncSetAttribute((const void *)k_ellcb_mul<TPB1>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_ellcb_mul<TPB1>), dim3(p.cb_nb * c.chunks), dim3(TPB1), (size_t)p.cb_cols * 8, st, p.ncol_own, p.cb_cols,
-                       c.chunks, (const int32_t *)p.cb_bstart, (const double *)p.cb_sval, (const uint16_t *)p.cb_lcol, x, p.cb_P,
-                       flag, gen);
+    const int nbands = std::max(1, p.cb_nbands);
+    const int gb = std::max(1, grid / nbands);                 // sum workgroups (= partial sums) per band
+    const int tiles_per_band = p.cb_RB / p.cb_R;
+    // one band: as before, (column blocks x chunks) workgroups and nontemporal products; banded: a fixed number of pieces
+    // per band and plain product stores / loads (they are meant to stay cached between the two launches)
+    const int pieces = nbands > 1 ? g_opt.ell_colblock_pieces : p.cb_nb * c.chunks;
+    const int nt = nbands > 1 ? g_opt.ell_colblock_nt : 1;
+    for (int g = 0; g < nbands; ++g) {
+        const int64_t band_first = (int64_t)g * p.cb_RB * p.max_d;      // first sorted position of the band (every row holds max_d slots)
+        double *Pj = p.cb_P - band_first;
+        hipLaunchKernelGGL((k_ellcb_mul<TPB1>), dim3(pieces), dim3(TPB1), (size_t)p.cb_cols * 8, st, p.ncol_own, p.cb_cols, p.cb_nb,
+                           (const int32_t *)p.cb_bstart + (int64_t)g * p.cb_nb, (const double *)p.cb_sval, (const uint16_t *)p.cb_lcol, x,
+                           Pj, nt, flag, gen);
+        const int32_t t0 = g * tiles_per_band, t1 = std::min(p.cb_ntiles, t0 + tiles_per_band);
+        double *pw = pwy ? pwy + (int64_t)g * gb : nullptr, *py = pyy ? pyy + (int64_t)g * gb : nullptr;
 #define R_CASE(RR)                                                                                              \
     if (p.cb_R == RR) {                                                                                         \
-        if (add) launch_sum<RR, true>(p, grid, y, w, pwy, pyy, flag, gen, chain ? 1 : 0);                        \
-        else launch_sum<RR, false>(p, grid, y, w, pwy, pyy, flag, gen, 0);                                      \
+        if (add) launch_sum<RR, true>(p, gb, t0, t1, Pj, nt, y, w, pw, py, flag, gen, chain ? 1 : 0);             \
+        else launch_sum<RR, false>(p, gb, t0, t1, Pj, nt, y, w, pw, py, flag, gen, 0);                           \
     }
-    R_CASE(64) R_CASE(128) R_CASE(192) R_CASE(256) R_CASE(512)
+        R_CASE(64) R_CASE(128) R_CASE(192) R_CASE(256) R_CASE(512)
 #undef R_CASE
+    }
     SGM_HIP(hipGetLastError());
     return SGM_OK;
 }
@@ -459,12 +517,16 @@ int64_t ell_colblock_resident_bytes(const Part &p)
 {
     if (!p.cb_P) return 0;
     const int64_t total = (int64_t)p.n * p.max_d, nruns = (int64_t)p.cb_ntiles * p.cb_nb;
-    return total * (4 + 8 + 2 + 2 + 8) + nruns * 8 + 4 * ((int64_t)p.cb_nb + 1);
+    const int64_t pbuf = std::min<int64_t>(total, (int64_t)p.cb_RB * p.max_d);        // ONE band's products
+    return total * (4 + 8 + 2 + 2) + pbuf * 8 + nruns * 8 + 4 * ((int64_t)p.cb_nb * p.cb_nbands + 1);
 }
 int64_t ell_colblock_matvec_bytes(const Part &p)
 {
     const int64_t total = (int64_t)p.n * p.max_d, nruns = (int64_t)p.cb_ntiles * p.cb_nb;
-    return total * (8 + 2 + 8) + (int64_t)p.cb_nb * cb_cfg().chunks * p.cb_cols * 8     // phase 1: values, columns, products, x blocks
+    // what the two phases move by construction, wherever it is served from (with row bands the products' 16 B per entry are
+    // meant to be served by the Infinity Cache: the PMC pass tells)
+    const int64_t xloads = p.cb_nbands > 1 ? (int64_t)p.cb_nbands * (g_opt.ell_colblock_pieces + p.cb_nb) : (int64_t)p.cb_nb * cb_cfg().chunks;
+    return total * (8 + 2 + 8) + xloads * p.cb_cols * 8                                  // phase 1: values, columns, products, x blocks
          + total * (8 + 2) + nruns * 8 + 8 * (int64_t)p.n;                              // phase 2: products, positions, run tables, y
 }
 

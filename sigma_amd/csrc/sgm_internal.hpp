@@ -42,6 +42,9 @@ struct Options {
     int ell_colblock_cols = 16384; // its column block (x entries staged in LDS per workgroup; even, <= 16384)
     int ell_colblock_rows = 0;     // rows per tile of its sum phase: 0 automatic, 256 or 512
     int ell_colblock_chunks = 16;  // workgroups per column block in the multiply phase (C4 sweep: 4 / 8 / 16 -> 1.32 / 1.31 / 1.27 ms)
+    int ell_colblock_band = 0;     // rows per band of the two-phase product: 0 automatic (products + streams of a band <= ~160 MB), -1 one band, else rows (rounded to tiles)
+    int ell_colblock_pieces = 512; // workgroups of the multiply phase per band (banded form)
+    int ell_colblock_nt = 0;       // banded form: 1 = nontemporal product stores / loads (0: plain, so that the products stay cached)
     int ildu_strips = 1;           // ILDU(0) factors of grid-like matrices (deps r-1, r-w): strip-pipelined triangular solves
     int gmres_cgs2 = 1;            // GMRES: blocked CGS-2 orthogonalisation (3 passes per step) instead of modified Gram-Schmidt
     int cg_small = 1;              // CG (plain or Jacobi) on a CSR matrix of <= 10240 rows: the whole solve in one workgroup (k_cg_small)
@@ -165,6 +168,7 @@ struct Part {
     void *cb_fdesc = nullptr;      // ntiles x nb run descriptors {sorted position, length | LDS base << 16}
     double *cb_P = nullptr;        // products val * x in sorted order (written by phase 1)
     int32_t cb_cols = 0, cb_nb = 0, cb_R = 0, cb_ntiles = 0;
+    int32_t cb_RB = 0, cb_nbands = 1;  // row bands: the two phases run band by band over ONE product buffer of cb_RB rows (it stays in the Infinity Cache)
     std::vector<HaloNbr> nbrs;
     double *xext = nullptr;        // owned+halo staging for plain-vector matvec (multi-part only)
     int dot_grid_override = 0;     // composite matrices: grid of the separate dot kernel

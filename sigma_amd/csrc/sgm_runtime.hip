@@ -164,6 +164,9 @@ int sgm_set_option(const char *name, int value)
     if (!strcmp(name, "ell_colblock_cols")) { g_opt.ell_colblock_cols = std::min(16384, std::max(2, value)) & ~1; return SGM_OK; }
     if (!strcmp(name, "ell_colblock_rows")) { g_opt.ell_colblock_rows = value == 512 ? 512 : value == 256 ? 256 : 0; return SGM_OK; }
     if (!strcmp(name, "ell_colblock_chunks")) { g_opt.ell_colblock_chunks = std::max(1, value); return SGM_OK; }
+    if (!strcmp(name, "ell_colblock_band")) { g_opt.ell_colblock_band = value < 0 ? -1 : value; return SGM_OK; }
+    if (!strcmp(name, "ell_colblock_pieces")) { g_opt.ell_colblock_pieces = std::min(8192, std::max(1, value)); return SGM_OK; }
+    if (!strcmp(name, "ell_colblock_nt")) { g_opt.ell_colblock_nt = value != 0; return SGM_OK; }
     if (!strcmp(name, "ildu_strips")) { g_opt.ildu_strips = value; return SGM_OK; }
     if (!strcmp(name, "cg_small")) { g_opt.cg_small = value; return SGM_OK; }
     if (!strcmp(name, "cg_small_chunk")) { g_opt.cg_small_chunk = std::max(1, value); return SGM_OK; }

@@ -534,10 +534,16 @@ def test_randomised_ellpack_every_kernel_vs_oracle(orc, max_d):
             assert np.array_equal(ta, ta_ref), key
 
 
-@pytest.mark.parametrize("n,max_d,dmin,cols,chunks,rows", [(3000, 32, None, 64, 3, 0), (1000, 7, 3, 16, 1, 0), (70001, 32, 24, 2048, 8, 256),
-                                                            (513, 9, None, 2, 2, 0), (5000, 100, 60, 256, 2, 0), (20000, 16, None, 16384, 8, 0),
-                                                            (70001, 32, 24, 2048, 8, 512), (4000, 40, 20, 128, 2, 0), (3000, 32, None, 64, 3, 256)])
-def test_ell_column_blocked_two_phase_vs_oracle(orc, n, max_d, dmin, cols, chunks, rows):
+@pytest.mark.parametrize("n,max_d,dmin,cols,chunks,rows,band", [
+    (3000, 32, None, 64, 3, 0, -1), (1000, 7, 3, 16, 1, 0, -1), (70001, 32, 24, 2048, 8, 256, -1),
+    (513, 9, None, 2, 2, 0, -1), (5000, 100, 60, 256, 2, 0, -1), (20000, 16, None, 16384, 8, 0, -1),
+    (70001, 32, 24, 2048, 8, 512, -1), (4000, 40, 20, 128, 2, 0, -1), (3000, 32, None, 64, 3, 256, -1),
+    # row bands (the two phases band by band over one product buffer): several bands, a partial last band, one tile per
+    # band, more pieces than entries allow, bands wider than the matrix (= one band)
+    (70001, 32, 24, 2048, 8, 512, 8192), (70001, 32, 24, 2048, 8, 256, 4096), (3000, 32, None, 64, 3, 0, 512),
+    (5000, 100, 60, 256, 2, 0, 640), (20000, 16, None, 16384, 8, 0, 3000), (1000, 7, 3, 16, 1, 0, 256),
+    (4000, 40, 20, 128, 2, 0, 100000), (513, 9, None, 2, 2, 0, 192)])
+def test_ell_column_blocked_two_phase_vs_oracle(orc, n, max_d, dmin, cols, chunks, rows, band):
     """k_ellcb (sgm_ellcb.hip): the two-phase product for ELLPACK matrices with random columns -- products
     through LDS-resident column blocks of x, then row sums in slot order from an LDS image of the tile's
     products.  Forced on (option ell_colblock = 2) for small matrices with small column blocks so that many
@@ -548,6 +554,8 @@ def test_ell_column_blocked_two_phase_vs_oracle(orc, n, max_d, dmin, cols, chunk
     sg.set_option("ell_colblock_cols", cols)
     sg.set_option("ell_colblock_chunks", chunks)
     sg.set_option("ell_colblock_rows", rows)
+    sg.set_option("ell_colblock_band", band)
+    sg.set_option("ell_colblock_pieces", 7 if band in (512, 192) else 512)
     try:
         ei, ej, ev = P.random_regular_ell(n, max_d, 777 + n, dmin=dmin)
         A = orc.EllMatrix.from_edges(n, n, ei, ej, ev)
@@ -604,6 +612,8 @@ def test_ell_column_blocked_two_phase_vs_oracle(orc, n, max_d, dmin, cols, chunk
         sg.set_option("ell_colblock_cols", 16384)
         sg.set_option("ell_colblock_chunks", 16)
         sg.set_option("ell_colblock_rows", 0)
+        sg.set_option("ell_colblock_band", 0)
+        sg.set_option("ell_colblock_pieces", 512)
 
 
 @pytest.mark.parametrize("nparts", [2, 3, 5])
@@ -1698,6 +1708,8 @@ def test_pipeline_abort_is_loud_and_recovers(orc):
             pcw = sg.ldu(); pcw.setup(H)
             sw = sg.cg(1e-12); sw.setup(H)
             uw = np.zeros(n); sw.solve(H, uw, b, pcw)
+            sbw = sg.bicgstab(1e-12); sbw.setup(H)
+            ubw = np.zeros(n); sbw.solve(H, ubw, b, pcw)
         finally:
             sg.set_option("ildu_strips", 1)
         for mode in ("apply", "cg", "bicgstab"):
@@ -1719,8 +1731,7 @@ def test_pipeline_abort_is_loud_and_recovers(orc):
                 else:
                     s = sg.bicgstab(1e-12); s.setup(H)
                     u = np.zeros(n); s.solve(H, u, b, pc)
-                    ur, itr, _, _ = orc.bicgstab(A, b, pc=ref, tol=1e-12)
-                    assert s.converged and abs(s.iterations - itr) <= 3 and np.abs(u - ur).max() / np.abs(ur).max() <= 1e-10
+                    assert s.converged and s.iterations == sbw.iterations and np.array_equal(u, ubw), (which, mode, s.iterations, sbw.iterations)
             finally:
                 sg.set_option("pipeline_spin_limit", 0)
             assert pc.get("pipeline_retired", np.int32)[0] == 1, (which, mode)
