@@ -141,33 +141,49 @@ __global__ void k_ellcb_sample(int32_t n, int32_t max_d, int32_t step, const int
 }
 
 // ------------------------------------------------------------------------------ phase 1
-// One band: its sorted positions [bstart[0], bstart[nb]) are cut into gridDim.x equal pieces (even boundaries: 16-byte
-// accesses); workgroup p multiplies piece p, walking the column blocks the piece overlaps -- for each the x block goes to
-// LDS, then the block's entries inside the piece are streamed (value 8 B + column-inside-block 2 B), multiplied and
-// their products stored.  `P` is the product buffer shifted so that P[j] belongs to sorted position j (a band's
+// One band.  A workgroup multiplies a range of the band's sorted positions, walking the column blocks the range overlaps --
+// for each the x block goes to LDS, then the block's entries inside the range are streamed (value 8 B + column-inside-block
+// 2 B, U x 16-byte loads per lane in flight), multiplied and their products stored.  Ranges: chunk c of column block b
+// (chunks > 0, grid = nb * chunks) or equal pieces of the whole band (chunks = 0, even boundaries).  `P` is the product buffer shifted so that P[j] belongs to sorted position j (a band's
 // buffer is reused by the next band).  Pieces, not (block, chunk) pairs: any grid -- a multiple of the CU count -- is
 // balanced whatever the number of column blocks.  NT: nontemporal product stores (single-band form; the banded form
 // keeps them plain so that the products wait in the cache for phase 2).
-template <int TPB>
-__global__ __launch_bounds__(TPB) void k_ellcb_mul(int32_t ncol, int32_t cb, int32_t nb, const int32_t *__restrict__ bstart,
+template <int TPB, int U>
+__global__ __launch_bounds__(TPB) void k_ellcb_mul(int32_t ncol, int32_t cb, int32_t nb, int32_t chunks, const int32_t *__restrict__ bstart,
                                                    const double *__restrict__ sval, const uint16_t *__restrict__ lcol,
                                                    const double *__restrict__ x, double *__restrict__ P, int nt,
                                                    const int *__restrict__ flag_done, int gen)
 {
     extern __shared__ double xs[];
     if (flag_done) { const int st = *flag_done; if (st && gen >= st) return; }
-    const int64_t jlo = bstart[0], jhi = bstart[nb], len = jhi - jlo;
-    const int64_t np = gridDim.x, pc = blockIdx.x;
-    int64_t j0 = jlo + len * pc / np, j1 = jlo + len * (pc + 1) / np;
-    if (pc > 0) j0 = (j0 + 1) & ~(int64_t)1;
-    if (pc + 1 < np) j1 = (j1 + 1) & ~(int64_t)1;
-    if (j1 > jhi) j1 = jhi;
-    if (j0 >= j1) return;
-    // the column block holding position j0: the last b with bstart[b] <= j0
-    int32_t lo = 0, hi = nb - 1;
-    while (lo < hi) {
-        const int32_t mid = (lo + hi + 1) >> 1;
-        if ((int64_t)bstart[mid] <= j0) lo = mid; else hi = mid - 1;
+    int64_t j0, j1;
+    int32_t lo;
+    if (chunks > 0) {
+        // (column block, chunk) pairs: grid = nb * chunks, every workgroup loads exactly one x block (one-band form)
+        lo = blockIdx.x / chunks;
+        const int32_t c = blockIdx.x % chunks;
+        const int64_t j0b = bstart[lo], j1b = bstart[lo + 1], len = j1b - j0b;
+        j0 = j0b + (len * c / chunks); j1 = j0b + (len * (c + 1) / chunks);
+        if (c > 0) j0 = (j0 + 1) & ~(int64_t)1;
+        if (c + 1 < chunks) j1 = (j1 + 1) & ~(int64_t)1;
+        if (j1 > j1b) j1 = j1b;
+        if (j0 >= j1) return;
+    } else {
+        // equal pieces of the band's positions (banded form: any grid is balanced whatever the number of column blocks)
+        const int64_t jlo = bstart[0], jhi = bstart[nb], len = jhi - jlo;
+        const int64_t np = gridDim.x, pc = blockIdx.x;
+        j0 = jlo + len * pc / np; j1 = jlo + len * (pc + 1) / np;
+        if (pc > 0) j0 = (j0 + 1) & ~(int64_t)1;
+        if (pc + 1 < np) j1 = (j1 + 1) & ~(int64_t)1;
+        if (j1 > jhi) j1 = jhi;
+        if (j0 >= j1) return;
+        // the column block holding position j0: the last b with bstart[b] <= j0
+        lo = 0;
+        int32_t hi = nb - 1;
+        while (lo < hi) {
+            const int32_t mid = (lo + hi + 1) >> 1;
+            if ((int64_t)bstart[mid] <= j0) lo = mid; else hi = mid - 1;
+        }
     }
     for (int32_t b = lo; j0 < j1 && b < nb; ++b) {
         const int64_t jz = min(j1, (int64_t)bstart[b + 1]);
@@ -190,7 +206,6 @@ __global__ __launch_bounds__(TPB) void k_ellcb_mul(int32_t ncol, int32_t cb, int
         const f64x2c *v2 = reinterpret_cast<const f64x2c *>(sval + ja);
         const uint32_t *c2 = reinterpret_cast<const uint32_t *>(lcol + ja);
         f64x2c *p2 = reinterpret_cast<f64x2c *>(P + ja);
-        constexpr int U = 4;
         int64_t q = threadIdx.x;
         for (; q + (int64_t)(U - 1) * TPB < npair; q += (int64_t)U * TPB) {
             f64x2c v[U];
@@ -335,8 +350,11 @@ bool use_ell_colblock(const Part &p) { return p.cb_P != nullptr && g_opt.ell_col
 // workgroups of one band's sum launch; the fused dots leave one partial sum per (band, workgroup)
 static int band_grid(const Part &p)
 {
-    const int tiles_per_band = p.cb_RB / p.cb_R;
-    return std::max(1, std::min(std::min(p.cb_ntiles, tiles_per_band), std::min(cb_cfg().grid2, kMaxGrid / std::max(1, p.cb_nbands))));
+    const int tiles = std::min(p.cb_ntiles, p.cb_RB / p.cb_R);
+    int cap = std::min(cb_cfg().grid2, kMaxGrid / std::max(1, p.cb_nbands));
+    // fewer workgroups than tiles: a whole number of rounds over the CUs (one 128 KiB image per CU), so that no CU walks a tile more
+    if (p.cb_nbands > 1 && tiles > cap && cap >= g_rt.num_cu) cap = cap / g_rt.num_cu * g_rt.num_cu;
+    return std::max(1, std::min(tiles, cap));
 }
 int ell_colblock_grid(const Part &p) { return band_grid(p) * std::max(1, p.cb_nbands); }
 
@@ -441,7 +459,8 @@ int build_ell_colblock(Part &p)
     hipLaunchKernelGGL(k_ellcb_runs, dim3((unsigned)((nruns + 255) / 256)), dim3(256), 0, st, ntiles, nb, R, (int32_t)RB, p.max_d,
                        (const int32_t *)p.cb_bstart, (const int32_t *)p.cb_perm, fdesc);
     hipLaunchKernelGGL(k_ellcb_bases, dim3((ntiles + 255) / 256), dim3(256), 0, st, ntiles, nb, fdesc);
-    SGM_TRY(dalloc(&p.cb_lpos, (size_t)total + 2));
+    const size_t lpos_count = (size_t)total;
+    SGM_TRY(dalloc(&p.cb_lpos, lpos_count + 2));
     hipLaunchKernelGGL(k_ellcb_lpos, dim3(vec_grid(total)), dim3(kBlock), 0, st, total, p.n, p.max_d, cb, nb, R,
                        (const int32_t *)p.cb_perm, (const int32_t *)p.ecol, (const int2 *)fdesc, p.cb_lpos);
     SGM_TRY(dalloc(&p.cb_P, (size_t)std::min<int64_t>(total, RB * p.max_d) + 2));       // ONE band's products
@@ -479,10 +498,10 @@ int launch_ell_colblock(const Part &p, int grid, const double *x, double *y, boo
 {
     const CbCfg c = cb_cfg();
     hipStream_t st = g_rt.stream;
-    constexpr int TPB1 = 512;
+    constexpr int TPB1 = 512, U1 = 4;      // (1024 threads x 4: 571 us on C4 against 559: the stream is not short of loads in flight)
     static bool attr_set = false;
     if (!attr_set) {       // more than 64 KiB of dynamic LDS needs the attribute (160 KiB per CU on gfx950)
-        SGM_HIP(hipFuncSetAttribute((const void *)k_ellcb_mul<TPB1>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+        SGM_HIP(hipFuncSetAttribute((const void *)k_ellcb_mul<TPB1, U1>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
         attr_set = true;
     }
     const int nbands = std::max(1, p.cb_nbands);
@@ -495,8 +514,8 @@ int launch_ell_colblock(const Part &p, int grid, const double *x, double *y, boo
     for (int g = 0; g < nbands; ++g) {
         const int64_t band_first = (int64_t)g * p.cb_RB * p.max_d;      // first sorted position of the band (every row holds max_d slots)
         double *Pj = p.cb_P - band_first;
-        hipLaunchKernelGGL((k_ellcb_mul<TPB1>), dim3(pieces), dim3(TPB1), (size_t)p.cb_cols * 8, st, p.ncol_own, p.cb_cols, p.cb_nb,
-                           (const int32_t *)p.cb_bstart + (int64_t)g * p.cb_nb, (const double *)p.cb_sval, (const uint16_t *)p.cb_lcol, x,
+        hipLaunchKernelGGL((k_ellcb_mul<TPB1, U1>), dim3(pieces), dim3(TPB1), (size_t)p.cb_cols * 8, st, p.ncol_own, p.cb_cols, p.cb_nb,
+                           nbands > 1 ? 0 : c.chunks, (const int32_t *)p.cb_bstart + (int64_t)g * p.cb_nb, (const double *)p.cb_sval, (const uint16_t *)p.cb_lcol, x,
                            Pj, nt, flag, gen);
         const int32_t t0 = g * tiles_per_band, t1 = std::min(p.cb_ntiles, t0 + tiles_per_band);
         double *pw = pwy ? pwy + (int64_t)g * gb : nullptr, *py = pyy ? pyy + (int64_t)g * gb : nullptr;
@@ -525,7 +544,7 @@ int64_t ell_colblock_matvec_bytes(const Part &p)
     const int64_t total = (int64_t)p.n * p.max_d, nruns = (int64_t)p.cb_ntiles * p.cb_nb;
     // what the two phases move by construction, wherever it is served from (with row bands the products' 16 B per entry are
     // meant to be served by the Infinity Cache: the PMC pass tells)
-    const int64_t xloads = p.cb_nbands > 1 ? (int64_t)p.cb_nbands * (g_opt.ell_colblock_pieces + p.cb_nb) : (int64_t)p.cb_nb * cb_cfg().chunks;
+    const int64_t xloads = p.cb_nbands > 1 ? (int64_t)p.cb_nbands * (g_opt.ell_colblock_pieces + p.cb_nb) : (int64_t)p.cb_nb * cb_cfg().chunks;   // (pieces straddle blocks)
     return total * (8 + 2 + 8) + xloads * p.cb_cols * 8                                  // phase 1: values, columns, products, x blocks
          + total * (8 + 2) + nruns * 8 + 8 * (int64_t)p.n;                              // phase 2: products, positions, run tables, y
 }

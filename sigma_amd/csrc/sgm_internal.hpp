@@ -42,7 +42,7 @@ struct Options {
     int ell_colblock_cols = 16384; // its column block (x entries staged in LDS per workgroup; even, <= 16384)
     int ell_colblock_rows = 0;     // rows per tile of its sum phase: 0 automatic, 256 or 512
     int ell_colblock_chunks = 16;  // workgroups per column block in the multiply phase (C4 sweep: 4 / 8 / 16 -> 1.32 / 1.31 / 1.27 ms)
-    int ell_colblock_band = 0;     // rows per band of the two-phase product: 0 automatic (products + streams of a band <= ~160 MB), -1 one band, else rows (rounded to tiles)
+    int ell_colblock_band = -1;    // rows per band of the two-phase product: -1 one band (default: bands measured slower), 0 automatic (products + streams of a band <= ~160 MB), else rows (rounded to tiles)
     int ell_colblock_pieces = 512; // workgroups of the multiply phase per band (banded form)
     int ell_colblock_nt = 0;       // banded form: 1 = nontemporal product stores / loads (0: plain, so that the products stay cached)
     int ildu_strips = 1;           // ILDU(0) factors of grid-like matrices (deps r-1, r-w): strip-pipelined triangular solves

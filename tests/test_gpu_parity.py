@@ -612,7 +612,7 @@ def test_ell_column_blocked_two_phase_vs_oracle(orc, n, max_d, dmin, cols, chunk
         sg.set_option("ell_colblock_cols", 16384)
         sg.set_option("ell_colblock_chunks", 16)
         sg.set_option("ell_colblock_rows", 0)
-        sg.set_option("ell_colblock_band", 0)
+        sg.set_option("ell_colblock_band", -1)
         sg.set_option("ell_colblock_pieces", 512)
 
 
