@@ -71,6 +71,10 @@ def parse_args():
     ap.add_argument("--c5-cg-steps", type=int, default=200)
     ap.add_argument("--force-dist", action="store_true",
                     help="take the RCCL row-partition code path even with one rank (testing aid)")
+    ap.add_argument("--halo-comm", action="store_true",
+                    help="N > 1: a second RCCL communicator for the halo send/recv pairs (A/B switch for halo / all-reduce overlap)")
+    ap.add_argument("--no-dist-overhead", action="store_true",
+                    help="N = 1: skip the `dist_overhead_1rank` leg (CG through the RCCL code path with one rank)")
     return ap.parse_args()
 
 
@@ -83,14 +87,18 @@ def spawn_ranks(args):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    import tempfile
     procs = []
+    # rank 0's line goes through a temporary FILE, not a pipe: nothing a child prints can fill a pipe buffer and block it
+    # while this parent waits for it to exit
+    cap = tempfile.TemporaryFile()
     for r in range(args.gpus):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "SGM_BENCH_CHILD": "1"})
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+                                      stdout=cap if r == 0 else subprocess.DEVNULL))
     # if one rank dies the others would wait in a collective for ever: end them (by PID) after a grace period
     deadline = None
     while any(p.poll() is None for p in procs):
@@ -102,13 +110,15 @@ def spawn_ranks(args):
                 if p.poll() is None:
                     p.kill()
         time.sleep(0.05)
-    out = procs[0].stdout.read().decode() if procs[0].stdout else ""
     for p in procs:
         try:
             p.wait(timeout=60)
         except subprocess.TimeoutExpired:
             p.kill()
             p.wait()
+    cap.seek(0)
+    out = cap.read().decode()
+    cap.close()
     sys.stdout.write(out)
     sys.stdout.flush()
     rcs = [p.returncode for p in procs]
@@ -184,9 +194,9 @@ def worker(args):
 
     comm = None
     if use_dist:
-        uid = [sg.Comm.unique_id() if rank == 0 else None]
+        uid = [sg.Comm.unique_id() if rank == 0 else None, sg.Comm.unique_id() if (rank == 0 and args.halo_comm) else None]
         dist.broadcast_object_list(uid, src=0)
-        comm = sg.Comm(rank, world, uid[0])
+        comm = sg.Comm(rank, world, uid[0], uid[1])
 
     def make_matrix(kind):
         """(A, n_loc, n_glob, i0, nnz, label, host_arrays)"""
@@ -266,7 +276,7 @@ def worker(args):
         torch.cuda.synchronize()
         return float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e-3
 
-    def cg_run(A, n_loc, n_glob, its_cap):
+    def cg_run(A, n_loc, n_glob, its_cap, profile_phases=False):
         s = sg.cg(1e-300)
         s.set_max_iter(its_cap)
         s.setup(A)
@@ -280,8 +290,20 @@ def worker(args):
         barrier()
         dtc = max_over_ranks(time.perf_counter() - t0)
         its, res2 = s.last_iterations, s.res2
+        phases = None
+        if profile_phases:
+            # a THIRD solve with the library's HIP-event phase timers on (kept out of the timed one: ~14 event records per
+            # iteration): where an iteration's time goes on this rank, and the slowest rank's figure per phase
+            u.zero_()
+            sg.dist_profile(True)
+            s.solve(A, u, bvec, check=False)
+            pr = sg.dist_profile_read()
+            sg.dist_profile(False)
+            n_it = max(1, s.last_iterations)
+            phases = {nm: {"ms_per_iter_rank0": v["ms"] / n_it, "ms_per_iter_max_over_ranks": max_over_ranks(v["ms"] / n_it),
+                           "events_per_iter": v["count"] / n_it} for nm, v in pr.items()}
         s.destroy()
-        return its, dtc, res2
+        return its, dtc, res2, phases
 
     # ---- the workload of the timed steps -----------------------------------------------------
     A, n_loc, n_glob, i0, nnz, label, host = make_matrix(args.workload)
@@ -365,7 +387,7 @@ def worker(args):
     # ---- CG iterations/s (device-resident loop, fixed iteration count) -----------------------
     cg = None
     if args.cg_steps > 0:
-        its, dtc, res2 = cg_run(A, n_loc, n_glob, args.cg_steps)
+        its, dtc, res2, cg_phases = cg_run(A, n_loc, n_glob, args.cg_steps, profile_phases=use_dist)
         # moved per iteration: the SpMV's bytes + 8 vector passes (q written by the SpMV is counted there;
         # r-update reads r,q writes r; x/p update reads x,p,r writes x,p) = 64 n;
         # SURVEY §8d grades on the fused floor B_csr + 72 n of the REFERENCE layout -- both reported
@@ -374,7 +396,13 @@ def worker(args):
         cg = {"iters_per_s": its / dtc, "iterations": its, "ms_per_iter": 1e3 * dtc / its,
               "moved_bytes_per_iter": moved_it, "GB/s_moved": moved_it * its / dtc / 1e9,
               "frac_of_hbm_peak": moved_it * its / dtc / 1e9 / (HBM_PEAK_GBS * world),
-              "effective_GBs_on_survey_floor": floor_it * its / dtc / 1e9, "final_res2": res2}
+              "effective_GBs_on_survey_floor": floor_it * its / dtc / 1e9, "final_res2": res2,
+              "phases": cg_phases}
+
+    # ---- N = 1: the fixed cost of the RCCL code path (real librccl, ONE rank) on the same matrix ----------------
+    dist_overhead = None
+    if rank == 0 and world == 1 and not use_dist and not args.no_dist_overhead and args.cg_steps > 0 and args.workload == "c2":
+        dist_overhead = dist_overhead_leg(args, sg, torch, dev, cg["iters_per_s"] if cg else None)
 
     # ---- CPU baseline (rank 0, N = 1): the reference itself on the SAME matrix ----------------
     cpu = None
@@ -410,7 +438,7 @@ def worker(args):
         dt5 = max_over_ranks(time.perf_counter() - t0) / 20
         _, mv5 = A5.footprint()
         mv5_all = sum_over_ranks(mv5)
-        its5, dtc5, res25 = cg_run(A5, n5, n5g, args.c5_cg_steps)
+        its5, dtc5, res25, phases5 = cg_run(A5, n5, n5g, args.c5_cg_steps, profile_phases=use_dist)
         moved5 = sum_over_ranks(mv5 + 64 * n5)
         c5 = {"workload": label5, "n": n5g, "nnz": int(sum_over_ranks(nnz5)), "kernel": A5.kernel,
               "spmv_ms": 1e3 * dt5, "spmv_GB/s_moved": mv5_all / dt5 / 1e9,
@@ -419,6 +447,7 @@ def worker(args):
               "cg_GB/s_moved": moved5 * its5 / dtc5 / 1e9,
               "cg_frac_of_hbm_peak": moved5 * its5 / dtc5 / 1e9 / (HBM_PEAK_GBS * world),
               "cg_final_res2": res25, "scaling": "strong", "product_bit_exact_on_every_rank": check_c5,
+              "phases": phases5, "halo_comm": bool(args.halo_comm),
               "note": "north_star target: cg_iters_per_s at n_gpus = 8 >= 6 x the n_gpus = 1 figure"}
         A5.destroy()
 
@@ -457,7 +486,7 @@ def worker(args):
                          "note": "achieved = moved_bytes_per_launch / avg_launch_ms: the sliced kernel reads 8W+4 bytes per "
                                  "row of its own layout (W = 5) + x once + y once.  cold_* = the same launch after 512 MiB "
                                  "of unrelated writes (nothing of the previous product left in L2 / Infinity Cache)"},
-            "spmv_variants": variants or None, "cg": cg, "c5_strong_scaling": c5, "c1_reference_sized": c1, "cpu_baseline": cpu,
+            "spmv_variants": variants or None, "cg": cg, "dist_overhead_1rank": dist_overhead, "c5_strong_scaling": c5, "c1_reference_sized": c1, "cpu_baseline": cpu,
             "selfcheck": {"product_bit_exact_on_every_rank": check_main,
                           "what": "every local row of one timed-workload product == its sum evaluated with torch in stored "
                                   "order from x(i) = sin(0.001 i), on every rank (halo values included)"},
@@ -469,6 +498,55 @@ def worker(args):
         dist.destroy_process_group()
     if not check_main or (c5 is not None and not c5["product_bit_exact_on_every_rank"]):
         sys.exit(3)          # a product that differs is not a measurement
+
+
+# ------------------------------------------------------------------------------------------ #
+def dist_overhead_leg(args, sg, torch, dev, plain_iters_per_s):
+    """CG on the workload matrix through the row-partition code path with ONE rank over the real librccl: the matrix is
+    a `dist_csr_matrix` (no neighbours), every dot goes partial sums -> one-block reduce -> ncclAllReduce (forced with one
+    rank: option dist_force_collectives) -> slot.  Beside the plain path's figure this is the fixed per-iteration cost the
+    distributed path adds before any other GPU takes part.  Never takes the bench line down."""
+    import numpy as np
+    out = {"what": "CG iterations/s on the same matrix through sgm_csr_create_dist + ncclAllReduce with one rank (real librccl) "
+                   "vs the plain single-GPU path"}
+    try:
+        comm = sg.Comm(0, 1, sg.Comm.unique_id())
+        arrays = local_rows_poisson2d(args.nx, args.ny, 1, 0)
+        n_loc = args.nx * args.ny
+        A = sg.dist_csr_matrix(comm, np.array([0, n_loc], np.int64), *arrays)
+        sg.set_option("dist_force_collectives", 1)
+        try:
+            s = sg.cg(1e-300)
+            s.set_max_iter(args.cg_steps)
+            s.setup(A)
+            b = torch.full((n_loc,), 1.0 / n_loc, dtype=torch.float64, device=dev)
+            u = torch.zeros(n_loc, dtype=torch.float64, device=dev)
+            s.solve(A, u, b, check=False)
+            u.zero_()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            s.solve(A, u, b, check=False)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            its = s.last_iterations
+            u.zero_()
+            sg.dist_profile(True)
+            s.solve(A, u, b, check=False)
+            pr = sg.dist_profile_read()
+            sg.dist_profile(False)
+            out.update({"iters_per_s_dist_path": its / dt, "ms_per_iter_dist_path": 1e3 * dt / its, "iterations": its,
+                        "iters_per_s_plain_path": plain_iters_per_s,
+                        "overhead_us_per_iter": (1e6 * dt / its - 1e6 / plain_iters_per_s) if plain_iters_per_s else None,
+                        "phases": {nm: {"ms_per_iter": v["ms"] / max(1, its), "events_per_iter": v["count"] / max(1, its)}
+                                   for nm, v in pr.items()}})
+            s.destroy()
+        finally:
+            sg.set_option("dist_force_collectives", 0)
+        A.destroy()
+        comm.destroy()
+    except Exception as e:
+        out["error"] = str(e)[:300]
+    return out
 
 
 # ------------------------------------------------------------------------------------------ #

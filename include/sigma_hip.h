@@ -109,6 +109,8 @@ int sgm_synchronize(void);
  * "bicgstab_small" (default 1): BiCGStab (plain or Jacobi-preconditioned) on a single-GPU CSR / structured ELLPACK matrix of at
  * most 4096 rows runs as ONE workgroup, like "cg_small" (the reference's own test size, n = 1024: 24.5 -> ~11 us per
  * iteration); in tree order its iteration count may differ from the launch loop's by a few.
+ * "dist_force_collectives" (default 0): 1 = a matrix distributed over ONE rank still issues its all-reduces (the fixed cost of
+ * the RCCL code path, measurable on a single-GPU box: bench.py's `dist_overhead_1rank`).
  * "pipeline_spin_limit" (default 0 = built-in, 2^22 polls): how often a wait inside the strip- / slab-pipelined ILDU sweeps
  * polls before it gives up.  A sweep that gives up is never returned: sgm_pc_apply and the solvers notice (a sticky
  * device word read at their next synchronisation), redo the work with the level-scheduled sweeps and retire the pipeline
@@ -308,6 +310,16 @@ int sgm_generalized_lanczos(sgm_mat A, sgm_mat B, sgm_solver solver_for_B, sgm_p
 int sgm_comm_unique_id(void *id128);
 int sgm_comm_init(sgm_comm *out, int rank, int nranks, const void *id128);
 int sgm_comm_destroy(sgm_comm c);
+/* sgm_comm_attach_halo_comm: a SECOND communicator (its own 128-byte id, broadcast like the first) for the halo send / recv
+ * pairs, so that they do not share a queue with the dots' all-reduces -- an A/B switch for the overlap of halo traffic
+ * with interior rows on a multi-GPU node.  Optional; without it one communicator carries both.
+ * sgm_dist_profile(on) / sgm_dist_profile_read: HIP-event timers around the phases of the row-partitioned path, summed
+ * since the last read: ms_out[6] / count_out[6] = { halo gather + send/recv on the communication stream (post -> done),
+ * interior-rows kernel(s), what the launch stream then still waits for the halo, boundary-rows kernel(s),
+ * per-dot partial -> slot reduction kernels, all-reduces }.  Reading synchronises the library's streams.           */
+int sgm_comm_attach_halo_comm(sgm_comm c, const void *id128);
+int sgm_dist_profile(int on);
+int sgm_dist_profile_read(double *ms_out /* 6 */, int64_t *count_out /* 6 */);
 int sgm_csr_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts /* nranks+1, 0-based */,
                         int64_t nnz_local, const int32_t *ptr_1based_local,
                         const int32_t *node_1based_global, const double *val, int where);

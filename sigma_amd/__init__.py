@@ -723,11 +723,14 @@ def gmres(tolerance=None, restart=30):
 class Comm:
     """RCCL communicator for the row partition (one process per GPU)."""
 
-    def __init__(self, rank, nranks, unique_id):
+    def __init__(self, rank, nranks, unique_id, halo_unique_id=None):
         self._h = C.c_void_p()
         self.rank, self.nranks = int(rank), int(nranks)
         buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
         _ck(lib().sgm_comm_init(C.byref(self._h), C.c_int(rank), C.c_int(nranks), buf))
+        if halo_unique_id is not None:        # a second communicator for the halo send / recv pairs
+            buf2 = (C.c_char * 128).from_buffer_copy(bytes(halo_unique_id))
+            _ck(lib().sgm_comm_attach_halo_comm(self._h, buf2))
 
     @staticmethod
     def unique_id():
@@ -739,6 +742,22 @@ class Comm:
         if self._h:
             _ck(lib().sgm_comm_destroy(self._h))
             self._h = C.c_void_p()
+
+
+DIST_PHASES = ("halo_post_to_done", "interior_rows", "halo_wait_exposed", "boundary_rows", "dot_reduce_kernels", "allreduce")
+
+
+def dist_profile(on):
+    """Switch the phase timers of the row-partitioned path on / off (and clear them)."""
+    _ck(lib().sgm_dist_profile(C.c_int(1 if on else 0)))
+
+
+def dist_profile_read():
+    """{phase: {"ms": total, "count": spans}} since the last read (synchronises the library's streams)."""
+    ms = (C.c_double * 6)()
+    cnt = (C.c_int64 * 6)()
+    _ck(lib().sgm_dist_profile_read(ms, cnt))
+    return {nm: {"ms": float(ms[k]), "count": int(cnt[k])} for k, nm in enumerate(DIST_PHASES)}
 
 
 def lanczos(A, nsteps, q1, want_Q=True):

@@ -83,13 +83,48 @@ static int load_rccl()
                              g_nccl.GetErrorString ? g_nccl.GetErrorString(r__) : "?");  \
     } while (0)
 
+// ------------------------------------------------------------------ phase timers
+namespace {
+struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> pool;            // every event ever created (reused after a read)
+    size_t used = 0;
+    struct Span { int phase; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    hipEvent_t open[PH_COUNT] = {nullptr};
+} g_prof;
+}  // namespace
+bool prof_on() { return g_prof.on; }
+hipEvent_t prof_event(hipStream_t st)
+{
+    if (!g_prof.on) return nullptr;
+    if (g_prof.used == g_prof.pool.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        g_prof.pool.push_back(e);
+    }
+    hipEvent_t e = g_prof.pool[g_prof.used++];
+    (void)hipEventRecord(e, st);
+    return e;
+}
+void prof_begin(int phase, hipStream_t st) { if (g_prof.on) g_prof.open[phase] = prof_event(st); }
+void prof_end(int phase, hipStream_t st)
+{
+    if (!g_prof.on || !g_prof.open[phase]) return;
+    hipEvent_t b = prof_event(st);
+    if (b) g_prof.spans.push_back({phase, g_prof.open[phase], b});
+    g_prof.open[phase] = nullptr;
+}
+void prof_span(int phase, hipEvent_t a, hipEvent_t b) { if (g_prof.on && a && b) g_prof.spans.push_back({phase, a, b}); }
+
 // ------------------------------------------------------------------ halo exchange
 int halo_exchange(sgm_mat A, double *const *xext, hipStream_t st)
 {
     if (A->comm) {
         Part &p = A->parts[0];
         if (p.nbrs.empty()) return SGM_OK;
-        ncclComm_t comm = (ncclComm_t)A->comm->nccl;
+        // (a second communicator, when one was attached, keeps the halo pairs out of the queue the dots' all-reduces use)
+        ncclComm_t comm = (ncclComm_t)(A->comm->nccl_halo ? A->comm->nccl_halo : A->comm->nccl);
         for (auto &nb : p.nbrs)
             if (nb.send_count)
                 hipLaunchKernelGGL(k_gather, dim3((nb.send_count + kBlock - 1) / kBlock), dim3(kBlock), 0,
@@ -128,6 +163,9 @@ __global__ void k_sum_parts(double *const *slots, int nparts, int count)
     for (int p = 0; p < nparts; ++p) slots[p][t] = s;
 }
 
+// testing aid (option "dist_force_collectives"): with ONE rank the all-reduce is still issued, so that the fixed cost of the
+// RCCL code path can be measured on a single-GPU box
+int g_force_collectives = 0;
 static double **g_slot_ptrs_dev = nullptr;
 static size_t g_slot_ptrs_cap = 0;
 
@@ -135,9 +173,11 @@ int allreduce_slots(sgm_mat A, double *const *slot_ptrs, int count)
 {
     hipStream_t st = g_rt.stream;
     if (A->comm) {
-        if (A->comm->nranks == 1) return SGM_OK;
+        if (A->comm->nranks == 1 && !g_force_collectives) return SGM_OK;
+        prof_begin(PH_ALLREDUCE, st);
         SGM_NCCL(g_nccl.AllReduce(slot_ptrs[0], slot_ptrs[0], (size_t)count, ncclFloat64, ncclSum,
                                   (ncclComm_t)A->comm->nccl, st));
+        prof_end(PH_ALLREDUCE, st);
         return SGM_OK;
     }
     const size_t P = A->parts.size();
@@ -460,9 +500,54 @@ int sgm_comm_init(sgm_comm *out, int rank, int nranks, const void *id128)
     return SGM_OK;
 }
 
+int sgm_comm_attach_halo_comm(sgm_comm c, const void *id128)
+{
+    SGM_TRY(require_init());
+    SGM_TRY(load_rccl());
+    if (!c || !id128) return fail(SGM_ERR_BAD_ARG, "sgm_comm_attach_halo_comm: bad argument");
+    if (c->nccl_halo) return fail(SGM_ERR_BAD_ARG, "sgm_comm_attach_halo_comm: a halo communicator is attached already");
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    ncclComm_t h = nullptr;
+    SGM_NCCL(g_nccl.CommInitRank(&h, c->nranks, id, c->rank));
+    c->nccl_halo = h;
+    return SGM_OK;
+}
+
+int sgm_dist_profile(int on)
+{
+    SGM_TRY(require_init());
+    if (g_rt.comm_stream) SGM_HIP(hipStreamSynchronize(g_rt.comm_stream));
+    SGM_HIP(hipStreamSynchronize(g_rt.stream));
+    g_prof.on = on != 0;
+    g_prof.used = 0;
+    g_prof.spans.clear();
+    for (auto &e : g_prof.open) e = nullptr;
+    return SGM_OK;
+}
+
+int sgm_dist_profile_read(double *ms_out, int64_t *count_out)
+{
+    SGM_TRY(require_init());
+    if (!ms_out || !count_out) return fail(SGM_ERR_BAD_ARG, "sgm_dist_profile_read: null argument");
+    if (g_rt.comm_stream) SGM_HIP(hipStreamSynchronize(g_rt.comm_stream));
+    SGM_HIP(hipStreamSynchronize(g_rt.stream));
+    for (int k = 0; k < PH_COUNT; ++k) { ms_out[k] = 0.0; count_out[k] = 0; }
+    for (const auto &sp : g_prof.spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) != hipSuccess) { (void)hipGetLastError(); continue; }
+        ms_out[sp.phase] += ms > 0.f ? (double)ms : 0.0;
+        count_out[sp.phase] += 1;
+    }
+    g_prof.used = 0;
+    g_prof.spans.clear();
+    return SGM_OK;
+}
+
 int sgm_comm_destroy(sgm_comm c)
 {
     if (!c) return SGM_OK;
+    if (c->nccl_halo && g_nccl.CommDestroy) (void)g_nccl.CommDestroy((ncclComm_t)c->nccl_halo);
     if (c->nccl && g_nccl.CommDestroy) (void)g_nccl.CommDestroy((ncclComm_t)c->nccl);
     delete c;
     return SGM_OK;

@@ -119,7 +119,7 @@ struct HaloNbr {
 
 // Slice schedule of the sliced kernels (sgm_spmv.hip, slice_sched): the order in which the workgroups of every XCD
 // take the 512-row slices of one row range; tab[it * grid + workgroup] = slice or -1
-struct SliceSched { int32_t *tab = nullptr; int32_t lo = 0, hi = 0, grid = 0, iters = 0; };
+struct SliceSched { int32_t *tab = nullptr; int32_t lo = 0, hi = 0, grid = 0, iters = 0, band = 0; };
 
 struct Part {
     int32_t n = 0;                 // owned rows
@@ -180,6 +180,7 @@ struct Part {
 struct sgm_comm_s {
     int rank = 0, nranks = 1;
     void *nccl = nullptr;          // ncclComm_t
+    void *nccl_halo = nullptr;     // optional second communicator: the halo send / recv pairs (sgm_comm_attach_halo_comm)
 };
 
 struct sgm_mat_s {
@@ -210,6 +211,16 @@ int matvec_t_dist(sgm_mat A, const double *x, double *y, int where, bool add);
 int halo_exchange(sgm_mat A, double *const *xext, hipStream_t st);
 // sum `count` scalar slots across parts / ranks (in place, every part gets the total)
 int allreduce_slots(sgm_mat A, double *const *slot_ptrs, int count);
+
+// Phase timers of the row-partitioned path (sgm_dist_profile): HIP events around the phases of every product and dot, so
+// that a multi-GPU run says where an iteration's time goes.  Off: no event is recorded.
+enum { PH_HALO = 0, PH_INTERIOR = 1, PH_HALO_WAIT = 2, PH_BOUNDARY = 3, PH_DOT_REDUCE = 4, PH_ALLREDUCE = 5, PH_COUNT = 6 };
+struct PhaseMark { hipEvent_t a = nullptr, b = nullptr; };
+bool prof_on();
+void prof_begin(int phase, hipStream_t st);              // records the phase's start event on st
+void prof_end(int phase, hipStream_t st);                // ... and its end event
+hipEvent_t prof_event(hipStream_t st);                   // a pooled event recorded on st now (null when off)
+void prof_span(int phase, hipEvent_t a, hipEvent_t b);   // a phase between two already recorded events
 
 // dot_order = 1 across ranks: one running sum (a device double) travels rank 0 -> 1 -> ... -> R-1, every rank continuing it over its
 // own rows in between; seq_chain_recv takes delivery from rank-1 (no-op on rank 0), seq_chain_share passes it on to rank+1

@@ -8,6 +8,7 @@ namespace sgm {
 std::string g_err;
 Runtime g_rt;
 Options g_opt;
+extern int g_force_collectives;     // sgm_dist.hip
 
 int fail(int code, const char *fmt, ...)
 {
@@ -178,6 +179,7 @@ int sgm_set_option(const char *name, int value)
         g_opt.dot_order = value;
         return SGM_OK;
     }
+    if (!strcmp(name, "dist_force_collectives")) { g_force_collectives = value != 0; return SGM_OK; }
     if (!strcmp(name, "bicgstab_small")) { g_opt.bicgstab_small = value; return SGM_OK; }
     if (!strcmp(name, "pipeline_spin_limit")) { g_opt.pipeline_spin_limit = std::max(0, value); return SGM_OK; }
     return fail(SGM_ERR_BAD_ARG, "sgm_set_option: unknown option '%s'", name);

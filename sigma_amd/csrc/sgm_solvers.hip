@@ -989,10 +989,12 @@ int finish_dots(sgm_solver s, sgm_mat A, const int *ks, int nk, const int (*vecs
     }
     if (!s->multi) return SGM_OK;
     // slots ks[] must be contiguous for the all-reduce: callers pass consecutive ids
+    prof_begin(PH_DOT_REDUCE, g_rt.stream);
     for (size_t ip = 0; ip < s->work.size(); ++ip)
         for (int t = 0; t < nk; ++t)
             hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, g_rt.stream, part(s, ip, ks[t]),
                                s->work[ip].count[ks[t]], s->work[ip].slots + ks[t]);
+    prof_end(PH_DOT_REDUCE, g_rt.stream);
     std::vector<double *> ptrs(s->work.size());
     for (size_t ip = 0; ip < s->work.size(); ++ip) ptrs[ip] = s->work[ip].slots + ks[0];
     return allreduce_slots(A, ptrs.data(), ks[nk - 1] - ks[0] + 1);

@@ -1409,11 +1409,14 @@ static const SliceSched *slice_sched(const Part &p, int32_t lo, int32_t hi, int 
     if (!g_opt.slice_sched || p.sched_period < 32 * kSlRows || grid < 8 || grid % 8) return nullptr;
     const int64_t nsl = ((int64_t)hi - lo + kSlRows - 1) / kSlRows;
     if (nsl < 2 * (int64_t)grid || 2 * (int64_t)p.sched_period > (int64_t)hi - lo) return nullptr;
+    // (a schedule built for another band width is stale: "slice_sched_band" may change between products)
+    for (int i = 0; i < p.nsched; ++i)
+        if (p.sched[i].band != g_opt.slice_sched_band) { free_slice_sched(const_cast<Part &>(p)); break; }
     for (int i = 0; i < p.nsched; ++i)
         if (p.sched[i].lo == lo && p.sched[i].hi == hi && p.sched[i].grid == grid) return p.sched[i].tab ? &p.sched[i] : nullptr;
     if (p.nsched >= 3) return nullptr;
     SliceSched &ss = p.sched[p.nsched++];
-    ss.lo = lo; ss.hi = hi; ss.grid = grid; ss.tab = nullptr;
+    ss.lo = lo; ss.hi = hi; ss.grid = grid; ss.tab = nullptr; ss.band = g_opt.slice_sched_band;
     std::vector<int32_t> tab;
     int iters = 0;
     slice_sched_table(nsl, p.sched_period, grid, g_opt.slice_sched_band, tab, iters);
@@ -1493,11 +1496,24 @@ int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
         }
         SGM_HIP(hipEventRecord(g_rt.ev_x_ready, g_rt.stream));
         SGM_HIP(hipStreamWaitEvent(g_rt.comm_stream, g_rt.ev_x_ready, 0));
+        prof_begin(PH_HALO, g_rt.comm_stream);           // gather kernels + grouped send / recv, post -> done
         SGM_TRY(halo_exchange(A, const_cast<double *const *>(x), g_rt.comm_stream));
+        prof_end(PH_HALO, g_rt.comm_stream);
         SGM_HIP(hipEventRecord(g_rt.ev_halo_done, g_rt.comm_stream));
     }
+    hipEvent_t ev_int_end = nullptr;
     for (int pass = 0; pass < 2; ++pass) {          // pass 0: ranges that need no halo; pass 1: the rest
+        if (exchange && prof_on()) {
+            if (pass == 0) prof_begin(PH_INTERIOR, g_rt.stream);
+            else { prof_end(PH_INTERIOR, g_rt.stream); ev_int_end = prof_event(g_rt.stream); }
+        }
         if (pass == 1 && exchange) SGM_HIP(hipStreamWaitEvent(g_rt.stream, g_rt.ev_halo_done, 0));
+        if (pass == 1 && exchange && prof_on()) {
+            // interior kernels: [begin, ev_int_end]; what the stream then waits for the halo: [ev_int_end, now]
+            hipEvent_t ev_b0 = prof_event(g_rt.stream);
+            prof_span(PH_HALO_WAIT, ev_int_end, ev_b0);
+            prof_begin(PH_BOUNDARY, g_rt.stream);
+        }
         for (size_t ip = 0; ip < P; ++ip) {
             const Part &p = A->parts[ip];
             const double *w = dots && dots->w ? dots->w[ip] : nullptr;
@@ -1522,6 +1538,7 @@ int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
             }
         }
     }
+    if (exchange && prof_on()) prof_end(PH_BOUNDARY, g_rt.stream);
     g_launch_flags = 0;
     SGM_HIP(hipGetLastError());
     return SGM_OK;

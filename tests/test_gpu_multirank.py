@@ -47,15 +47,20 @@ def _run_ranks(world, case, tmp_path, mock):
     else:
         env.pop("SGM_RCCL_LIB", None)
     outs = [str(tmp_path / f"rank{r}.json") for r in range(world)]
+    # the ranks' output goes to FILES: nothing a child prints can fill a pipe buffer and block it while we wait for it
+    logf = [open(str(tmp_path / f"rank{r}.log"), "wb") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r), str(world), str(port),
-                               case, outs[r]], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+                               case, outs[r]], env=env, stdout=logf[r], stderr=subprocess.STDOUT) for r in range(world)]
     deadline = time.time() + 420
     while any(p.poll() is None for p in procs) and time.time() < deadline:
         time.sleep(0.1)
     for p in procs:                 # the exact PIDs started here, nothing else
         if p.poll() is None:
             p.kill()
-    logs = [p.communicate()[0].decode(errors="replace")[-3000:] for p in procs]
+        p.wait()
+    for f in logf:
+        f.close()
+    logs = [open(str(tmp_path / f"rank{r}.log"), "rb").read().decode(errors="replace")[-3000:] for r in range(world)]
     results = []
     for r in range(world):
         assert os.path.exists(outs[r]), f"rank {r} wrote no result (rc {procs[r].returncode}):\n{logs[r]}"
@@ -103,6 +108,57 @@ def test_bench_gpus_2_typed_plainly_spawns_its_ranks(tmp_path):
     # every local row of both workloads' products, halo rows included, equals its stored-order sum on both ranks
     assert out["selfcheck"]["product_bit_exact_on_every_rank"] is True
     assert out["c5_strong_scaling"]["product_bit_exact_on_every_rank"] is True
+    _check_phase_fields(out, halo_comm=False)
+
+
+def _check_phase_fields(out, halo_comm):
+    """The per-phase HIP-event timers of the N > 1 path are in the line (what makes the first 8-GPU run self-explaining):
+    per CG iteration one halo exchange, one interior and one boundary launch group, two dot reductions and two all-reduces."""
+    for leg in (out["cg"], out["c5_strong_scaling"]):
+        ph = leg["phases"]
+        assert set(ph) == {"halo_post_to_done", "interior_rows", "halo_wait_exposed", "boundary_rows", "dot_reduce_kernels", "allreduce"}
+        for nm, v in ph.items():
+            assert v["ms_per_iter_rank0"] >= 0.0 and v["ms_per_iter_max_over_ranks"] >= v["ms_per_iter_rank0"] - 1e-12, (nm, v)
+        # (+1 product and +1 dot before the loop: counts per iteration are slightly above the steady-state figures)
+        assert 1.0 <= ph["halo_post_to_done"]["events_per_iter"] <= 1.2 and 1.0 <= ph["boundary_rows"]["events_per_iter"] <= 1.2
+        assert 2.0 <= ph["allreduce"]["events_per_iter"] <= 2.2 and 2.0 <= ph["dot_reduce_kernels"]["events_per_iter"] <= 2.2
+        assert ph["interior_rows"]["ms_per_iter_rank0"] > 0.0 and ph["allreduce"]["ms_per_iter_rank0"] > 0.0
+    assert out["c5_strong_scaling"]["halo_comm"] is halo_comm
+
+
+def test_bench_with_a_second_communicator_for_the_halo(tmp_path):
+    """--halo-comm: the halo send / recv pairs on a communicator of their own (A/B switch for the node); same products, same
+    iteration counts, phases reported."""
+    env = dict(os.environ)
+    env.update({"SGM_RCCL_LIB": MOCK, "SGM_BENCH_SAME_GPU": "1"})
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--spmv-per-step", "4", "--nx", "300", "--ny", "200", "--cg-steps", "20", "--c5-edge", "40",
+                        "--c5-cg-steps", "10", "--no-cpu", "--halo-comm"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["selfcheck"]["product_bit_exact_on_every_rank"] is True and out["c5_strong_scaling"]["product_bit_exact_on_every_rank"] is True
+    assert out["cg"]["iterations"] == 20 and out["c5_strong_scaling"]["cg_iterations"] == 10
+    _check_phase_fields(out, halo_comm=True)
+
+
+def test_dist_overhead_leg_runs_the_rccl_path_with_one_rank(tmp_path):
+    """N = 1 line: `dist_overhead_1rank` = CG through sgm_csr_create_dist + forced one-rank all-reduces (here over the
+    stand-in transport; on the driver's box over the real librccl) beside the plain path's figure."""
+    env = dict(os.environ)
+    env.update({"SGM_RCCL_LIB": MOCK})
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--spmv-per-step", "4",
+                        "--nx", "300", "--ny", "200", "--cg-steps", "20", "--no-c5", "--no-cpu", "--no-variants"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    d = out["dist_overhead_1rank"]
+    assert "error" not in d, d
+    assert d["iterations"] == 20 and d["iters_per_s_dist_path"] > 0 and d["iters_per_s_plain_path"] > 0
+    assert 2.0 <= d["phases"]["allreduce"]["events_per_iter"] <= 2.2 and d["phases"]["halo_post_to_done"]["events_per_iter"] == 0
 
 
 def test_bench_under_torch_distributed_run_like_the_driver_launches_it(tmp_path):
