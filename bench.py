@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 
 
 def spmv_bytes(n, m, nnz):
@@ -148,6 +148,13 @@ def worker(args):
     import sigma_amd as sg
     from sigma_amd import problems as P
 
+    # The one JSON line is the ONLY thing this process writes to its stdout: native libraries print there too (librccl
+    # writes a version banner to fd 1 when its first communicator comes up), so fd 1 is pointed at stderr for the rest of
+    # the run and the line goes to a private duplicate of the original stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    json_out = os.fdopen(json_fd, "w")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -386,8 +393,9 @@ def worker(args):
 
     # ---- CG iterations/s (device-resident loop, fixed iteration count) -----------------------
     cg = None
+    in_solver_ms = None
     if args.cg_steps > 0:
-        its, dtc, res2, cg_phases = cg_run(A, n_loc, n_glob, args.cg_steps, profile_phases=use_dist)
+        its, dtc, res2, cg_phases = cg_run(A, n_loc, n_glob, args.cg_steps, profile_phases=True)
         # moved per iteration: the SpMV's bytes + 8 vector passes (q written by the SpMV is counted there;
         # r-update reads r,q writes r; x/p update reads x,p,r writes x,p) = 64 n;
         # SURVEY §8d grades on the fused floor B_csr + 72 n of the REFERENCE layout -- both reported
@@ -397,7 +405,10 @@ def worker(args):
               "moved_bytes_per_iter": moved_it, "GB/s_moved": moved_it * its / dtc / 1e9,
               "frac_of_hbm_peak": moved_it * its / dtc / 1e9 / (HBM_PEAK_GBS * world),
               "effective_GBs_on_survey_floor": floor_it * its / dtc / 1e9, "final_res2": res2,
-              "phases": cg_phases}
+              "phases": cg_phases if use_dist else None}
+        # the product as it runs INSIDE the solver (every launch after two update passes have gone through the caches),
+        # from the library's HIP events around each of its launches
+        in_solver_ms = None if use_dist or not cg_phases else cg_phases["interior_rows"]["ms_per_iter_rank0"] / max(1e-9, cg_phases["interior_rows"]["events_per_iter"])
 
     # ---- N = 1: the fixed cost of the RCCL code path (real librccl, ONE rank) on the same matrix ----------------
     dist_overhead = None
@@ -451,6 +462,13 @@ def worker(args):
               "note": "north_star target: cg_iters_per_s at n_gpus = 8 >= 6 x the n_gpus = 1 figure"}
         A5.destroy()
 
+    # the streaming regime beside the headline figure: the 464^3 product on this GPU (7.6 GB moved: nothing stays on chip)
+    roofline_other = None
+    if c5 is not None and world == 1:
+        roofline_other = {"c5_464cubed_one_gpu": {"kernel": c5["kernel"], "spmv_ms": c5["spmv_ms"],
+                                                   "frac_of_hbm_peak_on_moved_bytes": c5["spmv_frac_of_hbm_peak"],
+                                                   "cg_frac_of_hbm_peak_on_moved_bytes": c5["cg_frac_of_hbm_peak"]}}
+
     # HBM bytes per launch from the PMC counters cannot be collected inside this process; they come
     # from the committed rocprofv3 --pmc passes over this same command (profiles/<round>/), and are
     # quoted only when that summary was collected with the kernel sources that run now
@@ -482,6 +500,9 @@ def worker(args):
                          "effective_GBs_on_reference_bytes": alg_bytes_rank / k_avg / 1e9,
                          "avg_launch_ms": 1e3 * k_avg, "cold_launch_ms": 1e3 * k_cold,
                          "cold_frac": moved_rank / k_cold / 1e9 / HBM_PEAK_GBS,
+                         "in_solver_launch_ms": in_solver_ms,
+                         "in_solver_frac": (moved_rank / (in_solver_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if in_solver_ms else None,
+                         "other": roofline_other,
                          "traffic_source": traffic_src, "csrc_sha1": kernel_sha,
                          "note": "achieved = moved_bytes_per_launch / avg_launch_ms: the sliced kernel reads 8W+4 bytes per "
                                  "row of its own layout (W = 5) + x once + y once.  cold_* = the same launch after 512 MiB "
@@ -491,7 +512,8 @@ def worker(args):
                           "what": "every local row of one timed-workload product == its sum evaluated with torch in stored "
                                   "order from x(i) = sin(0.001 i), on every rank (halo values included)"},
         }
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if use_dist:
         barrier()
         comm.destroy()

@@ -98,6 +98,10 @@ int sgm_synchronize(void);
  * plane stride of a 3-D grid) hand their slices to the workgroups in a band order per XCD, so that the
  * slices one plane apart -- which read the same x entries -- share one XCD's L2; only the order in
  * which whole slices are taken changes.  "slice_sched_band" (default 64): its band width in slices.
+ * "krylov_graph" (default 1): the CG / BiCGStab launch loops on one GPU (plain or Jacobi-preconditioned) go on as replays of ONE
+ * captured group of 16 iterations (a hipGraph: same kernels, same arguments, stop-flag generations relative to the group)
+ * once a solve has run "krylov_graph_after" iterations (default 64, rounded to a multiple of 16): the launch path costs
+ * ~1.8 us per kernel replayed against ~4.8 us launched, which is most of an iteration below n ~ 1e6.  0 = launch every kernel.
  * "dot_order" (default 0): how CG / BiCGStab (plain and preconditioned) add up their dot products.  0 = tree order
  * (per-workgroup partial sums, re-reduced in a fixed order): a legal order for the Fortran intrinsic, deterministic, and
  * the fast one.  1 = the order the reference build uses (amdflang -O2 on x86-64 turns dot_product into ONE accumulator

@@ -51,6 +51,8 @@ struct Options {
     int cg_small_chunk = 50000;    // its iterations per launch (the solve continues in the next launch from parked r, p)
     int slice_sched = 0;           // sliced kernels on matrices with a far stencil offset (3-D grids): band-ordered slice schedule per XCD
     int slice_sched_band = 64;     // its target band width in slices
+    int krylov_graph = 1;          // CG / BiCGStab launch loops (one GPU, plain or Jacobi): replay a captured group of 16 iterations (hipGraph)
+    int krylov_graph_after = 64;   // ... once the solve has run this many iterations (a multiple of 16: the capture has to pay for itself)
     int dot_order = 0;             // dot products of CG / BiCGStab: 0 = tree (per-workgroup partial sums), 1 = the reference's order
                                    // (one accumulator, first element to last: what amdflang -O2 makes of dot_product) -- validation mode
     int bicgstab_small = 1;        // BiCGStab (plain or Jacobi) on a CSR matrix of <= 4096 rows: the whole solve in one workgroup

@@ -174,6 +174,8 @@ int sgm_set_option(const char *name, int value)
     if (!strcmp(name, "slice_sched")) { g_opt.slice_sched = value; return SGM_OK; }
     if (!strcmp(name, "slice_sched_band")) { g_opt.slice_sched_band = std::max(8, value); return SGM_OK; }
     if (!strcmp(name, "gmres_cgs2")) { g_opt.gmres_cgs2 = value; return SGM_OK; }
+    if (!strcmp(name, "krylov_graph")) { g_opt.krylov_graph = value != 0; return SGM_OK; }
+    if (!strcmp(name, "krylov_graph_after")) { g_opt.krylov_graph_after = std::max(16, (value + 15) / 16 * 16); return SGM_OK; }
     if (!strcmp(name, "dot_order")) {
         if (value != 0 && value != 1) return fail(SGM_ERR_BAD_ARG, "sgm_set_option: dot_order is 0 (tree) or 1 (the reference's sequential order)");
         g_opt.dot_order = value;

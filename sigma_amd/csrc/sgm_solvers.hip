@@ -253,6 +253,13 @@ __global__ __launch_bounds__(kBlock) void k_check(ScalarRef ref, double tol, int
         if (!(sqrt(d) > tol)) *flag = 1;
     }
 }
+// Start of a batch of iterations whose kernels carry generations RELATIVE to the batch (1, 2, ...): a stop raised in an
+// earlier batch -- some generation of THAT batch -- becomes 1, which every generation of this and all later batches is >= :
+// they all exit at once.  This is what lets one captured batch (a hipGraph) be replayed unchanged.
+__global__ void k_flag_norm(int *flag)
+{
+    if (threadIdx.x == 0 && *flag) *flag = 1;
+}
 // one block: slot = sum(partials)
 __global__ __launch_bounds__(kBlock) void k_reduce(const double *part, int count, double *slot)
 {
@@ -1019,6 +1026,47 @@ int read_state(sgm_solver s, int *flag, int64_t *iters, double *res)
     return SGM_OK;
 }
 
+// A group of kGraphIters Krylov iterations captured once per solve as a hipGraph and replayed: below n ~ 1e6 an iteration of
+// the launch loops IS its launches (CG: three dependent ones, ~4.8 us each from the host; ~1.8 us each when replayed:
+// tools/graph_probe.cpp), so long solves of mid-sized systems spend two thirds of their time in the launch path.  The group
+// is what the loop would launch -- same kernels, same arguments, generations relative to the group (k_flag_norm) -- captured
+// on the launch stream after the solve has run long enough to pay for the capture.
+constexpr int kGraphIters = 16;
+struct GraphBatch {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool failed = false;
+    ~GraphBatch()
+    {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+    }
+    // body(): enqueues the group's launches on g_rt.stream
+    template <class Body>
+    bool ensure(Body &&body)
+    {
+        if (exec) return true;
+        if (failed) return false;
+        failed = true;                                     // (until the whole sequence below has worked)
+        if (hipStreamBeginCapture(g_rt.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return false; }
+        const int rc = body();
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(g_rt.stream, &g);
+        if (rc != SGM_OK || e != hipSuccess || !g) { (void)hipGetLastError(); if (g) (void)hipGraphDestroy(g); return false; }
+        graph = g;
+        if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); exec = nullptr; return false; }
+        failed = false;
+        return true;
+    }
+};
+// a solve qualifies when nothing but plain kernel launches on one stream makes up an iteration
+bool graph_applies(sgm_solver s, sgm_mat A, sgm_pc pc)
+{
+    const int pk = pc ? pc_kind(pc) : 0;
+    return g_opt.krylov_graph && !s->multi && s->work.size() == 1 && !A->comm && A->fmt != SGM_FMT_COMPOSITE &&
+           (pk == 0 || pk == SGM_PC_JACOBI) && !prof_on();
+}
+
 // ---------------------------------------------------------------------------------- CG
 enum { C_PQ = 0, C_RR0 = 1, C_RR1 = 2 };
 enum { V_P = 0, V_Q = 1, V_R = 2, V_Z = 3 };
@@ -1395,55 +1443,74 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
     int64_t k = 0;
     int flag = 0; int64_t iters = 0; double res = 0.0;
     const int64_t batch_max = pc_apply_is_short(pc) ? 16 : 1;
+    // one iteration (number k: it picks the parity of the r.r slots) with generation `gen`, relative to its batch
+    auto enqueue_iter = [&](int64_t k, int gen) -> int {
+        const int cur = (k & 1) ? C_RR1 : C_RR0, nxt = (k & 1) ? C_RR0 : C_RR1;
+        // q = A p, partial p.q
+        SpmvDots dots;
+        for (size_t ip = 0; ip < P; ++ip) {
+            v.cx[ip] = W(ip, V_P); v.y[ip] = W(ip, V_Q); v.w[ip] = W(ip, V_P); v.p0[ip] = part(s, ip, C_PQ);
+        }
+        dots.w = v.w.data(); dots.part_wy = v.p0.data();
+        // all parts share one flag value; spmv takes part 0's flag for every launch on
+        // this device (identical contents)
+        SGM_TRY(spmv_parts(A, v.cx.data(), v.y.data(), false, &dots, s->work[0].flag, &grid, gen));
+        for (size_t ip = 0; ip < P; ++ip) s->work[ip].count[C_PQ] = spmv_grid(A->parts[ip]);
+        { const int ks[1] = {C_PQ}; SGM_TRY(finish_dots(s, A, ks, 1, vpq, true, gen)); }
+        for (size_t ip = 0; ip < P; ++ip) {
+            PartWork &w = s->work[ip];
+            w.count[nxt] = dot_grid(w.n);
+            if (pk == 0)
+                launch_elem(w.n, FCgR<0>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_Q), W(ip, V_R), nullptr, nullptr,
+                                         part(s, ip, nxt)}, w.flag, gen);
+            else if (pk == SGM_PC_JACOBI)
+                launch_elem(w.n, FCgR<1>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_Q), W(ip, V_R), pc_idiag(pc, ip),
+                                         W(ip, V_Z), part(s, ip, nxt)}, w.flag, gen);
+            else
+                launch_elem(w.n, FCgR<2>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_Q), W(ip, V_R), nullptr, nullptr,
+                                         nullptr}, w.flag, gen);
+        }
+        if (pk != 0 && pk != SGM_PC_JACOBI) {
+            std::vector<const double *> rr(P); std::vector<double *> zz(P);
+            for (size_t ip = 0; ip < P; ++ip) { rr[ip] = W(ip, V_R); zz[ip] = W(ip, V_Z); }
+            SGM_TRY(pc_apply_parts(pc, A, rr.data(), zz.data(), v.flags.data()));
+            for (size_t ip = 0; ip < P; ++ip) {
+                PartWork &w = s->work[ip];
+                launch_elem(w.n, FDot2{W(ip, V_R), W(ip, V_Z), nullptr, nullptr, part(s, ip, nxt), nullptr}, w.flag, gen);
+            }
+        }
+        { const int ks[1] = {nxt}; SGM_TRY(finish_dots(s, A, ks, 1, vz, true, gen)); }
+        for (size_t ip = 0; ip < P; ++ip) {
+            PartWork &w = s->work[ip];
+            launch_elem(w.n, FCgPX{ref(s, ip, cur), ref(s, ip, C_PQ), ref(s, ip, nxt), pk == 0 ? W(ip, V_R) : W(ip, V_Z),
+                                   W(ip, V_P), x[ip], s->tolerance, w.flag, gen + 1, w.iters,
+                                   ip == 0 ? w.history : nullptr, s->hist_cap, w.res}, w.flag, gen);
+        }
+        return SGM_OK;
+    };
+    // `count` iterations from iteration k0 on, generations 1 .. count
+    auto enqueue_group = [&](int64_t k0, int count) -> int {
+        for (size_t ip = 0; ip < P; ++ip) hipLaunchKernelGGL(k_flag_norm, dim3(1), dim3(64), 0, g_rt.stream, s->work[ip].flag);
+        for (int j = 0; j < count; ++j) SGM_TRY(enqueue_iter(k0 + j, j + 1));
+        return SGM_OK;
+    };
+    const bool graphs = graph_applies(s, A, pc);
+    GraphBatch gb;
     for (;;) {
         // the host looks at the stop flag once per batch (a stream synchronisation + three small copies, ~20 us): batches
         // grow with the iterations already done -- at most an eighth of them run past the stop as early-exit kernels
         int64_t batch = batch_max > 1 ? std::min<int64_t>(128, std::max<int64_t>(batch_max, k / 8)) : batch_max;
         if (s->max_iter > 0) batch = std::min<int64_t>(batch, s->max_iter - k);
-        for (int64_t bi = 0; bi < batch; ++bi, ++k) {
-            const int cur = (k & 1) ? C_RR1 : C_RR0, nxt = (k & 1) ? C_RR0 : C_RR1;
-            // q = A p, partial p.q
-            SpmvDots dots;
-            for (size_t ip = 0; ip < P; ++ip) {
-                v.cx[ip] = W(ip, V_P); v.y[ip] = W(ip, V_Q); v.w[ip] = W(ip, V_P); v.p0[ip] = part(s, ip, C_PQ);
-            }
-            dots.w = v.w.data(); dots.part_wy = v.p0.data();
-            // all parts share one flag value; spmv takes part 0's flag for every launch on
-            // this device (identical contents)
-            SGM_TRY(spmv_parts(A, v.cx.data(), v.y.data(), false, &dots, s->work[0].flag, &grid,
-                               (int)std::min<int64_t>(k + 1, INT32_MAX - 2)));
-            for (size_t ip = 0; ip < P; ++ip) s->work[ip].count[C_PQ] = spmv_grid(A->parts[ip]);
-            const int gen = (int)std::min<int64_t>(k + 1, INT32_MAX - 2);
-            { const int ks[1] = {C_PQ}; SGM_TRY(finish_dots(s, A, ks, 1, vpq, true, gen)); }
-            for (size_t ip = 0; ip < P; ++ip) {
-                PartWork &w = s->work[ip];
-                w.count[nxt] = dot_grid(w.n);
-                if (pk == 0)
-                    launch_elem(w.n, FCgR<0>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_Q), W(ip, V_R), nullptr, nullptr,
-                                             part(s, ip, nxt)}, w.flag, gen);
-                else if (pk == SGM_PC_JACOBI)
-                    launch_elem(w.n, FCgR<1>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_Q), W(ip, V_R), pc_idiag(pc, ip),
-                                             W(ip, V_Z), part(s, ip, nxt)}, w.flag, gen);
-                else
-                    launch_elem(w.n, FCgR<2>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_Q), W(ip, V_R), nullptr, nullptr,
-                                             nullptr}, w.flag, gen);
-            }
-            if (pk != 0 && pk != SGM_PC_JACOBI) {
-                std::vector<const double *> rr(P); std::vector<double *> zz(P);
-                for (size_t ip = 0; ip < P; ++ip) { rr[ip] = W(ip, V_R); zz[ip] = W(ip, V_Z); }
-                SGM_TRY(pc_apply_parts(pc, A, rr.data(), zz.data(), v.flags.data()));
-                for (size_t ip = 0; ip < P; ++ip) {
-                    PartWork &w = s->work[ip];
-                    launch_elem(w.n, FDot2{W(ip, V_R), W(ip, V_Z), nullptr, nullptr, part(s, ip, nxt), nullptr}, w.flag, gen);
-                }
-            }
-            { const int ks[1] = {nxt}; SGM_TRY(finish_dots(s, A, ks, 1, vz, true, gen)); }
-            for (size_t ip = 0; ip < P; ++ip) {
-                PartWork &w = s->work[ip];
-                launch_elem(w.n, FCgPX{ref(s, ip, cur), ref(s, ip, C_PQ), ref(s, ip, nxt), pk == 0 ? W(ip, V_R) : W(ip, V_Z),
-                                       W(ip, V_P), x[ip], s->tolerance, w.flag, gen + 1, w.iters,
-                                       ip == 0 ? w.history : nullptr, s->hist_cap, w.res}, w.flag, gen);
-            }
+        // a solve that has run g_opt.krylov_graph_after iterations goes on as replays of one captured group of kGraphIters (k is
+        // a multiple of it here: the parity of the r.r slots repeats)
+        if (graphs && k >= g_opt.krylov_graph_after && k % kGraphIters == 0 && batch >= kGraphIters &&
+            gb.ensure([&]() { return enqueue_group(k, kGraphIters); })) {
+            const int64_t groups = batch / kGraphIters;
+            for (int64_t g = 0; g < groups; ++g) SGM_HIP(hipGraphLaunch(gb.exec, g_rt.stream));
+            k += groups * kGraphIters;
+        } else {
+            SGM_TRY(enqueue_group(k, (int)batch));
+            k += batch;
         }
         SGM_HIP(hipGetLastError());
         SGM_TRY(read_state(s, &flag, &iters, &res));
@@ -1677,84 +1744,97 @@ int run_bicgstab(sgm_solver s, sgm_mat A, double *const *x, const double *const 
             hipLaunchKernelGGL(k_check, dim3(1), dim3(kBlock), 0, g_rt.stream, ref(s, ip, B_RR + cur), s->tolerance,
                                s->work[ip].flag, s->work[ip].res);
     };
+    auto enqueue_iter = [&](int64_t k) -> int {
+        const int c = (int)(k & 1), o = c ^ 1;
+        for (size_t ip = 0; ip < P; ++ip) {
+            PartWork &w = s->work[ip];
+            BiScalars S{ref(s, ip, B_RR + c), ref(s, ip, B_RHO + c), ref(s, ip, B_RHO + o), ref(s, ip, B_R0V + o),
+                        ref(s, ip, B_ST + o), ref(s, ip, B_TT + o), ref(s, ip, B_R0V + c), ref(s, ip, B_ST + c),
+                        ref(s, ip, B_TT + c), k == 0, pk == 0};
+            launch_elem(w.n, FBiP{S, W(ip, W_R), W(ip, W_V), W(ip, W_P), s->tolerance, w.flag, w.iters,
+                                  ip == 0 ? w.history : nullptr, s->hist_cap, w.res}, w.flag);
+        }
+        // v = [M^-1] A p ; r0.v
+        SpmvDots dots;
+        for (size_t ip = 0; ip < P; ++ip) {
+            v.cx[ip] = W(ip, W_P); v.y[ip] = pk ? W(ip, W_Z) : W(ip, W_V);
+            v.w[ip] = W(ip, W_R0); v.p0[ip] = part(s, ip, B_R0V + c);
+        }
+        dots.w = v.w.data(); dots.part_wy = v.p0.data();
+        SGM_TRY(spmv_parts(A, v.cx.data(), v.y.data(), false, pk ? nullptr : &dots, s->work[0].flag, &grid));
+        for (size_t ip = 0; ip < P; ++ip) s->work[ip].count[B_R0V + c] = spmv_grid(A->parts[ip]);
+        if (pk) {
+            std::vector<const double *> zz(P); std::vector<double *> vv(P);
+            for (size_t ip = 0; ip < P; ++ip) { zz[ip] = W(ip, W_Z); vv[ip] = W(ip, W_V); }
+            SGM_TRY(pc_apply_parts(pc, A, zz.data(), vv.data(), v.flags.data()));
+            for (size_t ip = 0; ip < P; ++ip) {
+                PartWork &w = s->work[ip];
+                w.count[B_R0V + c] = dot_grid(w.n);
+                launch_elem(w.n, FDot2{W(ip, W_R0), W(ip, W_V), nullptr, nullptr, part(s, ip, B_R0V + c), nullptr},
+                            w.flag);
+            }
+        }
+        { const int ks[1] = {B_R0V + c}; SGM_TRY(finish_dots(s, A, ks, 1, v_r0v, true)); }
+        for (size_t ip = 0; ip < P; ++ip) {
+            PartWork &w = s->work[ip];
+            launch_elem(w.n, FBiS{ref(s, ip, B_RHO + c), ref(s, ip, B_R0V + c), W(ip, W_R), W(ip, W_V), W(ip, W_S)},
+                        w.flag);
+        }
+        // t = [M^-1] A s ; s.t , t.t
+        for (size_t ip = 0; ip < P; ++ip) {
+            v.cx[ip] = W(ip, W_S); v.y[ip] = pk ? W(ip, W_Z) : W(ip, W_T);
+            v.w[ip] = W(ip, W_S); v.p0[ip] = part(s, ip, B_ST + c); v.p1[ip] = part(s, ip, B_TT + c);
+        }
+        dots.w = v.w.data(); dots.part_wy = v.p0.data(); dots.part_yy = v.p1.data();
+        SGM_TRY(spmv_parts(A, v.cx.data(), v.y.data(), false, pk ? nullptr : &dots, s->work[0].flag, &grid));
+        for (size_t ip = 0; ip < P; ++ip) s->work[ip].count[B_ST + c] = s->work[ip].count[B_TT + c] = spmv_grid(A->parts[ip]);
+        if (pk) {
+            std::vector<const double *> zz(P); std::vector<double *> tt(P);
+            for (size_t ip = 0; ip < P; ++ip) { zz[ip] = W(ip, W_Z); tt[ip] = W(ip, W_T); }
+            SGM_TRY(pc_apply_parts(pc, A, zz.data(), tt.data(), v.flags.data()));
+            for (size_t ip = 0; ip < P; ++ip) {
+                PartWork &w = s->work[ip];
+                w.count[B_ST + c] = w.count[B_TT + c] = dot_grid(w.n);
+                launch_elem(w.n, FDot2{W(ip, W_S), W(ip, W_T), W(ip, W_T), W(ip, W_T), part(s, ip, B_ST + c),
+                                       part(s, ip, B_TT + c)}, w.flag);
+            }
+        }
+        // ST/TT ids are not adjacent for one parity: two calls keep slots contiguous
+        if (s->seq) { const int ks[2] = {B_ST + c, B_TT + c}; SGM_TRY(finish_dots(s, A, ks, 2, v_st_tt, true)); }
+        else {
+            { const int ks[1] = {B_ST + c}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+            { const int ks[1] = {B_TT + c}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+        }
+        for (size_t ip = 0; ip < P; ++ip) {
+            PartWork &w = s->work[ip];
+            w.count[B_RR + o] = w.count[B_RHO + o] = dot_grid(w.n);
+            launch_elem(w.n, FBiXR{ref(s, ip, B_RHO + c), ref(s, ip, B_R0V + c), ref(s, ip, B_ST + c),
+                                   ref(s, ip, B_TT + c), pk == 0, W(ip, W_P), W(ip, W_S), W(ip, W_T), W(ip, W_R0),
+                                   x[ip], W(ip, W_R), part(s, ip, B_RR + o), part(s, ip, B_RHO + o)}, w.flag);
+        }
+        if (s->seq) { const int ks[2] = {B_RR + o, B_RHO + o}; SGM_TRY(finish_dots(s, A, ks, 2, v_rr_rho, true)); }
+        else {
+            { const int ks[1] = {B_RR + o}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+            { const int ks[1] = {B_RHO + o}; SGM_TRY(finish_dots(s, A, ks, 1)); }
+        }
+        return SGM_OK;
+    };
+    const bool graphs = graph_applies(s, A, pc);
+    GraphBatch gb;
     for (;;) {
         // the host looks at the stop flag once per batch (a stream synchronisation + three small copies, ~20 us): batches
         // grow with the iterations already done -- at most an eighth of them run past the stop as early-exit kernels
         int64_t batch = batch_max > 1 ? std::min<int64_t>(128, std::max<int64_t>(batch_max, k / 8)) : batch_max;
         if (s->max_iter > 0) batch = std::min<int64_t>(batch, s->max_iter - k);
-        for (int64_t bi = 0; bi < batch; ++bi, ++k) {
-            const int c = (int)(k & 1), o = c ^ 1;
-            for (size_t ip = 0; ip < P; ++ip) {
-                PartWork &w = s->work[ip];
-                BiScalars S{ref(s, ip, B_RR + c), ref(s, ip, B_RHO + c), ref(s, ip, B_RHO + o), ref(s, ip, B_R0V + o),
-                            ref(s, ip, B_ST + o), ref(s, ip, B_TT + o), ref(s, ip, B_R0V + c), ref(s, ip, B_ST + c),
-                            ref(s, ip, B_TT + c), k == 0, pk == 0};
-                launch_elem(w.n, FBiP{S, W(ip, W_R), W(ip, W_V), W(ip, W_P), s->tolerance, w.flag, w.iters,
-                                      ip == 0 ? w.history : nullptr, s->hist_cap, w.res}, w.flag);
-            }
-            // v = [M^-1] A p ; r0.v
-            SpmvDots dots;
-            for (size_t ip = 0; ip < P; ++ip) {
-                v.cx[ip] = W(ip, W_P); v.y[ip] = pk ? W(ip, W_Z) : W(ip, W_V);
-                v.w[ip] = W(ip, W_R0); v.p0[ip] = part(s, ip, B_R0V + c);
-            }
-            dots.w = v.w.data(); dots.part_wy = v.p0.data();
-            SGM_TRY(spmv_parts(A, v.cx.data(), v.y.data(), false, pk ? nullptr : &dots, s->work[0].flag, &grid));
-            for (size_t ip = 0; ip < P; ++ip) s->work[ip].count[B_R0V + c] = spmv_grid(A->parts[ip]);
-            if (pk) {
-                std::vector<const double *> zz(P); std::vector<double *> vv(P);
-                for (size_t ip = 0; ip < P; ++ip) { zz[ip] = W(ip, W_Z); vv[ip] = W(ip, W_V); }
-                SGM_TRY(pc_apply_parts(pc, A, zz.data(), vv.data(), v.flags.data()));
-                for (size_t ip = 0; ip < P; ++ip) {
-                    PartWork &w = s->work[ip];
-                    w.count[B_R0V + c] = dot_grid(w.n);
-                    launch_elem(w.n, FDot2{W(ip, W_R0), W(ip, W_V), nullptr, nullptr, part(s, ip, B_R0V + c), nullptr},
-                                w.flag);
-                }
-            }
-            { const int ks[1] = {B_R0V + c}; SGM_TRY(finish_dots(s, A, ks, 1, v_r0v, true)); }
-            for (size_t ip = 0; ip < P; ++ip) {
-                PartWork &w = s->work[ip];
-                launch_elem(w.n, FBiS{ref(s, ip, B_RHO + c), ref(s, ip, B_R0V + c), W(ip, W_R), W(ip, W_V), W(ip, W_S)},
-                            w.flag);
-            }
-            // t = [M^-1] A s ; s.t , t.t
-            for (size_t ip = 0; ip < P; ++ip) {
-                v.cx[ip] = W(ip, W_S); v.y[ip] = pk ? W(ip, W_Z) : W(ip, W_T);
-                v.w[ip] = W(ip, W_S); v.p0[ip] = part(s, ip, B_ST + c); v.p1[ip] = part(s, ip, B_TT + c);
-            }
-            dots.w = v.w.data(); dots.part_wy = v.p0.data(); dots.part_yy = v.p1.data();
-            SGM_TRY(spmv_parts(A, v.cx.data(), v.y.data(), false, pk ? nullptr : &dots, s->work[0].flag, &grid));
-            for (size_t ip = 0; ip < P; ++ip) s->work[ip].count[B_ST + c] = s->work[ip].count[B_TT + c] = spmv_grid(A->parts[ip]);
-            if (pk) {
-                std::vector<const double *> zz(P); std::vector<double *> tt(P);
-                for (size_t ip = 0; ip < P; ++ip) { zz[ip] = W(ip, W_Z); tt[ip] = W(ip, W_T); }
-                SGM_TRY(pc_apply_parts(pc, A, zz.data(), tt.data(), v.flags.data()));
-                for (size_t ip = 0; ip < P; ++ip) {
-                    PartWork &w = s->work[ip];
-                    w.count[B_ST + c] = w.count[B_TT + c] = dot_grid(w.n);
-                    launch_elem(w.n, FDot2{W(ip, W_S), W(ip, W_T), W(ip, W_T), W(ip, W_T), part(s, ip, B_ST + c),
-                                           part(s, ip, B_TT + c)}, w.flag);
-                }
-            }
-            // ST/TT ids are not adjacent for one parity: two calls keep slots contiguous
-            if (s->seq) { const int ks[2] = {B_ST + c, B_TT + c}; SGM_TRY(finish_dots(s, A, ks, 2, v_st_tt, true)); }
-            else {
-                { const int ks[1] = {B_ST + c}; SGM_TRY(finish_dots(s, A, ks, 1)); }
-                { const int ks[1] = {B_TT + c}; SGM_TRY(finish_dots(s, A, ks, 1)); }
-            }
-            for (size_t ip = 0; ip < P; ++ip) {
-                PartWork &w = s->work[ip];
-                w.count[B_RR + o] = w.count[B_RHO + o] = dot_grid(w.n);
-                launch_elem(w.n, FBiXR{ref(s, ip, B_RHO + c), ref(s, ip, B_R0V + c), ref(s, ip, B_ST + c),
-                                       ref(s, ip, B_TT + c), pk == 0, W(ip, W_P), W(ip, W_S), W(ip, W_T), W(ip, W_R0),
-                                       x[ip], W(ip, W_R), part(s, ip, B_RR + o), part(s, ip, B_RHO + o)}, w.flag);
-            }
-            if (s->seq) { const int ks[2] = {B_RR + o, B_RHO + o}; SGM_TRY(finish_dots(s, A, ks, 2, v_rr_rho, true)); }
-            else {
-                { const int ks[1] = {B_RR + o}; SGM_TRY(finish_dots(s, A, ks, 1)); }
-                { const int ks[1] = {B_RHO + o}; SGM_TRY(finish_dots(s, A, ks, 1)); }
-            }
+        // (replays of one captured group of kGraphIters iterations once the solve has run long enough: see GraphBatch; the
+        //  kernels stop on any nonzero flag, so a group needs no generations)
+        if (graphs && k >= g_opt.krylov_graph_after && k % kGraphIters == 0 && batch >= kGraphIters &&
+            gb.ensure([&]() { for (int j = 0; j < kGraphIters; ++j) SGM_TRY(enqueue_iter(k + j)); return (int)SGM_OK; })) {
+            const int64_t groups = batch / kGraphIters;
+            for (int64_t g = 0; g < groups; ++g) SGM_HIP(hipGraphLaunch(gb.exec, g_rt.stream));
+            k += groups * kGraphIters;
+        } else {
+            for (int64_t bi = 0; bi < batch; ++bi, ++k) SGM_TRY(enqueue_iter(k));
         }
         // the loop test of the NEXT iteration decides whether we are done (k_check only ever
         // sets the flag, so an earlier in-batch stop is kept)

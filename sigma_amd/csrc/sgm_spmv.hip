@@ -1502,6 +1502,7 @@ int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
         SGM_HIP(hipEventRecord(g_rt.ev_halo_done, g_rt.comm_stream));
     }
     hipEvent_t ev_int_end = nullptr;
+    if (!exchange && prof_on()) prof_begin(PH_INTERIOR, g_rt.stream);      // no exchange: the whole product counts as interior rows
     for (int pass = 0; pass < 2; ++pass) {          // pass 0: ranges that need no halo; pass 1: the rest
         if (exchange && prof_on()) {
             if (pass == 0) prof_begin(PH_INTERIOR, g_rt.stream);
@@ -1538,7 +1539,7 @@ int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
             }
         }
     }
-    if (exchange && prof_on()) prof_end(PH_BOUNDARY, g_rt.stream);
+    if (prof_on()) prof_end(exchange ? PH_BOUNDARY : PH_INTERIOR, g_rt.stream);
     g_launch_flags = 0;
     SGM_HIP(hipGetLastError());
     return SGM_OK;

@@ -199,6 +199,6 @@ def test_every_documented_option_is_accepted_and_unknown_names_are_refused():
     for nm in sorted(known):
         cur = {"ell_colblock_cols": 16384, "ell_colblock_chunks": 16, "slice_sched_band": 64, "cg_small_chunk": 50000,
                "ell_colblock_rows": 0, "slice_sched": 0, "dot_order": 0, "pipeline_spin_limit": 0, "ell_colblock_band": -1,
-               "ell_colblock_pieces": 512, "ell_colblock_nt": 0}.get(nm, 1)
+               "ell_colblock_pieces": 512, "ell_colblock_nt": 0, "krylov_graph_after": 64, "dist_force_collectives": 0}.get(nm, 1)
         assert lib.sgm_set_option(nm.encode(), cur) == 0, nm          # (set to its default: nothing changes)
     assert lib.sgm_set_option(b"no_such_option", 1) != 0
