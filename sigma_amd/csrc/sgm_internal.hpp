@@ -51,7 +51,8 @@ struct Options {
     int cg_small_chunk = 50000;    // its iterations per launch (the solve continues in the next launch from parked r, p)
     int slice_sched = 0;           // sliced kernels on matrices with a far stencil offset (3-D grids): band-ordered slice schedule per XCD
     int slice_sched_band = 64;     // its target band width in slices
-    int krylov_graph = 1;          // CG / BiCGStab launch loops (one GPU, plain or Jacobi): replay a captured group of 16 iterations (hipGraph)
+    int krylov_graph = 1;          // CG / BiCGStab launch loops (one GPU, plain or Jacobi): replay a captured group of 16 iterations (hipGraph): the GPU-side
+                                   // floor (13.3 us per CG iteration at n = 1e5) whatever the host's launch rate is (13.7-18 us launched, box to box)
     int krylov_graph_after = 64;   // ... once the solve has run this many iterations (a multiple of 16: the capture has to pay for itself)
     int dot_order = 0;             // dot products of CG / BiCGStab: 0 = tree (per-workgroup partial sums), 1 = the reference's order
                                    // (one accumulator, first element to last: what amdflang -O2 makes of dot_product) -- validation mode
@@ -283,6 +284,56 @@ __device__ inline double load_scalar(ScalarRef r, double *red)
     double v = 0.0;
     for (int i = threadIdx.x; i < r.count; i += BLOCK) v += r.ptr[i];
     return block_sum<BLOCK>(v, red);
+}
+
+// K device scalars at once: the first round of every scalar's partial sums is requested before any of them is used, and
+// the K block sums share their two barriers -- ONE memory round trip and one reduction where K calls of load_scalar take K
+// of each (the prologue of the Krylov update kernels: 2-6 scalars; at n = 1e5 those round trips were a third of a CG
+// iteration).  Every scalar is summed in exactly load_scalar's order: same bits.  red: K * BLOCK / 64 doubles of LDS.
+template <int BLOCK, int K>
+__device__ inline void load_scalars(const ScalarRef (&r)[K], double (&out)[K], double *red)
+{
+    double v[K];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        // (count == 1: already reduced -- every thread reads the value itself, nothing is added to it)
+        const int i = r[k].count == 1 ? 0 : (int)threadIdx.x;
+        v[k] = i < r[k].count ? r[k].ptr[i] : 0.0;
+        any = any || r[k].count > 1;
+    }
+    if (!any) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) out[k] = v[k];
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (r[k].count > 1) {
+            v[k] = 0.0 + v[k];
+            for (int i = threadIdx.x + BLOCK; i < r[k].count; i += BLOCK) v[k] += r[k].ptr[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+        }
+    }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) red[k * (BLOCK / 64) + wave] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (r[k].count > 1) {
+            double s = red[k * (BLOCK / 64)];
+#pragma unroll
+            for (int w = 1; w < BLOCK / 64; ++w) s += red[k * (BLOCK / 64) + w];
+            out[k] = s;
+        } else {
+            out[k] = v[k];
+        }
+    }
 }
 
 }  // namespace sgm

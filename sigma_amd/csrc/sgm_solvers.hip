@@ -50,12 +50,21 @@ int pc_retire_pipelines(sgm_pc pc);
 // flag = k+2 when the new res2 meets the tolerance: every kernel of iterations > k is skipped,
 // while all workgroups of the setting kernel itself still run (they carry the last x update).
 // Kernels that do not take part in this (gen = INT_MAX) stop on any nonzero flag.
+template <class T, class = void> struct has_commit : std::false_type {};
+template <class T> struct has_commit<T, std::void_t<decltype(std::declval<T &>().commit())>> : std::true_type {};
 template <class F, bool NT>
 __global__ __launch_bounds__(kBlock) void k_elem(int64_t n, F f, const int *flag, int gen)
 {
-    __shared__ double red[kBlock / 64];
-    if (flag) { const int st = *flag; if (st && gen >= st) return; }
-    if (!f.prepare(red)) return;
+    __shared__ double red[8 * (kBlock / 64)];       // (up to 8 scalars per load_scalars call)
+    // The stop flag is REQUESTED first and LOOKED AT after prepare(): prepare() only loads and reduces scalars (no side
+    // effects), so the flag's round trip and the partial sums' are one wait instead of two -- below n ~ 1e5 these
+    // dependent round trips, not the launches, are what an iteration is made of.  Side effects (iteration count, history,
+    // raising the flag) live in commit(), which a skipped kernel never reaches.
+    const int st = flag ? *flag : 0;
+    const bool go = f.prepare(red);
+    if (st && gen >= st) return;
+    if constexpr (has_commit<F>::value) f.commit();
+    if (!go) return;
     const int64_t gtid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     const int64_t n2 = n >> 1;
@@ -173,9 +182,10 @@ struct FCgR {
     double alpha = 0.0, s = 0.0;
     __device__ bool prepare(double *red)
     {
-        const double a = load_scalar<kBlock>(res2, red);
-        const double b = load_scalar<kBlock>(dpr, red);
-        alpha = a / b;
+        const ScalarRef rs[2] = {res2, dpr};
+        double sc[2];
+        load_scalars<kBlock, 2>(rs, sc, red);
+        alpha = sc[0] / sc[1];
         return true;
     }
     __device__ void one(double qv, double &rv, double idv, double &zv)
@@ -209,22 +219,28 @@ struct FCgPX {
     static constexpr bool kDot = false;
     ScalarRef res2, dpr, dnew; const double *z; double *p, *x;
     double tol; int *flag; int stop_value; int64_t *iters; double *history; int64_t hist_cap; double *res_out;
-    double alpha = 0.0, beta = 0.0;
+    double alpha = 0.0, beta = 0.0, dnew_v = 0.0;
     __device__ bool prepare(double *red)
     {
-        const double a = load_scalar<kBlock>(res2, red);
-        const double b = load_scalar<kBlock>(dpr, red);
-        const double d = load_scalar<kBlock>(dnew, red);
+        const ScalarRef rs[3] = {res2, dpr, dnew};
+        double sc[3];
+        load_scalars<kBlock, 3>(rs, sc, red);
+        const double a = sc[0], b = sc[1];
+        dnew_v = sc[2];
         alpha = a / b;
-        beta = d / a;
+        beta = dnew_v / a;
+        return true;
+    }
+    __device__ void commit()
+    {
         if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const double d = dnew_v;
             const int64_t it = *iters;
             if (history && it < hist_cap) history[it] = d;
             *iters = it + 1;
             *res_out = d;
             if (!(sqrt(d) > tol)) *flag = stop_value;
         }
-        return true;
     }
     template <bool NT> __device__ void pair(int64_t i)
     {
@@ -374,30 +390,35 @@ struct FBiP {
     static constexpr bool kDot = false;
     BiScalars S; const double *r, *v; double *p;
     double tol; int *flag; int64_t *iters; double *history; int64_t hist_cap; double *res_out;
-    double beta = 0.0, omega = 1.0;
+    double beta = 0.0, omega = 1.0, res2_v = 0.0; bool stop_v = false;
     __device__ bool prepare(double *red)
     {
-        const double res2 = load_scalar<kBlock>(S.rr, red);
-        const bool stop = !(sqrt(res2) > tol);
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            const int64_t it = *iters;
-            *res_out = res2;
-            if (!S.first && history && it - 1 < hist_cap && it >= 1) history[it - 1] = res2;
-            if (stop) *flag = 1; else *iters = it + 1;
-        }
-        if (stop) return false;
-        const double rho = load_scalar<kBlock>(S.rho, red);
+        // (iteration 1 has no previous dots: their slots are read all the same -- zero-filled at setup -- and not used)
+        const ScalarRef rs[6] = {S.rr, S.rho, S.rho_old, S.r0v_old, S.st_old, S.tt_old};
+        double sc[6];
+        load_scalars<kBlock, 6>(rs, sc, red);
+        res2_v = sc[0];
+        stop_v = !(sqrt(res2_v) > tol);
+        if (stop_v) return false;
+        const double rho = sc[1];
         double rho_old = 1.0, alpha = 1.0;
         omega = 1.0;
         if (!S.first) {
-            rho_old = load_scalar<kBlock>(S.rho_old, red);
-            alpha = rho_old / load_scalar<kBlock>(S.r0v_old, red);
-            const double st = load_scalar<kBlock>(S.st_old, red);
-            const double tt = load_scalar<kBlock>(S.tt_old, red);
-            omega = bi_omega(st, tt, S.nan_guard);
+            rho_old = sc[2];
+            alpha = rho_old / sc[3];
+            omega = bi_omega(sc[4], sc[5], S.nan_guard);
         }
         beta = rho / rho_old * alpha / omega;
         return true;
+    }
+    __device__ void commit()
+    {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const int64_t it = *iters;
+            *res_out = res2_v;
+            if (!S.first && history && it - 1 < hist_cap && it >= 1) history[it - 1] = res2_v;
+            if (stop_v) *flag = 1; else *iters = it + 1;
+        }
     }
     template <bool NT> __device__ void pair(int64_t i)
     {
@@ -415,8 +436,10 @@ struct FBiS {
     ScalarRef rho, r0v; const double *r, *v; double *s; double alpha = 0.0;
     __device__ bool prepare(double *red)
     {
-        const double a = load_scalar<kBlock>(rho, red);
-        alpha = a / load_scalar<kBlock>(r0v, red);
+        const ScalarRef rs[2] = {rho, r0v};
+        double sc[2];
+        load_scalars<kBlock, 2>(rs, sc, red);
+        alpha = sc[0] / sc[1];
         return true;
     }
     template <bool NT> __device__ void pair(int64_t i)
@@ -435,10 +458,11 @@ struct FBiXR {
     double alpha = 0.0, omega = 0.0, srr = 0.0, srho = 0.0;
     __device__ bool prepare(double *red)
     {
-        const double a = load_scalar<kBlock>(rho, red);
-        alpha = a / load_scalar<kBlock>(r0v, red);
-        const double b = load_scalar<kBlock>(st, red);
-        omega = bi_omega(b, load_scalar<kBlock>(tt, red), nan_guard);
+        const ScalarRef rs[4] = {rho, r0v, st, tt};
+        double sc[4];
+        load_scalars<kBlock, 4>(rs, sc, red);
+        alpha = sc[0] / sc[1];
+        omega = bi_omega(sc[2], sc[3], nan_guard);
         return true;
     }
     __device__ void one(double pv, double sv, double tv, double r0v_, double &xv, double &rv)

@@ -491,11 +491,13 @@ __global__ __launch_bounds__(256) void k_csr_sl(
     constexpr int BLOCK = 256;
     __shared__ int32_t dl[16];
     __shared__ double red[BLOCK / 64];
-    if (flag_done) { const int st = *flag_done; if (st && gen >= st) return; }
+    // The stop flag, the offset dictionary and the first slice's code words and values are all REQUESTED before any of them
+    // is waited for (the flag is looked at before the first store): one memory round trip where flag -> dictionary -> slice
+    // would be three -- which is what a product on a small matrix (a slice or two per workgroup) consists of.
+    const int st = flag_done ? *flag_done : 0;
     const int tid = threadIdx.x;
     const bool chain = (remap & 256) != 0;
-    if (tid < 16) dl[tid] = dict[tid];
-    __syncthreads();
+    const int32_t dv = tid < 16 ? dict[tid] : 0;
     const int64_t nsl = ((int64_t)n + kSlRows - 1) / kSlRows;
     double dwy = 0.0, dyy = 0.0;
 
@@ -514,16 +516,25 @@ __global__ __launch_bounds__(256) void k_csr_sl(
     // a table, -1 = nothing left; the next entry is requested (a scalar load) before this slice's work
     int64_t sl = sched ? sched[blockIdx.x] : first;
     int sit = 0;
-    while (sl >= 0 && sl < nsl) {
-        int64_t nxt = sl + gridDim.x;
-        if (sched) { ++sit; nxt = sit < sched_iters ? sched[(int64_t)sit * gridDim.x + blockIdx.x] : -1; }
-        const int32_t row = (int32_t)(sl * kSlRows) + 2 * tid;          // even: 16-byte aligned pairs
+    u32x2 cw = {0xffffffffu, 0xffffffffu};
+    f64x2 v[W];
+    auto load_slice = [&](int64_t s_) {
+        const int32_t row_ = (int32_t)(s_ * kSlRows) + 2 * tid;          // even: 16-byte aligned pairs
         // (the code array is padded to whole slices with "no entry" words: rows >= n do nothing)
-        const u32x2 cw = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(scode + row));
-        const f64x2 *vb = reinterpret_cast<const f64x2 *>(sval + sl * (int64_t)(W * kSlRows)) + tid;
-        f64x2 v[W];
+        cw = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(scode + row_));
+        const f64x2 *vb = reinterpret_cast<const f64x2 *>(sval + s_ * (int64_t)(W * kSlRows)) + tid;
 #pragma unroll
         for (int u = 0; u < W; ++u) v[u] = __builtin_nontemporal_load(vb + u * BLOCK);
+    };
+    bool have = sl >= 0 && sl < nsl;
+    if (have) load_slice(sl);
+    if (st && gen >= st) return;
+    if (tid < 16) dl[tid] = dv;
+    __syncthreads();
+    while (have) {
+        int64_t nxt = sl + gridDim.x;
+        if (sched) { ++sit; nxt = sit < sched_iters ? sched[(int64_t)sit * gridDim.x + blockIdx.x] : -1; }
+        const int32_t row = (int32_t)(sl * kSlRows) + 2 * tid;
         f64x2 y0 = {0.0, 0.0};
         if (ADD) {
             if (row + 1 < n) y0 = *reinterpret_cast<const f64x2 *>(y + row);
@@ -557,6 +568,8 @@ __global__ __launch_bounds__(256) void k_csr_sl(
             if (DOT_YY) dyy += yi.x * yi.x;
         }
         sl = nxt;
+        have = sl >= 0 && sl < nsl;
+        if (have) load_slice(sl);
     }
     if (DOT_W) {
         const double t = block_sum<BLOCK>(dwy, red);
