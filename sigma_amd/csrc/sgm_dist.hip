@@ -589,12 +589,27 @@ int sgm_csr_create_dist_rect(sgm_mat *out, sgm_comm comm, const int64_t *row_sta
         node_h = hnode.data();
         ptr_h = hptr.data();
     }
-    if ((int64_t)ptr_h[n] - 1 != nnz) return fail(SGM_ERR_BAD_ARG, "sgm_csr_create_dist: ptr(n+1)-1 = %lld but nnz_local = %lld",
-                                                   (long long)ptr_h[n] - 1, (long long)nnz);
+    // What a rank finds wrong with ITS rows must not make it leave before the collectives below (its peers would wait in them
+    // for ever): the verdict travels in the all-gathered want matrix (a rank never asks itself for anything: its own slot
+    // carries -1 = "my rows were rejected"), and every rank returns the same error.
+    int local_rc = SGM_OK;
+    std::string local_msg;
     std::vector<int32_t> halo;
-    halo_plan(nc, c0, nnz, node_h, lnode.data(), halo);
     std::vector<int32_t> want, want_off, req;
-    SGM_TRY(dist_plan(me, R, col_starts, halo, want, want_off, req));
+    if ((int64_t)ptr_h[n] - 1 != nnz)
+        local_rc = fail(SGM_ERR_BAD_ARG, "sgm_csr_create_dist: ptr(n+1)-1 = %lld but nnz_local = %lld", (long long)ptr_h[n] - 1, (long long)nnz);
+    if (local_rc == SGM_OK) {
+        halo_plan(nc, c0, nnz, node_h, lnode.data(), halo);
+        local_rc = dist_plan(me, R, col_starts, halo, want, want_off, req);
+    }
+    if (local_rc != SGM_OK) {
+        local_msg = g_err;
+        if (R == 1) return local_rc;
+        want.assign((size_t)R, 0);
+        want[me] = -1;
+        req.clear();
+        halo.clear();
+    }
 
     MatGuard g;
     sgm_mat A = g.A = new sgm_mat_s;
@@ -608,7 +623,9 @@ int sgm_csr_create_dist_rect(sgm_mat *out, sgm_comm comm, const int64_t *row_sta
     A->halo_cols = halo;
     A->parts.resize(1);
     Part &p = A->parts[0];
-    if (where == SGM_DEVICE) {
+    if (local_rc != SGM_OK) {
+        // (rejected rows: nothing is built; this rank only takes part in the all-gather that spreads the verdict)
+    } else if (where == SGM_DEVICE) {
         // values stay on the device; only the renumbered node array is re-uploaded
         int32_t *dnode = nullptr;
         SGM_TRY(dalloc(&dnode, (size_t)std::max<int64_t>(nnz, 1)));
@@ -619,7 +636,7 @@ int sgm_csr_create_dist_rect(sgm_mat *out, sgm_comm comm, const int64_t *row_sta
         SGM_TRY(build_csr_part(p, n, nc, (int32_t)halo.size(), nnz, ptr_h, lnode.data(), val, SGM_HOST));
     }
     p.row_begin = r0;
-    set_interior_range(p, ptr_h, lnode.data());
+    if (local_rc == SGM_OK) set_interior_range(p, ptr_h, lnode.data());
     { std::vector<int32_t>().swap(hnode); std::vector<int32_t>().swap(lnode); }
 
     if (R > 1) {
@@ -639,6 +656,18 @@ int sgm_csr_create_dist_rect(sgm_mat *out, sgm_comm comm, const int64_t *row_sta
         SGM_HIP(hipStreamSynchronize(st));
         for (int q = 0; q < R; ++q)
             if (all[(size_t)me * R + q] != want[q]) return fail(SGM_ERR_RCCL, "sgm_csr_create_dist: all-gather returned a different want row");
+        // the verdicts: a rank whose rows were rejected, or a request for more entries than a rank owns -- every rank sees the
+        // same matrix, so every rank returns here or none does
+        for (int q = 0; q < R; ++q)
+            if (all[(size_t)q * R + q] < 0) {
+                if (q == me) { g_err = local_msg; return local_rc; }
+                return fail(SGM_ERR_BAD_ARG, "sgm_csr_create_dist: rank %d rejected its rows (see its error message)", q);
+            }
+        for (int q = 0; q < R; ++q)
+            for (int r = 0; r < R; ++r)
+                if (all[(size_t)q * R + r] > col_starts[r + 1] - col_starts[r])
+                    return fail(SGM_ERR_RCCL, "rank %d asks rank %d for %d entries of the %lld it owns", q, r, all[(size_t)q * R + r],
+                                (long long)(col_starts[r + 1] - col_starts[r]));
         std::vector<NbrPlan> plan;
         dist_neighbors(me, R, all.data(), plan);
         for (const NbrPlan &pl : plan) {
@@ -647,7 +676,6 @@ int sgm_csr_create_dist_rect(sgm_mat *out, sgm_comm comm, const int64_t *row_sta
             nb.send_count = pl.send_count;
             nb.recv_count = pl.recv_count;
             nb.recv_offset = pl.recv_offset;
-            if (pl.send_count > nc) return fail(SGM_ERR_RCCL, "rank %d asks for %d entries of the %d this rank owns", pl.peer, pl.send_count, nc);
             p.nbrs.push_back(nb);                       // buffers below are owned by the part from here on
             if (pl.send_count) {
                 SGM_TRY(dalloc(&p.nbrs.back().send_idx, (size_t)pl.send_count));
@@ -779,7 +807,12 @@ static int ensure_transpose_dist(sgm_mat A)
     std::vector<int64_t> roff(R + 1, 0);
     for (int q = 0; q < R; ++q) roff[q + 1] = roff[q] + all[(size_t)q * R + me];     // what rank q sends to me
     const int64_t nr = roff[R];
-    if (nr >= INT32_MAX) return fail(SGM_ERR_UNSUPPORTED, "matvec_t: the transposed row block exceeds int32 entries");
+    // (the verdict is the same on every rank -- each sees all the counts --, so nobody is left waiting in the exchange below)
+    for (int m = 0; m < R; ++m) {
+        int64_t tot = 0;
+        for (int q = 0; q < R; ++q) tot += all[(size_t)q * R + m];
+        if (tot >= INT32_MAX) return fail(SGM_ERR_UNSUPPORTED, "matvec_t: the transposed row block of rank %d exceeds int32 entries", m);
+    }
     int32_t *dsi = nullptr, *dsj = nullptr, *dri = nullptr, *drj = nullptr;
     double *dsv = nullptr, *drv = nullptr;
     SGM_TRY(dev(ns * 4, (void **)&dsi));

@@ -1052,7 +1052,7 @@ int read_state(sgm_solver s, int *flag, int64_t *iters, double *res)
 
 // A group of kGraphIters Krylov iterations captured once per solve as a hipGraph and replayed: below n ~ 1e6 an iteration of
 // the launch loops IS its launches (CG: three dependent ones, ~4.8 us each from the host; ~1.8 us each when replayed:
-// tools/graph_probe.cpp), so long solves of mid-sized systems spend two thirds of their time in the launch path.  The group
+// tools/probes/graph_probe.cpp), so long solves of mid-sized systems spend two thirds of their time in the launch path.  The group
 // is what the loop would launch -- same kernels, same arguments, generations relative to the group (k_flag_norm) -- captured
 // on the launch stream after the solve has run long enough to pay for the capture.
 constexpr int kGraphIters = 16;

@@ -476,7 +476,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_do(
 // words) plus 2 W gathers of x -- no LDS staging, no barrier, no row pointers; y leaves as one
 // 16-byte store.  HBM bytes per row: 8 W + 4 (+ x, y) instead of 9 nnz_row + 4.  Row blocks go
 // round-robin over the workgroups (it * grid + block), grid = min(slices, 4096): measured against
-// the LDS-staged kernel (tools/sl_ablate.cpp and bench): the 16-byte accesses and the plain map are
+// the LDS-staged kernel (tools/probes/sl_ablate.cpp and bench): the 16-byte accesses and the plain map are
 // worth 10-17 % each way of the comparison.  Products are rounded one by one and added in stored
 // order per row, exactly like the other kernels (bit-identical results).
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));

@@ -51,6 +51,27 @@ def run(rank, world, port, case, res):
             run_composite(rank, world, comm, dev, res)
             comm.destroy()
             return
+        if case == "badrows":
+            # rank 1 hands over rows whose ptr does not match nnz: EVERY rank must come back with an error (the verdict
+            # travels in the all-gather) instead of rank 1 leaving and its peers waiting in the collective for ever
+            n = 96 * 70
+            ptr, node, val = P.poisson2d_csr(96, 70)
+            starts = sg.partition_rows_by_nnz(ptr, world, align=2)
+            r0, r1 = int(starts[rank]), int(starts[rank + 1])
+            k0, k1 = ptr[r0] - 1, ptr[r1] - 1
+            lptr = (ptr[r0:r1 + 1] - k0).astype(np.int32)
+            if rank == 1:
+                lptr[-1] += 3
+            try:
+                sg.dist_csr_matrix(comm, starts, lptr, np.ascontiguousarray(node[k0:k1]), np.ascontiguousarray(val[k0:k1]))
+                raise AssertionError("sgm_csr_create_dist accepted rows whose ptr does not match nnz")
+            except sg.SigmaError as e:
+                msg = str(e)
+                assert ("ptr(n+1)-1" in msg) if rank == 1 else ("rank 1 rejected its rows" in msg), msg
+            res["n_halo"] = 1
+            res["solves"] = {}
+            comm.destroy()
+            return
         if case == "poisson2d":
             n = 96 * 70
             ptr, node, val = P.poisson2d_csr(96, 70)

@@ -81,6 +81,14 @@ def test_ranks_share_one_gpu_over_the_host_staged_transport(world, case, tmp_pat
         assert len(v) == 1, (k, v)
 
 
+def test_rejected_rows_on_one_rank_fail_on_every_rank_instead_of_hanging(tmp_path):
+    """sgm_csr_create_dist validates a rank's rows before its collectives; a rank that rejects its rows still takes part
+    in the all-gather, which carries the verdict: all three ranks return an error within seconds."""
+    t0 = time.time()
+    _run_ranks(3, "badrows", tmp_path, mock=True)
+    assert time.time() - t0 < 120
+
+
 @pytest.mark.parametrize("case", ["poisson2d", "laplace3d"])
 def test_ranks_on_two_gpus_over_rccl(case, tmp_path):
     if _device_count() < 2:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """C4 sweep of the column-blocked ELLPACK kernel's launch parameters (run on the GPU box)."""
 import json, os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 code = r'''
 import sys, json, time, numpy as np, torch
 sys.path.insert(0, %r)

@@ -4,13 +4,13 @@ nx x ny grid (6 neighbours + diagonal), vertices renumbered at random (what a me
 SpMV: no locality at all), then breadth_first_search + left/right permute on the device (permutations.f90:22-78,
 cs_matrices.f90:471-490) and the product again.  Prints us per product and the fraction of 8 TB/s on CSR bytes; the
 re-ordered product must equal the first one entry for entry (y2[p[i]] == y1[i]: rows keep their stored order).
-  python tools/fem_like.py [nx]"""
+  python tools/probes/fem_like.py [nx]"""
 import json
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 

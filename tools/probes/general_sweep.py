@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """k_csr_spmv (the any-row-length kernel) on the C2 matrix under one SGM_SPMV_CFG: us per product.
-  SGM_SPMV_CFG="block,vpt,nt,maxgrid,remap" python tools/general_sweep.py"""
+  SGM_SPMV_CFG="block,vpt,nt,maxgrid,remap" python tools/probes/general_sweep.py"""
 import sys, os, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import sigma_amd as sg
 from sigma_amd import problems as P

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Slice schedule A/B (one process per configuration; SGM_SLICE_SCHED / SGM_SPMV_CFG are read at init):
 SpMV time of the sliced kernel on 3-D grids, and a bit-identity check against the 1-byte-code kernel.
-  SGM_SLICE_SCHED=1,64 python tools/sched_probe.py 3d:464 3d:300"""
+  SGM_SLICE_SCHED=1,64 python tools/probes/sched_probe.py 3d:464 3d:300"""
 import json
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 
 import sigma_amd as sg  # noqa: E402

@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/sched; rm -rf $OUT; mkdir -p $OUT
 SPECS="${SPECS:-3d:464 3d:300 3d:215}"
-run() { echo "## SGM_SLICE_SCHED=$1 SGM_SPMV_CFG=$2"; SGM_SLICE_SCHED=$1 SGM_SPMV_CFG=$2 timeout 600 python tools/sched_probe.py $SPECS 2>&1 | grep -v Warning; }
+run() { echo "## SGM_SLICE_SCHED=$1 SGM_SPMV_CFG=$2"; SGM_SLICE_SCHED=$1 SGM_SPMV_CFG=$2 timeout 600 python tools/probes/sched_probe.py $SPECS 2>&1 | grep -v Warning; }
 {
 run 0 256,2,1,0,1,0
 run 1,64 256,2,1,0,1,0
@@ -18,7 +18,7 @@ run 0 256,2,1,2048,1,0
 cat $OUT/times.txt
 for S in 0 1,64; do
   tag=$(echo $S | tr ',' '_')
-  SGM_SLICE_SCHED=$S PROBE_REPS=3 PROBE_CHECK=0 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$tag -- python tools/sched_probe.py 3d:464 > $OUT/fetch_$tag.log 2>&1
+  SGM_SLICE_SCHED=$S PROBE_REPS=3 PROBE_CHECK=0 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$tag -- python tools/probes/sched_probe.py 3d:464 > $OUT/fetch_$tag.log 2>&1
 done
 python - <<'PY'
 import csv, glob, collections

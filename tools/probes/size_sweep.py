@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """SpMV time vs problem size and stencil shape (device-generated matrices): separates the
 size effect (Infinity Cache residency between launches) from the stencil's x reach.
-  python tools/size_sweep.py 2d:3162x3162 2d:10000x10000 3d:215 3d:464 1d:100000000"""
+  python tools/probes/size_sweep.py 2d:3162x3162 2d:10000x10000 3d:215 3d:464 1d:100000000"""
 import json
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 
 import sigma_amd as sg  # noqa: E402

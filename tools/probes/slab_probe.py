@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Per-step cost and workgroup-to-workgroup lag of k_trsv_slab: ILDU(0) applies on nx x ny x nz 7-point grids.
-  python tools/slab_probe.py [nx,ny,nz ...]"""
+  python tools/probes/slab_probe.py [nx,ny,nz ...]"""
 import sys, os, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import sigma_amd as sg
 from sigma_amd import problems as P

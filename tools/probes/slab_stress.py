@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Repeat ILDU(0) applies through the slab pipeline and compare every result with the level walkers' (bit for bit).
-  python tools/slab_stress.py w,h,nk[,reps] ..."""
+  python tools/probes/slab_stress.py w,h,nk[,reps] ..."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, sigma_amd as sg
 from sigma_amd import problems as P
 sg.init(0)
@@ -32,7 +32,7 @@ for arg in sys.argv[1:]:
     print(arg, "slabs", st, "mismatching applies:", bad, "/", reps, "first:", first, flush=True)
 # irregular patterns (the generic kernels: presence codes, per-row orders), generated as tests/test_gpu_parity.py does
 if os.environ.get("SLAB_STRESS_MIXED"):
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
     from test_gpu_parity import _grid3_like_matrix
     for w, h, nk, order, holes in ((200, 12, 9, "mixed", 0.0), (200, 12, 9, "asc", 0.2), (256, 20, 12, "mixed", 0.1), (130, 24, 10, "mixed", 0.0), (100, 20, 12, "mixed", 0.1)):
         n = w * h * nk

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Chain progress over time inside k_trsv_slab (clock samples every 16 steps): python tools/slab_trace.py nx ny nz [groups...]"""
+"""Chain progress over time inside k_trsv_slab (clock samples every 16 steps): python tools/probes/slab_trace.py nx ny nz [groups...]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, sigma_amd as sg
 from sigma_amd import problems as P
 sg.init(0)

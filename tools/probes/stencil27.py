@@ -2,7 +2,7 @@
 """27-point stencil on an m^3 grid (27 entries per interior row): the default kernel and, with the structured-matrix
 options off, the general ones.  us per product, fraction of 8 TB/s on reference-layout bytes (12 B/entry + 20 B/row)."""
 import sys, os, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import sigma_amd as sg
 sg.init(0); sg.use_torch_stream()

@@ -3,7 +3,7 @@
 kernel serves rows of 27 entries of similar length -- the sliced int32 form (k_csr_sl32<W=28>), the row-owner kernel
 or the streaming one."""
 import sys, os, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import sigma_amd as sg
 sg.init(0); sg.use_torch_stream()

@@ -2,8 +2,8 @@
 """One-off stress (not part of the suite): many seeded random matrices of every flavour through every CSR kernel
 combination, each product against the first combination's bits and a host evaluation of sampled rows in stored order."""
 import os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np
 import sigma_amd as sg
 sg.init(0)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-step cost and inter-strip lag of k_trsv_strip: ILDU(0) applies on nx x ny 5-point grids with 1, 2, 4 strips."""
 import sys, os, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import sigma_amd as sg
 from sigma_amd import problems as P
