@@ -100,8 +100,9 @@ int sgm_synchronize(void);
  * which whole slices are taken changes.  "slice_sched_band" (default 64): its band width in slices.
  * "krylov_graph" (default 1): the CG / BiCGStab launch loops on one GPU (plain or Jacobi-preconditioned) go on as replays of ONE
  * captured group of 16 iterations (a hipGraph: same kernels, same arguments, stop-flag generations relative to the group)
- * once a solve has run "krylov_graph_after" iterations (default 64, rounded to a multiple of 16): the launch path costs
- * ~1.8 us per kernel replayed against ~4.8 us launched, which is most of an iteration below n ~ 1e6.  0 = launch every kernel.
+ * once a solve has run long enough; 0 = launch every kernel.  Replays run at the GPU-side floor of an iteration (13.3 us for
+ * CG at n = 1e5) whatever the host's launch rate is (13.7-18 us when launched, box to box).
+ * "krylov_graph_after" (default 64, rounded up to a multiple of 16): the iterations a solve runs before its group is captured.
  * "dot_order" (default 0): how CG / BiCGStab (plain and preconditioned) add up their dot products.  0 = tree order
  * (per-workgroup partial sums, re-reduced in a fixed order): a legal order for the Fortran intrinsic, deterministic, and
  * the fast one.  1 = the order the reference build uses (amdflang -O2 on x86-64 turns dot_product into ONE accumulator
