@@ -98,6 +98,11 @@ int sgm_synchronize(void);
  * plane stride of a 3-D grid) hand their slices to the workgroups in a band order per XCD, so that the
  * slices one plane apart -- which read the same x entries -- share one XCD's L2; only the order in
  * which whole slices are taken changes.  "slice_sched_band" (default 64): its band width in slices.
+ * "csr_lean" (default 1): a matrix served by the 4-bit sliced form keeps ONLY that form (+ row pointers) in HBM -- C2: 0.48 GB
+ * instead of 1.13 GB.  Its CSR-order values, int32 columns and 1-byte codes are a function of the slices (slot u of a row is its
+ * u-th stored entry): they are rebuilt on the device for whoever reads them (the other kernels when options select them,
+ * sgm_mat_get, sgm_csr_set_values, transposes, preconditioner setup, permutations, the distributed transpose) and released
+ * again; 0 = every layout stays resident.  Takes effect when a matrix is created.
  * "krylov_graph" (default 1): the CG / BiCGStab launch loops on one GPU (plain or Jacobi-preconditioned) go on as replays of ONE
  * captured group of 16 iterations (a hipGraph: same kernels, same arguments, stop-flag generations relative to the group)
  * once a solve has run long enough; 0 = launch every kernel.  Replays run at the GPU-side floor of an iteration (13.3 us for

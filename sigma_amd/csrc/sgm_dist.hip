@@ -760,12 +760,14 @@ static int ensure_transpose_dist(sgm_mat A)
     hipStream_t st = g_rt.stream;
     std::vector<int32_t> hptr((size_t)n + 1), hcol((size_t)std::max<int64_t>(p.nnz, 1));
     std::vector<double> hval((size_t)std::max<int64_t>(p.nnz, 1));
+    SGM_TRY(csr_need_arrays(p));
     SGM_HIP(hipMemcpyAsync(hptr.data(), p.rowptr, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, st));
     if (p.nnz) {
         SGM_HIP(hipMemcpyAsync(hcol.data(), p.col, (size_t)p.nnz * 4, hipMemcpyDeviceToHost, st));
         SGM_HIP(hipMemcpyAsync(hval.data(), p.val, (size_t)p.nnz * 8, hipMemcpyDeviceToHost, st));
     }
     SGM_HIP(hipStreamSynchronize(st));
+    csr_release_arrays(p);
     // entries bucketed by the owner of their column, each bucket in (row, slot) order
     std::vector<int32_t> cnt(R, 0), off(R + 1, 0), owner((size_t)std::max<int64_t>(p.nnz, 1));
     for (int64_t k = 0; k < p.nnz; ++k) {

@@ -51,6 +51,9 @@ struct Options {
     int cg_small_chunk = 50000;    // its iterations per launch (the solve continues in the next launch from parked r, p)
     int slice_sched = 0;           // sliced kernels on matrices with a far stencil offset (3-D grids): band-ordered slice schedule per XCD
     int slice_sched_band = 64;     // its target band width in slices
+    int csr_lean = 1;              // matrices served by the 4-bit sliced form keep ONLY that form (+ row pointers): the int32 columns, the 1-byte
+                                   // codes and the CSR-order values are rebuilt from it when something asks (general kernels, preconditioner setup,
+                                   // sgm_mat_get, transposes, permutations) and released again; 0 = every layout stays resident (round 2)
     int krylov_graph = 1;          // CG / BiCGStab launch loops (one GPU, plain or Jacobi): replay a captured group of 16 iterations (hipGraph): the GPU-side
                                    // floor (13.3 us per CG iteration at n = 1e5) whatever the host's launch rate is (13.7-18 us launched, box to box)
     int krylov_graph_after = 64;   // ... once the solve has run this many iterations (a multiple of 16: the capture has to pay for itself)
@@ -149,6 +152,8 @@ struct Part {
     int32_t *scol = nullptr;       // sliced form WITHOUT a dictionary: the int32 column of every slot (-1 = no entry), same layout as sval
     uint8_t *sbcode = nullptr;     // sliced form for rows of 9..32 entries with a dictionary (k_csr_slb): 1-byte codes (255 = no entry),
                                    // per slice and chunk of 8 slots the 8 bytes of every row: ((slice * sw/8 + chunk) * 512 + row) * 8 + slot % 8
+    bool lean = false;             // val / col / code were released after the sliced form was built (option "csr_lean"): csr_need_arrays
+                                   // brings them back (from the sliced form) for whoever reads them, csr_release_arrays drops them again
     int32_t sw = 0;                // slots per row in sval (3, 5, 7 or 8)
     int32_t sched_period = 0;      // rows: the far offset most rows carry (a 3-D grid's plane), 0 = none / near
     mutable SliceSched sched[3];   // built on first use, one per row range launched (whole part, or interior / head / tail)
@@ -243,6 +248,9 @@ int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
                bool chain = false);
 
 int spmv_grid(const Part &p);
+// "csr_lean": the CSR-order arrays of a part that kept only its sliced form, on demand (no-op otherwise)
+int csr_need_arrays(const Part &p);
+void csr_release_arrays(const Part &p);
 
 // sgm_trsv3.hip: slab-pipelined triangular solves for ILDU(0) factors of 3-D grids (deps r-1, r-w, r-w*h)
 struct Slab3;

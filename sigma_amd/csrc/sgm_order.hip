@@ -39,7 +39,9 @@ int host_graph(sgm_mat A, const char *who, std::vector<int32_t> &ptr, std::vecto
     node.resize((size_t)p.nnz);
     SGM_HIP(hipStreamSynchronize(g_rt.stream));
     SGM_HIP(hipMemcpy(ptr.data(), p.rowptr, ptr.size() * 4, hipMemcpyDeviceToHost));       // 0-based on the device
+    SGM_TRY(csr_need_arrays(p));
     if (p.nnz) SGM_HIP(hipMemcpy(node.data(), p.col, node.size() * 4, hipMemcpyDeviceToHost));
+    csr_release_arrays(p);
     return SGM_OK;
 }
 
@@ -211,6 +213,8 @@ int sgm_graph_bfs_order(sgm_mat A, int32_t *p_out)
     const Part &pt = A->parts[0];
     const int32_t n = pt.n;
     if (n == 0) return SGM_OK;
+    SGM_TRY(csr_need_arrays(pt));          // the neighbour lists (a part that kept only its sliced form rebuilds them)
+    struct Release { const Part &p; ~Release() { csr_release_arrays(p); } } rel{pt};
     hipStream_t st = g_rt.stream;
     const size_t ne = (size_t)std::max<int64_t>(pt.nnz, 1);
     int32_t *p = nullptr, *first = nullptr, *fr[2] = {nullptr, nullptr}, *deg = nullptr, *off = nullptr, *cand = nullptr, *cnt = nullptr;
@@ -366,6 +370,7 @@ int sgm_mat_left_permute(sgm_mat A, const int32_t *p, int where)
         SGM_TRY(sgm_invalidate_transpose(A));
         return rebuild_ell_formats(pt);
     }
+    SGM_TRY(csr_need_arrays(pt));           // (a part that kept only its sliced form: the CSR-order arrays come back first)
     int32_t *len2 = nullptr, *rowptr2 = nullptr, *col2 = nullptr;
     double *val2 = nullptr;
     void *tmp = nullptr;
@@ -418,6 +423,7 @@ int sgm_mat_right_permute(sgm_mat A, const int32_t *p, int where)
         SGM_TRY(sgm_invalidate_transpose(A));
         return rebuild_ell_formats(pt);
     }
+    SGM_TRY(csr_need_arrays(pt));
     if (pt.nnz) hipLaunchKernelGGL(k_perm_cols, dim3(vec_grid(pt.nnz)), dim3(kBlock), 0, g_rt.stream, pt.nnz, pt.col, (const int32_t *)dp);
     const bool ok = hipStreamSynchronize(g_rt.stream) == hipSuccess && hipGetLastError() == hipSuccess;
     dfree(dp);

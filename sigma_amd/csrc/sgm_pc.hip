@@ -1225,6 +1225,8 @@ void trsv(const TriFactor &T, double *xp, const int *flag)
 // numbered >= ncol_own, are dropped).
 int download_block(const Part &p, std::vector<int32_t> &ptr1, std::vector<int32_t> &node1, std::vector<double> &val)
 {
+    SGM_TRY(csr_need_arrays(p));          // (a part that kept only its sliced form rebuilds col / val for the download)
+    struct Release { const Part &p; ~Release() { csr_release_arrays(p); } } rel{p};
     SGM_HIP(hipStreamSynchronize(g_rt.stream));
     if (p.n_halo == 0) {          // the whole part is its own diagonal block: straight into the 1-based arrays
         ptr1.resize((size_t)p.n + 1);
@@ -1347,9 +1349,11 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
     auto jacobi_rows = [&](const Part &p, int32_t fmt, int32_t row0, int32_t count, int32_t dcol, double *out) {
         const int grid = (count + kBlock - 1) / kBlock;
         if (!grid) return;
-        if (fmt == SGM_FMT_CSR)
+        if (fmt == SGM_FMT_CSR) {
+            if (csr_need_arrays(p) != SGM_OK) return;
             hipLaunchKernelGGL(k_jacobi_setup_csr, dim3(grid), dim3(kBlock), 0, st, count, row0, dcol, p.rowptr, p.col, p.val, out);
-        else
+            csr_release_arrays(p);
+        } else
             hipLaunchKernelGGL(k_jacobi_setup_ell, dim3(grid), dim3(kBlock), 0, st, count, row0, dcol, p.n, p.max_d, p.ecol,
                                p.eval, out);
     };

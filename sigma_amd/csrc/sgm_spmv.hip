@@ -985,7 +985,7 @@ int64_t ell_colblock_matvec_bytes(const Part &p);
 // k_csr_do exists for 256- and 512-thread workgroups only; with any other SGM_SPMV_CFG block size the
 // matrices it would serve take the streaming kernel (which has the 1024-thread variants) instead
 static bool do_block_ok() { const int b = spmv_cfg().block; return b == 256 || b == 512; }
-static bool use_offset_dict(const Part &p) { return p.code && g_opt.csr_offset_dict && do_block_ok(); }
+static bool use_offset_dict(const Part &p) { return (p.code || p.lean) && g_opt.csr_offset_dict && do_block_ok(); }
 static bool use_sliced(const Part &p) { return p.scode && g_opt.csr_sliced && g_opt.csr_offset_dict; }
 static bool use_sliced32(const Part &p) { return p.scol && g_opt.csr_sliced && !p.ecol; }
 static bool use_slicedb(const Part &p) { return p.sbcode && g_opt.csr_sliced && g_opt.csr_offset_dict; }
@@ -1450,6 +1450,7 @@ static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const doub
 {
     // a row range is the same kernel on shifted pointers: rowptr entries stay absolute offsets
     // into val/col/code; the offset-dict kernel forms columns as row + offset, so x shifts too
+    if (p.lean && !use_sliced(p)) (void)csr_need_arrays(p);      // a kernel other than the sliced one was asked for (options): its arrays come back and stay
     Part v;
     v.n = r.hi - r.lo;
     v.nnz = (int64_t)((double)p.nnz * v.n / (p.n > 0 ? p.n : 1));   // same row density => same tile choice as the full part
@@ -1635,6 +1636,75 @@ void set_interior_range(Part &p, const int32_t *ptr1, const int32_t *node1)
     }
     p.int_lo = best_lo * B;
     p.int_hi = std::min<int32_t>((best_lo + best_len) * B, p.n);
+}
+
+// ---- "csr_lean": the sliced form as the ONLY resident layout -----------------------------------------------------
+// C2 kept 1.13 GB resident for a kernel that reads 0.44 GB of it: CSR-order values (400 MB), int32 columns (200), 1-byte
+// codes (50) beside the sliced values + code words.  Slot u of a row in the sliced form IS the row's u-th stored entry
+// (k_dict_encode / k_sl_pack), so the three arrays are a pure function of (rowptr, scode, dict, sval): they are released
+// once the sliced form stands and rebuilt by k_sl_unpack for whoever reads them.
+__global__ __launch_bounds__(256) void k_sl_unpack(int32_t n, int32_t W, const int32_t *__restrict__ rowptr, const uint32_t *__restrict__ scode,
+                                                   const int32_t *__restrict__ dict, const double *__restrict__ sval,
+                                                   int32_t *__restrict__ col, double *__restrict__ val, uint8_t *__restrict__ code)
+{
+    __shared__ int32_t dl[16];
+    if (threadIdx.x < 16) dl[threadIdx.x] = dict[threadIdx.x];
+    __syncthreads();
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t cw = scode[i];
+        int32_t k = rowptr[i];
+        const double *src = sval + ((int64_t)(i >> 9) * W) * kSlRows + (i & (kSlRows - 1));
+        for (int u = 0; u < W; ++u) {
+            const uint32_t c = (cw >> (4 * u)) & 15u;
+            if (c == 15u) break;
+            if (col) col[k] = i + dl[c];
+            if (val) val[k] = src[(int64_t)u * kSlRows];
+            if (code) code[k] = (uint8_t)c;
+            ++k;
+        }
+    }
+}
+static bool lean_applies(const Part &p) { return g_opt.csr_lean && p.scode && p.sval && p.dict && !p.ecol && !p.scol && !p.sbcode && p.sw <= 8; }
+// after the sliced form has been built (or refreshed): keep only it
+static void csr_go_lean(Part &p)
+{
+    if (!lean_applies(p)) return;
+    dfree(p.val); dfree(p.col); dfree(p.code);
+    p.val = nullptr; p.col = nullptr; p.code = nullptr;
+    p.lean = true;
+}
+int csr_need_arrays(const Part &cp)
+{
+    Part &p = const_cast<Part &>(cp);
+    if (!p.lean || (p.val && p.col && p.code)) return SGM_OK;
+    hipStream_t st = g_rt.stream;
+    const int64_t nnz = p.nnz;
+    const bool mk_val = !p.val, mk_col = !p.col, mk_code = !p.code;
+    if (mk_col) { SGM_TRY(dalloc(&p.col, (size_t)nnz + 4)); SGM_HIP(hipMemsetAsync(p.col + nnz, 0, 4 * sizeof(int32_t), st)); }
+    if (mk_val) { SGM_TRY(dalloc(&p.val, (size_t)nnz + 2)); SGM_HIP(hipMemsetAsync(p.val + nnz, 0, 2 * sizeof(double), st)); }
+    if (mk_code) { SGM_TRY(dalloc(&p.code, (size_t)nnz + 32)); SGM_HIP(hipMemsetAsync(p.code + nnz, 0, 32, st)); }
+    if (p.n > 0)
+        hipLaunchKernelGGL(k_sl_unpack, dim3((unsigned)std::min<int64_t>(((int64_t)p.n + 255) / 256, 4096)), dim3(256), 0, st, p.n, p.sw,
+                           (const int32_t *)p.rowptr, (const uint32_t *)p.scode, (const int32_t *)p.dict, (const double *)p.sval,
+                           mk_col ? p.col : nullptr, mk_val ? p.val : nullptr, mk_code ? p.code : nullptr);
+    SGM_HIP(hipGetLastError());
+    return SGM_OK;
+}
+// a CSR-order value buffer to write new values into (they are then packed into the sliced form): allocated, not unpacked
+static int lean_val_buffer(Part &p)
+{
+    if (!p.lean || p.val) return SGM_OK;
+    SGM_TRY(dalloc(&p.val, (size_t)p.nnz + 2));
+    SGM_HIP(hipMemsetAsync(p.val + p.nnz, 0, 2 * sizeof(double), g_rt.stream));
+    return SGM_OK;
+}
+void csr_release_arrays(const Part &cp)
+{
+    Part &p = const_cast<Part &>(cp);
+    if (!p.lean || !lean_applies(p)) return;         // (option switched off meanwhile: what was rebuilt stays)
+    (void)hipStreamSynchronize(g_rt.stream);         // whoever asked for them has queued its reads on the stream
+    dfree(p.val); dfree(p.col); dfree(p.code);
+    p.val = nullptr; p.col = nullptr; p.code = nullptr;
 }
 
 // refresh the sliced copy of the values (no-op for parts without one)
@@ -1863,6 +1933,7 @@ static int build_offset_dict(Part &p, const int32_t *, const int32_t *)
     }
     SGM_HIP(hipStreamSynchronize(st));       // `dict` (host staging of the upload) goes out of scope
     if (p.scode || p.sbcode) SGM_TRY(detect_sched_period_csr(p, dict));
+    csr_go_lean(p);
     return SGM_OK;
 }
 
@@ -2032,6 +2103,8 @@ int build_csr_part(Part &p, int32_t n, int32_t ncol_own, int32_t n_halo, int64_t
 // after a change of the index arrays (matrix permutation): drop and rebuild the derived formats
 int rebuild_csr_formats(Part &p)
 {
+    SGM_TRY(csr_need_arrays(p));           // col / val are what the formats are rebuilt from
+    p.lean = false;
     dfree(p.code); dfree(p.dict); dfree(p.sval); dfree(p.scode); dfree(p.scol); dfree(p.sbcode);
     p.code = nullptr; p.dict = nullptr; p.sval = nullptr; p.scode = nullptr; p.scol = nullptr; p.sbcode = nullptr;
     p.ndict = 0; p.sw = 0; p.max_row = 0; p.sched_period = 0;
@@ -2191,7 +2264,8 @@ static int ensure_transpose(sgm_mat A)
             if (rc == SGM_OK) {
                 (void)hipMemsetAsync(tptr, 0, ((size_t)nt + 2) * 4, st);
                 (void)hipMemsetAsync(zeros, 0, m * 8, st);
-                if (nnz) {
+                if (nnz && !ell && csr_need_arrays(p) != SGM_OK) rc = SGM_ERR_ALLOC;
+                if (nnz && rc == SGM_OK) {
                     if (!ell)
                         hipLaunchKernelGGL(k_tr_keys_csr, dim3((unsigned)(((int64_t)p.n * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                                            p.n, (const int32_t *)p.rowptr, (const int32_t *)p.col, key, src, rowid, tptr);
@@ -2219,16 +2293,22 @@ static int ensure_transpose(sgm_mat A)
         }
         if (tmp) (void)hipFree(tmp);
         dfree(key); dfree(src); dfree(rowid); dfree(key2); dfree(tptr); dfree(tnode); dfree(zeros);
+        if (!ell) csr_release_arrays(p);
         if (rc != SGM_OK) { dfree(src2); if (T) sgm_mat_destroy(T); return rc; }
         A->tperm = src2;                                   // entry of A behind every entry of A^T
         A->T = T;
         A->t_stale = true;
     }
     if (A->t_stale && nnz) {
-        hipLaunchKernelGGL(k_gather_perm, dim3(vec_grid(nnz)), dim3(kBlock), 0, g_rt.stream, A->T->parts[0].val,
+        Part &tp = A->T->parts[0];
+        if (!ell) SGM_TRY(csr_need_arrays(p));             // A's values in CSR order (a lean part rebuilds them from its slices)
+        SGM_TRY(lean_val_buffer(tp));
+        hipLaunchKernelGGL(k_gather_perm, dim3(vec_grid(nnz)), dim3(kBlock), 0, g_rt.stream, tp.val,
                            (const double *)(ell ? p.eval : p.val), (const int32_t *)A->tperm, nnz);
         SGM_HIP(hipGetLastError());
-        SGM_TRY(pack_sliced(A->T->parts[0]));
+        SGM_TRY(pack_sliced(tp));
+        csr_release_arrays(tp);
+        if (!ell) csr_release_arrays(p);
     }
     A->t_stale = false;
     return SGM_OK;
@@ -2340,11 +2420,13 @@ int sgm_csr_set_values(sgm_mat A, const double *val, int where)
     A->t_stale = true;
     int64_t off = 0;
     for (auto &p : A->parts) {
+        SGM_TRY(lean_val_buffer(p));
         SGM_HIP(hipMemcpyAsync(p.val, val + off, (size_t)p.nnz * 8,
                                where == SGM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
                                g_rt.stream));
         off += p.nnz;
         SGM_TRY(pack_sliced(p));
+        csr_release_arrays(p);
     }
     SGM_HIP(hipStreamSynchronize(g_rt.stream));
     return SGM_OK;
@@ -2513,8 +2595,10 @@ int sgm_mat_get(sgm_mat A, const char *name, void *out, size_t bytes, size_t *ne
     const std::string nm(name);
     std::vector<int32_t> vi;
     std::vector<double> vd;
-    SGM_HIP(hipStreamSynchronize(g_rt.stream));
     const bool ell = A->fmt == SGM_FMT_ELL;
+    if (!ell && (nm == "node" || nm == "val")) SGM_TRY(csr_need_arrays(p));
+    struct Release { const Part &p; bool on; ~Release() { if (on) csr_release_arrays(p); } } rel{p, !ell};
+    SGM_HIP(hipStreamSynchronize(g_rt.stream));
     if (!ell && nm == "ptr") {
         vi.resize((size_t)p.n + 1);
         SGM_HIP(hipMemcpy(vi.data(), p.rowptr, vi.size() * 4, hipMemcpyDeviceToHost));

@@ -1690,6 +1690,62 @@ def test_colour_ordered_ildu_on_a_large_grid_vs_oracle(orc):
         H.left_permute(bad)
 
 
+def test_lean_footprint_and_on_demand_arrays(orc):
+    """Option csr_lean (default on): a matrix served by the 4-bit sliced form keeps only that form + row pointers resident
+    (<= 1.15 x what its kernel reads of the matrix); everything that needs the CSR-order arrays -- the other kernels,
+    sgm_mat_get, value updates, transposes, preconditioner setup, permutations -- gets them rebuilt from the slices,
+    bit for bit, and the footprint returns to the lean figure afterwards."""
+    nx, ny = 600, 400
+    n = nx * ny
+    ptr, node, val = P.poisson2d_csr(nx, ny)
+    A = orc.CsrMatrix(n, n, ptr, node, val)
+    H = hip_from_oracle(A)
+    assert H.kernel.startswith("k_csr_sl<")
+    res0, moved = H.footprint()
+    matrix_read = moved - 16 * n                       # what one product reads of the matrix itself (x and y excluded)
+    assert res0 <= 1.15 * matrix_read, (res0, matrix_read)
+    sg.set_option("csr_lean", 0)
+    try:
+        Hfat = hip_from_oracle(A)
+        resfat, _ = Hfat.footprint()
+    finally:
+        sg.set_option("csr_lean", 1)
+    assert resfat >= 2.0 * res0, (resfat, res0)        # (round 2 kept values twice + int32 columns + byte codes)
+    x = P.test_vector(n)
+    yref = A.matvec(x)
+    y = np.zeros(n); H.matvec(x, y); assert np.array_equal(y, yref)
+    # arrays read back from the slices == the arrays handed over
+    assert np.array_equal(H.get("node", np.int32), A.node) and np.array_equal(H.get("val", np.float64), A.val)
+    assert H.footprint()[0] == res0
+    # the other kernels on the same handle (their arrays come back and stay while the option is off)
+    for dict_opt, sl_opt, ro_opt, rg_opt, _tag in KERNEL_COMBOS:
+        _kernel_options(dict_opt, sl_opt, ro_opt, rg_opt)
+        try:
+            y[:] = -1.0; H.matvec(x, y)
+        finally:
+            _kernel_options(1, 1, 1)
+        assert np.array_equal(y, yref), _tag
+    # value update, transpose, Jacobi / ILDU setup
+    v2 = A.val * 1.25 + 0.5
+    H.set_values(v2)
+    A2 = orc.CsrMatrix(n, n, ptr, node, v2)
+    H.matvec(x, y); assert np.array_equal(y, A2.matvec(x))
+    t = np.zeros(n); H.matvec_t(x, t); assert np.array_equal(t, A2.matvec_t(x))
+    assert np.array_equal(H.get("val", np.float64), v2)
+    pj = sg.jacobi(); pj.setup(H)
+    assert np.array_equal(pj.get("idiag", np.float64), orc.Jacobi(A2).idiag)
+    pl = sg.ldu(); pl.setup(H)
+    refl = orc.Ildu(A2)
+    assert np.array_equal(pl.get("D", np.float64), refl.D)
+    z = np.zeros(n); pl.solve(H, z, x); assert np.array_equal(z, refl.solve(x))
+    # permutation (rebuilds every format from the CSR-order arrays)
+    pperm = H.bfs_order()
+    H.left_permute(pperm); H.right_permute(pperm)
+    B = orc.permuted(A2, pperm, pperm)
+    assert np.array_equal(H.get("node", np.int32), B.node) and np.array_equal(H.get("val", np.float64), B.val)
+    H.matvec(x, y); assert np.array_equal(y, B.matvec(x))
+
+
 def test_pipeline_abort_is_loud_and_recovers(orc):
     """The strip / slab pipelined triangular solves wait with a bound; a wait that gives up (a preempted or shared GPU)
     must never hand NaN patterns to the caller as a result.  Forced here with a spin limit of 1: sgm_pc_apply returns the
