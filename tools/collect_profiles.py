@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense gpurun_out/prof_round (tools/profile_round.sh) into profiles/<tag>/."""
 import csv, glob, hashlib, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", "prof_round"), os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
@@ -38,6 +38,17 @@ for d, c in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         if r["Counter_Name"] != c or "sgm::k_csr" not in r["Kernel_Name"]:
             continue
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        out["kernels"].setdefault(k, {}).setdefault(c, []).append(float(r["Counter_Value"]))
+# the CG update kernels and the C5 product: their own passes (bench.py with a CG leg and the C5 leg)
+for d, c in (("pmc_fetch_cg_c5", "FETCH_SIZE"), ("pmc_write_cg_c5", "WRITE_SIZE")):
+    f = newest(os.path.join(d, "*", "*counter_collection.csv"))
+    if not f:
+        continue
+    for r in csv.DictReader(open(f)):
+        nm = r["Kernel_Name"]
+        if r["Counter_Name"] != c or not ("k_elem<sgm::FCg" in nm or "k_csr_sl<7" in nm):
+            continue
+        k = nm.split("(")[0].replace("void ", "")
         out["kernels"].setdefault(k, {}).setdefault(c, []).append(float(r["Counter_Value"]))
 for k, v in out["kernels"].items():
     for c in list(v):
