@@ -625,6 +625,22 @@ def c1_leg(sg, P, torch, dev, n=10000, tol=1e-16):
     out = {"workload": f"tridiag(-1,2,-1) n={n}, CG from 0 to an absolute {tol:g} (BASELINE configs[0])",
            "gpu_ms": 1e3 * gpu_s, "gpu_iterations": int(s.last_iterations),
            "gpu_max_err_vs_analytic": float(np.abs(u.cpu().numpy() - v).max())}
+    # the same solve with the reference's dot_product order (option dot_order = 1: one accumulator, first element to last):
+    # the iterates are then the reference's bit for bit -- it stops where the reference stops
+    sg.set_option("dot_order", 1)
+    try:
+        u.zero_()
+        s.solve(A, u, b)
+        torch.cuda.synchronize()
+        u.zero_()
+        t0 = time.perf_counter()
+        s.solve(A, u, b)
+        torch.cuda.synchronize()
+        out["gpu_dot_order1_ms"] = 1e3 * (time.perf_counter() - t0)
+        out["gpu_dot_order1_iterations"] = int(s.last_iterations)
+        out["gpu_dot_order1_max_err_vs_analytic"] = float(np.abs(u.cpu().numpy() - v).max())
+    finally:
+        sg.set_option("dot_order", 0)
     s.destroy()
     A.destroy()
     drv = os.path.join(ROOT, "oracle", "_ref", "sigma_ref_driver")

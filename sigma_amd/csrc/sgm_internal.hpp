@@ -51,6 +51,7 @@ struct Options {
     int cg_small_chunk = 50000;    // its iterations per launch (the solve continues in the next launch from parked r, p)
     int slice_sched = 0;           // sliced kernels on matrices with a far stencil offset (3-D grids): band-ordered slice schedule per XCD
     int slice_sched_band = 64;     // its target band width in slices
+    int csr_sell = 1;              // general matrices (no offset dictionary, rows too long or too uneven for the uniform sliced form): SELL-128-512
     int csr_lean = 1;              // matrices served by the 4-bit sliced form keep ONLY that form (+ row pointers): the int32 columns, the 1-byte
                                    // codes and the CSR-order values are rebuilt from it when something asks (general kernels, preconditioner setup,
                                    // sgm_mat_get, transposes, permutations) and released again; 0 = every layout stays resident (round 2)
@@ -154,6 +155,13 @@ struct Part {
                                    // per slice and chunk of 8 slots the 8 bytes of every row: ((slice * sw/8 + chunk) * 512 + row) * 8 + slot % 8
     bool lean = false;             // val / col / code were released after the sliced form was built (option "csr_lean"): csr_need_arrays
                                    // brings them back (from the sliced form) for whoever reads them, csr_release_arrays drops them again
+    // SELL-128-512 (general matrices, any columns, rows of ANY length that differ inside a neighbourhood): the rows of every
+    // 512-row slice sorted by length, chunks of 128 sorted rows stored slot-major with the chunk's own width (k_csr_sell)
+    double *sl_val = nullptr;      // values, chunk c at sl_off[c], slot u of position q at + u * 128 + q
+    int32_t *sl_col = nullptr;     // columns beside them (-1 = no entry)
+    uint16_t *sl_perm = nullptr;   // position -> row inside its slice (0xffff = no row), n rounded up to whole slices
+    int64_t *sl_off = nullptr;     // chunks + 1 offsets (entries)
+    int64_t sl_total = 0;          // stored slots (entries + padding)
     int32_t sw = 0;                // slots per row in sval (3, 5, 7 or 8)
     int32_t sched_period = 0;      // rows: the far offset most rows carry (a 3-D grid's plane), 0 = none / near
     mutable SliceSched sched[3];   // built on first use, one per row range launched (whole part, or interior / head / tail)

@@ -581,6 +581,154 @@ __global__ __launch_bounds__(256) void k_csr_sl(
     }
 }
 
+// SELL-128-512: general matrices whose rows are too long (> 32 entries) or too uneven for one slice width.
+// The uniform sliced form pads every row to the longest one; rows of 20..40 or 33..64 entries then waste a third of the
+// stream, and the kernels that avoid padding (k_csr_do / k_csr_rl: tiles staged through LDS, a row walked by its owner
+// lane) run at 0.36-0.53 of the HBM peak, bound by the per-CU address / LDS pipes.  Here the rows
+// of every 512-row slice are SORTED by length (a permutation inside the slice: y and w are still touched within one 4 KB
+// window) and stored in chunks of 128 sorted rows, slot-major, each chunk with its own width = its longest row (rounded up
+// to 4): padding is what neighbours in the sorted order differ by -- a few per cent.  One wave owns one chunk (a lane two
+// adjacent positions): every matrix load is a coalesced 16 / 8 bytes per lane at a scalar base, no row pointer, no LDS, no
+// barrier; a row's entries keep their stored order, products are rounded one by one and added left to right: the
+// reference's row sum, bit for bit.
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+constexpr int kSellChunk = 128;
+template <bool ADD, bool DOT_W, bool DOT_YY>
+__global__ __launch_bounds__(256) void k_csr_sell(
+    int32_t n, const int64_t *__restrict__ off, const uint16_t *__restrict__ perm, const int32_t *__restrict__ scol,
+    const double *__restrict__ sval, const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ w,
+    double *__restrict__ part_wy, double *__restrict__ part_yy, const int *__restrict__ flag_done, int gen, int remap)
+{
+    constexpr int BLOCK = 256;
+    __shared__ double red[BLOCK / 64];
+    const int st = flag_done ? *flag_done : 0;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool chain = (remap & 256) != 0;
+    const int64_t nsl = ((int64_t)n + kSlRows - 1) / kSlRows;
+    double dwy = 0.0, dyy = 0.0;
+    if (st && gen >= st) return;
+
+    int64_t first = blockIdx.x;             // XCD-block-cyclic slices, see k_csr_sl
+    if ((remap & 255) >= 3) {
+        const int G = (remap & 255) == 3 ? 8 : (remap & 255) == 4 ? 2 : (remap & 255) == 6 ? 64 : (remap & 255) == 7 ? 128 : 32;
+        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        first = (int64_t)(loc / G) * (8 * G) + xcd * G + loc % G;
+    }
+    for (int64_t sl = first; sl < nsl; sl += gridDim.x) {
+        const int64_t chunk = sl * (kSlRows / kSellChunk) + wave;
+        const int64_t o0 = off[chunk];
+        const int32_t W = (int32_t)((off[chunk + 1] - o0) / kSellChunk);            // a multiple of 4
+        const u16x2 pr = *reinterpret_cast<const u16x2 *>(perm + chunk * kSellChunk + 2 * lane);
+        const int32_t base = (int32_t)(sl * kSlRows);
+        const bool va = pr.x != 0xffffu, vb_ = pr.y != 0xffffu;
+        const int32_t ra = base + pr.x, rb = base + pr.y;
+        double ya = 0.0, yb = 0.0;
+        if (ADD) { if (va) ya = y[ra]; if (vb_) yb = y[rb]; }
+        const f64x2 *vb = reinterpret_cast<const f64x2 *>(sval + o0) + lane;
+        const i32x2 *cb = reinterpret_cast<const i32x2 *>(scol + o0) + lane;
+        double za = (ADD && chain) ? ya : 0.0, zb = (ADD && chain) ? yb : 0.0;
+        auto slots = [&](int32_t c0, auto CHc) {
+            constexpr int CH = decltype(CHc)::value;
+            f64x2 v[CH];
+            i32x2 cc[CH];
+            double xa[CH], xb[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                v[u] = __builtin_nontemporal_load(vb + (int64_t)(c0 + u) * (kSellChunk / 2));
+                cc[u] = __builtin_nontemporal_load(cb + (int64_t)(c0 + u) * (kSellChunk / 2));
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                xa[u] = cc[u].x >= 0 ? x[cc[u].x] : 0.0;
+                xb[u] = cc[u].y >= 0 ? x[cc[u].y] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                if (cc[u].x >= 0) za = za + v[u].x * xa[u];
+                if (cc[u].y >= 0) zb = zb + v[u].y * xb[u];
+            }
+        };
+        int32_t c0 = 0;
+        for (; c0 + 8 <= W; c0 += 8) slots(c0, std::integral_constant<int, 8>());
+        if (c0 < W) slots(c0, std::integral_constant<int, 4>());
+        const double yia = ADD ? (chain ? za : ya + za) : 0.0 + za;
+        const double yib = ADD ? (chain ? zb : yb + zb) : 0.0 + zb;
+        if (va) {
+            y[ra] = yia;
+            if (DOT_W) dwy += w[ra] * yia;
+            if (DOT_YY) dyy += yia * yia;
+        }
+        if (vb_) {
+            y[rb] = yib;
+            if (DOT_W) dwy += w[rb] * yib;
+            if (DOT_YY) dyy += yib * yib;
+        }
+    }
+    if (DOT_W) {
+        const double t = block_sum<BLOCK>(dwy, red);
+        if (threadIdx.x == 0) part_wy[blockIdx.x] = t;
+    }
+    if (DOT_YY) {
+        const double t = block_sum<BLOCK>(dyy, red);
+        if (threadIdx.x == 0) part_yy[blockIdx.x] = t;
+    }
+}
+// setup: positions of a slice's rows sorted by length (longest first, ties by row: the sort is a pure function of the row
+// lengths), the chunks' widths (as entry counts, to be prefix-summed), ...
+__global__ __launch_bounds__(256) void k_sell_sort(int32_t n, const int32_t *__restrict__ rowptr, uint16_t *__restrict__ perm,
+                                                   int64_t *__restrict__ wid)
+{
+    __shared__ int32_t len[kSlRows];
+    __shared__ int32_t first_len[kSlRows / kSellChunk];
+    const int64_t nsl = ((int64_t)n + kSlRows - 1) / kSlRows;
+    for (int64_t sl = blockIdx.x; sl < nsl; sl += gridDim.x) {
+        __syncthreads();
+        for (int r = threadIdx.x; r < kSlRows; r += blockDim.x) {
+            const int64_t row = sl * kSlRows + r;
+            len[r] = row < n ? rowptr[row + 1] - rowptr[row] : -1;        // (rows past the end sort last)
+        }
+        if (threadIdx.x < kSlRows / kSellChunk) first_len[threadIdx.x] = 0;
+        __syncthreads();
+        for (int r = threadIdx.x; r < kSlRows; r += blockDim.x) {
+            const int32_t l = len[r];
+            int rank = 0;
+            for (int j = 0; j < kSlRows; ++j) rank += (len[j] > l || (len[j] == l && j < r)) ? 1 : 0;
+            perm[sl * kSlRows + rank] = l >= 0 ? (uint16_t)r : (uint16_t)0xffffu;
+            if (rank % kSellChunk == 0) first_len[rank / kSellChunk] = l > 0 ? l : 0;
+        }
+        __syncthreads();
+        if (threadIdx.x < kSlRows / kSellChunk)
+            wid[sl * (kSlRows / kSellChunk) + threadIdx.x] = (int64_t)((first_len[threadIdx.x] + 3) / 4 * 4) * kSellChunk;
+    }
+}
+// ... and the chunks' slots filled from the CSR arrays (val only: a value update)
+__global__ __launch_bounds__(256) void k_sell_fill(int32_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                   const double *__restrict__ val, const int64_t *__restrict__ off,
+                                                   const uint16_t *__restrict__ perm, int32_t *__restrict__ scol, double *__restrict__ sval)
+{
+    const int64_t nch = (((int64_t)n + kSlRows - 1) / kSlRows) * (kSlRows / kSellChunk);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nch; chunk += (int64_t)gridDim.x * 4) {
+        const int64_t o0 = off[chunk];
+        const int32_t W = (int32_t)((off[chunk + 1] - o0) / kSellChunk);
+        for (int h = 0; h < 2; ++h) {
+            const int q = lane + 64 * h;
+            const uint16_t pr = perm[chunk * kSellChunk + q];
+            int32_t k = 0, ke = 0;
+            if (pr != 0xffffu) {
+                const int64_t row = (chunk / (kSlRows / kSellChunk)) * kSlRows + pr;
+                k = rowptr[row]; ke = rowptr[row + 1];
+            }
+            for (int32_t u = 0; u < W; ++u) {
+                const bool has = k + u < ke;
+                sval[o0 + (int64_t)u * kSellChunk + q] = has ? val[k + u] : 0.0;
+                if (scol) scol[o0 + (int64_t)u * kSellChunk + q] = has ? col[k + u] : -1;
+            }
+        }
+    }
+}
+
 // The sliced form for matrices WITHOUT an offset dictionary (arbitrary columns) whose rows are short
 // (<= 32 entries) and of similar length: the int32 column of every slot is stored beside the value,
 // slot-major in the same 512-row slices (-1 = no entry); 12 bytes per slot like plain CSR, but every
@@ -989,7 +1137,8 @@ static bool use_offset_dict(const Part &p) { return (p.code || p.lean) && g_opt.
 static bool use_sliced(const Part &p) { return p.scode && g_opt.csr_sliced && g_opt.csr_offset_dict; }
 static bool use_sliced32(const Part &p) { return p.scol && g_opt.csr_sliced && !p.ecol; }
 static bool use_slicedb(const Part &p) { return p.sbcode && g_opt.csr_sliced && g_opt.csr_offset_dict; }
-static bool any_sliced(const Part &p) { return use_sliced(p) || use_sliced32(p) || use_slicedb(p); }
+static bool use_sell(const Part &p) { return p.sl_val && g_opt.csr_sliced && g_opt.csr_sell && !p.ecol; }
+static bool any_sliced(const Part &p) { return use_sliced(p) || use_sliced32(p) || use_slicedb(p) || use_sell(p); }
 // k_csr_do serves both the dictionary form and, for short rows, plain int32 columns
 static bool use_row_owner(const Part &p)
 {
@@ -1232,6 +1381,25 @@ static void launch_csr_sl32(const Part &p, int grid, const double *x, double *y,
 }
 
 template <bool ADD>
+static void launch_csr_sell(const Part &p, int grid, const double *x, double *y, const double *w,
+                            double *pwy, double *pyy, const int *flag, int gen)
+{
+    hipStream_t st = g_rt.stream;
+    const SpmvCfg &c = spmv_cfg();
+    int mode = c.remap == 1 ? ((grid <= kMaxGrid / 2 || (int64_t)p.n < (int64_t)32768 * kSlRows) ? 5 : 0) : (c.remap >= 3 ? c.remap : 0);
+    if (mode >= 3 && grid % (8 * (mode == 3 ? 8 : mode == 4 ? 2 : mode == 6 ? 64 : mode == 7 ? 128 : 32)) != 0) mode = 0;
+#define L(DW, DY)                                                                                                    \
+    hipLaunchKernelGGL((k_csr_sell<ADD, DW, DY>), dim3(grid), dim3(256), 0, st, p.n, (const int64_t *)p.sl_off,       \
+                       (const uint16_t *)p.sl_perm, (const int32_t *)p.sl_col, (const double *)p.sl_val, x, y, w, pwy, pyy, flag, \
+                       gen, mode | g_launch_flags)
+    if (w && pyy) L(true, true);
+    else if (w) L(true, false);
+    else if (pyy) L(false, true);
+    else L(false, false);
+#undef L
+}
+
+template <bool ADD>
 static void launch_csr_slb(const Part &p, int grid, const double *x, double *y, const double *w,
                            double *pwy, double *pyy, const int *flag, int gen)
 {
@@ -1463,6 +1631,11 @@ static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const doub
     if (sliced) { v.sval = p.sval + (int64_t)r.lo * p.sw; v.scode = p.scode + r.lo; v.sw = p.sw; }
     if (slicedb) { v.sval = p.sval + (int64_t)r.lo * p.sw; v.sbcode = p.sbcode + (int64_t)r.lo * ((p.sw + 7) / 8 * 8); v.sw = p.sw; }
     if (sliced32) { v.sval = p.sval + (int64_t)r.lo * p.sw; v.scol = p.scol + (int64_t)r.lo * p.sw; v.sw = p.sw; }
+    const bool sell = !sliced && !slicedb && !sliced32 && use_sell(p);
+    if (sell) {         // chunk offsets are absolute (into sl_val / sl_col); the chunk table and the positions shift with the range
+        v.sl_val = p.sl_val; v.sl_col = p.sl_col;
+        v.sl_off = p.sl_off + r.lo / kSellChunk; v.sl_perm = p.sl_perm + r.lo;
+    }
     const bool dict = use_offset_dict(p);
     const double *xs = dict ? x + r.lo : x;
     double *ys = y + r.lo;
@@ -1477,6 +1650,9 @@ static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const doub
     } else if (sliced32) {            // absolute columns: x is not shifted
         if (add) launch_csr_sl32<true>(v, r.grid, x, ys, ws, pw, py, flag_done, gen);
         else launch_csr_sl32<false>(v, r.grid, x, ys, ws, pw, py, flag_done, gen);
+    } else if (sell) {
+        if (add) launch_csr_sell<true>(v, r.grid, x, ys, ws, pw, py, flag_done, gen);
+        else launch_csr_sell<false>(v, r.grid, x, ys, ws, pw, py, flag_done, gen);
     } else if (use_row_owner(p)) {
         if (add) launch_csr_do<true>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
         else launch_csr_do<false>(v, r.grid, xs, ys, ws, pw, py, flag_done, gen);
@@ -1624,7 +1800,7 @@ void set_interior_range(Part &p, const int32_t *ptr1, const int32_t *node1)
     if (p.n_halo == 0 || p.n == 0) return;
     // ranges are cut at row-block boundaries of the kernel that will run them (512-row slices for the
     // sliced kernel; a multiple of the other kernels' 256-row blocks, so they can run the ranges too)
-    const int B = (p.scode || p.scol || p.sbcode) ? std::max(kSlRows, spmv_cfg().block) : spmv_cfg().block;
+    const int B = (p.scode || p.scol || p.sbcode || p.sl_val) ? std::max(kSlRows, spmv_cfg().block) : spmv_cfg().block;
     const int32_t nb = (p.n + B - 1) / B;
     int32_t best_lo = 0, best_len = 0, run_lo = 0, run_len = 0;
     for (int32_t b = 0; b < nb; ++b) {
@@ -1710,6 +1886,13 @@ void csr_release_arrays(const Part &cp)
 // refresh the sliced copy of the values (no-op for parts without one)
 int pack_sliced(Part &p)
 {
+    if (p.sl_val && p.n > 0) {          // SELL-128-512: the values of every slot again (columns stay)
+        const int64_t nch = (((int64_t)p.n + kSlRows - 1) / kSlRows) * (kSlRows / kSellChunk);
+        hipLaunchKernelGGL(k_sell_fill, dim3((unsigned)std::min<int64_t>((nch + 3) / 4, 65536)), dim3(256), 0, g_rt.stream, p.n,
+                           (const int32_t *)p.rowptr, (const int32_t *)nullptr, (const double *)p.val, (const int64_t *)p.sl_off,
+                           (const uint16_t *)p.sl_perm, (int32_t *)nullptr, p.sl_val);
+        SGM_HIP(hipGetLastError());
+    }
     if ((!p.scode && !p.scol && !p.sbcode) || p.n == 0) return SGM_OK;
     const int64_t nsl = ((int64_t)p.n + kSlRows - 1) / kSlRows;
     if (p.ecol)
@@ -1835,6 +2018,48 @@ static int32_t far_offset_of_sample(const std::vector<uint8_t> &codes, int64_t r
         if (4 * freq[(size_t)c] >= rows) far = std::max<int64_t>(far, std::llabs((long long)dict[(size_t)c]));
     return (int32_t)std::min<int64_t>(far, INT32_MAX);
 }
+// SELL-128-512 of a part (see k_csr_sell): built for matrices without an offset dictionary that the uniform sliced form
+// does not take, when sorting the rows of a slice keeps the padding below 30 % (a handful of very long rows among short
+// ones -- an arrow matrix -- would blow their chunks up: those matrices stay with the CSR kernels)
+static void free_sell(Part &p)
+{
+    dfree(p.sl_val); dfree(p.sl_col); dfree(p.sl_perm); dfree(p.sl_off);
+    p.sl_val = nullptr; p.sl_col = nullptr; p.sl_perm = nullptr; p.sl_off = nullptr; p.sl_total = 0;
+}
+static int build_sell(Part &p)
+{
+    free_sell(p);
+    if (!g_opt.csr_sliced || !g_opt.csr_sell || p.ecol || p.n < 1 || p.nnz < 4 * (int64_t)p.n || p.max_row < 1) return SGM_OK;
+    hipStream_t st = g_rt.stream;
+    const int64_t nsl = ((int64_t)p.n + kSlRows - 1) / kSlRows, nch = nsl * (kSlRows / kSellChunk);
+    SGM_TRY(dalloc(&p.sl_perm, (size_t)nsl * kSlRows));
+    SGM_TRY(dalloc(&p.sl_off, (size_t)nch + 1));
+    SGM_HIP(hipMemsetAsync(p.sl_off + nch, 0, sizeof(int64_t), st));
+    hipLaunchKernelGGL(k_sell_sort, dim3((unsigned)std::min<int64_t>(nsl, 65536)), dim3(256), 0, st, p.n, (const int32_t *)p.rowptr,
+                       p.sl_perm, p.sl_off);
+    void *tmp = nullptr;
+    size_t tb = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, p.sl_off, p.sl_off, (int)(nch + 1), st);
+    if (hipMalloc(&tmp, std::max<size_t>(tb, 16)) != hipSuccess) { free_sell(p); return fail(SGM_ERR_ALLOC, "SELL build: scan workspace"); }
+    (void)hipcub::DeviceScan::ExclusiveSum(tmp, tb, p.sl_off, p.sl_off, (int)(nch + 1), st);
+    int64_t total = 0;
+    const hipError_t e1 = hipMemcpyAsync(&total, p.sl_off + nch, sizeof(int64_t), hipMemcpyDeviceToHost, st);
+    const hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    if (e1 != hipSuccess || e2 != hipSuccess) { free_sell(p); return fail(SGM_ERR_HIP, "SELL build: scan failed"); }
+    if (total <= 0 || (double)total > 1.30 * (double)p.nnz) { free_sell(p); return SGM_OK; }
+    p.sl_total = total;
+    int rc = dalloc(&p.sl_val, (size_t)total + 2);
+    if (rc == SGM_OK) rc = dalloc(&p.sl_col, (size_t)total + 2);
+    if (rc != SGM_OK) { free_sell(p); return rc; }
+    hipLaunchKernelGGL(k_sell_fill, dim3((unsigned)std::min<int64_t>((nch + 3) / 4, 65536)), dim3(256), 0, st, p.n,
+                       (const int32_t *)p.rowptr, (const int32_t *)p.col, (const double *)p.val, (const int64_t *)p.sl_off,
+                       (const uint16_t *)p.sl_perm, p.sl_col, p.sl_val);
+    SGM_HIP(hipGetLastError());
+    SGM_HIP(hipStreamSynchronize(st));
+    return SGM_OK;
+}
+
 static int detect_sched_period_csr(Part &p, const std::vector<int32_t> &dict)
 {
     p.sched_period = 0;
@@ -1878,7 +2103,7 @@ static int build_offset_dict(Part &p, const int32_t *, const int32_t *)
     auto sliced32 = [&]() -> int {
         const int W = p.max_row <= 3 ? 3 : p.max_row <= 5 ? 5 : p.max_row <= 7 ? 7 : p.max_row <= 8 ? 8 : p.max_row <= 12 ? 12
                     : p.max_row <= 16 ? 16 : p.max_row <= 20 ? 20 : p.max_row <= 24 ? 24 : p.max_row <= 28 ? 28 : 32;
-        if (!g_opt.csr_sliced || p.max_row < 1 || p.max_row > 32 || (double)W * n > 1.25 * (double)nnz) return SGM_OK;
+        if (!g_opt.csr_sliced || p.max_row < 1 || p.max_row > 32 || (double)W * n > 1.25 * (double)nnz) return build_sell(p);
         const size_t rows_padded = ((size_t)n + kSlRows - 1) / kSlRows * kSlRows;
         SGM_TRY(dalloc(&p.scol, rows_padded * W));
         SGM_TRY(dalloc(&p.sval, rows_padded * W));
@@ -2107,6 +2332,7 @@ int rebuild_csr_formats(Part &p)
     p.lean = false;
     dfree(p.code); dfree(p.dict); dfree(p.sval); dfree(p.scode); dfree(p.scol); dfree(p.sbcode);
     p.code = nullptr; p.dict = nullptr; p.sval = nullptr; p.scode = nullptr; p.scol = nullptr; p.sbcode = nullptr;
+    free_sell(p);
     p.ndict = 0; p.sw = 0; p.max_row = 0; p.sched_period = 0;
     free_slice_sched(p);
     return build_offset_dict(p, nullptr, nullptr);
@@ -2135,6 +2361,7 @@ void free_part(Part &p)
     for (auto &nb : p.nbrs) { dfree(nb.send_idx); dfree(nb.send_buf); }
     free_slice_sched(p);
     free_ell_colblock(p);
+    free_sell(p);
     p = Part();
 }
 
@@ -2668,6 +2895,7 @@ int sgm_mat_kernel(sgm_mat A, char *buf, int len)
         } else if (use_sliced(p)) snprintf(name, sizeof name, "k_csr_sl<W=%d>", p.sw);
         else if (use_slicedb(p)) snprintf(name, sizeof name, "k_csr_slb<W=%d>", p.sw);
         else if (use_sliced32(p)) snprintf(name, sizeof name, "k_csr_sl32<W=%d>", p.sw);
+        else if (use_sell(p)) snprintf(name, sizeof name, "k_csr_sell<pad=%.3f>", p.nnz ? (double)p.sl_total / (double)p.nnz : 1.0);
         else if (use_offset_dict(p)) snprintf(name, sizeof name, "k_csr_do<256,%d,CW=1>", do_tile_for(p));
         else if (use_row_owner(p)) snprintf(name, sizeof name, "k_csr_do<256,%d,CW=4>", do_tile_for(p));
         else if (use_row_lines(p)) snprintf(name, sizeof name, "k_csr_rl");
@@ -2693,6 +2921,7 @@ static int64_t part_resident_bytes(const Part &p)
     if (p.scode) b += 4 * nsl * kSlRows;
     if (p.scol) b += 4 * nsl * kSlRows * p.sw;
     if (p.sbcode) b += nsl * kSlRows * ((p.sw + 7) / 8 * 8);
+    if (p.sl_val) b += 12 * p.sl_total + 2 * nsl * kSlRows + 8 * (nsl * (kSlRows / kSellChunk) + 1);
     if (p.ecol) b += 4 * (int64_t)p.n * p.max_d;
     if (p.eval) b += 8 * (int64_t)p.n * p.max_d;
     if (p.edeg) b += 4 * (int64_t)p.n;
@@ -2714,6 +2943,7 @@ static int64_t part_matvec_bytes(const sgm_mat_s *A, const Part &p)
     } else if (use_sliced(p)) m = nsl * kSlRows * (8 * (int64_t)p.sw + 4);
     else if (use_slicedb(p)) m = nsl * kSlRows * (8 * (int64_t)p.sw + (p.sw + 7) / 8 * 8);
     else if (use_sliced32(p)) m = nsl * kSlRows * 12 * (int64_t)p.sw;
+    else if (use_sell(p)) m = 12 * p.sl_total + 2 * nsl * kSlRows + 8 * nsl * (kSlRows / kSellChunk);      // slots (entries + padding), positions, chunk offsets
     else if (use_offset_dict(p)) m = 9 * p.nnz + 4 * ((int64_t)p.n + 1);
     else m = 12 * p.nnz + 4 * ((int64_t)p.n + 1);
     return m + 8 * p.xlen() + 8 * (int64_t)p.n;

@@ -735,7 +735,8 @@ def test_single_workgroup_cg_vs_oracle_and_vs_the_launch_loop(orc, kind):
 
 @pytest.mark.parametrize("n,lo,hi", [(700, 70, 120), (5000, 66, 90), (3001, 1, 200), (9000, 33, 64), (2500, 100, 2600), (4000, 10, 25)])
 def test_long_row_kernels_vs_oracle(orc, n, lo, hi):
-    """General matrices with LONG rows (arbitrary columns inside a band, no dictionary): the row-owner kernel up to 64
+    """General matrices with LONG rows (arbitrary columns inside a band, no dictionary): SELL-128-512 (rows of a slice sorted
+    by length, chunks of 128 with their own width: the default), the row-owner kernel up to 64
     entries per row, the line-staged row-owner kernel beyond (one 128-byte line of values per row and pass) and the
     streaming kernel -- matvec, y += A x, both transpose products, Inf/NaN in x, a row
     partition with halo ranges, and CG with the dots fused into the product, all against the oracle bit for bit."""
@@ -765,8 +766,9 @@ def test_long_row_kernels_vs_oracle(orc, n, lo, hi):
     ubr, itb, _, _ = orc.bicgstab(A, b, tol=1e-12)
     starts = sg.partition_rows_by_nnz(ptr, 3, align=2)
     seen = set()
-    for ro_opt, rg_opt in ((1, 1), (0, 1), (0, 0)):
+    for sell_opt, ro_opt, rg_opt in ((1, 1, 1), (0, 1, 1), (0, 0, 1), (0, 0, 0)):
         _kernel_options(1, 1, ro_opt, rg_opt)
+        sg.set_option("csr_sell", sell_opt)           # SELL-128-512 (the default for these matrices), then the CSR kernels
         try:
             H = sg.csr_matrix(n, n, ptr, node, val)
             seen.add(H.kernel.split("<")[0])
@@ -793,7 +795,8 @@ def test_long_row_kernels_vs_oracle(orc, n, lo, hi):
             sb.solve(H, ub, b)
         finally:
             _kernel_options(1, 1, 1, 1)
-        key = (n, lo, hi, ro_opt, rg_opt)
+            sg.set_option("csr_sell", 1)
+        key = (n, lo, hi, sell_opt, ro_opt, rg_opt)
         assert abs(sb.iterations - itb) <= 1 and np.abs(ub - ubr).max() / np.abs(ubr).max() <= 1e-11, (key, sb.iterations, itb)
         assert np.array_equal(y, y_ref), key
         assert np.array_equal(ya, ya_ref), key
@@ -807,6 +810,8 @@ def test_long_row_kernels_vs_oracle(orc, n, lo, hi):
     lens = S.getnnz(axis=1)
     uniform = int(lens.max()) * n <= 4 * S.nnz and S.nnz >= 16 * n and lens.max() <= 4096
     assert "k_csr_spmv" in seen and (("k_csr_rl" in seen) == bool(uniform)), (seen, uniform)
+    # SELL-128-512 takes every one of these matrices except the one whose two dense rows would blow their chunks up
+    assert ("k_csr_sell" in seen) == ((n, lo, hi) != (2500, 100, 2600)), (seen, n, lo, hi)
 
 
 def test_slice_schedule_keeps_results(orc):
