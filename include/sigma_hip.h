@@ -99,9 +99,10 @@ int sgm_synchronize(void);
  * slices one plane apart -- which read the same x entries -- share one XCD's L2; only the order in
  * which whole slices are taken changes.  "slice_sched_band" (default 64): its band width in slices.
  * "csr_sell" (default 1): general matrices (no offset dictionary) whose rows are too long or too uneven for the uniform sliced
- * form are stored as SELL-128-512: the rows of every 512-row slice sorted by length, chunks of 128 sorted rows slot-major
+ * form are stored as SELL-128-512: the rows of every window of 512 rows sorted by length, chunks of 128 sorted rows slot-major
  * with the chunk's own width (padding: a few per cent; built when it stays below 30 %).  One wave per chunk, coalesced
- * 16 / 8-byte loads, no LDS; rows keep their stored entry order (bit-identical sums).  0 = the CSR kernels (row owner,
+ * 16 / 8-byte loads, no LDS; rows keep their stored entry order (bit-identical sums).  Taken from a longest row of 49 entries
+ * on (shorter rows: the row-owner kernel is faster); 2 = whenever the padding allows; 0 = the CSR kernels (row owner,
  * line-staged, streaming).
  * "csr_lean" (default 1): a matrix served by the 4-bit sliced form keeps ONLY that form (+ row pointers) in HBM -- C2: 0.48 GB
  * instead of 1.13 GB.  Its CSR-order values, int32 columns and 1-byte codes are a function of the slices (slot u of a row is its

@@ -156,10 +156,10 @@ struct Part {
     bool lean = false;             // val / col / code were released after the sliced form was built (option "csr_lean"): csr_need_arrays
                                    // brings them back (from the sliced form) for whoever reads them, csr_release_arrays drops them again
     // SELL-128-512 (general matrices, any columns, rows of ANY length that differ inside a neighbourhood): the rows of every
-    // 512-row slice sorted by length, chunks of 128 sorted rows stored slot-major with the chunk's own width (k_csr_sell)
+    // window of 512 rows sorted by length, chunks of 128 sorted rows stored slot-major with the chunk's own width (k_csr_sell)
     double *sl_val = nullptr;      // values, chunk c at sl_off[c], slot u of position q at + u * 128 + q
     int32_t *sl_col = nullptr;     // columns beside them (-1 = no entry)
-    uint16_t *sl_perm = nullptr;   // position -> row inside its slice (0xffff = no row), n rounded up to whole slices
+    uint16_t *sl_perm = nullptr;   // position -> row inside its sort window (0xffff = no row), n rounded up to whole slices
     int64_t *sl_off = nullptr;     // chunks + 1 offsets (entries)
     int64_t sl_total = 0;          // stored slots (entries + padding)
     int32_t sw = 0;                // slots per row in sval (3, 5, 7 or 8)

@@ -174,7 +174,7 @@ int sgm_set_option(const char *name, int value)
     if (!strcmp(name, "slice_sched")) { g_opt.slice_sched = value; return SGM_OK; }
     if (!strcmp(name, "slice_sched_band")) { g_opt.slice_sched_band = std::max(8, value); return SGM_OK; }
     if (!strcmp(name, "gmres_cgs2")) { g_opt.gmres_cgs2 = value; return SGM_OK; }
-    if (!strcmp(name, "csr_sell")) { g_opt.csr_sell = value != 0; return SGM_OK; }
+    if (!strcmp(name, "csr_sell")) { g_opt.csr_sell = value < 0 ? 0 : value > 2 ? 2 : value; return SGM_OK; }
     if (!strcmp(name, "csr_lean")) { g_opt.csr_lean = value != 0; return SGM_OK; }
     if (!strcmp(name, "krylov_graph")) { g_opt.krylov_graph = value != 0; return SGM_OK; }
     if (!strcmp(name, "krylov_graph_after")) { g_opt.krylov_graph_after = std::max(16, (value + 15) / 16 * 16); return SGM_OK; }

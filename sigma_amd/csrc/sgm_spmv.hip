@@ -585,14 +585,17 @@ __global__ __launch_bounds__(256) void k_csr_sl(
 // The uniform sliced form pads every row to the longest one; rows of 20..40 or 33..64 entries then waste a third of the
 // stream, and the kernels that avoid padding (k_csr_do / k_csr_rl: tiles staged through LDS, a row walked by its owner
 // lane) run at 0.36-0.53 of the HBM peak, bound by the per-CU address / LDS pipes.  Here the rows
-// of every 512-row slice are SORTED by length (a permutation inside the slice: y and w are still touched within one 4 KB
-// window) and stored in chunks of 128 sorted rows, slot-major, each chunk with its own width = its longest row (rounded up
-// to 4): padding is what neighbours in the sorted order differ by -- a few per cent.  One wave owns one chunk (a lane two
+// of every window of 512 rows are SORTED by length (a permutation inside the window: y and w are still touched within one
+// 4 KB window, and a chunk's x gathers stay as local as the rows' neighbourhood) and stored in chunks of 128 sorted rows, slot-major, each chunk with its own width = its longest row (rounded
+// up to 2): padding is what neighbours in the sorted order differ by -- a few per cent.  One wave owns one chunk (a lane two
 // adjacent positions): every matrix load is a coalesced 16 / 8 bytes per lane at a scalar base, no row pointer, no LDS, no
 // barrier; a row's entries keep their stored order, products are rounded one by one and added left to right: the
 // reference's row sum, bit for bit.
 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 constexpr int kSellChunk = 128;
+constexpr int kSellSigma = 512;       // rows sorted together (a multiple of the 512-row slices).  Measured on the banded test matrices: windows of
+                                      // 2048 rows cut the padding from 10-12 % to 2-4 % and were 35-40 % SLOWER -- a chunk's 128 rows then come from a
+                                      // 2048-row neighbourhood and their x gathers no longer fit the CU's L1 (33..64 entries per row: 656 -> 920 us)
 template <bool ADD, bool DOT_W, bool DOT_YY>
 __global__ __launch_bounds__(256) void k_csr_sell(
     int32_t n, const int64_t *__restrict__ off, const uint16_t *__restrict__ perm, const int32_t *__restrict__ scol,
@@ -618,9 +621,9 @@ __global__ __launch_bounds__(256) void k_csr_sell(
     for (int64_t sl = first; sl < nsl; sl += gridDim.x) {
         const int64_t chunk = sl * (kSlRows / kSellChunk) + wave;
         const int64_t o0 = off[chunk];
-        const int32_t W = (int32_t)((off[chunk + 1] - o0) / kSellChunk);            // a multiple of 4
+        const int32_t W = (int32_t)((off[chunk + 1] - o0) / kSellChunk);            // a multiple of 2
         const u16x2 pr = *reinterpret_cast<const u16x2 *>(perm + chunk * kSellChunk + 2 * lane);
-        const int32_t base = (int32_t)(sl * kSlRows);
+        const int32_t base = (int32_t)(sl / (kSellSigma / kSlRows)) * kSellSigma;   // the sort window's first row
         const bool va = pr.x != 0xffffu, vb_ = pr.y != 0xffffu;
         const int32_t ra = base + pr.x, rb = base + pr.y;
         double ya = 0.0, yb = 0.0;
@@ -651,7 +654,8 @@ __global__ __launch_bounds__(256) void k_csr_sell(
         };
         int32_t c0 = 0;
         for (; c0 + 8 <= W; c0 += 8) slots(c0, std::integral_constant<int, 8>());
-        if (c0 < W) slots(c0, std::integral_constant<int, 4>());
+        if (c0 + 4 <= W) { slots(c0, std::integral_constant<int, 4>()); c0 += 4; }
+        if (c0 < W) slots(c0, std::integral_constant<int, 2>());
         const double yia = ADD ? (chain ? za : ya + za) : 0.0 + za;
         const double yib = ADD ? (chain ? zb : yb + zb) : 0.0 + zb;
         if (va) {
@@ -674,32 +678,36 @@ __global__ __launch_bounds__(256) void k_csr_sell(
         if (threadIdx.x == 0) part_yy[blockIdx.x] = t;
     }
 }
-// setup: positions of a slice's rows sorted by length (longest first, ties by row: the sort is a pure function of the row
+// setup: positions of a window's rows sorted by length (longest first, ties by row: the sort is a pure function of the row
 // lengths), the chunks' widths (as entry counts, to be prefix-summed), ...
 __global__ __launch_bounds__(256) void k_sell_sort(int32_t n, const int32_t *__restrict__ rowptr, uint16_t *__restrict__ perm,
                                                    int64_t *__restrict__ wid)
 {
-    __shared__ int32_t len[kSlRows];
-    __shared__ int32_t first_len[kSlRows / kSellChunk];
-    const int64_t nsl = ((int64_t)n + kSlRows - 1) / kSlRows;
-    for (int64_t sl = blockIdx.x; sl < nsl; sl += gridDim.x) {
+    __shared__ int32_t len[kSellSigma];
+    __shared__ int32_t first_len[kSellSigma / kSellChunk];
+    const int64_t nwin = ((int64_t)n + kSellSigma - 1) / kSellSigma;
+    const int64_t nch = (((int64_t)n + kSlRows - 1) / kSlRows) * (kSlRows / kSellChunk);       // chunks that exist (whole slices)
+    for (int64_t win = blockIdx.x; win < nwin; win += gridDim.x) {
         __syncthreads();
-        for (int r = threadIdx.x; r < kSlRows; r += blockDim.x) {
-            const int64_t row = sl * kSlRows + r;
+        for (int r = threadIdx.x; r < kSellSigma; r += blockDim.x) {
+            const int64_t row = win * kSellSigma + r;
             len[r] = row < n ? rowptr[row + 1] - rowptr[row] : -1;        // (rows past the end sort last)
         }
-        if (threadIdx.x < kSlRows / kSellChunk) first_len[threadIdx.x] = 0;
+        if (threadIdx.x < kSellSigma / kSellChunk) first_len[threadIdx.x] = 0;
         __syncthreads();
-        for (int r = threadIdx.x; r < kSlRows; r += blockDim.x) {
+        for (int r = threadIdx.x; r < kSellSigma; r += blockDim.x) {
             const int32_t l = len[r];
             int rank = 0;
-            for (int j = 0; j < kSlRows; ++j) rank += (len[j] > l || (len[j] == l && j < r)) ? 1 : 0;
-            perm[sl * kSlRows + rank] = l >= 0 ? (uint16_t)r : (uint16_t)0xffffu;
+            for (int j = 0; j < kSellSigma; ++j) rank += (len[j] > l || (len[j] == l && j < r)) ? 1 : 0;
+            const int64_t pos = win * kSellSigma + rank;
+            if (pos / kSellChunk < nch) perm[pos] = l >= 0 ? (uint16_t)r : (uint16_t)0xffffu;
             if (rank % kSellChunk == 0) first_len[rank / kSellChunk] = l > 0 ? l : 0;
         }
         __syncthreads();
-        if (threadIdx.x < kSlRows / kSellChunk)
-            wid[sl * (kSlRows / kSellChunk) + threadIdx.x] = (int64_t)((first_len[threadIdx.x] + 3) / 4 * 4) * kSellChunk;
+        if (threadIdx.x < kSellSigma / kSellChunk) {
+            const int64_t c = win * (kSellSigma / kSellChunk) + threadIdx.x;
+            if (c < nch) wid[c] = (int64_t)((first_len[threadIdx.x] + 1) / 2 * 2) * kSellChunk;
+        }
     }
 }
 // ... and the chunks' slots filled from the CSR arrays (val only: a value update)
@@ -717,7 +725,7 @@ __global__ __launch_bounds__(256) void k_sell_fill(int32_t n, const int32_t *__r
             const uint16_t pr = perm[chunk * kSellChunk + q];
             int32_t k = 0, ke = 0;
             if (pr != 0xffffu) {
-                const int64_t row = (chunk / (kSlRows / kSellChunk)) * kSlRows + pr;
+                const int64_t row = (chunk / (kSellSigma / kSellChunk)) * kSellSigma + pr;
                 k = rowptr[row]; ke = rowptr[row + 1];
             }
             for (int32_t u = 0; u < W; ++u) {
@@ -1133,11 +1141,12 @@ int64_t ell_colblock_matvec_bytes(const Part &p);
 // k_csr_do exists for 256- and 512-thread workgroups only; with any other SGM_SPMV_CFG block size the
 // matrices it would serve take the streaming kernel (which has the 1024-thread variants) instead
 static bool do_block_ok() { const int b = spmv_cfg().block; return b == 256 || b == 512; }
-static bool use_offset_dict(const Part &p) { return (p.code || p.lean) && g_opt.csr_offset_dict && do_block_ok(); }
+static bool use_offset_dict(const Part &p) { return (p.code || (p.lean && p.dict)) && g_opt.csr_offset_dict && do_block_ok(); }
 static bool use_sliced(const Part &p) { return p.scode && g_opt.csr_sliced && g_opt.csr_offset_dict; }
 static bool use_sliced32(const Part &p) { return p.scol && g_opt.csr_sliced && !p.ecol; }
 static bool use_slicedb(const Part &p) { return p.sbcode && g_opt.csr_sliced && g_opt.csr_offset_dict; }
 static bool use_sell(const Part &p) { return p.sl_val && g_opt.csr_sliced && g_opt.csr_sell && !p.ecol; }
+static bool lean_sell(const Part &p);      // (the SELL form is the part's only resident layout: see csr_lean below)
 static bool any_sliced(const Part &p) { return use_sliced(p) || use_sliced32(p) || use_slicedb(p) || use_sell(p); }
 // k_csr_do serves both the dictionary form and, for short rows, plain int32 columns
 static bool use_row_owner(const Part &p)
@@ -1618,7 +1627,7 @@ static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const doub
 {
     // a row range is the same kernel on shifted pointers: rowptr entries stay absolute offsets
     // into val/col/code; the offset-dict kernel forms columns as row + offset, so x shifts too
-    if (p.lean && !use_sliced(p)) (void)csr_need_arrays(p);      // a kernel other than the sliced one was asked for (options): its arrays come back and stay
+    if (p.lean && !(lean_sell(p) ? use_sell(p) : use_sliced(p))) (void)csr_need_arrays(p);      // a kernel other than the resident form's was asked for (options): its arrays come back and stay
     Part v;
     v.n = r.hi - r.lo;
     v.nnz = (int64_t)((double)p.nnz * v.n / (p.n > 0 ? p.n : 1));   // same row density => same tile choice as the full part
@@ -1800,7 +1809,7 @@ void set_interior_range(Part &p, const int32_t *ptr1, const int32_t *node1)
     if (p.n_halo == 0 || p.n == 0) return;
     // ranges are cut at row-block boundaries of the kernel that will run them (512-row slices for the
     // sliced kernel; a multiple of the other kernels' 256-row blocks, so they can run the ranges too)
-    const int B = (p.scode || p.scol || p.sbcode || p.sl_val) ? std::max(kSlRows, spmv_cfg().block) : spmv_cfg().block;
+    const int B = p.sl_val ? kSellSigma : (p.scode || p.scol || p.sbcode) ? std::max(kSlRows, spmv_cfg().block) : spmv_cfg().block;      // (SELL: whole sort windows)
     const int32_t nb = (p.n + B - 1) / B;
     int32_t best_lo = 0, best_len = 0, run_lo = 0, run_len = 0;
     for (int32_t b = 0; b < nb; ++b) {
@@ -1840,7 +1849,31 @@ __global__ __launch_bounds__(256) void k_sl_unpack(int32_t n, int32_t W, const i
         }
     }
 }
-static bool lean_applies(const Part &p) { return g_opt.csr_lean && p.scode && p.sval && p.dict && !p.ecol && !p.scol && !p.sbcode && p.sw <= 8; }
+// the same out of the SELL-128-512 form: position q of chunk c holds row perm(c, q); slot u is its u-th stored entry
+__global__ __launch_bounds__(256) void k_sell_unpack(int32_t n, const int32_t *__restrict__ rowptr, const int64_t *__restrict__ off,
+                                                     const uint16_t *__restrict__ perm, const int32_t *__restrict__ scol,
+                                                     const double *__restrict__ sval, int32_t *__restrict__ col, double *__restrict__ val)
+{
+    const int64_t nch = (((int64_t)n + kSlRows - 1) / kSlRows) * (kSlRows / kSellChunk);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nch; chunk += (int64_t)gridDim.x * 4) {
+        const int64_t o0 = off[chunk];
+        for (int h = 0; h < 2; ++h) {
+            const int q = lane + 64 * h;
+            const uint16_t pr = perm[chunk * kSellChunk + q];
+            if (pr == 0xffffu) continue;
+            const int64_t row = (chunk / (kSellSigma / kSellChunk)) * kSellSigma + pr;
+            const int32_t k = rowptr[row], len = rowptr[row + 1] - k;
+            for (int32_t u = 0; u < len; ++u) {
+                if (col) col[k + u] = scol[o0 + (int64_t)u * kSellChunk + q];
+                if (val) val[k + u] = sval[o0 + (int64_t)u * kSellChunk + q];
+            }
+        }
+    }
+}
+static bool lean_sliced(const Part &p) { return p.scode && p.sval && p.dict && !p.ecol && !p.scol && !p.sbcode && p.sw <= 8; }
+static bool lean_sell(const Part &p) { return p.sl_val && p.sl_col && !p.scode && !p.scol && !p.sbcode && !p.ecol; }
+static bool lean_applies(const Part &p) { return g_opt.csr_lean && (lean_sliced(p) || lean_sell(p)); }
 // after the sliced form has been built (or refreshed): keep only it
 static void csr_go_lean(Part &p)
 {
@@ -1852,18 +1885,29 @@ static void csr_go_lean(Part &p)
 int csr_need_arrays(const Part &cp)
 {
     Part &p = const_cast<Part &>(cp);
-    if (!p.lean || (p.val && p.col && p.code)) return SGM_OK;
+    if (!p.lean || (p.val && p.col && (p.code || lean_sell(p)))) return SGM_OK;
     hipStream_t st = g_rt.stream;
     const int64_t nnz = p.nnz;
     const bool mk_val = !p.val, mk_col = !p.col, mk_code = !p.code;
     if (mk_col) { SGM_TRY(dalloc(&p.col, (size_t)nnz + 4)); SGM_HIP(hipMemsetAsync(p.col + nnz, 0, 4 * sizeof(int32_t), st)); }
     if (mk_val) { SGM_TRY(dalloc(&p.val, (size_t)nnz + 2)); SGM_HIP(hipMemsetAsync(p.val + nnz, 0, 2 * sizeof(double), st)); }
+    if (lean_sell(p)) {           // (no dictionary: no byte codes to bring back)
+        const int64_t nch = (((int64_t)p.n + kSlRows - 1) / kSlRows) * (kSlRows / kSellChunk);
+        if (p.n > 0 && (mk_col || mk_val))
+            hipLaunchKernelGGL(k_sell_unpack, dim3((unsigned)std::min<int64_t>((nch + 3) / 4, 65536)), dim3(256), 0, st, p.n,
+                               (const int32_t *)p.rowptr, (const int64_t *)p.sl_off, (const uint16_t *)p.sl_perm, (const int32_t *)p.sl_col,
+                               (const double *)p.sl_val, mk_col ? p.col : nullptr, mk_val ? p.val : nullptr);
+        SGM_HIP(hipGetLastError());
+        SGM_HIP(hipStreamSynchronize(st));     // (readers may use blocking copies, which do not order against this stream)
+        return SGM_OK;
+    }
     if (mk_code) { SGM_TRY(dalloc(&p.code, (size_t)nnz + 32)); SGM_HIP(hipMemsetAsync(p.code + nnz, 0, 32, st)); }
     if (p.n > 0)
         hipLaunchKernelGGL(k_sl_unpack, dim3((unsigned)std::min<int64_t>(((int64_t)p.n + 255) / 256, 4096)), dim3(256), 0, st, p.n, p.sw,
                            (const int32_t *)p.rowptr, (const uint32_t *)p.scode, (const int32_t *)p.dict, (const double *)p.sval,
                            mk_col ? p.col : nullptr, mk_val ? p.val : nullptr, mk_code ? p.code : nullptr);
     SGM_HIP(hipGetLastError());
+    SGM_HIP(hipStreamSynchronize(st));         // (readers may use blocking copies, which do not order against this stream)
     return SGM_OK;
 }
 // a CSR-order value buffer to write new values into (they are then packed into the sliced form): allocated, not unpacked
@@ -2030,12 +2074,17 @@ static int build_sell(Part &p)
 {
     free_sell(p);
     if (!g_opt.csr_sliced || !g_opt.csr_sell || p.ecol || p.n < 1 || p.nnz < 4 * (int64_t)p.n || p.max_row < 1) return SGM_OK;
+    // rows of up to 48 entries stay with the row-owner kernel: its tiles hold consecutive rows, whose x gathers share more L1
+    // lines than a sorted chunk's (banded 20..40 entries per row: 719-753 us against 819 here; from 33..64 on SELL wins:
+    // 650 against 770-794, 64..128: 656 against 781-816, 150..300: 770 against 930)
+    if (p.max_row <= 48 && g_opt.csr_sell < 2) return SGM_OK;
     hipStream_t st = g_rt.stream;
     const int64_t nsl = ((int64_t)p.n + kSlRows - 1) / kSlRows, nch = nsl * (kSlRows / kSellChunk);
     SGM_TRY(dalloc(&p.sl_perm, (size_t)nsl * kSlRows));
     SGM_TRY(dalloc(&p.sl_off, (size_t)nch + 1));
     SGM_HIP(hipMemsetAsync(p.sl_off + nch, 0, sizeof(int64_t), st));
-    hipLaunchKernelGGL(k_sell_sort, dim3((unsigned)std::min<int64_t>(nsl, 65536)), dim3(256), 0, st, p.n, (const int32_t *)p.rowptr,
+    const int64_t nwin = ((int64_t)p.n + kSellSigma - 1) / kSellSigma;
+    hipLaunchKernelGGL(k_sell_sort, dim3((unsigned)std::min<int64_t>(nwin, 65536)), dim3(256), 0, st, p.n, (const int32_t *)p.rowptr,
                        p.sl_perm, p.sl_off);
     void *tmp = nullptr;
     size_t tb = 0;
@@ -2057,6 +2106,7 @@ static int build_sell(Part &p)
                        (const uint16_t *)p.sl_perm, p.sl_col, p.sl_val);
     SGM_HIP(hipGetLastError());
     SGM_HIP(hipStreamSynchronize(st));
+    csr_go_lean(p);
     return SGM_OK;
 }
 

@@ -766,9 +766,9 @@ def test_long_row_kernels_vs_oracle(orc, n, lo, hi):
     ubr, itb, _, _ = orc.bicgstab(A, b, tol=1e-12)
     starts = sg.partition_rows_by_nnz(ptr, 3, align=2)
     seen = set()
-    for sell_opt, ro_opt, rg_opt in ((1, 1, 1), (0, 1, 1), (0, 0, 1), (0, 0, 0)):
+    for sell_opt, ro_opt, rg_opt in ((2, 1, 1), (0, 1, 1), (0, 0, 1), (0, 0, 0)):
         _kernel_options(1, 1, ro_opt, rg_opt)
-        sg.set_option("csr_sell", sell_opt)           # SELL-128-512 (the default for these matrices), then the CSR kernels
+        sg.set_option("csr_sell", sell_opt)           # SELL-128-512 (2: whenever its padding allows; by default from rows of 49 entries on), then the CSR kernels
         try:
             H = sg.csr_matrix(n, n, ptr, node, val)
             seen.add(H.kernel.split("<")[0])
@@ -810,8 +810,16 @@ def test_long_row_kernels_vs_oracle(orc, n, lo, hi):
     lens = S.getnnz(axis=1)
     uniform = int(lens.max()) * n <= 4 * S.nnz and S.nnz >= 16 * n and lens.max() <= 4096
     assert "k_csr_spmv" in seen and (("k_csr_rl" in seen) == bool(uniform)), (seen, uniform)
-    # SELL-128-512 takes every one of these matrices except the one whose two dense rows would blow their chunks up
-    assert ("k_csr_sell" in seen) == ((n, lo, hi) != (2500, 100, 2600)), (seen, n, lo, hi)
+    # SELL-128-512 takes a matrix when sorting the rows of a 512-row window by length keeps the padding below 30 % (the
+    # clipped columns of these small matrices make a few rows at the edges several times longer than the rest)
+    slots = 0
+    for w0 in range(0, n, 512):
+        srt = np.sort(lens[w0:w0 + 512])[::-1]
+        for c in range(4):
+            seg = srt[c * 128:(c + 1) * 128]
+            if len(seg):
+                slots += ((int(seg[0]) + 1) // 2 * 2) * 128
+    assert ("k_csr_sell" in seen) == (slots <= 1.30 * S.nnz), (seen, n, lo, hi, slots / S.nnz)
 
 
 def test_slice_schedule_keeps_results(orc):

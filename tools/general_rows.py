@@ -12,7 +12,9 @@ CASES = ((4_000_000, 33, 64, 4096), (2_000_000, 64, 128, 8192), (8_000_000, 20, 
 if os.environ.get("GR_CASES"):          # e.g. GR_CASES=0,2 GR_KERNELS=1 GR_REPS=3 under a profiler
     CASES = tuple(CASES[int(t)] for t in os.environ["GR_CASES"].split(","))
 if os.environ.get("GR_OPTS") == "row_owner0": sg.set_option("csr_row_owner", 0)
-KERNELS = tuple(int(t) for t in os.environ.get("GR_KERNELS", "1,0").split(","))
+# kernels to time on every matrix: (csr_sell, csr_row_lines) -- SELL-128-512 whenever its padding allows, then the CSR kernels
+# (row owner up to 64 entries per row / line-staged beyond; streaming)
+KERNELS = tuple(tuple(int(v) for v in t.split(":")) for t in os.environ.get("GR_KERNELS", "2:1,0:1,0:0").split(","))
 REPS = int(os.environ.get("GR_REPS", "50"))
 for n, lo, hi, band in CASES:
     g = torch.Generator(device=dev); g.manual_seed(1)
@@ -26,11 +28,14 @@ for n, lo, hi, band in CASES:
     col = rows - band + slot * stride + torch.randint(0, stride, (nnz,), device=dev, generator=g)
     col = col.clamp_(0, n - 1)
     val = torch.rand(nnz, device=dev, generator=g, dtype=torch.float64)
+    sg.set_option("csr_sell", 2)
     A = sg.csr_matrix(n, n, (ptr + 1).to(torch.int32), (col + 1).to(torch.int32), val)
+    sg.set_option("csr_sell", 1)
     x = torch.rand(n, device=dev, dtype=torch.float64)
     moved = 12 * nnz + 4 * n + 16 * n
     ys = []
-    for rowline in KERNELS:
+    for sell, rowline in KERNELS:
+        sg.set_option("csr_sell", sell)
         sg.set_option("csr_row_lines", rowline)
         y = torch.zeros_like(x)
         for _ in range(min(5, REPS)): A.matvec(x, y)
@@ -52,6 +57,7 @@ for n, lo, hi, band in CASES:
             ok = ok and (0.0 + z == float(y[i]))
         print(json.dumps({"n": n, "nnz_per_row": [lo, hi], "kernel": A.kernel, "us": round(us, 1), "moved_GB": round(moved / 1e9, 3),
                           "TBs": round(moved / us / 1e6, 3), "frac_of_8TBs": round(moved / us / 8e6, 3), "rows_bit_exact": bool(ok)}), flush=True)
-    if len(ys) > 1: print(json.dumps({"kernels_bit_identical": bool(torch.equal(ys[0], ys[1]))}), flush=True)
+    if len(ys) > 1: print(json.dumps({"kernels_bit_identical": bool(all(torch.equal(ys[0], yy) for yy in ys[1:]))}), flush=True)
     sg.set_option("csr_row_lines", 1)
+    sg.set_option("csr_sell", 1)
     A.destroy()
