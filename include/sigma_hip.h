@@ -294,14 +294,16 @@ int sgm_solver_destroy(sgm_solver s);
  * LAPACK dstev): nsteps Lanczos steps with full re-orthogonalisation.  T_host: 3 x nsteps,
  * column-major (T(2,:) diagonal, T(1,:) = T(3,:) off-diagonal); Q_out (optional): n x nsteps
  * column-major Lanczos vectors.  q1 is the start vector (the reference draws it from a
- * time-seeded RNG); it is normalised inside.                                              */
+ * time-seeded RNG); it is normalised inside.  A may be row-partitioned: an in-process partition takes and
+ * returns global vectors, a rank of a matrix distributed over processes its owned slice of q1 and Q (n_local x nsteps);
+ * the dots are all-reduced, T is the same on every rank.                                    */
 int sgm_lanczos(sgm_mat A, int32_t nsteps, const double *q1, double *T_host, double *Q_out, int where);
 
 /* sgm_generalized_lanczos <- generalized_lanczos(A, B, T, Q)  src/eigensolver.f90:95-155: Lanczos for
  * A x = lambda B x.  Every step solves B w = v with `solver_for_B` (set up for B by the caller, like
  * B%set_solver; optional preconditioner), started from w = A q_i as the reference's
  * `call B%solve(w, v)` does (:140).  No re-orthogonalisation (the reference has none here); q1 is
- * normalised in the B-norm (:123-124).  T_host / Q_out as in sgm_lanczos.                  */
+ * normalised in the B-norm (:123-124).  T_host / Q_out as in sgm_lanczos; A and B may be row-partitioned (the same way). */
 int sgm_generalized_lanczos(sgm_mat A, sgm_mat B, sgm_solver solver_for_B, sgm_pc pc_or_null, int32_t nsteps,
                             const double *q1, double *T_host, double *Q_out, int where);
 

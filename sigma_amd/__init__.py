@@ -763,12 +763,16 @@ def dist_profile_read():
 def lanczos(A, nsteps, q1, want_Q=True):
     """lanczos(A, T, Q) (src/eigensolver.f90:27-90) on the device with the start vector q1:
     returns (T[3, nsteps], Q[n, nsteps] or None).  The eigenvalues of the tridiagonal
-    (diag T[1], off-diagonal T[2][:-1]) are what eigensolve :160-208 gets from dstev."""
+    (diag T[1], off-diagonal T[2][:-1]) are what eigensolve :160-208 gets from dstev.
+    A may be row-partitioned: an in-process partition takes and returns global vectors, a rank of a matrix distributed
+    over processes its owned slice of q1 and of Q (T is the same on every rank)."""
     if hasattr(A, "_build"):
         A._build()
     pq, w, _k = _arg(q1, np.float64)
+    nloc = getattr(A, "n_local", A.nrow)          # a rank of a distributed matrix works on its owned slice
+    _need(q1, nloc, "lanczos q1")
     T = np.zeros((nsteps, 3), np.float64)
-    Q = np.zeros((nsteps, A.nrow), np.float64) if want_Q else None
+    Q = np.zeros((nsteps, nloc), np.float64) if want_Q else None
     if w != SGM_HOST:
         raise TypeError("lanczos: pass the start vector as a numpy array")
     _ck(lib().sgm_lanczos(A._h, C.c_int32(nsteps), pq, C.c_void_p(T.ctypes.data),
@@ -789,9 +793,10 @@ def generalized_lanczos(A, B, nsteps, q1, want_Q=True):
     pq, w, _k = _arg(q1, np.float64)
     if w != SGM_HOST:
         raise TypeError("generalized_lanczos: pass the start vector as a numpy array")
-    _need(q1, A.nrow, "generalized_lanczos q1")
+    nloc = getattr(A, "n_local", A.nrow)
+    _need(q1, nloc, "generalized_lanczos q1")
     T = np.zeros((nsteps, 3), np.float64)
-    Q = np.zeros((nsteps, A.nrow), np.float64) if want_Q else None
+    Q = np.zeros((nsteps, nloc), np.float64) if want_Q else None
     _ck(lib().sgm_generalized_lanczos(A._h, B._h, B.solver._h, B.pc._h if B.pc is not None else None, C.c_int32(nsteps), pq,
                                       C.c_void_p(T.ctypes.data), C.c_void_p(Q.ctypes.data) if want_Q else None,
                                       C.c_int(SGM_HOST)))

@@ -256,6 +256,7 @@ int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
                bool chain = false);
 
 int spmv_grid(const Part &p);
+int matvec_plain(sgm_mat A, const double *x, double *y);     // device vectors, sgm_mat_matvec's layout, stream-ordered
 // "csr_lean": the CSR-order arrays of a part that kept only its sliced form, on demand (no-op otherwise)
 int csr_need_arrays(const Part &p);
 void csr_release_arrays(const Part &p);

@@ -2665,6 +2665,17 @@ static int matvec_impl(sgm_mat A, const double *x, double *y, int where, bool ad
     return finish();
 }
 
+// y = A x on device vectors laid out like sgm_mat_matvec's: one part (also one rank of a distributed matrix: x holds
+// [owned | halo room]) or an in-process partition (plain global vectors); stream-ordered, no synchronisation
+int matvec_plain(sgm_mat A, const double *x, double *y)
+{
+    const bool was_async = g_rt.async;
+    g_rt.async = true;
+    const int rc = matvec_impl(A, x, y, SGM_DEVICE, false);
+    g_rt.async = was_async;
+    return rc;
+}
+
 }  // namespace sgm
 
 using namespace sgm;

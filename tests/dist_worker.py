@@ -218,6 +218,26 @@ def run(rank, world, port, case, res):
         else:
             check("bicgstab_jacobi", sg.bicgstab(1e-12), sg.jacobi, orc.bicgstab(A, b, tol=1e-12, pc=orc.Jacobi(A)),
                   lambda i: max(2, 0.1 * i), 1e-10)
+        # ---- Lanczos over the ranks (SURVEY 8(f3) on a partitioned matrix): every rank its owned slice of q1 and Q, dots
+        #      all-reduced, T the same everywhere; against the oracle's serial run
+        if case in ("poisson2d", "laplace3d"):
+            q1 = np.random.RandomState(12).random_sample(n) * 2 - 1
+            Tl, Ql = sg.lanczos(H, 20, q1[r0:r1].copy())
+            Tlo, Qlo = orc.lanczos(A, 20, q1)
+            assert np.abs(Tl - Tlo).max() <= 1e-9, float(np.abs(Tl - Tlo).max())
+            assert np.abs(Ql[:, :8] - Qlo[r0:r1, :8]).max() <= 1e-10
+            out["lanczos"] = {"iterations": 20, "T_max_diff": float(np.abs(Tl - Tlo).max())}
+            # generalized: B = a mass-like matrix on the same pattern and partition, B%solve = CG(1e-14) over the ranks
+            rowsg = np.repeat(np.arange(1, n + 1), np.diff(ptr))
+            bval = np.where(rowsg == node, 1.0 + (rowsg % 7) / 16.0, -1.0 / 16.0)
+            HB = sg.dist_csr_matrix(comm, starts, lptr, lnode_g, np.ascontiguousarray(bval[k0:k1]))
+            HB.set_solver(sg.cg(1e-14))
+            Tg, Qg = sg.generalized_lanczos(H, HB, 12, q1[r0:r1].copy())
+            Tgo, Qgo = orc.generalized_lanczos(A, orc.CsrMatrix(n, n, ptr, node, bval), 12, q1, 1e-14)
+            assert np.abs(Tg - Tgo).max() <= 1e-9 and np.abs(Qg - Qgo[r0:r1]).max() <= 1e-9
+            out["generalized_lanczos"] = {"iterations": 12, "T_max_diff": float(np.abs(Tg - Tgo).max())}
+            HB.destroy()
+
         # ---- dot_order = 1: the running sum of every dot travels rank 0 -> 1 -> ... and each rank continues it over its
         #      own rows: the distributed iterates are BIT-IDENTICAL to the serial ones (the oracle's left-to-right dots)
         sg.set_option("dot_order", 1)

@@ -2297,6 +2297,39 @@ def test_generalized_lanczos_larger_problem_vs_oracle(orc):
     assert np.abs(Th - To).max() <= 1e-9 and np.abs(Qh - Qo).max() <= 1e-9
 
 
+@pytest.mark.parametrize("nparts", [2, 3])
+def test_lanczos_and_generalized_lanczos_on_a_row_partition(orc, nparts):
+    """Both Lanczos routines on an in-process row partition (what a multi-GPU run does per rank, on one GPU): products
+    row-bit-identical to the one-part matrix, so T and Q agree with the one-part run to rounding of the dots' order and
+    with the oracle to the same 1e-9 as the one-part tests; B%solve = CG(1e-14) on the partitioned B."""
+    nx, ny = 50, 40
+    n = nx * ny
+    ptr, node, val = P.poisson2d_csr(nx, ny)
+    rows = np.repeat(np.arange(1, n + 1), np.diff(ptr))
+    bval = np.where(rows == node, 1.0 + (rows % 7) / 16.0, -1.0 / 16.0)
+    Ao, Bo = orc.CsrMatrix(n, n, ptr, node, val), orc.CsrMatrix(n, n, ptr, node, bval)
+    starts = np.array([0] + [2 * ((n * k // nparts) // 2) for k in range(1, nparts)] + [n], np.int64)
+    q1 = np.random.RandomState(4).random_sample(n) * 2 - 1
+    A1 = sg.csr_matrix(n, n, ptr, node, val)
+    Ap = sg.partitioned_csr_matrix(n, n, ptr, node, val, starts)
+    T1, Q1 = sg.lanczos(A1, 30, q1)
+    Tp, Qp = sg.lanczos(Ap, 30, q1)
+    To, Qo = orc.lanczos(Ao, 30, q1)
+    assert np.abs(Tp - T1).max() <= 1e-11 and np.abs(Qp - Q1).max() <= 1e-10
+    assert np.abs(Tp - To).max() <= 1e-9 and np.abs(Qp[:, :10] - Qo[:, :10]).max() <= 1e-10
+    assert np.abs(Qp.T @ Qp - np.eye(30)).max() <= 1e-10
+    Bp = sg.partitioned_csr_matrix(n, n, ptr, node, bval, starts)
+    Bp.set_solver(sg.cg(1e-14))
+    Tg, Qg = sg.generalized_lanczos(Ap, Bp, 25, q1)
+    Tgo, Qgo = orc.generalized_lanczos(Ao, Bo, 25, q1, 1e-14)
+    assert np.abs(Tg - Tgo).max() <= 1e-9 and np.abs(Qg - Qgo).max() <= 1e-9
+    # differently partitioned A and B are refused
+    B1 = sg.csr_matrix(n, n, ptr, node, bval)
+    B1.set_solver(sg.cg(1e-14))
+    with pytest.raises(sg.SigmaError):
+        sg.generalized_lanczos(Ap, B1, 5, q1)
+
+
 # ------------------------------------------------------------ row partition on one GPU
 @pytest.mark.parametrize("nparts", [2, 3, 8])
 def test_partitioned_matvec_bit_exact_and_cg(orc, nparts):
