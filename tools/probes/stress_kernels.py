@@ -7,11 +7,12 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(
 import numpy as np
 import sigma_amd as sg
 sg.init(0)
-COMBOS = ((1, 1, 1, 1), (1, 0, 1, 1), (0, 1, 1, 1), (0, 0, 1, 1), (0, 0, 0, 1), (0, 0, 0, 0))
+# (offset dictionary, sliced forms, row owner, row lines, SELL-128-512: 2 = whenever its padding allows)
+COMBOS = ((1, 1, 1, 1, 1), (1, 1, 1, 1, 2), (1, 0, 1, 1, 0), (0, 1, 1, 1, 2), (0, 1, 1, 1, 0), (0, 0, 1, 1, 0), (0, 0, 0, 1, 0), (0, 0, 0, 0, 0))
 
 
 def opts(c):
-    for name, v in zip(("csr_offset_dict", "csr_sliced", "csr_row_owner", "csr_row_lines"), c):
+    for name, v in zip(("csr_offset_dict", "csr_sliced", "csr_row_owner", "csr_row_lines", "csr_sell"), c):
         sg.set_option(name, v)
 
 
@@ -90,7 +91,7 @@ def main():
                 if not (np.array_equal(y, ref[0]) and np.array_equal(ya, ref[1]) and np.array_equal(tt, ref[2])):
                     bad += 1; print("KERNEL MISMATCH", t, kind, n, m, c, H.kernel)
             H.destroy()
-    opts((1, 1, 1, 1))
+    opts((1, 1, 1, 1, 1))
     print(json.dumps({"trials": trials, "mismatches": bad, "kernels_seen": seen}))
 
 
