@@ -87,6 +87,10 @@ int sgm_synchronize(void);
  * product stores / loads in the banded form.
  * "ildu_strips" (default 1): ILDU(0) factors of grid-like matrices use the strip- / slab-pipelined
  * triangular solves; 0 keeps the level-scheduled walkers.
+ * "ildu_rows" (default 1): ILDU(0) factors of at most 32 levels (what greedy_color_ordering makes of a matrix: one level
+ * per colour) are swept in row space -- one launch per level on the vectors themselves, D folded
+ * into the U sweep, no gather / re-order / scatter around them (sgm_pc_get "row_levels" = {in use, launches of the L sweep,
+ * of the U sweep}); 0 = the level-order walkers.  Same bits either way.
  * "gmres_cgs2" (default 1): GMRES orthogonalises with blocked classical Gram-Schmidt applied twice (three
  * passes and three all-reduces per step); 0 = modified Gram-Schmidt.
  * "cg_small" (default 1): CG (plain or Jacobi-preconditioned) on a single-GPU CSR matrix of at most

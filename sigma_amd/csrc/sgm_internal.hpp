@@ -46,6 +46,7 @@ struct Options {
     int ell_colblock_pieces = 512; // workgroups of the multiply phase per band (banded form)
     int ell_colblock_nt = 0;       // banded form: 1 = nontemporal product stores / loads (0: plain, so that the products stay cached)
     int ildu_strips = 1;           // ILDU(0) factors of grid-like matrices (deps r-1, r-w): strip-pipelined triangular solves
+    int ildu_rows = 1;             // ILDU(0) factors of a few levels (colour orderings): row-space sweeps, one launch per level
     int gmres_cgs2 = 1;            // GMRES: blocked CGS-2 orthogonalisation (3 passes per step) instead of modified Gram-Schmidt
     int cg_small = 1;              // CG (plain or Jacobi) on a CSR matrix of <= 10240 rows: the whole solve in one workgroup (k_cg_small)
     int cg_small_chunk = 50000;    // its iterations per launch (the solve continues in the next launch from parked r, p)

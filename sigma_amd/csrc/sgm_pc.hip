@@ -44,6 +44,7 @@ constexpr int kTrsvBlock = 1024;
 constexpr int kNarrow = 4096;        // levels with <= this many rows are walked by one workgroup (4 rows per lane)
 constexpr int kRing = 8192;          // LDS ring of recent results (64 KiB): covers two narrow levels
 constexpr int kInline = 4;           // dependencies stored inside the row record
+constexpr int kRowLevels = 32;       // factors of at most this many levels are swept in row space, one launch per level
 
 struct TrsvRec {                     // one row of a triangular factor, in level order (64 bytes)
     int32_t cnt, k0;                 // entries of the row; offset of its entries in pq / pv
@@ -73,6 +74,14 @@ struct TriFactor {                   // strictly triangular factor on the device
     // applies; c: most dependencies of a row in the run
     struct Launch { int32_t l0, l1; bool narrow; int cls; bool ring; int c; };
     std::vector<Launch> schedule;
+    // row-space copy for factors of a few levels (colour orderings: one per colour): dependency ROWS and values, rc slots,
+    // slot-major over the level order -- the sweeps then run on the vectors themselves, one launch per level (k_trsv_rows)
+    struct RowLevel { int32_t b, e, c, row0; };      // positions [b, e); most entries of a row; row0 >= 0: rows row0, row0+1, ...
+    std::vector<RowLevel> row_levels;
+    bool rows_on = false;
+    int rc = 0;
+    int32_t *rq = nullptr;
+    double *rv = nullptr;
 };
 
 // A strictly triangular factor whose rows depend only on the previous row (r-1) and on the row one grid
@@ -265,6 +274,45 @@ __global__ void k_trsv_wide_soa(const int32_t *__restrict__ wq, const double *__
     for (int c = 0; c < C; ++c)
         if (q[c] >= 0) z = z - v[c] * xp[q[c]];
     xp[p] = z;
+}
+
+// One level in ROW space (factors of a few levels -- what the reference's greedy colouring makes of a matrix: one level per
+// colour): out[i] = src[i] (/ D[i]) - sum over the row's entries, stored order, of val * out[row of the entry];
+// i = the level's rows, through `order` or -- a level that is a run of consecutive rows -- counted from row0.  No gather
+// into level order before the sweeps, no re-ordering between them, no scatter after: the L sweep reads r and writes the
+// work vector, the U sweep divides by D as it picks its right-hand side up and writes z.  C = slots read (the most
+// entries of a row of the level; -1: `rc` of them in a loop).  Same operations in the same order as k_trsv_wide_soa
+// after k_perm_gather / k_lu_transition, so the same bits.
+template <int C, bool DIV>
+__global__ void k_trsv_rows(const int32_t *__restrict__ rq, const double *__restrict__ rv, uint32_t nstride, int rc,
+                            const int32_t *__restrict__ order, int32_t row0, int32_t begin, int32_t end, const double *src,
+                            const double *__restrict__ D, double *out, const int *flag)
+{
+    if (flag && *flag) return;
+    const int32_t p = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= end) return;
+    const int32_t i = row0 >= 0 ? row0 + (p - begin) : order[p];
+    double z = src[i];
+    if (DIV) z = z / D[i];
+    if (C >= 0) {
+        int32_t q[C > 0 ? C : 1];
+        double v[C > 0 ? C : 1];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {                       // (read once per sweep: past the caches the gathers live in)
+            q[c] = __builtin_nontemporal_load(rq + (size_t)c * nstride + p);
+            v[c] = __builtin_nontemporal_load(rv + (size_t)c * nstride + p);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            if (q[c] >= 0) z = z - v[c] * out[q[c]];
+    } else {
+        for (int c = 0; c < rc; ++c) {
+            const int32_t q = rq[(size_t)c * nstride + p];
+            if (q < 0) break;                              // (a row's entries fill its first slots)
+            z = z - rv[(size_t)c * nstride + p] * out[q];
+        }
+    }
+    out[i] = z;
 }
 
 // a run of narrow levels [l0, l1) walked by ONE workgroup.  The row records and right-hand
@@ -813,6 +861,7 @@ void free_ildu(IlduState &S)
 void free_tri(TriFactor &T)
 {
     dfree(T.order); dfree(T.recs); dfree(T.pq); dfree(T.pv); dfree(T.level_ptr_dev); dfree(T.dq); dfree(T.dq32); dfree(T.dv); dfree(T.wq);
+    dfree(T.rq); dfree(T.rv);
     T = TriFactor();
 }
 
@@ -907,6 +956,25 @@ int upload_tri(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const 
             T.schedule.push_back({l, e, true, c, ring_ok, cmax});
             l = e;
         }
+        // a few levels (whatever their widths): the row-space copy (dependency rows, slot-major over the level order)
+        T.rows_on = false;
+        T.rc = 0;
+        T.row_levels.clear();
+        if (nlev >= 1 && nlev <= kRowLevels && (size_t)n + kNarrow < (size_t)500000000) {
+            int cm = 0;
+            for (int32_t l = 0; l < nlev; ++l) {
+                const int32_t b = T.level_ptr[l], e = T.level_ptr[l + 1];
+                int c = 0;
+                bool run = true;
+                for (int32_t p2 = b; p2 < e; ++p2) {
+                    c = std::max(c, T.h_recs[p2].cnt);
+                    if (p2 > b) run = run && T.h_order[p2] == T.h_order[p2 - 1] + 1;
+                }
+                T.row_levels.push_back({b, e, c, run ? T.h_order[b] : -1});
+                cm = std::max(cm, c);
+            }
+            if (cm <= 64) { T.rows_on = true; T.rc = std::max(cm, 1); }
+        }
         // ring-walker copy of the structure: 16-bit ring slots (only read in ring runs), padded
         // by kNarrow rows so that lanes past a level's end read valid memory
         T.nstride = (size_t)n + kNarrow;
@@ -934,6 +1002,16 @@ int upload_tri(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const 
             SGM_TRY(dalloc(&T.wq, wq.size()));
             SGM_HIP(hipMemcpy(T.wq, wq.data(), wq.size() * 4, hipMemcpyHostToDevice));
         }
+        if (T.rows_on) {
+            std::vector<int32_t> rq(T.nstride * (size_t)T.rc, -1);
+            for (int32_t p = 0; p < n; ++p) {
+                const TrsvRec &r = T.h_recs[p];
+                for (int32_t j = 0; j < r.cnt; ++j) rq[(size_t)j * T.nstride + p] = T.h_order[T.h_pq[r.k0 + j]];
+            }
+            SGM_TRY(dalloc(&T.rq, rq.size()));
+            SGM_TRY(dalloc(&T.rv, rq.size()));
+            SGM_TRY(copy_big(T.rq, rq.data(), rq.size() * 4, hipMemcpyHostToDevice));
+        }
         SGM_TRY(dalloc(&T.order, (size_t)n));
         SGM_TRY(dalloc(&T.recs, (size_t)n));
         SGM_TRY(dalloc(&T.pq, nnz));
@@ -952,6 +1030,14 @@ int upload_tri(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const 
     }
     if (nnz) SGM_HIP(hipMemcpy(T.pv, hv.data(), nnz * 8, hipMemcpyHostToDevice));
     if (n) SGM_HIP(hipMemcpy(T.recs, T.h_recs.data(), (size_t)n * sizeof(TrsvRec), hipMemcpyHostToDevice));
+    if (n && T.rows_on) {
+        std::vector<double> sv(T.nstride * (size_t)T.rc, 0.0);
+        for (int32_t p = 0; p < n; ++p) {
+            const TrsvRec &r = T.h_recs[p];
+            for (int32_t j = 0; j < r.cnt; ++j) sv[(size_t)j * T.nstride + p] = hv[r.k0 + j];
+        }
+        SGM_TRY(copy_big(T.rv, sv.data(), sv.size() * 8, hipMemcpyHostToDevice));
+    }
     if (n) {
         std::vector<double> sv(T.nstride * kInline, 0.0);
         for (int32_t p = 0; p < n; ++p)
@@ -1162,6 +1248,40 @@ void apply_levels(const IlduState *S, const double *r, double *z, const int *fla
                        (const int32_t *)S->U.order, flag);
 }
 
+// the same through the row-space levels (both factors a few wide levels): one launch per level, nothing else
+bool rows_serve(const IlduState *S) { return g_opt.ildu_rows && S->levels_ready && S->L.rows_on && S->U.rows_on; }
+void sweep_rows(const TriFactor &T, const double *src, const double *D, double *out, const int *flag, bool div)
+{
+    hipStream_t st = g_rt.stream;
+    for (const auto &L : T.row_levels) {
+        const int32_t b = L.b, e = L.e;
+        const dim3 g((e - b + kBlock - 1) / kBlock);
+#define ROWS(CC)                                                                                                              \
+    do {                                                                                                                      \
+        if (div) hipLaunchKernelGGL((k_trsv_rows<CC, true>), g, dim3(kBlock), 0, st, (const int32_t *)T.rq, (const double *)T.rv, \
+                                    (uint32_t)T.nstride, T.rc, (const int32_t *)T.order, L.row0, b, e, src, D, out, flag);     \
+        else hipLaunchKernelGGL((k_trsv_rows<CC, false>), g, dim3(kBlock), 0, st, (const int32_t *)T.rq, (const double *)T.rv, \
+                                (uint32_t)T.nstride, T.rc, (const int32_t *)T.order, L.row0, b, e, src, D, out, flag);         \
+    } while (0)
+        switch (L.c) {
+        case 0: ROWS(0); break;
+        case 1: ROWS(1); break;
+        case 2: ROWS(2); break;
+        case 3: ROWS(3); break;
+        case 4: ROWS(4); break;
+        case 5: case 6: ROWS(6); break;
+        case 7: case 8: ROWS(8); break;
+        default: ROWS(-1); break;
+        }
+#undef ROWS
+    }
+}
+void apply_rows(const IlduState *S, const double *r, double *z, const int *flag)
+{
+    sweep_rows(S->L, r, nullptr, S->xpL, flag, false);                    // (I+L) y = r
+    sweep_rows(S->U, S->xpL, S->D, z, flag, true);                        // (I+U) z = y / D
+}
+
 // triangular solve in position space: xp holds the right-hand side on entry, the solution on exit
 void trsv(const TriFactor &T, double *xp, const int *flag)
 {
@@ -1266,14 +1386,18 @@ int download_block(const Part &p, std::vector<int32_t> &ptr1, std::vector<int32_
 namespace sgm {
 
 int pc_kind(sgm_pc pc) { return pc ? pc->kind : 0; }
-// an apply that is a handful of launches (Jacobi; ILDU through the strip pipeline) lets the solvers queue a whole
-// batch of iterations between two looks at the stop flag; thousands of level launches per apply do not
+// an apply that is a handful of launches (Jacobi; ILDU through the strip / slab pipeline or over a few wide levels) lets the
+// solvers queue a whole batch of iterations between two looks at the stop flag; thousands of level launches per apply do not
 bool pc_apply_is_short(sgm_pc pc)
 {
     if (!pc || pc->kind == SGM_PC_JACOBI) return true;
-    if (!g_opt.ildu_strips) return false;
-    for (const auto &S : pc->ild)
-        if (!S.grid_ok && !S.slab_ok) return false;
+    // (a colour-ordered matrix has two or three levels per factor: its level-scheduled apply is seven to nine launches)
+    for (const auto &S : pc->ild) {
+        if (g_opt.ildu_strips && (S.grid_ok || S.slab_ok)) continue;
+        if (!S.levels_ready) return false;
+        if (g_opt.ildu_rows && S.L.rows_on && S.U.rows_on) continue;         // at most 2 * kRowLevels launches
+        if (3 + S.L.schedule.size() + S.U.schedule.size() > 35) return false;
+    }
     return true;
 }
 const double *pc_idiag(sgm_pc pc, size_t part) { return pc->parts[part].idiag; }
@@ -1327,7 +1451,8 @@ int pc_apply_parts(sgm_pc pc, sgm_mat A, const double *const *r, double *const *
                 continue;
             }
             SGM_TRY(ensure_levels(&pc->ild[ip]));              // (built on first need when a pipelined path served the pattern so far)
-            apply_levels(S, r[ip], z[ip], flag);
+            if (rows_serve(S)) apply_rows(S, r[ip], z[ip], flag);
+            else apply_levels(S, r[ip], z[ip], flag);
         }
     }
     SGM_HIP(hipGetLastError());
@@ -1627,6 +1752,12 @@ int sgm_pc_get(sgm_pc pc, const char *name, void *out, size_t bytes, size_t *nee
             rv[0] = pc->retired;
             src = rv; sz = sizeof rv;
         }
+        else if (nm == "row_levels") {           // row-space level path in use: {1, launches of the L sweep, of the U sweep}; zeros = off
+            static int32_t rl[3];
+            const bool on = !(g_opt.ildu_strips && (S->grid_ok || S->slab_ok)) && rows_serve(S);
+            rl[0] = on; rl[1] = on ? (int32_t)S->L.row_levels.size() : 0; rl[2] = on ? (int32_t)S->U.row_levels.size() : 0;
+            src = rl; sz = sizeof rl;
+        }
         else if (nm == "levels") {
             SGM_TRY(ensure_levels(&pc->ild[0]));
             static int32_t lv[2];
@@ -1636,7 +1767,7 @@ int sgm_pc_get(sgm_pc pc, const char *name, void *out, size_t bytes, size_t *nee
         }
     }
     const bool known = nm == "strips" || nm == "strip_clocks" || nm == "slabs" || nm == "slab_clocks" || nm == "pipeline_retired" || nm == "idiag" || nm == "Lptr" || nm == "Lnode" || nm == "Lval" || nm == "Uptr" ||
-                       nm == "Unode" || nm == "Uval" || nm == "D" || nm == "levels";
+                       nm == "Unode" || nm == "Uval" || nm == "D" || nm == "levels" || nm == "row_levels";
     if (!known || (!src && sz)) return fail(SGM_ERR_BAD_ARG, "sgm_pc_get: unknown array '%s'", name);
     if (!src) src = &kEmpty;
     if (needed) *needed = sz;

@@ -169,6 +169,7 @@ int sgm_set_option(const char *name, int value)
     if (!strcmp(name, "ell_colblock_pieces")) { g_opt.ell_colblock_pieces = std::min(8192, std::max(1, value)); return SGM_OK; }
     if (!strcmp(name, "ell_colblock_nt")) { g_opt.ell_colblock_nt = value != 0; return SGM_OK; }
     if (!strcmp(name, "ildu_strips")) { g_opt.ildu_strips = value; return SGM_OK; }
+    if (!strcmp(name, "ildu_rows")) { g_opt.ildu_rows = value; return SGM_OK; }
     if (!strcmp(name, "cg_small")) { g_opt.cg_small = value; return SGM_OK; }
     if (!strcmp(name, "cg_small_chunk")) { g_opt.cg_small_chunk = std::max(1, value); return SGM_OK; }
     if (!strcmp(name, "slice_sched")) { g_opt.slice_sched = value; return SGM_OK; }

@@ -1703,6 +1703,96 @@ def test_colour_ordered_ildu_on_a_large_grid_vs_oracle(orc):
         H.left_permute(bad)
 
 
+def _random_symmetric(n, deg, seed):
+    """Diagonally dominant symmetric-pattern matrix with about `deg` random neighbours per row (1-based edge lists)."""
+    rs = np.random.RandomState(seed)
+    i = np.repeat(np.arange(n), deg)
+    j = rs.randint(0, n, size=i.size)
+    keep = i != j
+    i, j = i[keep], j[keep]
+    key = np.unique(np.minimum(i, j).astype(np.int64) * n + np.maximum(i, j))
+    lo, hi = (key // n).astype(np.int64), (key % n).astype(np.int64)
+    v = -rs.uniform(0.1, 1.0, size=lo.size)
+    w = -rs.uniform(0.1, 1.0, size=lo.size)               # (values need not be symmetric)
+    d = np.zeros(n)
+    np.add.at(d, lo, -v); np.add.at(d, hi, -w)
+    ei = np.concatenate([lo, hi, np.arange(n)]) + 1
+    ej = np.concatenate([hi, lo, np.arange(n)]) + 1
+    ev = np.concatenate([v, w, d + 1.0])
+    return ei.astype(np.int32), ej.astype(np.int32), ev
+
+
+@pytest.mark.parametrize("case", ["grid2d", "grid3d", "random6", "random20"])
+def test_row_space_level_sweeps_of_colour_ordered_factors(orc, case):
+    """Option ildu_rows: factors that are a few wide levels (a colour-ordered matrix: one level per colour) are swept in
+    row space, one launch per level.  Against the level-order walkers and the oracle's sequential sweeps, bit for bit:
+    2 colours with 4 / 6 entries per row (levels that are runs of consecutive rows), random graphs with 8..30 colours
+    (rows of up to ~40 entries: the slot-loop kernel; levels reached through the order array), repeated applies, a
+    second setup with new values, and a PCG solve either way."""
+    if case == "grid2d":
+        ptr, node, val = P.poisson2d_csr(300, 260); n = 300 * 260
+        A = orc.CsrMatrix(n, n, ptr, node, val)
+    elif case == "grid3d":
+        ptr, node, val = P.laplace3d_csr(40, 44, 48); n = 40 * 44 * 48
+        A = orc.CsrMatrix(n, n, ptr, node, val)
+    else:
+        n = 120000 if case == "random6" else 150000
+        ei, ej, ev = _random_symmetric(n, 3 if case == "random6" else 10, 5)
+        A = orc.CsrMatrix.from_edges(n, n, ei, ej, ev)
+    H = hip_from_oracle(A)
+    p, ptrs, nc = H.greedy_color_ordering()
+    H.left_permute(p); H.right_permute(p)
+    B = orc.permuted(A, p, p)
+    ref = orc.Ildu(B)
+    pc = sg.ldu()
+    pc.setup(H)
+    rl = pc.get("row_levels", np.int32)
+    lv = pc.get("levels", np.int32)
+    if case.startswith("grid"):
+        assert nc == 2 and list(lv) == [2, 2] and list(rl) == [1, 2, 2]
+    else:
+        # levels of the factors = colours at most (the late colours hold few rows: narrow levels, launched all the same)
+        assert lv[0] <= nc and lv[1] <= nc
+        assert list(rl) == ([1, lv[0], lv[1]] if max(lv) <= 32 else [0, 0, 0]), (nc, lv, rl)
+        if case == "random6":
+            assert rl[0] == 1, (nc, lv, rl)
+    x = np.random.RandomState(3).standard_normal(n)
+    want = ref.solve(x)
+    z = np.zeros(n)
+    pc.solve(H, z, x)
+    assert np.array_equal(z, want)
+    x2 = P.test_vector(n)
+    pc.solve(H, z, x2)                                       # work vector reused
+    assert np.array_equal(z, ref.solve(x2))
+    zin = x.copy()
+    pc.solve(H, zin, zin)                                    # in place
+    assert np.array_equal(zin, want)
+    sg.set_option("ildu_rows", 0)
+    try:
+        assert list(pc.get("row_levels", np.int32)) == [0, 0, 0]
+        z0 = np.zeros(n)
+        pc.solve(H, z0, x)
+        assert np.array_equal(z0, want)
+        u0 = np.zeros(n)
+        s0 = sg.cg(tolerance=1e-10)
+        s0.setup(H)
+        s0.solve(H, u0, x2, pc)
+        it0 = s0.iterations
+    finally:
+        sg.set_option("ildu_rows", 1)
+    u1 = np.zeros(n)
+    s1 = sg.cg(tolerance=1e-10)
+    s1.setup(H)
+    s1.solve(H, u1, x2, pc)
+    assert s1.iterations == it0 and np.array_equal(u1, u0)
+    # new values, same pattern: the value slots are refreshed, the index work is not redone
+    H.set_values(B.val * 1.5)
+    pc.setup(H)
+    B2 = orc.CsrMatrix(n, n, B.ptr, B.node, B.val * 1.5)
+    pc.solve(H, z, x)
+    assert np.array_equal(z, orc.Ildu(B2).solve(x))
+
+
 def test_lean_footprint_and_on_demand_arrays(orc):
     """Option csr_lean (default on): a matrix served by the 4-bit sliced form keeps only that form + row pointers resident
     (<= 1.15 x what its kernel reads of the matrix); everything that needs the CSR-order arrays -- the other kernels,

@@ -57,5 +57,7 @@ for name, mk in (("cg", None), ("jacobi", sg.jacobi), ("ildu0", sg.ldu)):
         extra["levels"] = pc.get("levels", np.int32).tolist()
         extra["strips"] = pc.get("strips", np.int32).tolist()
         extra["slabs"] = pc.get("slabs", np.int32).tolist()
+        extra["row_levels"] = pc.get("row_levels", np.int32).tolist()
+    extra["spmv_kernel"] = A.kernel.split("<")[0]
     print(json.dumps({"grid": nx, "pc": name, "setup_s": tset, "iterations": its, "solve_s": dt,
                       "ms_per_iter_incl_host_staging": 1e3 * dt / max(its, 1), **extra}), flush=True)
