@@ -266,8 +266,9 @@ void csr_release_arrays(const Part &p);
 struct Slab3;
 int slab3_build(Slab3 **out, int32_t n, const std::vector<int32_t> &Lptr, const std::vector<int32_t> &Lnode,
                 const std::vector<int32_t> &Uptr, const std::vector<int32_t> &Unode);      // *out null: not applicable
-int slab3_refresh(Slab3 *S, const std::vector<double> &Lval, const std::vector<double> &Uval, const std::vector<double> &D);
+int slab3_refresh(Slab3 *S, const double *Lval, const double *Uval, const double *D);     // (device pointers)
 void slab3_apply(const Slab3 *S, const double *r, double *z, const int *flag, int spin_limit, int32_t *sticky);
+void slab3_lower_result(const Slab3 *S, double *dst);
 int slab3_aborted(const Slab3 *S, int32_t *abL, int32_t *abU);
 void slab3_info(const Slab3 *S, int32_t out[6]);
 int slab3_clocks(const Slab3 *S, std::vector<long long> &out);

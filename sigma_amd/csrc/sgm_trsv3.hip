@@ -51,8 +51,7 @@ struct SlabTri {
     int32_t *progress = nullptr;           // device: NB*NI forwarded steps (diagnostics), [NB*NI] = abort word
     long long *clk = nullptr;              // device: 2 per (b, a): chain start / end
     std::vector<int32_t> h_pos;            // row -> position
-    std::vector<int32_t> h_src[3];         // position -> entry of the factor's val array per source (-1 = none)
-    std::vector<int32_t> h_code;
+    int32_t *src[3] = {nullptr, nullptr, nullptr};   // device: position -> entry of the factor's val array per source (-1 = none)
 };
 
 }  // namespace
@@ -400,6 +399,7 @@ __global__ void k_slab_scatter(int64_t np, double *__restrict__ dst, const doubl
 void free_tri(SlabTri &G)
 {
     dfree(G.rec); dfree(G.code); dfree(G.row); dfree(G.progress); dfree(G.clk);
+    for (auto &v : G.src) dfree(v);
     G = SlabTri();
 }
 
@@ -466,9 +466,10 @@ int build_tri(SlabTri &G, int32_t n, int32_t w, int32_t h, const std::vector<int
     G.NP = (int64_t)G.NB * G.NI * G.S * 64;
     if (G.NP >= INT32_MAX) return SGM_OK;                     // (positions are int32)
     std::vector<int32_t> hrow((size_t)G.NP, -1);
-    G.h_code.assign((size_t)G.NP, 0);
+    std::vector<int32_t> h_code((size_t)G.NP, 0);
     G.h_pos.assign(std::max(n, 1), 0);
-    for (auto &v : G.h_src) v.assign((size_t)G.NP, -1);
+    std::vector<int32_t> h_src[3];
+    for (auto &v : h_src) v.assign((size_t)G.NP, -1);
     bool any_bul = false, any_lub = false, any_other = false;
     G.regular = n == wh * G.nk;
     for (int32_t r = 0; r < n; ++r) {
@@ -485,12 +486,12 @@ int build_tri(SlabTri &G, int32_t n, int32_t w, int32_t h, const std::vector<int
             const int32_t dlt = lower ? r - (node1[e] - 1) : (node1[e] - 1) - r;
             const int id = dlt == 1 ? 2 : dlt == w ? 1 : 0;      // 0 back (r-wh), 1 up (r-w), 2 left (r-1)
             c |= 1 << id;
-            G.h_src[id][p] = e;
+            h_src[id][p] = e;
             ids[cnt] = id;
         }
         if ((c & 7) != ((k > 0 ? 1 : 0) | (j > 0 ? 2 : 0) | (i > 0 ? 4 : 0))) G.regular = false;
         c |= ids[0] << 3 | ids[1] << 5 | ids[2] << 7;
-        G.h_code[p] = c;
+        h_code[p] = c;
         if (cnt >= 2) {
             bool asc = true, desc = true;
             for (int q = 1; q < cnt; ++q) { if (ids[q] < ids[q - 1]) asc = false; if (ids[q] > ids[q - 1]) desc = false; }
@@ -506,22 +507,43 @@ int build_tri(SlabTri &G, int32_t n, int32_t w, int32_t h, const std::vector<int
     SGM_TRY(dalloc(&G.progress, (size_t)G.NB * G.NI + 1));
     SGM_TRY(dalloc(&G.clk, ((size_t)G.NB * G.NI * (2 + G.S / 16) + (size_t)G.NB * 512)));
     SGM_TRY(copy_big(G.row, hrow.data(), (size_t)G.NP * 4, hipMemcpyHostToDevice));
-    SGM_TRY(copy_big(G.code, G.h_code.data(), (size_t)G.NP * 4, hipMemcpyHostToDevice));
+    SGM_TRY(copy_big(G.code, h_code.data(), (size_t)G.NP * 4, hipMemcpyHostToDevice));
+    for (int id = 0; id < 3; ++id) {
+        SGM_TRY(dalloc(&G.src[id], (size_t)G.NP));
+        SGM_TRY(copy_big(G.src[id], h_src[id].data(), (size_t)G.NP * 4, hipMemcpyHostToDevice));
+    }
     SGM_HIP(hipMemset(G.clk, 0, ((size_t)G.NB * G.NI * (2 + G.S / 16) + (size_t)G.NB * 512) * 8));
     G.on = true;
     return SGM_OK;
 }
 
-int refresh_tri(SlabTri &G, const std::vector<double> &val)
+// records (every setup) from the factor's values on the device: {c_back, c_up}, {c_left, rhs = 0} per position
+__global__ void k_slab_records(int64_t np, const int32_t *__restrict__ s0, const int32_t *__restrict__ s1, const int32_t *__restrict__ s2,
+                               const double *__restrict__ val, f64x2s *__restrict__ rec)
 {
-    std::vector<double> hrec((size_t)G.NP * 4);
-    for (int64_t p = 0; p < G.NP; ++p) {
-        hrec[4 * p + 0] = G.h_src[0][p] >= 0 ? val[G.h_src[0][p]] : 0.0;
-        hrec[4 * p + 1] = G.h_src[1][p] >= 0 ? val[G.h_src[1][p]] : 0.0;
-        hrec[4 * p + 2] = G.h_src[2][p] >= 0 ? val[G.h_src[2][p]] : 0.0;
-        hrec[4 * p + 3] = 0.0;
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; p < np; p += stride) {
+        f64x2s a, b;
+        a.x = s0[p] >= 0 ? val[s0[p]] : 0.0;
+        a.y = s1[p] >= 0 ? val[s1[p]] : 0.0;
+        b.x = s2[p] >= 0 ? val[s2[p]] : 0.0;
+        b.y = 0.0;
+        rec[2 * p] = a;
+        rec[2 * p + 1] = b;
     }
-    SGM_TRY(copy_big(G.rec, hrec.data(), hrec.size() * 8, hipMemcpyHostToDevice));
+}
+__global__ void k_slab_diag(int64_t np, const int32_t *__restrict__ row, const double *__restrict__ D, double *__restrict__ Dp)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; p < np; p += stride) Dp[p] = row[p] >= 0 ? D[row[p]] : 1.0;
+}
+int refresh_tri(SlabTri &G, const double *val)
+{
+    hipLaunchKernelGGL(k_slab_records, dim3(vec_grid(G.NP)), dim3(kBlock), 0, g_rt.stream, G.NP, (const int32_t *)G.src[0],
+                       (const int32_t *)G.src[1], (const int32_t *)G.src[2], val, G.rec);
+    SGM_HIP(hipGetLastError());
     return SGM_OK;
 }
 
@@ -616,13 +638,13 @@ int slab3_build(Slab3 **out, int32_t n, const std::vector<int32_t> &Lptr, const 
     return SGM_OK;
 }
 
-int slab3_refresh(Slab3 *S, const std::vector<double> &Lval, const std::vector<double> &Uval, const std::vector<double> &D)
+// (Lval, Uval, D: the factors on the device)
+int slab3_refresh(Slab3 *S, const double *Lval, const double *Uval, const double *D)
 {
     SGM_TRY(refresh_tri(S->L, Lval));
     SGM_TRY(refresh_tri(S->U, Uval));
-    std::vector<double> gd((size_t)S->U.NP, 1.0);
-    for (int32_t r = 0; r < S->n; ++r) gd[S->U.h_pos[r]] = D[r];
-    SGM_TRY(copy_big(S->Dp, gd.data(), gd.size() * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_slab_diag, dim3(vec_grid(S->U.NP)), dim3(kBlock), 0, g_rt.stream, S->U.NP, (const int32_t *)S->U.row, D, S->Dp);
+    SGM_HIP(hipGetLastError());
     return SGM_OK;
 }
 
@@ -643,6 +665,13 @@ void slab3_apply(const Slab3 *S, const double *r, double *z, const int *flag, in
 }
 
 // abort words of the last sweeps (stream must be idle)
+// the result of the last L sweep in row order (setup self-check)
+void slab3_lower_result(const Slab3 *S, double *dst)
+{
+    hipLaunchKernelGGL(k_slab_scatter, dim3(vec_grid(S->L.NP)), dim3(kBlock), 0, g_rt.stream, S->L.NP, dst, (const double *)S->xL,
+                       (const int32_t *)S->L.row, (const int *)nullptr);
+}
+
 int slab3_aborted(const Slab3 *S, int32_t *abL, int32_t *abU)
 {
     SGM_HIP(hipMemcpy(abL, S->L.progress + (int64_t)S->L.NB * S->L.NI, 4, hipMemcpyDeviceToHost));
