@@ -265,7 +265,8 @@ void csr_release_arrays(const Part &p);
 // sgm_trsv3.hip: slab-pipelined triangular solves for ILDU(0) factors of 3-D grids (deps r-1, r-w, r-w*h)
 struct Slab3;
 int slab3_build(Slab3 **out, int32_t n, const std::vector<int32_t> &Lptr, const std::vector<int32_t> &Lnode,
-                const std::vector<int32_t> &Uptr, const std::vector<int32_t> &Unode);      // *out null: not applicable
+                const std::vector<int32_t> &Uptr, const std::vector<int32_t> &Unode, const int32_t *dLptr, const int32_t *dLnode,
+                const int32_t *dUptr, const int32_t *dUnode);      // *out null: not applicable
 int slab3_refresh(Slab3 *S, const double *Lval, const double *Uval, const double *D);     // (device pointers)
 void slab3_apply(const Slab3 *S, const double *r, double *z, const int *flag, int spin_limit, int32_t *sticky);
 void slab3_lower_result(const Slab3 *S, double *dst);

@@ -81,6 +81,7 @@ struct TriFactor {                   // strictly triangular factor on the device
     struct RowLevel { int32_t b, e, c, row0; };      // positions [b, e); most entries of a row; row0 >= 0: rows row0, row0+1, ...
     std::vector<RowLevel> row_levels;
     bool rows_on = false;
+    bool have_levels = false, have_walkers = false;   // index work done: levels (+ row-space copy) / the walkers' structures
     int rc = 0;
     int32_t *rq = nullptr;
     double *rv = nullptr;
@@ -125,11 +126,10 @@ struct IlduState {
     int32_t *mapLU = nullptr;                                // U position -> L position of the same row
     std::vector<int32_t> hLptr, hLnode, hUptr, hUnode;      // 1-based, as the reference holds them
     // the factors live on the device (0-based pattern copies, values in the pattern's order; D = the array above): the
-    // factorisation runs there, level by level of L's dependency graph (forder / flevel_ptr), and every structure the
+    // factorisation runs there, level by level of L's dependency graph (L.order / L.level_ptr), and every structure the
     // applies read is filled from these by kernels.  Host copies of the VALUES only on request (sgm_pc_get, self-check).
-    int32_t *dLptr = nullptr, *dLnode = nullptr, *dUptr = nullptr, *dUnode = nullptr, *forder = nullptr;
+    int32_t *dLptr = nullptr, *dLnode = nullptr, *dUptr = nullptr, *dUnode = nullptr;
     double *dLval = nullptr, *dUval = nullptr;
-    std::vector<int32_t> flevel_ptr;
     std::vector<double> hLval, hUval, hD;
     bool host_vals = false;
     // strip-pipeline path (both factors grid-like, see GridTri): results in position space and the L -> U hand-over
@@ -142,6 +142,7 @@ struct IlduState {
     bool slab_ok = false;
     // the level-scheduled structures are built on first need when a pipelined path serves the pattern
     bool levels_ready = false, levels_pattern = false;
+    bool walk_ready = false, walk_pattern = false;          // the same for the level walkers' structures (ensure_walkers)
 };
 
 struct sgm_pc_s {
@@ -961,9 +962,26 @@ __global__ void k_tri_entries(int64_t nnz, const int32_t *__restrict__ src, cons
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; k < nnz; k += stride) pv[k] = val[src[k]];
 }
-// the inline values of the row records and the slot-major copies (dv: kInline slots; rv: rc slots, null = none)
-__global__ void k_tri_slots(int32_t n, TrsvRec *recs, const double *__restrict__ pv, uint32_t nstride, double *__restrict__ dv,
-                            int rc, double *__restrict__ rv)
+// row-space copy of a factor (k_trsv_rows): slot j of position p = entry j of row order[p] -- its column, its value
+__global__ void k_rows_index(int32_t n, const int32_t *__restrict__ order, const int32_t *__restrict__ ptr, const int32_t *__restrict__ node,
+                             uint32_t nstride, int rc, int32_t *__restrict__ rq)
+{
+    const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int32_t i = order[p], b = ptr[i], cnt = ptr[i + 1] - b;
+    for (int j = 0; j < rc; ++j) rq[(size_t)j * nstride + p] = j < cnt ? node[b + j] : -1;
+}
+__global__ void k_rows_values(int32_t n, const int32_t *__restrict__ order, const int32_t *__restrict__ ptr, const double *__restrict__ val,
+                              uint32_t nstride, int rc, double *__restrict__ rv)
+{
+    const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int32_t i = order[p], b = ptr[i], cnt = ptr[i + 1] - b;
+    for (int j = 0; j < rc; ++j) rv[(size_t)j * nstride + p] = j < cnt ? val[b + j] : 0.0;
+}
+
+// the inline values of the row records and their slot-major copy (dv: kInline slots)
+__global__ void k_tri_slots(int32_t n, TrsvRec *recs, const double *__restrict__ pv, uint32_t nstride, double *__restrict__ dv)
 {
     const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
@@ -974,8 +992,6 @@ __global__ void k_tri_slots(int32_t n, TrsvRec *recs, const double *__restrict__
         recs[p].v[j] = v;
         dv[(size_t)j * nstride + p] = v;
     }
-    if (rv)
-        for (int j = 0; j < rc; ++j) rv[(size_t)j * nstride + p] = j < cnt ? pv[k0 + j] : 0.0;
 }
 
 // dependency levels of a strictly triangular pattern (1-based): level_ptr / order (position -> row, rows of a level in
@@ -1013,7 +1029,7 @@ void free_ildu(IlduState &S)
     free_tri(S.L);
     free_tri(S.U);
     dfree(S.D); dfree(S.xpL); dfree(S.xpU); dfree(S.Dp); dfree(S.mapLU);
-    dfree(S.dLptr); dfree(S.dLnode); dfree(S.dUptr); dfree(S.dUnode); dfree(S.forder); dfree(S.dLval); dfree(S.dUval);
+    dfree(S.dLptr); dfree(S.dLnode); dfree(S.dUptr); dfree(S.dUnode); dfree(S.dLval); dfree(S.dUval);
     free_grid(S.gL); free_grid(S.gU);
     dfree(S.gxL); dfree(S.gxU); dfree(S.gDp); dfree(S.gmapLU);
     slab3_free(S.slab);
@@ -1027,17 +1043,71 @@ void free_tri(TriFactor &T)
     T = TriFactor();
 }
 
-// upload a strictly triangular factor in level order.  lower: rows depend on smaller rows
-// (forward sweep 1..n); upper: on larger rows (backward sweep n..1).
-// (val: the factor's values on the device, in the pattern's order)
-int upload_tri(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const std::vector<int32_t> &node1,
-               const double *val, bool lower, bool pattern_changed)
+// Dependency levels of a strictly triangular factor and, for one of at most kRowLevels levels, its row-space copy.
+// lower: rows depend on smaller rows (forward sweep 1..n); upper: on larger rows (backward sweep n..1).  ptr1 / node1:
+// the pattern on the host (1-based); dptr / dnode / dval: the factor on the device (0-based, values in pattern order;
+// dval null: index work only).
+int tri_levels_dev(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const std::vector<int32_t> &node1,
+                   const int32_t *dptr, const int32_t *dnode, const double *dval, bool lower)
+{
+    hipStream_t st = g_rt.stream;
+    if (!T.have_levels) {
+        free_tri(T);
+        tri_levels(n, ptr1, node1, lower, T.level_ptr, T.h_order, &T.h_pos);
+        const int32_t nlev = (int32_t)T.level_ptr.size() - 1;
+        T.nstride = (size_t)n + kNarrow;          // (padded by kNarrow rows: lanes of the walkers past a level's end read valid memory)
+        SGM_TRY(dalloc(&T.order, (size_t)std::max(n, 1)));
+        SGM_TRY(dalloc(&T.level_ptr_dev, T.level_ptr.size()));
+        if (n) SGM_TRY(copy_big(T.order, T.h_order.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        SGM_HIP(hipMemcpy(T.level_ptr_dev, T.level_ptr.data(), T.level_ptr.size() * 4, hipMemcpyHostToDevice));
+        // a few levels (whatever their widths): the row-space copy (dependency rows, slot-major over the level order)
+        T.rows_on = false;
+        T.rc = 0;
+        T.row_levels.clear();
+        if (nlev >= 1 && nlev <= kRowLevels && (size_t)n + kNarrow < (size_t)500000000) {
+            int cm = 0;
+            for (int32_t l = 0; l < nlev; ++l) {
+                const int32_t b = T.level_ptr[l], e = T.level_ptr[l + 1];
+                int c = 0;
+                bool run = true;
+                for (int32_t p2 = b; p2 < e; ++p2) {
+                    const int32_t i = T.h_order[p2];
+                    c = std::max(c, ptr1[i + 1] - ptr1[i]);
+                    if (p2 > b) run = run && i == T.h_order[p2 - 1] + 1;
+                }
+                T.row_levels.push_back({b, e, c, run ? T.h_order[b] : -1});
+                cm = std::max(cm, c);
+            }
+            if (cm <= 64) {
+                T.rows_on = true;
+                T.rc = std::max(cm, 1);
+                SGM_TRY(dalloc(&T.rq, T.nstride * (size_t)T.rc));
+                SGM_TRY(dalloc(&T.rv, T.nstride * (size_t)T.rc));
+                SGM_HIP(hipMemsetAsync(T.rq, 0xff, T.nstride * (size_t)T.rc * 4, st));
+                SGM_HIP(hipMemsetAsync(T.rv, 0, T.nstride * (size_t)T.rc * 8, st));
+                if (n) hipLaunchKernelGGL(k_rows_index, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, (const int32_t *)T.order, dptr,
+                                          dnode, (uint32_t)T.nstride, T.rc, T.rq);
+            }
+        }
+        T.have_levels = true;
+    }
+    if (T.rows_on && n && dval)
+        hipLaunchKernelGGL(k_rows_values, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, (const int32_t *)T.order, dptr, dval,
+                           (uint32_t)T.nstride, T.rc, T.rv);
+    SGM_HIP(hipGetLastError());
+    return SGM_OK;
+}
+
+// The level walkers' structures of a factor (tri_levels_dev has run): records in level order, schedule, ring copies --
+// index work when the pattern is new, values (from the device factor) every time.
+int tri_walkers(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const std::vector<int32_t> &node1, const double *val)
 {
     const size_t nnz = node1.size();
-    if (pattern_changed) {
-        free_tri(T);
+    if (!T.have_walkers) {
+        dfree(T.recs); dfree(T.pq); dfree(T.pv); dfree(T.dq); dfree(T.dq32); dfree(T.dv); dfree(T.wq); dfree(T.src);
+        T.recs = nullptr; T.pq = nullptr; T.pv = nullptr; T.dq = nullptr; T.dq32 = nullptr; T.dv = nullptr; T.wq = nullptr; T.src = nullptr;
+        T.schedule.clear();
         std::vector<int32_t> h_src(std::max<size_t>(nnz, 1), 0);      // level-order entry -> factor entry
-        tri_levels(n, ptr1, node1, lower, T.level_ptr, T.h_order, &T.h_pos);
         const int32_t nlev = (int32_t)T.level_ptr.size() - 1;
         // rows in level order: dependency POSITIONS in stored order
         T.h_recs.assign(std::max(n, 1), TrsvRec());
@@ -1100,28 +1170,8 @@ int upload_tri(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const 
             T.schedule.push_back({l, e, true, c, ring_ok, cmax});
             l = e;
         }
-        // a few levels (whatever their widths): the row-space copy (dependency rows, slot-major over the level order)
-        T.rows_on = false;
-        T.rc = 0;
-        T.row_levels.clear();
-        if (nlev >= 1 && nlev <= kRowLevels && (size_t)n + kNarrow < (size_t)500000000) {
-            int cm = 0;
-            for (int32_t l = 0; l < nlev; ++l) {
-                const int32_t b = T.level_ptr[l], e = T.level_ptr[l + 1];
-                int c = 0;
-                bool run = true;
-                for (int32_t p2 = b; p2 < e; ++p2) {
-                    c = std::max(c, T.h_recs[p2].cnt);
-                    if (p2 > b) run = run && T.h_order[p2] == T.h_order[p2 - 1] + 1;
-                }
-                T.row_levels.push_back({b, e, c, run ? T.h_order[b] : -1});
-                cm = std::max(cm, c);
-            }
-            if (cm <= 64) { T.rows_on = true; T.rc = std::max(cm, 1); }
-        }
         // ring-walker copy of the structure: 16-bit ring slots (only read in ring runs), padded
         // by kNarrow rows so that lanes past a level's end read valid memory
-        T.nstride = (size_t)n + kNarrow;
         T.h_dq.assign(T.nstride, 0);
         for (int32_t p = 0; p < n; ++p) {
             const TrsvRec &r = T.h_recs[p];
@@ -1146,35 +1196,21 @@ int upload_tri(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const 
             SGM_TRY(dalloc(&T.wq, wq.size()));
             SGM_HIP(hipMemcpy(T.wq, wq.data(), wq.size() * 4, hipMemcpyHostToDevice));
         }
-        if (T.rows_on) {
-            std::vector<int32_t> rq(T.nstride * (size_t)T.rc, -1);
-            for (int32_t p = 0; p < n; ++p) {
-                const TrsvRec &r = T.h_recs[p];
-                for (int32_t j = 0; j < r.cnt; ++j) rq[(size_t)j * T.nstride + p] = T.h_order[T.h_pq[r.k0 + j]];
-            }
-            SGM_TRY(dalloc(&T.rq, rq.size()));
-            SGM_TRY(dalloc(&T.rv, rq.size()));
-            SGM_TRY(copy_big(T.rq, rq.data(), rq.size() * 4, hipMemcpyHostToDevice));
-        }
-        SGM_TRY(dalloc(&T.order, (size_t)n));
-        SGM_TRY(dalloc(&T.recs, (size_t)n));
+        SGM_TRY(dalloc(&T.recs, (size_t)std::max(n, 1)));
         SGM_TRY(dalloc(&T.pq, nnz));
         SGM_TRY(dalloc(&T.pv, nnz));
         SGM_TRY(dalloc(&T.src, nnz));
-        SGM_TRY(dalloc(&T.level_ptr_dev, T.level_ptr.size()));
-        if (n) SGM_HIP(hipMemcpy(T.order, T.h_order.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-        if (nnz) SGM_HIP(hipMemcpy(T.pq, T.h_pq.data(), nnz * 4, hipMemcpyHostToDevice));
-        if (nnz) SGM_HIP(hipMemcpy(T.src, h_src.data(), nnz * 4, hipMemcpyHostToDevice));
-        if (n) SGM_HIP(hipMemcpy(T.recs, T.h_recs.data(), (size_t)n * sizeof(TrsvRec), hipMemcpyHostToDevice));     // (values: k_tri_slots)
-        SGM_HIP(hipMemcpy(T.level_ptr_dev, T.level_ptr.data(), T.level_ptr.size() * 4, hipMemcpyHostToDevice));
+        if (nnz) SGM_TRY(copy_big(T.pq, T.h_pq.data(), nnz * 4, hipMemcpyHostToDevice));
+        if (nnz) SGM_TRY(copy_big(T.src, h_src.data(), nnz * 4, hipMemcpyHostToDevice));
+        if (n) SGM_TRY(copy_big(T.recs, T.h_recs.data(), (size_t)n * sizeof(TrsvRec), hipMemcpyHostToDevice));     // (values: k_tri_slots)
         SGM_HIP(hipMemsetAsync(T.dv, 0, T.nstride * kInline * 8, g_rt.stream));          // (the padding slots stay zero)
-        if (T.rv) SGM_HIP(hipMemsetAsync(T.rv, 0, T.nstride * (size_t)T.rc * 8, g_rt.stream));
+        T.have_walkers = true;
     }
-    // values (every setup), on the device: level-order copy, the inline part of the records, the slot-major copies
+    // values (every setup), on the device: level-order copy, the inline part of the records, the slot-major copy
     hipStream_t st = g_rt.stream;
     if (nnz) hipLaunchKernelGGL(k_tri_entries, dim3(vec_grid((int64_t)nnz)), dim3(kBlock), 0, st, (int64_t)nnz, (const int32_t *)T.src, val, T.pv);
     if (n) hipLaunchKernelGGL(k_tri_slots, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, T.recs, (const double *)T.pv,
-                              (uint32_t)T.nstride, T.dv, T.rc, T.rows_on ? T.rv : nullptr);
+                              (uint32_t)T.nstride, T.dv);
     SGM_HIP(hipGetLastError());
     return SGM_OK;
 }
@@ -1300,30 +1336,51 @@ void apply_grid(const IlduState *S, const double *r, double *z, const int *flag,
                        (const int32_t *)S->gU.row, flag);
 }
 
-// The level-scheduled structures of both factors (index work when the pattern is new, values always) and the work
-// vectors of apply_levels.  At setup when no pipelined path serves the pattern, otherwise on first need.
+// Dependency levels of both factors, their row-space copies when they have few levels (index work when the pattern is
+// new, values always) and the work vector of the row-space sweeps.  At setup when no pipelined path serves the pattern,
+// otherwise on first need.
 int ensure_levels(IlduState *S)
 {
     if (S->levels_ready) return SGM_OK;
     const int32_t n = S->n;
     const bool fresh = !S->levels_pattern;
-    SGM_TRY(upload_tri(S->L, n, S->hLptr, S->hLnode, S->dLval, true, fresh));
-    SGM_TRY(upload_tri(S->U, n, S->hUptr, S->hUnode, S->dUval, false, fresh));
+    SGM_TRY(tri_levels_dev(S->L, n, S->hLptr, S->hLnode, S->dLptr, S->dLnode, S->dLval, true));
+    SGM_TRY(tri_levels_dev(S->U, n, S->hUptr, S->hUnode, S->dUptr, S->dUnode, S->dUval, false));
     if (fresh) {
-        dfree(S->xpL); dfree(S->xpU); dfree(S->Dp); dfree(S->mapLU);
-        S->xpL = S->xpU = S->Dp = nullptr; S->mapLU = nullptr;
+        dfree(S->xpL);
+        S->xpL = nullptr;
         SGM_TRY(dalloc(&S->xpL, (size_t)n + kNarrow));     // + scratch slots of the level walker
+    }
+    S->levels_pattern = true;
+    S->levels_ready = true;
+    return SGM_OK;
+}
+
+// The level walkers' structures (records, schedules, ring copies, the L -> U hand-over in position space): built when
+// neither a pipelined path nor the row-space sweeps serve the pattern, otherwise on first need (an option switched
+// off, a retired pipeline).
+int ensure_walkers(IlduState *S)
+{
+    SGM_TRY(ensure_levels(S));
+    if (S->walk_ready) return SGM_OK;
+    const int32_t n = S->n;
+    const bool fresh = !S->walk_pattern;
+    SGM_TRY(tri_walkers(S->L, n, S->hLptr, S->hLnode, S->dLval));
+    SGM_TRY(tri_walkers(S->U, n, S->hUptr, S->hUnode, S->dUval));
+    if (fresh) {
+        dfree(S->xpU); dfree(S->Dp); dfree(S->mapLU);
+        S->xpU = S->Dp = nullptr; S->mapLU = nullptr;
         SGM_TRY(dalloc(&S->xpU, (size_t)n + kNarrow));
-        SGM_TRY(dalloc(&S->Dp, (size_t)n));
-        SGM_TRY(dalloc(&S->mapLU, (size_t)n));
+        SGM_TRY(dalloc(&S->Dp, (size_t)std::max(n, 1)));
+        SGM_TRY(dalloc(&S->mapLU, (size_t)std::max(n, 1)));
         std::vector<int32_t> map((size_t)std::max(n, 1));
         for (int32_t p = 0; p < n; ++p) map[p] = S->L.h_pos[S->U.h_order[p]];
-        if (n) SGM_HIP(hipMemcpy(S->mapLU, map.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        if (n) SGM_TRY(copy_big(S->mapLU, map.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     }
     if (n) hipLaunchKernelGGL(k_pos_diag, dim3(vec_grid(n)), dim3(kBlock), 0, g_rt.stream, (int64_t)n, (const int32_t *)S->U.order,
                               (const double *)S->D, S->Dp);                  // D in U's level order
-    S->levels_pattern = true;
-    S->levels_ready = true;
+    S->walk_pattern = true;
+    S->walk_ready = true;
     return SGM_OK;
 }
 
@@ -1506,7 +1563,7 @@ bool pc_apply_is_short(sgm_pc pc)
         if (g_opt.ildu_strips && (S.grid_ok || S.slab_ok)) continue;
         if (!S.levels_ready) return false;
         if (g_opt.ildu_rows && S.L.rows_on && S.U.rows_on) continue;         // at most 2 * kRowLevels launches
-        if (3 + S.L.schedule.size() + S.U.schedule.size() > 35) return false;
+        if (!S.walk_ready || 3 + S.L.schedule.size() + S.U.schedule.size() > 35) return false;
     }
     return true;
 }
@@ -1532,6 +1589,7 @@ int pc_retire_pipelines(sgm_pc pc)
         S.grid_ok = false;
         S.slab_ok = false;
         SGM_TRY(ensure_levels(&S));
+        if (!rows_serve(&S)) SGM_TRY(ensure_walkers(&S));
     }
     pc->retired += 1;
     SGM_HIP(hipMemsetAsync(pc->abort_sticky, 0, sizeof(int32_t), g_rt.stream));
@@ -1561,8 +1619,9 @@ int pc_apply_parts(sgm_pc pc, sgm_mat A, const double *const *r, double *const *
                 continue;
             }
             SGM_TRY(ensure_levels(&pc->ild[ip]));              // (built on first need when a pipelined path served the pattern so far)
-            if (rows_serve(S)) apply_rows(S, r[ip], z[ip], flag);
-            else apply_levels(S, r[ip], z[ip], flag);
+            if (rows_serve(S)) { apply_rows(S, r[ip], z[ip], flag); continue; }
+            SGM_TRY(ensure_walkers(&pc->ild[ip]));
+            apply_levels(S, r[ip], z[ip], flag);
         }
     }
     SGM_HIP(hipGetLastError());
@@ -1670,11 +1729,8 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             free_ildu(*S);
             SGM_TRY(ildu_pattern(S, P, own));
             lap("pattern (device) + its host copy");
-            // L's dependency levels: the order the rows are factorised in
-            std::vector<int32_t> order;
-            tri_levels(n, S->hLptr, S->hLnode, true, S->flevel_ptr, order, nullptr);
-            SGM_TRY(dalloc(&S->forder, (size_t)std::max(n, 1)));
-            if (n) SGM_TRY(copy_big(S->forder, order.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+            // L's dependency levels: the order the rows are factorised in (and what its sweeps use later)
+            SGM_TRY(tri_levels_dev(S->L, n, S->hLptr, S->hLnode, S->dLptr, S->dLnode, nullptr, true));
             SGM_TRY(dalloc(&S->dLval, std::max<size_t>(S->hLnode.size(), 1)));
             SGM_TRY(dalloc(&S->dUval, std::max<size_t>(S->hUnode.size(), 1)));
             SGM_TRY(dalloc(&S->D, (size_t)std::max(n, 1)));
@@ -1688,10 +1744,10 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             hipLaunchKernelGGL(k_ildu_init, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, own, (const int32_t *)P.rowptr,
                                (const int32_t *)P.col, (const double *)P.val, (const int32_t *)S->dLptr, (const int32_t *)S->dLnode,
                                S->dLval, (const int32_t *)S->dUptr, (const int32_t *)S->dUnode, S->dUval, S->D);
-            for (size_t l = 0; l + 1 < S->flevel_ptr.size(); ++l) {
-                const int32_t b = S->flevel_ptr[l], e = S->flevel_ptr[l + 1];
+            for (size_t l = 0; l + 1 < S->L.level_ptr.size(); ++l) {
+                const int32_t b = S->L.level_ptr[l], e = S->L.level_ptr[l + 1];
                 hipLaunchKernelGGL(k_ildu_factor_level, dim3((e - b + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
-                                   (const int32_t *)S->forder, b, e, (const int32_t *)S->dLptr, (const int32_t *)S->dLnode, S->dLval,
+                                   (const int32_t *)S->L.order, b, e, (const int32_t *)S->dLptr, (const int32_t *)S->dLnode, S->dLval,
                                    (const int32_t *)S->dUptr, (const int32_t *)S->dUnode, S->dUval, S->D);
             }
             SGM_HIP(hipGetLastError());
@@ -1699,7 +1755,8 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
         lap("factorisation (device)");
         // (the level-scheduled structures: ensure_levels, below or on first need)
         S->levels_ready = false;
-        if (fresh) S->levels_pattern = false;
+        S->walk_ready = false;
+        if (fresh) S->levels_pattern = S->walk_pattern = false;
         if (fresh) {        // grid-like factors get the strip layout
             free_grid(S->gL); free_grid(S->gU);
             dfree(S->gxL); dfree(S->gxU); dfree(S->gDp); dfree(S->gmapLU);
@@ -1726,7 +1783,7 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             S->slab = nullptr;
             S->slab_ok = false;
             if (g_opt.ildu_strips && !(S->gL.on && S->gU.on))
-                SGM_TRY(slab3_build(&S->slab, n, S->hLptr, S->hLnode, S->hUptr, S->hUnode));
+                SGM_TRY(slab3_build(&S->slab, n, S->hLptr, S->hLnode, S->hUptr, S->hUnode, S->dLptr, S->dLnode, S->dUptr, S->dUnode));
         }
         lap("strip / slab index work");
         if (S->slab) SGM_TRY(slab3_refresh(S->slab, S->dLval, S->dUval, S->D));
@@ -1737,9 +1794,13 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             hipLaunchKernelGGL(k_pos_diag, dim3(vec_grid(S->gU.NP)), dim3(kBlock), 0, st, S->gU.NP, (const int32_t *)S->gU.row,
                                (const double *)S->D, S->gDp);
         }
-        if (!have_grid && !S->slab) {         // no pipelined path for this pattern: the level walkers serve it
+        if (!have_grid && !S->slab) {         // no pipelined path for this pattern: the row-space sweeps or the level walkers serve it
             SGM_TRY(ensure_levels(S));
-            lap("level schedules + upload");
+            lap("levels, row-space copy");
+            if (!rows_serve(S)) {
+                SGM_TRY(ensure_walkers(S));
+                lap("level walkers' structures");
+            }
         }
         lap("strip / slab records");
         if ((have_grid || S->slab) && fresh) {
@@ -1789,7 +1850,8 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             lap("self-check");
             if (!same) {
                 SGM_TRY(ensure_levels(S));
-                lap("level schedules + upload");
+                if (!rows_serve(S)) SGM_TRY(ensure_walkers(S));
+                lap("levels, walkers' structures");
             }
         }
     }

@@ -50,7 +50,7 @@ struct SlabTri {
     int32_t *row = nullptr;                // device: position -> row (-1 = padding)
     int32_t *progress = nullptr;           // device: NB*NI forwarded steps (diagnostics), [NB*NI] = abort word
     long long *clk = nullptr;              // device: 2 per (b, a): chain start / end
-    std::vector<int32_t> h_pos;            // row -> position
+    int32_t *pos = nullptr;                // device: row -> position (index work only; freed after it)
     int32_t *src[3] = {nullptr, nullptr, nullptr};   // device: position -> entry of the factor's val array per source (-1 = none)
 };
 
@@ -400,6 +400,7 @@ void free_tri(SlabTri &G)
 {
     dfree(G.rec); dfree(G.code); dfree(G.row); dfree(G.progress); dfree(G.clk);
     for (auto &v : G.src) dfree(v);
+    dfree(G.pos);
     G = SlabTri();
 }
 
@@ -453,7 +454,51 @@ int choose_hb(int32_t nk, int32_t h, int NI, int R)
     return best;
 }
 
-int build_tri(SlabTri &G, int32_t n, int32_t w, int32_t h, const std::vector<int32_t> &ptr1, const std::vector<int32_t> &node1, bool lower)
+// index work of the slab layout, one lane per row (device pattern, 0-based): position of the row, its entries' places in
+// the factor's val array per source (0 back r-wh, 1 up r-w, 2 left r-1), presence bits and the three 2-bit source ids in
+// stored order; flags: [0] some row's order is back-up-left, [1] left-up-back, [2] anything else, [3] some row lacks a
+// dependency its grid position implies (or has one it does not).
+__global__ void k_slab_build(int32_t n, int32_t w, int32_t h, int32_t nk, int32_t NI, int32_t HB, int32_t S, int lower,
+                             const int32_t *__restrict__ ptr, const int32_t *__restrict__ node, int32_t *__restrict__ row,
+                             int32_t *__restrict__ s0, int32_t *__restrict__ s1, int32_t *__restrict__ s2, int32_t *__restrict__ code,
+                             int32_t *__restrict__ pos, int32_t *flags)
+{
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int64_t wh = (int64_t)w * h;
+    int32_t i = r % w, j = (int32_t)((r / w) % h), k = (int32_t)(r / wh);
+    if (!lower) { i = w - 1 - i; j = h - 1 - j; k = nk - 1 - k; }
+    const int32_t a = i / 64, l = i % 64, b = j / HB, jl = j % HB;
+    const int64_t t = (int64_t)k * HB + jl + l;
+    const int64_t p = (((int64_t)b * NI + a) * S + t) * 64 + l;
+    pos[r] = (int32_t)p;
+    row[p] = r;
+    int32_t c = 0, ids[3] = {3, 3, 3};
+    int cnt = 0;
+    for (int32_t e = ptr[r]; e < ptr[r + 1]; ++e, ++cnt) {
+        const int32_t dlt = lower ? r - node[e] : node[e] - r;
+        const int id = dlt == 1 ? 2 : dlt == w ? 1 : 0;
+        c |= 1 << id;
+        if (id == 0) s0[p] = e; else if (id == 1) s1[p] = e; else s2[p] = e;
+        if (cnt < 3) ids[cnt] = id;
+    }
+    if ((c & 7) != ((k > 0 ? 1 : 0) | (j > 0 ? 2 : 0) | (i > 0 ? 4 : 0))) flags[3] = 1;
+    c |= ids[0] << 3 | ids[1] << 5 | ids[2] << 7;
+    code[p] = c;
+    if (cnt >= 2) {
+        bool asc = true, desc = true;
+        for (int q = 1; q < cnt && q < 3; ++q) { if (ids[q] < ids[q - 1]) asc = false; if (ids[q] > ids[q - 1]) desc = false; }
+        flags[asc ? 0 : desc ? 1 : 2] = 1;
+    }
+}
+__global__ void k_slab_map(int32_t n, const int32_t *__restrict__ posU, const int32_t *__restrict__ posL, int32_t *__restrict__ map)
+{
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) map[posU[r]] = posL[r];
+}
+
+// (dptr / dnode: the factor's pattern on the device, 0-based; slab_dims has checked it on the host copy)
+int build_tri(SlabTri &G, int32_t n, int32_t w, int32_t h, const int32_t *dptr, const int32_t *dnode, bool lower)
 {
     free_tri(G);
     const int64_t wh = (int64_t)w * h;
@@ -465,54 +510,33 @@ int build_tri(SlabTri &G, int32_t n, int32_t w, int32_t h, const std::vector<int
     G.S = (int32_t)(((int64_t)G.nk * G.HB + 63 + 31) / 32 * 32);      // a multiple of every look-ahead depth
     G.NP = (int64_t)G.NB * G.NI * G.S * 64;
     if (G.NP >= INT32_MAX) return SGM_OK;                     // (positions are int32)
-    std::vector<int32_t> hrow((size_t)G.NP, -1);
-    std::vector<int32_t> h_code((size_t)G.NP, 0);
-    G.h_pos.assign(std::max(n, 1), 0);
-    std::vector<int32_t> h_src[3];
-    for (auto &v : h_src) v.assign((size_t)G.NP, -1);
-    bool any_bul = false, any_lub = false, any_other = false;
-    G.regular = n == wh * G.nk;
-    for (int32_t r = 0; r < n; ++r) {
-        int32_t i = r % w, j = (int32_t)((r / w) % h), k = (int32_t)(r / wh);
-        if (!lower) { i = w - 1 - i; j = h - 1 - j; k = G.nk - 1 - k; }
-        const int32_t a = i / 64, l = i % 64, b = j / G.HB, jl = j % G.HB;
-        const int64_t t = (int64_t)k * G.HB + jl + l;
-        const int64_t p = (((int64_t)b * G.NI + a) * G.S + t) * 64 + l;
-        G.h_pos[r] = (int32_t)p;
-        hrow[p] = r;
-        int32_t c = 0, ids[3] = {3, 3, 3};
-        int cnt = 0;
-        for (int32_t e = ptr1[r] - 1; e < ptr1[r + 1] - 1; ++e, ++cnt) {
-            const int32_t dlt = lower ? r - (node1[e] - 1) : (node1[e] - 1) - r;
-            const int id = dlt == 1 ? 2 : dlt == w ? 1 : 0;      // 0 back (r-wh), 1 up (r-w), 2 left (r-1)
-            c |= 1 << id;
-            h_src[id][p] = e;
-            ids[cnt] = id;
-        }
-        if ((c & 7) != ((k > 0 ? 1 : 0) | (j > 0 ? 2 : 0) | (i > 0 ? 4 : 0))) G.regular = false;
-        c |= ids[0] << 3 | ids[1] << 5 | ids[2] << 7;
-        h_code[p] = c;
-        if (cnt >= 2) {
-            bool asc = true, desc = true;
-            for (int q = 1; q < cnt; ++q) { if (ids[q] < ids[q - 1]) asc = false; if (ids[q] > ids[q - 1]) desc = false; }
-            if (asc) any_bul = true; else if (desc) any_lub = true; else any_other = true;
-        }
-    }
-    G.order = any_other || (any_bul && any_lub) ? 2 : any_lub ? 1 : 0;
+    hipStream_t st = g_rt.stream;
+    int32_t *flags = nullptr;
     SGM_TRY(dalloc(&G.rec, ((size_t)G.NP + kPadPos) * 2));            // + one look-ahead of padding: the chain never clamps
     SGM_TRY(dalloc(&G.code, (size_t)G.NP + kPadPos));
-    SGM_HIP(hipMemset(G.rec, 0, ((size_t)G.NP + kPadPos) * 16));
-    SGM_HIP(hipMemset(G.code, 0, ((size_t)G.NP + kPadPos) * 4));
     SGM_TRY(dalloc(&G.row, (size_t)G.NP));
     SGM_TRY(dalloc(&G.progress, (size_t)G.NB * G.NI + 1));
     SGM_TRY(dalloc(&G.clk, ((size_t)G.NB * G.NI * (2 + G.S / 16) + (size_t)G.NB * 512)));
-    SGM_TRY(copy_big(G.row, hrow.data(), (size_t)G.NP * 4, hipMemcpyHostToDevice));
-    SGM_TRY(copy_big(G.code, h_code.data(), (size_t)G.NP * 4, hipMemcpyHostToDevice));
+    SGM_TRY(dalloc(&G.pos, (size_t)std::max(n, 1)));
     for (int id = 0; id < 3; ++id) {
         SGM_TRY(dalloc(&G.src[id], (size_t)G.NP));
-        SGM_TRY(copy_big(G.src[id], h_src[id].data(), (size_t)G.NP * 4, hipMemcpyHostToDevice));
+        SGM_HIP(hipMemsetAsync(G.src[id], 0xff, (size_t)G.NP * 4, st));      // -1 = no such term
     }
-    SGM_HIP(hipMemset(G.clk, 0, ((size_t)G.NB * G.NI * (2 + G.S / 16) + (size_t)G.NB * 512) * 8));
+    SGM_TRY(dalloc(&flags, 4));
+    SGM_HIP(hipMemsetAsync(G.rec, 0, ((size_t)G.NP + kPadPos) * 16, st));
+    SGM_HIP(hipMemsetAsync(G.code, 0, ((size_t)G.NP + kPadPos) * 4, st));
+    SGM_HIP(hipMemsetAsync(G.row, 0xff, (size_t)G.NP * 4, st));             // -1 = padding
+    SGM_HIP(hipMemsetAsync(G.clk, 0, ((size_t)G.NB * G.NI * (2 + G.S / 16) + (size_t)G.NB * 512) * 8, st));
+    SGM_HIP(hipMemsetAsync(flags, 0, 16, st));
+    if (n) hipLaunchKernelGGL(k_slab_build, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, w, h, G.nk, G.NI, G.HB, G.S, lower ? 1 : 0,
+                              dptr, dnode, G.row, G.src[0], G.src[1], G.src[2], G.code, G.pos, flags);
+    int32_t hf[4] = {0, 0, 0, 0};
+    hipError_t e = hipMemcpyAsync(hf, flags, 16, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    dfree(flags);
+    SGM_HIP(e);
+    G.regular = n == wh * G.nk && !hf[3];
+    G.order = hf[2] || (hf[0] && hf[1]) ? 2 : hf[1] ? 1 : 0;
     G.on = true;
     return SGM_OK;
 }
@@ -606,9 +630,11 @@ void slab3_free(Slab3 *S)
     delete S;
 }
 
-// *out stays null when the factors are not a 3-D grid's (or too small / too wide for this path)
+// *out stays null when the factors are not a 3-D grid's (or too small / too wide for this path).  Host copies of the
+// patterns (1-based) for the detection, device copies (0-based) for the index work.
 int slab3_build(Slab3 **out, int32_t n, const std::vector<int32_t> &Lptr, const std::vector<int32_t> &Lnode,
-                const std::vector<int32_t> &Uptr, const std::vector<int32_t> &Unode)
+                const std::vector<int32_t> &Uptr, const std::vector<int32_t> &Unode, const int32_t *dLptr, const int32_t *dLnode,
+                const int32_t *dUptr, const int32_t *dUnode)
 {
     *out = nullptr;
     int32_t wl, hl, wu, hu;
@@ -620,19 +646,25 @@ int slab3_build(Slab3 **out, int32_t n, const std::vector<int32_t> &Lptr, const 
     if (wl < 32 || wl > 256 || hl < 8 || (n + wh - 1) / wh < 8) return SGM_OK;
     Slab3 *S = new Slab3;
     S->n = n;
-    int rc = build_tri(S->L, n, wl, hl, Lptr, Lnode, true);
-    if (rc == SGM_OK) rc = build_tri(S->U, n, wl, hl, Uptr, Unode, false);
+    int rc = build_tri(S->L, n, wl, hl, dLptr, dLnode, true);
+    if (rc == SGM_OK) rc = build_tri(S->U, n, wl, hl, dUptr, dUnode, false);
     if (rc != SGM_OK || !S->L.on || !S->U.on) { slab3_free(S); return rc; }
     rc = dalloc(&S->xL, (size_t)S->L.NP);
     if (rc == SGM_OK) rc = dalloc(&S->xU, (size_t)S->U.NP);
     if (rc == SGM_OK) rc = dalloc(&S->Dp, (size_t)S->U.NP);
     if (rc == SGM_OK) rc = dalloc(&S->mapLU, (size_t)S->U.NP);
     if (rc != SGM_OK) { slab3_free(S); return rc; }
-    std::vector<int32_t> map((size_t)S->U.NP, -1);
-    for (int32_t r = 0; r < n; ++r) map[S->U.h_pos[r]] = S->L.h_pos[r];
-    if (hipMemcpy(S->mapLU, map.data(), map.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    hipStream_t st = g_rt.stream;
+    hipError_t e = hipMemsetAsync(S->mapLU, 0xff, (size_t)S->U.NP * 4, st);
+    if (e == hipSuccess && n)
+        hipLaunchKernelGGL(k_slab_map, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, (const int32_t *)S->U.pos,
+                           (const int32_t *)S->L.pos, S->mapLU);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    dfree(S->L.pos); dfree(S->U.pos);
+    S->L.pos = S->U.pos = nullptr;
+    if (e != hipSuccess) {
         slab3_free(S);
-        return fail(SGM_ERR_HIP, "slab3_build: copy failed");
+        return fail(SGM_ERR_HIP, "slab3_build: index work failed");
     }
     *out = S;
     return SGM_OK;
