@@ -250,8 +250,10 @@ int sgm_axpy(int64_t n, double alpha, const double *x, double *y, int where);
 /* ---- preconditioners --------------------------------------------------------------- *
  * sgm_jacobi_create <- jacobi() + jacobi_setup      src/solver/jacobi_solvers.f90:23-63
  * sgm_ildu0_create  <- ldu(incomplete,level=0) + sparse_ldu_setup
- *                      src/solver/ldu_solvers.f90:73-130 (pattern :397-440, factorization
- *                      :275-387 run on the host once; factors + level sets live in HBM);
+ *                      src/solver/ldu_solvers.f90:73-130 (pattern :397-440 and factorization
+ *                      :275-387 run on the device -- the reference's statements per row, rows
+ *                      of one dependency level side by side --; the factors live in HBM, host
+ *                      copies of their values are made for sgm_pc_get only);
  *                      on a row-partitioned matrix: ILDU(0) of each part's diagonal block
  *                      (block-Jacobi, no exchange in the apply; iteration counts differ
  *                      from the one-part factorisation)
