@@ -132,6 +132,7 @@ struct IlduState {
     double *dLval = nullptr, *dUval = nullptr;
     std::vector<double> hLval, hUval, hD;
     bool host_vals = false;
+    int32_t maxL = 0, maxU = 0;                              // longest row of each factor
     // strip-pipeline path (both factors grid-like, see GridTri): results in position space and the L -> U hand-over
     GridTri gL, gU;
     double *gxL = nullptr, *gxU = nullptr, *gDp = nullptr;
@@ -933,6 +934,112 @@ __global__ void k_sweep_check(int32_t n, const int32_t *__restrict__ ptr, const 
     if (__double_as_longlong(t) != __double_as_longlong(x[i])) atomicAdd(bad, 1);
 }
 
+// The same for factors whose rows are short (every row of L at most ML entries, of U at most MU: 5-, 7-, 9-point
+// matrices): the row's own entries and the rows k it reads are fetched into registers up front -- five dependent memory
+// round trips (order, row pointers, own entries, pointers / D of the rows k, their entries) instead of the eleven or so
+// the scans above make one after the other; a launch of a narrow level is nothing but that chain.  Then the same
+// statements in the same order on the registers, and one store of the row.
+template <int M>
+__device__ inline double reg_get(const int32_t (&nd)[M], const double (&vl)[M], int cnt, int32_t j)
+{
+    double z = 0.0;
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+        if (m < cnt && nd[m] == j) z = vl[m];
+    return z;
+}
+template <int M>
+__device__ inline void reg_set(const int32_t (&nd)[M], double (&vl)[M], int cnt, int32_t j, double z)
+{
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+        if (m < cnt && nd[m] == j) vl[m] = z;
+}
+template <int M>
+__device__ inline void reg_add(const int32_t (&nd)[M], double (&vl)[M], int cnt, int32_t j, double z)
+{
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+        if (m < cnt && nd[m] == j) vl[m] = vl[m] + z;
+}
+template <int ML, int MU>
+__global__ void k_ildu_factor_level_short(const int32_t *__restrict__ order, int32_t begin, int32_t end,
+                                          const int32_t *__restrict__ Lptr, const int32_t *__restrict__ Lnode, double *Lval,
+                                          const int32_t *__restrict__ Uptr, const int32_t *__restrict__ Unode, double *Uval, double *D)
+{
+    const int32_t p = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= end) return;
+    const int32_t i = order[p];
+    const int32_t lb = Lptr[i], ub = Uptr[i];
+    const int dl = Lptr[i + 1] - lb, du = Uptr[i + 1] - ub;
+    int32_t ln[ML], un[MU];
+    double lv[ML], uv[MU];
+#pragma unroll
+    for (int m = 0; m < ML; ++m) { ln[m] = m < dl ? Lnode[lb + m] : -1; lv[m] = m < dl ? Lval[lb + m] : 0.0; }
+#pragma unroll
+    for (int m = 0; m < MU; ++m) { un[m] = m < du ? Unode[ub + m] : -1; uv[m] = m < du ? Uval[ub + m] : 0.0; }
+    double Di = D[i];
+    int32_t kb[ML];
+    int kc[ML];
+    double dk[ML];
+#pragma unroll
+    for (int a = 0; a < ML; ++a) {
+        const int32_t k = a < dl ? ln[a] : 0;
+        kb[a] = a < dl ? Uptr[k] : 0;
+        kc[a] = a < dl ? Uptr[k + 1] - kb[a] : 0;
+        dk[a] = a < dl ? D[k] : 1.0;
+    }
+    int32_t kn[ML][MU];
+    double kv[ML][MU];
+#pragma unroll
+    for (int a = 0; a < ML; ++a)
+#pragma unroll
+        for (int m = 0; m < MU; ++m) {
+            kn[a][m] = m < kc[a] ? Unode[kb[a] + m] : -1;
+            kv[a][m] = m < kc[a] ? Uval[kb[a] + m] : 0.0;
+        }
+#pragma unroll
+    for (int a = 0; a < ML; ++a) {
+        if (a < dl) {
+            const int32_t k = ln[a];
+            double Lik = reg_get<ML>(ln, lv, dl, k);
+            const double Uki = reg_get<MU>(kn[a], kv[a], kc[a], i);
+            const double Dk = dk[a];
+            reg_set<ML>(ln, lv, dl, k, Lik / Dk);
+            Lik = Lik / Dk;
+#pragma unroll
+            for (int c = 0; c < ML; ++c) {
+                if (c < dl && ln[c] > k) {
+                    const double Ukj = reg_get<MU>(kn[a], kv[a], kc[a], ln[c]);
+                    reg_add<ML>(ln, lv, dl, ln[c], -Lik * Dk * Ukj);
+                }
+            }
+            Di = Di - Lik * Dk * Uki;
+#pragma unroll
+            for (int c = 0; c < MU; ++c) {
+                if (c < du) {
+                    const double Ukj = reg_get<MU>(kn[a], kv[a], kc[a], un[c]);
+                    reg_add<MU>(un, uv, du, un[c], -Lik * Dk * Ukj);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MU; ++c) {
+        if (c < du) {
+            const double Uik = reg_get<MU>(un, uv, du, un[c]);
+            reg_set<MU>(un, uv, du, un[c], Uik / Di);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < ML; ++m)
+        if (m < dl) Lval[lb + m] = lv[m];
+#pragma unroll
+    for (int m = 0; m < MU; ++m)
+        if (m < du) Uval[ub + m] = uv[m];
+    D[i] = Di;
+}
+
 // values into the structures the applies read
 __global__ void k_grid_records(int64_t np, const int32_t *__restrict__ srcS, const int32_t *__restrict__ srcW,
                                const uint8_t *__restrict__ code, int order, const double *__restrict__ val, StripRec *__restrict__ rec)
@@ -1728,6 +1835,10 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
         if (fresh) {
             free_ildu(*S);
             SGM_TRY(ildu_pattern(S, P, own));
+            for (int32_t i = 0; i < n; ++i) {
+                S->maxL = std::max(S->maxL, S->hLptr[i + 1] - S->hLptr[i]);
+                S->maxU = std::max(S->maxU, S->hUptr[i + 1] - S->hUptr[i]);
+            }
             lap("pattern (device) + its host copy");
             // L's dependency levels: the order the rows are factorised in (and what its sweeps use later)
             SGM_TRY(tri_levels_dev(S->L, n, S->hLptr, S->hLnode, S->dLptr, S->dLnode, nullptr, true));
@@ -1746,6 +1857,13 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
                                S->dLval, (const int32_t *)S->dUptr, (const int32_t *)S->dUnode, S->dUval, S->D);
             for (size_t l = 0; l + 1 < S->L.level_ptr.size(); ++l) {
                 const int32_t b = S->L.level_ptr[l], e = S->L.level_ptr[l + 1];
+                static const bool no_short = getenv("SGM_ILDU_NO_SHORT") != nullptr;          // (tuning aid)
+                if (S->maxL <= 4 && S->maxU <= 4 && !no_short) {
+                    hipLaunchKernelGGL((k_ildu_factor_level_short<4, 4>), dim3((e - b + 63) / 64), dim3(64), 0, st,
+                                       (const int32_t *)S->L.order, b, e, (const int32_t *)S->dLptr, (const int32_t *)S->dLnode, S->dLval,
+                                       (const int32_t *)S->dUptr, (const int32_t *)S->dUnode, S->dUval, S->D);
+                    continue;
+                }
                 hipLaunchKernelGGL(k_ildu_factor_level, dim3((e - b + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
                                    (const int32_t *)S->L.order, b, e, (const int32_t *)S->dLptr, (const int32_t *)S->dLnode, S->dLval,
                                    (const int32_t *)S->dUptr, (const int32_t *)S->dUnode, S->dUval, S->D);

@@ -1241,6 +1241,72 @@ def test_preconditioners_golden_bit_exact(golden, name):
             assert np.array_equal(z, g[f"ref_s{s}_pcz"])
 
 
+@pytest.mark.parametrize("case", ["short_rows", "long_rows", "duplicates", "empty_rows", "no_diagonal"])
+def test_device_factorisation_statement_for_statement(orc, case):
+    """The ILDU(0) pattern pass and factorisation run on the device (k_ildu_split, k_ildu_init, k_ildu_factor_level /
+    _short): L, D, U and their index arrays against the oracle's statement-for-statement restatement, np.array_equal --
+    rows short enough for the register variant, rows that are not, repeated (i, j) entries (set_value / add_value write
+    EVERY match, get_value answers with the last), rows with no entries at all, a missing diagonal (D = 0: inf / nan
+    factors, the same ones), and a second setup after a value change."""
+    rs = np.random.RandomState(11)
+    if case == "short_rows":
+        n = 4000
+        i = np.repeat(np.arange(n), 3); j = np.clip(i + rs.choice([-40, -1, 1, 40], size=i.size), 0, n - 1)
+    elif case == "long_rows":
+        n = 3000
+        i = np.repeat(np.arange(n), 9); j = np.clip(i + rs.randint(-25, 26, size=i.size), 0, n - 1)
+    elif case == "duplicates":
+        n = 2500
+        i = np.repeat(np.arange(n), 4); j = np.clip(i + rs.choice([-3, -1, 1, 3], size=i.size), 0, n - 1)   # repeats on purpose
+    elif case == "empty_rows":
+        n = 2000
+        i = np.repeat(np.arange(n), 2); j = np.clip(i + rs.choice([-7, 7], size=i.size), 0, n - 1)
+        keep = (i % 5 != 0)
+        i, j = i[keep], j[keep]
+    else:
+        n = 1500
+        i = np.repeat(np.arange(n), 2); j = np.clip(i + rs.choice([-2, 2], size=i.size), 0, n - 1)
+    off = i != j
+    i, j = i[off], j[off]
+    if case != "duplicates":
+        key = np.unique(i.astype(np.int64) * n + j)
+        i, j = (key // n).astype(np.int64), (key % n).astype(np.int64)
+    v = rs.uniform(-1.0, -0.1, size=i.size)
+    rows = np.arange(n)
+    if case == "empty_rows":
+        rows = rows[rows % 5 != 0]
+    if case == "no_diagonal":
+        rows = rows[rows % 97 != 3]
+    # stored order: by row, the diagonal somewhere in the middle of the row (a stable sort keeps the duplicates' order)
+    ri = np.concatenate([i, rows]); rj = np.concatenate([j, rows]); rv = np.concatenate([v, np.full(rows.size, 6.0)])
+    o = np.lexsort((rs.rand(ri.size), ri))
+    ri, rj, rv = ri[o], rj[o], rv[o]
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(ri, minlength=n))]).astype(np.int32) + 1
+    A = orc.CsrMatrix(n, n, ptr, (rj + 1).astype(np.int32), rv)
+    ref = orc.Ildu(A)
+    H = hip_from_oracle(A)
+    pc = sg.ldu()
+    pc.setup(H)
+
+    def same_factors(ref):
+        for nm, dt, want in (("Lptr", np.int32, ref.Lptr), ("Lnode", np.int32, ref.Lnode), ("Uptr", np.int32, ref.Uptr),
+                             ("Unode", np.int32, ref.Unode)):
+            assert np.array_equal(pc.get(nm, dt), want), nm
+        for nm, want in (("Lval", ref.Lval), ("Uval", ref.Uval), ("D", ref.D)):
+            got = pc.get(nm, np.float64)
+            assert np.array_equal(got, want[:got.size], equal_nan=True), nm
+    same_factors(ref)
+    if case not in ("no_diagonal",):
+        b = P.test_vector(n)
+        z = np.zeros(n)
+        pc.solve(H, z, b)
+        assert np.array_equal(z, ref.solve(b), equal_nan=True)
+    H.set_values(rv * (1.0 + 0.25 * np.sin(np.arange(rv.size))))
+    pc.setup(H)
+    A2 = orc.CsrMatrix(n, n, ptr, (rj + 1).astype(np.int32), rv * (1.0 + 0.25 * np.sin(np.arange(rv.size))))
+    same_factors(orc.Ildu(A2))
+
+
 def test_ildu_apply_many_levels_vs_oracle(orc):
     """5-point grid 300x200: 499 dependency levels, wide and narrow level runs."""
     ptr, node, val = P.poisson2d_csr(300, 200)

@@ -18,6 +18,13 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_cg_
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ildu -- python tools/ildu_bench.py 1000 ildu0 > $OUT/stats_ildu.log 2>&1
 # ILDU(0)-PCG on the 100^3 grid: the slab-pipelined triangular solves
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ildu3 -- python tools/ildu_bench.py -100 ildu0 > $OUT/stats_ildu3.log 2>&1 < /dev/null
+# colour-ordered ILDU(0)-PCG at C2 size (row-space level sweeps): per-kernel times
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ildu_colour -- python tools/ildu_bench.py 3162 ildu0 colour > $OUT/stats_ildu_colour.log 2>&1 < /dev/null
+# time to solution: CG / Jacobi-PCG / ILDU(0)-PCG in natural and colour order, with the setup phases (SGM_PC_TIMING)
+for a in "1000 cg,jacobi,ildu0" "1000 cg,ildu0 colour" "3162 cg,ildu0" "3162 cg,ildu0 colour" "-100 cg,jacobi,ildu0" "-100 cg,ildu0 colour"; do
+  echo "== tools/ildu_bench.py $a"
+  SGM_PC_TIMING=1 timeout 600 python tools/ildu_bench.py $a 2>&1 | grep -E '^\{|ildu setup'
+done > $OUT/time_to_solution.log 2>&1
 # C3 GMRES(30): blocked CGS-2 vs modified Gram-Schmidt (launch counts per step come out of the Calls column)
 SGM_GMRES_CGS2=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_cgs2 -- python tools/bench_configs.py --configs c3 > $OUT/c3_cgs2.log 2>&1
 SGM_GMRES_CGS2=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_mgs -- python tools/bench_configs.py --configs c3 > $OUT/c3_mgs.log 2>&1
