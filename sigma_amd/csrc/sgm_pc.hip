@@ -918,6 +918,13 @@ __global__ void k_grid_map(int32_t n, const int32_t *__restrict__ posU, const in
     if (r < n) map[posU[r]] = posL[r];
 }
 
+__global__ void k_check_vector(int64_t n, double *__restrict__ r)       // the self-check's right-hand side
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) r[i] = 1.0 + 0.25 * (double)(i % 7) - 0.125 * (double)(i % 3);
+}
+
 // One sweep of ldu_solve checked row by row (setup self-check of the pipelined sweeps): row i of the result must be what
 // the reference's recurrence (ldu_solvers.f90:227-236, :254-263) makes of the right-hand side and of the RESULT's own
 // earlier rows -- t = rhs_i (/ D_i); t = t - val * x(node) over the row's entries in stored order -- bit for bit.  If
@@ -1925,8 +1932,6 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             // the pipelines hand data between workgroups inside one launch: before one is trusted with this pattern it
             // must reproduce the row-by-row sweeps of ldu_solve (ldu_solvers.f90:160-176, :208-265) bit for bit on a test
             // vector, and raise no abort.  Checked on the device, every row against the recurrence (k_sweep_check).
-            std::vector<double> rt((size_t)n);
-            for (int32_t i = 0; i < n; ++i) rt[i] = 1.0 + 0.25 * (i % 7) - 0.125 * (i % 3);
             double *dr = nullptr, *dz = nullptr, *dy = nullptr;
             int32_t *dbad = nullptr;
             struct Tmp { double *&a, *&b, *&c; int32_t *&d; ~Tmp() { dfree(a); dfree(b); dfree(c); dfree(d); } } tmp{dr, dz, dy, dbad};
@@ -1935,7 +1940,7 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             SGM_TRY(dalloc(&dy, (size_t)n));
             SGM_TRY(dalloc(&dbad, 1));
             hipStream_t st2 = g_rt.stream;
-            SGM_TRY(copy_big(dr, rt.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_check_vector, dim3(vec_grid(n)), dim3(kBlock), 0, st2, (int64_t)n, dr);
             (void)hipMemsetAsync(dz, 0, (size_t)n * 8, st2);
             (void)hipMemsetAsync(dy, 0, (size_t)n * 8, st2);
             (void)hipMemsetAsync(dbad, 0, 4, st2);
