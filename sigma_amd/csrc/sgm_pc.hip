@@ -1194,7 +1194,7 @@ int tri_levels_dev(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, co
             }
             if (cm <= 64) {
                 T.rows_on = true;
-                T.rc = std::max(cm, 1);
+                T.rc = cm <= 4 ? std::max(cm, 1) : cm <= 6 ? 6 : cm <= 8 ? 8 : cm;      // (the unrolled kernels read 6 / 8 slots)
                 SGM_TRY(dalloc(&T.rq, T.nstride * (size_t)T.rc));
                 SGM_TRY(dalloc(&T.rv, T.nstride * (size_t)T.rc));
                 SGM_HIP(hipMemsetAsync(T.rq, 0xff, T.nstride * (size_t)T.rc * 4, st));

@@ -1859,6 +1859,46 @@ def test_row_space_level_sweeps_of_colour_ordered_factors(orc, case):
     assert np.array_equal(z, orc.Ildu(B2).solve(x))
 
 
+@pytest.mark.parametrize("c", [1, 3, 5, 6, 7, 8, 9, 13])
+def test_row_space_sweeps_every_slot_count(orc, c):
+    """Three classes of m rows, every row of a class tied to exactly c rows of the class before: factors of three levels
+    with exactly c entries per row -- the row-space kernels unrolled for 1..4, 6 and 8 slots (5 and 7 read one padding
+    slot: the slot arrays are sized for what the kernel reads) and the slot loop beyond."""
+    m = 2100
+    n = 3 * m
+    r = np.arange(m)
+    ei, ej = [], []
+    for k in (1, 2):
+        for s in range(c):
+            a = k * m + r
+            b = (k - 1) * m + (r + 37 * s) % m
+            ei += [a, b]; ej += [b, a]
+    ei = np.concatenate(ei + [np.arange(n)]) + 1
+    ej = np.concatenate(ej + [np.arange(n)]) + 1
+    rs = np.random.RandomState(c)
+    ev = np.concatenate([-rs.uniform(0.1, 1.0, size=ei.size - n), np.full(n, 2.0 * c + 1.0)])
+    A = orc.CsrMatrix.from_edges(n, n, ei.astype(np.int32), ej.astype(np.int32), ev)
+    H = hip_from_oracle(A)
+    ref = orc.Ildu(A)
+    pc = sg.ldu()
+    pc.setup(H)
+    assert list(pc.get("levels", np.int32)) == [3, 3] and list(pc.get("row_levels", np.int32)) == [1, 3, 3]
+    lp = pc.get("Lptr", np.int32)
+    assert set(np.diff(lp)) == {0, c}
+    b = rs.standard_normal(n)
+    want = ref.solve(b)
+    z = np.zeros(n)
+    pc.solve(H, z, b)
+    assert np.array_equal(z, want)
+    sg.set_option("ildu_rows", 0)
+    try:
+        z0 = np.zeros(n)
+        pc.solve(H, z0, b)
+        assert np.array_equal(z0, want)
+    finally:
+        sg.set_option("ildu_rows", 1)
+
+
 def test_lean_footprint_and_on_demand_arrays(orc):
     """Option csr_lean (default on): a matrix served by the 4-bit sliced form keeps only that form + row pointers resident
     (<= 1.15 x what its kernel reads of the matrix); everything that needs the CSR-order arrays -- the other kernels,
