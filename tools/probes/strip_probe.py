@@ -7,7 +7,10 @@ import sigma_amd as sg
 from sigma_amd import problems as P
 sg.init(0)
 dev = torch.device("cuda", 0)
-for nx, ny in ((64, 16000), (128, 16000), (256, 16000), (1024, 4000)):
+CASES = ((64, 16000), (128, 16000), (256, 16000), (1024, 4000))
+if len(sys.argv) > 1:
+    CASES = CASES[:int(sys.argv[1])]
+for nx, ny in CASES:
     n = nx * ny
     ptr, node, val = P.poisson2d_csr(nx, ny)
     A = sg.csr_matrix(n, n, ptr, node, val)
