@@ -73,6 +73,7 @@ def parse_args():
                     help="take the RCCL row-partition code path even with one rank (testing aid)")
     ap.add_argument("--halo-comm", action="store_true",
                     help="N > 1: a second RCCL communicator for the halo send/recv pairs (A/B switch for halo / all-reduce overlap)")
+    ap.add_argument("--no-pcg", action="store_true", help="N = 1: skip the `pcg_time_to_solution` leg (CG vs ILDU(0)-PCG, 1000^2 grid)")
     ap.add_argument("--no-dist-overhead", action="store_true",
                     help="N = 1: skip the `dist_overhead_1rank` leg (CG through the RCCL code path with one rank)")
     return ap.parse_args()
@@ -425,6 +426,11 @@ def worker(args):
     if rank == 0 and world == 1 and not args.no_cpu:
         c1 = c1_leg(sg, P, torch, dev)
 
+    # ---- preconditioned solves, time to solution on the 1000^2 grid (setup + solve): CG, ILDU(0)-PCG in natural and colour order ----
+    pcg = None
+    if rank == 0 and world == 1 and not args.no_pcg:
+        pcg = pcg_leg(sg, P, torch, dev)
+
     kernel_sha = csrc_sha1()
     A.destroy()
     del x, y
@@ -507,7 +513,7 @@ def worker(args):
                          "note": "achieved = moved_bytes_per_launch / avg_launch_ms: the sliced kernel reads 8W+4 bytes per "
                                  "row of its own layout (W = 5) + x once + y once.  cold_* = the same launch after 512 MiB "
                                  "of unrelated writes (nothing of the previous product left in L2 / Infinity Cache)"},
-            "spmv_variants": variants or None, "cg": cg, "dist_overhead_1rank": dist_overhead, "c5_strong_scaling": c5, "c1_reference_sized": c1, "cpu_baseline": cpu,
+            "spmv_variants": variants or None, "cg": cg, "dist_overhead_1rank": dist_overhead, "c5_strong_scaling": c5, "c1_reference_sized": c1, "pcg_time_to_solution": pcg, "cpu_baseline": cpu,
             "selfcheck": {"product_bit_exact_on_every_rank": check_main,
                           "what": "every local row of one timed-workload product == its sum evaluated with torch in stored "
                                   "order from x(i) = sin(0.001 i), on every rank (halo values included)"},
@@ -600,6 +606,71 @@ def cpu_baseline(args, host, n_loc):
         ref["port_on_same_matrix"] = port
         return ref
     return port
+
+
+def pcg_leg(sg, P, torch, dev, nx=1000, tol=1e-8):
+    """5-point grid nx^2, b = A * (a smooth vector), from u = 0 to an absolute `tol`: plain CG, ILDU(0)-PCG on the matrix as it
+    is (strip-pipelined triangular sweeps) and after the reference's greedy_color_ordering + left/right permutation
+    (two-level factors: row-space sweeps).  Setup (pattern, factorisation, index work: on the device) and solve timed
+    separately, second solve of two."""
+    import numpy as np
+    n = nx * nx
+    ptr, node, val = P.poisson2d_csr(nx, nx)
+    xs = np.sin(np.arange(n) * 1e-3) + 1.0
+
+    def solve(A, b, pc):
+        s = sg.cg(tol)
+        s.setup(A)
+        u = torch.zeros(n, dtype=torch.float64, device=dev)
+        s.solve(A, u, b, pc)
+        torch.cuda.synchronize()
+        u.zero_()
+        t0 = time.perf_counter()
+        s.solve(A, u, b, pc)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, int(s.last_iterations), u
+
+    out = {"workload": f"5-point {nx}x{nx} grid (n={n}), CG from 0 to an absolute {tol:g}; seconds"}
+    A = sg.csr_matrix(n, n, ptr, node, val)
+    bh = np.zeros(n)
+    A.matvec(xs, bh)
+    b = torch.from_numpy(bh).to(dev)
+    t, it, u = solve(A, b, None)
+    out["cg"] = {"setup_s": 0.0, "solve_s": t, "iterations": it}
+    err_cg = float(np.abs(u.cpu().numpy() - xs).max())
+    t0 = time.perf_counter()
+    pc = sg.ldu()
+    pc.setup(A)
+    sg.synchronize()
+    ts = time.perf_counter() - t0
+    t, it, u = solve(A, b, pc)
+    out["ildu0_natural_order"] = {"setup_s": ts, "solve_s": t, "iterations": it, "triangular_sweeps": "strip pipeline" if pc.get("strips", np.int32)[0] else "level walkers"}
+    pc.destroy()
+    t0 = time.perf_counter()
+    p, _ptrs, nc = A.greedy_color_ordering()
+    t1 = time.perf_counter()
+    A.left_permute(p)
+    A.right_permute(p)
+    sg.synchronize()
+    t2 = time.perf_counter()
+    bp = np.empty(n)
+    bp[p - 1] = bh
+    b = torch.from_numpy(bp).to(dev)
+    t0s = time.perf_counter()
+    pc = sg.ldu()
+    pc.setup(A)
+    sg.synchronize()
+    ts = time.perf_counter() - t0s
+    t, it, u = solve(A, b, pc)
+    xp = np.empty(n)
+    xp[p - 1] = xs
+    out["ildu0_colour_order"] = {"ordering_s": t1 - t0, "permutation_s": t2 - t1, "colours": int(nc), "setup_s": ts, "solve_s": t, "iterations": it,
+                                 "row_space_levels": [int(v) for v in pc.get("row_levels", np.int32)],
+                                 "max_err_vs_the_vector_b_was_made_from": float(np.abs(u.cpu().numpy() - xp).max())}
+    out["cg"]["max_err_vs_the_vector_b_was_made_from"] = err_cg
+    pc.destroy()
+    A.destroy()
+    return out
 
 
 def c1_leg(sg, P, torch, dev, n=10000, tol=1e-16):

@@ -4,9 +4,13 @@
 // Jacobi: idiag(i) = 1/A(i,i) is extracted on the device by a row scan (the reference
 // calls A%get_value(i,i) per row, cs_matrices.f90:709-724); apply is one elementwise pass.
 //
-// ILDU(0): the factorisation runs once on the HOST (the reference's algorithm is a
-// sequential IKJ sweep built on get/set/add_value row scans; it is setup, not the hot
-// path) and keeps the reference's arithmetic order, so L-I, D, U-I are bit-identical.
+// ILDU(0): pattern pass and factorisation run on the DEVICE (k_ildu_count / _split / _init /
+// _factor_level): the reference's algorithm is a sequential IKJ sweep built on
+// get/set/add_value row scans; row i only reads rows k < i of its L pattern, so the rows of
+// one dependency level of L run side by side, each lane executing its row's statements in
+// the reference's order -- L-I, D, U-I are bit-identical.  Everything the applies read is
+// filled from the device factors by kernels; the host keeps the level computation, the
+// grid / slab detection and lazy copies for sgm_pc_get.
 // The APPLY is the hot part: x=b ; (I+L)^-1 ; x/D ; (I+U)^-1, each triangular solve a
 // row recurrence (ldu_solvers.f90:227-236).  Rows are grouped into dependency LEVELS at
 // setup; rows of one level are independent, each lane does its row's
@@ -17,7 +21,9 @@
 // dependencies are positions.  Wide levels get one launch each; runs of narrow levels
 // (<= 4096 rows) are walked by ONE 1024-thread workgroup that keeps the last 8192 results in
 // an LDS ring: a level then costs LDS reads + a barrier instead of four dependent global
-// round trips (3.9 us -> see DESIGN.md).
+// round trips (3.9 us -> see DESIGN.md).  Grid-like factors take the strip / slab pipelines
+// (k_trsv_strip, sgm_trsv3.hip), factors of a few levels (colour orderings) the row-space
+// sweeps (k_trsv_rows): no position space at all.
 #include <hipcub/hipcub.hpp>
 #include "sgm_internal.hpp"
 

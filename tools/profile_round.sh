@@ -5,13 +5,13 @@ cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_round
 rm -rf $OUT; mkdir -p $OUT
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo bench=$?
-BARGS="--steps 2 --warmup 1 --spmv-per-step 64 --cg-steps 30 --no-cpu --no-c5 --no-dist-overhead"
+BARGS="--steps 2 --warmup 1 --spmv-per-step 64 --cg-steps 30 --no-cpu --no-c5 --no-dist-overhead --no-pcg"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py $BARGS > $OUT/stats.log 2>&1
-PARGS="--steps 1 --warmup 1 --spmv-per-step 4 --cg-steps 0 --no-cpu --no-c5 --no-variants --no-dist-overhead"
+PARGS="--steps 1 --warmup 1 --spmv-per-step 4 --cg-steps 0 --no-cpu --no-c5 --no-variants --no-dist-overhead --no-pcg"
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python bench.py $PARGS > $OUT/pmc1.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python bench.py $PARGS > $OUT/pmc2.log 2>&1
 # HBM bytes of the CG update kernels (k_elem<FCgR / FCgPX>) and of the C5 product (k_csr_sl<7>, 464^3): their own PMC passes
-QARGS="--steps 1 --warmup 1 --spmv-per-step 2 --cg-steps 10 --c5-cg-steps 4 --no-cpu --no-variants --no-dist-overhead"
+QARGS="--steps 1 --warmup 1 --spmv-per-step 2 --cg-steps 10 --c5-cg-steps 4 --no-cpu --no-variants --no-dist-overhead --no-pcg"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_cg_c5 -- python bench.py $QARGS > $OUT/pmc3.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_cg_c5 -- python bench.py $QARGS > $OUT/pmc4.log 2>&1
 # ILDU(0)-PCG on the 1000^2 grid: per-kernel times of the triangular solves
