@@ -90,7 +90,10 @@ int sgm_synchronize(void);
  * "ildu_rows" (default 1): ILDU(0) factors of at most 32 levels (what greedy_color_ordering makes of a matrix: one level
  * per colour) are swept in row space -- one launch per level on the vectors themselves, D folded
  * into the U sweep, no gather / re-order / scatter around them (sgm_pc_get "row_levels" = {in use, launches of the L sweep,
- * of the U sweep}); 0 = the level-order walkers.  Same bits either way.
+ * of the U sweep}); 0 = the level-order walkers.  With 1 two launches are saved: L's first level, when it is the run of rows
+ * 0 .. n0-1 without entries (the first colour), is never copied -- whoever wants y(q), q < n0, reads r(q) -- and the level that
+ * is both L's last and U's first (the last colour) is finished inside the L sweep; 2 = row space with every level launched.
+ * Same bits whichever.
  * "gmres_cgs2" (default 1): GMRES orthogonalises with blocked classical Gram-Schmidt applied twice (three
  * passes and three all-reduces per step); 0 = modified Gram-Schmidt.
  * "cg_small" (default 1): CG (plain or Jacobi-preconditioned) on a single-GPU CSR matrix of at most

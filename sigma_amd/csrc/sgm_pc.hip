@@ -150,6 +150,10 @@ struct IlduState {
     // the level-scheduled structures are built on first need when a pipelined path serves the pattern
     bool levels_ready = false, levels_pattern = false;
     bool walk_ready = false, walk_pattern = false;          // the same for the level walkers' structures (ensure_walkers)
+    // row-space sweeps (apply_rows): L's level 0 is the entry-less run of rows 0 .. rows_n0-1 (0: it is not); L's last level
+    // and U's level 0 are the same entry-less run of rows
+    int32_t rows_n0 = 0;
+    bool rows_fin = false;
 };
 
 struct sgm_pc_s {
@@ -300,17 +304,23 @@ __global__ void k_trsv_wide_soa(const int32_t *__restrict__ wq, const double *__
 // work vector, the U sweep divides by D as it picks its right-hand side up and writes z.  C = slots read (the most
 // entries of a row of the level; -1: `rc` of them in a loop).  Same operations in the same order as k_trsv_wide_soa
 // after k_perm_gather / k_lu_transition, so the same bits.
-template <int C, bool DIV>
+// MODE 0: a level of the L sweep, y_i = r_i - sum val * y(node); MODE 1: the same for a level whose rows have no U entries
+// at all (U's level 0 -- with a colour ordering: the last colour), finished on the spot: z_i = y_i / D_i, y_i is never
+// stored; MODE 2: a level of the U sweep, z_i = y_i / D_i - sum val * z(node).  Rows below n0 are L's level 0 when that is
+// the run of rows 0 .. n0-1 (the first colour): their y IS r, so nobody copies it -- whoever wants y(q), q < n0, reads r(q).
+template <int C, int MODE>
 __global__ void k_trsv_rows(const int32_t *__restrict__ rq, const double *__restrict__ rv, uint32_t nstride, int rc,
-                            const int32_t *__restrict__ order, int32_t row0, int32_t begin, int32_t end, const double *src,
-                            const double *__restrict__ D, double *out, const int *flag)
+                            const int32_t *__restrict__ order, int32_t row0, int32_t begin, int32_t end, const double *r,
+                            double *y, const double *__restrict__ D, double *z, int32_t n0, const int *flag)
 {
     if (flag && *flag) return;
     const int32_t p = begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= end) return;
     const int32_t i = row0 >= 0 ? row0 + (p - begin) : order[p];
-    double z = src[i];
-    if (DIV) z = z / D[i];
+    double t;
+    if (MODE == 2) t = (i < n0 ? r[i] : y[i]) / D[i];
+    else t = r[i];
+    auto dep = [&](int32_t q) -> double { return MODE == 2 ? z[q] : (q < n0 ? r[q] : y[q]); };
     if (C >= 0) {
         int32_t q[C > 0 ? C : 1];
         double v[C > 0 ? C : 1];
@@ -321,15 +331,17 @@ __global__ void k_trsv_rows(const int32_t *__restrict__ rq, const double *__rest
         }
 #pragma unroll
         for (int c = 0; c < C; ++c)
-            if (q[c] >= 0) z = z - v[c] * out[q[c]];
+            if (q[c] >= 0) t = t - v[c] * dep(q[c]);
     } else {
         for (int c = 0; c < rc; ++c) {
             const int32_t q = rq[(size_t)c * nstride + p];
             if (q < 0) break;                              // (a row's entries fill its first slots)
-            z = z - rv[(size_t)c * nstride + p] * out[q];
+            t = t - rv[(size_t)c * nstride + p] * dep(q);
         }
     }
-    out[i] = z;
+    if (MODE == 0) y[i] = t;
+    else if (MODE == 1) z[i] = t / D[i];
+    else z[i] = t;
 }
 
 // a run of narrow levels [l0, l1) walked by ONE workgroup.  The row records and right-hand
@@ -1471,6 +1483,13 @@ int ensure_levels(IlduState *S)
         S->xpL = nullptr;
         SGM_TRY(dalloc(&S->xpL, (size_t)n + kNarrow));     // + scratch slots of the level walker
     }
+    S->rows_n0 = 0;
+    S->rows_fin = false;
+    if (S->L.rows_on && S->U.rows_on && !S->L.row_levels.empty() && !S->U.row_levels.empty()) {
+        const auto &l0 = S->L.row_levels.front(), &ll = S->L.row_levels.back(), &u0 = S->U.row_levels.front();
+        if (l0.c == 0 && l0.row0 == 0) S->rows_n0 = l0.e - l0.b;
+        S->rows_fin = S->L.row_levels.size() >= 2 && u0.c == 0 && u0.row0 >= 0 && u0.row0 == ll.row0 && u0.e - u0.b == ll.e - ll.b;
+    }
     S->levels_pattern = true;
     S->levels_ready = true;
     return SGM_OK;
@@ -1537,36 +1556,44 @@ void apply_levels(const IlduState *S, const double *r, double *z, const int *fla
 
 // the same through the row-space levels (both factors a few wide levels): one launch per level, nothing else
 bool rows_serve(const IlduState *S) { return g_opt.ildu_rows && S->levels_ready && S->L.rows_on && S->U.rows_on; }
-void sweep_rows(const TriFactor &T, const double *src, const double *D, double *out, const int *flag, bool div)
+void launch_rows(const TriFactor &T, const TriFactor::RowLevel &L, int mode, const double *r, double *y, const double *D, double *z,
+                 int32_t n0, const int *flag)
 {
     hipStream_t st = g_rt.stream;
-    for (const auto &L : T.row_levels) {
-        const int32_t b = L.b, e = L.e;
-        const dim3 g((e - b + kBlock - 1) / kBlock);
-#define ROWS(CC)                                                                                                              \
+    const int32_t b = L.b, e = L.e;
+    const dim3 g((e - b + kBlock - 1) / kBlock);
+#define ROWS_M(CC, MM)                                                                                                         \
+    hipLaunchKernelGGL((k_trsv_rows<CC, MM>), g, dim3(kBlock), 0, st, (const int32_t *)T.rq, (const double *)T.rv, (uint32_t)T.nstride, \
+                       T.rc, (const int32_t *)T.order, L.row0, b, e, r, y, D, z, n0, flag)
+#define ROWS(CC)                                                                                                               \
     do {                                                                                                                      \
-        if (div) hipLaunchKernelGGL((k_trsv_rows<CC, true>), g, dim3(kBlock), 0, st, (const int32_t *)T.rq, (const double *)T.rv, \
-                                    (uint32_t)T.nstride, T.rc, (const int32_t *)T.order, L.row0, b, e, src, D, out, flag);     \
-        else hipLaunchKernelGGL((k_trsv_rows<CC, false>), g, dim3(kBlock), 0, st, (const int32_t *)T.rq, (const double *)T.rv, \
-                                (uint32_t)T.nstride, T.rc, (const int32_t *)T.order, L.row0, b, e, src, D, out, flag);         \
+        if (mode == 0) ROWS_M(CC, 0); else if (mode == 1) ROWS_M(CC, 1); else ROWS_M(CC, 2);                                    \
     } while (0)
-        switch (L.c) {
-        case 0: ROWS(0); break;
-        case 1: ROWS(1); break;
-        case 2: ROWS(2); break;
-        case 3: ROWS(3); break;
-        case 4: ROWS(4); break;
-        case 5: case 6: ROWS(6); break;
-        case 7: case 8: ROWS(8); break;
-        default: ROWS(-1); break;
-        }
-#undef ROWS
+    switch (L.c) {
+    case 0: ROWS(0); break;
+    case 1: ROWS(1); break;
+    case 2: ROWS(2); break;
+    case 3: ROWS(3); break;
+    case 4: ROWS(4); break;
+    case 5: case 6: ROWS(6); break;
+    case 7: case 8: ROWS(8); break;
+    default: ROWS(-1); break;
     }
+#undef ROWS
+#undef ROWS_M
 }
+// (fused: ildu_rows = 1 -- L's first level, when it is rows 0 .. n0-1 without entries, is not copied; the L level that is
+// also U's level 0 is finished in the L sweep.  ildu_rows = 2 launches every level of both sweeps.)
 void apply_rows(const IlduState *S, const double *r, double *z, const int *flag)
 {
-    sweep_rows(S->L, r, nullptr, S->xpL, flag, false);                    // (I+L) y = r
-    sweep_rows(S->U, S->xpL, S->D, z, flag, true);                        // (I+U) z = y / D
+    const auto &Ls = S->L.row_levels, &Us = S->U.row_levels;
+    const bool fused = g_opt.ildu_rows == 1;
+    const int32_t n0 = fused ? S->rows_n0 : 0;
+    const bool fin = fused && S->rows_fin;
+    for (size_t k = n0 > 0 ? 1 : 0; k < Ls.size(); ++k)                    // (I+L) y = r
+        launch_rows(S->L, Ls[k], fin && k + 1 == Ls.size() ? 1 : 0, r, S->xpL, S->D, z, n0, flag);
+    for (size_t k = fin ? 1 : 0; k < Us.size(); ++k)                       // (I+U) z = y / D
+        launch_rows(S->U, Us[k], 2, r, S->xpL, S->D, z, n0, flag);
 }
 
 // triangular solve in position space: xp holds the right-hand side on entry, the solution on exit
@@ -2098,7 +2125,10 @@ int sgm_pc_get(sgm_pc pc, const char *name, void *out, size_t bytes, size_t *nee
         else if (nm == "row_levels") {           // row-space level path in use: {1, launches of the L sweep, of the U sweep}; zeros = off
             static int32_t rl[3];
             const bool on = !(g_opt.ildu_strips && (S->grid_ok || S->slab_ok)) && rows_serve(S);
-            rl[0] = on; rl[1] = on ? (int32_t)S->L.row_levels.size() : 0; rl[2] = on ? (int32_t)S->U.row_levels.size() : 0;
+            const bool fu = g_opt.ildu_rows == 1;
+            rl[0] = on;
+            rl[1] = on ? (int32_t)S->L.row_levels.size() - (fu && S->rows_n0 > 0 ? 1 : 0) : 0;
+            rl[2] = on ? (int32_t)S->U.row_levels.size() - (fu && S->rows_fin ? 1 : 0) : 0;
             src = rl; sz = sizeof rl;
         }
         else if (nm == "levels") {

@@ -62,7 +62,7 @@ def check(tag, A, H, bad):
             bad.append((tag, nm)); return
     b = np.random.RandomState(A.n).standard_normal(A.n)
     want = ref.solve(b)
-    for rows_on, strips_on in ((1, 1), (0, 1), (1, 0), (0, 0)):
+    for rows_on, strips_on in ((1, 1), (0, 1), (1, 0), (2, 0), (0, 0)):
         sg.set_option("ildu_rows", rows_on); sg.set_option("ildu_strips", strips_on)
         if os.environ.get("STRESS_TRACE"):
             print("    apply", rows_on, strips_on, flush=True); sg.synchronize()
