@@ -139,6 +139,7 @@ struct IlduState {
     std::vector<double> hLval, hUval, hD;
     bool host_vals = false;
     int32_t maxL = 0, maxU = 0;                              // longest row of each factor
+    int32_t nnzL = 0, nnzU = 0;
     // strip-pipeline path (both factors grid-like, see GridTri): results in position space and the L -> U hand-over
     GridTri gL, gU;
     double *gxL = nullptr, *gxU = nullptr, *gDp = nullptr;
@@ -809,7 +810,7 @@ __device__ inline void row_add(const int32_t *node, double *val, int32_t b, int3
 // j > i -> U.  Two passes over the rows of the part's diagonal block (columns >= ncol_own are halo slots: dropped):
 // counts (an exclusive scan between the launches makes the row pointers), fill.
 __global__ void k_ildu_count(int32_t n, int32_t ncol_own, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                             int32_t *__restrict__ lcnt, int32_t *__restrict__ ucnt)
+                             int32_t *__restrict__ lcnt, int32_t *__restrict__ ucnt, int32_t *longest)
 {
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n) return;
@@ -823,6 +824,8 @@ __global__ void k_ildu_count(int32_t n, int32_t ncol_own, const int32_t *__restr
         }
     lcnt[i] = l;                 // (slot n: 0 -- the scan's total lands there)
     ucnt[i] = u;
+    if (l) atomicMax(longest, l);
+    if (u) atomicMax(longest + 1, u);
 }
 __global__ void k_ildu_split(int32_t n, int32_t ncol_own, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                              const int32_t *__restrict__ Lptr, int32_t *__restrict__ Lnode,
@@ -836,6 +839,61 @@ __global__ void k_ildu_split(int32_t n, int32_t ncol_own, const int32_t *__restr
         if (j >= ncol_own) continue;
         if (j < i) Lnode[l++] = j;
         else if (j > i) Unode[u++] = j;
+    }
+}
+
+// Dependency levels of a strictly triangular pattern on the device, for factors of a FEW levels (colour orderings):
+// level(i) = 1 + max level(node) over the row's entries, relaxed in place until nothing moves (<= levels sweeps; values
+// only grow and never pass the true level).  flags[0]: something moved; flags[1]: a level reached `cap` -- too many
+// levels for this path, the host computes them.
+__global__ void k_level_relax(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ node, int32_t *level,
+                              int32_t cap, int32_t *flags)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t lv = 0;
+    for (int32_t k = ptr[i]; k < ptr[i + 1]; ++k) lv = max(lv, level[node[k]] + 1);
+    if (lv != level[i]) {
+        level[i] = lv;
+        flags[0] = 1;
+        if (lv >= cap) flags[1] = 1;
+    }
+}
+// (a handful of levels: the counts are gathered per workgroup in LDS first -- millions of atomics on two addresses crawl)
+__global__ void k_level_hist(int32_t n, const int32_t *__restrict__ level, int32_t *__restrict__ count, int32_t *__restrict__ rows)
+{
+    __shared__ int32_t h[kRowLevels + 2];
+    for (int q = threadIdx.x; q < kRowLevels + 2; q += blockDim.x) h[q] = 0;
+    __syncthreads();
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        atomicAdd(&h[level[i]], 1);
+        rows[i] = i;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < kRowLevels + 2; q += blockDim.x)
+        if (h[q]) atomicAdd(count + q, h[q]);
+}
+// per level (positions [begin[l], begin[l+1]) of the level order): most entries of a row, whether its rows are consecutive,
+// its first row
+__global__ void k_level_info(int32_t n, const int32_t *__restrict__ order, const int32_t *__restrict__ level,
+                             const int32_t *__restrict__ ptr, const int32_t *__restrict__ begin, int32_t *cmax, int32_t *notrun,
+                             int32_t *first)
+{
+    __shared__ int32_t m[kRowLevels + 2], nr[kRowLevels + 2];
+    for (int q = threadIdx.x; q < kRowLevels + 2; q += blockDim.x) { m[q] = 0; nr[q] = 0; }
+    __syncthreads();
+    const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) {
+        const int32_t i = order[p], l = level[i];
+        atomicMax(&m[l], ptr[i + 1] - ptr[i]);
+        if (p == begin[l]) first[l] = i;
+        else if (order[p - 1] + 1 != i) nr[l] = 1;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < kRowLevels + 2; q += blockDim.x) {
+        if (m[q]) atomicMax(cmax + q, m[q]);
+        if (nr[q]) notrun[q] = 1;
     }
 }
 
@@ -1175,10 +1233,104 @@ void free_tri(TriFactor &T)
     T = TriFactor();
 }
 
+// The same index work entirely on the device, for a factor of at most kRowLevels levels (what a colour ordering leaves):
+// levels by relaxation, the level order by a stable radix sort of the row numbers on their levels, per-level facts by
+// one more pass.  *served = false (and T untouched) when the factor has more levels than that or rows too long for the
+// row-space copy: the host pass (tri_levels_dev) then does it from the pattern's host copy.  No host copy of the pattern
+// is needed here; T.h_order / T.h_pos stay empty until the level walkers want them (tri_host_order).
+int tri_levels_device(TriFactor &T, int32_t n, const int32_t *dptr, const int32_t *dnode, bool *served)
+{
+    *served = false;
+    if (T.have_levels) { *served = T.rows_on; return SGM_OK; }
+    if (n < 1 || (size_t)n + kNarrow >= (size_t)500000000) return SGM_OK;
+    hipStream_t st = g_rt.stream;
+    int32_t *level = nullptr, *small = nullptr, *rows = nullptr, *order = nullptr, *keys = nullptr;
+    void *tmp = nullptr;
+    struct Tmp { int32_t *&a, *&b, *&c, *&d, *&e; void *&t; ~Tmp() { dfree(a); dfree(b); dfree(c); dfree(d); dfree(e); if (t) (void)hipFree(t); } }
+        guard{level, small, rows, order, keys, tmp};
+    SGM_TRY(dalloc(&level, (size_t)n));
+    SGM_TRY(dalloc(&small, (size_t)2 + 5 * (kRowLevels + 2)));      // flags[2] | count | begin | cmax | notrun | first
+    SGM_HIP(hipMemsetAsync(level, 0, (size_t)n * 4, st));
+    int32_t *flags = small;                              // [2]
+    const int grid = (n + kBlock - 1) / kBlock;
+    bool done = false;
+    for (int it = 0; it <= kRowLevels + 1 && !done; ++it) {
+        int32_t hf[2] = {0, 0};
+        SGM_HIP(hipMemsetAsync(flags, 0, 8, st));
+        hipLaunchKernelGGL(k_level_relax, dim3(grid), dim3(kBlock), 0, st, n, dptr, dnode, level, (int32_t)kRowLevels, flags);
+        SGM_HIP(hipMemcpyAsync(hf, flags, 8, hipMemcpyDeviceToHost, st));
+        SGM_HIP(hipStreamSynchronize(st));
+        if (hf[1]) return SGM_OK;                        // too many levels for this path
+        done = !hf[0];
+    }
+    if (!done) return SGM_OK;
+    // histogram -> level_ptr; stable sort of 0 .. n-1 on the levels -> level order (rows of a level ascending)
+    int32_t *count = small + 2, *begin = count + kRowLevels + 2, *cmax = begin + kRowLevels + 2, *notrun = cmax + kRowLevels + 2,
+            *first = notrun + kRowLevels + 2;
+    SGM_HIP(hipMemsetAsync(count, 0, (size_t)5 * (kRowLevels + 2) * 4, st));
+    SGM_TRY(dalloc(&rows, (size_t)n));
+    SGM_TRY(dalloc(&order, (size_t)n));
+    SGM_TRY(dalloc(&keys, (size_t)n));
+    hipLaunchKernelGGL(k_level_hist, dim3(grid), dim3(kBlock), 0, st, n, (const int32_t *)level, count, rows);
+    int32_t hcount[kRowLevels + 2];
+    SGM_HIP(hipMemcpyAsync(hcount, count, sizeof hcount, hipMemcpyDeviceToHost, st));
+    size_t tb = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const int32_t *)level, keys, (const int32_t *)rows, order, n, 0, 6, st);
+    SGM_HIP(hipMalloc(&tmp, std::max<size_t>(tb, 16)));
+    SGM_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, (const int32_t *)level, keys, (const int32_t *)rows, order, n, 0, 6, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    int32_t nlev = 0;
+    for (int l = 0; l < kRowLevels + 2; ++l) if (hcount[l]) nlev = l + 1;
+    if (nlev < 1 || nlev > kRowLevels) return SGM_OK;
+    std::vector<int32_t> lp((size_t)nlev + 1, 0);
+    for (int l = 0; l < nlev; ++l) lp[l + 1] = lp[l] + hcount[l];
+    SGM_HIP(hipMemcpyAsync(begin, lp.data(), (size_t)(nlev + 1) * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_level_info, dim3(grid), dim3(kBlock), 0, st, n, (const int32_t *)order, (const int32_t *)level, dptr,
+                       (const int32_t *)begin, cmax, notrun, first);
+    int32_t hinfo[3 * (kRowLevels + 2)];
+    SGM_HIP(hipMemcpyAsync(hinfo, cmax, sizeof hinfo, hipMemcpyDeviceToHost, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    const int32_t *hc = hinfo, *hn = hinfo + kRowLevels + 2, *hfst = hinfo + 2 * (kRowLevels + 2);
+    int cm = 0;
+    for (int l = 0; l < nlev; ++l) cm = std::max(cm, hc[l]);
+    if (cm > 64) return SGM_OK;
+    // commit
+    free_tri(T);
+    T.level_ptr = lp;
+    T.nstride = (size_t)n + kNarrow;
+    T.order = order; order = nullptr;                    // (the sorted row numbers ARE the level order)
+    SGM_TRY(dalloc(&T.level_ptr_dev, T.level_ptr.size()));
+    SGM_HIP(hipMemcpy(T.level_ptr_dev, T.level_ptr.data(), T.level_ptr.size() * 4, hipMemcpyHostToDevice));
+    for (int l = 0; l < nlev; ++l) T.row_levels.push_back({lp[l], lp[l + 1], hc[l], hn[l] ? -1 : hfst[l]});
+    T.rows_on = true;
+    T.rc = cm <= 4 ? std::max(cm, 1) : cm <= 6 ? 6 : cm <= 8 ? 8 : cm;      // (the unrolled kernels read 6 / 8 slots)
+    SGM_TRY(dalloc(&T.rq, T.nstride * (size_t)T.rc));
+    SGM_TRY(dalloc(&T.rv, T.nstride * (size_t)T.rc));
+    SGM_HIP(hipMemsetAsync(T.rq, 0xff, T.nstride * (size_t)T.rc * 4, st));
+    SGM_HIP(hipMemsetAsync(T.rv, 0, T.nstride * (size_t)T.rc * 8, st));
+    hipLaunchKernelGGL(k_rows_index, dim3(grid), dim3(kBlock), 0, st, n, (const int32_t *)T.order, dptr, dnode, (uint32_t)T.nstride, T.rc, T.rq);
+    SGM_HIP(hipGetLastError());
+    T.have_levels = true;
+    *served = true;
+    return SGM_OK;
+}
+// host copies of the level order for what still reads them (the level walkers' index work)
+int tri_host_order(TriFactor &T, int32_t n)
+{
+    if (!T.h_order.empty() || n < 1) return SGM_OK;
+    SGM_HIP(hipStreamSynchronize(g_rt.stream));
+    T.h_order.resize((size_t)n);
+    T.h_pos.resize((size_t)n);
+    SGM_TRY(copy_big(T.h_order.data(), T.order, (size_t)n * 4, hipMemcpyDeviceToHost));
+    for (int32_t p2 = 0; p2 < n; ++p2) T.h_pos[T.h_order[p2]] = p2;
+    return SGM_OK;
+}
+
 // Dependency levels of a strictly triangular factor and, for one of at most kRowLevels levels, its row-space copy.
 // lower: rows depend on smaller rows (forward sweep 1..n); upper: on larger rows (backward sweep n..1).  ptr1 / node1:
 // the pattern on the host (1-based); dptr / dnode / dval: the factor on the device (0-based, values in pattern order;
 // dval null: index work only).
+// (ptr1 / node1 may be EMPTY when the device pass is known to have served this factor: tri_levels_device below)
 int tri_levels_dev(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const std::vector<int32_t> &node1,
                    const int32_t *dptr, const int32_t *dnode, const double *dval, bool lower)
 {
@@ -1236,6 +1388,7 @@ int tri_walkers(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const
 {
     const size_t nnz = node1.size();
     if (!T.have_walkers) {
+        SGM_TRY(tri_host_order(T, n));
         dfree(T.recs); dfree(T.pq); dfree(T.pv); dfree(T.dq); dfree(T.dq32); dfree(T.dv); dfree(T.wq); dfree(T.src);
         T.recs = nullptr; T.pq = nullptr; T.pv = nullptr; T.dq = nullptr; T.dq32 = nullptr; T.dv = nullptr; T.wq = nullptr; T.src = nullptr;
         T.schedule.clear();
@@ -1471,11 +1624,17 @@ void apply_grid(const IlduState *S, const double *r, double *z, const int *flag,
 // Dependency levels of both factors, their row-space copies when they have few levels (index work when the pattern is
 // new, values always) and the work vector of the row-space sweeps.  At setup when no pipelined path serves the pattern,
 // otherwise on first need.
+int ensure_host_pattern(IlduState *S);
 int ensure_levels(IlduState *S)
 {
     if (S->levels_ready) return SGM_OK;
     const int32_t n = S->n;
     const bool fresh = !S->levels_pattern;
+    // factors of a few levels: all index work on the device; otherwise from the pattern's host copy
+    bool ls = false, us = false;
+    SGM_TRY(tri_levels_device(S->L, n, S->dLptr, S->dLnode, &ls));
+    SGM_TRY(tri_levels_device(S->U, n, S->dUptr, S->dUnode, &us));
+    if (!S->L.have_levels || !S->U.have_levels) SGM_TRY(ensure_host_pattern(S));
     SGM_TRY(tri_levels_dev(S->L, n, S->hLptr, S->hLnode, S->dLptr, S->dLnode, S->dLval, true));
     SGM_TRY(tri_levels_dev(S->U, n, S->hUptr, S->hUnode, S->dUptr, S->dUnode, S->dUval, false));
     if (fresh) {
@@ -1502,6 +1661,7 @@ int ensure_walkers(IlduState *S)
 {
     SGM_TRY(ensure_levels(S));
     if (S->walk_ready) return SGM_OK;
+    SGM_TRY(ensure_host_pattern(S));
     const int32_t n = S->n;
     const bool fresh = !S->walk_pattern;
     SGM_TRY(tri_walkers(S->L, n, S->hLptr, S->hLnode, S->dLval));
@@ -1528,8 +1688,8 @@ int ensure_host_values(IlduState *S)
 {
     if (S->host_vals) return SGM_OK;
     SGM_HIP(hipStreamSynchronize(g_rt.stream));
-    S->hLval.resize(S->hLnode.size());
-    S->hUval.resize(S->hUnode.size());
+    S->hLval.resize((size_t)S->nnzL);
+    S->hUval.resize((size_t)S->nnzU);
     S->hD.resize((size_t)S->n);
     if (!S->hLval.empty()) SGM_TRY(copy_big(S->hLval.data(), S->dLval, S->hLval.size() * 8, hipMemcpyDeviceToHost));
     if (!S->hUval.empty()) SGM_TRY(copy_big(S->hUval.data(), S->dUval, S->hUval.size() * 8, hipMemcpyDeviceToHost));
@@ -1654,44 +1814,55 @@ void trsv(const TriFactor &T, double *xp, const int *flag)
     }
 }
 
-// The factors' patterns on the device (0-based) from the part's CSR-order arrays, and their 1-based host copies (what
-// sgm_pc_get hands out and the host index work -- levels, grid / slab detection -- reads).
+// The factors' patterns on the device (0-based) from the part's CSR-order arrays ...
 int ildu_pattern(IlduState *S, const Part &P, int32_t own)
 {
     const int32_t n = P.n;
     hipStream_t st = g_rt.stream;
+    int32_t *longest = nullptr;
     SGM_TRY(dalloc(&S->dLptr, (size_t)n + 1));
     SGM_TRY(dalloc(&S->dUptr, (size_t)n + 1));
+    SGM_TRY(dalloc(&longest, 2));
+    struct Tmp { int32_t *&a; void *t = nullptr; ~Tmp() { dfree(a); if (t) (void)hipFree(t); } } guard{longest};
+    SGM_HIP(hipMemsetAsync(longest, 0, 8, st));
     const int grid = (n + 1 + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(k_ildu_count, dim3(grid), dim3(kBlock), 0, st, n, own, (const int32_t *)P.rowptr, (const int32_t *)P.col,
-                       S->dLptr, S->dUptr);
+                       S->dLptr, S->dUptr, longest);
     size_t tb = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, S->dLptr, S->dLptr, n + 1, st);
-    void *tmp = nullptr;
-    SGM_HIP(hipMalloc(&tmp, std::max<size_t>(tb, 16)));
-    hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tb, S->dLptr, S->dLptr, n + 1, st);
-    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, tb, S->dUptr, S->dUptr, n + 1, st);
-    int32_t tot[2] = {0, 0};
-    if (e == hipSuccess) e = hipMemcpyAsync(&tot[0], S->dLptr + n, 4, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(&tot[1], S->dUptr + n, 4, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(tmp);
-    SGM_HIP(e);
+    SGM_HIP(hipMalloc(&guard.t, std::max<size_t>(tb, 16)));
+    SGM_HIP(hipcub::DeviceScan::ExclusiveSum(guard.t, tb, S->dLptr, S->dLptr, n + 1, st));
+    SGM_HIP(hipcub::DeviceScan::ExclusiveSum(guard.t, tb, S->dUptr, S->dUptr, n + 1, st));
+    int32_t tot[2] = {0, 0}, lg[2] = {0, 0};
+    SGM_HIP(hipMemcpyAsync(&tot[0], S->dLptr + n, 4, hipMemcpyDeviceToHost, st));
+    SGM_HIP(hipMemcpyAsync(&tot[1], S->dUptr + n, 4, hipMemcpyDeviceToHost, st));
+    SGM_HIP(hipMemcpyAsync(lg, longest, 8, hipMemcpyDeviceToHost, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    S->nnzL = tot[0]; S->nnzU = tot[1];
+    S->maxL = lg[0]; S->maxU = lg[1];
     SGM_TRY(dalloc(&S->dLnode, (size_t)std::max(tot[0], 1)));
     SGM_TRY(dalloc(&S->dUnode, (size_t)std::max(tot[1], 1)));
     if (n) hipLaunchKernelGGL(k_ildu_split, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, own, (const int32_t *)P.rowptr,
                               (const int32_t *)P.col, (const int32_t *)S->dLptr, S->dLnode, (const int32_t *)S->dUptr, S->dUnode);
-    SGM_HIP(hipStreamSynchronize(st));
+    SGM_HIP(hipGetLastError());
+    return SGM_OK;
+}
+// ... and their 1-based host copies, when something asks: sgm_pc_get, the host's level pass (factors of many levels), the
+// grid / slab detection, the level walkers' index work
+int ensure_host_pattern(IlduState *S)
+{
+    if (!S->hLptr.empty() || !S->dLptr) return SGM_OK;
+    SGM_HIP(hipStreamSynchronize(g_rt.stream));
     auto down = [](std::vector<int32_t> &h, const int32_t *d, size_t cnt) -> int {
         h.resize(cnt);
         if (cnt) SGM_TRY(copy_big(h.data(), d, cnt * 4, hipMemcpyDeviceToHost));
         for (auto &v : h) v += 1;
         return SGM_OK;
     };
-    SGM_TRY(down(S->hLptr, S->dLptr, (size_t)n + 1));
-    SGM_TRY(down(S->hUptr, S->dUptr, (size_t)n + 1));
-    SGM_TRY(down(S->hLnode, S->dLnode, (size_t)tot[0]));
-    SGM_TRY(down(S->hUnode, S->dUnode, (size_t)tot[1]));
+    SGM_TRY(down(S->hLptr, S->dLptr, (size_t)S->n + 1));
+    SGM_TRY(down(S->hUptr, S->dUptr, (size_t)S->n + 1));
+    SGM_TRY(down(S->hLnode, S->dLnode, (size_t)S->nnzL));
+    SGM_TRY(down(S->hUnode, S->dUnode, (size_t)S->nnzU));
     return SGM_OK;
 }
 
@@ -1868,22 +2039,26 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             t_prev = t;
         };
         const int32_t n = P.n;
-        const bool fresh = S->n != n || S->hLptr.empty();      // ldu_solvers.f90:117-125: pattern once
+        const bool fresh = S->n != n || !S->dLptr;             // ldu_solvers.f90:117-125: pattern once
         SGM_TRY(csr_need_arrays(P));          // (a part that kept only its sliced form rebuilds col / val for the setup)
         struct Release { const Part &p; ~Release() { csr_release_arrays(p); } } rel{P};
         const int32_t own = P.n_halo == 0 ? INT32_MAX : P.ncol_own;
+        bool few = false;                     // L has at most kRowLevels levels (found on the device): no pipeline applies, no host pattern needed
         if (fresh) {
             free_ildu(*S);
+            S->n = n;
             SGM_TRY(ildu_pattern(S, P, own));
-            for (int32_t i = 0; i < n; ++i) {
-                S->maxL = std::max(S->maxL, S->hLptr[i + 1] - S->hLptr[i]);
-                S->maxU = std::max(S->maxU, S->hUptr[i + 1] - S->hUptr[i]);
+            lap("pattern (device)");
+            // L's dependency levels: the order the rows are factorised in (and what its sweeps use later) -- on the device
+            // when they are few, else from the pattern's host copy
+            SGM_TRY(tri_levels_device(S->L, n, S->dLptr, S->dLnode, &few));
+            if (!S->L.have_levels) {
+                SGM_TRY(ensure_host_pattern(S));
+                lap("host copy of the pattern");
+                SGM_TRY(tri_levels_dev(S->L, n, S->hLptr, S->hLnode, S->dLptr, S->dLnode, nullptr, true));
             }
-            lap("pattern (device) + its host copy");
-            // L's dependency levels: the order the rows are factorised in (and what its sweeps use later)
-            SGM_TRY(tri_levels_dev(S->L, n, S->hLptr, S->hLnode, S->dLptr, S->dLnode, nullptr, true));
-            SGM_TRY(dalloc(&S->dLval, std::max<size_t>(S->hLnode.size(), 1)));
-            SGM_TRY(dalloc(&S->dUval, std::max<size_t>(S->hUnode.size(), 1)));
+            SGM_TRY(dalloc(&S->dLval, (size_t)std::max(S->nnzL, 1)));
+            SGM_TRY(dalloc(&S->dUval, (size_t)std::max(S->nnzU, 1)));
             SGM_TRY(dalloc(&S->D, (size_t)std::max(n, 1)));
             lap("levels of L");
         }
@@ -1920,7 +2095,12 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             dfree(S->gxL); dfree(S->gxU); dfree(S->gDp); dfree(S->gmapLU);
             S->gxL = S->gxU = S->gDp = nullptr; S->gmapLU = nullptr;
             S->grid_ok = false;
-            const int32_t wl = grid_width(n, S->hLptr, S->hLnode, true), wu = grid_width(n, S->hUptr, S->hUnode, false);
+            int32_t wl = 0, wu = 0;
+            if (!few) {
+                SGM_TRY(ensure_host_pattern(S));
+                wl = grid_width(n, S->hLptr, S->hLnode, true);
+                wu = grid_width(n, S->hUptr, S->hUnode, false);
+            }
             if (g_opt.ildu_strips && wl >= 64 && wl == wu && (n + wl - 1) / wl >= 64) {
                 SGM_TRY(build_grid(S->gL, n, wl, S->dLptr, S->dLnode, true));
                 SGM_TRY(build_grid(S->gU, n, wl, S->dUptr, S->dUnode, false));
@@ -1940,7 +2120,7 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             slab3_free(S->slab);
             S->slab = nullptr;
             S->slab_ok = false;
-            if (g_opt.ildu_strips && !(S->gL.on && S->gU.on))
+            if (g_opt.ildu_strips && !few && !(S->gL.on && S->gU.on))
                 SGM_TRY(slab3_build(&S->slab, n, S->hLptr, S->hLnode, S->hUptr, S->hUnode, S->dLptr, S->dLnode, S->dUptr, S->dUnode));
         }
         lap("strip / slab index work");
@@ -2084,6 +2264,7 @@ int sgm_pc_get(sgm_pc pc, const char *name, void *out, size_t bytes, size_t *nee
         if (pc->ild.size() != 1) return fail(SGM_ERR_UNSUPPORTED, "sgm_pc_get: single-part ILDU only");
         IlduState *S = &pc->ild[0];
         if (nm == "Lval" || nm == "Uval" || nm == "D") SGM_TRY(ensure_host_values(S));
+        if (nm == "Lptr" || nm == "Lnode" || nm == "Uptr" || nm == "Unode") SGM_TRY(ensure_host_pattern(S));
         if (nm == "Lptr") { src = S->hLptr.data(); sz = S->hLptr.size() * 4; }
         else if (nm == "Lnode") { src = S->hLnode.data(); sz = S->hLnode.size() * 4; }
         else if (nm == "Lval") { src = S->hLval.data(); sz = S->hLval.size() * 8; }
