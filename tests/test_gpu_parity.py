@@ -1241,7 +1241,7 @@ def test_preconditioners_golden_bit_exact(golden, name):
             assert np.array_equal(z, g[f"ref_s{s}_pcz"])
 
 
-@pytest.mark.parametrize("case", ["short_rows", "long_rows", "duplicates", "empty_rows", "no_diagonal"])
+@pytest.mark.parametrize("case", ["short_rows", "long_rows", "duplicates", "empty_rows", "no_diagonal", "diagonal_only", "one_row"])
 def test_device_factorisation_statement_for_statement(orc, case):
     """The ILDU(0) pattern pass and factorisation run on the device (k_ildu_split, k_ildu_init, k_ildu_factor_level /
     _short): L, D, U and their index arrays against the oracle's statement-for-statement restatement, np.array_equal --
@@ -1263,6 +1263,9 @@ def test_device_factorisation_statement_for_statement(orc, case):
         i = np.repeat(np.arange(n), 2); j = np.clip(i + rs.choice([-7, 7], size=i.size), 0, n - 1)
         keep = (i % 5 != 0)
         i, j = i[keep], j[keep]
+    elif case in ("diagonal_only", "one_row"):
+        n = 700 if case == "diagonal_only" else 1
+        i = np.zeros(0, np.int64); j = np.zeros(0, np.int64)
     else:
         n = 1500
         i = np.repeat(np.arange(n), 2); j = np.clip(i + rs.choice([-2, 2], size=i.size), 0, n - 1)
