@@ -140,6 +140,11 @@ struct IlduState {
     bool host_vals = false;
     int32_t maxL = 0, maxU = 0;                              // longest row of each factor
     int32_t nnzL = 0, nnzU = 0;
+    // grid-like factors (found on the device, grid_detect_device): the factorisation walks the anti-diagonals of the grid;
+    // L's true dependency levels are then only built if something asks for them
+    int32_t *forder = nullptr;
+    std::vector<int32_t> flevel_ptr;
+    int32_t dev_wl = 0, dev_wu = 0;                          // grid widths found on the device (0: not grid-like / not looked)
     // strip-pipeline path (both factors grid-like, see GridTri): results in position space and the L -> U hand-over
     GridTri gL, gU;
     double *gxL = nullptr, *gxU = nullptr, *gDp = nullptr;
@@ -897,6 +902,53 @@ __global__ void k_level_info(int32_t n, const int32_t *__restrict__ order, const
     }
 }
 
+// grid_width on the device (the host version below reads a host copy of the pattern; this one keeps it where it is).
+// Pass 1: info[0] / info[1] = smallest / largest dependency distance > 1, info[2] = some row breaks the shape (a
+// dependency on the wrong side, more than two entries, the same column twice).  Pass 2, with the width w those agree on:
+// info[3] = an r-1 / r+1 dependency across a grid line, or a distance that is neither 1 nor w.
+__global__ void k_grid_detect1(int32_t n, int lower, const int32_t *__restrict__ ptr, const int32_t *__restrict__ node, int32_t *info)
+{
+    __shared__ int32_t lo, hi, bad;
+    if (threadIdx.x == 0) { lo = INT32_MAX; hi = 0; bad = 0; }
+    __syncthreads();
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) {
+        const int32_t b = ptr[r], cnt = ptr[r + 1] - b;
+        if (cnt > 2 || (cnt == 2 && node[b] == node[b + 1])) bad = 1;
+        for (int32_t k = b; k < b + cnt; ++k) {
+            const int32_t dlt = lower ? r - node[k] : node[k] - r;
+            if (dlt <= 0) bad = 1;
+            else if (dlt > 1) { atomicMin(&lo, dlt); atomicMax(&hi, dlt); }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (lo != INT32_MAX) { atomicMin(info, lo); atomicMax(info + 1, hi); }
+        if (bad) info[2] = 1;
+    }
+}
+__global__ void k_grid_detect2(int32_t n, int lower, int32_t w, const int32_t *__restrict__ ptr, const int32_t *__restrict__ node, int32_t *info)
+{
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    for (int32_t k = ptr[r]; k < ptr[r + 1]; ++k) {
+        const int32_t dlt = lower ? r - node[k] : node[k] - r;
+        if (dlt == 1) { if (lower ? r % w == 0 : (r + 1) % w == 0) info[3] = 1; }
+        else if (dlt != w) info[3] = 1;
+    }
+}
+// rows of a w-wide grid keyed by their anti-diagonal i + j: a valid levelling of a factor whose rows depend on r-1 and
+// r-w only (each of them one anti-diagonal back) -- the order its rows are factorised in
+__global__ void k_grid_keys(int32_t n, int32_t w, int32_t *__restrict__ key, int32_t *__restrict__ rows, int32_t *__restrict__ count)
+{
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int32_t k = r % w + r / w;
+    key[r] = k;
+    rows[r] = r;
+    atomicAdd(count + k, 1);
+}
+
 // sparse_static_pattern_ldu_factorization, first loop (ldu_solvers.f90:300-318): A's entries into L, D, U through
 // set_value, row by row in stored order
 __global__ void k_ildu_init(int32_t n, int32_t ncol_own, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
@@ -1219,7 +1271,7 @@ void free_ildu(IlduState &S)
     free_tri(S.L);
     free_tri(S.U);
     dfree(S.D); dfree(S.xpL); dfree(S.xpU); dfree(S.Dp); dfree(S.mapLU);
-    dfree(S.dLptr); dfree(S.dLnode); dfree(S.dUptr); dfree(S.dUnode); dfree(S.dLval); dfree(S.dUval);
+    dfree(S.dLptr); dfree(S.dLnode); dfree(S.dUptr); dfree(S.dUnode); dfree(S.dLval); dfree(S.dUval); dfree(S.forder);
     free_grid(S.gL); free_grid(S.gU);
     dfree(S.gxL); dfree(S.gxU); dfree(S.gDp); dfree(S.gmapLU);
     slab3_free(S.slab);
@@ -1814,6 +1866,62 @@ void trsv(const TriFactor &T, double *xp, const int *flag)
     }
 }
 
+// grid_width without a host copy of the pattern: 0 = not grid-like
+int grid_width_device(int32_t n, const int32_t *dptr, const int32_t *dnode, bool lower, int32_t *w_out)
+{
+    *w_out = 0;
+    if (n < 1) return SGM_OK;
+    hipStream_t st = g_rt.stream;
+    int32_t *info = nullptr;
+    SGM_TRY(dalloc(&info, 4));
+    struct Tmp { int32_t *&a; ~Tmp() { dfree(a); } } guard{info};
+    const int32_t init[4] = {INT32_MAX, 0, 0, 0};
+    int32_t h[4];
+    SGM_HIP(hipMemcpyAsync(info, init, 16, hipMemcpyHostToDevice, st));
+    const int grid = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_grid_detect1, dim3(grid), dim3(kBlock), 0, st, n, lower ? 1 : 0, dptr, dnode, info);
+    SGM_HIP(hipMemcpyAsync(h, info, 16, hipMemcpyDeviceToHost, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    if (h[2] || h[0] == INT32_MAX || h[0] != h[1] || h[0] < 2) return SGM_OK;
+    hipLaunchKernelGGL(k_grid_detect2, dim3(grid), dim3(kBlock), 0, st, n, lower ? 1 : 0, h[0], dptr, dnode, info);
+    SGM_HIP(hipMemcpyAsync(h, info, 16, hipMemcpyDeviceToHost, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    if (!h[3]) *w_out = h[0];
+    return SGM_OK;
+}
+// the factorisation order of a grid-like factor pair: rows sorted (stably) on their anti-diagonal
+int grid_factor_order(IlduState *S, int32_t n, int32_t w)
+{
+    hipStream_t st = g_rt.stream;
+    const int32_t nj = (n + w - 1) / w, nkeys = w + nj;          // keys 0 .. w-1 + nj-1
+    int bits = 1;
+    while ((1 << bits) < nkeys) ++bits;
+    int32_t *key = nullptr, *key2 = nullptr, *rows = nullptr, *count = nullptr;
+    void *tmp = nullptr;
+    struct Tmp { int32_t *&a, *&b, *&c, *&d; void *&t; ~Tmp() { dfree(a); dfree(b); dfree(c); dfree(d); if (t) (void)hipFree(t); } }
+        guard{key, key2, rows, count, tmp};
+    SGM_TRY(dalloc(&key, (size_t)n));
+    SGM_TRY(dalloc(&key2, (size_t)n));
+    SGM_TRY(dalloc(&rows, (size_t)n));
+    SGM_TRY(dalloc(&count, (size_t)nkeys));
+    dfree(S->forder);
+    S->forder = nullptr;
+    SGM_TRY(dalloc(&S->forder, (size_t)n));
+    SGM_HIP(hipMemsetAsync(count, 0, (size_t)nkeys * 4, st));
+    hipLaunchKernelGGL(k_grid_keys, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, w, key, rows, count);
+    size_t tb = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const int32_t *)key, key2, (const int32_t *)rows, S->forder, n, 0, bits, st);
+    SGM_HIP(hipMalloc(&tmp, std::max<size_t>(tb, 16)));
+    SGM_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, (const int32_t *)key, key2, (const int32_t *)rows, S->forder, n, 0, bits, st));
+    std::vector<int32_t> hc((size_t)nkeys);
+    SGM_HIP(hipMemcpyAsync(hc.data(), count, (size_t)nkeys * 4, hipMemcpyDeviceToHost, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    S->flevel_ptr.assign(1, 0);
+    for (int32_t k = 0; k < nkeys; ++k)
+        if (hc[k]) S->flevel_ptr.push_back(S->flevel_ptr.back() + hc[k]);
+    return SGM_OK;
+}
+
 // The factors' patterns on the device (0-based) from the part's CSR-order arrays ...
 int ildu_pattern(IlduState *S, const Part &P, int32_t own)
 {
@@ -2052,7 +2160,16 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             // L's dependency levels: the order the rows are factorised in (and what its sweeps use later) -- on the device
             // when they are few, else from the pattern's host copy
             SGM_TRY(tri_levels_device(S->L, n, S->dLptr, S->dLnode, &few));
-            if (!S->L.have_levels) {
+            if (!S->L.have_levels && g_opt.ildu_strips) {
+                // many levels: a grid-like pair (what the strip pipeline serves)?  Then the anti-diagonals are the order
+                SGM_TRY(grid_width_device(n, S->dLptr, S->dLnode, true, &S->dev_wl));
+                if (S->dev_wl >= 64) SGM_TRY(grid_width_device(n, S->dUptr, S->dUnode, false, &S->dev_wu));
+                if (S->dev_wl >= 64 && S->dev_wl == S->dev_wu && (n + S->dev_wl - 1) / S->dev_wl >= 64)
+                    SGM_TRY(grid_factor_order(S, n, S->dev_wl));
+                else S->dev_wl = S->dev_wu = 0;
+                lap("grid detection, anti-diagonal order");
+            }
+            if (!S->L.have_levels && !S->forder) {
                 SGM_TRY(ensure_host_pattern(S));
                 lap("host copy of the pattern");
                 SGM_TRY(tri_levels_dev(S->L, n, S->hLptr, S->hLnode, S->dLptr, S->dLnode, nullptr, true));
@@ -2070,17 +2187,20 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             hipLaunchKernelGGL(k_ildu_init, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, own, (const int32_t *)P.rowptr,
                                (const int32_t *)P.col, (const double *)P.val, (const int32_t *)S->dLptr, (const int32_t *)S->dLnode,
                                S->dLval, (const int32_t *)S->dUptr, (const int32_t *)S->dUnode, S->dUval, S->D);
-            for (size_t l = 0; l + 1 < S->L.level_ptr.size(); ++l) {
-                const int32_t b = S->L.level_ptr[l], e = S->L.level_ptr[l + 1];
+            // (rows in the order of L's dependency levels, or -- grid-like factors -- of the grid's anti-diagonals)
+            const std::vector<int32_t> &flp = S->forder ? S->flevel_ptr : S->L.level_ptr;
+            const int32_t *ford = S->forder ? S->forder : S->L.order;
+            for (size_t l = 0; l + 1 < flp.size(); ++l) {
+                const int32_t b = flp[l], e = flp[l + 1];
                 static const bool no_short = getenv("SGM_ILDU_NO_SHORT") != nullptr;          // (tuning aid)
                 if (S->maxL <= 4 && S->maxU <= 4 && !no_short) {
                     hipLaunchKernelGGL((k_ildu_factor_level_short<4, 4>), dim3((e - b + 63) / 64), dim3(64), 0, st,
-                                       (const int32_t *)S->L.order, b, e, (const int32_t *)S->dLptr, (const int32_t *)S->dLnode, S->dLval,
+                                       ford, b, e, (const int32_t *)S->dLptr, (const int32_t *)S->dLnode, S->dLval,
                                        (const int32_t *)S->dUptr, (const int32_t *)S->dUnode, S->dUval, S->D);
                     continue;
                 }
                 hipLaunchKernelGGL(k_ildu_factor_level, dim3((e - b + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
-                                   (const int32_t *)S->L.order, b, e, (const int32_t *)S->dLptr, (const int32_t *)S->dLnode, S->dLval,
+                                   ford, b, e, (const int32_t *)S->dLptr, (const int32_t *)S->dLnode, S->dLval,
                                    (const int32_t *)S->dUptr, (const int32_t *)S->dUnode, S->dUval, S->D);
             }
             SGM_HIP(hipGetLastError());
@@ -2095,8 +2215,8 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             dfree(S->gxL); dfree(S->gxU); dfree(S->gDp); dfree(S->gmapLU);
             S->gxL = S->gxU = S->gDp = nullptr; S->gmapLU = nullptr;
             S->grid_ok = false;
-            int32_t wl = 0, wu = 0;
-            if (!few) {
+            int32_t wl = S->dev_wl, wu = S->dev_wu;          // (found on the device already when the pair is grid-like)
+            if (!few && !wl) {
                 SGM_TRY(ensure_host_pattern(S));
                 wl = grid_width(n, S->hLptr, S->hLnode, true);
                 wu = grid_width(n, S->hUptr, S->hUnode, false);
@@ -2120,6 +2240,7 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             slab3_free(S->slab);
             S->slab = nullptr;
             S->slab_ok = false;
+            if (g_opt.ildu_strips && !few && !(S->gL.on && S->gU.on)) SGM_TRY(ensure_host_pattern(S));
             if (g_opt.ildu_strips && !few && !(S->gL.on && S->gU.on))
                 SGM_TRY(slab3_build(&S->slab, n, S->hLptr, S->hLnode, S->hUptr, S->hUnode, S->dLptr, S->dLnode, S->dUptr, S->dUnode));
         }
