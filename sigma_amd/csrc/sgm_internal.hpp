@@ -270,6 +270,8 @@ int slab3_build(Slab3 **out, int32_t n, const std::vector<int32_t> &Lptr, const 
 int slab3_refresh(Slab3 *S, const double *Lval, const double *Uval, const double *D);     // (device pointers)
 void slab3_apply(const Slab3 *S, const double *r, double *z, const int *flag, int spin_limit, int32_t *sticky);
 void slab3_lower_result(const Slab3 *S, double *dst);
+int slab_dims_device(int32_t n, const int32_t *dptr, const int32_t *dnode, bool lower, int32_t *w, int32_t *h);
+void slab3_dims(const Slab3 *S, int32_t *w, int32_t *h);
 int slab3_aborted(const Slab3 *S, int32_t *abL, int32_t *abU);
 void slab3_info(const Slab3 *S, int32_t out[6]);
 int slab3_clocks(const Slab3 *S, std::vector<long long> &out);

@@ -145,6 +145,7 @@ struct IlduState {
     int32_t *forder = nullptr;
     std::vector<int32_t> flevel_ptr;
     int32_t dev_wl = 0, dev_wu = 0;                          // grid widths found on the device (0: not grid-like / not looked)
+    bool dev_slab = false;                                   // a 3-D grid's factors, found on the device
     // strip-pipeline path (both factors grid-like, see GridTri): results in position space and the L -> U hand-over
     GridTri gL, gU;
     double *gxL = nullptr, *gxU = nullptr, *gDp = nullptr;
@@ -939,11 +940,12 @@ __global__ void k_grid_detect2(int32_t n, int lower, int32_t w, const int32_t *_
 }
 // rows of a w-wide grid keyed by their anti-diagonal i + j: a valid levelling of a factor whose rows depend on r-1 and
 // r-w only (each of them one anti-diagonal back) -- the order its rows are factorised in
-__global__ void k_grid_keys(int32_t n, int32_t w, int32_t *__restrict__ key, int32_t *__restrict__ rows, int32_t *__restrict__ count)
+// (h > 0: a w x h x nk grid, rows depend on r-1, r-w, r-w*h: keyed by i + j + k)
+__global__ void k_grid_keys(int32_t n, int32_t w, int32_t h, int32_t *__restrict__ key, int32_t *__restrict__ rows, int32_t *__restrict__ count)
 {
     const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    const int32_t k = r % w + r / w;
+    const int32_t k = h > 0 ? r % w + (r / w) % h + r / (w * h) : r % w + r / w;
     key[r] = k;
     rows[r] = r;
     atomicAdd(count + k, 1);
@@ -1890,10 +1892,11 @@ int grid_width_device(int32_t n, const int32_t *dptr, const int32_t *dnode, bool
     return SGM_OK;
 }
 // the factorisation order of a grid-like factor pair: rows sorted (stably) on their anti-diagonal
-int grid_factor_order(IlduState *S, int32_t n, int32_t w)
+int grid_factor_order(IlduState *S, int32_t n, int32_t w, int32_t h)
 {
     hipStream_t st = g_rt.stream;
-    const int32_t nj = (n + w - 1) / w, nkeys = w + nj;          // keys 0 .. w-1 + nj-1
+    const int32_t nj = (n + w - 1) / w;
+    const int32_t nkeys = h > 0 ? w + h + (int32_t)((n + (int64_t)w * h - 1) / ((int64_t)w * h)) : w + nj;   // keys 0 .. w-1 + nj-1
     int bits = 1;
     while ((1 << bits) < nkeys) ++bits;
     int32_t *key = nullptr, *key2 = nullptr, *rows = nullptr, *count = nullptr;
@@ -1908,7 +1911,7 @@ int grid_factor_order(IlduState *S, int32_t n, int32_t w)
     S->forder = nullptr;
     SGM_TRY(dalloc(&S->forder, (size_t)n));
     SGM_HIP(hipMemsetAsync(count, 0, (size_t)nkeys * 4, st));
-    hipLaunchKernelGGL(k_grid_keys, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, w, key, rows, count);
+    hipLaunchKernelGGL(k_grid_keys, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, w, h, key, rows, count);
     size_t tb = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const int32_t *)key, key2, (const int32_t *)rows, S->forder, n, 0, bits, st);
     SGM_HIP(hipMalloc(&tmp, std::max<size_t>(tb, 16)));
@@ -2165,8 +2168,19 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
                 SGM_TRY(grid_width_device(n, S->dLptr, S->dLnode, true, &S->dev_wl));
                 if (S->dev_wl >= 64) SGM_TRY(grid_width_device(n, S->dUptr, S->dUnode, false, &S->dev_wu));
                 if (S->dev_wl >= 64 && S->dev_wl == S->dev_wu && (n + S->dev_wl - 1) / S->dev_wl >= 64)
-                    SGM_TRY(grid_factor_order(S, n, S->dev_wl));
-                else S->dev_wl = S->dev_wu = 0;
+                    SGM_TRY(grid_factor_order(S, n, S->dev_wl, 0));
+                else {
+                    S->dev_wl = S->dev_wu = 0;
+                    // ... or a 3-D grid's (what the slab pipeline serves: the same bounds as slab3_build)?
+                    int32_t wl3, hl3, wu3 = 0, hu3 = 0;
+                    SGM_TRY(slab_dims_device(n, S->dLptr, S->dLnode, true, &wl3, &hl3));
+                    if (wl3) SGM_TRY(slab_dims_device(n, S->dUptr, S->dUnode, false, &wu3, &hu3));
+                    const int64_t wh3 = (int64_t)wl3 * hl3;
+                    if (wl3 && wl3 == wu3 && hl3 == hu3 && wl3 >= 32 && wl3 <= 256 && hl3 >= 8 && (n + wh3 - 1) / wh3 >= 8) {
+                        SGM_TRY(grid_factor_order(S, n, wl3, hl3));
+                        S->dev_slab = true;
+                    }
+                }
                 lap("grid detection, anti-diagonal order");
             }
             if (!S->L.have_levels && !S->forder) {
@@ -2216,7 +2230,7 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             S->gxL = S->gxU = S->gDp = nullptr; S->gmapLU = nullptr;
             S->grid_ok = false;
             int32_t wl = S->dev_wl, wu = S->dev_wu;          // (found on the device already when the pair is grid-like)
-            if (!few && !wl) {
+            if (!few && !wl && !S->dev_slab) {
                 SGM_TRY(ensure_host_pattern(S));
                 wl = grid_width(n, S->hLptr, S->hLnode, true);
                 wu = grid_width(n, S->hUptr, S->hUnode, false);
@@ -2240,7 +2254,7 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             slab3_free(S->slab);
             S->slab = nullptr;
             S->slab_ok = false;
-            if (g_opt.ildu_strips && !few && !(S->gL.on && S->gU.on)) SGM_TRY(ensure_host_pattern(S));
+            if (g_opt.ildu_strips && !few && !(S->gL.on && S->gU.on) && !S->dev_slab) SGM_TRY(ensure_host_pattern(S));
             if (g_opt.ildu_strips && !few && !(S->gL.on && S->gU.on))
                 SGM_TRY(slab3_build(&S->slab, n, S->hLptr, S->hLnode, S->hUptr, S->hUnode, S->dLptr, S->dLnode, S->dUptr, S->dUnode));
         }

@@ -630,6 +630,74 @@ void slab3_free(Slab3 *S)
     delete S;
 }
 
+// slab_dims on the device (no host copy of the pattern).  Pass 1: info[0] / info[1] = smallest / largest dependency distance
+// > 1 (a 3-D grid's factor has exactly two: w and w*h), info[2] = a row breaks the shape (more than three entries, a
+// dependency on the wrong side).  Pass 2, with w and h: info[3] = a distance that is none of 1, w, w*h, the same distance
+// twice in a row, an r-1 dependency across a line, an r-w one across a plane.
+__global__ void k_slab_detect1(int32_t n, int lower, const int32_t *__restrict__ ptr, const int32_t *__restrict__ node, int32_t *info)
+{
+    __shared__ int32_t lo, hi, bad;
+    if (threadIdx.x == 0) { lo = INT32_MAX; hi = 0; bad = 0; }
+    __syncthreads();
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) {
+        const int32_t b = ptr[r], cnt = ptr[r + 1] - b;
+        if (cnt > 3) bad = 1;
+        for (int32_t k = b; k < b + cnt; ++k) {
+            const int32_t dlt = lower ? r - node[k] : node[k] - r;
+            if (dlt <= 0) bad = 1;
+            else if (dlt > 1) { atomicMin(&lo, dlt); atomicMax(&hi, dlt); }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (lo != INT32_MAX) { atomicMin(info, lo); atomicMax(info + 1, hi); }
+        if (bad) info[2] = 1;
+    }
+}
+__global__ void k_slab_detect2(int32_t n, int lower, int32_t ww, int32_t hh, const int32_t *__restrict__ ptr,
+                               const int32_t *__restrict__ node, int32_t *info)
+{
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    int seen[3] = {0, 0, 0};
+    const int32_t wh = ww * hh;
+    for (int32_t k = ptr[r]; k < ptr[r + 1]; ++k) {
+        const int32_t c = node[k];
+        const int32_t dlt = lower ? r - c : c - r;
+        const int32_t hi = lower ? r : c;                             // the later of the two rows
+        if (dlt != 1 && dlt != ww && dlt != wh) { info[3] = 1; return; }
+        const int id = dlt == 1 ? 2 : dlt == ww ? 1 : 0;
+        if (seen[id]++) info[3] = 1;                                  // duplicate entries: the general walkers
+        if (dlt == 1 && hi % ww == 0) info[3] = 1;
+        if (dlt == ww && (hi / ww) % hh == 0) info[3] = 1;
+    }
+}
+// w = h = 0: not a 3-D grid's factor
+int slab_dims_device(int32_t n, const int32_t *dptr, const int32_t *dnode, bool lower, int32_t *w, int32_t *h)
+{
+    *w = *h = 0;
+    if (n < 1) return SGM_OK;
+    hipStream_t st = g_rt.stream;
+    int32_t *info = nullptr;
+    SGM_TRY(dalloc(&info, 4));
+    struct Tmp { int32_t *&a; ~Tmp() { dfree(a); } } guard{info};
+    const int32_t init[4] = {INT32_MAX, 0, 0, 0};
+    int32_t hv[4];
+    SGM_HIP(hipMemcpyAsync(info, init, 16, hipMemcpyHostToDevice, st));
+    const int grid = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_slab_detect1, dim3(grid), dim3(kBlock), 0, st, n, lower ? 1 : 0, dptr, dnode, info);
+    SGM_HIP(hipMemcpyAsync(hv, info, 16, hipMemcpyDeviceToHost, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    const int32_t d1 = hv[0], d2 = hv[1];
+    if (hv[2] || d1 == INT32_MAX || d1 < 2 || d2 <= d1 || d2 % d1 || d2 / d1 < 2) return SGM_OK;
+    hipLaunchKernelGGL(k_slab_detect2, dim3(grid), dim3(kBlock), 0, st, n, lower ? 1 : 0, d1, d2 / d1, dptr, dnode, info);
+    SGM_HIP(hipMemcpyAsync(hv, info, 16, hipMemcpyDeviceToHost, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    if (!hv[3]) { *w = d1; *h = d2 / d1; }
+    return SGM_OK;
+}
+
 // *out stays null when the factors are not a 3-D grid's (or too small / too wide for this path).  Host copies of the
 // patterns (1-based) for the detection, device copies (0-based) for the index work.
 int slab3_build(Slab3 **out, int32_t n, const std::vector<int32_t> &Lptr, const std::vector<int32_t> &Lnode,
@@ -638,9 +706,15 @@ int slab3_build(Slab3 **out, int32_t n, const std::vector<int32_t> &Lptr, const 
 {
     *out = nullptr;
     int32_t wl, hl, wu, hu;
-    slab_dims(n, Lptr, Lnode, true, wl, hl);
-    if (!wl) return SGM_OK;
-    slab_dims(n, Uptr, Unode, false, wu, hu);
+    if (Lptr.empty()) {                  // (no host copy of the pattern: the same questions asked on the device)
+        SGM_TRY(slab_dims_device(n, dLptr, dLnode, true, &wl, &hl));
+        if (!wl) return SGM_OK;
+        SGM_TRY(slab_dims_device(n, dUptr, dUnode, false, &wu, &hu));
+    } else {
+        slab_dims(n, Lptr, Lnode, true, wl, hl);
+        if (!wl) return SGM_OK;
+        slab_dims(n, Uptr, Unode, false, wu, hu);
+    }
     if (wl != wu || hl != hu) return SGM_OK;
     const int64_t wh = (int64_t)wl * hl;
     if (wl < 32 || wl > 256 || hl < 8 || (n + wh - 1) / wh < 8) return SGM_OK;
@@ -697,6 +771,8 @@ void slab3_apply(const Slab3 *S, const double *r, double *z, const int *flag, in
 }
 
 // abort words of the last sweeps (stream must be idle)
+void slab3_dims(const Slab3 *S, int32_t *w, int32_t *h) { *w = S->L.w; *h = S->L.h; }
+
 // the result of the last L sweep in row order (setup self-check)
 void slab3_lower_result(const Slab3 *S, double *dst)
 {
