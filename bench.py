@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 
 
 def spmv_bytes(n, m, nnz):
@@ -76,7 +76,96 @@ def parse_args():
     ap.add_argument("--no-pcg", action="store_true", help="N = 1: skip the `pcg_time_to_solution` leg (CG vs ILDU(0)-PCG, 1000^2 grid)")
     ap.add_argument("--no-dist-overhead", action="store_true",
                     help="N = 1: skip the `dist_overhead_1rank` leg (CG through the RCCL code path with one rank)")
+    ap.add_argument("--no-c3", action="store_true", help="N = 1: skip the C3 leg (1-D advection-diffusion n = 1e7: SpMV, BiCGStab, GMRES(30))")
+    ap.add_argument("--no-c4", action="store_true", help="N = 1: skip the C4 leg (ELLPACK random digraph, degree 32, n = 5e6: SpMV)")
+    ap.add_argument("--c3-n", type=int, default=10_000_000)
+    ap.add_argument("--c3-iters", type=int, default=300)
+    ap.add_argument("--c4-n", type=int, default=5_000_000)
+    ap.add_argument("--pcg-nx", type=int, default=3162, help="N = 1: grid edge of the second `pcg_time_to_solution` row (0 = skip it)")
+    ap.add_argument("--stall-s", type=float, default=300.0,
+                    help="every rank: seconds without a heartbeat (a phase change of this script, or a beat of the library: "
+                         "solver batches, halo posts, all-reduces) after which the rank prints where it is stuck and exits 86")
+    ap.add_argument("--deadline-s", type=float, default=1500.0,
+                    help="whole-run limit: a rank past it prints where it is and exits 86; with `--gpus N` typed plainly the "
+                         "parent also kills its children (by PID) then and prints every rank's last phase")
     return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------ #
+# Heartbeat + watchdog: ranks that all block in a collective would otherwise run into
+# the caller's timeout silently.  Every rank keeps "<dir>/rank<r>.hb" = its current phase; a daemon thread
+# looks once a second at (this script's phase counter, the library's own heartbeat -- sgm_heartbeat, readable
+# while the main thread is blocked inside the library) and, when nothing has moved for --stall-s or the run is
+# past --deadline-s, writes the state, prints it and ends the process with os._exit(86).  Under
+# torch.distributed.run that makes the launcher end the other ranks; typed as `python bench.py --gpus N` the
+# parent does the same by PID.  No process is ever exec()ed or killed by pattern.
+# ------------------------------------------------------------------------------------------ #
+class Heartbeat:
+    EXIT = 86
+
+    def __init__(self, rank, stall_s, deadline_s, sg=None):
+        import threading
+        self.rank, self.stall_s, self.deadline_s, self.sg = rank, stall_s, deadline_s, sg
+        self.dir = os.environ.get("SGM_BENCH_HB_DIR")
+        self.name, self.count, self.t_phase = "start", 0, time.time()
+        self.t0 = time.time()
+        self.done = False
+        self._last_sig, self._last_move = None, time.time()
+        self._write()
+        self._thr = threading.Thread(target=self._watch, daemon=True)
+        self._thr.start()
+
+    def phase(self, name):
+        self.name, self.count, self.t_phase = name, self.count + 1, time.time()
+        self._write()
+
+    def state(self):
+        st = {"rank": self.rank, "phase": self.name, "phase_no": self.count, "in_phase_s": round(time.time() - self.t_phase, 1),
+              "elapsed_s": round(time.time() - self.t0, 1)}
+        if self.sg is not None:
+            try:
+                st["library"] = self.sg.heartbeat()
+            except Exception as e:       # the watchdog must never be what takes the run down
+                st["library"] = {"error": str(e)[:100]}
+        return st
+
+    def _write(self, extra=None):
+        if not self.dir:
+            return
+        try:
+            st = self.state()
+            if extra:
+                st.update(extra)
+            tmp = os.path.join(self.dir, f"rank{self.rank}.hb.tmp")
+            with open(tmp, "w") as f:
+                json.dump(st, f)
+            os.replace(tmp, os.path.join(self.dir, f"rank{self.rank}.hb"))
+        except OSError:
+            pass
+
+    def _watch(self):
+        while not self.done:
+            time.sleep(1.0)
+            st = self.state()
+            lib = st.get("library") or {}
+            sig = (st["phase_no"], lib.get("beats"), lib.get("iteration"))
+            now = time.time()
+            if sig != self._last_sig:
+                self._last_sig, self._last_move = sig, now
+            why = None
+            if now - self._last_move > self.stall_s:
+                why = f"no heartbeat for {now - self._last_move:.0f} s (--stall-s {self.stall_s:g})"
+            elif now - self.t0 > self.deadline_s:
+                why = f"run past --deadline-s {self.deadline_s:g}"
+            if why and not self.done:
+                self._write({"stalled": why})
+                sys.stderr.write(f"[bench] rank {self.rank} STALLED: {why}; state: {json.dumps(st)}\n")
+                sys.stderr.flush()
+                os._exit(self.EXIT)
+
+    def finish(self):
+        self.done = True
+        self.phase("done")
 
 
 # ------------------------------------------------------------------------------------------ #
@@ -93,20 +182,38 @@ def spawn_ranks(args):
     # rank 0's line goes through a temporary FILE, not a pipe: nothing a child prints can fill a pipe buffer and block it
     # while this parent waits for it to exit
     cap = tempfile.TemporaryFile()
+    hb_dir = tempfile.mkdtemp(prefix="sgm_bench_hb_")
     for r in range(args.gpus):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
-                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "SGM_BENCH_CHILD": "1"})
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "SGM_BENCH_CHILD": "1", "SGM_BENCH_HB_DIR": hb_dir})
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=cap if r == 0 else subprocess.DEVNULL))
-    # if one rank dies the others would wait in a collective for ever: end them (by PID) after a grace period
-    deadline = None
+
+    def last_phases():
+        out = []
+        for r in range(args.gpus):
+            try:
+                out.append(json.load(open(os.path.join(hb_dir, f"rank{r}.hb"))))
+            except (OSError, ValueError):
+                out.append({"rank": r, "phase": "(no heartbeat file)"})
+        return out
+
+    # if one rank dies the others would wait in a collective for ever: end them (by PID) after a grace period; if ALL of them
+    # block (every rank waits in a collective) the children's own watchdogs fire after --stall-s, and this parent is the
+    # backstop at --deadline-s (+ a margin so that the children get to report first)
+    t_start, grace, killed = time.time(), None, False
     while any(p.poll() is None for p in procs):
         rcs = [p.poll() for p in procs]
-        if deadline is None and any(rc not in (None, 0) for rc in rcs):
-            deadline = time.time() + 20.0
-        if deadline is not None and time.time() > deadline:
+        if grace is None and any(rc not in (None, 0) for rc in rcs):
+            grace = time.time() + 20.0
+        if (grace is not None and time.time() > grace) or time.time() - t_start > args.deadline_s + 15.0:
+            if not killed:
+                sys.stderr.write("[bench] ending the remaining ranks; last heartbeat of every rank:\n")
+                for st in last_phases():
+                    sys.stderr.write("[bench]   " + json.dumps(st) + "\n")
+            killed = True
             for p in procs:
                 if p.poll() is None:
                     p.kill()
@@ -126,6 +233,11 @@ def spawn_ranks(args):
     worst = max((abs(rc) for rc in rcs), default=0)
     if worst:
         sys.stderr.write(f"[bench] rank exit codes: {rcs}\n")
+        if not killed:
+            for st in last_phases():
+                sys.stderr.write("[bench]   " + json.dumps(st) + "\n")
+    import shutil
+    shutil.rmtree(hb_dir, ignore_errors=True)
     return min(worst, 255)
 
 
@@ -162,6 +274,7 @@ def worker(args):
     if os.environ.get("SGM_BENCH_SAME_GPU"):      # testing aid: all ranks on device 0 (with the mock transport)
         local_rank = 0
     sg.init(local_rank)                           # fails loudly (SGM_ERR_NO_DEVICE) without a GPU
+    hb = Heartbeat(rank, args.stall_s, args.deadline_s, sg)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # every kernel of the library is launched on THIS torch stream, so torch.cuda.Event
@@ -178,6 +291,7 @@ def worker(args):
         # launch stream) -- are the only RCCL communicators of the process.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        hb.phase("control plane: torch.distributed gloo rendezvous")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def barrier():
@@ -202,6 +316,7 @@ def worker(args):
 
     comm = None
     if use_dist:
+        hb.phase("RCCL bootstrap: unique id broadcast + sgm_comm_init (ncclCommInitRank)")
         uid = [sg.Comm.unique_id() if rank == 0 else None, sg.Comm.unique_id() if (rank == 0 and args.halo_comm) else None]
         dist.broadcast_object_list(uid, src=0)
         comm = sg.Comm(rank, world, uid[0], uid[1])
@@ -209,6 +324,7 @@ def worker(args):
     def make_matrix(kind):
         """(A, n_loc, n_glob, i0, nnz, label, host_arrays)"""
         host = None
+        hb.phase(f"{kind}: generating this rank's rows + create" + (" (sgm_csr_create_dist: collective)" if use_dist else ""))
         if kind == "c2":
             nx, ny = args.nx, args.ny
             n_loc = nx * ny
@@ -284,7 +400,8 @@ def worker(args):
         torch.cuda.synchronize()
         return float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e-3
 
-    def cg_run(A, n_loc, n_glob, its_cap, profile_phases=False):
+    def cg_run(A, n_loc, n_glob, its_cap, profile_phases=False, tag=""):
+        hb.phase(f"{tag}: CG, {its_cap} fixed iterations (warm-up solve, timed solve" + (", profiled solve)" if profile_phases else ")"))
         s = sg.cg(1e-300)
         s.set_max_iter(its_cap)
         s.setup(A)
@@ -320,15 +437,19 @@ def worker(args):
     resident_rank, moved_rank = A.footprint()
     inner = max(1, args.spmv_per_step)
 
+    hb.phase(f"{args.workload}: first product + self-check against the stored-order row sums")
     A.matvec(x, y)
     torch.cuda.synchronize()
     check_main = selfcheck(args.workload, y, n_loc, i0)
     if not check_main:
         sys.stderr.write(f"[bench] rank {rank}: the product differs from its row sums in stored order -- not a measurement\n")
+    hb.phase(f"{args.workload}: {args.warmup} warm-up steps of {inner} products")
     for _ in range(args.warmup):
         for _ in range(inner):
             A.matvec(x, y)
+    hb.phase(f"{args.workload}: barrier before the timed steps")
     barrier()
+    hb.phase(f"{args.workload}: {args.steps} timed steps of {inner} products (halo exchange per product when N > 1)")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         for _ in range(inner):
@@ -343,6 +464,7 @@ def worker(args):
     effective = alg_all * launches / dt / 1e9
 
     # ---- dominant kernel with HIP events on the launch stream -------------------------------
+    hb.phase(f"{args.workload}: per-launch HIP-event timing (warm and cold)")
     k_avg = time_kernel(A, x, y)
     main_kernel = A.kernel
     scratch = torch.zeros(512 * 1024 * 1024 // 8, dtype=torch.float64, device=dev)     # 512 MiB
@@ -361,6 +483,7 @@ def worker(args):
 
     variants = {}
     if not use_dist and not args.no_variants and args.workload == "c2":
+        hb.phase("c2: the other CSR kernels on the same matrix")
         variants["sliced 4-bit codes, 2 rows per lane (default for rows <= 8 entries / <= 15 offsets)"] = \
             variant_entry(A, k_avg, k_cold)
         for vlabel, opts in (("offset_dict_u8_codes, LDS-staged row-owner kernel (stencil-like matrices with longer rows / more offsets)",
@@ -396,7 +519,7 @@ def worker(args):
     cg = None
     in_solver_ms = None
     if args.cg_steps > 0:
-        its, dtc, res2, cg_phases = cg_run(A, n_loc, n_glob, args.cg_steps, profile_phases=True)
+        its, dtc, res2, cg_phases = cg_run(A, n_loc, n_glob, args.cg_steps, profile_phases=True, tag=args.workload)
         # moved per iteration: the SpMV's bytes + 8 vector passes (q written by the SpMV is counted there;
         # r-update reads r,q writes r; x/p update reads x,p,r writes x,p) = 64 n;
         # SURVEY §8d grades on the fused floor B_csr + 72 n of the REFERENCE layout -- both reported
@@ -414,22 +537,29 @@ def worker(args):
     # ---- N = 1: the fixed cost of the RCCL code path (real librccl, ONE rank) on the same matrix ----------------
     dist_overhead = None
     if rank == 0 and world == 1 and not use_dist and not args.no_dist_overhead and args.cg_steps > 0 and args.workload == "c2":
+        hb.phase("c2: CG through the RCCL code path with one rank (dist_overhead_1rank)")
         dist_overhead = dist_overhead_leg(args, sg, torch, dev, cg["iters_per_s"] if cg else None)
 
     # ---- CPU baseline (rank 0, N = 1): the reference itself on the SAME matrix ----------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu and host is not None:
+        hb.phase("cpu_baseline: the reference + the oracle port on the host cores (about 25 s)")
         cpu = cpu_baseline(args, host, n_loc)
 
     # ---- C1 (BASELINE configs[0], the reference's own CPU-sized case): tridiagonal n = 10,000, CG to 1e-16 ----
     c1 = None
     if rank == 0 and world == 1 and not args.no_cpu:
+        hb.phase("c1: tridiagonal n = 10,000, CG to 1e-16 (device, device in the reference's dot order, reference on the host)")
         c1 = c1_leg(sg, P, torch, dev)
 
     # ---- preconditioned solves, time to solution on the 1000^2 grid (setup + solve): CG, ILDU(0)-PCG in natural and colour order ----
     pcg = None
     if rank == 0 and world == 1 and not args.no_pcg:
+        hb.phase("pcg_time_to_solution: CG vs ILDU(0)-PCG (natural / colour order), 1000^2")
         pcg = pcg_leg(sg, P, torch, dev)
+        if args.pcg_nx and args.pcg_nx != 1000:
+            hb.phase(f"pcg_time_to_solution: the same at {args.pcg_nx}^2 (C2 size)")
+            pcg = {"grid_1000": pcg, f"grid_{args.pcg_nx}": pcg_leg(sg, P, torch, dev, nx=args.pcg_nx)}
 
     kernel_sha = csrc_sha1()
     A.destroy()
@@ -440,11 +570,13 @@ def worker(args):
     if not args.no_c5 and args.workload == "c2":
         A5, n5, n5g, i5, nnz5, label5, _ = make_matrix("c5")
         x5, y5 = vectors(A5, n5, i5)
+        hb.phase("c5: first product + self-check")
         A5.matvec(x5, y5)
         torch.cuda.synchronize()
         check_c5 = selfcheck("c5", y5, n5, i5)
         if not check_c5:
             sys.stderr.write(f"[bench] rank {rank}: the C5 product differs from its row sums in stored order\n")
+        hb.phase("c5: 3 + 20 products between barriers")
         for _ in range(3):
             A5.matvec(x5, y5)
         barrier()
@@ -455,7 +587,7 @@ def worker(args):
         dt5 = max_over_ranks(time.perf_counter() - t0) / 20
         _, mv5 = A5.footprint()
         mv5_all = sum_over_ranks(mv5)
-        its5, dtc5, res25, phases5 = cg_run(A5, n5, n5g, args.c5_cg_steps, profile_phases=use_dist)
+        its5, dtc5, res25, phases5 = cg_run(A5, n5, n5g, args.c5_cg_steps, profile_phases=use_dist, tag="c5")
         moved5 = sum_over_ranks(mv5 + 64 * n5)
         c5 = {"workload": label5, "n": n5g, "nnz": int(sum_over_ranks(nnz5)), "kernel": A5.kernel,
               "spmv_ms": 1e3 * dt5, "spmv_GB/s_moved": mv5_all / dt5 / 1e9,
@@ -468,12 +600,46 @@ def worker(args):
               "note": "north_star target: cg_iters_per_s at n_gpus = 8 >= 6 x the n_gpus = 1 figure"}
         A5.destroy()
 
-    # the streaming regime beside the headline figure: the 464^3 product on this GPU (7.6 GB moved: nothing stays on chip)
-    roofline_other = None
-    if c5 is not None and world == 1:
-        roofline_other = {"c5_464cubed_one_gpu": {"kernel": c5["kernel"], "spmv_ms": c5["spmv_ms"],
-                                                   "frac_of_hbm_peak_on_moved_bytes": c5["spmv_frac_of_hbm_peak"],
-                                                   "cg_frac_of_hbm_peak_on_moved_bytes": c5["cg_frac_of_hbm_peak"]}}
+    # ---- N = 1: the other single-GPU configs of BASELINE.json (C3: configs[2], C4: configs[3]) ---------------------
+    c3 = c4 = None
+    if rank == 0 and world == 1 and not use_dist and args.workload == "c2":
+        if not args.no_c3:
+            hb.phase("c3: 1-D advection-diffusion n = 1e7: SpMV, BiCGStab, GMRES(30)")
+            c3 = c3_leg(sg, P, torch, dev, n=args.c3_n, iters=args.c3_iters)
+        if not args.no_c4:
+            hb.phase("c4: ELLPACK random digraph n = 5e6, degree 32: generate on the device, create, SpMV")
+            c4 = c4_leg(sg, P, torch, dev, n=args.c4_n)
+
+    # What the driver's record keeps of this line is the contract keys and the SCALAR entries of `roofline`, `config` and
+    # `cpu_baseline` (nested objects and other top-level keys are reduced to their names): the whole metric -- SpMV GB/s AND CG
+    # iterations/s on C2 -- and the other configs therefore sit in `roofline` as flat scalars (names <= 40 characters), every
+    # fraction named after the bytes it is made of (see spmv_fracs); the nested legs stay in the line for readers of stdout.
+    flat = {}
+    if cg is not None:
+        flat.update({"c2_cg_iters_per_s": cg["iters_per_s"], "c2_cg_ms_per_iter": cg["ms_per_iter"],
+                     "c2_cg_frac_moved": cg["frac_of_hbm_peak"],
+                     "c2_cg_eff_GBs_on_survey_floor": cg["effective_GBs_on_survey_floor"]})
+    if c5 is not None:
+        tag = "c5_1gpu" if world == 1 else f"c5_{world}gpu"
+        flat.update({f"{tag}_spmv_ms": c5["spmv_ms"], f"{tag}_spmv_frac_moved": c5["spmv_frac_of_hbm_peak"],
+                     f"{tag}_cg_iters_per_s": c5["cg_iters_per_s"], f"{tag}_cg_frac_moved": c5["cg_frac_of_hbm_peak"]})
+    if c3 is not None:
+        flat.update({"c3_spmv_ms": c3["spmv_ms"], "c3_spmv_frac_moved": c3["frac_moved"],
+                     "c3_spmv_layout_compression": c3["layout_compression"],
+                     "c3_bicgstab_iters_per_s": c3["bicgstab"]["iters_per_s"], "c3_bicgstab_frac_moved": c3["bicgstab"]["frac_moved"],
+                     "c3_gmres30_iters_per_s": c3["gmres30"]["iters_per_s"], "c3_gmres30_frac_moved": c3["gmres30"]["frac_moved"]})
+    if c4 is not None:
+        flat.update({"c4_spmv_ms": c4["spmv_ms"], "c4_spmv_frac_moved": c4["frac_moved"],
+                     "c4_spmv_frac_survey_bytes": c4["frac_survey_bytes"], "c4_product_bit_exact": c4["product_bit_exact"]})
+    if pcg is not None:
+        for key, leg in (pcg.items() if "cg" not in pcg else [("grid_1000", pcg)]):
+            g = key.replace("grid_", "")
+            co = leg["ildu0_colour_order"]
+            flat[f"pcg{g}_cg_solve_s"] = leg["cg"]["setup_s"] + leg["cg"]["solve_s"]
+            flat[f"pcg{g}_ildu_natural_total_s"] = leg["ildu0_natural_order"]["setup_s"] + leg["ildu0_natural_order"]["solve_s"]
+            flat[f"pcg{g}_ildu_colour_total_s"] = co["ordering_s"] + co["permutation_s"] + co["setup_s"] + co["solve_s"]
+    roofline_other = {"c2_cg": cg, "c3": c3, "c4": c4,
+                      "c5_on_this_many_gpus": {k: v for k, v in (c5 or {}).items() if k != "phases"} or None}
 
     # HBM bytes per launch from the PMC counters cannot be collected inside this process; they come
     # from the committed rocprofv3 --pmc passes over this same command (profiles/<round>/), and are
@@ -500,7 +666,7 @@ def worker(args):
                        "value_counts": "bytes the kernel moves by construction (stored format + x + y), not the reference layout's"},
             "effective_GBs_on_reference_bytes": effective,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, **flat,
                          "kernel": main_kernel, "moved_bytes_per_launch": moved_rank,
                          "algorithmic_bytes_per_launch_reference_layout": alg_bytes_rank,
                          "effective_GBs_on_reference_bytes": alg_bytes_rank / k_avg / 1e9,
@@ -513,19 +679,154 @@ def worker(args):
                          "note": "achieved = moved_bytes_per_launch / avg_launch_ms: the sliced kernel reads 8W+4 bytes per "
                                  "row of its own layout (W = 5) + x once + y once.  cold_* = the same launch after 512 MiB "
                                  "of unrelated writes (nothing of the previous product left in L2 / Infinity Cache)"},
-            "spmv_variants": variants or None, "cg": cg, "dist_overhead_1rank": dist_overhead, "c5_strong_scaling": c5, "c1_reference_sized": c1, "pcg_time_to_solution": pcg, "cpu_baseline": cpu,
+            "spmv_variants": variants or None, "cg": cg, "dist_overhead_1rank": dist_overhead, "c5_strong_scaling": c5,
+            "c3": c3, "c4": c4, "c1_reference_sized": c1, "pcg_time_to_solution": pcg, "cpu_baseline": cpu,
             "selfcheck": {"product_bit_exact_on_every_rank": check_main,
                           "what": "every local row of one timed-workload product == its sum evaluated with torch in stored "
                                   "order from x(i) = sin(0.001 i), on every rank (halo values included)"},
         }
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
+    hb.phase("teardown")
     if use_dist:
         barrier()
         comm.destroy()
         dist.destroy_process_group()
-    if not check_main or (c5 is not None and not c5["product_bit_exact_on_every_rank"]):
+    hb.finish()
+    if not check_main or (c5 is not None and not c5["product_bit_exact_on_every_rank"]) or \
+            any(leg is not None and not leg["product_bit_exact"] for leg in (c3, c4)):
         sys.exit(3)          # a product that differs is not a measurement
+
+
+# ------------------------------------------------------------------------------------------ #
+# Two byte counts per product, kept apart by NAME everywhere in the line:
+#   frac_moved        = bytes the running kernel moves by construction (sgm_mat_footprint: its stored format as it reads it
+#                       + x once + y once) / time / 8 TB/s.  Never above 1.
+#   frac_survey_bytes = SURVEY 8d's algorithmic bytes of the REFERENCE layout (B_csr / B_ell) / time / 8 TB/s -- reported only
+#                       where the kernel moves at least those bytes (then it is a true lower bound on achieved HBM); where the
+#                       kernel reads a COMPRESSED layout (moved < survey bytes) the figure would be a rate no memory system
+#                       delivered, so the line carries `layout_compression` = survey / moved instead and leaves it null.
+def spmv_fracs(t, moved, survey):
+    out = {"spmv_ms": 1e3 * t, "moved_bytes_per_launch": int(moved), "survey_bytes_per_launch": int(survey),
+           "frac_moved": moved / t / 1e9 / HBM_PEAK_GBS,
+           "frac_survey_bytes": (survey / t / 1e9 / HBM_PEAK_GBS) if moved >= survey else None,
+           "layout_compression": survey / moved}
+    return out
+
+
+def timed_launches(torch, fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e-3 / reps
+
+
+def fixed_iterations(sg, torch, mk, A, n, b, its):
+    s = mk()
+    s.set_max_iter(its)
+    s.setup(A)
+    u = torch.zeros(n, dtype=torch.float64, device=b.device)
+    s.solve(A, u, b, check=False)
+    u.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s.solve(A, u, b, check=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = (int(s.last_iterations), dt, float(s.res2))
+    s.destroy()
+    return out
+
+
+def c3_leg(sg, P, torch, dev, n=10_000_000, iters=300):
+    """BASELINE configs[2]: 1-D advection-diffusion (nonsymmetric tridiagonal, test/solver_test_advection_diffusion_1d.f90:64-82
+    at n = 1e7), generated on the device: SpMV, BiCGStab and GMRES(30) for a FIXED number of iterations (SURVEY 8d C3:
+    the problem does not converge at this size; iterations/s and the residual are what is reported)."""
+    dx, c = 1.0 / (n + 1), 0.5
+    ptr, node, val = P.tridiag_csr_torch(n, 2.0, -1.0 + c * dx / 2, -1.0 - c * dx / 2, dev)
+    nnz = int(val.numel())
+    torch.cuda.synchronize()
+    A = sg.csr_matrix(n, n, ptr, node, val)
+    x = torch.sin(0.001 * torch.arange(1, n + 1, dtype=torch.float64, device=dev))
+    y = torch.zeros(n, dtype=torch.float64, device=dev)
+    A.matvec(x, y)
+    torch.cuda.synchronize()
+    # every row against its sum in stored order (lower, diagonal, upper), torch elementwise ops: products rounded, then added
+    lo, up = -1.0 - c * dx / 2, -1.0 + c * dx / 2
+    z = torch.zeros(n, dtype=torch.float64, device=dev)
+    z[1:] = z[1:] + lo * x[:-1]
+    z = z + 2.0 * x
+    z[:-1] = z[:-1] + up * x[1:]
+    ok = bool(torch.equal(0.0 + z, y))
+    del z, ptr, node, val
+    t = timed_launches(torch, lambda: A.matvec(x, y), 50)
+    _, moved = A.footprint()
+    survey = spmv_bytes(n, n, nnz)
+    out = {"workload": f"C3 1-D advection-diffusion CSR, n={n}, nnz={nnz} (generated on the device)", "kernel": A.kernel,
+           "product_bit_exact": ok}
+    out.update(spmv_fracs(t, moved, survey))
+    b = torch.full((n,), 2.0 * dx * dx, dtype=torch.float64, device=dev)
+    # moved bytes per iteration.  BiCGStab: two products + 12 vector passes (SURVEY 8d's fused floor is 14 passes on the
+    # reference layout; the two product outputs are counted inside `moved`).  GMRES(30) with blocked CGS-2 at basis size j:
+    # one product + (3 j + 6) passes; averaged over a restart cycle j = 1..30, + the cycle's x update (32 passes) and residual product
+    its, dt, res2 = fixed_iterations(sg, torch, lambda: sg.bicgstab(1e-300), A, n, b, iters)
+    per_it = 2 * moved + 96 * n
+    out["bicgstab"] = {"iterations": its, "iters_per_s": its / dt, "ms_per_iter": 1e3 * dt / its, "final_res2": res2,
+                       "moved_bytes_per_iter": per_it, "frac_moved": per_it * its / dt / 1e9 / HBM_PEAK_GBS}
+    its, dt, res2 = fixed_iterations(sg, torch, lambda: sg.gmres(1e-300, 30), A, n, b, iters)
+    cyc = sum(moved + 8 * n * (3 * j + 6) for j in range(1, 31)) + 8 * n * 32 + moved
+    out["gmres30"] = {"iterations": its, "iters_per_s": its / dt, "ms_per_iter": 1e3 * dt / its, "final_res2": res2,
+                      "moved_bytes_per_restart_cycle": cyc, "frac_moved": cyc * (its / 30.0) / dt / 1e9 / HBM_PEAK_GBS,
+                      "orthogonalisation": "blocked CGS-2 (3 passes + 3 reductions per step)"}
+    A.destroy()
+    return out
+
+
+def c4_leg(sg, P, torch, dev, n=5_000_000, d=32, both_kernels=True):
+    """BASELINE configs[3]: ELLPACK random digraph, degree 32, n = 5e6 (per-row 64-bit LCG, duplicates
+    rejected, val(k,i) = 1/(k + (i mod 7))), generated ON THE DEVICE (the host generator took 8.9 s): SpMV with the
+    default kernel (column-blocked two-phase product) and with the plain slot-major kernel."""
+    t0 = time.perf_counter()
+    node, val = P.random_regular_ell_torch(n, d, 12345, dev)
+    torch.cuda.synchronize()
+    gen_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    A = sg.ellpack_matrix(n, n, node, val)
+    sg.synchronize()
+    create_s = time.perf_counter() - t0
+    x = torch.sin(0.001 * torch.arange(1, n + 1, dtype=torch.float64, device=dev))
+    y = torch.zeros(n, dtype=torch.float64, device=dev)
+    A.matvec(x, y)
+    torch.cuda.synchronize()
+    # ellpack_matvec_add's loop (ellpack_matrices.f90:652-661) with torch: all d slots in slot order, products rounded, then added
+    z = torch.zeros(n, dtype=torch.float64, device=dev)
+    for k in range(d):
+        z = z + val[:, k] * x[(node[:, k] - 1).to(torch.int64)]
+    ok = bool(torch.equal(0.0 + z, y))
+    del z, node, val
+    survey = 12 * n * d + 16 * n
+    out = {"workload": f"C4 ELLPACK random digraph, degree {d}, n={n} (generated on the device)", "generate_s": gen_s,
+           "create_s": create_s, "resident_bytes": A.footprint()[0], "product_bit_exact": ok}
+    t = timed_launches(torch, lambda: A.matvec(x, y), 30)
+    out["kernel"] = A.kernel
+    out.update(spmv_fracs(t, A.footprint()[1], survey))
+    if both_kernels:
+        sg.set_option("ell_colblock", 0)
+        try:
+            t2 = timed_launches(torch, lambda: A.matvec(x, y), 15)
+            e = {"kernel": A.kernel}
+            e.update(spmv_fracs(t2, A.footprint()[1], survey))
+            out["slot_major_kernel"] = e
+        finally:
+            sg.set_option("ell_colblock", 1)
+    A.destroy()
+    return out
 
 
 # ------------------------------------------------------------------------------------------ #

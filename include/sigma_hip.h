@@ -144,6 +144,12 @@ int sgm_set_option(const char *name, int value);
  * tab_out may be NULL to ask for iters_out only; capacity in entries (>= iters * grid).          */
 int sgm_slice_sched_host(int64_t n_slices, int64_t period_rows, int32_t grid, int32_t band_slices,
                          int32_t *tab_out, int64_t capacity, int32_t *iters_out);
+/* sgm_heartbeat: where the thread that drives the library is right now -- callable from ANOTHER host thread while that one
+ * is blocked in a synchronisation or a collective (bench.py's watchdog: a multi-GPU run that hangs says where).
+ * out6 = {phase code, beats (bumped at every phase change and solver batch), iterations the running solve has queued,
+ * halo exchanges posted, all-reduces posted, solver calls entered}; phase_name (optional) receives the phase in words.
+ * Two ranks stuck with different post counts name the rank that fell behind.  No HIP call; never blocks.              */
+int sgm_heartbeat(int64_t *out6, char *phase_name, int len);
 int sgm_malloc(void **p, size_t bytes);   /* HBM buffer for hosts without a device allocator */
 int sgm_free(void *p);
 int sgm_memcpy(void *dst, const void *src, size_t bytes, int kind); /* 0 h2d, 1 d2h, 2 d2d */

@@ -910,6 +910,16 @@ def slice_sched_host(n_slices, period_rows, grid, band_slices=64):
     return tab.reshape(it.value, grid)
 
 
+def heartbeat():
+    """sgm_heartbeat: where the thread driving the library is right now; callable from another thread (no HIP call).
+    {"phase": words, "phase_code", "beats", "iteration", "halo_posts", "allreduce_posts", "solves"}."""
+    out = (C.c_int64 * 6)()
+    name = C.create_string_buffer(160)
+    lib().sgm_heartbeat(out, name, C.c_int(160))
+    return {"phase": name.value.decode(), "phase_code": int(out[0]), "beats": int(out[1]), "iteration": int(out[2]),
+            "halo_posts": int(out[3]), "allreduce_posts": int(out[4]), "solves": int(out[5])}
+
+
 def dot(a, b):
     pa, wa, _k1 = _arg(a, np.float64)
     pb, wb, _k2 = _arg(b, np.float64)

@@ -18,8 +18,6 @@
 
 namespace sgm {
 
-int build_csr_part(Part &p, int32_t n, int32_t ncol_own, int32_t n_halo, int64_t nnz,
-                   const int32_t *ptr1, const int32_t *node1, const double *val, int where);
 void free_part(Part &p);
 void set_interior_range(Part &p, const int32_t *ptr1, const int32_t *node1);
 __global__ void k_gather(double *__restrict__ dst, const double *__restrict__ src,
@@ -129,6 +127,9 @@ int halo_exchange(sgm_mat A, double *const *xext, hipStream_t st)
             if (nb.send_count)
                 hipLaunchKernelGGL(k_gather, dim3((nb.send_count + kBlock - 1) / kBlock), dim3(kBlock), 0,
                                    st, nb.send_buf, (const double *)xext[0], nb.send_idx, nb.send_count);
+        const int hb_prev = g_hb.phase;
+        hb_phase(HB_HALO_POST);
+        g_hb.halo_posts = g_hb.halo_posts + 1;
         SGM_NCCL(g_nccl.GroupStart());
         for (auto &nb : p.nbrs) {
             if (nb.send_count) SGM_NCCL(g_nccl.Send(nb.send_buf, nb.send_count, ncclFloat64, nb.peer, comm, st));
@@ -137,6 +138,7 @@ int halo_exchange(sgm_mat A, double *const *xext, hipStream_t st)
                                      nb.peer, comm, st));
         }
         SGM_NCCL(g_nccl.GroupEnd());
+        hb_phase(hb_prev);
         return SGM_OK;
     }
     // in-process partitions: the sender's list is gathered straight into the peer's halo
@@ -175,8 +177,12 @@ int allreduce_slots(sgm_mat A, double *const *slot_ptrs, int count)
     if (A->comm) {
         if (A->comm->nranks == 1 && !g_force_collectives) return SGM_OK;
         prof_begin(PH_ALLREDUCE, st);
+        const int hb_prev = g_hb.phase;
+        hb_phase(HB_ALLREDUCE_POST);
+        g_hb.allreduce_posts = g_hb.allreduce_posts + 1;
         SGM_NCCL(g_nccl.AllReduce(slot_ptrs[0], slot_ptrs[0], (size_t)count, ncclFloat64, ncclSum,
                                   (ncclComm_t)A->comm->nccl, st));
+        hb_phase(hb_prev);
         prof_end(PH_ALLREDUCE, st);
         return SGM_OK;
     }
@@ -435,6 +441,21 @@ int sgm_csr_create_partitioned(sgm_mat *out, int32_t nparts, const int64_t *row_
     if (!out || nparts < 1 || !row_starts || !ptr || nrow != ncol || row_starts[0] != 0 ||
         row_starts[nparts] != nrow)
         return fail(SGM_ERR_BAD_ARG, "sgm_csr_create_partitioned: bad argument (square matrices only)");
+    // host arrays, cut up on the host below: check them here (sgm_csr_create's checks, same codes)
+    if (ptr[0] != 1) return fail(SGM_ERR_BAD_ARG, "csr create: ptr(1) = %d, expected 1 (1-based row pointers)", ptr[0]);
+    for (int32_t i = 0; i < nrow; ++i)
+        if (ptr[i + 1] < ptr[i])
+            return fail(SGM_ERR_BAD_ARG, "csr create: row pointers decrease at row %d: ptr(%d) = %d > ptr(%d) = %d", i + 1, i + 1, ptr[i],
+                        i + 2, ptr[i + 1]);
+    if ((int64_t)ptr[nrow] - 1 != nnz)
+        return fail(SGM_ERR_DIMS, "csr create: ptr(%d) - 1 = %lld entries, but nnz = %lld", nrow + 1, (long long)ptr[nrow] - 1, (long long)nnz);
+    if (nnz && (!node || !val)) return fail(SGM_ERR_BAD_ARG, "sgm_csr_create_partitioned: null arrays");
+    for (int p = 0; p < nparts; ++p)
+        if (row_starts[p + 1] < row_starts[p]) return fail(SGM_ERR_BAD_ARG, "sgm_csr_create_partitioned: row_starts must not decrease");
+    for (int32_t i = 0; i < nrow; ++i)
+        for (int64_t k = ptr[i] - 1; k < ptr[i + 1] - 1; ++k)
+            if (node[k] < 1 || node[k] > ncol)
+                return fail(SGM_ERR_DIMS, "csr create: node(%lld) = %d in row %d is outside 1..%d", (long long)k + 1, node[k], i + 1, ncol);
     MatGuard g;
     sgm_mat A = g.A = new sgm_mat_s;
     A->fmt = SGM_FMT_CSR;
@@ -623,22 +644,34 @@ int sgm_csr_create_dist_rect(sgm_mat *out, sgm_comm comm, const int64_t *row_sta
     A->halo_cols = halo;
     A->parts.resize(1);
     Part &p = A->parts[0];
-    if (local_rc != SGM_OK) {
-        // (rejected rows: nothing is built; this rank only takes part in the all-gather that spreads the verdict)
-    } else if (where == SGM_DEVICE) {
-        // values stay on the device; only the renumbered node array is re-uploaded
-        int32_t *dnode = nullptr;
-        SGM_TRY(dalloc(&dnode, (size_t)std::max<int64_t>(nnz, 1)));
-        g.scratch.push_back(dnode);
-        if (nnz) SGM_HIP(hipMemcpyAsync(dnode, lnode.data(), (size_t)nnz * 4, hipMemcpyHostToDevice, st));
-        SGM_TRY(build_csr_part(p, n, nc, (int32_t)halo.size(), nnz, ptr, dnode, val, SGM_DEVICE));
-    } else {
-        SGM_TRY(build_csr_part(p, n, nc, (int32_t)halo.size(), nnz, ptr_h, lnode.data(), val, SGM_HOST));
+    // Building the part can fail too (a row pointer array that is not monotone, device memory): that verdict has to travel like
+    // the ones above -- a rank that returned here would leave its peers waiting in the all-gather below.
+    auto build_local = [&]() -> int {
+        if (where == SGM_DEVICE) {
+            // values stay on the device; only the renumbered node array is re-uploaded
+            int32_t *dnode = nullptr;
+            SGM_TRY(dalloc(&dnode, (size_t)std::max<int64_t>(nnz, 1)));
+            g.scratch.push_back(dnode);
+            if (nnz) SGM_HIP(hipMemcpyAsync(dnode, lnode.data(), (size_t)nnz * 4, hipMemcpyHostToDevice, st));
+            return build_csr_part(p, n, nc, (int32_t)halo.size(), nnz, ptr, dnode, val, SGM_DEVICE);
+        }
+        return build_csr_part(p, n, nc, (int32_t)halo.size(), nnz, ptr_h, lnode.data(), val, SGM_HOST);
+    };
+    if (local_rc == SGM_OK) {       // (rejected rows: nothing is built; the rank only takes part in the all-gather that spreads the verdict)
+        local_rc = build_local();
+        if (local_rc != SGM_OK) {
+            local_msg = g_err;
+            if (R == 1) return local_rc;
+            want.assign((size_t)R, 0);
+            want[me] = -1;
+            req.clear();
+        }
     }
     p.row_begin = r0;
     if (local_rc == SGM_OK) set_interior_range(p, ptr_h, lnode.data());
     { std::vector<int32_t>().swap(hnode); std::vector<int32_t>().swap(lnode); }
 
+    struct HbScope { int prev; HbScope() : prev(g_hb.phase) { hb_phase(HB_CREATE_DIST); } ~HbScope() { hb_phase(prev); } } hb_scope;
     if (R > 1) {
         // all ranks learn the full want matrix, then neighbours swap their request lists
         int32_t *d_want = nullptr, *d_all = nullptr, *d_req = nullptr;

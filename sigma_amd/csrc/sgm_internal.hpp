@@ -82,6 +82,22 @@ int finish();   // hipStreamSynchronize unless async
 // pageable host <-> device, chunked through pinned buffers (synchronous)
 int copy_big(void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
 
+// Heartbeat (sgm_heartbeat): where the host thread of this process is inside the library, readable from ANOTHER thread while
+// that thread is blocked in a synchronisation or a collective -- what makes a hang on a multi-GPU run say where it hangs.
+// Plain counters written by the one thread that drives the library; a reader only ever looks.
+enum { HB_IDLE = 0, HB_CREATE_DIST = 1, HB_HALO_POST = 2, HB_ALLREDUCE_POST = 3, HB_SOLVER_ENQUEUE = 4, HB_SOLVER_WAIT = 5,
+       HB_SEQ_CHAIN = 6, HB_TRANSPOSE_DIST = 7, HB_PHASES = 8 };
+struct Heartbeat {
+    volatile int32_t phase = HB_IDLE;
+    volatile int64_t beats = 0;            // bumped at every phase change and every solver batch
+    volatile int64_t iteration = 0;        // iterations of the running solve the host has queued so far
+    volatile int64_t halo_posts = 0;       // halo exchanges posted (send/recv groups) since sgm_init
+    volatile int64_t allreduce_posts = 0;  // all-reduces posted
+    volatile int64_t solves = 0;           // solver calls entered
+};
+extern Heartbeat g_hb;
+inline void hb_phase(int ph) { g_hb.phase = ph; g_hb.beats = g_hb.beats + 1; }
+
 template <class T>
 int dalloc(T **p, size_t count)
 {
@@ -256,6 +272,10 @@ int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
                const SpmvDots *dots, const int *flag_done, int *grid_out, int gen = 0x7fffffff,
                bool chain = false);
 
+// upload one CSR row block (1-based arrays as the Fortran holds them) and build its device formats; `validate` checks the
+// index arrays on the device as they are converted (SGM_ERR_BAD_ARG / SGM_ERR_DIMS naming the first offending row)
+int build_csr_part(Part &p, int32_t n, int32_t ncol_own, int32_t n_halo, int64_t nnz,
+                   const int32_t *ptr1, const int32_t *node1, const double *val, int where, bool validate = true);
 int spmv_grid(const Part &p);
 int matvec_plain(sgm_mat A, const double *x, double *y);     // device vectors, sgm_mat_matvec's layout, stream-ordered
 // "csr_lean": the CSR-order arrays of a part that kept only its sliced form, on demand (no-op otherwise)

@@ -370,7 +370,7 @@ int sgm_mat_left_permute(sgm_mat A, const int32_t *p, int where)
         SGM_TRY(sgm_invalidate_transpose(A));
         return rebuild_ell_formats(pt);
     }
-    SGM_TRY(csr_need_arrays(pt));           // (a part that kept only its sliced form: the CSR-order arrays come back first)
+    if (int rcn = csr_need_arrays(pt)) { dfree(dp); return rcn; }           // (a part that kept only its sliced form: the CSR-order arrays come back first)
     int32_t *len2 = nullptr, *rowptr2 = nullptr, *col2 = nullptr;
     double *val2 = nullptr;
     void *tmp = nullptr;
@@ -423,7 +423,7 @@ int sgm_mat_right_permute(sgm_mat A, const int32_t *p, int where)
         SGM_TRY(sgm_invalidate_transpose(A));
         return rebuild_ell_formats(pt);
     }
-    SGM_TRY(csr_need_arrays(pt));
+    if (int rcn = csr_need_arrays(pt)) { dfree(dp); return rcn; }
     if (pt.nnz) hipLaunchKernelGGL(k_perm_cols, dim3(vec_grid(pt.nnz)), dim3(kBlock), 0, g_rt.stream, pt.nnz, pt.col, (const int32_t *)dp);
     const bool ok = hipStreamSynchronize(g_rt.stream) == hipSuccess && hipGetLastError() == hipSuccess;
     dfree(dp);

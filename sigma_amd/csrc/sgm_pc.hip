@@ -2364,7 +2364,15 @@ int sgm_pc_apply(sgm_pc pc, const double *r, double *z, int where)
     sgm_mat_s view;
     view.parts.resize(1);
     view.parts[0].n = pc->n;
-    const double *rs[1] = {sr.dev};
+    // in-place apply (r == z on the device) through a pipelined sweep: a sweep that gives up has scattered its "not yet
+    // written" patterns over z = r by the time anyone notices, so the redo below needs a right-hand side of its own
+    Staged rkeep;
+    if (sr.dev == sz.dev && pc_abort_word(pc)) {
+        SGM_TRY(dalloc(&rkeep.dev, (size_t)pc->n));
+        rkeep.owned = true;
+        SGM_HIP(hipMemcpyAsync(rkeep.dev, sr.dev, (size_t)pc->n * sizeof(double), hipMemcpyDeviceToDevice, g_rt.stream));
+    }
+    const double *rs[1] = {rkeep.dev ? rkeep.dev : sr.dev};
     double *zs[1] = {sz.dev};
     SGM_TRY(pc_apply_parts(pc, &view, rs, zs, nullptr));
     if (int32_t *ab = pc_abort_word(pc)) {

@@ -8,6 +8,7 @@ namespace sgm {
 std::string g_err;
 Runtime g_rt;
 Options g_opt;
+Heartbeat g_hb;
 extern int g_force_collectives;     // sgm_dist.hip
 
 int fail(int code, const char *fmt, ...)
@@ -188,6 +189,22 @@ int sgm_set_option(const char *name, int value)
     if (!strcmp(name, "bicgstab_small")) { g_opt.bicgstab_small = value; return SGM_OK; }
     if (!strcmp(name, "pipeline_spin_limit")) { g_opt.pipeline_spin_limit = std::max(0, value); return SGM_OK; }
     return fail(SGM_ERR_BAD_ARG, "sgm_set_option: unknown option '%s'", name);
+}
+
+int sgm_heartbeat(int64_t *out6, char *phase_name, int len)
+{
+    static const char *const names[HB_PHASES] = {
+        "idle (outside the library, or in a call without collectives)", "create_dist: all-gather of the want matrix / swap of the request lists",
+        "product: halo send/recv group being posted", "dot: all-reduce being posted", "solver: queueing a batch of iterations",
+        "solver: waiting for the queued batch (stream synchronisation; a collective that never completes hangs HERE)",
+        "dot_order=1: running sum travelling rank to rank", "distributed transpose: entry exchange"};
+    const int32_t ph = g_hb.phase;
+    if (out6) {
+        out6[0] = ph; out6[1] = g_hb.beats; out6[2] = g_hb.iteration; out6[3] = g_hb.halo_posts; out6[4] = g_hb.allreduce_posts;
+        out6[5] = g_hb.solves;
+    }
+    if (phase_name && len > 0) snprintf(phase_name, (size_t)len, "%s", ph >= 0 && ph < HB_PHASES ? names[ph] : "?");
+    return SGM_OK;
 }
 
 int sgm_malloc(void **p, size_t bytes)

@@ -1046,7 +1046,10 @@ int read_state(sgm_solver s, int *flag, int64_t *iters, double *res)
     SGM_HIP(hipMemcpyAsync(iters, w.iters, sizeof(int64_t), hipMemcpyDeviceToHost, g_rt.stream));
     SGM_HIP(hipMemcpyAsync(res, w.res, sizeof(double), hipMemcpyDeviceToHost, g_rt.stream));
     if (s->abort_dev) SGM_HIP(hipMemcpyAsync(&s->aborted, s->abort_dev, sizeof(int32_t), hipMemcpyDeviceToHost, g_rt.stream));
+    hb_phase(HB_SOLVER_WAIT);
     SGM_HIP(hipStreamSynchronize(g_rt.stream));
+    hb_phase(HB_SOLVER_ENQUEUE);
+    g_hb.iteration = *iters;
     return SGM_OK;
 }
 
@@ -1524,6 +1527,7 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
         // the host looks at the stop flag once per batch (a stream synchronisation + three small copies, ~20 us): batches
         // grow with the iterations already done -- at most an eighth of them run past the stop as early-exit kernels
         int64_t batch = batch_max > 1 ? std::min<int64_t>(128, std::max<int64_t>(batch_max, k / 8)) : batch_max;
+        if (graphs && batch > kGraphIters) batch -= batch % kGraphIters;     // k stays on the replay grid whatever krylov_graph_after is
         if (s->max_iter > 0) batch = std::min<int64_t>(batch, s->max_iter - k);
         // a solve that has run g_opt.krylov_graph_after iterations goes on as replays of one captured group of kGraphIters (k is
         // a multiple of it here: the parity of the r.r slots repeats)
@@ -1849,6 +1853,7 @@ int run_bicgstab(sgm_solver s, sgm_mat A, double *const *x, const double *const 
         // the host looks at the stop flag once per batch (a stream synchronisation + three small copies, ~20 us): batches
         // grow with the iterations already done -- at most an eighth of them run past the stop as early-exit kernels
         int64_t batch = batch_max > 1 ? std::min<int64_t>(128, std::max<int64_t>(batch_max, k / 8)) : batch_max;
+        if (graphs && batch > kGraphIters) batch -= batch % kGraphIters;     // k stays on the replay grid whatever krylov_graph_after is
         if (s->max_iter > 0) batch = std::min<int64_t>(batch, s->max_iter - k);
         // (replays of one captured group of kGraphIters iterations once the solve has run long enough: see GraphBatch; the
         //  kernels stop on any nonzero flag, so a group needs no generations)
@@ -2154,6 +2159,7 @@ int sgm_solver_solve(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc
         SGM_HIP(hipMemcpyAsync(s->x_backup, sx.dev, (size_t)nvec * 8, hipMemcpyDeviceToDevice, g_rt.stream));
     }
     int rc = SGM_OK;
+    struct HbScope { HbScope() { g_hb.solves = g_hb.solves + 1; g_hb.iteration = 0; hb_phase(HB_SOLVER_ENQUEUE); } ~HbScope() { hb_phase(HB_IDLE); } } hb_scope;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (s->kind == SGM_SOLVER_CG) rc = run_cg(s, A, xs.data(), bs.data(), pc);
         else if (s->kind == SGM_SOLVER_BICGSTAB) rc = run_bicgstab(s, A, xs.data(), bs.data(), pc);

@@ -47,9 +47,40 @@ __global__ void k_dec1(int32_t *a, int64_t n)
     for (; i < n; i += stride) a[i] -= 1;
 }
 
+// Validation of the index arrays a caller hands to sgm_csr_create (the reference prints and exits on a bad
+// index only where it happens to look, sparse_matrix_interfaces.f90:663-687; a wild `node` here would be a
+// GPU memory fault inside the product).  bad[0] = first row i (0-based) whose pointers are malformed --
+// ptr(1) /= 1, ptr(i+1) < ptr(i), ptr(n+1) - 1 /= nnz (reported as row n) --, bad[1] = first entry k (0-based) whose
+// 1-based column lies outside 1..ncols.  Both start at INT64_MAX; the create reads them at the synchronisation
+// it makes anyway.  The pointer pass runs on the 1-based upload BEFORE k_dec1 (it reads a neighbour); the
+// column pass is the decrement itself.
+__global__ void k_check_ptr1(const int32_t *__restrict__ ptr1, int64_t n, int64_t nnz, unsigned long long *bad)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i <= n; i += stride) {
+        const int32_t a = ptr1[i];
+        bool ok = true;
+        if (i == 0) ok = a == 1;
+        if (i < n) ok = ok && ptr1[i + 1] >= a;
+        else ok = ok && (int64_t)a - 1 == nnz;
+        if (!ok) atomicMin(bad, (unsigned long long)i);
+    }
+}
+__global__ void k_dec1_check_cols(int32_t *a, int64_t nnz, int64_t ncols, unsigned long long *bad)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; k < nnz; k += stride) {
+        const int32_t c = a[k];
+        if (c < 1 || c > ncols) atomicMin(bad + 1, (unsigned long long)k);
+        a[k] = c - 1;
+    }
+}
+
 __global__ void k_ell_transpose(const int32_t *__restrict__ node, const double *__restrict__ val,
                                 int32_t *__restrict__ ecol, double *__restrict__ eval,
-                                int32_t n, int32_t max_d)
+                                int32_t n, int32_t max_d, int32_t ncol = 0, unsigned long long *bad = nullptr)
 {
     // in: (max_d, n) column-major = row i contiguous; out: slot-major [k*n + i]
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -59,7 +90,12 @@ __global__ void k_ell_transpose(const int32_t *__restrict__ node, const double *
         const int32_t k = (int32_t)(t / n), i = (int32_t)(t % n);
         // an empty row keeps node = 0 in the reference (it then reads x(0): README.md:71-73);
         // clamp so that the padding product 0.0 * x(1) stays inside the vector
-        if (node) ecol[t] = max(node[(int64_t)i * max_d + k] - 1, 0);
+        if (node) {
+            const int32_t c = node[(int64_t)i * max_d + k];
+            // (validation of sgm_ell_create's input: 0 is the reference's empty-row marker, anything else must be a column)
+            if (bad && (c < 0 || c > ncol)) atomicMin(bad, (unsigned long long)((int64_t)i * max_d + k));
+            ecol[t] = max(c - 1, 0);
+        }
         if (val) eval[t] = val[(int64_t)i * max_d + k];
     }
 }
@@ -1627,7 +1663,6 @@ static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const doub
 {
     // a row range is the same kernel on shifted pointers: rowptr entries stay absolute offsets
     // into val/col/code; the offset-dict kernel forms columns as row + offset, so x shifts too
-    if (p.lean && !(lean_sell(p) ? use_sell(p) : use_sliced(p))) (void)csr_need_arrays(p);      // a kernel other than the resident form's was asked for (options): its arrays come back and stay
     Part v;
     v.n = r.hi - r.lo;
     v.nnz = (int64_t)((double)p.nnz * v.n / (p.n > 0 ? p.n : 1));   // same row density => same tile choice as the full part
@@ -1682,6 +1717,12 @@ int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
 {
     if (A->fmt == SGM_FMT_COMPOSITE) return composite_spmv(A, x[0], y[0], add, dots, flag_done, grid_out, gen);
     const size_t P = A->parts.size();
+    // a kernel other than the resident form's was asked for (options) on a lean part: its arrays come back and stay.  Resolved
+    // here, before anything is launched (an allocation failure is SGM_ERR_ALLOC, not a kernel on null arrays; the solvers'
+    // first, uncaptured iterations have been through here before a graph capture starts)
+    if (A->fmt == SGM_FMT_CSR)
+        for (const Part &p : A->parts)
+            if (p.lean && !(lean_sell(p) ? use_sell(p) : use_sliced(p))) SGM_TRY(csr_need_arrays(p));
     g_launch_flags = chain ? 256 : 0;
     bool exchange = false;
     if (A->distributed())
@@ -2348,9 +2389,13 @@ static int build_ell_offset_dict(Part &p)
 }
 
 // Upload one CSR row block.  ptr1 is 1-based local (n+1), node1 is 1-based and already
-// renumbered to [owned | halo]; `where` says where the three arrays live.
+// renumbered to [owned | halo]; `where` says where the three arrays live.  With `validate` the
+// index arrays are checked on the device as they are converted (k_check_ptr1, k_dec1_check_cols):
+// a malformed pointer array is SGM_ERR_BAD_ARG, a pointer array that does not end at nnz or a
+// column outside 1..ncol_own+n_halo is SGM_ERR_DIMS, each naming the first offending row --
+// never a memory fault inside a later product.
 int build_csr_part(Part &p, int32_t n, int32_t ncol_own, int32_t n_halo, int64_t nnz,
-                   const int32_t *ptr1, const int32_t *node1, const double *val, int where)
+                   const int32_t *ptr1, const int32_t *node1, const double *val, int where, bool validate)
 {
     p.n = n;
     p.ncol_own = ncol_own;
@@ -2361,6 +2406,11 @@ int build_csr_part(Part &p, int32_t n, int32_t ncol_own, int32_t n_halo, int64_t
     SGM_TRY(dalloc(&p.val, (size_t)nnz + 2));
     hipStream_t st = g_rt.stream;
     const hipMemcpyKind kind = where == SGM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    unsigned long long *bad = nullptr;                 // validation verdict: {first bad row, first bad entry}
+    if (validate) {
+        SGM_TRY(dalloc(&bad, 2));
+        SGM_HIP(hipMemsetAsync(bad, 0xff, 2 * sizeof(unsigned long long), st));
+    }
     SGM_HIP(hipMemsetAsync(p.col + nnz, 0, 4 * sizeof(int32_t), st));
     SGM_HIP(hipMemsetAsync(p.val + nnz, 0, 2 * sizeof(double), st));
     SGM_HIP(hipMemcpyAsync(p.rowptr, ptr1, ((size_t)n + 1) * sizeof(int32_t), kind, st));
@@ -2368,10 +2418,41 @@ int build_csr_part(Part &p, int32_t n, int32_t ncol_own, int32_t n_halo, int64_t
         SGM_HIP(hipMemcpyAsync(p.col, node1, (size_t)nnz * sizeof(int32_t), kind, st));
         SGM_HIP(hipMemcpyAsync(p.val, val, (size_t)nnz * sizeof(double), kind, st));
     }
+    if (validate)
+        hipLaunchKernelGGL(k_check_ptr1, dim3(vec_grid(n + 1)), dim3(kBlock), 0, st, (const int32_t *)p.rowptr, (int64_t)n, nnz, bad);
     hipLaunchKernelGGL(k_dec1, dim3(vec_grid(n + 1)), dim3(kBlock), 0, st, p.rowptr, (int64_t)n + 1);
-    if (nnz) hipLaunchKernelGGL(k_dec1, dim3(vec_grid(nnz)), dim3(kBlock), 0, st, p.col, nnz);
+    if (nnz) {
+        if (validate)
+            hipLaunchKernelGGL(k_dec1_check_cols, dim3(vec_grid(nnz)), dim3(kBlock), 0, st, p.col, nnz, (int64_t)ncol_own + n_halo, bad);
+        else
+            hipLaunchKernelGGL(k_dec1, dim3(vec_grid(nnz)), dim3(kBlock), 0, st, p.col, nnz);
+    }
     SGM_HIP(hipGetLastError());
+    unsigned long long hbad[2] = {~0ull, ~0ull};
+    if (validate) SGM_HIP(hipMemcpyAsync(hbad, bad, sizeof hbad, hipMemcpyDeviceToHost, st));
     SGM_HIP(hipStreamSynchronize(st));   // host staging buffers may go away after return
+    dfree(bad);
+    if (hbad[0] != ~0ull) {
+        const int64_t i = (int64_t)hbad[0];
+        int32_t v[2] = {0, 0};            // (0-based by now)
+        SGM_HIP(hipMemcpy(v, p.rowptr + i, (i < n ? 2 : 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (i == n)
+            return fail(SGM_ERR_DIMS, "csr create: ptr(%lld) - 1 = %lld entries, but nnz = %lld", (long long)n + 1, (long long)v[0],
+                        (long long)nnz);
+        if (i == 0 && v[0] != 0) return fail(SGM_ERR_BAD_ARG, "csr create: ptr(1) = %d, expected 1 (1-based row pointers)", v[0] + 1);
+        return fail(SGM_ERR_BAD_ARG, "csr create: row pointers decrease at row %lld: ptr(%lld) = %d > ptr(%lld) = %d", (long long)i + 1,
+                    (long long)i + 1, v[0] + 1, (long long)i + 2, v[1] + 1);
+    }
+    if (hbad[1] != ~0ull) {
+        const int64_t k = (int64_t)hbad[1];
+        int32_t c = 0;
+        SGM_HIP(hipMemcpy(&c, p.col + k, sizeof c, hipMemcpyDeviceToHost));
+        std::vector<int32_t> hp((size_t)n + 1);          // error path only: the row that holds entry k
+        SGM_HIP(hipMemcpy(hp.data(), p.rowptr, hp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        const int64_t row = std::upper_bound(hp.begin(), hp.end(), (int32_t)k) - hp.begin();      // 1-based
+        return fail(SGM_ERR_DIMS, "csr create: node(%lld) = %d in row %lld is outside 1..%lld", (long long)k + 1, c + 1, (long long)row,
+                    (long long)ncol_own + n_halo);
+    }
     return build_offset_dict(p, where == SGM_HOST ? ptr1 : nullptr, where == SGM_HOST ? node1 : nullptr);
 }
 
@@ -2566,7 +2647,7 @@ static int ensure_transpose(sgm_mat A)
             T->ncol = A->nrow;
             T->nnz = nnz;
             T->parts.resize(1);
-            rc = build_csr_part(T->parts[0], T->nrow, T->ncol, 0, nnz, tptr, tnode, zeros, SGM_DEVICE);
+            rc = build_csr_part(T->parts[0], T->nrow, T->ncol, 0, nnz, tptr, tnode, zeros, SGM_DEVICE, false);
         }
         if (tmp) (void)hipFree(tmp);
         dfree(key); dfree(src); dfree(rowid); dfree(key2); dfree(tptr); dfree(tnode); dfree(zeros);
@@ -2695,7 +2776,7 @@ int sgm_csr_create(sgm_mat *out, int32_t nrow, int32_t ncol, int64_t nnz, const 
     A->ncol = ncol;
     A->nnz = nnz;
     A->parts.resize(1);
-    int rc = build_csr_part(A->parts[0], nrow, ncol, 0, nnz, ptr, node, val, where);
+    int rc = build_csr_part(A->parts[0], nrow, ncol, 0, nnz, ptr, node, val, where, true);
     if (rc != SGM_OK) { sgm_mat_destroy(A); return rc; }
     *out = A;
     return SGM_OK;
@@ -2742,17 +2823,32 @@ int sgm_ell_create(sgm_mat *out, int32_t nrow, int32_t ncol, int32_t max_d, cons
     if (rc != SGM_OK) { sgm_mat_destroy(A); return rc; }
     *out = A;
     if (total == 0) return SGM_OK;
+    // (from here on *out owns A: an error return leaves a handle the caller may destroy -- except for rejected
+    // index arrays, where nothing usable exists)
     int32_t *tn = nullptr;
+    unsigned long long *bad = nullptr, hbad = ~0ull;
+    SGM_TRY(dalloc(&bad, 1));
+    SGM_HIP(hipMemsetAsync(bad, 0xff, sizeof(unsigned long long), g_rt.stream));
+    const int32_t *src = node;
     if (where == SGM_HOST) {
         SGM_TRY(dalloc(&tn, total));
         SGM_HIP(hipMemcpyAsync(tn, node, total * 4, hipMemcpyHostToDevice, g_rt.stream));
-        hipLaunchKernelGGL(k_ell_transpose, dim3(vec_grid(total)), dim3(kBlock), 0, g_rt.stream, tn,
-                           (const double *)nullptr, p.ecol, p.eval, nrow, max_d);
-        SGM_HIP(hipStreamSynchronize(g_rt.stream));
-        dfree(tn);
-    } else {
-        hipLaunchKernelGGL(k_ell_transpose, dim3(vec_grid(total)), dim3(kBlock), 0, g_rt.stream, node,
-                           (const double *)nullptr, p.ecol, p.eval, nrow, max_d);
+        src = tn;
+    }
+    hipLaunchKernelGGL(k_ell_transpose, dim3(vec_grid(total)), dim3(kBlock), 0, g_rt.stream, src, (const double *)nullptr, p.ecol,
+                       p.eval, nrow, max_d, ncol, bad);
+    SGM_HIP(hipMemcpyAsync(&hbad, bad, sizeof hbad, hipMemcpyDeviceToHost, g_rt.stream));
+    SGM_HIP(hipStreamSynchronize(g_rt.stream));
+    dfree(tn);
+    dfree(bad);
+    if (hbad != ~0ull) {
+        int32_t c = 0;
+        const int64_t e = (int64_t)hbad;        // entry (slot k, row i) of the (max_d, n) array: e = i * max_d + k
+        SGM_HIP(hipMemcpy(&c, node + e, sizeof c, where == SGM_HOST ? hipMemcpyHostToHost : hipMemcpyDeviceToHost));
+        *out = nullptr;
+        sgm_mat_destroy(A);
+        return fail(SGM_ERR_DIMS, "ellpack create: node(%lld,%lld) = %d is outside 0..%d", (long long)(e % max_d) + 1,
+                    (long long)(e / max_d) + 1, c, ncol);
     }
     SGM_TRY(build_ell_offset_dict(p));
     SGM_TRY(build_ell_colblock(p));

@@ -207,6 +207,85 @@ def random_regular_ell(n, d=32, seed=12345, dmin=None):
     return ei.astype(I4), ej.astype(I4), ev
 
 
+# --------------------------------------------------------------------------- #
+# the same stencil matrices generated with torch on a device (plumbing for the
+# full-size configs: no 1 GB host arrays, no PCIe upload); entry order = the
+# numpy generators' (tests compare them at small sizes)
+# --------------------------------------------------------------------------- #
+def stencil_csr_torch(k, offs_masks_vals, device):
+    """Rows k (0-based global row numbers, int64 tensor) of a stencil matrix: offs_masks_vals = [(column offset, mask of
+    the rows that hold the entry, value)] in stored order.  Returns local 1-based ptr (int32), GLOBAL 1-based node
+    (int32), val (float64)."""
+    import torch
+    n = k.numel()
+    cols = torch.stack([k + 1 + o for o, _, _ in offs_masks_vals], dim=1)
+    mask = torch.stack([m for _, m, _ in offs_masks_vals], dim=1)
+    vals = torch.tensor([v for _, _, v in offs_masks_vals], dtype=torch.float64, device=device).expand(n, -1)
+    ptr = torch.ones(n + 1, dtype=torch.int64, device=device)
+    ptr[1:] += torch.cumsum(mask.sum(dim=1), 0)
+    return ptr.to(torch.int32), cols[mask].to(torch.int32), vals[mask].contiguous()
+
+
+def tridiag_csr_torch(n, diag, upper, lower, device):
+    """tridiag_csr on a device: the reference's insertion order leaves every row as (i,i-1),(i,i),(i,i+1)."""
+    import torch
+    k = torch.arange(n, device=device, dtype=torch.int64)
+    one = torch.ones(n, dtype=torch.bool, device=device)
+    return stencil_csr_torch(k, [(-1, k > 0, lower), (0, one, diag), (1, k < n - 1, upper)], device)
+
+
+def laplace3d_rows_torch(nx, ny, nz, device, z0=0, z1=None):
+    """Rows of the planes [z0, z1) of laplace3d_csr(nx, ny, nz) (entry order -z,-y,-x,C,+x,+y,+z)."""
+    import torch
+    z1 = nz if z1 is None else z1
+    pl = nx * ny
+    k = torch.arange(z0 * pl, z1 * pl, device=device, dtype=torch.int64)
+    i, j, l = k % nx, (k // nx) % ny, k // pl
+    one = torch.ones_like(k, dtype=torch.bool)
+    return stencil_csr_torch(k, [(-pl, l > 0, -1.0), (-nx, j > 0, -1.0), (-1, i > 0, -1.0), (0, one, 6.0), (1, i < nx - 1, -1.0),
+                                 (nx, j < ny - 1, -1.0), (pl, l < nz - 1, -1.0)], device)
+
+
+def random_regular_ell_torch(n, d=32, seed=12345, device=None, chunk=1 << 20):
+    """random_regular_ell(n, d, seed) (no padding variant) evaluated with torch on `device`, row chunk by
+    row chunk: returns (node, val) as (n, d) int32 / float64 tensors -- the ELLPACK arrays the edge list of
+    the numpy generator assembles to (every row holds exactly d slots in insertion order), entry for entry
+    (tests/test_oracle_golden.py compares the two at a small size).  int64 arithmetic wraps like the uint64
+    LCG; the logical shift is an arithmetic one with the sign bits masked off."""
+    import torch
+    assert n > 2 * d
+    dev = device if device is not None else torch.device("cpu")
+    A = 6364136223846793005
+    Cc = 1442695040888963407
+    G = 0x9E3779B97F4A7C15 - (1 << 64)          # the golden-ratio increment as a two's-complement int64
+    ndraw = d + 16
+    node = torch.empty((n, d), dtype=torch.int32, device=dev)
+    val = torch.empty((n, d), dtype=torch.float64, device=dev)
+    slot = torch.arange(1, d + 1, dtype=torch.int64, device=dev)
+    for r0 in range(0, n, chunk):
+        r1 = min(n, r0 + chunk)
+        rows = torch.arange(r0 + 1, r1 + 1, dtype=torch.int64, device=dev)
+        s = seed + rows * G
+        cand = torch.empty((r1 - r0, ndraw + 1), dtype=torch.int64, device=dev)
+        cand[:, 0] = rows
+        for t in range(ndraw):
+            s = s * A + Cc
+            cand[:, t + 1] = 1 + ((s >> 16) & 0x0000FFFFFFFFFFFF) % n
+        srt, order = torch.sort(cand, dim=1, stable=True)
+        dup_sorted = torch.zeros_like(srt, dtype=torch.bool)
+        dup_sorted[:, 1:] = srt[:, 1:] == srt[:, :-1]
+        dup = torch.empty_like(dup_sorted)
+        dup.scatter_(1, order, dup_sorted)
+        keep = ~dup
+        rank = torch.cumsum(keep, dim=1)
+        keep &= rank <= d
+        if not bool((keep.sum(dim=1) == d).all()):
+            raise AssertionError("not enough distinct draws")
+        node[r0:r1] = cand[keep].view(r1 - r0, d).to(torch.int32)
+        val[r0:r1] = 1.0 / (slot[None, :] + (rows % 7)[:, None]).to(torch.float64)
+    return node, val
+
+
 def random_spd_edges(n, seed=1, p=None, skew=False):
     """The matrix family of test/solver_test_jacobi.f90:62-128 (random graph
     Laplacian + I, optionally with the skew perturbation of :240-257), made

@@ -105,9 +105,25 @@ size_t type_size(ncclDataType_t t)
     }
 }
 
+// Test hook (tests/test_gpu_multirank.py: the bench watchdog): MOCK_RCCL_STALL="<rank>:<groups>" makes that rank stop dead
+// inside its (groups+1)-th send/recv group -- what a rank stuck in a halo exchange over a broken link looks like to its peers.
+void maybe_stall(int rank)
+{
+    static int want_rank = -2, after = 0, seen = 0;
+    if (want_rank == -2) {
+        want_rank = -1;
+        if (const char *e = getenv("MOCK_RCCL_STALL")) sscanf(e, "%d:%d", &want_rank, &after);
+    }
+    if (rank != want_rank) return;
+    if (++seen <= after) return;
+    fprintf(stderr, "[mock_rccl] rank %d: stalling in send/recv group %d (MOCK_RCCL_STALL)\n", rank, seen);
+    for (;;) sleep(1);
+}
+
 ncclResult_t run_ops()
 {
     if (g_ops.empty()) return ncclSuccess;
+    maybe_stall(g_ops[0].c->rank);
     reap();
     for (auto &o : g_ops) if (hipStreamSynchronize(o.st) != hipSuccess) return ncclUnhandledCudaError;
     for (auto &o : g_ops) {

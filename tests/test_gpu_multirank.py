@@ -187,3 +187,35 @@ def test_bench_under_torch_distributed_run_like_the_driver_launches_it(tmp_path)
     out = json.loads(line[0])
     assert out["n_gpus"] == 2 and out["cg"]["iterations"] == 20 and out["c5_strong_scaling"]["cg_iterations"] == 10
     assert out["selfcheck"]["product_bit_exact_on_every_rank"] is True and out["c5_strong_scaling"]["product_bit_exact_on_every_rank"] is True
+
+
+@pytest.mark.parametrize("launcher", ["plain", "torchrun"])
+def test_a_rank_stuck_in_the_halo_exchange_is_named_and_the_run_ends(launcher, tmp_path):
+    """ranks that all block in a collective must not run into the caller's timeout silently.  The
+    stand-in transport stops rank 1 dead inside a halo send/recv group (MOCK_RCCL_STALL); both ranks' watchdogs notice
+    that neither this script's phase nor the library's heartbeat (sgm_heartbeat: read from a second thread while the main
+    one is blocked) has moved for --stall-s, print where they are and exit 86 -- within the deadline, phase named, also
+    when the ranks are children of torch.distributed.run like the driver starts them."""
+    env = dict(os.environ)
+    env.update({"SGM_RCCL_LIB": MOCK, "SGM_BENCH_SAME_GPU": "1", "MOCK_RCCL_STALL": "1:12"})
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    bench_args = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spmv-per-step", "40",
+                  "--nx", "300", "--ny", "200", "--cg-steps", "20", "--c5-edge", "40", "--c5-cg-steps", "10", "--no-cpu",
+                  "--stall-s", "8", "--deadline-s", "200"]
+    if launcher == "plain":
+        cmd = [sys.executable] + bench_args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + bench_args
+    t0 = time.time()
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    took = time.time() - t0
+    assert p.returncode != 0, p.stderr[-3000:]
+    assert took < 150, took
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{\"metric\"")], "a stalled run must not print a bench line"
+    assert "STALLED" in p.stderr and "no heartbeat for" in p.stderr, p.stderr[-3000:]
+    # the library's own phase (read while the main thread was blocked inside it) and this script's phase are both named
+    assert "halo send/recv group being posted" in p.stderr, p.stderr[-3000:]
+    assert "products" in p.stderr, p.stderr[-3000:]
+    assert "[mock_rccl] rank 1: stalling" in p.stderr

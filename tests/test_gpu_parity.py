@@ -2779,9 +2779,6 @@ def test_full_size_c3_tridiagonal_spmv_and_krylov_residuals():
     torch evaluation in stored order; BiCGStab and GMRES(30) for a fixed 30 iterations: the
     recursive residual the solver reports equals the true residual b - A u recomputed by SpMV."""
     import torch
-    import sys, os
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-    from bench_configs import stencil_csr_torch
     dev = torch.device("cuda", 0)
     n = 10_000_000
     dx = 1.0 / (n + 1)
@@ -2823,9 +2820,7 @@ def test_full_size_c5_mini_and_c4_every_row_bit_exact():
     full cross-section) and C4 (ELLPACK random digraph, degree 32, n = 5e6 at 1/4 size): every
     row bit-exact against the torch evaluation in stored order."""
     import torch
-    import sys, os
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-    from bench_configs import laplace3d_torch
+    laplace3d_torch = P.laplace3d_rows_torch
     dev = torch.device("cuda", 0)
     nx, ny, nz = 464, 464, 58
     n = nx * ny * nz
@@ -2897,9 +2892,7 @@ def test_full_size_c5_464_cubed_every_row_bit_exact_and_cg_energy():
     y = A x equals the torch evaluation in stored order (checked slab by slab to bound memory); exact row
     sums for x = 1 (0 inside, positive on the boundary); 20 CG iterations decrease the energy norm."""
     import torch
-    import sys, os
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-    from bench_configs import laplace3d_torch
+    laplace3d_torch = P.laplace3d_rows_torch
     dev = torch.device("cuda", 0)
     m = 464
     n = m ** 3
