@@ -60,6 +60,13 @@ if [ -f "$LIBDIR/libsigma_hip.so" ]; then
       -L"$LIBDIR" -lsigma_hip -Wl,-rpath,'$ORIGIN/../../sigma_amd' \
       -Wl,-z,execstack -Wl,--unresolved-symbols=ignore-all
   echo "built $OUT/hip_binding_test"
+  # one rank of a row-partitioned solve through the same binding (hip_comm + hip_dist_csr_matrix); started once per rank
+  # by tests/test_gpu_multirank.py
+  "$FC" -O2 -fPIC -c "$HERE/hip_dist_test.f90" -o hip_dist_test.o
+  "$FC" -O2 -o "$OUT/hip_dist_test" hip_dist_test.o hip_binding.o $OBJS \
+      -L"$LIBDIR" -lsigma_hip -Wl,-rpath,'$ORIGIN/../../sigma_amd' \
+      -Wl,-z,execstack -Wl,--unresolved-symbols=ignore-all
+  echo "built $OUT/hip_dist_test"
 else
   echo "libsigma_hip.so not built yet - skipping hip_binding_test"
 fi

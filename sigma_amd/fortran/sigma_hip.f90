@@ -21,9 +21,22 @@
 ! pushes them to HBM.  Nonzero status from the C side is turned into the   !
 ! reference's error behaviour: print + call exit(1) (cg_solvers.f90:61-65).!
 !                                                                          !
+!   type(sparse_matrix) composite             type(hip_sparse_matrix)      !
+!     sparse_matrix_composites.f90:41-162       set_submatrix, matvec(_t)  !
+!   lanczos(A,T,Q), generalized_lanczos       hip_lanczos,                 !
+!     eigensolver.f90:27-38,95-108              hip_generalized_lanczos    !
+!   add_edge / convert / set_value assembly   hip_csr_from_edges           !
+!   (nothing: "This loop can be parallelized" hip_comm, hip_dist_csr_matrix!
+!     sparse_matrix_composites.f90:1086)        one process per GPU, RCCL  !
+!                                                                          !
+! Every matrix type extends the abstract hip_matrix (a device handle that  !
+! `upload` brings up to date); the solvers take class(hip_matrix).         !
+!                                                                          !
 ! This file does NOT depend on the reference's modules, so that it builds  !
-! on the GPU box; INTEGRATION.md shows the ~40-line variant that extends   !
-! the reference's own csr_matrix / linear_solver types instead.            !
+! on the GPU box; oracle/hip_binding.f90 (quoted in INTEGRATION.md) is the !
+! variant that extends the reference's own csr_matrix / linear_solver      !
+! types instead.  Every entry point of include/sigma_hip.h has its         !
+! interface block here (tests/test_cabi_cpu.py checks the list).           !
 !==========================================================================!
 module sigma_hip
 
@@ -260,19 +273,296 @@ interface
         type(c_ptr), value :: s
         integer(c_int) :: rc
     end function
+    ! ---- the rest of include/sigma_hip.h ------------------------------------
+    function sgm_finalize() bind(c, name='sgm_finalize') result(rc)
+        import :: c_int
+        integer(c_int) :: rc
+    end function
+    function sgm_set_stream(stream) bind(c, name='sgm_set_stream') result(rc)
+        import :: c_ptr, c_int
+        type(c_ptr), value :: stream
+        integer(c_int) :: rc
+    end function
+    function sgm_set_async(on) bind(c, name='sgm_set_async') result(rc)
+        import :: c_int
+        integer(c_int), value :: on
+        integer(c_int) :: rc
+    end function
+    function sgm_synchronize() bind(c, name='sgm_synchronize') result(rc)
+        import :: c_int
+        integer(c_int) :: rc
+    end function
+    function sgm_heartbeat(out6, phase_name, len) bind(c, name='sgm_heartbeat') result(rc)
+        import :: c_int, c_int64_t, c_char
+        integer(c_int64_t), intent(out) :: out6(6)
+        character(kind=c_char), intent(out) :: phase_name(*)
+        integer(c_int), value :: len
+        integer(c_int) :: rc
+    end function
+    function sgm_malloc(p, bytes) bind(c, name='sgm_malloc') result(rc)
+        import :: c_ptr, c_int, c_size_t
+        type(c_ptr), intent(out) :: p
+        integer(c_size_t), value :: bytes
+        integer(c_int) :: rc
+    end function
+    function sgm_free(p) bind(c, name='sgm_free') result(rc)
+        import :: c_ptr, c_int
+        type(c_ptr), value :: p
+        integer(c_int) :: rc
+    end function
+    function sgm_memcpy(dst, src, bytes, kind) bind(c, name='sgm_memcpy') result(rc)
+        import :: c_ptr, c_int, c_size_t
+        type(c_ptr), value :: dst, src
+        integer(c_size_t), value :: bytes
+        integer(c_int), value :: kind          ! 0 host -> device, 1 device -> host, 2 device -> device
+        integer(c_int) :: rc
+    end function
+    function sgm_dot(n, a, b, res, where) bind(c, name='sgm_dot') result(rc)
+        import :: c_int, c_int64_t, c_double
+        integer(c_int64_t), value :: n
+        real(c_double), intent(in) :: a(*), b(*)
+        real(c_double), intent(out) :: res
+        integer(c_int), value :: where
+        integer(c_int) :: rc
+    end function
+    function sgm_axpy(n, alpha, x, y, where) bind(c, name='sgm_axpy') result(rc)
+        import :: c_int, c_int64_t, c_double
+        integer(c_int64_t), value :: n
+        real(c_double), value :: alpha
+        real(c_double), intent(in) :: x(*)
+        real(c_double), intent(inout) :: y(*)
+        integer(c_int), value :: where
+        integer(c_int) :: rc
+    end function
+    function sgm_csr_from_edges(A, nrow, ncol, ne, ei, ej, ev, where) bind(c, name='sgm_csr_from_edges') result(rc)
+        import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
+        type(c_ptr), intent(out) :: A
+        integer(c_int32_t), value :: nrow, ncol
+        integer(c_int64_t), value :: ne
+        integer(c_int32_t), intent(in) :: ei(*), ej(*)
+        real(c_double), intent(in) :: ev(*)
+        integer(c_int), value :: where
+        integer(c_int) :: rc
+    end function
+    function sgm_ell_from_edges(A, nrow, ncol, ne, ei, ej, ev, where) bind(c, name='sgm_ell_from_edges') result(rc)
+        import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
+        type(c_ptr), intent(out) :: A
+        integer(c_int32_t), value :: nrow, ncol
+        integer(c_int64_t), value :: ne
+        integer(c_int32_t), intent(in) :: ei(*), ej(*)
+        real(c_double), intent(in) :: ev(*)
+        integer(c_int), value :: where
+        integer(c_int) :: rc
+    end function
+    function sgm_composite_create(A, nrb, ncb, row_ptr, col_ptr, blocks) bind(c, name='sgm_composite_create') result(rc)
+        import :: c_ptr, c_int, c_int32_t
+        type(c_ptr), intent(out) :: A
+        integer(c_int32_t), value :: nrb, ncb
+        integer(c_int32_t), intent(in) :: row_ptr(*), col_ptr(*)
+        type(c_ptr), intent(in) :: blocks(*)
+        integer(c_int) :: rc
+    end function
+    function sgm_mat_info(A, nrow, ncol, nnz, fmt, x_len) bind(c, name='sgm_mat_info') result(rc)
+        import :: c_ptr, c_int, c_int32_t, c_int64_t
+        type(c_ptr), value :: A
+        integer(c_int32_t), intent(out) :: nrow, ncol, fmt
+        integer(c_int64_t), intent(out) :: nnz, x_len
+        integer(c_int) :: rc
+    end function
+    function sgm_mat_kernel(A, buf, len) bind(c, name='sgm_mat_kernel') result(rc)
+        import :: c_ptr, c_int, c_char
+        type(c_ptr), value :: A
+        character(kind=c_char), intent(out) :: buf(*)
+        integer(c_int), value :: len
+        integer(c_int) :: rc
+    end function
+    function sgm_mat_footprint(A, resident_bytes, matvec_bytes) bind(c, name='sgm_mat_footprint') result(rc)
+        import :: c_ptr, c_int, c_int64_t
+        type(c_ptr), value :: A
+        integer(c_int64_t), intent(out) :: resident_bytes, matvec_bytes
+        integer(c_int) :: rc
+    end function
+    function sgm_pc_get(pc, name, out, bytes, needed) bind(c, name='sgm_pc_get') result(rc)
+        import
+        type(c_ptr), value :: pc
+        character(kind=c_char), intent(in) :: name(*)
+        type(c_ptr), value :: out
+        integer(c_size_t), value :: bytes
+        type(c_ptr), value :: needed
+        integer(c_int) :: rc
+    end function
+    function sgm_solver_set_max_iter(s, max_iter) bind(c, name='sgm_solver_set_max_iter') result(rc)
+        import :: c_ptr, c_int, c_int64_t
+        type(c_ptr), value :: s
+        integer(c_int64_t), value :: max_iter
+        integer(c_int) :: rc
+    end function
+    function sgm_solver_set_history(s, capacity) bind(c, name='sgm_solver_set_history') result(rc)
+        import :: c_ptr, c_int, c_int64_t
+        type(c_ptr), value :: s
+        integer(c_int64_t), value :: capacity
+        integer(c_int) :: rc
+    end function
+    function sgm_solver_get_history(s, out, capacity, count) bind(c, name='sgm_solver_get_history') result(rc)
+        import :: c_ptr, c_int, c_int64_t, c_double
+        type(c_ptr), value :: s
+        real(c_double), intent(out) :: out(*)
+        integer(c_int64_t), value :: capacity
+        integer(c_int64_t), intent(out) :: count
+        integer(c_int) :: rc
+    end function
+    function sgm_lanczos(A, nsteps, q1, T, Q, where) bind(c, name='sgm_lanczos') result(rc)
+        import :: c_ptr, c_int, c_int32_t, c_double
+        type(c_ptr), value :: A
+        integer(c_int32_t), value :: nsteps
+        real(c_double), intent(in) :: q1(*)
+        real(c_double), intent(out) :: T(3, *), Q(*)
+        integer(c_int), value :: where
+        integer(c_int) :: rc
+    end function
+    function sgm_generalized_lanczos(A, B, solver, pc, nsteps, q1, T, Q, where) &
+            & bind(c, name='sgm_generalized_lanczos') result(rc)
+        import :: c_ptr, c_int, c_int32_t, c_double
+        type(c_ptr), value :: A, B, solver, pc
+        integer(c_int32_t), value :: nsteps
+        real(c_double), intent(in) :: q1(*)
+        real(c_double), intent(out) :: T(3, *), Q(*)
+        integer(c_int), value :: where
+        integer(c_int) :: rc
+    end function
+    ! ---- row-partitioned multi-GPU -----------------------------------------------
+    function sgm_comm_unique_id(id) bind(c, name='sgm_comm_unique_id') result(rc)
+        import :: c_int, c_char
+        character(kind=c_char), intent(out) :: id(128)
+        integer(c_int) :: rc
+    end function
+    function sgm_comm_init(comm, rank, nranks, id) bind(c, name='sgm_comm_init') result(rc)
+        import :: c_ptr, c_int, c_char
+        type(c_ptr), intent(out) :: comm
+        integer(c_int), value :: rank, nranks
+        character(kind=c_char), intent(in) :: id(128)
+        integer(c_int) :: rc
+    end function
+    function sgm_comm_attach_halo_comm(comm, id) bind(c, name='sgm_comm_attach_halo_comm') result(rc)
+        import :: c_ptr, c_int, c_char
+        type(c_ptr), value :: comm
+        character(kind=c_char), intent(in) :: id(128)
+        integer(c_int) :: rc
+    end function
+    function sgm_comm_destroy(comm) bind(c, name='sgm_comm_destroy') result(rc)
+        import :: c_ptr, c_int
+        type(c_ptr), value :: comm
+        integer(c_int) :: rc
+    end function
+    function sgm_dist_profile(on) bind(c, name='sgm_dist_profile') result(rc)
+        import :: c_int
+        integer(c_int), value :: on
+        integer(c_int) :: rc
+    end function
+    function sgm_dist_profile_read(ms, count) bind(c, name='sgm_dist_profile_read') result(rc)
+        import :: c_int, c_int64_t, c_double
+        real(c_double), intent(out) :: ms(6)
+        integer(c_int64_t), intent(out) :: count(6)
+        integer(c_int) :: rc
+    end function
+    function sgm_partition_rows_by_nnz(nrow, ptr, nparts, align, row_starts) &
+            & bind(c, name='sgm_partition_rows_by_nnz') result(rc)
+        import :: c_int, c_int32_t, c_int64_t
+        integer(c_int32_t), value :: nrow, nparts, align
+        integer(c_int32_t), intent(in) :: ptr(*)
+        integer(c_int64_t), intent(out) :: row_starts(*)
+        integer(c_int) :: rc
+    end function
+    function sgm_csr_create_dist(A, comm, row_starts, nnz, ptr, node, val, where) &
+            & bind(c, name='sgm_csr_create_dist') result(rc)
+        import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
+        type(c_ptr), intent(out) :: A
+        type(c_ptr), value :: comm
+        integer(c_int64_t), intent(in) :: row_starts(*)
+        integer(c_int64_t), value :: nnz
+        integer(c_int32_t), intent(in) :: ptr(*), node(*)
+        real(c_double), intent(in) :: val(*)
+        integer(c_int), value :: where
+        integer(c_int) :: rc
+    end function
+    function sgm_csr_create_dist_rect(A, comm, row_starts, col_starts, nnz, ptr, node, val, where) &
+            & bind(c, name='sgm_csr_create_dist_rect') result(rc)
+        import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
+        type(c_ptr), intent(out) :: A
+        type(c_ptr), value :: comm
+        integer(c_int64_t), intent(in) :: row_starts(*), col_starts(*)
+        integer(c_int64_t), value :: nnz
+        integer(c_int32_t), intent(in) :: ptr(*), node(*)
+        real(c_double), intent(in) :: val(*)
+        integer(c_int), value :: where
+        integer(c_int) :: rc
+    end function
+    function sgm_ell_create_dist(A, comm, row_starts, max_d, node, val, where) &
+            & bind(c, name='sgm_ell_create_dist') result(rc)
+        import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
+        type(c_ptr), intent(out) :: A
+        type(c_ptr), value :: comm
+        integer(c_int64_t), intent(in) :: row_starts(*)
+        integer(c_int32_t), value :: max_d
+        integer(c_int32_t), intent(in) :: node(*)
+        real(c_double), intent(in) :: val(*)
+        integer(c_int), value :: where
+        integer(c_int) :: rc
+    end function
+    function sgm_csr_create_partitioned(A, nparts, row_starts, nrow, ncol, nnz, ptr, node, val) &
+            & bind(c, name='sgm_csr_create_partitioned') result(rc)
+        import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
+        type(c_ptr), intent(out) :: A
+        integer(c_int32_t), value :: nparts, nrow, ncol
+        integer(c_int64_t), intent(in) :: row_starts(*)
+        integer(c_int64_t), value :: nnz
+        integer(c_int32_t), intent(in) :: ptr(*), node(*)
+        real(c_double), intent(in) :: val(*)
+        integer(c_int) :: rc
+    end function
+    function c_usleep(us) bind(c, name='usleep') result(rc)
+        import :: c_int
+        integer(c_int), value :: us
+        integer(c_int) :: rc
+    end function
 end interface
 
 
 !--------------------------------------------------------------------------!
-type :: hip_csr_matrix                                                     !
+type, abstract :: hip_matrix                                               !
+!--------------------------------------------------------------------------!
+! linear_operator (linear_operator_interface.f90:18-45) as this layer sees !
+! it: dimensions + one device handle that `upload` brings up to date.      !
+! matvec / matvec_add / matvec_t / matvec_t_add are the same for every     !
+! matrix type: upload, then the C entry point.                             !
+!--------------------------------------------------------------------------!
+    integer :: nrow = 0, ncol = 0
+    type(c_ptr) :: handle = c_null_ptr
+contains
+    procedure(hip_matrix_upload_ifc), deferred :: upload
+    procedure :: matvec => hip_matrix_matvec
+    procedure :: matvec_add => hip_matrix_matvec_add
+    procedure :: matvec_t => hip_matrix_matvec_t
+    procedure :: matvec_t_add => hip_matrix_matvec_t_add
+    procedure :: kernel_name => hip_matrix_kernel_name
+end type hip_matrix
+
+abstract interface
+    subroutine hip_matrix_upload_ifc(A)
+        import :: hip_matrix
+        class(hip_matrix), intent(inout) :: A
+    end subroutine
+end interface
+
+
+!--------------------------------------------------------------------------!
+type, extends(hip_matrix) :: hip_csr_matrix                                !
 !--------------------------------------------------------------------------!
 ! Same host data as csr_matrix (cs_matrices.f90:32-38,112): ptr/node of    !
 ! the cs_graph, val of the matrix.                                         !
 !--------------------------------------------------------------------------!
-    integer :: nrow = 0, ncol = 0
     integer, allocatable :: ptr(:), node(:)
     real(dp), allocatable :: val(:)
-    type(c_ptr) :: handle = c_null_ptr
     logical :: values_dirty = .true.
 contains
     procedure :: init => hip_csr_init
@@ -281,10 +571,6 @@ contains
     procedure :: add_value => hip_csr_add_value
     procedure :: zero => hip_csr_zero
     procedure :: upload => hip_csr_upload
-    procedure :: matvec => hip_csr_matvec
-    procedure :: matvec_add => hip_csr_matvec_add
-    procedure :: matvec_t => hip_csr_matvec_t
-    procedure :: matvec_t_add => hip_csr_matvec_t_add
     procedure :: left_permute => hip_csr_left_permute
     procedure :: right_permute => hip_csr_right_permute
     procedure :: destroy => hip_csr_destroy
@@ -292,16 +578,15 @@ end type hip_csr_matrix
 
 
 !--------------------------------------------------------------------------!
-type :: hip_ellpack_matrix                                                 !
+type, extends(hip_matrix) :: hip_ellpack_matrix                            !
 !--------------------------------------------------------------------------!
 ! Same host data as ellpack_matrix (ellpack_matrices.f90:28-33):           !
 ! node(max_d,n), degrees(n), val(max_d,n); padding slots repeat the last   !
 ! neighbour (ellpack_graphs.f90:164).                                      !
 !--------------------------------------------------------------------------!
-    integer :: nrow = 0, ncol = 0, max_d = 0
+    integer :: max_d = 0
     integer, allocatable :: node(:,:), degrees(:)
     real(dp), allocatable :: val(:,:)
-    type(c_ptr) :: handle = c_null_ptr
     logical :: values_dirty = .true.
 contains
     procedure :: init => hip_ell_init
@@ -309,10 +594,94 @@ contains
     procedure :: set_value => hip_ell_set_value
     procedure :: zero => hip_ell_zero
     procedure :: upload => hip_ell_upload
-    procedure :: matvec => hip_ell_matvec
-    procedure :: matvec_add => hip_ell_matvec_add
     procedure :: destroy => hip_ell_destroy
 end type hip_ellpack_matrix
+
+
+!--------------------------------------------------------------------------!
+type :: hip_matrix_pointer                                                 !
+!--------------------------------------------------------------------------!
+    class(hip_matrix), pointer :: mat => null()
+end type hip_matrix_pointer
+
+
+!--------------------------------------------------------------------------!
+type, extends(hip_matrix) :: hip_sparse_matrix                             !
+!--------------------------------------------------------------------------!
+! type(sparse_matrix), the block "matrix of matrices"                      !
+! (sparse_matrix_composites.f90:41-162): set_num_blocks, set_block_sizes,  !
+! set_submatrix(it, jt, B) with hip_csr_matrix / hip_ellpack_matrix leaves !
+! (which stay the caller's); matvec_add is the reference's block loop      !
+! (:1076-1099) run by the device over ONE handle (sgm_composite_create);   !
+! the unpreconditioned and Jacobi-preconditioned solvers take it like any  !
+! other matrix.                                                            !
+!--------------------------------------------------------------------------!
+    integer :: num_row_mats = 0, num_col_mats = 0
+    integer, allocatable :: row_ptr(:), col_ptr(:)
+    type(hip_matrix_pointer), allocatable :: sub_mats(:,:)
+    type(c_ptr), allocatable :: built_from(:)
+contains
+    procedure :: set_num_blocks => hip_comp_set_num_blocks
+    procedure :: set_block_sizes => hip_comp_set_block_sizes
+    procedure :: set_submatrix => hip_comp_set_submatrix
+    procedure :: upload => hip_comp_upload
+    procedure :: destroy => hip_comp_destroy
+end type hip_sparse_matrix
+
+
+!--------------------------------------------------------------------------!
+type :: hip_comm                                                           !
+!--------------------------------------------------------------------------!
+! One process per GPU, rank r of nranks; RCCL's 128-byte unique id goes    !
+! from rank 0 to the others through a file (no MPI needed).                !
+!--------------------------------------------------------------------------!
+    integer :: rank = 0, nranks = 1
+    type(c_ptr) :: handle = c_null_ptr
+contains
+    procedure :: init => hip_comm_init
+    procedure :: destroy => hip_comm_destroy
+end type hip_comm
+
+
+!--------------------------------------------------------------------------!
+type, extends(hip_matrix) :: hip_dist_csr_matrix                           !
+!--------------------------------------------------------------------------!
+! This rank's contiguous row block of a square CSR matrix partitioned over !
+! the ranks of a hip_comm.  nrow = ncol = the owned rows: products and     !
+! solves take the owned slices of the vectors; halo entries of x travel    !
+! between neighbour ranks inside the library, dot products inside the      !
+! solvers are all-reduced.                                                 !
+!--------------------------------------------------------------------------!
+    integer :: nrow_global = 0, row_first = 0, row_last = 0
+    integer(c_int64_t) :: x_len = 0
+    integer(c_int64_t), allocatable :: row_starts(:)
+contains
+    procedure :: distribute => hip_dist_distribute
+    procedure :: upload => hip_dist_upload
+    procedure :: matvec => hip_dist_matvec
+    procedure :: matvec_add => hip_dist_matvec_add
+    procedure :: destroy => hip_dist_destroy
+end type hip_dist_csr_matrix
+
+
+!--------------------------------------------------------------------------!
+type :: hip_device_vector                                                  !
+!--------------------------------------------------------------------------!
+! A vector that lives in HBM (sgm_malloc / sgm_memcpy / sgm_free): solves  !
+! and products on device vectors cross PCIe only when the host asks        !
+! (upload / download).  `view` is a Fortran array pointer onto the device  !
+! memory -- an ADDRESS to hand to the library with SGM_DEVICE, never to be !
+! dereferenced on the host.                                                !
+!--------------------------------------------------------------------------!
+    integer :: n = 0
+    type(c_ptr) :: p = c_null_ptr
+    real(dp), pointer :: view(:) => null()
+contains
+    procedure :: alloc => hip_dvec_alloc
+    procedure :: upload => hip_dvec_upload
+    procedure :: download => hip_dvec_download
+    procedure :: free => hip_dvec_free
+end type hip_device_vector
 
 
 !--------------------------------------------------------------------------!
@@ -329,14 +698,12 @@ type :: hip_linear_solver                                                  !
     integer :: restart = 30
     type(c_ptr) :: handle = c_null_ptr
 contains
-    procedure :: setup_csr => hip_solver_setup_csr
-    procedure :: setup_ell => hip_solver_setup_ell
-    generic :: setup => setup_csr, setup_ell
-    procedure :: solve_csr => hip_solver_solve_csr
-    procedure :: solve_csr_pc => hip_solver_solve_csr_pc
-    procedure :: solve_ell => hip_solver_solve_ell
-    procedure :: solve_ell_pc => hip_solver_solve_ell_pc
-    generic :: solve => solve_csr, solve_csr_pc, solve_ell, solve_ell_pc
+    procedure :: setup => hip_solver_setup
+    procedure :: solve_plain => hip_solver_solve
+    procedure :: solve_pc => hip_solver_solve_pc
+    generic :: solve => solve_plain, solve_pc
+    procedure :: solve_device => hip_solver_solve_device
+    procedure :: set_max_iter => hip_solver_set_max_iter
     procedure :: destroy => hip_solver_destroy
 end type hip_linear_solver
 
@@ -454,37 +821,55 @@ subroutine hip_csr_upload(A)
     A%values_dirty = .false.
 end subroutine
 
-subroutine hip_csr_matvec(A, x, y)      ! linear_operator_interface.f90:185-194
-    class(hip_csr_matrix), intent(inout) :: A
+!==========================================================================!
+!==== products: the same for every matrix type                          ====!
+!==========================================================================!
+subroutine hip_matrix_matvec(A, x, y)      ! linear_operator_interface.f90:185-194
+    class(hip_matrix), intent(inout) :: A
     real(dp), intent(in) :: x(:)
     real(dp), intent(out) :: y(:)
     call A%upload()
     call hip_check(sgm_mat_matvec(A%handle, x, y, SGM_HOST))
 end subroutine
 
-subroutine hip_csr_matvec_add(A, x, y)  ! cs_matrices.f90:600-622
-    class(hip_csr_matrix), intent(inout) :: A
+subroutine hip_matrix_matvec_add(A, x, y)  ! cs_matrices.f90:600-622, ellpack_matrices.f90:640-665
+    class(hip_matrix), intent(inout) :: A
     real(dp), intent(in) :: x(:)
     real(dp), intent(inout) :: y(:)
     call A%upload()
     call hip_check(sgm_mat_matvec_add(A%handle, x, y, SGM_HOST))
 end subroutine
 
-subroutine hip_csr_matvec_t(A, x, y)    ! linear_operator_interface.f90:199-208
-    class(hip_csr_matrix), intent(inout) :: A
+subroutine hip_matrix_matvec_t(A, x, y)    ! linear_operator_interface.f90:199-208
+    class(hip_matrix), intent(inout) :: A
     real(dp), intent(in) :: x(:)
     real(dp), intent(out) :: y(:)
     call A%upload()
     call hip_check(sgm_mat_matvec_t(A%handle, x, y, SGM_HOST))
 end subroutine
 
-subroutine hip_csr_matvec_t_add(A, x, y)  ! csc_matvec_add, cs_matrices.f90:627-647
-    class(hip_csr_matrix), intent(inout) :: A
+subroutine hip_matrix_matvec_t_add(A, x, y)  ! csc_matvec_add, cs_matrices.f90:627-647
+    class(hip_matrix), intent(inout) :: A
     real(dp), intent(in) :: x(:)
     real(dp), intent(inout) :: y(:)
     call A%upload()
     call hip_check(sgm_mat_matvec_t_add(A%handle, x, y, SGM_HOST))
 end subroutine
+
+function hip_matrix_kernel_name(A) result(name)
+    ! the SpMV kernel variant the matrix runs with (diagnostics: sgm_mat_kernel)
+    class(hip_matrix), intent(inout) :: A
+    character(len=:), allocatable :: name
+    character(kind=c_char) :: buf(64)
+    integer :: k
+    call A%upload()
+    call hip_check(sgm_mat_kernel(A%handle, buf, 64_c_int))
+    name = ''
+    do k = 1, 64
+        if (buf(k) == c_null_char) exit
+        name = name // buf(k)
+    enddo
+end function
 
 ! cs_matrices.f90:471-490: the permutation runs on the device; the host copies of the arrays
 ! (kept for get_value / set_value) are refreshed from it
@@ -617,22 +1002,6 @@ subroutine hip_ell_upload(A)
     A%values_dirty = .false.
 end subroutine
 
-subroutine hip_ell_matvec(A, x, y)
-    class(hip_ellpack_matrix), intent(inout) :: A
-    real(dp), intent(in) :: x(:)
-    real(dp), intent(out) :: y(:)
-    call A%upload()
-    call hip_check(sgm_mat_matvec(A%handle, x, y, SGM_HOST))
-end subroutine
-
-subroutine hip_ell_matvec_add(A, x, y)             ! ellpack_matrices.f90:640-665
-    class(hip_ellpack_matrix), intent(inout) :: A
-    real(dp), intent(in) :: x(:)
-    real(dp), intent(inout) :: y(:)
-    call A%upload()
-    call hip_check(sgm_mat_matvec_add(A%handle, x, y, SGM_HOST))
-end subroutine
-
 subroutine hip_ell_destroy(A)
     class(hip_ellpack_matrix), intent(inout) :: A
     if (c_associated(A%handle)) call hip_check(sgm_mat_destroy(A%handle))
@@ -720,16 +1089,9 @@ subroutine hip_solver_setup_handle(s, Ah, nrow)
     s%initialized = .true.
 end subroutine
 
-subroutine hip_solver_setup_csr(s, A)
+subroutine hip_solver_setup(s, A)
     class(hip_linear_solver), intent(inout) :: s
-    type(hip_csr_matrix), intent(inout) :: A
-    call A%upload()
-    call hip_solver_setup_handle(s, A%handle, A%nrow)
-end subroutine
-
-subroutine hip_solver_setup_ell(s, A)
-    class(hip_linear_solver), intent(inout) :: s
-    type(hip_ellpack_matrix), intent(inout) :: A
+    class(hip_matrix), intent(inout) :: A
     call A%upload()
     call hip_solver_setup_handle(s, A%handle, A%nrow)
 end subroutine
@@ -742,28 +1104,30 @@ subroutine hip_solver_solve_handle(s, Ah, x, b, pch)
     integer(c_int64_t) :: its, last
     real(c_double) :: res2
     integer(c_int32_t) :: conv
+    integer(c_int) :: rc
     if (s%kind > 10) then
         ! a preconditioner used as a solver: pc%solve(A, x, b)  (jacobi_solve / ldu_solve)
         call hip_check(sgm_pc_apply(s%handle, b, x, SGM_HOST))
         return
     endif
-    call hip_check(sgm_solver_solve(s%handle, Ah, x, b, pch, SGM_HOST))
+    rc = sgm_solver_solve(s%handle, Ah, x, b, pch, SGM_HOST)
+    if (rc /= 5) call hip_check(rc)         ! 5 = stopped at the set_max_iter extension: the caller reads %iterations
     call hip_check(sgm_solver_info(s%handle, its, res2, conv, last))
     s%iterations = int(its)
 end subroutine
 
-subroutine hip_solver_solve_csr(s, A, x, b)
+subroutine hip_solver_solve(s, A, x, b)
     class(hip_linear_solver), intent(inout) :: s
-    type(hip_csr_matrix), intent(inout) :: A
+    class(hip_matrix), intent(inout) :: A
     real(dp), intent(inout) :: x(:)
     real(dp), intent(in) :: b(:)
     call A%upload()
     call hip_solver_solve_handle(s, A%handle, x, b, c_null_ptr)
 end subroutine
 
-subroutine hip_solver_solve_csr_pc(s, A, x, b, pc)
+subroutine hip_solver_solve_pc(s, A, x, b, pc)
     class(hip_linear_solver), intent(inout) :: s
-    type(hip_csr_matrix), intent(inout) :: A
+    class(hip_matrix), intent(inout) :: A
     real(dp), intent(inout) :: x(:)
     real(dp), intent(in) :: b(:)
     type(hip_linear_solver), intent(inout) :: pc
@@ -771,23 +1135,76 @@ subroutine hip_solver_solve_csr_pc(s, A, x, b, pc)
     call hip_solver_solve_handle(s, A%handle, x, b, pc%handle)
 end subroutine
 
-subroutine hip_solver_solve_ell(s, A, x, b)
+subroutine hip_solver_solve_device(s, A, x, b, pc)
+    ! the same solve on vectors that already live in HBM: nothing crosses PCIe
     class(hip_linear_solver), intent(inout) :: s
-    type(hip_ellpack_matrix), intent(inout) :: A
-    real(dp), intent(inout) :: x(:)
-    real(dp), intent(in) :: b(:)
+    class(hip_matrix), intent(inout) :: A
+    type(hip_device_vector), intent(inout) :: x
+    type(hip_device_vector), intent(in) :: b
+    type(hip_linear_solver), intent(inout), optional :: pc
+    integer(c_int64_t) :: its, last
+    real(c_double) :: res2
+    integer(c_int32_t) :: conv
+    type(c_ptr) :: hp
+    integer(c_int) :: rc
+    hp = c_null_ptr
+    if (present(pc)) hp = pc%handle
     call A%upload()
-    call hip_solver_solve_handle(s, A%handle, x, b, c_null_ptr)
+    rc = sgm_solver_solve(s%handle, A%handle, x%view, b%view, hp, SGM_DEVICE)
+    if (rc /= 5) call hip_check(rc)
+    call hip_check(sgm_solver_info(s%handle, its, res2, conv, last))
+    s%iterations = int(its)
 end subroutine
 
-subroutine hip_solver_solve_ell_pc(s, A, x, b, pc)
+subroutine hip_dvec_alloc(v, n)
+    class(hip_device_vector), intent(inout) :: v
+    integer, intent(in) :: n
+    call hip_check(sgm_malloc(v%p, int(8, c_size_t) * max(n, 1)))
+    v%n = n
+    call c_f_pointer(v%p, v%view, [n])
+end subroutine
+
+subroutine hip_dvec_upload(v, x)
+    class(hip_device_vector), intent(inout) :: v
+    real(dp), intent(in), target :: x(:)
+    call hip_check(sgm_memcpy(v%p, c_loc(x), int(8, c_size_t) * v%n, 0_c_int))
+end subroutine
+
+subroutine hip_dvec_download(v, x)
+    class(hip_device_vector), intent(in) :: v
+    real(dp), intent(out), target :: x(:)
+    call hip_check(sgm_memcpy(c_loc(x), v%p, int(8, c_size_t) * v%n, 1_c_int))
+end subroutine
+
+subroutine hip_dvec_free(v)
+    class(hip_device_vector), intent(inout) :: v
+    if (c_associated(v%p)) call hip_check(sgm_free(v%p))
+    v%p = c_null_ptr
+    v%n = 0
+    nullify(v%view)
+end subroutine
+
+function hip_dot(x, y) result(d)          ! dot_product(a, b), cg_solvers.f90:131 (device kernel, host vectors)
+    real(dp), intent(in) :: x(:), y(:)
+    real(dp) :: d
+    call hip_check(sgm_dot(int(size(x), c_int64_t), x, y, d, SGM_HOST))
+end function
+
+subroutine hip_axpy(alpha, x, y)          ! y = y + alpha * x, cg_solvers.f90:137-138
+    real(dp), intent(in) :: alpha, x(:)
+    real(dp), intent(inout) :: y(:)
+    call hip_check(sgm_axpy(int(size(x), c_int64_t), alpha, x, y, SGM_HOST))
+end subroutine
+
+subroutine hip_solver_set_max_iter(s, max_iter)
+    ! extension (the reference has no iteration cap): takes effect at the next setup / solve
     class(hip_linear_solver), intent(inout) :: s
-    type(hip_ellpack_matrix), intent(inout) :: A
-    real(dp), intent(inout) :: x(:)
-    real(dp), intent(in) :: b(:)
-    type(hip_linear_solver), intent(inout) :: pc
-    call A%upload()
-    call hip_solver_solve_handle(s, A%handle, x, b, pc%handle)
+    integer, intent(in) :: max_iter
+    if (.not. c_associated(s%handle)) then
+        print *, 'hip_linear_solver%set_max_iter: call setup first'
+        call exit(1)
+    endif
+    call hip_check(sgm_solver_set_max_iter(s%handle, int(max_iter, c_int64_t)))
 end subroutine
 
 subroutine hip_solver_destroy(s)                   ! cg_solvers.f90:199-212
@@ -803,6 +1220,291 @@ subroutine hip_solver_destroy(s)                   ! cg_solvers.f90:199-212
     s%nn = 0
     s%iterations = 0
     s%initialized = .false.
+end subroutine
+
+
+
+!==========================================================================!
+!==== assembly on the device (sgm_csr_from_edges)                       ====!
+!==========================================================================!
+subroutine hip_csr_from_edges(A, nrow, ncol, ei, ej, ev)
+    ! g%add_edge(i,j)... ; convert_graph_type ; A%set_graph ; A%set_value(i,j,z)... (test/solver_test_jacobi.f90:73-128)
+    ! from the edge list in insertion order: repeated edges ignored, the last value written wins.  The arrays the
+    ! reference would hold are read back into A%ptr / A%node / A%val.
+    type(hip_csr_matrix), intent(inout), target :: A
+    integer, intent(in) :: nrow, ncol
+    integer(c_int32_t), intent(in) :: ei(:), ej(:)
+    real(dp), intent(in) :: ev(:)
+    integer(c_int32_t) :: n32, m32, fmt
+    integer(c_int64_t) :: nnz, xl
+    call hip_check(sgm_csr_from_edges(A%handle, int(nrow, c_int32_t), int(ncol, c_int32_t), int(size(ei), c_int64_t), &
+        & ei, ej, ev, SGM_HOST))
+    call hip_check(sgm_mat_info(A%handle, n32, m32, nnz, fmt, xl))
+    A%nrow = nrow
+    A%ncol = ncol
+    if (allocated(A%ptr)) deallocate(A%ptr, A%node, A%val)
+    allocate(A%ptr(nrow + 1), A%node(nnz), A%val(nnz))
+    call hip_csr_download(A)
+end subroutine
+
+
+!==========================================================================!
+!==== the composite (sparse_matrix_composites.f90:41-162)               ====!
+!==========================================================================!
+subroutine hip_comp_set_num_blocks(A, num_row_mats, num_col_mats)      ! :203-223
+    class(hip_sparse_matrix), intent(inout) :: A
+    integer, intent(in) :: num_row_mats, num_col_mats
+    A%num_row_mats = num_row_mats
+    A%num_col_mats = num_col_mats
+    allocate(A%row_ptr(num_row_mats + 1), A%col_ptr(num_col_mats + 1))
+    A%row_ptr = 0
+    A%col_ptr = 0
+    allocate(A%sub_mats(num_row_mats, num_col_mats))
+end subroutine
+
+subroutine hip_comp_set_block_sizes(A, rows, cols)                     ! :228-263
+    class(hip_sparse_matrix), intent(inout) :: A
+    integer, intent(in) :: rows(:), cols(:)
+    integer :: it
+    if (.not. allocated(A%sub_mats)) call A%set_num_blocks(size(rows), size(cols))
+    A%row_ptr(1) = 1
+    A%col_ptr(1) = 1
+    do it = 1, A%num_row_mats
+        A%row_ptr(it + 1) = A%row_ptr(it) + rows(it)
+    enddo
+    do it = 1, A%num_col_mats
+        A%col_ptr(it + 1) = A%col_ptr(it) + cols(it)
+    enddo
+    A%nrow = A%row_ptr(A%num_row_mats + 1) - 1
+    A%ncol = A%col_ptr(A%num_col_mats + 1) - 1
+end subroutine
+
+subroutine hip_comp_set_submatrix(A, it, jt, B)                        ! :1031-1066
+    class(hip_sparse_matrix), intent(inout) :: A
+    integer, intent(in) :: it, jt
+    class(hip_matrix), target :: B
+    A%sub_mats(it, jt)%mat => B
+end subroutine
+
+subroutine hip_comp_upload(A)
+    ! the leaves first (their host edits), then ONE device operator over their handles; it is re-made when a leaf
+    ! handle is a new one (the leaf was re-created) or the layout changed
+    class(hip_sparse_matrix), intent(inout) :: A
+    type(c_ptr), allocatable :: blocks(:)
+    logical :: remake
+    integer :: it, jt, k
+    allocate(blocks(A%num_row_mats * A%num_col_mats))
+    do it = 1, A%num_row_mats
+        do jt = 1, A%num_col_mats
+            k = (it - 1) * A%num_col_mats + jt
+            blocks(k) = c_null_ptr
+            if (associated(A%sub_mats(it, jt)%mat)) then
+                call A%sub_mats(it, jt)%mat%upload()
+                blocks(k) = A%sub_mats(it, jt)%mat%handle
+            endif
+        enddo
+    enddo
+    remake = .not. c_associated(A%handle) .or. .not. allocated(A%built_from)
+    if (.not. remake) then
+        do k = 1, size(blocks)
+            if (c_associated(blocks(k)) .neqv. c_associated(A%built_from(k))) remake = .true.
+            if (c_associated(blocks(k)) .and. c_associated(A%built_from(k))) then
+                if (.not. c_associated(blocks(k), A%built_from(k))) remake = .true.
+            endif
+        enddo
+    endif
+    if (remake) then
+        if (c_associated(A%handle)) call hip_check(sgm_mat_destroy(A%handle))
+        call hip_check(sgm_composite_create(A%handle, int(A%num_row_mats, c_int32_t), int(A%num_col_mats, c_int32_t), &
+            & A%row_ptr, A%col_ptr, blocks))
+        A%built_from = blocks
+    endif
+end subroutine
+
+subroutine hip_comp_destroy(A)
+    class(hip_sparse_matrix), intent(inout) :: A
+    if (c_associated(A%handle)) call hip_check(sgm_mat_destroy(A%handle))
+    A%handle = c_null_ptr
+    if (allocated(A%sub_mats)) deallocate(A%sub_mats, A%row_ptr, A%col_ptr)
+    if (allocated(A%built_from)) deallocate(A%built_from)
+    A%num_row_mats = 0
+    A%num_col_mats = 0
+end subroutine
+
+
+!==========================================================================!
+!==== Lanczos (src/eigensolver.f90)                                     ====!
+!==========================================================================!
+subroutine hip_lanczos(A, T, Q, q1)
+    ! lanczos(A, T, Q) (eigensolver.f90:27-90); q1 (optional): the start vector -- the reference draws it from a
+    ! time-seeded RNG (:46-52); without it a random one is drawn here the same way (random_number, 2 q - 1)
+    class(hip_matrix), intent(inout) :: A
+    real(dp), intent(out) :: T(:,:), Q(:,:)
+    real(dp), intent(in), optional :: q1(:)
+    real(dp), allocatable :: q0(:), Tc(:,:), Qc(:,:)
+    integer :: n
+    n = size(T, 2)
+    allocate(q0(A%nrow), Tc(3, n), Qc(A%nrow, n))
+    if (present(q1)) then
+        q0 = q1
+    else
+        call random_number(q0)
+        q0 = 2 * q0 - 1
+    endif
+    call A%upload()
+    call hip_check(sgm_lanczos(A%handle, int(n, c_int32_t), q0, Tc, Qc, SGM_HOST))
+    T = 0.0_dp
+    Q = 0.0_dp
+    T(1:3, 1:n) = Tc
+    Q(1:A%nrow, 1:n) = Qc
+end subroutine
+
+subroutine hip_generalized_lanczos(A, B, solver_for_B, T, Q, q1, pc)
+    ! generalized_lanczos(A, B, T, Q) (eigensolver.f90:95-155): the reference finds B's solver in B%solver
+    ! (B%set_solver); this layer's matrices carry no solver, so it is an argument (set up for B by the caller)
+    class(hip_matrix), intent(inout) :: A, B
+    type(hip_linear_solver), intent(inout) :: solver_for_B
+    real(dp), intent(out) :: T(:,:), Q(:,:)
+    real(dp), intent(in), optional :: q1(:)
+    type(hip_linear_solver), intent(inout), optional :: pc
+    real(dp), allocatable :: q0(:), Tc(:,:), Qc(:,:)
+    type(c_ptr) :: hp
+    integer :: n
+    n = size(T, 2)
+    allocate(q0(A%nrow), Tc(3, n), Qc(A%nrow, n))
+    if (present(q1)) then
+        q0 = q1
+    else
+        call random_number(q0)
+        q0 = 2 * q0 - 1
+    endif
+    hp = c_null_ptr
+    if (present(pc)) hp = pc%handle
+    call A%upload()
+    call B%upload()
+    call hip_check(sgm_generalized_lanczos(A%handle, B%handle, solver_for_B%handle, hp, int(n, c_int32_t), q0, Tc, Qc, &
+        & SGM_HOST))
+    T = 0.0_dp
+    Q = 0.0_dp
+    T(1:3, 1:n) = Tc
+    Q(1:A%nrow, 1:n) = Qc
+end subroutine
+
+
+!==========================================================================!
+!==== row-partitioned multi-GPU: one process per GPU                    ====!
+!==========================================================================!
+subroutine hip_comm_init(comm, rank, nranks, id_file, device)
+    ! rank 0 makes RCCL's unique id, writes it to `id_file` and then creates `id_file`.ready; the other ranks wait
+    ! for the marker and read the id.  device (optional): the GPU this process drives (default: rank)
+    class(hip_comm), intent(inout) :: comm
+    integer, intent(in) :: rank, nranks
+    character(len=*), intent(in) :: id_file
+    integer, intent(in), optional :: device
+    character(kind=c_char) :: id(128)
+    integer :: u, dev, waited
+    logical :: there
+    dev = rank
+    if (present(device)) dev = device
+    call hip_check(sgm_init(int(dev, c_int)))
+    comm%rank = rank
+    comm%nranks = nranks
+    if (rank == 0) then
+        call hip_check(sgm_comm_unique_id(id))
+        open(newunit=u, file=id_file, access='stream', form='unformatted', status='replace')
+        write(u) id
+        close(u)
+        open(newunit=u, file=id_file // '.ready', status='replace')
+        write(u, *) nranks
+        close(u)
+    else
+        waited = 0
+        do
+            inquire(file=id_file // '.ready', exist=there)
+            if (there) exit
+            if (waited > 120 * 100) then
+                print *, 'hip_comm%init: rank', rank, 'waited 120 s for ', id_file
+                call exit(1)
+            endif
+            u = c_usleep(10000_c_int)
+            waited = waited + 1
+        enddo
+        open(newunit=u, file=id_file, access='stream', form='unformatted', status='old')
+        read(u) id
+        close(u)
+    endif
+    call hip_check(sgm_comm_init(comm%handle, int(rank, c_int), int(nranks, c_int), id))
+end subroutine
+
+subroutine hip_comm_destroy(comm)
+    class(hip_comm), intent(inout) :: comm
+    if (c_associated(comm%handle)) call hip_check(sgm_comm_destroy(comm%handle))
+    comm%handle = c_null_ptr
+end subroutine
+
+subroutine hip_dist_distribute(Ad, comm, A)
+    ! every rank holds the assembled matrix A and keeps its own row block of it on its GPU: contiguous blocks
+    ! balanced by stored entries (sgm_partition_rows_by_nnz), boundaries on even rows.  Collective.
+    class(hip_dist_csr_matrix), intent(inout) :: Ad
+    type(hip_comm), intent(in) :: comm
+    type(hip_csr_matrix), intent(in) :: A
+    integer(c_int32_t), allocatable :: lptr(:)
+    integer(c_int32_t) :: n32, m32, fmt
+    integer(c_int64_t) :: nnz, nnz_glob
+    integer :: r0, r1, k0, k1
+    allocate(Ad%row_starts(comm%nranks + 1))
+    call hip_check(sgm_partition_rows_by_nnz(int(A%nrow, c_int32_t), A%ptr, int(comm%nranks, c_int32_t), 2_c_int32_t, &
+        & Ad%row_starts))
+    r0 = int(Ad%row_starts(comm%rank + 1))
+    r1 = int(Ad%row_starts(comm%rank + 2))
+    k0 = A%ptr(r0 + 1)
+    k1 = A%ptr(r1 + 1)
+    nnz = k1 - k0
+    allocate(lptr(r1 - r0 + 1))
+    lptr = A%ptr(r0 + 1 : r1 + 1) - k0 + 1
+    call hip_check(sgm_csr_create_dist(Ad%handle, comm%handle, Ad%row_starts, nnz, lptr, A%node(k0 : k1 - 1), &
+        & A%val(k0 : k1 - 1), SGM_HOST))
+    call hip_check(sgm_mat_info(Ad%handle, n32, m32, nnz_glob, fmt, Ad%x_len))
+    Ad%nrow_global = A%nrow
+    Ad%row_first = r0 + 1
+    Ad%row_last = r1
+    Ad%nrow = r1 - r0
+    Ad%ncol = r1 - r0
+end subroutine
+
+subroutine hip_dist_upload(A)
+    class(hip_dist_csr_matrix), intent(inout) :: A
+    if (.not. c_associated(A%handle)) then
+        print *, 'hip_dist_csr_matrix used before distribute'
+        call exit(1)
+    endif
+end subroutine
+
+subroutine hip_dist_matvec_add(A, x, y)
+    ! x, y: the owned slices; the library reads x as [owned | halo room] and fills the halo part itself
+    class(hip_dist_csr_matrix), intent(inout) :: A
+    real(dp), intent(in) :: x(:)
+    real(dp), intent(inout) :: y(:)
+    real(dp), allocatable :: xext(:)
+    allocate(xext(max(A%x_len, 1_c_int64_t)))
+    xext = 0.0_dp
+    xext(1 : A%nrow) = x(1 : A%nrow)
+    call hip_check(sgm_mat_matvec_add(A%handle, xext, y, SGM_HOST))
+end subroutine
+
+subroutine hip_dist_matvec(A, x, y)
+    class(hip_dist_csr_matrix), intent(inout) :: A
+    real(dp), intent(in) :: x(:)
+    real(dp), intent(out) :: y(:)
+    y = 0.0_dp
+    call hip_dist_matvec_add(A, x, y)
+end subroutine
+
+subroutine hip_dist_destroy(A)
+    class(hip_dist_csr_matrix), intent(inout) :: A
+    if (c_associated(A%handle)) call hip_check(sgm_mat_destroy(A%handle))
+    A%handle = c_null_ptr
+    if (allocated(A%row_starts)) deallocate(A%row_starts)
 end subroutine
 
 end module sigma_hip

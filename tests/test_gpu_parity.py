@@ -2954,6 +2954,24 @@ def test_fortran_host_layer():
     assert "all sigma_hip Fortran checks passed" in r.stdout
 
 
+def test_fortran_host_layer_reaches_the_whole_surface():
+    """sigma_amd/fortran/surface_test_hip: device assembly, the composite, Lanczos / generalized Lanczos, device
+    vectors (sgm_malloc / sgm_memcpy), dot / axpy -- every part of the C ABI the first example does not touch,
+    through module sigma_hip."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sigma_amd", "fortran", "surface_test_hip")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran example not built (no amdflang at build time)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout.replace("\n ", "")          # (list-directed output wraps at 80 columns)
+    for line in ("hip_csr_from_edges: arrays and product identical", "composite: hip_cg iterations", "hip_lanczos: recurrence",
+                 "hip_generalized_lanczos: three-term recurrence", "device vectors: the same solve, bit for bit",
+                 "all sigma_hip surface checks passed"):
+        assert line in out, r.stdout
+
+
 def test_reference_side_binding_runs_the_references_own_tests():
     """oracle/_ref/hip_binding_test (built in the reference container by oracle/build_ref.sh; the
     binary travels, the reference sources do not): the reference's graph / matrix code on the host,
@@ -2972,6 +2990,14 @@ def test_reference_side_binding_runs_the_references_own_tests():
     assert "bit-identical to the reference" in p.stdout and "all passed" in p.stdout
     its = [int(ln.split("iterations")[1].split()[0]) for ln in p.stdout.splitlines() if "reference cg() on hip matrix" in ln]
     assert its == [64]          # the reference's own count on this problem
+    # round 4: the flows of the reference's remaining solver / matvec / eigensolver tests and the composite, hip types
+    for line in ("jacobi flow: stationary iteration error", "jacobi flow: hip_cg + hip_jacobi error",
+                 "jacobi flow: hip_bicgstab + hip_jacobi on the perturbed matrix", "incomplete cholesky flow: stationary iteration error",
+                 "incomplete cholesky flow: hip_cg + hip_ldu error", "matvec / matvec_t against the dense product: within 1e-15",
+                 "hip_csr_from_edges: ptr / node / val and products identical",
+                 "composite (2 x 2 hip leaves): block loop and one-handle product bit-identical", "composite: reference cg iterations",
+                 "hip_lanczos: three-term recurrence and orthogonality within 1e-14", "hip_generalized_lanczos: recurrence within 1e-14"):
+        assert line in p.stdout.replace("\n ", ""), p.stdout
 
 
 @pytest.mark.gpu

@@ -7,6 +7,9 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+_TOOLS = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _TOOLS)
+sys.path.insert(0, os.path.join(_TOOLS, "probes"))
 import torch  # noqa: E402
 
 import sigma_amd as sg  # noqa: E402

@@ -7,6 +7,9 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+_TOOLS = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _TOOLS)
+sys.path.insert(0, os.path.join(_TOOLS, "probes"))
 import torch  # noqa: E402
 
 import sigma_amd as sg  # noqa: E402
@@ -32,6 +35,9 @@ def build(spec, dev):
         one = torch.ones(n, dtype=torch.bool, device=dev)
         return n, stencil_csr_torch(n, [(-nx, j > 0, -1.0), (-1, i > 0, -1.0), (0, one, 4.0),
                                         (1, i < nx - 1, -1.0), (nx, j < ny - 1, -1.0)], dev)
+    if "x" in dims:       # 3d:464x464x58 = one of eight ranks' z-slab of the 464^3 grid (interior planes only: no halo)
+        nx, ny, nz = (int(t) for t in dims.split("x"))
+        return nx * ny * nz, laplace3d_torch(nx, ny, nz, dev)
     m = int(dims)
     return m ** 3, laplace3d_torch(m, m, m, dev)
 
