@@ -493,14 +493,12 @@ def worker(args):
                              ("int32_columns, streaming gather (general kernel, any row length)",
                               {"csr_offset_dict": 0, "csr_row_owner": 0, "csr_row_lines": 0})):
             for k, v in opts.items():
-                sg.set_option(k, v)
+                A.set_option(k, v)              # this handle's own options (they are per handle)
             for _ in range(5):
                 A.matvec(x, y)
             variants[vlabel] = variant_entry(A, time_kernel(A, x, y, reps=50), time_kernel(A, x, y, reps=20, flush=scratch))
-            sg.set_option("csr_offset_dict", 1)
-            sg.set_option("csr_row_owner", 1)
-            sg.set_option("csr_row_lines", 1)
-            sg.set_option("csr_sliced", 1)
+            for k in ("csr_offset_dict", "csr_row_owner", "csr_row_lines", "csr_sliced"):
+                A.set_option(k, 1)
         # a handle created WITHOUT the dictionary: short rows take the sliced int32-column kernel
         # (what a matrix with arbitrary columns and rows <= 32 entries of similar length gets; 12 B per slot)
         sg.set_option("csr_offset_dict", 0)
@@ -817,14 +815,11 @@ def c4_leg(sg, P, torch, dev, n=5_000_000, d=32, both_kernels=True):
     out["kernel"] = A.kernel
     out.update(spmv_fracs(t, A.footprint()[1], survey))
     if both_kernels:
-        sg.set_option("ell_colblock", 0)
-        try:
-            t2 = timed_launches(torch, lambda: A.matvec(x, y), 15)
-            e = {"kernel": A.kernel}
-            e.update(spmv_fracs(t2, A.footprint()[1], survey))
-            out["slot_major_kernel"] = e
-        finally:
-            sg.set_option("ell_colblock", 1)
+        A.set_option("ell_colblock", 0)
+        t2 = timed_launches(torch, lambda: A.matvec(x, y), 15)
+        e = {"kernel": A.kernel}
+        e.update(spmv_fracs(t2, A.footprint()[1], survey))
+        out["slot_major_kernel"] = e
     A.destroy()
     return out
 
@@ -999,20 +994,17 @@ def c1_leg(sg, P, torch, dev, n=10000, tol=1e-16):
            "gpu_max_err_vs_analytic": float(np.abs(u.cpu().numpy() - v).max())}
     # the same solve with the reference's dot_product order (option dot_order = 1: one accumulator, first element to last):
     # the iterates are then the reference's bit for bit -- it stops where the reference stops
-    sg.set_option("dot_order", 1)
-    try:
-        u.zero_()
-        s.solve(A, u, b)
-        torch.cuda.synchronize()
-        u.zero_()
-        t0 = time.perf_counter()
-        s.solve(A, u, b)
-        torch.cuda.synchronize()
-        out["gpu_dot_order1_ms"] = 1e3 * (time.perf_counter() - t0)
-        out["gpu_dot_order1_iterations"] = int(s.last_iterations)
-        out["gpu_dot_order1_max_err_vs_analytic"] = float(np.abs(u.cpu().numpy() - v).max())
-    finally:
-        sg.set_option("dot_order", 0)
+    s.set_option("dot_order", 1)
+    u.zero_()
+    s.solve(A, u, b)
+    torch.cuda.synchronize()
+    u.zero_()
+    t0 = time.perf_counter()
+    s.solve(A, u, b)
+    torch.cuda.synchronize()
+    out["gpu_dot_order1_ms"] = 1e3 * (time.perf_counter() - t0)
+    out["gpu_dot_order1_iterations"] = int(s.last_iterations)
+    out["gpu_dot_order1_max_err_vs_analytic"] = float(np.abs(u.cpu().numpy() - v).max())
     s.destroy()
     A.destroy()
     drv = os.path.join(ROOT, "oracle", "_ref", "sigma_ref_driver")

@@ -58,87 +58,85 @@ const char *sgm_last_error(void);
 int sgm_set_stream(void *hip_stream);     /* adopt the caller's hipStream_t (NULL = library stream) */
 int sgm_set_async(int on);                /* 1: calls return without hipStreamSynchronize */
 int sgm_synchronize(void);
-/* options: "csr_offset_dict" (default 1): CSR matrices whose column-minus-row offsets take
- * at most 255 distinct values (every stencil / banded matrix) get a second device copy of
- * the column indices as 1-byte dictionary codes, and matvec streams 9 instead of 12 bytes
- * per stored entry.  Results are bit-identical either way; 0 forces the int32 kernels.
- * "ell_offset_dict" (default 1): the same for ELLPACK matrices with max_d <= 16.
- * "csr_row_owner" (default 1): int32-column matrices whose rows hold <= 64 entries use the
- * row-owner gather kernel; 0 forces the kernels for longer rows.
- * "csr_row_lines" (default 1): int32-column matrices with longer rows of similar length (mean >= 16
- * entries, no row beyond 4096 or beyond 4 x the mean) use the line-staged row-owner kernel (one 128-byte line of values per row and pass, every row of a
- * 256-row block walked by its owner lane); 0 forces the balanced streaming-gather kernel (any row
- * length).
- * "csr_sliced" (default 1): offset-dictionary matrices whose rows hold <= 8 entries from <= 15
- * distinct offsets (1-D/2-D/3-D stencils) also keep their values in slices of 512 rows,
- * slot-major, plus one 32-bit word of 4-bit codes per row; a lane owns two adjacent rows, every
- * load is 16 bytes wide, coalesced and independent, no row pointers are read (8 W + 4 bytes per
- * row of width W).  5-17 % faster than the 1-byte-code kernel; 0 keeps that.
- * "ell_colblock" (default 1): ELLPACK matrices whose columns have no locality (x >= 16 MB, rows of >= 8
- * slots) take the column-blocked two-phase product (products through LDS-resident x blocks, then ordered
- * row sums); 0 never, 2 always.  "ell_colblock_cols" (default 16384): x entries per block;
- * "ell_colblock_chunks" (default 16): workgroups per block in the first phase;
- * "ell_colblock_rows" (default 0 = automatic, 256 or 512): rows per tile of the second phase.
- * "ell_colblock_band" (default -1 = one band): rows per ROW BAND of that product -- with bands the two phases run band by
- * band over one product buffer of a band's size, so that the products' round trip can stay in the 256 MiB Infinity Cache
- * (0 = automatic: a band's products + streams <= ~160 MB; else a row count, rounded up to whole tiles).  Measured on C4:
- * the second phase gains 9 %, the first loses 30 % to its per-launch x-block loads -- hence off.
- * "ell_colblock_pieces" (default 512): workgroups of the first phase per band; "ell_colblock_nt" (default 0): 1 = nontemporal
- * product stores / loads in the banded form.
- * "ildu_strips" (default 1): ILDU(0) factors of grid-like matrices use the strip- / slab-pipelined
- * triangular solves; 0 keeps the level-scheduled walkers.
- * "ildu_rows" (default 1): ILDU(0) factors of at most 32 levels (what greedy_color_ordering makes of a matrix: one level
- * per colour) are swept in row space -- one launch per level on the vectors themselves, D folded
- * into the U sweep, no gather / re-order / scatter around them (sgm_pc_get "row_levels" = {in use, launches of the L sweep,
- * of the U sweep}); 0 = the level-order walkers.  With 1 two launches are saved: L's first level, when it is the run of rows
- * 0 .. n0-1 without entries (the first colour), is never copied -- whoever wants y(q), q < n0, reads r(q) -- and the level that
- * is both L's last and U's first (the last colour) is finished inside the L sweep; 2 = row space with every level launched.
- * Same bits whichever.
- * "gmres_cgs2" (default 1): GMRES orthogonalises with blocked classical Gram-Schmidt applied twice (three
- * passes and three all-reduces per step); 0 = modified Gram-Schmidt.
- * "cg_small" (default 1): CG (plain or Jacobi-preconditioned) on a single-GPU CSR matrix of at most
- * 10240 rows (stencil matrices; 4096 otherwise) runs as ONE workgroup -- p in LDS, x and r in registers,
- * no launch inside the loop; same statements as the launch-per-kernel loop, only the dot products'
- * summation order differs.  "cg_small_chunk" (default 50000): iterations per launch of that kernel (the
- * solve continues in the next launch from parked r, p, res2 -- bit-identical to the uncut solve).
- * "slice_sched" (default 0: measured within noise of the computed slice maps): sliced matrices most of whose rows carry an offset of >= 32 slices (the
- * plane stride of a 3-D grid) hand their slices to the workgroups in a band order per XCD, so that the
- * slices one plane apart -- which read the same x entries -- share one XCD's L2; only the order in
- * which whole slices are taken changes.  "slice_sched_band" (default 64): its band width in slices.
- * "csr_sell" (default 1): general matrices (no offset dictionary) whose rows are too long or too uneven for the uniform sliced
- * form are stored as SELL-128-512: the rows of every window of 512 rows sorted by length, chunks of 128 sorted rows slot-major
- * with the chunk's own width (padding: a few per cent; built when it stays below 30 %).  One wave per chunk, coalesced
- * 16 / 8-byte loads, no LDS; rows keep their stored entry order (bit-identical sums).  Taken from a longest row of 49 entries
- * on (shorter rows: the row-owner kernel is faster); 2 = whenever the padding allows; 0 = the CSR kernels (row owner,
- * line-staged, streaming).
- * "csr_lean" (default 1): a matrix served by the 4-bit sliced form keeps ONLY that form (+ row pointers) in HBM -- C2: 0.48 GB
- * instead of 1.13 GB.  Its CSR-order values, int32 columns and 1-byte codes are a function of the slices (slot u of a row is its
- * u-th stored entry): they are rebuilt on the device for whoever reads them (the other kernels when options select them,
- * sgm_mat_get, sgm_csr_set_values, transposes, preconditioner setup, permutations, the distributed transpose) and released
- * again; 0 = every layout stays resident.  Takes effect when a matrix is created.
- * "krylov_graph" (default 1): the CG / BiCGStab launch loops on one GPU (plain or Jacobi-preconditioned) go on as replays of ONE
- * captured group of 16 iterations (a hipGraph: same kernels, same arguments, stop-flag generations relative to the group)
- * once a solve has run long enough; 0 = launch every kernel.  Replays run at the GPU-side floor of an iteration (13.3 us for
- * CG at n = 1e5) whatever the host's launch rate is (13.7-18 us when launched, box to box).
- * "krylov_graph_after" (default 64, rounded up to a multiple of 16): the iterations a solve runs before its group is captured.
- * "dot_order" (default 0): how CG / BiCGStab (plain and preconditioned) add up their dot products.  0 = tree order
- * (per-workgroup partial sums, re-reduced in a fixed order): a legal order for the Fortran intrinsic, deterministic, and
- * the fast one.  1 = the order the reference build uses (amdflang -O2 on x86-64 turns dot_product into ONE accumulator
- * fed first element to last, cg_solvers.f90:131,135,140, bicgstab_solvers.f90:152,155,160,164,169): products formed in
- * parallel, parked in LDS, added by one wave left to right (about 4 ns per element: a VALIDATION mode for n up to ~1e5, not a
- * production one).  With it every iterate, iteration count and residual is BIT-IDENTICAL to the reference's -- also on
- * row partitions and across ranks, where the running sum is handed part to part / rank to rank.  GMRES (no reference
- * counterpart) keeps the tree order.
- * "bicgstab_small" (default 1): BiCGStab (plain or Jacobi-preconditioned) on a single-GPU CSR / structured ELLPACK matrix of at
- * most 4096 rows runs as ONE workgroup, like "cg_small" (the reference's own test size, n = 1024: 24.5 -> ~11 us per
- * iteration); in tree order its iteration count may differ from the launch loop's by a few.
- * "dist_force_collectives" (default 0): 1 = a matrix distributed over ONE rank still issues its all-reduces (the fixed cost of
- * the RCCL code path, measurable on a single-GPU box: bench.py's `dist_overhead_1rank`).
- * "pipeline_spin_limit" (default 0 = built-in, 2^22 polls): how often a wait inside the strip- / slab-pipelined ILDU sweeps
- * polls before it gives up.  A sweep that gives up is never returned: sgm_pc_apply and the solvers notice (a sticky
- * device word read at their next synchronisation), redo the work with the level-scheduled sweeps and retire the pipeline
- * for that preconditioner (sgm_pc_get "pipeline_retired").  Tests set 1 to force that path.  */
+/* ---- options ------------------------------------------------------------------------- *
+ * Options choose among device formats / kernels / loop structures that all give the SAME bits (the one exception,
+ * "dot_order", is spelled out below).  They are PER HANDLE: a matrix, solver or preconditioner copies the process-wide
+ * defaults when it is created and keeps its own copy from then on --
+ *     sgm_set_option(name, v)            the default that handles created LATER start with (touches no existing handle)
+ *     sgm_mat_set_option(A, name, v)     this matrix      (composite: every block; A^T follows A)
+ *     sgm_solver_set_option(s, name, v)  this solver      (read at the next solve)
+ *     sgm_pc_set_option(pc, name, v)     this preconditioner
+ * -- so two handles of one process may run different kernels, and no caller can change another caller's solver.
+ * Unknown names, or a name of the wrong group, are SGM_ERR_BAD_ARG.
+ *
+ * Matrix options
+ *   "csr_offset_dict" (1)  CSR matrices whose column-minus-row offsets take <= 255 distinct values (every stencil / banded
+ *                          matrix) hold their columns as 1-byte dictionary codes: 9 instead of 12 bytes per entry; 0 = int32 kernels
+ *   "ell_offset_dict" (1)  the same for ELLPACK matrices with max_d <= 16
+ *   "csr_sliced" (1)       rows of <= 8 entries from <= 15 offsets (1-D / 2-D / 3-D stencils): values in slices of 512 rows,
+ *                          slot-major, one 32-bit word of 4-bit codes per row, a lane owns two adjacent rows, no row pointers
+ *                          read (8 W + 4 bytes per row of width W; k_csr_sl).  Its siblings for rows of 9..32 entries with a
+ *                          dictionary (k_csr_slb) and for <= 32 similar-length entries at arbitrary columns (k_csr_sl32)
+ *   "csr_row_owner" (1)    int32-column matrices with rows <= 64 entries: row-owner gather kernel; 0 = kernels for longer rows
+ *   "csr_row_lines" (1)    longer rows of similar length (mean >= 16, none beyond 4096 or 4 x the mean): line-staged row-owner
+ *                          kernel; 0 = the balanced streaming-gather kernel (any row length)
+ *   "csr_sell" (1)         general matrices whose rows are too long / uneven for the uniform sliced form: SELL-128-512 (rows of
+ *                          every 512-row window sorted by length, chunks of 128 rows slot-major with the chunk's own width),
+ *                          taken from a longest row of 49 entries on; 2 = whenever the padding allows; 0 = the CSR kernels
+ *   "csr_lean" (1)         a matrix served by the sliced / SELL form keeps ONLY that form (+ row pointers) in HBM (C2: 0.48
+ *                          instead of 1.13 GB); its CSR-order arrays are rebuilt on the device for whoever reads them
+ *   "ell_colblock" (1)     ELLPACK matrices whose columns have no locality (x >= 16 MB, >= 8 slots per row): column-blocked
+ *                          two-phase product (products through LDS-resident x blocks, then ordered row sums); 0 never, 2 always
+ *   "ell_colblock_cols" (16384, <= 20480 = 160 KiB of LDS)  x entries per block
+ *   "ell_colblock_rows" (0 = automatic; 256 or 512)  rows per tile of the second phase
+ *   "slice_sched" (0)      sliced matrices most of whose rows carry a far offset (the plane stride of a 3-D grid): the slices
+ *                          are handed to the XCDs tile by tile -- the plane is cut into bands (1 = of 64 slices, n > 1 = of n
+ *                          slices), XCD x sweeps bands x, x + 8, ... plane after plane, so that the three planes a band reads
+ *                          share ONE XCD's L2.  464^3: fabric reads 9.9 -> 7.1 GB per product (band 8), time -4 %
+ *                          (profiles/r04/c5_slice_sched_sweep.txt); only the order of whole slices changes
+ * Solver options
+ *   "cg_small" (1)         CG (plain / Jacobi) with the WHOLE SOLVE in one launch: on a single-GPU matrix of <= 10240 rows
+ *                          (stencil; 4096 otherwise) and <= 49k stored slots as ONE workgroup -- p in LDS, x and r in
+ *                          registers --; on a larger stencil matrix, up to 256 x 4096 rows, as up to 256 co-resident workgroups
+ *                          (one per CU) that own 1024..4096 rows each and meet twice per iteration through sc1 stores / polls
+ *                          (k_cg_coop: n = 1e6 17.7 instead of 36 us per iteration, n = 1e5 10.7 instead of 13.0); every wait
+ *                          is bounded, a hand-off that gives up hands the solve to the launch loop.  A launch runs at most
+ *                          50000 iterations (n > 1: at most n) and the solve continues in the next one from parked r, p,
+ *                          res2, bit-identical to the uncut solve; 0 = the launch loop (three kernels per iteration)
+ *   "bicgstab_small" (1)   the same for BiCGStab (<= 4096 rows)
+ *   "krylov_graph" (1)     the CG / BiCGStab launch loops on one GPU (plain / Jacobi) go on as replays of ONE captured group
+ *                          of 16 iterations (a hipGraph) once a solve has run 64 iterations (n > 1: n, rounded up to a
+ *                          multiple of 16); 0 = launch every kernel
+ *   "gmres_cgs2" (1)       GMRES orthogonalises with blocked classical Gram-Schmidt applied twice (three passes and three
+ *                          all-reduces per step); 0 = modified Gram-Schmidt
+ *   "dot_order" (0)        how CG / BiCGStab add up their dot products.  0 = tree order (per-workgroup partial sums,
+ *                          re-reduced in a fixed order): a legal order for the Fortran intrinsic, deterministic, the fast one.
+ *                          1 = the order the reference build uses (amdflang -O2 turns dot_product into ONE accumulator fed
+ *                          first element to last, cg_solvers.f90:131,135,140): every iterate, iteration count and residual is
+ *                          then BIT-IDENTICAL to the reference's, also on row partitions and across ranks; about 4 ns per
+ *                          element -- a VALIDATION mode for n up to ~1e5.  GMRES (no reference counterpart) keeps the tree order
+ * Preconditioner options
+ *   "ildu_strips" (1)      ILDU(0) factors of grid-like matrices use the strip- / slab-pipelined triangular solves; 0 = the
+ *                          level-scheduled walkers
+ *   "ildu_rows" (1)        ILDU(0) factors of <= 32 levels (what a colour ordering leaves) are swept in row space, one launch
+ *                          per level on the vectors themselves; 2 = every level launched (1 skips two); 0 = the walkers
+ *   "pipeline_spin_limit" (0 = built-in, 2^22 polls)  how often a wait inside the pipelined sweeps polls before it gives up
+ *                          (a sweep that gives up is redone with the walkers and the pipeline retired for that handle:
+ *                          sgm_pc_get "pipeline_retired"); tests set 1 to force that path
+ *   "ildu_reorder" (0)     1 = the preconditioner is ILDU(0) of the COLOUR-ORDERED matrix P A P^T (P = the reference's
+ *                          greedy_color_ordering of A's graph, permutations.f90:162-205; on the device for bipartite graphs such
+ *                          as the 5- / 7-point grids) applied as z = P^T M^-1 P r.  Its factors have one dependency level per
+ *                          colour whatever order A is in, so an apply is a few bandwidth-bound launches instead of a
+ *                          dependency chain of nx + ny levels; the solver keeps working on A, b, x as they are.  A different
+ *                          (equally valid) preconditioner than ILDU(0) in A's own order: iteration counts are those of the
+ *                          permuted system -- off by default because the reference's `ldu()` factors A in the given order
+ * Process-wide (sgm_set_option only)
+ *   "dist_force_collectives" (0)  1 = a matrix distributed over ONE rank still issues its all-reduces (the fixed cost of the
+ *                          RCCL code path, measurable on a single-GPU box: bench.py's `dist_overhead_1rank`)          */
 int sgm_set_option(const char *name, int value);
+int sgm_mat_set_option(sgm_mat A, const char *name, int value);
+int sgm_solver_set_option(sgm_solver s, const char *name, int value);
+int sgm_pc_set_option(sgm_pc pc, const char *name, int value);
 /* The schedule itself, host-only (no HIP call; what the library uploads for a row range of n_slices
  * 512-row slices): tab_out[it * grid + workgroup] = slice or -1, iters_out = entries per workgroup.
  * tab_out may be NULL to ask for iters_out only; capacity in entries (>= iters * grid).          */
@@ -266,10 +264,13 @@ int sgm_axpy(int64_t n, double alpha, const double *x, double *y, int where);
  *                      on a row-partitioned matrix: ILDU(0) of each part's diagonal block
  *                      (block-Jacobi, no exchange in the apply; iteration counts differ
  *                      from the one-part factorisation)
- * sgm_pc_setup      <- pc%setup(A) again after the values changed
+ * sgm_pc_create     <- jacobi() / ldu(...) as factories: the object before it has seen a matrix (set options, then setup)
+ * sgm_pc_setup      <- pc%setup(A): the first one, or again after the values changed
  * sgm_pc_apply      <- pc%solve(A, z, r): jacobi_solve :68-81 / ldu_solve :160-176
  * sgm_pc_get        <- read back idiag / L,D,U for parity checks ("idiag","Lptr","Lnode",
- *                      "Lval","Uptr","Unode","Uval","D"; 1-based like the reference)       */
+ *                      "Lval","Uptr","Unode","Uval","D"; 1-based like the reference; with "ildu_reorder" they are
+ *                      the factors of P A P^T and "perm" is p, row i of A = row p(i) of that matrix)          */
+int sgm_pc_create(sgm_pc *out, int32_t kind /* SGM_PC_JACOBI | SGM_PC_ILDU0 */);   /* the factory alone: no matrix seen yet */
 int sgm_jacobi_create(sgm_pc *out, sgm_mat A);
 int sgm_ildu0_create(sgm_pc *out, sgm_mat A);
 int sgm_pc_setup(sgm_pc pc, sgm_mat A);

@@ -292,6 +292,33 @@ interface   ! include/sigma_hip.h
         integer(c_int), value :: where
         integer(c_int) :: rc
     end function
+    function sgm_mat_set_option(A, name, value) bind(c, name='sgm_mat_set_option') result(rc)
+        import :: c_ptr, c_int, c_char
+        type(c_ptr), value :: A
+        character(kind=c_char), intent(in) :: name(*)
+        integer(c_int), value :: value
+        integer(c_int) :: rc
+    end function
+    function sgm_solver_set_option(s, name, value) bind(c, name='sgm_solver_set_option') result(rc)
+        import :: c_ptr, c_int, c_char
+        type(c_ptr), value :: s
+        character(kind=c_char), intent(in) :: name(*)
+        integer(c_int), value :: value
+        integer(c_int) :: rc
+    end function
+    function sgm_pc_set_option(pc, name, value) bind(c, name='sgm_pc_set_option') result(rc)
+        import :: c_ptr, c_int, c_char
+        type(c_ptr), value :: pc
+        character(kind=c_char), intent(in) :: name(*)
+        integer(c_int), value :: value
+        integer(c_int) :: rc
+    end function
+    function sgm_pc_create(pc, kind) bind(c, name='sgm_pc_create') result(rc)
+        import :: c_ptr, c_int, c_int32_t
+        type(c_ptr), intent(out) :: pc
+        integer(c_int32_t), value :: kind
+        integer(c_int) :: rc
+    end function
     function c_usleep(us) bind(c, name='usleep') result(rc)
         import :: c_int
         integer(c_int), value :: us
@@ -384,6 +411,7 @@ contains
     ! for host code that writes A%val directly
     procedure :: values_changed => hip_csr_values_changed
     procedure :: device_handle => hip_csr_device_handle
+    procedure :: set_option => hip_csr_set_option
 end type hip_csr_matrix
 
 
@@ -408,6 +436,7 @@ contains
     procedure :: destroy => hip_ell_destroy
     procedure :: values_changed => hip_ell_values_changed
     procedure :: device_handle => hip_ell_device_handle
+    procedure :: set_option => hip_ell_set_option
 end type hip_ellpack_matrix
 
 
@@ -664,6 +693,15 @@ subroutine hip_csr_values_changed(A)
     call stale(A%dev, .false.)
 end subroutine hip_csr_values_changed
 
+subroutine hip_csr_set_option(A, name, value)
+    ! this matrix's own kernel-selection option (sgm_mat_set_option); a structure change re-creates the device copy
+    ! with the process-wide defaults again
+    class(hip_csr_matrix), intent(in) :: A
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: value
+    call hip_check(sgm_mat_set_option(A%device_handle(), trim(name) // c_null_char, value), 'sgm_mat_set_option')
+end subroutine hip_csr_set_option
+
 subroutine hip_csr_destroy(A)
     class(hip_csr_matrix), intent(inout) :: A
     if (associated(A%dev)) then
@@ -823,6 +861,13 @@ subroutine hip_ell_values_changed(A)
     class(hip_ellpack_matrix), intent(inout) :: A
     call stale(A%dev, .false.)
 end subroutine hip_ell_values_changed
+
+subroutine hip_ell_set_option(A, name, value)
+    class(hip_ellpack_matrix), intent(in) :: A
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: value
+    call hip_check(sgm_mat_set_option(A%device_handle(), trim(name) // c_null_char, value), 'sgm_mat_set_option')
+end subroutine hip_ell_set_option
 
 subroutine hip_ell_destroy(A)
     class(hip_ellpack_matrix), intent(inout) :: A
@@ -1199,6 +1244,7 @@ type, extends(linear_solver) :: hip_krylov_solver                          !
     type(c_ptr) :: handle = c_null_ptr
 contains
     procedure :: setup => hip_krylov_setup
+    procedure :: set_option => hip_krylov_set_option
     procedure :: linear_solve => hip_krylov_solve
     procedure :: linear_solve_pc => hip_krylov_solve_pc
     procedure :: destroy => hip_krylov_destroy
@@ -1215,6 +1261,7 @@ type, extends(linear_solver) :: hip_preconditioner                         !
     type(c_ptr) :: handle = c_null_ptr
 contains
     procedure :: setup => hip_pc_setup
+    procedure :: set_option => hip_pc_set_option
     procedure :: linear_solve => hip_pc_solve
     procedure :: destroy => hip_pc_destroy
 end type hip_preconditioner
@@ -1295,13 +1342,66 @@ function hip_jacobi() result(pc)
     pc => p
 end function hip_jacobi
 
-function hip_ldu() result(pc)       ! ldu(incomplete = .true., level = 0), ldu_solvers.f90:73-86
+function hip_ldu(reorder) result(pc)       ! ldu(incomplete = .true., level = 0), ldu_solvers.f90:73-86
+    ! reorder = "colour" (an extension, off by default): ILDU(0) of the colour-ordered matrix P A P^T, P = the reference's
+    ! greedy_color_ordering of A's graph (permutations.f90:162-205), applied as z = P^T M^-1 P r.  A, b and x stay as the
+    ! caller holds them; the factors have one dependency level per colour, so an apply is a few bandwidth-bound launches
+    ! instead of a chain of nx + ny levels.  The iteration counts are those of the permuted system.
+    character(len=*), intent(in), optional :: reorder
     class(linear_solver), pointer :: pc
     type(hip_preconditioner), pointer :: p
     allocate(p)
     p%kind = PC_LDU
+    if (present(reorder)) then
+        if (reorder == "colour" .or. reorder == "color") then
+            call hip_pc_set_option(p, "ildu_reorder", 1)
+        elseif (reorder /= "natural") then
+            print *, "hip_ldu: reorder is colour or natural"
+            print *, "Terminating."
+            call exit(1)
+        endif
+    endif
     pc => p
 end function hip_ldu
+
+
+!--------------------------------------------------------------------------!
+subroutine krylov_handle(solver)                                           !
+!--------------------------------------------------------------------------!
+! the factory object (hip_cg(tol) ...) becomes a library handle; it has    !
+! seen no matrix yet, so options can be set on it before setup             !
+!--------------------------------------------------------------------------!
+    class(hip_krylov_solver), intent(inout) :: solver
+
+    if (c_associated(solver%handle)) return
+    select case(solver%kind)
+        case(KIND_CG)
+            call hip_check(sgm_cg_create(solver%handle, solver%tolerance), 'sgm_cg_create')
+        case(KIND_BICGSTAB)
+            call hip_check(sgm_bicgstab_create(solver%handle, solver%tolerance), 'sgm_bicgstab_create')
+        case default
+            call hip_check(sgm_gmres_create(solver%handle, solver%tolerance, solver%restart), 'sgm_gmres_create')
+    end select
+
+end subroutine krylov_handle
+
+
+!--------------------------------------------------------------------------!
+subroutine hip_krylov_set_option(solver, name, value)                      !
+!--------------------------------------------------------------------------!
+! this solver's own option ("dot_order", "cg_small", "krylov_graph" ...:   !
+! include/sigma_hip.h); e.g. solver%set_option("dot_order", 1) makes CG /  !
+! BiCGStab add their dot products in the reference build's order -- the    !
+! iterates are then the CPU build's bit for bit (validation runs)          !
+!--------------------------------------------------------------------------!
+    class(hip_krylov_solver), intent(inout) :: solver
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: value
+
+    call krylov_handle(solver)
+    call hip_check(sgm_solver_set_option(solver%handle, trim(name) // c_null_char, value), 'sgm_solver_set_option')
+
+end subroutine hip_krylov_set_option
 
 
 !--------------------------------------------------------------------------!
@@ -1317,16 +1417,7 @@ subroutine hip_krylov_setup(solver, A)                                     !
     endif
     solver%nn = A%nrow
     solver%iterations = 0
-    if (.not. c_associated(solver%handle)) then
-        select case(solver%kind)
-            case(KIND_CG)
-                call hip_check(sgm_cg_create(solver%handle, solver%tolerance), 'sgm_cg_create')
-            case(KIND_BICGSTAB)
-                call hip_check(sgm_bicgstab_create(solver%handle, solver%tolerance), 'sgm_bicgstab_create')
-            case default
-                call hip_check(sgm_gmres_create(solver%handle, solver%tolerance, solver%restart), 'sgm_gmres_create')
-        end select
-    endif
+    call krylov_handle(solver)
     call hip_check(sgm_solver_setup(solver%handle, matrix_handle(A)), 'sgm_solver_setup')
     solver%initialized = .true.
 
@@ -1408,16 +1499,29 @@ subroutine hip_pc_setup(solver, A)                                         !
     class(linear_operator), intent(in) :: A
 
     solver%nn = A%nrow
-    if (c_associated(solver%handle)) then
-        call hip_check(sgm_pc_setup(solver%handle, matrix_handle(A)), 'sgm_pc_setup')
-    elseif (solver%kind == PC_JACOBI) then
-        call hip_check(sgm_jacobi_create(solver%handle, matrix_handle(A)), 'sgm_jacobi_create')
-    else
-        call hip_check(sgm_ildu0_create(solver%handle, matrix_handle(A)), 'sgm_ildu0_create')
-    endif
+    call pc_handle(solver)
+    call hip_check(sgm_pc_setup(solver%handle, matrix_handle(A)), 'sgm_pc_setup')
     solver%initialized = .true.
 
 end subroutine hip_pc_setup
+
+
+subroutine pc_handle(solver)
+    ! jacobi() / ldu() as factories (jacobi_solvers.f90:23-31, ldu_solvers.f90:73-86): the object before any matrix
+    class(hip_preconditioner), intent(inout) :: solver
+    if (c_associated(solver%handle)) return
+    call hip_check(sgm_pc_create(solver%handle, solver%kind), 'sgm_pc_create')
+end subroutine pc_handle
+
+
+subroutine hip_pc_set_option(solver, name, value)
+    ! this preconditioner's own option ("ildu_strips", "ildu_rows"); before the first setup it decides which sweeps are built
+    class(hip_preconditioner), intent(inout) :: solver
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: value
+    call pc_handle(solver)
+    call hip_check(sgm_pc_set_option(solver%handle, trim(name) // c_null_char, value), 'sgm_pc_set_option')
+end subroutine hip_pc_set_option
 
 
 !--------------------------------------------------------------------------!

@@ -455,6 +455,17 @@ subroutine test_incomplete_cholesky_flow()                                 !
     err = maxval(dabs(x - w))
     if (err > 1.0e-15) call fail('ILDU-preconditioned hip CG failed', err)
     print *, 'incomplete cholesky flow: hip_cg + hip_ldu error', err
+    ! the same solve with the reordering preconditioner: ILDU(0) of the colour-ordered matrix (greedy_color_ordering of
+    ! this random graph runs on the host: it is not bipartite), M, rhs and x untouched
+    call pcs%destroy()
+    deallocate(pcs)
+    pcs => hip_ldu(reorder = "colour")
+    call pcs%setup(M)
+    x = 0.0_dp
+    call ks%solve(M, x, rhs, pcs)
+    err = maxval(dabs(x - w))
+    if (err > 1.0e-15) call fail('hip CG with the reordering ILDU preconditioner failed', err)
+    print *, 'incomplete cholesky flow: hip_cg + hip_ldu(reorder = colour) error', err
     call ks%destroy()
     call pcs%destroy()
     deallocate(ks, pcs)

@@ -120,12 +120,8 @@ def synchronize():
 
 
 def set_option(name, value):
-    """sgm_set_option: "csr_offset_dict" 1/0 (1-byte column codes for stencil-like matrices),
-    "csr_row_owner" 1/0 (row-owner gather for int32-column matrices with rows <= 64 entries),
-    "csr_row_lines" 1/0 (line-staged row-owner kernel for longer rows), "slice_sched" 0/1 (band-ordered slices on 3-D grids),
-    "csr_sliced" 1/0 (slot-major slices + 4-bit codes for rows <= 8 entries / <= 15 offsets; default on),
-    "ell_offset_dict" 1/0, "ell_colblock" 0/1/2, "ell_colblock_cols", "ell_colblock_chunks", "ell_colblock_rows" 0/256/512,
-    "ildu_strips" 1/0, "gmres_cgs2" 1/0, "cg_small" 1/0 (single-workgroup CG for small systems), "cg_small_chunk"."""
+    """sgm_set_option: the DEFAULT that matrices / solvers / preconditioners created later start with (options are per
+    handle: include/sigma_hip.h lists them; A.set_option / solver.set_option / pc.set_option change one handle)."""
     _ck(lib().sgm_set_option(name.encode(), C.c_int(int(value))))
 
 
@@ -289,9 +285,16 @@ class _Matrix:
         pp, w, _k = _arg(p, np.int32)
         _ck(lib().sgm_mat_right_permute(self._h, pp, C.c_int(w)))
 
+    def set_option(self, name, value):
+        """sgm_mat_set_option: this matrix's own kernel-selection option (same bits whichever)."""
+        if hasattr(self, "_build"):
+            self._build()
+        _ck(lib().sgm_mat_set_option(self._h, name.encode(), C.c_int(int(value))))
+        return self
+
     @property
     def kernel(self):
-        """Name of the SpMV kernel variant this matrix runs with under the current options."""
+        """Name of the SpMV kernel variant this matrix runs with under its options."""
         buf = C.create_string_buffer(64)
         _ck(lib().sgm_mat_kernel(self._h, buf, C.c_int(64)))
         return buf.value.decode()
@@ -521,22 +524,32 @@ class ellpack_matrix(_Matrix):
 # ------------------------------------------------------------------------------------ #
 class _Preconditioner:
     """linear_solver used as a preconditioner (setup / solve / destroy)."""
-    _create = None
+    _kind = 0
 
     def __init__(self):
         self._h = C.c_void_p()
         self.nn = 0
         self.initialized = False
+        self._opts = {}
 
     def setup(self, A):
         if hasattr(A, "_build"):
             A._build()
         if not self._h:
-            _ck(getattr(lib(), self._create)(C.byref(self._h), A._h))
-        else:
-            _ck(lib().sgm_pc_setup(self._h, A._h))
+            # the factory (jacobi() / ldu()) has seen no matrix: options set before the first setup decide how it builds
+            _ck(lib().sgm_pc_create(C.byref(self._h), C.c_int32(self._kind)))
+            for k, v in self._opts.items():
+                _ck(lib().sgm_pc_set_option(self._h, k.encode(), C.c_int(int(v))))
+        _ck(lib().sgm_pc_setup(self._h, A._h))
         self.nn = getattr(A, "n_local", A.nrow)
         self.initialized = True
+
+    def set_option(self, name, value):
+        """sgm_pc_set_option: this preconditioner's own "ildu_strips" / "ildu_rows" / "pipeline_spin_limit"."""
+        self._opts[name] = int(value)
+        if self._h:
+            _ck(lib().sgm_pc_set_option(self._h, name.encode(), C.c_int(int(value))))
+        return self
 
     def solve(self, A, x, b):
         """pc%solve(A, x, b): x = M^-1 b."""
@@ -567,7 +580,7 @@ class _Preconditioner:
 
 
 class jacobi_solver(_Preconditioner):
-    _create = "sgm_jacobi_create"
+    _kind = 1       # SGM_PC_JACOBI
 
     @property
     def idiag(self):
@@ -575,7 +588,7 @@ class jacobi_solver(_Preconditioner):
 
 
 class sparse_ldu_solver(_Preconditioner):
-    _create = "sgm_ildu0_create"
+    _kind = 2       # SGM_PC_ILDU0
 
 
 def jacobi():
@@ -583,10 +596,17 @@ def jacobi():
     return jacobi_solver()
 
 
-def ldu(incomplete=True, level=0):
+def ldu(incomplete=True, level=0, reorder=None):
     """ldu(incomplete, level) factory (ldu_solvers.f90:73-86).  Like the reference
-    (ldu_set_params :143-151) the arguments are accepted and forced to ILDU(0)."""
-    return sparse_ldu_solver()
+    (ldu_set_params :143-151) the arguments are accepted and forced to ILDU(0).
+    reorder="colour" (an extension, off by default): ILDU(0) of the colour-ordered matrix P A P^T -- P = the reference's
+    greedy_color_ordering of A's graph -- applied as z = P^T M^-1 P r; A, b and x stay as the caller holds them."""
+    pc = sparse_ldu_solver()
+    if reorder in ("colour", "color"):
+        pc.set_option("ildu_reorder", 1)
+    elif reorder not in (None, "natural"):
+        raise SigmaError(1, f"ldu: reorder is None or 'colour', not {reorder!r}")
+    return pc
 
 
 class _Solver:
@@ -599,9 +619,18 @@ class _Solver:
         self.initialized = False
         self._max_iter = 0
         self._hist = 0
+        self._opts = {}
 
     def _create(self):
         raise NotImplementedError
+
+    def set_option(self, name, value):
+        """sgm_solver_set_option: this solver's own "cg_small" / "bicgstab_small" / "krylov_graph" / "dot_order" /
+        "gmres_cgs2" (read at the next solve)."""
+        self._opts[name] = int(value)
+        if self._h:
+            _ck(lib().sgm_solver_set_option(self._h, name.encode(), C.c_int(int(value))))
+        return self
 
     def setup(self, A):
         if hasattr(A, "_build"):
@@ -612,6 +641,8 @@ class _Solver:
                 _ck(lib().sgm_solver_set_max_iter(self._h, C.c_int64(self._max_iter)))
             if self._hist:
                 _ck(lib().sgm_solver_set_history(self._h, C.c_int64(self._hist)))
+            for k, v in self._opts.items():
+                _ck(lib().sgm_solver_set_option(self._h, k.encode(), C.c_int(int(v))))
         _ck(lib().sgm_solver_setup(self._h, A._h))
         self.nn = A.nrow
         self.initialized = True

@@ -23,12 +23,8 @@
 // slot's 0 * x(last) term is kept).  Built at sgm_ell_create when the matrix looks random
 // (option "ell_colblock": 0 never, 1 automatic, 2 always).
 //
-// Row bands (round 3).  The products make a 16-byte round trip per entry (8 B written by phase 1, read by phase 2): 2.56 GB
-// of the 5.2 GB the two phases move on C4.  Sorting by (row band, column block, row, slot) instead and running the phases
-// band by band -- mul(band 0), sum(band 0), mul(band 1), ... -- over ONE product buffer of a band's size keeps that round
-// trip inside the 256 MiB Infinity Cache: a line stays resident while everything loaded or stored between its two uses fits
-// (guide, "Infinity Cache"), i.e. a band's products + the streams of both phases: rows_per_band * max_d * ~20 B <= ~160 MB
-// (C4: 262144 rows, 20 bands, 64 MB of products).  Row sums do not change: only which launch forms a product does.
+// (Round 3 also ran the two phases band by band over one product buffer sized for the Infinity Cache -- measured slower,
+// profiles/r03/c4_row_bands_kernel_stats.txt, and removed in round 4; the products make their round trip through HBM.)
 #include "sgm_internal.hpp"
 
 #include <hipcub/hipcub.hpp>
@@ -41,15 +37,15 @@ typedef double f64x2c __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------ setup kernels
 // key of entry e = i*max_d + k (row-major: a stable sort by key leaves (row, slot) order inside a block)
-// key = band * nb + column block (band = row / RB)
-__global__ void k_ellcb_keys(int32_t n, int32_t max_d, int32_t cb, int32_t nb, int32_t RB, const int32_t *__restrict__ ecol,
+// key = column block
+__global__ void k_ellcb_keys(int32_t n, int32_t max_d, int32_t cb, const int32_t *__restrict__ ecol,
                              uint16_t *__restrict__ key, int32_t *__restrict__ ent)
 {
     const int64_t total = (int64_t)n * max_d;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
         const int32_t i = (int32_t)(e / max_d), k = (int32_t)(e % max_d);
-        key[e] = (uint16_t)((i / RB) * nb + ecol[(int64_t)k * n + i] / cb);
+        key[e] = (uint16_t)(ecol[(int64_t)k * n + i] / cb);
         ent[e] = (int32_t)e;
     }
 }
@@ -81,13 +77,13 @@ __global__ void k_ellcb_gather(int64_t total, int32_t n, int32_t max_d, int32_t 
 // run (t, b): the entries of column block b whose rows lie in tile t = sorted positions
 // [start, start + len); rows ascend inside a block, so both ends are binary searches.
 // Descriptor = {start, len | base << 16}: base = where the run sits in the tile's LDS image.
-__global__ void k_ellcb_runs(int32_t ntiles, int32_t nb, int32_t R, int32_t RB, int32_t max_d, const int32_t *__restrict__ bstart,
+__global__ void k_ellcb_runs(int32_t ntiles, int32_t nb, int32_t R, int32_t max_d, const int32_t *__restrict__ bstart,
                              const int32_t *__restrict__ perm, int2 *__restrict__ fdesc)
 {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= (int64_t)ntiles * nb) return;
     const int32_t t = (int32_t)(id / nb), b = (int32_t)(id % nb);
-    const int32_t kb = (int32_t)(((int64_t)t * R) / RB) * nb + b;       // (band of the tile, column block): RB is a multiple of R
+    const int32_t kb = b;
     auto first_row_at_least = [&](int64_t row) {
         int32_t lo = bstart[kb], hi = bstart[kb + 1];
         while (lo < hi) {
@@ -141,50 +137,24 @@ __global__ void k_ellcb_sample(int32_t n, int32_t max_d, int32_t step, const int
 }
 
 // ------------------------------------------------------------------------------ phase 1
-// One band.  A workgroup multiplies a range of the band's sorted positions, walking the column blocks the range overlaps --
-// for each the x block goes to LDS, then the block's entries inside the range are streamed (value 8 B + column-inside-block
-// 2 B, U x 16-byte loads per lane in flight), multiplied and their products stored.  Ranges: chunk c of column block b
-// (chunks > 0, grid = nb * chunks) or equal pieces of the whole band (chunks = 0, even boundaries).  `P` is the product buffer shifted so that P[j] belongs to sorted position j (a band's
-// buffer is reused by the next band).  Pieces, not (block, chunk) pairs: any grid -- a multiple of the CU count -- is
-// balanced whatever the number of column blocks.  NT: nontemporal product stores (single-band form; the banded form
-// keeps them plain so that the products wait in the cache for phase 2).
+// Workgroup (column block b, chunk c of it): the x block goes to LDS, then the chunk's entries are streamed (value 8 B +
+// column-inside-block 2 B, U x 16-byte loads per lane in flight), multiplied and their products stored (nontemporal:
+// nobody reads them before the next launch).  grid = nb * chunks: every workgroup loads exactly one x block.
 template <int TPB, int U>
 __global__ __launch_bounds__(TPB) void k_ellcb_mul(int32_t ncol, int32_t cb, int32_t nb, int32_t chunks, const int32_t *__restrict__ bstart,
                                                    const double *__restrict__ sval, const uint16_t *__restrict__ lcol,
-                                                   const double *__restrict__ x, double *__restrict__ P, int nt,
+                                                   const double *__restrict__ x, double *__restrict__ P,
                                                    const int *__restrict__ flag_done, int gen)
 {
     extern __shared__ double xs[];
     if (flag_done) { const int st = *flag_done; if (st && gen >= st) return; }
-    int64_t j0, j1;
-    int32_t lo;
-    if (chunks > 0) {
-        // (column block, chunk) pairs: grid = nb * chunks, every workgroup loads exactly one x block (one-band form)
-        lo = blockIdx.x / chunks;
-        const int32_t c = blockIdx.x % chunks;
-        const int64_t j0b = bstart[lo], j1b = bstart[lo + 1], len = j1b - j0b;
-        j0 = j0b + (len * c / chunks); j1 = j0b + (len * (c + 1) / chunks);
-        if (c > 0) j0 = (j0 + 1) & ~(int64_t)1;
-        if (c + 1 < chunks) j1 = (j1 + 1) & ~(int64_t)1;
-        if (j1 > j1b) j1 = j1b;
-        if (j0 >= j1) return;
-    } else {
-        // equal pieces of the band's positions (banded form: any grid is balanced whatever the number of column blocks)
-        const int64_t jlo = bstart[0], jhi = bstart[nb], len = jhi - jlo;
-        const int64_t np = gridDim.x, pc = blockIdx.x;
-        j0 = jlo + len * pc / np; j1 = jlo + len * (pc + 1) / np;
-        if (pc > 0) j0 = (j0 + 1) & ~(int64_t)1;
-        if (pc + 1 < np) j1 = (j1 + 1) & ~(int64_t)1;
-        if (j1 > jhi) j1 = jhi;
-        if (j0 >= j1) return;
-        // the column block holding position j0: the last b with bstart[b] <= j0
-        lo = 0;
-        int32_t hi = nb - 1;
-        while (lo < hi) {
-            const int32_t mid = (lo + hi + 1) >> 1;
-            if ((int64_t)bstart[mid] <= j0) lo = mid; else hi = mid - 1;
-        }
-    }
+    const int32_t lo = blockIdx.x / chunks, c = blockIdx.x % chunks;
+    const int64_t j0b = bstart[lo], j1b = bstart[lo + 1], len = j1b - j0b;
+    int64_t j0 = j0b + (len * c / chunks), j1 = j0b + (len * (c + 1) / chunks);
+    if (c > 0) j0 = (j0 + 1) & ~(int64_t)1;
+    if (c + 1 < chunks) j1 = (j1 + 1) & ~(int64_t)1;
+    if (j1 > j1b) j1 = j1b;
+    if (j0 >= j1) return;
     for (int32_t b = lo; j0 < j1 && b < nb; ++b) {
         const int64_t jz = min(j1, (int64_t)bstart[b + 1]);
         if (jz <= j0) continue;
@@ -220,7 +190,7 @@ __global__ __launch_bounds__(TPB) void k_ellcb_mul(int32_t ncol, int32_t cb, int
                 f64x2c o;
                 o.x = v[u].x * xs[cc[u] & 0xffffu];
                 o.y = v[u].y * xs[cc[u] >> 16];
-                if (nt) __builtin_nontemporal_store(o, p2 + q + (int64_t)u * TPB); else p2[q + (int64_t)u * TPB] = o;
+                __builtin_nontemporal_store(o, p2 + q + (int64_t)u * TPB);
             }
         }
         for (; q < npair; q += TPB) {
@@ -246,12 +216,12 @@ __global__ __launch_bounds__(TPB) void k_ellcb_mul(int32_t ncol, int32_t cb, int
 // R rows per tile, TPB = CM * R threads: all TPB / 64 waves copy runs, the first R threads own the rows.
 // FULLW: one run per wave instruction (64 lanes; tiles of 512 rows, runs average 54 entries) instead of two half-wave runs.
 template <int R, int TPB, int MAXD, bool ADD, bool DOT_W, bool DOT_YY, bool FULLW = false>
-__global__ __launch_bounds__(TPB) void k_ellcb_sum(int32_t n, int32_t max_d, int32_t nb, int32_t t0, int32_t ntiles,
+__global__ __launch_bounds__(TPB) void k_ellcb_sum(int32_t n, int32_t max_d, int32_t nb, int32_t ntiles,
                                                    const int2 *__restrict__ fdesc, const uint16_t *__restrict__ lpos,
                                                    const double *__restrict__ P, double *__restrict__ y,
                                                    const double *__restrict__ w, double *__restrict__ part_wy,
                                                    double *__restrict__ part_yy, const int *__restrict__ flag_done, int gen,
-                                                   int chain, int nt)
+                                                   int chain)
 {
     extern __shared__ double img[];
     __shared__ double red[TPB / 64];
@@ -263,8 +233,7 @@ __global__ __launch_bounds__(TPB) void k_ellcb_sum(int32_t n, int32_t max_d, int
     const int wave = threadIdx.x >> 6;
     const int32_t per = (nb + NW - 1) / NW, bw0 = wave * per, bw1 = min(nb, bw0 + per);
     double dwy = 0.0, dyy = 0.0;
-    // tiles [t0, ntiles) of this launch (one band); P is shifted so that P[j] belongs to sorted position j
-    for (int32_t t = t0 + blockIdx.x; t < ntiles; t += gridDim.x) {
+    for (int32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int32_t i = t * R + (int32_t)threadIdx.x;
         const bool live = (int)threadIdx.x < R && i < n;
         // positions of this lane's row (slots 0..MAXD-1 in registers; longer rows re-read them later)
@@ -287,7 +256,7 @@ __global__ __launch_bounds__(TPB) void k_ellcb_sum(int32_t n, int32_t max_d, int
                     const uint32_t lb = (uint32_t)__shfl(d.y, src, 64);
                     l[u] = (int32_t)(lb & 0xffffu);
                     o[u] = (int32_t)(lb >> 16);
-                    v[u] = q < l[u] ? (nt ? __builtin_nontemporal_load(P + g[u] + q) : P[g[u] + q]) : 0.0;
+                    v[u] = q < l[u] ? __builtin_nontemporal_load(P + g[u] + q) : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -323,16 +292,17 @@ __global__ __launch_bounds__(TPB) void k_ellcb_sum(int32_t n, int32_t max_d, int
 }
 
 // ------------------------------------------------------------------------------ host side
-// options "ell_colblock_cols" / "ell_colblock_chunks" (sgm_set_option); SGM_ELLCB_GRID = phase-2 grid cap (tuning aid)
-struct CbCfg { int cb, chunks, grid2; };
-static CbCfg cb_cfg()
+// matrix options "ell_colblock_cols" / "ell_colblock_rows"; tuning aids read from the environment when a form is built:
+// SGM_ELLCB_CHUNKS = workgroups per column block in the multiply phase (16; C4 sweep 4 / 8 / 16: 1.32 / 1.31 / 1.27 ms),
+// SGM_ELLCB_GRID = phase-2 grid cap
+static int cb_grid2()
 {
     static int grid2 = 0;
     if (!grid2) {
         grid2 = 2048;
         if (const char *e = getenv("SGM_ELLCB_GRID")) grid2 = std::min(kMaxGrid, std::max(1, atoi(e)));
     }
-    return CbCfg{g_opt.ell_colblock_cols, g_opt.ell_colblock_chunks, grid2};
+    return grid2;
 }
 
 void free_ell_colblock(Part &p)
@@ -341,30 +311,21 @@ void free_ell_colblock(Part &p)
     dfree(p.cb_fdesc); dfree(p.cb_P);
     p.cb_perm = nullptr; p.cb_sval = nullptr; p.cb_lcol = nullptr; p.cb_bstart = nullptr; p.cb_lpos = nullptr;
     p.cb_fdesc = nullptr; p.cb_P = nullptr;
-    p.cb_cols = p.cb_nb = p.cb_R = p.cb_ntiles = 0;
-    p.cb_RB = 0; p.cb_nbands = 1;
+    p.cb_cols = p.cb_nb = p.cb_R = p.cb_ntiles = p.cb_chunks = 0;
 }
 
-bool use_ell_colblock(const Part &p) { return p.cb_P != nullptr && g_opt.ell_colblock != 0; }
+bool use_ell_colblock(const Part &p) { return p.cb_P != nullptr && p.opt.ell_colblock != 0; }
 
-// workgroups of one band's sum launch; the fused dots leave one partial sum per (band, workgroup)
-static int band_grid(const Part &p)
-{
-    const int tiles = std::min(p.cb_ntiles, p.cb_RB / p.cb_R);
-    int cap = std::min(cb_cfg().grid2, kMaxGrid / std::max(1, p.cb_nbands));
-    // fewer workgroups than tiles: a whole number of rounds over the CUs (one 128 KiB image per CU), so that no CU walks a tile more
-    if (p.cb_nbands > 1 && tiles > cap && cap >= g_rt.num_cu) cap = cap / g_rt.num_cu * g_rt.num_cu;
-    return std::max(1, std::min(tiles, cap));
-}
-int ell_colblock_grid(const Part &p) { return band_grid(p) * std::max(1, p.cb_nbands); }
+// workgroups of the sum launch = partial sums the fused dots leave
+int ell_colblock_grid(const Part &p) { return std::max(1, std::min(p.cb_ntiles, cb_grid2())); }
 
 // does the matrix qualify, and do its columns look random?
 static int wants_colblock(const Part &p, bool *yes)
 {
     *yes = false;
-    if (!g_opt.ell_colblock || !p.ecol || p.n <= 0 || p.max_d < 1) return SGM_OK;
+    if (!p.opt.ell_colblock || !p.ecol || p.n <= 0 || p.max_d < 1) return SGM_OK;
     if ((int64_t)p.n * p.max_d >= INT32_MAX || p.max_d > 128) return SGM_OK;
-    if (g_opt.ell_colblock >= 2) { *yes = true; return SGM_OK; }
+    if (p.opt.ell_colblock >= 2) { *yes = true; return SGM_OK; }
     if (p.ecode || p.scode) return SGM_OK;                        // structured: the dictionary kernels serve it
     if ((int64_t)p.ncol_own * 8 < (int64_t)16 << 20 || p.max_d < 8) return SGM_OK;   // x within reach of the L2s / too few gathers
     unsigned long long *dsum = nullptr, hsum = 0;
@@ -393,40 +354,26 @@ int refresh_ell_colblock_values(Part &p)
     return SGM_OK;
 }
 
-// index work of the column-blocked form (once per structure)
+// index work of the column-blocked form (once per structure; the matrix's options at that moment are what it is built with)
 int build_ell_colblock(Part &p)
 {
     free_ell_colblock(p);
     bool yes = false;
     SGM_TRY(wants_colblock(p, &yes));
     if (!yes) return SGM_OK;
-    const CbCfg c = cb_cfg();
     hipStream_t st = g_rt.stream;
     const int64_t total = (int64_t)p.n * p.max_d;
-    const int32_t cb = c.cb, nb = (p.ncol_own + cb - 1) / cb;
+    const int32_t cb = p.opt.ell_colblock_cols, nb = (p.ncol_own + cb - 1) / cb;
     if (nb > 65535) return SGM_OK;
     // tile image <= 64 KiB (two workgroups per CU) -- or, option ell_colblock_rows = 512 (automatic for rows <= 32 slots:
     // runs twice as long, one 1024-thread workgroup per CU with a 128 KiB image) -- whole waves
     static const int rows_env = getenv("SGM_ELLCB_ROWS") ? atoi(getenv("SGM_ELLCB_ROWS")) : 0;      // tuning aid
-    const int want_rows = rows_env ? rows_env : g_opt.ell_colblock_rows;
+    const int want_rows = rows_env ? rows_env : p.opt.ell_colblock_rows;
     int32_t R = std::min(256, 8192 / p.max_d) / 64 * 64;
     if ((want_rows == 512 || (want_rows == 0 && p.max_d >= 16)) && p.max_d <= 32) R = 512;
     if (R < 64) return SGM_OK;
     const int32_t ntiles = (p.n + R - 1) / R;
-    // row bands: a band's products (8 B per entry) + what both phases stream meanwhile (10 + 2 B per entry) <= ~160 MB
-    int64_t RB = p.n;
-    if (g_opt.ell_colblock_band > 0) RB = g_opt.ell_colblock_band;
-    else if (g_opt.ell_colblock_band == 0) RB = ((int64_t)160 << 20) / ((int64_t)p.max_d * 20);
-    RB = std::max<int64_t>(R, (RB + R - 1) / R * R);
-    if (RB >= p.n) RB = (int64_t)ntiles * R;                 // one band
-    int32_t nbands = (int32_t)(((int64_t)ntiles * R + RB - 1) / RB);
-    while ((int64_t)nbands * nb > 65535) {                   // 16-bit sort keys: fewer, larger bands
-        RB = (RB * 2 + R - 1) / R * R;
-        nbands = (int32_t)(((int64_t)ntiles * R + RB - 1) / RB);
-    }
-    if ((RB * p.max_d) & 1) return SGM_OK;                   // (a band's first sorted position must be even: R is a multiple of 64, so it is)
-    p.cb_cols = cb; p.cb_nb = nb; p.cb_R = R; p.cb_ntiles = ntiles; p.cb_RB = (int32_t)RB; p.cb_nbands = nbands;
-    const int32_t nkeys = nbands * nb;
+    p.cb_cols = cb; p.cb_nb = nb; p.cb_R = R; p.cb_ntiles = ntiles; p.cb_chunks = getenv("SGM_ELLCB_CHUNKS") ? std::max(1, atoi(getenv("SGM_ELLCB_CHUNKS"))) : 16;
 
     uint16_t *key = nullptr, *skey = nullptr;
     int32_t *ent = nullptr;
@@ -436,9 +383,9 @@ int build_ell_colblock(Part &p)
     SGM_TRY(dalloc(&skey, (size_t)total));
     SGM_TRY(dalloc(&ent, (size_t)total));
     SGM_TRY(dalloc(&p.cb_perm, (size_t)total + 2));
-    hipLaunchKernelGGL(k_ellcb_keys, dim3(vec_grid(total)), dim3(kBlock), 0, st, p.n, p.max_d, cb, nb, (int32_t)RB, (const int32_t *)p.ecol, key, ent);
+    hipLaunchKernelGGL(k_ellcb_keys, dim3(vec_grid(total)), dim3(kBlock), 0, st, p.n, p.max_d, cb, (const int32_t *)p.ecol, key, ent);
     int bits = 1;
-    while ((1 << bits) < nkeys) ++bits;
+    while ((1 << bits) < nb) ++bits;
     size_t tmp_bytes = 0;
     SGM_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key, skey, ent, p.cb_perm, (int)total, 0, bits, st));
     char *tmpc = nullptr;
@@ -446,8 +393,8 @@ int build_ell_colblock(Part &p)
     tmp = tmpc;
     SGM_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, key, skey, ent, p.cb_perm, (int)total, 0, bits, st));   // stable
 
-    SGM_TRY(dalloc(&p.cb_bstart, (size_t)nkeys + 1));
-    hipLaunchKernelGGL(k_ellcb_bstart, dim3((nkeys + 1 + 255) / 256), dim3(256), 0, st, total, nkeys, (const uint16_t *)skey, p.cb_bstart);
+    SGM_TRY(dalloc(&p.cb_bstart, (size_t)nb + 1));
+    hipLaunchKernelGGL(k_ellcb_bstart, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, total, nb, (const uint16_t *)skey, p.cb_bstart);
     SGM_TRY(dalloc(&p.cb_sval, (size_t)total + 2));
     SGM_TRY(dalloc(&p.cb_lcol, (size_t)total + 2));
     hipLaunchKernelGGL(k_ellcb_gather, dim3(vec_grid(total)), dim3(kBlock), 0, st, total, p.n, p.max_d, cb,
@@ -456,22 +403,21 @@ int build_ell_colblock(Part &p)
     int2 *fdesc = nullptr;
     SGM_TRY(dalloc(&fdesc, (size_t)nruns));
     p.cb_fdesc = fdesc;
-    hipLaunchKernelGGL(k_ellcb_runs, dim3((unsigned)((nruns + 255) / 256)), dim3(256), 0, st, ntiles, nb, R, (int32_t)RB, p.max_d,
+    hipLaunchKernelGGL(k_ellcb_runs, dim3((unsigned)((nruns + 255) / 256)), dim3(256), 0, st, ntiles, nb, R, p.max_d,
                        (const int32_t *)p.cb_bstart, (const int32_t *)p.cb_perm, fdesc);
     hipLaunchKernelGGL(k_ellcb_bases, dim3((ntiles + 255) / 256), dim3(256), 0, st, ntiles, nb, fdesc);
     const size_t lpos_count = (size_t)total;
     SGM_TRY(dalloc(&p.cb_lpos, lpos_count + 2));
     hipLaunchKernelGGL(k_ellcb_lpos, dim3(vec_grid(total)), dim3(kBlock), 0, st, total, p.n, p.max_d, cb, nb, R,
                        (const int32_t *)p.cb_perm, (const int32_t *)p.ecol, (const int2 *)fdesc, p.cb_lpos);
-    SGM_TRY(dalloc(&p.cb_P, (size_t)std::min<int64_t>(total, RB * p.max_d) + 2));       // ONE band's products
+    SGM_TRY(dalloc(&p.cb_P, (size_t)total + 2));
     SGM_HIP(hipGetLastError());
     SGM_HIP(hipStreamSynchronize(st));
     return SGM_OK;
 }
 
 template <int R, bool ADD>
-static void launch_sum(const Part &p, int grid, int32_t t0, int32_t t1, const double *Pj, int nt, double *y, const double *w, double *pwy,
-                       double *pyy, const int *flag, int gen, int chain)
+static void launch_sum(const Part &p, int grid, double *y, const double *w, double *pwy, double *pyy, const int *flag, int gen, int chain)
 {
     hipStream_t st = g_rt.stream;
     const size_t lds = (size_t)p.cb_R * p.max_d * 8;
@@ -482,9 +428,8 @@ static void launch_sum(const Part &p, int grid, int32_t t0, int32_t t1, const do
     do {                                                                                                              \
         static bool attr = false;                                                                                     \
         if (BIG && !attr) { (void)hipFuncSetAttribute((const void *)k_ellcb_sum<R, TPB, MAXD, ADD, DW, DY, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 32 * 8); attr = true; } \
-        hipLaunchKernelGGL((k_ellcb_sum<R, TPB, MAXD, ADD, DW, DY, BIG>), dim3(grid), dim3(TPB), lds, st, p.n, p.max_d, p.cb_nb, t0, t1, \
-                           (const int2 *)p.cb_fdesc, (const uint16_t *)p.cb_lpos, Pj, y, w, pwy, pyy, flag,              \
-                           gen, chain, nt);                                                                           \
+        hipLaunchKernelGGL((k_ellcb_sum<R, TPB, MAXD, ADD, DW, DY, BIG>), dim3(grid), dim3(TPB), lds, st, p.n, p.max_d, p.cb_nb, p.cb_ntiles, \
+                           (const int2 *)p.cb_fdesc, (const uint16_t *)p.cb_lpos, (const double *)p.cb_P, y, w, pwy, pyy, flag, gen, chain); \
     } while (0)
     if (w && pyy) L(true, true);
     else if (w) L(true, false);
@@ -496,37 +441,23 @@ static void launch_sum(const Part &p, int grid, int32_t t0, int32_t t1, const do
 int launch_ell_colblock(const Part &p, int grid, const double *x, double *y, bool add, bool chain, const double *w,
                         double *pwy, double *pyy, const int *flag, int gen)
 {
-    const CbCfg c = cb_cfg();
     hipStream_t st = g_rt.stream;
     constexpr int TPB1 = 512, U1 = 4;      // (1024 threads x 4: 571 us on C4 against 559: the stream is not short of loads in flight)
     static bool attr_set = false;
     if (!attr_set) {       // more than 64 KiB of dynamic LDS needs the attribute (160 KiB per CU on gfx950)
-        SGM_HIP(hipFuncSetAttribute((const void *)k_ellcb_mul<TPB1, U1>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+        SGM_HIP(hipFuncSetAttribute((const void *)k_ellcb_mul<TPB1, U1>, hipFuncAttributeMaxDynamicSharedMemorySize, kEllcbMaxCols * 8));
         attr_set = true;
     }
-    const int nbands = std::max(1, p.cb_nbands);
-    const int gb = std::max(1, grid / nbands);                 // sum workgroups (= partial sums) per band
-    const int tiles_per_band = p.cb_RB / p.cb_R;
-    // one band: as before, (column blocks x chunks) workgroups and nontemporal products; banded: a fixed number of pieces
-    // per band and plain product stores / loads (they are meant to stay cached between the two launches)
-    const int pieces = nbands > 1 ? g_opt.ell_colblock_pieces : p.cb_nb * c.chunks;
-    const int nt = nbands > 1 ? g_opt.ell_colblock_nt : 1;
-    for (int g = 0; g < nbands; ++g) {
-        const int64_t band_first = (int64_t)g * p.cb_RB * p.max_d;      // first sorted position of the band (every row holds max_d slots)
-        double *Pj = p.cb_P - band_first;
-        hipLaunchKernelGGL((k_ellcb_mul<TPB1, U1>), dim3(pieces), dim3(TPB1), (size_t)p.cb_cols * 8, st, p.ncol_own, p.cb_cols, p.cb_nb,
-                           nbands > 1 ? 0 : c.chunks, (const int32_t *)p.cb_bstart + (int64_t)g * p.cb_nb, (const double *)p.cb_sval, (const uint16_t *)p.cb_lcol, x,
-                           Pj, nt, flag, gen);
-        const int32_t t0 = g * tiles_per_band, t1 = std::min(p.cb_ntiles, t0 + tiles_per_band);
-        double *pw = pwy ? pwy + (int64_t)g * gb : nullptr, *py = pyy ? pyy + (int64_t)g * gb : nullptr;
-#define R_CASE(RR)                                                                                              \
-    if (p.cb_R == RR) {                                                                                         \
-        if (add) launch_sum<RR, true>(p, gb, t0, t1, Pj, nt, y, w, pw, py, flag, gen, chain ? 1 : 0);             \
-        else launch_sum<RR, false>(p, gb, t0, t1, Pj, nt, y, w, pw, py, flag, gen, 0);                           \
+    hipLaunchKernelGGL((k_ellcb_mul<TPB1, U1>), dim3(p.cb_nb * p.cb_chunks), dim3(TPB1), (size_t)p.cb_cols * 8, st, p.ncol_own, p.cb_cols,
+                       p.cb_nb, p.cb_chunks, (const int32_t *)p.cb_bstart, (const double *)p.cb_sval, (const uint16_t *)p.cb_lcol, x, p.cb_P,
+                       flag, gen);
+#define R_CASE(RR)                                                                              \
+    if (p.cb_R == RR) {                                                                         \
+        if (add) launch_sum<RR, true>(p, grid, y, w, pwy, pyy, flag, gen, chain ? 1 : 0);        \
+        else launch_sum<RR, false>(p, grid, y, w, pwy, pyy, flag, gen, 0);                       \
     }
-        R_CASE(64) R_CASE(128) R_CASE(192) R_CASE(256) R_CASE(512)
+    R_CASE(64) R_CASE(128) R_CASE(192) R_CASE(256) R_CASE(512)
 #undef R_CASE
-    }
     SGM_HIP(hipGetLastError());
     return SGM_OK;
 }
@@ -536,15 +467,12 @@ int64_t ell_colblock_resident_bytes(const Part &p)
 {
     if (!p.cb_P) return 0;
     const int64_t total = (int64_t)p.n * p.max_d, nruns = (int64_t)p.cb_ntiles * p.cb_nb;
-    const int64_t pbuf = std::min<int64_t>(total, (int64_t)p.cb_RB * p.max_d);        // ONE band's products
-    return total * (4 + 8 + 2 + 2) + pbuf * 8 + nruns * 8 + 4 * ((int64_t)p.cb_nb * p.cb_nbands + 1);
+    return total * (4 + 8 + 2 + 2) + total * 8 + nruns * 8 + 4 * ((int64_t)p.cb_nb + 1);
 }
 int64_t ell_colblock_matvec_bytes(const Part &p)
 {
     const int64_t total = (int64_t)p.n * p.max_d, nruns = (int64_t)p.cb_ntiles * p.cb_nb;
-    // what the two phases move by construction, wherever it is served from (with row bands the products' 16 B per entry are
-    // meant to be served by the Infinity Cache: the PMC pass tells)
-    const int64_t xloads = p.cb_nbands > 1 ? (int64_t)p.cb_nbands * (g_opt.ell_colblock_pieces + p.cb_nb) : (int64_t)p.cb_nb * cb_cfg().chunks;   // (pieces straddle blocks)
+    const int64_t xloads = (int64_t)p.cb_nb * p.cb_chunks;
     return total * (8 + 2 + 8) + xloads * p.cb_cols * 8                                  // phase 1: values, columns, products, x blocks
          + total * (8 + 2) + nruns * 8 + 8 * (int64_t)p.n;                              // phase 2: products, positions, run tables, y
 }

@@ -32,38 +32,46 @@ int fail(int code, const char *fmt, ...);
     } while (0)
 
 // ------------------------------------------------------------------ runtime
-struct Options {
+// Options are PER HANDLE: a matrix / solver / preconditioner copies the process-wide defaults (sgm_set_option) when it
+// is created and keeps its own copy from then on (sgm_mat_set_option / sgm_solver_set_option / sgm_pc_set_option); two
+// handles of one process may run different kernels, and changing a default never touches an existing handle.
+constexpr int kEllcbMaxCols = 20480;   // x entries of one column block = 160 KiB of LDS, all a gfx950 workgroup may have
+struct MatOptions {
     int csr_offset_dict = 1;       // use the 1-byte column code kernel when a matrix allows it
     int ell_offset_dict = 1;       // ELLPACK twin of csr_offset_dict (max_d <= 16)
     int csr_row_owner = 1;         // int32 columns, rows <= 64 entries: gather by the row's owner lane
-    int csr_row_lines = 1;         // int32 columns, rows longer than that (up to 4096 entries): one 128-byte line of val per row and pass, all rows of a block walked by their owner lanes (k_csr_rl)
-    int csr_sliced = 1;            // rows <= 8 entries, <= 15 offsets: slot-major slices + 4-bit codes (k_csr_sl)
+    int csr_row_lines = 1;         // int32 columns, longer rows (up to 4096 entries): one 128-byte line of val per row and pass (k_csr_rl)
+    int csr_sliced = 1;            // rows <= 8 entries, <= 15 offsets: slot-major slices + 4-bit codes (k_csr_sl); its siblings k_csr_slb / k_csr_sl32
+    int csr_sell = 1;              // general matrices whose rows are too long / uneven for the uniform sliced form: SELL-128-512 (2 = whenever the padding allows)
+    int csr_lean = 1;              // a matrix served by the sliced / SELL form keeps ONLY that form (+ row pointers) resident
     int ell_colblock = 1;          // ELLPACK with random columns: column-blocked two-phase product (0 never, 1 automatic, 2 always)
-    int ell_colblock_cols = 16384; // its column block (x entries staged in LDS per workgroup; even, <= 16384)
+    int ell_colblock_cols = 16384; // its column block: x entries staged in LDS per workgroup (even, <= kEllcbMaxCols)
     int ell_colblock_rows = 0;     // rows per tile of its sum phase: 0 automatic, 256 or 512
-    int ell_colblock_chunks = 16;  // workgroups per column block in the multiply phase (C4 sweep: 4 / 8 / 16 -> 1.32 / 1.31 / 1.27 ms)
-    int ell_colblock_band = -1;    // rows per band of the two-phase product: -1 one band (default: bands measured slower), 0 automatic (products + streams of a band <= ~160 MB), else rows (rounded to tiles)
-    int ell_colblock_pieces = 512; // workgroups of the multiply phase per band (banded form)
-    int ell_colblock_nt = 0;       // banded form: 1 = nontemporal product stores / loads (0: plain, so that the products stay cached)
-    int ildu_strips = 1;           // ILDU(0) factors of grid-like matrices (deps r-1, r-w): strip-pipelined triangular solves
-    int ildu_rows = 1;             // ILDU(0) factors of a few levels (colour orderings): row-space sweeps, one launch per level
-    int gmres_cgs2 = 1;            // GMRES: blocked CGS-2 orthogonalisation (3 passes per step) instead of modified Gram-Schmidt
-    int cg_small = 1;              // CG (plain or Jacobi) on a CSR matrix of <= 10240 rows: the whole solve in one workgroup (k_cg_small)
-    int cg_small_chunk = 50000;    // its iterations per launch (the solve continues in the next launch from parked r, p)
-    int slice_sched = 0;           // sliced kernels on matrices with a far stencil offset (3-D grids): band-ordered slice schedule per XCD
-    int slice_sched_band = 64;     // its target band width in slices
-    int csr_sell = 1;              // general matrices (no offset dictionary, rows too long or too uneven for the uniform sliced form): SELL-128-512
-    int csr_lean = 1;              // matrices served by the 4-bit sliced form keep ONLY that form (+ row pointers): the int32 columns, the 1-byte
-                                   // codes and the CSR-order values are rebuilt from it when something asks (general kernels, preconditioner setup,
-                                   // sgm_mat_get, transposes, permutations) and released again; 0 = every layout stays resident (round 2)
-    int krylov_graph = 1;          // CG / BiCGStab launch loops (one GPU, plain or Jacobi): replay a captured group of 16 iterations (hipGraph): the GPU-side
-                                   // floor (13.3 us per CG iteration at n = 1e5) whatever the host's launch rate is (13.7-18 us launched, box to box)
-    int krylov_graph_after = 64;   // ... once the solve has run this many iterations (a multiple of 16: the capture has to pay for itself)
-    int dot_order = 0;             // dot products of CG / BiCGStab: 0 = tree (per-workgroup partial sums), 1 = the reference's order
-                                   // (one accumulator, first element to last: what amdflang -O2 makes of dot_product) -- validation mode
-    int bicgstab_small = 1;        // BiCGStab (plain or Jacobi) on a CSR matrix of <= 4096 rows: the whole solve in one workgroup
-    int pipeline_spin_limit = 0;   // strip / slab triangular solves: polls before a wait gives up (0 = built-in limit; tests set 1 to force an abort)
+    int slice_sched = 0;           // sliced kernels on matrices with a far stencil offset (3-D grids): tile-ordered slice schedule per XCD;
+                                   // 0 off, 1 = bands of 64 slices, n > 1 = bands of n slices
 };
+struct SolverOptions {
+    int cg_small = 1;              // CG (plain or Jacobi) on a small CSR matrix: the whole solve in one workgroup (k_cg_small);
+                                   // 0 off, 1 on (50000 iterations per launch), n > 1 on with n iterations per launch
+    int bicgstab_small = 1;        // BiCGStab (plain or Jacobi) on a CSR matrix of <= 4096 rows: the whole solve in one workgroup
+    int krylov_graph = 1;          // CG / BiCGStab launch loops (one GPU, plain or Jacobi): replay a captured group of 16 iterations (hipGraph);
+                                   // 0 off, 1 = once the solve has run 64 iterations, n > 1 = after n (rounded up to a multiple of 16)
+    int dot_order = 0;             // dot products of CG / BiCGStab: 0 = tree (per-workgroup partial sums), 1 = the reference's order
+    int gmres_cgs2 = 1;            // GMRES: blocked CGS-2 orthogonalisation (3 passes per step) instead of modified Gram-Schmidt
+};
+struct PcOptions {
+    int ildu_strips = 1;           // ILDU(0) factors of grid-like matrices (deps r-1, r-w[, r-wh]): strip- / slab-pipelined triangular solves
+    int ildu_rows = 1;             // ILDU(0) factors of a few levels (colour orderings): row-space sweeps, one launch per level (2 = every level launched)
+    int pipeline_spin_limit = 0;   // strip / slab triangular solves: polls before a wait gives up (0 = built-in limit; tests set 1 to force an abort)
+    int ildu_reorder = 0;          // ILDU(0) of the colour-ordered matrix P A P^T (the reference's greedy_color_ordering), applied as
+                                   // z = P^T M^-1 P r: a factorisation of a few wide levels whatever order A is in; 0 = A as it is
+};
+struct Options { MatOptions mat; SolverOptions solver; PcOptions pc; };      // the defaults handles are created with
+// name -> field of one of the three groups (nullptr: not in that group); shared by sgm_set_option and the per-handle setters
+int *mat_option_field(MatOptions &o, const char *name);
+int *solver_option_field(SolverOptions &o, const char *name);
+int *pc_option_field(PcOptions &o, const char *name);
+int normalise_option(const char *name, int value, int *out);     // range checks / rounding shared by all setters
 extern Options g_opt;
 
 struct Runtime {
@@ -146,6 +154,7 @@ struct HaloNbr {
 struct SliceSched { int32_t *tab = nullptr; int32_t lo = 0, hi = 0, grid = 0, iters = 0, band = 0; };
 
 struct Part {
+    MatOptions opt = g_opt.mat;    // this matrix's options: the defaults at the moment the part is made; every part of a matrix holds the same
     int32_t n = 0;                 // owned rows
     int32_t ncol_own = 0;          // owned columns (== n for the square partitions used)
     int32_t n_halo = 0;
@@ -200,8 +209,7 @@ struct Part {
     uint16_t *cb_lpos = nullptr;   // slot-major: position of entry (k, i) in its tile's LDS image
     void *cb_fdesc = nullptr;      // ntiles x nb run descriptors {sorted position, length | LDS base << 16}
     double *cb_P = nullptr;        // products val * x in sorted order (written by phase 1)
-    int32_t cb_cols = 0, cb_nb = 0, cb_R = 0, cb_ntiles = 0;
-    int32_t cb_RB = 0, cb_nbands = 1;  // row bands: the two phases run band by band over ONE product buffer of cb_RB rows (it stays in the Infinity Cache)
+    int32_t cb_cols = 0, cb_nb = 0, cb_R = 0, cb_ntiles = 0, cb_chunks = 0;
     std::vector<HaloNbr> nbrs;
     double *xext = nullptr;        // owned+halo staging for plain-vector matvec (multi-part only)
     int dot_grid_override = 0;     // composite matrices: grid of the separate dot kernel
@@ -276,6 +284,8 @@ int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
 // index arrays on the device as they are converted (SGM_ERR_BAD_ARG / SGM_ERR_DIMS naming the first offending row)
 int build_csr_part(Part &p, int32_t n, int32_t ncol_own, int32_t n_halo, int64_t nnz,
                    const int32_t *ptr1, const int32_t *node1, const double *val, int where, bool validate = true);
+int clone_csr_plain(sgm_mat A, sgm_mat *out);                                   // plain-CSR device copy (setup scratch)
+int color_order_device(sgm_mat A, int32_t **dp, std::vector<int32_t> &ptrs);    // greedy_color_ordering, p left on the device (sgm_order.hip)
 int spmv_grid(const Part &p);
 int matvec_plain(sgm_mat A, const double *x, double *y);     // device vectors, sgm_mat_matvec's layout, stream-ordered
 // "csr_lean": the CSR-order arrays of a part that kept only its sliced form, on demand (no-op otherwise)

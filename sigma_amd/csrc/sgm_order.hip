@@ -199,7 +199,153 @@ int stage_perm(const char *who, int32_t n, const int32_t *p, int where, int32_t 
     return SGM_OK;
 }
 
+// ---- greedy colouring on the device, for the graphs where it is a parallel computation -----------------
+// greedy_coloring (permutations.f90:83-157) colours the vertices in breadth-first queue order from vertex 1; each takes,
+// among the colours in use that none of its already coloured neighbours has, the one with the fewest members, else a new
+// one.  In general every decision reads the tallies the previous one left: sequential.  But when
+//   (a) every vertex is reached from vertex 1,
+//   (b) every neighbour j /= i of a vertex i sits an ODD number of breadth-first levels away from it, and
+//   (c) every vertex but the first has a neighbour on a lower level
+// (a bipartite, structurally symmetric graph: every 5- / 7-point grid, holes and all) the result is forced: by induction
+// over the queue order a vertex on an even level finds all its coloured neighbours in colour 2 and at least one of them
+// there, so colour 1 is its only candidate (and vice versa; the second vertex of the queue opens colour 2): colour =
+// 1 + (level mod 2), whatever the tallies.  Levels are a level-synchronous sweep, (a)-(c) are checked inside it; if one
+// fails the caller runs the sequential host pass -- which also stays as the checker of this one (tests, SGM_COLOR_HOST=1).
+__global__ __launch_bounds__(256) void k_lvl_step(int32_t L, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                  int32_t *level, const int32_t *__restrict__ cur, int32_t *__restrict__ nxt,
+                                                  int32_t *cnt /* ring of 4 */, int32_t *state /* [0] bad, [1] vertices reached, [2] first empty level */)
+{
+    const int32_t m = cnt[L & 3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        cnt[(L + 2) & 3] = 0;                      // (nobody reads or appends to that slot during this launch)
+        if (m == 0) atomicMin(&state[2], L);
+        else atomicAdd(&state[1], m);
+    }
+    const int32_t stride = gridDim.x * blockDim.x;
+    for (int32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < m; t += stride) {
+        const int32_t i = cur[t];
+        bool lower = L == 0, odd = true;
+        for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+            const int32_t j = col[k];
+            if (j == i) continue;                  // (the diagonal: its own colour is 0 = "queued" when a vertex looks, :119-128)
+            int32_t lj = level[j];
+            if (lj == -1) {
+                const int32_t old = atomicCAS(&level[j], -1, L + 1);
+                if (old == -1) nxt[atomicAdd(&cnt[(L + 1) & 3], 1)] = j;
+                lj = L + 1;
+            }
+            odd = odd && (((lj - L) & 1) != 0);
+            lower = lower || lj < L;
+        }
+        if (!odd || !lower) state[0] = 1;
+    }
+}
+__global__ void k_color_flags(int32_t n, const int32_t *__restrict__ level, int32_t *__restrict__ is1)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) is1[i] = (level[i] & 1) == 0;
+}
+// colours[i] = 1 + level mod 2, or the ordering p(i) = position when the vertices are sorted by colour, ties by index
+__global__ void k_color_out(int32_t n, int32_t n1, const int32_t *__restrict__ level, const int32_t *__restrict__ before1,
+                            int32_t *__restrict__ colors, int32_t *__restrict__ p)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool c1 = (level[i] & 1) == 0;
+    if (colors) colors[i] = c1 ? 1 : 2;
+    if (p) p[i] = c1 ? 1 + before1[i] : n1 + 1 + (i - before1[i]);
+}
+
+// *ok = false: the graph is not of the kind above (nothing written).  colors_dev / p_dev (either may be null): device
+// arrays of n int32; *n1 = vertices of colour 1 (0-based position where colour 2 starts)
+int greedy_coloring_device(const Part &pt, int32_t *colors_dev, int32_t *p_dev, int32_t *n1_out, int32_t *ncolors, bool *ok)
+{
+    *ok = false;
+    const int32_t n = pt.n;
+    if (n < 1 || getenv("SGM_COLOR_HOST")) return SGM_OK;
+    SGM_TRY(csr_need_arrays(pt));
+    struct Release { const Part &p; ~Release() { csr_release_arrays(p); } } rel{pt};
+    hipStream_t st = g_rt.stream;
+    int32_t *level = nullptr, *fr[2] = {nullptr, nullptr}, *cnt = nullptr, *state = nullptr, *before = nullptr;
+    void *tmp = nullptr;
+    struct Scratch { int32_t **a, **b, **c, **d, **e, **f; void **g; ~Scratch() { dfree(*a); dfree(*b); dfree(*c); dfree(*d); dfree(*e); dfree(*f); if (*g) (void)hipFree(*g); } }
+        guard{&level, &fr[0], &fr[1], &cnt, &state, &before, &tmp};
+    SGM_TRY(dalloc(&level, (size_t)n));
+    SGM_TRY(dalloc(&fr[0], (size_t)n));
+    SGM_TRY(dalloc(&fr[1], (size_t)n));
+    SGM_TRY(dalloc(&cnt, 4));
+    SGM_TRY(dalloc(&state, 4));
+    hipLaunchKernelGGL(k_fill_i32, dim3(vec_grid(n)), dim3(kBlock), 0, st, (int64_t)n, level, -1);
+    const int32_t init_cnt[4] = {1, 0, 0, 0}, init_state[4] = {0, 0, INT32_MAX, 0}, zero = 0;
+    SGM_HIP(hipMemcpyAsync(cnt, init_cnt, sizeof init_cnt, hipMemcpyHostToDevice, st));
+    SGM_HIP(hipMemcpyAsync(state, init_state, sizeof init_state, hipMemcpyHostToDevice, st));
+    SGM_HIP(hipMemcpyAsync(fr[0], &zero, 4, hipMemcpyHostToDevice, st));         // the queue starts with vertex 1, level 0
+    SGM_HIP(hipMemcpyAsync(level, &zero, 4, hipMemcpyHostToDevice, st));
+    // one launch per level, 64 levels between two looks at the state; a fixed grid walks any frontier
+    int32_t hstate[4] = {0, 0, INT32_MAX, 0};
+    for (int32_t L = 0; hstate[2] == INT32_MAX && hstate[0] == 0 && L <= n; L += 64) {
+        for (int32_t l = L; l < L + 64; ++l)
+            hipLaunchKernelGGL(k_lvl_step, dim3(128), dim3(256), 0, st, l, (const int32_t *)pt.rowptr, (const int32_t *)pt.col, level,
+                               (const int32_t *)fr[l & 1], fr[(l + 1) & 1], cnt, state);
+        SGM_HIP(hipMemcpyAsync(hstate, state, sizeof hstate, hipMemcpyDeviceToHost, st));
+        SGM_HIP(hipStreamSynchronize(st));
+    }
+    SGM_HIP(hipGetLastError());
+    if (hstate[0] != 0 || hstate[1] != n) return SGM_OK;          // not that kind of graph / not connected: the host pass decides
+    SGM_TRY(dalloc(&before, (size_t)n + 1));
+    hipLaunchKernelGGL(k_color_flags, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, (const int32_t *)level, before);
+    size_t tb = 0;
+    SGM_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, before, before, n + 1, st));
+    SGM_HIP(hipMalloc(&tmp, std::max<size_t>(tb, 16)));
+    SGM_HIP(hipMemsetAsync(before + n, 0, 4, st));
+    SGM_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, before, before, n + 1, st));
+    int32_t n1 = 0;
+    SGM_HIP(hipMemcpyAsync(&n1, before + n, 4, hipMemcpyDeviceToHost, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    hipLaunchKernelGGL(k_color_out, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, n1, (const int32_t *)level,
+                       (const int32_t *)before, colors_dev, p_dev);
+    SGM_HIP(hipGetLastError());
+    SGM_HIP(hipStreamSynchronize(st));
+    if (n1_out) *n1_out = n1;
+    if (ncolors) *ncolors = n1 < n ? 2 : 1;
+    *ok = true;
+    return SGM_OK;
+}
+
 }  // namespace
+
+namespace sgm {
+// greedy_color_ordering with the permutation left ON THE DEVICE (the reordering preconditioner, sgm_pc.hip): *dp = n int32,
+// 1-based like the reference's p; ptrs = first position of every colour (num_colors + 1 entries, 1-based)
+int color_order_device(sgm_mat A, int32_t **dp, std::vector<int32_t> &ptrs)
+{
+    *dp = nullptr;
+    if (!A || A->fmt != SGM_FMT_CSR || A->distributed() || A->nrow != A->ncol)
+        return fail(SGM_ERR_UNSUPPORTED, "colour ordering: single-GPU square CSR matrices only");
+    const Part &pt = A->parts[0];
+    const int32_t n = pt.n;
+    SGM_TRY(dalloc(dp, (size_t)std::max(n, 1)));
+    bool ok = false;
+    int32_t n1 = 0, nc = 0;
+    int rc = greedy_coloring_device(pt, nullptr, *dp, &n1, &nc, &ok);
+    if (rc == SGM_OK && ok) {
+        ptrs.assign({1, n1 + 1});
+        if (nc == 2) ptrs.push_back(n + 1);
+        return SGM_OK;
+    }
+    if (rc == SGM_OK) {
+        std::vector<int32_t> hp((size_t)std::max(n, 1)), hptrs((size_t)n + 2, 0);
+        int32_t hnc = 0;
+        rc = sgm_graph_greedy_color_order(A, hp.data(), hptrs.data(), n + 2, &hnc);
+        if (rc == SGM_OK) {
+            ptrs.assign(hptrs.begin(), hptrs.begin() + hnc + 1);
+            if (n && hipMemcpy(*dp, hp.data(), (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) rc = fail(SGM_ERR_HIP, "colour ordering: upload failed");
+        }
+    }
+    if (rc != SGM_OK) { dfree(*dp); *dp = nullptr; }
+    return rc;
+}
+}  // namespace sgm
 
 extern "C" {
 
@@ -301,12 +447,37 @@ int sgm_graph_bfs_order(sgm_mat A, int32_t *p_out)
     return rc;
 }
 
+// device path of the two colouring entry points: fills the host array from the device result; *done = false: take the host pass
+static int try_device_coloring(sgm_mat A, const char *who, bool ordering, int32_t *out_host, int32_t *n1, int32_t *nc, bool *done)
+{
+    *done = false;
+    if (!A) return fail(SGM_ERR_BAD_ARG, "%s: null matrix", who);
+    if (A->fmt != SGM_FMT_CSR || A->distributed() || A->nrow != A->ncol) return SGM_OK;      // (the host pass reports it)
+    const Part &pt = A->parts[0];
+    if (pt.n < 1) return SGM_OK;
+    int32_t *d = nullptr;
+    SGM_TRY(dalloc(&d, (size_t)pt.n));
+    bool ok = false;
+    int rc = greedy_coloring_device(pt, ordering ? nullptr : d, ordering ? d : nullptr, n1, nc, &ok);
+    if (rc == SGM_OK && ok && hipMemcpy(out_host, d, (size_t)pt.n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(SGM_ERR_HIP, "%s: copy back failed", who);
+    dfree(d);
+    *done = rc == SGM_OK && ok;
+    return rc;
+}
+
 int sgm_graph_greedy_coloring(sgm_mat A, int32_t *colors_out, int32_t *num_colors)
 {
     SGM_TRY(require_init());
+    if (!colors_out) return fail(SGM_ERR_BAD_ARG, "sgm_graph_greedy_coloring: null output");
+    {   // graphs whose colouring is forced (bipartite, symmetric, connected from vertex 1): on the device
+        bool done = false;
+        int32_t n1 = 0, nc = 0;
+        SGM_TRY(try_device_coloring(A, "sgm_graph_greedy_coloring", false, colors_out, &n1, &nc, &done));
+        if (done) { if (num_colors) *num_colors = nc; return SGM_OK; }
+    }
     std::vector<int32_t> ptr, node;
     SGM_TRY(host_graph(A, "sgm_graph_greedy_coloring", ptr, node));
-    if (!colors_out) return fail(SGM_ERR_BAD_ARG, "sgm_graph_greedy_coloring: null output");
     const int32_t used = greedy_coloring_host(A->nrow, ptr, node, colors_out);
     if (num_colors) *num_colors = used;
     return SGM_OK;
@@ -315,9 +486,20 @@ int sgm_graph_greedy_coloring(sgm_mat A, int32_t *colors_out, int32_t *num_color
 int sgm_graph_greedy_color_order(sgm_mat A, int32_t *p_out, int32_t *ptrs_out, int32_t ptrs_len, int32_t *num_colors)
 {
     SGM_TRY(require_init());
+    if (!p_out || !num_colors) return fail(SGM_ERR_BAD_ARG, "sgm_graph_greedy_color_order: null output");
+    {
+        bool done = false;
+        int32_t n1 = 0, nc = 0;
+        SGM_TRY(try_device_coloring(A, "sgm_graph_greedy_color_order", true, p_out, &n1, &nc, &done));
+        if (done) {
+            if (ptrs_out && ptrs_len < nc + 1) return fail(SGM_ERR_BAD_ARG, "sgm_graph_greedy_color_order: ptrs needs %d entries", nc + 1);
+            if (ptrs_out) { ptrs_out[0] = 1; ptrs_out[1] = n1 + 1; if (nc == 2) ptrs_out[2] = A->nrow + 1; }
+            *num_colors = nc;
+            return SGM_OK;
+        }
+    }
     std::vector<int32_t> ptr, node;
     SGM_TRY(host_graph(A, "sgm_graph_greedy_color_order", ptr, node));
-    if (!p_out || !num_colors) return fail(SGM_ERR_BAD_ARG, "sgm_graph_greedy_color_order: null output");
     const int32_t n = A->nrow;
     const int32_t nc = greedy_coloring_host(n, ptr, node, p_out);
     for (int32_t i = 0; i < n; ++i)

@@ -125,6 +125,7 @@ struct PartPC {
 // ILDU(0) of one diagonal block (the whole matrix on one GPU; with a row partition, the owned
 // rows x owned columns of each part: block-Jacobi ILDU)
 struct IlduState {
+    PcOptions opt = g_opt.pc;        // the owning preconditioner's options (kept equal to sgm_pc_s::opt)
     int32_t n = 0;
     TriFactor L, U;
     double *D = nullptr;
@@ -171,6 +172,13 @@ struct sgm_pc_s {
     std::vector<double> hidiag;
     int32_t *abort_sticky = nullptr; // device: set by a pipelined triangular sweep that gave up; cleared by the host only
     int retired = 0;                 // pipelines switched off after an abort (diagnostics: sgm_pc_get "pipeline_retired")
+    PcOptions opt = g_opt.pc;        // this preconditioner's options: the defaults at its creation, then sgm_pc_set_option
+    // option "ildu_reorder": the factors are those of P A P^T; perm = p (1-based: row i of A is row p(i) of the permuted
+    // matrix), rp / zp = right-hand side and result in the permuted order
+    int32_t *perm = nullptr;
+    double *rp = nullptr, *zp = nullptr;
+    int32_t perm_colors = 0;
+    double reorder_ms[3] = {0, 0, 0};  // last setup: ordering, permuted copy, (factorisation is in the regular phases)
 };
 
 namespace {
@@ -1277,7 +1285,9 @@ void free_ildu(IlduState &S)
     free_grid(S.gL); free_grid(S.gU);
     dfree(S.gxL); dfree(S.gxU); dfree(S.gDp); dfree(S.gmapLU);
     slab3_free(S.slab);
+    const PcOptions keep = S.opt;          // (the owning preconditioner's options outlive a rebuild of its factors)
     S = IlduState();
+    S.opt = keep;
 }
 
 void free_tri(TriFactor &T)
@@ -1769,7 +1779,7 @@ void apply_levels(const IlduState *S, const double *r, double *z, const int *fla
 }
 
 // the same through the row-space levels (both factors a few wide levels): one launch per level, nothing else
-bool rows_serve(const IlduState *S) { return g_opt.ildu_rows && S->levels_ready && S->L.rows_on && S->U.rows_on; }
+bool rows_serve(const IlduState *S) { return S->opt.ildu_rows && S->levels_ready && S->L.rows_on && S->U.rows_on; }
 void launch_rows(const TriFactor &T, const TriFactor::RowLevel &L, int mode, const double *r, double *y, const double *D, double *z,
                  int32_t n0, const int *flag)
 {
@@ -1801,7 +1811,7 @@ void launch_rows(const TriFactor &T, const TriFactor::RowLevel &L, int mode, con
 void apply_rows(const IlduState *S, const double *r, double *z, const int *flag)
 {
     const auto &Ls = S->L.row_levels, &Us = S->U.row_levels;
-    const bool fused = g_opt.ildu_rows == 1;
+    const bool fused = S->opt.ildu_rows == 1;
     const int32_t n0 = fused ? S->rows_n0 : 0;
     const bool fin = fused && S->rows_fin;
     for (size_t k = n0 > 0 ? 1 : 0; k < Ls.size(); ++k)                    // (I+L) y = r
@@ -1989,9 +1999,9 @@ bool pc_apply_is_short(sgm_pc pc)
     if (!pc || pc->kind == SGM_PC_JACOBI) return true;
     // (a colour-ordered matrix has two or three levels per factor: its level-scheduled apply is seven to nine launches)
     for (const auto &S : pc->ild) {
-        if (g_opt.ildu_strips && (S.grid_ok || S.slab_ok)) continue;
+        if (pc->opt.ildu_strips && (S.grid_ok || S.slab_ok)) continue;
         if (!S.levels_ready) return false;
-        if (g_opt.ildu_rows && S.L.rows_on && S.U.rows_on) continue;         // at most 2 * kRowLevels launches
+        if (pc->opt.ildu_rows && S.L.rows_on && S.U.rows_on) continue;         // at most 2 * kRowLevels launches
         if (!S.walk_ready || 3 + S.L.schedule.size() + S.U.schedule.size() > 35) return false;
     }
     return true;
@@ -2003,7 +2013,7 @@ const double *pc_idiag(sgm_pc pc, size_t part) { return pc->parts[part].idiag; }
 // and everything computed from it -- is not to be used.
 int32_t *pc_abort_word(sgm_pc pc)
 {
-    if (!pc || pc->kind != SGM_PC_ILDU0 || !g_opt.ildu_strips || !pc->abort_sticky) return nullptr;
+    if (!pc || pc->kind != SGM_PC_ILDU0 || !pc->opt.ildu_strips || !pc->abort_sticky) return nullptr;
     for (const auto &S : pc->ild)
         if (S.grid_ok || S.slab_ok) return pc->abort_sticky;
     return nullptr;
@@ -2025,7 +2035,45 @@ int pc_retire_pipelines(sgm_pc pc)
     return SGM_OK;
 }
 
+// dst[p(i) - 1] = src[i]  /  dst[i] = src[p(i) - 1]
+__global__ void k_perm_to(int32_t n, const int32_t *__restrict__ p1, const double *__restrict__ src, double *__restrict__ dst,
+                          const int *__restrict__ flag)
+{
+    if (flag && *flag) return;
+    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t stride = gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[p1[i] - 1] = src[i];
+}
+__global__ void k_perm_from(int32_t n, const int32_t *__restrict__ p1, const double *__restrict__ src, double *__restrict__ dst,
+                            const int *__restrict__ flag)
+{
+    if (flag && *flag) return;
+    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t stride = gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = src[p1[i] - 1];
+}
+
+static int pc_apply_parts_ordered(sgm_pc pc, sgm_mat A, const double *const *r, double *const *z, const int *const *flags);
+
 int pc_apply_parts(sgm_pc pc, sgm_mat A, const double *const *r, double *const *z, const int *const *flags)
+{
+    if (pc->kind == SGM_PC_ILDU0 && pc->perm) {
+        // z = P^T M^-1 P r: into the colour order, the sweeps there, back
+        hipStream_t st = g_rt.stream;
+        const int32_t n = pc->n;
+        const int *flag = flags ? flags[0] : nullptr;
+        hipLaunchKernelGGL(k_perm_to, dim3(vec_grid(n)), dim3(kBlock), 0, st, n, (const int32_t *)pc->perm, r[0], pc->rp, flag);
+        const double *rr[1] = {pc->rp};
+        double *zz[1] = {pc->zp};
+        SGM_TRY(pc_apply_parts_ordered(pc, A, rr, zz, flags));
+        hipLaunchKernelGGL(k_perm_from, dim3(vec_grid(n)), dim3(kBlock), 0, st, n, (const int32_t *)pc->perm, (const double *)pc->zp, z[0], flag);
+        SGM_HIP(hipGetLastError());
+        return SGM_OK;
+    }
+    return pc_apply_parts_ordered(pc, A, r, z, flags);
+}
+
+static int pc_apply_parts_ordered(sgm_pc pc, sgm_mat A, const double *const *r, double *const *z, const int *const *flags)
 {
     hipStream_t st = g_rt.stream;
     if (pc->kind == SGM_PC_JACOBI) {
@@ -2038,12 +2086,12 @@ int pc_apply_parts(sgm_pc pc, sgm_mat A, const double *const *r, double *const *
         for (size_t ip = 0; ip < pc->ild.size(); ++ip) {      // block-Jacobi over the parts: no exchange
             const IlduState *S = &pc->ild[ip];
             const int *flag = flags ? flags[ip] : nullptr;
-            const int spin = g_opt.pipeline_spin_limit > 0 ? g_opt.pipeline_spin_limit : kStripSpinLimit;
-            if (S->grid_ok && g_opt.ildu_strips) {                 // grid-like factors: one strip-pipelined launch per sweep
+            const int spin = pc->opt.pipeline_spin_limit > 0 ? pc->opt.pipeline_spin_limit : kStripSpinLimit;
+            if (S->grid_ok && S->opt.ildu_strips) {                 // grid-like factors: one strip-pipelined launch per sweep
                 apply_grid(S, r[ip], z[ip], flag, spin, pc->abort_sticky);
                 continue;
             }
-            if (S->slab_ok && g_opt.ildu_strips) {                 // 3-D grid factors: one slab-pipelined launch per sweep
+            if (S->slab_ok && S->opt.ildu_strips) {                 // 3-D grid factors: one slab-pipelined launch per sweep
                 slab3_apply(S->slab, r[ip], z[ip], flag, spin, pc->abort_sticky);
                 continue;
             }
@@ -2061,10 +2109,50 @@ int pc_apply_parts(sgm_pc pc, sgm_mat A, const double *const *r, double *const *
 
 extern "C" {
 
+static int pc_setup_ordered(sgm_pc pc, sgm_mat A);
+
 int sgm_pc_setup(sgm_pc pc, sgm_mat A)
 {
     SGM_TRY(require_init());
     if (!pc || !A) return fail(SGM_ERR_BAD_ARG, "sgm_pc_setup: null argument");
+    const bool reorder = pc->kind == SGM_PC_ILDU0 && pc->opt.ildu_reorder && A->fmt == SGM_FMT_CSR && A->parts.size() == 1 && !A->comm &&
+                         A->nrow == A->ncol && A->nrow > 0;
+    if (!reorder) {
+        if (pc->perm) { dfree(pc->perm); dfree(pc->rp); dfree(pc->zp); pc->perm = nullptr; pc->rp = pc->zp = nullptr; for (auto &S : pc->ild) free_ildu(S); pc->ild.clear(); }
+        return pc_setup_ordered(pc, A);
+    }
+    // ILDU(0) of the colour-ordered matrix: the ordering once per pattern (ldu_solvers.f90:117-125 builds the pattern once),
+    // a permuted scratch copy of A per setup (the values may have changed), the regular device-side setup on that copy
+    auto t0 = std::chrono::steady_clock::now();
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { (void)hipStreamSynchronize(g_rt.stream); return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    const int32_t n = A->nrow;
+    if (!pc->perm || pc->n != n) {
+        dfree(pc->perm); dfree(pc->rp); dfree(pc->zp);
+        pc->perm = nullptr; pc->rp = pc->zp = nullptr;
+        for (auto &S : pc->ild) free_ildu(S);
+        pc->ild.clear();
+        std::vector<int32_t> ptrs;
+        SGM_TRY(color_order_device(A, &pc->perm, ptrs));
+        pc->perm_colors = (int32_t)ptrs.size() - 1;
+        SGM_TRY(dalloc(&pc->rp, (size_t)n + 2));
+        SGM_TRY(dalloc(&pc->zp, (size_t)n + 2));
+        pc->reorder_ms[0] = ms_since(t0);
+    }
+    t0 = std::chrono::steady_clock::now();
+    sgm_mat Ap = nullptr;
+    SGM_TRY(clone_csr_plain(A, &Ap));
+    int rc = sgm_mat_left_permute(Ap, pc->perm, SGM_DEVICE);
+    if (rc == SGM_OK) rc = sgm_mat_right_permute(Ap, pc->perm, SGM_DEVICE);
+    pc->reorder_ms[1] = ms_since(t0);
+    t0 = std::chrono::steady_clock::now();
+    if (rc == SGM_OK) rc = pc_setup_ordered(pc, Ap);
+    pc->reorder_ms[2] = ms_since(t0);
+    sgm_mat_destroy(Ap);
+    return rc;
+}
+
+static int pc_setup_ordered(sgm_pc pc, sgm_mat A)
+{
     if (A->nrow != A->ncol)      // jacobi_solvers.f90:46-50, ldu_solvers.f90:104-108
         return fail(SGM_ERR_DIMS, "Cannot make a %s solver for a non-square matrix",
                     pc->kind == SGM_PC_JACOBI ? "Jacobi" : "LDU");
@@ -2134,6 +2222,7 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
     if (pc->ild.size() != A->parts.size()) {
         for (auto &S : pc->ild) free_ildu(S);
         pc->ild.assign(A->parts.size(), IlduState());
+        for (auto &S0 : pc->ild) S0.opt = pc->opt;
     }
     pc->n = A->nrow;
     for (size_t ip = 0; ip < A->parts.size(); ++ip) {
@@ -2163,7 +2252,7 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             // L's dependency levels: the order the rows are factorised in (and what its sweeps use later) -- on the device
             // when they are few, else from the pattern's host copy
             SGM_TRY(tri_levels_device(S->L, n, S->dLptr, S->dLnode, &few));
-            if (!S->L.have_levels && g_opt.ildu_strips) {
+            if (!S->L.have_levels && S->opt.ildu_strips) {
                 // many levels: a grid-like pair (what the strip pipeline serves)?  Then the anti-diagonals are the order
                 SGM_TRY(grid_width_device(n, S->dLptr, S->dLnode, true, &S->dev_wl));
                 if (S->dev_wl >= 64) SGM_TRY(grid_width_device(n, S->dUptr, S->dUnode, false, &S->dev_wu));
@@ -2235,7 +2324,7 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
                 wl = grid_width(n, S->hLptr, S->hLnode, true);
                 wu = grid_width(n, S->hUptr, S->hUnode, false);
             }
-            if (g_opt.ildu_strips && wl >= 64 && wl == wu && (n + wl - 1) / wl >= 64) {
+            if (S->opt.ildu_strips && wl >= 64 && wl == wu && (n + wl - 1) / wl >= 64) {
                 SGM_TRY(build_grid(S->gL, n, wl, S->dLptr, S->dLnode, true));
                 SGM_TRY(build_grid(S->gU, n, wl, S->dUptr, S->dUnode, false));
                 if (S->gL.on && S->gU.on) {
@@ -2254,8 +2343,8 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             slab3_free(S->slab);
             S->slab = nullptr;
             S->slab_ok = false;
-            if (g_opt.ildu_strips && !few && !(S->gL.on && S->gU.on) && !S->dev_slab) SGM_TRY(ensure_host_pattern(S));
-            if (g_opt.ildu_strips && !few && !(S->gL.on && S->gU.on))
+            if (S->opt.ildu_strips && !few && !(S->gL.on && S->gU.on) && !S->dev_slab) SGM_TRY(ensure_host_pattern(S));
+            if (S->opt.ildu_strips && !few && !(S->gL.on && S->gU.on))
                 SGM_TRY(slab3_build(&S->slab, n, S->hLptr, S->hLnode, S->hUptr, S->hUnode, S->dLptr, S->dLnode, S->dUptr, S->dUnode));
         }
         lap("strip / slab index work");
@@ -2329,6 +2418,17 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
     return SGM_OK;
 }
 
+/* sgm_pc_create: the factory alone -- jacobi() / ldu() (jacobi_solvers.f90:23-31, ldu_solvers.f90:73-86) return an object
+ * that has seen no matrix yet; options can be set on it before the first sgm_pc_setup builds its sweeps. */
+int sgm_pc_create(sgm_pc *out, int32_t kind)
+{
+    if (!out || (kind != SGM_PC_JACOBI && kind != SGM_PC_ILDU0)) return fail(SGM_ERR_BAD_ARG, "sgm_pc_create: kind is SGM_PC_JACOBI or SGM_PC_ILDU0");
+    sgm_pc pc = new sgm_pc_s;
+    pc->kind = kind;
+    *out = pc;
+    return SGM_OK;
+}
+
 int sgm_jacobi_create(sgm_pc *out, sgm_mat A)
 {
     if (!out) return fail(SGM_ERR_BAD_ARG, "sgm_jacobi_create: null out pointer");
@@ -2348,6 +2448,21 @@ int sgm_ildu0_create(sgm_pc *out, sgm_mat A)
     int rc = sgm_pc_setup(pc, A);
     if (rc != SGM_OK) { sgm_pc_destroy(pc); return rc; }
     *out = pc;
+    return SGM_OK;
+}
+
+/* sgm_pc_set_option: this preconditioner's own copy of "ildu_strips", "ildu_rows", "pipeline_spin_limit" (sgm_set_option
+ * only changes what preconditioners created LATER start with).  Which sweeps exist is decided at setup: switching a path
+ * off acts from the next apply on, switching one on that was off at setup takes effect at the next sgm_pc_setup. */
+int sgm_pc_set_option(sgm_pc pc, const char *name, int value)
+{
+    if (!pc || !name) return fail(SGM_ERR_BAD_ARG, "sgm_pc_set_option: null argument");
+    int v = 0;
+    SGM_TRY(normalise_option(name, value, &v));
+    int *f = pc_option_field(pc->opt, name);
+    if (!f) return fail(SGM_ERR_BAD_ARG, "sgm_pc_set_option: '%s' is not a preconditioner option", name);
+    *f = v;
+    for (auto &S : pc->ild) S.opt = pc->opt;
     return SGM_OK;
 }
 
@@ -2417,7 +2532,7 @@ int sgm_pc_get(sgm_pc pc, const char *name, void *out, size_t bytes, size_t *nee
         else if (nm == "D") { src = S->hD.data(); sz = S->hD.size() * 8; }
         else if (nm == "strips") {          // strip pipeline in use: {strips per sweep, steps per strip, order variant of L, of U}; zeros = off
             static int32_t sv[4];
-            const bool on = S->grid_ok && g_opt.ildu_strips;
+            const bool on = S->grid_ok && S->opt.ildu_strips;
             sv[0] = on ? S->gL.NI : 0; sv[1] = on ? S->gL.S : 0; sv[2] = on ? S->gL.order : 0; sv[3] = on ? S->gU.order : 0;
             src = sv; sz = sizeof sv;
         }
@@ -2432,7 +2547,7 @@ int sgm_pc_get(sgm_pc pc, const char *name, void *out, size_t bytes, size_t *nee
         else if (nm == "slabs") {           // slab pipeline in use: {strips, line groups, lines per group, steps, order of L, of U}; zeros = off
             static int32_t sv[6];
             memset(sv, 0, sizeof sv);
-            if (S->slab_ok && g_opt.ildu_strips) slab3_info(S->slab, sv);
+            if (S->slab_ok && S->opt.ildu_strips) slab3_info(S->slab, sv);
             src = sv; sz = sizeof sv;
         }
         else if (nm == "slab_clocks" && S->slab_ok) {
@@ -2441,6 +2556,18 @@ int sgm_pc_get(sgm_pc pc, const char *name, void *out, size_t bytes, size_t *nee
             SGM_TRY(slab3_clocks(S->slab, ck));
             src = ck.data(); sz = ck.size() * 8;
         }
+        else if (nm == "perm") {                 // option ildu_reorder: p (1-based; row i of A = row p(i) of the factorised matrix); empty = natural order
+            static std::vector<int32_t> hp;
+            hp.assign((size_t)(pc->perm ? pc->n : 0), 0);
+            if (pc->perm && pc->n) { SGM_HIP(hipStreamSynchronize(g_rt.stream)); SGM_HIP(hipMemcpy(hp.data(), pc->perm, hp.size() * 4, hipMemcpyDeviceToHost)); }
+            src = hp.data(); sz = hp.size() * 4;
+            if (!sz) src = &kEmpty;
+        }
+        else if (nm == "reorder_ms") {           // last setup with ildu_reorder: {ordering, permuted copy, setup on the copy, colours}
+            static double rm[4];
+            rm[0] = pc->reorder_ms[0]; rm[1] = pc->reorder_ms[1]; rm[2] = pc->reorder_ms[2]; rm[3] = pc->perm ? pc->perm_colors : 0;
+            src = rm; sz = sizeof rm;
+        }
         else if (nm == "pipeline_retired") {     // how often a pipelined sweep gave up and the pipelines were retired (0 = never)
             static int32_t rv[1];
             rv[0] = pc->retired;
@@ -2448,8 +2575,8 @@ int sgm_pc_get(sgm_pc pc, const char *name, void *out, size_t bytes, size_t *nee
         }
         else if (nm == "row_levels") {           // row-space level path in use: {1, launches of the L sweep, of the U sweep}; zeros = off
             static int32_t rl[3];
-            const bool on = !(g_opt.ildu_strips && (S->grid_ok || S->slab_ok)) && rows_serve(S);
-            const bool fu = g_opt.ildu_rows == 1;
+            const bool on = !(S->opt.ildu_strips && (S->grid_ok || S->slab_ok)) && rows_serve(S);
+            const bool fu = S->opt.ildu_rows == 1;
             rl[0] = on;
             rl[1] = on ? (int32_t)S->L.row_levels.size() - (fu && S->rows_n0 > 0 ? 1 : 0) : 0;
             rl[2] = on ? (int32_t)S->U.row_levels.size() - (fu && S->rows_fin ? 1 : 0) : 0;
@@ -2464,7 +2591,7 @@ int sgm_pc_get(sgm_pc pc, const char *name, void *out, size_t bytes, size_t *nee
         }
     }
     const bool known = nm == "strips" || nm == "strip_clocks" || nm == "slabs" || nm == "slab_clocks" || nm == "pipeline_retired" || nm == "idiag" || nm == "Lptr" || nm == "Lnode" || nm == "Lval" || nm == "Uptr" ||
-                       nm == "Unode" || nm == "Uval" || nm == "D" || nm == "levels" || nm == "row_levels";
+                       nm == "Unode" || nm == "Uval" || nm == "D" || nm == "levels" || nm == "row_levels" || nm == "perm" || nm == "reorder_ms";
     if (!known || (!src && sz)) return fail(SGM_ERR_BAD_ARG, "sgm_pc_get: unknown array '%s'", name);
     if (!src) src = &kEmpty;
     if (needed) *needed = sz;
@@ -2481,6 +2608,7 @@ int sgm_pc_destroy(sgm_pc pc)
     for (auto &pp : pc->parts) dfree(pp.idiag);
     for (auto &S : pc->ild) free_ildu(S);
     dfree(pc->abort_sticky);
+    dfree(pc->perm); dfree(pc->rp); dfree(pc->zp);
     delete pc;
     return SGM_OK;
 }

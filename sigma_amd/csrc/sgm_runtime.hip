@@ -85,6 +85,45 @@ int copy_big(void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
     return SGM_OK;
 }
 
+#define SGM_OPT(group, field) if (!strcmp(name, #field)) return &o.field;
+int *mat_option_field(MatOptions &o, const char *name)
+{
+    SGM_OPT(mat, csr_offset_dict) SGM_OPT(mat, ell_offset_dict) SGM_OPT(mat, csr_row_owner) SGM_OPT(mat, csr_row_lines)
+    SGM_OPT(mat, csr_sliced) SGM_OPT(mat, csr_sell) SGM_OPT(mat, csr_lean) SGM_OPT(mat, ell_colblock) SGM_OPT(mat, ell_colblock_cols)
+    SGM_OPT(mat, ell_colblock_rows) SGM_OPT(mat, slice_sched)
+    return nullptr;
+}
+int *solver_option_field(SolverOptions &o, const char *name)
+{
+    SGM_OPT(solver, cg_small) SGM_OPT(solver, bicgstab_small) SGM_OPT(solver, krylov_graph) SGM_OPT(solver, dot_order)
+    SGM_OPT(solver, gmres_cgs2)
+    return nullptr;
+}
+int *pc_option_field(PcOptions &o, const char *name)
+{
+    SGM_OPT(pc, ildu_strips) SGM_OPT(pc, ildu_rows) SGM_OPT(pc, pipeline_spin_limit) SGM_OPT(pc, ildu_reorder)
+    return nullptr;
+}
+#undef SGM_OPT
+
+int normalise_option(const char *name, int value, int *out)
+{
+    int v = value;
+    if (!strcmp(name, "ell_colblock_cols")) v = std::min(kEllcbMaxCols, std::max(2, value)) & ~1;
+    else if (!strcmp(name, "ell_colblock_rows")) v = value == 512 ? 512 : value == 256 ? 256 : 0;
+    else if (!strcmp(name, "ildu_reorder")) v = value != 0;
+    else if (!strcmp(name, "csr_sell")) v = value < 0 ? 0 : value > 2 ? 2 : value;
+    else if (!strcmp(name, "csr_lean")) v = value != 0;
+    else if (!strcmp(name, "slice_sched")) v = value <= 0 ? 0 : value == 1 ? 1 : std::max(4, value);
+    else if (!strcmp(name, "krylov_graph")) v = value <= 0 ? 0 : value == 1 ? 1 : std::max(16, (value + 15) / 16 * 16);
+    else if (!strcmp(name, "cg_small")) v = std::max(0, value);
+    else if (!strcmp(name, "pipeline_spin_limit")) v = std::max(0, value);
+    else if (!strcmp(name, "dot_order") && value != 0 && value != 1)
+        return fail(SGM_ERR_BAD_ARG, "option dot_order is 0 (tree) or 1 (the reference's sequential order)");
+    *out = v;
+    return SGM_OK;
+}
+
 }  // namespace sgm
 
 using namespace sgm;
@@ -115,11 +154,15 @@ int sgm_init(int device)
     g_rt.stream = g_rt.own_stream;
     g_rt.device = device;
     g_rt.ready = true;
-    if (const char *e = getenv("SGM_CSR_SLICED")) g_opt.csr_sliced = atoi(e);      // tuning aid (see sgm_set_option)
-    if (const char *e = getenv("SGM_GMRES_CGS2")) g_opt.gmres_cgs2 = atoi(e);
-    if (const char *e = getenv("SGM_DOT_ORDER")) g_opt.dot_order = atoi(e) == 1 ? 1 : 0;
-    if (const char *e = getenv("SGM_ILDU_STRIPS")) g_opt.ildu_strips = atoi(e);
-    if (const char *e = getenv("SGM_SLICE_SCHED")) sscanf(e, "%d,%d", &g_opt.slice_sched, &g_opt.slice_sched_band);
+    if (const char *e = getenv("SGM_CSR_SLICED")) g_opt.mat.csr_sliced = atoi(e);      // tuning aid (see sgm_set_option)
+    if (const char *e = getenv("SGM_GMRES_CGS2")) g_opt.solver.gmres_cgs2 = atoi(e);
+    if (const char *e = getenv("SGM_DOT_ORDER")) g_opt.solver.dot_order = atoi(e) == 1 ? 1 : 0;
+    if (const char *e = getenv("SGM_ILDU_STRIPS")) g_opt.pc.ildu_strips = atoi(e);
+    if (const char *e = getenv("SGM_SLICE_SCHED")) {          // "<on>,<band>" (tuning aid)
+        int on = 0, band = 64;
+        sscanf(e, "%d,%d", &on, &band);
+        g_opt.mat.slice_sched = on ? (band == 64 ? 1 : std::max(4, band)) : 0;
+    }
     return SGM_OK;
 }
 
@@ -157,38 +200,15 @@ int sgm_synchronize(void)
 int sgm_set_option(const char *name, int value)
 {
     if (!name) return fail(SGM_ERR_BAD_ARG, "sgm_set_option: null name");
-    if (!strcmp(name, "csr_offset_dict")) { g_opt.csr_offset_dict = value; return SGM_OK; }
-    if (!strcmp(name, "csr_row_owner")) { g_opt.csr_row_owner = value; return SGM_OK; }
-    if (!strcmp(name, "csr_sliced")) { g_opt.csr_sliced = value; return SGM_OK; }
-    if (!strcmp(name, "csr_row_lines")) { g_opt.csr_row_lines = value; return SGM_OK; }
-    if (!strcmp(name, "ell_offset_dict")) { g_opt.ell_offset_dict = value; return SGM_OK; }
-    if (!strcmp(name, "ell_colblock")) { g_opt.ell_colblock = value; return SGM_OK; }
-    if (!strcmp(name, "ell_colblock_cols")) { g_opt.ell_colblock_cols = std::min(16384, std::max(2, value)) & ~1; return SGM_OK; }
-    if (!strcmp(name, "ell_colblock_rows")) { g_opt.ell_colblock_rows = value == 512 ? 512 : value == 256 ? 256 : 0; return SGM_OK; }
-    if (!strcmp(name, "ell_colblock_chunks")) { g_opt.ell_colblock_chunks = std::max(1, value); return SGM_OK; }
-    if (!strcmp(name, "ell_colblock_band")) { g_opt.ell_colblock_band = value < 0 ? -1 : value; return SGM_OK; }
-    if (!strcmp(name, "ell_colblock_pieces")) { g_opt.ell_colblock_pieces = std::min(8192, std::max(1, value)); return SGM_OK; }
-    if (!strcmp(name, "ell_colblock_nt")) { g_opt.ell_colblock_nt = value != 0; return SGM_OK; }
-    if (!strcmp(name, "ildu_strips")) { g_opt.ildu_strips = value; return SGM_OK; }
-    if (!strcmp(name, "ildu_rows")) { g_opt.ildu_rows = value; return SGM_OK; }
-    if (!strcmp(name, "cg_small")) { g_opt.cg_small = value; return SGM_OK; }
-    if (!strcmp(name, "cg_small_chunk")) { g_opt.cg_small_chunk = std::max(1, value); return SGM_OK; }
-    if (!strcmp(name, "slice_sched")) { g_opt.slice_sched = value; return SGM_OK; }
-    if (!strcmp(name, "slice_sched_band")) { g_opt.slice_sched_band = std::max(8, value); return SGM_OK; }
-    if (!strcmp(name, "gmres_cgs2")) { g_opt.gmres_cgs2 = value; return SGM_OK; }
-    if (!strcmp(name, "csr_sell")) { g_opt.csr_sell = value < 0 ? 0 : value > 2 ? 2 : value; return SGM_OK; }
-    if (!strcmp(name, "csr_lean")) { g_opt.csr_lean = value != 0; return SGM_OK; }
-    if (!strcmp(name, "krylov_graph")) { g_opt.krylov_graph = value != 0; return SGM_OK; }
-    if (!strcmp(name, "krylov_graph_after")) { g_opt.krylov_graph_after = std::max(16, (value + 15) / 16 * 16); return SGM_OK; }
-    if (!strcmp(name, "dot_order")) {
-        if (value != 0 && value != 1) return fail(SGM_ERR_BAD_ARG, "sgm_set_option: dot_order is 0 (tree) or 1 (the reference's sequential order)");
-        g_opt.dot_order = value;
-        return SGM_OK;
-    }
-    if (!strcmp(name, "dist_force_collectives")) { g_force_collectives = value != 0; return SGM_OK; }
-    if (!strcmp(name, "bicgstab_small")) { g_opt.bicgstab_small = value; return SGM_OK; }
-    if (!strcmp(name, "pipeline_spin_limit")) { g_opt.pipeline_spin_limit = std::max(0, value); return SGM_OK; }
-    return fail(SGM_ERR_BAD_ARG, "sgm_set_option: unknown option '%s'", name);
+    if (!strcmp(name, "dist_force_collectives")) { g_force_collectives = value != 0; return SGM_OK; }      // (process-wide by nature)
+    int v = 0;
+    SGM_TRY(normalise_option(name, value, &v));
+    int *f = mat_option_field(g_opt.mat, name);
+    if (!f) f = solver_option_field(g_opt.solver, name);
+    if (!f) f = pc_option_field(g_opt.pc, name);
+    if (!f) return fail(SGM_ERR_BAD_ARG, "sgm_set_option: unknown option '%s'", name);
+    *f = v;
+    return SGM_OK;
 }
 
 int sgm_heartbeat(int64_t *out6, char *phase_name, int len)

@@ -947,6 +947,14 @@ struct sgm_solver_s {
     std::vector<PartWork> work;
     std::vector<double> history;
     bool multi = false;
+    // cooperative CG (k_cg_coop): exchange vector + dot slots + {counter, abort}; the counter is monotonic across launches
+    double *coop_buf = nullptr;
+    int coop_base = 0, coop_reach = -1;
+    int64_t coop_iters0 = 0;
+    bool coop_retired = false;
+    SolverOptions opt = g_opt.solver;   // this solver's options: the defaults at its creation, then sgm_solver_set_option
+    int64_t small_chunk() const { return opt.cg_small > 1 ? opt.cg_small : 50000; }          // iterations per launch of the one-workgroup kernels
+    int64_t graph_after() const { return opt.krylov_graph > 1 ? opt.krylov_graph : 64; }     // iterations before the group is captured
 };
 
 namespace {
@@ -963,6 +971,9 @@ void free_work(sgm_solver s)
     s->work.clear();
     dfree(s->x_backup);
     s->x_backup = nullptr;
+    dfree(s->coop_buf);
+    s->coop_buf = nullptr;
+    s->coop_reach = -1;
 }
 
 // ScalarRef of partial array k on part ip
@@ -1090,7 +1101,7 @@ struct GraphBatch {
 bool graph_applies(sgm_solver s, sgm_mat A, sgm_pc pc)
 {
     const int pk = pc ? pc_kind(pc) : 0;
-    return g_opt.krylov_graph && !s->multi && s->work.size() == 1 && !A->comm && A->fmt != SGM_FMT_COMPOSITE &&
+    return s->opt.krylov_graph && !s->multi && s->work.size() == 1 && !A->comm && A->fmt != SGM_FMT_COMPOSITE &&
            (pk == 0 || pk == SGM_PC_JACOBI) && !prof_on();
 }
 
@@ -1343,11 +1354,11 @@ constexpr int kBiSmallMax = 4096;           // BiCGStab: seven vectors in regist
 // 0.0 * x(last neighbour) terms are added like the reference's ellpack_matvec_add does)
 static bool cg_small_sliced(const Part &p)
 {
-    return p.scode && p.sval && p.dict && g_opt.csr_sliced && (p.ecol ? g_opt.ell_offset_dict : g_opt.csr_offset_dict) && p.sw <= 8;
+    return p.scode && p.sval && p.dict && p.opt.csr_sliced && (p.ecol ? p.opt.ell_offset_dict : p.opt.csr_offset_dict) && p.sw <= 8;
 }
 static bool small_applies(sgm_solver s, sgm_mat A, sgm_pc pc, bool bicg)
 {
-    if (!(bicg ? g_opt.bicgstab_small : g_opt.cg_small) || s->multi || A->parts.size() != 1 ||
+    if (!(bicg ? s->opt.bicgstab_small : s->opt.cg_small) || s->multi || A->parts.size() != 1 ||
         (A->fmt != SGM_FMT_CSR && A->fmt != SGM_FMT_ELL))
         return false;
     const Part &p = A->parts[0];
@@ -1389,7 +1400,7 @@ static int run_cg_small(sgm_solver s, sgm_mat A, double *x, const double *b, sgm
     const size_t lds = ((s->seq ? 2 : 1) * npad + 16) * sizeof(double);
     // the reference's loop has no iteration cap; a launch has one (kCgSmallChunk iterations), after which the solve
     // continues in the next launch from r, p and res2 parked in the solver's work vectors -- the host stays in control
-    const int64_t kCgSmallChunk = std::max(1, g_opt.cg_small_chunk);
+    const int64_t kCgSmallChunk = s->small_chunk();
     int flag = 0; int64_t iters = 0; double res = 0.0;
     *ran = true;
     for (int resume = 0;; resume = 1) {
@@ -1422,12 +1433,386 @@ static int run_cg_small(sgm_solver s, sgm_mat A, double *x, const double *b, sgm
     return SGM_OK;
 }
 
+// ---- CG on a mid-sized system: the whole solve in ONE launch of up to 256 co-resident workgroups ------------------------
+// Between k_cg_small's reach (one workgroup, <= 10240 rows) and n ~ 1e6 (256 workgroups x 4096 rows) an iteration of the launch loop is three dependent
+// kernels of ~4.4 us each, whatever the traffic (n = 1e5: 13.3 us for 1.4 us of bytes; n = 1e6: 36 us for 15).  Here the
+// k_cg_small scheme is spread over G workgroups, one per CU: workgroup b owns RMAX * 1024 consecutive rows -- x and r in the
+// registers of the row's thread, its part of p plus a halo of `H` rows either side in LDS, the matrix re-read from its sliced
+// form every iteration (L2 / Infinity Cache hits at these sizes) -- and an iteration needs TWO grid-wide hand-offs:
+//   (1) q = A p on the own rows, partial p.q -> slot[b]                     | arrive / wait | every workgroup adds the G partials
+//   (2) r -= alpha q, z = M^-1 r, partial r.z -> slot[G + b]; the z of its     | arrive / wait | in the same order: same bits
+//       first and last H rows -> a global vector                              |               | everywhere, no broadcast
+//   (3) x += alpha p, p = z + beta p on the own rows AND on the halo (the neighbours' z from the global vector: the p halo
+//       is kept up to date locally, no third hand-off)
+// Hand-offs follow the guide's counter recipe (cdna_hip_programming.md section 6, Guideline 16): published doubles leave as sc1
+// (agent-scope, write-through) stores, every wave drains its stores, the workgroup joins, lane 0 adds to ONE monotonic
+// counter; waiters poll it with relaxed sc1 loads and read the published data with sc1 loads only.  Every wait is bounded:
+// a workgroup that gives up raises `abort` -- nothing has been written to x, r, p by then -- and the host runs the launch
+// loop instead (grids of <= 256 single-workgroup-per-CU blocks are co-resident on an otherwise idle GPU, but nothing
+// promises it).  Same statements and operands as the launch loop / cg_solve (cg_solvers.f90:129-145); only the dot
+// products' summation order differs (per-workgroup block sums, then the G partials in index order).
+__device__ inline void st_sc1(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline double ld_sc1(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// One grid-wide hand-off = one all-reduced scalar.  No counter and no atomic: workgroup b publishes its partial sum in
+// slot[h % 4][b] (an sc1 store, after every wave has drained the sc1 stores of whatever else it publishes with this hand-off);
+// thread t < G of EVERY workgroup polls slot[h % 4][t] with sc1 loads until it no longer holds the "not yet written"
+// pattern (a NaN with a payload no arithmetic produces), and the block sum of the G values -- same order everywhere -- is the
+// scalar.  A slot set is re-armed two hand-offs ahead of its reuse by its owners (slot[(h + 2) % 4][b] when b has passed
+// h): every reader of that set's previous use arrived at hand-off h - 1 before anyone could pass it.  Bounded: a poll that
+// gives up raises `abort`, and every poll loop looks at it.
+constexpr unsigned long long kCoopPoison = 0x7ff8c0de5a5a0001ull;
+__device__ inline bool coop_handoff(double *slots /* 4 x 256 */, int h, double mine, int G, int *abort, int spin_limit, double *red, int *lds_ok,
+                                    double *sum_out)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's sc1 stores (boundary rows) have left
+    __syncthreads();
+    const int tid = threadIdx.x;
+    double *set = slots + (h & 3) * 256;
+    if (tid == 0) {
+        *lds_ok = 1;
+        st_sc1(set + blockIdx.x, mine);
+    }
+    double v = 0.0;
+    int ok = 1;
+    if (tid < G) {
+        int spins = 0;
+        for (;;) {
+            v = ld_sc1(set + tid);
+            if (__double_as_longlong(v) != (long long)kCoopPoison) break;
+            if (++spins > spin_limit || ((spins & 31) == 0 && __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0; v = 0.0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();                                         // (lds_ok = 1 is visible before anyone clears it)
+    if (!ok) *lds_ok = 0;
+    const double ssum = block_sum<1024>(v, red);             // (its barriers publish lds_ok)
+    if (tid == 0) st_sc1(slots + ((h + 2) & 3) * 256 + blockIdx.x, __longlong_as_double((long long)kCoopPoison));
+    *sum_out = ssum;
+    return *lds_ok != 0;
+}
+
+// SW > 0: the own rows' matrix entries (SW slots each) are loaded ONCE and live in registers for the whole launch (RMAX * SW
+// doubles per thread; what an iteration then reads from memory is the hand-offs); SW = 0: streamed every iteration.
+template <int RMAX, bool JAC, int SW>
+__global__ __launch_bounds__(1024) void k_cg_coop(
+    int32_t n, int32_t sw, int32_t H, const uint32_t *__restrict__ scode, const int32_t *__restrict__ dict, const double *__restrict__ sval,
+    double *x, const double *b, const double *__restrict__ idiag, double tol, int64_t it_end, int resume,
+    double *__restrict__ wr, double *__restrict__ wp, double *gz /* n: the exchanged z rows */, double *slots /* 4 x 256 */,
+    int *abort, int h0 /* number of the first hand-off of this launch */, int spin_limit,
+    int *flag, int64_t *iters, double *res_out, double *history, int64_t hist_cap)
+{
+    constexpr int BLOCK = 1024, RPW = RMAX * BLOCK;
+    extern __shared__ double lds[];
+    double *pl = lds;                                   // p of rows r0 - H .. r0 + RPW + H - 1
+    double *red = pl + RPW + 2 * H;                      // 16 doubles of block-sum scratch
+    int *lds_ok = reinterpret_cast<int *>(red + 16);
+    __shared__ int32_t dl[16];
+    const int tid = threadIdx.x, G = gridDim.x, wg = blockIdx.x;
+    const int32_t r0 = wg * RPW, r1 = min(n, r0 + RPW);
+    if (tid < 16) dl[tid] = dict[tid];
+    int h = h0;
+    // all-reduce of one partial sum per workgroup (+ whatever this workgroup published with sc1 stores before the call)
+    auto handoff = [&](double mine, double &total) { const bool ok_ = coop_handoff(slots, h, mine, G, abort, spin_limit, red, lds_ok, &total); ++h; return ok_; };
+    auto own_dot = [&](const double (&prod)[RMAX]) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) sacc += prod[u];
+        return block_sum<BLOCK>(sacc, red);
+    };
+    // the halo of a vector that lives in global memory (published with sc1 stores by its owners) into pl
+    uint32_t cwr[RMAX];
+    double mv[RMAX][SW > 0 ? SW : 1];
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+        const int32_t i = r0 + tid + u * BLOCK;
+        cwr[u] = i < r1 ? scode[i] : 0xffffffffu;
+        if (SW > 0) {
+#pragma unroll
+            for (int e = 0; e < SW; ++e)
+                mv[u][e] = ((cwr[u] >> (4 * e)) & 15u) != 15u ? sval[((int64_t)(i >> 9) * sw + e) * 512 + (i & 511)] : 0.0;
+        }
+    }
+    auto row_sums = [&](double (&q)[RMAX]) {
+        if (SW > 0) {
+#pragma unroll
+            for (int u = 0; u < RMAX; ++u) {
+                double z = 0.0;
+#pragma unroll
+                for (int e = 0; e < SW; ++e) {
+                    const uint32_t cd = (cwr[u] >> (4 * e)) & 15u;
+                    if (cd != 15u) z = z + mv[u][e] * pl[H + tid + u * BLOCK + dl[cd]];
+                }
+                q[u] = 0.0 + z;
+            }
+            return;
+        }
+        uint32_t cw[RMAX];
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            q[u] = 0.0;
+            cw[u] = cwr[u];
+        }
+        for (int32_t e = 0; e < sw; ++e) {
+            double v[RMAX];
+#pragma unroll
+            for (int u = 0; u < RMAX; ++u) {
+                const int32_t i = r0 + tid + u * BLOCK;
+                if (((cw[u] >> (4 * e)) & 15u) != 15u) v[u] = sval[((int64_t)(i >> 9) * sw + e) * 512 + (i & 511)];
+            }
+#pragma unroll
+            for (int u = 0; u < RMAX; ++u) {
+                const uint32_t cd = (cw[u] >> (4 * e)) & 15u;
+                if (cd != 15u) q[u] = q[u] + v[u] * pl[H + tid + u * BLOCK + dl[cd]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) q[u] = 0.0 + q[u];
+    };
+    // publish the first / last H own rows of z; (after the hand-off) halo rows of pl <- f(neighbour's z, old halo p)
+    auto publish = [&](const double (&zr)[RMAX]) {
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t li = tid + u * BLOCK, i = r0 + li;
+            if (i < r1 && (li < H || i >= r1 - H)) st_sc1(gz + i, zr[u]);
+        }
+    };
+    double xr[RMAX], rr[RMAX], prod[RMAX];
+    // ---- start: p = x in LDS (own rows + halo) for r = b - A x
+    for (int32_t li = tid; li < RPW + 2 * H; li += BLOCK) {
+        const int32_t i = r0 - H + li;
+        pl[li] = (i >= 0 && i < n) ? (resume ? wp[i] : x[i]) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+        const int32_t i = r0 + tid + u * BLOCK;
+        xr[u] = i < r1 ? x[i] : 0.0;
+        rr[u] = 0.0;
+    }
+    __syncthreads();
+    double res2;
+    int64_t it = 0;
+    bool ok = true;
+    if (!resume) {
+        double zr[RMAX];
+        row_sums(zr);
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = r0 + tid + u * BLOCK;
+            const double q = zr[u];
+            zr[u] = 0.0; prod[u] = 0.0;
+            if (i < r1) {
+                rr[u] = b[i] - q;
+                zr[u] = JAC ? idiag[i] * rr[u] : rr[u];
+                prod[u] = rr[u] * zr[u];
+            }
+        }
+        const double mine = own_dot(prod);                 // (its barriers: every row sum has read x out of LDS)
+        publish(zr);
+        ok = handoff(mine, res2);
+        if (ok) {
+            // p = z: own rows from registers, halo rows from the neighbours' published z
+#pragma unroll
+            for (int u = 0; u < RMAX; ++u) pl[H + tid + u * BLOCK] = zr[u];
+            for (int32_t li = tid; li < 2 * H; li += BLOCK) {
+                const int32_t l2 = li < H ? li : RPW + li, i = r0 - H + l2;        // left halo, then right halo
+                pl[l2] = (i >= 0 && i < n && (i < r0 || i >= r1)) ? ld_sc1(gz + i) : 0.0;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = r0 + tid + u * BLOCK;
+            if (i < r1) rr[u] = wr[i];
+        }
+        res2 = *res_out;
+        it = *iters;
+    }
+    __syncthreads();
+    bool conv = ok && !(sqrt(res2) > tol);
+    while (ok && !conv && it < it_end) {
+        double qv[RMAX], zr[RMAX];
+        row_sums(qv);
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = r0 + tid + u * BLOCK;
+            prod[u] = i < r1 ? pl[H + tid + u * BLOCK] * qv[u] : 0.0;
+        }
+        double mine = own_dot(prod), dpr, dnew;
+        ok = handoff(mine, dpr);                            // ---- hand-off 1: p.q
+        if (!ok) break;
+        const double alpha = res2 / dpr;
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = r0 + tid + u * BLOCK;
+            prod[u] = 0.0; zr[u] = 0.0;
+            if (i < r1) {
+                rr[u] = rr[u] - alpha * qv[u];
+                zr[u] = JAC ? idiag[i] * rr[u] : rr[u];
+                prod[u] = rr[u] * zr[u];
+            }
+        }
+        mine = own_dot(prod);
+        publish(zr);
+        ok = handoff(mine, dnew);                           // ---- hand-off 2: r.z and the boundary rows of z
+        if (!ok) break;
+        const double beta = dnew / res2;
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = r0 + tid + u * BLOCK;
+            if (i < r1) {
+                const double pv = pl[H + tid + u * BLOCK];
+                xr[u] = xr[u] + alpha * pv;
+                pl[H + tid + u * BLOCK] = zr[u] + beta * pv;
+            }
+        }
+        for (int32_t li = tid; li < 2 * H; li += BLOCK) {
+            const int32_t l2 = li < H ? li : RPW + li, i = r0 - H + l2;
+            if (i >= 0 && i < n && (i < r0 || i >= r1)) pl[l2] = ld_sc1(gz + i) + beta * pl[l2];
+        }
+        __syncthreads();
+        if (wg == 0 && tid == 0 && history && it < hist_cap) history[it] = dnew;
+        ++it;
+        res2 = dnew;
+        conv = !(sqrt(res2) > tol);
+    }
+    if (!ok) return;                                        // (nothing of x, r, p has been written: the host takes the launch loop)
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+        const int32_t i = r0 + tid + u * BLOCK;
+        if (i < r1) {
+            x[i] = xr[u];
+            if (!conv) { wr[i] = rr[u]; wp[i] = pl[H + tid + u * BLOCK]; }
+        }
+    }
+    if (wg == 0 && tid == 0) { *iters = it; *res_out = res2; *flag = conv ? 1 : 0; }
+}
+
+constexpr int kCoopSpinLimit = 1 << 19;       // polls (about a microsecond each) before a hand-off gives up
+// sliced stencil matrix on one GPU, plain or Jacobi, tree-order dots, beyond the one-workgroup kernel and up to 256 workgroups
+static bool coop_applies(sgm_solver s, sgm_mat A, sgm_pc pc, int *rmax_out, int *halo_out)
+{
+    static const bool off = getenv("SGM_CG_COOP") && atoi(getenv("SGM_CG_COOP")) == 0;
+    if (off || !s->opt.cg_small || s->multi || s->seq || A->parts.size() != 1 || A->comm || A->fmt != SGM_FMT_CSR || prof_on()) return false;
+    const Part &p = A->parts[0];
+    if (p.n_halo != 0 || !cg_small_sliced(p) || p.n < 2048 || p.ndict < 1 || p.ndict > 15) return false;        // (k_cg_small had its turn already)
+    const int pk = pc ? pc_kind(pc) : 0;
+    if (pk != 0 && pk != SGM_PC_JACOBI) return false;
+    if (s->coop_reach < 0) {                                   // the stencil's reach in rows: the largest |offset| of the dictionary
+        int32_t hd[16] = {0};
+        if (hipMemcpy(hd, p.dict, sizeof hd, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return false; }
+        int32_t reach = 0;
+        for (int k = 0; k < p.ndict; ++k) reach = std::max(reach, std::abs(hd[k]));
+        s->coop_reach = reach;
+    }
+    const int H = (s->coop_reach + 1) & ~1;
+    static const int force_rmax = getenv("SGM_CG_COOP_RMAX") ? atoi(getenv("SGM_CG_COOP_RMAX")) : 0;
+    for (int rmax : {1, 2, 4}) {
+        if (force_rmax && rmax != force_rmax) continue;
+        const int64_t rpw = (int64_t)rmax * 1024, G = (p.n + rpw - 1) / rpw;
+        // one workgroup per CU (co-residency), neighbours only (H <= rows per workgroup), LDS: p + halo + scratch <= 160 KiB
+        if (G > std::min(256, g_rt.num_cu) || H > rpw || (rpw + 2 * H + 32) * 8 > 160 * 1024) continue;
+        *rmax_out = rmax; *halo_out = H;
+        return true;
+    }
+    return false;
+}
+
+// *ran = false: the kernel could not be launched here, or a hand-off gave up -- the caller runs the launch loop from the caller's x
+static int run_cg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc pc, int rmax, int H, bool *ran)
+{
+    const Part &p = A->parts[0];
+    PartWork &w = s->work[0];
+    const bool jac = pc && pc_kind(pc) == SGM_PC_JACOBI;
+    const int64_t rpw = (int64_t)rmax * 1024;
+    const int G = (int)((p.n + rpw - 1) / rpw);
+    const size_t lds = (size_t)(rpw + 2 * H + 32) * sizeof(double);
+    *ran = false;
+    auto arm = [&]() -> int {                                  // every slot "not yet written", abort word clear, hand-offs from 0
+        std::vector<unsigned long long> pat(4 * 256, kCoopPoison);
+        SGM_HIP(hipMemcpyAsync(s->coop_buf + p.n, pat.data(), pat.size() * 8, hipMemcpyHostToDevice, g_rt.stream));
+        SGM_HIP(hipMemsetAsync(s->coop_buf + p.n + 4 * 256, 0, 64, g_rt.stream));
+        SGM_HIP(hipStreamSynchronize(g_rt.stream));
+        s->coop_base = 0;
+        return SGM_OK;
+    };
+    if (!s->coop_buf) {
+        if (dalloc(&s->coop_buf, (size_t)p.n + 4 * 256 + 64) != SGM_OK) return SGM_OK;
+        SGM_TRY(arm());
+    }
+    double *gz = s->coop_buf, *slots = gz + p.n;
+    int *abortw = reinterpret_cast<int *>(slots + 4 * 256);
+    int flag = 0; int64_t iters = 0; double res = 0.0;
+    for (int resume = 0;; resume = 1) {
+        int64_t it_end = iters + s->small_chunk();
+        if (s->max_iter > 0) it_end = std::min<int64_t>(it_end, s->max_iter);
+        static const int spin_env = getenv("SGM_CG_COOP_SPIN") ? atoi(getenv("SGM_CG_COOP_SPIN")) : 0;
+        const int spin = spin_env > 0 ? spin_env : kCoopSpinLimit;
+#define LC(R, J, W)                                                                                                    \
+    do {                                                                                                             \
+        if (!allow_lds((const void *)k_cg_coop<R, J, W>, lds)) return SGM_OK;                                         \
+        hipLaunchKernelGGL((k_cg_coop<R, J, W>), dim3(G), dim3(1024), lds, g_rt.stream, p.n, p.sw, H, (const uint32_t *)p.scode, \
+                           (const int32_t *)p.dict, (const double *)p.sval, x, b, jac ? pc_idiag(pc, 0) : nullptr,   \
+                           s->tolerance, it_end, resume, w.vec[V_R], w.vec[V_P], gz, slots, abortw, s->coop_base & 3, spin, \
+                           w.flag, w.iters, w.res, w.history, s->hist_cap);                                           \
+    } while (0)
+#define LCJ(R, W) do { if (jac) LC(R, true, W); else LC(R, false, W); } while (0)
+        // the matrix in registers where RMAX * sw doubles fit beside x, r and the temporaries (<= 20 per thread)
+#define LCW(R) do { if (p.sw == 3) LCJ(R, 3); else if (p.sw == 5) LCJ(R, 5); else if (p.sw == 7) LCJ(R, 7); else LCJ(R, 8); } while (0)
+        static const bool stream_env = getenv("SGM_CG_COOP_STREAM") != nullptr;          // tuning aid: never keep the matrix in registers
+        // (RMAX = 4 with the matrix in registers spills 14-76 VGPRs, RMAX = 10 streamed 99-157: not instantiated)
+        if (rmax == 1 && !stream_env) LCW(1);
+        else if (rmax == 2 && !stream_env) LCW(2);
+        else if (rmax == 1) LCJ(1, 0);
+        else if (rmax == 2) LCJ(2, 0);
+        else LCJ(4, 0);
+#undef LCW
+#undef LCJ
+#undef LC
+        SGM_HIP(hipGetLastError());
+        int habort = 0;
+        SGM_HIP(hipMemcpyAsync(&habort, abortw, sizeof(int), hipMemcpyDeviceToHost, g_rt.stream));
+        SGM_TRY(read_state(s, &flag, &iters, &res));
+        if (habort) {
+            // a hand-off gave up (the grid was not co-resident, or the GPU is shared): x, r, p are untouched by this launch --
+            // but a resumed solve has moved x already: restart is only exact from the caller's x, which launch 1 left alone
+            fprintf(stderr, "[sigma_hip] cooperative CG gave up waiting for a workgroup (grid not co-resident / shared GPU?): "
+                            "this solver takes the launch loop from now on\n");
+            SGM_TRY(arm());
+            s->coop_retired = true;
+            if (resume) return fail(SGM_ERR_HIP, "cooperative CG aborted in a continued launch");
+            return SGM_OK;
+        }
+        // hand-offs this launch made: 2 per iteration (+ 1 at the start of a fresh solve); only their count mod 4 matters
+        s->coop_base = (int)((s->coop_base + 2 * (iters - (resume ? s->coop_iters0 : 0)) + (resume ? 0 : 1)) & 3);
+        s->coop_iters0 = iters;
+        if (flag || (s->max_iter > 0 && iters >= s->max_iter)) break;
+    }
+    *ran = true;
+    s->last_iterations = iters;
+    s->res2 = res;
+    s->converged = flag;
+    return SGM_OK;
+}
+
 int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sgm_pc pc)
 {
     if (small_applies(s, A, pc, false)) {
         bool ran = false;
         SGM_TRY(run_cg_small(s, A, x[0], b[0], pc, &ran));
         if (ran) return SGM_OK;
+    }
+    {
+        int rmax = 0, H = 0;
+        if (!s->coop_retired && coop_applies(s, A, pc, &rmax, &H)) {
+            bool ran = false;
+            SGM_TRY(run_cg_coop(s, A, x[0], b[0], pc, rmax, H, &ran));
+            if (ran) return SGM_OK;
+        }
     }
     const size_t P = s->work.size();
     const int pk = pc ? pc_kind(pc) : 0;
@@ -1529,9 +1914,9 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
         int64_t batch = batch_max > 1 ? std::min<int64_t>(128, std::max<int64_t>(batch_max, k / 8)) : batch_max;
         if (graphs && batch > kGraphIters) batch -= batch % kGraphIters;     // k stays on the replay grid whatever krylov_graph_after is
         if (s->max_iter > 0) batch = std::min<int64_t>(batch, s->max_iter - k);
-        // a solve that has run g_opt.krylov_graph_after iterations goes on as replays of one captured group of kGraphIters (k is
+        // a solve that has run graph_after() iterations goes on as replays of one captured group of kGraphIters (k is
         // a multiple of it here: the parity of the r.r slots repeats)
-        if (graphs && k >= g_opt.krylov_graph_after && k % kGraphIters == 0 && batch >= kGraphIters &&
+        if (graphs && k >= s->graph_after() && k % kGraphIters == 0 && batch >= kGraphIters &&
             gb.ensure([&]() { return enqueue_group(k, kGraphIters); })) {
             const int64_t groups = batch / kGraphIters;
             for (int64_t g = 0; g < groups; ++g) SGM_HIP(hipGraphLaunch(gb.exec, g_rt.stream));
@@ -1696,7 +2081,7 @@ static int run_bicgstab_small(sgm_solver s, sgm_mat A, double *x, const double *
     const bool sliced = cg_small_sliced(p);
     const size_t npad = (size_t)((p.n + 1) & ~1);
     const size_t lds = ((s->seq ? 3 : 1) * npad + 16) * sizeof(double);
-    const int64_t chunk = std::max(1, g_opt.cg_small_chunk);
+    const int64_t chunk = s->small_chunk();
     int flag = 0; int64_t iters = 0; double res = 0.0;
     *ran = true;
     for (int resume = 0;; resume = 1) {
@@ -1857,7 +2242,7 @@ int run_bicgstab(sgm_solver s, sgm_mat A, double *const *x, const double *const 
         if (s->max_iter > 0) batch = std::min<int64_t>(batch, s->max_iter - k);
         // (replays of one captured group of kGraphIters iterations once the solve has run long enough: see GraphBatch; the
         //  kernels stop on any nonzero flag, so a group needs no generations)
-        if (graphs && k >= g_opt.krylov_graph_after && k % kGraphIters == 0 && batch >= kGraphIters &&
+        if (graphs && k >= s->graph_after() && k % kGraphIters == 0 && batch >= kGraphIters &&
             gb.ensure([&]() { for (int j = 0; j < kGraphIters; ++j) SGM_TRY(enqueue_iter(k + j)); return (int)SGM_OK; })) {
             const int64_t groups = batch / kGraphIters;
             for (int64_t g = 0; g < groups; ++g) SGM_HIP(hipGraphLaunch(gb.exec, g_rt.stream));
@@ -1895,7 +2280,7 @@ int run_gmres(sgm_solver s, sgm_mat A, double *const *x, const double *const *b,
     for (size_t ip = 0; ip < P; ++ip) v.flags[ip] = s->work[ip].flag;
     // Gram-Schmidt variant: CGS-2 (blocked, 3 passes per step) unless the option is off or the restart
     // length exceeds its 32-vector kernels; modified Gram-Schmidt (j+2 fused passes) otherwise
-    const bool cgs2 = g_opt.gmres_cgs2 && m <= 32;
+    const bool cgs2 = s->opt.gmres_cgs2 && m <= 32;
     // partial array ids.  MGS: 0..m = h column (h_0..h_j, norm at j+1), NRM = m+1 the start norm.
     // CGS-2: 0..m-1 = h1, H2.. = h2, NRM = norm (start norm and step norm)
     const int H2 = m + 1, NRM = cgs2 ? 2 * m + 2 : m + 1;
@@ -2108,6 +2493,19 @@ int sgm_solver_set_max_iter(sgm_solver s, int64_t max_iter)
     return SGM_OK;
 }
 
+/* sgm_solver_set_option: this solver's own copy of "cg_small", "bicgstab_small", "krylov_graph", "dot_order", "gmres_cgs2"
+ * (sgm_set_option only changes what solvers created LATER start with); read at the next solve. */
+int sgm_solver_set_option(sgm_solver s, const char *name, int value)
+{
+    if (!s || !name) return fail(SGM_ERR_BAD_ARG, "sgm_solver_set_option: null argument");
+    int v = 0;
+    SGM_TRY(normalise_option(name, value, &v));
+    int *f = solver_option_field(s->opt, name);
+    if (!f) return fail(SGM_ERR_BAD_ARG, "sgm_solver_set_option: '%s' is not a solver option", name);
+    *f = v;
+    return SGM_OK;
+}
+
 int sgm_solver_set_history(sgm_solver s, int64_t capacity)
 {
     if (!s) return fail(SGM_ERR_BAD_ARG, "null solver");
@@ -2147,7 +2545,7 @@ int sgm_solver_solve(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc
     }
     // dot_order = 1: CG / BiCGStab add their dot products in the reference's order (GMRES has no reference counterpart
     // and keeps the tree order)
-    s->seq = g_opt.dot_order == 1 && s->kind != SGM_SOLVER_GMRES;
+    s->seq = s->opt.dot_order == 1 && s->kind != SGM_SOLVER_GMRES;
     // A pipelined ILDU sweep has bounded waits; one that gives up leaves NaN patterns behind and raises the preconditioner's
     // sticky word.  It is read with every look at the stop flag (read_state); if it was raised the iterates are spoiled:
     // the pipelines are retired, the initial guess restored and the solve run again with the level-scheduled sweeps --

@@ -1177,11 +1177,11 @@ int64_t ell_colblock_matvec_bytes(const Part &p);
 // k_csr_do exists for 256- and 512-thread workgroups only; with any other SGM_SPMV_CFG block size the
 // matrices it would serve take the streaming kernel (which has the 1024-thread variants) instead
 static bool do_block_ok() { const int b = spmv_cfg().block; return b == 256 || b == 512; }
-static bool use_offset_dict(const Part &p) { return (p.code || (p.lean && p.dict)) && g_opt.csr_offset_dict && do_block_ok(); }
-static bool use_sliced(const Part &p) { return p.scode && g_opt.csr_sliced && g_opt.csr_offset_dict; }
-static bool use_sliced32(const Part &p) { return p.scol && g_opt.csr_sliced && !p.ecol; }
-static bool use_slicedb(const Part &p) { return p.sbcode && g_opt.csr_sliced && g_opt.csr_offset_dict; }
-static bool use_sell(const Part &p) { return p.sl_val && g_opt.csr_sliced && g_opt.csr_sell && !p.ecol; }
+static bool use_offset_dict(const Part &p) { return (p.code || (p.lean && p.dict)) && p.opt.csr_offset_dict && do_block_ok(); }
+static bool use_sliced(const Part &p) { return p.scode && p.opt.csr_sliced && p.opt.csr_offset_dict; }
+static bool use_sliced32(const Part &p) { return p.scol && p.opt.csr_sliced && !p.ecol; }
+static bool use_slicedb(const Part &p) { return p.sbcode && p.opt.csr_sliced && p.opt.csr_offset_dict; }
+static bool use_sell(const Part &p) { return p.sl_val && p.opt.csr_sliced && p.opt.csr_sell && !p.ecol; }
 static bool lean_sell(const Part &p);      // (the SELL form is the part's only resident layout: see csr_lean below)
 static bool any_sliced(const Part &p) { return use_sliced(p) || use_sliced32(p) || use_slicedb(p) || use_sell(p); }
 // k_csr_do serves both the dictionary form and, for short rows, plain int32 columns
@@ -1189,7 +1189,7 @@ static bool use_row_owner(const Part &p)
 {
     // (rows of 33..64 entries, banded: 809-822 us against 906 with k_csr_rl and 1100-1150 with k_csr_spmv; beyond 64 the
     // few lanes that own a tile's rows walk too long: 64..128 entries 1160 us against 890 with k_csr_rl)
-    return use_offset_dict(p) || (do_block_ok() && g_opt.csr_row_owner && p.max_row > 0 && p.max_row <= 64);
+    return use_offset_dict(p) || (do_block_ok() && p.opt.csr_row_owner && p.max_row > 0 && p.max_row <= 64);
 }
 
 // long rows without a dictionary: the line-staged row-owner kernel (k_csr_rl).  A block takes as many passes as its
@@ -1202,7 +1202,7 @@ static bool use_row_lines(const Part &p)
     // ... and rows of SIMILAR length, at least a line long on average: every row of a block waits for the block's longest one
     // (the 5-point matrix forced through it: 491 us against 153 with k_csr_spmv), so a few long rows among short ones
     // (max > 4 x mean) also stay with the streaming kernel
-    return g_opt.csr_row_lines && !any_sliced(p) && !use_row_owner(p) && p.n > 0 && p.max_row <= 4096 &&
+    return p.opt.csr_row_lines && !any_sliced(p) && !use_row_owner(p) && p.n > 0 && p.max_row <= 4096 &&
            p.nnz >= 16 * (int64_t)p.n && (int64_t)p.max_row * p.n <= 4 * p.nnz;
 }
 static int row_lines_resident_per_cu()
@@ -1481,7 +1481,7 @@ static EllCfg &ell_cfg()
     }
     return c;
 }
-static bool use_sliced_ell(const Part &p) { return p.ecol && p.scode && g_opt.csr_sliced && g_opt.ell_offset_dict; }
+static bool use_sliced_ell(const Part &p) { return p.ecol && p.scode && p.opt.csr_sliced && p.opt.ell_offset_dict; }
 int ell_grid(const Part &p)
 {
     if (use_ell_colblock(p)) return ell_colblock_grid(p);
@@ -1493,7 +1493,7 @@ int ell_grid(const Part &p)
     int64_t cap = ell_cfg().grid;
     // k_ell_do<16> holds 16 values + 16 x entries per lane: 77-88 VGPRs, 5 waves/SIMD with the fused
     // dots -- a grid-stride launch sized for 8 resident workgroups per CU would run a second round
-    if (p.ecode && g_opt.ell_offset_dict && p.emdp == 16) cap = std::min<int64_t>(cap, (int64_t)5 * g_rt.num_cu);
+    if (p.ecode && p.opt.ell_offset_dict && p.emdp == 16) cap = std::min<int64_t>(cap, (int64_t)5 * g_rt.num_cu);
     return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
 }
 
@@ -1514,7 +1514,7 @@ static void launch_ell(const Part &p, int grid, const double *x, double *y, cons
     }
     hipStream_t st = g_rt.stream;
     const EllCfg &c = ell_cfg();
-    if (p.ecode && g_opt.ell_offset_dict) {
+    if (p.ecode && p.opt.ell_offset_dict) {
 #define LD(M, DW, DY)                                                                                   \
     hipLaunchKernelGGL((k_ell_do<M, ADD, DW, DY>), dim3(grid), dim3(kBlock), 0, st, p.n, p.max_d, p.ecode, \
                        p.dict, p.eval, x, y, w, pwy, pyy, flag, gen, g_launch_flags & 256)
@@ -1632,20 +1632,21 @@ extern "C" int sgm_slice_sched_host(int64_t n_slices, int64_t period_rows, int32
 // too few slices for it to matter
 static const SliceSched *slice_sched(const Part &p, int32_t lo, int32_t hi, int grid)
 {
-    if (!g_opt.slice_sched || p.sched_period < 32 * kSlRows || grid < 8 || grid % 8) return nullptr;
+    if (!p.opt.slice_sched || p.sched_period < 32 * kSlRows || grid < 8 || grid % 8) return nullptr;
+    const int band = p.opt.slice_sched == 1 ? 64 : p.opt.slice_sched;
     const int64_t nsl = ((int64_t)hi - lo + kSlRows - 1) / kSlRows;
     if (nsl < 2 * (int64_t)grid || 2 * (int64_t)p.sched_period > (int64_t)hi - lo) return nullptr;
-    // (a schedule built for another band width is stale: "slice_sched_band" may change between products)
+    // (a schedule built for another band width is stale: the option may change between products)
     for (int i = 0; i < p.nsched; ++i)
-        if (p.sched[i].band != g_opt.slice_sched_band) { free_slice_sched(const_cast<Part &>(p)); break; }
+        if (p.sched[i].band != band) { free_slice_sched(const_cast<Part &>(p)); break; }
     for (int i = 0; i < p.nsched; ++i)
         if (p.sched[i].lo == lo && p.sched[i].hi == hi && p.sched[i].grid == grid) return p.sched[i].tab ? &p.sched[i] : nullptr;
     if (p.nsched >= 3) return nullptr;
     SliceSched &ss = p.sched[p.nsched++];
-    ss.lo = lo; ss.hi = hi; ss.grid = grid; ss.tab = nullptr; ss.band = g_opt.slice_sched_band;
+    ss.lo = lo; ss.hi = hi; ss.grid = grid; ss.tab = nullptr; ss.band = band;
     std::vector<int32_t> tab;
     int iters = 0;
-    slice_sched_table(nsl, p.sched_period, grid, g_opt.slice_sched_band, tab, iters);
+    slice_sched_table(nsl, p.sched_period, grid, band, tab, iters);
     int32_t *d = nullptr;
     if (dalloc(&d, tab.size()) != SGM_OK) return nullptr;
     if (hipMemcpy(d, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { dfree(d); return nullptr; }
@@ -1664,6 +1665,7 @@ static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const doub
     // a row range is the same kernel on shifted pointers: rowptr entries stay absolute offsets
     // into val/col/code; the offset-dict kernel forms columns as row + offset, so x shifts too
     Part v;
+    v.opt = p.opt;
     v.n = r.hi - r.lo;
     v.nnz = (int64_t)((double)p.nnz * v.n / (p.n > 0 ? p.n : 1));   // same row density => same tile choice as the full part
     v.n_halo = p.n_halo; v.ncol_own = p.ncol_own;
@@ -1914,7 +1916,7 @@ __global__ __launch_bounds__(256) void k_sell_unpack(int32_t n, const int32_t *_
 }
 static bool lean_sliced(const Part &p) { return p.scode && p.sval && p.dict && !p.ecol && !p.scol && !p.sbcode && p.sw <= 8; }
 static bool lean_sell(const Part &p) { return p.sl_val && p.sl_col && !p.scode && !p.scol && !p.sbcode && !p.ecol; }
-static bool lean_applies(const Part &p) { return g_opt.csr_lean && (lean_sliced(p) || lean_sell(p)); }
+static bool lean_applies(const Part &p) { return p.opt.csr_lean && (lean_sliced(p) || lean_sell(p)); }
 // after the sliced form has been built (or refreshed): keep only it
 static void csr_go_lean(Part &p)
 {
@@ -2114,11 +2116,11 @@ static void free_sell(Part &p)
 static int build_sell(Part &p)
 {
     free_sell(p);
-    if (!g_opt.csr_sliced || !g_opt.csr_sell || p.ecol || p.n < 1 || p.nnz < 4 * (int64_t)p.n || p.max_row < 1) return SGM_OK;
+    if (!p.opt.csr_sliced || !p.opt.csr_sell || p.ecol || p.n < 1 || p.nnz < 4 * (int64_t)p.n || p.max_row < 1) return SGM_OK;
     // rows of up to 48 entries stay with the row-owner kernel: its tiles hold consecutive rows, whose x gathers share more L1
     // lines than a sorted chunk's (banded 20..40 entries per row: 719-753 us against 819 here; from 33..64 on SELL wins:
     // 650 against 770-794, 64..128: 656 against 781-816, 150..300: 770 against 930)
-    if (p.max_row <= 48 && g_opt.csr_sell < 2) return SGM_OK;
+    if (p.max_row <= 48 && p.opt.csr_sell < 2) return SGM_OK;
     hipStream_t st = g_rt.stream;
     const int64_t nsl = ((int64_t)p.n + kSlRows - 1) / kSlRows, nch = nsl * (kSlRows / kSellChunk);
     SGM_TRY(dalloc(&p.sl_perm, (size_t)nsl * kSlRows));
@@ -2194,7 +2196,7 @@ static int build_offset_dict(Part &p, const int32_t *, const int32_t *)
     auto sliced32 = [&]() -> int {
         const int W = p.max_row <= 3 ? 3 : p.max_row <= 5 ? 5 : p.max_row <= 7 ? 7 : p.max_row <= 8 ? 8 : p.max_row <= 12 ? 12
                     : p.max_row <= 16 ? 16 : p.max_row <= 20 ? 20 : p.max_row <= 24 ? 24 : p.max_row <= 28 ? 28 : 32;
-        if (!g_opt.csr_sliced || p.max_row < 1 || p.max_row > 32 || (double)W * n > 1.25 * (double)nnz) return build_sell(p);
+        if (!p.opt.csr_sliced || p.max_row < 1 || p.max_row > 32 || (double)W * n > 1.25 * (double)nnz) return build_sell(p);
         const size_t rows_padded = ((size_t)n + kSlRows - 1) / kSlRows * kSlRows;
         SGM_TRY(dalloc(&p.scol, rows_padded * W));
         SGM_TRY(dalloc(&p.sval, rows_padded * W));
@@ -2204,7 +2206,7 @@ static int build_offset_dict(Part &p, const int32_t *, const int32_t *)
         SGM_HIP(hipGetLastError());
         return pack_sliced(p);
     };
-    if (!g_opt.csr_offset_dict || hcnt[0] > 255) return sliced32();
+    if (!p.opt.csr_offset_dict || hcnt[0] > 255) return sliced32();
     std::vector<int32_t> dict;
     for (int32_t v : htab) if (v != kDictEmpty) dict.push_back(v);
     std::sort(dict.begin(), dict.end());
@@ -2216,7 +2218,7 @@ static int build_offset_dict(Part &p, const int32_t *, const int32_t *)
     SGM_HIP(hipMemsetAsync(p.code + nnz, 0, 32, st));
     // sliced form: short rows, few offsets, little padding
     const int W = p.max_row <= 3 ? 3 : p.max_row <= 5 ? 5 : p.max_row <= 7 ? 7 : 8;
-    const bool sliced = g_opt.csr_sliced && p.ndict <= 15 && p.max_row >= 1 && p.max_row <= 8 && (double)W * n <= 1.25 * (double)nnz;
+    const bool sliced = p.opt.csr_sliced && p.ndict <= 15 && p.max_row >= 1 && p.max_row <= 8 && (double)W * n <= 1.25 * (double)nnz;
     size_t rows_padded = 0;
     if (sliced) {
         rows_padded = ((size_t)n + kSlRows - 1) / kSlRows * kSlRows;
@@ -2237,7 +2239,7 @@ static int build_offset_dict(Part &p, const int32_t *, const int32_t *)
 #undef PICK
     if (const char *e = getenv("SGM_SLB_W")) { const int f = atoi(e); if (f >= p.max_row && f <= 32) Wb = f; }      // tuning aid (an instantiated width)
     const int Wc = (Wb + 7) / 8 * 8;                          // code bytes per row in eights
-    if (!sliced && g_opt.csr_sliced && Wb && p.ndict <= 255 && p.max_row > 8 && (double)Wb * n <= 1.35 * (double)nnz) {
+    if (!sliced && p.opt.csr_sliced && Wb && p.ndict <= 255 && p.max_row > 8 && (double)Wb * n <= 1.35 * (double)nnz) {
         rows_padded = ((size_t)n + kSlRows - 1) / kSlRows * kSlRows;
         SGM_TRY(dalloc(&p.sbcode, rows_padded * Wc));
         SGM_TRY(dalloc(&p.sval, rows_padded * Wb));
@@ -2361,7 +2363,7 @@ static int build_ell_offset_dict(Part &p)
     p.emdp = mdp;
     // sliced form (see k_csr_sl): every one of the max_d slots is an entry (padding slots keep their
     // 0.0 * x(last neighbour) term, like the reference), so the CSR kernel applies as it is
-    const bool sliced = g_opt.csr_sliced && ndict <= 15 && p.max_d >= 1 && p.max_d <= 8;
+    const bool sliced = p.opt.csr_sliced && ndict <= 15 && p.max_d >= 1 && p.max_d <= 8;
     if (sliced) {
         const int W = p.max_d <= 3 ? 3 : p.max_d <= 5 ? 5 : p.max_d <= 7 ? 7 : 8;
         const size_t rows_padded = ((size_t)p.n + kSlRows - 1) / kSlRows * kSlRows;
@@ -2454,6 +2456,39 @@ int build_csr_part(Part &p, int32_t n, int32_t ncol_own, int32_t n_halo, int64_t
                     (long long)ncol_own + n_halo);
     }
     return build_offset_dict(p, where == SGM_HOST ? ptr1 : nullptr, where == SGM_HOST ? node1 : nullptr);
+}
+
+// A plain-CSR copy of a single-part CSR matrix (device to device; no derived SpMV format): scratch for setup work that wants to
+// permute a matrix without touching the caller's (the reordering preconditioner, sgm_pc.hip)
+int clone_csr_plain(sgm_mat A, sgm_mat *out)
+{
+    *out = nullptr;
+    if (!A || A->fmt != SGM_FMT_CSR || A->parts.size() != 1 || A->comm)
+        return fail(SGM_ERR_UNSUPPORTED, "clone_csr_plain: single-GPU CSR matrices only");
+    const Part &p = A->parts[0];
+    SGM_TRY(csr_need_arrays(p));
+    struct Release { const Part &p; ~Release() { csr_release_arrays(p); } } rel{p};
+    sgm_mat C = new sgm_mat_s;
+    C->fmt = SGM_FMT_CSR; C->nrow = A->nrow; C->ncol = A->ncol; C->nnz = A->nnz;
+    C->parts.resize(1);
+    Part &q = C->parts[0];
+    q.opt.csr_offset_dict = 0; q.opt.csr_sliced = 0; q.opt.csr_sell = 0; q.opt.csr_lean = 0; q.opt.slice_sched = 0;
+    q.n = p.n; q.ncol_own = p.ncol_own; q.n_halo = 0; q.nnz = p.nnz; q.max_row = p.max_row;
+    hipStream_t st = g_rt.stream;
+    int rc = dalloc(&q.rowptr, (size_t)p.n + 1);
+    if (rc == SGM_OK) rc = dalloc(&q.col, (size_t)p.nnz + 4);
+    if (rc == SGM_OK) rc = dalloc(&q.val, (size_t)p.nnz + 2);
+    if (rc != SGM_OK) { sgm_mat_destroy(C); return rc; }
+    (void)hipMemcpyAsync(q.rowptr, p.rowptr, ((size_t)p.n + 1) * 4, hipMemcpyDeviceToDevice, st);
+    (void)hipMemsetAsync(q.col + p.nnz, 0, 16, st);
+    (void)hipMemsetAsync(q.val + p.nnz, 0, 16, st);
+    if (p.nnz) {
+        (void)hipMemcpyAsync(q.col, p.col, (size_t)p.nnz * 4, hipMemcpyDeviceToDevice, st);
+        (void)hipMemcpyAsync(q.val, p.val, (size_t)p.nnz * 8, hipMemcpyDeviceToDevice, st);
+    }
+    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { sgm_mat_destroy(C); return fail(SGM_ERR_HIP, "clone_csr_plain: copy failed"); }
+    *out = C;
+    return SGM_OK;
 }
 
 // after a change of the index arrays (matrix permutation): drop and rebuild the derived formats
@@ -2647,6 +2682,7 @@ static int ensure_transpose(sgm_mat A)
             T->ncol = A->nrow;
             T->nnz = nnz;
             T->parts.resize(1);
+            T->parts[0].opt = p.opt;                       // A^T runs with A's options
             rc = build_csr_part(T->parts[0], T->nrow, T->ncol, 0, nnz, tptr, tnode, zeros, SGM_DEVICE, false);
         }
         if (tmp) (void)hipFree(tmp);
@@ -2880,6 +2916,45 @@ int sgm_ell_set_values(sgm_mat A, const double *val, int where)
     return SGM_OK;
 }
 
+/* sgm_mat_set_option: this matrix's own copy of a kernel-selection option (sgm_set_option only changes what matrices
+ * created LATER start with).  Options that choose among forms the handle already holds (csr_sliced, csr_offset_dict,
+ * csr_row_owner, csr_row_lines, csr_sell, ell_offset_dict, ell_colblock 0 / nonzero, slice_sched) act from the next
+ * product on; the ones a form is BUILT with (ell_colblock 0 <-> built, ell_colblock_cols / _rows, csr_lean)
+ * rebuild / release that form here.  Every choice gives the same bits.  On a composite: applied to every block. */
+int sgm_mat_set_option(sgm_mat A, const char *name, int value)
+{
+    SGM_TRY(require_init());
+    if (!A || !name) return fail(SGM_ERR_BAD_ARG, "sgm_mat_set_option: null argument");
+    int v = 0;
+    SGM_TRY(normalise_option(name, value, &v));
+    MatOptions probe;
+    if (!mat_option_field(probe, name)) return fail(SGM_ERR_BAD_ARG, "sgm_mat_set_option: '%s' is not a matrix option", name);
+    if (A->fmt == SGM_FMT_COMPOSITE) {
+        for (sgm_mat_s *B : A->blocks)
+            if (B) SGM_TRY(sgm_mat_set_option(B, name, value));
+        return SGM_OK;
+    }
+    const bool cb_shape = !strcmp(name, "ell_colblock_cols") || !strcmp(name, "ell_colblock_rows");
+    for (Part &p : A->parts) {
+        int *f = mat_option_field(p.opt, name);
+        const int old = *f;
+        *f = v;
+        if (old == v) continue;
+        if (p.ecol && (cb_shape || (!strcmp(name, "ell_colblock") && ((old != 0) != (v != 0) || v == 2 || old == 2)))) {
+            SGM_TRY(build_ell_colblock(p));           // (frees the old form first; decides again whether the matrix wants one)
+            SGM_TRY(refresh_ell_colblock_values(p));
+            SGM_HIP(hipStreamSynchronize(g_rt.stream));
+        }
+        if (!strcmp(name, "csr_lean") && !p.ecol) {
+            if (v == 0) { SGM_TRY(csr_need_arrays(p)); p.lean = false; }
+            else csr_go_lean(p);
+        }
+        if (!strcmp(name, "slice_sched")) free_slice_sched(p);
+    }
+    if (A->T) SGM_TRY(sgm_mat_set_option(A->T, name, value));
+    return SGM_OK;
+}
+
 int sgm_mat_matvec(sgm_mat A, const double *x, double *y, int where)
 {
     return matvec_impl(A, x, y, where, false);
@@ -3047,7 +3122,7 @@ int sgm_mat_kernel(sgm_mat A, char *buf, int len)
         if (A->fmt == SGM_FMT_ELL) {
             if (use_ell_colblock(p)) snprintf(name, sizeof name, "k_ellcb<cols=%d,R=%d>", p.cb_cols, p.cb_R);
             else if (use_sliced_ell(p)) snprintf(name, sizeof name, "k_csr_sl<W=%d>", p.sw);
-            else if (p.ecode && g_opt.ell_offset_dict) snprintf(name, sizeof name, "k_ell_do<MDP=%d>", p.emdp);
+            else if (p.ecode && p.opt.ell_offset_dict) snprintf(name, sizeof name, "k_ell_do<MDP=%d>", p.emdp);
             else snprintf(name, sizeof name, "k_ell_spmv");
         } else if (use_sliced(p)) snprintf(name, sizeof name, "k_csr_sl<W=%d>", p.sw);
         else if (use_slicedb(p)) snprintf(name, sizeof name, "k_csr_slb<W=%d>", p.sw);
@@ -3095,7 +3170,7 @@ static int64_t part_matvec_bytes(const sgm_mat_s *A, const Part &p)
     if (A->fmt == SGM_FMT_ELL) {
         if (use_ell_colblock(p)) return ell_colblock_matvec_bytes(p);
         if (use_sliced_ell(p)) m = nsl * kSlRows * (8 * (int64_t)p.sw + 4);
-        else if (p.ecode && g_opt.ell_offset_dict) m = (int64_t)p.n * (8 * (int64_t)p.max_d + p.emdp);
+        else if (p.ecode && p.opt.ell_offset_dict) m = (int64_t)p.n * (8 * (int64_t)p.max_d + p.emdp);
         else m = 12 * (int64_t)p.n * p.max_d;
     } else if (use_sliced(p)) m = nsl * kSlRows * (8 * (int64_t)p.sw + 4);
     else if (use_slicedb(p)) m = nsl * kSlRows * (8 * (int64_t)p.sw + (p.sw + 7) / 8 * 8);

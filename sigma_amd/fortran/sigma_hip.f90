@@ -520,6 +520,33 @@ interface
         real(c_double), intent(in) :: val(*)
         integer(c_int) :: rc
     end function
+    function sgm_mat_set_option(A, name, value) bind(c, name='sgm_mat_set_option') result(rc)
+        import :: c_ptr, c_int, c_char
+        type(c_ptr), value :: A
+        character(kind=c_char), intent(in) :: name(*)
+        integer(c_int), value :: value
+        integer(c_int) :: rc
+    end function
+    function sgm_solver_set_option(s, name, value) bind(c, name='sgm_solver_set_option') result(rc)
+        import :: c_ptr, c_int, c_char
+        type(c_ptr), value :: s
+        character(kind=c_char), intent(in) :: name(*)
+        integer(c_int), value :: value
+        integer(c_int) :: rc
+    end function
+    function sgm_pc_set_option(pc, name, value) bind(c, name='sgm_pc_set_option') result(rc)
+        import :: c_ptr, c_int, c_char
+        type(c_ptr), value :: pc
+        character(kind=c_char), intent(in) :: name(*)
+        integer(c_int), value :: value
+        integer(c_int) :: rc
+    end function
+    function sgm_pc_create(pc, kind) bind(c, name='sgm_pc_create') result(rc)
+        import :: c_ptr, c_int, c_int32_t
+        type(c_ptr), intent(out) :: pc
+        integer(c_int32_t), value :: kind          ! 1 jacobi, 2 ildu(0)
+        integer(c_int) :: rc
+    end function
     function c_usleep(us) bind(c, name='usleep') result(rc)
         import :: c_int
         integer(c_int), value :: us
@@ -545,6 +572,7 @@ contains
     procedure :: matvec_t => hip_matrix_matvec_t
     procedure :: matvec_t_add => hip_matrix_matvec_t_add
     procedure :: kernel_name => hip_matrix_kernel_name
+    procedure :: set_option => hip_matrix_set_option
 end type hip_matrix
 
 abstract interface
@@ -703,6 +731,7 @@ contains
     procedure :: solve_pc => hip_solver_solve_pc
     generic :: solve => solve_plain, solve_pc
     procedure :: solve_device => hip_solver_solve_device
+    procedure :: set_option => hip_solver_set_option
     procedure :: set_max_iter => hip_solver_set_max_iter
     procedure :: destroy => hip_solver_destroy
 end type hip_linear_solver
@@ -743,6 +772,17 @@ subroutine hip_set_option(name, value)
     integer, intent(in) :: value
     call hip_check(sgm_set_option(trim(name) // c_null_char, int(value, c_int)))
 end subroutine hip_set_option
+
+
+subroutine hip_matrix_set_option(A, name, value)
+    ! this matrix's own kernel-selection option (sgm_mat_set_option); hip_set_option only changes what matrices
+    ! created later start with
+    class(hip_matrix), intent(inout) :: A
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: value
+    call A%upload()
+    call hip_check(sgm_mat_set_option(A%handle, trim(name) // c_null_char, int(value, c_int)))
+end subroutine hip_matrix_set_option
 
 
 !==========================================================================!
@@ -1045,45 +1085,61 @@ function hip_jacobi() result(s)                    ! jacobi_solvers.f90:23-31
     s%kind = 11
 end function
 
-function hip_ldu(incomplete, level) result(s)      ! ldu_solvers.f90:73-86
+function hip_ldu(incomplete, level, reorder) result(s)      ! ldu_solvers.f90:73-86
+    ! reorder = "colour" (extension, off by default): ILDU(0) of the colour-ordered matrix P A P^T (P = greedy_color_ordering of
+    ! the graph of A) applied as z = P^T M^-1 P r -- A, b, x stay as they are; iteration counts are the permuted system's
     logical, intent(in), optional :: incomplete
     integer, intent(in), optional :: level
+    character(len=*), intent(in), optional :: reorder
     type(hip_linear_solver), pointer :: s
     allocate(s)
     s%kind = 12       ! like ldu_set_params :143-151: always ILDU(0)
+    if (present(reorder)) then
+        if (reorder == "colour" .or. reorder == "color") call s%set_option("ildu_reorder", 1)
+    endif
 end function
+
+subroutine hip_solver_make_handle(s)
+    ! the factory object becomes a library handle (no matrix needed yet: options can be set on it before setup)
+    class(hip_linear_solver), intent(inout) :: s
+    if (c_associated(s%handle)) return
+    select case (s%kind)
+    case (1)
+        call hip_check(sgm_cg_create(s%handle, s%tolerance))
+    case (2)
+        call hip_check(sgm_bicgstab_create(s%handle, s%tolerance))
+    case (3)
+        call hip_check(sgm_gmres_create(s%handle, s%tolerance, int(s%restart, c_int32_t)))
+    case (11)
+        call hip_check(sgm_pc_create(s%handle, 1_c_int32_t))
+    case (12)
+        call hip_check(sgm_pc_create(s%handle, 2_c_int32_t))
+    end select
+end subroutine
+
+subroutine hip_solver_set_option(s, name, value)
+    ! this solver's / preconditioner's own option (sgm_solver_set_option / sgm_pc_set_option)
+    class(hip_linear_solver), intent(inout) :: s
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: value
+    call hip_solver_make_handle(s)
+    if (s%kind > 10) then
+        call hip_check(sgm_pc_set_option(s%handle, trim(name) // c_null_char, int(value, c_int)))
+    else
+        call hip_check(sgm_solver_set_option(s%handle, trim(name) // c_null_char, int(value, c_int)))
+    endif
+end subroutine
 
 subroutine hip_solver_setup_handle(s, Ah, nrow)
     class(hip_linear_solver), intent(inout) :: s
     type(c_ptr), intent(in) :: Ah
     integer, intent(in) :: nrow
-    select case (s%kind)
-    case (1)
-        if (.not. c_associated(s%handle)) &
-            & call hip_check(sgm_cg_create(s%handle, s%tolerance))
+    call hip_solver_make_handle(s)
+    if (s%kind > 10) then
+        call hip_check(sgm_pc_setup(s%handle, Ah))
+    else
         call hip_check(sgm_solver_setup(s%handle, Ah))
-    case (2)
-        if (.not. c_associated(s%handle)) &
-            & call hip_check(sgm_bicgstab_create(s%handle, s%tolerance))
-        call hip_check(sgm_solver_setup(s%handle, Ah))
-    case (3)
-        if (.not. c_associated(s%handle)) &
-            & call hip_check(sgm_gmres_create(s%handle, s%tolerance, &
-            & int(s%restart, c_int32_t)))
-        call hip_check(sgm_solver_setup(s%handle, Ah))
-    case (11)
-        if (.not. c_associated(s%handle)) then
-            call hip_check(sgm_jacobi_create(s%handle, Ah))
-        else
-            call hip_check(sgm_pc_setup(s%handle, Ah))
-        endif
-    case (12)
-        if (.not. c_associated(s%handle)) then
-            call hip_check(sgm_ildu0_create(s%handle, Ah))
-        else
-            call hip_check(sgm_pc_setup(s%handle, Ah))
-        endif
-    end select
+    endif
     s%nn = nrow
     s%iterations = 0                    ! cg_solvers.f90:72
     s%initialized = .true.

@@ -362,6 +362,30 @@ subroutine test_device_vectors()                                           !
     if (s%iterations /= its1 .or. any(u1 /= u2)) call fail('solve on device vectors differs from the one on host vectors', &
         & maxval(dabs(u1 - u2)))
     print *, 'device vectors: the same solve, bit for bit,', its1, 'iterations'
+    ! the reordering ILDU(0) preconditioner: A, f, u stay in natural order, the factors are those of the colour-ordered matrix
+    block
+        type(hip_linear_solver), pointer :: pr, pn
+        real(dp), allocatable :: u3(:), u4(:)
+        integer :: itn
+        allocate(u3(n), u4(n))
+        pn => hip_ldu()
+        pr => hip_ldu(reorder = "colour")
+        call pn%setup(A)
+        call pr%setup(A)
+        call s%setup(A)
+        u3 = 0.0_dp
+        call s%solve(A, u3, f, pn)
+        itn = s%iterations
+        call s%setup(A)
+        u4 = 0.0_dp
+        call s%solve(A, u4, f, pr)
+        print *, 'ILDU-PCG iterations: natural order', itn, ' colour order (reorder)', s%iterations
+        if (maxval(dabs(u3 - u4)) > 1.0e-11 * maxval(dabs(u3))) call fail('reordering ILDU-PCG differs from the natural-order solve', &
+            & maxval(dabs(u3 - u4)))
+        call pn%destroy()
+        call pr%destroy()
+        deallocate(pn, pr)
+    end block
     ! dot_product / axpy statements (cg_solvers.f90:131,137)
     d = hip_dot(f, u1)
     if (dabs(d - dot_product(f, u1)) > 1.0e-15 * dabs(d)) call fail('hip_dot differs from dot_product', d)

@@ -120,3 +120,84 @@ def test_validation_costs_next_to_nothing_at_c2_size():
     # what is asserted is only that create stays what it was (tens of ms), the figure itself goes to the log
     print(f"C2-size sgm_csr_create from device arrays: {min(ts) * 1e3:.1f} ms (min of 3)")
     assert min(ts) < 0.5
+
+
+# ---------------------------------------------------------------------------- options are per handle
+def test_options_are_per_handle_two_matrices_with_different_kernels_coexist():
+    """SURVEY 8b "Ownership": no global state besides the HIP/RCCL context.  sgm_set_option is only the default a handle
+    is CREATED with; every matrix keeps its own copy (sgm_mat_set_option), so two matrices of one process run different
+    kernels side by side, and changing a default never touches an existing handle.  Same bits whichever kernel."""
+    n, ptr, node, val = _poisson(120, 90)
+    x = P.test_vector(n)
+    A = sg.csr_matrix(n, n, ptr, node, val)
+    sg.set_option("csr_sliced", 0)
+    try:
+        B = sg.csr_matrix(n, n, ptr, node, val)          # created while the default is off
+        assert A.kernel.startswith("k_csr_sl<"), A.kernel      # ... which did not touch A
+    finally:
+        sg.set_option("csr_sliced", 1)
+    assert "CW=1" in B.kernel and A.kernel.startswith("k_csr_sl<"), (A.kernel, B.kernel)       # and B keeps what it was created with
+    C_ = sg.csr_matrix(n, n, ptr, node, val)
+    C_.set_option("csr_offset_dict", 0)
+    C_.set_option("csr_sliced", 0)
+    C_.set_option("csr_row_owner", 0)
+    C_.set_option("csr_row_lines", 0)
+    assert C_.kernel.startswith("k_csr_spmv"), C_.kernel
+    ys = []
+    for M in (A, B, C_, A, C_, B):                        # interleaved: no product changes what another handle runs
+        y = np.zeros(n)
+        M.matvec(x, y)
+        ys.append(y)
+    for y in ys[1:]:
+        assert np.array_equal(y, ys[0])
+    assert (A.kernel.split("<")[0], B.kernel.split("<")[0], C_.kernel.split("<")[0]) == ("k_csr_sl", "k_csr_do", "k_csr_spmv")
+    # back on: the handle returns to the form it still holds
+    C_.set_option("csr_offset_dict", 1); C_.set_option("csr_sliced", 1)
+    assert C_.kernel.startswith("k_csr_sl<")
+    # a name of another group, or an unknown one, is refused
+    _raises(BAD_ARG, "not a matrix option", lambda: A.set_option("dot_order", 1))
+    _raises(BAD_ARG, "not a matrix option", lambda: A.set_option("no_such_option", 1))
+    # csr_lean on one handle: its CSR-order arrays come back and stay; the other handle stays lean
+    r_a, _ = A.footprint()
+    A.set_option("csr_lean", 0)
+    assert A.footprint()[0] > 1.5 * r_a and sg.csr_matrix(n, n, ptr, node, val).footprint()[0] == r_a
+    A.set_option("csr_lean", 1)
+    assert A.footprint()[0] == r_a
+
+
+def test_solver_and_preconditioner_options_are_per_handle(tmp_path):
+    import oracle as orc
+    n, ptr, node, val = _poisson(64, 48)
+    A = sg.csr_matrix(n, n, ptr, node, val)
+    Ao = orc.CsrMatrix(n, n, ptr, node, val)
+    b = np.full(n, 1.0 / n)
+    ur, itr, _, _ = orc.cg(Ao, b, tol=1e-12)             # the oracle adds its dots in the reference's order
+    exact, tree = sg.cg(1e-12), sg.cg(1e-12)
+    exact.set_option("dot_order", 1)                      # before the handle exists: applied when setup creates it
+    exact.setup(A); tree.setup(A)
+    u1, u0 = np.zeros(n), np.zeros(n)
+    tree.solve(A, u0, b)
+    exact.solve(A, u1, b)
+    tree2 = sg.cg(1e-12); tree2.setup(A)
+    u2 = np.zeros(n); tree2.solve(A, u2, b)
+    assert exact.iterations == itr and np.array_equal(u1, ur)                    # bit-identical to the reference order ...
+    assert np.array_equal(u0, u2) and not np.array_equal(u0, u1)                 # ... while its neighbours stay in tree order
+    assert abs(tree.iterations - itr) <= 1 and np.abs(u0 - ur).max() <= 1e-12 * np.abs(ur).max() * 10
+    # the launch loop on one solver, the one-workgroup kernel on the other: same iterates
+    loop = sg.cg(1e-12); loop.set_option("cg_small", 0); loop.setup(A)
+    u3 = np.zeros(n); loop.solve(A, u3, b)
+    assert abs(loop.iterations - tree.iterations) <= 1 and np.abs(u3 - u0).max() <= 1e-12
+    _raises(BAD_ARG, "not a solver option", lambda: tree.set_option("csr_sliced", 0))
+    # preconditioners: the factory object takes options before its first setup decides which sweeps to build
+    n, ptr, node, val = _poisson(128, 96)                 # (wide and tall enough for the strip pipeline)
+    A = sg.csr_matrix(n, n, ptr, node, val)
+    Ao = orc.CsrMatrix(n, n, ptr, node, val)
+    pw, pp = sg.ldu(), sg.ldu()
+    pw.set_option("ildu_strips", 0)
+    pw.setup(A); pp.setup(A)
+    assert pw.get("strips", np.int32)[0] == 0 and pp.get("strips", np.int32)[0] > 0
+    r = P.test_vector(n)
+    z1, z2 = np.zeros(n), np.zeros(n)
+    pw.solve(A, z1, r); pp.solve(A, z2, r)
+    assert np.array_equal(z1, z2) and np.array_equal(z1, orc.Ildu(Ao).solve(r))
+    _raises(BAD_ARG, "not a preconditioner option", lambda: pp.set_option("dot_order", 1))

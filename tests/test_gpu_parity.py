@@ -362,11 +362,13 @@ def test_composite_vs_reference_fixture(golden, name):
         assert np.abs(u - ur).max() / np.abs(ur).max() <= max(1e-12, kappa * tol), k
 
 
-def _kernel_options(dict_opt, sl_opt, ro_opt, rg_opt=1):
-    sg.set_option("csr_offset_dict", dict_opt)
-    sg.set_option("csr_sliced", sl_opt)
-    sg.set_option("csr_row_owner", ro_opt)
-    sg.set_option("csr_row_lines", rg_opt)
+def _kernel_options(dict_opt, sl_opt, ro_opt, rg_opt=1, H=None):
+    """The defaults matrices created next start with -- or, with H, that handle's own options."""
+    f = sg.set_option if H is None else H.set_option
+    f("csr_offset_dict", dict_opt)
+    f("csr_sliced", sl_opt)
+    f("csr_row_owner", ro_opt)
+    f("csr_row_lines", rg_opt)
 
 
 # (offset dictionary, sliced forms, row-owner gather, line-staged row owner, the kernel a stencil matrix then takes)
@@ -534,32 +536,34 @@ def test_randomised_ellpack_every_kernel_vs_oracle(orc, max_d):
             assert np.array_equal(ta, ta_ref), key
 
 
-@pytest.mark.parametrize("n,max_d,dmin,cols,chunks,rows,band", [
-    (3000, 32, None, 64, 3, 0, -1), (1000, 7, 3, 16, 1, 0, -1), (70001, 32, 24, 2048, 8, 256, -1),
-    (513, 9, None, 2, 2, 0, -1), (5000, 100, 60, 256, 2, 0, -1), (20000, 16, None, 16384, 8, 0, -1),
-    (70001, 32, 24, 2048, 8, 512, -1), (4000, 40, 20, 128, 2, 0, -1), (3000, 32, None, 64, 3, 256, -1),
-    # row bands (the two phases band by band over one product buffer): several bands, a partial last band, one tile per
-    # band, more pieces than entries allow, bands wider than the matrix (= one band)
-    (70001, 32, 24, 2048, 8, 512, 8192), (70001, 32, 24, 2048, 8, 256, 4096), (3000, 32, None, 64, 3, 0, 512),
-    (5000, 100, 60, 256, 2, 0, 640), (20000, 16, None, 16384, 8, 0, 3000), (1000, 7, 3, 16, 1, 0, 256),
-    (4000, 40, 20, 128, 2, 0, 100000), (513, 9, None, 2, 2, 0, 192)])
-def test_ell_column_blocked_two_phase_vs_oracle(orc, n, max_d, dmin, cols, chunks, rows, band):
+@pytest.mark.parametrize("n,max_d,dmin,cols,chunks,rows", [
+    (3000, 32, None, 64, 3, 0), (1000, 7, 3, 16, 1, 0), (70001, 32, 24, 2048, 8, 256),
+    (513, 9, None, 2, 2, 0), (5000, 100, 60, 256, 2, 0), (20000, 16, None, 16384, 8, 0),
+    (70001, 32, 24, 2048, 8, 512), (4000, 40, 20, 128, 2, 0), (3000, 32, None, 64, 3, 256),
+    (50000, 32, None, 20480, 4, 0)])
+def test_ell_column_blocked_two_phase_vs_oracle(orc, n, max_d, dmin, cols, chunks, rows):
     """k_ellcb (sgm_ellcb.hip): the two-phase product for ELLPACK matrices with random columns -- products
     through LDS-resident column blocks of x, then row sums in slot order from an LDS image of the tile's
     products.  Forced on (option ell_colblock = 2) for small matrices with small column blocks so that many
     blocks, chunks, odd run boundaries, padded rows (0 * x(last) terms), partial tiles and the tile heights
     (R = 64 / 192 / 256 by max_d; 512 with whole-wave runs for rows of 16..32 slots, or 256 on request) are exercised:
     bit-exact against the oracle, like k_ell_spmv."""
+    # (the defaults a matrix is created with ...)
     sg.set_option("ell_colblock", 2)
     sg.set_option("ell_colblock_cols", cols)
-    sg.set_option("ell_colblock_chunks", chunks)
-    sg.set_option("ell_colblock_rows", rows)
-    sg.set_option("ell_colblock_band", band)
-    sg.set_option("ell_colblock_pieces", 7 if band in (512, 192) else 512)
     try:
         ei, ej, ev = P.random_regular_ell(n, max_d, 777 + n, dmin=dmin)
         A = orc.EllMatrix.from_edges(n, n, ei, ej, ev)
         H = sg.ellpack_matrix(n, n, A.node, A.val)
+    finally:
+        sg.set_option("ell_colblock", 1)
+        sg.set_option("ell_colblock_cols", 16384)
+    try:
+        # (... and options changed on the handle itself: the form is rebuilt with them)
+        os.environ["SGM_ELLCB_CHUNKS"] = str(chunks)          # (a tuning aid read when the form is built)
+        H.set_option("ell_colblock_rows", rows)
+        H.set_option("ell_colblock", 0)                       # released ...
+        H.set_option("ell_colblock", 2)                       # ... and built again, with the chunk count above
         assert H.kernel.startswith("k_ellcb"), H.kernel
         want_r = 512 if (rows != 256 and 16 <= max_d <= 32) else min(256, 8192 // max_d) // 64 * 64
         assert H.kernel.endswith(f"R={want_r}>"), (H.kernel, want_r)
@@ -572,12 +576,13 @@ def test_ell_column_blocked_two_phase_vs_oracle(orc, n, max_d, dmin, cols, chunk
         H.matvec_add(x, ya)
         assert np.array_equal(ya, A.matvec_add(x, y0.copy()))
         # the same handle with the plain kernel (option off): identical bits
-        sg.set_option("ell_colblock", 0)
+        H.set_option("ell_colblock", 0)
         assert H.kernel == "k_ell_spmv"
         y2 = np.zeros(n)
         H.matvec(x, y2)
         assert np.array_equal(y2, y)
-        sg.set_option("ell_colblock", 2)
+        H.set_option("ell_colblock", 2)
+        assert H.kernel.startswith("k_ellcb"), H.kernel
         # non-finite x entries propagate like the reference (also through padding slots)
         xn = x.copy()
         xn[rs.randint(0, n, 5)] = np.inf
@@ -608,12 +613,8 @@ def test_ell_column_blocked_two_phase_vs_oracle(orc, n, max_d, dmin, cols, chunk
         fin = np.isfinite(hr) & (hr > 0)
         assert (np.abs(s.history[fin] - hr[fin]) / hr[fin])[:2].max() <= 1e-9
     finally:
-        sg.set_option("ell_colblock", 1)
-        sg.set_option("ell_colblock_cols", 16384)
-        sg.set_option("ell_colblock_chunks", 16)
-        sg.set_option("ell_colblock_rows", 0)
-        sg.set_option("ell_colblock_band", -1)
-        sg.set_option("ell_colblock_pieces", 512)
+        os.environ.pop("SGM_ELLCB_CHUNKS", None)
+        H.destroy()
 
 
 @pytest.mark.parametrize("nparts", [2, 3, 5])
@@ -697,8 +698,7 @@ def test_single_workgroup_cg_vs_oracle_and_vs_the_launch_loop(orc, kind):
         ur, itr, _, hist_r = orc.cg(A, b, tol=tol, pc=pco, history=4096)
         res = {}
         for small, chunk in ((1, 50000), (1, 7), (0, 50000)):
-            sg.set_option("cg_small", small)
-            sg.set_option("cg_small_chunk", chunk)
+            sg.set_option("cg_small", chunk if (small and chunk != 50000) else small)     # n > 1: on, n iterations per launch
             try:
                 pc = None
                 if jac:
@@ -719,7 +719,6 @@ def test_single_workgroup_cg_vs_oracle_and_vs_the_launch_loop(orc, kind):
                 assert sv2.last_iterations == 9
             finally:
                 sg.set_option("cg_small", 1)
-                sg.set_option("cg_small_chunk", 50000)
         for key, (u, its, hist) in res.items():
             assert abs(its - itr) <= 1, (kind, jac, key, its, itr)
             assert np.abs(u - ur).max() / np.abs(ur).max() <= 1e-11, (kind, jac, key)
@@ -841,7 +840,7 @@ def test_slice_schedule_keeps_results(orc):
     ptr1, node1, val = (ptr + 1).to(torch.int32), (Ccol[M] + 1).to(torch.int32), V[M].contiguous()
     x = torch.sin(0.37 * torch.arange(1, n + 1, dtype=torch.float64, device=dev))
     out = {}
-    for sched in (0, 1):
+    for sched in (0, 1, 8):              # off, bands of 64 slices, bands of 8 slices (the (y-block, z) tile order)
         sg.set_option("slice_sched", sched)
         try:
             A = sg.csr_matrix(n, n, ptr1, node1, val)
@@ -860,9 +859,10 @@ def test_slice_schedule_keeps_results(orc):
             del A
         finally:
             sg.set_option("slice_sched", 0)
-    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
-    # (the fused p.q partial sums follow the workgroups' slices, so CG's scalars differ in their last bits)
-    assert np.abs(out[0][2] - out[1][2]).max() <= 1e-9 * np.abs(out[0][2]).max()
+    for sc in (1, 8):
+        assert np.array_equal(out[0][0], out[sc][0]) and np.array_equal(out[0][1], out[sc][1])
+        # (the fused p.q partial sums follow the workgroups' slices, so CG's scalars differ in their last bits)
+        assert np.abs(out[0][2] - out[sc][2]).max() <= 1e-9 * np.abs(out[0][2]).max()
     # a sample of rows against the host sum in stored order
     rs = np.random.RandomState(3)
     hp, hn, hv, hx = ptr1.cpu().numpy(), node1.cpu().numpy(), val.cpu().numpy(), x.cpu().numpy()
@@ -914,12 +914,10 @@ def test_sliced_int32_kernel_short_rows_without_dictionary(orc, n, wmax):
     y = np.zeros(n)
     H.matvec(x, y)
     assert np.array_equal(y, A2.matvec(x))
-    sg.set_option("csr_sliced", 0)
-    try:
-        y1 = np.zeros(n)
-        H.matvec(x, y1)
-    finally:
-        sg.set_option("csr_sliced", 1)
+    H.set_option("csr_sliced", 0)
+    y1 = np.zeros(n)
+    H.matvec(x, y1)
+    H.set_option("csr_sliced", 1)
     assert np.array_equal(y1, y)
 
 
@@ -1004,14 +1002,12 @@ def test_sliced_byte_coded_kernel_rows_of_9_to_32_entries(orc, kind):
     for opts in ({"csr_sliced": 0}, {"csr_sliced": 0, "csr_offset_dict": 0}, {"csr_sliced": 0, "csr_offset_dict": 0, "csr_row_owner": 0},
                  {"csr_sliced": 0, "csr_offset_dict": 0, "csr_row_owner": 0, "csr_row_lines": 0}):
         for k_, v_ in opts.items():
-            sg.set_option(k_, v_)
-        try:
-            assert not H.kernel.startswith("k_csr_slb")
-            y1 = np.zeros(n)
-            H.matvec(x, y1)
-        finally:
-            for k_ in opts:
-                sg.set_option(k_, 1)
+            H.set_option(k_, v_)
+        assert not H.kernel.startswith("k_csr_slb")
+        y1 = np.zeros(n)
+        H.matvec(x, y1)
+        for k_ in opts:
+            H.set_option(k_, 1)
         assert np.array_equal(y1, y), opts
     # in-process row partition (ranges cut at slice boundaries, halo columns renumbered)
     if n > 2000:
@@ -1077,13 +1073,11 @@ def _sliced_checks(orc, A, n, m, ptr, node, val):
     H.matvec_t(xt, t)
     assert np.array_equal(t, A2.matvec_t(xt))
     # the 1-byte-code kernel on the same handle agrees
-    sg.set_option("csr_sliced", 0)
-    try:
-        assert "CW=1" in H.kernel
-        y1 = np.zeros(n)
-        H.matvec(x, y1)
-    finally:
-        sg.set_option("csr_sliced", 1)
+    H.set_option("csr_sliced", 0)
+    assert "CW=1" in H.kernel
+    y1 = np.zeros(n)
+    H.matvec(x, y1)
+    H.set_option("csr_sliced", 1)
     assert np.array_equal(y1, y)
 
 
@@ -1457,14 +1451,14 @@ def test_ildu_slab_pipeline_vs_level_walkers_and_oracle(orc, w, h, nk, tail, ord
         z = np.zeros(n)
         pc.solve(H, z, r)
         assert np.array_equal(z, opc.solve(r)), trial
-    sg.set_option("ildu_strips", 0)
+    pc.set_option("ildu_strips", 0)
     try:
         assert pc.get("slabs", np.int32)[0] == 0
         z2 = np.zeros(n)
         pc.solve(H, z2, r)
         assert np.array_equal(z2, z)
     finally:
-        sg.set_option("ildu_strips", 1)
+        pc.set_option("ildu_strips", 1)
     b = P.test_vector(n)
     ur, itr, _, _ = orc.cg(A, b, tol=1e-12, pc=opc)
     s = sg.cg(1e-12)
@@ -1524,12 +1518,12 @@ def test_ildu_pipelines_at_size_vs_oracle(orc, shape):
         z = np.zeros(n)
         pc.solve(H, z, r)
         assert np.array_equal(z, zo), trial
-    sg.set_option("ildu_strips", 0)
+    pc.set_option("ildu_strips", 0)
     try:
         z2 = np.zeros(n)
         pc.solve(H, z2, r)
     finally:
-        sg.set_option("ildu_strips", 1)
+        pc.set_option("ildu_strips", 1)
     assert np.array_equal(z2, zo)
     b = np.full(n, 1.0 / n)
     ur, itr, _, _ = orc.cg(A, b, tol=1e-8, pc=opc)
@@ -1561,14 +1555,14 @@ def test_ildu_strip_pipeline_vs_level_walkers_and_oracle(orc, n, w, order, holes
         z = np.zeros(n)
         pc.solve(H, z, r)
         assert np.array_equal(z, opc.solve(r)), trial
-    sg.set_option("ildu_strips", 0)
+    pc.set_option("ildu_strips", 0)
     try:
         assert pc.get("strips", np.int32)[0] == 0
         z2 = np.zeros(n)
         pc.solve(H, z2, r)
         assert np.array_equal(z2, z)
     finally:
-        sg.set_option("ildu_strips", 1)
+        pc.set_option("ildu_strips", 1)
     # inside a solver (16 iterations queued per look at the stop flag) and after a value update
     b = P.test_vector(n)
     ur, itr, _, _ = orc.cg(A, b, tol=1e-12, pc=opc)
@@ -1843,7 +1837,7 @@ def test_row_space_level_sweeps_of_colour_ordered_factors(orc, case):
     zin = x.copy()
     pc.solve(H, zin, zin)                                    # in place
     assert np.array_equal(zin, want)
-    sg.set_option("ildu_rows", 2)                            # every level launched, nothing fused
+    pc.set_option("ildu_rows", 2)                            # every level launched, nothing fused
     try:
         assert list(pc.get("row_levels", np.int32)) == [1, lv[0], lv[1]]
         z2 = np.zeros(n)
@@ -1853,8 +1847,8 @@ def test_row_space_level_sweeps_of_colour_ordered_factors(orc, case):
         pc.solve(H, zin, zin)
         assert np.array_equal(zin, want)
     finally:
-        sg.set_option("ildu_rows", 1)
-    sg.set_option("ildu_rows", 0)
+        pc.set_option("ildu_rows", 1)
+    pc.set_option("ildu_rows", 0)
     try:
         assert list(pc.get("row_levels", np.int32)) == [0, 0, 0]
         z0 = np.zeros(n)
@@ -1866,7 +1860,7 @@ def test_row_space_level_sweeps_of_colour_ordered_factors(orc, case):
         s0.solve(H, u0, x2, pc)
         it0 = s0.iterations
     finally:
-        sg.set_option("ildu_rows", 1)
+        pc.set_option("ildu_rows", 1)
     u1 = np.zeros(n)
     s1 = sg.cg(tolerance=1e-10)
     s1.setup(H)
@@ -1912,13 +1906,13 @@ def test_row_space_sweeps_every_slot_count(orc, c):
     pc.solve(H, z, b)
     assert np.array_equal(z, want)
     for mode in (2, 0):
-        sg.set_option("ildu_rows", mode)
+        pc.set_option("ildu_rows", mode)
         try:
             z0 = np.zeros(n)
             pc.solve(H, z0, b)
             assert np.array_equal(z0, want)
         finally:
-            sg.set_option("ildu_rows", 1)
+            pc.set_option("ildu_rows", 1)
 
 
 def test_lean_footprint_and_on_demand_arrays(orc):
@@ -1950,11 +1944,9 @@ def test_lean_footprint_and_on_demand_arrays(orc):
     assert H.footprint()[0] == res0
     # the other kernels on the same handle (their arrays come back and stay while the option is off)
     for dict_opt, sl_opt, ro_opt, rg_opt, _tag in KERNEL_COMBOS:
-        _kernel_options(dict_opt, sl_opt, ro_opt, rg_opt)
-        try:
-            y[:] = -1.0; H.matvec(x, y)
-        finally:
-            _kernel_options(1, 1, 1)
+        _kernel_options(dict_opt, sl_opt, ro_opt, rg_opt, H=H)
+        y[:] = -1.0; H.matvec(x, y)
+        _kernel_options(1, 1, 1, H=H)
         assert np.array_equal(y, yref), _tag
     # value update, transpose, Jacobi / ILDU setup
     v2 = A.val * 1.25 + 0.5
@@ -2004,7 +1996,7 @@ def test_pipeline_abort_is_loud_and_recovers(orc):
             pc.setup(H)                                  # (self-check at setup runs with the built-in limit)
             assert pc.get(which, np.int32)[0] > 0, (which, "pipeline not in use")
             assert pc.get("pipeline_retired", np.int32)[0] == 0
-            sg.set_option("pipeline_spin_limit", 1)
+            pc.set_option("pipeline_spin_limit", 1)
             try:
                 if mode == "apply":
                     z = np.zeros(n)
@@ -2020,7 +2012,7 @@ def test_pipeline_abort_is_loud_and_recovers(orc):
                     u = np.zeros(n); s.solve(H, u, b, pc)
                     assert s.converged and s.iterations == sbw.iterations and np.array_equal(u, ubw), (which, mode, s.iterations, sbw.iterations)
             finally:
-                sg.set_option("pipeline_spin_limit", 0)
+                pc.set_option("pipeline_spin_limit", 0)
             assert pc.get("pipeline_retired", np.int32)[0] == 1, (which, mode)
             assert pc.get(which, np.int32)[0] == 0, (which, mode, "pipeline still in use after an abort")
             # the retired handle keeps working (level walkers), bit-exact
@@ -2875,16 +2867,13 @@ def test_full_size_c4_ellpack_every_row_bit_exact_both_kernels():
     ref = _torch_rowsum_in_stored_order(cols, vals, None, x)
     assert torch.equal(y, ref)
     del cols, vals
-    sg.set_option("ell_colblock", 0)
-    try:
-        assert E.kernel == "k_ell_spmv"
-        y2 = torch.zeros(n, dtype=torch.float64, device=dev)
-        torch.cuda.synchronize()
-        E.matvec(x, y2)
-        torch.cuda.synchronize()
-        assert torch.equal(y2, ref)
-    finally:
-        sg.set_option("ell_colblock", 1)
+    E.set_option("ell_colblock", 0)          # this handle's own option: the column-blocked form is released
+    assert E.kernel == "k_ell_spmv"
+    y2 = torch.zeros(n, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    E.matvec(x, y2)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, ref)
 
 
 def test_full_size_c5_464_cubed_every_row_bit_exact_and_cg_energy():
@@ -2968,6 +2957,7 @@ def test_fortran_host_layer_reaches_the_whole_surface():
     out = r.stdout.replace("\n ", "")          # (list-directed output wraps at 80 columns)
     for line in ("hip_csr_from_edges: arrays and product identical", "composite: hip_cg iterations", "hip_lanczos: recurrence",
                  "hip_generalized_lanczos: three-term recurrence", "device vectors: the same solve, bit for bit",
+                 "ILDU-PCG iterations: natural order",
                  "all sigma_hip surface checks passed"):
         assert line in out, r.stdout
 
@@ -2993,7 +2983,8 @@ def test_reference_side_binding_runs_the_references_own_tests():
     # round 4: the flows of the reference's remaining solver / matvec / eigensolver tests and the composite, hip types
     for line in ("jacobi flow: stationary iteration error", "jacobi flow: hip_cg + hip_jacobi error",
                  "jacobi flow: hip_bicgstab + hip_jacobi on the perturbed matrix", "incomplete cholesky flow: stationary iteration error",
-                 "incomplete cholesky flow: hip_cg + hip_ldu error", "matvec / matvec_t against the dense product: within 1e-15",
+                 "incomplete cholesky flow: hip_cg + hip_ldu error", "incomplete cholesky flow: hip_cg + hip_ldu(reorder = colour) error",
+                 "matvec / matvec_t against the dense product: within 1e-15",
                  "hip_csr_from_edges: ptr / node / val and products identical",
                  "composite (2 x 2 hip leaves): block loop and one-handle product bit-identical", "composite: reference cg iterations",
                  "hip_lanczos: three-term recurrence and orthogonality within 1e-14", "hip_generalized_lanczos: recurrence within 1e-14"):

@@ -35,8 +35,8 @@ for n, lo, hi, band in CASES:
     moved = 12 * nnz + 4 * n + 16 * n
     ys = []
     for sell, rowline in KERNELS:
-        sg.set_option("csr_sell", sell)
-        sg.set_option("csr_row_lines", rowline)
+        A.set_option("csr_sell", sell)
+        A.set_option("csr_row_lines", rowline)
         y = torch.zeros_like(x)
         for _ in range(min(5, REPS)): A.matvec(x, y)
         torch.cuda.synchronize()
@@ -58,6 +58,4 @@ for n, lo, hi, band in CASES:
         print(json.dumps({"n": n, "nnz_per_row": [lo, hi], "kernel": A.kernel, "us": round(us, 1), "moved_GB": round(moved / 1e9, 3),
                           "TBs": round(moved / us / 1e6, 3), "frac_of_8TBs": round(moved / us / 8e6, 3), "rows_bit_exact": bool(ok)}), flush=True)
     if len(ys) > 1: print(json.dumps({"kernels_bit_identical": bool(all(torch.equal(ys[0], yy) for yy in ys[1:]))}), flush=True)
-    sg.set_option("csr_row_lines", 1)
-    sg.set_option("csr_sell", 1)
     A.destroy()

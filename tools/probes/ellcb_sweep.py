@@ -11,8 +11,7 @@ sg.init(0)
 dev = torch.device("cuda", 0)
 st = torch.cuda.Stream(device=dev); torch.cuda.set_stream(st); sg.use_torch_stream(); sg.set_async(True)
 n = 5_000_000
-ei, ej, ev = P.random_regular_ell(n, 32, 12345)
-node, val = ej.reshape(n, 32), ev.reshape(n, 32)
+node, val = P.random_regular_ell_torch(n, 32, 12345, dev)
 x = torch.sin(0.001 * torch.arange(1, n + 1, dtype=torch.float64, device=dev))
 y = torch.zeros(n, dtype=torch.float64, device=dev)
 def timed(A, reps=20):
@@ -23,11 +22,11 @@ def timed(A, reps=20):
     for _ in range(reps): A.matvec(x, y)
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps * 1e3
-for cols in (16384, 8192):
+for cols in (20480, 16384, 8192):
     sg.set_option("ell_colblock_cols", cols)
     A = sg.ellpack_matrix(n, n, node, val)
     for chunks in (4, 8, 16):
-        sg.set_option("ell_colblock_chunks", chunks)
+        __import__("os").environ["SGM_ELLCB_CHUNKS"] = str(chunks); A.set_option("ell_colblock", 0); A.set_option("ell_colblock", 1)
         print(json.dumps({"cols": cols, "chunks": chunks, "grid2": int(__import__("os").environ.get("SGM_ELLCB_GRID", 2048)), "us": timed(A), "kernel": A.kernel}), flush=True)
     A.destroy()
 ''' % ROOT

@@ -38,12 +38,12 @@ def main():
                "sched": os.environ.get("SGM_SLICE_SCHED", "default"), "cfg": os.environ.get("SGM_SPMV_CFG", "default"),
                "us": round(t * 1e6, 1), "moved_TBs": round(moved / t / 1e12, 3), "frac": round(moved / t / 8e12, 3)}
         if os.environ.get("PROBE_CHECK", "1") == "1":
-            sg.set_option("csr_sliced", 0)
+            A.set_option("csr_sliced", 0)
             y2 = torch.zeros(n, dtype=torch.float64, device=dev)
             A.matvec(x, y2)
             sg.synchronize()
             out["bit_identical_to_dict_kernel"] = bool(torch.equal(y, y2))
-            sg.set_option("csr_sliced", 1)
+            A.set_option("csr_sliced", 1)
             del y2
         print(json.dumps(out), flush=True)
         del A, x, y

@@ -60,14 +60,14 @@ def main():
         alg = 12 * nnz + 4 * (n + 1) + 16 * n
         w = next(k for k in (3, 5, 7, 8) if k >= (nnz + n - 1) // n)
         for name, opt, sl in (("sliced", 1, 1), ("dict", 1, 0), ("int32", 0, 0)):
-            sg.set_option("csr_offset_dict", opt)
-            sg.set_option("csr_sliced", sl)
+            A.set_option("csr_offset_dict", opt)
+            A.set_option("csr_sliced", sl)
             t = timed(lambda: A.matvec(x, y), 20)
             stored = ((8 * w + 4) * n + 16 * n) if sl else (9 if opt else 12) * nnz + 4 * (n + 1) + 16 * n
             out[name] = {"us": round(t * 1e6, 1), "frac_alg": round(alg / t / 8e12, 3),
                          "stored_TBs": round(stored / t / 1e12, 2)}
-        sg.set_option("csr_offset_dict", 1)
-        sg.set_option("csr_sliced", 1)
+        A.set_option("csr_offset_dict", 1)
+        A.set_option("csr_sliced", 1)
         print(json.dumps(out), flush=True)
         del A, x, y
         torch.cuda.empty_cache()

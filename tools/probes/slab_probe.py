@@ -35,7 +35,7 @@ for nx, ny, nz in shapes:
         print("   chain start/end us per (group, strip):", rows[:8], "...", rows[-4:])
         out["chain_ns_per_step"] = float(np.median((ck[:, 1] - ck[:, 0]) * 10.0 / st[3]))
         out["sweep_us_by_clocks"] = float((ck[:, 1].max() - t0c) / 100.0)
-    sg.set_option("ildu_strips", 0)
+    pc.set_option("ildu_strips", 0)
     for _ in range(2):
         pc.solve(A, z, r)
     torch.cuda.synchronize()
@@ -44,5 +44,5 @@ for nx, ny, nz in shapes:
         pc.solve(A, z, r)
     torch.cuda.synchronize()
     out["apply_us_level_walkers"] = (time.perf_counter() - t0) / 5 * 1e6
-    sg.set_option("ildu_strips", 1)
+    pc.set_option("ildu_strips", 1)
     print(json.dumps(out), flush=True)

@@ -19,7 +19,7 @@ for arg in sys.argv[1:]:
     st = pc.get("slabs", np.int32).tolist()
     r = torch.from_numpy(rs.standard_normal(n)).cuda()
     z = torch.zeros_like(r); zref = torch.zeros_like(r)
-    sg.set_option("ildu_strips", 0); pc.solve(A, zref, r); sg.set_option("ildu_strips", 1)
+    pc.set_option("ildu_strips", 0); pc.solve(A, zref, r); pc.set_option("ildu_strips", 1)
     bad = 0; first = None
     for k in range(reps):
         z.zero_()
@@ -43,7 +43,7 @@ if os.environ.get("SLAB_STRESS_MIXED"):
         rs = np.random.RandomState(2)
         r = torch.from_numpy(rs.standard_normal(n)).cuda()
         z = torch.zeros_like(r); zref = torch.zeros_like(r)
-        sg.set_option("ildu_strips", 0); pc.solve(A, zref, r); sg.set_option("ildu_strips", 1)
+        pc.set_option("ildu_strips", 0); pc.solve(A, zref, r); pc.set_option("ildu_strips", 1)
         bad = 0; first = None
         for k in range(300):
             z.zero_()

@@ -63,13 +63,13 @@ def check(tag, A, H, bad):
     b = np.random.RandomState(A.n).standard_normal(A.n)
     want = ref.solve(b)
     for rows_on, strips_on in ((1, 1), (0, 1), (1, 0), (2, 0), (0, 0)):
-        sg.set_option("ildu_rows", rows_on); sg.set_option("ildu_strips", strips_on)
+        pc.set_option("ildu_rows", rows_on); pc.set_option("ildu_strips", strips_on)
         if os.environ.get("STRESS_TRACE"):
             print("    apply", rows_on, strips_on, flush=True); sg.synchronize()
         z = np.zeros(A.n); pc.solve(H, z, b)
         if not np.array_equal(z, want, equal_nan=True):
             bad.append((tag, "apply", rows_on, strips_on))
-    sg.set_option("ildu_rows", 1); sg.set_option("ildu_strips", 1)
+    pc.set_option("ildu_rows", 1); pc.set_option("ildu_strips", 1)
     v2 = A.val * (1.0 + 0.1 * np.cos(np.arange(A.val.size)))
     H.set_values(v2); pc.setup(H)
     A2 = orc.CsrMatrix(A.n, A.n, A.ptr, A.node, v2)
