@@ -2293,6 +2293,45 @@ def test_residual_history_exact_in_reference_dot_order(orc, dot_order_1):
                     assert np.array_equal(x, xr), (fn.__name__, pk, small)
 
 
+@pytest.mark.parametrize("what", ["ildu", "three_parts", "one_launch"])
+def test_default_dot_order_launch_loop_against_the_exact_mode_at_2e5(orc, what):
+    """the PRODUCTION order of the dot products (tree) is checked where the exact mode
+    (dot_order = 1, bit-identical to the reference) is still affordable AND the launch loop -- not the one-workgroup
+    kernels -- runs: n = 448 x 448 = 200704, ILDU(0)-PCG (strip-pipelined sweeps), CG on three in-process row blocks, and
+    the cooperative one-launch CG.  Gate: same iteration count +-1, solutions within 1e-12 relative of the exact mode's,
+    the first 50 residuals within 1e-12 relative."""
+    nx = 448
+    n = nx * nx
+    ptr, node, val = P.poisson2d_csr(nx, nx)
+    b = np.sin(0.01 * np.arange(1, n + 1))
+    tol = 1e-9
+
+    def run(dot_order):
+        if what == "three_parts":
+            H = sg.partitioned_csr_matrix(n, n, ptr, node, val, sg.partition_rows_by_nnz(ptr, 3, align=512))
+        else:
+            H = sg.csr_matrix(n, n, ptr, node, val)
+        pc = None
+        if what == "ildu":
+            pc = sg.ldu(); pc.setup(H)
+        s = sg.cg(tol)
+        s.set_history(50)
+        s.set_option("dot_order", dot_order)
+        if what != "one_launch":
+            s.set_option("cg_small", 0)
+        s.setup(H)
+        u = np.zeros(n)
+        s.solve(H, u, b, pc)
+        return u, s.iterations, np.array(s.history)
+
+    u1, it1, h1 = run(1)                 # the reference's order
+    u0, it0, h0 = run(0)                 # the default
+    assert abs(it0 - it1) <= 1, (what, it0, it1)
+    assert np.abs(u0 - u1).max() <= 1e-12 * np.abs(u1).max() * max(1.0, 1e3 * tol / 1e-9), (what, np.abs(u0 - u1).max() / np.abs(u1).max())
+    k = min(len(h0), len(h1), 50)
+    assert np.abs(h0[:k] - h1[:k]).max() <= 1e-12 * h1[:k].max(), (what, np.abs(h0[:k] - h1[:k]).max() / h1[:k].max())
+
+
 def test_reference_dot_order_on_partitions_and_odd_sizes(orc, dot_order_1):
     """dot_order = 1 beyond the one-workgroup sizes and across in-process partitions: the running sum is handed from one
     part's k_dot_seq to the next, so a P-way partitioned solve adds the same products in the same global order -- iterates
@@ -2703,7 +2742,7 @@ def test_rccl_single_rank(orc):
 # ------------------------------------------------------- full benchmark size (BASELINE C2)
 def test_full_size_properties():
     """5-point Poisson at nx=ny=3162 (n = 9,998,244): properties that do not need the
-    oracle -- exact row sums for x = 1, sampled rows recomputed on the host in the stored
+    oracle -- exact row sums for x = 1, EVERY row against a torch evaluation in the stored
     order (bit-exact), linearity in exact arithmetic cases, and CG monotonic energy."""
     import torch
     nx = ny = 3162
@@ -2717,13 +2756,17 @@ def test_full_size_properties():
     assert np.array_equal(y, expect)
     x = P.test_vector(n)
     A.matvec(x, y)
-    rs = np.random.RandomState(0)
-    rows = np.unique(np.concatenate([rs.randint(0, n, 20000), [0, 1, nx - 1, nx, n - nx, n - 1]]))
-    for r in rows:
-        z = 0.0
-        for k in range(ptr[r] - 1, ptr[r + 1] - 1):
-            z = z + val[k] * x[node[k] - 1]
-        assert y[r] == 0.0 + z
+    # EVERY row against its sum in stored order (S, W, C, E, N as inserted), evaluated by torch one slot at a time --
+    # products rounded, then added: an independent evaluation of csr_matvec_add's loop (cs_matrices.f90:611-620)
+    dev = torch.device("cuda", 0)
+    tp, tn, tv = torch.from_numpy(ptr.astype(np.int64)).to(dev), torch.from_numpy(node.astype(np.int64) - 1).to(dev), torch.from_numpy(val).to(dev)
+    start, ln = tp[:-1] - 1, tp[1:] - tp[:-1]
+    cols = torch.stack([tn[torch.clamp(start + k, max=tn.numel() - 1)] for k in range(5)], dim=1)
+    vals = torch.stack([tv[torch.clamp(start + k, max=tn.numel() - 1)] for k in range(5)], dim=1)
+    mask = torch.stack([ln > k for k in range(5)], dim=1)
+    ref = 0.0 + _torch_rowsum_in_stored_order(cols, vals, mask, torch.from_numpy(x).to(dev))
+    assert torch.equal(ref, torch.from_numpy(y).to(dev))
+    del tp, tn, tv, cols, vals, mask, ref
     # scaling x by a power of two scales y exactly
     y2 = np.zeros(n)
     A.matvec(4.0 * x, y2)

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """ILDU(0)-PCG vs Jacobi-PCG vs CG on a 2-D Poisson grid: iterations and time (one GPU).
-  python tools/ildu_bench.py <nx> [cg,jacobi,ildu0] [colour]
+  python tools/ildu_bench.py <nx> [cg,jacobi,ildu0,ildu0_reorder] [colour]
 `colour`: the matrix is first re-ordered by the reference's own greedy_color_ordering
-(permutations.f90) and permuted symmetrically -- ILDU(0) then has as many dependency levels as colours."""
+(permutations.f90) and permuted symmetrically -- ILDU(0) then has as many dependency levels as colours.
+`ildu0_reorder`: sg.ldu(reorder="colour") on the matrix AS IT IS -- the colour ordering inside the preconditioner."""
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -34,7 +35,7 @@ if colour:
     b = bp
     print(json.dumps({"grid": nx, "reordering": "greedy_color_ordering", "colours": nc, "ordering_s": t1 - t0,
                       "permute_s": t2 - t1}), flush=True)
-for name, mk in (("cg", None), ("jacobi", sg.jacobi), ("ildu0", sg.ldu)):
+for name, mk in (("cg", None), ("jacobi", sg.jacobi), ("ildu0", sg.ldu), ("ildu0_reorder", lambda: sg.ldu(reorder="colour"))):
     if name not in only:
         continue
     pc = mk() if mk else None
@@ -53,7 +54,9 @@ for name, mk in (("cg", None), ("jacobi", sg.jacobi), ("ildu0", sg.ldu)):
     dt = time.time() - t0
     its = s.iterations - it0
     extra = {}
-    if name == "ildu0":
+    if name == "ildu0_reorder":
+        extra["reorder_ms"] = dict(zip(("ordering", "permuted_copy", "setup_on_copy", "colours"), pc.get("reorder_ms", np.float64).tolist()))
+    if name.startswith("ildu0"):
         extra["levels"] = pc.get("levels", np.int32).tolist()
         extra["strips"] = pc.get("strips", np.int32).tolist()
         extra["slabs"] = pc.get("slabs", np.int32).tolist()

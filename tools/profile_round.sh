@@ -5,34 +5,34 @@ cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_round
 rm -rf $OUT; mkdir -p $OUT
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo bench=$?
-BARGS="--steps 2 --warmup 1 --spmv-per-step 64 --cg-steps 30 --no-cpu --no-c5 --no-dist-overhead --no-pcg"
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py $BARGS > $OUT/stats.log 2>&1
-PARGS="--steps 1 --warmup 1 --spmv-per-step 4 --cg-steps 0 --no-cpu --no-c5 --no-variants --no-dist-overhead --no-pcg"
-timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python bench.py $PARGS > $OUT/pmc1.log 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python bench.py $PARGS > $OUT/pmc2.log 2>&1
+BARGS="--steps 2 --warmup 1 --spmv-per-step 64 --cg-steps 30 --no-cpu --no-c5 --no-c3 --no-c4 --no-dist-overhead --no-pcg"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py $BARGS > $OUT/stats.log 2>&1
+PARGS="--steps 1 --warmup 1 --spmv-per-step 4 --cg-steps 0 --no-cpu --no-c5 --no-c3 --no-c4 --no-variants --no-dist-overhead --no-pcg"
+timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $PARGS > $OUT/pmc1.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py $PARGS > $OUT/pmc2.log 2>&1
 # HBM bytes of the CG update kernels (k_elem<FCgR / FCgPX>) and of the C5 product (k_csr_sl<7>, 464^3): their own PMC passes
-QARGS="--steps 1 --warmup 1 --spmv-per-step 2 --cg-steps 10 --c5-cg-steps 4 --no-cpu --no-variants --no-dist-overhead --no-pcg"
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_cg_c5 -- python bench.py $QARGS > $OUT/pmc3.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_cg_c5 -- python bench.py $QARGS > $OUT/pmc4.log 2>&1
+QARGS="--steps 1 --warmup 1 --spmv-per-step 2 --cg-steps 10 --c5-cg-steps 4 --no-cpu --no-c3 --no-c4 --no-variants --no-dist-overhead --no-pcg"
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_cg_c5 -- python3 bench.py $QARGS > $OUT/pmc3.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_cg_c5 -- python3 bench.py $QARGS > $OUT/pmc4.log 2>&1
 # ILDU(0)-PCG on the 1000^2 grid: per-kernel times of the triangular solves
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ildu -- python tools/ildu_bench.py 1000 ildu0 > $OUT/stats_ildu.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ildu -- python3 tools/ildu_bench.py 1000 ildu0 > $OUT/stats_ildu.log 2>&1
 # ILDU(0)-PCG on the 100^3 grid: the slab-pipelined triangular solves
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ildu3 -- python tools/ildu_bench.py -100 ildu0 > $OUT/stats_ildu3.log 2>&1 < /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ildu3 -- python3 tools/ildu_bench.py -100 ildu0 > $OUT/stats_ildu3.log 2>&1 < /dev/null
 # colour-ordered ILDU(0)-PCG at C2 size (row-space level sweeps): per-kernel times
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ildu_colour -- python tools/ildu_bench.py 3162 ildu0 colour > $OUT/stats_ildu_colour.log 2>&1 < /dev/null
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ildu_colour -- python3 tools/ildu_bench.py 3162 ildu0 colour > $OUT/stats_ildu_colour.log 2>&1 < /dev/null
 # time to solution: CG / Jacobi-PCG / ILDU(0)-PCG in natural and colour order, with the setup phases (SGM_PC_TIMING)
-for a in "1000 cg,jacobi,ildu0" "1000 cg,ildu0 colour" "3162 cg,ildu0" "3162 cg,ildu0 colour" "-100 cg,jacobi,ildu0" "-100 cg,ildu0 colour"; do
+for a in "1000 cg,jacobi,ildu0,ildu0_reorder" "1000 cg,ildu0 colour" "3162 cg,ildu0,ildu0_reorder" "3162 cg,ildu0 colour" "-100 cg,jacobi,ildu0,ildu0_reorder" "-100 cg,ildu0 colour"; do
   echo "== tools/ildu_bench.py $a"
   SGM_PC_TIMING=1 timeout 600 python tools/ildu_bench.py $a 2>&1 | grep -E '^\{|ildu setup'
 done > $OUT/time_to_solution.log 2>&1
 # C3 GMRES(30): blocked CGS-2 vs modified Gram-Schmidt (launch counts per step come out of the Calls column)
-SGM_GMRES_CGS2=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_cgs2 -- python tools/bench_configs.py --configs c3 > $OUT/c3_cgs2.log 2>&1
-SGM_GMRES_CGS2=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_mgs -- python tools/bench_configs.py --configs c3 > $OUT/c3_mgs.log 2>&1
+SGM_GMRES_CGS2=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_cgs2 -- python3 tools/bench_configs.py --configs c3 > $OUT/c3_cgs2.log 2>&1
+SGM_GMRES_CGS2=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_mgs -- python3 tools/bench_configs.py --configs c3 > $OUT/c3_mgs.log 2>&1
 # C4 / C5: per-kernel times
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_configs -- python tools/bench_configs.py --configs c4,c5 > $OUT/configs.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_configs -- python3 tools/bench_configs.py --configs c4,c5 > $OUT/configs.log 2>&1
 grep -h '^{' $OUT/c3_cgs2.log $OUT/c3_mgs.log $OUT/configs.log > $OUT/configs.jsonl
 cat $OUT/bench.json | cut -c1-600
 # the bench line once more, now that this round's PMC passes exist: condense them on the box (profiles/r03/pmc_hbm_traffic.json
 # with the fingerprint of the sources that just ran) so that `roofline.traffic` of the line is this run's own figure
-python tools/collect_profiles.py ${TAG:-r03} > /dev/null 2>&1
+python tools/collect_profiles.py ${TAG:-r04} > /dev/null 2>&1
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo bench_with_traffic=$?
