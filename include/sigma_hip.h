@@ -87,7 +87,7 @@ int sgm_synchronize(void);
  *                          instead of 1.13 GB); its CSR-order arrays are rebuilt on the device for whoever reads them
  *   "ell_colblock" (1)     ELLPACK matrices whose columns have no locality (x >= 16 MB, >= 8 slots per row): column-blocked
  *                          two-phase product (products through LDS-resident x blocks, then ordered row sums); 0 never, 2 always
- *   "ell_colblock_cols" (16384, <= 20480 = 160 KiB of LDS)  x entries per block
+ *   "ell_colblock_cols" (16384 = 128 KiB of LDS, the maximum)  x entries per block
  *   "ell_colblock_rows" (0 = automatic; 256 or 512)  rows per tile of the second phase
  *   "slice_sched" (0)      sliced matrices most of whose rows carry a far offset (the plane stride of a 3-D grid): the slices
  *                          are handed to the XCDs tile by tile -- the plane is cut into bands (1 = of 64 slices, n > 1 = of n

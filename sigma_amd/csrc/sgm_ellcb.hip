@@ -371,7 +371,8 @@ int build_ell_colblock(Part &p)
     const int want_rows = rows_env ? rows_env : p.opt.ell_colblock_rows;
     int32_t R = std::min(256, 8192 / p.max_d) / 64 * 64;
     if ((want_rows == 512 || (want_rows == 0 && p.max_d >= 16)) && p.max_d <= 32) R = 512;
-    if (want_rows == 608 && p.max_d <= 32) R = 608;          // 152 KiB image: with 20480-column blocks the runs are 48 % longer than at 512 / 16384
+    // (round 4: 20480-column blocks and a 152 KiB image of 608 rows -- runs 48 % longer -- measured SLOWER, 1222 / 1171 / 1321 us
+    //  against 1134: profiles/r04/c4_cols_rows_sweep.jsonl; the run length is not what bounds the second phase)
     if (R < 64) return SGM_OK;
     const int32_t ntiles = (p.n + R - 1) / R;
     p.cb_cols = cb; p.cb_nb = nb; p.cb_R = R; p.cb_ntiles = ntiles; p.cb_chunks = getenv("SGM_ELLCB_CHUNKS") ? std::max(1, atoi(getenv("SGM_ELLCB_CHUNKS"))) : 16;
@@ -422,8 +423,8 @@ static void launch_sum(const Part &p, int grid, double *y, const double *w, doub
 {
     hipStream_t st = g_rt.stream;
     const size_t lds = (size_t)p.cb_R * p.max_d * 8;
-    constexpr bool BIG = R >= 512;                   // 128 KiB image (R = 512; 152 KiB at R = 608), 1024 threads, whole-wave runs
-    constexpr int MAXD = (R == 608 ? 19456 : BIG ? 16384 : 8192) / R;   // the longest row a tile of R rows allows
+    constexpr bool BIG = R == 512;                   // 128 KiB image, 1024 threads, whole-wave runs
+    constexpr int MAXD = (BIG ? 16384 : 8192) / R;   // the longest row a tile of R rows allows
     constexpr int TPB = BIG ? 1024 : 2 * R;          // twice as many waves copy runs as there are rows (C4: 696 -> see DESIGN)
 #define L(DW, DY)                                                                                                     \
     do {                                                                                                              \
@@ -457,7 +458,7 @@ int launch_ell_colblock(const Part &p, int grid, const double *x, double *y, boo
         if (add) launch_sum<RR, true>(p, grid, y, w, pwy, pyy, flag, gen, chain ? 1 : 0);        \
         else launch_sum<RR, false>(p, grid, y, w, pwy, pyy, flag, gen, 0);                       \
     }
-    R_CASE(64) R_CASE(128) R_CASE(192) R_CASE(256) R_CASE(512) R_CASE(608)
+    R_CASE(64) R_CASE(128) R_CASE(192) R_CASE(256) R_CASE(512)
 #undef R_CASE
     SGM_HIP(hipGetLastError());
     return SGM_OK;

@@ -35,7 +35,7 @@ int fail(int code, const char *fmt, ...);
 // Options are PER HANDLE: a matrix / solver / preconditioner copies the process-wide defaults (sgm_set_option) when it
 // is created and keeps its own copy from then on (sgm_mat_set_option / sgm_solver_set_option / sgm_pc_set_option); two
 // handles of one process may run different kernels, and changing a default never touches an existing handle.
-constexpr int kEllcbMaxCols = 20480;   // x entries of one column block = 160 KiB of LDS, all a gfx950 workgroup may have
+constexpr int kEllcbMaxCols = 16384;   // x entries of one column block = 128 KiB of LDS (20480 = all 160 KiB measured slower: profiles/r04/c4_cols_rows_sweep.jsonl)
 struct MatOptions {
     int csr_offset_dict = 1;       // use the 1-byte column code kernel when a matrix allows it
     int ell_offset_dict = 1;       // ELLPACK twin of csr_offset_dict (max_d <= 16)

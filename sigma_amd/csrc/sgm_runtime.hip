@@ -110,7 +110,7 @@ int normalise_option(const char *name, int value, int *out)
 {
     int v = value;
     if (!strcmp(name, "ell_colblock_cols")) v = std::min(kEllcbMaxCols, std::max(2, value)) & ~1;
-    else if (!strcmp(name, "ell_colblock_rows")) v = value == 608 ? 608 : value == 512 ? 512 : value == 256 ? 256 : 0;
+    else if (!strcmp(name, "ell_colblock_rows")) v = value == 512 ? 512 : value == 256 ? 256 : 0;
     else if (!strcmp(name, "ildu_reorder")) v = value != 0;
     else if (!strcmp(name, "csr_sell")) v = value < 0 ? 0 : value > 2 ? 2 : value;
     else if (!strcmp(name, "csr_lean")) v = value != 0;

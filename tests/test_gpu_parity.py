@@ -539,8 +539,7 @@ def test_randomised_ellpack_every_kernel_vs_oracle(orc, max_d):
 @pytest.mark.parametrize("n,max_d,dmin,cols,chunks,rows", [
     (3000, 32, None, 64, 3, 0), (1000, 7, 3, 16, 1, 0), (70001, 32, 24, 2048, 8, 256),
     (513, 9, None, 2, 2, 0), (5000, 100, 60, 256, 2, 0), (20000, 16, None, 16384, 8, 0),
-    (70001, 32, 24, 2048, 8, 512), (4000, 40, 20, 128, 2, 0), (3000, 32, None, 64, 3, 256),
-    (50000, 32, None, 20480, 4, 0)])
+    (70001, 32, 24, 2048, 8, 512), (4000, 40, 20, 128, 2, 0), (3000, 32, None, 64, 3, 256)])
 def test_ell_column_blocked_two_phase_vs_oracle(orc, n, max_d, dmin, cols, chunks, rows):
     """k_ellcb (sgm_ellcb.hip): the two-phase product for ELLPACK matrices with random columns -- products
     through LDS-resident column blocks of x, then row sums in slot order from an LDS image of the tile's
