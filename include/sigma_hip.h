@@ -92,8 +92,9 @@ int sgm_synchronize(void);
  *   "slice_sched" (0)      sliced matrices most of whose rows carry a far offset (the plane stride of a 3-D grid): the slices
  *                          are handed to the XCDs tile by tile -- the plane is cut into bands (1 = of 64 slices, n > 1 = of n
  *                          slices), XCD x sweeps bands x, x + 8, ... plane after plane, so that the three planes a band reads
- *                          share ONE XCD's L2.  464^3: fabric reads 9.9 -> 7.1 GB per product (band 8), time -4 %
- *                          (profiles/r04/c5_slice_sched_sweep.txt); only the order of whole slices changes
+ *                          share ONE XCD's L2.  464^3: fabric reads 9.9 -> 8.6 GB per product with bands of 64, 7.1 GB
+ *                          with bands of 8 -- and the time stays within run-to-run noise (the re-fetched planes were
+ *                          Infinity-Cache hits; profiles/r04/c5_slice_sched_sweep.txt), hence off; only the ORDER of whole slices changes
  * Solver options
  *   "cg_small" (1)         CG (plain / Jacobi) with the WHOLE SOLVE in one launch: on a single-GPU matrix of <= 10240 rows
  *                          (stencil; 4096 otherwise) and <= 49k stored slots as ONE workgroup -- p in LDS, x and r in

@@ -48,7 +48,9 @@ struct MatOptions {
     int ell_colblock_cols = 16384; // its column block: x entries staged in LDS per workgroup (even, <= kEllcbMaxCols)
     int ell_colblock_rows = 0;     // rows per tile of its sum phase: 0 automatic, 256 or 512
     int slice_sched = 0;           // sliced kernels on matrices with a far stencil offset (3-D grids): tile-ordered slice schedule per XCD;
-                                   // 0 off, 1 = bands of 64 slices, n > 1 = bands of n slices
+                                   // 0 off, 1 = bands of 64 slices, n > 1 = bands of n slices.  Off: the counters drop (fabric reads 9.9 ->
+                                   // 8.6 / 7.1 GB at 464^3) but the time is within run-to-run noise of the computed maps (round 4: 1514 -> 1456 us
+                                   // in one sweep, 1512 -> 1527 in the next; CG 367 -> 354 it/s): profiles/r04/c5_slice_sched_sweep.txt
 };
 struct SolverOptions {
     int cg_small = 1;              // CG (plain or Jacobi) on a small CSR matrix: the whole solve in one workgroup (k_cg_small);

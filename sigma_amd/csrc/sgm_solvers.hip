@@ -947,6 +947,7 @@ struct sgm_solver_s {
     std::vector<PartWork> work;
     std::vector<double> history;
     bool multi = false;
+    bool reduce_single = false;       // one part: collapse every dot to its slot with a one-block kernel (see finish_dots)
     // cooperative CG (k_cg_coop): exchange vector + dot slots + {counter, abort}; the counter is monotonic across launches
     double *coop_buf = nullptr;
     int coop_base = 0, coop_reach = -1;
@@ -980,7 +981,7 @@ void free_work(sgm_solver s)
 ScalarRef ref(sgm_solver s, size_t ip, int k)
 {
     PartWork &w = s->work[ip];
-    if (s->multi || s->seq) return ScalarRef{w.slots + k, 1};
+    if (s->multi || s->seq || s->reduce_single) return ScalarRef{w.slots + k, 1};
     return ScalarRef{w.partials + (size_t)k * kMaxGrid, w.count[k]};
 }
 double *part(sgm_solver s, size_t ip, int k) { return s->work[ip].partials + (size_t)k * kMaxGrid; }
@@ -1027,6 +1028,15 @@ int finish_dots(sgm_solver s, sgm_mat A, const int *ks, int nk, const int (*vecs
             if (ranks) SGM_TRY(seq_chain_share(A, s->work[0].slots + ks[t]));
             t += nd;
         }
+        return SGM_OK;
+    }
+    if (s->reduce_single) {
+        // one part, a solver whose update kernels each read many scalars (BiCGStab: up to six), a large system: every dot is
+        // collapsed ONCE by a one-block kernel instead of being re-reduced from its <= 4096 partials by each of the 2048
+        // workgroups of every consumer (k_reduce IS load_scalar: same order, same bits)
+        for (int t = 0; t < nk; ++t)
+            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, g_rt.stream, part(s, 0, ks[t]), s->work[0].count[ks[t]],
+                               s->work[0].slots + ks[t]);
         return SGM_OK;
     }
     if (!s->multi) return SGM_OK;
@@ -2454,6 +2464,11 @@ int sgm_solver_setup(sgm_solver s, sgm_mat A)
     s->nn = A->nrow;
     s->iterations = 0;          // cg_solvers.f90:72
     s->multi = A->distributed();
+    {
+        static const int rs_env = getenv("SGM_REDUCE_SINGLE") ? atoi(getenv("SGM_REDUCE_SINGLE")) : -1;      // tuning aid
+        s->reduce_single = !s->multi && A->fmt != SGM_FMT_COMPOSITE && s->kind == SGM_SOLVER_BICGSTAB &&
+                           (rs_env >= 0 ? rs_env != 0 : A->nrow >= (1 << 21));
+    }
     bool realloc = !s->initialized || s->work.size() != A->parts.size();
     for (size_t ip = 0; !realloc && ip < A->parts.size(); ++ip)
         realloc = s->work[ip].n != A->parts[ip].n || s->work[ip].next != A->parts[ip].xlen();

@@ -240,3 +240,54 @@ def test_every_documented_option_is_accepted_and_unknown_names_are_refused():
     assert lib.sgm_set_option(b"dot_order", 2) != 0
     # the per-handle setters refuse a null handle instead of dereferencing it
     assert lib.sgm_solver_set_option(None, b"dot_order", 1) != 0 and lib.sgm_pc_set_option(None, b"ildu_rows", 1) != 0
+
+
+def test_device_side_generators_reproduce_the_numpy_ones():
+    """bench.py generates C3 / C4 / C5 on the device with torch (sigma_amd.problems.*_torch); here the same functions on
+    the CPU against the numpy generators the golden fixtures and the oracle tests use -- entry for entry."""
+    import torch
+    dev = torch.device("cpu")
+    for a, b in ((P.tridiag_csr(257, 2.0, -0.9, -1.1), P.tridiag_csr_torch(257, 2.0, -0.9, -1.1, dev)),
+                 (P.laplace3d_csr(7, 5, 4), P.laplace3d_rows_torch(7, 5, 4, dev))):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y.numpy())
+    # a z-slab of the 3-D grid = the same rows of the whole matrix (local ptr, global columns)
+    ptr, node, val = P.laplace3d_csr(6, 5, 7)
+    p2, n2, v2 = (t.numpy() for t in P.laplace3d_rows_torch(6, 5, 7, dev, z0=2, z1=5))
+    r0, r1 = 2 * 30, 5 * 30
+    assert np.array_equal(p2, ptr[r0:r1 + 1] - ptr[r0] + 1)
+    assert np.array_equal(n2, node[ptr[r0] - 1:ptr[r1] - 1]) and np.array_equal(v2, val[ptr[r0] - 1:ptr[r1] - 1])
+    n = 3000
+    ei, ej, ev = P.random_regular_ell(n, 32, 12345)
+    node, val = P.random_regular_ell_torch(n, 32, 12345, dev, chunk=1000)
+    assert np.array_equal(node.numpy(), ej.reshape(n, 32)) and np.array_equal(val.numpy(), ev.reshape(n, 32))
+
+
+def test_heartbeat_is_readable_without_a_gpu_and_from_any_thread():
+    hb = sg.heartbeat()
+    assert hb["phase_code"] == 0 and hb["phase"].startswith("idle") and hb["halo_posts"] == 0
+
+
+def test_bench_watchdog_ends_a_process_that_stops_making_progress(tmp_path):
+    """bench.Heartbeat: a rank whose phase does not change for --stall-s prints where it is and exits 86 (here a process that
+    simply sleeps; on the GPU box tests/test_gpu_multirank.py stalls a rank inside a halo exchange)."""
+    import subprocess
+    import sys
+    import time
+    code = ("import sys, time; sys.path.insert(0, %r)\n"
+            "import bench\n"
+            "hb = bench.Heartbeat(3, 1.5, 100.0)\n"
+            "hb.phase('c2: timed steps (test)')\n"
+            "time.sleep(60)\n" % ROOT)
+    env = dict(os.environ, SGM_BENCH_HB_DIR=str(tmp_path))
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 86 and time.time() - t0 < 30
+    assert "rank 3 STALLED" in p.stderr and "c2: timed steps (test)" in p.stderr
+    import json
+    st = json.load(open(tmp_path / "rank3.hb"))
+    assert st["phase"] == "c2: timed steps (test)" and "no heartbeat" in st["stalled"]
+    # ... and the deadline on a process that keeps beating
+    code2 = code.replace("1.5, 100.0", "50.0, 2.0").replace("time.sleep(60)", "\nfor i in range(600):\n    hb.phase(f'step {i}'); time.sleep(0.1)")
+    p = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 86 and "past --deadline-s" in p.stderr
