@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "../../include/sigma_hip.h"
@@ -226,7 +227,11 @@ struct sgm_comm_s {
     void *nccl_halo = nullptr;     // optional second communicator: the halo send / recv pairs (sgm_comm_attach_halo_comm)
 };
 
+// every matrix handle has a serial number of its own, and a version that every change of its entries or their order bumps:
+// what a cached derivative (a preconditioner's permuted copy) checks before it stands in for the matrix
+inline uint64_t next_mat_serial() { static std::atomic<uint64_t> c{0}; return ++c; }
 struct sgm_mat_s {
+    uint64_t serial = next_mat_serial(), version = 0;
     int32_t fmt = 0;
     int32_t nrow = 0, ncol = 0;    // global
     int64_t nnz = 0;               // global (local sum when distributed)
@@ -315,12 +320,49 @@ void slab3_free(Slab3 *S);
 #if defined(__HIPCC__)
 namespace sgm {
 
+// Sum over the 64 lanes of a wave, every lane the same bits: the butterfly
+//     for (off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+// without its six trips through the LDS crossbar (ds_bpermute: ~130 cycles each for a double, a dependent chain -- 0.75 us
+// per block sum of a 1024-thread workgroup, four of them in an iteration of the single-launch CG kernels).  Offsets 32 and 16
+// are gfx950's v_permlane32_swap / v_permlane16_swap of the register with a copy of itself: one result holds the lower
+// half's (the even rows') values in every lane, the other the upper half's (the odd rows'), and their sum is own + partner or
+// partner + own -- the same bits.  After them every row of 16 lanes holds the same 16 values, and after each further step the
+// period halves: lane j's partner j ^ 8, j ^ 4, j ^ 2, j ^ 1 holds what the lane 8, 4, 2, 1 places round the row holds, which
+// is a DPP row rotation on the operand read.  Bit-identical to the butterfly (tools/probes/wave_sum_probe.cpp compares them).
+template <int CTRL>
+__device__ inline double dpp_lane(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double wave_sum(double v)
+{
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+    }
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+    }
+    v += dpp_lane<0x128>(v);        // row_ror:8
+    v += dpp_lane<0x124>(v);        // row_ror:4
+    v += dpp_lane<0x122>(v);        // row_ror:2
+    v += dpp_lane<0x121>(v);        // row_ror:1
+    return v;
+}
+
 // Deterministic block-wide sum; every thread returns the same bits.
 template <int BLOCK>
 __device__ inline double block_sum(double v, double *red /* BLOCK/64 doubles of LDS */)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    v = wave_sum(v);
     const int wave = threadIdx.x >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[wave] = v;
@@ -366,8 +408,7 @@ __device__ inline void load_scalars(const ScalarRef (&r)[K], double (&out)[K], d
         if (r[k].count > 1) {
             v[k] = 0.0 + v[k];
             for (int i = threadIdx.x + BLOCK; i < r[k].count; i += BLOCK) v[k] += r[k].ptr[i];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+            v[k] = wave_sum(v[k]);
         }
     }
     const int wave = threadIdx.x >> 6;

@@ -256,6 +256,94 @@ __global__ void k_color_out(int32_t n, int32_t n1, const int32_t *__restrict__ l
     if (p) p[i] = c1 ? 1 + before1[i] : n1 + 1 + (i - before1[i]);
 }
 
+// ---- the same colours without walking the levels one after another ---------------------------------------------------
+// On a structurally SYMMETRIC graph (c) always holds and (b) says "bipartite": then the colour of a vertex is 1 + the parity
+// of its distance from vertex 1, and that parity needs no breadth-first search -- it is what a union-find with one parity bit
+// per link maintains when every edge (i, j) is recorded as "i and j differ".  All edges at once, any order (the sweep
+// above costs one launch per level: 6323 of them on a 3162 x 3162 grid):
+//   word P[v] = parent << 1 | (parity of v relative to that parent); a root points at itself, parity 0
+//   * every stored word is a TRUE relation between v and one of its ancestors and stays true for ever (a vertex that has a
+//     parent never becomes a root again; roots are only ever hooked under a root of SMALLER index: no cycles, and the root of
+//     a finished component is its smallest vertex) -- so stale reads (the XCDs' L2s are not coherent with each other within a
+//     launch) only make a climb stop early, and the hook itself is a compare-and-swap at device scope whose returned word,
+//     when it fails, is the true link to climb on from (strictly smaller index every time: bounded);
+//   * path halving writes true relations over true relations (never over a root).
+// Afterwards, in launches of their own (coherent): every vertex climbs to its root -- all roots 0 <=> connected (a) -- and
+// every edge is checked both ways: its ends differ in parity (b), and (j, i) is stored where (i, j) is (symmetry).  Any
+// failure: *ok stays false and the level sweep above (then the host pass) decides.
+__device__ inline uint32_t uf_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void uf_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// climb from x (parity px of the starting vertex relative to x) to the root as this thread sees it, halving the path
+__device__ inline void uf_climb(uint32_t *P, uint32_t &x, uint32_t &px)
+{
+    for (;;) {
+        const uint32_t w = uf_ld(P + x), p = w >> 1;
+        if (p == x) return;
+        const uint32_t wp = uf_ld(P + p), g = wp >> 1;
+        if (g == p) { px ^= w & 1u; x = p; return; }
+        uf_st(P + x, (g << 1) | ((w ^ wp) & 1u));
+        px ^= (w ^ wp) & 1u;
+        x = g;
+    }
+}
+__global__ void k_uf_init(int32_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, uint32_t *__restrict__ P)
+{
+    const int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    uint32_t w = (uint32_t)v << 1;
+    for (int32_t k = rowptr[v]; k < rowptr[v + 1]; ++k)
+        if (col[k] < v) { w = ((uint32_t)col[k] << 1) | 1u; break; }
+    P[v] = w;
+}
+__global__ void k_uf_union(int32_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, uint32_t *P, int32_t *state)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool first = true;
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+        const int32_t j = col[k];
+        if (j >= i) continue;                        // every edge once, from its larger end (the symmetry check follows)
+        if (first) { first = false; continue; }      // (k_uf_init's link)
+        uint32_t u = (uint32_t)i, v = (uint32_t)j, pu = 0, pv = 0;
+        for (;;) {
+            uf_climb(P, u, pu);
+            uf_climb(P, v, pv);
+            if (u == v) { if (pu == pv) state[0] = 1; break; }        // an odd cycle
+            if (u < v) { const uint32_t t = u; u = v; v = t; const uint32_t tp = pu; pu = pv; pv = tp; }
+            const uint32_t old = atomicCAS(P + u, u << 1, (v << 1) | (pu ^ pv ^ 1u));
+            if (old == (u << 1)) break;
+            pu ^= old & 1u;                          // somebody hooked u first: its true link
+            u = old >> 1;
+        }
+    }
+}
+__global__ void k_uf_flatten(int32_t n, uint32_t *P, int32_t *__restrict__ level, int32_t *state)
+{
+    const int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    uint32_t x = (uint32_t)v, px = 0;
+    uf_climb(P, x, px);
+    level[v] = (int32_t)px;
+    if (x != 0u) state[0] = 1;                       // not reached from vertex 1
+}
+__global__ void k_uf_verify(int32_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const int32_t *__restrict__ level,
+                            int32_t *state)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t li = level[i];
+    bool good = true;
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1] && good; ++k) {
+        const int32_t j = col[k];
+        if (j == i) continue;
+        good = level[j] != li;
+        bool back = false;
+        for (int32_t m = rowptr[j]; m < rowptr[j + 1] && !back; ++m) back = col[m] == i;
+        good = good && back;
+    }
+    if (!good) state[0] = 1;
+}
+
 // *ok = false: the graph is not of the kind above (nothing written).  colors_dev / p_dev (either may be null): device
 // arrays of n int32; *n1 = vertices of colour 1 (0-based position where colour 2 starts)
 int greedy_coloring_device(const Part &pt, int32_t *colors_dev, int32_t *p_dev, int32_t *n1_out, int32_t *ncolors, bool *ok)
@@ -275,23 +363,41 @@ int greedy_coloring_device(const Part &pt, int32_t *colors_dev, int32_t *p_dev, 
     SGM_TRY(dalloc(&fr[1], (size_t)n));
     SGM_TRY(dalloc(&cnt, 4));
     SGM_TRY(dalloc(&state, 4));
-    hipLaunchKernelGGL(k_fill_i32, dim3(vec_grid(n)), dim3(kBlock), 0, st, (int64_t)n, level, -1);
     const int32_t init_cnt[4] = {1, 0, 0, 0}, init_state[4] = {0, 0, INT32_MAX, 0}, zero = 0;
-    SGM_HIP(hipMemcpyAsync(cnt, init_cnt, sizeof init_cnt, hipMemcpyHostToDevice, st));
-    SGM_HIP(hipMemcpyAsync(state, init_state, sizeof init_state, hipMemcpyHostToDevice, st));
-    SGM_HIP(hipMemcpyAsync(fr[0], &zero, 4, hipMemcpyHostToDevice, st));         // the queue starts with vertex 1, level 0
-    SGM_HIP(hipMemcpyAsync(level, &zero, 4, hipMemcpyHostToDevice, st));
-    // one launch per level, 64 levels between two looks at the state; a fixed grid walks any frontier
     int32_t hstate[4] = {0, 0, INT32_MAX, 0};
-    for (int32_t L = 0; hstate[2] == INT32_MAX && hstate[0] == 0 && L <= n; L += 64) {
-        for (int32_t l = L; l < L + 64; ++l)
-            hipLaunchKernelGGL(k_lvl_step, dim3(128), dim3(256), 0, st, l, (const int32_t *)pt.rowptr, (const int32_t *)pt.col, level,
-                               (const int32_t *)fr[l & 1], fr[(l + 1) & 1], cnt, state);
+    const int gridn = (n + kBlock - 1) / kBlock;
+    bool parity_done = false;
+    if (!getenv("SGM_COLOR_LEVELS")) {                                    // (tests: force the level sweep)
+        uint32_t *P = reinterpret_cast<uint32_t *>(fr[0]);
+        SGM_HIP(hipMemcpyAsync(state, init_state, sizeof init_state, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_uf_init, dim3(gridn), dim3(kBlock), 0, st, n, (const int32_t *)pt.rowptr, (const int32_t *)pt.col, P);
+        hipLaunchKernelGGL(k_uf_union, dim3(gridn), dim3(kBlock), 0, st, n, (const int32_t *)pt.rowptr, (const int32_t *)pt.col, P, state);
+        hipLaunchKernelGGL(k_uf_flatten, dim3(gridn), dim3(kBlock), 0, st, n, P, level, state);
+        hipLaunchKernelGGL(k_uf_verify, dim3(gridn), dim3(kBlock), 0, st, n, (const int32_t *)pt.rowptr, (const int32_t *)pt.col,
+                           (const int32_t *)level, state);
+        SGM_HIP(hipGetLastError());
         SGM_HIP(hipMemcpyAsync(hstate, state, sizeof hstate, hipMemcpyDeviceToHost, st));
         SGM_HIP(hipStreamSynchronize(st));
+        parity_done = hstate[0] == 0;
+        hstate[0] = 0;
     }
-    SGM_HIP(hipGetLastError());
-    if (hstate[0] != 0 || hstate[1] != n) return SGM_OK;          // not that kind of graph / not connected: the host pass decides
+    if (!parity_done) {
+        hipLaunchKernelGGL(k_fill_i32, dim3(vec_grid(n)), dim3(kBlock), 0, st, (int64_t)n, level, -1);
+        SGM_HIP(hipMemcpyAsync(cnt, init_cnt, sizeof init_cnt, hipMemcpyHostToDevice, st));
+        SGM_HIP(hipMemcpyAsync(state, init_state, sizeof init_state, hipMemcpyHostToDevice, st));
+        SGM_HIP(hipMemcpyAsync(fr[0], &zero, 4, hipMemcpyHostToDevice, st));         // the queue starts with vertex 1, level 0
+        SGM_HIP(hipMemcpyAsync(level, &zero, 4, hipMemcpyHostToDevice, st));
+        // one launch per level, 64 levels between two looks at the state; a fixed grid walks any frontier
+        for (int32_t L = 0; hstate[2] == INT32_MAX && hstate[0] == 0 && L <= n; L += 64) {
+            for (int32_t l = L; l < L + 64; ++l)
+                hipLaunchKernelGGL(k_lvl_step, dim3(128), dim3(256), 0, st, l, (const int32_t *)pt.rowptr, (const int32_t *)pt.col, level,
+                                   (const int32_t *)fr[l & 1], fr[(l + 1) & 1], cnt, state);
+            SGM_HIP(hipMemcpyAsync(hstate, state, sizeof hstate, hipMemcpyDeviceToHost, st));
+            SGM_HIP(hipStreamSynchronize(st));
+        }
+        SGM_HIP(hipGetLastError());
+        if (hstate[0] != 0 || hstate[1] != n) return SGM_OK;          // not that kind of graph / not connected: the host pass decides
+    }
     SGM_TRY(dalloc(&before, (size_t)n + 1));
     hipLaunchKernelGGL(k_color_flags, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, (const int32_t *)level, before);
     size_t tb = 0;
@@ -524,6 +630,7 @@ int sgm_mat_left_permute(sgm_mat A, const int32_t *p, int where)
 {
     SGM_TRY(require_init());
     if (!A || !p) return fail(SGM_ERR_BAD_ARG, "sgm_mat_left_permute: null argument");
+    A->version += 1;
     if ((A->fmt != SGM_FMT_CSR && A->fmt != SGM_FMT_ELL) || A->distributed())
         return fail(SGM_ERR_UNSUPPORTED, "sgm_mat_left_permute: single-GPU CSR / ELLPACK matrices only");
     Part &pt = A->parts[0];
@@ -591,6 +698,7 @@ int sgm_mat_right_permute(sgm_mat A, const int32_t *p, int where)
 {
     SGM_TRY(require_init());
     if (!A || !p) return fail(SGM_ERR_BAD_ARG, "sgm_mat_right_permute: null argument");
+    A->version += 1;
     if ((A->fmt != SGM_FMT_CSR && A->fmt != SGM_FMT_ELL) || A->distributed())
         return fail(SGM_ERR_UNSUPPORTED, "sgm_mat_right_permute: single-GPU CSR / ELLPACK matrices only");
     Part &pt = A->parts[0];

@@ -45,6 +45,8 @@ int stage_out(const Staged &s, double *v, int64_t n, int where);
 }  // namespace sgm
 using namespace sgm;
 
+namespace sgm { int rebuild_csr_formats(Part &p); }          // sgm_spmv.hip
+
 namespace {
 
 constexpr int kTrsvBlock = 1024;
@@ -179,6 +181,12 @@ struct sgm_pc_s {
     double *rp = nullptr, *zp = nullptr;
     int32_t perm_colors = 0;
     double reorder_ms[3] = {0, 0, 0};  // last setup: ordering, permuted copy, (factorisation is in the regular phases)
+    // the permuted matrix itself, kept (with A's kernel forms) for the Krylov solvers: they run the whole solve in the
+    // permuted order -- b and x permuted once each way -- instead of permuting r and z in every apply (in_permuted: vectors
+    // handed to pc_apply_parts are in that order already)
+    sgm_mat Ap = nullptr;
+    uint64_t Ap_serial = 0, Ap_version = 0;            // ... of the matrix it is the permutation of
+    bool in_permuted = false;
 };
 
 namespace {
@@ -357,6 +365,60 @@ __global__ void k_trsv_rows(const int32_t *__restrict__ rq, const double *__rest
     if (MODE == 0) y[i] = t;
     else if (MODE == 1) z[i] = t / D[i];
     else z[i] = t;
+}
+
+// PCG's  r = r - alpha q ; z = M^-1 r ; partial r.z  inside the two launches of a TWO-level factorisation (what the greedy
+// colouring makes of a 5- / 7-point matrix: L = the rows of colour 2 reading colour 1, U = the rows of colour 1 reading
+// colour 2) -- the r update (k_elem<FCgR<2>>: read r, q, write r) and the dot (k_elem<FDot2>: read r, z) cost 43 + 24 us of a
+// 403 us iteration at n = 1e7 as launches of their own.  alpha = res2 / dpr from the partial sums like FCgR's prepare.
+//   MODE 1 (rows n0 .. n-1, first launch):  r_i -= alpha q_i ; z_i = (r_i - sum val * (r_j - alpha q_j)) / D_i     [j < n0: updated on the fly,
+//   MODE 2 (rows 0 .. n0-1, second launch): r_i -= alpha q_i ; z_i = r_i / D_i - sum val * z_j                      their owner stores them in launch 2]
+// Same statements and operand order per row as FCgR<2> + k_trsv_rows<C, 1 / 2>: r and z bit-identical; the dot is summed per
+// block of this grid instead of k_elem's (tree order either way).
+template <int C, int MODE>
+__global__ __launch_bounds__(kBlock) void k_trsv_rows_cg(const int32_t *__restrict__ rq, const double *__restrict__ rv, uint32_t nstride, int rc,
+                                                         const int32_t *__restrict__ order, int32_t row0, int32_t begin, int32_t end, double *r,
+                                                         const double *__restrict__ q, ScalarRef res2, ScalarRef dpr, const double *__restrict__ D,
+                                                         double *z, double *part, const int *flag, int gen)
+{
+    __shared__ double red[2 * (kBlock / 64)];
+    const int st = flag ? *flag : 0;
+    const ScalarRef rs[2] = {res2, dpr};
+    double sc[2];
+    load_scalars<kBlock, 2>(rs, sc, red);
+    if (st && gen >= st) return;
+    const double alpha = sc[0] / sc[1];
+    double s = 0.0;
+    for (int32_t p = begin + blockIdx.x * kBlock + threadIdx.x; p < end; p += gridDim.x * kBlock) {
+        const int32_t i = row0 >= 0 ? row0 + (p - begin) : order[p];
+        const double ri = r[i] - alpha * q[i];
+        r[i] = ri;
+        double t = MODE == 2 ? ri / D[i] : ri;
+        auto dep = [&](int32_t j) -> double { return MODE == 2 ? z[j] : r[j] - alpha * q[j]; };
+        if (C >= 0) {
+            int32_t qq[C > 0 ? C : 1];
+            double v[C > 0 ? C : 1];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                qq[c] = __builtin_nontemporal_load(rq + (size_t)c * nstride + p);
+                v[c] = __builtin_nontemporal_load(rv + (size_t)c * nstride + p);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                if (qq[c] >= 0) t = t - v[c] * dep(qq[c]);
+        } else {
+            for (int c = 0; c < rc; ++c) {
+                const int32_t j = rq[(size_t)c * nstride + p];
+                if (j < 0) break;
+                t = t - rv[(size_t)c * nstride + p] * dep(j);
+            }
+        }
+        const double zi = MODE == 1 ? t / D[i] : t;
+        z[i] = zi;
+        s += ri * zi;
+    }
+    const double tot = block_sum<kBlock>(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
 }
 
 // a run of narrow levels [l0, l1) walked by ONE workgroup.  The row records and right-hand
@@ -1820,6 +1882,34 @@ void apply_rows(const IlduState *S, const double *r, double *z, const int *flag)
         launch_rows(S->U, Us[k], 2, r, S->xpL, S->D, z, n0, flag);
 }
 
+// both factors exactly two row-space levels, the outer ones entry-less (a two-colour ordering): k_trsv_rows_cg's case
+bool rows_two_level(const IlduState *S)
+{
+    return rows_serve(S) && S->opt.ildu_rows == 1 && S->rows_n0 > 0 && S->rows_fin && S->L.row_levels.size() == 2 && S->U.row_levels.size() == 2;
+}
+constexpr int kRowsCgGrid = 2048;            // blocks per launch (grid-stride): 2 x 2048 partial sums <= kMaxGrid
+void launch_rows_cg(const TriFactor &T, const TriFactor::RowLevel &L, int mode, double *r, const double *q, ScalarRef res2, ScalarRef dpr,
+                    const double *D, double *z, double *part, int grid, const int *flag, int gen)
+{
+    hipStream_t st = g_rt.stream;
+#define ROWS_M(CC, MM)                                                                                                         \
+    hipLaunchKernelGGL((k_trsv_rows_cg<CC, MM>), dim3(grid), dim3(kBlock), 0, st, (const int32_t *)T.rq, (const double *)T.rv, (uint32_t)T.nstride, \
+                       T.rc, (const int32_t *)T.order, L.row0, L.b, L.e, r, q, res2, dpr, D, z, part, flag, gen)
+#define ROWS(CC) do { if (mode == 1) ROWS_M(CC, 1); else ROWS_M(CC, 2); } while (0)
+    switch (L.c) {
+    case 0: ROWS(0); break;
+    case 1: ROWS(1); break;
+    case 2: ROWS(2); break;
+    case 3: ROWS(3); break;
+    case 4: ROWS(4); break;
+    case 5: case 6: ROWS(6); break;
+    case 7: case 8: ROWS(8); break;
+    default: ROWS(-1); break;
+    }
+#undef ROWS
+#undef ROWS_M
+}
+
 // triangular solve in position space: xp holds the right-hand side on entry, the solution on exit
 void trsv(const TriFactor &T, double *xp, const int *flag)
 {
@@ -2008,6 +2098,18 @@ bool pc_apply_is_short(sgm_pc pc)
 }
 const double *pc_idiag(sgm_pc pc, size_t part) { return pc->parts[part].idiag; }
 
+// ILDU(0) of the colour-ordered matrix (option ildu_reorder): the permuted matrix the factors belong to (null: none / natural
+// order).  A solver that finds one runs in the permuted order: x and b through pc_permute_vec once each way, the products on
+// this matrix, and pc_in_permuted(pc, true) around the solve so that the applies skip their own two permutations.
+// Only for the very matrix it was made from, unchanged since (the reference lets any matrix be solved with any preconditioner:
+// for another one the applies permute r and z themselves).
+sgm_mat pc_permuted_matrix(sgm_pc pc, sgm_mat A)
+{
+    if (!pc || pc->kind != SGM_PC_ILDU0 || !pc->perm || !pc->Ap || !A) return nullptr;
+    return pc->Ap_serial == A->serial && pc->Ap_version == A->version ? pc->Ap : nullptr;
+}
+void pc_in_permuted(sgm_pc pc, bool on) { if (pc) pc->in_permuted = on; }
+
 // The sticky abort word of a preconditioner whose apply runs through a pipelined triangular solve right now (null otherwise:
 // nothing to watch).  Whoever synchronises after such applies copies it back; nonzero = some sweep gave up and its result --
 // and everything computed from it -- is not to be used.
@@ -2055,9 +2157,35 @@ __global__ void k_perm_from(int32_t n, const int32_t *__restrict__ p1, const dou
 
 static int pc_apply_parts_ordered(sgm_pc pc, sgm_mat A, const double *const *r, double *const *z, const int *const *flags);
 
+// dst = P src (to_permuted) or dst = P^T src
+void pc_permute_vec(sgm_pc pc, const double *src, double *dst, bool to_permuted)
+{
+    const int32_t n = pc->n;
+    if (to_permuted) hipLaunchKernelGGL(k_perm_to, dim3(vec_grid(n)), dim3(kBlock), 0, g_rt.stream, n, (const int32_t *)pc->perm, src, dst, (const int *)nullptr);
+    else hipLaunchKernelGGL(k_perm_from, dim3(vec_grid(n)), dim3(kBlock), 0, g_rt.stream, n, (const int32_t *)pc->perm, src, dst, (const int *)nullptr);
+}
+
+// CG's "r -= alpha q; z = M^-1 r; partial sums of r.z" as the two launches of a two-level row-space factorisation
+// (k_trsv_rows_cg).  false: this preconditioner is not of that kind here -- the caller launches the three steps itself.
+// *count = partial sums left in `part`.
+bool pc_cg_fused(sgm_pc pc, ScalarRef res2, ScalarRef dpr, const double *q, double *r, double *z, double *part, int *count, const int *flag, int gen)
+{
+    static const bool off = getenv("SGM_PCG_FUSED") && atoi(getenv("SGM_PCG_FUSED")) == 0;
+    if (off || !pc || pc->kind != SGM_PC_ILDU0 || pc->ild.size() != 1 || (pc->perm && !pc->in_permuted)) return false;
+    const IlduState *S = &pc->ild[0];
+    if ((S->opt.ildu_strips && (S->grid_ok || S->slab_ok)) || !S->levels_ready || !rows_two_level(S)) return false;
+    const auto &L1 = S->L.row_levels[1], &U1 = S->U.row_levels[1];
+    const int g1 = std::max(1, std::min(kRowsCgGrid, (L1.e - L1.b + kBlock - 1) / kBlock));
+    const int g2 = std::max(1, std::min(kRowsCgGrid, (U1.e - U1.b + kBlock - 1) / kBlock));
+    launch_rows_cg(S->L, L1, 1, r, q, res2, dpr, S->D, z, part, g1, flag, gen);
+    launch_rows_cg(S->U, U1, 2, r, q, res2, dpr, S->D, z, part + g1, g2, flag, gen);
+    *count = g1 + g2;
+    return true;
+}
+
 int pc_apply_parts(sgm_pc pc, sgm_mat A, const double *const *r, double *const *z, const int *const *flags)
 {
-    if (pc->kind == SGM_PC_ILDU0 && pc->perm) {
+    if (pc->kind == SGM_PC_ILDU0 && pc->perm && !pc->in_permuted) {
         // z = P^T M^-1 P r: into the colour order, the sweeps there, back
         hipStream_t st = g_rt.stream;
         const int32_t n = pc->n;
@@ -2119,6 +2247,7 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
                          A->nrow == A->ncol && A->nrow > 0;
     if (!reorder) {
         if (pc->perm) { dfree(pc->perm); dfree(pc->rp); dfree(pc->zp); pc->perm = nullptr; pc->rp = pc->zp = nullptr; for (auto &S : pc->ild) free_ildu(S); pc->ild.clear(); }
+        if (pc->Ap) { sgm_mat_destroy(pc->Ap); pc->Ap = nullptr; }
         return pc_setup_ordered(pc, A);
     }
     // ILDU(0) of the colour-ordered matrix: the ordering once per pattern (ldu_solvers.f90:117-125 builds the pattern once),
@@ -2139,15 +2268,22 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
         pc->reorder_ms[0] = ms_since(t0);
     }
     t0 = std::chrono::steady_clock::now();
+    if (pc->Ap) { sgm_mat_destroy(pc->Ap); pc->Ap = nullptr; }
     sgm_mat Ap = nullptr;
     SGM_TRY(clone_csr_plain(A, &Ap));
     int rc = sgm_mat_left_permute(Ap, pc->perm, SGM_DEVICE);
     if (rc == SGM_OK) rc = sgm_mat_right_permute(Ap, pc->perm, SGM_DEVICE);
+    if (rc == SGM_OK) {                                   // the kernel forms A itself has, once, on the finished copy
+        Ap->parts[0].opt = A->parts[0].opt;
+        Ap->parts[0].opt.csr_lean = 0;                    // (the factorisation below reads the CSR-order arrays)
+        rc = rebuild_csr_formats(Ap->parts[0]);
+    }
     pc->reorder_ms[1] = ms_since(t0);
     t0 = std::chrono::steady_clock::now();
     if (rc == SGM_OK) rc = pc_setup_ordered(pc, Ap);
     pc->reorder_ms[2] = ms_since(t0);
-    sgm_mat_destroy(Ap);
+    if (rc == SGM_OK) { pc->Ap = Ap; pc->Ap_serial = A->serial; pc->Ap_version = A->version; }
+    else sgm_mat_destroy(Ap);
     return rc;
 }
 
@@ -2609,6 +2745,7 @@ int sgm_pc_destroy(sgm_pc pc)
     for (auto &S : pc->ild) free_ildu(S);
     dfree(pc->abort_sticky);
     dfree(pc->perm); dfree(pc->rp); dfree(pc->zp);
+    if (pc->Ap) sgm_mat_destroy(pc->Ap);
     delete pc;
     return SGM_OK;
 }

@@ -40,6 +40,10 @@ bool pc_apply_is_short(sgm_pc pc);
 const double *pc_idiag(sgm_pc pc, size_t part);
 int32_t *pc_abort_word(sgm_pc pc);        // sgm_pc.hip: sticky abort word of a pipelined ILDU apply (null: nothing to watch)
 int pc_retire_pipelines(sgm_pc pc);
+sgm_mat pc_permuted_matrix(sgm_pc pc, sgm_mat A);    // ILDU of the colour-ordered A: P A P^T (the solve runs in its order); null otherwise
+void pc_in_permuted(sgm_pc pc, bool on);
+void pc_permute_vec(sgm_pc pc, const double *src, double *dst, bool to_permuted);
+bool pc_cg_fused(sgm_pc pc, ScalarRef res2, ScalarRef dpr, const double *q, double *r, double *z, double *part, int *count, const int *flag, int gen);
 
 // ------------------------------------------------------------------ generic fused kernel
 // F provides: bool prepare(double* red) (block-uniform; false = nothing to do),
@@ -952,7 +956,8 @@ struct sgm_solver_s {
     double *coop_buf = nullptr;
     int coop_base = 0, coop_reach = -1;
     int64_t coop_iters0 = 0;
-    bool coop_retired = false;
+    bool coop_retired = false, coop_xl_retired = false;
+    double *perm_x = nullptr, *perm_b = nullptr;       // x and b in the order of a reordering preconditioner's matrix (sgm_solver_solve)
     SolverOptions opt = g_opt.solver;   // this solver's options: the defaults at its creation, then sgm_solver_set_option
     int64_t small_chunk() const { return opt.cg_small > 1 ? opt.cg_small : 50000; }          // iterations per launch of the one-workgroup kernels
     int64_t graph_after() const { return opt.krylov_graph > 1 ? opt.krylov_graph : 64; }     // iterations before the group is captured
@@ -974,6 +979,8 @@ void free_work(sgm_solver s)
     s->x_backup = nullptr;
     dfree(s->coop_buf);
     s->coop_buf = nullptr;
+    dfree(s->perm_x); dfree(s->perm_b);
+    s->perm_x = s->perm_b = nullptr;
     s->coop_reach = -1;
 }
 
@@ -1463,6 +1470,17 @@ static int run_cg_small(sgm_solver s, sgm_mat A, double *x, const double *b, sgm
 // products' summation order differs (per-workgroup block sums, then the G partials in index order).
 __device__ inline void st_sc1(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline double ld_sc1(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a store that stays in the storing XCD's L2 (write-through from the CU's L1 like every store): what the XCD-local variant
+// publishes with once every participant has proved to sit on ONE XCD, whose L2 is then the coherence point; readers keep
+// their sc1 loads (L1 bypassed, served by that L2)
+__device__ inline void st_l2(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void st_pub(double *p, double v, bool l2) { if (l2) st_l2(p, v); else st_sc1(p, v); }
+__device__ inline int xcc_id()
+{
+    int v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
+    return v & 15;
+}
 
 // One grid-wide hand-off = one all-reduced scalar.  No counter and no atomic: workgroup b publishes its partial sum in
 // slot[h % 4][b] (an sc1 store, after every wave has drained the sc1 stores of whatever else it publishes with this hand-off);
@@ -1472,16 +1490,29 @@ __device__ inline double ld_sc1(const double *p) { return __hip_atomic_load(p, _
 // h): every reader of that set's previous use arrived at hand-off h - 1 before anyone could pass it.  Bounded: a poll that
 // gives up raises `abort`, and every poll loop looks at it.
 constexpr unsigned long long kCoopPoison = 0x7ff8c0de5a5a0001ull;
-__device__ inline bool coop_handoff(double *slots /* 4 x 256 */, int h, double mine, int G, int *abort, int spin_limit, double *red, int *lds_ok,
-                                    double *sum_out)
+#ifdef SGM_COOP_PROBE
+// tuning aid (-DSGM_COOP_PROBE builds only): where an iteration's time goes, in 10 ns ticks summed over the launch, as seen by
+// thread 0 of workgroup 0.  [0..7] the phases of the iteration, [8..11] inside a hand-off, [15] iterations
+__device__ long long g_coop_probe[16];
+#define PROBE_T(k) do { if (probing) { const long long t_ = wall_clock64(); pacc[k] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define PROBE_T(k) do { } while (0)
+#endif
+__device__ inline bool coop_handoff(double *slots /* 4 x 256 */, int h, double mine, int wg, int G, bool l2, int *abort, int spin_limit, double *red,
+                                    int *lds_ok, double *sum_out, long long *pacc = nullptr)
 {
+#ifdef SGM_COOP_PROBE
+    const bool probing = pacc != nullptr;
+    long long tlast = probing ? wall_clock64() : 0;
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's sc1 stores (boundary rows) have left
     __syncthreads();
+    PROBE_T(8);
     const int tid = threadIdx.x;
     double *set = slots + (h & 3) * 256;
     if (tid == 0) {
         *lds_ok = 1;
-        st_sc1(set + blockIdx.x, mine);
+        st_pub(set + wg, mine, l2);
     }
     double v = 0.0;
     int ok = 1;
@@ -1498,17 +1529,26 @@ __device__ inline bool coop_handoff(double *slots /* 4 x 256 */, int h, double m
             __builtin_amdgcn_s_sleep(1);
         }
     }
+    PROBE_T(9);
     __syncthreads();                                         // (lds_ok = 1 is visible before anyone clears it)
+    PROBE_T(10);
     if (!ok) *lds_ok = 0;
     const double ssum = block_sum<1024>(v, red);             // (its barriers publish lds_ok)
-    if (tid == 0) st_sc1(slots + ((h + 2) & 3) * 256 + blockIdx.x, __longlong_as_double((long long)kCoopPoison));
+    PROBE_T(11);
+    if (tid == 0) st_pub(slots + ((h + 2) & 3) * 256 + wg, __longlong_as_double((long long)kCoopPoison), l2);
     *sum_out = ssum;
     return *lds_ok != 0;
 }
 
 // SW > 0: the own rows' matrix entries (SW slots each) are loaded ONCE and live in registers for the whole launch (RMAX * SW
 // doubles per thread; what an iteration then reads from memory is the hand-offs); SW = 0: streamed every iteration.
-template <int RMAX, bool JAC, int SW>
+// XL (XCD-local; systems of up to 32 workgroups' rows): the grid is 8 x G workgroups, of which those with blockIdx % 8 == 0 --
+// dealt to ONE XCD by the round-robin dispatch -- take part and the others leave at once.  The participants first PROVE the
+// co-location: a hand-off of the general (sc1, placement-independent) kind carries 64^(own XCC id), and only a sum of
+// G x 64^(own id) -- every participant on this XCD -- lets the launch continue; anything else raises `abort` like a poll that gave up.
+// From then on the published doubles leave as stores that STAY in that XCD's L2 and the sc1 polls are L2 hits: a hand-off
+// costs a few hundred cycles instead of two trips over the fabric.
+template <int RMAX, bool JAC, int SW, bool XL>
 __global__ __launch_bounds__(1024) void k_cg_coop(
     int32_t n, int32_t sw, int32_t H, const uint32_t *__restrict__ scode, const int32_t *__restrict__ dict, const double *__restrict__ sval,
     double *x, const double *b, const double *__restrict__ idiag, double tol, int64_t it_end, int resume,
@@ -1522,12 +1562,19 @@ __global__ __launch_bounds__(1024) void k_cg_coop(
     double *red = pl + RPW + 2 * H;                      // 16 doubles of block-sum scratch
     int *lds_ok = reinterpret_cast<int *>(red + 16);
     __shared__ int32_t dl[16];
-    const int tid = threadIdx.x, G = gridDim.x, wg = blockIdx.x;
+    if (XL && (blockIdx.x & 7) != 0) return;
+    const int tid = threadIdx.x, G = XL ? (int)(gridDim.x >> 3) : (int)gridDim.x, wg = XL ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int32_t r0 = wg * RPW, r1 = min(n, r0 + RPW);
     if (tid < 16) dl[tid] = dict[tid];
     int h = h0;
-    // all-reduce of one partial sum per workgroup (+ whatever this workgroup published with sc1 stores before the call)
-    auto handoff = [&](double mine, double &total) { const bool ok_ = coop_handoff(slots, h, mine, G, abort, spin_limit, red, lds_ok, &total); ++h; return ok_; };
+    // all-reduce of one partial sum per workgroup (+ whatever this workgroup published before the call)
+#ifdef SGM_COOP_PROBE
+    long long pacc_[16] = {0}, *pacc = pacc_, tlast = 0;
+    const bool probing = wg == 0 && tid == 0;
+    auto handoff = [&](double mine, double &total) { const bool ok_ = coop_handoff(slots, h, mine, wg, G, XL, abort, spin_limit, red, lds_ok, &total, probing ? pacc : nullptr); ++h; return ok_; };
+#else
+    auto handoff = [&](double mine, double &total) { const bool ok_ = coop_handoff(slots, h, mine, wg, G, XL, abort, spin_limit, red, lds_ok, &total); ++h; return ok_; };
+#endif
     auto own_dot = [&](const double (&prod)[RMAX]) {
         double sacc = 0.0;
 #pragma unroll
@@ -1588,7 +1635,7 @@ __global__ __launch_bounds__(1024) void k_cg_coop(
 #pragma unroll
         for (int u = 0; u < RMAX; ++u) {
             const int32_t li = tid + u * BLOCK, i = r0 + li;
-            if (i < r1 && (li < H || i >= r1 - H)) st_sc1(gz + i, zr[u]);
+            if (i < r1 && (li < H || i >= r1 - H)) st_pub(gz + i, zr[u], XL);
         }
     };
     double xr[RMAX], rr[RMAX], prod[RMAX];
@@ -1607,6 +1654,17 @@ __global__ __launch_bounds__(1024) void k_cg_coop(
     double res2;
     int64_t it = 0;
     bool ok = true;
+    if (XL) {                                              // the proof of co-location (placement-independent hand-off)
+        double total;
+        const double mark = __longlong_as_double((long long)(1023 + 6 * xcc_id()) << 52);       // 64^id
+        ok = coop_handoff(slots, h, mark, wg, G, false, abort, spin_limit, red, lds_ok, &total);
+        ++h;
+        if (ok && total != mark * (double)G) {
+            if (tid == 0) __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = false;
+        }
+        if (!ok) return;
+    }
     if (!resume) {
         double zr[RMAX];
         row_sums(zr);
@@ -1646,15 +1704,24 @@ __global__ __launch_bounds__(1024) void k_cg_coop(
     bool conv = ok && !(sqrt(res2) > tol);
     while (ok && !conv && it < it_end) {
         double qv[RMAX], zr[RMAX];
+#ifdef SGM_COOP_PROBE
+        if (probing) tlast = wall_clock64();
+#endif
         row_sums(qv);
+        PROBE_T(0);
 #pragma unroll
         for (int u = 0; u < RMAX; ++u) {
             const int32_t i = r0 + tid + u * BLOCK;
             prod[u] = i < r1 ? pl[H + tid + u * BLOCK] * qv[u] : 0.0;
         }
         double mine = own_dot(prod), dpr, dnew;
+        PROBE_T(1);
         ok = handoff(mine, dpr);                            // ---- hand-off 1: p.q
         if (!ok) break;
+#ifdef SGM_COOP_PROBE
+        if (probing) tlast = wall_clock64();
+#endif
+        PROBE_T(2);
         const double alpha = res2 / dpr;
 #pragma unroll
         for (int u = 0; u < RMAX; ++u) {
@@ -1667,9 +1734,14 @@ __global__ __launch_bounds__(1024) void k_cg_coop(
             }
         }
         mine = own_dot(prod);
+        PROBE_T(3);
         publish(zr);
+        PROBE_T(4);
         ok = handoff(mine, dnew);                           // ---- hand-off 2: r.z and the boundary rows of z
         if (!ok) break;
+#ifdef SGM_COOP_PROBE
+        if (probing) tlast = wall_clock64();
+#endif
         const double beta = dnew / res2;
 #pragma unroll
         for (int u = 0; u < RMAX; ++u) {
@@ -1684,7 +1756,12 @@ __global__ __launch_bounds__(1024) void k_cg_coop(
             const int32_t l2 = li < H ? li : RPW + li, i = r0 - H + l2;
             if (i >= 0 && i < n && (i < r0 || i >= r1)) pl[l2] = ld_sc1(gz + i) + beta * pl[l2];
         }
+        PROBE_T(5);
         __syncthreads();
+        PROBE_T(6);
+#ifdef SGM_COOP_PROBE
+        if (probing) pacc[15] += 1;
+#endif
         if (wg == 0 && tid == 0 && history && it < hist_cap) history[it] = dnew;
         ++it;
         res2 = dnew;
@@ -1700,11 +1777,21 @@ __global__ __launch_bounds__(1024) void k_cg_coop(
         }
     }
     if (wg == 0 && tid == 0) { *iters = it; *res_out = res2; *flag = conv ? 1 : 0; }
+#ifdef SGM_COOP_PROBE
+    if (probing)
+        for (int k = 0; k < 16; ++k) g_coop_probe[k] = pacc[k];
+#endif
 }
+#ifdef SGM_COOP_PROBE
+extern "C" int sgm_debug_coop_probe(long long out[16])
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coop_probe), sizeof(long long) * 16) == hipSuccess ? 0 : 1;
+}
+#endif
 
 constexpr int kCoopSpinLimit = 1 << 19;       // polls (about a microsecond each) before a hand-off gives up
 // sliced stencil matrix on one GPU, plain or Jacobi, tree-order dots, beyond the one-workgroup kernel and up to 256 workgroups
-static bool coop_applies(sgm_solver s, sgm_mat A, sgm_pc pc, int *rmax_out, int *halo_out)
+static bool coop_applies(sgm_solver s, sgm_mat A, sgm_pc pc, int *rmax_out, int *halo_out, bool *xl_out)
 {
     static const bool off = getenv("SGM_CG_COOP") && atoi(getenv("SGM_CG_COOP")) == 0;
     if (off || !s->opt.cg_small || s->multi || s->seq || A->parts.size() != 1 || A->comm || A->fmt != SGM_FMT_CSR || prof_on()) return false;
@@ -1721,6 +1808,18 @@ static bool coop_applies(sgm_solver s, sgm_mat A, sgm_pc pc, int *rmax_out, int 
     }
     const int H = (s->coop_reach + 1) & ~1;
     static const int force_rmax = getenv("SGM_CG_COOP_RMAX") ? atoi(getenv("SGM_CG_COOP_RMAX")) : 0;
+    // XCD-local variant: the whole system on the <= 32 CUs of one XCD (1, 2, 3 rows per thread with the matrix in registers, 4 streamed)
+    static const bool xl_off = getenv("SGM_CG_COOP_XCD") && atoi(getenv("SGM_CG_COOP_XCD")) == 0;
+    *xl_out = false;
+    if (!xl_off && !s->coop_xl_retired && g_rt.num_cu >= 64) {
+        for (int rmax : {1, 2, 3, 4}) {
+            if (force_rmax && rmax != force_rmax) continue;
+            const int64_t rpw = (int64_t)rmax * 1024, G = (p.n + rpw - 1) / rpw;
+            if (G > std::min(32, g_rt.num_cu / 8) || H > rpw || (rpw + 2 * H + 32) * 8 > 160 * 1024) continue;
+            *rmax_out = rmax; *halo_out = H; *xl_out = true;
+            return true;
+        }
+    }
     for (int rmax : {1, 2, 4}) {
         if (force_rmax && rmax != force_rmax) continue;
         const int64_t rpw = (int64_t)rmax * 1024, G = (p.n + rpw - 1) / rpw;
@@ -1733,7 +1832,7 @@ static bool coop_applies(sgm_solver s, sgm_mat A, sgm_pc pc, int *rmax_out, int 
 }
 
 // *ran = false: the kernel could not be launched here, or a hand-off gave up -- the caller runs the launch loop from the caller's x
-static int run_cg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc pc, int rmax, int H, bool *ran)
+static int run_cg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc pc, int rmax, int H, bool xl, bool *ran)
 {
     const Part &p = A->parts[0];
     PartWork &w = s->work[0];
@@ -1762,24 +1861,33 @@ static int run_cg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_
         if (s->max_iter > 0) it_end = std::min<int64_t>(it_end, s->max_iter);
         static const int spin_env = getenv("SGM_CG_COOP_SPIN") ? atoi(getenv("SGM_CG_COOP_SPIN")) : 0;
         const int spin = spin_env > 0 ? spin_env : kCoopSpinLimit;
-#define LC(R, J, W)                                                                                                    \
+#define LC(R, J, W, X)                                                                                                 \
     do {                                                                                                             \
-        if (!allow_lds((const void *)k_cg_coop<R, J, W>, lds)) return SGM_OK;                                         \
-        hipLaunchKernelGGL((k_cg_coop<R, J, W>), dim3(G), dim3(1024), lds, g_rt.stream, p.n, p.sw, H, (const uint32_t *)p.scode, \
+        if (!allow_lds((const void *)k_cg_coop<R, J, W, X>, lds)) return SGM_OK;                                      \
+        hipLaunchKernelGGL((k_cg_coop<R, J, W, X>), dim3(X ? 8 * G : G), dim3(1024), lds, g_rt.stream, p.n, p.sw, H, (const uint32_t *)p.scode, \
                            (const int32_t *)p.dict, (const double *)p.sval, x, b, jac ? pc_idiag(pc, 0) : nullptr,   \
                            s->tolerance, it_end, resume, w.vec[V_R], w.vec[V_P], gz, slots, abortw, s->coop_base & 3, spin, \
                            w.flag, w.iters, w.res, w.history, s->hist_cap);                                           \
     } while (0)
-#define LCJ(R, W) do { if (jac) LC(R, true, W); else LC(R, false, W); } while (0)
-        // the matrix in registers where RMAX * sw doubles fit beside x, r and the temporaries (<= 20 per thread)
-#define LCW(R) do { if (p.sw == 3) LCJ(R, 3); else if (p.sw == 5) LCJ(R, 5); else if (p.sw == 7) LCJ(R, 7); else LCJ(R, 8); } while (0)
+#define LCJ(R, W, X) do { if (jac) LC(R, true, W, X); else LC(R, false, W, X); } while (0)
+        // the matrix in registers where RMAX * sw doubles fit beside x, r and the temporaries
+#define LCW(R, X) do { if (p.sw == 3) LCJ(R, 3, X); else if (p.sw == 5) LCJ(R, 5, X); else if (p.sw == 7) LCJ(R, 7, X); else LCJ(R, 8, X); } while (0)
         static const bool stream_env = getenv("SGM_CG_COOP_STREAM") != nullptr;          // tuning aid: never keep the matrix in registers
         // (RMAX = 4 with the matrix in registers spills 14-76 VGPRs, RMAX = 10 streamed 99-157: not instantiated)
-        if (rmax == 1 && !stream_env) LCW(1);
-        else if (rmax == 2 && !stream_env) LCW(2);
-        else if (rmax == 1) LCJ(1, 0);
-        else if (rmax == 2) LCJ(2, 0);
-        else LCJ(4, 0);
+        if (xl) {
+            if (rmax == 1 && !stream_env) LCW(1, true);
+            else if (rmax == 2 && !stream_env) LCW(2, true);
+            else if (rmax == 3 && !stream_env && p.sw <= 5) { if (p.sw == 3) LCJ(3, 3, true); else LCJ(3, 5, true); }
+            else if (rmax == 1) LCJ(1, 0, true);
+            else if (rmax == 2) LCJ(2, 0, true);
+            else if (rmax == 3) LCJ(3, 0, true);
+            else LCJ(4, 0, true);
+        }
+        else if (rmax == 1 && !stream_env) LCW(1, false);
+        else if (rmax == 2 && !stream_env) LCW(2, false);
+        else if (rmax == 1) LCJ(1, 0, false);
+        else if (rmax == 2) LCJ(2, 0, false);
+        else LCJ(4, 0, false);
 #undef LCW
 #undef LCJ
 #undef LC
@@ -1790,15 +1898,21 @@ static int run_cg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_
         if (habort) {
             // a hand-off gave up (the grid was not co-resident, or the GPU is shared): x, r, p are untouched by this launch --
             // but a resumed solve has moved x already: restart is only exact from the caller's x, which launch 1 left alone
-            fprintf(stderr, "[sigma_hip] cooperative CG gave up waiting for a workgroup (grid not co-resident / shared GPU?): "
-                            "this solver takes the launch loop from now on\n");
             SGM_TRY(arm());
-            s->coop_retired = true;
+            if (xl) {
+                // (the participants were not dealt to one XCD, or one of them never started: the all-CU variant has its turn)
+                s->coop_xl_retired = true;
+            } else {
+                fprintf(stderr, "[sigma_hip] cooperative CG gave up waiting for a workgroup (grid not co-resident / shared GPU?): "
+                                "this solver takes the launch loop from now on\n");
+                s->coop_retired = true;
+            }
             if (resume) return fail(SGM_ERR_HIP, "cooperative CG aborted in a continued launch");
             return SGM_OK;
         }
-        // hand-offs this launch made: 2 per iteration (+ 1 at the start of a fresh solve); only their count mod 4 matters
-        s->coop_base = (int)((s->coop_base + 2 * (iters - (resume ? s->coop_iters0 : 0)) + (resume ? 0 : 1)) & 3);
+        // hand-offs this launch made: 2 per iteration (+ 1 at the start of a fresh solve, + 1 for the XCD-local variant's proof
+        // of co-location); only their count mod 4 matters
+        s->coop_base = (int)((s->coop_base + 2 * (iters - (resume ? s->coop_iters0 : 0)) + (resume ? 0 : 1) + (xl ? 1 : 0)) & 3);
         s->coop_iters0 = iters;
         if (flag || (s->max_iter > 0 && iters >= s->max_iter)) break;
     }
@@ -1806,23 +1920,43 @@ static int run_cg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_
     s->last_iterations = iters;
     s->res2 = res;
     s->converged = flag;
+    static const bool trace = getenv("SGM_TRACE") != nullptr;
+    if (trace)
+        fprintf(stderr, "[sigma_hip] cg: one cooperative launch per %lld iterations, %s, %d workgroups x %lld rows\n", (long long)s->small_chunk(),
+                xl ? "on one XCD" : "all CUs", G, (long long)rpw);
     return SGM_OK;
 }
 
 int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sgm_pc pc)
 {
+    auto coop = [&](bool *ran) -> int {
+        int rmax = 0, H = 0;
+        bool xl = false;
+        *ran = false;
+        for (int attempt = 0; attempt < 2 && !*ran && !s->coop_retired && coop_applies(s, A, pc, &rmax, &H, &xl); ++attempt) {
+            SGM_TRY(run_cg_coop(s, A, x[0], b[0], pc, rmax, H, xl, ran));
+            if (!*ran && xl) s->coop_xl_retired = true;
+            if (!xl) break;                                  // (the XCD-local variant stood down: once more with all CUs)
+        }
+        return SGM_OK;
+    };
+    bool ran = false, coop_tried = false;
     if (small_applies(s, A, pc, false)) {
-        bool ran = false;
+        // one workgroup takes ~1.5 us + 0.22 us per 1000 stored slots per iteration, a few workgroups of one XCD ~5 us whatever
+        // the size (round 4: tridiagonal n = 1e4 9.9 vs 5.0 us): the cooperative kernel first where it applies (>= 2048 rows)
+        // and the system has more than 12288 slots
+        const Part &p0 = A->parts[0];
+        if ((cg_small_sliced(p0) ? (int64_t)p0.n * p0.sw : p0.nnz) > 12288) {
+            coop_tried = true;
+            SGM_TRY(coop(&ran));
+            if (ran) return SGM_OK;
+        }
         SGM_TRY(run_cg_small(s, A, x[0], b[0], pc, &ran));
         if (ran) return SGM_OK;
     }
-    {
-        int rmax = 0, H = 0;
-        if (!s->coop_retired && coop_applies(s, A, pc, &rmax, &H)) {
-            bool ran = false;
-            SGM_TRY(run_cg_coop(s, A, x[0], b[0], pc, rmax, H, &ran));
-            if (ran) return SGM_OK;
-        }
+    if (!coop_tried) {
+        SGM_TRY(coop(&ran));
+        if (ran) return SGM_OK;
     }
     const size_t P = s->work.size();
     const int pk = pc ? pc_kind(pc) : 0;
@@ -1879,6 +2013,7 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
         SGM_TRY(spmv_parts(A, v.cx.data(), v.y.data(), false, &dots, s->work[0].flag, &grid, gen));
         for (size_t ip = 0; ip < P; ++ip) s->work[ip].count[C_PQ] = spmv_grid(A->parts[ip]);
         { const int ks[1] = {C_PQ}; SGM_TRY(finish_dots(s, A, ks, 1, vpq, true, gen)); }
+        bool fused_pc = false;
         for (size_t ip = 0; ip < P; ++ip) {
             PartWork &w = s->work[ip];
             w.count[nxt] = dot_grid(w.n);
@@ -1888,11 +2023,14 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
             else if (pk == SGM_PC_JACOBI)
                 launch_elem(w.n, FCgR<1>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_Q), W(ip, V_R), pc_idiag(pc, ip),
                                          W(ip, V_Z), part(s, ip, nxt)}, w.flag, gen);
+            else if (P == 1 && !s->seq && pc_cg_fused(pc, ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_Q), W(ip, V_R), W(ip, V_Z), part(s, ip, nxt),
+                                                     &w.count[nxt], w.flag, gen))
+                fused_pc = true;                           // (r update, both sweeps and the partial sums of r.z: two launches)
             else
                 launch_elem(w.n, FCgR<2>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_Q), W(ip, V_R), nullptr, nullptr,
                                          nullptr}, w.flag, gen);
         }
-        if (pk != 0 && pk != SGM_PC_JACOBI) {
+        if (pk != 0 && pk != SGM_PC_JACOBI && !fused_pc) {
             std::vector<const double *> rr(P); std::vector<double *> zz(P);
             for (size_t ip = 0; ip < P; ++ip) { rr[ip] = W(ip, V_R); zz[ip] = W(ip, V_Z); }
             SGM_TRY(pc_apply_parts(pc, A, rr.data(), zz.data(), v.flags.data()));
@@ -2573,10 +2711,26 @@ int sgm_solver_solve(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc
     }
     int rc = SGM_OK;
     struct HbScope { HbScope() { g_hb.solves = g_hb.solves + 1; g_hb.iteration = 0; hb_phase(HB_SOLVER_ENQUEUE); } ~HbScope() { hb_phase(HB_IDLE); } } hb_scope;
+    // A preconditioner that factorised the colour-ordered matrix P A P^T (option ildu_reorder) brings that matrix along: the
+    // whole solve runs in its order -- x' = P x, b' = P b once, the products on P A P^T, x = P^T x' at the end -- the same
+    // iteration as on A with P^T M^-1 P (permutations commute with dot products up to the order of the sum), without two
+    // permutations of r and z around every apply.  Only for the matrix the preconditioner was set up with, unchanged since.
+    sgm_mat Arun = A;
+    struct PermScope { sgm_pc pc = nullptr; ~PermScope() { if (pc) pc_in_permuted(pc, false); } } perm_scope;
+    static const bool perm_off = getenv("SGM_SOLVE_PERMUTED") && atoi(getenv("SGM_SOLVE_PERMUTED")) == 0;      // tuning aid / tests
+    if (sgm_mat Ap = perm_off ? nullptr : pc_permuted_matrix(pc, A); Ap && P == 1 && !A->comm && Ap->nrow == A->nrow) {
+        if (!s->perm_x) { SGM_TRY(dalloc(&s->perm_x, (size_t)nvec + 2)); SGM_TRY(dalloc(&s->perm_b, (size_t)nvec + 2)); }
+        pc_permute_vec(pc, sx.dev, s->perm_x, true);
+        pc_permute_vec(pc, sb.dev, s->perm_b, true);
+        xs[0] = s->perm_x; bs[0] = s->perm_b;
+        Arun = Ap;
+        perm_scope.pc = pc;
+        pc_in_permuted(pc, true);
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
-        if (s->kind == SGM_SOLVER_CG) rc = run_cg(s, A, xs.data(), bs.data(), pc);
-        else if (s->kind == SGM_SOLVER_BICGSTAB) rc = run_bicgstab(s, A, xs.data(), bs.data(), pc);
-        else rc = run_gmres(s, A, xs.data(), bs.data(), pc);
+        if (s->kind == SGM_SOLVER_CG) rc = run_cg(s, Arun, xs.data(), bs.data(), pc);
+        else if (s->kind == SGM_SOLVER_BICGSTAB) rc = run_bicgstab(s, Arun, xs.data(), bs.data(), pc);
+        else rc = run_gmres(s, Arun, xs.data(), bs.data(), pc);
         if (rc != SGM_OK) return rc;
         if (!s->aborted) break;
         if (attempt == 1) return fail(SGM_ERR_HIP, "sgm_solver_solve: a triangular sweep aborted again after the pipelines were retired");
@@ -2584,6 +2738,7 @@ int sgm_solver_solve(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc
         s->abort_dev = nullptr;
         s->aborted = 0;
         SGM_HIP(hipMemcpyAsync(sx.dev, s->x_backup, (size_t)nvec * 8, hipMemcpyDeviceToDevice, g_rt.stream));
+        if (Arun != A) pc_permute_vec(pc, sx.dev, s->perm_x, true);
         for (size_t ip = 0; ip < P; ++ip) {
             PartWork &w = s->work[ip];
             SGM_HIP(hipMemsetAsync(w.flag, 0, sizeof(int), g_rt.stream));
@@ -2592,6 +2747,7 @@ int sgm_solver_solve(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc
         }
     }
     s->abort_dev = nullptr;
+    if (Arun != A) pc_permute_vec(pc, s->perm_x, sx.dev, false);
     s->iterations += s->last_iterations;
     if (s->hist_cap) {
         const int64_t cnt = std::min<int64_t>(s->last_iterations, s->hist_cap);

@@ -2823,6 +2823,7 @@ int sgm_csr_set_values(sgm_mat A, const double *val, int where)
     SGM_TRY(require_init());
     if (!A || A->fmt != SGM_FMT_CSR || !val) return fail(SGM_ERR_BAD_ARG, "sgm_csr_set_values: bad argument");
     A->t_stale = true;
+    A->version += 1;
     int64_t off = 0;
     for (auto &p : A->parts) {
         SGM_TRY(lean_val_buffer(p));
@@ -2897,6 +2898,7 @@ int sgm_ell_set_values(sgm_mat A, const double *val, int where)
     if (!A || A->fmt != SGM_FMT_ELL || !val) return fail(SGM_ERR_BAD_ARG, "sgm_ell_set_values: bad argument");
     Part &p = A->parts[0];
     A->t_stale = true;
+    A->version += 1;
     const size_t total = (size_t)p.n * p.max_d;
     if (!total) return SGM_OK;
     double *tv = nullptr;

@@ -32,6 +32,8 @@ def _cases():
     yield "2-D 5-point 320 x 317 (n = 101440)", 320 * 317, P.poisson2d_csr(320, 317)
     yield "3-D 7-point 40 x 37 x 33 (halo = a plane of 1480 rows)", 40 * 37 * 33, P.laplace3d_csr(40, 37, 33)
     yield "1-D tridiagonal n = 50001 (odd: a scalar tail, halo 2)", 50001, P.tridiag_csr(50001, 2.5, -1.0, -1.0)
+    yield "2-D 5-point 300 x 300 (n = 90000: three rows per thread on one XCD)", 300 * 300, P.poisson2d_csr(300, 300)
+    yield "2-D 5-point 520 x 410 (n = 213200: beyond one XCD, the all-CU variant)", 520 * 410, P.poisson2d_csr(520, 410)
 
 
 @pytest.mark.parametrize("jac", [False, True])
@@ -131,3 +133,46 @@ def test_cooperative_cg_gives_up_loudly_and_the_launch_loop_takes_over(tmp_path)
     its = [ln for ln in p.stdout.splitlines() if ln.startswith("ITS")][0].split()
     assert its[1] == its[2] and its[3] == "True", p.stdout          # the fallback IS the launch loop: bit-identical to it
     assert "cooperative CG gave up waiting" in p.stderr
+
+
+def test_one_xcd_variant_runs_where_it_fits_and_equals_the_all_cu_variant_bit_for_bit():
+    """Systems of up to 32 workgroups' rows run on the CUs of ONE XCD (hand-offs through that XCD's L2) once the participants
+    have proved their co-location; the same rows per workgroup on all CUs (SGM_CG_COOP_XCD=0) sum the same partials in the
+    same order: bit-identical solutions and histories.  SGM_TRACE names the variant that ran."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np, sigma_amd as sg, hashlib\n"
+            "from sigma_amd import problems as P\n"
+            "sg.init(0)\n"
+            "for nx, ny in ((150, 131), (250, 240), (300, 300), (330, 330), (520, 410)):\n"
+            "    n = nx * ny\n"
+            "    ptr, node, val = P.poisson2d_csr(nx, ny)\n"
+            "    A = sg.csr_matrix(n, n, ptr, node, val)\n"
+            "    b = np.cos(0.003 * np.arange(n))\n"
+            "    s = sg.cg(1e-10); s.set_history(100000); s.setup(A)\n"
+            "    u = np.zeros(n); s.solve(A, u, b)\n"
+            "    print('SOLVE', n, s.iterations, hashlib.sha1(u.tobytes() + np.array(s.history).tobytes()).hexdigest())\n" % ROOT)
+    runs = {}
+    for xcd in ("1", "0"):
+        env = dict(os.environ, SGM_CG_COOP_XCD=xcd, SGM_TRACE="1")
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        runs[xcd] = ([ln for ln in p.stdout.splitlines() if ln.startswith("SOLVE")],
+                     [ln for ln in p.stderr.splitlines() if "cooperative launch" in ln])
+    on, off = runs["1"], runs["0"]
+    assert len(on[0]) == 5 and len(on[1]) == 5 and len(off[1]) == 5, (on, off)
+    assert ["one XCD" in ln for ln in on[1]] == [True, True, True, True, False], on[1]
+    assert not any("one XCD" in ln for ln in off[1]), off[1]
+    # rows per workgroup: the one-XCD variant takes 1, 2, 3, 4 rows per thread; the all-CU variant 1 (<= 256 workgroups) --
+    # different partitions of the dot products, so only the LAST case (all CUs either way) must agree bit for bit here ...
+    assert on[0][4] == off[0][4]
+    # ... and with the rows per thread pinned the two variants are the same arithmetic everywhere
+    runs2 = {}
+    for xcd in ("1", "0"):
+        env = dict(os.environ, SGM_CG_COOP_XCD=xcd, SGM_CG_COOP_RMAX="4")
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        runs2[xcd] = [ln for ln in p.stdout.splitlines() if ln.startswith("SOLVE")]
+    assert runs2["1"] == runs2["0"] and len(runs2["1"]) == 5, runs2
+    # iteration counts of the default selection within +-1 of the pinned one (same statements, other summation order)
+    for a, b in zip(on[0], runs2["1"]):
+        assert abs(int(a.split()[2]) - int(b.split()[2])) <= 1, (a, b)

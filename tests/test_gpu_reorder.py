@@ -5,6 +5,8 @@ are connected from vertex 1 (every 5- / 7-point grid, holes and all) its result 
 level mod 2) -- and the library computes it with a level-synchronous sweep.  The sequential host pass stays as the checker:
 every case here runs both and compares them with the oracle's restatement of the reference, array for array."""
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -13,6 +15,7 @@ import sigma_amd as sg
 from sigma_amd import problems as P
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -59,6 +62,18 @@ def _both_passes(H):
         o1 = H.greedy_color_ordering()
     except sg.SigmaError as e:
         o1 = str(e)
+    # the device pass has two forms -- parities by union-find (symmetric graphs), then the level sweep: the second alone
+    os.environ["SGM_COLOR_LEVELS"] = "1"
+    try:
+        c3, nc3 = H.greedy_coloring()
+        try:
+            o3 = H.greedy_color_ordering()
+        except sg.SigmaError as e:
+            o3 = str(e)
+    finally:
+        os.environ.pop("SGM_COLOR_LEVELS", None)
+    assert np.array_equal(c1, c3) and nc1 == nc3
+    assert (o1 == o3) if isinstance(o1, str) else (np.array_equal(o1[0], o3[0]) and np.array_equal(o1[1], o3[1]) and o1[2] == o3[2])
     os.environ["SGM_COLOR_HOST"] = "1"
     try:
         c2, nc2 = H.greedy_coloring()
@@ -208,3 +223,87 @@ def test_colour_ordering_at_c2_size_takes_milliseconds():
     assert np.array_equal(p, want)
     print(f"greedy_color_ordering at n = {n}: {min(ts) * 1e3:.1f} ms (incl. the copy of p to the host)")
     assert min(ts) < 0.12
+
+
+_PERMUTED_SOLVE = r"""
+import sys, json, hashlib
+sys.path.insert(0, %r)
+import numpy as np, sigma_amd as sg
+from sigma_amd import problems as P
+sg.init(0)
+nx, ny = 150, 120
+n = nx * ny
+ptr, node, val = P.poisson2d_csr(nx, ny)
+rows = np.repeat(np.arange(1, n + 1), np.diff(ptr))
+val = val * (1.0 + 0.05 * np.cos(0.3 * (rows + node)))
+H = sg.csr_matrix(n, n, ptr, node, val)
+pc = sg.ldu(reorder="colour"); pc.setup(H)
+b = np.sin(0.01 * np.arange(n)) + 0.2
+out = {}
+def resid(M, u):
+    Au = np.zeros(n); M.matvec(u, Au)
+    return float(np.abs(Au - b).max() / np.abs(b).max())
+for kind in ("cg", "bicgstab", "gmres"):
+    s = getattr(sg, kind)(1e-10); s.set_history(100000); s.setup(H)
+    u = np.full(n, 0.125)
+    s.solve(H, u, b, pc)
+    out[kind] = {"iterations": int(s.iterations), "resid": resid(H, u), "u": u.tolist() if kind == "cg" else None,
+                 "history": [float(h) for h in s.history][:40]}
+# another matrix (same pattern, other values) solved with the preconditioner of H: M^-1 is only an approximation then, the
+# system solved must be the other matrix's
+v2 = val * (1.0 + 0.3 * np.sin(0.11 * ((rows + node) %% 97)))          # (a function of row + column: still symmetric)
+B = sg.csr_matrix(n, n, ptr, node, v2)
+s = sg.cg(1e-10); s.setup(B)
+u = np.zeros(n); s.solve(B, u, b, pc)
+out["other_matrix"] = {"iterations": int(s.iterations), "resid": resid(B, u)}
+# the values of H change and the preconditioner is NOT set up again: still H's (new) system
+H.set_values(val * 0.75)
+s = sg.cg(1e-10); s.setup(H)
+u = np.zeros(n); s.solve(H, u, b, pc)
+out["stale_pc"] = {"iterations": int(s.iterations), "resid": resid(H, u)}
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_solvers_run_in_the_colour_order_and_fuse_the_sweeps_without_changing_the_iteration(orc):
+    """A Krylov solve with sg.ldu(reorder="colour") runs in the permuted order (x, b permuted once each way, products on the
+    preconditioner's P A P^T) and CG folds r -= alpha q and the partial sums of r.z into the two row-space sweeps.  Both are
+    the same iteration as permuting r and z around every apply / as the three separate steps (SGM_SOLVE_PERMUTED=0,
+    SGM_PCG_FUSED=0): iteration counts within one, solutions within 1e-9.  The permuted matrix stands in ONLY for the matrix
+    the preconditioner was set up with, unchanged since."""
+    import json
+    runs = {}
+    for name, env in (("default", {}), ("no_permuted_solve", {"SGM_SOLVE_PERMUTED": "0"}), ("no_fused_sweeps", {"SGM_PCG_FUSED": "0"})):
+        p = subprocess.run([sys.executable, "-c", _PERMUTED_SOLVE % ROOT], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr[-3000:]
+        runs[name] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
+    d = runs["default"]
+    for kind in ("cg", "bicgstab", "gmres"):
+        assert d[kind]["resid"] < 1e-8, (kind, d[kind]["resid"])
+    assert d["other_matrix"]["resid"] < 1e-8 and d["stale_pc"]["resid"] < 1e-8, (d["other_matrix"], d["stale_pc"])
+    u0 = np.array(d["cg"]["u"])
+    for name in ("no_permuted_solve", "no_fused_sweeps"):
+        o = runs[name]
+        assert abs(o["cg"]["iterations"] - d["cg"]["iterations"]) <= 1, (name, o["cg"]["iterations"], d["cg"]["iterations"])
+        assert np.abs(np.array(o["cg"]["u"]) - u0).max() <= 1e-9 * np.abs(u0).max(), name
+        h0, h1 = np.array(d["cg"]["history"]), np.array(o["cg"]["history"])
+        k = min(len(h0), len(h1))
+        assert np.abs(h0[:k] - h1[:k]).max() <= 1e-9 * h0[:k].max(), name
+        for kind in ("bicgstab", "gmres"):
+            assert abs(o[kind]["iterations"] - d[kind]["iterations"]) <= max(3, d[kind]["iterations"] // 10), (name, kind)
+        assert o["other_matrix"]["iterations"] == d["other_matrix"]["iterations"] or abs(o["other_matrix"]["iterations"] - d["other_matrix"]["iterations"]) <= 1
+    # the oracle's PCG on the permuted system: the same iteration count as before the solve moved into that order
+    nx, ny = 150, 120
+    n = nx * ny
+    ptr, node, val = P.poisson2d_csr(nx, ny)
+    rows = np.repeat(np.arange(1, n + 1), np.diff(ptr))
+    val = val * (1.0 + 0.05 * np.cos(0.3 * (rows + node)))
+    A = orc.CsrMatrix(n, n, ptr, node, val)
+    p, _, _ = orc.greedy_color_ordering(A)
+    Ap = orc.permuted(A, p, p)
+    b = np.sin(0.01 * np.arange(n)) + 0.2
+    bp = np.empty(n); bp[p - 1] = b
+    x0 = np.full(n, 0.125)
+    ur, itr, _, _ = orc.cg(Ap, bp, x0=x0, tol=1e-10, pc=orc.Ildu(Ap))
+    assert abs(d["cg"]["iterations"] - itr) <= 1, (d["cg"]["iterations"], itr)
+    assert np.abs(u0 - ur[p - 1]).max() <= 1e-9 * np.abs(ur).max()

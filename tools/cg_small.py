@@ -8,12 +8,14 @@ from sigma_amd import problems as P
 sg.init(0); sg.use_torch_stream()
 dev = torch.device("cuda", 0)
 GRAPH = [int(v) for v in os.environ.get("KRYLOV_GRAPH", "1,0").split(",")]
-for nx in (32, 100, 316, 1000, 2000):
+NXS = [int(v) for v in os.environ.get("NXS", "32,100,316,1000,2000").split(",")]
+SOLVERS = os.environ.get("SOLVERS", "cg,bicgstab").split(",")
+for nx in NXS:
     n = nx * nx
     ptr, node, val = P.poisson2d_csr(nx, nx)
     A = sg.csr_matrix(n, n, torch.from_numpy(ptr).to(dev), torch.from_numpy(node).to(dev), torch.from_numpy(val).to(dev))
     b = torch.full((n,), 1.0 / n, dtype=torch.float64, device=dev)
-    for kind, graph in [(k, g) for k in ("cg", "bicgstab") for g in GRAPH]:
+    for kind, graph in [(k, g) for k in SOLVERS for g in GRAPH]:
         sg.set_option("krylov_graph", graph)
         s = sg.cg(1e-300) if kind == "cg" else sg.bicgstab(1e-300)
         s.setup(A)
@@ -29,6 +31,8 @@ for nx in (32, 100, 316, 1000, 2000):
         dt = time.perf_counter() - t0
         print(json.dumps({"nx": nx, "n": n, "solver": kind, "krylov_graph": graph, "iterations": s.last_iterations, "us_per_iter": round(dt / max(1, s.last_iterations) * 1e6, 2)}), flush=True)
 # C1 of BASELINE.json: tridiagonal (-1, 2, -1), n = 10,000, CG
+if os.environ.get("NO_C1"):
+    sys.exit(0)
 n = 10000
 ptr = np.zeros(n + 1, np.int32); deg = np.full(n, 3); deg[0] = deg[-1] = 2
 ptr[0] = 1; ptr[1:] = 1 + np.cumsum(deg)
