@@ -93,6 +93,12 @@ struct TriFactor {                   // strictly triangular factor on the device
     int rc = 0;
     int32_t *rq = nullptr;
     double *rv = nullptr;
+    // the dependency rows once more as 4-bit codes (rc <= 8 and at most 15 distinct offsets "dependency row - own row" in the
+    // whole factor -- any stencil matrix in any of the reference's orderings): rcode[p] = eight codes of position p (15 =
+    // no entry), rdict = the offsets.  4 bytes per row where rq holds 4 * rc: the fused PCG sweeps read these.
+    uint32_t *rcode = nullptr;
+    int32_t *rdict = nullptr;
+    int nrdict = 0;
 };
 
 // A strictly triangular factor whose rows depend only on the previous row (r-1) and on the row one grid
@@ -320,6 +326,12 @@ __global__ void k_trsv_wide_soa(const int32_t *__restrict__ wq, const double *__
     xp[p] = z;
 }
 
+// Row-space tables rq / rv, slice-major: the rc slots of 512 consecutive positions lie side by side, so a sweep's tile reads ONE
+// contiguous run (rc * 6 KiB for both tables) instead of 2 * rc streams a whole vector apart.  (Measured in round 4 against
+// the slot-major layout it replaced: the same time -- the sweeps are not bound by the number of open streams.)  Size <=
+// (n + 511) * rc entries.
+__host__ __device__ inline size_t rs_at(int c, uint32_t p, int rc) { return ((size_t)(p >> 9) * rc + c) * 512 + (p & 511u); }
+
 // One level in ROW space (factors of a few levels -- what the reference's greedy colouring makes of a matrix: one level per
 // colour): out[i] = src[i] (/ D[i]) - sum over the row's entries, stored order, of val * out[row of the entry];
 // i = the level's rows, through `order` or -- a level that is a run of consecutive rows -- counted from row0.  No gather
@@ -337,7 +349,12 @@ __global__ void k_trsv_rows(const int32_t *__restrict__ rq, const double *__rest
                             double *y, const double *__restrict__ D, double *z, int32_t n0, const int *flag)
 {
     if (flag && *flag) return;
-    const int32_t p = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    // tile -> workgroup: the dispatcher deals workgroups b, b + 8, ... to one XCD; they take CONSECUTIVE tiles of 256 positions
+    // (XCD k: the k-th eighth of the level), so that a row and its neighbours a grid line away -- other tiles, the same
+    // vector entries -- meet in one L2 instead of being fetched once per XCD (the grid is 8 * ceil(tiles / 8) workgroups)
+    const int32_t tiles_per_xcd = gridDim.x >> 3;
+    const int32_t tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    const int32_t p = begin + tile * (int32_t)blockDim.x + threadIdx.x;
     if (p >= end) return;
     const int32_t i = row0 >= 0 ? row0 + (p - begin) : order[p];
     double t;
@@ -349,17 +366,17 @@ __global__ void k_trsv_rows(const int32_t *__restrict__ rq, const double *__rest
         double v[C > 0 ? C : 1];
 #pragma unroll
         for (int c = 0; c < C; ++c) {                       // (read once per sweep: past the caches the gathers live in)
-            q[c] = __builtin_nontemporal_load(rq + (size_t)c * nstride + p);
-            v[c] = __builtin_nontemporal_load(rv + (size_t)c * nstride + p);
+            q[c] = __builtin_nontemporal_load(rq + rs_at(c, p, rc));
+            v[c] = __builtin_nontemporal_load(rv + rs_at(c, p, rc));
         }
 #pragma unroll
         for (int c = 0; c < C; ++c)
             if (q[c] >= 0) t = t - v[c] * dep(q[c]);
     } else {
         for (int c = 0; c < rc; ++c) {
-            const int32_t q = rq[(size_t)c * nstride + p];
+            const int32_t q = rq[rs_at(c, p, rc)];
             if (q < 0) break;                              // (a row's entries fill its first slots)
-            t = t - rv[(size_t)c * nstride + p] * dep(q);
+            t = t - rv[rs_at(c, p, rc)] * dep(q);
         }
     }
     if (MODE == 0) y[i] = t;
@@ -371,8 +388,10 @@ __global__ void k_trsv_rows(const int32_t *__restrict__ rq, const double *__rest
 // colouring makes of a 5- / 7-point matrix: L = the rows of colour 2 reading colour 1, U = the rows of colour 1 reading
 // colour 2) -- the r update (k_elem<FCgR<2>>: read r, q, write r) and the dot (k_elem<FDot2>: read r, z) cost 43 + 24 us of a
 // 403 us iteration at n = 1e7 as launches of their own.  alpha = res2 / dpr from the partial sums like FCgR's prepare.
-//   MODE 1 (rows n0 .. n-1, first launch):  r_i -= alpha q_i ; z_i = (r_i - sum val * (r_j - alpha q_j)) / D_i     [j < n0: updated on the fly,
-//   MODE 2 (rows 0 .. n0-1, second launch): r_i -= alpha q_i ; z_i = r_i / D_i - sum val * z_j                      their owner stores them in launch 2]
+//   (before them the caller has updated the entry-less rows 0 .. n0-1 -- a streaming launch over a third of the bytes: with
+//    r_j - alpha q_j formed on the fly in MODE 1 its gathers doubled and the launch ran at 4.3 TB/s, 120 us)
+//   MODE 1 (rows n0 .. n-1): r_i -= alpha q_i ; z_i = (r_i - sum val * r_j) / D_i      [j < n0]
+//   MODE 2 (rows 0 .. n0-1): z_i = r_i / D_i - sum val * z_j                            [j >= n0]
 // Same statements and operand order per row as FCgR<2> + k_trsv_rows<C, 1 / 2>: r and z bit-identical; the dot is summed per
 // block of this grid instead of k_elem's (tree order either way).
 template <int C, int MODE>
@@ -389,33 +408,135 @@ __global__ __launch_bounds__(kBlock) void k_trsv_rows_cg(const int32_t *__restri
     if (st && gen >= st) return;
     const double alpha = sc[0] / sc[1];
     double s = 0.0;
-    for (int32_t p = begin + blockIdx.x * kBlock + threadIdx.x; p < end; p += gridDim.x * kBlock) {
+    // (tiles of 256 positions; XCD k = workgroups k, k + 8, ... walks the k-th eighth of them in order: k_trsv_rows' map)
+    const int32_t tiles = (end - begin + kBlock - 1) / kBlock, tiles_per_xcd = (tiles + 7) >> 3, wg_per_xcd = gridDim.x >> 3;
+    const int32_t t_end = min(tiles, ((int32_t)(blockIdx.x & 7) + 1) * tiles_per_xcd);
+    for (int32_t tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3); tile < t_end; tile += wg_per_xcd) {
+        const int32_t p = begin + tile * kBlock + threadIdx.x;
+        if (p >= end) continue;
         const int32_t i = row0 >= 0 ? row0 + (p - begin) : order[p];
-        const double ri = r[i] - alpha * q[i];
-        r[i] = ri;
+        const double ri = MODE == 1 ? r[i] - alpha * q[i] : r[i];
+        if (MODE == 1) r[i] = ri;
         double t = MODE == 2 ? ri / D[i] : ri;
-        auto dep = [&](int32_t j) -> double { return MODE == 2 ? z[j] : r[j] - alpha * q[j]; };
+        auto dep = [&](int32_t j) -> double { return MODE == 2 ? z[j] : r[j]; };
         if (C >= 0) {
             int32_t qq[C > 0 ? C : 1];
             double v[C > 0 ? C : 1];
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                qq[c] = __builtin_nontemporal_load(rq + (size_t)c * nstride + p);
-                v[c] = __builtin_nontemporal_load(rv + (size_t)c * nstride + p);
+                qq[c] = __builtin_nontemporal_load(rq + rs_at(c, p, rc));
+                v[c] = __builtin_nontemporal_load(rv + rs_at(c, p, rc));
             }
 #pragma unroll
             for (int c = 0; c < C; ++c)
                 if (qq[c] >= 0) t = t - v[c] * dep(qq[c]);
         } else {
             for (int c = 0; c < rc; ++c) {
-                const int32_t j = rq[(size_t)c * nstride + p];
+                const int32_t j = rq[rs_at(c, p, rc)];
                 if (j < 0) break;
-                t = t - rv[(size_t)c * nstride + p] * dep(j);
+                t = t - rv[rs_at(c, p, rc)] * dep(j);
             }
         }
         const double zi = MODE == 1 ? t / D[i] : t;
         z[i] = zi;
         s += ri * zi;
+    }
+    const double tot = block_sum<kBlock>(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// The same with TWO consecutive rows per lane and 16-byte accesses (8-byte for the row numbers) on every stream -- the level
+// is a run of consecutive rows (row0 >= 0) with an even first position and first row, slot stride even; an odd last row
+// goes alone.  Half the memory instructions per byte: the one-row form streams at 4.3-4.8 TB/s where the vector kernels
+// reach 5.6-6.6.  Per row the same statements in the same order: same bits.
+typedef double f64x2p __attribute__((ext_vector_type(2)));
+typedef int32_t i32x2p __attribute__((ext_vector_type(2)));
+// CODED: the dependency rows come from the 4-bit codes (rcode, rdict) instead of rq: 4 bytes per row instead of 4 * C.
+typedef uint32_t u32x2p __attribute__((ext_vector_type(2)));
+template <int C, int MODE, bool CODED>
+__global__ __launch_bounds__(kBlock) void k_trsv_rows_cg2(const int32_t *__restrict__ rq, const double *__restrict__ rv, int rc,
+                                                          const uint32_t *__restrict__ rcode, const int32_t *__restrict__ rdict,
+                                                          int32_t row0, int32_t begin, int32_t end, double *r, const double *__restrict__ q,
+                                                          ScalarRef res2, ScalarRef dpr, const double *__restrict__ D, double *z, double *part,
+                                                          const int *flag, int gen)
+{
+    __shared__ double red[2 * (kBlock / 64)];
+    __shared__ int32_t dl[16];
+    if (CODED) {
+        if (threadIdx.x < 16) dl[threadIdx.x] = rdict[threadIdx.x];
+        __syncthreads();
+    }
+    const int st = flag ? *flag : 0;
+    const ScalarRef rs[2] = {res2, dpr};
+    double sc[2];
+    load_scalars<kBlock, 2>(rs, sc, red);
+    if (st && gen >= st) return;
+    const double alpha = sc[0] / sc[1];
+    double s = 0.0;
+    constexpr int TILE = 2 * kBlock;
+    const int32_t tiles = (end - begin + TILE - 1) / TILE, tiles_per_xcd = (tiles + 7) >> 3, wg_per_xcd = gridDim.x >> 3;
+    const int32_t t_end = min(tiles, ((int32_t)(blockIdx.x & 7) + 1) * tiles_per_xcd);
+    auto dep = [&](int32_t j) -> double { return MODE == 2 ? z[j] : r[j]; };
+    for (int32_t tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3); tile < t_end; tile += wg_per_xcd) {
+        const int32_t p = begin + tile * TILE + 2 * (int32_t)threadIdx.x;
+        if (p >= end) continue;
+        const int32_t i = row0 + (p - begin);
+        if (p + 1 < end) {
+            const f64x2p rr = *reinterpret_cast<const f64x2p *>(r + i), dd = *reinterpret_cast<const f64x2p *>(D + i);
+            f64x2p qo;
+            qo.x = 0.0; qo.y = 0.0;
+            if (MODE == 1) qo = *reinterpret_cast<const f64x2p *>(q + i);
+            i32x2p jj[C > 0 ? C : 1];
+            f64x2p vv[C > 0 ? C : 1];
+            u32x2p cw;
+            if (CODED) cw = __builtin_nontemporal_load(reinterpret_cast<const u32x2p *>(rcode + p));
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                if (CODED) {
+                    const uint32_t na = (cw.x >> (4 * c)) & 15u, nb = (cw.y >> (4 * c)) & 15u;
+                    jj[c].x = na == 15u ? -1 : i + dl[na];
+                    jj[c].y = nb == 15u ? -1 : i + 1 + dl[nb];
+                } else
+                    jj[c] = __builtin_nontemporal_load(reinterpret_cast<const i32x2p *>(rq + rs_at(c, p, rc)));
+                vv[c] = __builtin_nontemporal_load(reinterpret_cast<const f64x2p *>(rv + rs_at(c, p, rc)));
+            }
+            const double ra = MODE == 1 ? rr.x - alpha * qo.x : rr.x, rb = MODE == 1 ? rr.y - alpha * qo.y : rr.y;
+            if (MODE == 1) {
+                f64x2p rn; rn.x = ra; rn.y = rb;
+                *reinterpret_cast<f64x2p *>(r + i) = rn;
+            }
+            double ta = MODE == 2 ? ra / dd.x : ra, tb = MODE == 2 ? rb / dd.y : rb;
+            // (the two rows' entries side by side: every slot's operands are requested before either row uses them)
+            double da[C > 0 ? C : 1], db[C > 0 ? C : 1];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                da[c] = jj[c].x >= 0 ? dep(jj[c].x) : 0.0;
+                db[c] = jj[c].y >= 0 ? dep(jj[c].y) : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                if (jj[c].x >= 0) ta = ta - vv[c].x * da[c];
+                if (jj[c].y >= 0) tb = tb - vv[c].y * db[c];
+            }
+            f64x2p zn;
+            zn.x = MODE == 1 ? ta / dd.x : ta;
+            zn.y = MODE == 1 ? tb / dd.y : tb;
+            *reinterpret_cast<f64x2p *>(z + i) = zn;
+            s += ra * zn.x;
+            s += rb * zn.y;
+        } else {
+            const double ri = MODE == 1 ? r[i] - alpha * q[i] : r[i];
+            if (MODE == 1) r[i] = ri;
+            double t = MODE == 2 ? ri / D[i] : ri;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int32_t j = rq[rs_at(c, p, rc)];
+                if (j >= 0) t = t - rv[rs_at(c, p, rc)] * dep(j);
+            }
+            const double zi = MODE == 1 ? t / D[i] : t;
+            z[i] = zi;
+            s += ri * zi;
+        }
     }
     const double tot = block_sum<kBlock>(s, red);
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
@@ -1283,7 +1404,7 @@ __global__ void k_rows_index(int32_t n, const int32_t *__restrict__ order, const
     const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const int32_t i = order[p], b = ptr[i], cnt = ptr[i + 1] - b;
-    for (int j = 0; j < rc; ++j) rq[(size_t)j * nstride + p] = j < cnt ? node[b + j] : -1;
+    for (int j = 0; j < rc; ++j) rq[rs_at(j, p, rc)] = j < cnt ? node[b + j] : -1;
 }
 __global__ void k_rows_values(int32_t n, const int32_t *__restrict__ order, const int32_t *__restrict__ ptr, const double *__restrict__ val,
                               uint32_t nstride, int rc, double *__restrict__ rv)
@@ -1291,7 +1412,85 @@ __global__ void k_rows_values(int32_t n, const int32_t *__restrict__ order, cons
     const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const int32_t i = order[p], b = ptr[i], cnt = ptr[i + 1] - b;
-    for (int j = 0; j < rc; ++j) rv[(size_t)j * nstride + p] = j < cnt ? val[b + j] : 0.0;
+    for (int j = 0; j < rc; ++j) rv[rs_at(j, p, rc)] = j < cnt ? val[b + j] : 0.0;
+}
+
+// distinct offsets (dependency row - own row) of the row-space copy into a 64-slot table (INT32_MIN = free); *overflow: more
+__global__ void k_rows_offsets(int32_t n, const int32_t *__restrict__ order, const int32_t *__restrict__ rq, int rc, int32_t *table, int *overflow)
+{
+    const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int32_t i = order[p];
+    for (int c = 0; c < rc; ++c) {
+        const int32_t j = rq[rs_at(c, p, rc)];
+        if (j < 0) continue;
+        const int32_t d = j - i;
+        uint32_t h = ((uint32_t)d * 2654435761u) >> 26;
+        int probe = 0;
+        for (; probe < 64; ++probe, h = (h + 1) & 63u) {
+            int32_t cur = __hip_atomic_load(table + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (almost always: already there)
+            if (cur == d) break;
+            if (cur == INT32_MIN) {
+                cur = atomicCAS(table + h, INT32_MIN, d);
+                if (cur == INT32_MIN || cur == d) break;
+            }
+        }
+        if (probe == 64) *overflow = 1;
+    }
+}
+__global__ void k_rows_encode(int32_t n, const int32_t *__restrict__ order, const int32_t *__restrict__ rq, int rc, const int32_t *__restrict__ dict,
+                              int ndict, uint32_t *__restrict__ rcode)
+{
+    __shared__ int32_t dl[16];
+    if (threadIdx.x < 16) dl[threadIdx.x] = (int)threadIdx.x < ndict ? dict[threadIdx.x] : INT32_MIN;
+    __syncthreads();
+    const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int32_t i = order[p];
+    uint32_t code = 0;
+    for (int c = 0; c < 8; ++c) {
+        uint32_t nib = 15u;
+        const int32_t j = c < rc ? rq[rs_at(c, p, rc)] : -1;
+        if (j >= 0)
+            for (int k = 0; k < ndict; ++k)
+                if (dl[k] == j - i) { nib = (uint32_t)k; break; }
+        code |= nib << (4 * c);
+    }
+    rcode[p] = code;
+}
+// after k_rows_index: the codes, where the factor allows them (see TriFactor::rcode)
+int rows_encode(TriFactor &T, int32_t n)
+{
+    dfree(T.rcode); dfree(T.rdict);
+    T.rcode = nullptr; T.rdict = nullptr; T.nrdict = 0;
+    if (!T.rows_on || T.rc > 8 || n < 1) return SGM_OK;
+    hipStream_t st = g_rt.stream;
+    int32_t *table = nullptr;
+    SGM_TRY(dalloc(&table, 64 + 1));
+    std::vector<int32_t> h(65, INT32_MIN);
+    h[64] = 0;
+    SGM_HIP(hipMemcpyAsync(table, h.data(), 65 * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_rows_offsets, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, (const int32_t *)T.order, (const int32_t *)T.rq, T.rc,
+                       table, reinterpret_cast<int *>(table + 64));
+    SGM_HIP(hipMemcpyAsync(h.data(), table, 65 * 4, hipMemcpyDeviceToHost, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    dfree(table);
+    std::vector<int32_t> dict;
+    for (int k = 0; k < 64; ++k)
+        if (h[k] != INT32_MIN) dict.push_back(h[k]);
+    if (h[64] != 0 || dict.size() > 15) return SGM_OK;
+    std::sort(dict.begin(), dict.end());
+    dict.resize(16, 0);
+    T.nrdict = 0;
+    for (int k = 0; k < 64; ++k) T.nrdict += h[k] != INT32_MIN;
+    SGM_TRY(dalloc(&T.rdict, 16));
+    SGM_TRY(dalloc(&T.rcode, (size_t)n + 2));
+    SGM_HIP(hipMemcpyAsync(T.rdict, dict.data(), 16 * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_rows_encode, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, (const int32_t *)T.order, (const int32_t *)T.rq, T.rc,
+                       (const int32_t *)T.rdict, T.nrdict, T.rcode);
+    SGM_HIP(hipGetLastError());
+    SGM_HIP(hipStreamSynchronize(st));                   // (dict is a local)
+    return SGM_OK;
 }
 
 // the inline values of the row records and their slot-major copy (dv: kInline slots)
@@ -1355,7 +1554,7 @@ void free_ildu(IlduState &S)
 void free_tri(TriFactor &T)
 {
     dfree(T.order); dfree(T.recs); dfree(T.pq); dfree(T.pv); dfree(T.level_ptr_dev); dfree(T.dq); dfree(T.dq32); dfree(T.dv); dfree(T.wq);
-    dfree(T.rq); dfree(T.rv); dfree(T.src);
+    dfree(T.rq); dfree(T.rv); dfree(T.src); dfree(T.rcode); dfree(T.rdict);
     T = TriFactor();
 }
 
@@ -1436,6 +1635,7 @@ int tri_levels_device(TriFactor &T, int32_t n, const int32_t *dptr, const int32_
     SGM_HIP(hipMemsetAsync(T.rv, 0, T.nstride * (size_t)T.rc * 8, st));
     hipLaunchKernelGGL(k_rows_index, dim3(grid), dim3(kBlock), 0, st, n, (const int32_t *)T.order, dptr, dnode, (uint32_t)T.nstride, T.rc, T.rq);
     SGM_HIP(hipGetLastError());
+    SGM_TRY(rows_encode(T, n));
     T.have_levels = true;
     *served = true;
     return SGM_OK;
@@ -1497,6 +1697,7 @@ int tri_levels_dev(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, co
                 SGM_HIP(hipMemsetAsync(T.rv, 0, T.nstride * (size_t)T.rc * 8, st));
                 if (n) hipLaunchKernelGGL(k_rows_index, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, (const int32_t *)T.order, dptr,
                                           dnode, (uint32_t)T.nstride, T.rc, T.rq);
+                SGM_TRY(rows_encode(T, n));
             }
         }
         T.have_levels = true;
@@ -1847,7 +2048,7 @@ void launch_rows(const TriFactor &T, const TriFactor::RowLevel &L, int mode, con
 {
     hipStream_t st = g_rt.stream;
     const int32_t b = L.b, e = L.e;
-    const dim3 g((e - b + kBlock - 1) / kBlock);
+    const dim3 g(8 * (((e - b + kBlock - 1) / kBlock + 7) / 8));           // (a multiple of 8: see the tile map in the kernel)
 #define ROWS_M(CC, MM)                                                                                                         \
     hipLaunchKernelGGL((k_trsv_rows<CC, MM>), g, dim3(kBlock), 0, st, (const int32_t *)T.rq, (const double *)T.rv, (uint32_t)T.nstride, \
                        T.rc, (const int32_t *)T.order, L.row0, b, e, r, y, D, z, n0, flag)
@@ -1892,6 +2093,25 @@ void launch_rows_cg(const TriFactor &T, const TriFactor::RowLevel &L, int mode, 
                     const double *D, double *z, double *part, int grid, const int *flag, int gen)
 {
     hipStream_t st = g_rt.stream;
+    static const bool no_pairs = getenv("SGM_PCG_NO_PAIRS") != nullptr;                  // tuning aids
+    static const bool no_codes = getenv("SGM_PCG_NO_CODES") != nullptr;
+    if (!no_pairs && L.row0 >= 0 && (L.row0 & 1) == 0 && (L.b & 1) == 0 && L.c >= 1 && L.c <= 4) {
+        const bool coded = T.rcode && !no_codes;
+#define ROWS2_M(CC, MM, CD)                                                                                                    \
+    hipLaunchKernelGGL((k_trsv_rows_cg2<CC, MM, CD>), dim3(grid), dim3(kBlock), 0, st, (const int32_t *)T.rq, (const double *)T.rv, T.rc, \
+                       (const uint32_t *)T.rcode, (const int32_t *)T.rdict, L.row0, L.b, L.e, r, q, res2, dpr, D, z, part, flag, gen)
+#define ROWS2(CC) do { if (mode == 1) { if (coded) ROWS2_M(CC, 1, true); else ROWS2_M(CC, 1, false); }                          \
+                       else { if (coded) ROWS2_M(CC, 2, true); else ROWS2_M(CC, 2, false); } } while (0)
+        switch (L.c) {
+        case 1: ROWS2(1); break;
+        case 2: ROWS2(2); break;
+        case 3: ROWS2(3); break;
+        default: ROWS2(4); break;
+        }
+#undef ROWS2
+#undef ROWS2_M
+        return;
+    }
 #define ROWS_M(CC, MM)                                                                                                         \
     hipLaunchKernelGGL((k_trsv_rows_cg<CC, MM>), dim3(grid), dim3(kBlock), 0, st, (const int32_t *)T.rq, (const double *)T.rv, (uint32_t)T.nstride, \
                        T.rc, (const int32_t *)T.order, L.row0, L.b, L.e, r, q, res2, dpr, D, z, part, flag, gen)
@@ -2168,15 +2388,23 @@ void pc_permute_vec(sgm_pc pc, const double *src, double *dst, bool to_permuted)
 // CG's "r -= alpha q; z = M^-1 r; partial sums of r.z" as the two launches of a two-level row-space factorisation
 // (k_trsv_rows_cg).  false: this preconditioner is not of that kind here -- the caller launches the three steps itself.
 // *count = partial sums left in `part`.
-bool pc_cg_fused(sgm_pc pc, ScalarRef res2, ScalarRef dpr, const double *q, double *r, double *z, double *part, int *count, const int *flag, int gen)
+// pc_cg_fused_rows: 0 = not that kind, else n0 -- the caller first updates r(0 .. n0-1) -= alpha q (the rows without L
+// entries: nobody else writes them), then calls pc_cg_fused, which updates the others as its first sweep reaches them
+int32_t pc_cg_fused_rows(sgm_pc pc)
 {
     static const bool off = getenv("SGM_PCG_FUSED") && atoi(getenv("SGM_PCG_FUSED")) == 0;
-    if (off || !pc || pc->kind != SGM_PC_ILDU0 || pc->ild.size() != 1 || (pc->perm && !pc->in_permuted)) return false;
+    if (off || !pc || pc->kind != SGM_PC_ILDU0 || pc->ild.size() != 1 || (pc->perm && !pc->in_permuted)) return 0;
     const IlduState *S = &pc->ild[0];
-    if ((S->opt.ildu_strips && (S->grid_ok || S->slab_ok)) || !S->levels_ready || !rows_two_level(S)) return false;
+    if ((S->opt.ildu_strips && (S->grid_ok || S->slab_ok)) || !S->levels_ready || !rows_two_level(S)) return 0;
+    return S->rows_n0;
+}
+bool pc_cg_fused(sgm_pc pc, ScalarRef res2, ScalarRef dpr, const double *q, double *r, double *z, double *part, int *count, const int *flag, int gen)
+{
+    if (!pc_cg_fused_rows(pc)) return false;
+    const IlduState *S = &pc->ild[0];
     const auto &L1 = S->L.row_levels[1], &U1 = S->U.row_levels[1];
-    const int g1 = std::max(1, std::min(kRowsCgGrid, (L1.e - L1.b + kBlock - 1) / kBlock));
-    const int g2 = std::max(1, std::min(kRowsCgGrid, (U1.e - U1.b + kBlock - 1) / kBlock));
+    auto grid_for = [](int32_t rows) { return 8 * std::max(1, std::min(kRowsCgGrid / 8, ((rows + kBlock - 1) / kBlock + 7) / 8)); };
+    const int g1 = grid_for(L1.e - L1.b), g2 = grid_for(U1.e - U1.b);
     launch_rows_cg(S->L, L1, 1, r, q, res2, dpr, S->D, z, part, g1, flag, gen);
     launch_rows_cg(S->U, U1, 2, r, q, res2, dpr, S->D, z, part + g1, g2, flag, gen);
     *count = g1 + g2;

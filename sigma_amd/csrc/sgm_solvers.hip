@@ -43,6 +43,7 @@ int pc_retire_pipelines(sgm_pc pc);
 sgm_mat pc_permuted_matrix(sgm_pc pc, sgm_mat A);    // ILDU of the colour-ordered A: P A P^T (the solve runs in its order); null otherwise
 void pc_in_permuted(sgm_pc pc, bool on);
 void pc_permute_vec(sgm_pc pc, const double *src, double *dst, bool to_permuted);
+int32_t pc_cg_fused_rows(sgm_pc pc);
 bool pc_cg_fused(sgm_pc pc, ScalarRef res2, ScalarRef dpr, const double *q, double *r, double *z, double *part, int *count, const int *flag, int gen);
 
 // ------------------------------------------------------------------ generic fused kernel
@@ -1490,6 +1491,11 @@ __device__ inline int xcc_id()
 // h): every reader of that set's previous use arrived at hand-off h - 1 before anyone could pass it.  Bounded: a poll that
 // gives up raises `abort`, and every poll loop looks at it.
 constexpr unsigned long long kCoopPoison = 0x7ff8c0de5a5a0001ull;
+// The slot sets exist in kCoopReplicas copies, kCoopRepStride doubles apart (lines -- and memory channels -- of their own): a
+// publisher writes all of them with ONE wave instruction (lane k stores copy k), a workgroup polls the copy of its XCD.  With
+// one copy, 256 workgroups re-reading the same 16 lines made a poll round a queue at one or two channels (2.3 us per
+// all-CU hand-off against 0.4 inside one XCD).  Which copy a workgroup polls is a matter of speed only.
+constexpr int kCoopReplicas = 8, kCoopRepStride = 4 * 256 + 32;
 #ifdef SGM_COOP_PROBE
 // tuning aid (-DSGM_COOP_PROBE builds only): where an iteration's time goes, in 10 ns ticks summed over the launch, as seen by
 // thread 0 of workgroup 0.  [0..7] the phases of the iteration, [8..11] inside a hand-off, [15] iterations
@@ -1498,9 +1504,11 @@ __device__ long long g_coop_probe[16];
 #else
 #define PROBE_T(k) do { } while (0)
 #endif
-__device__ inline bool coop_handoff(double *slots /* 4 x 256 */, int h, double mine, int wg, int G, bool l2, int *abort, int spin_limit, double *red,
-                                    int *lds_ok, double *sum_out, long long *pacc = nullptr)
+__device__ inline bool coop_handoff(double *slots /* replicas x 4 x 256 */, int h, double mine, int wg, int G, bool l2, int *abort, int spin_limit, double *red,
+                                    int *lds_ok, double *sum_out, int reps, long long *pacc = nullptr)
 {
+    // (reps = 1, the one-XCD variant: copy 0 only, for its proof of co-location too -- at most 32 pollers)
+    const int my_rep = reps == 1 ? 0 : (xcc_id() & (kCoopReplicas - 1));
 #ifdef SGM_COOP_PROBE
     const bool probing = pacc != nullptr;
     long long tlast = probing ? wall_clock64() : 0;
@@ -1510,16 +1518,14 @@ __device__ inline bool coop_handoff(double *slots /* 4 x 256 */, int h, double m
     PROBE_T(8);
     const int tid = threadIdx.x;
     double *set = slots + (h & 3) * 256;
-    if (tid == 0) {
-        *lds_ok = 1;
-        st_pub(set + wg, mine, l2);
-    }
+    if (tid == 0) *lds_ok = 1;
+    if (tid < reps) st_pub(set + tid * kCoopRepStride + wg, mine, l2);
     double v = 0.0;
     int ok = 1;
     if (tid < G) {
         int spins = 0;
         for (;;) {
-            v = ld_sc1(set + tid);
+            v = ld_sc1(set + my_rep * kCoopRepStride + tid);
             if (__double_as_longlong(v) != (long long)kCoopPoison) break;
             if (++spins > spin_limit || ((spins & 31) == 0 && __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                 __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1535,7 +1541,7 @@ __device__ inline bool coop_handoff(double *slots /* 4 x 256 */, int h, double m
     if (!ok) *lds_ok = 0;
     const double ssum = block_sum<1024>(v, red);             // (its barriers publish lds_ok)
     PROBE_T(11);
-    if (tid == 0) st_pub(slots + ((h + 2) & 3) * 256 + wg, __longlong_as_double((long long)kCoopPoison), l2);
+    if (tid < reps) st_pub(slots + ((h + 2) & 3) * 256 + tid * kCoopRepStride + wg, __longlong_as_double((long long)kCoopPoison), l2);
     *sum_out = ssum;
     return *lds_ok != 0;
 }
@@ -1571,9 +1577,9 @@ __global__ __launch_bounds__(1024) void k_cg_coop(
 #ifdef SGM_COOP_PROBE
     long long pacc_[16] = {0}, *pacc = pacc_, tlast = 0;
     const bool probing = wg == 0 && tid == 0;
-    auto handoff = [&](double mine, double &total) { const bool ok_ = coop_handoff(slots, h, mine, wg, G, XL, abort, spin_limit, red, lds_ok, &total, probing ? pacc : nullptr); ++h; return ok_; };
+    auto handoff = [&](double mine, double &total) { const bool ok_ = coop_handoff(slots, h, mine, wg, G, XL, abort, spin_limit, red, lds_ok, &total, XL ? 1 : kCoopReplicas, probing ? pacc : nullptr); ++h; return ok_; };
 #else
-    auto handoff = [&](double mine, double &total) { const bool ok_ = coop_handoff(slots, h, mine, wg, G, XL, abort, spin_limit, red, lds_ok, &total); ++h; return ok_; };
+    auto handoff = [&](double mine, double &total) { const bool ok_ = coop_handoff(slots, h, mine, wg, G, XL, abort, spin_limit, red, lds_ok, &total, XL ? 1 : kCoopReplicas); ++h; return ok_; };
 #endif
     auto own_dot = [&](const double (&prod)[RMAX]) {
         double sacc = 0.0;
@@ -1657,7 +1663,7 @@ __global__ __launch_bounds__(1024) void k_cg_coop(
     if (XL) {                                              // the proof of co-location (placement-independent hand-off)
         double total;
         const double mark = __longlong_as_double((long long)(1023 + 6 * xcc_id()) << 52);       // 64^id
-        ok = coop_handoff(slots, h, mark, wg, G, false, abort, spin_limit, red, lds_ok, &total);
+        ok = coop_handoff(slots, h, mark, wg, G, false, abort, spin_limit, red, lds_ok, &total, 1);
         ++h;
         if (ok && total != mark * (double)G) {
             if (tid == 0) __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1808,12 +1814,14 @@ static bool coop_applies(sgm_solver s, sgm_mat A, sgm_pc pc, int *rmax_out, int 
     }
     const int H = (s->coop_reach + 1) & ~1;
     static const int force_rmax = getenv("SGM_CG_COOP_RMAX") ? atoi(getenv("SGM_CG_COOP_RMAX")) : 0;
-    // XCD-local variant: the whole system on the <= 32 CUs of one XCD (1, 2, 3 rows per thread with the matrix in registers, 4 streamed)
+    // XCD-local variant: the whole system on the <= 32 CUs of one XCD, 1, 2 or 3 rows per thread with the matrix in registers
+    // (4 rows per thread stream the matrix through one XCD's L2 / fabric port: 8.6-9.8 us per iteration at n = 1e5 .. 1.3e5
+    // where the all-CU variant with one row per thread takes ~8.5)
     static const bool xl_off = getenv("SGM_CG_COOP_XCD") && atoi(getenv("SGM_CG_COOP_XCD")) == 0;
     *xl_out = false;
     if (!xl_off && !s->coop_xl_retired && g_rt.num_cu >= 64) {
         for (int rmax : {1, 2, 3, 4}) {
-            if (force_rmax && rmax != force_rmax) continue;
+            if (force_rmax ? rmax != force_rmax : rmax == 4) continue;
             const int64_t rpw = (int64_t)rmax * 1024, G = (p.n + rpw - 1) / rpw;
             if (G > std::min(32, g_rt.num_cu / 8) || H > rpw || (rpw + 2 * H + 32) * 8 > 160 * 1024) continue;
             *rmax_out = rmax; *halo_out = H; *xl_out = true;
@@ -1842,19 +1850,19 @@ static int run_cg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_
     const size_t lds = (size_t)(rpw + 2 * H + 32) * sizeof(double);
     *ran = false;
     auto arm = [&]() -> int {                                  // every slot "not yet written", abort word clear, hand-offs from 0
-        std::vector<unsigned long long> pat(4 * 256, kCoopPoison);
+        std::vector<unsigned long long> pat((size_t)kCoopReplicas * kCoopRepStride, kCoopPoison);
         SGM_HIP(hipMemcpyAsync(s->coop_buf + p.n, pat.data(), pat.size() * 8, hipMemcpyHostToDevice, g_rt.stream));
-        SGM_HIP(hipMemsetAsync(s->coop_buf + p.n + 4 * 256, 0, 64, g_rt.stream));
+        SGM_HIP(hipMemsetAsync(s->coop_buf + p.n + (size_t)kCoopReplicas * kCoopRepStride, 0, 64, g_rt.stream));
         SGM_HIP(hipStreamSynchronize(g_rt.stream));
         s->coop_base = 0;
         return SGM_OK;
     };
     if (!s->coop_buf) {
-        if (dalloc(&s->coop_buf, (size_t)p.n + 4 * 256 + 64) != SGM_OK) return SGM_OK;
+        if (dalloc(&s->coop_buf, (size_t)p.n + (size_t)kCoopReplicas * kCoopRepStride + 64) != SGM_OK) return SGM_OK;
         SGM_TRY(arm());
     }
     double *gz = s->coop_buf, *slots = gz + p.n;
-    int *abortw = reinterpret_cast<int *>(slots + 4 * 256);
+    int *abortw = reinterpret_cast<int *>(slots + (size_t)kCoopReplicas * kCoopRepStride);
     int flag = 0; int64_t iters = 0; double res = 0.0;
     for (int resume = 0;; resume = 1) {
         int64_t it_end = iters + s->small_chunk();
@@ -2023,9 +2031,14 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
             else if (pk == SGM_PC_JACOBI)
                 launch_elem(w.n, FCgR<1>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_Q), W(ip, V_R), pc_idiag(pc, ip),
                                          W(ip, V_Z), part(s, ip, nxt)}, w.flag, gen);
-            else if (P == 1 && !s->seq && pc_cg_fused(pc, ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_Q), W(ip, V_R), W(ip, V_Z), part(s, ip, nxt),
-                                                     &w.count[nxt], w.flag, gen))
-                fused_pc = true;                           // (r update, both sweeps and the partial sums of r.z: two launches)
+            else if (const int32_t n0 = (P == 1 && !s->seq) ? pc_cg_fused_rows(pc) : 0) {
+                // two-level factors: r -= alpha q on the rows without L entries, then that update for the other rows, both sweeps
+                // and the partial sums of r.z in the sweeps' two launches
+                launch_elem((int64_t)n0, FCgR<2>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_Q), W(ip, V_R), nullptr, nullptr, nullptr}, w.flag, gen);
+                fused_pc = pc_cg_fused(pc, ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_Q), W(ip, V_R), W(ip, V_Z), part(s, ip, nxt), &w.count[nxt],
+                                       w.flag, gen);
+                if (!fused_pc) return fail(SGM_ERR_HIP, "run_cg: the fused sweeps withdrew after their first step");
+            }
             else
                 launch_elem(w.n, FCgR<2>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_Q), W(ip, V_R), nullptr, nullptr,
                                          nullptr}, w.flag, gen);

@@ -1864,7 +1864,8 @@ def test_row_space_level_sweeps_of_colour_ordered_factors(orc, case):
     s1 = sg.cg(tolerance=1e-10)
     s1.setup(H)
     s1.solve(H, u1, x2, pc)
-    assert s1.iterations == it0 and np.array_equal(u1, u0)
+    # (CG folds its r update and r.z into the row-space sweeps: the same r and z, the dot summed over another partition)
+    assert abs(s1.iterations - it0) <= 1 and np.abs(u1 - u0).max() <= 1e-10 * np.abs(u0).max()
     # new values, same pattern: the value slots are refreshed, the index work is not redone
     H.set_values(B.val * 1.5)
     pc.setup(H)
