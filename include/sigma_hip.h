@@ -126,9 +126,11 @@ int sgm_synchronize(void);
  *                          sgm_pc_get "pipeline_retired"); tests set 1 to force that path
  *   "ildu_reorder" (0)     1 = the preconditioner is ILDU(0) of the COLOUR-ORDERED matrix P A P^T (P = the reference's
  *                          greedy_color_ordering of A's graph, permutations.f90:162-205; on the device for bipartite graphs such
- *                          as the 5- / 7-point grids) applied as z = P^T M^-1 P r.  Its factors have one dependency level per
+ *                          as the 5- / 7-point grids); sgm_pc_apply is z = P^T M^-1 P r.  Its factors have one dependency level per
  *                          colour whatever order A is in, so an apply is a few bandwidth-bound launches instead of a
- *                          dependency chain of nx + ny levels; the solver keeps working on A, b, x as they are.  A different
+ *                          dependency chain of nx + ny levels.  The caller keeps A, b, x as they are; the preconditioner keeps
+ *                          P A P^T, and sgm_solver_solve -- handed the matrix the preconditioner was set up with, unchanged
+ *                          since -- runs the whole solve in that order (x, b permuted once each way).  A different
  *                          (equally valid) preconditioner than ILDU(0) in A's own order: iteration counts are those of the
  *                          permuted system -- off by default because the reference's `ldu()` factors A in the given order
  * Process-wide (sgm_set_option only)

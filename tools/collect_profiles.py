@@ -21,6 +21,11 @@ for sub, name in (("stats", "kernel_stats.csv"), ("stats_ildu", "kernel_stats_il
         shutil.copy(f, os.path.join(dst, name))
 if os.path.exists(os.path.join(src, "time_to_solution.log")):
     shutil.copy(os.path.join(src, "time_to_solution.log"), os.path.join(dst, "time_to_solution_cg_jacobi_ildu.txt"))
+for name, to in (("pmc_colour_ildu.txt", "pmc_colour_ildu.txt"), ("cg_small_coop.jsonl", "cg_per_iteration_cooperative.jsonl"),
+                 ("cg_small_launch_loop.jsonl", "cg_per_iteration_launch_loop.jsonl"), ("bicgstab_small.jsonl", "bicgstab_per_iteration.jsonl"),
+                 ("coop_probe.jsonl", "cg_coop_phase_timers.jsonl"), ("wave_sum_probe.txt", "wave_sum_probe.txt")):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, to))
 if os.path.exists(os.path.join(src, "configs.jsonl")):
     shutil.copy(os.path.join(src, "configs.jsonl"), os.path.join(dst, "configs_c3_c4_c5.jsonl"))
 

@@ -20,6 +20,17 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_i
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ildu3 -- python3 tools/ildu_bench.py -100 ildu0 > $OUT/stats_ildu3.log 2>&1 < /dev/null
 # colour-ordered ILDU(0)-PCG at C2 size (row-space level sweeps): per-kernel times
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ildu_colour -- python3 tools/ildu_bench.py 3162 ildu0 colour > $OUT/stats_ildu_colour.log 2>&1 < /dev/null
+# HBM bytes of the colour-ordered sweeps (k_trsv_rows_cg2, k_trsv_rows2) and the product on the permuted matrix
+bash tools/probes/pmc_colour_ildu.sh > $OUT/pmc_colour_ildu.txt 2>&1
+# CG per iteration on mid-sized grids (one-workgroup / one-XCD / all-CU cooperative kernels, launch loop beyond), C1, and
+# where an iteration of the cooperative kernel spends its time (phase timers: the -DSGM_COOP_PROBE build of the library)
+NXS=32,64,100,181,256,300,316,362,500,700,1000,1500,2000 SOLVERS=cg KRYLOV_GRAPH=1 timeout 600 python tools/cg_small.py 2>&1 | grep '^{' > $OUT/cg_small_coop.jsonl
+NXS=100,316,1000,2000 SOLVERS=cg KRYLOV_GRAPH=1 NO_C1=1 SGM_CG_COOP=0 timeout 600 python tools/cg_small.py 2>&1 | grep '^{' > $OUT/cg_small_launch_loop.jsonl
+NXS=32,100,316,1000 SOLVERS=bicgstab KRYLOV_GRAPH=1 NO_C1=1 timeout 600 python tools/cg_small.py 2>&1 | grep '^{' > $OUT/bicgstab_small.jsonl
+if [ -f tools/probes/libsigma_hip_probe.so ]; then
+  NXS=100,256,300,500,1000 timeout 300 python tools/probes/coop_probe.py 2>&1 | grep '^{' > $OUT/coop_probe.jsonl
+fi
+[ -x tools/probes/wave_sum_probe ] && ./tools/probes/wave_sum_probe > $OUT/wave_sum_probe.txt 2>&1
 # time to solution: CG / Jacobi-PCG / ILDU(0)-PCG in natural and colour order, with the setup phases (SGM_PC_TIMING)
 for a in "1000 cg,jacobi,ildu0,ildu0_reorder" "1000 cg,ildu0 colour" "3162 cg,ildu0,ildu0_reorder" "3162 cg,ildu0 colour" "-100 cg,jacobi,ildu0,ildu0_reorder" "-100 cg,ildu0 colour"; do
   echo "== tools/ildu_bench.py $a"
@@ -36,3 +47,6 @@ cat $OUT/bench.json | cut -c1-600
 # with the fingerprint of the sources that just ran) so that `roofline.traffic` of the line is this run's own figure
 python tools/collect_profiles.py ${TAG:-r04} > /dev/null 2>&1
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo bench_with_traffic=$?
+# what travels back is capped at 64 MiB: the per-dispatch traces are not needed once the stats exist
+find $OUT -name "*kernel_trace.csv" -delete
+du -sh $OUT
