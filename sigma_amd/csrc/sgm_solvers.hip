@@ -732,6 +732,15 @@ __global__ __launch_bounds__(kBlock) void k_gs(int64_t n, int k, double *__restr
     }
 }
 // block c: slots[c] = sum of partial array c (count entries each, kMaxGrid apart)
+// up to four dots collapsed by one launch: block b = dot b (k_reduce's sum, same order)
+struct ReduceSet { const double *part[4]; int count[4]; double *slot[4]; };
+__global__ __launch_bounds__(kBlock) void k_reduce_set(ReduceSet rs)
+{
+    __shared__ double red[kBlock / 64];
+    ScalarRef r{rs.part[blockIdx.x], rs.count[blockIdx.x]};
+    const double d = load_scalar<kBlock>(r, red);
+    if (threadIdx.x == 0) *rs.slot[blockIdx.x] = d;
+}
 __global__ __launch_bounds__(kBlock) void k_reduce_many(const double *parts, int count, double *slots)
 {
     __shared__ double red[kBlock / 64];
@@ -1042,9 +1051,16 @@ int finish_dots(sgm_solver s, sgm_mat A, const int *ks, int nk, const int (*vecs
         // one part, a solver whose update kernels each read many scalars (BiCGStab: up to six), a large system: every dot is
         // collapsed ONCE by a one-block kernel instead of being re-reduced from its <= 4096 partials by each of the 2048
         // workgroups of every consumer (k_reduce IS load_scalar: same order, same bits)
-        for (int t = 0; t < nk; ++t)
-            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, g_rt.stream, part(s, 0, ks[t]), s->work[0].count[ks[t]],
-                               s->work[0].slots + ks[t]);
+        for (int t = 0; t < nk; t += 4) {
+            ReduceSet rs{};
+            const int m = std::min(4, nk - t);
+            for (int u = 0; u < m; ++u) {
+                rs.part[u] = part(s, 0, ks[t + u]);
+                rs.count[u] = s->work[0].count[ks[t + u]];
+                rs.slot[u] = s->work[0].slots + ks[t + u];
+            }
+            hipLaunchKernelGGL(k_reduce_set, dim3(m), dim3(kBlock), 0, g_rt.stream, rs);
+        }
         return SGM_OK;
     }
     if (!s->multi) return SGM_OK;
@@ -1554,7 +1570,10 @@ __device__ inline bool coop_handoff(double *slots /* replicas x 4 x 256 */, int 
 // G x 64^(own id) -- every participant on this XCD -- lets the launch continue; anything else raises `abort` like a poll that gave up.
 // From then on the published doubles leave as stores that STAY in that XCD's L2 and the sc1 polls are L2 hits: a hand-off
 // costs a few hundred cycles instead of two trips over the fabric.
-template <int RMAX, bool JAC, int SW, bool XL>
+// LS (streamed form only): the first LS slots of the own rows are copied into LDS once (beside p) and only the others are
+// re-read every iteration -- at 4 rows per thread 3 of a 5-point matrix's 5 slots fit (96 KiB), and what is left of a
+// 1e6-row matrix (16 MB) stays in the L2s instead of streaming 40 MB from the Infinity Cache per iteration.
+template <int RMAX, bool JAC, int SW, bool XL, int LS = 0>
 __global__ __launch_bounds__(1024) void k_cg_coop(
     int32_t n, int32_t sw, int32_t H, const uint32_t *__restrict__ scode, const int32_t *__restrict__ dict, const double *__restrict__ sval,
     double *x, const double *b, const double *__restrict__ idiag, double tol, int64_t it_end, int resume,
@@ -1567,6 +1586,7 @@ __global__ __launch_bounds__(1024) void k_cg_coop(
     double *pl = lds;                                   // p of rows r0 - H .. r0 + RPW + H - 1
     double *red = pl + RPW + 2 * H;                      // 16 doubles of block-sum scratch
     int *lds_ok = reinterpret_cast<int *>(red + 16);
+    double *ml = red + 32;                               // LS x RPW matrix entries (LS > 0)
     __shared__ int32_t dl[16];
     if (XL && (blockIdx.x & 7) != 0) return;
     const int tid = threadIdx.x, G = XL ? (int)(gridDim.x >> 3) : (int)gridDim.x, wg = XL ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
@@ -1599,6 +1619,11 @@ __global__ __launch_bounds__(1024) void k_cg_coop(
             for (int e = 0; e < SW; ++e)
                 mv[u][e] = ((cwr[u] >> (4 * e)) & 15u) != 15u ? sval[((int64_t)(i >> 9) * sw + e) * 512 + (i & 511)] : 0.0;
         }
+        if (SW == 0 && LS > 0) {
+#pragma unroll
+            for (int e = 0; e < LS; ++e)
+                ml[e * RPW + tid + u * BLOCK] = (e < sw && ((cwr[u] >> (4 * e)) & 15u) != 15u) ? sval[((int64_t)(i >> 9) * sw + e) * 512 + (i & 511)] : 0.0;
+        }
     }
     auto row_sums = [&](double (&q)[RMAX]) {
         if (SW > 0) {
@@ -1625,7 +1650,8 @@ __global__ __launch_bounds__(1024) void k_cg_coop(
 #pragma unroll
             for (int u = 0; u < RMAX; ++u) {
                 const int32_t i = r0 + tid + u * BLOCK;
-                if (((cw[u] >> (4 * e)) & 15u) != 15u) v[u] = sval[((int64_t)(i >> 9) * sw + e) * 512 + (i & 511)];
+                if (LS > 0 && e < LS) v[u] = ml[e * RPW + tid + u * BLOCK];       // (its own thread wrote it: no barrier needed)
+                else if (((cw[u] >> (4 * e)) & 15u) != 15u) v[u] = sval[((int64_t)(i >> 9) * sw + e) * 512 + (i & 511)];
             }
 #pragma unroll
             for (int u = 0; u < RMAX; ++u) {
@@ -1847,7 +1873,10 @@ static int run_cg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_
     const bool jac = pc && pc_kind(pc) == SGM_PC_JACOBI;
     const int64_t rpw = (int64_t)rmax * 1024;
     const int G = (int)((p.n + rpw - 1) / rpw);
-    const size_t lds = (size_t)(rpw + 2 * H + 32) * sizeof(double);
+    // 4 rows per thread (streamed matrix): three slots of it in LDS where they fit beside p and its halo
+    static const bool no_ls = getenv("SGM_CG_COOP_NO_LDS_MATRIX") != nullptr;          // tuning aid
+    const bool ls3 = !no_ls && !xl && rmax == 4 && (size_t)(rpw + 2 * H + 32 + 3 * rpw) * sizeof(double) <= 160 * 1024;
+    const size_t lds = (size_t)(rpw + 2 * H + 32 + (ls3 ? 3 * rpw : 0)) * sizeof(double);
     *ran = false;
     auto arm = [&]() -> int {                                  // every slot "not yet written", abort word clear, hand-offs from 0
         std::vector<unsigned long long> pat((size_t)kCoopReplicas * kCoopRepStride, kCoopPoison);
@@ -1877,6 +1906,14 @@ static int run_cg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_
                            s->tolerance, it_end, resume, w.vec[V_R], w.vec[V_P], gz, slots, abortw, s->coop_base & 3, spin, \
                            w.flag, w.iters, w.res, w.history, s->hist_cap);                                           \
     } while (0)
+#define LC5(R, J, W, X, L)                                                                                              \
+    do {                                                                                                             \
+        if (!allow_lds((const void *)k_cg_coop<R, J, W, X, L>, lds)) return SGM_OK;                                   \
+        hipLaunchKernelGGL((k_cg_coop<R, J, W, X, L>), dim3(X ? 8 * G : G), dim3(1024), lds, g_rt.stream, p.n, p.sw, H, (const uint32_t *)p.scode, \
+                           (const int32_t *)p.dict, (const double *)p.sval, x, b, jac ? pc_idiag(pc, 0) : nullptr,   \
+                           s->tolerance, it_end, resume, w.vec[V_R], w.vec[V_P], gz, slots, abortw, s->coop_base & 3, spin, \
+                           w.flag, w.iters, w.res, w.history, s->hist_cap);                                           \
+    } while (0)
 #define LCJ(R, W, X) do { if (jac) LC(R, true, W, X); else LC(R, false, W, X); } while (0)
         // the matrix in registers where RMAX * sw doubles fit beside x, r and the temporaries
 #define LCW(R, X) do { if (p.sw == 3) LCJ(R, 3, X); else if (p.sw == 5) LCJ(R, 5, X); else if (p.sw == 7) LCJ(R, 7, X); else LCJ(R, 8, X); } while (0)
@@ -1895,9 +1932,11 @@ static int run_cg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_
         else if (rmax == 2 && !stream_env) LCW(2, false);
         else if (rmax == 1) LCJ(1, 0, false);
         else if (rmax == 2) LCJ(2, 0, false);
+        else if (ls3) { if (jac) LC5(4, true, 0, false, 3); else LC5(4, false, 0, false, 3); }
         else LCJ(4, 0, false);
 #undef LCW
 #undef LCJ
+#undef LC5
 #undef LC
         SGM_HIP(hipGetLastError());
         int habort = 0;
@@ -2375,6 +2414,7 @@ int run_bicgstab(sgm_solver s, sgm_mat A, double *const *x, const double *const 
         }
         // ST/TT ids are not adjacent for one parity: two calls keep slots contiguous
         if (s->seq) { const int ks[2] = {B_ST + c, B_TT + c}; SGM_TRY(finish_dots(s, A, ks, 2, v_st_tt, true)); }
+        else if (s->reduce_single) { const int ks[2] = {B_ST + c, B_TT + c}; SGM_TRY(finish_dots(s, A, ks, 2)); }      // (one launch collapses both)
         else {
             { const int ks[1] = {B_ST + c}; SGM_TRY(finish_dots(s, A, ks, 1)); }
             { const int ks[1] = {B_TT + c}; SGM_TRY(finish_dots(s, A, ks, 1)); }
@@ -2387,6 +2427,7 @@ int run_bicgstab(sgm_solver s, sgm_mat A, double *const *x, const double *const 
                                    x[ip], W(ip, W_R), part(s, ip, B_RR + o), part(s, ip, B_RHO + o)}, w.flag);
         }
         if (s->seq) { const int ks[2] = {B_RR + o, B_RHO + o}; SGM_TRY(finish_dots(s, A, ks, 2, v_rr_rho, true)); }
+        else if (s->reduce_single) { const int ks[2] = {B_RR + o, B_RHO + o}; SGM_TRY(finish_dots(s, A, ks, 2)); }
         else {
             { const int ks[1] = {B_RR + o}; SGM_TRY(finish_dots(s, A, ks, 1)); }
             { const int ks[1] = {B_RHO + o}; SGM_TRY(finish_dots(s, A, ks, 1)); }
@@ -2617,7 +2658,8 @@ int sgm_solver_setup(sgm_solver s, sgm_mat A)
     s->multi = A->distributed();
     {
         static const int rs_env = getenv("SGM_REDUCE_SINGLE") ? atoi(getenv("SGM_REDUCE_SINGLE")) : -1;      // tuning aid
-        s->reduce_single = !s->multi && A->fmt != SGM_FMT_COMPOSITE && s->kind == SGM_SOLVER_BICGSTAB &&
+        // (BiCGStab: six scalars per update kernel, C3 2535 -> 2859 it/s; CG: two or three, C2 4650 -> 4730)
+        s->reduce_single = !s->multi && A->fmt != SGM_FMT_COMPOSITE && (s->kind == SGM_SOLVER_BICGSTAB || s->kind == SGM_SOLVER_CG) &&
                            (rs_env >= 0 ? rs_env != 0 : A->nrow >= (1 << 21));
     }
     bool realloc = !s->initialized || s->work.size() != A->parts.size();

@@ -100,6 +100,12 @@ def main():
                 seen["not connected"] = seen.get("not connected", 0) + 1
                 H.destroy()
                 continue
+            try:                                              # the device ordering (union-find / level sweep / host pass) is the reference's
+                pref, _, ncref = orc.greedy_color_ordering(A)
+                if not np.array_equal(p, pref) or int(nc) != int(ncref):
+                    bad.append(((t, kind, n), "greedy_color_ordering"))
+            except ValueError:
+                bad.append(((t, kind, n), "greedy_color_ordering: oracle refuses, library orders"))
             H.left_permute(p); H.right_permute(p)
             B = orc.permuted(A, p, p)
             check((t, kind, n, "colour", int(nc)), B, H, bad)
