@@ -2594,9 +2594,8 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
     int rc = sgm_mat_left_permute(Ap, pc->perm, SGM_DEVICE);
     if (rc == SGM_OK) rc = sgm_mat_right_permute(Ap, pc->perm, SGM_DEVICE);
     if (rc == SGM_OK) {                                   // the kernel forms A itself has, once, on the finished copy
-        Ap->parts[0].opt = A->parts[0].opt;
-        Ap->parts[0].opt.csr_lean = 0;                    // (the factorisation below reads the CSR-order arrays)
-        rc = rebuild_csr_formats(Ap->parts[0]);
+        Ap->parts[0].opt = A->parts[0].opt;               // (csr_lean included: the factorisation below gets the CSR-order arrays
+        rc = rebuild_csr_formats(Ap->parts[0]);           //  rebuilt for its duration, like any reader of a lean matrix)
     }
     pc->reorder_ms[1] = ms_since(t0);
     t0 = std::chrono::steady_clock::now();

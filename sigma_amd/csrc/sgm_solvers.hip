@@ -1849,7 +1849,7 @@ static bool coop_applies(sgm_solver s, sgm_mat A, sgm_pc pc, int *rmax_out, int 
         for (int rmax : {1, 2, 3, 4}) {
             if (force_rmax ? rmax != force_rmax : rmax == 4) continue;
             const int64_t rpw = (int64_t)rmax * 1024, G = (p.n + rpw - 1) / rpw;
-            if (G > std::min(32, g_rt.num_cu / 8) || H > rpw || (rpw + 2 * H + 32) * 8 > 160 * 1024) continue;
+            if (G > std::min(32, g_rt.num_cu / 8) || (rpw + 2 * H + 32) * 8 > 160 * 1024) continue;
             *rmax_out = rmax; *halo_out = H; *xl_out = true;
             return true;
         }
@@ -1857,8 +1857,9 @@ static bool coop_applies(sgm_solver s, sgm_mat A, sgm_pc pc, int *rmax_out, int 
     for (int rmax : {1, 2, 4}) {
         if (force_rmax && rmax != force_rmax) continue;
         const int64_t rpw = (int64_t)rmax * 1024, G = (p.n + rpw - 1) / rpw;
-        // one workgroup per CU (co-residency), neighbours only (H <= rows per workgroup), LDS: p + halo + scratch <= 160 KiB
-        if (G > std::min(256, g_rt.num_cu) || H > rpw || (rpw + 2 * H + 32) * 8 > 160 * 1024) continue;
+        // one workgroup per CU (co-residency), LDS: p + halo + scratch <= 160 KiB.  (A halo wider than a workgroup's rows -- the
+        // planes of a 3-D grid -- is fine: then every row is published, and the halo is read from several owners' rows.)
+        if (G > std::min(256, g_rt.num_cu) || (rpw + 2 * H + 32) * 8 > 160 * 1024) continue;
         *rmax_out = rmax; *halo_out = H;
         return true;
     }

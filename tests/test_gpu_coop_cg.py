@@ -34,6 +34,7 @@ def _cases():
     yield "1-D tridiagonal n = 50001 (odd: a scalar tail, halo 2)", 50001, P.tridiag_csr(50001, 2.5, -1.0, -1.0)
     yield "2-D 5-point 300 x 300 (n = 90000: three rows per thread on one XCD)", 300 * 300, P.poisson2d_csr(300, 300)
     yield "2-D 5-point 520 x 410 (n = 213200: beyond one XCD, the all-CU variant)", 520 * 410, P.poisson2d_csr(520, 410)
+    yield "3-D 7-point 70 x 66 x 30 (halo = a plane of 4620 rows, wider than a workgroup's 1024)", 70 * 66 * 30, P.laplace3d_csr(70, 66, 30)
 
 
 @pytest.mark.parametrize("jac", [False, True])
