@@ -373,6 +373,23 @@ __device__ inline double block_sum(double v, double *red /* BLOCK/64 doubles of 
     return s;
 }
 
+// two block sums sharing their barriers (each summed exactly as block_sum does: same bits); red: 2 * BLOCK / 64 doubles
+template <int BLOCK>
+__device__ inline void block_sum2(double a, double b, double *red, double &sa, double &sb)
+{
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[wave] = a; red[BLOCK / 64 + wave] = b; }
+    __syncthreads();
+    double s = red[0], t = red[BLOCK / 64];
+#pragma unroll
+    for (int w = 1; w < BLOCK / 64; ++w) { s += red[w]; t += red[BLOCK / 64 + w]; }
+    sa = s;
+    sb = t;
+}
+
 template <int BLOCK>
 __device__ inline double load_scalar(ScalarRef r, double *red)
 {

@@ -1511,7 +1511,8 @@ constexpr unsigned long long kCoopPoison = 0x7ff8c0de5a5a0001ull;
 // publisher writes all of them with ONE wave instruction (lane k stores copy k), a workgroup polls the copy of its XCD.  With
 // one copy, 256 workgroups re-reading the same 16 lines made a poll round a queue at one or two channels (2.3 us per
 // all-CU hand-off against 0.4 inside one XCD).  Which copy a workgroup polls is a matter of speed only.
-constexpr int kCoopReplicas = 8, kCoopRepStride = 4 * 256 + 32;
+constexpr int kCoopReplicas = 8, kCoopRepStride = 4 * 256 + 32, kCoopSecond = kCoopReplicas * kCoopRepStride;      // (second scalar of a hand-off: a region of its own)
+constexpr int kCoopSlotDoubles = 2 * kCoopSecond;
 #ifdef SGM_COOP_PROBE
 // tuning aid (-DSGM_COOP_PROBE builds only): where an iteration's time goes, in 10 ns ticks summed over the launch, as seen by
 // thread 0 of workgroup 0.  [0..7] the phases of the iteration, [8..11] inside a hand-off, [15] iterations
@@ -1521,7 +1522,7 @@ __device__ long long g_coop_probe[16];
 #define PROBE_T(k) do { } while (0)
 #endif
 __device__ inline bool coop_handoff(double *slots /* replicas x 4 x 256 */, int h, double mine, int wg, int G, bool l2, int *abort, int spin_limit, double *red,
-                                    int *lds_ok, double *sum_out, int reps, long long *pacc = nullptr)
+                                    int *lds_ok, double *sum_out, int reps, long long *pacc = nullptr, bool second_region = false)
 {
     // (reps = 1, the one-XCD variant: copy 0 only, for its proof of co-location too -- at most 32 pollers)
     const int my_rep = reps == 1 ? 0 : (xcc_id() & (kCoopReplicas - 1));
@@ -1557,8 +1558,89 @@ __device__ inline bool coop_handoff(double *slots /* replicas x 4 x 256 */, int 
     if (!ok) *lds_ok = 0;
     const double ssum = block_sum<1024>(v, red);             // (its barriers publish lds_ok)
     PROBE_T(11);
-    if (tid < reps) st_pub(slots + ((h + 2) & 3) * 256 + tid * kCoopRepStride + wg, __longlong_as_double((long long)kCoopPoison), l2);
+    if (tid < reps) {
+        st_pub(slots + ((h + 2) & 3) * 256 + tid * kCoopRepStride + wg, __longlong_as_double((long long)kCoopPoison), l2);
+        if (second_region) st_pub(slots + kCoopSecond + ((h + 2) & 3) * 256 + tid * kCoopRepStride + wg, __longlong_as_double((long long)kCoopPoison), l2);
+    }
     *sum_out = ssum;
+    return *lds_ok != 0;
+}
+// The same hand-off carrying TWO scalars (BiCGStab's t.s and t.t, r.r and r0.r): the second one through a slot region of its
+// own, kCoopSecond doubles further on.  A kernel that uses it passes second_region = true to EVERY hand-off it makes, so that
+// both regions' sets are re-armed two hand-offs ahead whichever kind those hand-offs are.
+__device__ inline bool coop_handoff2(double *slots, int h, double mine_a, double mine_b, int wg, int G, bool l2, int *abort, int spin_limit, double *red,
+                                     int *lds_ok, double *sum_a, double *sum_b, int reps)
+{
+    const int my_rep = reps == 1 ? 0 : (xcc_id() & (kCoopReplicas - 1));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int tid = threadIdx.x;
+    double *set = slots + (h & 3) * 256;
+    if (tid == 0) *lds_ok = 1;
+    if (tid < reps) {
+        st_pub(set + tid * kCoopRepStride + wg, mine_a, l2);
+        st_pub(set + kCoopSecond + tid * kCoopRepStride + wg, mine_b, l2);
+    }
+    double va = 0.0, vb = 0.0;
+    int ok = 1;
+    if (tid < G) {
+        int spins = 0;
+        for (;;) {
+            va = ld_sc1(set + my_rep * kCoopRepStride + tid);
+            vb = ld_sc1(set + kCoopSecond + my_rep * kCoopRepStride + tid);
+            if (__double_as_longlong(va) != (long long)kCoopPoison && __double_as_longlong(vb) != (long long)kCoopPoison) break;
+            if (++spins > spin_limit || ((spins & 31) == 0 && __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0; va = 0.0; vb = 0.0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    if (!ok) *lds_ok = 0;
+    double sa, sb;
+    block_sum2<1024>(va, vb, red, sa, sb);                   // (red: 32 doubles here; its barriers publish lds_ok)
+    if (tid < reps) {
+        st_pub(slots + ((h + 2) & 3) * 256 + tid * kCoopRepStride + wg, __longlong_as_double((long long)kCoopPoison), l2);
+        st_pub(slots + kCoopSecond + ((h + 2) & 3) * 256 + tid * kCoopRepStride + wg, __longlong_as_double((long long)kCoopPoison), l2);
+    }
+    *sum_a = sa;
+    *sum_b = sb;
+    return *lds_ok != 0;
+}
+// ... and carrying NO scalar: "every workgroup has published what it publishes with this hand-off" (boundary rows).  The same
+// slots (a 0.0 where a partial sum would stand), no sum.
+__device__ inline bool coop_sync(double *slots, int h, int wg, int G, bool l2, int *abort, int spin_limit, int *lds_ok, int reps)
+{
+    const int my_rep = reps == 1 ? 0 : (xcc_id() & (kCoopReplicas - 1));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int tid = threadIdx.x;
+    double *set = slots + (h & 3) * 256;
+    if (tid == 0) *lds_ok = 1;
+    if (tid < reps) st_pub(set + tid * kCoopRepStride + wg, 0.0, l2);
+    int ok = 1;
+    if (tid < G) {
+        int spins = 0;
+        for (;;) {
+            const double v = ld_sc1(set + my_rep * kCoopRepStride + tid);
+            if (__double_as_longlong(v) != (long long)kCoopPoison) break;
+            if (++spins > spin_limit || ((spins & 31) == 0 && __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    if (!ok) *lds_ok = 0;
+    __syncthreads();
+    if (tid < reps) {
+        st_pub(slots + ((h + 2) & 3) * 256 + tid * kCoopRepStride + wg, __longlong_as_double((long long)kCoopPoison), l2);
+        st_pub(slots + kCoopSecond + ((h + 2) & 3) * 256 + tid * kCoopRepStride + wg, __longlong_as_double((long long)kCoopPoison), l2);
+    }
     return *lds_ok != 0;
 }
 
@@ -1823,10 +1905,10 @@ extern "C" int sgm_debug_coop_probe(long long out[16])
 
 constexpr int kCoopSpinLimit = 1 << 19;       // polls (about a microsecond each) before a hand-off gives up
 // sliced stencil matrix on one GPU, plain or Jacobi, tree-order dots, beyond the one-workgroup kernel and up to 256 workgroups
-static bool coop_applies(sgm_solver s, sgm_mat A, sgm_pc pc, int *rmax_out, int *halo_out, bool *xl_out)
+static bool coop_applies(sgm_solver s, sgm_mat A, sgm_pc pc, int *rmax_out, int *halo_out, bool *xl_out, bool bicg = false)
 {
     static const bool off = getenv("SGM_CG_COOP") && atoi(getenv("SGM_CG_COOP")) == 0;
-    if (off || !s->opt.cg_small || s->multi || s->seq || A->parts.size() != 1 || A->comm || A->fmt != SGM_FMT_CSR || prof_on()) return false;
+    if (off || !(bicg ? s->opt.bicgstab_small : s->opt.cg_small) || s->multi || s->seq || A->parts.size() != 1 || A->comm || A->fmt != SGM_FMT_CSR || prof_on()) return false;
     const Part &p = A->parts[0];
     if (p.n_halo != 0 || !cg_small_sliced(p) || p.n < 2048 || p.ndict < 1 || p.ndict > 15) return false;        // (k_cg_small had its turn already)
     const int pk = pc ? pc_kind(pc) : 0;
@@ -1848,8 +1930,12 @@ static bool coop_applies(sgm_solver s, sgm_mat A, sgm_pc pc, int *rmax_out, int 
     if (!xl_off && !s->coop_xl_retired && g_rt.num_cu >= 64) {
         for (int rmax : {1, 2, 3, 4}) {
             if (force_rmax ? rmax != force_rmax : rmax == 4) continue;
+            // (k_bicg_coop: 1, 2 or 4 rows per thread, and on one XCD only one -- two there take 17.6 us per iteration at
+            //  n = 65536 where 64 workgroups of one row per thread on all CUs take 15.0)
+            if (bicg && rmax != 1 && !force_rmax) continue;
+            if (bicg && rmax == 3) continue;
             const int64_t rpw = (int64_t)rmax * 1024, G = (p.n + rpw - 1) / rpw;
-            if (G > std::min(32, g_rt.num_cu / 8) || (rpw + 2 * H + 32) * 8 > 160 * 1024) continue;
+            if (G > std::min(32, g_rt.num_cu / 8) || (rpw + (bicg ? 4 : 2) * H + 48 + (bicg && rmax >= 2 ? 2 * rpw : 0)) * 8 > 160 * 1024) continue;
             *rmax_out = rmax; *halo_out = H; *xl_out = true;
             return true;
         }
@@ -1859,11 +1945,22 @@ static bool coop_applies(sgm_solver s, sgm_mat A, sgm_pc pc, int *rmax_out, int 
         const int64_t rpw = (int64_t)rmax * 1024, G = (p.n + rpw - 1) / rpw;
         // one workgroup per CU (co-residency), LDS: p + halo + scratch <= 160 KiB.  (A halo wider than a workgroup's rows -- the
         // planes of a 3-D grid -- is fine: then every row is published, and the halo is read from several owners' rows.)
-        if (G > std::min(256, g_rt.num_cu) || (rpw + 2 * H + 32) * 8 > 160 * 1024) continue;
+        if (G > std::min(256, g_rt.num_cu) || (rpw + (bicg ? 4 : 2) * H + 48 + (bicg && rmax >= 2 ? 2 * rpw : 0)) * 8 > 160 * 1024) continue;
         *rmax_out = rmax; *halo_out = H;
         return true;
     }
     return false;
+}
+
+// every slot of the cooperative kernels' exchange buffer "not yet written", abort word clear, hand-offs counted from 0
+static int coop_arm(sgm_solver s, size_t n /* doubles of exchange vectors in front of the slots */)
+{
+    std::vector<unsigned long long> pat((size_t)kCoopSlotDoubles, kCoopPoison);
+    SGM_HIP(hipMemcpyAsync(s->coop_buf + n, pat.data(), pat.size() * 8, hipMemcpyHostToDevice, g_rt.stream));
+    SGM_HIP(hipMemsetAsync(s->coop_buf + n + (size_t)kCoopSlotDoubles, 0, 64, g_rt.stream));
+    SGM_HIP(hipStreamSynchronize(g_rt.stream));
+    s->coop_base = 0;
+    return SGM_OK;
 }
 
 // *ran = false: the kernel could not be launched here, or a hand-off gave up -- the caller runs the launch loop from the caller's x
@@ -1879,20 +1976,13 @@ static int run_cg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_
     const bool ls3 = !no_ls && !xl && rmax == 4 && (size_t)(rpw + 2 * H + 32 + 3 * rpw) * sizeof(double) <= 160 * 1024;
     const size_t lds = (size_t)(rpw + 2 * H + 32 + (ls3 ? 3 * rpw : 0)) * sizeof(double);
     *ran = false;
-    auto arm = [&]() -> int {                                  // every slot "not yet written", abort word clear, hand-offs from 0
-        std::vector<unsigned long long> pat((size_t)kCoopReplicas * kCoopRepStride, kCoopPoison);
-        SGM_HIP(hipMemcpyAsync(s->coop_buf + p.n, pat.data(), pat.size() * 8, hipMemcpyHostToDevice, g_rt.stream));
-        SGM_HIP(hipMemsetAsync(s->coop_buf + p.n + (size_t)kCoopReplicas * kCoopRepStride, 0, 64, g_rt.stream));
-        SGM_HIP(hipStreamSynchronize(g_rt.stream));
-        s->coop_base = 0;
-        return SGM_OK;
-    };
+    auto arm = [&]() -> int { return coop_arm(s, p.n); };
     if (!s->coop_buf) {
-        if (dalloc(&s->coop_buf, (size_t)p.n + (size_t)kCoopReplicas * kCoopRepStride + 64) != SGM_OK) return SGM_OK;
+        if (dalloc(&s->coop_buf, (size_t)p.n + (size_t)kCoopSlotDoubles + 64) != SGM_OK) return SGM_OK;
         SGM_TRY(arm());
     }
     double *gz = s->coop_buf, *slots = gz + p.n;
-    int *abortw = reinterpret_cast<int *>(slots + (size_t)kCoopReplicas * kCoopRepStride);
+    int *abortw = reinterpret_cast<int *>(slots + (size_t)kCoopSlotDoubles);
     int flag = 0; int64_t iters = 0; double res = 0.0;
     for (int resume = 0;; resume = 1) {
         int64_t it_end = iters + s->small_chunk();
@@ -2312,11 +2402,378 @@ static int run_bicgstab_small(sgm_solver s, sgm_mat A, double *x, const double *
     return SGM_OK;
 }
 
+
+// ---- BiCGStab on a mid-sized system: the whole solve in ONE cooperative launch ------------------------------------------
+// k_bicgstab_small's statements (bicgstab_solvers.f90:124-177 / :182-237 with a diagonal M) spread over G workgroups the way
+// k_cg_coop spreads CG: workgroup b owns RMAX * 1024 rows -- r, p, v (and, one row per thread, x and r0; else those two in
+// LDS) in the registers of the row's thread, the vector being multiplied (p, then s) + halo in LDS -- and an iteration needs
+// THREE grid-wide hand-offs:
+//   v = [M^-1] A p, partial r0.v; boundary rows of v published                      | (b) r0.v        -> alpha
+//   s = r - alpha v on the own rows AND on the halo (r's halo is kept, v's just arrived)
+//   t = [M^-1] A s, partials t.s, t.t                                               | (d) two scalars -> omega
+//   x += alpha p + omega s ; r = s - omega t ; w = p - omega v; partials r.r, r0.r;
+//   boundary rows of r and of w published                                           | (e) two scalars -> res2, rho -> beta
+//   p = r + beta w on the own rows AND on the halo
+// Neither halo needs a hand-off of its own: what a neighbour lacks for p and for s is ONE SCALAR (beta, alpha), which the
+// hand-off that carries the vectors' ingredients delivers anyway.  The halo values are formed by the same two statements
+// as the owner's (w = p - omega v; p = r + beta w; s = r - alpha v): same bits.  Hand-offs, bounds, abort and fall-back as
+// in k_cg_coop (every hand-off re-arms both scalar regions of the slot sets); three exchange vectors (r, w, v).
+// The launch loop takes 19.1 / 21.2 / 72.7 us per iteration at n = 1e4 / 1e5 / 1e6.
+template <int RMAX, bool JAC, int SW, bool XL>
+__global__ __launch_bounds__(1024) void k_bicg_coop(
+    int32_t n, int32_t sw, int32_t H, const uint32_t *__restrict__ scode, const int32_t *__restrict__ dict, const double *__restrict__ sval,
+    double *x, const double *b, const double *__restrict__ idiag, double tol, int64_t it_end, int resume,
+    double *__restrict__ wr, double *__restrict__ wr0, double *__restrict__ wp, double *__restrict__ wv, double *__restrict__ scal,
+    double *gz /* 3 n: boundary rows of r, w, v */, double *slots, int *abort, int h0, int spin_limit, int *flag, int64_t *iters,
+    double *res_out, double *history, int64_t hist_cap)
+{
+    constexpr int BLOCK = 1024, RPW = RMAX * BLOCK;
+    extern __shared__ double lds[];
+    double *pl = lds;                                   // the vector being multiplied: rows r0 - H .. r0 + RPW + H - 1
+    double *red = pl + RPW + 2 * H;                      // 32 doubles: two block sums side by side
+    int *lds_ok = reinterpret_cast<int *>(red + 32);
+    // two or more rows per thread: x and r0 (touched once and twice per iteration) live in LDS, not in registers -- with all
+    // seven vectors in registers two rows per thread spill 18-80 VGPRs, four ~100
+    constexpr bool LDSV = RMAX >= 2;
+    double *rh = red + 48;                               // r on the halo rows (2 H)
+    double *xs = rh + 2 * H, *r0s = xs + RPW;
+    __shared__ int32_t dl[16];
+    if (XL && (blockIdx.x & 7) != 0) return;
+    const int tid = threadIdx.x, G = XL ? (int)(gridDim.x >> 3) : (int)gridDim.x, wg = XL ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int reps = XL ? 1 : kCoopReplicas;
+    const int32_t r0w = wg * RPW, r1w = min(n, r0w + RPW);
+    double *gz_r = gz, *gz_w = gz + n, *gz_v = gz + 2 * (size_t)n;
+    if (tid < 16) dl[tid] = dict[tid];
+    int h = h0;
+    auto handoff1 = [&](double mine, double &total) {
+        const bool ok_ = coop_handoff(slots, h, mine, wg, G, XL, abort, spin_limit, red, lds_ok, &total, reps, nullptr, true);
+        ++h;
+        return ok_;
+    };
+    auto handoff2 = [&](double ma, double mb, double &ta, double &tb) {
+        const bool ok_ = coop_handoff2(slots, h, ma, mb, wg, G, XL, abort, spin_limit, red, lds_ok, &ta, &tb, reps);
+        ++h;
+        return ok_;
+    };
+    uint32_t cwr[RMAX];
+    double mv[RMAX][SW > 0 ? SW : 1];
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+        const int32_t i = r0w + tid + u * BLOCK;
+        cwr[u] = i < r1w ? scode[i] : 0xffffffffu;
+        if (SW > 0) {
+#pragma unroll
+            for (int e = 0; e < SW; ++e)
+                mv[u][e] = ((cwr[u] >> (4 * e)) & 15u) != 15u ? sval[((int64_t)(i >> 9) * sw + e) * 512 + (i & 511)] : 0.0;
+        }
+    }
+    // the rows' sums over pl (k_cg_coop's row_sums: same order of additions as every other kernel of the library)
+    auto row_sums = [&](double (&q)[RMAX]) {
+        if (SW > 0) {
+#pragma unroll
+            for (int u = 0; u < RMAX; ++u) {
+                double z = 0.0;
+#pragma unroll
+                for (int e = 0; e < SW; ++e) {
+                    const uint32_t cd = (cwr[u] >> (4 * e)) & 15u;
+                    if (cd != 15u) z = z + mv[u][e] * pl[H + tid + u * BLOCK + dl[cd]];
+                }
+                q[u] = 0.0 + z;
+            }
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) q[u] = 0.0;
+        for (int32_t e = 0; e < sw; ++e) {
+            double v[RMAX];
+#pragma unroll
+            for (int u = 0; u < RMAX; ++u) {
+                const int32_t i = r0w + tid + u * BLOCK;
+                if (((cwr[u] >> (4 * e)) & 15u) != 15u) v[u] = sval[((int64_t)(i >> 9) * sw + e) * 512 + (i & 511)];
+            }
+#pragma unroll
+            for (int u = 0; u < RMAX; ++u) {
+                const uint32_t cd = (cwr[u] >> (4 * e)) & 15u;
+                if (cd != 15u) q[u] = q[u] + v[u] * pl[H + tid + u * BLOCK + dl[cd]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) q[u] = 0.0 + q[u];
+    };
+    // the boundary rows of an own-row vector to an exchange vector
+    auto publish = [&](double *dst, const double (&w)[RMAX]) {
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t li = tid + u * BLOCK, i = r0w + li;
+            if (i < r1w && (li < H || i >= r1w - H)) st_pub(dst + i, w[u], XL);
+        }
+    };
+    auto block_dot = [&](const double (&prod)[RMAX]) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) sacc += prod[u];
+        return block_sum<BLOCK>(sacc, red);
+    };
+    auto block_dot2 = [&](const double (&pa)[RMAX], const double (&pb)[RMAX], double &sa, double &sb) {
+        double a = 0.0, c = 0.0;
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) { a += pa[u]; c += pb[u]; }
+        block_sum2<BLOCK>(a, c, red, sa, sb);
+    };
+    double xr[LDSV ? 1 : RMAX], rr[RMAX], r0[LDSV ? 1 : RMAX], pp[RMAX], vv[RMAX], prod0[RMAX], prod1[RMAX];
+    auto X = [&](int u) -> double & { return LDSV ? xs[tid + u * BLOCK] : xr[LDSV ? 0 : u]; };
+    auto R0 = [&](int u) -> double & { return LDSV ? r0s[tid + u * BLOCK] : r0[LDSV ? 0 : u]; };
+    double alpha = 1.0, omega = 1.0, rho_old = 1.0, rho = 1.0, res2 = 0.0;       // bicgstab_solvers.f90:144-147
+    int64_t it = 0;
+    for (int32_t li = tid; li < RPW + 2 * H; li += BLOCK) {
+        const int32_t i = r0w - H + li;
+        pl[li] = (i >= 0 && i < n) ? x[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+        const int32_t i = r0w + tid + u * BLOCK;
+        X(u) = i < r1w ? x[i] : 0.0;
+        rr[u] = 0.0; R0(u) = 0.0; pp[u] = 0.0; vv[u] = 0.0;
+    }
+    __syncthreads();
+    bool ok = true;
+    if (XL) {                                              // the proof of co-location (k_cg_coop)
+        double total;
+        const double mark = __longlong_as_double((long long)(1023 + 6 * xcc_id()) << 52);
+        ok = coop_handoff(slots, h, mark, wg, G, false, abort, spin_limit, red, lds_ok, &total, 1, nullptr, true);
+        ++h;
+        if (ok && total != mark * (double)G) {
+            if (tid == 0) __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = false;
+        }
+        if (!ok) return;
+    }
+    bool from_work = resume != 0;                          // first pass of a continued launch: the halos come from the work vectors
+    if (!resume) {
+        // r0 = [M^-1] (b - A x) ; r = r0 ; v = p = 0 ; res2 = r.r ; rho of the first iteration = r0.r: the same products
+        double q[RMAX];
+        row_sums(q);
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = r0w + tid + u * BLOCK;
+            prod0[u] = 0.0;
+            if (i < r1w) {
+                const double w = b[i] - q[u];
+                const double w0 = JAC ? idiag[i] * w : w;
+                R0(u) = w0;
+                rr[u] = w0;
+                prod0[u] = rr[u] * rr[u];
+            }
+        }
+        const double mine = block_dot(prod0);
+        publish(gz_r, rr);
+        publish(gz_w, pp);                                 // (w = p - omega v = 0)
+        ok = handoff1(mine, res2);
+        rho = res2;
+    } else {
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = r0w + tid + u * BLOCK;
+            if (i < r1w) { rr[u] = wr[i]; R0(u) = wr0[i]; pp[u] = wp[i]; vv[u] = wv[i]; }
+        }
+        alpha = scal[0]; omega = scal[1]; rho_old = scal[2]; rho = scal[3];
+        res2 = *res_out;
+        it = *iters;
+    }
+    bool conv = ok && !(sqrt(res2) > tol);
+    while (ok && !conv && it < it_end) {
+        const double beta = rho / rho_old * alpha / omega;
+        __syncthreads();                                   // every row sum of the previous product has read pl
+        // p = r + beta (p - omega v): own rows, and the halo rows from their owners' r and w = p - omega v
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t li = tid + u * BLOCK, i = r0w + li;
+            if (i < r1w) {
+                const double w = pp[u] - omega * vv[u];
+                pp[u] = rr[u] + beta * w;
+                pl[H + li] = pp[u];
+            }
+        }
+        for (int32_t li = tid; li < 2 * H; li += BLOCK) {
+            const int32_t l2 = li < H ? li : RPW + li, i = r0w - H + l2;
+            double rv = 0.0, wv_ = 0.0;
+            if (i >= 0 && i < n && (i < r0w || i >= r1w)) {
+                if (from_work) { rv = wr[i]; wv_ = wp[i] - omega * wv[i]; }
+                else { rv = ld_sc1(gz_r + i); wv_ = ld_sc1(gz_w + i); }
+            }
+            rh[li] = rv;
+            pl[l2] = rv + beta * wv_;
+        }
+        from_work = false;
+        __syncthreads();
+        double q[RMAX], ss[RMAX];
+        row_sums(q);                                       // v = [M^-1] A p
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = r0w + tid + u * BLOCK;
+            prod0[u] = 0.0;
+            if (i < r1w) { vv[u] = JAC ? idiag[i] * q[u] : q[u]; prod0[u] = R0(u) * vv[u]; }
+        }
+        double mine = block_dot(prod0), r0v;               // (its barriers: the product has read p)
+        publish(gz_v, vv);
+        ok = handoff1(mine, r0v);                           // ---- (b) r0.v ; v's boundary rows
+        if (!ok) break;
+        alpha = rho / r0v;
+        // s = r - alpha v: own rows and halo
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t li = tid + u * BLOCK, i = r0w + li;
+            ss[u] = 0.0;
+            if (i < r1w) { ss[u] = rr[u] - alpha * vv[u]; pl[H + li] = ss[u]; }
+        }
+        for (int32_t li = tid; li < 2 * H; li += BLOCK) {
+            const int32_t l2 = li < H ? li : RPW + li, i = r0w - H + l2;
+            pl[l2] = (i >= 0 && i < n && (i < r0w || i >= r1w)) ? rh[li] - alpha * ld_sc1(gz_v + i) : 0.0;
+        }
+        __syncthreads();
+        row_sums(q);                                       // t = [M^-1] A s
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = r0w + tid + u * BLOCK;
+            prod0[u] = 0.0; prod1[u] = 0.0;
+            if (i < r1w) {
+                if (JAC) q[u] = idiag[i] * q[u];
+                prod0[u] = ss[u] * q[u];
+                prod1[u] = q[u] * q[u];
+            }
+        }
+        double ma, mb, st, tt;
+        block_dot2(prod0, prod1, ma, mb);
+        ok = handoff2(ma, mb, st, tt);                      // ---- (d) t.s, t.t
+        if (!ok) break;
+        omega = st / tt;
+        if (!JAC && isnan(omega)) omega = 0.0;             // bicgstab_solvers.f90:165 (plain variant only)
+        double wn[RMAX];
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int32_t i = r0w + tid + u * BLOCK;
+            prod0[u] = 0.0; prod1[u] = 0.0; wn[u] = 0.0;
+            if (i < r1w) {
+                X(u) = X(u) + alpha * pp[u] + omega * ss[u];
+                rr[u] = ss[u] - omega * q[u];
+                wn[u] = pp[u] - omega * vv[u];             // (what the next iteration's p update starts from: the neighbours' copy)
+                prod0[u] = rr[u] * rr[u];
+                prod1[u] = R0(u) * rr[u];
+            }
+        }
+        rho_old = rho;
+        block_dot2(prod0, prod1, ma, mb);
+        publish(gz_r, rr);
+        publish(gz_w, wn);
+        ok = handoff2(ma, mb, res2, rho);                   // ---- (e) r.r ; rho of the next iteration = r0.r ; boundary rows of r, w
+        if (!ok) break;
+        if (wg == 0 && tid == 0 && history && it < hist_cap) history[it] = res2;
+        ++it;
+        conv = !(sqrt(res2) > tol);
+    }
+    if (!ok) return;                                        // (nothing has been written: the host takes the launch loop)
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+        const int32_t i = r0w + tid + u * BLOCK;
+        if (i < r1w) {
+            x[i] = X(u);
+            if (!conv) { wr[i] = rr[u]; wr0[i] = R0(u); wp[i] = pp[u]; wv[i] = vv[u]; }
+        }
+    }
+    if (wg == 0 && tid == 0) {
+        scal[0] = alpha; scal[1] = omega; scal[2] = rho_old; scal[3] = rho;
+        *iters = it; *res_out = res2; *flag = conv ? 1 : 0;
+    }
+}
+
+// hand-offs of one launch: 3 per iteration, + 1 at the start of a fresh solve, + 1 for the one-XCD variant's proof
+static int run_bicg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc pc, int rmax, int H, bool xl, bool *ran)
+{
+    const Part &p = A->parts[0];
+    PartWork &w = s->work[0];
+    const bool jac = pc && pc_kind(pc) == SGM_PC_JACOBI;
+    const int64_t rpw = (int64_t)rmax * 1024;
+    const int G = (int)((p.n + rpw - 1) / rpw);
+    const size_t lds = (size_t)(rpw + 4 * H + 48 + (rmax >= 2 ? 2 * rpw : 0)) * sizeof(double);      // p / s + halo, scratch, r's halo, (x, r0)
+    const size_t nx = 3 * (size_t)p.n;                                                                // exchange vectors: r, w, v
+    *ran = false;
+    if (!s->coop_buf) {
+        if (dalloc(&s->coop_buf, nx + (size_t)kCoopSlotDoubles + 64) != SGM_OK) return SGM_OK;
+        SGM_TRY(coop_arm(s, nx));
+    }
+    double *gz = s->coop_buf, *slots = gz + nx;
+    int *abortw = reinterpret_cast<int *>(slots + (size_t)kCoopSlotDoubles);
+    int flag = 0; int64_t iters = 0; double res = 0.0;
+    for (int resume = 0;; resume = 1) {
+        int64_t it_end = iters + s->small_chunk();
+        if (s->max_iter > 0) it_end = std::min<int64_t>(it_end, s->max_iter);
+        static const int spin_env = getenv("SGM_CG_COOP_SPIN") ? atoi(getenv("SGM_CG_COOP_SPIN")) : 0;
+        const int spin = spin_env > 0 ? spin_env : kCoopSpinLimit;
+#define LB(R, J, W, X)                                                                                                 \
+    do {                                                                                                             \
+        if (!allow_lds((const void *)k_bicg_coop<R, J, W, X>, lds)) return SGM_OK;                                    \
+        hipLaunchKernelGGL((k_bicg_coop<R, J, W, X>), dim3(X ? 8 * G : G), dim3(1024), lds, g_rt.stream, p.n, p.sw, H, (const uint32_t *)p.scode, \
+                           (const int32_t *)p.dict, (const double *)p.sval, x, b, jac ? pc_idiag(pc, 0) : nullptr, s->tolerance, it_end,  \
+                           resume, w.vec[W_R], w.vec[W_R0], w.vec[W_P], w.vec[W_V], w.slots, gz, slots, abortw, s->coop_base & 3, spin,  \
+                           w.flag, w.iters, w.res, w.history, s->hist_cap);                                           \
+    } while (0)
+#define LBJ(R, W, X) do { if (jac) LB(R, true, W, X); else LB(R, false, W, X); } while (0)
+#define LBX(R, W) do { if (xl) LBJ(R, W, true); else LBJ(R, W, false); } while (0)
+        // the matrix in registers where it fits beside the five vectors (one row per thread: any slice width; two: <= 5 slots)
+        static const bool stream_env = getenv("SGM_CG_COOP_STREAM") != nullptr;
+        if (rmax == 1 && !stream_env) { if (p.sw == 3) LBX(1, 3); else if (p.sw == 5) LBX(1, 5); else if (p.sw == 7) LBX(1, 7); else LBX(1, 8); }
+        else if (rmax == 2 && !stream_env && p.sw <= 5) { if (p.sw == 3) LBX(2, 3); else LBX(2, 5); }
+        else if (rmax == 1) LBX(1, 0);
+        else if (rmax == 2) LBX(2, 0);
+        else LBX(4, 0);
+#undef LBX
+#undef LBJ
+#undef LB
+        SGM_HIP(hipGetLastError());
+        int habort = 0;
+        SGM_HIP(hipMemcpyAsync(&habort, abortw, sizeof(int), hipMemcpyDeviceToHost, g_rt.stream));
+        SGM_TRY(read_state(s, &flag, &iters, &res));
+        if (habort) {
+            SGM_TRY(coop_arm(s, nx));
+            if (xl) s->coop_xl_retired = true;
+            else {
+                fprintf(stderr, "[sigma_hip] cooperative BiCGStab gave up waiting for a workgroup (grid not co-resident / shared GPU?): "
+                                "this solver takes the launch loop from now on\n");
+                s->coop_retired = true;
+            }
+            if (resume) return fail(SGM_ERR_HIP, "cooperative BiCGStab aborted in a continued launch");
+            return SGM_OK;
+        }
+        s->coop_base = (int)((s->coop_base + 3 * (iters - (resume ? s->coop_iters0 : 0)) + (resume ? 0 : 1) + (xl ? 1 : 0)) & 3);
+        s->coop_iters0 = iters;
+        if (flag || (s->max_iter > 0 && iters >= s->max_iter)) break;
+    }
+    *ran = true;
+    s->last_iterations = iters;
+    s->res2 = res;
+    s->converged = flag;
+    static const bool trace = getenv("SGM_TRACE") != nullptr;
+    if (trace)
+        fprintf(stderr, "[sigma_hip] bicgstab: one cooperative launch per %lld iterations, %s, %d workgroups x %lld rows\n", (long long)s->small_chunk(),
+                xl ? "on one XCD" : "all CUs", G, (long long)rpw);
+    return SGM_OK;
+}
+
 int run_bicgstab(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sgm_pc pc)
 {
     if (small_applies(s, A, pc, true)) {
         bool ran = false;
         SGM_TRY(run_bicgstab_small(s, A, x[0], b[0], pc, &ran));
+        if (ran) return SGM_OK;
+    }
+    {
+        int rmax = 0, H = 0;
+        bool xl = false, ran = false;
+        for (int attempt = 0; attempt < 2 && !ran && !s->coop_retired && coop_applies(s, A, pc, &rmax, &H, &xl, true); ++attempt) {
+            SGM_TRY(run_bicg_coop(s, A, x[0], b[0], pc, rmax, H, xl, &ran));
+            if (!ran && xl) s->coop_xl_retired = true;
+            if (!xl) break;
+        }
         if (ran) return SGM_OK;
     }
     const size_t P = s->work.size();

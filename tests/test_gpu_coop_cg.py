@@ -189,3 +189,103 @@ def test_wave_sum_is_the_shuffle_butterfly_bit_for_bit():
                                "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "probes", "wave_sum_probe.cpp"), "-o", exe])
     p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "0 of 524288 lanes differ" in p.stdout and "block_sum<1024>: 0 differ" in p.stdout, p.stdout + p.stderr
+
+
+def _nonsymmetric(ptr, node, val):
+    """the 5- / 7-point stencil with an upwind-like skew -- entries right of the diagonal x 0.8, left of it x 1.2 -- and the
+    diagonal x 1.05 (strictly dominant: without it the interior rows sum to zero and BiCGStab breaks down in every implementation)"""
+    rows = np.repeat(np.arange(1, len(ptr)), np.diff(ptr))
+    return val * (1.0 + 0.2 * np.sign(rows - node)) * np.where(rows == node, 1.05, 1.0)
+
+
+@pytest.mark.parametrize("jac", [False, True])
+def test_cooperative_bicgstab_vs_oracle_and_launch_loop(orc, jac):
+    """k_bicg_coop: BiCGStab as one cooperative launch (five hand-offs per iteration, two of them carrying two scalars).
+    Same statements as bicgstab_solve(_pc) and as the launch loop; the dots' summation order differs, so the gates are the
+    launch loop's: iteration counts within max(3, 10 %) of the oracle's, true residual at the tolerance, solutions within 1e-7."""
+    cases = [("2-D 150 x 131 (one XCD, one row per thread)", 150 * 131, P.poisson2d_csr(150, 131)),
+             ("2-D 256 x 250 (all CUs, one row per thread)", 256 * 250, P.poisson2d_csr(256, 250)),
+             ("2-D 600 x 500 (all CUs, two rows per thread)", 600 * 500, P.poisson2d_csr(600, 500)),
+             ("2-D 500 x 450 (all CUs)", 500 * 450, P.poisson2d_csr(500, 450)),
+             ("2-D 760 x 700 (all CUs, four rows per thread)", 760 * 700, P.poisson2d_csr(760, 700)),
+             ("3-D 40 x 37 x 33", 40 * 37 * 33, P.laplace3d_csr(40, 37, 33)),
+             ("1-D n = 50001", 50001, P.tridiag_csr(50001, 2.5, -1.0, -1.0))]
+    for label, n, (ptr, node, val) in cases:
+        val = _nonsymmetric(ptr, node, val)
+        A = orc.CsrMatrix(n, n, ptr, node, val)
+        H = sg.csr_matrix(n, n, ptr, node, val)
+        b = np.sin(0.01 * np.arange(1, n + 1)) + 0.5
+        tol = 1e-9
+        pco = orc.Jacobi(A) if jac else None
+        x0 = np.full(n, 0.25)
+        ur, itr = orc.bicgstab(A, b, x0=x0.copy(), tol=tol, pc=pco)[:2]
+        out = {}
+        for mode in ("coop", "loop"):
+            pc = None
+            if jac:
+                pc = sg.jacobi(); pc.setup(H)
+            s = sg.bicgstab(tol)
+            s.set_history(100000)
+            if mode == "loop":
+                s.set_option("bicgstab_small", 0)
+            s.setup(H)
+            u = x0.copy()
+            s.solve(H, u, b, pc)
+            Au = np.zeros(n); H.matvec(u, Au)
+            out[mode] = (u, s.iterations, np.array(s.history))
+            assert s.converged and np.sqrt(s.res2) <= tol, (label, mode)
+            assert abs(s.iterations - itr) <= max(3, itr // 10), (label, mode, s.iterations, itr)
+            assert np.abs(Au - b).max() <= 1e-7 * np.abs(b).max(), (label, mode)
+            assert np.abs(u - ur).max() <= 1e-7 * np.abs(ur).max(), (label, mode)
+        k = min(len(out["coop"][2]), len(out["loop"][2]), 20)
+        assert np.abs(out["coop"][2][:k] - out["loop"][2][:k]).max() <= 1e-8 * out["loop"][2][:k].max(), label
+
+
+def test_cooperative_bicgstab_cut_into_launches_capped_and_falling_back(tmp_path):
+    """Launches of at most `bicgstab_small` iterations hand r, r0, p, v and the four scalars on: bit-identical to the uncut solve;
+    set_max_iter stops it; with a spin limit of 1 the hand-offs give up at once and the launch loop returns the same answer;
+    SGM_TRACE names the variant."""
+    nx, ny = 200, 160
+    n = nx * ny
+    ptr, node, val = P.poisson2d_csr(nx, ny)
+    val = _nonsymmetric(ptr, node, val)
+    H = sg.csr_matrix(n, n, ptr, node, val)
+    b = np.full(n, 1.0 / n)
+    res = {}
+    for chunk in (1, 7, 64):
+        s = sg.bicgstab(1e-10)
+        s.set_history(10000)
+        s.set_option("bicgstab_small", chunk)
+        s.setup(H)
+        u = np.zeros(n)
+        s.solve(H, u, b)
+        res[chunk] = (u, s.iterations, np.array(s.history))
+    for chunk in (7, 64):
+        assert res[chunk][1] == res[1][1] and np.array_equal(res[chunk][0], res[1][0]) and np.array_equal(res[chunk][2], res[1][2])
+    s = sg.bicgstab(1e-300)
+    s.set_max_iter(23)
+    s.setup(H)
+    u = np.zeros(n)
+    s.solve(H, u, b, check=False)
+    assert s.last_iterations == 23 and not s.converged
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np, sigma_amd as sg\n"
+            "from sigma_amd import problems as P\n"
+            "sg.init(0)\n"
+            "n = 200 * 160\n"
+            "ptr, node, val = P.poisson2d_csr(200, 160)\n"
+            "rows = np.repeat(np.arange(1, n + 1), np.diff(ptr)); val = val * (1.0 + 0.2 * np.sign(rows - node)) * np.where(rows == node, 1.05, 1.0)\n"
+            "A = sg.csr_matrix(n, n, ptr, node, val)\n"
+            "b = np.full(n, 1.0 / n)\n"
+            "s = sg.bicgstab(1e-10); s.setup(A)\n"
+            "u = np.zeros(n); s.solve(A, u, b)\n"
+            "s2 = sg.bicgstab(1e-10); s2.set_option('bicgstab_small', 0); s2.setup(A)\n"
+            "u2 = np.zeros(n); s2.solve(A, u2, b)\n"
+            "print('ITS', s.iterations, s2.iterations, bool(np.array_equal(u, u2)))\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, SGM_CG_COOP_SPIN="1"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    its = [ln for ln in p.stdout.splitlines() if ln.startswith("ITS")][0].split()
+    assert its[1] == its[2] and its[3] == "True", p.stdout
+    assert "cooperative BiCGStab gave up waiting" in p.stderr
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, SGM_TRACE="1"))
+    assert p.returncode == 0 and "bicgstab: one cooperative launch" in p.stderr and "on one XCD" in p.stderr, p.stderr[-1000:]
