@@ -104,7 +104,8 @@ int sgm_synchronize(void);
  *                          is bounded, a hand-off that gives up hands the solve to the launch loop.  A launch runs at most
  *                          50000 iterations (n > 1: at most n) and the solve continues in the next one from parked r, p,
  *                          res2, bit-identical to the uncut solve; 0 = the launch loop (three kernels per iteration)
- *   "bicgstab_small" (1)   the same for BiCGStab (<= 4096 rows)
+ *   "bicgstab_small" (1)   the same for BiCGStab (one workgroup <= 4096 rows; the cooperative kernel k_bicg_coop beyond, for
+ *                          the systems the cooperative CG kernel takes)
  *   "krylov_graph" (1)     the CG / BiCGStab launch loops on one GPU (plain / Jacobi) go on as replays of ONE captured group
  *                          of 16 iterations (a hipGraph) once a solve has run 64 iterations (n > 1: n, rounded up to a
  *                          multiple of 16); 0 = launch every kernel
