@@ -1538,6 +1538,7 @@ int rows_encode(TriFactor &T, int32_t n)
     if (!T.rows_on || T.rc > 8 || n < 1) return SGM_OK;
     hipStream_t st = g_rt.stream;
     int32_t *table = nullptr;
+    struct Guard { int32_t *&t; ~Guard() { dfree(t); } } guard{table};
     SGM_TRY(dalloc(&table, 64 + 1));
     std::vector<int32_t> h(65, INT32_MIN);
     h[64] = 0;
@@ -1546,7 +1547,6 @@ int rows_encode(TriFactor &T, int32_t n)
                        table, reinterpret_cast<int *>(table + 64));
     SGM_HIP(hipMemcpyAsync(h.data(), table, 65 * 4, hipMemcpyDeviceToHost, st));
     SGM_HIP(hipStreamSynchronize(st));
-    dfree(table);
     std::vector<int32_t> dict;
     for (int k = 0; k < 64; ++k)
         if (h[k] != INT32_MIN) dict.push_back(h[k]);

@@ -1609,41 +1609,6 @@ __device__ inline bool coop_handoff2(double *slots, int h, double mine_a, double
     *sum_b = sb;
     return *lds_ok != 0;
 }
-// ... and carrying NO scalar: "every workgroup has published what it publishes with this hand-off" (boundary rows).  The same
-// slots (a 0.0 where a partial sum would stand), no sum.
-__device__ inline bool coop_sync(double *slots, int h, int wg, int G, bool l2, int *abort, int spin_limit, int *lds_ok, int reps)
-{
-    const int my_rep = reps == 1 ? 0 : (xcc_id() & (kCoopReplicas - 1));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int tid = threadIdx.x;
-    double *set = slots + (h & 3) * 256;
-    if (tid == 0) *lds_ok = 1;
-    if (tid < reps) st_pub(set + tid * kCoopRepStride + wg, 0.0, l2);
-    int ok = 1;
-    if (tid < G) {
-        int spins = 0;
-        for (;;) {
-            const double v = ld_sc1(set + my_rep * kCoopRepStride + tid);
-            if (__double_as_longlong(v) != (long long)kCoopPoison) break;
-            if (++spins > spin_limit || ((spins & 31) == 0 && __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = 0;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    __syncthreads();
-    if (!ok) *lds_ok = 0;
-    __syncthreads();
-    if (tid < reps) {
-        st_pub(slots + ((h + 2) & 3) * 256 + tid * kCoopRepStride + wg, __longlong_as_double((long long)kCoopPoison), l2);
-        st_pub(slots + kCoopSecond + ((h + 2) & 3) * 256 + tid * kCoopRepStride + wg, __longlong_as_double((long long)kCoopPoison), l2);
-    }
-    return *lds_ok != 0;
-}
-
 // SW > 0: the own rows' matrix entries (SW slots each) are loaded ONCE and live in registers for the whole launch (RMAX * SW
 // doubles per thread; what an iteration then reads from memory is the hand-offs); SW = 0: streamed every iteration.
 // XL (XCD-local; systems of up to 32 workgroups' rows): the grid is 8 x G workgroups, of which those with blockIdx % 8 == 0 --
