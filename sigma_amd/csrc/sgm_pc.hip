@@ -2120,9 +2120,8 @@ void launch_rows(const TriFactor &T, const TriFactor::RowLevel &L, int mode, con
 {
     hipStream_t st = g_rt.stream;
     const int32_t b = L.b, e = L.e;
-    static const bool no_pairs = getenv("SGM_TRSV_ROWS_NO_PAIRS") != nullptr, no_codes = getenv("SGM_PCG_NO_CODES") != nullptr;       // tuning aids
-    if (!no_pairs && L.row0 >= 0 && (L.row0 & 1) == 0 && (b & 1) == 0 && (n0 & 1) == 0 && L.c >= 1 && L.c <= 4) {
-        const bool coded = T.rcode && !no_codes;
+    if (L.row0 >= 0 && (L.row0 & 1) == 0 && (b & 1) == 0 && (n0 & 1) == 0 && L.c >= 1 && L.c <= 4) {
+        const bool coded = T.rcode != nullptr;
         const dim3 g2(8 * (((e - b + 2 * kBlock - 1) / (2 * kBlock) + 7) / 8));
 #define R2_M(CC, MM, CD)                                                                                                        \
     hipLaunchKernelGGL((k_trsv_rows2<CC, MM, CD>), g2, dim3(kBlock), 0, st, (const int32_t *)T.rq, (const double *)T.rv, T.rc,   \
@@ -2185,10 +2184,8 @@ void launch_rows_cg(const TriFactor &T, const TriFactor::RowLevel &L, int mode, 
                     const double *D, double *z, double *part, int grid, const int *flag, int gen)
 {
     hipStream_t st = g_rt.stream;
-    static const bool no_pairs = getenv("SGM_PCG_NO_PAIRS") != nullptr;                  // tuning aids
-    static const bool no_codes = getenv("SGM_PCG_NO_CODES") != nullptr;
-    if (!no_pairs && L.row0 >= 0 && (L.row0 & 1) == 0 && (L.b & 1) == 0 && L.c >= 1 && L.c <= 4) {
-        const bool coded = T.rcode && !no_codes;
+    if (L.row0 >= 0 && (L.row0 & 1) == 0 && (L.b & 1) == 0 && L.c >= 1 && L.c <= 4) {
+        const bool coded = T.rcode != nullptr;
 #define ROWS2_M(CC, MM, CD)                                                                                                    \
     hipLaunchKernelGGL((k_trsv_rows_cg2<CC, MM, CD>), dim3(grid), dim3(kBlock), 0, st, (const int32_t *)T.rq, (const double *)T.rv, T.rc, \
                        (const uint32_t *)T.rcode, (const int32_t *)T.rdict, L.row0, L.b, L.e, r, q, res2, dpr, D, z, part, flag, gen)

@@ -1940,8 +1940,7 @@ static int run_cg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_
     const int64_t rpw = (int64_t)rmax * 1024;
     const int G = (int)((p.n + rpw - 1) / rpw);
     // 4 rows per thread (streamed matrix): three slots of it in LDS where they fit beside p and its halo
-    static const bool no_ls = getenv("SGM_CG_COOP_NO_LDS_MATRIX") != nullptr;          // tuning aid
-    const bool ls3 = !no_ls && !xl && rmax == 4 && (size_t)(rpw + 2 * H + 32 + 3 * rpw) * sizeof(double) <= 160 * 1024;
+    const bool ls3 = !xl && rmax == 4 && (size_t)(rpw + 2 * H + 32 + 3 * rpw) * sizeof(double) <= 160 * 1024;
     const size_t lds = (size_t)(rpw + 2 * H + 32 + (ls3 ? 3 * rpw : 0)) * sizeof(double);
     *ran = false;
     auto arm = [&]() -> int { return coop_arm(s, p.n); };
