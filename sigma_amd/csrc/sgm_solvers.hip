@@ -1623,7 +1623,9 @@ __device__ inline bool coop_handoff2(double *slots, int h, double mine_a, double
 // LS (streamed form only): the first LS slots of the own rows are copied into LDS once (beside p) and only the others are
 // re-read every iteration -- at 4 rows per thread 3 of a 5-point matrix's 5 slots fit (96 KiB), and what is left of a
 // 1e6-row matrix (16 MB) stays in the L2s instead of streaming 40 MB from the Infinity Cache per iteration.
-template <int RMAX, bool JAC, int SW, bool XL, int LS = 0>
+// RL: r lives in LDS beside p instead of in registers (eight rows per thread: systems of up to 256 x 8192 rows, where the
+// launch loop is traffic-bound at 57 us per iteration and everything but the matrix fits the chip).
+template <int RMAX, bool JAC, int SW, bool XL, int LS = 0, bool RL = false>
 __global__ __launch_bounds__(1024) void k_cg_coop(
     int32_t n, int32_t sw, int32_t H, const uint32_t *__restrict__ scode, const int32_t *__restrict__ dict, const double *__restrict__ sval,
     double *x, const double *b, const double *__restrict__ idiag, double tol, int64_t it_end, int resume,
@@ -1636,7 +1638,8 @@ __global__ __launch_bounds__(1024) void k_cg_coop(
     double *pl = lds;                                   // p of rows r0 - H .. r0 + RPW + H - 1
     double *red = pl + RPW + 2 * H;                      // 16 doubles of block-sum scratch
     int *lds_ok = reinterpret_cast<int *>(red + 16);
-    double *ml = red + 32;                               // LS x RPW matrix entries (LS > 0)
+    double *ml = red + 32;                               // LS x RPW matrix entries (LS > 0) -- or, RL, the own rows of r
+    double *rls = red + 32;
     __shared__ int32_t dl[16];
     if (XL && (blockIdx.x & 7) != 0) return;
     const int tid = threadIdx.x, G = XL ? (int)(gridDim.x >> 3) : (int)gridDim.x, wg = XL ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
@@ -1720,7 +1723,8 @@ __global__ __launch_bounds__(1024) void k_cg_coop(
             if (i < r1 && (li < H || i >= r1 - H)) st_pub(gz + i, zr[u], XL);
         }
     };
-    double xr[RMAX], rr[RMAX], prod[RMAX];
+    double xr[RMAX], rr[RL ? 1 : RMAX], prod[RMAX];
+    auto R = [&](int u) -> double & { return RL ? rls[tid + u * BLOCK] : rr[RL ? 0 : u]; };
     // ---- start: p = x in LDS (own rows + halo) for r = b - A x
     for (int32_t li = tid; li < RPW + 2 * H; li += BLOCK) {
         const int32_t i = r0 - H + li;
@@ -1730,7 +1734,7 @@ __global__ __launch_bounds__(1024) void k_cg_coop(
     for (int u = 0; u < RMAX; ++u) {
         const int32_t i = r0 + tid + u * BLOCK;
         xr[u] = i < r1 ? x[i] : 0.0;
-        rr[u] = 0.0;
+        R(u) = 0.0;
     }
     __syncthreads();
     double res2;
@@ -1756,9 +1760,9 @@ __global__ __launch_bounds__(1024) void k_cg_coop(
             const double q = zr[u];
             zr[u] = 0.0; prod[u] = 0.0;
             if (i < r1) {
-                rr[u] = b[i] - q;
-                zr[u] = JAC ? idiag[i] * rr[u] : rr[u];
-                prod[u] = rr[u] * zr[u];
+                R(u) = b[i] - q;
+                zr[u] = JAC ? idiag[i] * R(u) : R(u);
+                prod[u] = R(u) * zr[u];
             }
         }
         const double mine = own_dot(prod);                 // (its barriers: every row sum has read x out of LDS)
@@ -1777,7 +1781,7 @@ __global__ __launch_bounds__(1024) void k_cg_coop(
 #pragma unroll
         for (int u = 0; u < RMAX; ++u) {
             const int32_t i = r0 + tid + u * BLOCK;
-            if (i < r1) rr[u] = wr[i];
+            if (i < r1) R(u) = wr[i];
         }
         res2 = *res_out;
         it = *iters;
@@ -1810,9 +1814,9 @@ __global__ __launch_bounds__(1024) void k_cg_coop(
             const int32_t i = r0 + tid + u * BLOCK;
             prod[u] = 0.0; zr[u] = 0.0;
             if (i < r1) {
-                rr[u] = rr[u] - alpha * qv[u];
-                zr[u] = JAC ? idiag[i] * rr[u] : rr[u];
-                prod[u] = rr[u] * zr[u];
+                R(u) = R(u) - alpha * qv[u];
+                zr[u] = JAC ? idiag[i] * R(u) : R(u);
+                prod[u] = R(u) * zr[u];
             }
         }
         mine = own_dot(prod);
@@ -1855,7 +1859,7 @@ __global__ __launch_bounds__(1024) void k_cg_coop(
         const int32_t i = r0 + tid + u * BLOCK;
         if (i < r1) {
             x[i] = xr[u];
-            if (!conv) { wr[i] = rr[u]; wp[i] = pl[H + tid + u * BLOCK]; }
+            if (!conv) { wr[i] = R(u); wp[i] = pl[H + tid + u * BLOCK]; }
         }
     }
     if (wg == 0 && tid == 0) { *iters = it; *res_out = res2; *flag = conv ? 1 : 0; }
@@ -1908,12 +1912,13 @@ static bool coop_applies(sgm_solver s, sgm_mat A, sgm_pc pc, int *rmax_out, int 
             return true;
         }
     }
-    for (int rmax : {1, 2, 4}) {
+    for (int rmax : {1, 2, 4, 8}) {
         if (force_rmax && rmax != force_rmax) continue;
+        if (rmax == 8 && bicg) continue;                      // (CG only: r moves into LDS to make room)
         const int64_t rpw = (int64_t)rmax * 1024, G = (p.n + rpw - 1) / rpw;
         // one workgroup per CU (co-residency), LDS: p + halo + scratch <= 160 KiB.  (A halo wider than a workgroup's rows -- the
         // planes of a 3-D grid -- is fine: then every row is published, and the halo is read from several owners' rows.)
-        if (G > std::min(256, g_rt.num_cu) || (rpw + (bicg ? 4 : 2) * H + 48 + (bicg && rmax >= 2 ? 2 * rpw : 0)) * 8 > 160 * 1024) continue;
+        if (G > std::min(256, g_rt.num_cu) || (rpw + (bicg ? 4 : 2) * H + 48 + ((bicg && rmax >= 2) ? 2 * rpw : rmax == 8 ? rpw : 0)) * 8 > 160 * 1024) continue;
         *rmax_out = rmax; *halo_out = H;
         return true;
     }
@@ -1941,7 +1946,7 @@ static int run_cg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_
     const int G = (int)((p.n + rpw - 1) / rpw);
     // 4 rows per thread (streamed matrix): three slots of it in LDS where they fit beside p and its halo
     const bool ls3 = !xl && rmax == 4 && (size_t)(rpw + 2 * H + 32 + 3 * rpw) * sizeof(double) <= 160 * 1024;
-    const size_t lds = (size_t)(rpw + 2 * H + 32 + (ls3 ? 3 * rpw : 0)) * sizeof(double);
+    const size_t lds = (size_t)(rpw + 2 * H + 32 + (ls3 ? 3 * rpw : rmax == 8 ? rpw : 0)) * sizeof(double);
     *ran = false;
     auto arm = [&]() -> int { return coop_arm(s, p.n); };
     if (!s->coop_buf) {
@@ -1972,6 +1977,14 @@ static int run_cg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_
                            s->tolerance, it_end, resume, w.vec[V_R], w.vec[V_P], gz, slots, abortw, s->coop_base & 3, spin, \
                            w.flag, w.iters, w.res, w.history, s->hist_cap);                                           \
     } while (0)
+#define LC6(R, J)                                                                                                      \
+    do {                                                                                                             \
+        if (!allow_lds((const void *)k_cg_coop<R, J, 0, false, 0, true>, lds)) return SGM_OK;                         \
+        hipLaunchKernelGGL((k_cg_coop<R, J, 0, false, 0, true>), dim3(G), dim3(1024), lds, g_rt.stream, p.n, p.sw, H, (const uint32_t *)p.scode, \
+                           (const int32_t *)p.dict, (const double *)p.sval, x, b, jac ? pc_idiag(pc, 0) : nullptr,   \
+                           s->tolerance, it_end, resume, w.vec[V_R], w.vec[V_P], gz, slots, abortw, s->coop_base & 3, spin, \
+                           w.flag, w.iters, w.res, w.history, s->hist_cap);                                           \
+    } while (0)
 #define LCJ(R, W, X) do { if (jac) LC(R, true, W, X); else LC(R, false, W, X); } while (0)
         // the matrix in registers where RMAX * sw doubles fit beside x, r and the temporaries
 #define LCW(R, X) do { if (p.sw == 3) LCJ(R, 3, X); else if (p.sw == 5) LCJ(R, 5, X); else if (p.sw == 7) LCJ(R, 7, X); else LCJ(R, 8, X); } while (0)
@@ -1990,10 +2003,12 @@ static int run_cg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_
         else if (rmax == 2 && !stream_env) LCW(2, false);
         else if (rmax == 1) LCJ(1, 0, false);
         else if (rmax == 2) LCJ(2, 0, false);
+        else if (rmax == 8) { if (jac) LC6(8, true); else LC6(8, false); }
         else if (ls3) { if (jac) LC5(4, true, 0, false, 3); else LC5(4, false, 0, false, 3); }
         else LCJ(4, 0, false);
 #undef LCW
 #undef LCJ
+#undef LC6
 #undef LC5
 #undef LC
         SGM_HIP(hipGetLastError());

@@ -289,3 +289,39 @@ def test_cooperative_bicgstab_cut_into_launches_capped_and_falling_back(tmp_path
     assert "cooperative BiCGStab gave up waiting" in p.stderr
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, SGM_TRACE="1"))
     assert p.returncode == 0 and "bicgstab: one cooperative launch" in p.stderr and "on one XCD" in p.stderr, p.stderr[-1000:]
+
+
+def test_cooperative_cg_eight_rows_per_thread_with_r_in_lds_vs_launch_loop():
+    """Between 1,048,576 and 2,097,152 rows the cooperative CG kernel keeps r in LDS beside p (eight rows per thread): against
+    the launch loop on a 1300 x 1100 grid with variable coefficients (too large for the oracle's single thread in a test):
+    iterations within one, solutions within 1e-10, true residual at the tolerance; SGM_TRACE names 8192 rows per workgroup."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np, sigma_amd as sg\n"
+            "from sigma_amd import problems as P\n"
+            "sg.init(0)\n"
+            "nx, ny = 1300, 1100\n"
+            "n = nx * ny\n"
+            "ptr, node, val = P.poisson2d_csr(nx, ny)\n"
+            "rows = np.repeat(np.arange(1, n + 1), np.diff(ptr))\n"
+            "val = val * (1.0 + 0.1 * np.cos(0.37 * (rows + node))) * np.where(rows == node, 1.1, 1.0)\n"
+            "A = sg.csr_matrix(n, n, ptr, node, val)\n"
+            "b = np.sin(0.01 * np.arange(1, n + 1)) + 0.5\n"
+            "out = []\n"
+            "for jac in (False, True):\n"
+            "    for small in (1, 0):\n"
+            "        pc = None\n"
+            "        if jac:\n"
+            "            pc = sg.jacobi(); pc.setup(A)\n"
+            "        s = sg.cg(1e-9); s.set_option('cg_small', small); s.setup(A)\n"
+            "        u = np.full(n, 0.2); s.solve(A, u, b, pc)\n"
+            "        Au = np.zeros(n); A.matvec(u, Au)\n"
+            "        out.append((u, s.iterations, float(np.abs(Au - b).max())))\n"
+            "    (uc, ic, rc), (ul, il, rl) = out[-2], out[-1]\n"
+            "    print('PAIR', int(jac), ic, il, float(np.abs(uc - ul).max() / np.abs(ul).max()), rc, rl)\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, SGM_TRACE="1"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    pairs = [ln.split() for ln in p.stdout.splitlines() if ln.startswith("PAIR")]
+    assert len(pairs) == 2, p.stdout
+    for _, jac, ic, il, du, rc, rl in pairs:
+        assert abs(int(ic) - int(il)) <= 1 and float(du) <= 1e-10 and float(rc) <= 1e-7 and float(rl) <= 1e-7, (jac, ic, il, du, rc, rl)
+    assert "x 8192 rows" in p.stderr, p.stderr[-1500:]

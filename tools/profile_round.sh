@@ -24,8 +24,8 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_i
 bash tools/probes/pmc_colour_ildu.sh > $OUT/pmc_colour_ildu.txt 2>&1
 # CG per iteration on mid-sized grids (one-workgroup / one-XCD / all-CU cooperative kernels, launch loop beyond), C1, and
 # where an iteration of the cooperative kernel spends its time (phase timers: the -DSGM_COOP_PROBE build of the library)
-NXS=32,64,100,181,256,300,316,362,500,700,1000,1500,2000 SOLVERS=cg KRYLOV_GRAPH=1 timeout 600 python tools/cg_small.py 2>&1 | grep '^{' > $OUT/cg_small_coop.jsonl
-NXS=100,316,1000,2000 SOLVERS=cg KRYLOV_GRAPH=1 NO_C1=1 SGM_CG_COOP=0 timeout 600 python tools/cg_small.py 2>&1 | grep '^{' > $OUT/cg_small_launch_loop.jsonl
+NXS=32,64,100,181,256,300,316,362,500,700,1000,1100,1448,1500,2000 SOLVERS=cg KRYLOV_GRAPH=1 timeout 600 python tools/cg_small.py 2>&1 | grep '^{' > $OUT/cg_small_coop.jsonl
+NXS=100,316,1000,1448,2000 SOLVERS=cg KRYLOV_GRAPH=1 NO_C1=1 SGM_CG_COOP=0 timeout 600 python tools/cg_small.py 2>&1 | grep '^{' > $OUT/cg_small_launch_loop.jsonl
 NXS=32,100,316,1000 SOLVERS=bicgstab KRYLOV_GRAPH=1 NO_C1=1 timeout 600 python tools/cg_small.py 2>&1 | grep '^{' > $OUT/bicgstab_small.jsonl
 if [ -f tools/probes/libsigma_hip_probe.so ]; then
   NXS=100,256,300,500,1000 timeout 300 python tools/probes/coop_probe.py 2>&1 | grep '^{' > $OUT/coop_probe.jsonl
