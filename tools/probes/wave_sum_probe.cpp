@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <vector>
@@ -36,14 +37,15 @@ int main()
         if (i / 1024 == 9 && i % 1024 == 77) v = NAN;
         h[i] = v;
     }
-    double *d, *a, *b, *c;
-    hipMalloc(&d, n * 8); hipMalloc(&a, n * 8); hipMalloc(&b, n * 8); hipMalloc(&c, n * 8);
-    hipMemcpy(d, h.data(), n * 8, hipMemcpyHostToDevice);
+    double *d = nullptr, *a = nullptr, *b = nullptr, *c = nullptr;
+    auto ok = [](hipError_t e) { if (e != hipSuccess) { printf("HIP error: %s\n", hipGetErrorString(e)); exit(2); } };
+    ok(hipMalloc(&d, n * 8)); ok(hipMalloc(&a, n * 8)); ok(hipMalloc(&b, n * 8)); ok(hipMalloc(&c, n * 8));
+    ok(hipMemcpy(d, h.data(), n * 8, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_both, dim3(blocks), dim3(1024), 0, 0, d, a, b, c);
     std::vector<double> ha(n), hb(n), hc(n);
-    hipMemcpy(ha.data(), a, n * 8, hipMemcpyDeviceToHost);
-    hipMemcpy(hb.data(), b, n * 8, hipMemcpyDeviceToHost);
-    if (hipMemcpy(hc.data(), c, n * 8, hipMemcpyDeviceToHost) != hipSuccess) { printf("HIP error\n"); return 2; }
+    ok(hipMemcpy(ha.data(), a, n * 8, hipMemcpyDeviceToHost));
+    ok(hipMemcpy(hb.data(), b, n * 8, hipMemcpyDeviceToHost));
+    ok(hipMemcpy(hc.data(), c, n * 8, hipMemcpyDeviceToHost));
     long bad = 0, badblk = 0;
     for (int i = 0; i < n; ++i) {
         if (std::memcmp(&ha[i], &hb[i], 8) != 0) { if (bad++ < 5) printf("lane %d: shfl %a fast %a\n", i, ha[i], hb[i]); }
