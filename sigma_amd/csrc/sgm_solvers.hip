@@ -3226,7 +3226,8 @@ int sgm_solver_solve(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc
     struct PermScope { sgm_pc pc = nullptr; ~PermScope() { if (pc) pc_in_permuted(pc, false); } } perm_scope;
     static const bool perm_off = getenv("SGM_SOLVE_PERMUTED") && atoi(getenv("SGM_SOLVE_PERMUTED")) == 0;      // tuning aid / tests
     if (sgm_mat Ap = perm_off ? nullptr : pc_permuted_matrix(pc, A); Ap && P == 1 && !A->comm && Ap->nrow == A->nrow) {
-        if (!s->perm_x) { SGM_TRY(dalloc(&s->perm_x, (size_t)nvec + 2)); SGM_TRY(dalloc(&s->perm_b, (size_t)nvec + 2)); }
+        if (!s->perm_x) SGM_TRY(dalloc(&s->perm_x, (size_t)nvec + 2));
+        if (!s->perm_b) SGM_TRY(dalloc(&s->perm_b, (size_t)nvec + 2));
         pc_permute_vec(pc, sx.dev, s->perm_x, true);
         pc_permute_vec(pc, sb.dev, s->perm_b, true);
         xs[0] = s->perm_x; bs[0] = s->perm_b;
