@@ -1880,16 +1880,21 @@ constexpr int kCoopSpinLimit = 1 << 19;       // polls (about a microsecond each
 static bool coop_applies(sgm_solver s, sgm_mat A, sgm_pc pc, int *rmax_out, int *halo_out, bool *xl_out, bool bicg = false)
 {
     static const bool off = getenv("SGM_CG_COOP") && atoi(getenv("SGM_CG_COOP")) == 0;
-    if (off || !(bicg ? s->opt.bicgstab_small : s->opt.cg_small) || s->multi || s->seq || A->parts.size() != 1 || A->comm || A->fmt != SGM_FMT_CSR || prof_on()) return false;
+    if (off || !(bicg ? s->opt.bicgstab_small : s->opt.cg_small) || s->multi || s->seq || A->parts.size() != 1 || A->comm ||
+        (A->fmt != SGM_FMT_CSR && A->fmt != SGM_FMT_ELL) || prof_on())
+        return false;
     const Part &p = A->parts[0];
-    if (p.n_halo != 0 || !cg_small_sliced(p) || p.n < 2048 || p.ndict < 1 || p.ndict > 15) return false;        // (k_cg_small had its turn already)
+    // (an ELLPACK matrix in its sliced form is the same arrays: every slot an entry, padding = 0.0 x the last neighbour;
+    //  its dictionary's unused entries are 0)
+    const int ndict = p.ecol ? 15 : p.ndict;
+    if (p.n_halo != 0 || !cg_small_sliced(p) || p.n < 2048 || ndict < 1 || ndict > 15) return false;        // (k_cg_small had its turn already)
     const int pk = pc ? pc_kind(pc) : 0;
     if (pk != 0 && pk != SGM_PC_JACOBI) return false;
     if (s->coop_reach < 0) {                                   // the stencil's reach in rows: the largest |offset| of the dictionary
         int32_t hd[16] = {0};
         if (hipMemcpy(hd, p.dict, sizeof hd, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return false; }
         int32_t reach = 0;
-        for (int k = 0; k < p.ndict; ++k) reach = std::max(reach, std::abs(hd[k]));
+        for (int k = 0; k < ndict; ++k) reach = std::max(reach, std::abs(hd[k]));
         s->coop_reach = reach;
     }
     const int H = (s->coop_reach + 1) & ~1;

@@ -325,3 +325,32 @@ def test_cooperative_cg_eight_rows_per_thread_with_r_in_lds_vs_launch_loop():
     for _, jac, ic, il, du, rc, rl in pairs:
         assert abs(int(ic) - int(il)) <= 1 and float(du) <= 1e-10 and float(rc) <= 1e-7 and float(rl) <= 1e-7, (jac, ic, il, du, rc, rl)
     assert "x 8192 rows" in p.stderr, p.stderr[-1500:]
+
+
+def test_cooperative_kernels_take_structured_ellpack_matrices(orc):
+    """An ELLPACK matrix with <= 8 slots from <= 15 offsets lives in the same sliced form as a CSR one (every slot an entry,
+    padding = 0.0 x the last neighbour, like the reference's ellpack_matvec_add): the cooperative CG / BiCGStab kernels
+    take it -- against the oracle's solvers on the oracle's ELLPACK restatement, and SGM_TRACE says so."""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, sigma_amd as sg, oracle as orc\n"
+            "from sigma_amd import problems as P\n"
+            "sg.init(0)\n"
+            "nx, ny = 210, 190\n"
+            "n = nx * ny\n"
+            "ei, ej, ev = P.poisson2d_edges(nx, ny)\n"
+            "ev = np.where(ei == ej, ev * 1.05, ev * (1.0 + 0.2 * np.sign(ei - ej)))\n"
+            "As = orc.EllMatrix.from_edges(n, n, ei, ej, np.where(ei == ej, 4.2, -1.0))\n"
+            "An = orc.EllMatrix.from_edges(n, n, ei, ej, ev)\n"
+            "b = np.sin(0.01 * np.arange(1, n + 1)) + 0.5\n"
+            "for name, A, solver, ref in (('cg', As, sg.cg, orc.cg), ('bicgstab', An, sg.bicgstab, orc.bicgstab)):\n"
+            "    H = sg.ellpack_matrix(n, n, A.node, A.val)\n"
+            "    ur, itr = ref(A, b, x0=np.full(n, 0.25), tol=1e-9)[:2]\n"
+            "    s = solver(1e-9); s.setup(H)\n"
+            "    u = np.full(n, 0.25); s.solve(H, u, b)\n"
+            "    print('RES', name, s.iterations, itr, float(np.abs(u - ur).max() / np.abs(ur).max()))\n" % (ROOT, os.path.join(ROOT, "tests")))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, SGM_TRACE="1"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = {ln.split()[1]: ln.split()[2:] for ln in p.stdout.splitlines() if ln.startswith("RES")}
+    assert abs(int(res["cg"][0]) - int(res["cg"][1])) <= 1 and float(res["cg"][2]) <= 1e-9, res
+    assert abs(int(res["bicgstab"][0]) - int(res["bicgstab"][1])) <= max(3, int(res["bicgstab"][1]) // 10) and float(res["bicgstab"][2]) <= 1e-7, res
+    assert "cg: one cooperative launch" in p.stderr and "bicgstab: one cooperative launch" in p.stderr, p.stderr[-1500:]
