@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 
 
 def spmv_bytes(n, m, nnz):
@@ -76,6 +76,14 @@ def parse_args():
     ap.add_argument("--no-pcg", action="store_true", help="N = 1: skip the `pcg_time_to_solution` leg (CG vs ILDU(0)-PCG, 1000^2 grid)")
     ap.add_argument("--no-dist-overhead", action="store_true",
                     help="N = 1: skip the `dist_overhead_1rank` leg (CG through the RCCL code path with one rank)")
+    ap.add_argument("--no-c5-parts", action="store_true",
+                    help="N = 1: skip the `c5_8parts` leg (the 464^3 matrix as 8 in-process z-slabs on this GPU: what ONE of 8 ranks "
+                         "has to do per CG iteration, and the speed-up that bounds)")
+    ap.add_argument("--c5-parts", type=int, default=8)
+    ap.add_argument("--halo-fused", type=int, default=1, choices=[0, 1, 2],
+                    help="N > 1: option dist_halo_fused of the CG solves (1: r's boundary rows in one RCCL group with the all-reduce of "
+                         "r.r, p's halo formed locally; 2: a group of their own; 0: p exchanged in front of every product)")
+    ap.add_argument("--no-ceilings", action="store_true", help="N = 1: skip tools/stream_bench (measured streaming ceilings of this GPU)")
     ap.add_argument("--no-c3", action="store_true", help="N = 1: skip the C3 leg (1-D advection-diffusion n = 1e7: SpMV, BiCGStab, GMRES(30))")
     ap.add_argument("--no-c4", action="store_true", help="N = 1: skip the C4 leg (ELLPACK random digraph, degree 32, n = 5e6: SpMV)")
     ap.add_argument("--c3-n", type=int, default=10_000_000)
@@ -404,6 +412,7 @@ def worker(args):
         hb.phase(f"{tag}: CG, {its_cap} fixed iterations (warm-up solve, timed solve" + (", profiled solve)" if profile_phases else ")"))
         s = sg.cg(1e-300)
         s.set_max_iter(its_cap)
+        s.set_option("dist_halo_fused", 0 if args.halo_comm else args.halo_fused)     # (a second communicator only serves mode 0)
         s.setup(A)
         bvec = torch.full((n_loc,), 1.0 / n_glob, dtype=torch.float64, device=dev)
         u = torch.zeros(n_loc, dtype=torch.float64, device=dev)
@@ -429,6 +438,12 @@ def worker(args):
                            "events_per_iter": v["count"] / n_it} for nm, v in pr.items()}
         s.destroy()
         return its, dtc, res2, phases
+
+    # ---- N = 1: what a plain streaming kernel reaches on THIS GPU today (tools/stream_bench, a child process) --------------
+    ceilings = None
+    if rank == 0 and world == 1 and not use_dist and not args.no_ceilings and args.workload == "c2":
+        hb.phase("stream ceilings: tools/stream_bench at 600 and 7600 MiB")
+        ceilings = stream_ceilings()
 
     # ---- the workload of the timed steps -----------------------------------------------------
     A, n_loc, n_glob, i0, nnz, label, host = make_matrix(args.workload)
@@ -598,6 +613,16 @@ def worker(args):
               "note": "north_star target: cg_iters_per_s at n_gpus = 8 >= 6 x the n_gpus = 1 figure"}
         A5.destroy()
 
+    # ---- N = 1: C5 as 8 in-process z-slabs on this GPU: one rank's share of a CG iteration, and the speed-up it bounds ----
+    c5p = None
+    if rank == 0 and world == 1 and not use_dist and not args.no_c5 and not args.no_c5_parts and args.workload == "c2" and c5 is not None:
+        hb.phase(f"c5_{args.c5_parts}parts: 464^3 as {args.c5_parts} in-process parts (create, products, CG)")
+        ar_ms = None
+        if dist_overhead and "phases" in dist_overhead:
+            ph = dist_overhead["phases"]["allreduce"]
+            ar_ms = ph["ms_per_iter"] / max(1e-9, ph["events_per_iter"])
+        c5p = c5_parts_leg(args, sg, torch, dev, c5, ar_ms)
+
     # ---- N = 1: the other single-GPU configs of BASELINE.json (C3: configs[2], C4: configs[3]) ---------------------
     c3 = c4 = None
     if rank == 0 and world == 1 and not use_dist and args.workload == "c2":
@@ -621,6 +646,18 @@ def worker(args):
         tag = "c5_1gpu" if world == 1 else f"c5_{world}gpu"
         flat.update({f"{tag}_spmv_ms": c5["spmv_ms"], f"{tag}_spmv_frac_moved": c5["spmv_frac_of_hbm_peak"],
                      f"{tag}_cg_iters_per_s": c5["cg_iters_per_s"], f"{tag}_cg_frac_moved": c5["cg_frac_of_hbm_peak"]})
+    if c5p is not None and "error" not in c5p:
+        flat.update({k: v for k, v in c5p.items() if k.startswith("c5_") and isinstance(v, (int, float))})
+    if ceilings is not None:
+        flat.update(ceilings["flat"])
+        for key, fp in (("c2", "600"), ("c5", "7600")):
+            cp = ceilings["flat"].get(f"ceiling_copy_{fp}MiB_GBs")
+            mx = ceilings["flat"].get(f"ceiling_mix8r1w_{fp}MiB_GBs")
+            got = achieved if key == "c2" else (c5["spmv_GB/s_moved"] if c5 else None)
+            if cp and got:
+                flat[f"{key}_frac_of_copy_ceiling"] = got / cp
+            if mx and got:
+                flat[f"{key}_frac_of_mix_ceiling"] = got / mx
     if c3 is not None:
         flat.update({"c3_spmv_ms": c3["spmv_ms"], "c3_spmv_frac_moved": c3["frac_moved"],
                      "c3_spmv_layout_compression": c3["layout_compression"],
@@ -681,6 +718,7 @@ def worker(args):
                                  "row of its own layout (W = 5) + x once + y once.  cold_* = the same launch after 512 MiB "
                                  "of unrelated writes (nothing of the previous product left in L2 / Infinity Cache)"},
             "spmv_variants": variants or None, "cg": cg, "dist_overhead_1rank": dist_overhead, "c5_strong_scaling": c5,
+            "c5_parts_model": c5p, "stream_ceilings": ceilings,
             "c3": c3, "c4": c4, "c1_reference_sized": c1, "pcg_time_to_solution": pcg, "cpu_baseline": cpu,
             "selfcheck": {"product_bit_exact_on_every_rank": check_main,
                           "what": "every local row of one timed-workload product == its sum evaluated with torch in stored "
@@ -871,6 +909,121 @@ def dist_overhead_leg(args, sg, torch, dev, plain_iters_per_s):
             sg.set_option("dist_force_collectives", 0)
         A.destroy()
         comm.destroy()
+    except Exception as e:
+        out["error"] = str(e)[:300]
+    return out
+
+
+def stream_ceilings():
+    """tools/stream_bench (built by __graft_entry__.build()) at the footprints of C2 (600 MiB) and of C5 on one GPU (7600 MiB):
+    read-only, copy and the 8-reads-per-write mix of 16-byte streams an SpMV on the sliced layout amounts to -- the ceilings the
+    fractions of 8 TB/s are to be read against.  A child process of its own (nothing of this process's GPU state is shared);
+    None when the binary is missing.  Never takes the line down."""
+    exe = os.path.join(ROOT, "tools", "stream_bench")
+    if not os.path.exists(exe):
+        return None
+    out = {"what": "best of each kind over grids / load flavours, GB/s (r+w for copy and mix); tools/stream_bench.cpp", "flat": {}}
+    try:
+        for mib in (600, 7600):
+            p = subprocess.run([exe, str(mib)], capture_output=True, text=True, timeout=120)
+            best = {}
+            for ln in p.stdout.splitlines():
+                kind = "read" if ln.startswith("read") else "copy" if ln.startswith("copy") else "mix8r1w" if ln.startswith("mix 8") else \
+                       "mix3r1w" if ln.startswith("mix 3") else None
+                if kind:
+                    best[kind] = max(best.get(kind, 0.0), float(ln.split("us")[1].split("GB/s")[0]))
+            out[f"{mib}MiB"] = best
+            for kind, v in best.items():
+                out["flat"][f"ceiling_{kind}_{mib}MiB_GBs"] = v
+    except Exception as e:
+        out["error"] = str(e)[:200]
+    return out
+
+
+def c5_parts_leg(args, sg, torch, dev, c5, allreduce_ms):
+    """The C5 matrix (7-point m^3) as P in-process z-slabs on THIS GPU (sgm_csr_create_partitioned_parts: the partition, halo
+    lists, gathers, per-part kernels and reductions an 8-rank run has, all parts taking turns on one GPU): CG for the same
+    fixed iteration count.  ms_per_iter / P is what ONE rank's kernels cost per iteration; with the all-reduce latency of the
+    real librccl (one rank: `dist_overhead_1rank`) twice per iteration that bounds the 8-GPU speed-up from above:
+        c5_model_Pgpu_speedup = t_1gpu_iter / (t_Pparts_iter / P + 2 t_allreduce)
+    -- what P GPUs CAN reach before the costs only a real node shows (xGMI latency of the send / recv pairs, the all-reduce
+    across 8 ranks instead of 1, load imbalance).  Never takes the line down."""
+    import numpy as np
+    P = args.c5_parts
+    out = {"what": c5_parts_leg.__doc__.split("\n\n")[0][:200]}
+    try:
+        m = args.c5_edge
+        zs = [(m * r) // P for r in range(P + 1)]
+        starts = np.array([z * m * m for z in zs], dtype=np.int64)
+        n = m ** 3
+        t0 = time.perf_counter()
+        parts = [local_rows_laplace3d(m, zs[k], zs[k + 1], dev) for k in range(P)]
+        torch.cuda.synchronize()
+        A = sg.partitioned_csr_matrix.from_parts(starts, parts)
+        del parts
+        torch.cuda.synchronize()
+        create_s = time.perf_counter() - t0
+        x = torch.sin(0.001 * torch.arange(1, n + 1, dtype=torch.float64, device=dev))
+        y = torch.zeros(n, dtype=torch.float64, device=dev)
+        A.matvec(x, y)
+        # every row against the one-part product of the same x (the C5 leg checked that one against its stored-order sums)
+        k = torch.arange(0, n, device=dev, dtype=torch.int64)
+        pl = m * m
+        i, j, l = k % m, (k // m) % m, k // pl
+        z = torch.zeros(n, dtype=torch.float64, device=dev)
+        for o, mask, v in [(-pl, l > 0, -1.0), (-m, j > 0, -1.0), (-1, i > 0, -1.0), (0, None, 6.0), (1, i < m - 1, -1.0),
+                           (m, j < m - 1, -1.0), (pl, l < m - 1, -1.0)]:
+            xo = torch.sin(0.001 * (k + (o + 1)).to(torch.float64))
+            z = z + v * xo if mask is None else torch.where(mask, z + v * xo, z)
+        exact = bool(torch.equal(0.0 + z, y))
+        del k, i, j, l, z, xo
+        t_spmv = timed_launches(torch, lambda: A.matvec(x, y), 10)
+        del x, y
+        b = torch.full((n,), 1.0 / n, dtype=torch.float64, device=dev)
+        res = {}
+        for mode in (1, 0):
+            s = sg.cg(1e-300)
+            s.set_max_iter(args.c5_cg_steps)
+            s.set_option("dist_halo_fused", mode)
+            s.setup(A)
+            u = torch.zeros(n, dtype=torch.float64, device=dev)
+            s.solve(A, u, b, check=False)
+            u.zero_()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            s.solve(A, u, b, check=False)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            its = s.last_iterations
+            u.zero_()
+            sg.dist_profile(True)
+            s.solve(A, u, b, check=False)
+            pr = sg.dist_profile_read()
+            sg.dist_profile(False)
+            res[mode] = {"ms_per_iter": 1e3 * dt / its, "iterations": its, "final_res2": s.res2,
+                         "phases_ms_per_iter": {nm: v["ms"] / max(1, its) for nm, v in pr.items()},
+                         "phase_events_per_iter": {nm: v["count"] / max(1, its) for nm, v in pr.items()}}
+            s.destroy()
+            del u
+        A.destroy()
+        t1 = c5["cg_ms_per_iter"]
+        tp = res[1]["ms_per_iter"]
+        ar = allreduce_ms if allreduce_ms is not None else 0.0
+        ph = res[1]["phases_ms_per_iter"]
+        out.update({
+            "parts": P, "create_s": create_s, "product_bit_exact": exact,
+            "cg_fused_halo": res[1], "cg_p_exchanged_by_every_product": res[0],
+            "same_res2_both_modes": res[0]["final_res2"] == res[1]["final_res2"],
+            f"c5_{P}parts_spmv_ms": 1e3 * t_spmv, f"c5_{P}parts_cg_ms_per_iter": tp,
+            f"c5_{P}parts_cg_ms_per_iter_per_part": tp / P,
+            f"c5_{P}parts_cg_ms_per_iter_mode0": res[0]["ms_per_iter"],
+            f"c5_{P}parts_products_ms_per_part": (ph["interior_rows"] + ph["boundary_rows"]) / P,
+            f"c5_{P}parts_halo_ms_per_part": ph["halo_post_to_done"] / P,
+            f"c5_{P}parts_dot_reduce_ms_per_part": (ph["dot_reduce_kernels"] + ph["allreduce"]) / P,
+            "c5_1part_cg_ms_per_iter": t1, "c5_allreduce_1rank_ms": allreduce_ms,
+            f"c5_model_{P}gpu_speedup": t1 / (tp / P + 2.0 * ar),
+            f"c5_model_{P}gpu_cg_iters_per_s": 1e3 / (tp / P + 2.0 * ar),
+        })
     except Exception as e:
         out["error"] = str(e)[:300]
     return out

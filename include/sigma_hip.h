@@ -117,6 +117,13 @@ int sgm_synchronize(void);
  *                          first element to last, cg_solvers.f90:131,135,140): every iterate, iteration count and residual is
  *                          then BIT-IDENTICAL to the reference's, also on row partitions and across ranks; about 4 ns per
  *                          element -- a VALIDATION mode for n up to ~1e5.  GMRES (no reference counterpart) keeps the tree order
+ *   "dist_halo_fused" (1)  CG on a row partition (ranks or in-process parts): the boundary rows of r (z with a preconditioner)
+ *                          travel in the same step as the all-reduce of r.r (r.z) -- over RCCL ONE ncclGroup holding the
+ *                          send / recv pairs and the all-reduce -- and every part forms its halo copy of p itself by the owner's
+ *                          statement p = r + beta p (cg_solvers.f90:142): the product starts without an exchange and without a
+ *                          wait for one.  Same operands, same statement: the same bits as exchanging p.  2 = the send / recv
+ *                          group on its own just before the all-reduce; 0 = p's halo exchanged in front of every product
+ *                          (on the communication stream, overlapped with the interior rows)
  * Preconditioner options
  *   "ildu_strips" (1)      ILDU(0) factors of grid-like matrices use the strip- / slab-pipelined triangular solves; 0 = the
  *                          level-scheduled walkers
@@ -356,6 +363,12 @@ int sgm_comm_destroy(sgm_comm c);
  * interior-rows kernel(s), what the launch stream then still waits for the halo, boundary-rows kernel(s),
  * per-dot partial -> slot reduction kernels, all-reduces }.  Reading synchronises the library's streams.           */
 int sgm_comm_attach_halo_comm(sgm_comm c, const void *id128);
+/* sgm_comm_group_selftest: one ncclGroup holding a send / recv pair (rank to itself) and an in-place all-reduce of one double
+ * -- the group CG posts per iteration with "dist_halo_fused" = 1 -- on this communicator's transport.  out3 = { the double
+ * the pair delivered (42 + rank), the all-reduced 1.0 (= nranks), microseconds of the second such group }.  No reference
+ * counterpart (the reference has no communication); a probe that lets a one-GPU box show that the real
+ * librccl accepts the mixed group. */
+int sgm_comm_group_selftest(sgm_comm c, double *out3);
 int sgm_dist_profile(int on);
 int sgm_dist_profile_read(double *ms_out /* 6 */, int64_t *count_out /* 6 */);
 int sgm_csr_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts /* nranks+1, 0-based */,
@@ -378,6 +391,15 @@ int sgm_csr_create_partitioned(sgm_mat *out, int32_t nparts, const int64_t *row_
                                int32_t nrow, int32_t ncol, int64_t nnz,
                                const int32_t *ptr_1based, const int32_t *node_1based,
                                const double *val /* host arrays */);
+/* sgm_csr_create_partitioned_parts: the same in-process partition handed over PART BY PART: for every part its rows as
+ * sgm_csr_create_dist takes a rank's (local 1-based row pointers, GLOBAL 1-based columns, values), all host or all device
+ * arrays -- for matrices too large to assemble whole on the host (the 7-point 464^3 grid of BASELINE config 5: 8.8 GB).  Same
+ * planners and parts as sgm_csr_create_partitioned; no reference counterpart (the reference has one address space:
+ * cs_matrices.f90:32-107). */
+int sgm_csr_create_partitioned_parts(sgm_mat *out, int32_t nparts, const int64_t *row_starts /* nparts+1 */,
+                                     const int64_t *nnz_of_part, const int32_t *const *ptr_1based_local_of_part,
+                                     const int32_t *const *node_1based_global_of_part, const double *const *val_of_part,
+                                     int where);
 int sgm_halo_plan_host(int32_t n_own, int64_t col_begin /* first owned global column, 0-based */,
                        int64_t nnz, const int32_t *node_1based_global,
                        int32_t *node_1based_local_out, int32_t *halo_cols_out /* capacity nnz */,

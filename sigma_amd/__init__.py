@@ -410,6 +410,34 @@ class partitioned_csr_matrix(_Matrix):
                                              C.c_void_p(val.ctypes.data)))
 
 
+    @classmethod
+    def from_parts(cls, row_starts, parts):
+        """sgm_csr_create_partitioned_parts: the same in-process partition handed over part by part -- parts[k] =
+        (ptr_local, node_global, val) of rows row_starts[k] .. row_starts[k+1]-1, numpy arrays or device tensors (all
+        of one kind) -- for matrices too large to assemble whole on the host."""
+        self = cls.__new__(cls)
+        _Matrix.__init__(self)
+        rs = np.ascontiguousarray(row_starts, np.int64)
+        P = len(rs) - 1
+        assert len(parts) == P
+        keep, wheres = [], []
+        pp, pn, pv = (C.c_void_p * P)(), (C.c_void_p * P)(), (C.c_void_p * P)()
+        nnz = (C.c_int64 * P)()
+        for k, (a, b, c) in enumerate(parts):
+            p1, w1, k1 = _arg(a, np.int32)
+            p2, w2, k2 = _arg(b, np.int32)
+            p3, w3, k3 = _arg(c, np.float64)
+            keep += [k1, k2, k3]
+            wheres += [w1, w2, w3]
+            pp[k], pn[k], pv[k] = p1, p2, p3
+            nnz[k] = int(len(c))
+        self.nrow = self.ncol = int(rs[-1])
+        self.nnz = int(sum(nnz))
+        _ck(lib().sgm_csr_create_partitioned_parts(C.byref(self._h), C.c_int32(P), C.c_void_p(rs.ctypes.data), nnz, pp, pn, pv,
+                                                   C.c_int(_same_where(*wheres))))
+        return self
+
+
 class dist_csr_matrix(_Matrix):
     """This rank's row block of a matrix partitioned over processes (RCCL).  col_starts: the partition of x when it
     is not the rows' (sgm_csr_create_dist_rect: an off-diagonal block of a composite)."""
@@ -768,6 +796,13 @@ class Comm:
         buf = (C.c_char * 128)()
         _ck(lib().sgm_comm_unique_id(buf))
         return bytes(buf)
+
+    def group_selftest(self):
+        """sgm_comm_group_selftest: one group of send / recv (to itself) + all-reduce on this communicator's transport;
+        returns (delivered, allreduced, microseconds) -- delivered must be 42 + rank, allreduced nranks."""
+        out = (C.c_double * 3)()
+        _ck(lib().sgm_comm_group_selftest(self._h, out))
+        return float(out[0]), float(out[1]), float(out[2])
 
     def destroy(self):
         if self._h:

@@ -15,6 +15,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 
 namespace sgm {
 
@@ -168,8 +169,27 @@ __global__ void k_sum_parts(double *const *slots, int nparts, int count)
 // testing aid (option "dist_force_collectives"): with ONE rank the all-reduce is still issued, so that the fixed cost of the
 // RCCL code path can be measured on a single-GPU box
 int g_force_collectives = 0;
-static double **g_slot_ptrs_dev = nullptr;
-static size_t g_slot_ptrs_cap = 0;
+
+// In-process parts: the device table of the parts' slot pointers, one per distinct set of pointers (a solver's slot arrays
+// never move while it lives, so a solve uploads each of its few tables once and no call waits for the host afterwards).
+// A table is found again only by EXACTLY the pointers it holds, so a recycled address can never name a stale table.
+static int slot_table(double *const *slot_ptrs, size_t P, double ***out)
+{
+    static std::vector<std::pair<std::vector<double *>, double **>> tabs;
+    for (auto &t : tabs)
+        if (t.first.size() == P && std::equal(t.first.begin(), t.first.end(), slot_ptrs)) { *out = t.second; return SGM_OK; }
+    if (tabs.size() >= 256) {                    // (solvers come and go: start over rather than grow without bound)
+        SGM_HIP(hipStreamSynchronize(g_rt.stream));
+        for (auto &t : tabs) dfree(t.second);
+        tabs.clear();
+    }
+    double **dev = nullptr;
+    SGM_TRY(dalloc(&dev, P));
+    SGM_HIP(hipMemcpy(dev, slot_ptrs, P * sizeof(double *), hipMemcpyHostToDevice));
+    tabs.emplace_back(std::vector<double *>(slot_ptrs, slot_ptrs + P), dev);
+    *out = dev;
+    return SGM_OK;
+}
 
 int allreduce_slots(sgm_mat A, double *const *slot_ptrs, int count)
 {
@@ -189,18 +209,58 @@ int allreduce_slots(sgm_mat A, double *const *slot_ptrs, int count)
     const size_t P = A->parts.size();
     if (P <= 1) return SGM_OK;
     if (count > 64) return fail(SGM_ERR_BAD_ARG, "allreduce_slots: count %d > 64", count);
-    // a fresh pointer table per call keeps in-flight calls independent (tiny, test-only path)
-    if (g_slot_ptrs_cap < P) {
-        dfree(g_slot_ptrs_dev);
-        SGM_TRY(dalloc(&g_slot_ptrs_dev, P * 64));
-        g_slot_ptrs_cap = P;
-    }
-    static size_t ring = 0;
-    double **tab = g_slot_ptrs_dev + (ring++ % 64) * P;
-    SGM_HIP(hipMemcpyAsync(tab, slot_ptrs, P * sizeof(double *), hipMemcpyHostToDevice, st));
-    SGM_HIP(hipStreamSynchronize(st));   // slot_ptrs is a host temporary
+    double **tab = nullptr;
+    SGM_TRY(slot_table(slot_ptrs, P, &tab));
+    prof_begin(PH_ALLREDUCE, st);
     hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(64), 0, st, (double *const *)tab, (int)P, count);
+    prof_end(PH_ALLREDUCE, st);
     SGM_HIP(hipGetLastError());
+    return SGM_OK;
+}
+
+// The boundary rows of an extended vector to the neighbours' halo slots AND the sum of `count` scalar slots, in one step on
+// the launch stream -- what a CG iteration needs between "r -= alpha q" and "p = r + beta p" once p's halo is formed locally
+// (run_cg): over RCCL the send / recv pairs and the all-reduce are ONE group (one launch of the communication kernel, the
+// pairs on their direct links beside the all-reduce's ring); `grouped` = false posts the same operations one after the other.
+int halo_exchange_allreduce(sgm_mat A, double *const *uext, double *const *slot_ptrs, int count, bool grouped)
+{
+    hipStream_t st = g_rt.stream;
+    if (!A->comm) {
+        prof_begin(PH_HALO, st);
+        SGM_TRY(halo_exchange(A, uext, st));
+        prof_end(PH_HALO, st);
+        return allreduce_slots(A, slot_ptrs, count);
+    }
+    Part &p = A->parts[0];
+    const bool reduce = A->comm->nranks > 1 || g_force_collectives;
+    if (!grouped || p.nbrs.empty() || !reduce) {
+        if (!p.nbrs.empty()) {
+            prof_begin(PH_HALO, st);
+            SGM_TRY(halo_exchange(A, uext, st));
+            prof_end(PH_HALO, st);
+        }
+        return allreduce_slots(A, slot_ptrs, count);
+    }
+    ncclComm_t comm = (ncclComm_t)A->comm->nccl;          // (one group = one communicator: the all-reduce's)
+    for (auto &nb : p.nbrs)
+        if (nb.send_count)
+            hipLaunchKernelGGL(k_gather, dim3((nb.send_count + kBlock - 1) / kBlock), dim3(kBlock), 0, st, nb.send_buf,
+                               (const double *)uext[0], nb.send_idx, nb.send_count);
+    const int hb_prev = g_hb.phase;
+    hb_phase(HB_HALO_POST);
+    g_hb.halo_posts = g_hb.halo_posts + 1;
+    g_hb.allreduce_posts = g_hb.allreduce_posts + 1;
+    prof_begin(PH_ALLREDUCE, st);                          // (the group is timed as the all-reduce it contains)
+    SGM_NCCL(g_nccl.GroupStart());
+    for (auto &nb : p.nbrs) {
+        if (nb.send_count) SGM_NCCL(g_nccl.Send(nb.send_buf, nb.send_count, ncclFloat64, nb.peer, comm, st));
+        if (nb.recv_count)
+            SGM_NCCL(g_nccl.Recv(uext[0] + p.ncol_own + nb.recv_offset, nb.recv_count, ncclFloat64, nb.peer, comm, st));
+    }
+    SGM_NCCL(g_nccl.AllReduce(slot_ptrs[0], slot_ptrs[0], (size_t)count, ncclFloat64, ncclSum, comm, st));
+    SGM_NCCL(g_nccl.GroupEnd());
+    prof_end(PH_ALLREDUCE, st);
+    hb_phase(hb_prev);
     return SGM_OK;
 }
 
@@ -494,6 +554,88 @@ int sgm_csr_create_partitioned(sgm_mat *out, int32_t nparts, const int64_t *row_
     return SGM_OK;
 }
 
+/* sgm_csr_create_partitioned_parts: the same in-process row partition, handed over PART BY PART -- for every part its rows as
+ * sgm_csr_create_dist takes a rank's (local 1-based row pointers, GLOBAL 1-based columns, values; host or device arrays) -- so
+ * that a matrix too large to be assembled whole on the host (7-point 464^3: 8.8 GB of arrays) can be built from row blocks
+ * generated on the device.  Same planners, same parts, same products as sgm_csr_create_partitioned on the whole arrays. */
+int sgm_csr_create_partitioned_parts(sgm_mat *out, int32_t nparts, const int64_t *row_starts, const int64_t *nnz_of_part,
+                                     const int32_t *const *ptr_of_part, const int32_t *const *node_of_part,
+                                     const double *const *val_of_part, int where)
+{
+    SGM_TRY(require_init());
+    if (!out || nparts < 1 || !row_starts || !nnz_of_part || !ptr_of_part || !node_of_part || !val_of_part || row_starts[0] != 0 ||
+        row_starts[nparts] > INT32_MAX)
+        return fail(SGM_ERR_BAD_ARG, "sgm_csr_create_partitioned_parts: bad argument");
+    for (int p = 0; p < nparts; ++p) {
+        if (row_starts[p + 1] < row_starts[p]) return fail(SGM_ERR_BAD_ARG, "sgm_csr_create_partitioned_parts: row_starts must not decrease");
+        if (p && (row_starts[p] & 1)) return fail(SGM_ERR_UNSUPPORTED, "partition boundaries must be even rows (16-B vector access)");
+        if (!ptr_of_part[p] || (nnz_of_part[p] && (!node_of_part[p] || !val_of_part[p])))
+            return fail(SGM_ERR_BAD_ARG, "sgm_csr_create_partitioned_parts: null arrays of part %d", p);
+    }
+    hipStream_t st = g_rt.stream;
+    const int32_t nrow = (int32_t)row_starts[nparts];
+    MatGuard g;
+    sgm_mat A = g.A = new sgm_mat_s;
+    A->fmt = SGM_FMT_CSR;
+    A->nrow = A->ncol = nrow;
+    A->nnz = 0;
+    A->parts.resize(nparts);
+    std::vector<std::vector<int32_t>> halos(nparts);
+    for (int ip = 0; ip < nparts; ++ip) {
+        const int64_t r0 = row_starts[ip], nnz = nnz_of_part[ip];
+        const int32_t n = (int32_t)(row_starts[ip + 1] - r0);
+        std::vector<int32_t> hnode, hptr, lnode((size_t)std::max<int64_t>(nnz, 1));
+        const int32_t *node_h = node_of_part[ip], *ptr_h = ptr_of_part[ip];
+        if (where == SGM_DEVICE) {
+            hnode.resize((size_t)std::max<int64_t>(nnz, 1));
+            hptr.resize((size_t)n + 1);
+            if (nnz) SGM_TRY(copy_big(hnode.data(), node_of_part[ip], (size_t)nnz * 4, hipMemcpyDeviceToHost));
+            SGM_HIP(hipMemcpyAsync(hptr.data(), ptr_of_part[ip], ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, st));
+            SGM_HIP(hipStreamSynchronize(st));
+            node_h = hnode.data();
+            ptr_h = hptr.data();
+        }
+        if (ptr_h[0] != 1 || (int64_t)ptr_h[n] - 1 != nnz)
+            return fail(SGM_ERR_BAD_ARG, "sgm_csr_create_partitioned_parts: part %d: ptr(1) = %d, ptr(n+1)-1 = %lld, nnz = %lld", ip, ptr_h[0],
+                        (long long)ptr_h[n] - 1, (long long)nnz);
+        for (int64_t k = 0; k < nnz; ++k)
+            if (node_h[k] < 1 || node_h[k] > nrow)
+                return fail(SGM_ERR_DIMS, "csr create: part %d: node(%lld) = %d is outside 1..%d", ip, (long long)k + 1, node_h[k], nrow);
+        halo_plan(n, r0, nnz, node_h, lnode.data(), halos[ip]);
+        Part &p = A->parts[ip];
+        if (where == SGM_DEVICE) {
+            int32_t *dnode = nullptr;                  // values stay on the device; only the renumbered columns are uploaded
+            SGM_TRY(dalloc(&dnode, (size_t)std::max<int64_t>(nnz, 1)));
+            g.scratch.push_back(dnode);
+            if (nnz) SGM_TRY(copy_big(dnode, lnode.data(), (size_t)nnz * 4, hipMemcpyHostToDevice));
+            SGM_TRY(build_csr_part(p, n, n, (int32_t)halos[ip].size(), nnz, ptr_of_part[ip], dnode, val_of_part[ip], SGM_DEVICE));
+            SGM_HIP(hipStreamSynchronize(st));
+            dfree(dnode);
+            g.scratch.pop_back();
+        } else {
+            SGM_TRY(build_csr_part(p, n, n, (int32_t)halos[ip].size(), nnz, ptr_h, lnode.data(), val_of_part[ip], SGM_HOST));
+        }
+        SGM_TRY(dalloc(&p.xext, (size_t)p.xlen()));
+        p.row_begin = r0;
+        set_interior_range(p, ptr_h, lnode.data());
+        A->nnz += nnz;
+    }
+    std::vector<Link> links;
+    SGM_TRY(partition_links(nparts, row_starts, halos, links));
+    for (const Link &l : links) {
+        HaloNbr nb;
+        nb.peer = l.receiver;
+        nb.send_count = (int32_t)l.idx.size();
+        nb.recv_offset = l.recv_offset;
+        SGM_TRY(dalloc(&nb.send_idx, l.idx.size()));
+        A->parts[l.sender].nbrs.push_back(nb);
+        SGM_HIP(hipMemcpyAsync(nb.send_idx, l.idx.data(), l.idx.size() * 4, hipMemcpyHostToDevice, g_rt.stream));
+        SGM_HIP(hipStreamSynchronize(g_rt.stream));
+    }
+    *out = g.release();
+    return SGM_OK;
+}
+
 int sgm_comm_unique_id(void *id128)
 {
     SGM_TRY(load_rccl());
@@ -562,6 +704,41 @@ int sgm_dist_profile_read(double *ms_out, int64_t *count_out)
     }
     g_prof.used = 0;
     g_prof.spans.clear();
+    return SGM_OK;
+}
+
+// sgm_comm_group_selftest: ONE ncclGroup that holds a send / recv pair (this rank to itself) AND an in-place all-reduce of one
+// double -- the shape of the group the CG loop posts with option dist_halo_fused = 1 -- on the transport this communicator
+// was made with.  out3 = {what the pair delivered (must be 42 + rank), the all-reduced 1.0 (must be nranks), microseconds}.
+// What it is for: a single-GPU box can show that the REAL librccl takes a group mixing point-to-point and collective
+// operations before the first multi-GPU run depends on it.
+int sgm_comm_group_selftest(sgm_comm c, double *out3)
+{
+    SGM_TRY(require_init());
+    if (!c || !out3) return fail(SGM_ERR_BAD_ARG, "sgm_comm_group_selftest: null argument");
+    double *d = nullptr;
+    SGM_TRY(dalloc(&d, 4));
+    struct Tmp { double *&p; ~Tmp() { dfree(p); } } tmp{d};
+    const double h[4] = {42.0 + c->rank, -1.0, 1.0, 0.0};
+    hipStream_t st = g_rt.stream;
+    SGM_HIP(hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    ncclComm_t comm = (ncclComm_t)c->nccl;
+    double us = 0.0;
+    for (int rep = 0; rep < 2; ++rep) {                 // (the second pass is the timed one: the first sets the channels up)
+        const auto t0 = std::chrono::steady_clock::now();
+        SGM_NCCL(g_nccl.GroupStart());
+        SGM_NCCL(g_nccl.Send(d, 1, ncclFloat64, c->rank, comm, st));
+        SGM_NCCL(g_nccl.Recv(d + 1, 1, ncclFloat64, c->rank, comm, st));
+        if (rep == 0) SGM_NCCL(g_nccl.AllReduce(d + 2, d + 2, 1, ncclFloat64, ncclSum, comm, st));
+        else SGM_NCCL(g_nccl.AllReduce(d + 3, d + 3, 1, ncclFloat64, ncclSum, comm, st));
+        SGM_NCCL(g_nccl.GroupEnd());
+        SGM_HIP(hipStreamSynchronize(st));
+        us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    }
+    double r[4] = {0, 0, 0, 0};
+    SGM_HIP(hipMemcpy(r, d, sizeof r, hipMemcpyDeviceToHost));
+    out3[0] = r[1]; out3[1] = r[2]; out3[2] = us;
     return SGM_OK;
 }
 

@@ -293,17 +293,8 @@ __global__ __launch_bounds__(TPB) void k_ellcb_sum(int32_t n, int32_t max_d, int
 
 // ------------------------------------------------------------------------------ host side
 // matrix options "ell_colblock_cols" / "ell_colblock_rows"; tuning aids read from the environment when a form is built:
-// SGM_ELLCB_CHUNKS = workgroups per column block in the multiply phase (16; C4 sweep 4 / 8 / 16: 1.32 / 1.31 / 1.27 ms),
-// SGM_ELLCB_GRID = phase-2 grid cap
-static int cb_grid2()
-{
-    static int grid2 = 0;
-    if (!grid2) {
-        grid2 = 2048;
-        if (const char *e = getenv("SGM_ELLCB_GRID")) grid2 = std::min(kMaxGrid, std::max(1, atoi(e)));
-    }
-    return grid2;
-}
+// workgroups per column block in the multiply phase: 16 (C4 sweep 4 / 8 / 16: 1.32 / 1.31 / 1.27 ms); phase-2 grid cap: 2048
+static int cb_grid2() { return 2048; }
 
 void free_ell_colblock(Part &p)
 {
@@ -367,15 +358,14 @@ int build_ell_colblock(Part &p)
     if (nb > 65535) return SGM_OK;
     // tile image <= 64 KiB (two workgroups per CU) -- or, option ell_colblock_rows = 512 (automatic for rows <= 32 slots:
     // runs twice as long, one 1024-thread workgroup per CU with a 128 KiB image) -- whole waves
-    static const int rows_env = getenv("SGM_ELLCB_ROWS") ? atoi(getenv("SGM_ELLCB_ROWS")) : 0;      // tuning aid
-    const int want_rows = rows_env ? rows_env : p.opt.ell_colblock_rows;
+    const int want_rows = p.opt.ell_colblock_rows;
     int32_t R = std::min(256, 8192 / p.max_d) / 64 * 64;
     if ((want_rows == 512 || (want_rows == 0 && p.max_d >= 16)) && p.max_d <= 32) R = 512;
     // (round 4: 20480-column blocks and a 152 KiB image of 608 rows -- runs 48 % longer -- measured SLOWER, 1222 / 1171 / 1321 us
     //  against 1134: profiles/r04/c4_cols_rows_sweep.jsonl; the run length is not what bounds the second phase)
     if (R < 64) return SGM_OK;
     const int32_t ntiles = (p.n + R - 1) / R;
-    p.cb_cols = cb; p.cb_nb = nb; p.cb_R = R; p.cb_ntiles = ntiles; p.cb_chunks = getenv("SGM_ELLCB_CHUNKS") ? std::max(1, atoi(getenv("SGM_ELLCB_CHUNKS"))) : 16;
+    p.cb_cols = cb; p.cb_nb = nb; p.cb_R = R; p.cb_ntiles = ntiles; p.cb_chunks = 16;
 
     uint16_t *key = nullptr, *skey = nullptr;
     int32_t *ent = nullptr;

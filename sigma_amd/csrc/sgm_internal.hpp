@@ -61,6 +61,9 @@ struct SolverOptions {
                                    // 0 off, 1 = once the solve has run 64 iterations, n > 1 = after n (rounded up to a multiple of 16)
     int dot_order = 0;             // dot products of CG / BiCGStab: 0 = tree (per-workgroup partial sums), 1 = the reference's order
     int gmres_cgs2 = 1;            // GMRES: blocked CGS-2 orthogonalisation (3 passes per step) instead of modified Gram-Schmidt
+    int dist_halo_fused = 1;       // CG on a row partition: the boundary rows of r (z) travel beside the all-reduce of r.r (r.z) and p's
+                                   // halo is formed locally -- no exchange in front of the product; 1 = one RCCL group with the all-reduce,
+                                   // 2 = its own send / recv group just before it, 0 = off (p's halo exchanged by every product)
 };
 struct PcOptions {
     int ildu_strips = 1;           // ILDU(0) factors of grid-like matrices (deps r-1, r-w[, r-wh]): strip- / slab-pipelined triangular solves
@@ -173,6 +176,8 @@ struct Part {
     uint8_t *code = nullptr;
     int32_t *dict = nullptr;       // 256 entries
     int32_t ndict = 0;
+    int32_t dict_reach = 0;        // largest |offset| of the dictionary (set where the dictionary is built: the cooperative
+                                   // kernels size their halo window from it)
     int32_t max_row = 0;           // longest row (entries); picks the row-owner kernel for short rows
     // sliced form (rows <= 8 entries, <= 15 distinct offsets, little padding): slices of 256
     // rows, values slot-major inside a slice (entry (slot u, row r) at ((r/256)*sw + u)*256 + r%256),
@@ -232,6 +237,7 @@ struct sgm_comm_s {
 inline uint64_t next_mat_serial() { static std::atomic<uint64_t> c{0}; return ++c; }
 struct sgm_mat_s {
     uint64_t serial = next_mat_serial(), version = 0;
+    uint64_t pattern_version = 0;  // bumped by what changes the POSITIONS of the entries (the permutations); version counts those and value changes
     int32_t fmt = 0;
     int32_t nrow = 0, ncol = 0;    // global
     int64_t nnz = 0;               // global (local sum when distributed)
@@ -259,6 +265,8 @@ int matvec_t_dist(sgm_mat A, const double *x, double *y, int where, bool add);
 int halo_exchange(sgm_mat A, double *const *xext, hipStream_t st);
 // sum `count` scalar slots across parts / ranks (in place, every part gets the total)
 int allreduce_slots(sgm_mat A, double *const *slot_ptrs, int count);
+// both at once on the launch stream (over RCCL: one group); uext = one extended vector per local part
+int halo_exchange_allreduce(sgm_mat A, double *const *uext, double *const *slot_ptrs, int count, bool grouped);
 
 // Phase timers of the row-partitioned path (sgm_dist_profile): HIP events around the phases of every product and dot, so
 // that a multi-GPU run says where an iteration's time goes.  Off: no event is recorded.
@@ -285,7 +293,7 @@ struct SpmvDots {
 };
 int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
                const SpmvDots *dots, const int *flag_done, int *grid_out, int gen = 0x7fffffff,
-               bool chain = false);
+               bool chain = false, bool halo_ready = false);      // halo_ready: x's halo slots are current -- no exchange
 
 // upload one CSR row block (1-based arrays as the Fortran holds them) and build its device formats; `validate` checks the
 // index arrays on the device as they are converted (SGM_ERR_BAD_ARG / SGM_ERR_DIMS naming the first offending row)
@@ -293,6 +301,13 @@ int build_csr_part(Part &p, int32_t n, int32_t ncol_own, int32_t n_halo, int64_t
                    const int32_t *ptr1, const int32_t *node1, const double *val, int where, bool validate = true);
 int clone_csr_plain(sgm_mat A, sgm_mat *out);                                   // plain-CSR device copy (setup scratch)
 int color_order_device(sgm_mat A, int32_t **dp, std::vector<int32_t> &ptrs);    // greedy_color_ordering, p left on the device (sgm_order.hip)
+// (sgm_order.hip) a row block's DIAGONAL block (its rows x its owned columns) as a plain single-GPU CSR matrix: what a part
+// of a row partition colours / orders locally
+int diag_block_plain(const Part &p, sgm_mat *out);
+// (sgm_order.hip) q = the row block p with row i moved to row p1(i), its owned columns renumbered by p1 (1-based, device) and
+// its halo columns as they are; stored order inside the rows kept; p's kernel forms (options) and halo links (the sender's
+// row numbers mapped through p1).  No interior range: a product on q runs after its halo has arrived.
+int permuted_part(const Part &p, const int32_t *p1_dev, Part &q);
 int spmv_grid(const Part &p);
 int matvec_plain(sgm_mat A, const double *x, double *y);     // device vectors, sgm_mat_matvec's layout, stream-ordered
 // "csr_lean": the CSR-order arrays of a part that kept only its sliced form, on demand (no-op otherwise)

@@ -21,6 +21,7 @@
 
 namespace sgm {
 int rebuild_csr_formats(Part &p);          // sgm_spmv.hip
+void free_part(Part &p);                   // sgm_spmv.hip
 int rebuild_ell_formats(Part &p);          // sgm_spmv.hip
 int sgm_invalidate_transpose(sgm_mat A);   // sgm_spmv.hip
 }
@@ -367,7 +368,9 @@ int greedy_coloring_device(const Part &pt, int32_t *colors_dev, int32_t *p_dev, 
     int32_t hstate[4] = {0, 0, INT32_MAX, 0};
     const int gridn = (n + kBlock - 1) / kBlock;
     bool parity_done = false;
-    if (!getenv("SGM_COLOR_LEVELS")) {                                    // (tests: force the level sweep)
+    // (the union-find pass verifies symmetry by scanning row j for every edge (i, j): quadratic in the degree -- a hub of a
+    //  million leaves would cost 1e12 steps.  Rows beyond 64 entries leave it to the level sweep / the linear host pass.)
+    if (!getenv("SGM_COLOR_LEVELS") && pt.max_row <= 64) {                // (tests: force the level sweep)
         uint32_t *P = reinterpret_cast<uint32_t *>(fr[0]);
         SGM_HIP(hipMemcpyAsync(state, init_state, sizeof init_state, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_uf_init, dim3(gridn), dim3(kBlock), 0, st, n, (const int32_t *)pt.rowptr, (const int32_t *)pt.col, P);
@@ -451,6 +454,137 @@ int color_order_device(sgm_mat A, int32_t **dp, std::vector<int32_t> &ptrs)
     if (rc != SGM_OK) { dfree(*dp); *dp = nullptr; }
     return rc;
 }
+
+// ---- row blocks of a partition: local orderings (the reordering preconditioner on parts / ranks, sgm_pc.hip) -----------------
+namespace {
+__global__ void k_blk_count(int32_t n, int32_t own, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, int32_t *__restrict__ cnt)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    int32_t c = 0;
+    if (i < n)
+        for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) c += col[k] < own;
+    cnt[i] = c;
+}
+__global__ void k_blk_fill(int32_t n, int32_t own, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                           const double *__restrict__ val, const int32_t *__restrict__ rowptr2, int32_t *__restrict__ col2, double *__restrict__ val2)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t d = rowptr2[i];
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
+        if (col[k] < own) { col2[d] = col[k]; val2[d] = val[k]; ++d; }
+}
+__global__ void k_perm_cols_own(int64_t nnz, int32_t own, int32_t *__restrict__ col, const int32_t *__restrict__ p1)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; k < nnz; k += stride) { const int32_t c = col[k]; if (c < own) col[k] = p1[c] - 1; }
+}
+__global__ void k_map_idx(int32_t count, const int32_t *__restrict__ src, const int32_t *__restrict__ p1, int32_t *__restrict__ dst)
+{
+    const int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < count) dst[j] = p1[src[j]] - 1;
+}
+// exclusive scan of n + 1 int32 counts in place
+int scan_counts(int32_t *a, int32_t n1)
+{
+    size_t tb = 0;
+    void *tmp = nullptr;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, a, a, n1, g_rt.stream);
+    SGM_HIP(hipMalloc(&tmp, std::max<size_t>(tb, 16)));
+    const hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tb, a, a, n1, g_rt.stream);
+    const hipError_t e2 = hipStreamSynchronize(g_rt.stream);
+    (void)hipFree(tmp);
+    SGM_HIP(e);
+    SGM_HIP(e2);
+    return SGM_OK;
+}
+}  // namespace
+
+int diag_block_plain(const Part &p, sgm_mat *out)
+{
+    *out = nullptr;
+    SGM_TRY(csr_need_arrays(p));
+    struct Release { const Part &p; ~Release() { csr_release_arrays(p); } } rel{p};
+    hipStream_t st = g_rt.stream;
+    const int32_t n = p.n, own = p.n_halo == 0 ? INT32_MAX : p.ncol_own;
+    sgm_mat C = new sgm_mat_s;
+    struct Guard { sgm_mat &C; ~Guard() { if (C) sgm_mat_destroy(C); } } guard{C};
+    C->fmt = SGM_FMT_CSR; C->nrow = C->ncol = n;
+    C->parts.resize(1);
+    Part &q = C->parts[0];
+    q.opt.csr_offset_dict = 0; q.opt.csr_sliced = 0; q.opt.csr_sell = 0; q.opt.csr_lean = 0; q.opt.slice_sched = 0;
+    q.n = n; q.ncol_own = n; q.n_halo = 0;
+    SGM_TRY(dalloc(&q.rowptr, (size_t)n + 1));
+    hipLaunchKernelGGL(k_blk_count, dim3((n + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, own, (const int32_t *)p.rowptr,
+                       (const int32_t *)p.col, q.rowptr);
+    SGM_TRY(scan_counts(q.rowptr, n + 1));
+    int32_t tot = 0;
+    SGM_HIP(hipMemcpy(&tot, q.rowptr + n, 4, hipMemcpyDeviceToHost));
+    q.nnz = C->nnz = tot;
+    q.max_row = p.max_row;
+    SGM_TRY(dalloc(&q.col, (size_t)tot + 4));
+    SGM_TRY(dalloc(&q.val, (size_t)tot + 2));
+    SGM_HIP(hipMemsetAsync(q.col + tot, 0, 16, st));
+    SGM_HIP(hipMemsetAsync(q.val + tot, 0, 16, st));
+    if (n) hipLaunchKernelGGL(k_blk_fill, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, own, (const int32_t *)p.rowptr,
+                              (const int32_t *)p.col, (const double *)p.val, (const int32_t *)q.rowptr, q.col, q.val);
+    SGM_HIP(hipGetLastError());
+    SGM_HIP(hipStreamSynchronize(st));
+    *out = C;
+    C = nullptr;
+    return SGM_OK;
+}
+
+int permuted_part(const Part &p, const int32_t *p1, Part &q)
+{
+    SGM_TRY(csr_need_arrays(p));
+    struct Release { const Part &p; ~Release() { csr_release_arrays(p); } } rel{p};
+    hipStream_t st = g_rt.stream;
+    const int32_t n = p.n;
+    free_part(q);
+    q.opt = p.opt;
+    q.n = n; q.ncol_own = p.ncol_own; q.n_halo = p.n_halo; q.nnz = p.nnz; q.row_begin = p.row_begin;
+    q.int_lo = q.int_hi = 0;
+    int32_t *len2 = nullptr;
+    struct Tmp { int32_t *&a; ~Tmp() { dfree(a); } } tmp{len2};
+    SGM_TRY(dalloc(&len2, (size_t)n + 1));
+    SGM_TRY(dalloc(&q.rowptr, (size_t)n + 1));
+    SGM_TRY(dalloc(&q.col, (size_t)p.nnz + 4));
+    SGM_TRY(dalloc(&q.val, (size_t)p.nnz + 2));
+    SGM_HIP(hipMemsetAsync(len2, 0, ((size_t)n + 1) * 4, st));
+    SGM_HIP(hipMemsetAsync(q.col + p.nnz, 0, 16, st));
+    SGM_HIP(hipMemsetAsync(q.val + p.nnz, 0, 16, st));
+    if (n) hipLaunchKernelGGL(k_perm_lengths, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, (const int32_t *)p.rowptr, p1, len2);
+    SGM_TRY(scan_counts(len2, n + 1));
+    SGM_HIP(hipMemcpyAsync(q.rowptr, len2, ((size_t)n + 1) * 4, hipMemcpyDeviceToDevice, st));
+    if (n) hipLaunchKernelGGL(k_perm_rows, dim3((unsigned)(((int64_t)n * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, n,
+                              (const int32_t *)p.rowptr, p1, (const int32_t *)q.rowptr, (const int32_t *)p.col, (const double *)p.val,
+                              q.col, q.val);
+    if (p.nnz) hipLaunchKernelGGL(k_perm_cols_own, dim3(vec_grid(p.nnz)), dim3(kBlock), 0, st, p.nnz, p.n_halo == 0 ? INT32_MAX : p.ncol_own,
+                                  q.col, p1);
+    SGM_HIP(hipGetLastError());
+    SGM_HIP(hipStreamSynchronize(st));
+    SGM_TRY(rebuild_csr_formats(q));
+    if (p.xext) SGM_TRY(dalloc(&q.xext, (size_t)q.xlen()));
+    for (const HaloNbr &nb : p.nbrs) {
+        HaloNbr m = nb;
+        m.send_idx = nullptr; m.send_buf = nullptr;
+        q.nbrs.push_back(m);                              // (owned by q from here on: free_part releases what follows)
+        HaloNbr &o = q.nbrs.back();
+        if (nb.send_idx) {
+            SGM_TRY(dalloc(&o.send_idx, (size_t)std::max(nb.send_count, 1)));
+            if (nb.send_count) hipLaunchKernelGGL(k_map_idx, dim3((nb.send_count + kBlock - 1) / kBlock), dim3(kBlock), 0, st, nb.send_count,
+                                                  (const int32_t *)nb.send_idx, p1, o.send_idx);
+        }
+        if (nb.send_buf) SGM_TRY(dalloc(&o.send_buf, (size_t)std::max(nb.send_count, 1)));
+    }
+    SGM_HIP(hipGetLastError());
+    SGM_HIP(hipStreamSynchronize(st));
+    return SGM_OK;
+}
+
 }  // namespace sgm
 
 extern "C" {
@@ -631,6 +765,7 @@ int sgm_mat_left_permute(sgm_mat A, const int32_t *p, int where)
     SGM_TRY(require_init());
     if (!A || !p) return fail(SGM_ERR_BAD_ARG, "sgm_mat_left_permute: null argument");
     A->version += 1;
+    A->pattern_version += 1;
     if ((A->fmt != SGM_FMT_CSR && A->fmt != SGM_FMT_ELL) || A->distributed())
         return fail(SGM_ERR_UNSUPPORTED, "sgm_mat_left_permute: single-GPU CSR / ELLPACK matrices only");
     Part &pt = A->parts[0];
@@ -699,6 +834,7 @@ int sgm_mat_right_permute(sgm_mat A, const int32_t *p, int where)
     SGM_TRY(require_init());
     if (!A || !p) return fail(SGM_ERR_BAD_ARG, "sgm_mat_right_permute: null argument");
     A->version += 1;
+    A->pattern_version += 1;
     if ((A->fmt != SGM_FMT_CSR && A->fmt != SGM_FMT_ELL) || A->distributed())
         return fail(SGM_ERR_UNSUPPORTED, "sgm_mat_right_permute: single-GPU CSR / ELLPACK matrices only");
     Part &pt = A->parts[0];

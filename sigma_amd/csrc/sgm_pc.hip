@@ -181,11 +181,12 @@ struct sgm_pc_s {
     int32_t *abort_sticky = nullptr; // device: set by a pipelined triangular sweep that gave up; cleared by the host only
     int retired = 0;                 // pipelines switched off after an abort (diagnostics: sgm_pc_get "pipeline_retired")
     PcOptions opt = g_opt.pc;        // this preconditioner's options: the defaults at its creation, then sgm_pc_set_option
-    // option "ildu_reorder": the factors are those of P A P^T; perm = p (1-based: row i of A is row p(i) of the permuted
-    // matrix), rp / zp = right-hand side and result in the permuted order
-    int32_t *perm = nullptr;
-    double *rp = nullptr, *zp = nullptr;
-    int32_t perm_colors = 0;
+    // option "ildu_reorder": the factors are those of P A P^T -- on a row partition of P_k A_kk P_k^T for every part k, each
+    // part ordering its own diagonal block (no communication; halo columns keep their numbers).  perm = p (1-based, local:
+    // row i of the part is row p(i) of the permuted part), rp / zp = right-hand side and result in the permuted order
+    struct Reorder { int32_t *perm = nullptr; double *rp = nullptr, *zp = nullptr; int32_t n = 0, colors = 0; };
+    std::vector<Reorder> ro;            // one per part; empty = natural order
+    uint64_t ro_serial = 0, ro_pattern = 0;     // the matrix (serial number, pattern version) the orderings were found for
     double reorder_ms[3] = {0, 0, 0};  // last setup: ordering, permuted copy, (factorisation is in the regular phases)
     // the permuted matrix itself, kept (with A's kernel forms) for the Krylov solvers: they run the whole solve in the
     // permuted order -- b and x permuted once each way -- instead of permuting r and z in every apply (in_permuted: vectors
@@ -1809,7 +1810,7 @@ int tri_walkers(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const
             }
         }
         // schedule: wide levels alone, runs of narrow levels together
-        static const int narrow = getenv("SGM_TRSV_NARROW") ? std::min(atoi(getenv("SGM_TRSV_NARROW")), kNarrow) : kNarrow;
+        constexpr int narrow = kNarrow;
         std::vector<int8_t> lev_cls(nlev, 0);
         {
             std::vector<int8_t> raw(nlev, 0);
@@ -1984,11 +1985,10 @@ int refresh_grid_values(GridTri &G, const double *val)
 void trsv_grid(const GridTri &G, double *xp, const int *flag, int spin_limit, int32_t *sticky)
 {
     hipStream_t st = g_rt.stream;
-    static const int xcd_env = getenv("SGM_STRIP_XCD") ? atoi(getenv("SGM_STRIP_XCD")) : -1;
-    static const int depth = getenv("SGM_STRIP_DEPTH") ? atoi(getenv("SGM_STRIP_DEPTH")) : kStripDepth;
-    const int one_xcd = xcd_env > 0 ? 1 : 0;             // (measured: 0.83 vs 0.87 ms at 1000^2, 2.06 vs 1.85 at 2000^2: within noise, off)
+    constexpr int depth = kStripDepth;
+    constexpr int one_xcd = 0;            // (all strips on one XCD measured 0.83 vs 0.87 ms at 1000^2, 2.06 vs 1.85 at 2000^2: within noise, off)
     // 96 KiB of (unused) dynamic LDS per workgroup: at most ONE strip per CU, so that no two chain waves share a SIMD
-    static const size_t lds_pad = getenv("SGM_STRIP_LDS") ? (size_t)atoi(getenv("SGM_STRIP_LDS")) : (size_t)96 * 1024;
+    constexpr size_t lds_pad = (size_t)96 * 1024;
 #define STRIP_K(DD, OO, LL)                                                                                                      \
     do {                                                                                                                         \
         static bool attr = false;                                                                                                \
@@ -1996,7 +1996,7 @@ void trsv_grid(const GridTri &G, double *xp, const int *flag, int spin_limit, in
         hipLaunchKernelGGL((k_trsv_strip<DD, kStripChunk, OO, LL>), dim3(one_xcd ? G.NI * 8 : G.NI), dim3(192), lds_pad, st, G.NI, G.S, \
                            (const StripRec *)G.rec, xp, G.edge, G.progress, flag, one_xcd, spin_limit, sticky);                  \
     } while (0)
-    // look-ahead (SGM_STRIP_DEPTH): 32 register slots with 20 steps in flight (3 memory operations per step, vmcnt counts to 63),
+    // look-ahead (kStripDepth): 32 register slots with 20 steps in flight (3 memory operations per step, vmcnt counts to 63),
     // 32 with all 32 in flight (the compiler then drains the queue once per trip of the unrolled loop), or 16
     if (depth == 20) { if (G.order == 0) STRIP_K(32, 0, 20); else if (G.order == 1) STRIP_K(32, 1, 20); else STRIP_K(32, 2, 20); }
     else if (depth >= 32) { if (G.order == 0) STRIP_K(32, 0, 32); else if (G.order == 1) STRIP_K(32, 1, 32); else STRIP_K(32, 2, 32); }
@@ -2238,23 +2238,13 @@ void trsv(const TriFactor &T, double *xp, const int *flag)
     do {                                                                      \
         if (L.c <= 2) RING(TT, R, DD, 2, AA); else if (L.c == 3) RING(TT, R, DD, 3, AA); else RING(TT, R, DD, 4, AA); \
     } while (0)
-            static const bool no_ring = getenv("SGM_TRSV_NO_RING") != nullptr;                       // tuning aids
-            static const bool no_pair = getenv("SGM_TRSV_NO_PAIR") != nullptr;
-            if (L.ring && !no_ring && T.nstride < (size_t)500000000) {       // (32-bit byte offsets)
-                // class = widest level of the run: <= 256, 512, 1024, 2048, 4096 rows
-                if (no_pair) {
-                    if (L.cls == 0) RINGC(256, 1, 4, 1);
-                    else if (L.cls == 1) RINGC(512, 1, 4, 1);
-                    else if (L.cls == 2) RINGC(1024, 1, 4, 1);
-                    else if (L.cls == 3) RINGC(1024, 2, 2, 1);
-                    else RINGC(1024, 4, 1, 1);
-                } else {
-                    if (L.cls == 0) RINGC(256, 1, 4, 1);
-                    else if (L.cls == 1) RINGC(256, 1, 4, 2);
-                    else if (L.cls == 2) RINGC(512, 1, 4, 2);
-                    else if (L.cls == 3) RINGC(1024, 1, 2, 2);
-                    else RINGC(1024, 2, 1, 2);
-                }
+            if (L.ring && T.nstride < (size_t)500000000) {       // (32-bit byte offsets)
+                // class = widest level of the run: <= 256, 512, 1024, 2048, 4096 rows (two rows per lane pair from 512 on)
+                if (L.cls == 0) RINGC(256, 1, 4, 1);
+                else if (L.cls == 1) RINGC(256, 1, 4, 2);
+                else if (L.cls == 2) RINGC(512, 1, 4, 2);
+                else if (L.cls == 3) RINGC(1024, 1, 2, 2);
+                else RINGC(1024, 2, 1, 2);
             } else if (L.cls <= 2) WALK(1, 2);
             else if (L.cls == 3) WALK(2, 1);
             else WALK(4, 1);
@@ -2414,7 +2404,7 @@ const double *pc_idiag(sgm_pc pc, size_t part) { return pc->parts[part].idiag; }
 // for another one the applies permute r and z themselves).
 sgm_mat pc_permuted_matrix(sgm_pc pc, sgm_mat A)
 {
-    if (!pc || pc->kind != SGM_PC_ILDU0 || !pc->perm || !pc->Ap || !A) return nullptr;
+    if (!pc || pc->kind != SGM_PC_ILDU0 || pc->ro.empty() || !pc->Ap || !A) return nullptr;
     return pc->Ap_serial == A->serial && pc->Ap_version == A->version ? pc->Ap : nullptr;
 }
 void pc_in_permuted(sgm_pc pc, bool on) { if (pc) pc->in_permuted = on; }
@@ -2466,12 +2456,13 @@ __global__ void k_perm_from(int32_t n, const int32_t *__restrict__ p1, const dou
 
 static int pc_apply_parts_ordered(sgm_pc pc, sgm_mat A, const double *const *r, double *const *z, const int *const *flags);
 
-// dst = P src (to_permuted) or dst = P^T src
-void pc_permute_vec(sgm_pc pc, const double *src, double *dst, bool to_permuted)
+// part ip's slice: dst = P src (to_permuted) or dst = P^T src
+void pc_permute_vec(sgm_pc pc, size_t ip, const double *src, double *dst, bool to_permuted)
 {
-    const int32_t n = pc->n;
-    if (to_permuted) hipLaunchKernelGGL(k_perm_to, dim3(vec_grid(n)), dim3(kBlock), 0, g_rt.stream, n, (const int32_t *)pc->perm, src, dst, (const int *)nullptr);
-    else hipLaunchKernelGGL(k_perm_from, dim3(vec_grid(n)), dim3(kBlock), 0, g_rt.stream, n, (const int32_t *)pc->perm, src, dst, (const int *)nullptr);
+    const int32_t n = pc->ro[ip].n;
+    if (!n) return;
+    if (to_permuted) hipLaunchKernelGGL(k_perm_to, dim3(vec_grid(n)), dim3(kBlock), 0, g_rt.stream, n, (const int32_t *)pc->ro[ip].perm, src, dst, (const int *)nullptr);
+    else hipLaunchKernelGGL(k_perm_from, dim3(vec_grid(n)), dim3(kBlock), 0, g_rt.stream, n, (const int32_t *)pc->ro[ip].perm, src, dst, (const int *)nullptr);
 }
 
 // CG's "r -= alpha q; z = M^-1 r; partial sums of r.z" as the two launches of a two-level row-space factorisation
@@ -2479,18 +2470,17 @@ void pc_permute_vec(sgm_pc pc, const double *src, double *dst, bool to_permuted)
 // *count = partial sums left in `part`.
 // pc_cg_fused_rows: 0 = not that kind, else n0 -- the caller first updates r(0 .. n0-1) -= alpha q (the rows without L
 // entries: nobody else writes them), then calls pc_cg_fused, which updates the others as its first sweep reaches them
-int32_t pc_cg_fused_rows(sgm_pc pc)
+int32_t pc_cg_fused_rows(sgm_pc pc, size_t ip)
 {
-    static const bool off = getenv("SGM_PCG_FUSED") && atoi(getenv("SGM_PCG_FUSED")) == 0;
-    if (off || !pc || pc->kind != SGM_PC_ILDU0 || pc->ild.size() != 1 || (pc->perm && !pc->in_permuted)) return 0;
-    const IlduState *S = &pc->ild[0];
+    if (!pc || pc->kind != SGM_PC_ILDU0 || ip >= pc->ild.size() || (!pc->ro.empty() && !pc->in_permuted)) return 0;
+    const IlduState *S = &pc->ild[ip];
     if ((S->opt.ildu_strips && (S->grid_ok || S->slab_ok)) || !S->levels_ready || !rows_two_level(S)) return 0;
     return S->rows_n0;
 }
-bool pc_cg_fused(sgm_pc pc, ScalarRef res2, ScalarRef dpr, const double *q, double *r, double *z, double *part, int *count, const int *flag, int gen)
+bool pc_cg_fused(sgm_pc pc, size_t ip, ScalarRef res2, ScalarRef dpr, const double *q, double *r, double *z, double *part, int *count, const int *flag, int gen)
 {
-    if (!pc_cg_fused_rows(pc)) return false;
-    const IlduState *S = &pc->ild[0];
+    if (!pc_cg_fused_rows(pc, ip)) return false;
+    const IlduState *S = &pc->ild[ip];
     const auto &L1 = S->L.row_levels[1], &U1 = S->U.row_levels[1];
     auto grid_for = [](int32_t rows) { return 8 * std::max(1, std::min(kRowsCgGrid / 8, ((rows + kBlock - 1) / kBlock + 7) / 8)); };
     const int g1 = grid_for(L1.e - L1.b), g2 = grid_for(U1.e - U1.b);
@@ -2502,16 +2492,22 @@ bool pc_cg_fused(sgm_pc pc, ScalarRef res2, ScalarRef dpr, const double *q, doub
 
 int pc_apply_parts(sgm_pc pc, sgm_mat A, const double *const *r, double *const *z, const int *const *flags)
 {
-    if (pc->kind == SGM_PC_ILDU0 && pc->perm && !pc->in_permuted) {
-        // z = P^T M^-1 P r: into the colour order, the sweeps there, back
+    if (pc->kind == SGM_PC_ILDU0 && !pc->ro.empty() && !pc->in_permuted) {
+        // z = P^T M^-1 P r, part by part: into the colour order, the sweeps there, back
         hipStream_t st = g_rt.stream;
-        const int32_t n = pc->n;
-        const int *flag = flags ? flags[0] : nullptr;
-        hipLaunchKernelGGL(k_perm_to, dim3(vec_grid(n)), dim3(kBlock), 0, st, n, (const int32_t *)pc->perm, r[0], pc->rp, flag);
-        const double *rr[1] = {pc->rp};
-        double *zz[1] = {pc->zp};
-        SGM_TRY(pc_apply_parts_ordered(pc, A, rr, zz, flags));
-        hipLaunchKernelGGL(k_perm_from, dim3(vec_grid(n)), dim3(kBlock), 0, st, n, (const int32_t *)pc->perm, (const double *)pc->zp, z[0], flag);
+        const size_t P = pc->ro.size();
+        std::vector<const double *> rr(P);
+        std::vector<double *> zz(P);
+        for (size_t ip = 0; ip < P; ++ip) {
+            const auto &R = pc->ro[ip];
+            if (R.n) hipLaunchKernelGGL(k_perm_to, dim3(vec_grid(R.n)), dim3(kBlock), 0, st, R.n, (const int32_t *)R.perm, r[ip], R.rp, flags ? flags[ip] : nullptr);
+            rr[ip] = R.rp; zz[ip] = R.zp;
+        }
+        SGM_TRY(pc_apply_parts_ordered(pc, A, rr.data(), zz.data(), flags));
+        for (size_t ip = 0; ip < P; ++ip) {
+            const auto &R = pc->ro[ip];
+            if (R.n) hipLaunchKernelGGL(k_perm_from, dim3(vec_grid(R.n)), dim3(kBlock), 0, st, R.n, (const int32_t *)R.perm, (const double *)R.zp, z[ip], flags ? flags[ip] : nullptr);
+        }
         SGM_HIP(hipGetLastError());
         return SGM_OK;
     }
@@ -2556,44 +2552,64 @@ extern "C" {
 
 static int pc_setup_ordered(sgm_pc pc, sgm_mat A);
 
+static void free_reorder(sgm_pc pc)
+{
+    for (auto &R : pc->ro) { dfree(R.perm); dfree(R.rp); dfree(R.zp); }
+    pc->ro.clear();
+}
+
 int sgm_pc_setup(sgm_pc pc, sgm_mat A)
 {
     SGM_TRY(require_init());
     if (!pc || !A) return fail(SGM_ERR_BAD_ARG, "sgm_pc_setup: null argument");
-    const bool reorder = pc->kind == SGM_PC_ILDU0 && pc->opt.ildu_reorder && A->fmt == SGM_FMT_CSR && A->parts.size() == 1 && !A->comm &&
-                         A->nrow == A->ncol && A->nrow > 0;
+    const bool reorder = pc->kind == SGM_PC_ILDU0 && pc->opt.ildu_reorder && A->fmt == SGM_FMT_CSR && A->nrow == A->ncol && A->nrow > 0;
     if (!reorder) {
-        if (pc->perm) { dfree(pc->perm); dfree(pc->rp); dfree(pc->zp); pc->perm = nullptr; pc->rp = pc->zp = nullptr; for (auto &S : pc->ild) free_ildu(S); pc->ild.clear(); }
+        if (!pc->ro.empty()) { free_reorder(pc); for (auto &S : pc->ild) free_ildu(S); pc->ild.clear(); }
         if (pc->Ap) { sgm_mat_destroy(pc->Ap); pc->Ap = nullptr; }
         return pc_setup_ordered(pc, A);
     }
     // ILDU(0) of the colour-ordered matrix: the ordering once per pattern (ldu_solvers.f90:117-125 builds the pattern once),
-    // a permuted scratch copy of A per setup (the values may have changed), the regular device-side setup on that copy
+    // a permuted copy of A per setup (the values may have changed), the regular device-side setup on that copy.  On a row
+    // partition every part orders its own DIAGONAL block (greedy_color_ordering of A_kk's graph, permutations.f90:83-205; no
+    // communication) and the copy's part k is P_k A_k [P_k^T (+) I]: rows and owned columns renumbered, halo columns and
+    // the neighbours' request lists' meaning kept (the lists are mapped through P_k) -- block-Jacobi ILDU(0) of the ordered
+    // blocks, SURVEY 8e.
     auto t0 = std::chrono::steady_clock::now();
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { (void)hipStreamSynchronize(g_rt.stream); return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
-    const int32_t n = A->nrow;
-    if (!pc->perm || pc->n != n) {
-        dfree(pc->perm); dfree(pc->rp); dfree(pc->zp);
-        pc->perm = nullptr; pc->rp = pc->zp = nullptr;
+    const size_t P = A->parts.size();
+    bool same = pc->ro.size() == P && pc->ro_serial == A->serial && pc->ro_pattern == A->pattern_version;
+    for (size_t ip = 0; same && ip < P; ++ip) same = pc->ro[ip].n == A->parts[ip].n && pc->ro[ip].perm && pc->ro[ip].rp && pc->ro[ip].zp;
+    if (!same) {
+        free_reorder(pc);
         for (auto &S : pc->ild) free_ildu(S);
         pc->ild.clear();
-        std::vector<int32_t> ptrs;
-        SGM_TRY(color_order_device(A, &pc->perm, ptrs));
-        pc->perm_colors = (int32_t)ptrs.size() - 1;
-        SGM_TRY(dalloc(&pc->rp, (size_t)n + 2));
-        SGM_TRY(dalloc(&pc->zp, (size_t)n + 2));
+        pc->ro.resize(P);
+        struct Undo { sgm_pc pc; bool armed = true; ~Undo() { if (armed) free_reorder(pc); } } undo{pc};      // (a failure below leaves no half-made ordering behind)
+        for (size_t ip = 0; ip < P; ++ip) {
+            sgm_mat B = nullptr;
+            SGM_TRY(diag_block_plain(A->parts[ip], &B));
+            std::vector<int32_t> ptrs;
+            const int rc = color_order_device(B, &pc->ro[ip].perm, ptrs);
+            sgm_mat_destroy(B);
+            if (rc != SGM_OK) return rc;
+            pc->ro[ip].n = A->parts[ip].n;
+            pc->ro[ip].colors = (int32_t)ptrs.size() - 1;
+            SGM_TRY(dalloc(&pc->ro[ip].rp, (size_t)pc->ro[ip].n + 2));
+            SGM_TRY(dalloc(&pc->ro[ip].zp, (size_t)pc->ro[ip].n + 2));
+        }
+        undo.armed = false;
+        pc->ro_serial = A->serial;
+        pc->ro_pattern = A->pattern_version;
         pc->reorder_ms[0] = ms_since(t0);
     }
     t0 = std::chrono::steady_clock::now();
     if (pc->Ap) { sgm_mat_destroy(pc->Ap); pc->Ap = nullptr; }
-    sgm_mat Ap = nullptr;
-    SGM_TRY(clone_csr_plain(A, &Ap));
-    int rc = sgm_mat_left_permute(Ap, pc->perm, SGM_DEVICE);
-    if (rc == SGM_OK) rc = sgm_mat_right_permute(Ap, pc->perm, SGM_DEVICE);
-    if (rc == SGM_OK) {                                   // the kernel forms A itself has, once, on the finished copy
-        Ap->parts[0].opt = A->parts[0].opt;               // (csr_lean included: the factorisation below gets the CSR-order arrays
-        rc = rebuild_csr_formats(Ap->parts[0]);           //  rebuilt for its duration, like any reader of a lean matrix)
-    }
+    sgm_mat Ap = new sgm_mat_s;
+    Ap->fmt = SGM_FMT_CSR; Ap->nrow = A->nrow; Ap->ncol = A->ncol; Ap->nnz = A->nnz;
+    Ap->comm = A->comm; Ap->row_starts = A->row_starts; Ap->col_starts = A->col_starts; Ap->halo_cols = A->halo_cols;
+    Ap->parts.resize(P);
+    int rc = SGM_OK;
+    for (size_t ip = 0; rc == SGM_OK && ip < P; ++ip) rc = permuted_part(A->parts[ip], pc->ro[ip].perm, Ap->parts[ip]);
     pc->reorder_ms[1] = ms_since(t0);
     t0 = std::chrono::steady_clock::now();
     if (rc == SGM_OK) rc = pc_setup_ordered(pc, Ap);
@@ -2747,8 +2763,7 @@ static int pc_setup_ordered(sgm_pc pc, sgm_mat A)
             const int32_t *ford = S->forder ? S->forder : S->L.order;
             for (size_t l = 0; l + 1 < flp.size(); ++l) {
                 const int32_t b = flp[l], e = flp[l + 1];
-                static const bool no_short = getenv("SGM_ILDU_NO_SHORT") != nullptr;          // (tuning aid)
-                if (S->maxL <= 4 && S->maxU <= 4 && !no_short) {
+                if (S->maxL <= 4 && S->maxU <= 4) {
                     hipLaunchKernelGGL((k_ildu_factor_level_short<4, 4>), dim3((e - b + 63) / 64), dim3(64), 0, st,
                                        ford, b, e, (const int32_t *)S->dLptr, (const int32_t *)S->dLnode, S->dLval,
                                        (const int32_t *)S->dUptr, (const int32_t *)S->dUnode, S->dUval, S->D);
@@ -2927,10 +2942,17 @@ int sgm_pc_apply(sgm_pc pc, const double *r, double *z, int where)
     Staged sr, sz;
     SGM_TRY(stage_in(sr, r, pc->n, where, true));
     SGM_TRY(stage_in(sz, z, pc->n, where, false));
-    // a throw-away matrix view with the right part count for pc_apply_parts
+    // a throw-away matrix view with the right part count for pc_apply_parts (block-Jacobi ILDU on an in-process partition:
+    // the caller's vectors are global, part k's slice starts where the rows of the parts before it end)
+    const size_t NP = pc->kind == SGM_PC_ILDU0 ? std::max<size_t>(pc->ild.size(), 1) : 1;
     sgm_mat_s view;
-    view.parts.resize(1);
-    view.parts[0].n = pc->n;
+    view.parts.resize(NP);
+    if (NP == 1) view.parts[0].n = pc->n;
+    else {
+        int64_t tot = 0;
+        for (size_t ip = 0; ip < NP; ++ip) { view.parts[ip].n = pc->ild[ip].n; tot += pc->ild[ip].n; }
+        if (tot != pc->n) return fail(SGM_ERR_UNSUPPORTED, "sgm_pc_apply: stand-alone apply of a preconditioner set up on a matrix distributed over ranks");
+    }
     // in-place apply (r == z on the device) through a pipelined sweep: a sweep that gives up has scattered its "not yet
     // written" patterns over z = r by the time anyone notices, so the redo below needs a right-hand side of its own
     Staged rkeep;
@@ -2939,8 +2961,11 @@ int sgm_pc_apply(sgm_pc pc, const double *r, double *z, int where)
         rkeep.owned = true;
         SGM_HIP(hipMemcpyAsync(rkeep.dev, sr.dev, (size_t)pc->n * sizeof(double), hipMemcpyDeviceToDevice, g_rt.stream));
     }
-    const double *rs[1] = {rkeep.dev ? rkeep.dev : sr.dev};
-    double *zs[1] = {sz.dev};
+    std::vector<const double *> rsv(NP);
+    std::vector<double *> zsv(NP);
+    { int64_t off = 0; for (size_t ip = 0; ip < NP; ++ip) { rsv[ip] = (rkeep.dev ? rkeep.dev : sr.dev) + off; zsv[ip] = sz.dev + off; off += view.parts[ip].n; } }
+    const double *const *rs = rsv.data();
+    double *const *zs = zsv.data();
     SGM_TRY(pc_apply_parts(pc, &view, rs, zs, nullptr));
     if (int32_t *ab = pc_abort_word(pc)) {
         // a pipelined sweep may give up (bounded waits): look before the result leaves -- one 4-byte copy and a
@@ -3010,14 +3035,14 @@ int sgm_pc_get(sgm_pc pc, const char *name, void *out, size_t bytes, size_t *nee
         }
         else if (nm == "perm") {                 // option ildu_reorder: p (1-based; row i of A = row p(i) of the factorised matrix); empty = natural order
             static std::vector<int32_t> hp;
-            hp.assign((size_t)(pc->perm ? pc->n : 0), 0);
-            if (pc->perm && pc->n) { SGM_HIP(hipStreamSynchronize(g_rt.stream)); SGM_HIP(hipMemcpy(hp.data(), pc->perm, hp.size() * 4, hipMemcpyDeviceToHost)); }
+            hp.assign((size_t)(!pc->ro.empty() ? pc->n : 0), 0);
+            if (!pc->ro.empty() && pc->n) { SGM_HIP(hipStreamSynchronize(g_rt.stream)); SGM_HIP(hipMemcpy(hp.data(), pc->ro[0].perm, hp.size() * 4, hipMemcpyDeviceToHost)); }
             src = hp.data(); sz = hp.size() * 4;
             if (!sz) src = &kEmpty;
         }
         else if (nm == "reorder_ms") {           // last setup with ildu_reorder: {ordering, permuted copy, setup on the copy, colours}
             static double rm[4];
-            rm[0] = pc->reorder_ms[0]; rm[1] = pc->reorder_ms[1]; rm[2] = pc->reorder_ms[2]; rm[3] = pc->perm ? pc->perm_colors : 0;
+            rm[0] = pc->reorder_ms[0]; rm[1] = pc->reorder_ms[1]; rm[2] = pc->reorder_ms[2]; rm[3] = !pc->ro.empty() ? pc->ro[0].colors : 0;
             src = rm; sz = sizeof rm;
         }
         else if (nm == "pipeline_retired") {     // how often a pipelined sweep gave up and the pipelines were retired (0 = never)
@@ -3060,7 +3085,7 @@ int sgm_pc_destroy(sgm_pc pc)
     for (auto &pp : pc->parts) dfree(pp.idiag);
     for (auto &S : pc->ild) free_ildu(S);
     dfree(pc->abort_sticky);
-    dfree(pc->perm); dfree(pc->rp); dfree(pc->zp);
+    free_reorder(pc);
     if (pc->Ap) sgm_mat_destroy(pc->Ap);
     delete pc;
     return SGM_OK;

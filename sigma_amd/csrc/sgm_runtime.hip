@@ -96,7 +96,7 @@ int *mat_option_field(MatOptions &o, const char *name)
 int *solver_option_field(SolverOptions &o, const char *name)
 {
     SGM_OPT(solver, cg_small) SGM_OPT(solver, bicgstab_small) SGM_OPT(solver, krylov_graph) SGM_OPT(solver, dot_order)
-    SGM_OPT(solver, gmres_cgs2)
+    SGM_OPT(solver, gmres_cgs2) SGM_OPT(solver, dist_halo_fused)
     return nullptr;
 }
 int *pc_option_field(PcOptions &o, const char *name)
@@ -117,6 +117,7 @@ int normalise_option(const char *name, int value, int *out)
     else if (!strcmp(name, "slice_sched")) v = value <= 0 ? 0 : value == 1 ? 1 : std::max(4, value);
     else if (!strcmp(name, "krylov_graph")) v = value <= 0 ? 0 : value == 1 ? 1 : std::max(16, (value + 15) / 16 * 16);
     else if (!strcmp(name, "cg_small")) v = std::max(0, value);
+    else if (!strcmp(name, "dist_halo_fused")) v = value < 0 ? 0 : value > 2 ? 2 : value;
     else if (!strcmp(name, "pipeline_spin_limit")) v = std::max(0, value);
     else if (!strcmp(name, "dot_order") && value != 0 && value != 1)
         return fail(SGM_ERR_BAD_ARG, "option dot_order is 0 (tree) or 1 (the reference's sequential order)");
@@ -154,15 +155,6 @@ int sgm_init(int device)
     g_rt.stream = g_rt.own_stream;
     g_rt.device = device;
     g_rt.ready = true;
-    if (const char *e = getenv("SGM_CSR_SLICED")) g_opt.mat.csr_sliced = atoi(e);      // tuning aid (see sgm_set_option)
-    if (const char *e = getenv("SGM_GMRES_CGS2")) g_opt.solver.gmres_cgs2 = atoi(e);
-    if (const char *e = getenv("SGM_DOT_ORDER")) g_opt.solver.dot_order = atoi(e) == 1 ? 1 : 0;
-    if (const char *e = getenv("SGM_ILDU_STRIPS")) g_opt.pc.ildu_strips = atoi(e);
-    if (const char *e = getenv("SGM_SLICE_SCHED")) {          // "<on>,<band>" (tuning aid)
-        int on = 0, band = 64;
-        sscanf(e, "%d,%d", &on, &band);
-        g_opt.mat.slice_sched = on ? (band == 64 ? 1 : std::max(4, band)) : 0;
-    }
     return SGM_OK;
 }
 

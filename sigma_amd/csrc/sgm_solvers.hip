@@ -42,9 +42,9 @@ int32_t *pc_abort_word(sgm_pc pc);        // sgm_pc.hip: sticky abort word of a 
 int pc_retire_pipelines(sgm_pc pc);
 sgm_mat pc_permuted_matrix(sgm_pc pc, sgm_mat A);    // ILDU of the colour-ordered A: P A P^T (the solve runs in its order); null otherwise
 void pc_in_permuted(sgm_pc pc, bool on);
-void pc_permute_vec(sgm_pc pc, const double *src, double *dst, bool to_permuted);
-int32_t pc_cg_fused_rows(sgm_pc pc);
-bool pc_cg_fused(sgm_pc pc, ScalarRef res2, ScalarRef dpr, const double *q, double *r, double *z, double *part, int *count, const int *flag, int gen);
+void pc_permute_vec(sgm_pc pc, size_t part, const double *src, double *dst, bool to_permuted);
+int32_t pc_cg_fused_rows(sgm_pc pc, size_t part);
+bool pc_cg_fused(sgm_pc pc, size_t ip, ScalarRef res2, ScalarRef dpr, const double *q, double *r, double *z, double *part, int *count, const int *flag, int gen);
 
 // ------------------------------------------------------------------ generic fused kernel
 // F provides: bool prepare(double* red) (block-uniform; false = nothing to do),
@@ -224,6 +224,10 @@ struct FCgPX {
     static constexpr bool kDot = false;
     ScalarRef res2, dpr, dnew; const double *z; double *p, *x;
     double tol; int *flag; int stop_value; int64_t *iters; double *history; int64_t hist_cap; double *res_out;
+    // nx: elements that have an x (the owned rows).  The launch may run past them over the HALO slots of z and p
+    // (run_cg, option dist_halo_fused): there only p = z + beta*p is formed -- the owner's statement on the owner's operands,
+    // so the neighbour's copy of p's boundary rows has the owner's bits without travelling.
+    int64_t nx = INT64_MAX;
     double alpha = 0.0, beta = 0.0, dnew_v = 0.0;
     __device__ bool prepare(double *red)
     {
@@ -249,6 +253,7 @@ struct FCgPX {
     }
     template <bool NT> __device__ void pair(int64_t i)
     {
+        if (2 * i + 1 >= nx) { single(2 * i); single(2 * i + 1); return; }
         const double2 zz = ld2<NT>(z, i); double2 pp = ld2<NT>(p, i), xx = ld2<NT>(x, i);
         xx.x = xx.x + alpha * pp.x; xx.y = xx.y + alpha * pp.y;
         pp.x = zz.x + beta * pp.x; pp.y = zz.y + beta * pp.y;
@@ -257,7 +262,7 @@ struct FCgPX {
     __device__ void single(int64_t i)
     {
         const double pv = p[i];
-        x[i] = x[i] + alpha * pv;
+        if (i < nx) x[i] = x[i] + alpha * pv;
         p[i] = z[i] + beta * pv;
     }
     __device__ void finish(double *) {}
@@ -964,7 +969,7 @@ struct sgm_solver_s {
     bool reduce_single = false;       // one part: collapse every dot to its slot with a one-block kernel (see finish_dots)
     // cooperative CG (k_cg_coop): exchange vector + dot slots + {counter, abort}; the counter is monotonic across launches
     double *coop_buf = nullptr;
-    int coop_base = 0, coop_reach = -1;
+    int coop_base = 0;
     int64_t coop_iters0 = 0;
     bool coop_retired = false, coop_xl_retired = false;
     double *perm_x = nullptr, *perm_b = nullptr;       // x and b in the order of a reordering preconditioner's matrix (sgm_solver_solve)
@@ -991,7 +996,6 @@ void free_work(sgm_solver s)
     s->coop_buf = nullptr;
     dfree(s->perm_x); dfree(s->perm_b);
     s->perm_x = s->perm_b = nullptr;
-    s->coop_reach = -1;
 }
 
 // ScalarRef of partial array k on part ip
@@ -1008,9 +1012,12 @@ double *part(sgm_solver s, size_t ip, int k) { return s->work[ip].partials + (si
 // ignored and the products are formed again, in order (k_dot_seq).  Across in-process parts the running sum is handed
 // from one part's kernel to the next one's; across ranks it travels rank 0 -> 1 -> ... (seq_chain_recv / _share), so a
 // partitioned solve adds the same products in the same global order as the one-part solve.
+// `halo_of` (one extended vector per part, multi-part solves only): its boundary rows travel to the neighbours' halo slots in
+// the same step as the sums (halo_exchange_allreduce)
 int finish_dots(sgm_solver s, sgm_mat A, const int *ks, int nk, const int (*vecs)[2] = nullptr, bool use_flag = false,
-                int gen = INT32_MAX)
+                int gen = INT32_MAX, double *const *halo_of = nullptr)
 {
+    if (halo_of && s->seq) SGM_TRY(halo_exchange(A, halo_of, g_rt.stream));
     if (s->seq) {
         if (!vecs) return fail(SGM_ERR_UNSUPPORTED, "dot_order = 1: this dot product has no sequential form");
         const size_t P = s->work.size();
@@ -1073,6 +1080,7 @@ int finish_dots(sgm_solver s, sgm_mat A, const int *ks, int nk, const int (*vecs
     prof_end(PH_DOT_REDUCE, g_rt.stream);
     std::vector<double *> ptrs(s->work.size());
     for (size_t ip = 0; ip < s->work.size(); ++ip) ptrs[ip] = s->work[ip].slots + ks[0];
+    if (halo_of) return halo_exchange_allreduce(A, halo_of, ptrs.data(), ks[nk - 1] - ks[0] + 1, s->opt.dist_halo_fused == 1);
     return allreduce_slots(A, ptrs.data(), ks[nk - 1] - ks[0] + 1);
 }
 
@@ -1853,7 +1861,7 @@ __global__ __launch_bounds__(1024) void k_cg_coop(
         res2 = dnew;
         conv = !(sqrt(res2) > tol);
     }
-    if (!ok) return;                                        // (nothing of x, r, p has been written: the host takes the launch loop)
+    if (!ok) return;                                        // (the host puts the caller's x back and takes the launch loop)
 #pragma unroll
     for (int u = 0; u < RMAX; ++u) {
         const int32_t i = r0 + tid + u * BLOCK;
@@ -1890,14 +1898,9 @@ static bool coop_applies(sgm_solver s, sgm_mat A, sgm_pc pc, int *rmax_out, int 
     if (p.n_halo != 0 || !cg_small_sliced(p) || p.n < 2048 || ndict < 1 || ndict > 15) return false;        // (k_cg_small had its turn already)
     const int pk = pc ? pc_kind(pc) : 0;
     if (pk != 0 && pk != SGM_PC_JACOBI) return false;
-    if (s->coop_reach < 0) {                                   // the stencil's reach in rows: the largest |offset| of the dictionary
-        int32_t hd[16] = {0};
-        if (hipMemcpy(hd, p.dict, sizeof hd, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return false; }
-        int32_t reach = 0;
-        for (int k = 0; k < ndict; ++k) reach = std::max(reach, std::abs(hd[k]));
-        s->coop_reach = reach;
-    }
-    const int H = (s->coop_reach + 1) & ~1;
+    // the stencil's reach in rows (the largest |offset| of THIS matrix's dictionary, kept on the part where the dictionary is
+    // built -- never cached on the solver: one handle may serve matrices of the same size and different stencils)
+    const int H = (p.dict_reach + 1) & ~1;
     static const int force_rmax = getenv("SGM_CG_COOP_RMAX") ? atoi(getenv("SGM_CG_COOP_RMAX")) : 0;
     // XCD-local variant: the whole system on the <= 32 CUs of one XCD, 1, 2 or 3 rows per thread with the matrix in registers
     // (4 rows per thread stream the matrix through one XCD's L2 / fabric port: 8.6-9.8 us per iteration at n = 1e5 .. 1.3e5
@@ -1961,6 +1964,11 @@ static int run_cg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_
     double *gz = s->coop_buf, *slots = gz + p.n;
     int *abortw = reinterpret_cast<int *>(slots + (size_t)kCoopSlotDoubles);
     int flag = 0; int64_t iters = 0; double res = 0.0;
+    // the caller's x, kept until the first launch has ended: a hand-off that gives up at the LAST join of a launch can leave
+    // workgroups that passed it storing their rows of x while the others leave theirs -- an aborted first launch hands the
+    // launch loop the caller's x again, not that mixture
+    if (!s->x_backup) SGM_TRY(dalloc(&s->x_backup, (size_t)p.n + 2));
+    SGM_HIP(hipMemcpyAsync(s->x_backup, x, (size_t)p.n * 8, hipMemcpyDeviceToDevice, g_rt.stream));
     for (int resume = 0;; resume = 1) {
         int64_t it_end = iters + s->small_chunk();
         if (s->max_iter > 0) it_end = std::min<int64_t>(it_end, s->max_iter);
@@ -2021,9 +2029,10 @@ static int run_cg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_
         SGM_HIP(hipMemcpyAsync(&habort, abortw, sizeof(int), hipMemcpyDeviceToHost, g_rt.stream));
         SGM_TRY(read_state(s, &flag, &iters, &res));
         if (habort) {
-            // a hand-off gave up (the grid was not co-resident, or the GPU is shared): x, r, p are untouched by this launch --
-            // but a resumed solve has moved x already: restart is only exact from the caller's x, which launch 1 left alone
+            // a hand-off gave up (the grid was not co-resident, or the GPU is shared).  A resumed solve has moved x already:
+            // restart is only exact from the caller's x, which is put back after a first launch
             SGM_TRY(arm());
+            if (!resume) SGM_HIP(hipMemcpyAsync(x, s->x_backup, (size_t)p.n * 8, hipMemcpyDeviceToDevice, g_rt.stream));
             if (xl) {
                 // (the participants were not dealt to one XCD, or one of them never started: the all-CU variant has its turn)
                 s->coop_xl_retired = true;
@@ -2116,7 +2125,20 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
         }
     }
     const int vz[1][2] = {{V_R, pk == 0 ? V_R : V_Z}}, vpq[1][2] = {{V_P, V_Q}};     // operands of r.r / r.z and p.q
-    { const int ks[1] = {C_RR0}; SGM_TRY(finish_dots(s, A, ks, 1, vz)); }
+    // Row partitions (option dist_halo_fused): p's halo is FORMED where it is used.  The boundary rows of u (r, or z with a
+    // preconditioner) travel beside the all-reduce of r.u -- one communication step between "r -= alpha q" and the p update
+    // (cg_solvers.f90:138-142) instead of an all-reduce there and an exchange of p in front of the next product -- and the p
+    // update runs over the halo slots too: p_halo = u_halo + beta * p_halo, the owner's statement on the owner's operands,
+    // hence the owner's bits.  The product then starts with a complete p: no exchange, no wait for one.
+    bool fuse = s->multi && s->opt.dist_halo_fused && A->fmt != SGM_FMT_COMPOSITE;
+    for (size_t ip = 0; fuse && ip < P; ++ip) fuse = A->parts[ip].ncol_own == A->parts[ip].n;
+    std::vector<double *> uext(P);
+    for (size_t ip = 0; ip < P; ++ip) uext[ip] = W(ip, pk == 0 ? V_R : V_Z);
+    { const int ks[1] = {C_RR0}; SGM_TRY(finish_dots(s, A, ks, 1, vz, false, INT32_MAX, fuse ? uext.data() : nullptr)); }
+    if (fuse)
+        for (size_t ip = 0; ip < P; ++ip)          // p = u on the halo slots as on the owned rows (cg_solvers.f90:130 / :172)
+            if (const int32_t nh = A->parts[ip].n_halo)
+                SGM_HIP(hipMemcpyAsync(W(ip, V_P) + s->work[ip].n, uext[ip] + s->work[ip].n, (size_t)nh * 8, hipMemcpyDeviceToDevice, g_rt.stream));
     for (size_t ip = 0; ip < P; ++ip)
         hipLaunchKernelGGL(k_check, dim3(1), dim3(kBlock), 0, g_rt.stream, ref(s, ip, C_RR0), s->tolerance,
                            s->work[ip].flag, s->work[ip].res);
@@ -2135,10 +2157,13 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
         dots.w = v.w.data(); dots.part_wy = v.p0.data();
         // all parts share one flag value; spmv takes part 0's flag for every launch on
         // this device (identical contents)
-        SGM_TRY(spmv_parts(A, v.cx.data(), v.y.data(), false, &dots, s->work[0].flag, &grid, gen));
+        SGM_TRY(spmv_parts(A, v.cx.data(), v.y.data(), false, &dots, s->work[0].flag, &grid, gen, false, /*halo_ready=*/fuse));
         for (size_t ip = 0; ip < P; ++ip) s->work[ip].count[C_PQ] = spmv_grid(A->parts[ip]);
         { const int ks[1] = {C_PQ}; SGM_TRY(finish_dots(s, A, ks, 1, vpq, true, gen)); }
         bool fused_pc = false;
+        // two-level factors on EVERY part (colour orderings): the r update, both sweeps and the partial sums of r.z in the sweeps' launches
+        bool all_fused = pk == SGM_PC_ILDU0 && !s->seq;
+        for (size_t ip = 0; all_fused && ip < P; ++ip) all_fused = pc_cg_fused_rows(pc, ip) > 0;
         for (size_t ip = 0; ip < P; ++ip) {
             PartWork &w = s->work[ip];
             w.count[nxt] = dot_grid(w.n);
@@ -2148,11 +2173,11 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
             else if (pk == SGM_PC_JACOBI)
                 launch_elem(w.n, FCgR<1>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_Q), W(ip, V_R), pc_idiag(pc, ip),
                                          W(ip, V_Z), part(s, ip, nxt)}, w.flag, gen);
-            else if (const int32_t n0 = (P == 1 && !s->seq) ? pc_cg_fused_rows(pc) : 0) {
+            else if (const int32_t n0 = all_fused ? pc_cg_fused_rows(pc, ip) : 0) {
                 // two-level factors: r -= alpha q on the rows without L entries, then that update for the other rows, both sweeps
                 // and the partial sums of r.z in the sweeps' two launches
                 launch_elem((int64_t)n0, FCgR<2>{ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_Q), W(ip, V_R), nullptr, nullptr, nullptr}, w.flag, gen);
-                fused_pc = pc_cg_fused(pc, ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_Q), W(ip, V_R), W(ip, V_Z), part(s, ip, nxt), &w.count[nxt],
+                fused_pc = pc_cg_fused(pc, ip, ref(s, ip, cur), ref(s, ip, C_PQ), W(ip, V_Q), W(ip, V_R), W(ip, V_Z), part(s, ip, nxt), &w.count[nxt],
                                        w.flag, gen);
                 if (!fused_pc) return fail(SGM_ERR_HIP, "run_cg: the fused sweeps withdrew after their first step");
             }
@@ -2169,12 +2194,13 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
                 launch_elem(w.n, FDot2{W(ip, V_R), W(ip, V_Z), nullptr, nullptr, part(s, ip, nxt), nullptr}, w.flag, gen);
             }
         }
-        { const int ks[1] = {nxt}; SGM_TRY(finish_dots(s, A, ks, 1, vz, true, gen)); }
+        { const int ks[1] = {nxt}; SGM_TRY(finish_dots(s, A, ks, 1, vz, true, gen, fuse ? uext.data() : nullptr)); }
         for (size_t ip = 0; ip < P; ++ip) {
             PartWork &w = s->work[ip];
-            launch_elem(w.n, FCgPX{ref(s, ip, cur), ref(s, ip, C_PQ), ref(s, ip, nxt), pk == 0 ? W(ip, V_R) : W(ip, V_Z),
-                                   W(ip, V_P), x[ip], s->tolerance, w.flag, gen + 1, w.iters,
-                                   ip == 0 ? w.history : nullptr, s->hist_cap, w.res}, w.flag, gen);
+            launch_elem(w.n + (fuse ? A->parts[ip].n_halo : 0),
+                        FCgPX{ref(s, ip, cur), ref(s, ip, C_PQ), ref(s, ip, nxt), pk == 0 ? W(ip, V_R) : W(ip, V_Z),
+                              W(ip, V_P), x[ip], s->tolerance, w.flag, gen + 1, w.iters,
+                              ip == 0 ? w.history : nullptr, s->hist_cap, w.res, fuse ? w.n : INT64_MAX}, w.flag, gen);
         }
         return SGM_OK;
     };
@@ -2658,7 +2684,7 @@ __global__ __launch_bounds__(1024) void k_bicg_coop(
         ++it;
         conv = !(sqrt(res2) > tol);
     }
-    if (!ok) return;                                        // (nothing has been written: the host takes the launch loop)
+    if (!ok) return;                                        // (the host puts the caller's x back and takes the launch loop)
 #pragma unroll
     for (int u = 0; u < RMAX; ++u) {
         const int32_t i = r0w + tid + u * BLOCK;
@@ -2691,6 +2717,8 @@ static int run_bicg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sg
     double *gz = s->coop_buf, *slots = gz + nx;
     int *abortw = reinterpret_cast<int *>(slots + (size_t)kCoopSlotDoubles);
     int flag = 0; int64_t iters = 0; double res = 0.0;
+    if (!s->x_backup) SGM_TRY(dalloc(&s->x_backup, (size_t)p.n + 2));            // (as in run_cg_coop: the caller's x, for an aborted first launch)
+    SGM_HIP(hipMemcpyAsync(s->x_backup, x, (size_t)p.n * 8, hipMemcpyDeviceToDevice, g_rt.stream));
     for (int resume = 0;; resume = 1) {
         int64_t it_end = iters + s->small_chunk();
         if (s->max_iter > 0) it_end = std::min<int64_t>(it_end, s->max_iter);
@@ -2722,6 +2750,7 @@ static int run_bicg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sg
         SGM_TRY(read_state(s, &flag, &iters, &res));
         if (habort) {
             SGM_TRY(coop_arm(s, nx));
+            if (!resume) SGM_HIP(hipMemcpyAsync(x, s->x_backup, (size_t)p.n * 8, hipMemcpyDeviceToDevice, g_rt.stream));
             if (xl) s->coop_xl_retired = true;
             else {
                 fprintf(stderr, "[sigma_hip] cooperative BiCGStab gave up waiting for a workgroup (grid not co-resident / shared GPU?): "
@@ -3230,12 +3259,15 @@ int sgm_solver_solve(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc
     sgm_mat Arun = A;
     struct PermScope { sgm_pc pc = nullptr; ~PermScope() { if (pc) pc_in_permuted(pc, false); } } perm_scope;
     static const bool perm_off = getenv("SGM_SOLVE_PERMUTED") && atoi(getenv("SGM_SOLVE_PERMUTED")) == 0;      // tuning aid / tests
-    if (sgm_mat Ap = perm_off ? nullptr : pc_permuted_matrix(pc, A); Ap && P == 1 && !A->comm && Ap->nrow == A->nrow) {
+    if (sgm_mat Ap = perm_off ? nullptr : pc_permuted_matrix(pc, A); Ap && Ap->parts.size() == P && Ap->nrow == A->nrow) {
         if (!s->perm_x) SGM_TRY(dalloc(&s->perm_x, (size_t)nvec + 2));
         if (!s->perm_b) SGM_TRY(dalloc(&s->perm_b, (size_t)nvec + 2));
-        pc_permute_vec(pc, sx.dev, s->perm_x, true);
-        pc_permute_vec(pc, sb.dev, s->perm_b, true);
-        xs[0] = s->perm_x; bs[0] = s->perm_b;
+        for (size_t ip = 0; ip < P; ++ip) {          // every part / rank its own slice, by its own local ordering
+            const int64_t off = xs[ip] - sx.dev;
+            pc_permute_vec(pc, ip, sx.dev + off, s->perm_x + off, true);
+            pc_permute_vec(pc, ip, sb.dev + off, s->perm_b + off, true);
+            xs[ip] = s->perm_x + off; bs[ip] = s->perm_b + off;
+        }
         Arun = Ap;
         perm_scope.pc = pc;
         pc_in_permuted(pc, true);
@@ -3251,7 +3283,8 @@ int sgm_solver_solve(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc
         s->abort_dev = nullptr;
         s->aborted = 0;
         SGM_HIP(hipMemcpyAsync(sx.dev, s->x_backup, (size_t)nvec * 8, hipMemcpyDeviceToDevice, g_rt.stream));
-        if (Arun != A) pc_permute_vec(pc, sx.dev, s->perm_x, true);
+        if (Arun != A)
+            for (size_t ip = 0; ip < P; ++ip) { const int64_t off = xs[ip] - s->perm_x; pc_permute_vec(pc, ip, sx.dev + off, s->perm_x + off, true); }
         for (size_t ip = 0; ip < P; ++ip) {
             PartWork &w = s->work[ip];
             SGM_HIP(hipMemsetAsync(w.flag, 0, sizeof(int), g_rt.stream));
@@ -3260,7 +3293,8 @@ int sgm_solver_solve(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc
         }
     }
     s->abort_dev = nullptr;
-    if (Arun != A) pc_permute_vec(pc, s->perm_x, sx.dev, false);
+    if (Arun != A)
+        for (size_t ip = 0; ip < P; ++ip) { const int64_t off = xs[ip] - s->perm_x; pc_permute_vec(pc, ip, s->perm_x + off, sx.dev + off, false); }
     s->iterations += s->last_iterations;
     if (s->hist_cap) {
         const int64_t cnt = std::min<int64_t>(s->last_iterations, s->hist_cap);

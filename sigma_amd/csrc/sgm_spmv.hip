@@ -1140,8 +1140,7 @@ __global__ void k_gather(double *__restrict__ dst, const double *__restrict__ sr
 // ---------------------------------------------------------------------------------
 static int g_launch_flags = 0;        // 256: chained accumulation (see k_csr_* `chain`)
 
-// Launch configuration of the CSR kernel.  SGM_SPMV_CFG="block,vpt,nt,maxgrid,remap"
-// overrides the default (tuning aid; results do not depend on it).
+// Launch configuration of the CSR kernel (block, vpt, nt, maxgrid, remap: fixed; the sweeps that chose them are in CHANGELOG.md)
 struct SpmvCfg { int block = 256, vpt = 2, nt = 1, maxgrid = 0, remap = 1, do_vpt = 0; };   // 0 = automatic
 static SpmvCfg &spmv_cfg()
 {
@@ -1149,8 +1148,6 @@ static SpmvCfg &spmv_cfg()
     static bool init = false;
     if (!init) {
         init = true;
-        if (const char *e = getenv("SGM_SPMV_CFG"))
-            sscanf(e, "%d,%d,%d,%d,%d,%d", &c.block, &c.vpt, &c.nt, &c.maxgrid, &c.remap, &c.do_vpt);
         if (c.maxgrid > kMaxGrid) c.maxgrid = kMaxGrid;
         // only instantiated (block, vpt) pairs: anything else would launch a kernel of another shape
         if (c.block != 256 && c.block != 512 && c.block != 1024) c.block = 256;
@@ -1174,7 +1171,7 @@ int launch_ell_colblock(const Part &p, int grid, const double *x, double *y, boo
                         double *pwy, double *pyy, const int *flag, int gen);
 int64_t ell_colblock_resident_bytes(const Part &p);
 int64_t ell_colblock_matvec_bytes(const Part &p);
-// k_csr_do exists for 256- and 512-thread workgroups only; with any other SGM_SPMV_CFG block size the
+// k_csr_do exists for 256- and 512-thread workgroups only; with any other block size the
 // matrices it would serve take the streaming kernel (which has the 1024-thread variants) instead
 static bool do_block_ok() { const int b = spmv_cfg().block; return b == 256 || b == 512; }
 static bool use_offset_dict(const Part &p) { return (p.code || (p.lean && p.dict)) && p.opt.csr_offset_dict && do_block_ok(); }
@@ -1468,7 +1465,7 @@ static void launch_csr_slb(const Part &p, int grid, const double *x, double *y, 
 #undef L
 }
 
-// SGM_ELL_CFG="U,nt,grid": slots in flight per lane, nontemporal matrix loads, grid cap (tuning aid)
+// slots in flight per lane, nontemporal matrix loads, grid cap
 struct EllCfg { int u = 8, nt = 1, grid = 2048; };
 static EllCfg &ell_cfg()
 {
@@ -1476,7 +1473,6 @@ static EllCfg &ell_cfg()
     static bool init = false;
     if (!init) {
         init = true;
-        if (const char *e = getenv("SGM_ELL_CFG")) sscanf(e, "%d,%d,%d", &c.u, &c.nt, &c.grid);
         if (c.grid > kMaxGrid) c.grid = kMaxGrid;
     }
     return c;
@@ -1715,7 +1711,7 @@ static int composite_spmv(sgm_mat A, const double *x, double *y, bool add, const
                           const int *flag_done, int *grid_out, int gen);
 
 int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
-               const SpmvDots *dots, const int *flag_done, int *grid_out, int gen, bool chain)
+               const SpmvDots *dots, const int *flag_done, int *grid_out, int gen, bool chain, bool halo_ready)
 {
     if (A->fmt == SGM_FMT_COMPOSITE) return composite_spmv(A, x[0], y[0], add, dots, flag_done, grid_out, gen);
     const size_t P = A->parts.size();
@@ -1727,7 +1723,7 @@ int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
             if (p.lean && !(lean_sell(p) ? use_sell(p) : use_sliced(p))) SGM_TRY(csr_need_arrays(p));
     g_launch_flags = chain ? 256 : 0;
     bool exchange = false;
-    if (A->distributed())
+    if (A->distributed() && !halo_ready)
         for (const Part &p : A->parts) exchange = exchange || !p.nbrs.empty();
     if (exchange) {
         // halo exchange on the communication stream, overlapped with the interior rows
@@ -2211,6 +2207,8 @@ static int build_offset_dict(Part &p, const int32_t *, const int32_t *)
     for (int32_t v : htab) if (v != kDictEmpty) dict.push_back(v);
     std::sort(dict.begin(), dict.end());
     p.ndict = (int32_t)dict.size();
+    p.dict_reach = 0;
+    for (int32_t v : dict) p.dict_reach = std::max(p.dict_reach, v < 0 ? -v : v);
     dict.resize(256, 0);
     SGM_TRY(dalloc(&p.code, (size_t)nnz + 32));
     SGM_TRY(dalloc(&p.dict, (size_t)256));
@@ -2237,7 +2235,6 @@ static int build_offset_dict(Part &p, const int32_t *, const int32_t *)
 #define PICK(WW) if (!Wb && p.max_row <= WW) Wb = WW;
     SGM_SLB_WIDTHS(PICK)
 #undef PICK
-    if (const char *e = getenv("SGM_SLB_W")) { const int f = atoi(e); if (f >= p.max_row && f <= 32) Wb = f; }      // tuning aid (an instantiated width)
     const int Wc = (Wb + 7) / 8 * 8;                          // code bytes per row in eights
     if (!sliced && p.opt.csr_sliced && Wb && p.ndict <= 255 && p.max_row > 8 && (double)Wb * n <= 1.35 * (double)nnz) {
         rows_padded = ((size_t)n + kSlRows - 1) / kSlRows * kSlRows;
@@ -2353,6 +2350,8 @@ static int build_ell_offset_dict(Part &p)
     for (int32_t v : htab) if (v != kDictEmpty) dict.push_back(v);
     std::sort(dict.begin(), dict.end());
     const int ndict = (int)dict.size();
+    p.dict_reach = 0;
+    for (int32_t v : dict) p.dict_reach = std::max(p.dict_reach, v < 0 ? -v : v);
     dict.resize(256, 0);
     const int mdp = p.max_d <= 4 ? 4 : p.max_d <= 8 ? 8 : 16;
     const size_t code_bytes = (size_t)p.n * mdp + 16;
@@ -2499,14 +2498,14 @@ int rebuild_csr_formats(Part &p)
     dfree(p.code); dfree(p.dict); dfree(p.sval); dfree(p.scode); dfree(p.scol); dfree(p.sbcode);
     p.code = nullptr; p.dict = nullptr; p.sval = nullptr; p.scode = nullptr; p.scol = nullptr; p.sbcode = nullptr;
     free_sell(p);
-    p.ndict = 0; p.sw = 0; p.max_row = 0; p.sched_period = 0;
+    p.ndict = 0; p.dict_reach = 0; p.sw = 0; p.max_row = 0; p.sched_period = 0;
     free_slice_sched(p);
     return build_offset_dict(p, nullptr, nullptr);
 }
 int rebuild_ell_formats(Part &p)
 {
     dfree(p.ecode); dfree(p.dict); dfree(p.sval); dfree(p.scode);
-    p.ecode = nullptr; p.dict = nullptr; p.emdp = 0; p.sval = nullptr; p.scode = nullptr; p.sw = 0; p.sched_period = 0;
+    p.ecode = nullptr; p.dict = nullptr; p.dict_reach = 0; p.emdp = 0; p.sval = nullptr; p.scode = nullptr; p.sw = 0; p.sched_period = 0;
     free_slice_sched(p);
     SGM_TRY(build_ell_offset_dict(p));
     SGM_TRY(build_ell_colblock(p));

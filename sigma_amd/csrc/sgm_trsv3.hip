@@ -441,14 +441,12 @@ void slab_dims(int32_t n, const std::vector<int32_t> &ptr1, const std::vector<in
 
 int choose_hb(int32_t nk, int32_t h, int NI, int R)
 {
-    static const int forced = getenv("SGM_SLAB_HB") ? atoi(getenv("SGM_SLAB_HB")) : 0;
     int best = 0;
     double best_cost = 0;
     for (int hb = 2; hb <= 16; hb *= 2) {
         if (hb + 8 >= R) continue;
         const int nb = (h + hb - 1) / hb;
         const double cost = (double)nk * hb + 63.0 + 64.0 * (NI - 1) + (double)(nb - 1) * (hb + 56.0);     // a hop between workgroups costs ~7 us, a step ~0.11
-        if (forced == hb) return hb;
         if (!best || cost < best_cost) { best = hb; best_cost = cost; }
     }
     return best;
@@ -580,7 +578,7 @@ template <int DEPTH, int HB, int ORDER, bool REG, int TPB>
 void launch_slab(const SlabTri &G, double *xp, const int *flag, int spin, int32_t *sticky)
 {
     constexpr int CH = 8;
-    static const size_t pad = getenv("SGM_SLAB_LDS") ? (size_t)atoi(getenv("SGM_SLAB_LDS")) : (size_t)96 * 1024;
+    constexpr size_t pad = (size_t)96 * 1024;
     // at least 96 KiB per workgroup: ONE workgroup per CU, so that chain waves of two workgroups never share a SIMD
     const size_t lds = std::max(slab_lds(G.NI, 2 * DEPTH, CH), pad);
     static size_t attr = 0;
@@ -597,8 +595,7 @@ void launch_slab(const SlabTri &G, double *xp, const int *flag, int spin, int32_
 template <int HB>
 void launch_slab_o(const SlabTri &G, double *xp, const int *flag, int spin, int32_t *sticky)
 {
-    static const int depth_env = getenv("SGM_SLAB_DEPTH") ? atoi(getenv("SGM_SLAB_DEPTH")) : 32;
-    const bool deep = G.NI <= 2 && G.regular && G.order != 2 && depth_env >= 32;
+    const bool deep = G.NI <= 2 && G.regular && G.order != 2;
     if (G.order == 0) {
         if (deep) launch_slab<32, HB, 0, true, 256>(G, xp, flag, spin, sticky);
         else if (G.regular) launch_slab<16, HB, 0, true, 384>(G, xp, flag, spin, sticky);

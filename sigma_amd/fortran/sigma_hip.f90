@@ -520,6 +520,16 @@ interface
         real(c_double), intent(in) :: val(*)
         integer(c_int) :: rc
     end function
+    function sgm_csr_create_partitioned_parts(A, nparts, row_starts, nnz_of_part, ptr_of_part, node_of_part, val_of_part, where) &
+            & bind(c, name='sgm_csr_create_partitioned_parts') result(rc)
+        import :: c_ptr, c_int, c_int32_t, c_int64_t
+        type(c_ptr), intent(out) :: A
+        integer(c_int32_t), value :: nparts
+        integer(c_int64_t), intent(in) :: row_starts(*), nnz_of_part(*)
+        type(c_ptr), intent(in) :: ptr_of_part(*), node_of_part(*), val_of_part(*)      ! c_loc of every part's arrays
+        integer(c_int), value :: where
+        integer(c_int) :: rc
+    end function
     function sgm_mat_set_option(A, name, value) bind(c, name='sgm_mat_set_option') result(rc)
         import :: c_ptr, c_int, c_char
         type(c_ptr), value :: A

@@ -215,6 +215,29 @@ def run(rank, world, port, case, res):
             Ab = orc.CsrMatrix(n, n, np.concatenate([[1], 1 + np.cumsum(cnt)]).astype(np.int32), node[keep].copy(), val[keep].copy())
             check("cg_ildu_blockjacobi", sg.cg(1e-12), sg.ldu, orc.cg(A, b, tol=1e-12, pc=orc.Ildu(Ab)), lambda i: 1, max(rt, 1e-11))
             check("bicgstab", sg.bicgstab(1e-13), None, orc.bicgstab(A, b, tol=1e-13), lambda i: max(2, 0.1 * i), max(rt, 1e-11))
+            # ---- option dist_halo_fused: p's halo formed locally from the boundary rows of r (z) that travel beside the
+            #      all-reduce of r.r (r.z) -- 1: one group with it, 2: a group of its own -- against 0, p exchanged by every
+            #      product: the same bits, iterate for iterate
+            fused = {}
+            for mode in (0, 1, 2):
+                for nm, pc_mk in (("cg", None), ("cg_jacobi", sg.jacobi), ("cg_ildu", sg.ldu)):
+                    sv = sg.cg(1e-12)
+                    sv.set_option("dist_halo_fused", mode)
+                    sv.set_history(100000)
+                    sv.setup(H)
+                    pcm = pc_mk() if pc_mk else None
+                    if pcm is not None:
+                        pcm.setup(H)
+                    u = np.full(n_own, 0.125)
+                    sv.solve(H, u, bl, pcm)
+                    fused[(nm, mode)] = (u, int(sv.iterations), np.array(sv.history))
+                    sv.destroy()
+                    if pcm is not None:
+                        pcm.destroy()
+            for (nm, mode), (u, it, hist) in fused.items():
+                u0, it0, hist0 = fused[(nm, 0)]
+                assert it == it0 and np.array_equal(u, u0) and np.array_equal(hist, hist0), ("dist_halo_fused", nm, mode, it, it0)
+            out["halo_fused_modes"] = {"iterations": fused[("cg", 1)][1], "bit_identical_to_exchanging_p": True}
         else:
             check("bicgstab_jacobi", sg.bicgstab(1e-12), sg.jacobi, orc.bicgstab(A, b, tol=1e-12, pc=orc.Jacobi(A)),
                   lambda i: max(2, 0.1 * i), 1e-10)

@@ -126,6 +126,7 @@ NOT_FOR_A_FORTRAN_HOST = {
     "sgm_partition_links_host": "same",
     "sgm_mat_halo_nbr": "reads the exchange plan of a built matrix back for the parity tests",
     "sgm_slice_sched_host": "the slice schedule as a host table, so that a CPU test can check it is a permutation",
+    "sgm_comm_group_selftest": "a transport probe (does this RCCL take a group of send / recv + all-reduce?) for the GPU tests",
 }
 
 
@@ -226,14 +227,14 @@ def test_every_documented_option_is_accepted_and_unknown_names_are_refused():
     src = open(os.path.join(ROOT, "sigma_amd", "csrc", "sgm_runtime.hip")).read()
     known = set(re.findall(r"SGM_OPT\((?:mat|solver|pc), ([a-z_0-9]+)\)", src)) | {"dist_force_collectives"}
     assert names == known, (names - known, known - names)
-    assert len(known) <= 21            # 20 per-handle options + the one process-wide switch
+    assert len(known) <= 22            # 21 per-handle options + the one process-wide switch
     # the measured-slower paths of round 3 are gone
     for gone in ("ell_colblock_band", "ell_colblock_pieces", "ell_colblock_nt", "slice_sched_band", "cg_small_chunk",
                  "krylov_graph_after", "ell_colblock_chunks"):
         assert gone not in known and sg.lib().sgm_set_option(gone.encode(), 1) != 0
     lib = sg.lib()
     defaults = {"ell_colblock_cols": 16384, "ell_colblock_rows": 0, "slice_sched": 0, "dot_order": 0, "ildu_reorder": 0,
-                "pipeline_spin_limit": 0, "dist_force_collectives": 0}
+                "pipeline_spin_limit": 0, "dist_force_collectives": 0, "dist_halo_fused": 1}
     for nm in sorted(known):
         assert lib.sgm_set_option(nm.encode(), defaults.get(nm, 1)) == 0, nm          # (set to its default: nothing changes)
     assert lib.sgm_set_option(b"no_such_option", 1) != 0

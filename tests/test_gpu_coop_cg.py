@@ -354,3 +354,34 @@ def test_cooperative_kernels_take_structured_ellpack_matrices(orc):
     assert abs(int(res["cg"][0]) - int(res["cg"][1])) <= 1 and float(res["cg"][2]) <= 1e-9, res
     assert abs(int(res["bicgstab"][0]) - int(res["bicgstab"][1])) <= max(3, int(res["bicgstab"][1]) // 10) and float(res["bicgstab"][2]) <= 1e-7, res
     assert "cg: one cooperative launch" in p.stderr and "bicgstab: one cooperative launch" in p.stderr, p.stderr[-1500:]
+
+
+@pytest.mark.parametrize("kind", ["cg", "bicgstab"])
+def test_one_solver_handle_serves_matrices_of_one_size_and_different_stencils(orc, kind):
+    """The halo window of the cooperative kernels is the reach of the dictionary of the matrix being solved (kept on the
+    matrix part where the dictionary is built), not of the first matrix a solver handle met: a handle set up on a
+    tridiagonal matrix (reach 1) then solves a 100 x 100 grid (reach 100) of the same n -- with and without a second
+    setup, the reference only asks for matching sizes (cg_solvers.f90:52-90) -- and the other way round."""
+    n = 10000
+    mats = {"tridiagonal": P.tridiag_csr(n, 2.5, -1.0, -1.0), "grid 100 x 100": P.poisson2d_csr(100, 100)}
+    if kind == "bicgstab":
+        mats = {k: (p, c, _nonsymmetric(p, c, v)) for k, (p, c, v) in mats.items()}
+    b = np.sin(0.01 * np.arange(1, n + 1)) + 0.5
+    ref = orc.cg if kind == "cg" else orc.bicgstab
+    for order in (("tridiagonal", "grid 100 x 100"), ("grid 100 x 100", "tridiagonal")):
+        for again in (False, True):
+            s = (sg.cg if kind == "cg" else sg.bicgstab)(1e-9)
+            first = True
+            for name in order + order[:1]:
+                ptr, node, val = mats[name]
+                H = sg.csr_matrix(n, n, ptr, node, val)
+                assert H.kernel.startswith("k_csr_sl<"), (name, H.kernel)
+                if first or again:
+                    s.setup(H)
+                first = False
+                u = np.zeros(n)
+                s.solve(H, u, b)
+                ur, itr = ref(orc.CsrMatrix(n, n, ptr, node, val), b, tol=1e-9)[:2]
+                slack = 1 if kind == "cg" else max(3, itr // 10)
+                assert s.converged and abs(s.last_iterations - itr) <= slack, (kind, order, again, name, s.last_iterations, itr)
+                assert np.abs(u - ur).max() <= 1e-8 * np.abs(ur).max(), (kind, order, again, name)

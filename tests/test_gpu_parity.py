@@ -2678,6 +2678,41 @@ def test_partitioned_block_jacobi_ildu(orc, nparts):
             pc.get("D", np.float64)
 
 
+@pytest.mark.parametrize("nparts", [2, 3, 8])
+def test_partitioned_cg_forms_p_halo_locally_bit_identical_to_exchanging_it(orc, nparts):
+    """Option dist_halo_fused (default 1): on a row partition the boundary rows of r (z with a preconditioner) travel beside
+    the all-reduce of r.r (r.z) and every part forms its halo copy of p by the owner's statement p = r + beta p
+    (cg_solvers.f90:142) -- instead of exchanging p in front of every product (0).  Same operands, same statement: iterates,
+    iteration counts and residual histories are the same BITS in all three modes, plain / Jacobi / block-Jacobi ILDU, also
+    with odd part sizes... (in-process parts start on even rows: ranks cover the odd case, tests/dist_worker.py)."""
+    for (ptr, node, val), n in ((P.poisson2d_csr(90, 70), 6300), (P.laplace3d_csr(14, 12, 24), 4032)):
+        starts = (np.arange(nparts + 1) * n // nparts) // 2 * 2
+        starts[-1] = n
+        H = sg.partitioned_csr_matrix(n, n, ptr, node, val, starts)
+        A = orc.CsrMatrix(n, n, ptr, node, val)
+        b = np.sin(0.01 * np.arange(1, n + 1)) + 0.5
+        for pc_mk in (None, sg.jacobi, sg.ldu):
+            got = {}
+            for mode in (0, 1, 2):
+                s = sg.cg(1e-11)
+                s.set_option("dist_halo_fused", mode)
+                s.set_history(10000)
+                s.setup(H)
+                pc = pc_mk() if pc_mk else None
+                if pc:
+                    pc.setup(H)
+                u = np.full(n, 0.125)
+                s.solve(H, u, b, pc)
+                got[mode] = (u, s.iterations, np.array(s.history))
+                assert s.converged
+            for mode in (1, 2):
+                assert got[mode][1] == got[0][1], (pc_mk, mode, got[mode][1], got[0][1])
+                assert np.array_equal(got[mode][0], got[0][0]) and np.array_equal(got[mode][2], got[0][2]), (pc_mk, mode)
+            if pc_mk is not sg.ldu:
+                ur, itr = orc.cg(A, b, x0=np.full(n, 0.125), tol=1e-11, pc=orc.Jacobi(A) if pc_mk else None)[:2]
+                assert abs(got[1][1] - itr) <= 1 and np.abs(got[1][0] - ur).max() <= 1e-10 * np.abs(ur).max()
+
+
 @pytest.mark.parametrize("dict_opt", [1, 0])
 def test_partitioned_overlap_split_bit_exact(orc, dict_opt):
     """Row blocks with halo columns are split into interior rows (run while the halo
@@ -2736,6 +2771,11 @@ def test_rccl_single_rank(orc):
     s.solve(H, u, b)
     assert abs(s.iterations - itr) <= 1 and np.abs(u - ur).max() / np.abs(ur).max() <= 1e-12
     H.destroy()
+    # the REAL librccl takes the group CG posts per iteration on a row partition (option dist_halo_fused = 1): send / recv
+    # pair + all-reduce between one ncclGroupStart / End
+    got, summed, us = comm.group_selftest()
+    assert got == 42.0 and summed == 1.0, (got, summed)
+    print(f"librccl: group of send / recv + all-reduce on one rank: {us:.1f} us")
     comm.destroy()
 
 
