@@ -89,6 +89,9 @@ int sgm_synchronize(void);
  *                          two-phase product (products through LDS-resident x blocks, then ordered row sums); 0 never, 2 always
  *   "ell_colblock_cols" (16384 = 128 KiB of LDS, the maximum)  x entries per block
  *   "ell_colblock_rows" (0 = automatic; 256 or 512)  rows per tile of the second phase
+ *   "coloring_pass" (0)    sgm_graph_greedy_coloring / _greedy_color_order on this matrix's graph: 0 = the fastest pass that
+ *                          applies (parities by union-find on the device, level sweep on the device, the reference's sequential
+ *                          pass on the host), 1 = from the level sweep on, 2 = the host pass; the same colours whichever
  *   "slice_sched" (0)      sliced matrices most of whose rows carry a far offset (the plane stride of a 3-D grid): the slices
  *                          are handed to the XCDs tile by tile -- the plane is cut into bands (1 = of 64 slices, n > 1 = of n
  *                          slices), XCD x sweeps bands x, x + 8, ... plane after plane, so that the three planes a band reads
@@ -109,14 +112,25 @@ int sgm_synchronize(void);
  *   "krylov_graph" (1)     the CG / BiCGStab launch loops on one GPU (plain / Jacobi) go on as replays of ONE captured group
  *                          of 16 iterations (a hipGraph) once a solve has run 64 iterations (n > 1: n, rounded up to a
  *                          multiple of 16); 0 = launch every kernel
- *   "gmres_cgs2" (1)       GMRES orthogonalises with blocked classical Gram-Schmidt applied twice (three passes and three
- *                          all-reduces per step); 0 = modified Gram-Schmidt
+ *   "gmres_cgs2" (1)       how GMRES orthogonalises: 1 = classical Gram-Schmidt applied twice in its low-synchronisation form --
+ *                          the stored basis vector is the ONCE-projected one and the second projection lives in the Cholesky
+ *                          factor R of the stored columns' Gram matrix (V = S R^-1 never formed; H = R Gs R^-1): the basis is
+ *                          read twice per step and two reductions (all-reduces) are taken, 2 k + 3 vector passes at basis
+ *                          size k; 2 = blocked CGS-2 with the second projection applied (three passes, three reductions,
+ *                          3 k + 8); 0 = modified Gram-Schmidt (k + 2 dependent passes), the checker
  *   "dot_order" (0)        how CG / BiCGStab add up their dot products.  0 = tree order (per-workgroup partial sums,
  *                          re-reduced in a fixed order): a legal order for the Fortran intrinsic, deterministic, the fast one.
  *                          1 = the order the reference build uses (amdflang -O2 turns dot_product into ONE accumulator fed
  *                          first element to last, cg_solvers.f90:131,135,140): every iterate, iteration count and residual is
  *                          then BIT-IDENTICAL to the reference's, also on row partitions and across ranks; about 4 ns per
  *                          element -- a VALIDATION mode for n up to ~1e5.  GMRES (no reference counterpart) keeps the tree order
+ *   "coop_spin_limit" (0 = built-in, 2^19 polls)  how often a hand-off of the cooperative CG / BiCGStab kernels polls before
+ *                          it gives up (the launch loop then takes the solve from the caller's x); tests set 1 to force that path
+ *   "cg_coop_variant" (0)  which cooperative kernel serves a system, all the same statements: low four bits = rows per thread
+ *                          pinned (1, 2, 4 or 8; 0 = by size), + 16 = never the variant that keeps a small system on one XCD
+ *   "reorder_solve" (2)    with a preconditioner that factorised the colour-ordered matrix ("ildu_reorder"): 2 = the whole solve
+ *                          runs in that order (x, b permuted once each way, products on P A P^T) and CG folds its r update and
+ *                          r.z into the two sweeps; 1 = that order, separate steps; 0 = r and z permuted around every apply
  *   "dist_halo_fused" (1)  CG on a row partition (ranks or in-process parts): the boundary rows of r (z with a preconditioner)
  *                          travel in the same step as the all-reduce of r.r (r.z) -- over RCCL ONE ncclGroup holding the
  *                          send / recv pairs and the all-reduce -- and every part forms its halo copy of p itself by the owner's
@@ -287,6 +301,16 @@ int sgm_ildu0_create(sgm_pc *out, sgm_mat A);
 int sgm_pc_setup(sgm_pc pc, sgm_mat A);
 int sgm_pc_apply(sgm_pc pc, const double *r, double *z, int where);
 int sgm_pc_get(sgm_pc pc, const char *name, void *out_host, size_t bytes, size_t *needed);
+/* sgm_pc_info: which sweeps serve part `part` (0 on one GPU) of a preconditioner that has been set up, and what an apply
+ * costs -- the reference's `ldu()` (ldu_solvers.f90:73-86) factors A in the order it is given, and on a naturally ordered grid
+ * the triangular solves of ldu_solve (:160-176, row recurrences :227-236, :254-263) are a dependency chain of nx + ny levels:
+ * correct, the reference's semantics, and 50-100 x below the HBM roofline.  This says so BEFORE the solve:
+ *   out4[0], out4[1]  dependency levels of L, of U        out4[2]  path: 0 diagonal scaling, 1 row-space sweeps (bandwidth-
+ *   bound), 2 strip pipeline, 3 slab pipeline, 4 level walkers        out4[3]  colours of the ordering (0 = A's own order)
+ *   est_us  estimated microseconds per apply               path_name  e.g. "strip pipeline, 6323 levels", "row space, 2 levels"
+ * With SGM_TRACE set every sgm_pc_setup prints the same line on stderr.  The remedy for a chain: ldu(reorder = "colour")
+ * (option "ildu_reorder"), INTEGRATION.md. */
+int sgm_pc_info(sgm_pc pc, int32_t part, int32_t *out4, double *est_us, char *path_name, int len);
 int sgm_pc_destroy(sgm_pc pc);
 
 /* ---- solvers ------------------------------------------------------------------------ *

@@ -306,6 +306,16 @@ interface   ! include/sigma_hip.h
         integer(c_int), value :: value
         integer(c_int) :: rc
     end function
+    function sgm_pc_info(pc, part, out4, est_us, path_name, len) bind(c, name='sgm_pc_info') result(rc)
+        import :: c_ptr, c_int, c_int32_t, c_double, c_char
+        type(c_ptr), value :: pc
+        integer(c_int32_t), value :: part
+        integer(c_int32_t), intent(out) :: out4(4)
+        real(c_double), intent(out) :: est_us
+        character(kind=c_char), intent(out) :: path_name(*)
+        integer(c_int), value :: len
+        integer(c_int) :: rc
+    end function
     function sgm_pc_set_option(pc, name, value) bind(c, name='sgm_pc_set_option') result(rc)
         import :: c_ptr, c_int, c_char
         type(c_ptr), value :: pc
@@ -1262,6 +1272,7 @@ type, extends(linear_solver) :: hip_preconditioner                         !
 contains
     procedure :: setup => hip_pc_setup
     procedure :: set_option => hip_pc_set_option
+    procedure :: info => hip_pc_info
     procedure :: linear_solve => hip_pc_solve
     procedure :: destroy => hip_pc_destroy
 end type hip_preconditioner
@@ -1522,6 +1533,32 @@ subroutine hip_pc_set_option(solver, name, value)
     call pc_handle(solver)
     call hip_check(sgm_pc_set_option(solver%handle, trim(name) // c_null_char, value), 'sgm_pc_set_option')
 end subroutine hip_pc_set_option
+
+
+subroutine hip_pc_info(solver, levels, path, colours, est_us, name, part)
+    ! after setup: which sweeps serve the applies and what one costs (sgm_pc_info) -- ldu() of a naturally ordered grid
+    ! (solver_test_incomplete_cholesky.f90:137-141) answers "strip pipeline, <nx + ny - 1> levels": a dependency chain;
+    ! with solver%set_option("ildu_reorder", 1) before setup it answers "row space, 2 levels"
+    class(hip_preconditioner), intent(inout) :: solver
+    integer, intent(out) :: levels(2), path, colours
+    real(dp), intent(out) :: est_us
+    character(len=*), intent(out) :: name
+    integer, intent(in), optional :: part
+    integer(c_int32_t) :: o(4)
+    real(c_double) :: us
+    character(kind=c_char) :: buf(160)
+    integer :: k, ip
+    ip = 0
+    if (present(part)) ip = part
+    call pc_handle(solver)
+    call hip_check(sgm_pc_info(solver%handle, int(ip, c_int32_t), o, us, buf, 160_c_int), 'sgm_pc_info')
+    levels = int(o(1:2)); path = int(o(3)); colours = int(o(4)); est_us = real(us, dp)
+    name = ' '
+    do k = 1, min(len(name), 160)
+        if (buf(k) == c_null_char) exit
+        name(k:k) = buf(k)
+    enddo
+end subroutine hip_pc_info
 
 
 !--------------------------------------------------------------------------!

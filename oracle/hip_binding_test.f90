@@ -461,6 +461,17 @@ subroutine test_incomplete_cholesky_flow()                                 !
     deallocate(pcs)
     pcs => hip_ldu(reorder = "colour")
     call pcs%setup(M)
+    block      ! which sweeps will serve the applies (sgm_pc_info): the colour-ordered factors have one level per colour
+        integer :: lv(2), path, ncol
+        real(dp) :: est
+        character(len=80) :: what
+        select type (pcs)
+        class is (hip_preconditioner)
+            call pcs%info(lv, path, ncol, est, what)
+            print *, 'incomplete cholesky flow: hip_ldu(reorder = colour) is served by: ', trim(what), ',', ncol, 'colours'
+            if (ncol < 2 .or. lv(1) /= ncol .or. lv(2) /= ncol) call fail('sgm_pc_info: levels differ from the colours of the ordering', real(lv(1), dp))
+        end select
+    end block
     x = 0.0_dp
     call ks%solve(M, x, rhs, pcs)
     err = maxval(dabs(x - w))

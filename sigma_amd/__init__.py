@@ -572,6 +572,16 @@ class _Preconditioner:
         self.nn = getattr(A, "n_local", A.nrow)
         self.initialized = True
 
+    def info(self, part=0):
+        """sgm_pc_info: {"levels": (L, U), "path": 0..4, "colours": n, "est_us": per apply, "name": e.g. "strip pipeline,
+        6323 levels"} -- whether an apply will be a dependency chain (natural-order ILDU of a grid) or a few bandwidth-bound
+        sweeps (ldu(reorder="colour"))."""
+        o = (C.c_int32 * 4)()
+        us = C.c_double()
+        nm = C.create_string_buffer(160)
+        _ck(lib().sgm_pc_info(self._h, C.c_int32(part), o, C.byref(us), nm, C.c_int(160)))
+        return {"levels": (int(o[0]), int(o[1])), "path": int(o[2]), "colours": int(o[3]), "est_us": float(us.value), "name": nm.value.decode()}
+
     def set_option(self, name, value):
         """sgm_pc_set_option: this preconditioner's own "ildu_strips" / "ildu_rows" / "pipeline_spin_limit"."""
         self._opts[name] = int(value)

@@ -1097,7 +1097,9 @@ static int ensure_transpose_dist(sgm_mat A)
 
 int matvec_t_dist(sgm_mat A, const double *x, double *y, int where, bool add)
 {
-    if (A->fmt != SGM_FMT_CSR) return fail(SGM_ERR_UNSUPPORTED, "matvec_t: CSR matrices only when distributed");
+    // (an ELLPACK matrix distributed over ranks IS CSR rows of fixed length here -- sgm_ell_create_dist stores the padding slots
+    //  as entries --, so ellpack_matvec_t_add's scatter over all max_d slots, ellpack_matrices.f90:670-693, is this same path)
+    if (A->fmt != SGM_FMT_CSR) return fail(SGM_ERR_UNSUPPORTED, "matvec_t: a distributed matrix holds CSR rows (sgm_csr_create_dist / sgm_ell_create_dist)");
     SGM_TRY(ensure_transpose_dist(A));
     sgm_mat T = A->T;
     Part &pt = T->parts[0];

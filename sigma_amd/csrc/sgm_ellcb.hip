@@ -36,16 +36,32 @@ namespace sgm {
 typedef double f64x2c __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------ setup kernels
+// Where the entries come from: an ELLPACK matrix (every one of the max_d slots of a row is an entry: a padding slot keeps its
+// 0 * x(last neighbour) term, like ellpack_matvec_add) or a CSR matrix with scattered columns and rows of <= 128 entries (slot k
+// of row i = its k-th stored entry; slots beyond the row's length do not exist: they take no part in either phase, so the row
+// sum is csr_matvec_add's, cs_matrices.f90:611-620, term for term).
+struct EllSrc {
+    const int32_t *ecol; const double *eval; int32_t n, max_d;
+    __device__ bool has(int32_t, int32_t) const { return true; }
+    __device__ int32_t col(int32_t i, int32_t k) const { return ecol[(int64_t)k * n + i]; }
+    __device__ double val(int32_t i, int32_t k) const { return eval[(int64_t)k * n + i]; }
+};
+struct CsrSrc {
+    const int32_t *rowptr, *ccol; const double *cval; int32_t n, max_d;
+    __device__ bool has(int32_t i, int32_t k) const { return k < rowptr[i + 1] - rowptr[i]; }
+    __device__ int32_t col(int32_t i, int32_t k) const { return ccol[rowptr[i] + k]; }
+    __device__ double val(int32_t i, int32_t k) const { return cval[rowptr[i] + k]; }
+};
 // key of entry e = i*max_d + k (row-major: a stable sort by key leaves (row, slot) order inside a block)
-// key = column block
-__global__ void k_ellcb_keys(int32_t n, int32_t max_d, int32_t cb, const int32_t *__restrict__ ecol,
-                             uint16_t *__restrict__ key, int32_t *__restrict__ ent)
+// key = column block; a slot that holds no entry gets key nb: it sorts behind every block and nobody looks at it again
+template <class Src>
+__global__ void k_ellcb_keys(Src S, int32_t cb, int32_t nb, uint16_t *__restrict__ key, int32_t *__restrict__ ent)
 {
-    const int64_t total = (int64_t)n * max_d;
+    const int64_t total = (int64_t)S.n * S.max_d;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int32_t i = (int32_t)(e / max_d), k = (int32_t)(e % max_d);
-        key[e] = (uint16_t)(ecol[(int64_t)k * n + i] / cb);
+        const int32_t i = (int32_t)(e / S.max_d), k = (int32_t)(e % S.max_d);
+        key[e] = S.has(i, k) ? (uint16_t)(S.col(i, k) / cb) : (uint16_t)nb;
         ent[e] = (int32_t)e;
     }
 }
@@ -61,17 +77,16 @@ __global__ void k_ellcb_bstart(int64_t total, int32_t nb, const uint16_t *__rest
     }
     bstart[b] = (int32_t)lo;
 }
-// values (and, with lcol != null, block-local columns) in sorted order
-__global__ void k_ellcb_gather(int64_t total, int32_t n, int32_t max_d, int32_t cb, const int32_t *__restrict__ perm,
-                               const int32_t *__restrict__ ecol, const double *__restrict__ eval,
+// values (and, with lcol != null, block-local columns) in sorted order; `count` = the sorted positions that hold entries
+template <class Src>
+__global__ void k_ellcb_gather(int64_t count, Src S, int32_t cb, const int32_t *__restrict__ perm,
                                double *__restrict__ sval, uint16_t *__restrict__ lcol)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
-        const int32_t e = perm[j], i = e / max_d, k = e % max_d;
-        const int64_t s = (int64_t)k * n + i;
-        sval[j] = eval[s];
-        if (lcol) lcol[j] = (uint16_t)(ecol[s] % cb);
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
+        const int32_t e = perm[j], i = e / S.max_d, k = e % S.max_d;
+        sval[j] = S.val(i, k);
+        if (lcol) lcol[j] = (uint16_t)(S.col(i, k) % cb);
     }
 }
 // run (t, b): the entries of column block b whose rows lie in tile t = sorted positions
@@ -110,30 +125,32 @@ __global__ void k_ellcb_bases(int32_t ntiles, int32_t nb, int2 *__restrict__ fde
     }
 }
 // lpos (slot-major like eval): where entry (k, i) sits in its tile's LDS image
-__global__ void k_ellcb_lpos(int64_t total, int32_t n, int32_t max_d, int32_t cb, int32_t nb, int32_t R,
-                             const int32_t *__restrict__ perm, const int32_t *__restrict__ ecol,
-                             const int2 *__restrict__ fdesc, uint16_t *__restrict__ lpos)
+template <class Src>
+__global__ void k_ellcb_lpos(int64_t count, Src S, int32_t cb, int32_t nb, int32_t R,
+                             const int32_t *__restrict__ perm, const int2 *__restrict__ fdesc, uint16_t *__restrict__ lpos)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
-        const int32_t e = perm[j], i = e / max_d, k = e % max_d;
-        const int64_t s = (int64_t)k * n + i;
-        const int2 d = fdesc[(int64_t)(i / R) * nb + ecol[s] / cb];
-        lpos[s] = (uint16_t)(((uint32_t)d.y >> 16) + (uint32_t)(j - d.x));
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
+        const int32_t e = perm[j], i = e / S.max_d, k = e % S.max_d;
+        const int2 d = fdesc[(int64_t)(i / R) * nb + S.col(i, k) / cb];
+        lpos[(int64_t)k * S.n + i] = (uint16_t)(((uint32_t)d.y >> 16) + (uint32_t)(j - d.x));
     }
 }
-// mean |column - row| over a sample of rows (is the matrix "random"?)
-__global__ void k_ellcb_sample(int32_t n, int32_t max_d, int32_t step, const int32_t *__restrict__ ecol,
-                               unsigned long long *sum)
+// mean |column - row| over a sample of rows (is the matrix "random"?); cnt = the entries looked at
+template <class Src>
+__global__ void k_ellcb_sample(Src S, int32_t step, unsigned long long *sum, unsigned long long *cnt)
 {
     const int32_t r = (blockIdx.x * blockDim.x + threadIdx.x) * step;
-    if (r >= n) return;
-    unsigned long long s = 0;
-    for (int32_t k = 0; k < max_d; ++k) {
-        const int32_t c = ecol[(int64_t)k * n + r];
-        s += (unsigned long long)(c > r ? c - r : r - c);
+    if (r >= S.n) return;
+    unsigned long long s = 0, c = 0;
+    for (int32_t k = 0; k < S.max_d; ++k) {
+        if (!S.has(r, k)) break;
+        const int32_t cc = S.col(r, k);
+        s += (unsigned long long)(cc > r ? cc - r : r - cc);
+        ++c;
     }
     atomicAdd(sum, s);
+    atomicAdd(cnt, c);
 }
 
 // ------------------------------------------------------------------------------ phase 1
@@ -221,7 +238,7 @@ __global__ __launch_bounds__(TPB) void k_ellcb_sum(int32_t n, int32_t max_d, int
                                                    const double *__restrict__ P, double *__restrict__ y,
                                                    const double *__restrict__ w, double *__restrict__ part_wy,
                                                    double *__restrict__ part_yy, const int *__restrict__ flag_done, int gen,
-                                                   int chain)
+                                                   int chain, const int32_t *__restrict__ rowptr /* CSR origin: row lengths; null = all max_d slots */)
 {
     extern __shared__ double img[];
     __shared__ double red[TPB / 64];
@@ -236,11 +253,12 @@ __global__ __launch_bounds__(TPB) void k_ellcb_sum(int32_t n, int32_t max_d, int
     for (int32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int32_t i = t * R + (int32_t)threadIdx.x;
         const bool live = (int)threadIdx.x < R && i < n;
+        const int32_t deg = !live ? 0 : rowptr ? rowptr[i + 1] - rowptr[i] : max_d;       // slots of this row that hold entries
         // positions of this lane's row (slots 0..MAXD-1 in registers; longer rows re-read them later)
         uint16_t pz[MAXD];
 #pragma unroll
         for (int k = 0; k < MAXD; ++k)
-            pz[k] = (live && k < max_d) ? __builtin_nontemporal_load(lpos + (int64_t)k * n + i) : (uint16_t)0;
+            pz[k] = k < deg ? __builtin_nontemporal_load(lpos + (int64_t)k * n + i) : (uint16_t)0;
         const int2 *D = fdesc + (int64_t)t * nb;
         for (int32_t b0 = bw0; b0 < bw1; b0 += 64) {
             const int32_t cnt = min(64, bw1 - b0);
@@ -272,8 +290,8 @@ __global__ __launch_bounds__(TPB) void k_ellcb_sum(int32_t n, int32_t max_d, int
             double z = (ADD && chain) ? y0 : 0.0;
 #pragma unroll
             for (int k = 0; k < MAXD; ++k)
-                if (k < max_d) z = z + img[pz[k]];
-            for (int32_t k = MAXD; k < max_d; ++k) z = z + img[lpos[(int64_t)k * n + i]];
+                if (k < deg) z = z + img[pz[k]];
+            for (int32_t k = MAXD; k < deg; ++k) z = z + img[lpos[(int64_t)k * n + i]];
             const double yi = ADD ? (chain ? z : y0 + z) : 0.0 + z;
             y[i] = yi;
             if (DOT_W) dwy += w[i] * yi;
@@ -303,33 +321,44 @@ void free_ell_colblock(Part &p)
     p.cb_perm = nullptr; p.cb_sval = nullptr; p.cb_lcol = nullptr; p.cb_bstart = nullptr; p.cb_lpos = nullptr;
     p.cb_fdesc = nullptr; p.cb_P = nullptr;
     p.cb_cols = p.cb_nb = p.cb_R = p.cb_ntiles = p.cb_chunks = 0;
+    p.cb_count = 0;
 }
 
 bool use_ell_colblock(const Part &p) { return p.cb_P != nullptr && p.opt.ell_colblock != 0; }
+static bool cb_from_csr(const Part &p) { return !p.ecol; }
+static EllSrc ell_src(const Part &p) { return EllSrc{p.ecol, p.eval, p.n, p.cb_maxd}; }
+static CsrSrc csr_src(const Part &p) { return CsrSrc{p.rowptr, p.col, p.val, p.n, p.cb_maxd}; }
 
 // workgroups of the sum launch = partial sums the fused dots leave
 int ell_colblock_grid(const Part &p) { return std::max(1, std::min(p.cb_ntiles, cb_grid2())); }
 
 // does the matrix qualify, and do its columns look random?
-static int wants_colblock(const Part &p, bool *yes)
+static int wants_colblock(Part &p, bool *yes)
 {
     *yes = false;
-    if (!p.opt.ell_colblock || !p.ecol || p.n <= 0 || p.max_d < 1) return SGM_OK;
-    if ((int64_t)p.n * p.max_d >= INT32_MAX || p.max_d > 128) return SGM_OK;
+    const bool csr = cb_from_csr(p);
+    p.cb_maxd = csr ? p.max_row : p.max_d;
+    if (!p.opt.ell_colblock || p.n <= 0 || p.cb_maxd < 1 || p.n_halo != 0) return SGM_OK;
+    if (csr && (!p.rowptr || !p.col || !p.val || p.lean)) return SGM_OK;
+    if ((int64_t)p.n * p.cb_maxd >= INT32_MAX || p.cb_maxd > 128) return SGM_OK;
+    // a CSR matrix: rows of similar length only (the 2-byte positions and the sort keys are per SLOT: n * max_row of them)
+    if (csr && (double)p.n * p.cb_maxd > 2.0 * (double)std::max<int64_t>(p.nnz, 1)) return SGM_OK;
     if (p.opt.ell_colblock >= 2) { *yes = true; return SGM_OK; }
-    if (p.ecode || p.scode) return SGM_OK;                        // structured: the dictionary kernels serve it
-    if ((int64_t)p.ncol_own * 8 < (int64_t)16 << 20 || p.max_d < 8) return SGM_OK;   // x within reach of the L2s / too few gathers
-    unsigned long long *dsum = nullptr, hsum = 0;
-    SGM_TRY(dalloc(&dsum, 1));
+    if (p.ecode || p.scode || p.code || p.sbcode) return SGM_OK;  // structured: the dictionary kernels serve it
+    if ((int64_t)p.ncol_own * 8 < (int64_t)16 << 20 || p.cb_maxd < 8) return SGM_OK;   // x within reach of the L2s / too few gathers
+    unsigned long long *dsum = nullptr, hsum[2] = {0, 0};
+    SGM_TRY(dalloc(&dsum, 2));
     hipStream_t st = g_rt.stream;
-    SGM_HIP(hipMemsetAsync(dsum, 0, 8, st));
+    SGM_HIP(hipMemsetAsync(dsum, 0, 16, st));
     const int32_t step = std::max(1, p.n / 4096), rows = (p.n + step - 1) / step;
-    hipLaunchKernelGGL(k_ellcb_sample, dim3((rows + 255) / 256), dim3(256), 0, st, p.n, p.max_d, step, (const int32_t *)p.ecol, dsum);
-    SGM_HIP(hipMemcpyAsync(&hsum, dsum, 8, hipMemcpyDeviceToHost, st));
+    if (csr) hipLaunchKernelGGL((k_ellcb_sample<CsrSrc>), dim3((rows + 255) / 256), dim3(256), 0, st, csr_src(p), step, dsum, dsum + 1);
+    else hipLaunchKernelGGL((k_ellcb_sample<EllSrc>), dim3((rows + 255) / 256), dim3(256), 0, st, ell_src(p), step, dsum, dsum + 1);
+    SGM_HIP(hipMemcpyAsync(hsum, dsum, 16, hipMemcpyDeviceToHost, st));
     SGM_HIP(hipStreamSynchronize(st));
     dfree(dsum);
-    const double mean = (double)hsum / ((double)rows * p.max_d);
-    *yes = mean > (double)p.ncol_own / 16.0;
+    const double mean = (double)hsum[0] / (double)std::max<unsigned long long>(hsum[1], 1);
+    p.col_spread = mean;
+    *yes = mean > (double)p.ncol_own / 16.0 && (!csr || (double)hsum[1] >= 8.0 * rows);
     return SGM_OK;
 }
 
@@ -337,10 +366,14 @@ static int wants_colblock(const Part &p, bool *yes)
 int refresh_ell_colblock_values(Part &p)
 {
     if (!p.cb_P) return SGM_OK;
-    const int64_t total = (int64_t)p.n * p.max_d;
-    hipLaunchKernelGGL(k_ellcb_gather, dim3(vec_grid(total)), dim3(kBlock), 0, g_rt.stream, total, p.n, p.max_d, p.cb_cols,
-                       (const int32_t *)p.cb_perm, (const int32_t *)p.ecol, (const double *)p.eval, p.cb_sval,
-                       (uint16_t *)nullptr);
+    const int64_t count = p.cb_count;
+    if (cb_from_csr(p)) {
+        SGM_TRY(csr_need_arrays(p));
+        hipLaunchKernelGGL((k_ellcb_gather<CsrSrc>), dim3(vec_grid(count)), dim3(kBlock), 0, g_rt.stream, count, csr_src(p), p.cb_cols,
+                           (const int32_t *)p.cb_perm, p.cb_sval, (uint16_t *)nullptr);
+    } else
+        hipLaunchKernelGGL((k_ellcb_gather<EllSrc>), dim3(vec_grid(count)), dim3(kBlock), 0, g_rt.stream, count, ell_src(p), p.cb_cols,
+                           (const int32_t *)p.cb_perm, p.cb_sval, (uint16_t *)nullptr);
     SGM_HIP(hipGetLastError());
     return SGM_OK;
 }
@@ -352,15 +385,17 @@ int build_ell_colblock(Part &p)
     bool yes = false;
     SGM_TRY(wants_colblock(p, &yes));
     if (!yes) return SGM_OK;
+    const bool csr = cb_from_csr(p);
     hipStream_t st = g_rt.stream;
-    const int64_t total = (int64_t)p.n * p.max_d;
+    const int32_t md = p.cb_maxd;
+    const int64_t total = (int64_t)p.n * md;
     const int32_t cb = p.opt.ell_colblock_cols, nb = (p.ncol_own + cb - 1) / cb;
-    if (nb > 65535) return SGM_OK;
+    if (nb > 65534) return SGM_OK;
     // tile image <= 64 KiB (two workgroups per CU) -- or, option ell_colblock_rows = 512 (automatic for rows <= 32 slots:
     // runs twice as long, one 1024-thread workgroup per CU with a 128 KiB image) -- whole waves
     const int want_rows = p.opt.ell_colblock_rows;
-    int32_t R = std::min(256, 8192 / p.max_d) / 64 * 64;
-    if ((want_rows == 512 || (want_rows == 0 && p.max_d >= 16)) && p.max_d <= 32) R = 512;
+    int32_t R = std::min(256, 8192 / md) / 64 * 64;
+    if ((want_rows == 512 || (want_rows == 0 && md >= 16)) && md <= 32) R = 512;
     // (round 4: 20480-column blocks and a 152 KiB image of 608 rows -- runs 48 % longer -- measured SLOWER, 1222 / 1171 / 1321 us
     //  against 1134: profiles/r04/c4_cols_rows_sweep.jsonl; the run length is not what bounds the second phase)
     if (R < 64) return SGM_OK;
@@ -375,9 +410,10 @@ int build_ell_colblock(Part &p)
     SGM_TRY(dalloc(&skey, (size_t)total));
     SGM_TRY(dalloc(&ent, (size_t)total));
     SGM_TRY(dalloc(&p.cb_perm, (size_t)total + 2));
-    hipLaunchKernelGGL(k_ellcb_keys, dim3(vec_grid(total)), dim3(kBlock), 0, st, p.n, p.max_d, cb, (const int32_t *)p.ecol, key, ent);
+    if (csr) hipLaunchKernelGGL((k_ellcb_keys<CsrSrc>), dim3(vec_grid(total)), dim3(kBlock), 0, st, csr_src(p), cb, nb, key, ent);
+    else hipLaunchKernelGGL((k_ellcb_keys<EllSrc>), dim3(vec_grid(total)), dim3(kBlock), 0, st, ell_src(p), cb, nb, key, ent);
     int bits = 1;
-    while ((1 << bits) < nb) ++bits;
+    while ((1 << bits) < nb + 1) ++bits;               // (keys 0 .. nb: nb = "no entry")
     size_t tmp_bytes = 0;
     SGM_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key, skey, ent, p.cb_perm, (int)total, 0, bits, st));
     char *tmpc = nullptr;
@@ -387,22 +423,29 @@ int build_ell_colblock(Part &p)
 
     SGM_TRY(dalloc(&p.cb_bstart, (size_t)nb + 1));
     hipLaunchKernelGGL(k_ellcb_bstart, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, total, nb, (const uint16_t *)skey, p.cb_bstart);
-    SGM_TRY(dalloc(&p.cb_sval, (size_t)total + 2));
-    SGM_TRY(dalloc(&p.cb_lcol, (size_t)total + 2));
-    hipLaunchKernelGGL(k_ellcb_gather, dim3(vec_grid(total)), dim3(kBlock), 0, st, total, p.n, p.max_d, cb,
-                       (const int32_t *)p.cb_perm, (const int32_t *)p.ecol, (const double *)p.eval, p.cb_sval, p.cb_lcol);
+    int32_t count32 = 0;                                // sorted positions that hold entries (= total for an ELLPACK matrix)
+    SGM_HIP(hipMemcpyAsync(&count32, p.cb_bstart + nb, 4, hipMemcpyDeviceToHost, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    const int64_t count = p.cb_count = count32;
+    SGM_TRY(dalloc(&p.cb_sval, (size_t)count + 2));
+    SGM_TRY(dalloc(&p.cb_lcol, (size_t)count + 2));
+    if (csr) hipLaunchKernelGGL((k_ellcb_gather<CsrSrc>), dim3(vec_grid(count)), dim3(kBlock), 0, st, count, csr_src(p), cb,
+                                (const int32_t *)p.cb_perm, p.cb_sval, p.cb_lcol);
+    else hipLaunchKernelGGL((k_ellcb_gather<EllSrc>), dim3(vec_grid(count)), dim3(kBlock), 0, st, count, ell_src(p), cb,
+                            (const int32_t *)p.cb_perm, p.cb_sval, p.cb_lcol);
     const int64_t nruns = (int64_t)ntiles * nb;
     int2 *fdesc = nullptr;
     SGM_TRY(dalloc(&fdesc, (size_t)nruns));
     p.cb_fdesc = fdesc;
-    hipLaunchKernelGGL(k_ellcb_runs, dim3((unsigned)((nruns + 255) / 256)), dim3(256), 0, st, ntiles, nb, R, p.max_d,
+    hipLaunchKernelGGL(k_ellcb_runs, dim3((unsigned)((nruns + 255) / 256)), dim3(256), 0, st, ntiles, nb, R, md,
                        (const int32_t *)p.cb_bstart, (const int32_t *)p.cb_perm, fdesc);
     hipLaunchKernelGGL(k_ellcb_bases, dim3((ntiles + 255) / 256), dim3(256), 0, st, ntiles, nb, fdesc);
-    const size_t lpos_count = (size_t)total;
-    SGM_TRY(dalloc(&p.cb_lpos, lpos_count + 2));
-    hipLaunchKernelGGL(k_ellcb_lpos, dim3(vec_grid(total)), dim3(kBlock), 0, st, total, p.n, p.max_d, cb, nb, R,
-                       (const int32_t *)p.cb_perm, (const int32_t *)p.ecol, (const int2 *)fdesc, p.cb_lpos);
-    SGM_TRY(dalloc(&p.cb_P, (size_t)total + 2));
+    SGM_TRY(dalloc(&p.cb_lpos, (size_t)total + 2));
+    if (csr) hipLaunchKernelGGL((k_ellcb_lpos<CsrSrc>), dim3(vec_grid(count)), dim3(kBlock), 0, st, count, csr_src(p), cb, nb, R,
+                                (const int32_t *)p.cb_perm, (const int2 *)fdesc, p.cb_lpos);
+    else hipLaunchKernelGGL((k_ellcb_lpos<EllSrc>), dim3(vec_grid(count)), dim3(kBlock), 0, st, count, ell_src(p), cb, nb, R,
+                            (const int32_t *)p.cb_perm, (const int2 *)fdesc, p.cb_lpos);
+    SGM_TRY(dalloc(&p.cb_P, (size_t)count + 2));
     SGM_HIP(hipGetLastError());
     SGM_HIP(hipStreamSynchronize(st));
     return SGM_OK;
@@ -412,7 +455,7 @@ template <int R, bool ADD>
 static void launch_sum(const Part &p, int grid, double *y, const double *w, double *pwy, double *pyy, const int *flag, int gen, int chain)
 {
     hipStream_t st = g_rt.stream;
-    const size_t lds = (size_t)p.cb_R * p.max_d * 8;
+    const size_t lds = (size_t)p.cb_R * p.cb_maxd * 8;
     constexpr bool BIG = R == 512;                   // 128 KiB image, 1024 threads, whole-wave runs
     constexpr int MAXD = (BIG ? 16384 : 8192) / R;   // the longest row a tile of R rows allows
     constexpr int TPB = BIG ? 1024 : 2 * R;          // twice as many waves copy runs as there are rows (C4: 696 -> see DESIGN)
@@ -420,8 +463,9 @@ static void launch_sum(const Part &p, int grid, double *y, const double *w, doub
     do {                                                                                                              \
         static bool attr = false;                                                                                     \
         if (BIG && !attr) { (void)hipFuncSetAttribute((const void *)k_ellcb_sum<R, TPB, MAXD, ADD, DW, DY, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, R * MAXD * 8); attr = true; } \
-        hipLaunchKernelGGL((k_ellcb_sum<R, TPB, MAXD, ADD, DW, DY, BIG>), dim3(grid), dim3(TPB), lds, st, p.n, p.max_d, p.cb_nb, p.cb_ntiles, \
-                           (const int2 *)p.cb_fdesc, (const uint16_t *)p.cb_lpos, (const double *)p.cb_P, y, w, pwy, pyy, flag, gen, chain); \
+        hipLaunchKernelGGL((k_ellcb_sum<R, TPB, MAXD, ADD, DW, DY, BIG>), dim3(grid), dim3(TPB), lds, st, p.n, p.cb_maxd, p.cb_nb, p.cb_ntiles, \
+                           (const int2 *)p.cb_fdesc, (const uint16_t *)p.cb_lpos, (const double *)p.cb_P, y, w, pwy, pyy, flag, gen, chain, \
+                           cb_from_csr(p) ? (const int32_t *)p.rowptr : (const int32_t *)nullptr); \
     } while (0)
     if (w && pyy) L(true, true);
     else if (w) L(true, false);
@@ -458,15 +502,15 @@ int launch_ell_colblock(const Part &p, int grid, const double *x, double *y, boo
 int64_t ell_colblock_resident_bytes(const Part &p)
 {
     if (!p.cb_P) return 0;
-    const int64_t total = (int64_t)p.n * p.max_d, nruns = (int64_t)p.cb_ntiles * p.cb_nb;
-    return total * (4 + 8 + 2 + 2) + total * 8 + nruns * 8 + 4 * ((int64_t)p.cb_nb + 1);
+    const int64_t total = (int64_t)p.n * p.cb_maxd, count = p.cb_count, nruns = (int64_t)p.cb_ntiles * p.cb_nb;
+    return total * (4 + 2) + count * (8 + 2) + count * 8 + nruns * 8 + 4 * ((int64_t)p.cb_nb + 1);
 }
 int64_t ell_colblock_matvec_bytes(const Part &p)
 {
-    const int64_t total = (int64_t)p.n * p.max_d, nruns = (int64_t)p.cb_ntiles * p.cb_nb;
+    const int64_t count = p.cb_count, nruns = (int64_t)p.cb_ntiles * p.cb_nb;
     const int64_t xloads = (int64_t)p.cb_nb * p.cb_chunks;
-    return total * (8 + 2 + 8) + xloads * p.cb_cols * 8                                  // phase 1: values, columns, products, x blocks
-         + total * (8 + 2) + nruns * 8 + 8 * (int64_t)p.n;                              // phase 2: products, positions, run tables, y
+    return count * (8 + 2 + 8) + xloads * p.cb_cols * 8                                  // phase 1: values, columns, products, x blocks
+         + count * (8 + 2) + nruns * 8 + 8 * (int64_t)p.n + (cb_from_csr(p) ? 4 * (int64_t)p.n : 0);   // phase 2: products, positions, run tables, y (+ row lengths)
 }
 
 }  // namespace sgm

@@ -48,6 +48,9 @@ struct MatOptions {
     int ell_colblock = 1;          // ELLPACK with random columns: column-blocked two-phase product (0 never, 1 automatic, 2 always)
     int ell_colblock_cols = 16384; // its column block: x entries staged in LDS per workgroup (even, <= kEllcbMaxCols)
     int ell_colblock_rows = 0;     // rows per tile of its sum phase: 0 automatic, 256 or 512
+    int coloring_pass = 0;         // greedy colouring / colour ordering of this matrix's graph: 0 = the fastest pass that applies (union-find
+                                   // parity on the device, level sweep on the device, sequential host pass), 1 = from the level sweep on,
+                                   // 2 = the host pass -- the same colours whichever (tests compare the passes)
     int slice_sched = 0;           // sliced kernels on matrices with a far stencil offset (3-D grids): tile-ordered slice schedule per XCD;
                                    // 0 off, 1 = bands of 64 slices, n > 1 = bands of n slices.  Off: the counters drop (fabric reads 9.9 ->
                                    // 8.6 / 7.1 GB at 464^3) but the time is within run-to-run noise of the computed maps (round 4: 1514 -> 1456 us
@@ -60,7 +63,11 @@ struct SolverOptions {
     int krylov_graph = 1;          // CG / BiCGStab launch loops (one GPU, plain or Jacobi): replay a captured group of 16 iterations (hipGraph);
                                    // 0 off, 1 = once the solve has run 64 iterations, n > 1 = after n (rounded up to a multiple of 16)
     int dot_order = 0;             // dot products of CG / BiCGStab: 0 = tree (per-workgroup partial sums), 1 = the reference's order
-    int gmres_cgs2 = 1;            // GMRES: blocked CGS-2 orthogonalisation (3 passes per step) instead of modified Gram-Schmidt
+    int gmres_cgs2 = 1;            // GMRES: 1 = low-synchronisation CGS-2 (k_gsl: basis read twice per step), 2 = blocked CGS-2 (three passes), 0 = modified Gram-Schmidt
+    int coop_spin_limit = 0;       // cooperative CG / BiCGStab: polls before a hand-off gives up (0 = built-in 2^19; tests set 1 to force the fall-back)
+    int cg_coop_variant = 0;       // cooperative CG / BiCGStab: low 4 bits pin the rows per thread (1, 2, 4, 8; 0 = by size), +16 = never the one-XCD variant
+    int reorder_solve = 2;         // a preconditioner with ildu_reorder: 2 = the solve runs in the permuted order and CG folds its r update and
+                                   // r.z into the two sweeps, 1 = permuted order, separate steps, 0 = r and z permuted around every apply
     int dist_halo_fused = 1;       // CG on a row partition: the boundary rows of r (z) travel beside the all-reduce of r.r (r.z) and p's
                                    // halo is formed locally -- no exchange in front of the product; 1 = one RCCL group with the all-reduce,
                                    // 2 = its own send / recv group just before it, 0 = off (p's halo exchanged by every product)
@@ -92,6 +99,7 @@ struct Runtime {
 };
 extern Runtime g_rt;
 int require_init();
+bool trace_on();   // SGM_TRACE set: which path ran, one line per solve / setup on stderr
 int finish();   // hipStreamSynchronize unless async
 // pageable host <-> device, chunked through pinned buffers (synchronous)
 int copy_big(void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
@@ -218,6 +226,9 @@ struct Part {
     void *cb_fdesc = nullptr;      // ntiles x nb run descriptors {sorted position, length | LDS base << 16}
     double *cb_P = nullptr;        // products val * x in sorted order (written by phase 1)
     int32_t cb_cols = 0, cb_nb = 0, cb_R = 0, cb_ntiles = 0, cb_chunks = 0;
+    int32_t cb_maxd = 0;           // slots per row of that form: max_d (ELLPACK) or the longest row (a CSR matrix with scattered columns)
+    int64_t cb_count = 0;          // sorted positions that hold entries (= n * max_d for an ELLPACK matrix, nnz for a CSR one)
+    double col_spread = -1.0;      // mean |column - row| over a sample of rows, when it was looked at (-1: not)
     std::vector<HaloNbr> nbrs;
     double *xext = nullptr;        // owned+halo staging for plain-vector matvec (multi-part only)
     int dot_grid_override = 0;     // composite matrices: grid of the separate dot kernel

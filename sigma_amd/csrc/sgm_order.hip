@@ -351,7 +351,7 @@ int greedy_coloring_device(const Part &pt, int32_t *colors_dev, int32_t *p_dev, 
 {
     *ok = false;
     const int32_t n = pt.n;
-    if (n < 1 || getenv("SGM_COLOR_HOST")) return SGM_OK;
+    if (n < 1 || pt.opt.coloring_pass == 2) return SGM_OK;
     SGM_TRY(csr_need_arrays(pt));
     struct Release { const Part &p; ~Release() { csr_release_arrays(p); } } rel{pt};
     hipStream_t st = g_rt.stream;
@@ -370,7 +370,7 @@ int greedy_coloring_device(const Part &pt, int32_t *colors_dev, int32_t *p_dev, 
     bool parity_done = false;
     // (the union-find pass verifies symmetry by scanning row j for every edge (i, j): quadratic in the degree -- a hub of a
     //  million leaves would cost 1e12 steps.  Rows beyond 64 entries leave it to the level sweep / the linear host pass.)
-    if (!getenv("SGM_COLOR_LEVELS") && pt.max_row <= 64) {                // (tests: force the level sweep)
+    if (pt.opt.coloring_pass == 0 && pt.max_row <= 64) {
         uint32_t *P = reinterpret_cast<uint32_t *>(fr[0]);
         SGM_HIP(hipMemcpyAsync(state, init_state, sizeof init_state, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_uf_init, dim3(gridn), dim3(kBlock), 0, st, n, (const int32_t *)pt.rowptr, (const int32_t *)pt.col, P);
@@ -515,6 +515,7 @@ int diag_block_plain(const Part &p, sgm_mat *out)
     C->parts.resize(1);
     Part &q = C->parts[0];
     q.opt.csr_offset_dict = 0; q.opt.csr_sliced = 0; q.opt.csr_sell = 0; q.opt.csr_lean = 0; q.opt.slice_sched = 0;
+    q.opt.coloring_pass = p.opt.coloring_pass;
     q.n = n; q.ncol_own = n; q.n_halo = 0;
     SGM_TRY(dalloc(&q.rowptr, (size_t)n + 1));
     hipLaunchKernelGGL(k_blk_count, dim3((n + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, own, (const int32_t *)p.rowptr,

@@ -2551,6 +2551,21 @@ static int pc_apply_parts_ordered(sgm_pc pc, sgm_mat A, const double *const *r, 
 extern "C" {
 
 static int pc_setup_ordered(sgm_pc pc, sgm_mat A);
+int sgm_pc_info(sgm_pc pc, int32_t part, int32_t *out4, double *est_us, char *path_name, int len);
+
+// SGM_TRACE: one line per setup naming the sweeps that will serve the applies (sgm_pc_info) -- a chain-bound `ldu()` says so
+static void trace_setup(sgm_pc pc)
+{
+    if (!trace_on()) return;
+    const size_t P = pc->kind == SGM_PC_JACOBI ? 1 : pc->ild.size();
+    for (size_t ip = 0; ip < P && ip < 2; ++ip) {
+        int32_t o[4]; double us = 0.0; char nm[160];
+        if (sgm_pc_info(pc, (int32_t)ip, o, &us, nm, (int)sizeof nm) != SGM_OK) return;
+        fprintf(stderr, "[sigma_hip] %s setup%s: %s, about %.0f us per apply%s%s\n", pc->kind == SGM_PC_JACOBI ? "jacobi" : "ildu",
+                P > 1 ? (ip == 0 ? " (part 0)" : " (part 1)") : "", nm, us, o[3] ? ", colour-ordered" : "",
+                o[2] >= 2 && !o[3] ? " -- a dependency chain: ldu(reorder=\"colour\") / option ildu_reorder makes it two bandwidth-bound sweeps" : "");
+    }
+}
 
 static void free_reorder(sgm_pc pc)
 {
@@ -2566,7 +2581,9 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
     if (!reorder) {
         if (!pc->ro.empty()) { free_reorder(pc); for (auto &S : pc->ild) free_ildu(S); pc->ild.clear(); }
         if (pc->Ap) { sgm_mat_destroy(pc->Ap); pc->Ap = nullptr; }
-        return pc_setup_ordered(pc, A);
+        const int rc0 = pc_setup_ordered(pc, A);
+        if (rc0 == SGM_OK) trace_setup(pc);
+        return rc0;
     }
     // ILDU(0) of the colour-ordered matrix: the ordering once per pattern (ldu_solvers.f90:117-125 builds the pattern once),
     // a permuted copy of A per setup (the values may have changed), the regular device-side setup on that copy.  On a row
@@ -2616,6 +2633,7 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
     pc->reorder_ms[2] = ms_since(t0);
     if (rc == SGM_OK) { pc->Ap = Ap; pc->Ap_serial = A->serial; pc->Ap_version = A->version; }
     else sgm_mat_destroy(Ap);
+    if (rc == SGM_OK) trace_setup(pc);
     return rc;
 }
 
@@ -3076,6 +3094,66 @@ int sgm_pc_get(sgm_pc pc, const char *name, void *out, size_t bytes, size_t *nee
         if (bytes < sz) return fail(SGM_ERR_BAD_ARG, "sgm_pc_get: buffer too small (%zu < %zu)", bytes, sz);
         memcpy(out, src, sz);
     }
+    return SGM_OK;
+}
+
+/* sgm_pc_info: which sweeps serve part `part` of this preconditioner and what an apply costs -- so that a caller who builds
+ * `ldu()` the way the reference's tests do (solver_test_incomplete_cholesky.f90:137-141) can SEE that the factors of a
+ * naturally ordered grid are a dependency chain before paying for it.
+ *   out[0], out[1]  dependency levels of L and of U (the row recurrences of ldu_solvers.f90:227-236, :254-263 can start a level
+ *                   only when the one before it is done); 1 for a diagonal preconditioner
+ *   out[2]          path: 0 diagonal scaling (Jacobi), 1 row-space sweeps (one launch per level, bandwidth-bound), 2 strip
+ *                   pipeline (2-D grid factors), 3 slab pipeline (3-D grid factors), 4 level walkers
+ *   out[3]          colours of the ordering the factors belong to (option ildu_reorder); 0 = the matrix's own order
+ *   est_us          estimated microseconds per apply on this GPU (from the path's measured constants)
+ *   path_name       the same in words */
+int sgm_pc_info(sgm_pc pc, int32_t part, int32_t *out4, double *est_us, char *path_name, int len)
+{
+    if (!pc) return fail(SGM_ERR_BAD_ARG, "sgm_pc_info: null preconditioner");
+    int32_t o[4] = {1, 1, 0, 0};
+    double us = 0.0;
+    char nm[160] = "";
+    if (pc->kind == SGM_PC_JACOBI) {
+        if (part < 0 || (size_t)part >= std::max<size_t>(pc->parts.size(), 1)) return fail(SGM_ERR_BAD_ARG, "sgm_pc_info: part %d", part);
+        us = 24.0 * pc->n / 5.5e6;
+        snprintf(nm, sizeof nm, "diagonal scaling, 1 level");
+    } else {
+        if (part < 0 || (size_t)part >= pc->ild.size()) return fail(SGM_ERR_BAD_ARG, "sgm_pc_info: part %d of %zu (set the preconditioner up first)", part, pc->ild.size());
+        IlduState *S = &pc->ild[(size_t)part];
+        o[3] = (size_t)part < pc->ro.size() ? pc->ro[(size_t)part].colors : 0;
+        if (S->grid_ok && S->opt.ildu_strips) {
+            // a w x nj grid in natural order: rows (i, j) with i + j equal form a level
+            o[0] = o[1] = S->gL.w + S->gL.nj - 1;
+            o[2] = 2;
+            us = 2.0 * (0.075 * S->gL.S + 9.9 * std::max(0, S->gL.NI - 1)) + 3.0 * 16.0 * S->gL.NP / 5.5e6;
+            snprintf(nm, sizeof nm, "strip pipeline, %d levels", o[0]);
+        } else if (S->slab_ok && S->opt.ildu_strips) {
+            int32_t w = 0, h = 0, sv[6] = {0, 0, 0, 0, 0, 0};
+            slab3_dims(S->slab, &w, &h);
+            slab3_info(S->slab, sv);
+            const int32_t nk = (int32_t)((S->n + (int64_t)w * h - 1) / ((int64_t)w * h));
+            o[0] = o[1] = w + h + nk - 2;
+            o[2] = 3;
+            us = 2.0 * (0.135 * sv[3] + 6.5 * std::max(0, sv[1] - 1)) + 3.0 * 16.0 * S->n / 5.5e6;
+            snprintf(nm, sizeof nm, "slab pipeline, %d levels", o[0]);
+        } else {
+            SGM_TRY(ensure_levels(S));
+            o[0] = (int32_t)S->L.level_ptr.size() - 1;
+            o[1] = (int32_t)S->U.level_ptr.size() - 1;
+            if (rows_serve(S)) {
+                o[2] = 1;
+                us = (12.0 * ((double)S->nnzL + S->nnzU) + 56.0 * S->n) / 5.5e6;
+                snprintf(nm, sizeof nm, "row space, %d levels", std::max(o[0], o[1]));
+            } else {
+                o[2] = 4;
+                us = 0.36 * ((double)o[0] + o[1]) + (12.0 * ((double)S->nnzL + S->nnzU) + 56.0 * S->n) / 5.5e6;
+                snprintf(nm, sizeof nm, "level walkers, %d levels", std::max(o[0], o[1]));
+            }
+        }
+    }
+    if (out4) memcpy(out4, o, sizeof o);
+    if (est_us) *est_us = us;
+    if (path_name && len > 0) snprintf(path_name, (size_t)len, "%s", nm);
     return SGM_OK;
 }
 

@@ -22,6 +22,12 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+bool trace_on()
+{
+    static const bool on = getenv("SGM_TRACE") != nullptr;
+    return on;
+}
+
 int require_init()
 {
     if (g_rt.ready) return SGM_OK;
@@ -90,13 +96,14 @@ int *mat_option_field(MatOptions &o, const char *name)
 {
     SGM_OPT(mat, csr_offset_dict) SGM_OPT(mat, ell_offset_dict) SGM_OPT(mat, csr_row_owner) SGM_OPT(mat, csr_row_lines)
     SGM_OPT(mat, csr_sliced) SGM_OPT(mat, csr_sell) SGM_OPT(mat, csr_lean) SGM_OPT(mat, ell_colblock) SGM_OPT(mat, ell_colblock_cols)
-    SGM_OPT(mat, ell_colblock_rows) SGM_OPT(mat, slice_sched)
+    SGM_OPT(mat, ell_colblock_rows) SGM_OPT(mat, slice_sched) SGM_OPT(mat, coloring_pass)
     return nullptr;
 }
 int *solver_option_field(SolverOptions &o, const char *name)
 {
     SGM_OPT(solver, cg_small) SGM_OPT(solver, bicgstab_small) SGM_OPT(solver, krylov_graph) SGM_OPT(solver, dot_order)
-    SGM_OPT(solver, gmres_cgs2) SGM_OPT(solver, dist_halo_fused)
+    SGM_OPT(solver, gmres_cgs2) SGM_OPT(solver, dist_halo_fused) SGM_OPT(solver, coop_spin_limit) SGM_OPT(solver, cg_coop_variant)
+    SGM_OPT(solver, reorder_solve)
     return nullptr;
 }
 int *pc_option_field(PcOptions &o, const char *name)
@@ -117,7 +124,15 @@ int normalise_option(const char *name, int value, int *out)
     else if (!strcmp(name, "slice_sched")) v = value <= 0 ? 0 : value == 1 ? 1 : std::max(4, value);
     else if (!strcmp(name, "krylov_graph")) v = value <= 0 ? 0 : value == 1 ? 1 : std::max(16, (value + 15) / 16 * 16);
     else if (!strcmp(name, "cg_small")) v = std::max(0, value);
-    else if (!strcmp(name, "dist_halo_fused")) v = value < 0 ? 0 : value > 2 ? 2 : value;
+    else if (!strcmp(name, "dist_halo_fused") || !strcmp(name, "reorder_solve")) v = value < 0 ? 0 : value > 2 ? 2 : value;
+    else if (!strcmp(name, "coop_spin_limit")) v = std::max(0, value);
+    else if (!strcmp(name, "gmres_cgs2")) v = value < 0 ? 0 : value > 2 ? 2 : value;
+    else if (!strcmp(name, "cg_coop_variant")) {
+        const int r = value & 15;
+        if (value < 0 || value > 31 || (r != 0 && r != 1 && r != 2 && r != 4 && r != 8))
+            return fail(SGM_ERR_BAD_ARG, "option cg_coop_variant: rows per thread 0 (by size), 1, 2, 4 or 8, + 16 = no one-XCD variant");
+    }
+    else if (!strcmp(name, "coloring_pass")) v = value < 0 ? 0 : value > 2 ? 2 : value;
     else if (!strcmp(name, "pipeline_spin_limit")) v = std::max(0, value);
     else if (!strcmp(name, "dot_order") && value != 0 && value != 1)
         return fail(SGM_ERR_BAD_ARG, "option dot_order is 0 (tree) or 1 (the reference's sequential order)");

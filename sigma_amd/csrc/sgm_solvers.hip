@@ -522,7 +522,13 @@ struct GmresState {                 // lives in device memory, one per part (all
     double H[(kGmresMaxRestart + 1) * kGmresMaxRestart];   // column-major, R after rotations
     double cs[kGmresMaxRestart], sn[kGmresMaxRestart], g[kGmresMaxRestart + 1], y[kGmresMaxRestart];
     int j;                          // Arnoldi steps done in this cycle
+    // low-synchronisation Gram-Schmidt (k_gsl, gmres_cgs2 = 1): the STORED columns S are projected once and never corrected;
+    // R = the Cholesky factor of their Gram matrix S^T S (upper, column-major, leading dimension kGsLd) makes V = S R^-1 the
+    // orthonormal basis, Gs the Hessenberg matrix of the stored basis (A S_k = S_{k+1} Gs), coef the projection the second pass
+    // subtracts ([a_0 .. a_{k-1}, 1 / alpha])
+    double R[33 * 33], Gs[34 * 33], coef[34];
 };
+constexpr int kGsLd = 33;
 // w = w - h_prev*v_prev (if v_prev) ; partial w.v_cur (v_cur == nullptr: partial w.w)
 struct FMgs {
     double *w; const double *v_prev, *v_cur; ScalarRef h_prev; double *part; double h = 0.0, s = 0.0;
@@ -577,6 +583,7 @@ __global__ __launch_bounds__(kBlock) void k_gmres_start(ScalarRef nrm2, GmresSta
         const double beta = sqrt(d);
         G->j = 0;
         G->g[0] = beta;
+        G->R[0] = 1.0;                       // (k_gsl: the Gram matrix of the one stored column s_0 = r / beta)
         *res_out = beta * beta;
         if (!(beta > tol)) *flag = 1;
     }
@@ -753,6 +760,189 @@ __global__ __launch_bounds__(kBlock) void k_reduce_many(const double *parts, int
     const double d = load_scalar<kBlock>(r, red);
     if (threadIdx.x == 0) slots[blockIdx.x] = d;
 }
+// ---- low-synchronisation Gram-Schmidt: the basis read TWICE per step, two reductions -------------------------------------
+// Classical Gram-Schmidt applied twice reads the basis three times (h1 = V^T w | w -= V h1, h2 = V^T w | w -= V h2, norm): the
+// second correction cannot start before h2 has been summed.  Here it is never applied to the vector: the stored column
+// s_{k} = (z - S a) / alpha is the ONCE-projected vector, and what the second projection would have removed is kept as numbers --
+// the new column (S^T s_k, s_k . s_k) of the Gram matrix of the stored columns, measured by the same pass that forms s_k.  With
+// R = chol(S^T S) the orthonormal basis is V = S R^-1 (never formed), the projection of the next z is the exact one,
+// a = (S^T S)^-1 S^T z = R^-1 R^-T (S^T z), and Arnoldi's relation in the orthonormal basis is A V_k = V_{k+1} (R Gs R^-1).
+// (The inverse-compact-WY / "low-synch" Gram-Schmidt of the GMRES literature, written with the full Gram factor.)
+//   pass 1 (MODE 0)  g = S^T z, t = z.z                                   k + 1 reads
+//   small            a = R^-1 R^-T g ; alpha = sqrt(t - |R^-T g|^2)         (k_gmres_ls1: one workgroup)
+//   pass 2 (MODE 1)  s_k = (z - S a) / alpha ; c = S^T s_k, d = s_k.s_k    k + 1 reads, 1 write
+//   small            R grows by (R^-T c, sqrt(d - |R^-T c|^2)) ; H(:, j) = R Gs R^-1 e_j ; rotations      (k_gmres_ls2)
+// 2 k + 3 vector passes per step where blocked CGS-2 + the scaling pass took 3 k + 8; two all-reduces across ranks, not three.
+template <int KB, int MODE>
+__global__ __launch_bounds__(kBlock) void k_gsl(int64_t n, int kk, const double *__restrict__ z, double *V, int64_t ldv,
+                                                const double *__restrict__ coef, double *__restrict__ part_out, const int *flag)
+{
+    __shared__ double red[kBlock / 64];
+    if (flag && *flag) return;
+    double a[KB], acc[KB];
+#pragma unroll
+    for (int c = 0; c < KB; ++c) {
+        a[c] = (MODE == 1 && c < kk) ? coef[c] : 0.0;
+        acc[c] = 0.0;
+    }
+    const double inv_alpha = MODE == 1 ? coef[kk] : 0.0;
+    double own = 0.0;                                   // z.z (pass 1) / s_k.s_k (pass 2)
+    const int64_t gtid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t n2 = n >> 1;
+    for (int64_t i = gtid; i < n2; i += stride) {
+        double2 wv = ld2<false>(z, i);
+        double2 vv[KB];
+#pragma unroll
+        for (int c = 0; c < KB; ++c)
+            if (c < kk) vv[c] = ld2<true>(V + (size_t)c * ldv, i);
+        if (MODE == 1) {
+#pragma unroll
+            for (int c = 0; c < KB; ++c)
+                if (c < kk) { wv.x = wv.x - a[c] * vv[c].x; wv.y = wv.y - a[c] * vv[c].y; }
+            wv.x = wv.x * inv_alpha; wv.y = wv.y * inv_alpha;
+            st2<false>(V + (size_t)kk * ldv, i, wv);
+        }
+#pragma unroll
+        for (int c = 0; c < KB; ++c)
+            if (c < kk) { acc[c] += vv[c].x * wv.x; acc[c] += vv[c].y * wv.y; }
+        own += wv.x * wv.x; own += wv.y * wv.y;
+    }
+    if ((n & 1) && gtid == 0) {
+        const int64_t i = n - 1;
+        double wv = z[i];
+        if (MODE == 1) {
+#pragma unroll
+            for (int c = 0; c < KB; ++c)
+                if (c < kk) wv = wv - a[c] * V[(size_t)c * ldv + i];
+            wv = wv * inv_alpha;
+            V[(size_t)kk * ldv + i] = wv;
+        }
+#pragma unroll
+        for (int c = 0; c < KB; ++c)
+            if (c < kk) acc[c] += V[(size_t)c * ldv + i] * wv;
+        own += wv * wv;
+    }
+#pragma unroll
+    for (int c = 0; c < KB; ++c)
+        if (c < kk) {                        // kk is uniform: every thread takes the same branches
+            const double t = block_sum<kBlock>(acc[c], red);
+            if (threadIdx.x == 0) part_out[(size_t)c * kMaxGrid + blockIdx.x] = t;
+        }
+    const double t = block_sum<kBlock>(own, red);
+    if (threadIdx.x == 0) part_out[(size_t)kk * kMaxGrid + blockIdx.x] = t;
+}
+
+// R (kk x kk, upper) into LDS, cooperatively: the small dense steps below then run on one lane out of LDS
+__device__ inline void gsl_load_R(const GmresState *G, int kk, double *Rl)
+{
+    for (int e = threadIdx.x; e < kk * kGsLd; e += blockDim.x) Rl[e] = G->R[e];
+    __syncthreads();
+}
+// after pass 1 (slots g[0..kk-1], t at [kk]): a = (S^T S)^-1 g through R, alpha from Pythagoras (a scale only: what it misses
+// ends up in R), column j of Gs
+__global__ __launch_bounds__(64) void k_gmres_ls1(const double *gt, GmresState *G, const int *flag)
+{
+    __shared__ double Rl[33 * kGsLd];
+    __shared__ double u[34];
+    if (*flag) return;
+    const int j = G->j, kk = j + 1;
+    gsl_load_R(G, kk, Rl);
+    if (threadIdx.x != 0) return;
+    double uu = 0.0;
+    for (int i = 0; i < kk; ++i) {                     // R^T u = g
+        double sacc = gt[i];
+        for (int l = 0; l < i; ++l) sacc = sacc - Rl[l + i * kGsLd] * u[l];
+        u[i] = sacc / Rl[i + i * kGsLd];
+        uu += u[i] * u[i];
+    }
+    for (int i = kk - 1; i >= 0; --i) {                // R a = u
+        double sacc = u[i];
+        for (int l = i + 1; l < kk; ++l) sacc = sacc - Rl[i + l * kGsLd] * u[l];
+        u[i] = sacc / Rl[i + i * kGsLd];
+    }
+    const double t = gt[kk], est = t - uu;
+    const double alpha = est > 1e-24 * t ? sqrt(est) : (t > 0.0 ? 1e-12 * sqrt(t) : 1.0);
+    for (int i = 0; i < kk; ++i) { G->coef[i] = u[i]; G->Gs[i + j * 34] = u[i]; }
+    G->coef[kk] = 1.0 / alpha;
+    G->Gs[kk + j * 34] = alpha;
+}
+// after pass 2 (slots c[0..kk-1], d at [kk]): R grows by a column, column j of H = R Gs R^-1 e_j, then the rotations, the residual
+// estimate and the loop test exactly as k_gmres_givens
+__global__ __launch_bounds__(64) void k_gmres_ls2(const double *cd, int m, GmresState *G, double tol, int *flag, int64_t *iters,
+                                                  double *history, int64_t hist_cap, double *res_out)
+{
+    __shared__ double Rl[34 * kGsLd];
+    __shared__ double q[34], pv[34];
+    if (*flag) return;
+    const int j = G->j, kk = j + 1;
+    gsl_load_R(G, kk, Rl);
+    if (threadIdx.x != 0) return;
+    double rr = 0.0;
+    for (int i = 0; i < kk; ++i) {                     // R^T r = c : the new column of R
+        double sacc = cd[i];
+        for (int l = 0; l < i; ++l) sacc = sacc - Rl[l + i * kGsLd] * Rl[l + kk * kGsLd];
+        const double ri = sacc / Rl[i + i * kGsLd];
+        Rl[i + kk * kGsLd] = ri;
+        G->R[i + kk * kGsLd] = ri;
+        rr += ri * ri;
+    }
+    const double d = cd[kk], rho2 = d - rr;
+    const double rho = rho2 > 1e-24 * d ? sqrt(rho2) : (d > 0.0 ? 1e-12 * sqrt(d) : 1.0);
+    Rl[kk + kk * kGsLd] = rho;
+    G->R[kk + kk * kGsLd] = rho;
+    for (int i = kk - 1; i >= 0; --i) {                // R_kk q = e_j : the last column of R_kk^-1
+        double sacc = i == j ? 1.0 : 0.0;
+        for (int l = i + 1; l < kk; ++l) sacc = sacc - Rl[i + l * kGsLd] * q[l];
+        q[i] = sacc / Rl[i + i * kGsLd];
+    }
+    for (int i = 0; i <= kk; ++i) {                    // p = Gs(:, 0..j) q   (Gs is upper Hessenberg: row i has columns >= i - 1)
+        double sacc = 0.0;
+        for (int l = i > 0 ? i - 1 : 0; l <= j; ++l) sacc += G->Gs[i + l * 34] * q[l];
+        pv[i] = sacc;
+    }
+    double *H = G->H + (size_t)j * (m + 1);
+    for (int i = 0; i <= kk; ++i) {                    // H(:, j) = R_{kk+1} p
+        double sacc = 0.0;
+        for (int l = i; l <= kk; ++l) sacc += Rl[i + l * kGsLd] * pv[l];
+        H[i] = sacc;
+    }
+    for (int i = 0; i < j; ++i) {
+        const double h0 = H[i], h1_ = H[i + 1];
+        H[i] = G->cs[i] * h0 + G->sn[i] * h1_;
+        H[i + 1] = -G->sn[i] * h0 + G->cs[i] * h1_;
+    }
+    const double h0 = H[j], hn = H[j + 1];
+    const double dd = sqrt(h0 * h0 + hn * hn);
+    G->cs[j] = h0 / dd;
+    G->sn[j] = hn / dd;
+    H[j] = dd;
+    H[j + 1] = 0.0;
+    G->g[j + 1] = -G->sn[j] * G->g[j];
+    G->g[j] = G->cs[j] * G->g[j];
+    const double res = fabs(G->g[j + 1]);
+    const int64_t it = *iters;
+    if (history && it < hist_cap) history[it] = res * res;
+    *iters = it + 1;
+    *res_out = res * res;
+    G->j = j + 1;
+    if (!(res > tol)) *flag = 1;
+}
+// end of a cycle: the coefficients of the orthonormal basis (k_gmres_solve_y) become those of the stored columns, y <- R^-1 y
+__global__ __launch_bounds__(64) void k_gmres_ls_y(GmresState *G)
+{
+    __shared__ double Rl[33 * kGsLd];
+    const int k = G->j;
+    if (k <= 0) return;
+    gsl_load_R(G, k, Rl);
+    if (threadIdx.x != 0) return;
+    for (int i = k - 1; i >= 0; --i) {
+        double sacc = G->y[i];
+        for (int l = i + 1; l < k; ++l) sacc = sacc - Rl[i + l * kGsLd] * G->y[l];
+        G->y[i] = sacc / Rl[i + i * kGsLd];
+    }
+}
+
 // k_gmres_givens for the CGS-2 path: column j of H = h1 + h2 (reduced slots), norm^2 in its own slot
 __global__ __launch_bounds__(64) void k_gmres_givens2(const double *h1, const double *h2, const double *nrm2, int m,
                                                       GmresState *G, double tol, int *flag, int64_t *iters,
@@ -881,7 +1071,6 @@ struct FSubScaled {
 // Grid policy of the vector kernels.  Kernels that leave partial sums need grid <= kMaxGrid;
 // pure update kernels take one pass over a large grid (a copy-like stream runs ~30 % faster
 // that way on MI355X than as a small persistent grid: tools/stream_bench.cpp).
-// SGM_VEC_CFG="dot_grid,nodot_grid" overrides (tuning aid).
 struct VecCfg { int dot_grid = 1024, nodot_grid = 2048; };
 static VecCfg &vec_cfg()
 {
@@ -889,7 +1078,6 @@ static VecCfg &vec_cfg()
     static bool init = false;
     if (!init) {
         init = true;
-        if (const char *e = getenv("SGM_VEC_CFG")) sscanf(e, "%d,%d", &c.dot_grid, &c.nodot_grid);
         if (c.dot_grid > kMaxGrid) c.dot_grid = kMaxGrid;
     }
     return c;
@@ -1887,8 +2075,7 @@ constexpr int kCoopSpinLimit = 1 << 19;       // polls (about a microsecond each
 // sliced stencil matrix on one GPU, plain or Jacobi, tree-order dots, beyond the one-workgroup kernel and up to 256 workgroups
 static bool coop_applies(sgm_solver s, sgm_mat A, sgm_pc pc, int *rmax_out, int *halo_out, bool *xl_out, bool bicg = false)
 {
-    static const bool off = getenv("SGM_CG_COOP") && atoi(getenv("SGM_CG_COOP")) == 0;
-    if (off || !(bicg ? s->opt.bicgstab_small : s->opt.cg_small) || s->multi || s->seq || A->parts.size() != 1 || A->comm ||
+    if (!(bicg ? s->opt.bicgstab_small : s->opt.cg_small) || s->multi || s->seq || A->parts.size() != 1 || A->comm ||
         (A->fmt != SGM_FMT_CSR && A->fmt != SGM_FMT_ELL) || prof_on())
         return false;
     const Part &p = A->parts[0];
@@ -1901,11 +2088,12 @@ static bool coop_applies(sgm_solver s, sgm_mat A, sgm_pc pc, int *rmax_out, int 
     // the stencil's reach in rows (the largest |offset| of THIS matrix's dictionary, kept on the part where the dictionary is
     // built -- never cached on the solver: one handle may serve matrices of the same size and different stencils)
     const int H = (p.dict_reach + 1) & ~1;
-    static const int force_rmax = getenv("SGM_CG_COOP_RMAX") ? atoi(getenv("SGM_CG_COOP_RMAX")) : 0;
+    // option cg_coop_variant: low four bits = rows per thread pinned (1, 2, 4, 8; 0 = chosen by size), 16 = never the one-XCD variant
+    const int force_rmax = s->opt.cg_coop_variant & 15;
     // XCD-local variant: the whole system on the <= 32 CUs of one XCD, 1, 2 or 3 rows per thread with the matrix in registers
     // (4 rows per thread stream the matrix through one XCD's L2 / fabric port: 8.6-9.8 us per iteration at n = 1e5 .. 1.3e5
     // where the all-CU variant with one row per thread takes ~8.5)
-    static const bool xl_off = getenv("SGM_CG_COOP_XCD") && atoi(getenv("SGM_CG_COOP_XCD")) == 0;
+    const bool xl_off = (s->opt.cg_coop_variant & 16) != 0;
     *xl_out = false;
     if (!xl_off && !s->coop_xl_retired && g_rt.num_cu >= 64) {
         for (int rmax : {1, 2, 3, 4}) {
@@ -1972,8 +2160,7 @@ static int run_cg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_
     for (int resume = 0;; resume = 1) {
         int64_t it_end = iters + s->small_chunk();
         if (s->max_iter > 0) it_end = std::min<int64_t>(it_end, s->max_iter);
-        static const int spin_env = getenv("SGM_CG_COOP_SPIN") ? atoi(getenv("SGM_CG_COOP_SPIN")) : 0;
-        const int spin = spin_env > 0 ? spin_env : kCoopSpinLimit;
+        const int spin = s->opt.coop_spin_limit > 0 ? s->opt.coop_spin_limit : kCoopSpinLimit;
 #define LC(R, J, W, X)                                                                                                 \
     do {                                                                                                             \
         if (!allow_lds((const void *)k_cg_coop<R, J, W, X>, lds)) return SGM_OK;                                      \
@@ -2001,7 +2188,7 @@ static int run_cg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_
 #define LCJ(R, W, X) do { if (jac) LC(R, true, W, X); else LC(R, false, W, X); } while (0)
         // the matrix in registers where RMAX * sw doubles fit beside x, r and the temporaries
 #define LCW(R, X) do { if (p.sw == 3) LCJ(R, 3, X); else if (p.sw == 5) LCJ(R, 5, X); else if (p.sw == 7) LCJ(R, 7, X); else LCJ(R, 8, X); } while (0)
-        static const bool stream_env = getenv("SGM_CG_COOP_STREAM") != nullptr;          // tuning aid: never keep the matrix in registers
+        constexpr bool stream_env = false;          // (true: never keep the matrix in registers -- measured slower wherever the registers hold it)
         // (RMAX = 4 with the matrix in registers spills 14-76 VGPRs, RMAX = 10 streamed 99-157: not instantiated)
         if (xl) {
             if (rmax == 1 && !stream_env) LCW(1, true);
@@ -2054,8 +2241,7 @@ static int run_cg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_
     s->last_iterations = iters;
     s->res2 = res;
     s->converged = flag;
-    static const bool trace = getenv("SGM_TRACE") != nullptr;
-    if (trace)
+    if (trace_on())
         fprintf(stderr, "[sigma_hip] cg: one cooperative launch per %lld iterations, %s, %d workgroups x %lld rows\n", (long long)s->small_chunk(),
                 xl ? "on one XCD" : "all CUs", G, (long long)rpw);
     return SGM_OK;
@@ -2162,7 +2348,7 @@ int run_cg(sgm_solver s, sgm_mat A, double *const *x, const double *const *b, sg
         { const int ks[1] = {C_PQ}; SGM_TRY(finish_dots(s, A, ks, 1, vpq, true, gen)); }
         bool fused_pc = false;
         // two-level factors on EVERY part (colour orderings): the r update, both sweeps and the partial sums of r.z in the sweeps' launches
-        bool all_fused = pk == SGM_PC_ILDU0 && !s->seq;
+        bool all_fused = pk == SGM_PC_ILDU0 && !s->seq && s->opt.reorder_solve >= 2;
         for (size_t ip = 0; all_fused && ip < P; ++ip) all_fused = pc_cg_fused_rows(pc, ip) > 0;
         for (size_t ip = 0; ip < P; ++ip) {
             PartWork &w = s->work[ip];
@@ -2722,8 +2908,7 @@ static int run_bicg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sg
     for (int resume = 0;; resume = 1) {
         int64_t it_end = iters + s->small_chunk();
         if (s->max_iter > 0) it_end = std::min<int64_t>(it_end, s->max_iter);
-        static const int spin_env = getenv("SGM_CG_COOP_SPIN") ? atoi(getenv("SGM_CG_COOP_SPIN")) : 0;
-        const int spin = spin_env > 0 ? spin_env : kCoopSpinLimit;
+        const int spin = s->opt.coop_spin_limit > 0 ? s->opt.coop_spin_limit : kCoopSpinLimit;
 #define LB(R, J, W, X)                                                                                                 \
     do {                                                                                                             \
         if (!allow_lds((const void *)k_bicg_coop<R, J, W, X>, lds)) return SGM_OK;                                    \
@@ -2735,7 +2920,7 @@ static int run_bicg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sg
 #define LBJ(R, W, X) do { if (jac) LB(R, true, W, X); else LB(R, false, W, X); } while (0)
 #define LBX(R, W) do { if (xl) LBJ(R, W, true); else LBJ(R, W, false); } while (0)
         // the matrix in registers where it fits beside the five vectors (one row per thread: any slice width; two: <= 5 slots)
-        static const bool stream_env = getenv("SGM_CG_COOP_STREAM") != nullptr;
+        constexpr bool stream_env = false;
         if (rmax == 1 && !stream_env) { if (p.sw == 3) LBX(1, 3); else if (p.sw == 5) LBX(1, 5); else if (p.sw == 7) LBX(1, 7); else LBX(1, 8); }
         else if (rmax == 2 && !stream_env && p.sw <= 5) { if (p.sw == 3) LBX(2, 3); else LBX(2, 5); }
         else if (rmax == 1) LBX(1, 0);
@@ -2768,8 +2953,7 @@ static int run_bicg_coop(sgm_solver s, sgm_mat A, double *x, const double *b, sg
     s->last_iterations = iters;
     s->res2 = res;
     s->converged = flag;
-    static const bool trace = getenv("SGM_TRACE") != nullptr;
-    if (trace)
+    if (trace_on())
         fprintf(stderr, "[sigma_hip] bicgstab: one cooperative launch per %lld iterations, %s, %d workgroups x %lld rows\n", (long long)s->small_chunk(),
                 xl ? "on one XCD" : "all CUs", G, (long long)rpw);
     return SGM_OK;
@@ -2968,10 +3152,14 @@ int run_gmres(sgm_solver s, sgm_mat A, double *const *x, const double *const *b,
     for (size_t ip = 0; ip < P; ++ip) v.flags[ip] = s->work[ip].flag;
     // Gram-Schmidt variant: CGS-2 (blocked, 3 passes per step) unless the option is off or the restart
     // length exceeds its 32-vector kernels; modified Gram-Schmidt (j+2 fused passes) otherwise
-    const bool cgs2 = s->opt.gmres_cgs2 && m <= 32;
+    // ... and, the default, its low-synchronisation form (k_gsl: two passes, two reductions per step)
+    const bool lowsync = s->opt.gmres_cgs2 == 1 && m <= 32;
+    const bool cgs2 = s->opt.gmres_cgs2 == 2 && m <= 32;
     // partial array ids.  MGS: 0..m = h column (h_0..h_j, norm at j+1), NRM = m+1 the start norm.
     // CGS-2: 0..m-1 = h1, H2.. = h2, NRM = norm (start norm and step norm)
-    const int H2 = m + 1, NRM = cgs2 ? 2 * m + 2 : m + 1;
+    // low-sync: 0..k = g and t of pass 1, LS2.. = c and d of pass 2, NRM = the start norm
+    const int LS2 = 36;
+    const int H2 = m + 1, NRM = lowsync ? 71 : cgs2 ? 2 * m + 2 : m + 1;
     int64_t done_steps = 0;
     int flag = 0; int64_t iters = 0; double res = 0.0;
 
@@ -3026,6 +3214,44 @@ int run_gmres(sgm_solver s, sgm_mat A, double *const *x, const double *const *b,
         if (s->max_iter > 0) steps = (int)std::min<int64_t>(m, s->max_iter - done_steps);
         for (int j = 0; j < steps; ++j) {
             SGM_TRY(apply_A(1, j, wv.data()));
+            if (lowsync) {
+                const int k = j + 1;                 // stored columns s_0 .. s_j; the step writes s_k
+                auto pass = [&](int mode, PartWork &w, double *out) {
+#define SGM_GSL(KB)                                                                                             \
+    do {                                                                                                        \
+        if (mode == 0) hipLaunchKernelGGL((k_gsl<KB, 0>), dim3(dot_grid(w.n)), dim3(kBlock), 0, g_rt.stream, w.n, k, (const double *)w.vec[G_W], \
+                                          w.V, w.next, (const double *)w.gmres->coef, out, (const int *)w.flag); \
+        else hipLaunchKernelGGL((k_gsl<KB, 1>), dim3(dot_grid(w.n)), dim3(kBlock), 0, g_rt.stream, w.n, k, (const double *)w.vec[G_W], \
+                                w.V, w.next, (const double *)w.gmres->coef, out, (const int *)w.flag);          \
+    } while (0)
+                    if (k <= 4) SGM_GSL(4); else if (k <= 8) SGM_GSL(8); else if (k <= 16) SGM_GSL(16); else SGM_GSL(32);
+#undef SGM_GSL
+                };
+                auto reduce_sum = [&](int id0, int cnt) -> int {
+                    for (size_t ip = 0; ip < P; ++ip) {
+                        PartWork &w = s->work[ip];
+                        hipLaunchKernelGGL(k_reduce_many, dim3(cnt), dim3(kBlock), 0, g_rt.stream, part(s, ip, id0),
+                                           dot_grid(w.n), w.slots + id0);
+                    }
+                    if (!s->multi) return SGM_OK;
+                    std::vector<double *> ptrs(P);
+                    for (size_t ip = 0; ip < P; ++ip) ptrs[ip] = s->work[ip].slots + id0;
+                    return allreduce_slots(A, ptrs.data(), cnt);
+                };
+                for (size_t ip = 0; ip < P; ++ip) pass(0, s->work[ip], part(s, ip, 0));
+                SGM_TRY(reduce_sum(0, k + 1));
+                for (size_t ip = 0; ip < P; ++ip)
+                    hipLaunchKernelGGL(k_gmres_ls1, dim3(1), dim3(64), 0, g_rt.stream, (const double *)s->work[ip].slots, s->work[ip].gmres,
+                                       (const int *)s->work[ip].flag);
+                for (size_t ip = 0; ip < P; ++ip) pass(1, s->work[ip], part(s, ip, LS2));
+                SGM_TRY(reduce_sum(LS2, k + 1));
+                for (size_t ip = 0; ip < P; ++ip) {
+                    PartWork &w = s->work[ip];
+                    hipLaunchKernelGGL(k_gmres_ls2, dim3(1), dim3(64), 0, g_rt.stream, (const double *)(w.slots + LS2), m, w.gmres,
+                                       s->tolerance, w.flag, w.iters, ip == 0 ? w.history : nullptr, s->hist_cap, w.res);
+                }
+                continue;
+            }
             if (cgs2) {
                 const int k = j + 1;
                 auto gs = [&](int mode, PartWork &w, const double *h_in, double *out) {
@@ -3094,6 +3320,7 @@ int run_gmres(sgm_solver s, sgm_mat A, double *const *x, const double *const *b,
         for (size_t ip = 0; ip < P; ++ip) {
             PartWork &w = s->work[ip];
             hipLaunchKernelGGL(k_gmres_solve_y, dim3(1), dim3(64), 0, g_rt.stream, w.gmres, m);
+            if (lowsync) hipLaunchKernelGGL(k_gmres_ls_y, dim3(1), dim3(64), 0, g_rt.stream, w.gmres);      // (x += V y = S (R^-1 y))
             launch_elem(w.n, FGmresUpdate{x[ip], w.V, w.next, w.gmres}, nullptr);
         }
         SGM_HIP(hipGetLastError());
@@ -3143,10 +3370,9 @@ int sgm_solver_setup(sgm_solver s, sgm_mat A)
     s->iterations = 0;          // cg_solvers.f90:72
     s->multi = A->distributed();
     {
-        static const int rs_env = getenv("SGM_REDUCE_SINGLE") ? atoi(getenv("SGM_REDUCE_SINGLE")) : -1;      // tuning aid
         // (BiCGStab: six scalars per update kernel, C3 2535 -> 2859 it/s; CG: two or three, C2 4650 -> 4730)
         s->reduce_single = !s->multi && A->fmt != SGM_FMT_COMPOSITE && (s->kind == SGM_SOLVER_BICGSTAB || s->kind == SGM_SOLVER_CG) &&
-                           (rs_env >= 0 ? rs_env != 0 : A->nrow >= (1 << 21));
+                           A->nrow >= (1 << 21);
     }
     bool realloc = !s->initialized || s->work.size() != A->parts.size();
     for (size_t ip = 0; !realloc && ip < A->parts.size(); ++ip)
@@ -3258,7 +3484,7 @@ int sgm_solver_solve(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc
     // permutations of r and z around every apply.  Only for the matrix the preconditioner was set up with, unchanged since.
     sgm_mat Arun = A;
     struct PermScope { sgm_pc pc = nullptr; ~PermScope() { if (pc) pc_in_permuted(pc, false); } } perm_scope;
-    static const bool perm_off = getenv("SGM_SOLVE_PERMUTED") && atoi(getenv("SGM_SOLVE_PERMUTED")) == 0;      // tuning aid / tests
+    const bool perm_off = s->opt.reorder_solve == 0;      // (option reorder_solve: 0 = r and z permuted around every apply instead)
     if (sgm_mat Ap = perm_off ? nullptr : pc_permuted_matrix(pc, A); Ap && Ap->parts.size() == P && Ap->nrow == A->nrow) {
         if (!s->perm_x) SGM_TRY(dalloc(&s->perm_x, (size_t)nvec + 2));
         if (!s->perm_b) SGM_TRY(dalloc(&s->perm_b, (size_t)nvec + 2));
@@ -3391,7 +3617,6 @@ int sgm_lanczos(sgm_mat A, int32_t nsteps, const double *q1, double *T_host, dou
     SGM_TRY(require_init());
     if (!A || nsteps < 2 || !q1 || !T_host) return fail(SGM_ERR_BAD_ARG, "sgm_lanczos: bad argument");
     if (A->nrow != A->ncol) return fail(SGM_ERR_DIMS, "sgm_lanczos: square matrices only");
-    if (A->fmt == SGM_FMT_COMPOSITE && A->comm) return fail(SGM_ERR_UNSUPPORTED, "sgm_lanczos: composites over distributed leaves are not supported");
     LzCtx L;
     SGM_TRY(L.init(A));
     const int64_t n = L.nloc, ld = L.ld;
@@ -3475,8 +3700,11 @@ int sgm_generalized_lanczos(sgm_mat A, sgm_mat B, sgm_solver solver, sgm_pc pc, 
     if (!A || !B || !solver || nsteps < 2 || !q1 || !T_host) return fail(SGM_ERR_BAD_ARG, "sgm_generalized_lanczos: bad argument");
     if (A->nrow != A->ncol || B->nrow != B->ncol || A->nrow != B->nrow)
         return fail(SGM_ERR_DIMS, "sgm_generalized_lanczos: A and B must be square and of one size");
-    if ((A->comm != B->comm) || A->parts.size() != B->parts.size() || A->fmt == SGM_FMT_COMPOSITE || B->fmt == SGM_FMT_COMPOSITE)
-        return fail(SGM_ERR_UNSUPPORTED, "sgm_generalized_lanczos: A and B must be leaf matrices partitioned the same way");
+    // (composites -- the reference's own test runs on one, eigensolver_test_generalized_lanczos.f90:150 -- work on their local
+    //  vector layout: the concatenation of this rank's slices of the block vectors, the same for A and B)
+    if ((A->comm != B->comm) || A->parts.size() != B->parts.size() || (A->fmt == SGM_FMT_COMPOSITE) != (B->fmt == SGM_FMT_COMPOSITE) ||
+        (A->fmt == SGM_FMT_COMPOSITE && (A->blk_row_ptr != B->blk_row_ptr || A->blk_col_ptr != B->blk_col_ptr)))
+        return fail(SGM_ERR_UNSUPPORTED, "sgm_generalized_lanczos: A and B must be partitioned (and, composites, blocked) the same way");
     for (size_t ip = 0; ip < A->parts.size(); ++ip)
         if (A->parts[ip].n != B->parts[ip].n || A->parts[ip].row_begin != B->parts[ip].row_begin)
             return fail(SGM_ERR_UNSUPPORTED, "sgm_generalized_lanczos: A and B must be partitioned the same way");

@@ -1286,6 +1286,7 @@ int spmv_grid(const Part &p)       // = number of partial sums one SpMV leaves p
 {
     if (p.dot_grid_override) return p.dot_grid_override;
     if (p.ecol) return ell_grid(p);
+    if (use_ell_colblock(p)) return ell_colblock_grid(p);
     RowRange r[3];
     const int nr = spmv_ranges(p, r);
     return nr ? r[nr - 1].part_off + r[nr - 1].grid : 8;
@@ -1766,6 +1767,13 @@ int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
                 else launch_ell<false>(p, grid, x[ip], y[ip], w, pwy, pyy, flag_done, gen);
                 continue;
             }
+            if (use_ell_colblock(p)) {         // a CSR matrix with scattered columns (no halo: single-GPU parts only)
+                if (pass == 1) continue;
+                const int grid = ell_colblock_grid(p);
+                if (grid_out) *grid_out = grid;
+                SGM_TRY(launch_ell_colblock(p, grid, x[ip], y[ip], add, chain, w, pwy, pyy, flag_done, gen));
+                continue;
+            }
             RowRange r[3];
             const int nr = spmv_ranges(p, r, dots != nullptr);
             if (grid_out) *grid_out = spmv_grid(p);
@@ -2190,6 +2198,10 @@ static int build_offset_dict(Part &p, const int32_t *, const int32_t *)
     p.max_row = hcnt[1];
     // without a dictionary (option off at creation, or more than 255 offsets): try the int32 sliced form
     auto sliced32 = [&]() -> int {
+        // scattered columns (x far beyond the L2s' reach, no offset structure): the column-blocked two-phase form the ELLPACK
+        // matrices of that kind get (sgm_ellcb.hip) -- every gather an LDS access; same products, same order of additions
+        SGM_TRY(build_ell_colblock(p));
+        if (p.cb_P) return SGM_OK;
         const int W = p.max_row <= 3 ? 3 : p.max_row <= 5 ? 5 : p.max_row <= 7 ? 7 : p.max_row <= 8 ? 8 : p.max_row <= 12 ? 12
                     : p.max_row <= 16 ? 16 : p.max_row <= 20 ? 20 : p.max_row <= 24 ? 24 : p.max_row <= 28 ? 28 : 32;
         if (!p.opt.csr_sliced || p.max_row < 1 || p.max_row > 32 || (double)W * n > 1.25 * (double)nnz) return build_sell(p);
@@ -2831,6 +2843,7 @@ int sgm_csr_set_values(sgm_mat A, const double *val, int where)
                                g_rt.stream));
         off += p.nnz;
         SGM_TRY(pack_sliced(p));
+        if (p.cb_P) SGM_TRY(refresh_ell_colblock_values(p));
         csr_release_arrays(p);
     }
     SGM_HIP(hipStreamSynchronize(g_rt.stream));
@@ -2941,7 +2954,8 @@ int sgm_mat_set_option(sgm_mat A, const char *name, int value)
         const int old = *f;
         *f = v;
         if (old == v) continue;
-        if (p.ecol && (cb_shape || (!strcmp(name, "ell_colblock") && ((old != 0) != (v != 0) || v == 2 || old == 2)))) {
+        if ((p.ecol || (!p.lean && p.rowptr && p.col && p.val && p.n_halo == 0 && !p.sval && !p.sl_val)) &&
+            (cb_shape || (!strcmp(name, "ell_colblock") && ((old != 0) != (v != 0) || v == 2 || old == 2)))) {
             SGM_TRY(build_ell_colblock(p));           // (frees the old form first; decides again whether the matrix wants one)
             SGM_TRY(refresh_ell_colblock_values(p));
             SGM_HIP(hipStreamSynchronize(g_rt.stream));
@@ -3125,7 +3139,8 @@ int sgm_mat_kernel(sgm_mat A, char *buf, int len)
             else if (use_sliced_ell(p)) snprintf(name, sizeof name, "k_csr_sl<W=%d>", p.sw);
             else if (p.ecode && p.opt.ell_offset_dict) snprintf(name, sizeof name, "k_ell_do<MDP=%d>", p.emdp);
             else snprintf(name, sizeof name, "k_ell_spmv");
-        } else if (use_sliced(p)) snprintf(name, sizeof name, "k_csr_sl<W=%d>", p.sw);
+        } else if (use_ell_colblock(p)) snprintf(name, sizeof name, "k_ellcb<cols=%d,R=%d,csr>", p.cb_cols, p.cb_R);
+        else if (use_sliced(p)) snprintf(name, sizeof name, "k_csr_sl<W=%d>", p.sw);
         else if (use_slicedb(p)) snprintf(name, sizeof name, "k_csr_slb<W=%d>", p.sw);
         else if (use_sliced32(p)) snprintf(name, sizeof name, "k_csr_sl32<W=%d>", p.sw);
         else if (use_sell(p)) snprintf(name, sizeof name, "k_csr_sell<pad=%.3f>", p.nnz ? (double)p.sl_total / (double)p.nnz : 1.0);
@@ -3173,7 +3188,8 @@ static int64_t part_matvec_bytes(const sgm_mat_s *A, const Part &p)
         if (use_sliced_ell(p)) m = nsl * kSlRows * (8 * (int64_t)p.sw + 4);
         else if (p.ecode && p.opt.ell_offset_dict) m = (int64_t)p.n * (8 * (int64_t)p.max_d + p.emdp);
         else m = 12 * (int64_t)p.n * p.max_d;
-    } else if (use_sliced(p)) m = nsl * kSlRows * (8 * (int64_t)p.sw + 4);
+    } else if (use_ell_colblock(p)) return ell_colblock_matvec_bytes(p);
+    else if (use_sliced(p)) m = nsl * kSlRows * (8 * (int64_t)p.sw + 4);
     else if (use_slicedb(p)) m = nsl * kSlRows * (8 * (int64_t)p.sw + (p.sw + 7) / 8 * 8);
     else if (use_sliced32(p)) m = nsl * kSlRows * 12 * (int64_t)p.sw;
     else if (use_sell(p)) m = 12 * p.sl_total + 2 * nsl * kSlRows + 8 * nsl * (kSlRows / kSellChunk);      // slots (entries + padding), positions, chunk offsets

@@ -382,6 +382,16 @@ interface
         integer(c_int64_t), intent(out) :: resident_bytes, matvec_bytes
         integer(c_int) :: rc
     end function
+    function sgm_pc_info(pc, part, out4, est_us, path_name, len) bind(c, name='sgm_pc_info') result(rc)
+        import :: c_ptr, c_int, c_int32_t, c_double, c_char
+        type(c_ptr), value :: pc
+        integer(c_int32_t), value :: part
+        integer(c_int32_t), intent(out) :: out4(4)
+        real(c_double), intent(out) :: est_us
+        character(kind=c_char), intent(out) :: path_name(*)
+        integer(c_int), value :: len
+        integer(c_int) :: rc
+    end function
     function sgm_pc_get(pc, name, out, bytes, needed) bind(c, name='sgm_pc_get') result(rc)
         import
         type(c_ptr), value :: pc
@@ -742,6 +752,7 @@ contains
     generic :: solve => solve_plain, solve_pc
     procedure :: solve_device => hip_solver_solve_device
     procedure :: set_option => hip_solver_set_option
+    procedure :: info => hip_solver_pc_info
     procedure :: set_max_iter => hip_solver_set_max_iter
     procedure :: destroy => hip_solver_destroy
 end type hip_linear_solver
@@ -1138,6 +1149,36 @@ subroutine hip_solver_set_option(s, name, value)
     else
         call hip_check(sgm_solver_set_option(s%handle, trim(name) // c_null_char, int(value, c_int)))
     endif
+end subroutine
+
+subroutine hip_solver_pc_info(s, levels, path, colours, est_us, name, part)
+    ! a preconditioner that has been set up (jacobi / ldu): which sweeps serve its applies and what one costs (sgm_pc_info) --
+    ! levels(2) of L and U, path 0 diagonal / 1 row space / 2 strip pipeline / 3 slab pipeline / 4 level walkers, colours of
+    ! the ordering (0 = A's own), estimated microseconds per apply, the same in words ("strip pipeline, 6323 levels")
+    class(hip_linear_solver), intent(inout) :: s
+    integer, intent(out) :: levels(2), path, colours
+    real(dp), intent(out) :: est_us
+    character(len=*), intent(out) :: name
+    integer, intent(in), optional :: part
+    integer(c_int32_t) :: o(4)
+    real(c_double) :: us
+    character(kind=c_char) :: buf(160)
+    integer :: k, ip
+    ip = 0
+    if (present(part)) ip = part
+    if (s%kind <= 10) then
+        print *, 'info: not a preconditioner'
+        print *, 'Terminating.'
+        call exit(1)
+    endif
+    call hip_solver_make_handle(s)
+    call hip_check(sgm_pc_info(s%handle, int(ip, c_int32_t), o, us, buf, 160_c_int))
+    levels = int(o(1:2)); path = int(o(3)); colours = int(o(4)); est_us = real(us, dp)
+    name = ' '
+    do k = 1, min(len(name), 160)
+        if (buf(k) == c_null_char) exit
+        name(k:k) = buf(k)
+    enddo
 end subroutine
 
 subroutine hip_solver_setup_handle(s, Ah, nrow)

@@ -372,6 +372,18 @@ subroutine test_device_vectors()                                           !
         pr => hip_ldu(reorder = "colour")
         call pn%setup(A)
         call pr%setup(A)
+        block      ! sgm_pc_info: what will serve the applies -- natural order: many dependency levels; colour order: two
+            integer :: lv(2), lc(2), path, ncol
+            real(dp) :: est
+            character(len=80) :: what
+            call pn%info(lv, path, ncol, est, what)
+            print *, 'hip_ldu():                  ', trim(what), ' about', est, 'us per apply'
+            if (ncol /= 0) call fail('natural-order ILDU reports an ordering', real(ncol, dp))
+            call pr%info(lc, path, ncol, est, what)
+            print *, 'hip_ldu(reorder = "colour"):', trim(what), ' about', est, 'us per apply'
+            if (ncol /= 2 .or. lc(1) /= 2 .or. lc(2) /= 2 .or. path /= 1 .or. lv(1) <= lc(1)) &
+                & call fail('colour-ordered ILDU is not two row-space levels', real(lc(1), dp))
+        end block
         call s%setup(A)
         u3 = 0.0_dp
         call s%solve(A, u3, f, pn)

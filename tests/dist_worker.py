@@ -179,6 +179,16 @@ def run(rank, world, port, case, res):
         ye = np.zeros(e1 - e0)
         He.matvec(xel, ye)
         assert np.array_equal(ye, E.matvec(xe_full)[e0:e1]), "distributed ELLPACK rows differ from ellpack_matvec_add"
+        # ... and the transposed products (ellpack_matvec_t_add, ellpack_matrices.f90:670-693: the scatter runs over ALL max_d
+        # slots, padding included -- they are stored entries here): every y(i) the reference's terms in the reference's order
+        te_ref = E.matvec_t(xe_full)
+        te = np.full(e1 - e0, 4.0)
+        He.matvec_t(xe_full[e0:e1].copy(), te)
+        assert np.array_equal(te, te_ref[e0:e1]), "distributed ELLPACK matvec_t differs from ellpack_matvec_t_add"
+        ye0 = np.random.RandomState(5).standard_normal(ne)
+        tea = ye0[e0:e1].copy()
+        He.matvec_t_add(xe_full[e0:e1].copy(), tea)
+        assert np.array_equal(tea, E.matvec_t_add(xe_full, ye0.copy())[e0:e1])
         He.destroy()
 
         # ---- Krylov loops with all-reduced dots
@@ -238,6 +248,37 @@ def run(rank, world, port, case, res):
                 u0, it0, hist0 = fused[(nm, 0)]
                 assert it == it0 and np.array_equal(u, u0) and np.array_equal(hist, hist0), ("dist_halo_fused", nm, mode, it, it0)
             out["halo_fused_modes"] = {"iterations": fused[("cg", 1)][1], "bit_identical_to_exchanging_p": True}
+            # ---- ldu(reorder="colour") over the ranks: every rank orders its own diagonal block (greedy_color_ordering of
+            #      A_kk's graph, no communication), block-Jacobi ILDU(0) of the ordered blocks, the solve in the permuted
+            #      order rank by rank.  Oracle: the same ordering block by block, A permuted by it, PCG with ILDU(0) of its
+            #      block-diagonal part.  (Not for the long-row matrix: its blocks are not bipartite, nothing to gain.)
+            if case in ("poisson2d", "laplace3d"):
+                pglob = np.zeros(n, np.int32)
+                for kq in range(world):
+                    q0, q1 = int(starts[kq]), int(starts[kq + 1])
+                    a0, a1 = Ab.ptr[q0] - 1, Ab.ptr[q1] - 1
+                    Bq = orc.CsrMatrix(q1 - q0, q1 - q0, (Ab.ptr[q0:q1 + 1] - a0).astype(np.int32), (Ab.node[a0:a1] - q0).astype(np.int32), Ab.val[a0:a1].copy())
+                    pglob[q0:q1] = orc.greedy_color_ordering(Bq)[0] + q0
+                Apm = orc.permuted(A, pglob, pglob)
+                rowsP = np.repeat(np.arange(n), np.diff(Apm.ptr))
+                keepP = blk[rowsP] == blk[Apm.node - 1]
+                cntP = np.bincount(rowsP[keepP], minlength=n)
+                AbP = orc.CsrMatrix(n, n, np.concatenate([[1], 1 + np.cumsum(cntP)]).astype(np.int32), Apm.node[keepP].copy(), Apm.val[keepP].copy())
+                bpm = np.empty(n); bpm[pglob - 1] = b
+                urp, itrp = orc.cg(Apm, bpm, tol=1e-12, pc=orc.Ildu(AbP))[:2]
+                for mode in (2, 0):
+                    sv = sg.cg(1e-12)
+                    sv.set_option("reorder_solve", mode)
+                    sv.setup(H)
+                    pcm = sg.ldu(reorder="colour")
+                    pcm.setup(H)
+                    u = np.zeros(n_own)
+                    sv.solve(H, u, bl, pcm)
+                    relc = float(np.abs(u - urp[pglob - 1][r0:r1]).max() / np.abs(urp).max())
+                    assert abs(sv.iterations - itrp) <= 1 and relc <= 1e-10, ("cg_ildu_colour", mode, sv.iterations, itrp, relc)
+                    out[f"cg_ildu_colour_mode{mode}"] = {"iterations": int(sv.iterations), "oracle_iterations": int(itrp), "rel": relc}
+                    sv.destroy()
+                    pcm.destroy()
         else:
             check("bicgstab_jacobi", sg.bicgstab(1e-12), sg.jacobi, orc.bicgstab(A, b, tol=1e-12, pc=orc.Jacobi(A)),
                   lambda i: max(2, 0.1 * i), 1e-10)
@@ -383,6 +424,36 @@ def run_composite(rank, world, comm, dev, res):
         rel = float(np.abs(u - local(ur)).max() / np.abs(ur).max())
         out[name] = {"iterations": int(s.iterations), "oracle_iterations": int(itr), "rel": rel}
         assert abs(s.iterations - itr) <= 2 and rel <= 1e-11, (name, s.iterations, itr, rel)
+    # Lanczos on the composite (src/eigensolver.f90:27-90: only A%matvec and dot products -- the block loops above and
+    # all-reduces): T the same on every rank and the oracle's serial run's, Q this rank's slices of the block vectors
+    q1 = np.random.RandomState(12).random_sample(n) * 2 - 1
+    Tl, Ql = sg.lanczos(S, 16, local(q1))
+    Tlo, Qlo = orc.lanczos(A, 16, q1)
+    assert np.abs(Tl - Tlo).max() <= 1e-9, float(np.abs(Tl - Tlo).max())
+    assert np.abs(Ql[:, :8] - np.stack([local(Qlo[:, c]) for c in range(8)], axis=1)).max() <= 1e-10
+    out["lanczos_composite"] = {"iterations": 16, "T_max_diff": float(np.abs(Tl - Tlo).max())}
+    # generalized Lanczos, A and B composites over the same distributed leaves' partitions, B%solve = CG(1e-14) over the
+    # ranks (the reference's own test runs it on a composite: eigensolver_test_generalized_lanczos.f90:150)
+    rowsg = np.repeat(np.arange(1, n + 1), np.diff(ptr))
+    bval = np.where(rowsg == node, 1.0 + (rowsg % 7) / 16.0, -1.0 / 16.0)
+    Bsp = sp.csr_matrix((bval, node - 1, ptr - 1), shape=(n, n))
+    Bsp.sort_indices()
+    SB = sg.sparse_matrix(np.array([1, m + 1, n + 1], np.int32), np.array([1, m + 1, n + 1], np.int32))
+    leaves_b = []
+    for i in range(2):
+        for j in range(2):
+            Bb = Bsp[cuts[i]:cuts[i + 1], cuts[j]:cuts[j + 1]].tocsr()
+            Bb.sort_indices()
+            r0, r1 = int(parts[i][rank]), int(parts[i][rank + 1])
+            Lb = Bb[r0:r1]
+            leaves_b.append(sg.dist_csr_matrix(comm, parts[i], (Lb.indptr + 1).astype(np.int32), (Lb.indices + 1).astype(np.int32),
+                                               Lb.data.copy(), col_starts=parts[j]))
+            SB.set_submatrix(i + 1, j + 1, leaves_b[-1])
+    SB.set_solver(sg.cg(1e-14))
+    Tg, Qg = sg.generalized_lanczos(S, SB, 10, local(q1))
+    Tgo, Qgo = orc.generalized_lanczos(A, orc.CsrMatrix(n, n, ptr, node, bval), 10, q1, 1e-14)
+    assert np.abs(Tg - Tgo).max() <= 1e-9 and np.abs(Qg - np.stack([local(Qgo[:, c]) for c in range(10)], axis=1)).max() <= 1e-9
+    out["generalized_lanczos_composite"] = {"iterations": 10, "T_max_diff": float(np.abs(Tg - Tgo).max())}
     res["solves"] = out
     res["n_local"] = int(len(xl))
     res["n_halo"] = int(sum(leaves_d[i][j].x_len - leaves_d[i][j].nc_local for i in range(2) for j in range(2)))

@@ -166,9 +166,16 @@ def test_reference_side_binding_links_and_dies_like_the_reference_without_a_gpu(
 
 
 def test_integration_md_quotes_the_compiled_binding_verbatim():
+    """INTEGRATION.md shows excerpts of the compiled binding (tools/sync_integration_md.py refreshes them): every fenced
+    Fortran block of the document is verbatim text of oracle/hip_binding.f90, and the document stays a document."""
     src = open(os.path.join(ROOT, "oracle", "hip_binding.f90")).read()
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    assert src.strip() in doc, "INTEGRATION.md must carry oracle/hip_binding.f90 verbatim (tools/sync_integration_md.py)"
+    blocks = re.findall(r"```fortran\n(.*?)\n```", doc, flags=re.S)
+    assert len(blocks) >= 4
+    for b in blocks:
+        assert b in src, "an excerpt in INTEGRATION.md is not verbatim text of oracle/hip_binding.f90:\n" + b[:200]
+    assert len(doc.splitlines()) <= 400, "INTEGRATION.md is the flows + excerpts, not a copy of the binding"
+    assert "Which parity gate each dot order meets" in doc and "9388" in doc and "sgm_pc_info" in doc
 
 
 def test_one_hip_runtime_per_process_whichever_side_loads_first():
@@ -227,14 +234,26 @@ def test_every_documented_option_is_accepted_and_unknown_names_are_refused():
     src = open(os.path.join(ROOT, "sigma_amd", "csrc", "sgm_runtime.hip")).read()
     known = set(re.findall(r"SGM_OPT\((?:mat|solver|pc), ([a-z_0-9]+)\)", src)) | {"dist_force_collectives"}
     assert names == known, (names - known, known - names)
-    assert len(known) <= 22            # 21 per-handle options + the one process-wide switch
+    assert len(known) <= 26            # 25 per-handle options + the one process-wide switch
+    # ... and nothing else selects a kernel or an arithmetic order: the library reads three environment variables, none of which
+    # changes a result -- SGM_TRACE (which path ran, on stderr), SGM_PC_TIMING (setup phase times on stderr),
+    # SGM_RCCL_LIB (which RCCL build to dlopen)
+    envs = set()
+    for fn in os.listdir(os.path.join(ROOT, "sigma_amd", "csrc")):
+        if fn.endswith((".hip", ".hpp")):
+            envs |= set(re.findall(r'getenv\("([A-Z_0-9]+)"\)', open(os.path.join(ROOT, "sigma_amd", "csrc", fn)).read()))
+    assert envs == {"SGM_TRACE", "SGM_PC_TIMING", "SGM_RCCL_LIB"}, envs
+    nsites = sum(open(os.path.join(ROOT, "sigma_amd", "csrc", fn)).read().count("getenv(") for fn in os.listdir(os.path.join(ROOT, "sigma_amd", "csrc"))
+                 if fn.endswith((".hip", ".hpp")))
+    assert nsites <= 5, nsites
     # the measured-slower paths of round 3 are gone
     for gone in ("ell_colblock_band", "ell_colblock_pieces", "ell_colblock_nt", "slice_sched_band", "cg_small_chunk",
                  "krylov_graph_after", "ell_colblock_chunks"):
         assert gone not in known and sg.lib().sgm_set_option(gone.encode(), 1) != 0
     lib = sg.lib()
     defaults = {"ell_colblock_cols": 16384, "ell_colblock_rows": 0, "slice_sched": 0, "dot_order": 0, "ildu_reorder": 0,
-                "pipeline_spin_limit": 0, "dist_force_collectives": 0, "dist_halo_fused": 1}
+                "pipeline_spin_limit": 0, "dist_force_collectives": 0, "dist_halo_fused": 1, "coop_spin_limit": 0,
+                "cg_coop_variant": 0, "reorder_solve": 2, "coloring_pass": 0}
     for nm in sorted(known):
         assert lib.sgm_set_option(nm.encode(), defaults.get(nm, 1)) == 0, nm          # (set to its default: nothing changes)
     assert lib.sgm_set_option(b"no_such_option", 1) != 0

@@ -112,8 +112,7 @@ def test_cooperative_cg_cut_into_launches_and_capped(orc):
 
 
 def test_cooperative_cg_gives_up_loudly_and_the_launch_loop_takes_over(tmp_path):
-    """Every wait is bounded.  With a spin limit of 1 (SGM_CG_COOP_SPIN, a test hook read at the first cooperative solve of
-    a process) a hand-off gives up at once: nothing of x has been written, the solver says so on stderr, retires the
+    """Every wait is bounded.  With a spin limit of 1 (solver option coop_spin_limit) a hand-off gives up at once: nothing of x has been written, the solver says so on stderr, retires the
     cooperative kernel for that handle and runs the launch loop -- same answer."""
     code = ("import sys; sys.path.insert(0, %r)\n"
             "import numpy as np, sigma_amd as sg\n"
@@ -123,13 +122,12 @@ def test_cooperative_cg_gives_up_loudly_and_the_launch_loop_takes_over(tmp_path)
             "ptr, node, val = P.poisson2d_csr(200, 160)\n"
             "A = sg.csr_matrix(n, n, ptr, node, val)\n"
             "b = np.full(n, 1.0 / n)\n"
-            "s = sg.cg(1e-10); s.setup(A)\n"
+            "s = sg.cg(1e-10); s.set_option('coop_spin_limit', 1); s.setup(A)\n"
             "u = np.zeros(n); s.solve(A, u, b)\n"
             "s2 = sg.cg(1e-10); s2.set_option('cg_small', 0); s2.setup(A)\n"
             "u2 = np.zeros(n); s2.solve(A, u2, b)\n"
             "print('ITS', s.iterations, s2.iterations, bool(np.array_equal(u, u2)))\n" % ROOT)
-    env = dict(os.environ, SGM_CG_COOP_SPIN="1")
-    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     its = [ln for ln in p.stdout.splitlines() if ln.startswith("ITS")][0].split()
     assert its[1] == its[2] and its[3] == "True", p.stdout          # the fallback IS the launch loop: bit-identical to it
@@ -138,7 +136,7 @@ def test_cooperative_cg_gives_up_loudly_and_the_launch_loop_takes_over(tmp_path)
 
 def test_one_xcd_variant_runs_where_it_fits_and_equals_the_all_cu_variant_bit_for_bit():
     """Systems of up to 32 workgroups' rows run on the CUs of ONE XCD (hand-offs through that XCD's L2) once the participants
-    have proved their co-location; the same rows per workgroup on all CUs (SGM_CG_COOP_XCD=0) sum the same partials in the
+    have proved their co-location; the same rows per workgroup on all CUs (solver option cg_coop_variant = 16) sum the same partials in the
     same order: bit-identical solutions and histories.  SGM_TRACE names the variant that ran."""
     code = ("import sys; sys.path.insert(0, %r)\n"
             "import numpy as np, sigma_amd as sg, hashlib\n"
@@ -149,13 +147,13 @@ def test_one_xcd_variant_runs_where_it_fits_and_equals_the_all_cu_variant_bit_fo
             "    ptr, node, val = P.poisson2d_csr(nx, ny)\n"
             "    A = sg.csr_matrix(n, n, ptr, node, val)\n"
             "    b = np.cos(0.003 * np.arange(n))\n"
-            "    s = sg.cg(1e-10); s.set_history(100000); s.setup(A)\n"
+            "    s = sg.cg(1e-10); s.set_option('cg_coop_variant', int(sys.argv[1])); s.set_history(100000); s.setup(A)\n"
             "    u = np.zeros(n); s.solve(A, u, b)\n"
             "    print('SOLVE', n, s.iterations, hashlib.sha1(u.tobytes() + np.array(s.history).tobytes()).hexdigest())\n" % ROOT)
     runs = {}
-    for xcd in ("1", "0"):
-        env = dict(os.environ, SGM_CG_COOP_XCD=xcd, SGM_TRACE="1")
-        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    for xcd in ("1", "0"):          # option cg_coop_variant: + 16 = never the one-XCD variant
+        env = dict(os.environ, SGM_TRACE="1")
+        p = subprocess.run([sys.executable, "-c", code, "0" if xcd == "1" else "16"], capture_output=True, text=True, timeout=600, env=env)
         assert p.returncode == 0, p.stderr[-2000:]
         runs[xcd] = ([ln for ln in p.stdout.splitlines() if ln.startswith("SOLVE")],
                      [ln for ln in p.stderr.splitlines() if "cooperative launch" in ln])
@@ -168,9 +166,8 @@ def test_one_xcd_variant_runs_where_it_fits_and_equals_the_all_cu_variant_bit_fo
     assert on[0][3:] == off[0][3:]
     # ... and with the rows per thread pinned the two variants are the same arithmetic everywhere
     runs2 = {}
-    for xcd in ("1", "0"):
-        env = dict(os.environ, SGM_CG_COOP_XCD=xcd, SGM_CG_COOP_RMAX="4")
-        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    for xcd in ("1", "0"):          # (low four bits: rows per thread pinned to 4)
+        p = subprocess.run([sys.executable, "-c", code, "4" if xcd == "1" else "20"], capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         runs2[xcd] = [ln for ln in p.stdout.splitlines() if ln.startswith("SOLVE")]
     assert runs2["1"] == runs2["0"] and len(runs2["1"]) == 5, runs2
@@ -277,17 +274,17 @@ def test_cooperative_bicgstab_cut_into_launches_capped_and_falling_back(tmp_path
             "rows = np.repeat(np.arange(1, n + 1), np.diff(ptr)); val = val * (1.0 + 0.2 * np.sign(rows - node)) * np.where(rows == node, 1.05, 1.0)\n"
             "A = sg.csr_matrix(n, n, ptr, node, val)\n"
             "b = np.full(n, 1.0 / n)\n"
-            "s = sg.bicgstab(1e-10); s.setup(A)\n"
+            "s = sg.bicgstab(1e-10); s.set_option('coop_spin_limit', int(sys.argv[1])); s.setup(A)\n"
             "u = np.zeros(n); s.solve(A, u, b)\n"
             "s2 = sg.bicgstab(1e-10); s2.set_option('bicgstab_small', 0); s2.setup(A)\n"
             "u2 = np.zeros(n); s2.solve(A, u2, b)\n"
             "print('ITS', s.iterations, s2.iterations, bool(np.array_equal(u, u2)))\n" % ROOT)
-    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, SGM_CG_COOP_SPIN="1"))
+    p = subprocess.run([sys.executable, "-c", code, "1"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     its = [ln for ln in p.stdout.splitlines() if ln.startswith("ITS")][0].split()
     assert its[1] == its[2] and its[3] == "True", p.stdout
     assert "cooperative BiCGStab gave up waiting" in p.stderr
-    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, SGM_TRACE="1"))
+    p = subprocess.run([sys.executable, "-c", code, "0"], capture_output=True, text=True, timeout=600, env=dict(os.environ, SGM_TRACE="1"))
     assert p.returncode == 0 and "bicgstab: one cooperative launch" in p.stderr and "on one XCD" in p.stderr, p.stderr[-1000:]
 
 

@@ -55,34 +55,25 @@ def _grid_with_holes(nx, ny, seed, frac, dead_vertices=False):
 
 
 def _both_passes(H):
-    """(device-or-host result, host result) of greedy_coloring and greedy_color_ordering on one handle."""
-    os.environ.pop("SGM_COLOR_HOST", None)
-    c1, nc1 = H.greedy_coloring()
-    try:
-        o1 = H.greedy_color_ordering()
-    except sg.SigmaError as e:
-        o1 = str(e)
-    # the device pass has two forms -- parities by union-find (symmetric graphs), then the level sweep: the second alone
-    os.environ["SGM_COLOR_LEVELS"] = "1"
-    try:
-        c3, nc3 = H.greedy_coloring()
+    """(device-or-host result, host result) of greedy_coloring and greedy_color_ordering on one handle (matrix option
+    "coloring_pass": 0 = the fastest pass that applies, 1 = from the level sweep on, 2 = the sequential host pass)."""
+    def run(mode):
+        H.set_option("coloring_pass", mode)
         try:
-            o3 = H.greedy_color_ordering()
-        except sg.SigmaError as e:
-            o3 = str(e)
-    finally:
-        os.environ.pop("SGM_COLOR_LEVELS", None)
+            c, nc = H.greedy_coloring()
+            try:
+                o = H.greedy_color_ordering()
+            except sg.SigmaError as e:
+                o = str(e)
+        finally:
+            H.set_option("coloring_pass", 0)
+        return c, nc, o
+    c1, nc1, o1 = run(0)
+    # the device pass has two forms -- parities by union-find (symmetric graphs), then the level sweep: the second alone
+    c3, nc3, o3 = run(1)
     assert np.array_equal(c1, c3) and nc1 == nc3
     assert (o1 == o3) if isinstance(o1, str) else (np.array_equal(o1[0], o3[0]) and np.array_equal(o1[1], o3[1]) and o1[2] == o3[2])
-    os.environ["SGM_COLOR_HOST"] = "1"
-    try:
-        c2, nc2 = H.greedy_coloring()
-        try:
-            o2 = H.greedy_color_ordering()
-        except sg.SigmaError as e:
-            o2 = str(e)
-    finally:
-        os.environ.pop("SGM_COLOR_HOST", None)
+    c2, nc2, o2 = run(2)
     return (c1, nc1, o1), (c2, nc2, o2)
 
 
@@ -225,6 +216,37 @@ def test_colour_ordering_at_c2_size_takes_milliseconds():
     assert min(ts) < 0.12
 
 
+def test_pc_info_names_the_chain_and_the_remedy_at_c2_size():
+    """sgm_pc_info: `ldu()` of the naturally ordered 3162^2 grid -- the reference's flow,
+    solver_test_incomplete_cholesky.f90:137-141 -- is served by the strip pipeline over 3162 + 3162 - 1 = 6323 dependency
+    levels; `ldu(reorder="colour")` by two row-space levels.  SGM_TRACE prints the same at setup."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np, torch, json, sigma_amd as sg\n"
+            "from sigma_amd import problems as P\n"
+            "sg.init(0)\n"
+            "nx = 3162; n = nx * nx\n"
+            "A = sg.csr_matrix(n, n, *(torch.from_numpy(a).cuda() for a in P.poisson2d_csr(nx, nx)))\n"
+            "out = {}\n"
+            "for name, pc in (('natural', sg.ldu()), ('colour', sg.ldu(reorder='colour'))):\n"
+            "    pc.setup(A)\n"
+            "    out[name] = pc.info()\n"
+            "    pc.destroy()\n"
+            "pj = sg.jacobi(); pj.setup(A); out['jacobi'] = pj.info()\n"
+            "print('INFO ' + json.dumps(out))\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, SGM_TRACE="1"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    import json
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("INFO ")][0][5:])
+    assert d["natural"]["name"] == "strip pipeline, 6323 levels" and d["natural"]["path"] == 2 and d["natural"]["colours"] == 0, d["natural"]
+    assert d["colour"]["name"] == "row space, 2 levels" and d["colour"]["path"] == 1 and d["colour"]["colours"] == 2, d["colour"]
+    assert d["colour"]["levels"] == [2, 2] and d["natural"]["levels"] == [6323, 6323]
+    # the estimates are what tells a caller which one to take: the chain is several times the two bandwidth-bound sweeps
+    assert d["natural"]["est_us"] > 4 * d["colour"]["est_us"] > 0, (d["natural"]["est_us"], d["colour"]["est_us"])
+    assert d["jacobi"]["path"] == 0 and d["jacobi"]["levels"] == [1, 1]
+    assert "ildu setup: strip pipeline, 6323 levels" in p.stderr and "a dependency chain" in p.stderr, p.stderr[-1500:]
+    assert "ildu setup: row space, 2 levels" in p.stderr and "colour-ordered" in p.stderr, p.stderr[-1500:]
+
+
 _PERMUTED_SOLVE = r"""
 import sys, json, hashlib
 sys.path.insert(0, %r)
@@ -243,8 +265,9 @@ out = {}
 def resid(M, u):
     Au = np.zeros(n); M.matvec(u, Au)
     return float(np.abs(Au - b).max() / np.abs(b).max())
+MODE = int(sys.argv[1])
 for kind in ("cg", "bicgstab", "gmres"):
-    s = getattr(sg, kind)(1e-10); s.set_history(100000); s.setup(H)
+    s = getattr(sg, kind)(1e-10); s.set_option("reorder_solve", MODE); s.set_history(100000); s.setup(H)
     u = np.full(n, 0.125)
     s.solve(H, u, b, pc)
     out[kind] = {"iterations": int(s.iterations), "resid": resid(H, u), "u": u.tolist() if kind == "cg" else None,
@@ -253,12 +276,12 @@ for kind in ("cg", "bicgstab", "gmres"):
 # system solved must be the other matrix's
 v2 = val * (1.0 + 0.3 * np.sin(0.11 * ((rows + node) %% 97)))          # (a function of row + column: still symmetric)
 B = sg.csr_matrix(n, n, ptr, node, v2)
-s = sg.cg(1e-10); s.setup(B)
+s = sg.cg(1e-10); s.set_option("reorder_solve", MODE); s.setup(B)
 u = np.zeros(n); s.solve(B, u, b, pc)
 out["other_matrix"] = {"iterations": int(s.iterations), "resid": resid(B, u)}
 # the values of H change and the preconditioner is NOT set up again: still H's (new) system
 H.set_values(val * 0.75)
-s = sg.cg(1e-10); s.setup(H)
+s = sg.cg(1e-10); s.set_option("reorder_solve", MODE); s.setup(H)
 u = np.zeros(n); s.solve(H, u, b, pc)
 out["stale_pc"] = {"iterations": int(s.iterations), "resid": resid(H, u)}
 print("RESULT " + json.dumps(out))
@@ -268,13 +291,13 @@ print("RESULT " + json.dumps(out))
 def test_solvers_run_in_the_colour_order_and_fuse_the_sweeps_without_changing_the_iteration(orc):
     """A Krylov solve with sg.ldu(reorder="colour") runs in the permuted order (x, b permuted once each way, products on the
     preconditioner's P A P^T) and CG folds r -= alpha q and the partial sums of r.z into the two row-space sweeps.  Both are
-    the same iteration as permuting r and z around every apply / as the three separate steps (SGM_SOLVE_PERMUTED=0,
-    SGM_PCG_FUSED=0): iteration counts within one, solutions within 1e-9.  The permuted matrix stands in ONLY for the matrix
+    the same iteration as permuting r and z around every apply / as the three separate steps (solver option reorder_solve
+    = 0 / 1): iteration counts within one, solutions within 1e-9.  The permuted matrix stands in ONLY for the matrix
     the preconditioner was set up with, unchanged since."""
     import json
     runs = {}
-    for name, env in (("default", {}), ("no_permuted_solve", {"SGM_SOLVE_PERMUTED": "0"}), ("no_fused_sweeps", {"SGM_PCG_FUSED": "0"})):
-        p = subprocess.run([sys.executable, "-c", _PERMUTED_SOLVE % ROOT], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+    for name, mode in (("default", 2), ("no_permuted_solve", 0), ("no_fused_sweeps", 1)):
+        p = subprocess.run([sys.executable, "-c", _PERMUTED_SOLVE % ROOT, str(mode)], capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, p.stderr[-3000:]
         runs[name] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
     d = runs["default"]

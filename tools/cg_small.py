@@ -10,6 +10,7 @@ dev = torch.device("cuda", 0)
 GRAPH = [int(v) for v in os.environ.get("KRYLOV_GRAPH", "1,0").split(",")]
 NXS = [int(v) for v in os.environ.get("NXS", "32,100,316,1000,2000").split(",")]
 SOLVERS = os.environ.get("SOLVERS", "cg,bicgstab").split(",")
+LAUNCH_LOOP = bool(os.environ.get("LAUNCH_LOOP"))      # solver options cg_small / bicgstab_small = 0: the launch loops alone
 for nx in NXS:
     n = nx * nx
     ptr, node, val = P.poisson2d_csr(nx, nx)
@@ -18,6 +19,8 @@ for nx in NXS:
     for kind, graph in [(k, g) for k in SOLVERS for g in GRAPH]:
         sg.set_option("krylov_graph", graph)
         s = sg.cg(1e-300) if kind == "cg" else sg.bicgstab(1e-300)
+        if LAUNCH_LOOP:
+            s.set_option("cg_small" if kind == "cg" else "bicgstab_small", 0)
         s.setup(A)
         iters = 2000 if kind == "cg" else 1000
         s.set_max_iter(iters)

@@ -25,7 +25,7 @@ bash tools/probes/pmc_colour_ildu.sh > $OUT/pmc_colour_ildu.txt 2>&1
 # CG per iteration on mid-sized grids (one-workgroup / one-XCD / all-CU cooperative kernels, launch loop beyond), C1, and
 # where an iteration of the cooperative kernel spends its time (phase timers: the -DSGM_COOP_PROBE build of the library)
 NXS=32,64,100,181,256,300,316,362,500,700,1000,1100,1448,1500,2000 SOLVERS=cg KRYLOV_GRAPH=1 timeout 600 python tools/cg_small.py 2>&1 | grep '^{' > $OUT/cg_small_coop.jsonl
-NXS=100,316,1000,1448,2000 SOLVERS=cg KRYLOV_GRAPH=1 NO_C1=1 SGM_CG_COOP=0 timeout 600 python tools/cg_small.py 2>&1 | grep '^{' > $OUT/cg_small_launch_loop.jsonl
+NXS=100,316,1000,1448,2000 SOLVERS=cg KRYLOV_GRAPH=1 NO_C1=1 LAUNCH_LOOP=1 timeout 600 python tools/cg_small.py 2>&1 | grep '^{' > $OUT/cg_small_launch_loop.jsonl
 NXS=32,100,316,1000 SOLVERS=bicgstab KRYLOV_GRAPH=1 NO_C1=1 timeout 600 python tools/cg_small.py 2>&1 | grep '^{' > $OUT/bicgstab_small.jsonl
 if [ -f tools/probes/libsigma_hip_probe.so ]; then
   NXS=100,256,300,500,1000 timeout 300 python tools/probes/coop_probe.py 2>&1 | grep '^{' > $OUT/coop_probe.jsonl
@@ -37,8 +37,8 @@ for a in "1000 cg,jacobi,ildu0,ildu0_reorder" "1000 cg,ildu0 colour" "3162 cg,il
   SGM_PC_TIMING=1 timeout 600 python tools/ildu_bench.py $a 2>&1 | grep -E '^\{|ildu setup'
 done > $OUT/time_to_solution.log 2>&1
 # C3 GMRES(30): blocked CGS-2 vs modified Gram-Schmidt (launch counts per step come out of the Calls column)
-SGM_GMRES_CGS2=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_cgs2 -- python3 tools/bench_configs.py --configs c3 > $OUT/c3_cgs2.log 2>&1
-SGM_GMRES_CGS2=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_mgs -- python3 tools/bench_configs.py --configs c3 > $OUT/c3_mgs.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_cgs2 -- python3 tools/bench_configs.py --configs c3 > $OUT/c3_cgs2.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_mgs -- python3 tools/bench_configs.py --configs c3 --gmres-mgs > $OUT/c3_mgs.log 2>&1
 # C4 / C5: per-kernel times
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_configs -- python3 tools/bench_configs.py --configs c4,c5 > $OUT/configs.log 2>&1
 grep -h '^{' $OUT/c3_cgs2.log $OUT/c3_mgs.log $OUT/configs.log > $OUT/configs.jsonl
