@@ -783,7 +783,7 @@ def fixed_iterations(sg, torch, mk, A, n, b, its):
     return out
 
 
-def c3_leg(sg, P, torch, dev, n=10_000_000, iters=300):
+def c3_leg(sg, P, torch, dev, n=10_000_000, iters=300, gmres_orth=1):
     """BASELINE configs[2]: 1-D advection-diffusion (nonsymmetric tridiagonal, test/solver_test_advection_diffusion_1d.f90:64-82
     at n = 1e7), generated on the device: SpMV, BiCGStab and GMRES(30) for a FIXED number of iterations (SURVEY 8d C3:
     the problem does not converge at this size; iterations/s and the residual are what is reported)."""
@@ -818,11 +818,19 @@ def c3_leg(sg, P, torch, dev, n=10_000_000, iters=300):
     per_it = 2 * moved + 96 * n
     out["bicgstab"] = {"iterations": its, "iters_per_s": its / dt, "ms_per_iter": 1e3 * dt / its, "final_res2": res2,
                        "moved_bytes_per_iter": per_it, "frac_moved": per_it * its / dt / 1e9 / HBM_PEAK_GBS}
-    its, dt, res2 = fixed_iterations(sg, torch, lambda: sg.gmres(1e-300, 30), A, n, b, iters)
-    cyc = sum(moved + 8 * n * (3 * j + 6) for j in range(1, 31)) + 8 * n * 32 + moved
+    def mk_gmres():
+        s = sg.gmres(1e-300, 30)
+        s.set_option("gmres_cgs2", gmres_orth)
+        return s
+    its, dt, res2 = fixed_iterations(sg, torch, mk_gmres, A, n, b, iters)
+    # vector passes at basis size j: low-synchronisation CGS-2 reads the basis twice and z twice and writes the new column
+    # (2 j + 3); blocked CGS-2 three times + w twice written + the scaling pass (3 j + 6 + 2); MGS 4 j + 8
+    passes = {1: lambda j: 2 * j + 3, 2: lambda j: 3 * j + 8, 0: lambda j: 4 * j + 8}[gmres_orth]
+    cyc = sum(moved + 8 * n * passes(j) for j in range(1, 31)) + 8 * n * 32 + moved
     out["gmres30"] = {"iterations": its, "iters_per_s": its / dt, "ms_per_iter": 1e3 * dt / its, "final_res2": res2,
                       "moved_bytes_per_restart_cycle": cyc, "frac_moved": cyc * (its / 30.0) / dt / 1e9 / HBM_PEAK_GBS,
-                      "orthogonalisation": "blocked CGS-2 (3 passes + 3 reductions per step)"}
+                      "orthogonalisation": {1: "low-synchronisation CGS-2 (basis read twice, 2 reductions per step)",
+                                            2: "blocked CGS-2 (3 passes + 3 reductions per step)", 0: "modified Gram-Schmidt"}[gmres_orth]}
     A.destroy()
     return out
 

@@ -384,6 +384,9 @@ int build_ell_colblock(Part &p)
     free_ell_colblock(p);
     bool yes = false;
     SGM_TRY(wants_colblock(p, &yes));
+    if (trace_on() && (p.opt.ell_colblock >= 2 || yes))
+        fprintf(stderr, "[sigma_hip] column-blocked form (%s, n = %d, slots per row %d, option %d): %s\n", cb_from_csr(p) ? "csr" : "ellpack", p.n,
+                p.cb_maxd, p.opt.ell_colblock, yes ? "building" : "declined");
     if (!yes) return SGM_OK;
     const bool csr = cb_from_csr(p);
     hipStream_t st = g_rt.stream;

@@ -319,7 +319,7 @@ int diag_block_plain(const Part &p, sgm_mat *out);
 // its halo columns as they are; stored order inside the rows kept; p's kernel forms (options) and halo links (the sender's
 // row numbers mapped through p1).  No interior range: a product on q runs after its halo has arrived.
 int permuted_part(const Part &p, const int32_t *p1_dev, Part &q);
-int spmv_grid(const Part &p);
+int spmv_grid(const Part &p, bool whole = false);      // whole: the product launched with halo_ready (one range)
 int matvec_plain(sgm_mat A, const double *x, double *y);     // device vectors, sgm_mat_matvec's layout, stream-ordered
 // "csr_lean": the CSR-order arrays of a part that kept only its sliced form, on demand (no-op otherwise)
 int csr_need_arrays(const Part &p);

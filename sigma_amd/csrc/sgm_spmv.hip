@@ -1258,7 +1258,9 @@ static int grid_for_rows(const Part &p, int64_t rows, int64_t limit, bool dots =
 // only owned columns ("interior", one contiguous run of row blocks found at setup) can run
 // while the halo exchange is still in flight; the head / tail ranges follow it.
 struct RowRange { int32_t lo, hi; int grid, part_off; };
-static int spmv_ranges(const Part &p, RowRange out[3], bool dots = true)
+// whole: the halo is known to be in place (CG on a partition forms p's halo itself, option dist_halo_fused): no reason to cut
+// the rows -- one launch like a part without halo columns.
+static int spmv_ranges(const Part &p, RowRange out[3], bool dots = true, bool whole = false)
 {
     int nr = 0, off = 0;
     auto add = [&](int32_t lo, int32_t hi) {       // grids sum to <= kMaxGrid partial slots
@@ -1267,7 +1269,7 @@ static int spmv_ranges(const Part &p, RowRange out[3], bool dots = true)
         off += out[nr].grid;
         ++nr;
     };
-    if (p.n_halo == 0 || p.int_hi <= p.int_lo) {
+    if (p.n_halo == 0 || p.int_hi <= p.int_lo || whole) {
         if (any_sliced(p)) {           // one range, all kMaxGrid partial slots are its own
             out[0] = RowRange{0, p.n, grid_for_rows(p, p.n > 0 ? p.n : 1, kMaxGrid, dots), 0};
             return 1;
@@ -1282,13 +1284,13 @@ static int spmv_ranges(const Part &p, RowRange out[3], bool dots = true)
     return nr;
 }
 
-int spmv_grid(const Part &p)       // = number of partial sums one SpMV leaves per fused dot
+int spmv_grid(const Part &p, bool whole)       // = number of partial sums one SpMV leaves per fused dot
 {
     if (p.dot_grid_override) return p.dot_grid_override;
     if (p.ecol) return ell_grid(p);
     if (use_ell_colblock(p)) return ell_colblock_grid(p);
     RowRange r[3];
-    const int nr = spmv_ranges(p, r);
+    const int nr = spmv_ranges(p, r, true, whole);
     return nr ? r[nr - 1].part_off + r[nr - 1].grid : 8;
 }
 
@@ -1775,6 +1777,8 @@ int spmv_parts(sgm_mat A, const double *const *x, double *const *y, bool add,
                 continue;
             }
             RowRange r[3];
+            // (halo_ready or not, the rows are cut the same way: the partial sums of a fused dot are laid out per range, and
+            //  CG with dist_halo_fused must leave the bits of the exchanged-p path)
             const int nr = spmv_ranges(p, r, dots != nullptr);
             if (grid_out) *grid_out = spmv_grid(p);
             const bool split = nr > 1;              // r[0] is the interior range
@@ -2712,6 +2716,7 @@ static int ensure_transpose(sgm_mat A)
                            (const double *)(ell ? p.eval : p.val), (const int32_t *)A->tperm, nnz);
         SGM_HIP(hipGetLastError());
         SGM_TRY(pack_sliced(tp));
+        if (tp.cb_P) SGM_TRY(refresh_ell_colblock_values(tp));      // (a transpose with scattered columns has the column-blocked form)
         csr_release_arrays(tp);
         if (!ell) csr_release_arrays(p);
     }

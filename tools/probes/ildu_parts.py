@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Colour-ordered ILDU(0)-PCG on a row partition: the 2-D Poisson nx^2 matrix as P in-process parts,
+sg.ldu(reorder="colour") -- every part orders and factors its own diagonal block -- against the same solve on one part.
+  python tools/probes/ildu_parts.py 3162 8 [iterations]
+Fixed iteration count (device vectors: no host staging in the timed region); microseconds per iteration."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import sigma_amd as sg  # noqa: E402
+from sigma_amd import problems as P  # noqa: E402
+
+nx = int(sys.argv[1]) if len(sys.argv) > 1 else 3162
+parts = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+n = nx * nx
+dev = torch.device("cuda", 0)
+sg.init(0)
+st = torch.cuda.Stream(device=dev)
+torch.cuda.set_stream(st)
+sg.use_torch_stream()
+ptr, node, val = P.poisson2d_csr(nx, nx)
+b = torch.full((n,), 1.0 / n, dtype=torch.float64, device=dev)
+for label, np_ in (("one part", 1), (f"{parts} in-process parts", parts)):
+    if np_ == 1:
+        A = sg.csr_matrix(n, n, ptr, node, val)
+    else:
+        starts = (np.arange(np_ + 1) * (nx // np_) * nx).astype(np.int64)       # whole grid lines per part
+        starts[-1] = n
+        starts = starts // 2 * 2
+        starts[-1] = n
+        A = sg.partitioned_csr_matrix(n, n, ptr, node, val, starts)
+    for pcname, mk in (("none", None), ("ildu0 colour", lambda: sg.ldu(reorder="colour"))):
+        pc = mk() if mk else None
+        t0 = time.perf_counter()
+        if pc:
+            pc.setup(A)
+        sg.synchronize()
+        tset = time.perf_counter() - t0
+        s = sg.cg(1e-300)
+        s.set_max_iter(iters)
+        s.setup(A)
+        u = torch.zeros(n, dtype=torch.float64, device=dev)
+        sg.set_async(True)
+        s.solve(A, u, b, pc, check=False)
+        u.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.solve(A, u, b, pc, check=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        sg.set_async(False)
+        out = {"grid": nx, "matrix": label, "pc": pcname, "setup_s": tset, "iterations": s.last_iterations,
+               "us_per_iter": 1e6 * dt / max(1, s.last_iterations), "res2": s.res2}
+        if pc:
+            out["pc_info_part0"] = pc.info(0)
+        print(json.dumps(out), flush=True)
+        s.destroy()
+        if pc:
+            pc.destroy()
+    A.destroy()
