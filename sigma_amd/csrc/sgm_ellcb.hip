@@ -342,7 +342,8 @@ static int wants_colblock(Part &p, bool *yes)
     if (csr && (!p.rowptr || !p.col || !p.val || p.lean)) return SGM_OK;
     if ((int64_t)p.n * p.cb_maxd >= INT32_MAX || p.cb_maxd > 128) return SGM_OK;
     // a CSR matrix: rows of similar length only (the 2-byte positions and the sort keys are per SLOT: n * max_row of them)
-    if (csr && (double)p.n * p.cb_maxd > 2.0 * (double)std::max<int64_t>(p.nnz, 1)) return SGM_OK;
+    const double slots_per_entry = (double)p.n * p.cb_maxd / (double)std::max<int64_t>(p.nnz, 1);
+    if (csr && slots_per_entry > (p.opt.ell_colblock >= 2 ? 16.0 : 2.0)) return SGM_OK;
     if (p.opt.ell_colblock >= 2) { *yes = true; return SGM_OK; }
     if (p.ecode || p.scode || p.code || p.sbcode) return SGM_OK;  // structured: the dictionary kernels serve it
     if ((int64_t)p.ncol_own * 8 < (int64_t)16 << 20 || p.cb_maxd < 8) return SGM_OK;   // x within reach of the L2s / too few gathers

@@ -475,9 +475,27 @@ __global__ __launch_bounds__(kBlock) void k_trsv_rows_cg2(const int32_t *__restr
     const double alpha = sc[0] / sc[1];
     double s = 0.0;
     constexpr int TILE = 2 * kBlock;
+    auto dep = [&](int32_t j) -> double { return MODE == 2 ? z[j] : r[j]; };
+    // a level that starts at an odd position / row (both odd: the caller checks): its first row alone, the pairs from the next
+    const int32_t peel = begin & 1;
+    if (peel && blockIdx.x == 0 && threadIdx.x == 0 && begin < end) {
+        const int32_t p = begin, i = row0;
+        const double ri = MODE == 1 ? r[i] - alpha * q[i] : r[i];
+        if (MODE == 1) r[i] = ri;
+        double t = MODE == 2 ? ri / D[i] : ri;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int32_t j = rq[rs_at(c, p, rc)];
+            if (j >= 0) t = t - rv[rs_at(c, p, rc)] * dep(j);
+        }
+        const double zi = MODE == 1 ? t / D[i] : t;
+        z[i] = zi;
+        s += ri * zi;
+    }
+    begin += peel;
+    row0 += peel;
     const int32_t tiles = (end - begin + TILE - 1) / TILE, tiles_per_xcd = (tiles + 7) >> 3, wg_per_xcd = gridDim.x >> 3;
     const int32_t t_end = min(tiles, ((int32_t)(blockIdx.x & 7) + 1) * tiles_per_xcd);
-    auto dep = [&](int32_t j) -> double { return MODE == 2 ? z[j] : r[j]; };
     for (int32_t tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3); tile < t_end; tile += wg_per_xcd) {
         const int32_t p = begin + tile * TILE + 2 * (int32_t)threadIdx.x;
         if (p >= end) continue;
@@ -558,13 +576,29 @@ __global__ __launch_bounds__(kBlock) void k_trsv_rows2(const int32_t *__restrict
         if (threadIdx.x < 16) dl[threadIdx.x] = rdict[threadIdx.x];
         __syncthreads();
     }
+    auto dep = [&](int32_t j) -> double { return MODE == 2 ? z[j] : (j < n0 ? r[j] : y[j]); };
+    auto rhs = [&](int32_t k) -> double { return MODE == 2 ? (k < n0 ? r[k] : y[k]) : r[k]; };
+    // a level that starts at an odd position / row (both odd, its rows on one side of n0: the caller checks): the first row alone
+    const int32_t peel = begin & 1;
+    if (peel && blockIdx.x == 0 && threadIdx.x == 0 && begin < end) {
+        const int32_t p = begin, i = row0;
+        double t = MODE == 2 ? rhs(i) / D[i] : rhs(i);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int32_t j = rq[rs_at(c, p, rc)];
+            if (j >= 0) t = t - rv[rs_at(c, p, rc)] * dep(j);
+        }
+        if (MODE == 0) y[i] = t;
+        else if (MODE == 1) z[i] = t / D[i];
+        else z[i] = t;
+    }
+    begin += peel;
+    row0 += peel;
     const int32_t tiles_per_xcd = gridDim.x >> 3;
     const int32_t tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
     const int32_t p = begin + tile * 2 * kBlock + 2 * (int32_t)threadIdx.x;
     if (p >= end) return;
     const int32_t i = row0 + (p - begin);
-    auto dep = [&](int32_t j) -> double { return MODE == 2 ? z[j] : (j < n0 ? r[j] : y[j]); };
-    auto rhs = [&](int32_t k) -> double { return MODE == 2 ? (k < n0 ? r[k] : y[k]) : r[k]; };
     if (p + 1 < end) {
         // (i even: rows i, i + 1 lie on one side of the even n0 or straddle nothing -- n0 odd is the caller's scalar case)
         const double *src = MODE == 2 ? (i < n0 ? r : y) : r;
@@ -2120,7 +2154,11 @@ void launch_rows(const TriFactor &T, const TriFactor::RowLevel &L, int mode, con
 {
     hipStream_t st = g_rt.stream;
     const int32_t b = L.b, e = L.e;
-    if (L.row0 >= 0 && (L.row0 & 1) == 0 && (b & 1) == 0 && (n0 & 1) == 0 && L.c >= 1 && L.c <= 4) {
+    // two rows per lane: row and position of the level of one parity (an odd start is peeled), and no pair astride n0 -- n0 even, or
+    // the level's rows all on one side of it with the pairs aligned to the level's own start
+    const bool pairs_ok = L.row0 >= 0 && ((L.row0 ^ b) & 1) == 0 &&
+                          (((n0 & 1) == 0 && (L.row0 & 1) == 0) || L.row0 >= n0 || L.row0 + (e - b) <= n0);
+    if (pairs_ok && L.c >= 1 && L.c <= 4) {
         const bool coded = T.rcode != nullptr;
         const dim3 g2(8 * (((e - b + 2 * kBlock - 1) / (2 * kBlock) + 7) / 8));
 #define R2_M(CC, MM, CD)                                                                                                        \
@@ -2184,7 +2222,7 @@ void launch_rows_cg(const TriFactor &T, const TriFactor::RowLevel &L, int mode, 
                     const double *D, double *z, double *part, int grid, const int *flag, int gen)
 {
     hipStream_t st = g_rt.stream;
-    if (L.row0 >= 0 && (L.row0 & 1) == 0 && (L.b & 1) == 0 && L.c >= 1 && L.c <= 4) {
+    if (L.row0 >= 0 && ((L.row0 ^ L.b) & 1) == 0 && L.c >= 1 && L.c <= 4) {           // (both even, or both odd: the kernel peels the first row)
         const bool coded = T.rcode != nullptr;
 #define ROWS2_M(CC, MM, CD)                                                                                                    \
     hipLaunchKernelGGL((k_trsv_rows_cg2<CC, MM, CD>), dim3(grid), dim3(kBlock), 0, st, (const int32_t *)T.rq, (const double *)T.rv, T.rc, \

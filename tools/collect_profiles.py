@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense gpurun_out/prof_round (tools/profile_round.sh) into profiles/<tag>/."""
 import csv, glob, hashlib, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", "prof_round"), os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
@@ -14,7 +14,7 @@ def newest(pattern):
 
 
 for sub, name in (("stats", "kernel_stats.csv"), ("stats_ildu", "kernel_stats_ildu_pcg_1000x1000.csv"), ("stats_ildu3", "kernel_stats_ildu_100cubed.csv"),
-                  ("stats_c3_cgs2", "kernel_stats_c3_gmres_cgs2.csv"), ("stats_c3_mgs", "kernel_stats_c3_gmres_mgs.csv"),
+                  ("stats_c3_lowsync", "kernel_stats_c3_gmres_lowsync.csv"), ("stats_c3_cgs2", "kernel_stats_c3_gmres_cgs2.csv"), ("stats_c3_mgs", "kernel_stats_c3_gmres_mgs.csv"),
                   ("stats_configs", "kernel_stats_configs_c4_c5.csv"), ("stats_ildu_colour", "kernel_stats_ildu_pcg_colour_3162x3162.csv")):
     f = newest(os.path.join(sub, "*", "*kernel_stats.csv"))
     if f:
@@ -23,7 +23,9 @@ if os.path.exists(os.path.join(src, "time_to_solution.log")):
     shutil.copy(os.path.join(src, "time_to_solution.log"), os.path.join(dst, "time_to_solution_cg_jacobi_ildu.txt"))
 for name, to in (("pmc_colour_ildu.txt", "pmc_colour_ildu.txt"), ("cg_small_coop.jsonl", "cg_per_iteration_cooperative.jsonl"),
                  ("cg_small_launch_loop.jsonl", "cg_per_iteration_launch_loop.jsonl"), ("bicgstab_small.jsonl", "bicgstab_per_iteration.jsonl"),
-                 ("coop_probe.jsonl", "cg_coop_phase_timers.jsonl"), ("wave_sum_probe.txt", "wave_sum_probe.txt")):
+                 ("coop_probe.jsonl", "cg_coop_phase_timers.jsonl"), ("wave_sum_probe.txt", "wave_sum_probe.txt"),
+                 ("scattered_csr.json", "scattered_csr.json"), ("ildu_colour_parts_kernel_sums.txt", "ildu_colour_parts_kernel_sums.txt"),
+                 ("stream_ceilings.txt", "stream_ceilings.txt"), ("c5_counters.txt", "c5_product_counters.txt")):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, to))
 if os.path.exists(os.path.join(src, "configs.jsonl")):

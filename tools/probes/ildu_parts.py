@@ -19,6 +19,7 @@ from sigma_amd import problems as P  # noqa: E402
 nx = int(sys.argv[1]) if len(sys.argv) > 1 else 3162
 parts = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+only = sys.argv[4] if len(sys.argv) > 4 else ""           # "one" / "parts": one matrix form; + ":none" / ":ildu": one preconditioner
 n = nx * nx
 dev = torch.device("cuda", 0)
 sg.init(0)
@@ -28,6 +29,8 @@ sg.use_torch_stream()
 ptr, node, val = P.poisson2d_csr(nx, nx)
 b = torch.full((n,), 1.0 / n, dtype=torch.float64, device=dev)
 for label, np_ in (("one part", 1), (f"{parts} in-process parts", parts)):
+    if only and only.split(":")[0] != ("one" if np_ == 1 else "parts"):
+        continue
     if np_ == 1:
         A = sg.csr_matrix(n, n, ptr, node, val)
     else:
@@ -37,6 +40,8 @@ for label, np_ in (("one part", 1), (f"{parts} in-process parts", parts)):
         starts[-1] = n
         A = sg.partitioned_csr_matrix(n, n, ptr, node, val, starts)
     for pcname, mk in (("none", None), ("ildu0 colour", lambda: sg.ldu(reorder="colour"))):
+        if ":" in only and only.split(":")[1] != ("none" if mk is None else "ildu"):
+            continue
         pc = mk() if mk else None
         t0 = time.perf_counter()
         if pc:

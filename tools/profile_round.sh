@@ -5,13 +5,13 @@ cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_round
 rm -rf $OUT; mkdir -p $OUT
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo bench=$?
-BARGS="--steps 2 --warmup 1 --spmv-per-step 64 --cg-steps 30 --no-cpu --no-c5 --no-c3 --no-c4 --no-dist-overhead --no-pcg"
+BARGS="--steps 2 --warmup 1 --spmv-per-step 64 --cg-steps 30 --no-cpu --no-c5 --no-c3 --no-c4 --no-dist-overhead --no-pcg --no-ceilings"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py $BARGS > $OUT/stats.log 2>&1
-PARGS="--steps 1 --warmup 1 --spmv-per-step 4 --cg-steps 0 --no-cpu --no-c5 --no-c3 --no-c4 --no-variants --no-dist-overhead --no-pcg"
+PARGS="--steps 1 --warmup 1 --spmv-per-step 4 --cg-steps 0 --no-cpu --no-c5 --no-c3 --no-c4 --no-variants --no-dist-overhead --no-pcg --no-ceilings"
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $PARGS > $OUT/pmc1.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py $PARGS > $OUT/pmc2.log 2>&1
 # HBM bytes of the CG update kernels (k_elem<FCgR / FCgPX>) and of the C5 product (k_csr_sl<7>, 464^3): their own PMC passes
-QARGS="--steps 1 --warmup 1 --spmv-per-step 2 --cg-steps 10 --c5-cg-steps 4 --no-cpu --no-c3 --no-c4 --no-variants --no-dist-overhead --no-pcg"
+QARGS="--steps 1 --warmup 1 --spmv-per-step 2 --cg-steps 10 --c5-cg-steps 4 --no-cpu --no-c3 --no-c4 --no-variants --no-dist-overhead --no-pcg --no-ceilings --no-c5-parts"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_cg_c5 -- python3 bench.py $QARGS > $OUT/pmc3.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_cg_c5 -- python3 bench.py $QARGS > $OUT/pmc4.log 2>&1
 # ILDU(0)-PCG on the 1000^2 grid: per-kernel times of the triangular solves
@@ -36,16 +36,25 @@ for a in "1000 cg,jacobi,ildu0,ildu0_reorder" "1000 cg,ildu0 colour" "3162 cg,il
   echo "== tools/ildu_bench.py $a"
   SGM_PC_TIMING=1 timeout 600 python tools/ildu_bench.py $a 2>&1 | grep -E '^\{|ildu setup'
 done > $OUT/time_to_solution.log 2>&1
-# C3 GMRES(30): blocked CGS-2 vs modified Gram-Schmidt (launch counts per step come out of the Calls column)
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_cgs2 -- python3 tools/bench_configs.py --configs c3 > $OUT/c3_cgs2.log 2>&1
+# C3 GMRES(30): low-synchronisation CGS-2 (default) vs blocked CGS-2 vs modified Gram-Schmidt (launch counts per step come out of the Calls column)
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_lowsync -- python3 tools/bench_configs.py --configs c3 > $OUT/c3_lowsync.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_cgs2 -- python3 tools/bench_configs.py --configs c3 --gmres-cgs2 > $OUT/c3_cgs2.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_mgs -- python3 tools/bench_configs.py --configs c3 --gmres-mgs > $OUT/c3_mgs.log 2>&1
+# a CSR matrix with scattered columns (n = 5e6, 8..32 per row): the column-blocked form against the row kernels
+timeout 600 python tools/probes/scattered_csr.py 2>&1 | grep '^{' > $OUT/scattered_csr.json
+# colour-ordered ILDU(0)-PCG at C2 size on 8 in-process parts against one part: wall clock and kernel-time sums
+bash tools/probes/ildu_parts_stats.sh > /dev/null 2>&1
+cp gpurun_out/r05_parts/summary.txt $OUT/ildu_colour_parts_kernel_sums.txt
+# the streaming ceilings and the counter passes of the C5 product (tools/probes/ceilings_r05.sh)
+bash tools/probes/ceilings_r05.sh > /dev/null 2>&1
+cp gpurun_out/r05_ceilings/stream_ceilings.txt gpurun_out/r05_ceilings/c5_counters.txt $OUT/
 # C4 / C5: per-kernel times
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_configs -- python3 tools/bench_configs.py --configs c4,c5 > $OUT/configs.log 2>&1
-grep -h '^{' $OUT/c3_cgs2.log $OUT/c3_mgs.log $OUT/configs.log > $OUT/configs.jsonl
+grep -h '^{' $OUT/c3_lowsync.log $OUT/c3_cgs2.log $OUT/c3_mgs.log $OUT/configs.log > $OUT/configs.jsonl
 cat $OUT/bench.json | cut -c1-600
 # the bench line once more, now that this round's PMC passes exist: condense them on the box (profiles/r03/pmc_hbm_traffic.json
 # with the fingerprint of the sources that just ran) so that `roofline.traffic` of the line is this run's own figure
-python tools/collect_profiles.py ${TAG:-r04} > /dev/null 2>&1
+python tools/collect_profiles.py ${TAG:-r05} > /dev/null 2>&1
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo bench_with_traffic=$?
 # what travels back is capped at 64 MiB: the per-dispatch traces are not needed once the stats exist
 find $OUT -name "*kernel_trace.csv" -delete
