@@ -83,6 +83,9 @@ int sgm_synchronize(void);
  *   "csr_sell" (1)         general matrices whose rows are too long / uneven for the uniform sliced form: SELL-128-512 (rows of
  *                          every 512-row window sorted by length, chunks of 128 rows slot-major with the chunk's own width),
  *                          taken from a longest row of 49 entries on; 2 = whenever the padding allows; 0 = the CSR kernels
+ *   "csr_xwindow" (1)      the SELL form of a BANDED matrix (every 512-row slice gathers from a window of x that fits 144 KiB of
+ *                          LDS, and re-uses it): the slice's window is staged in LDS with coalesced loads and every gather is an
+ *                          LDS read, instead of one 128-byte line moved L2 -> L1 per 8-byte gather; 0 = gathers from L2
  *   "csr_lean" (1)         a matrix served by the sliced / SELL form keeps ONLY that form (+ row pointers) in HBM (C2: 0.48
  *                          instead of 1.13 GB); its CSR-order arrays are rebuilt on the device for whoever reads them
  *   "ell_colblock" (1)     ELLPACK matrices whose columns have no locality (x >= 16 MB, >= 8 slots per row): column-blocked

@@ -44,6 +44,7 @@ struct MatOptions {
     int csr_row_lines = 1;         // int32 columns, longer rows (up to 4096 entries): one 128-byte line of val per row and pass (k_csr_rl)
     int csr_sliced = 1;            // rows <= 8 entries, <= 15 offsets: slot-major slices + 4-bit codes (k_csr_sl); its siblings k_csr_slb / k_csr_sl32
     int csr_sell = 1;              // general matrices whose rows are too long / uneven for the uniform sliced form: SELL-128-512 (2 = whenever the padding allows)
+    int csr_xwindow = 1;           // SELL form of a banded matrix: every slice's window of x staged in LDS (k_csr_sell<.., XW>); 0 = gathers from L2
     int csr_lean = 1;              // a matrix served by the sliced / SELL form keeps ONLY that form (+ row pointers) resident
     int ell_colblock = 1;          // ELLPACK with random columns: column-blocked two-phase product (0 never, 1 automatic, 2 always)
     int ell_colblock_cols = 16384; // its column block: x entries staged in LDS per workgroup (even, <= kEllcbMaxCols)
@@ -204,6 +205,8 @@ struct Part {
     uint16_t *sl_perm = nullptr;   // position -> row inside its sort window (0xffff = no row), n rounded up to whole slices
     int64_t *sl_off = nullptr;     // chunks + 1 offsets (entries)
     int64_t sl_total = 0;          // stored slots (entries + padding)
+    int32_t *sl_win0 = nullptr;    // banded matrices: first column (even) of the window of x every 512-row slice gathers from ...
+    int32_t sl_span = 0;           // ... and the longest window (entries, even): k_csr_sell stages it in LDS (null / 0: not banded enough)
     int32_t sw = 0;                // slots per row in sval (3, 5, 7 or 8)
     int32_t sched_period = 0;      // rows: the far offset most rows carry (a 3-D grid's plane), 0 = none / near
     mutable SliceSched sched[3];   // built on first use, one per row range launched (whole part, or interior / head / tail)

@@ -95,7 +95,7 @@ int copy_big(void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
 int *mat_option_field(MatOptions &o, const char *name)
 {
     SGM_OPT(mat, csr_offset_dict) SGM_OPT(mat, ell_offset_dict) SGM_OPT(mat, csr_row_owner) SGM_OPT(mat, csr_row_lines)
-    SGM_OPT(mat, csr_sliced) SGM_OPT(mat, csr_sell) SGM_OPT(mat, csr_lean) SGM_OPT(mat, ell_colblock) SGM_OPT(mat, ell_colblock_cols)
+    SGM_OPT(mat, csr_sliced) SGM_OPT(mat, csr_sell) SGM_OPT(mat, csr_xwindow) SGM_OPT(mat, csr_lean) SGM_OPT(mat, ell_colblock) SGM_OPT(mat, ell_colblock_cols)
     SGM_OPT(mat, ell_colblock_rows) SGM_OPT(mat, slice_sched) SGM_OPT(mat, coloring_pass)
     return nullptr;
 }
@@ -120,7 +120,7 @@ int normalise_option(const char *name, int value, int *out)
     else if (!strcmp(name, "ell_colblock_rows")) v = value == 512 ? 512 : value == 256 ? 256 : 0;
     else if (!strcmp(name, "ildu_reorder")) v = value != 0;
     else if (!strcmp(name, "csr_sell")) v = value < 0 ? 0 : value > 2 ? 2 : value;
-    else if (!strcmp(name, "csr_lean")) v = value != 0;
+    else if (!strcmp(name, "csr_lean") || !strcmp(name, "csr_xwindow")) v = value != 0;
     else if (!strcmp(name, "slice_sched")) v = value <= 0 ? 0 : value == 1 ? 1 : std::max(4, value);
     else if (!strcmp(name, "krylov_graph")) v = value <= 0 ? 0 : value == 1 ? 1 : std::max(16, (value + 15) / 16 * 16);
     else if (!strcmp(name, "cg_small")) v = std::max(0, value);

@@ -632,13 +632,20 @@ constexpr int kSellChunk = 128;
 constexpr int kSellSigma = 512;       // rows sorted together (a multiple of the 512-row slices).  Measured on the banded test matrices: windows of
                                       // 2048 rows cut the padding from 10-12 % to 2-4 % and were 35-40 % SLOWER -- a chunk's 128 rows then come from a
                                       // 2048-row neighbourhood and their x gathers no longer fit the CU's L1 (33..64 entries per row: 656 -> 920 us)
-template <bool ADD, bool DOT_W, bool DOT_YY>
+// XW (x window): on banded matrices the gathers of a 512-row slice fall into a window of a few thousand columns, and what
+// bounds the kernel without it is the L2 -> L1 line rate of those gathers (one 128-byte line moved per 8-byte gather: 0.47 of
+// the HBM roofline on CSR bytes with rows of 33..300 entries).  With XW the slice's window of x -- win0[slice] .. + span,
+// found at build (k_sell_window) -- is loaded into LDS with coalesced 16-byte loads first and every gather is an LDS read.
+// Same products, same order of additions: bit-identical.  Taken when every slice's window fits 144 KiB of LDS.
+template <bool ADD, bool DOT_W, bool DOT_YY, bool XW = false>
 __global__ __launch_bounds__(256) void k_csr_sell(
     int32_t n, const int64_t *__restrict__ off, const uint16_t *__restrict__ perm, const int32_t *__restrict__ scol,
     const double *__restrict__ sval, const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ w,
-    double *__restrict__ part_wy, double *__restrict__ part_yy, const int *__restrict__ flag_done, int gen, int remap)
+    double *__restrict__ part_wy, double *__restrict__ part_yy, const int *__restrict__ flag_done, int gen, int remap,
+    const int32_t *__restrict__ win0 = nullptr, int32_t span = 0, int32_t xlen = 0)
 {
     constexpr int BLOCK = 256;
+    extern __shared__ double xs[];               // XW: the slice's window of x
     __shared__ double red[BLOCK / 64];
     const int st = flag_done ? *flag_done : 0;
     const int lane = threadIdx.x & 63;
@@ -658,6 +665,17 @@ __global__ __launch_bounds__(256) void k_csr_sell(
         const int64_t chunk = sl * (kSlRows / kSellChunk) + wave;
         const int64_t o0 = off[chunk];
         const int32_t W = (int32_t)((off[chunk + 1] - o0) / kSellChunk);            // a multiple of 2
+        int32_t w0 = 0;
+        if (XW) {
+            w0 = win0[sl];                                                          // (even: 16-byte loads)
+            const int32_t cnt = min(span, xlen - w0);
+            __syncthreads();                                                        // the previous slice's gathers are done with xs
+            const f64x2 *src = reinterpret_cast<const f64x2 *>(x + w0);
+            f64x2 *dst = reinterpret_cast<f64x2 *>(xs);
+            for (int32_t t = threadIdx.x; t < (cnt >> 1); t += BLOCK) dst[t] = src[t];
+            if ((cnt & 1) && threadIdx.x == 0) xs[cnt - 1] = x[w0 + cnt - 1];
+            __syncthreads();
+        }
         const u16x2 pr = *reinterpret_cast<const u16x2 *>(perm + chunk * kSellChunk + 2 * lane);
         const int32_t base = (int32_t)(sl / (kSellSigma / kSlRows)) * kSellSigma;   // the sort window's first row
         const bool va = pr.x != 0xffffu, vb_ = pr.y != 0xffffu;
@@ -679,8 +697,8 @@ __global__ __launch_bounds__(256) void k_csr_sell(
             }
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
-                xa[u] = cc[u].x >= 0 ? x[cc[u].x] : 0.0;
-                xb[u] = cc[u].y >= 0 ? x[cc[u].y] : 0.0;
+                xa[u] = cc[u].x >= 0 ? (XW ? xs[cc[u].x - w0] : x[cc[u].x]) : 0.0;
+                xb[u] = cc[u].y >= 0 ? (XW ? xs[cc[u].y - w0] : x[cc[u].y]) : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
@@ -712,6 +730,32 @@ __global__ __launch_bounds__(256) void k_csr_sell(
     if (DOT_YY) {
         const double t = block_sum<BLOCK>(dyy, red);
         if (threadIdx.x == 0) part_yy[blockIdx.x] = t;
+    }
+}
+// setup: the window of columns every 512-row slice gathers from (its first column rounded down to even, and the span to the
+// last one); the longest span of the part by atomicMax
+__global__ __launch_bounds__(256) void k_sell_window(int64_t nsl, const int64_t *__restrict__ off, const int32_t *__restrict__ scol,
+                                                     int32_t *__restrict__ win0, int32_t *__restrict__ max_span)
+{
+    __shared__ int32_t lo_s[4], hi_s[4];
+    for (int64_t sl = blockIdx.x; sl < nsl; sl += gridDim.x) {
+        const int64_t a = off[sl * (kSlRows / kSellChunk)], b = off[(sl + 1) * (kSlRows / kSellChunk)];
+        int32_t lo = INT32_MAX, hi = -1;
+        for (int64_t k = a + threadIdx.x; k < b; k += 256) {
+            const int32_t c = scol[k];
+            if (c >= 0) { lo = min(lo, c); hi = max(hi, c); }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { lo_s[threadIdx.x >> 6] = lo; hi_s[threadIdx.x >> 6] = hi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int t = 1; t < 4; ++t) { lo_s[0] = min(lo_s[0], lo_s[t]); hi_s[0] = max(hi_s[0], hi_s[t]); }
+            const int32_t l = hi_s[0] < 0 ? 0 : lo_s[0] & ~1;
+            win0[sl] = l;
+            if (hi_s[0] >= 0) atomicMax(max_span, hi_s[0] - l + 1);
+        }
     }
 }
 // setup: positions of a window's rows sorted by length (longest first, ties by row: the sort is a pure function of the row
@@ -1437,10 +1481,27 @@ static void launch_csr_sell(const Part &p, int grid, const double *x, double *y,
     hipLaunchKernelGGL((k_csr_sell<ADD, DW, DY>), dim3(grid), dim3(256), 0, st, p.n, (const int64_t *)p.sl_off,       \
                        (const uint16_t *)p.sl_perm, (const int32_t *)p.sl_col, (const double *)p.sl_val, x, y, w, pwy, pyy, flag, \
                        gen, mode | g_launch_flags)
+#define LX(DW, DY)                                                                                                   \
+    do {                                                                                                             \
+        static size_t attr = 0;                                                                                      \
+        if (attr < lds) { (void)hipFuncSetAttribute((const void *)k_csr_sell<ADD, DW, DY, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = lds; } \
+        hipLaunchKernelGGL((k_csr_sell<ADD, DW, DY, true>), dim3(grid), dim3(256), lds, st, p.n, (const int64_t *)p.sl_off, \
+                           (const uint16_t *)p.sl_perm, (const int32_t *)p.sl_col, (const double *)p.sl_val, x, y, w, pwy, pyy, flag, \
+                           gen, mode | g_launch_flags, (const int32_t *)p.sl_win0, p.sl_span, (int32_t)p.xlen());     \
+    } while (0)
+    if (p.sl_win0 && p.opt.csr_xwindow) {        // banded: the slice's window of x through LDS
+        const size_t lds = (size_t)p.sl_span * 8;
+        if (w && pyy) LX(true, true);
+        else if (w) LX(true, false);
+        else if (pyy) LX(false, true);
+        else LX(false, false);
+        return;
+    }
     if (w && pyy) L(true, true);
     else if (w) L(true, false);
     else if (pyy) L(false, true);
     else L(false, false);
+#undef LX
 #undef L
 }
 
@@ -1680,6 +1741,7 @@ static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const doub
     if (sell) {         // chunk offsets are absolute (into sl_val / sl_col); the chunk table and the positions shift with the range
         v.sl_val = p.sl_val; v.sl_col = p.sl_col;
         v.sl_off = p.sl_off + r.lo / kSellChunk; v.sl_perm = p.sl_perm + r.lo;
+        v.sl_win0 = p.sl_win0 ? p.sl_win0 + r.lo / kSlRows : nullptr; v.sl_span = p.sl_span;
     }
     const bool dict = use_offset_dict(p);
     const double *xs = dict ? x + r.lo : x;
@@ -2118,8 +2180,9 @@ static int32_t far_offset_of_sample(const std::vector<uint8_t> &codes, int64_t r
 // ones -- an arrow matrix -- would blow their chunks up: those matrices stay with the CSR kernels)
 static void free_sell(Part &p)
 {
-    dfree(p.sl_val); dfree(p.sl_col); dfree(p.sl_perm); dfree(p.sl_off);
+    dfree(p.sl_val); dfree(p.sl_col); dfree(p.sl_perm); dfree(p.sl_off); dfree(p.sl_win0);
     p.sl_val = nullptr; p.sl_col = nullptr; p.sl_perm = nullptr; p.sl_off = nullptr; p.sl_total = 0;
+    p.sl_win0 = nullptr; p.sl_span = 0;
 }
 static int build_sell(Part &p)
 {
@@ -2156,6 +2219,25 @@ static int build_sell(Part &p)
                        (const int32_t *)p.rowptr, (const int32_t *)p.col, (const double *)p.val, (const int64_t *)p.sl_off,
                        (const uint16_t *)p.sl_perm, p.sl_col, p.sl_val);
     SGM_HIP(hipGetLastError());
+    // the windows of x the slices gather from: where every one of them fits the LDS the kernel stages it there (XW)
+    {
+        int32_t *mx = nullptr;
+        SGM_TRY(dalloc(&p.sl_win0, (size_t)nsl));
+        SGM_TRY(dalloc(&mx, 1));
+        SGM_HIP(hipMemsetAsync(mx, 0, 4, st));
+        hipLaunchKernelGGL(k_sell_window, dim3((unsigned)std::min<int64_t>(nsl, 65536)), dim3(256), 0, st, nsl, (const int64_t *)p.sl_off,
+                           (const int32_t *)p.sl_col, p.sl_win0, mx);
+        int32_t span = 0;
+        const hipError_t e3 = hipMemcpyAsync(&span, mx, 4, hipMemcpyDeviceToHost, st);
+        const hipError_t e4 = hipStreamSynchronize(st);
+        dfree(mx);
+        SGM_HIP(e3);
+        SGM_HIP(e4);
+        span = (span + 2) & ~1;                                     // (even, and one spare entry for an odd tail)
+        // worth it when the window is re-used: a slice's rows must reference its columns several times over
+        if (span < 2 || (size_t)span * 8 > (size_t)144 * 1024 || (double)span * (double)nsl > 0.5 * (double)total) { dfree(p.sl_win0); p.sl_win0 = nullptr; span = 0; }
+        p.sl_span = span;
+    }
     SGM_HIP(hipStreamSynchronize(st));
     csr_go_lean(p);
     return SGM_OK;
@@ -3148,7 +3230,8 @@ int sgm_mat_kernel(sgm_mat A, char *buf, int len)
         else if (use_sliced(p)) snprintf(name, sizeof name, "k_csr_sl<W=%d>", p.sw);
         else if (use_slicedb(p)) snprintf(name, sizeof name, "k_csr_slb<W=%d>", p.sw);
         else if (use_sliced32(p)) snprintf(name, sizeof name, "k_csr_sl32<W=%d>", p.sw);
-        else if (use_sell(p)) snprintf(name, sizeof name, "k_csr_sell<pad=%.3f>", p.nnz ? (double)p.sl_total / (double)p.nnz : 1.0);
+        else if (use_sell(p)) snprintf(name, sizeof name, p.sl_win0 && p.opt.csr_xwindow ? "k_csr_sell<pad=%.3f,xw=%d>" : "k_csr_sell<pad=%.3f>",
+                                       p.nnz ? (double)p.sl_total / (double)p.nnz : 1.0, p.sl_span);
         else if (use_offset_dict(p)) snprintf(name, sizeof name, "k_csr_do<256,%d,CW=1>", do_tile_for(p));
         else if (use_row_owner(p)) snprintf(name, sizeof name, "k_csr_do<256,%d,CW=4>", do_tile_for(p));
         else if (use_row_lines(p)) snprintf(name, sizeof name, "k_csr_rl");
@@ -3197,7 +3280,11 @@ static int64_t part_matvec_bytes(const sgm_mat_s *A, const Part &p)
     else if (use_sliced(p)) m = nsl * kSlRows * (8 * (int64_t)p.sw + 4);
     else if (use_slicedb(p)) m = nsl * kSlRows * (8 * (int64_t)p.sw + (p.sw + 7) / 8 * 8);
     else if (use_sliced32(p)) m = nsl * kSlRows * 12 * (int64_t)p.sw;
-    else if (use_sell(p)) m = 12 * p.sl_total + 2 * nsl * kSlRows + 8 * nsl * (kSlRows / kSellChunk);      // slots (entries + padding), positions, chunk offsets
+    else if (use_sell(p)) {
+        m = 12 * p.sl_total + 2 * nsl * kSlRows + 8 * nsl * (kSlRows / kSellChunk);      // slots (entries + padding), positions, chunk offsets
+        if (p.sl_win0 && p.opt.csr_xwindow)              // every slice loads its window of x (instead of "every x entry once")
+            return m + nsl * (8 * (int64_t)p.sl_span + 4) + 8 * (int64_t)p.n;
+    }
     else if (use_offset_dict(p)) m = 9 * p.nnz + 4 * ((int64_t)p.n + 1);
     else m = 12 * p.nnz + 4 * ((int64_t)p.n + 1);
     return m + 8 * p.xlen() + 8 * (int64_t)p.n;

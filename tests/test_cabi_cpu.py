@@ -234,7 +234,7 @@ def test_every_documented_option_is_accepted_and_unknown_names_are_refused():
     src = open(os.path.join(ROOT, "sigma_amd", "csrc", "sgm_runtime.hip")).read()
     known = set(re.findall(r"SGM_OPT\((?:mat|solver|pc), ([a-z_0-9]+)\)", src)) | {"dist_force_collectives"}
     assert names == known, (names - known, known - names)
-    assert len(known) <= 26            # 25 per-handle options + the one process-wide switch
+    assert len(known) <= 27            # 26 per-handle options + the one process-wide switch
     # ... and nothing else selects a kernel or an arithmetic order: the library reads three environment variables, none of which
     # changes a result -- SGM_TRACE (which path ran, on stderr), SGM_PC_TIMING (setup phase times on stderr),
     # SGM_RCCL_LIB (which RCCL build to dlopen)

@@ -853,6 +853,14 @@ def test_long_row_kernels_vs_oracle(orc, n, lo, hi):
             H.matvec_t_add(x, ta)
             yb = np.zeros(n)
             H.matvec(xb, yb)
+            if "xw=" in H.kernel:             # banded enough: the slices' windows of x staged in LDS -- and the same bits without
+                seen.add("xw")
+                H.set_option("csr_xwindow", 0)
+                assert "xw=" not in H.kernel and H.kernel.startswith("k_csr_sell")
+                y_nx = np.zeros(n)
+                H.matvec(x, y_nx)
+                assert np.array_equal(y_nx, y)
+                H.set_option("csr_xwindow", 1)
             Hp = sg.partitioned_csr_matrix(n, n, ptr, node, val, starts)
             yp = np.zeros(n)
             Hp.matvec(x, yp)
@@ -891,6 +899,9 @@ def test_long_row_kernels_vs_oracle(orc, n, lo, hi):
             if len(seg):
                 slots += ((int(seg[0]) + 1) // 2 * 2) * 128
     assert ("k_csr_sell" in seen) == (slots <= 1.30 * S.nnz), (seen, n, lo, hi, slots / S.nnz)
+    # ... and its x-window variant the banded ones among them (a slice's window of 512 + 2 x band columns in LDS, re-used)
+    if (n, lo, hi) in ((5000, 66, 90), (9000, 33, 64)):
+        assert "xw" in seen, (seen, n, lo, hi)
 
 
 def test_slice_schedule_keeps_results(orc):
@@ -2795,6 +2806,55 @@ def test_partitioned_block_jacobi_ildu(orc, nparts):
         # the factors of a multi-part ILDU are per part: the single-matrix getter refuses
         with pytest.raises(sg.SigmaError):
             pc.get("D", np.float64)
+
+
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_partition_handed_over_part_by_part_equals_the_one_cut_from_whole_arrays(orc, where):
+    """sgm_csr_create_partitioned_parts (row blocks with GLOBAL columns, as a rank hands its rows to sgm_csr_create_dist;
+    host arrays or device tensors) builds the partition sgm_csr_create_partitioned cuts out of the whole arrays: the same
+    halo lists and send lists, products bit-identical to the serial rows, CG the same bits."""
+    import torch
+    ptr, node, val = P.laplace3d_csr(20, 18, 26)
+    n = 20 * 18 * 26
+    A = orc.CsrMatrix(n, n, ptr, node, val)
+    starts = (np.arange(5) * n // 4) // 2 * 2
+    starts[-1] = n
+    H0 = sg.partitioned_csr_matrix(n, n, ptr, node, val, starts)
+    parts = []
+    for k in range(4):
+        r0, r1 = int(starts[k]), int(starts[k + 1])
+        k0, k1 = ptr[r0] - 1, ptr[r1] - 1
+        blk = ((ptr[r0:r1 + 1] - k0).astype(np.int32), node[k0:k1].copy(), val[k0:k1].copy())
+        parts.append(tuple(torch.from_numpy(a).cuda() for a in blk) if where == "device" else blk)
+    H1 = sg.partitioned_csr_matrix.from_parts(starts, parts)
+    for k in range(4):
+        a, b_ = H0.halo_nbrs(k), H1.halo_nbrs(k)
+        assert len(a) == len(b_) and len(a) >= 1
+        for u, v in zip(a, b_):
+            assert (u["peer"], u["send_count"], u["recv_count"], u["recv_offset"]) == (v["peer"], v["send_count"], v["recv_count"], v["recv_offset"])
+            assert np.array_equal(u["send_idx"], v["send_idx"])
+    x = np.random.RandomState(2).standard_normal(n)
+    y0, y1 = np.zeros(n), np.zeros(n)
+    H0.matvec(x, y0)
+    H1.matvec(x, y1)
+    assert np.array_equal(y1, A.matvec(x)) and np.array_equal(y0, y1)
+    b = np.full(n, 1.0 / n)
+    us = []
+    for H in (H0, H1):
+        s = sg.cg(1e-12)
+        s.set_history(1000)
+        s.setup(H)
+        u = np.zeros(n)
+        s.solve(H, u, b)
+        us.append((u, s.iterations, np.array(s.history)))
+    assert us[0][1] == us[1][1] and np.array_equal(us[0][0], us[1][0]) and np.array_equal(us[0][2], us[1][2])
+    # malformed input of one part is refused with the part named
+    bad = list(parts)
+    p0 = bad[1]
+    bad[1] = (p0[0], p0[1][:-1] if where == "host" else p0[1][:-1].contiguous(), p0[2][:-1] if where == "host" else p0[2][:-1].contiguous())
+    with pytest.raises(sg.SigmaError) as e:
+        sg.partitioned_csr_matrix.from_parts(starts, bad)
+    assert "part 1" in str(e.value)
 
 
 def _blockwise_colour_order(orc, A, starts):

@@ -14,7 +14,8 @@ if os.environ.get("GR_CASES"):          # e.g. GR_CASES=0,2 GR_KERNELS=1 GR_REPS
 if os.environ.get("GR_OPTS") == "row_owner0": sg.set_option("csr_row_owner", 0)
 # kernels to time on every matrix: (csr_sell, csr_row_lines) -- SELL-128-512 whenever its padding allows, then the CSR kernels
 # (row owner up to 64 entries per row / line-staged beyond; streaming)
-KERNELS = tuple(tuple(int(v) for v in t.split(":")) for t in os.environ.get("GR_KERNELS", "2:1,0:1,0:0").split(","))
+# (a third field: csr_xwindow, the SELL kernel's LDS-staged window of x -- "2:1:0" = SELL without it)
+KERNELS = tuple(tuple(int(v) for v in t.split(":")) for t in os.environ.get("GR_KERNELS", "2:1:1,2:1:0,0:1:1,0:0:1").split(","))
 REPS = int(os.environ.get("GR_REPS", "50"))
 for n, lo, hi, band in CASES:
     g = torch.Generator(device=dev); g.manual_seed(1)
@@ -34,9 +35,10 @@ for n, lo, hi, band in CASES:
     x = torch.rand(n, device=dev, dtype=torch.float64)
     moved = 12 * nnz + 4 * n + 16 * n
     ys = []
-    for sell, rowline in KERNELS:
+    for sell, rowline, xw in KERNELS:
         A.set_option("csr_sell", sell)
         A.set_option("csr_row_lines", rowline)
+        A.set_option("csr_xwindow", xw)
         y = torch.zeros_like(x)
         for _ in range(min(5, REPS)): A.matvec(x, y)
         torch.cuda.synchronize()
