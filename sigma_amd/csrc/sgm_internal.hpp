@@ -206,6 +206,7 @@ struct Part {
     int64_t *sl_off = nullptr;     // chunks + 1 offsets (entries)
     int64_t sl_total = 0;          // stored slots (entries + padding)
     int32_t *sl_win0 = nullptr;    // banded matrices: first column (even) of the window of x every 512-row slice gathers from ...
+    int32_t sl_gs = 1;             // slices behind one window (1, or 2 for wide windows: a 512-thread workgroup)
     int32_t sl_span = 0;           // ... and the longest window (entries, even): k_csr_sell stages it in LDS (null / 0: not banded enough)
     int32_t sw = 0;                // slots per row in sval (3, 5, 7 or 8)
     int32_t sched_period = 0;      // rows: the far offset most rows carry (a 3-D grid's plane), 0 = none / near

@@ -637,15 +637,17 @@ constexpr int kSellSigma = 512;       // rows sorted together (a multiple of the
 // the HBM roofline on CSR bytes with rows of 33..300 entries).  With XW the slice's window of x -- win0[slice] .. + span,
 // found at build (k_sell_window) -- is loaded into LDS with coalesced 16-byte loads first and every gather is an LDS read.
 // Same products, same order of additions: bit-identical.  Taken when every slice's window fits 144 KiB of LDS.
-template <bool ADD, bool DOT_W, bool DOT_YY, bool XW = false>
-__global__ __launch_bounds__(256) void k_csr_sell(
+// GS = 2 (wide windows: one workgroup per CU either way): a 512-thread workgroup takes TWO adjacent slices behind one window --
+// 512 more columns for twice the rows, and eight waves' loads in flight instead of four.
+template <bool ADD, bool DOT_W, bool DOT_YY, bool XW = false, int GS = 1>
+__global__ __launch_bounds__(256 * GS) void k_csr_sell(
     int32_t n, const int64_t *__restrict__ off, const uint16_t *__restrict__ perm, const int32_t *__restrict__ scol,
     const double *__restrict__ sval, const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ w,
     double *__restrict__ part_wy, double *__restrict__ part_yy, const int *__restrict__ flag_done, int gen, int remap,
     const int32_t *__restrict__ win0 = nullptr, int32_t span = 0, int32_t xlen = 0)
 {
-    constexpr int BLOCK = 256;
-    extern __shared__ double xs[];               // XW: the slice's window of x
+    constexpr int BLOCK = 256 * GS;
+    extern __shared__ double xs[];               // XW: the window of x of the workgroup's slice(s)
     __shared__ double red[BLOCK / 64];
     const int st = flag_done ? *flag_done : 0;
     const int lane = threadIdx.x & 63;
@@ -661,13 +663,16 @@ __global__ __launch_bounds__(256) void k_csr_sell(
         const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
         first = (int64_t)(loc / G) * (8 * G) + xcd * G + loc % G;
     }
-    for (int64_t sl = first; sl < nsl; sl += gridDim.x) {
-        const int64_t chunk = sl * (kSlRows / kSellChunk) + wave;
+    const int64_t ngr = (nsl + GS - 1) / GS;
+    for (int64_t gr = first; gr < ngr; gr += gridDim.x) {
+        const int64_t sl = gr * GS + (GS == 2 ? (wave >> 2) : 0);
+        const bool has = sl < nsl;                                                  // (GS = 2: the last group may hold one slice)
+        const int64_t chunk = (has ? sl : nsl - 1) * (kSlRows / kSellChunk) + (GS == 2 ? (wave & 3) : wave);
         const int64_t o0 = off[chunk];
-        const int32_t W = (int32_t)((off[chunk + 1] - o0) / kSellChunk);            // a multiple of 2
+        const int32_t W = has ? (int32_t)((off[chunk + 1] - o0) / kSellChunk) : 0;  // a multiple of 2
         int32_t w0 = 0;
         if (XW) {
-            w0 = win0[sl];                                                          // (even: 16-byte loads)
+            w0 = win0[gr];                                                          // (even: 16-byte loads)
             const int32_t cnt = min(span, xlen - w0);
             __syncthreads();                                                        // the previous slice's gathers are done with xs
             const f64x2 *src = reinterpret_cast<const f64x2 *>(x + w0);
@@ -678,7 +683,7 @@ __global__ __launch_bounds__(256) void k_csr_sell(
         }
         const u16x2 pr = *reinterpret_cast<const u16x2 *>(perm + chunk * kSellChunk + 2 * lane);
         const int32_t base = (int32_t)(sl / (kSellSigma / kSlRows)) * kSellSigma;   // the sort window's first row
-        const bool va = pr.x != 0xffffu, vb_ = pr.y != 0xffffu;
+        const bool va = has && pr.x != 0xffffu, vb_ = has && pr.y != 0xffffu;
         const int32_t ra = base + pr.x, rb = base + pr.y;
         double ya = 0.0, yb = 0.0;
         if (ADD) { if (va) ya = y[ra]; if (vb_) yb = y[rb]; }
@@ -734,12 +739,13 @@ __global__ __launch_bounds__(256) void k_csr_sell(
 }
 // setup: the window of columns every 512-row slice gathers from (its first column rounded down to even, and the span to the
 // last one); the longest span of the part by atomicMax
-__global__ __launch_bounds__(256) void k_sell_window(int64_t nsl, const int64_t *__restrict__ off, const int32_t *__restrict__ scol,
+__global__ __launch_bounds__(256) void k_sell_window(int64_t nsl, int gs, const int64_t *__restrict__ off, const int32_t *__restrict__ scol,
                                                      int32_t *__restrict__ win0, int32_t *__restrict__ max_span)
 {
     __shared__ int32_t lo_s[4], hi_s[4];
-    for (int64_t sl = blockIdx.x; sl < nsl; sl += gridDim.x) {
-        const int64_t a = off[sl * (kSlRows / kSellChunk)], b = off[(sl + 1) * (kSlRows / kSellChunk)];
+    const int64_t ngr = (nsl + gs - 1) / gs;
+    for (int64_t sl = blockIdx.x; sl < ngr; sl += gridDim.x) {            // (sl: group of gs slices)
+        const int64_t a = off[sl * gs * (kSlRows / kSellChunk)], b = off[min((sl + 1) * gs, nsl) * (kSlRows / kSellChunk)];
         int32_t lo = INT32_MAX, hi = -1;
         for (int64_t k = a + threadIdx.x; k < b; k += 256) {
             const int32_t c = scol[k];
@@ -1481,15 +1487,16 @@ static void launch_csr_sell(const Part &p, int grid, const double *x, double *y,
     hipLaunchKernelGGL((k_csr_sell<ADD, DW, DY>), dim3(grid), dim3(256), 0, st, p.n, (const int64_t *)p.sl_off,       \
                        (const uint16_t *)p.sl_perm, (const int32_t *)p.sl_col, (const double *)p.sl_val, x, y, w, pwy, pyy, flag, \
                        gen, mode | g_launch_flags)
-#define LX(DW, DY)                                                                                                   \
+#define LXG(DW, DY, GG)                                                                                              \
     do {                                                                                                             \
         static size_t attr = 0;                                                                                      \
-        if (attr < lds) { (void)hipFuncSetAttribute((const void *)k_csr_sell<ADD, DW, DY, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = lds; } \
-        hipLaunchKernelGGL((k_csr_sell<ADD, DW, DY, true>), dim3(grid), dim3(256), lds, st, p.n, (const int64_t *)p.sl_off, \
+        if (attr < lds) { (void)hipFuncSetAttribute((const void *)k_csr_sell<ADD, DW, DY, true, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = lds; } \
+        hipLaunchKernelGGL((k_csr_sell<ADD, DW, DY, true, GG>), dim3(grid), dim3(256 * GG), lds, st, p.n, (const int64_t *)p.sl_off, \
                            (const uint16_t *)p.sl_perm, (const int32_t *)p.sl_col, (const double *)p.sl_val, x, y, w, pwy, pyy, flag, \
                            gen, mode | g_launch_flags, (const int32_t *)p.sl_win0, p.sl_span, (int32_t)p.xlen());     \
     } while (0)
-    if (p.sl_win0 && p.opt.csr_xwindow) {        // banded: the slice's window of x through LDS
+#define LX(DW, DY) do { if (p.sl_gs == 2) LXG(DW, DY, 2); else LXG(DW, DY, 1); } while (0)
+    if (p.sl_win0 && p.opt.csr_xwindow) {        // banded: the window of x of one (two) slice(s) through LDS
         const size_t lds = (size_t)p.sl_span * 8;
         if (w && pyy) LX(true, true);
         else if (w) LX(true, false);
@@ -1502,6 +1509,7 @@ static void launch_csr_sell(const Part &p, int grid, const double *x, double *y,
     else if (pyy) L(false, true);
     else L(false, false);
 #undef LX
+#undef LXG
 #undef L
 }
 
@@ -1741,7 +1749,8 @@ static void launch_range(sgm_mat A, const Part &p, const RowRange &r, const doub
     if (sell) {         // chunk offsets are absolute (into sl_val / sl_col); the chunk table and the positions shift with the range
         v.sl_val = p.sl_val; v.sl_col = p.sl_col;
         v.sl_off = p.sl_off + r.lo / kSellChunk; v.sl_perm = p.sl_perm + r.lo;
-        v.sl_win0 = p.sl_win0 ? p.sl_win0 + r.lo / kSlRows : nullptr; v.sl_span = p.sl_span;
+        v.sl_gs = p.sl_gs;          // (windows exist on parts without halo columns only: their one range starts at row 0)
+        v.sl_win0 = p.sl_win0 ? p.sl_win0 + r.lo / (kSlRows * p.sl_gs) : nullptr; v.sl_span = p.sl_span;
     }
     const bool dict = use_offset_dict(p);
     const double *xs = dict ? x + r.lo : x;
@@ -2188,10 +2197,12 @@ static int build_sell(Part &p)
 {
     free_sell(p);
     if (!p.opt.csr_sliced || !p.opt.csr_sell || p.ecol || p.n < 1 || p.nnz < 4 * (int64_t)p.n || p.max_row < 1) return SGM_OK;
-    // rows of up to 48 entries stay with the row-owner kernel: its tiles hold consecutive rows, whose x gathers share more L1
-    // lines than a sorted chunk's (banded 20..40 entries per row: 719-753 us against 819 here; from 33..64 on SELL wins:
-    // 650 against 770-794, 64..128: 656 against 781-816, 150..300: 770 against 930)
-    if (p.max_row <= 48 && p.opt.csr_sell < 2) return SGM_OK;
+    // rows of up to 48 entries stay with the row-owner kernel UNLESS the slices' windows of x fit the LDS (decided below): its
+    // tiles hold consecutive rows, whose x gathers share more L1 lines than a sorted chunk's (banded 20..40 entries per row:
+    // 719-753 us against 793-819 here without the window -- and 553 with it; from 33..64 on SELL wins either way:
+    // 620-650 against 757-794, 64..128: 649 against 792-816, 150..300: 750 against 922)
+    const bool short_rows = p.max_row <= 48 && p.opt.csr_sell < 2;
+    if (short_rows && (!p.opt.csr_xwindow || p.n_halo != 0 || p.max_row < 8)) return SGM_OK;
     hipStream_t st = g_rt.stream;
     const int64_t nsl = ((int64_t)p.n + kSlRows - 1) / kSlRows, nch = nsl * (kSlRows / kSellChunk);
     SGM_TRY(dalloc(&p.sl_perm, (size_t)nsl * kSlRows));
@@ -2219,25 +2230,41 @@ static int build_sell(Part &p)
                        (const int32_t *)p.rowptr, (const int32_t *)p.col, (const double *)p.val, (const int64_t *)p.sl_off,
                        (const uint16_t *)p.sl_perm, p.sl_col, p.sl_val);
     SGM_HIP(hipGetLastError());
-    // the windows of x the slices gather from: where every one of them fits the LDS the kernel stages it there (XW)
-    {
+    // the windows of x the slices gather from: where every one of them fits the LDS the kernel stages it there (XW).  Parts
+    // with halo columns are left out (their windows span the halo region, and their row ranges are cut by slices).
+    p.sl_gs = 1;
+    if (p.n_halo == 0) {
         int32_t *mx = nullptr;
         SGM_TRY(dalloc(&p.sl_win0, (size_t)nsl));
         SGM_TRY(dalloc(&mx, 1));
-        SGM_HIP(hipMemsetAsync(mx, 0, 4, st));
-        hipLaunchKernelGGL(k_sell_window, dim3((unsigned)std::min<int64_t>(nsl, 65536)), dim3(256), 0, st, nsl, (const int64_t *)p.sl_off,
-                           (const int32_t *)p.sl_col, p.sl_win0, mx);
+        struct Tmp { int32_t *&a; ~Tmp() { dfree(a); } } tmpmx{mx};
+        constexpr size_t kLdsCap = (size_t)152 * 1024;
+        auto windows = [&](int gs, int32_t *span_out) -> int {
+            SGM_HIP(hipMemsetAsync(mx, 0, 4, st));
+            hipLaunchKernelGGL(k_sell_window, dim3((unsigned)std::min<int64_t>(nsl, 65536)), dim3(256), 0, st, nsl, gs, (const int64_t *)p.sl_off,
+                               (const int32_t *)p.sl_col, p.sl_win0, mx);
+            int32_t span = 0;
+            SGM_HIP(hipMemcpyAsync(&span, mx, 4, hipMemcpyDeviceToHost, st));
+            SGM_HIP(hipStreamSynchronize(st));
+            *span_out = (span + 2) & ~1;                            // (even, and one spare entry for an odd tail)
+            return SGM_OK;
+        };
         int32_t span = 0;
-        const hipError_t e3 = hipMemcpyAsync(&span, mx, 4, hipMemcpyDeviceToHost, st);
-        const hipError_t e4 = hipStreamSynchronize(st);
-        dfree(mx);
-        SGM_HIP(e3);
-        SGM_HIP(e4);
-        span = (span + 2) & ~1;                                     // (even, and one spare entry for an odd tail)
+        SGM_TRY(windows(1, &span));
+        // a window beyond 72 KiB leaves room for ONE workgroup per CU: let it be a 512-thread one over two slices
+        if ((size_t)span * 8 > (size_t)72 * 1024) {
+            int32_t span2 = 0;
+            SGM_TRY(windows(2, &span2));
+            if ((size_t)span2 * 8 <= kLdsCap) { span = span2; p.sl_gs = 2; }
+            else if ((size_t)span * 8 <= kLdsCap) SGM_TRY(windows(1, &span));       // (back to one slice per window)
+        }
         // worth it when the window is re-used: a slice's rows must reference its columns several times over
-        if (span < 2 || (size_t)span * 8 > (size_t)144 * 1024 || (double)span * (double)nsl > 0.5 * (double)total) { dfree(p.sl_win0); p.sl_win0 = nullptr; span = 0; }
+        if (span < 2 || (size_t)span * 8 > kLdsCap || (double)span * (double)((nsl + p.sl_gs - 1) / p.sl_gs) > 0.5 * (double)total) {
+            dfree(p.sl_win0); p.sl_win0 = nullptr; span = 0; p.sl_gs = 1;
+        }
         p.sl_span = span;
     }
+    if (short_rows && !p.sl_win0) { free_sell(p); return SGM_OK; }        // (short rows without a window: the row-owner kernel)
     SGM_HIP(hipStreamSynchronize(st));
     csr_go_lean(p);
     return SGM_OK;
@@ -3230,8 +3257,8 @@ int sgm_mat_kernel(sgm_mat A, char *buf, int len)
         else if (use_sliced(p)) snprintf(name, sizeof name, "k_csr_sl<W=%d>", p.sw);
         else if (use_slicedb(p)) snprintf(name, sizeof name, "k_csr_slb<W=%d>", p.sw);
         else if (use_sliced32(p)) snprintf(name, sizeof name, "k_csr_sl32<W=%d>", p.sw);
-        else if (use_sell(p)) snprintf(name, sizeof name, p.sl_win0 && p.opt.csr_xwindow ? "k_csr_sell<pad=%.3f,xw=%d>" : "k_csr_sell<pad=%.3f>",
-                                       p.nnz ? (double)p.sl_total / (double)p.nnz : 1.0, p.sl_span);
+        else if (use_sell(p)) snprintf(name, sizeof name, p.sl_win0 && p.opt.csr_xwindow ? "k_csr_sell<pad=%.3f,xw=%dx%d>" : "k_csr_sell<pad=%.3f>",
+                                       p.nnz ? (double)p.sl_total / (double)p.nnz : 1.0, p.sl_span, p.sl_gs);
         else if (use_offset_dict(p)) snprintf(name, sizeof name, "k_csr_do<256,%d,CW=1>", do_tile_for(p));
         else if (use_row_owner(p)) snprintf(name, sizeof name, "k_csr_do<256,%d,CW=4>", do_tile_for(p));
         else if (use_row_lines(p)) snprintf(name, sizeof name, "k_csr_rl");
@@ -3283,7 +3310,7 @@ static int64_t part_matvec_bytes(const sgm_mat_s *A, const Part &p)
     else if (use_sell(p)) {
         m = 12 * p.sl_total + 2 * nsl * kSlRows + 8 * nsl * (kSlRows / kSellChunk);      // slots (entries + padding), positions, chunk offsets
         if (p.sl_win0 && p.opt.csr_xwindow)              // every slice loads its window of x (instead of "every x entry once")
-            return m + nsl * (8 * (int64_t)p.sl_span + 4) + 8 * (int64_t)p.n;
+            return m + ((nsl + p.sl_gs - 1) / p.sl_gs) * (8 * (int64_t)p.sl_span + 4) + 8 * (int64_t)p.n;
     }
     else if (use_offset_dict(p)) m = 9 * p.nnz + 4 * ((int64_t)p.n + 1);
     else m = 12 * p.nnz + 4 * ((int64_t)p.n + 1);
