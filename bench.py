@@ -328,6 +328,26 @@ def worker(args):
         uid = [sg.Comm.unique_id() if rank == 0 else None, sg.Comm.unique_id() if (rank == 0 and args.halo_comm) else None]
         dist.broadcast_object_list(uid, src=0)
         comm = sg.Comm(rank, world, uid[0], uid[1])
+    # CG's communication pattern on a partition (option dist_halo_fused): 1 = the boundary rows of r in ONE RCCL group with the
+    # all-reduce of r.r.  Every rank first posts such a group once (send / recv to itself + an all-reduce over all ranks): a
+    # transport that refuses the mixed group says so HERE, and the solves fall back to two separate calls (mode 2).
+    halo_mode = 0 if args.halo_comm else args.halo_fused
+    group_probe = None
+    if use_dist and halo_mode == 1:
+        hb.phase("RCCL: probing a group of send / recv + all-reduce (sgm_comm_group_selftest)")
+        try:
+            got, summed, us = comm.group_selftest()
+            ok = got == 42.0 + rank and summed == float(world)
+            group_probe = {"ok": bool(ok), "us": us}
+        except sg.SigmaError as e:
+            ok = False
+            group_probe = {"ok": False, "error": str(e)[:200]}
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if t.item() != 1.0:
+            halo_mode = 2
+            if rank == 0:
+                sys.stderr.write(f"[bench] the transport refused a group of send / recv + all-reduce ({group_probe}): CG posts them separately (dist_halo_fused = 2)\n")
 
     def make_matrix(kind):
         """(A, n_loc, n_glob, i0, nnz, label, host_arrays)"""
@@ -412,7 +432,7 @@ def worker(args):
         hb.phase(f"{tag}: CG, {its_cap} fixed iterations (warm-up solve, timed solve" + (", profiled solve)" if profile_phases else ")"))
         s = sg.cg(1e-300)
         s.set_max_iter(its_cap)
-        s.set_option("dist_halo_fused", 0 if args.halo_comm else args.halo_fused)     # (a second communicator only serves mode 0)
+        s.set_option("dist_halo_fused", halo_mode)     # (a second communicator only serves mode 0)
         s.setup(A)
         bvec = torch.full((n_loc,), 1.0 / n_glob, dtype=torch.float64, device=dev)
         u = torch.zeros(n_loc, dtype=torch.float64, device=dev)
@@ -699,6 +719,7 @@ def worker(args):
             "config": {"workload": f"{label} (rank 0: n={n_loc}, nnz={nnz}), fp64 SpMV y=A*x",
                        "spmv_per_step": inner, "rows_per_gpu": n_loc, "nnz_per_gpu": int(nnz),
                        "parallelism": f"row-partition x{world}",
+                       "cg_dist_halo_fused": halo_mode if use_dist else None, "rccl_group_probe": group_probe,
                        "matrix_resident_bytes_per_gpu": resident_rank,
                        "reference_layout_bytes_per_gpu": 12 * nnz + 4 * (n_loc + 1),
                        "value_counts": "bytes the kernel moves by construction (stored format + x + y), not the reference layout's"},
