@@ -845,13 +845,13 @@ def c3_leg(sg, P, torch, dev, n=10_000_000, iters=300, gmres_orth=1):
         return s
     its, dt, res2 = fixed_iterations(sg, torch, mk_gmres, A, n, b, iters)
     # vector passes at basis size j: low-synchronisation CGS-2 reads the basis twice and z twice and writes the new column
-    # (2 j + 3); blocked CGS-2 three times + w twice written + the scaling pass (3 j + 6 + 2); MGS 4 j + 8
-    passes = {1: lambda j: 2 * j + 3, 2: lambda j: 3 * j + 8, 0: lambda j: 4 * j + 8}[gmres_orth]
+    # (2 j + 3); MGS 4 j + 8
+    passes = {1: lambda j: 2 * j + 3, 0: lambda j: 4 * j + 8}[gmres_orth]
     cyc = sum(moved + 8 * n * passes(j) for j in range(1, 31)) + 8 * n * 32 + moved
     out["gmres30"] = {"iterations": its, "iters_per_s": its / dt, "ms_per_iter": 1e3 * dt / its, "final_res2": res2,
                       "moved_bytes_per_restart_cycle": cyc, "frac_moved": cyc * (its / 30.0) / dt / 1e9 / HBM_PEAK_GBS,
                       "orthogonalisation": {1: "low-synchronisation CGS-2 (basis read twice, 2 reductions per step)",
-                                            2: "blocked CGS-2 (3 passes + 3 reductions per step)", 0: "modified Gram-Schmidt"}[gmres_orth]}
+                                            0: "modified Gram-Schmidt"}[gmres_orth]}
     A.destroy()
     return out
 

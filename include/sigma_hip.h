@@ -119,8 +119,9 @@ int sgm_synchronize(void);
  *                          the stored basis vector is the ONCE-projected one and the second projection lives in the Cholesky
  *                          factor R of the stored columns' Gram matrix (V = S R^-1 never formed; H = R Gs R^-1): the basis is
  *                          read twice per step and two reductions (all-reduces) are taken, 2 k + 3 vector passes at basis
- *                          size k; 2 = blocked CGS-2 with the second projection applied (three passes, three reductions,
- *                          3 k + 8); 0 = modified Gram-Schmidt (k + 2 dependent passes), the checker
+ *                          size k; 0 = modified Gram-Schmidt (k + 2 dependent passes and reductions, 4 k + 8 vector passes),
+ *                          the checker.  (Round 4's blocked CGS-2 with the second projection applied -- three passes, three
+ *                          reductions -- was 1265 it/s on C3 against 1644 and is gone.)
  *   "dot_order" (0)        how CG / BiCGStab add up their dot products.  0 = tree order (per-workgroup partial sums,
  *                          re-reduced in a fixed order): a legal order for the Fortran intrinsic, deterministic, the fast one.
  *                          1 = the order the reference build uses (amdflang -O2 turns dot_product into ONE accumulator fed

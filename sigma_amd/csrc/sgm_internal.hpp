@@ -64,7 +64,7 @@ struct SolverOptions {
     int krylov_graph = 1;          // CG / BiCGStab launch loops (one GPU, plain or Jacobi): replay a captured group of 16 iterations (hipGraph);
                                    // 0 off, 1 = once the solve has run 64 iterations, n > 1 = after n (rounded up to a multiple of 16)
     int dot_order = 0;             // dot products of CG / BiCGStab: 0 = tree (per-workgroup partial sums), 1 = the reference's order
-    int gmres_cgs2 = 1;            // GMRES: 1 = low-synchronisation CGS-2 (k_gsl: basis read twice per step), 2 = blocked CGS-2 (three passes), 0 = modified Gram-Schmidt
+    int gmres_cgs2 = 1;            // GMRES: 1 = low-synchronisation CGS-2 (k_gsl: basis read twice per step), 0 = modified Gram-Schmidt
     int coop_spin_limit = 0;       // cooperative CG / BiCGStab: polls before a hand-off gives up (0 = built-in 2^19; tests set 1 to force the fall-back)
     int cg_coop_variant = 0;       // cooperative CG / BiCGStab: low 4 bits pin the rows per thread (1, 2, 4, 8; 0 = by size), +16 = never the one-XCD variant
     int reorder_solve = 2;         // a preconditioner with ildu_reorder: 2 = the solve runs in the permuted order and CG folds its r update and

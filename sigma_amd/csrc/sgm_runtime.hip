@@ -126,7 +126,7 @@ int normalise_option(const char *name, int value, int *out)
     else if (!strcmp(name, "cg_small")) v = std::max(0, value);
     else if (!strcmp(name, "dist_halo_fused") || !strcmp(name, "reorder_solve")) v = value < 0 ? 0 : value > 2 ? 2 : value;
     else if (!strcmp(name, "coop_spin_limit")) v = std::max(0, value);
-    else if (!strcmp(name, "gmres_cgs2")) v = value < 0 ? 0 : value > 2 ? 2 : value;
+    else if (!strcmp(name, "gmres_cgs2")) v = value != 0;
     else if (!strcmp(name, "cg_coop_variant")) {
         const int r = value & 15;
         if (value < 0 || value > 31 || (r != 0 && r != 1 && r != 2 && r != 4 && r != 8))

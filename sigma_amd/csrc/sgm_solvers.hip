@@ -667,82 +667,6 @@ struct FGmresUpdate {
     __device__ void finish(double *) {}
 };
 
-// ---- blocked Gram-Schmidt for GMRES (CGS-2: classical Gram-Schmidt applied twice) ----------------
-// Orthogonalising w against v_0..v_{k-1} one vector at a time (modified Gram-Schmidt) is k dependent
-// passes: k launches and, across ranks, k sequential all-reduces.  CGS-2 needs three passes whatever k is:
-//   MODE 0   h1 = V^T w                                   (k partial sums per workgroup)
-//   MODE 1   w -= V h1 ;  h2 = V^T w   in the same pass   (every v_c[i] is in registers for both)
-//   MODE 2   w -= V h2 ;  partial w.w
-// h = h1 + h2 is the Hessenberg column.  (3k+8) vector passes per step instead of (4k+8), and three
-// count-k / count-k / count-1 all-reduces instead of k+2.  The k coefficients are wave-uniform (scalar
-// registers); the k basis entries of a lane's pair and the k accumulators are its vector registers,
-// so KB = 4/8/16/32 variants keep small steps cheap.
-template <int KB, int MODE>
-__global__ __launch_bounds__(kBlock) void k_gs(int64_t n, int k, double *__restrict__ w, const double *__restrict__ V,
-                                               int64_t ldv, const double *__restrict__ h_in, double *__restrict__ part_out,
-                                               const int *flag)
-{
-    __shared__ double red[kBlock / 64];
-    if (flag && *flag) return;
-    double hin[KB], acc[KB];
-#pragma unroll
-    for (int c = 0; c < KB; ++c) {
-        hin[c] = (MODE != 0 && c < k) ? h_in[c] : 0.0;
-        acc[c] = 0.0;
-    }
-    double nrm = 0.0;
-    const int64_t gtid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    const int64_t n2 = n >> 1;
-    for (int64_t i = gtid; i < n2; i += stride) {
-        double2 wv = ld2<false>(w, i);
-        double2 vv[KB];
-#pragma unroll
-        for (int c = 0; c < KB; ++c)
-            if (c < k) vv[c] = ld2<true>(V + (size_t)c * ldv, i);
-        if (MODE != 0) {
-#pragma unroll
-            for (int c = 0; c < KB; ++c)
-                if (c < k) { wv.x = wv.x - hin[c] * vv[c].x; wv.y = wv.y - hin[c] * vv[c].y; }
-            st2<false>(w, i, wv);
-        }
-        if (MODE != 2) {
-#pragma unroll
-            for (int c = 0; c < KB; ++c)
-                if (c < k) { acc[c] += vv[c].x * wv.x; acc[c] += vv[c].y * wv.y; }
-        } else {
-            nrm += wv.x * wv.x; nrm += wv.y * wv.y;
-        }
-    }
-    if ((n & 1) && gtid == 0) {
-        const int64_t i = n - 1;
-        double wv = w[i];
-        if (MODE != 0) {
-#pragma unroll
-            for (int c = 0; c < KB; ++c)
-                if (c < k) wv = wv - hin[c] * V[(size_t)c * ldv + i];
-            w[i] = wv;
-        }
-        if (MODE != 2) {
-#pragma unroll
-            for (int c = 0; c < KB; ++c)
-                if (c < k) acc[c] += V[(size_t)c * ldv + i] * wv;
-        } else {
-            nrm += wv * wv;
-        }
-    }
-    if (MODE != 2) {
-#pragma unroll
-        for (int c = 0; c < KB; ++c)
-            if (c < k) {                     // k is uniform: every thread takes the same branches
-                const double t = block_sum<kBlock>(acc[c], red);
-                if (threadIdx.x == 0) part_out[(size_t)c * kMaxGrid + blockIdx.x] = t;
-            }
-    } else {
-        const double t = block_sum<kBlock>(nrm, red);
-        if (threadIdx.x == 0) part_out[blockIdx.x] = t;
-    }
-}
 // block c: slots[c] = sum of partial array c (count entries each, kMaxGrid apart)
 // up to four dots collapsed by one launch: block b = dot b (k_reduce's sum, same order)
 struct ReduceSet { const double *part[4]; int count[4]; double *slot[4]; };
@@ -943,38 +867,6 @@ __global__ __launch_bounds__(64) void k_gmres_ls_y(GmresState *G)
     }
 }
 
-// k_gmres_givens for the CGS-2 path: column j of H = h1 + h2 (reduced slots), norm^2 in its own slot
-__global__ __launch_bounds__(64) void k_gmres_givens2(const double *h1, const double *h2, const double *nrm2, int m,
-                                                      GmresState *G, double tol, int *flag, int64_t *iters,
-                                                      double *history, int64_t hist_cap, double *res_out)
-{
-    if (*flag || threadIdx.x != 0) return;
-    const int j = G->j;
-    double *H = G->H + (size_t)j * (m + 1);
-    for (int i = 0; i <= j; ++i) H[i] = h1[i] + h2[i];
-    H[j + 1] = sqrt(nrm2[0]);
-    for (int i = 0; i < j; ++i) {
-        const double h0 = H[i], h1_ = H[i + 1];
-        H[i] = G->cs[i] * h0 + G->sn[i] * h1_;
-        H[i + 1] = -G->sn[i] * h0 + G->cs[i] * h1_;
-    }
-    const double h0 = H[j], hn = H[j + 1];
-    const double d = sqrt(h0 * h0 + hn * hn);
-    G->cs[j] = h0 / d;
-    G->sn[j] = hn / d;
-    H[j] = d;
-    H[j + 1] = 0.0;
-    G->g[j + 1] = -G->sn[j] * G->g[j];
-    G->g[j] = G->cs[j] * G->g[j];
-    const double res = fabs(G->g[j + 1]);
-    const int64_t it = *iters;
-    if (history && it < hist_cap) history[it] = res * res;
-    *iters = it + 1;
-    *res_out = res * res;
-    G->j = j + 1;
-    if (!(res > tol)) *flag = 1;
-}
-
 // ---- Lanczos (src/eigensolver.f90:27-90) -------------------------------------------------
 // w = w - alpha*q_i - beta*q_{i-1}   (eigensolver.f90:69; beta = sqrt(sum(nrm2)), q_prev may be null)
 struct FLanczosW {
@@ -1118,7 +1010,7 @@ using namespace sgm;
 // solver object
 // ======================================================================================
 namespace {
-constexpr int kNumPartials = 72;     // partial arrays per part (GMRES: restart+2 with MGS, 2*restart+3 with CGS-2)
+constexpr int kNumPartials = 72;     // partial arrays per part (GMRES: restart+2 with MGS; the low-synchronisation form: 0..32, 36..68, 71)
 
 struct PartWork {
     int64_t n = 0, next = 0;         // owned length, extended (owned+halo) length
@@ -3150,16 +3042,13 @@ int run_gmres(sgm_solver s, sgm_mat A, double *const *x, const double *const *b,
     auto Vc = [&](size_t ip, int c) { return s->work[ip].V + (size_t)c * s->work[ip].next; };
     int grid = 0;
     for (size_t ip = 0; ip < P; ++ip) v.flags[ip] = s->work[ip].flag;
-    // Gram-Schmidt variant: CGS-2 (blocked, 3 passes per step) unless the option is off or the restart
-    // length exceeds its 32-vector kernels; modified Gram-Schmidt (j+2 fused passes) otherwise
-    // ... and, the default, its low-synchronisation form (k_gsl: two passes, two reductions per step)
-    const bool lowsync = s->opt.gmres_cgs2 == 1 && m <= 32;
-    const bool cgs2 = s->opt.gmres_cgs2 == 2 && m <= 32;
+    // Gram-Schmidt variant: low-synchronisation CGS-2 (k_gsl: two passes, two reductions per step) unless the option is off or
+    // the restart length exceeds its 32-vector kernels; modified Gram-Schmidt (j+2 fused passes) otherwise
+    const bool lowsync = s->opt.gmres_cgs2 != 0 && m <= 32;
     // partial array ids.  MGS: 0..m = h column (h_0..h_j, norm at j+1), NRM = m+1 the start norm.
-    // CGS-2: 0..m-1 = h1, H2.. = h2, NRM = norm (start norm and step norm)
     // low-sync: 0..k = g and t of pass 1, LS2.. = c and d of pass 2, NRM = the start norm
     const int LS2 = 36;
-    const int H2 = m + 1, NRM = lowsync ? 71 : cgs2 ? 2 * m + 2 : m + 1;
+    const int NRM = lowsync ? 71 : m + 1;
     int64_t done_steps = 0;
     int flag = 0; int64_t iters = 0; double res = 0.0;
 
@@ -3248,48 +3137,6 @@ int run_gmres(sgm_solver s, sgm_mat A, double *const *x, const double *const *b,
                 for (size_t ip = 0; ip < P; ++ip) {
                     PartWork &w = s->work[ip];
                     hipLaunchKernelGGL(k_gmres_ls2, dim3(1), dim3(64), 0, g_rt.stream, (const double *)(w.slots + LS2), m, w.gmres,
-                                       s->tolerance, w.flag, w.iters, ip == 0 ? w.history : nullptr, s->hist_cap, w.res);
-                }
-                continue;
-            }
-            if (cgs2) {
-                const int k = j + 1;
-                auto gs = [&](int mode, PartWork &w, const double *h_in, double *out) {
-#define SGM_GS(KB)                                                                                              \
-    do {                                                                                                        \
-        if (mode == 0) hipLaunchKernelGGL((k_gs<KB, 0>), dim3(dot_grid(w.n)), dim3(kBlock), 0, g_rt.stream, w.n, k, w.vec[G_W], \
-                                          (const double *)w.V, w.next, h_in, out, (const int *)w.flag);         \
-        else if (mode == 1) hipLaunchKernelGGL((k_gs<KB, 1>), dim3(dot_grid(w.n)), dim3(kBlock), 0, g_rt.stream, w.n, k, w.vec[G_W], \
-                                               (const double *)w.V, w.next, h_in, out, (const int *)w.flag);    \
-        else hipLaunchKernelGGL((k_gs<KB, 2>), dim3(dot_grid(w.n)), dim3(kBlock), 0, g_rt.stream, w.n, k, w.vec[G_W], \
-                                (const double *)w.V, w.next, h_in, out, (const int *)w.flag);                   \
-    } while (0)
-                    if (k <= 4) SGM_GS(4); else if (k <= 8) SGM_GS(8); else if (k <= 16) SGM_GS(16); else SGM_GS(32);
-#undef SGM_GS
-                };
-                // slots always hold the reduced (and, across ranks / parts, summed) coefficients
-                auto reduce_sum = [&](int id0, int cnt) -> int {
-                    for (size_t ip = 0; ip < P; ++ip) {
-                        PartWork &w = s->work[ip];
-                        hipLaunchKernelGGL(k_reduce_many, dim3(cnt), dim3(kBlock), 0, g_rt.stream, part(s, ip, id0),
-                                           dot_grid(w.n), w.slots + id0);
-                    }
-                    if (!s->multi) return SGM_OK;
-                    std::vector<double *> ptrs(P);
-                    for (size_t ip = 0; ip < P; ++ip) ptrs[ip] = s->work[ip].slots + id0;
-                    return allreduce_slots(A, ptrs.data(), cnt);
-                };
-                for (size_t ip = 0; ip < P; ++ip) gs(0, s->work[ip], nullptr, part(s, ip, 0));
-                SGM_TRY(reduce_sum(0, k));
-                for (size_t ip = 0; ip < P; ++ip) gs(1, s->work[ip], s->work[ip].slots, part(s, ip, H2));
-                SGM_TRY(reduce_sum(H2, k));
-                for (size_t ip = 0; ip < P; ++ip) gs(2, s->work[ip], s->work[ip].slots + H2, part(s, ip, NRM));
-                SGM_TRY(reduce_sum(NRM, 1));
-                for (size_t ip = 0; ip < P; ++ip) {
-                    PartWork &w = s->work[ip];
-                    launch_elem(w.n, FScaleInv{Vc(ip, j + 1), W(ip, G_W), ScalarRef{w.slots + NRM, 1}}, w.flag);
-                    hipLaunchKernelGGL(k_gmres_givens2, dim3(1), dim3(64), 0, g_rt.stream, (const double *)w.slots,
-                                       (const double *)(w.slots + H2), (const double *)(w.slots + NRM), m, w.gmres,
                                        s->tolerance, w.flag, w.iters, ip == 0 ? w.history : nullptr, s->hist_cap, w.res);
                 }
                 continue;

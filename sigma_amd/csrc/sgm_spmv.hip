@@ -2623,6 +2623,7 @@ int rebuild_csr_formats(Part &p)
     dfree(p.code); dfree(p.dict); dfree(p.sval); dfree(p.scode); dfree(p.scol); dfree(p.sbcode);
     p.code = nullptr; p.dict = nullptr; p.sval = nullptr; p.scode = nullptr; p.scol = nullptr; p.sbcode = nullptr;
     free_sell(p);
+    free_ell_colblock(p);          // (a scattered matrix's column-blocked form: the new order may have an offset dictionary instead)
     p.ndict = 0; p.dict_reach = 0; p.sw = 0; p.max_row = 0; p.sched_period = 0;
     free_slice_sched(p);
     return build_offset_dict(p, nullptr, nullptr);

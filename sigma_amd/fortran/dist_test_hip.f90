@@ -89,6 +89,35 @@ implicit none
     endif
     call s%destroy()
     deallocate(s)
+    ! the reordering preconditioner over the ranks: every rank orders its own diagonal block (no communication), block-Jacobi
+    ! ILDU(0) of the ordered blocks, the solve in the permuted order rank by rank -- against plain CG's solution
+    block
+        type(hip_linear_solver), pointer :: pc
+        integer :: lv(2), path, ncol
+        real(dp) :: est
+        character(len=80) :: what
+        pc => hip_ldu(reorder = "colour")
+        call pc%setup(Ad)
+        call pc%info(lv, path, ncol, est, what)
+        print *, 'rank', rank, ': hip_ldu(reorder = colour) on its rows: ', trim(what), ',', ncol, 'colours'
+        if (ncol /= 2 .or. path /= 1) then
+            print *, 'rank', rank, ': the colour-ordered block is not two row-space levels'
+            call exit(1)
+        endif
+        ul = 0.0_dp
+        s => hip_cg(1.d-12)
+        call s%setup(Ad)
+        call s%solve(Ad, ul, f(r0 : r1), pc)
+        err = maxval(dabs(ul - u(r0 : r1))) / maxval(dabs(u))
+        print *, 'rank', rank, ': colour-ordered block-Jacobi ILDU-PCG', s%iterations, 'iterations, relative difference', err
+        if (s%iterations >= its1 .or. err > 1.0e-10) then
+            print *, 'rank', rank, ': distributed ILDU-PCG with the reordering preconditioner differs'
+            call exit(1)
+        endif
+        call s%destroy()
+        call pc%destroy()
+        deallocate(s, pc)
+    end block
     call Ad%destroy()
     call comm%destroy()
     call A%destroy()

@@ -41,7 +41,6 @@ def main():
     ap.add_argument("--configs", default="c3,c4,c5")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the problems (testing)")
     ap.add_argument("--gmres-mgs", action="store_true", help="C3: GMRES(30) with modified Gram-Schmidt (solver option gmres_cgs2 = 0)")
-    ap.add_argument("--gmres-cgs2", action="store_true", help="C3: GMRES(30) with blocked CGS-2, three passes (gmres_cgs2 = 2)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     sg.init(0)
@@ -72,7 +71,7 @@ def main():
         del A, d_ei, d_ej, d_ev
 
     if "c3" in todo:
-        print(json.dumps(bench.c3_leg(sg, P, torch, dev, n=int(1e7 * args.scale), gmres_orth=0 if args.gmres_mgs else 2 if args.gmres_cgs2 else 1)), flush=True)
+        print(json.dumps(bench.c3_leg(sg, P, torch, dev, n=int(1e7 * args.scale), gmres_orth=0 if args.gmres_mgs else 1)), flush=True)
 
     if "c4" in todo:
         print(json.dumps(bench.c4_leg(sg, P, torch, dev, n=int(5e6 * args.scale))), flush=True)

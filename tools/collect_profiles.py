@@ -14,7 +14,7 @@ def newest(pattern):
 
 
 for sub, name in (("stats", "kernel_stats.csv"), ("stats_ildu", "kernel_stats_ildu_pcg_1000x1000.csv"), ("stats_ildu3", "kernel_stats_ildu_100cubed.csv"),
-                  ("stats_c3_lowsync", "kernel_stats_c3_gmres_lowsync.csv"), ("stats_c3_cgs2", "kernel_stats_c3_gmres_cgs2.csv"), ("stats_c3_mgs", "kernel_stats_c3_gmres_mgs.csv"),
+                  ("stats_c3_lowsync", "kernel_stats_c3_gmres_lowsync.csv"), ("stats_c3_mgs", "kernel_stats_c3_gmres_mgs.csv"),
                   ("stats_configs", "kernel_stats_configs_c4_c5.csv"), ("stats_ildu_colour", "kernel_stats_ildu_pcg_colour_3162x3162.csv")):
     f = newest(os.path.join(sub, "*", "*kernel_stats.csv"))
     if f:

@@ -36,9 +36,8 @@ for a in "1000 cg,jacobi,ildu0,ildu0_reorder" "1000 cg,ildu0 colour" "3162 cg,il
   echo "== tools/ildu_bench.py $a"
   SGM_PC_TIMING=1 timeout 600 python tools/ildu_bench.py $a 2>&1 | grep -E '^\{|ildu setup'
 done > $OUT/time_to_solution.log 2>&1
-# C3 GMRES(30): low-synchronisation CGS-2 (default) vs blocked CGS-2 vs modified Gram-Schmidt (launch counts per step come out of the Calls column)
+# C3 GMRES(30): low-synchronisation CGS-2 (default) vs modified Gram-Schmidt (launch counts per step come out of the Calls column)
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_lowsync -- python3 tools/bench_configs.py --configs c3 > $OUT/c3_lowsync.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_cgs2 -- python3 tools/bench_configs.py --configs c3 --gmres-cgs2 > $OUT/c3_cgs2.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_mgs -- python3 tools/bench_configs.py --configs c3 --gmres-mgs > $OUT/c3_mgs.log 2>&1
 # a CSR matrix with scattered columns (n = 5e6, 8..32 per row): the column-blocked form against the row kernels
 timeout 600 python tools/probes/scattered_csr.py 2>&1 | grep '^{' > $OUT/scattered_csr.json
@@ -50,7 +49,7 @@ bash tools/probes/ceilings_r05.sh > /dev/null 2>&1
 cp gpurun_out/r05_ceilings/stream_ceilings.txt gpurun_out/r05_ceilings/c5_counters.txt $OUT/
 # C4 / C5: per-kernel times
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_configs -- python3 tools/bench_configs.py --configs c4,c5 > $OUT/configs.log 2>&1
-grep -h '^{' $OUT/c3_lowsync.log $OUT/c3_cgs2.log $OUT/c3_mgs.log $OUT/configs.log > $OUT/configs.jsonl
+grep -h '^{' $OUT/c3_lowsync.log $OUT/c3_mgs.log $OUT/configs.log > $OUT/configs.jsonl
 cat $OUT/bench.json | cut -c1-600
 # the bench line once more, now that this round's PMC passes exist: condense them on the box (profiles/r03/pmc_hbm_traffic.json
 # with the fingerprint of the sources that just ran) so that `roofline.traffic` of the line is this run's own figure
