@@ -757,39 +757,64 @@ __global__ __launch_bounds__(kBlock) void k_gsl(int64_t n, int kk, const double 
     if (threadIdx.x == 0) part_out[(size_t)kk * kMaxGrid + blockIdx.x] = t;
 }
 
-// R (kk x kk, upper) into LDS, cooperatively: the small dense steps below then run on one lane out of LDS
+// The small dense steps run on ONE WAVE out of LDS: lane i holds entry i of each vector, the triangular solves sweep by
+// columns (the pivot lane's value goes round by __shfl, the other lanes update their own entry), the matrix-vector products are
+// a row per lane.  kGsLd = 33 makes both R(i, lane) and R(lane, i) conflict-free LDS reads.
 __device__ inline void gsl_load_R(const GmresState *G, int kk, double *Rl)
 {
     for (int e = threadIdx.x; e < kk * kGsLd; e += blockDim.x) Rl[e] = G->R[e];
     __syncthreads();
+}
+// entry `from` of a lane-held vector in every lane (`from` is uniform: v_readlane, no trip through the LDS crossbar)
+__device__ inline double lane_value(double v, int from)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), from), __builtin_amdgcn_readlane(__double2loint(v), from));
+}
+// lane i: 1 / R(i, i) -- the pivots are divided out once, in parallel, and not on the solves' dependent chain
+__device__ inline double wave_inv_diag(const double *Rl, int kk)
+{
+    const int lane = threadIdx.x;
+    return lane < kk ? 1.0 / Rl[lane + lane * kGsLd] : 0.0;
+}
+// R^T u = b (R upper, kk x kk): lane i passes b_i in and gets u_i back.  Row i's sum runs over l = 0..i-1 ascending.
+__device__ inline double wave_solve_Rt(const double *Rl, int kk, double dinv, double b)
+{
+    const int lane = threadIdx.x;
+    b = b * dinv;                                        // (row i scaled by 1 / R(i,i): b_i is u_i once its sum is complete)
+    for (int i = 0; i + 1 < kk; ++i) {
+        const double ui = lane_value(b, i);
+        if (lane > i && lane < kk) b = b - (Rl[i + lane * kGsLd] * dinv) * ui;
+    }
+    return b;
+}
+// R a = b
+__device__ inline double wave_solve_R(const double *Rl, int kk, double dinv, double b)
+{
+    const int lane = threadIdx.x;
+    b = b * dinv;
+    for (int i = kk - 1; i > 0; --i) {
+        const double ai = lane_value(b, i);
+        if (lane < i) b = b - (Rl[lane + i * kGsLd] * dinv) * ai;
+    }
+    return b;
 }
 // after pass 1 (slots g[0..kk-1], t at [kk]): a = (S^T S)^-1 g through R, alpha from Pythagoras (a scale only: what it misses
 // ends up in R), column j of Gs
 __global__ __launch_bounds__(64) void k_gmres_ls1(const double *gt, GmresState *G, const int *flag)
 {
     __shared__ double Rl[33 * kGsLd];
-    __shared__ double u[34];
     if (*flag) return;
-    const int j = G->j, kk = j + 1;
+    const int j = G->j, kk = j + 1, lane = threadIdx.x;
+    const double g = lane <= kk ? gt[lane] : 0.0;        // (issued before R's load: one round trip for both)
     gsl_load_R(G, kk, Rl);
-    if (threadIdx.x != 0) return;
-    double uu = 0.0;
-    for (int i = 0; i < kk; ++i) {                     // R^T u = g
-        double sacc = gt[i];
-        for (int l = 0; l < i; ++l) sacc = sacc - Rl[l + i * kGsLd] * u[l];
-        u[i] = sacc / Rl[i + i * kGsLd];
-        uu += u[i] * u[i];
-    }
-    for (int i = kk - 1; i >= 0; --i) {                // R a = u
-        double sacc = u[i];
-        for (int l = i + 1; l < kk; ++l) sacc = sacc - Rl[i + l * kGsLd] * u[l];
-        u[i] = sacc / Rl[i + i * kGsLd];
-    }
-    const double t = gt[kk], est = t - uu;
+    const double dinv = wave_inv_diag(Rl, kk);
+    const double u = wave_solve_Rt(Rl, kk, dinv, lane < kk ? g : 0.0);
+    const double uu = wave_sum(u * u);
+    const double a = wave_solve_R(Rl, kk, dinv, u);
+    const double t = __shfl(g, kk), est = t - uu;
     const double alpha = est > 1e-24 * t ? sqrt(est) : (t > 0.0 ? 1e-12 * sqrt(t) : 1.0);
-    for (int i = 0; i < kk; ++i) { G->coef[i] = u[i]; G->Gs[i + j * 34] = u[i]; }
-    G->coef[kk] = 1.0 / alpha;
-    G->Gs[kk + j * 34] = alpha;
+    if (lane < kk) { G->coef[lane] = a; G->Gs[lane + j * 34] = a; }
+    if (lane == kk) { G->coef[kk] = 1.0 / alpha; G->Gs[kk + j * 34] = alpha; }
 }
 // after pass 2 (slots c[0..kk-1], d at [kk]): R grows by a column, column j of H = R Gs R^-1 e_j, then the rotations, the residual
 // estimate and the loop test exactly as k_gmres_givens
@@ -797,74 +822,74 @@ __global__ __launch_bounds__(64) void k_gmres_ls2(const double *cd, int m, Gmres
                                                   double *history, int64_t hist_cap, double *res_out)
 {
     __shared__ double Rl[34 * kGsLd];
-    __shared__ double q[34], pv[34];
+    __shared__ double Gl[34 * 33];
+    __shared__ double q[64], pv[64], hv[64], csl[32], snl[32];
     if (*flag) return;
-    const int j = G->j, kk = j + 1;
+    const int j = G->j, kk = j + 1, lane = threadIdx.x;
+    const double c = lane <= kk ? cd[lane] : 0.0;
+    if (lane < j) { csl[lane] = G->cs[lane]; snl[lane] = G->sn[lane]; }
+    for (int e = lane; e < kk * 34; e += 64) Gl[e] = G->Gs[e];          // columns 0..j of Gs
     gsl_load_R(G, kk, Rl);
-    if (threadIdx.x != 0) return;
-    double rr = 0.0;
-    for (int i = 0; i < kk; ++i) {                     // R^T r = c : the new column of R
-        double sacc = cd[i];
-        for (int l = 0; l < i; ++l) sacc = sacc - Rl[l + i * kGsLd] * Rl[l + kk * kGsLd];
-        const double ri = sacc / Rl[i + i * kGsLd];
-        Rl[i + kk * kGsLd] = ri;
-        G->R[i + kk * kGsLd] = ri;
-        rr += ri * ri;
-    }
-    const double d = cd[kk], rho2 = d - rr;
+    const double dinv = wave_inv_diag(Rl, kk);
+    const double r = wave_solve_Rt(Rl, kk, dinv, lane < kk ? c : 0.0); // R^T r = c : the new column of R
+    const double rr = wave_sum(r * r);
+    const double d = __shfl(c, kk), rho2 = d - rr;
     const double rho = rho2 > 1e-24 * d ? sqrt(rho2) : (d > 0.0 ? 1e-12 * sqrt(d) : 1.0);
-    Rl[kk + kk * kGsLd] = rho;
-    G->R[kk + kk * kGsLd] = rho;
-    for (int i = kk - 1; i >= 0; --i) {                // R_kk q = e_j : the last column of R_kk^-1
-        double sacc = i == j ? 1.0 : 0.0;
-        for (int l = i + 1; l < kk; ++l) sacc = sacc - Rl[i + l * kGsLd] * q[l];
-        q[i] = sacc / Rl[i + i * kGsLd];
+    if (lane <= kk) {
+        const double v = lane < kk ? r : rho;
+        Rl[lane + kk * kGsLd] = v;
+        G->R[lane + kk * kGsLd] = v;
     }
-    for (int i = 0; i <= kk; ++i) {                    // p = Gs(:, 0..j) q   (Gs is upper Hessenberg: row i has columns >= i - 1)
-        double sacc = 0.0;
-        for (int l = i > 0 ? i - 1 : 0; l <= j; ++l) sacc += G->Gs[i + l * 34] * q[l];
-        pv[i] = sacc;
-    }
+    q[lane] = wave_solve_R(Rl, kk, dinv, lane == j ? 1.0 : 0.0);             // R_kk q = e_j : the last column of R_kk^-1
+    __syncthreads();
+    double sacc = 0.0;                                                  // p = Gs(:, 0..j) q   (upper Hessenberg: row i has columns >= i - 1)
+    if (lane <= kk)
+        for (int l = lane > 0 ? lane - 1 : 0; l <= j; ++l) sacc += Gl[lane + l * 34] * q[l];
+    pv[lane] = sacc;
+    __syncthreads();
+    sacc = 0.0;                                                         // H(:, j) = R_{kk+1} p
+    if (lane <= kk)
+        for (int l = lane; l <= kk; ++l) sacc += Rl[lane + l * kGsLd] * pv[l];
+    hv[lane] = sacc;
+    __syncthreads();
     double *H = G->H + (size_t)j * (m + 1);
-    for (int i = 0; i <= kk; ++i) {                    // H(:, j) = R_{kk+1} p
-        double sacc = 0.0;
-        for (int l = i; l <= kk; ++l) sacc += Rl[i + l * kGsLd] * pv[l];
-        H[i] = sacc;
+    if (lane == 0) {
+        for (int i = 0; i < j; ++i) {
+            const double h0 = hv[i], h1_ = hv[i + 1];
+            hv[i] = csl[i] * h0 + snl[i] * h1_;
+            hv[i + 1] = -snl[i] * h0 + csl[i] * h1_;
+        }
+        const double h0 = hv[j], hn = hv[j + 1];
+        const double dd = sqrt(h0 * h0 + hn * hn);
+        const double cj = h0 / dd, sj = hn / dd;
+        G->cs[j] = cj;
+        G->sn[j] = sj;
+        hv[j] = dd;
+        hv[j + 1] = 0.0;
+        const double gj = G->g[j];
+        G->g[j + 1] = -sj * gj;
+        G->g[j] = cj * gj;
+        const double res = fabs(sj * gj);
+        const int64_t it = *iters;
+        if (history && it < hist_cap) history[it] = res * res;
+        *iters = it + 1;
+        *res_out = res * res;
+        G->j = j + 1;
+        if (!(res > tol)) *flag = 1;
     }
-    for (int i = 0; i < j; ++i) {
-        const double h0 = H[i], h1_ = H[i + 1];
-        H[i] = G->cs[i] * h0 + G->sn[i] * h1_;
-        H[i + 1] = -G->sn[i] * h0 + G->cs[i] * h1_;
-    }
-    const double h0 = H[j], hn = H[j + 1];
-    const double dd = sqrt(h0 * h0 + hn * hn);
-    G->cs[j] = h0 / dd;
-    G->sn[j] = hn / dd;
-    H[j] = dd;
-    H[j + 1] = 0.0;
-    G->g[j + 1] = -G->sn[j] * G->g[j];
-    G->g[j] = G->cs[j] * G->g[j];
-    const double res = fabs(G->g[j + 1]);
-    const int64_t it = *iters;
-    if (history && it < hist_cap) history[it] = res * res;
-    *iters = it + 1;
-    *res_out = res * res;
-    G->j = j + 1;
-    if (!(res > tol)) *flag = 1;
+    __syncthreads();
+    if (lane <= kk) H[lane] = hv[lane];
 }
 // end of a cycle: the coefficients of the orthonormal basis (k_gmres_solve_y) become those of the stored columns, y <- R^-1 y
 __global__ __launch_bounds__(64) void k_gmres_ls_y(GmresState *G)
 {
     __shared__ double Rl[33 * kGsLd];
-    const int k = G->j;
+    const int k = G->j, lane = threadIdx.x;
     if (k <= 0) return;
+    const double y = lane < k ? G->y[lane] : 0.0;
     gsl_load_R(G, k, Rl);
-    if (threadIdx.x != 0) return;
-    for (int i = k - 1; i >= 0; --i) {
-        double sacc = G->y[i];
-        for (int l = i + 1; l < k; ++l) sacc = sacc - Rl[i + l * kGsLd] * G->y[l];
-        G->y[i] = sacc / Rl[i + i * kGsLd];
-    }
+    const double a = wave_solve_R(Rl, k, wave_inv_diag(Rl, k), y);
+    if (lane < k) G->y[lane] = a;
 }
 
 // ---- Lanczos (src/eigensolver.f90:27-90) -------------------------------------------------
