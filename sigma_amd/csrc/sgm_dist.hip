@@ -117,6 +117,22 @@ void prof_end(int phase, hipStream_t st)
 void prof_span(int phase, hipEvent_t a, hipEvent_t b) { if (g_prof.on && a && b) g_prof.spans.push_back({phase, a, b}); }
 
 // ------------------------------------------------------------------ halo exchange
+// the links of an in-process partition, by value in the kernel's arguments: link l copies count[l] entries idx[l][.] of part
+// src[l]'s vector into part dst[l]'s halo slots from dst_off[l] on (k_gather's statement)
+constexpr int kLinkMax = 64, kLinkParts = 64;
+struct GatherLinks {
+    double *x[kLinkParts];
+    const int32_t *idx[kLinkMax];
+    int64_t dst_off[kLinkMax];
+    int32_t count[kLinkMax], src[kLinkMax], dst[kLinkMax];
+};
+__global__ __launch_bounds__(kBlock) void k_gather_links(GatherLinks g)
+{
+    const int l = blockIdx.y;
+    const int32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < g.count[l]) g.x[g.dst[l]][g.dst_off[l] + i] = g.x[g.src[l]][g.idx[l][i]];
+}
+
 int halo_exchange(sgm_mat A, double *const *xext, hipStream_t st)
 {
     if (A->comm) {
@@ -142,7 +158,32 @@ int halo_exchange(sgm_mat A, double *const *xext, hipStream_t st)
         hb_phase(hb_prev);
         return SGM_OK;
     }
-    // in-process partitions: the sender's list is gathered straight into the peer's halo
+    // in-process partitions: the sender's list is gathered straight into the peer's halo -- every link of the partition by ONE
+    // launch when the table fits the kernel's arguments (blockIdx.y = link), link by link otherwise
+    {
+        GatherLinks g;
+        int nl = 0, maxc = 0;
+        bool fits = A->parts.size() <= (size_t)kLinkParts;
+        for (size_t ip = 0; fits && ip < A->parts.size(); ++ip) {
+            g.x[ip] = xext[ip];
+            for (auto &nb : A->parts[ip].nbrs) {
+                if (!nb.send_count) continue;
+                if (nl == kLinkMax) { fits = false; break; }
+                g.idx[nl] = nb.send_idx;
+                g.dst_off[nl] = (int64_t)A->parts[nb.peer].ncol_own + nb.recv_offset;
+                g.count[nl] = nb.send_count;
+                g.src[nl] = (int32_t)ip;
+                g.dst[nl] = nb.peer;
+                maxc = std::max(maxc, (int)nb.send_count);
+                ++nl;
+            }
+        }
+        if (fits && nl > 1) {
+            hipLaunchKernelGGL(k_gather_links, dim3((maxc + kBlock - 1) / kBlock, nl), dim3(kBlock), 0, st, g);
+            SGM_HIP(hipGetLastError());
+            return SGM_OK;
+        }
+    }
     for (size_t ip = 0; ip < A->parts.size(); ++ip) {
         Part &p = A->parts[ip];
         for (auto &nb : p.nbrs) {

@@ -295,6 +295,17 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const double *part, int count
     if (threadIdx.x == 0) *slot = d;
 }
 
+// the same for a table of partial arrays (an in-process partition's parts x dots): block b = entry b
+constexpr int kReduceTabMax = 96;
+struct ReduceTab { const double *part[kReduceTabMax]; double *slot[kReduceTabMax]; int count[kReduceTabMax]; };
+__global__ __launch_bounds__(kBlock) void k_reduce_tab(ReduceTab rt)
+{
+    __shared__ double red[kBlock / 64];
+    ScalarRef r{rt.part[blockIdx.x], rt.count[blockIdx.x]};
+    const double d = load_scalar<kBlock>(r, red);
+    if (threadIdx.x == 0) *rt.slot[blockIdx.x] = d;
+}
+
 // ---- dot_order = 1: the reference's dot_product order -----------------------------------------------------
 // The pinned reference build (amdflang -O2, x86-64 without FMA) turns `dot_product(a, b)` into ONE accumulator that
 // starts at +0.0 and takes the individually rounded products a(i) * b(i) first element to last
@@ -1178,10 +1189,23 @@ int finish_dots(sgm_solver s, sgm_mat A, const int *ks, int nk, const int (*vecs
     if (!s->multi) return SGM_OK;
     // slots ks[] must be contiguous for the all-reduce: callers pass consecutive ids
     prof_begin(PH_DOT_REDUCE, g_rt.stream);
-    for (size_t ip = 0; ip < s->work.size(); ++ip)
-        for (int t = 0; t < nk; ++t)
-            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, g_rt.stream, part(s, ip, ks[t]),
-                               s->work[ip].count[ks[t]], s->work[ip].slots + ks[t]);
+    if (!A->comm && s->work.size() * (size_t)nk <= (size_t)kReduceTabMax) {
+        // an in-process partition: every part's partial sums of every dot by one launch
+        ReduceTab rt;
+        int e = 0;
+        for (size_t ip = 0; ip < s->work.size(); ++ip)
+            for (int t = 0; t < nk; ++t, ++e) {
+                rt.part[e] = part(s, ip, ks[t]);
+                rt.count[e] = s->work[ip].count[ks[t]];
+                rt.slot[e] = s->work[ip].slots + ks[t];
+            }
+        hipLaunchKernelGGL(k_reduce_tab, dim3(e), dim3(kBlock), 0, g_rt.stream, rt);
+    } else {
+        for (size_t ip = 0; ip < s->work.size(); ++ip)
+            for (int t = 0; t < nk; ++t)
+                hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, g_rt.stream, part(s, ip, ks[t]),
+                                   s->work[ip].count[ks[t]], s->work[ip].slots + ks[t]);
+    }
     prof_end(PH_DOT_REDUCE, g_rt.stream);
     std::vector<double *> ptrs(s->work.size());
     for (size_t ip = 0; ip < s->work.size(); ++ip) ptrs[ip] = s->work[ip].slots + ks[0];
@@ -1244,12 +1268,19 @@ struct GraphBatch {
         return true;
     }
 };
-// a solve qualifies when nothing but plain kernel launches on one stream makes up an iteration
+// a solve qualifies when nothing but kernel launches (and stream forks that join again) makes up an iteration: one GPU's matrix or
+// the parts of an in-process partition (their gathers and sums are kernels: 73 launches per CG iteration with 8 parts, and the
+// iteration is its launch path until they are replayed), plain, Jacobi, or ILDU(0) with two-level factors on every part (a colour
+// ordering: the sweeps are two row-space launches; the pipelined sweeps of a natural order have an abort word the host watches)
 bool graph_applies(sgm_solver s, sgm_mat A, sgm_pc pc)
 {
     const int pk = pc ? pc_kind(pc) : 0;
-    return s->opt.krylov_graph && !s->multi && s->work.size() == 1 && !A->comm && A->fmt != SGM_FMT_COMPOSITE &&
-           (pk == 0 || pk == SGM_PC_JACOBI) && !prof_on();
+    bool pc_ok = pk == 0 || pk == SGM_PC_JACOBI;
+    if (pk == SGM_PC_ILDU0 && !s->seq && s->opt.reorder_solve >= 2) {
+        pc_ok = true;
+        for (size_t ip = 0; pc_ok && ip < s->work.size(); ++ip) pc_ok = pc_cg_fused_rows(pc, ip) > 0;
+    }
+    return s->opt.krylov_graph && !A->comm && A->fmt != SGM_FMT_COMPOSITE && pc_ok && !prof_on();
 }
 
 // ---------------------------------------------------------------------------------- CG

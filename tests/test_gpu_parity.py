@@ -2840,6 +2840,47 @@ def test_partitioned_block_jacobi_ildu(orc, nparts):
             pc.get("D", np.float64)
 
 
+@pytest.mark.parametrize("nparts", [1, 4])
+def test_replayed_iteration_groups_are_the_launch_loop(nparts):
+    """Option krylov_graph: after 64 iterations the launch loops go on as replays of ONE captured group of 16 (a hipGraph).
+    One GPU's matrix or an in-process partition (its gathers / sums of partial sums are kernels, one launch each), plain,
+    Jacobi, or ILDU(0) of a colour ordering (two-level factors: the sweeps are row-space launches).  Same kernels, same
+    arguments: the solve is the launch loop's bit for bit -- iterations, solution, residual history."""
+    nx, ny = 160, 150
+    n = nx * ny
+    ptr, node, val = P.poisson2d_csr(nx, ny)
+    b = P.test_vector(n)
+    if nparts == 1:
+        H = sg.csr_matrix(n, n, ptr, node, val)
+    else:
+        starts = (np.arange(nparts + 1) * n // nparts) // 2 * 2
+        starts[-1] = n
+        H = sg.partitioned_csr_matrix(n, n, ptr, node, val, starts)
+    for mk_pc in (lambda: None, sg.jacobi, lambda: sg.ldu(reorder="colour")):
+        for mk in (sg.cg, sg.bicgstab):
+            got = []
+            for graph in (1, 0):
+                pc = mk_pc()
+                if pc is not None:
+                    pc.setup(H)
+                s = mk(1e-13)
+                s.set_option("cg_small", 0)                 # (one part this small would run as a single launch)
+                s.set_option("bicgstab_small", 0)
+                s.set_option("krylov_graph", graph)
+                s.setup(H)
+                s.set_history(4096)
+                u = np.zeros(n)
+                s.solve(H, u, b, pc)
+                got.append((u, s.iterations, s.history.copy()))
+                s.destroy()
+                if pc is not None:
+                    pc.destroy()
+            assert got[0][1] == got[1][1] and got[0][1] > 80, (nparts, got[0][1], got[1][1])      # (long enough to have been replayed)
+            assert np.array_equal(got[0][0], got[1][0])
+            assert np.array_equal(got[0][2], got[1][2])
+    H.destroy()
+
+
 @pytest.mark.parametrize("where", ["host", "device"])
 def test_partition_handed_over_part_by_part_equals_the_one_cut_from_whole_arrays(orc, where):
     """sgm_csr_create_partitioned_parts (row blocks with GLOBAL columns, as a rank hands its rows to sgm_csr_create_dist;

@@ -20,6 +20,7 @@ nx = int(sys.argv[1]) if len(sys.argv) > 1 else 3162
 parts = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 only = sys.argv[4] if len(sys.argv) > 4 else ""           # "one" / "parts": one matrix form; + ":none" / ":ildu": one preconditioner
+graph = not (len(sys.argv) > 5 and sys.argv[5] == "nograph")      # "nograph": the launch loop without the replayed groups
 n = nx * nx
 dev = torch.device("cuda", 0)
 sg.init(0)
@@ -50,6 +51,8 @@ for label, np_ in (("one part", 1), (f"{parts} in-process parts", parts)):
         tset = time.perf_counter() - t0
         s = sg.cg(1e-300)
         s.set_max_iter(iters)
+        if not graph:
+            s.set_option("krylov_graph", 0)
         s.setup(A)
         u = torch.zeros(n, dtype=torch.float64, device=dev)
         sg.set_async(True)
@@ -62,7 +65,7 @@ for label, np_ in (("one part", 1), (f"{parts} in-process parts", parts)):
         dt = time.perf_counter() - t0
         sg.set_async(False)
         out = {"grid": nx, "matrix": label, "pc": pcname, "setup_s": tset, "iterations": s.last_iterations,
-               "us_per_iter": 1e6 * dt / max(1, s.last_iterations), "res2": s.res2}
+               "us_per_iter": 1e6 * dt / max(1, s.last_iterations), "res2": s.res2, "krylov_graph": graph}
         if pc:
             out["pc_info_part0"] = pc.info(0)
         print(json.dumps(out), flush=True)
