@@ -1,4 +1,4 @@
-"""k_cg_coop: CG on a mid-sized system as ONE launch of up to 256 co-resident workgroups (sgm_solvers.hip; VERDICT r03
+"""k_cg_coop: CG on a mid-sized system as ONE launch of up to 256 co-resident workgroups (sgm_cg.hip, sgm_coop.hpp; VERDICT r03
 item 6).  Same statements as the launch loop and the reference's cg_solve; only the dot products' summation order differs,
 so the gates are the launch loop's: iteration count within +-1 of the oracle's and of the launch loop's, solutions within
 max(1e-12, kappa * tol)."""
