@@ -330,6 +330,8 @@ int sgm_pc_destroy(sgm_pc pc);
  *                        iteration cap unless sgm_solver_set_max_iter (an extension) is
  *                        called; `iterations` accumulates across solves like the reference.
  *                        The whole loop is device-resident: x and b cross the boundary once.
+ *                        A breakdown (NaN res2) ends the loop as it ends the reference's; `converged` is then 0
+ *                        (and the call returns SGM_ERR_NOT_CONVERGED when an iteration cap is set).
  * sgm_solver_destroy  <- solver%destroy()          cg_solvers.f90:199-212                 */
 int sgm_cg_create(sgm_solver *out, double tolerance);
 int sgm_bicgstab_create(sgm_solver *out, double tolerance);

@@ -430,6 +430,9 @@ int sgm_solver_solve(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc
         }
     }
     s->abort_dev = nullptr;
+    // A breakdown (BiCGStab: rho or omega reaches 0 / 0) ends the loop as it ends the reference's -- `dsqrt(res2) > tolerance` is
+    // false for a NaN (bicgstab_solvers.f90:154, :214) -- with x full of NaNs.  That is not "converged".
+    if (s->res2 != s->res2) s->converged = 0;
     if (Arun != A)
         for (size_t ip = 0; ip < P; ++ip) { const int64_t off = xs[ip] - s->perm_x; pc_permute_vec(pc, ip, s->perm_x + off, sx.dev + off, false); }
     s->iterations += s->last_iterations;
@@ -441,8 +444,9 @@ int sgm_solver_solve(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc
     SGM_TRY(stage_out(sx, x, nvec, where));
     SGM_TRY(finish());
     if (s->max_iter > 0 && !s->converged) {
-        fail(SGM_ERR_NOT_CONVERGED, "solver stopped at max_iter=%lld with sqrt(res2)=%g > %g",
-             (long long)s->max_iter, std::sqrt(s->res2), s->tolerance);
+        if (s->res2 != s->res2) fail(SGM_ERR_NOT_CONVERGED, "solver broke down after %lld iterations (res2 is NaN)", (long long)s->last_iterations);
+        else fail(SGM_ERR_NOT_CONVERGED, "solver stopped at max_iter=%lld with sqrt(res2)=%g > %g",
+                  (long long)s->max_iter, std::sqrt(s->res2), s->tolerance);
         return SGM_ERR_NOT_CONVERGED;
     }
     return SGM_OK;

@@ -3422,3 +3422,20 @@ def test_torch_imported_after_the_library_still_sees_the_gpu():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-600:]
     assert float(out.stdout.split()[-1]) > 0.0
+
+
+@pytest.mark.parametrize("seed", [1002, 1007, 1008, 1010, 1015, 1021])
+def test_format_fuzzer_seeds(seed):
+    """A few seeds of tests/fuzz_formats.py (mid-sized matrices of random structure under random per-matrix options: every
+    product, also after set_values and a symmetric permutation, equals the oracle's rows bit for bit)."""
+    import fuzz_formats
+    assert fuzz_formats.one(seed, verbose=False) == []
+
+
+@pytest.mark.parametrize("seed", [5006, 5007, 5128, 5917, 6160, 7868])
+def test_solver_fuzzer_seeds(seed):
+    """A few seeds of tests/fuzz_solvers.py (SPD systems of random structure, one matrix or a random row partition, random
+    preconditioner and Krylov loop): with dot_order = 1 the oracle's solve bit for bit, in tree order within the stated slack;
+    seed 7868 is a BiCGStab breakdown of the tree-order run (NaN: the loop ends like the reference's, never as converged)."""
+    import fuzz_solvers
+    assert fuzz_solvers.one(seed, verbose=False, colour=False) == []
