@@ -5,7 +5,7 @@ LDS, the column-blocked two-phase form, SELL, the lean layouts -- with random st
 product (matvec, matvec_add, both transposes, after set_values, after a symmetric permutation) must equal the oracle's rows
 bit for bit (cs_matrices.f90:600-622).
 
-    python tests/fuzz_formats.py [seconds] [first_seed]
+    python tests/fuzz_formats.py [seconds] [first_seed]          (every third seed is an ELLPACK matrix: one_ell)
 
 Prints one line per matrix and the failing seed if any; exit code 1 on a mismatch."""
 import os
@@ -137,6 +137,62 @@ def one(seed, verbose=True):
     return bad
 
 
+def one_ell(seed, verbose=True):
+    """The ELLPACK twin (ellpack_matrices.f90:640-693): rows of 1..max_d neighbours padded the reference's way."""
+    rs = np.random.RandomState(seed)
+    kind = ["stencil", "band", "scattered", "ragged"][int(rs.randint(0, 4))]
+    n = int(10 ** rs.uniform(2.5, 6.4))
+    md = int(rs.choice([1, 2, 3, 5, 7, 8, 9, 12, 16, 20, 32, 40]))
+    n = min(n, 12_000_000 // md)
+    m = n if rs.rand() < 0.8 else max(1, int(n * rs.uniform(0.3, 2.0)))
+    deg = np.full(n, md) if kind in ("stencil", "scattered") else rs.randint(1 if kind == "band" else 0, md + 1, size=n)
+    if deg.max(initial=0) == 0:
+        deg[0] = 1
+    rows = np.repeat(np.arange(n), deg)
+    if kind == "stencil":
+        offs = np.sort(rs.choice(np.arange(-3 * md, 3 * md + 1), size=md, replace=False)) * int(rs.choice([1, 1, 37]))
+        cols = rows + np.tile(offs, n)
+        cols = np.clip(cols, 0, m - 1)                     # (clipped at the edges: repeated neighbours there, kept by set_value's rule)
+    elif kind == "band":
+        bw = int(10 ** rs.uniform(0.5, 3.5))
+        cols = np.clip((rows * (m / n)).astype(np.int64) + rs.randint(-bw, bw + 1, size=rows.size), 0, m - 1)
+    else:
+        cols = rs.randint(0, m, size=rows.size)
+    ei, ej, ev = (rows + 1).astype(np.int32), (cols + 1).astype(np.int32), rs.standard_normal(rows.size)
+    E = orc.EllMatrix.from_edges(n, m, ei, ej, ev)
+    opts = {"ell_offset_dict": int(rs.choice([1, 1, 0])), "csr_sliced": int(rs.choice([1, 1, 0])), "ell_colblock": int(rs.choice([1, 1, 2, 0])),
+            "ell_colblock_cols": int(rs.choice([16384, 16384, 4096, 2048])), "ell_colblock_rows": int(rs.choice([0, 0, 256, 512]))}
+    defaults = {"ell_offset_dict": 1, "csr_sliced": 1, "ell_colblock": 1, "ell_colblock_cols": 16384, "ell_colblock_rows": 0}
+    x, y0, xt = rs.standard_normal(m), rs.standard_normal(n), rs.standard_normal(n)
+    bad = []
+    try:
+        for k, v in opts.items():
+            sg.set_option(k, v)
+        H = sg.ellpack_matrix(n, m, E.node, E.val)
+        kern = H.kernel
+        y = np.zeros(n); H.matvec(x, y)
+        if not np.array_equal(y, E.matvec(x)): bad.append("matvec")
+        ya = y0.copy(); H.matvec_add(x, ya)
+        if not np.array_equal(ya, E.matvec_add(x, y0.copy())): bad.append("matvec_add")
+        t = np.zeros(m); H.matvec_t(xt, t)
+        if not np.array_equal(t, E.matvec_t(xt)): bad.append("matvec_t")
+        v2 = np.where(E.val != 0.0, rs.standard_normal(E.val.shape), E.val)         # new values on the same pattern
+        H.set_values(v2)
+        E2 = orc.EllMatrix(n, m, E.max_d, E.node, v2, E.degrees)
+        y = np.zeros(n); H.matvec(x, y)
+        if not np.array_equal(y, E2.matvec(x)): bad.append("matvec after set_values")
+        t = np.zeros(m); H.matvec_t(xt, t)
+        if not np.array_equal(t, E2.matvec_t(xt)): bad.append("matvec_t after set_values")
+        H.destroy()
+    finally:
+        for k, v in defaults.items():
+            sg.set_option(k, v)
+    changed = {k: v for k, v in opts.items() if v != defaults[k]}
+    if verbose or bad:
+        print(f"seed {seed}: ell {kind} n={n} m={m} max_d={E.max_d} {changed} {kern}" + (f"  MISMATCH: {bad}" if bad else ""), flush=True)
+    return bad
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -145,7 +201,7 @@ def main():
     failures = []
     count = 0
     while time.time() - t0 < seconds:
-        if one(seed):
+        if (one_ell if seed % 3 == 2 else one)(seed):
             failures.append(seed)
         seed += 1
         count += 1
