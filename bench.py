@@ -46,7 +46,7 @@ def csrc_sha1():
     """Fingerprint of the kernel sources; PMC summaries under profiles/ carry the one they were
     collected with, and `traffic` is only quoted when it matches what runs now."""
     h = hashlib.sha1()
-    for f in ("sgm_spmv.hip", "sgm_internal.hpp"):          # the SpMV kernels and the header they share
+    for f in ("sgm_spmv.hip", "sgm_spmv_select.hpp", "sgm_internal.hpp"):          # the SpMV kernels and the header they share
         h.update(open(os.path.join(ROOT, "sigma_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 

@@ -8,7 +8,7 @@ against the oracle's loops on the same system (cg_solvers.f90:116-194, bicgstab_
 Gates: ILDU(0) applies bit-exact (block-Jacobi ILDU on a partition); with dot_order = 1 (systems up to 60000 rows) CG and
 BiCGStab are the oracle's solve BIT FOR BIT -- iterations and solution, one matrix or in-process parts; in the default (tree)
 order at tolerance 1e-8: CG iterations +-2 (+-6 %), BiCGStab within a factor 3 (its plateaus end when rounding says so), GMRES(30) +-2 against the oracle's CGS-2
-(its modified Gram-Schmidt stagnates near 1e-10 on these systems: another algorithm, not a gate); solutions 1e-7 relative.
+(its modified Gram-Schmidt stagnates near 1e-10 on these systems: another algorithm, not a gate); solutions 1e-6 relative.
 
     python tests/fuzz_solvers.py [seconds] [first_seed]"""
 import os
@@ -192,7 +192,7 @@ def one(seed, verbose=True, colour=True):
         if abs(it - itr) > slack:
             bad.append(f"iterations {it} vs {itr}")
         err = np.abs(u - ur).max() / max(np.abs(ur).max(), 1e-300)
-        if not err <= 1e-7 * max(1.0, itr / 50):
+        if not err <= 1e-6 * max(1.0, itr / 50):
             bad.append(f"solution {err:.2e}")
         info = f"it {it}/{itr} err {err:.1e}"
     if solver == "cg" and nparts > 1 and pck in ("none", "jacobi"):

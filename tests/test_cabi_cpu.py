@@ -311,3 +311,18 @@ def test_bench_watchdog_ends_a_process_that_stops_making_progress(tmp_path):
     code2 = code.replace("1.5, 100.0", "50.0, 2.0").replace("time.sleep(60)", "\nfor i in range(600):\n    hb.phase(f'step {i}'); time.sleep(0.1)")
     p = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=120, env=env)
     assert p.returncode == 86 and "past --deadline-s" in p.stderr
+
+
+def test_header_is_c99_and_a_plain_c_program_links_and_fails_loudly_without_a_gpu(tmp_path):
+    """include/sigma_hip.h is a C header: tools/c_driver.c (BASELINE C1 through the C ABI, no C++ and no Python in the
+    process) compiles as strict C99 against it, links with libsigma_hip.so alone, and -- here, without a GPU -- stops at
+    sgm_init with the library's own message instead of computing anything on the host."""
+    import subprocess
+    exe = str(tmp_path / "c_driver")
+    so_dir = os.path.join(ROOT, "sigma_amd")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tools", "c_driver.c"), "-L", so_dir, "-lsigma_hip", "-Wl,-rpath," + so_dir, "-lm", "-o", exe],
+                   check=True, capture_output=True, text=True)
+    p = subprocess.run([exe, "100"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 2, (p.returncode, p.stdout, p.stderr)
+    assert "sgm_init" in p.stderr and "no CPU path" in p.stderr, p.stderr

@@ -201,3 +201,25 @@ def test_solver_and_preconditioner_options_are_per_handle(tmp_path):
     pw.solve(A, z1, r); pp.solve(A, z2, r)
     assert np.array_equal(z1, z2) and np.array_equal(z1, orc.Ildu(Ao).solve(r))
     _raises(BAD_ARG, "not a preconditioner option", lambda: pp.set_option("dot_order", 1))
+
+
+@pytest.mark.parametrize("dot_order,iterations", [(0, 5000), (1, 9388)])
+def test_c1_from_plain_c_through_the_header(tmp_path, dot_order, iterations):
+    """tools/c_driver.c: BASELINE C1 (the reference's solver_test_diffusion_1d at n = 10000) from a C99 program that sees only
+    include/sigma_hip.h and libsigma_hip.so -- host arrays in, solution out.  Tree-order dots stop after 5000 iterations,
+    dot_order = 1 after the compiled reference's 9388 (tests/test_gpu_parity.py has the bit-identity of that solve); both
+    reach the analytic solution."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_driver")
+    so_dir = os.path.join(root, "sigma_amd")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O2", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tools", "c_driver.c"), "-L", so_dir, "-lsigma_hip", "-Wl,-rpath," + so_dir, "-lm", "-o", exe],
+                   check=True, capture_output=True, text=True)
+    p = subprocess.run([exe, "10000", str(dot_order)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["iterations"] == iterations and out["converged"] == 1, out
+    assert out["max_err_vs_analytic"] <= 1e-9 and out["matvec_row2"] == 0.0, out

@@ -32,7 +32,7 @@ if os.path.exists(os.path.join(src, "configs.jsonl")):
     shutil.copy(os.path.join(src, "configs.jsonl"), os.path.join(dst, "configs_c3_c4_c5.jsonl"))
 
 h = hashlib.sha1()
-for f in ("sgm_spmv.hip", "sgm_internal.hpp"):
+for f in ("sgm_spmv.hip", "sgm_spmv_select.hpp", "sgm_internal.hpp"):
     h.update(open(os.path.join(root, "sigma_amd", "csrc", f), "rb").read())
 out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 1 --spmv-per-step 4 "
                   "--cg-steps 0 --no-cpu --no-c5 --no-variants",
