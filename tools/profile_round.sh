@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_round
 rm -rf $OUT; mkdir -p $OUT
-timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo bench=$?
+T0=$(date +%s); timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo bench=$? wall=$(( $(date +%s) - T0 ))s | tee $OUT/bench_wall.txt
 BARGS="--steps 2 --warmup 1 --spmv-per-step 64 --cg-steps 30 --no-cpu --no-c5 --no-c3 --no-c4 --no-dist-overhead --no-pcg --no-ceilings"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py $BARGS > $OUT/stats.log 2>&1
 PARGS="--steps 1 --warmup 1 --spmv-per-step 4 --cg-steps 0 --no-cpu --no-c5 --no-c3 --no-c4 --no-variants --no-dist-overhead --no-pcg --no-ceilings"
