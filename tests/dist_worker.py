@@ -51,6 +51,11 @@ def run(rank, world, port, case, res):
             run_composite(rank, world, comm, dev, res)
             comm.destroy()
             return
+        if case.startswith("fuzz:"):
+            _, seed0, count = case.split(":")
+            run_fuzz(rank, world, comm, res, int(seed0), int(count))
+            comm.destroy()
+            return
         if case == "badrows":
             # rank 1 hands over rows whose ptr does not match nnz: EVERY rank must come back with an error (the verdict
             # travels in the all-gather) instead of rank 1 leaving and its peers waiting in the collective for ever
@@ -335,6 +340,99 @@ def run(rank, world, port, case, res):
         comm.destroy()
     finally:
         dist.destroy_process_group()
+
+
+def run_fuzz(rank, world, comm, res, seed0, count):
+    """`count` seeded systems of tests/fuzz_solvers.py's generator, each cut into `world` row blocks at RANDOM even boundaries
+    (blocks of a few rows, blocks without neighbours, every rank a neighbour of every other on the random graphs): products
+    and transposed products of the owned rows bit-exact, CG in the reference's dot order with a random preconditioner the
+    oracle's solve bit for bit, tree-order CG the same bits whether p is exchanged or its halo formed locally."""
+    import numpy as np
+    import oracle as orc
+    import sigma_amd as sg
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fuzz_solvers as F
+    done = []
+    for seed in range(seed0, seed0 + count):
+        rs = np.random.RandomState(seed)
+        kind, n, (ptr, node, val) = F.make(rs)
+        if n < 4 * world or n > 120000:
+            continue
+        A = orc.CsrMatrix(n, n, ptr, node, val)
+        cuts = np.sort(rs.choice(np.arange(1, n // 2), size=world - 1, replace=False)) * 2
+        starts = np.concatenate([[0], cuts, [n]]).astype(np.int64)
+        pck = ["none", "jacobi", "ildu", "ildu_colour"][int(rs.randint(0, 4))]
+        r0, r1 = int(starts[rank]), int(starts[rank + 1])
+        n_own = r1 - r0
+        k0, k1 = ptr[r0] - 1, ptr[r1] - 1
+        lptr = (ptr[r0:r1 + 1] - k0).astype(np.int32)
+        H = sg.dist_csr_matrix(comm, starts, lptr, np.ascontiguousarray(node[k0:k1]), np.ascontiguousarray(val[k0:k1]))
+        tag = (seed, kind, n, [int(v) for v in starts], pck)
+        x, xt, b = rs.standard_normal(n), rs.standard_normal(n), rs.standard_normal(n)
+        xe = np.zeros(H.x_len); xe[:n_own] = x[r0:r1]
+        y = np.zeros(n_own); H.matvec(xe, y)
+        assert np.array_equal(y, A.matvec(x)[r0:r1]), ("matvec", tag)
+        t = np.zeros(n_own); H.matvec_t(xt[r0:r1].copy(), t)
+        assert np.array_equal(t, A.matvec_t(xt)[r0:r1]), ("matvec_t", tag)
+        # the oracle's system: the diagonal blocks for ILDU, the blockwise colour order for reorder="colour"
+        Ao, bo, perm, opc, mk = A, b, None, None, None
+        if pck == "jacobi":
+            opc, mk = orc.Jacobi(A), sg.jacobi
+        elif pck == "ildu":
+            opc, mk = orc.Ildu(F.block_diagonal(A, starts)), sg.ldu
+        elif pck == "ildu_colour":
+            Ab = F.block_diagonal(A, starts)
+            perm = np.zeros(n, np.int32)
+            for k in range(world):
+                q0, q1 = int(starts[k]), int(starts[k + 1])
+                a0, a1 = Ab.ptr[q0] - 1, Ab.ptr[q1] - 1
+                B = orc.CsrMatrix(q1 - q0, q1 - q0, (Ab.ptr[q0:q1 + 1] - a0).astype(np.int32), (Ab.node[a0:a1] - q0).astype(np.int32), Ab.val[a0:a1].copy())
+                try:
+                    perm[q0:q1] = orc.greedy_color_ordering(B)[0] + q0
+                except ValueError:
+                    perm = None
+                    break
+            if perm is None:                      # a block not connected from its first vertex: plain block-Jacobi ILDU instead
+                pck, opc, mk = "ildu", orc.Ildu(Ab), sg.ldu
+            else:
+                Ao = orc.permuted(A, perm, perm)
+                opc = orc.Ildu(F.block_diagonal(Ao, starts))
+                bo = np.empty(n); bo[perm - 1] = b
+                mk = lambda: sg.ldu(reorder="colour")
+        ur, itr = orc.cg(Ao, bo, tol=1e-8, pc=opc, max_iter=300)[:2]
+        if perm is not None:
+            ur = ur[perm - 1]
+        bl = b[r0:r1].copy()
+        pc = mk() if mk else None
+        if pc is not None:
+            pc.setup(H)
+        se = sg.cg(1e-8)
+        se.set_option("dot_order", 1)
+        se.set_max_iter(300)
+        se.setup(H)
+        u = np.zeros(n_own)
+        se.solve(H, u, bl, pc, check=False)
+        assert se.last_iterations == itr, ("dot_order=1 iterations", tag, se.last_iterations, itr)
+        assert np.array_equal(u, ur[r0:r1]), ("dot_order=1 solution", tag, float(np.abs(u - ur[r0:r1]).max()))
+        se.destroy()
+        got = {}
+        for mode in (0, 1):
+            sv = sg.cg(1e-8)
+            sv.set_option("dist_halo_fused", mode)
+            sv.set_max_iter(300)
+            sv.setup(H)
+            u = np.zeros(n_own)
+            sv.solve(H, u, bl, pc, check=False)
+            got[mode] = (u, sv.last_iterations)
+            sv.destroy()
+        assert got[0][1] == got[1][1] and np.array_equal(got[0][0], got[1][0]), ("dist_halo_fused", tag, got[0][1], got[1][1])
+        if pc is not None:
+            pc.destroy()
+        H.destroy()
+        done.append(seed)
+    res["n_halo"] = 1
+    res["solves"] = {"fuzz": {"iterations": len(done)}}
+    res["seeds"] = done
 
 
 def run_composite(rank, world, comm, dev, res):

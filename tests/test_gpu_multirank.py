@@ -81,6 +81,15 @@ def test_ranks_share_one_gpu_over_the_host_staged_transport(world, case, tmp_pat
         assert len(v) == 1, (k, v)
 
 
+@pytest.mark.parametrize("world,seed0", [(2, 300000), (3, 300100), (4, 300200)])
+def test_rank_fuzz_seeds(world, seed0, tmp_path):
+    """tests/dist_worker.py `fuzz:<seed>:<count>`: seeded systems of tests/fuzz_solvers.py's generator over ranks with RANDOM
+    row boundaries -- products bit-exact, dot_order = 1 CG (random preconditioner, colour-ordered ILDU included) the oracle's
+    solve bit for bit, tree-order CG the same bits with p exchanged or its halo formed locally."""
+    results = _run_ranks(world, f"fuzz:{seed0}:12", tmp_path, mock=True)
+    assert len({tuple(r["seeds"]) for r in results}) == 1 and len(results[0]["seeds"]) >= 6, [r["seeds"] for r in results]
+
+
 def test_rejected_rows_on_one_rank_fail_on_every_rank_instead_of_hanging(tmp_path):
     """sgm_csr_create_dist validates a rank's rows before its collectives; a rank that rejects its rows still takes part
     in the all-gather, which carries the verdict: all three ranks return an error within seconds."""
