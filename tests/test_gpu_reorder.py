@@ -330,3 +330,15 @@ def test_solvers_run_in_the_colour_order_and_fuse_the_sweeps_without_changing_th
     ur, itr, _, _ = orc.cg(Ap, bp, x0=x0, tol=1e-10, pc=orc.Ildu(Ap))
     assert abs(d["cg"]["iterations"] - itr) <= 1, (d["cg"]["iterations"], itr)
     assert np.abs(u0 - ur[p - 1]).max() <= 1e-9 * np.abs(ur).max()
+
+
+@pytest.mark.parametrize("seed", [700001, 700008, 700010, 700014, 700020, 700033, 700047])
+def test_graph_fuzzer_seeds(seed):
+    """A few seeds of tests/fuzz_graphs.py (random graphs of seven kinds: breadth-first order, greedy colouring and colour
+    ordering through all three passes, the symmetric permutation by the ordering -- the oracle's results bit for bit; a graph
+    not connected from vertex 1 refused by both sides)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fuzz_graphs
+    assert fuzz_graphs.one(seed, verbose=False) == []
