@@ -465,6 +465,11 @@ static int build_sell(Part &p)
     // tiles hold consecutive rows, whose x gathers share more L1 lines than a sorted chunk's (banded 20..40 entries per row:
     // 719-753 us against 793-819 here without the window -- and 553 with it; from 33..64 on SELL wins either way:
     // 620-650 against 757-794, 64..128: 649 against 792-816, 150..300: 750 against 922)
+    // A few rows far longer than the rest: their chunk's lanes would walk max_row slots alone, every eight of them two
+    // dependent round trips to memory with nothing to hide them (one row of 1000 entries among 250,000 of 8: 166 us against 33
+    // without it; tools/probes/long_row_probe.py) -- the streaming kernel's owner lane adds a long row out of LDS at the pace of
+    // the additions themselves.
+    if (p.max_row > 256 && (int64_t)p.max_row * p.n > 16 * p.nnz && p.opt.csr_sell < 2) return SGM_OK;
     const bool short_rows = p.max_row <= 48 && p.opt.csr_sell < 2;
     if (short_rows && (!p.opt.csr_xwindow || p.n_halo != 0 || p.max_row < 8)) return SGM_OK;
     hipStream_t st = g_rt.stream;
@@ -637,6 +642,18 @@ static int build_offset_dict(Part &p, const int32_t *, const int32_t *)
     }
     SGM_HIP(hipStreamSynchronize(st));       // `dict` (host staging of the upload) goes out of scope
     if (p.scode || p.sbcode) SGM_TRY(detect_sched_period_csr(p, dict));
+    // Rows too long or too uneven for the sliced forms: the SELL form (+ the slices' windows of x) where its own rules accept
+    // the matrix, instead of the row-owner kernel with 1-byte codes -- whose owner lanes walk whole rows: dense bands and
+    // blocks of 60..200 entries per row ran at 0.01-0.06 of the roofline with it (tools/perf_survey.py: n = 60301, 199 per
+    // row: 559 us), an order of magnitude behind SELL on the same matrices.
+    if (!p.scode && !p.sbcode) {
+        SGM_TRY(build_sell(p));
+        if (p.sl_val) {              // (the part is now what a matrix without a dictionary is: nothing reads the byte codes again)
+            dfree(p.code); dfree(p.dict);
+            p.code = nullptr; p.dict = nullptr;
+            p.ndict = 0; p.dict_reach = 0;
+        }
+    }
     csr_go_lean(p);
     return SGM_OK;
 }

@@ -123,6 +123,32 @@ __global__ __launch_bounds__(BLOCK) void k_csr_spmv(
             // (eight independent LDS reads, then the adds in stored order: a long row is a serial chain of adds, but it
             // need not be a serial chain of LDS round trips as well)
             const int32_t kend = min(ke, te);
+            if (kend - k >= 24) {
+                // a LONG row (a tile may hold nothing else): groups of eight without predicates, the next group's LDS reads in
+                // flight while this one is added -- the lane then runs at the chain's own pace, one dependent add per entry
+                // (4.2 ns; tools/probes/long_row_probe.py: 33 ns per entry with the predicated loop below alone, which is what a
+                // product with ONE row of 1e5 entries waited for)
+                const double *pp = prod + (k - ts);
+                double a[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] = pp[u];
+                int32_t left = kend - k;
+                while (left >= 24) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) b[u] = pp[8 + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) z = z + a[u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) a[u] = pp[16 + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) z = z + b[u];
+                    pp += 16; left -= 16;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) z = z + a[u];
+                left -= 8;
+                k = kend - left;
+            }
             while (k < kend) {
                 const int cnt = min(kend - k, 8);
                 double pv[8];
