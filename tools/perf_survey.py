@@ -4,7 +4,7 @@
 HBM-bound (>= 2e6 stored entries), default options: kernel name and the fraction of 8 TB/s on the reference layout's bytes
 (12 nnz + 4 (n + 1) + 8 m + 8 n).  One JSON line per matrix, then the fractions by kind and kernel.
 
-    python tools/perf_survey.py [seconds] [first_seed]"""
+    python tools/perf_survey.py [seconds] [first_seed] [ell]"""
 import json
 import os
 import sys
@@ -25,9 +25,28 @@ exec(compile(_src.split("OPTIONS = (")[0].replace("import oracle as orc\n", ""),
 make = _ns["make"]
 
 
+def make_ell(rs):
+    """ELLPACK matrices with full rows (no padding): stencil-like, banded, scattered columns."""
+    kind = ["ell_stencil", "ell_band", "ell_scattered"][int(rs.randint(0, 3))]
+    md = int(rs.choice([3, 5, 7, 8, 9, 12, 16, 20, 27, 32, 40]))
+    n = int(10 ** rs.uniform(5.0, 6.6))
+    n = max(1000, min(n, 12_000_000 // md))
+    rows = np.arange(n)[:, None]
+    if kind == "ell_stencil":
+        offs = np.sort(rs.choice(np.arange(-3 * md, 3 * md + 1), size=md, replace=False)) * int(rs.choice([1, 1, 37, 1000]))
+        node = np.clip(rows + offs[None, :], 0, n - 1)
+    elif kind == "ell_band":
+        bw = int(10 ** rs.uniform(0.5, 4.0))
+        node = np.clip(rows + rs.randint(-bw, bw + 1, size=(n, md)), 0, n - 1)
+    else:
+        node = rs.randint(0, n, size=(n, md))
+    return kind, n, md, (node + 1).astype(np.int32), rs.standard_normal((n, md))
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 900000
+    ell = len(sys.argv) > 3 and sys.argv[3] == "ell"
     sg.init(0)
     dev = torch.device("cuda", 0)
     st = torch.cuda.Stream(device=dev)
@@ -38,11 +57,15 @@ def main():
     while time.time() - t0 < seconds:
         rs = np.random.RandomState(seed)
         seed += 1
-        kind, n, m, ptr, node, val = make(rs)
+        if ell:
+            kind, n, md, node, val = make_ell(rs)
+            m, ptr = n, np.arange(0, n * md + 1, md) + 1
+        else:
+            kind, n, m, ptr, node, val = make(rs)
         if val.size < 2_000_000:
             continue
         tc = time.perf_counter()
-        H = sg.csr_matrix(n, m, ptr, node, val)
+        H = sg.ellpack_matrix(n, m, node, val) if ell else sg.csr_matrix(n, m, ptr, node, val)
         sg.synchronize()
         create_s = time.perf_counter() - tc
         x = torch.randn(m, dtype=torch.float64, device=dev)
@@ -57,7 +80,7 @@ def main():
         e1.record(st)
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        bytes_ref = 12 * val.size + 4 * (n + 1) + 8 * m + 8 * n
+        bytes_ref = 12 * val.size + (0 if ell else 4 * (n + 1)) + 8 * m + 8 * n          # (B_ell = 12 n max_d + 8 m + 8 n)
         deg = np.diff(ptr)
         row = {"seed": seed - 1, "kind": kind, "n": n, "m": m, "nnz": int(val.size), "mean_row": float(deg.mean()), "max_row": int(deg.max()),
                "kernel": H.kernel, "ms": ms, "frac_reference_bytes": bytes_ref / (ms * 1e-3) / 8e12, "create_s": create_s}
