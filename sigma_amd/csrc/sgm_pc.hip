@@ -3180,11 +3180,14 @@ int sgm_pc_info(sgm_pc pc, int32_t part, int32_t *out4, double *est_us, char *pa
             o[1] = (int32_t)S->U.level_ptr.size() - 1;
             if (rows_serve(S)) {
                 o[2] = 1;
-                us = (12.0 * ((double)S->nnzL + S->nnzU) + 56.0 * S->n) / 5.5e6;
+                // one launch per level and sweep (+ the two permutations of a stand-alone apply in a colour order), about 4.5 us each
+                // when the levels are small: a 2-level apply of 1e5 rows is 32 us of launches around 2 us of traffic
+                us = (12.0 * ((double)S->nnzL + S->nnzU) + 56.0 * S->n) / 5.5e6 + 4.5 * ((double)o[0] + o[1] + (o[3] ? 2 : 0));
                 snprintf(nm, sizeof nm, "row space, %d levels", std::max(o[0], o[1]));
             } else {
                 o[2] = 4;
-                us = 0.36 * ((double)o[0] + o[1]) + (12.0 * ((double)S->nnzL + S->nnzU) + 56.0 * S->n) / 5.5e6;
+                // (0.3 us per level and sweep, measured on factors of 1e3 ... 1e5 levels: tools/pc_survey.py)
+                us = 0.30 * ((double)o[0] + o[1]) + (12.0 * ((double)S->nnzL + S->nnzU) + 56.0 * S->n) / 5.5e6;
                 snprintf(nm, sizeof nm, "level walkers, %d levels", std::max(o[0], o[1]));
             }
         }
