@@ -1092,19 +1092,19 @@ __global__ void k_grid_scatter(int64_t np, double *__restrict__ dst, const doubl
 // ---- ILDU(0) on the device ----------------------------------------------------------------------------------------
 // get_value / set_value / add_value of the reference's csr_matrix on one row of a factor (cs_matrices.f90: a scan of the
 // row; the LAST matching entry answers a get, EVERY matching entry takes a set / add)
-__device__ inline double row_get(const int32_t *node, const double *val, int32_t b, int32_t e, int32_t j)
+__host__ __device__ inline double row_get(const int32_t *node, const double *val, int32_t b, int32_t e, int32_t j)
 {
     double z = 0.0;
     for (int32_t k = b; k < e; ++k)
         if (node[k] == j) z = val[k];
     return z;
 }
-__device__ inline void row_set(const int32_t *node, double *val, int32_t b, int32_t e, int32_t j, double z)
+__host__ __device__ inline void row_set(const int32_t *node, double *val, int32_t b, int32_t e, int32_t j, double z)
 {
     for (int32_t k = b; k < e; ++k)
         if (node[k] == j) val[k] = z;
 }
-__device__ inline void row_add(const int32_t *node, double *val, int32_t b, int32_t e, int32_t j, double z)
+__host__ __device__ inline void row_add(const int32_t *node, double *val, int32_t b, int32_t e, int32_t j, double z)
 {
     for (int32_t k = b; k < e; ++k)
         if (node[k] == j) val[k] = val[k] + z;
@@ -1276,13 +1276,21 @@ __global__ void k_ildu_init(int32_t n, int32_t ncol_own, const int32_t *__restri
 // its main loop (ldu_solvers.f90:334-382), the statements of one row in the reference's order; the rows of one
 // dependency level of L side by side (row i reads rows k < i of its L pattern only -- final since an earlier level --
 // and writes its own).  One lane per row.
+__host__ __device__ inline void ildu_factor_row(int32_t i, const int32_t *Lptr, const int32_t *Lnode, double *Lval, const int32_t *Uptr,
+                                                const int32_t *Unode, double *Uval, double *D);
 __global__ void k_ildu_factor_level(const int32_t *__restrict__ order, int32_t begin, int32_t end,
                                     const int32_t *__restrict__ Lptr, const int32_t *__restrict__ Lnode, double *Lval,
                                     const int32_t *__restrict__ Uptr, const int32_t *__restrict__ Unode, double *Uval, double *D)
 {
     const int32_t p = begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= end) return;
-    const int32_t i = order[p];
+    ildu_factor_row(order[p], Lptr, Lnode, Lval, Uptr, Unode, Uval, D);
+}
+// (also run row after row on the HOST for factors that are chains: see pc_setup_ordered -- the same statements compiled with the
+// same -ffp-contract=off, the same bits)
+__host__ __device__ inline void ildu_factor_row(int32_t i, const int32_t *Lptr, const int32_t *Lnode, double *Lval, const int32_t *Uptr,
+                                                const int32_t *Unode, double *Uval, double *D)
+{
     const int32_t lb = Lptr[i], le = Lptr[i + 1], ub = Uptr[i], ue = Uptr[i + 1];
     double Di = D[i];
     for (int32_t a = lb; a < le; ++a) {
@@ -2808,6 +2816,7 @@ static int pc_setup_ordered(sgm_pc pc, sgm_mat A)
         }
         S->n = n;
         S->host_vals = false;
+        bool host_factor = false;
         if (n) {
             // sparse_static_pattern_ldu_factorization (ldu_solvers.f90:275-387) on the device: the fill, then one launch per
             // dependency level of L
@@ -2817,7 +2826,30 @@ static int pc_setup_ordered(sgm_pc pc, sgm_mat A)
             // (rows in the order of L's dependency levels, or -- grid-like factors -- of the grid's anti-diagonals)
             const std::vector<int32_t> &flp = S->forder ? S->flevel_ptr : S->L.level_ptr;
             const int32_t *ford = S->forder ? S->forder : S->L.order;
-            for (size_t l = 0; l + 1 < flp.size(); ++l) {
+            // A factor that is (nearly) a chain -- thousands of levels of a few rows each: bands with their first off-diagonal,
+            // 1-D problems -- would be one launch per row (n = 4e5: 1.9 s of launches; tools/probes/chain_setup.py).  Its rows are
+            // factored on the HOST instead, one after the other in natural order (row i reads rows k < i only: the reference's own
+            // loop order), by the very statements of k_ildu_factor_level, and the values go back: two copies and ~0.1 us per row.
+            const size_t nlev = flp.size() - 1;
+            host_factor = nlev > 4096 && (int64_t)nlev * 8 > (int64_t)n;
+            if (host_factor) {
+                std::vector<int32_t> hLp((size_t)n + 1), hUp((size_t)n + 1), hLn((size_t)std::max(S->nnzL, 1)), hUn((size_t)std::max(S->nnzU, 1));
+                std::vector<double> hLv((size_t)std::max(S->nnzL, 1)), hUv((size_t)std::max(S->nnzU, 1)), hD((size_t)n);
+                SGM_HIP(hipMemcpyAsync(hLp.data(), S->dLptr, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, st));
+                SGM_HIP(hipMemcpyAsync(hUp.data(), S->dUptr, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, st));
+                if (S->nnzL) SGM_HIP(hipMemcpyAsync(hLn.data(), S->dLnode, (size_t)S->nnzL * 4, hipMemcpyDeviceToHost, st));
+                if (S->nnzU) SGM_HIP(hipMemcpyAsync(hUn.data(), S->dUnode, (size_t)S->nnzU * 4, hipMemcpyDeviceToHost, st));
+                if (S->nnzL) SGM_HIP(hipMemcpyAsync(hLv.data(), S->dLval, (size_t)S->nnzL * 8, hipMemcpyDeviceToHost, st));
+                if (S->nnzU) SGM_HIP(hipMemcpyAsync(hUv.data(), S->dUval, (size_t)S->nnzU * 8, hipMemcpyDeviceToHost, st));
+                SGM_HIP(hipMemcpyAsync(hD.data(), S->D, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+                SGM_HIP(hipStreamSynchronize(st));
+                for (int32_t i = 0; i < n; ++i) ildu_factor_row(i, hLp.data(), hLn.data(), hLv.data(), hUp.data(), hUn.data(), hUv.data(), hD.data());
+                if (S->nnzL) SGM_HIP(hipMemcpyAsync(S->dLval, hLv.data(), (size_t)S->nnzL * 8, hipMemcpyHostToDevice, st));
+                if (S->nnzU) SGM_HIP(hipMemcpyAsync(S->dUval, hUv.data(), (size_t)S->nnzU * 8, hipMemcpyHostToDevice, st));
+                SGM_HIP(hipMemcpyAsync(S->D, hD.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+                SGM_HIP(hipStreamSynchronize(st));          // (the host vectors go out of scope)
+            }
+            for (size_t l = 0; !host_factor && l + 1 < flp.size(); ++l) {
                 const int32_t b = flp[l], e = flp[l + 1];
                 if (S->maxL <= 4 && S->maxU <= 4) {
                     hipLaunchKernelGGL((k_ildu_factor_level_short<4, 4>), dim3((e - b + 63) / 64), dim3(64), 0, st,
@@ -2831,7 +2863,7 @@ static int pc_setup_ordered(sgm_pc pc, sgm_mat A)
             }
             SGM_HIP(hipGetLastError());
         }
-        lap("factorisation (device)");
+        lap(host_factor ? "factorisation (host: a chain)" : "factorisation (device)");
         // (the level-scheduled structures: ensure_levels, below or on first need)
         S->levels_ready = false;
         S->walk_ready = false;
