@@ -80,7 +80,7 @@ struct TriFactor {                   // strictly triangular factor on the device
     int32_t *src = nullptr;                          // device: level-order entry -> entry of the factor's val array
     std::vector<TrsvRec> h_recs;
     std::vector<int32_t> h_pq;
-    // cls: 0..2 = 256/512/1024 threads (one row per lane), 3/4 = 2/4 rows per lane; ring: k_trsv_walk_ring
+    // cls: -1 = one wave (levels of <= 64 rows), 0..2 = 256/512/1024 threads (one row per lane), 3/4 = 2/4 rows per lane; ring: k_trsv_walk_ring
     // applies; c: most dependencies of a row in the run
     struct Launch { int32_t l0, l1; bool narrow; int cls; bool ring; int c; };
     std::vector<Launch> schedule;
@@ -1858,7 +1858,7 @@ int tri_walkers(TriFactor &T, int32_t n, const std::vector<int32_t> &ptr1, const
             std::vector<int8_t> raw(nlev, 0);
             for (int32_t l = 0; l < nlev; ++l) {
                 const int32_t w = T.level_ptr[l + 1] - T.level_ptr[l];
-                raw[l] = w <= 256 ? 0 : w <= 512 ? 1 : w <= kTrsvBlock ? 2 : w <= 2 * kTrsvBlock ? 3 : w <= narrow ? 4 : 5;
+                raw[l] = w <= 64 ? -1 : w <= 256 ? 0 : w <= 512 ? 1 : w <= kTrsvBlock ? 2 : w <= 2 * kTrsvBlock ? 3 : w <= narrow ? 4 : 5;      // (-1: one wave)
             }
             for (int32_t l = 0; l < nlev; ++l) {          // window maximum over narrow neighbours
                 int8_t m = raw[l];
@@ -2286,7 +2286,9 @@ void trsv(const TriFactor &T, double *xp, const int *flag)
     } while (0)
             if (L.ring && T.nstride < (size_t)500000000) {       // (32-bit byte offsets)
                 // class = widest level of the run: <= 256, 512, 1024, 2048, 4096 rows (two rows per lane pair from 512 on)
-                if (L.cls == 0) RINGC(256, 1, 4, 1);
+                // (-1: levels of at most 64 rows -- chains: ONE wave, whose level barrier costs nothing)
+                if (L.cls < 0) RINGC(64, 1, 4, 1);
+                else if (L.cls == 0) RINGC(256, 1, 4, 1);
                 else if (L.cls == 1) RINGC(256, 1, 4, 2);
                 else if (L.cls == 2) RINGC(512, 1, 4, 2);
                 else if (L.cls == 3) RINGC(1024, 1, 2, 2);
@@ -3218,8 +3220,10 @@ int sgm_pc_info(sgm_pc pc, int32_t part, int32_t *out4, double *est_us, char *pa
                 snprintf(nm, sizeof nm, "row space, %d levels", std::max(o[0], o[1]));
             } else {
                 o[2] = 4;
-                // (0.3 us per level and sweep, measured on factors of 1e3 ... 1e5 levels: tools/pc_survey.py)
-                us = 0.30 * ((double)o[0] + o[1]) + (12.0 * ((double)S->nnzL + S->nnzU) + 56.0 * S->n) / 5.5e6;
+                // (0.3 us per level and sweep, 0.16 where the levels are a wave wide at most -- chains --, measured on factors of
+                //  1e3 ... 4e5 levels: tools/pc_survey.py)
+                const double per_level = (int64_t)std::max(o[0], 1) * 64 >= (int64_t)S->n ? 0.16 : 0.30;
+                us = per_level * ((double)o[0] + o[1]) + (12.0 * ((double)S->nnzL + S->nnzU) + 56.0 * S->n) / 5.5e6;
                 snprintf(nm, sizeof nm, "level walkers, %d levels", std::max(o[0], o[1]));
             }
         }

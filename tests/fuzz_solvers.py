@@ -7,7 +7,7 @@ against the oracle's loops on the same system (cg_solvers.f90:116-194, bicgstab_
 
 Gates: ILDU(0) applies bit-exact (block-Jacobi ILDU on a partition); with dot_order = 1 (systems up to 60000 rows) CG and
 BiCGStab are the oracle's solve BIT FOR BIT -- iterations and solution, one matrix or in-process parts; in the default (tree)
-order at tolerance 1e-8: CG iterations +-2 (+-6 %), BiCGStab within a factor 3 (its plateaus end when rounding says so), GMRES(30) +-2 against the oracle's CGS-2
+order at tolerance 1e-8: CG iterations +-2 (+-6 %), BiCGStab within a factor 3 (its plateaus end when rounding says so), GMRES(30) +-2 (+-3 %) against the oracle's CGS-2
 (its modified Gram-Schmidt stagnates near 1e-10 on these systems: another algorithm, not a gate); solutions 1e-6 relative.
 
     python tests/fuzz_solvers.py [seconds] [first_seed]"""
@@ -152,7 +152,7 @@ def one(seed, verbose=True, colour=True):
     else:
         ur, itr = orc.gmres(A, bo, tol=tol, pc=opc, max_iter=cap, restart=30, orth="cgs2")[:2]
         s = sg.gmres(tol, 30)
-        slack = 2
+        slack = max(2, int(0.03 * itr))          # (a restarted run that crawls for hundreds of iterations ends where rounding says)
     if perm is not None:
         ur = ur[perm - 1]                                   # back to the caller's order
         A = Aorig
