@@ -346,7 +346,10 @@ static int wants_colblock(Part &p, bool *yes)
     if (csr && slots_per_entry > (p.opt.ell_colblock >= 2 ? 16.0 : 2.0)) return SGM_OK;
     if (p.opt.ell_colblock >= 2) { *yes = true; return SGM_OK; }
     if (p.ecode || p.scode || p.code || p.sbcode) return SGM_OK;  // structured: the dictionary kernels serve it
-    if ((int64_t)p.ncol_own * 8 < (int64_t)16 << 20 || p.cb_maxd < 8) return SGM_OK;   // x within reach of the L2s / too few gathers
+    // x within reach of the L2s / too few gathers.  (7 MiB: with uniformly random columns the two-phase form overtakes the row
+    // kernels between x = 4 and 8 MB -- 16 / 32 per row at 7.6 MB: 1.06 / 1.25 x, 11.4 MB: 1.39 / 1.64, 15.3 MB: 1.55 / 1.84;
+    // tools/probes/colblock_threshold.py.  The limit was 16 MiB until that sweep.)
+    if ((int64_t)p.ncol_own * 8 < (int64_t)7 << 20 || p.cb_maxd < 8) return SGM_OK;
     unsigned long long *dsum = nullptr, hsum[2] = {0, 0};
     SGM_TRY(dalloc(&dsum, 2));
     hipStream_t st = g_rt.stream;
