@@ -657,45 +657,8 @@ def worker(args):
     # `cpu_baseline` (nested objects and other top-level keys are reduced to their names): the whole metric -- SpMV GB/s AND CG
     # iterations/s on C2 -- and the other configs therefore sit in `roofline` as flat scalars (names <= 40 characters), every
     # fraction named after the bytes it is made of (see spmv_fracs); the nested legs stay in the line for readers of stdout.
-    flat = {}
-    if cg is not None:
-        flat.update({"c2_cg_iters_per_s": cg["iters_per_s"], "c2_cg_ms_per_iter": cg["ms_per_iter"],
-                     "c2_cg_frac_moved": cg["frac_of_hbm_peak"],
-                     "c2_cg_eff_GBs_on_survey_floor": cg["effective_GBs_on_survey_floor"]})
-    if c5 is not None:
-        tag = "c5_1gpu" if world == 1 else f"c5_{world}gpu"
-        flat.update({f"{tag}_spmv_ms": c5["spmv_ms"], f"{tag}_spmv_frac_moved": c5["spmv_frac_of_hbm_peak"],
-                     f"{tag}_cg_iters_per_s": c5["cg_iters_per_s"], f"{tag}_cg_frac_moved": c5["cg_frac_of_hbm_peak"]})
-    if c5p is not None and "error" not in c5p:
-        flat.update({k: v for k, v in c5p.items() if k.startswith("c5_") and isinstance(v, (int, float))})
-    if ceilings is not None:
-        flat.update(ceilings["flat"])
-        for key, fp in (("c2", "600"), ("c5", "7600")):
-            cp = ceilings["flat"].get(f"ceiling_copy_{fp}MiB_GBs")
-            mx = ceilings["flat"].get(f"ceiling_mix8r1w_{fp}MiB_GBs")
-            got = achieved if key == "c2" else (c5["spmv_GB/s_moved"] if c5 else None)
-            if cp and got:
-                flat[f"{key}_frac_of_copy_ceiling"] = got / cp
-            if mx and got:
-                flat[f"{key}_frac_of_mix_ceiling"] = got / mx
-    if c3 is not None:
-        flat.update({"c3_spmv_ms": c3["spmv_ms"], "c3_spmv_frac_moved": c3["frac_moved"],
-                     "c3_spmv_layout_compression": c3["layout_compression"],
-                     "c3_bicgstab_iters_per_s": c3["bicgstab"]["iters_per_s"], "c3_bicgstab_frac_moved": c3["bicgstab"]["frac_moved"],
-                     "c3_gmres30_iters_per_s": c3["gmres30"]["iters_per_s"], "c3_gmres30_frac_moved": c3["gmres30"]["frac_moved"]})
-    if c4 is not None:
-        flat.update({"c4_spmv_ms": c4["spmv_ms"], "c4_spmv_frac_moved": c4["frac_moved"],
-                     "c4_spmv_frac_survey_bytes": c4["frac_survey_bytes"], "c4_product_bit_exact": c4["product_bit_exact"]})
-    if pcg is not None:
-        for key, leg in (pcg.items() if "cg" not in pcg else [("grid_1000", pcg)]):
-            g = key.replace("grid_", "")
-            co = leg["ildu0_colour_order"]
-            flat[f"pcg{g}_cg_solve_s"] = leg["cg"]["setup_s"] + leg["cg"]["solve_s"]
-            flat[f"pcg{g}_ildu_natural_total_s"] = leg["ildu0_natural_order"]["setup_s"] + leg["ildu0_natural_order"]["solve_s"]
-            flat[f"pcg{g}_ildu_colour_total_s"] = co["ordering_s"] + co["permutation_s"] + co["setup_s"] + co["solve_s"]
-            ro = leg["ildu0_reorder_inside_the_preconditioner"]
-            flat[f"pcg{g}_ildu_reorder_total_s"] = ro["setup_s"] + ro["solve_s"]
-            flat[f"pcg{g}_ildu_reorder_over_cg"] = ro["total_s_over_plain_cg_s"]
+    flat = flat_roofline_keys(world, cg=cg, c5=c5, c5p=c5p, ceilings=ceilings, c3=c3, c4=c4, pcg=pcg, achieved=achieved,
+                              moved_rank=moved_rank, k_cold=k_cold, in_solver_ms=in_solver_ms)
     roofline_other = {"c2_cg": cg, "c3": c3, "c4": c4,
                       "c5_on_this_many_gpus": {k: v for k, v in (c5 or {}).items() if k != "phases"} or None}
 
@@ -730,14 +693,15 @@ def worker(args):
                          "algorithmic_bytes_per_launch_reference_layout": alg_bytes_rank,
                          "effective_GBs_on_reference_bytes": alg_bytes_rank / k_avg / 1e9,
                          "avg_launch_ms": 1e3 * k_avg, "cold_launch_ms": 1e3 * k_cold,
-                         "cold_frac": moved_rank / k_cold / 1e9 / HBM_PEAK_GBS,
                          "in_solver_launch_ms": in_solver_ms,
-                         "in_solver_frac": (moved_rank / (in_solver_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if in_solver_ms else None,
                          "other": roofline_other,
                          "traffic_source": traffic_src, "csrc_sha1": kernel_sha,
-                         "note": "achieved = moved_bytes_per_launch / avg_launch_ms: the sliced kernel reads 8W+4 bytes per "
-                                 "row of its own layout (W = 5) + x once + y once.  cold_* = the same launch after 512 MiB "
-                                 "of unrelated writes (nothing of the previous product left in L2 / Infinity Cache)"},
+                         "note": "frac / achieved are the WARM figure: moved_bytes_per_launch / avg_launch_ms of back-to-back "
+                                 "products on the same x (the sliced kernel reads 8W+4 bytes per row of its own layout, W = 5, "
+                                 "+ x once + y once).  cold_frac = the same launch after 512 MiB of unrelated writes (nothing of "
+                                 "the previous product left in L2 / Infinity Cache); in_solver_frac = the launch as it runs inside "
+                                 "CG.  `traffic` is 2 x FETCH_SIZE + WRITE_SIZE from the PMC passes: FETCH_SIZE counts Infinity-"
+                                 "Cache hits (MI355X_MICROARCH.md), so it is fabric traffic, an upper bound of DRAM traffic"},
             "spmv_variants": variants or None, "cg": cg, "dist_overhead_1rank": dist_overhead, "c5_strong_scaling": c5,
             "c5_parts_model": c5p, "stream_ceilings": ceilings,
             "c3": c3, "c4": c4, "c1_reference_sized": c1, "pcg_time_to_solution": pcg, "cpu_baseline": cpu,
@@ -1052,10 +1016,95 @@ def c5_parts_leg(args, sg, torch, dev, c5, allreduce_ms):
             "c5_1part_cg_ms_per_iter": t1, "c5_allreduce_1rank_ms": allreduce_ms,
             f"c5_model_{P}gpu_speedup": t1 / (tp / P + 2.0 * ar),
             f"c5_model_{P}gpu_cg_iters_per_s": 1e3 / (tp / P + 2.0 * ar),
+            # the same formula with an all-reduce of 30 us / 55 us (what 8 ranks over xGMI may plausibly cost; the one-rank
+            # figure above is a lower bound of that term): the range a first measured SCALE line is to be read against
+            f"c5_model_{P}gpu_speedup_ar30us": t1 / (tp / P + 2.0 * 0.030),
+            f"c5_model_{P}gpu_speedup_ar55us": t1 / (tp / P + 2.0 * 0.055),
+            "model_note": "c5_model_* are MODELLED upper bounds (in-process parts on one GPU + an assumed all-reduce latency), "
+                          "not measurements of a multi-GPU run",
         })
     except Exception as e:
         out["error"] = str(e)[:300]
     return out
+
+
+# ------------------------------------------------------------------------------------------ #
+# What the driver's record keeps of the JSON line is the contract keys and the first 24 SCALAR entries of `roofline` (six of
+# them are bound / achieved / peak / unit / frac / traffic), the scalars of `config` and of `cpu_baseline`; nested objects and
+# other top-level keys are reduced to their names.  The 18 scalars that follow `traffic` are therefore chosen, in this order,
+# as one line per thing BASELINE.json grades; every other figure follows and stays in the nested legs.
+# tests/test_cabi_cpu.py::test_bench_flat_keys_fit_the_drivers_record holds this list.
+# ------------------------------------------------------------------------------------------ #
+FLAT_HEAD = (
+    "cold_frac", "in_solver_frac",
+    "c2_cg_iters_per_s", "c2_cg_frac_moved",
+    "c3_spmv_frac_moved", "c3_bicgstab_iters_per_s", "c3_gmres30_iters_per_s",
+    "c4_spmv_ms", "c4_spmv_frac_survey_bytes", "c4_product_bit_exact",
+    "c5_1gpu_spmv_frac_moved", "c5_1gpu_cg_iters_per_s",
+    "c5_8parts_cg_ms_per_iter_per_part", "c5_allreduce_1rank_ms", "c5_model_8gpu_speedup",
+    "ceiling_copy_600MiB_GBs", "ceiling_copy_7600MiB_GBs", "pcg3162_ildu_reorder_over_cg",
+)
+DRIVER_KEEPS_ROOFLINE_SCALARS = 24
+
+
+def flat_roofline_keys(world, cg=None, c5=None, c5p=None, ceilings=None, c3=None, c4=None, pcg=None, achieved=None,
+                       moved_rank=None, k_cold=None, in_solver_ms=None):
+    """Flat scalars of `roofline` (names <= 40 characters, every fraction named after the bytes it is made of): FLAT_HEAD
+    first, in that order, then the rest.  With N > 1 the c5 keys carry the rank count (c5_8gpu_...) and lead the line."""
+    allk = {}
+    if moved_rank and k_cold:
+        allk["cold_frac"] = moved_rank / k_cold / 1e9 / HBM_PEAK_GBS
+    if moved_rank and in_solver_ms:
+        allk["in_solver_frac"] = moved_rank / (in_solver_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if cg is not None:
+        allk.update({"c2_cg_iters_per_s": cg["iters_per_s"], "c2_cg_ms_per_iter": cg["ms_per_iter"],
+                     "c2_cg_frac_moved": cg["frac_of_hbm_peak"],
+                     "c2_cg_eff_GBs_on_survey_floor": cg["effective_GBs_on_survey_floor"]})
+    if c5 is not None:
+        tag = "c5_1gpu" if world == 1 else f"c5_{world}gpu"
+        allk.update({f"{tag}_spmv_ms": c5["spmv_ms"], f"{tag}_spmv_frac_moved": c5["spmv_frac_of_hbm_peak"],
+                     f"{tag}_cg_iters_per_s": c5["cg_iters_per_s"], f"{tag}_cg_frac_moved": c5["cg_frac_of_hbm_peak"]})
+    if c5p is not None and "error" not in c5p:
+        allk.update({k: v for k, v in c5p.items() if k.startswith("c5_") and isinstance(v, (int, float))})
+    if ceilings is not None:
+        allk.update(ceilings["flat"])
+        for key, fp in (("c2", "600"), ("c5", "7600")):
+            cp = ceilings["flat"].get(f"ceiling_copy_{fp}MiB_GBs")
+            mx = ceilings["flat"].get(f"ceiling_mix8r1w_{fp}MiB_GBs")
+            got = achieved if key == "c2" else (c5["spmv_GB/s_moved"] if c5 else None)
+            if cp and got:
+                allk[f"{key}_frac_of_copy_ceiling"] = got / cp
+            if mx and got:
+                allk[f"{key}_frac_of_mix_ceiling"] = got / mx
+    if c3 is not None:
+        allk.update({"c3_spmv_ms": c3["spmv_ms"], "c3_spmv_frac_moved": c3["frac_moved"],
+                     "c3_spmv_layout_compression": c3["layout_compression"],
+                     "c3_bicgstab_iters_per_s": c3["bicgstab"]["iters_per_s"], "c3_bicgstab_frac_moved": c3["bicgstab"]["frac_moved"],
+                     "c3_gmres30_iters_per_s": c3["gmres30"]["iters_per_s"], "c3_gmres30_frac_moved": c3["gmres30"]["frac_moved"]})
+    if c4 is not None:
+        allk.update({"c4_spmv_ms": c4["spmv_ms"], "c4_spmv_frac_moved": c4["frac_moved"],
+                     "c4_spmv_frac_survey_bytes": c4["frac_survey_bytes"], "c4_product_bit_exact": c4["product_bit_exact"]})
+    if pcg is not None:
+        for key, leg in (pcg.items() if "cg" not in pcg else [("grid_1000", pcg)]):
+            g = key.replace("grid_", "")
+            co = leg["ildu0_colour_order"]
+            allk[f"pcg{g}_cg_solve_s"] = leg["cg"]["setup_s"] + leg["cg"]["solve_s"]
+            allk[f"pcg{g}_ildu_natural_total_s"] = leg["ildu0_natural_order"]["setup_s"] + leg["ildu0_natural_order"]["solve_s"]
+            allk[f"pcg{g}_ildu_colour_total_s"] = co["ordering_s"] + co["permutation_s"] + co["setup_s"] + co["solve_s"]
+            ro = leg["ildu0_reorder_inside_the_preconditioner"]
+            allk[f"pcg{g}_ildu_reorder_total_s"] = ro["setup_s"] + ro["solve_s"]
+            allk[f"pcg{g}_ildu_reorder_over_cg"] = ro["total_s_over_plain_cg_s"]
+    flat = {}
+    if world > 1:                          # the scaling line: what this rank count measured comes first
+        for k in allk:
+            if k.startswith(f"c5_{world}gpu_"):
+                flat[k] = allk[k]
+    for k in FLAT_HEAD:
+        if k in allk:
+            flat[k] = allk[k]
+    for k, v in allk.items():
+        flat.setdefault(k, v)
+    return flat
 
 
 # ------------------------------------------------------------------------------------------ #

@@ -326,3 +326,44 @@ def test_header_is_c99_and_a_plain_c_program_links_and_fails_loudly_without_a_gp
     p = subprocess.run([exe, "100"], capture_output=True, text=True, timeout=120)
     assert p.returncode == 2, (p.returncode, p.stdout, p.stderr)
     assert "sgm_init" in p.stderr and "no CPU path" in p.stderr, p.stderr
+
+
+def test_bench_flat_keys_fit_the_drivers_record():
+    """The driver keeps the first 24 scalars of `roofline` (6 are bound..traffic): the 18 after them must be the one-per-graded-
+    thing list of VERDICT r05 item 1, whatever else the legs emit (r05's record lost C3 / C4 / cold / in-solver to new keys)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    wanted = ["cold_frac", "in_solver_frac", "c2_cg_iters_per_s", "c2_cg_frac_moved", "c3_spmv_frac_moved",
+              "c3_bicgstab_iters_per_s", "c3_gmres30_iters_per_s", "c4_spmv_ms", "c4_spmv_frac_survey_bytes",
+              "c4_product_bit_exact", "c5_1gpu_spmv_frac_moved", "c5_1gpu_cg_iters_per_s",
+              "c5_8parts_cg_ms_per_iter_per_part", "c5_allreduce_1rank_ms", "c5_model_8gpu_speedup",
+              "ceiling_copy_600MiB_GBs", "ceiling_copy_7600MiB_GBs", "pcg3162_ildu_reorder_over_cg"]
+    assert list(bench.FLAT_HEAD) == wanted
+    assert 6 + len(wanted) == bench.DRIVER_KEEPS_ROOFLINE_SCALARS
+    assert all(len(k) <= 40 for k in wanted)
+    # a dry line: every leg present, with more keys than the record holds
+    cg = {"iters_per_s": 1.0, "ms_per_iter": 1.0, "frac_of_hbm_peak": 0.5, "effective_GBs_on_survey_floor": 1.0}
+    c5 = {"spmv_ms": 1.0, "spmv_frac_of_hbm_peak": 0.5, "cg_iters_per_s": 1.0, "cg_frac_of_hbm_peak": 0.5, "spmv_GB/s_moved": 1.0}
+    c5p = {f"c5_8parts_{k}": 1.0 for k in ("spmv_ms", "cg_ms_per_iter", "cg_ms_per_iter_per_part", "cg_ms_per_iter_mode0",
+                                           "products_ms_per_part", "halo_ms_per_part", "dot_reduce_ms_per_part")}
+    c5p.update({"c5_1part_cg_ms_per_iter": 1.0, "c5_allreduce_1rank_ms": 0.005, "c5_model_8gpu_speedup": 7.0,
+                "c5_model_8gpu_cg_iters_per_s": 1.0, "c5_model_8gpu_speedup_ar30us": 6.6, "model_note": "x", "parts": 8})
+    ceil = {"flat": {f"ceiling_{k}_{m}MiB_GBs": 1.0 for k in ("copy", "read", "mix8r1w") for m in (600, 7600)}}
+    c3 = {"spmv_ms": 1.0, "frac_moved": 0.5, "layout_compression": 1.0, "bicgstab": {"iters_per_s": 1.0, "frac_moved": 0.5},
+          "gmres30": {"iters_per_s": 1.0, "frac_moved": 0.5}}
+    c4 = {"spmv_ms": 1.0, "frac_moved": 0.5, "frac_survey_bytes": 0.2, "product_bit_exact": True}
+    leg = {"cg": {"setup_s": 0.0, "solve_s": 1.0}, "ildu0_natural_order": {"setup_s": 0.0, "solve_s": 1.0},
+           "ildu0_colour_order": {"ordering_s": 0.0, "permutation_s": 0.0, "setup_s": 0.0, "solve_s": 1.0},
+           "ildu0_reorder_inside_the_preconditioner": {"setup_s": 0.0, "solve_s": 1.0, "total_s_over_plain_cg_s": 0.8}}
+    flat = bench.flat_roofline_keys(1, cg=cg, c5=c5, c5p=c5p, ceilings=ceil, c3=c3, c4=c4,
+                                    pcg={"grid_1000": leg, "grid_3162": leg}, achieved=6000.0, moved_rank=6e8, k_cold=1e-4,
+                                    in_solver_ms=0.1)
+    assert list(flat)[:18] == wanted, list(flat)[:18]
+    assert len(flat) > 18 and "c5_model_8gpu_speedup_ar30us" in flat and "model_note" not in flat
+    assert all(isinstance(v, (int, float, bool)) for v in flat.values())
+    # N = 8: what the 8 ranks measured leads the line
+    flat8 = bench.flat_roofline_keys(8, cg=cg, c5=c5, moved_rank=6e8, k_cold=1e-4)
+    assert list(flat8)[:4] == ["c5_8gpu_spmv_ms", "c5_8gpu_spmv_frac_moved", "c5_8gpu_cg_iters_per_s", "c5_8gpu_cg_frac_moved"]
+    assert "c2_cg_iters_per_s" in list(flat8)[:8]
