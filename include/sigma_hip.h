@@ -332,12 +332,18 @@ int sgm_pc_destroy(sgm_pc pc);
  *                        The whole loop is device-resident: x and b cross the boundary once.
  *                        A breakdown (NaN res2) ends the loop as it ends the reference's; `converged` is then 0
  *                        (and the call returns SGM_ERR_NOT_CONVERGED when an iteration cap is set).
+ * sgm_solver_set_tolerance <- solver%set_params(tolerance) cg_solvers.f90:95-111, bicgstab_solvers.f90:103-119, and any
+ *                        later edit of the public field solver%tolerance, which the reference's loops read at every solve
+ *                        (cg_solvers.f90:133,175): the next solve on this handle stops at the new ABSOLUTE tolerance;
+ *                        work vectors, options and the accumulated `iterations` are kept.  Both Fortran layers and
+ *                        sigma_amd push the host object's tolerance in front of every solve.
  * sgm_solver_destroy  <- solver%destroy()          cg_solvers.f90:199-212                 */
 int sgm_cg_create(sgm_solver *out, double tolerance);
 int sgm_bicgstab_create(sgm_solver *out, double tolerance);
 int sgm_gmres_create(sgm_solver *out, double tolerance, int32_t restart);
 int sgm_solver_setup(sgm_solver s, sgm_mat A);
 int sgm_solver_set_max_iter(sgm_solver s, int64_t max_iter /* <= 0: unbounded */);
+int sgm_solver_set_tolerance(sgm_solver s, double tolerance);
 int sgm_solver_set_history(sgm_solver s, int64_t capacity); /* record res2 per iteration */
 int sgm_solver_solve(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc pc_or_null,
                      int where);
@@ -399,6 +405,12 @@ int sgm_comm_attach_halo_comm(sgm_comm c, const void *id128);
  * counterpart (the reference has no communication); a probe that lets a one-GPU box show that the real
  * librccl accepts the mixed group. */
 int sgm_comm_group_selftest(sgm_comm c, double *out3);
+/* sgm_comm_group_ok: what sgm_comm_init's own probe found (1 / 0).  With more than one rank sgm_comm_init posts, once and
+ * collectively, the group CG depends on with "dist_halo_fused" = 1 -- one double to the right neighbour, one from the left and
+ * an all-reduce in ONE ncclGroup -- and the ranks agree on the outcome with a plain all-reduce.  0 = some rank's transport
+ * refused the group or delivered wrong values: every solve on this communicator then posts the pairs and the all-reduce one
+ * after the other (the order "dist_halo_fused" = 2 uses) instead of failing in its first iteration.  No reference counterpart (the reference has no communication). */
+int sgm_comm_group_ok(sgm_comm c);
 int sgm_dist_profile(int on);
 int sgm_dist_profile_read(double *ms_out /* 6 */, int64_t *count_out /* 6 */);
 int sgm_csr_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts /* nranks+1, 0-based */,

@@ -299,6 +299,12 @@ interface   ! include/sigma_hip.h
         integer(c_int), value :: value
         integer(c_int) :: rc
     end function
+    function sgm_solver_set_tolerance(s, tolerance) bind(c, name='sgm_solver_set_tolerance') result(rc)
+        import :: c_ptr, c_int, c_double
+        type(c_ptr), value :: s
+        real(c_double), value :: tolerance
+        integer(c_int) :: rc
+    end function
     function sgm_solver_set_option(s, name, value) bind(c, name='sgm_solver_set_option') result(rc)
         import :: c_ptr, c_int, c_char
         type(c_ptr), value :: s
@@ -1254,6 +1260,7 @@ type, extends(linear_solver) :: hip_krylov_solver                          !
     type(c_ptr) :: handle = c_null_ptr
 contains
     procedure :: setup => hip_krylov_setup
+    procedure :: set_params => hip_krylov_set_params
     procedure :: set_option => hip_krylov_set_option
     procedure :: linear_solve => hip_krylov_solve
     procedure :: linear_solve_pc => hip_krylov_solve_pc
@@ -1398,6 +1405,25 @@ end subroutine krylov_handle
 
 
 !--------------------------------------------------------------------------!
+subroutine hip_krylov_set_params(solver, tolerance)                        !
+!--------------------------------------------------------------------------!
+! cg_set_params (cg_solvers.f90:95-111) / bicgstab_set_params              !
+! (bicgstab_solvers.f90:103-119): may be called again at any time; the     !
+! field is pushed to the handle in front of every solve (run)              !
+!--------------------------------------------------------------------------!
+    class(hip_krylov_solver), intent(inout) :: solver
+    real(dp), intent(in), optional :: tolerance
+
+    if (present(tolerance)) then
+        solver%tolerance = tolerance
+    else
+        solver%tolerance = 1.0d-16
+    endif
+
+end subroutine hip_krylov_set_params
+
+
+!--------------------------------------------------------------------------!
 subroutine hip_krylov_set_option(solver, name, value)                      !
 !--------------------------------------------------------------------------!
 ! this solver's own option ("dot_order", "cg_small", "krylov_graph" ...:   !
@@ -1484,6 +1510,9 @@ subroutine run(solver, hA, x, b, hpc)
     real(c_double) :: res2
     integer(c_int32_t) :: conv
 
+    ! solver%tolerance is a public field the reference's loop reads at every solve (cg_solvers.f90:133): an edit made after
+    ! the handle exists -- directly or through set_params -- must count
+    call hip_check(sgm_solver_set_tolerance(solver%handle, solver%tolerance), 'sgm_solver_set_tolerance')
     call hip_check(sgm_solver_solve(solver%handle, hA, x, b, hpc, SGM_HOST), 'sgm_solver_solve')
     call hip_check(sgm_solver_info(solver%handle, its, res2, conv, last), 'sgm_solver_info')
     solver%iterations = int(its)        ! accumulates across solves like cg_solvers.f90:145
@@ -1661,6 +1690,7 @@ subroutine hip_generalized_lanczos(A, B, T, Q)                             !
         select type(s => B%solver)
             class is(hip_krylov_solver)
                 hs = s%handle
+                if (c_associated(hs)) call hip_check(sgm_solver_set_tolerance(hs, s%tolerance), 'sgm_solver_set_tolerance')
         end select
     endif
     if (.not. c_associated(hs)) then

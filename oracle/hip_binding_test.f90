@@ -137,6 +137,37 @@ implicit none
         call exit(1)
     endif
 
+    ! 2b. solver%tolerance is a live public field (cg_solvers.f90:17,133) and set_params may be called again (:95-111):
+    !     the same handle, first with a tolerance the initial residual already meets (no iteration, u untouched), then the
+    !     field edited directly, then through set_params -- `iterations` accumulates (cg_solvers.f90:72,145)
+    select type(solver)
+        type is(hip_krylov_solver)
+            u = 0.0_dp
+            solver%tolerance = 1.0_dp
+            call solver%solve(A, u, f)
+            if (solver%iterations /= its_hip .or. any(u /= 0.0_dp)) then
+                print *, 'a tolerance of 1 edited on the live solver was ignored: iterations', solver%iterations
+                call exit(1)
+            endif
+            solver%tolerance = 1.d-16
+            call solver%solve(A, u, f)
+            misfit = maxval(dabs(u - v))
+            print *, 'hip_cg() after editing solver%tolerance: iterations', solver%iterations, ' error', misfit
+            if (misfit > 1.0e-14 .or. abs(solver%iterations - 2 * its_hip) > 1) then
+                print *, 'the edited tolerance did not reach the device loop.'
+                call exit(1)
+            endif
+            u = 0.0_dp
+            call solver%set_params(1.0_dp)
+            call solver%solve(A, u, f)
+            if (any(u /= 0.0_dp)) then
+                print *, 'set_params(1) on the live solver was ignored'
+                call exit(1)
+            endif
+            call solver%set_params()
+            if (solver%tolerance /= 1.d-16) call exit(1)
+    end select
+
     ! 3. the A%solve facade with a Jacobi preconditioner
     pc => hip_jacobi()
     call A%set_solver(solver)

@@ -685,6 +685,11 @@ class _Solver:
         self.nn = A.nrow
         self.initialized = True
 
+    def set_params(self, tolerance=None):
+        """solver%set_params(tolerance) (cg_solvers.f90:95-111): without an argument the tolerance goes back to 1e-16."""
+        self.tolerance = 1.0e-16 if tolerance is None else float(tolerance)
+        return self
+
     def set_max_iter(self, max_iter):
         """Extension: the reference has no iteration cap.  <= 0 = unbounded."""
         self._max_iter = int(max_iter)
@@ -703,6 +708,8 @@ class _Solver:
         _need(x, nloc, "solve x"); _need(b, nloc, "solve b")
         px, wx, _k1 = _arg(x, np.float64, writable=True)
         pb, wb, _k2 = _arg(b, np.float64)
+        # solver.tolerance is a live public field, read at every solve like cg_solvers.f90:133
+        _ck(lib().sgm_solver_set_tolerance(self._h, C.c_double(float(self.tolerance))))
         rc = lib().sgm_solver_solve(self._h, A._h, px, pb, pc._h if pc is not None else None,
                                     C.c_int(_same_where(wx, wb)))
         if rc == 5 and not check:
@@ -814,6 +821,11 @@ class Comm:
         _ck(lib().sgm_comm_group_selftest(self._h, out))
         return float(out[0]), float(out[1]), float(out[2])
 
+    @property
+    def group_ok(self):
+        """sgm_comm_group_ok: did this transport take the probe group of sgm_comm_init (pairs + all-reduce in one group)?"""
+        return bool(lib().sgm_comm_group_ok(self._h))
+
     def destroy(self):
         if self._h:
             _ck(lib().sgm_comm_destroy(self._h))
@@ -873,6 +885,7 @@ def generalized_lanczos(A, B, nsteps, q1, want_Q=True):
     _need(q1, nloc, "generalized_lanczos q1")
     T = np.zeros((nsteps, 3), np.float64)
     Q = np.zeros((nsteps, nloc), np.float64) if want_Q else None
+    _ck(lib().sgm_solver_set_tolerance(B.solver._h, C.c_double(float(B.solver.tolerance))))
     _ck(lib().sgm_generalized_lanczos(A._h, B._h, B.solver._h, B.pc._h if B.pc is not None else None, C.c_int32(nsteps), pq,
                                       C.c_void_p(T.ctypes.data), C.c_void_p(Q.ctypes.data) if want_Q else None,
                                       C.c_int(SGM_HOST)))

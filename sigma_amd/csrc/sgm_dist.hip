@@ -274,6 +274,7 @@ int halo_exchange_allreduce(sgm_mat A, double *const *uext, double *const *slot_
     }
     Part &p = A->parts[0];
     const bool reduce = A->comm->nranks > 1 || g_force_collectives;
+    grouped = grouped && A->comm->group_ok;                // (what sgm_comm_init found this transport to take)
     if (!grouped || p.nbrs.empty() || !reduce) {
         if (!p.nbrs.empty()) {
             prof_begin(PH_HALO, st);
@@ -687,6 +688,54 @@ int sgm_comm_unique_id(void *id128)
     return SGM_OK;
 }
 
+// The group CG posts per iteration with option dist_halo_fused = 1 -- send / recv pairs with the neighbours AND an all-reduce in
+// ONE ncclGroup -- tried once per communicator before any solve depends on it: every rank sends one double to its
+// right neighbour, receives one from its left and all-reduces a 1.0 in the same group.  A transport that REFUSES the group
+// (an error from any call of it) or delivers wrong values makes this rank vote 0; the votes are summed by a plain all-reduce,
+// and anything short of nranks sets group_ok = 0 on every rank: the solvers then post the pairs and the all-reduce one after
+// the other (the order option dist_halo_fused = 2 uses), which every transport that passed sgm_comm_init can do.  A transport
+// that HANGS on the group hangs here, at creation, where sgm_heartbeat names the phase -- not inside the first solve.
+static int probe_mixed_group(sgm_comm c)
+{
+    double *d = nullptr;
+    SGM_TRY(dalloc(&d, 4));
+    struct Tmp { double *&p; ~Tmp() { dfree(p); } } tmp{d};
+    const int R = c->nranks, right = (c->rank + 1) % R, left = (c->rank + R - 1) % R;
+    const double h[4] = {42.0 + c->rank, -1.0, 1.0, 1.0};
+    hipStream_t st = g_rt.stream;
+    SGM_HIP(hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    ncclComm_t comm = (ncclComm_t)c->nccl;
+    const int hb_prev = g_hb.phase;
+    hb_phase(HB_HALO_POST);
+    bool ok = g_nccl.GroupStart() == ncclSuccess;
+    ok = g_nccl.Send(d, 1, ncclFloat64, right, comm, st) == ncclSuccess && ok;
+    ok = g_nccl.Recv(d + 1, 1, ncclFloat64, left, comm, st) == ncclSuccess && ok;
+    ok = g_nccl.AllReduce(d + 2, d + 2, 1, ncclFloat64, ncclSum, comm, st) == ncclSuccess && ok;
+    ok = g_nccl.GroupEnd() == ncclSuccess && ok;
+    ok = hipStreamSynchronize(st) == hipSuccess && ok;
+    hb_phase(hb_prev);
+    double r[4] = {0, 0, 0, 0};
+    if (ok) {
+        SGM_HIP(hipMemcpy(r, d, sizeof r, hipMemcpyDeviceToHost));
+        ok = r[1] == 42.0 + left && r[2] == (double)R;
+    } else {
+        (void)hipGetLastError();
+    }
+    const double vote = ok ? 1.0 : 0.0;
+    SGM_HIP(hipMemcpy(d + 3, &vote, sizeof vote, hipMemcpyHostToDevice));
+    SGM_NCCL(g_nccl.AllReduce(d + 3, d + 3, 1, ncclFloat64, ncclSum, comm, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    double votes = 0.0;
+    SGM_HIP(hipMemcpy(&votes, d + 3, sizeof votes, hipMemcpyDeviceToHost));
+    c->group_ok = votes == (double)R ? 1 : 0;
+    if (trace_on() || !c->group_ok)
+        fprintf(stderr, "[sigma_hip] rank %d/%d: one group of send/recv pairs + all-reduce: %s (%d of %d ranks)%s\n", c->rank, R,
+                c->group_ok ? "taken" : "REFUSED", (int)votes, R,
+                c->group_ok ? "" : " -- CG posts the pairs and the all-reduce separately (as with dist_halo_fused = 2)");
+    return SGM_OK;
+}
+
 int sgm_comm_init(sgm_comm *out, int rank, int nranks, const void *id128)
 {
     SGM_TRY(require_init());
@@ -700,6 +749,10 @@ int sgm_comm_init(sgm_comm *out, int rank, int nranks, const void *id128)
     h->rank = rank;
     h->nranks = nranks;
     h->nccl = c;
+    if (nranks > 1) {
+        const int rc = probe_mixed_group(h);
+        if (rc != SGM_OK) { sgm_comm_destroy(h); return rc; }
+    }
     *out = h;
     return SGM_OK;
 }
@@ -781,6 +834,11 @@ int sgm_comm_group_selftest(sgm_comm c, double *out3)
     SGM_HIP(hipMemcpy(r, d, sizeof r, hipMemcpyDeviceToHost));
     out3[0] = r[1]; out3[1] = r[2]; out3[2] = us;
     return SGM_OK;
+}
+
+int sgm_comm_group_ok(sgm_comm c)
+{
+    return c ? c->group_ok : 0;
 }
 
 int sgm_comm_destroy(sgm_comm c)

@@ -245,6 +245,10 @@ struct sgm_comm_s {
     int rank = 0, nranks = 1;
     void *nccl = nullptr;          // ncclComm_t
     void *nccl_halo = nullptr;     // optional second communicator: the halo send / recv pairs (sgm_comm_attach_halo_comm)
+    // does this transport take ONE group holding neighbour send / recv pairs AND an all-reduce (what CG posts per iteration with
+    // option dist_halo_fused = 1)?  Probed once, collectively, by sgm_comm_init and agreed over all ranks; 0 = the solvers
+    // post the pairs and the all-reduce separately (what dist_halo_fused = 2 does), whatever the option says
+    int group_ok = 1;
 };
 
 // every matrix handle has a serial number of its own, and a version that every change of its entries or their order bumps:

@@ -270,6 +270,18 @@ int sgm_gmres_create(sgm_solver *out, double tolerance, int32_t restart)
     return solver_create(out, SGM_SOLVER_GMRES, tolerance, restart);
 }
 
+// solver%tolerance is a public field the reference's loops read at every solve (`do while( dsqrt(res2)>solver%tolerance )`,
+// cg_solvers.f90:133,175; bicgstab_solvers.f90:153) and set_params may be called again (cg_solvers.f90:95-111): the tolerance of
+// a handle is live.  It is a launch argument of the loop kernels, read when a solve starts; work vectors, `iterations` and the
+// options are untouched.
+int sgm_solver_set_tolerance(sgm_solver s, double tolerance)
+{
+    if (!s) return fail(SGM_ERR_BAD_ARG, "sgm_solver_set_tolerance: null solver");
+    if (tolerance != tolerance) return fail(SGM_ERR_BAD_ARG, "sgm_solver_set_tolerance: the tolerance is NaN");
+    s->tolerance = tolerance;
+    return SGM_OK;
+}
+
 int sgm_solver_setup(sgm_solver s, sgm_mat A)
 {
     SGM_TRY(require_init());

@@ -401,6 +401,12 @@ interface
         type(c_ptr), value :: needed
         integer(c_int) :: rc
     end function
+    function sgm_solver_set_tolerance(s, tolerance) bind(c, name='sgm_solver_set_tolerance') result(rc)
+        import :: c_ptr, c_int, c_double
+        type(c_ptr), value :: s
+        real(c_double), value :: tolerance
+        integer(c_int) :: rc
+    end function
     function sgm_solver_set_max_iter(s, max_iter) bind(c, name='sgm_solver_set_max_iter') result(rc)
         import :: c_ptr, c_int, c_int64_t
         type(c_ptr), value :: s
@@ -754,6 +760,7 @@ contains
     procedure :: set_option => hip_solver_set_option
     procedure :: info => hip_solver_pc_info
     procedure :: set_max_iter => hip_solver_set_max_iter
+    procedure :: set_params => hip_solver_set_params
     procedure :: destroy => hip_solver_destroy
 end type hip_linear_solver
 
@@ -1217,10 +1224,23 @@ subroutine hip_solver_solve_handle(s, Ah, x, b, pch)
         call hip_check(sgm_pc_apply(s%handle, b, x, SGM_HOST))
         return
     endif
+    ! s%tolerance is live: the reference's loop reads the field at every solve (cg_solvers.f90:133)
+    call hip_check(sgm_solver_set_tolerance(s%handle, s%tolerance))
     rc = sgm_solver_solve(s%handle, Ah, x, b, pch, SGM_HOST)
     if (rc /= 5) call hip_check(rc)         ! 5 = stopped at the set_max_iter extension: the caller reads %iterations
     call hip_check(sgm_solver_info(s%handle, its, res2, conv, last))
     s%iterations = int(its)
+end subroutine
+
+subroutine hip_solver_set_params(s, tolerance)
+    ! cg_set_params (cg_solvers.f90:95-111): callable again at any time; pushed to the handle in front of every solve
+    class(hip_linear_solver), intent(inout) :: s
+    real(dp), intent(in), optional :: tolerance
+    if (present(tolerance)) then
+        s%tolerance = tolerance
+    else
+        s%tolerance = 1.0d-16
+    endif
 end subroutine
 
 subroutine hip_solver_solve(s, A, x, b)
@@ -1257,6 +1277,7 @@ subroutine hip_solver_solve_device(s, A, x, b, pc)
     hp = c_null_ptr
     if (present(pc)) hp = pc%handle
     call A%upload()
+    call hip_check(sgm_solver_set_tolerance(s%handle, s%tolerance))
     rc = sgm_solver_solve(s%handle, A%handle, x%view, b%view, hp, SGM_DEVICE)
     if (rc /= 5) call hip_check(rc)
     call hip_check(sgm_solver_info(s%handle, its, res2, conv, last))
@@ -1489,6 +1510,7 @@ subroutine hip_generalized_lanczos(A, B, solver_for_B, T, Q, q1, pc)
     if (present(pc)) hp = pc%handle
     call A%upload()
     call B%upload()
+    call hip_check(sgm_solver_set_tolerance(solver_for_B%handle, solver_for_B%tolerance))
     call hip_check(sgm_generalized_lanczos(A%handle, B%handle, solver_for_B%handle, hp, int(n, c_int32_t), q0, Tc, Qc, &
         & SGM_HOST))
     T = 0.0_dp

@@ -362,6 +362,23 @@ subroutine test_device_vectors()                                           !
     if (s%iterations /= its1 .or. any(u1 /= u2)) call fail('solve on device vectors differs from the one on host vectors', &
         & maxval(dabs(u1 - u2)))
     print *, 'device vectors: the same solve, bit for bit,', its1, 'iterations'
+    ! s%tolerance is live (cg_solvers.f90:17,133; set_params :95-111): a loose tolerance on the same handle stops early, the
+    ! tight one set afterwards continues from there, and `iterations` accumulates over the two solves (cg_solvers.f90:145)
+    block
+        integer :: it_loose
+        call s%setup(A)
+        u2 = 0.0_dp
+        s%tolerance = 1.d-6
+        call s%solve(A, u2, f, pc)
+        it_loose = s%iterations
+        if (it_loose >= its1 .or. maxval(dabs(u1 - u2)) < 1.d-11) call fail('a tolerance of 1e-6 edited on the live solver was ignored', &
+            & real(it_loose, dp))
+        call s%set_params(1.d-12)
+        call s%solve(A, u2, f, pc)
+        if (s%iterations <= it_loose .or. maxval(dabs(u1 - u2)) > 1.d-9 * maxval(dabs(u1))) &
+            & call fail('set_params(1e-12) on the live solver did not reach the device loop', maxval(dabs(u1 - u2)))
+        print *, 'live tolerance: 1e-6 ->', it_loose, ' iterations, then 1e-12 ->', s%iterations, ' in total'
+    end block
     ! the reordering ILDU(0) preconditioner: A, f, u stay in natural order, the factors are those of the colour-ordered matrix
     block
         type(hip_linear_solver), pointer :: pr, pn

@@ -46,6 +46,7 @@ def run(rank, world, port, case, res):
         uid = [sg.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         comm = sg.Comm(rank, world, uid[0])
+        res["group_ok"] = comm.group_ok          # sgm_comm_init's probe: pairs + all-reduce in one group on this transport
 
         if case == "composite":
             run_composite(rank, world, comm, dev, res)

@@ -229,15 +229,27 @@ const char *ncclGetErrorString(ncclResult_t r)
         case ncclUnhandledCudaError: return "mock_rccl: HIP error";
         case ncclSystemError: return "mock_rccl: system error / timeout";
         case ncclInvalidArgument: return "mock_rccl: invalid argument";
+        case ncclInvalidUsage: return "mock_rccl: a group mixing send / recv with an all-reduce is refused (MOCK_RCCL_REFUSE_MIXED_GROUP)";
         default: return "mock_rccl: error";
     }
 }
+
+// Test hook: MOCK_RCCL_REFUSE_MIXED_GROUP=1 makes this transport refuse a group that holds BOTH point-to-point operations
+// and an all-reduce (ncclInvalidUsage from the all-reduce and from ncclGroupEnd, the queued pairs dropped) -- on every rank
+// alike, so nobody waits for a peer.  What sgm_comm_init's probe must find and the solvers must then work around.
+static bool refuse_mixed()
+{
+    static const bool on = getenv("MOCK_RCCL_REFUSE_MIXED_GROUP") != nullptr;
+    return on;
+}
+static bool g_refused = false;
 
 ncclResult_t ncclGroupStart() { ++g_depth; return ncclSuccess; }
 ncclResult_t ncclGroupEnd()
 {
     if (--g_depth > 0) return ncclSuccess;
     g_depth = 0;
+    if (g_refused) { g_refused = false; g_ops.clear(); return ncclInvalidUsage; }
     return run_ops();
 }
 
@@ -283,6 +295,7 @@ ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataT
                            hipStream_t st)
 {
     if (t != ncclFloat64 || op != ncclSum) return ncclInvalidArgument;
+    if (g_depth > 0 && !g_ops.empty() && refuse_mixed()) { g_refused = true; return ncclInvalidUsage; }
     return collective(send, recv, count * 8, true, (Comm *)comm, st);
 }
 

@@ -38,10 +38,11 @@ def _device_count():
     return torch.cuda.device_count()
 
 
-def _run_ranks(world, case, tmp_path, mock):
+def _run_ranks(world, case, tmp_path, mock, extra_env=None):
     port = _free_port()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(extra_env or {})
     if mock:
         env["SGM_RCCL_LIB"] = MOCK
     else:
@@ -72,16 +73,27 @@ def _run_ranks(world, case, tmp_path, mock):
 
 
 @pytest.mark.parametrize("world,case", [(2, "poisson2d"), (2, "laplace3d"), (3, "laplace3d"), (3, "random"), (4, "poisson2d"),
-                                        (3, "longrows"), (2, "composite"), (3, "composite")])
+                                        (3, "longrows"), (2, "composite"), (3, "composite"), (8, "laplace3d")])
 def test_ranks_share_one_gpu_over_the_host_staged_transport(world, case, tmp_path):
     assert os.path.exists(MOCK), "tests/mock_rccl/librccl_mock.so is missing: run __graft_entry__.build()"
     results = _run_ranks(world, case, tmp_path, mock=True)
+    assert all(r["group_ok"] for r in results)          # (the stand-in transport takes the mixed group, like librccl does)
     its = {k: {r["solves"][k]["iterations"] for r in results} for k in results[0]["solves"]}
     for k, v in its.items():        # every rank stops at the same iteration (the flag follows all-reduced values)
         assert len(v) == 1, (k, v)
 
 
-@pytest.mark.parametrize("world,seed0", [(2, 300000), (3, 300100), (4, 300200)])
+def test_a_transport_that_refuses_the_mixed_group_is_found_at_comm_init_and_worked_around(tmp_path):
+    """with dist_halo_fused = 1 (the default) CG posts ONE group of send / recv pairs + all-reduce; a
+    transport that refuses it must not fail every distributed solve.  sgm_comm_init probes the group once, the ranks agree
+    (sgm_comm_group_ok = 0 everywhere) and the solvers post pairs and all-reduce separately: the whole worker -- products,
+    CG / PCG / BiCGStab against the oracle, modes 0 / 1 / 2 the same bits -- passes on such a transport."""
+    results = _run_ranks(3, "poisson2d", tmp_path, mock=True, extra_env={"MOCK_RCCL_REFUSE_MIXED_GROUP": "1"})
+    assert [r["group_ok"] for r in results] == [False] * 3
+    assert results[0]["solves"]["halo_fused_modes"]["bit_identical_to_exchanging_p"] is True
+
+
+@pytest.mark.parametrize("world,seed0", [(2, 300000), (3, 300100), (4, 300200), (8, 300300)])
 def test_rank_fuzz_seeds(world, seed0, tmp_path):
     """tests/dist_worker.py `fuzz:<seed>:<count>`: seeded systems of tests/fuzz_solvers.py's generator over ranks with RANDOM
     row boundaries -- products bit-exact, dot_order = 1 CG (random preconditioner, colour-ordered ILDU included) the oracle's
@@ -125,6 +137,40 @@ def test_bench_gpus_2_typed_plainly_spawns_its_ranks(tmp_path):
     # every local row of both workloads' products, halo rows included, equals its stored-order sum on both ranks
     assert out["selfcheck"]["product_bit_exact_on_every_rank"] is True
     assert out["c5_strong_scaling"]["product_bit_exact_on_every_rank"] is True
+    _check_phase_fields(out, halo_comm=False)
+
+
+@pytest.mark.parametrize("launcher", ["plain", "torchrun"])
+def test_bench_gpus_8_runs_end_to_end_before_a_node_does(launcher, tmp_path):
+    """the command the driver types on an 8-GPU node, `bench.py --gpus 8`, executed with EIGHT rank
+    processes (all on the one GPU of the box, over the host-staged transport) -- typed plainly (the parent spawns) and under
+    torch.distributed.run (the driver's line).  Every rank's products bit-exact, the strong-scaling keys named after the rank
+    count, per-phase timers present, and the modelled figures absent (they belong to the N = 1 line only)."""
+    env = dict(os.environ)
+    env.update({"SGM_RCCL_LIB": MOCK, "SGM_BENCH_SAME_GPU": "1"})
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    bench_args = [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--spmv-per-step", "4",
+                  "--nx", "300", "--ny", "200", "--cg-steps", "20", "--c5-edge", "96", "--c5-cg-steps", "10", "--no-cpu"]
+    if launcher == "plain":
+        cmd = [sys.executable] + bench_args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + bench_args
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, p.stdout[-2000:]
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["config"]["parallelism"] == "row-partition x8"
+    assert out["cg"]["iterations"] == 20 and out["c5_strong_scaling"]["cg_iterations"] == 10
+    assert out["selfcheck"]["product_bit_exact_on_every_rank"] is True
+    assert out["c5_strong_scaling"]["product_bit_exact_on_every_rank"] is True
+    rf = out["roofline"]
+    assert rf["c5_8gpu_cg_iters_per_s"] > 0 and rf["c5_8gpu_spmv_ms"] > 0 and rf["frac"] <= 1.0
+    assert list(rf)[6:10] == ["c5_8gpu_spmv_ms", "c5_8gpu_spmv_frac_moved", "c5_8gpu_cg_iters_per_s", "c5_8gpu_cg_frac_moved"]
+    assert not [k for k in rf if k.startswith("c5_model_")], "modelled figures belong to the N = 1 line"
+    assert out["c5_strong_scaling"]["n"] == 96 ** 3
     _check_phase_fields(out, halo_comm=False)
 
 

@@ -2288,6 +2288,67 @@ def test_solver_semantics(golden, orc):
     assert np.abs(u4 - g["ref_s2_u"]).max() / np.abs(g["ref_s2_u"]).max() <= 1e-12
 
 
+@pytest.mark.parametrize("kind", ["cg", "cg_jacobi", "bicgstab", "gmres"])
+@pytest.mark.parametrize("small", [1, 0])
+def test_tolerance_is_live_on_an_existing_handle(golden, orc, kind, small):
+    """solver%tolerance is a public field the reference's loops read at every solve (cg_solvers.f90:17,133,175;
+    bicgstab_solvers.f90:153) and set_params may be called again (cg_solvers.f90:95-111): the same handle solved to 1e-6, then
+    to 1e-12 from where the first solve stopped.  Against the oracle doing the same two solves: the stops and the accumulated
+    `iterations` (cg_solvers.f90:72,145) agree, and in the reference's dot order both iterates are the oracle's bit for bit.
+    (sgm_solver_set_tolerance.)"""
+    g = golden("poisson2d_32x24")
+    A = hip_matrix(g)
+    Ao = orc.CsrMatrix(int(g["n"]), int(g["n"]), g["ptr"], g["node"], g["val"])
+    n, b = int(g["n"]), g["b"]
+    mk = {"cg": sg.cg, "cg_jacobi": sg.cg, "bicgstab": sg.bicgstab, "gmres": sg.gmres}[kind]
+    for order in (1, 0):
+        if kind == "gmres" and order == 1:
+            continue                     # (no reference implementation: nothing to be bit-identical to)
+        solver = mk(1e-6)
+        solver.set_option("dot_order", order)
+        for o in ("cg_small", "bicgstab_small"):
+            solver.set_option(o, small)
+        solver.setup(A)
+        pc = None
+        if kind == "cg_jacobi":
+            pc = sg.jacobi()
+            pc.setup(A)
+        u = np.zeros(n)
+        solver.solve(A, u, b, pc)
+        it1, ua = solver.iterations, u.copy()
+        assert solver.converged and 1e-12 < np.sqrt(solver.res2) <= 1e-6
+        solver.tolerance = 1e-12          # the public field, edited after the handle exists
+        solver.solve(A, u, b, pc)
+        it2 = solver.iterations
+        assert it2 > it1 and solver.last_iterations == it2 - it1 and np.sqrt(solver.res2) <= 1e-12
+        assert not np.array_equal(u, ua)
+        if kind != "gmres":
+            ref = orc.cg if kind.startswith("cg") else orc.bicgstab
+            pco = orc.Jacobi(Ao) if pc is not None else None
+            r1 = ref(Ao, b, tol=1e-6, pc=pco)
+            r2 = ref(Ao, b, tol=1e-12, pc=pco, x0=r1[0])
+            if order == 1:
+                assert it1 == r1[1] and it2 == r1[1] + r2[1], (it1, it2, r1[1], r2[1])
+                assert np.array_equal(ua, r1[0]) and np.array_equal(u, r2[0])
+            else:
+                assert abs(it1 - r1[1]) <= 1 and abs(it2 - r1[1] - r2[1]) <= 2
+                assert np.abs(u - r2[0]).max() / np.abs(r2[0]).max() <= 1e-10
+        # ... and back up: a tolerance the residual already meets enters no iteration and leaves x alone (set_params form)
+        solver.set_params(1e-3)
+        ub = u.copy()
+        solver.solve(A, u, b, pc)
+        assert solver.iterations == it2 and np.array_equal(u, ub)
+        assert solver.set_params().tolerance == 1e-16        # cg_solvers.f90:106
+        solver.destroy()
+        if pc is not None:
+            pc.destroy()
+    with pytest.raises(sg.SigmaError):
+        s = sg.cg(1e-6)
+        s.setup(A)
+        s.tolerance = float("nan")
+        s.solve(A, np.zeros(n), b)
+
+
 def test_solver_edge_cases(orc):
     """Zero right-hand side (the loop is never entered, cg_solvers.f90:133), a 1 x 1 system,
     odd sizes (vector kernels have a scalar tail), a non-zero initial guess, and the
