@@ -41,6 +41,7 @@ use graphs
 use sparse_matrices
 use linear_operator_interface
 use cg_solvers
+use ldu_solvers
 use hip_matrices
 use hip_solvers
 use hip_eigensolver
@@ -50,8 +51,8 @@ implicit none
     class(graph_interface), pointer :: g, h
     type(hip_ellpack_matrix) :: A
     type(hip_csr_matrix) :: B
-    class(linear_solver), pointer :: solver, pc
-    real(dp), allocatable :: u(:), v(:), f(:), y(:), yr(:)
+    class(linear_solver), pointer :: solver, pc, rsolver, rpc
+    real(dp), allocatable :: u(:), v(:), f(:), y(:), yr(:), ur(:)
     type(ellpack_matrix) :: Ar
     real(dp) :: dx, misfit, c
     integer :: i, nn, its_ref, its_hip
@@ -167,6 +168,39 @@ implicit none
             call solver%set_params()
             if (solver%tolerance /= 1.d-16) call exit(1)
     end select
+
+    ! 2c. ldu() on the ELLPACK operand (sparse_ldu_setup takes any sparse_matrix_interface, ldu_solvers.f90:95-130, and
+    !     reads it through the edge cursor: real entries, not padding): hip_cg + hip_ldu on A against the reference's
+    !     cg + ldu on its own ellpack_matrix
+    allocate(ur(nn))
+    rsolver => cg(1.d-16)
+    rpc => ldu(incomplete = .true., level = 0)
+    call rsolver%setup(Ar)
+    call rpc%setup(Ar)
+    ur = 0.0_dp
+    call rsolver%solve(Ar, ur, f, rpc)
+    pc => hip_ldu()
+    call pc%setup(A)
+    call solver%setup(A)
+    u = 0.0_dp
+    call solver%solve(A, u, f, pc)
+    misfit = maxval(dabs(u - ur))
+    select type(solver)
+        type is(hip_krylov_solver)
+            select type(rsolver)
+                type is(cg_solver)
+                    print *, 'hip_cg() + hip_ldu() on ELLPACK: iterations', solver%iterations, ' reference', &
+                        & rsolver%iterations, ' difference', misfit
+                    if (misfit > 1.0e-14 .or. abs(solver%iterations - rsolver%iterations) > 1) then
+                        print *, 'hip_ldu() on an ELLPACK matrix failed.'
+                        call exit(1)
+                    endif
+            end select
+    end select
+    call pc%destroy()
+    call rsolver%destroy()
+    call rpc%destroy()
+    deallocate(pc, rsolver, rpc, ur)
 
     ! 3. the A%solve facade with a Jacobi preconditioner
     pc => hip_jacobi()

@@ -119,7 +119,10 @@ def main():
     case("poisson2d_32x24", n, n, CSR, edges, P.test_vector(n), b,
          [(CG, NOPC, 1e-12), (CG, JACOBI, 1e-12), (CG, LDU, 1e-12),
           (BICGSTAB, NOPC, 1e-12), (BICGSTAB, JACOBI, 1e-12), (BICGSTAB, LDU, 1e-12)])
-    case("poisson2d_ell_32x24", n, n, ELL, edges, P.test_vector(n), b, [(CG, NOPC, 1e-12)])
+    # (CG / BiCGStab + LDU on the ELLPACK operand: sparse_ldu_setup takes any sparse_matrix_interface, ldu_solvers.f90:95-130,
+    #  and reads it through the get_edges cursor -- the rows' real entries, never the padding)
+    case("poisson2d_ell_32x24", n, n, ELL, edges, P.test_vector(n), b,
+         [(CG, NOPC, 1e-12), (CG, LDU, 1e-12), (BICGSTAB, LDU, 1e-12)])
 
     # -- C5 mini: 7-point Laplacian 8x7x6 ---------------------------------------
     nx, ny, nz = 8, 7, 6
@@ -149,6 +152,12 @@ def main():
                   else [(BICGSTAB, NOPC, 1e-13), (BICGSTAB, JACOBI, 1e-13),
                         (BICGSTAB, LDU, 1e-13)])
         case(f"random_{tag}_128", n, n, CSR, edges, xs, b, solves)
+
+    # ... and the SPD member of that family held in ELLPACK: rows of 3..13 entries in max_d = 13 slots, so most rows carry padding
+    #     (the last neighbour repeated, value 0) that the LDU pattern and fill must not see
+    edges = P.random_spd_edges(n, seed=3, skew=False)
+    case("random_spd_ell_padded_128", n, n, ELL, edges, rs.random_sample(n), rs.random_sample(n),
+         [(CG, NOPC, 1e-14), (CG, JACOBI, 1e-14), (CG, LDU, 1e-14), (BICGSTAB, LDU, 1e-13)])
 
     # duplicate edges in the insertion list (ll_graph%add_edge skips them; the second
     # set_value wins): exercises the de-duplication of the graph build

@@ -178,13 +178,24 @@ class Jacobi:
         return x
 
 
+def ell_real_entries(E):
+    """What the reference's edge cursor hands out for an ellpack_matrix (ellpack_graphs.f90:310-369, get_entries
+    ellpack_matrices.f90): row after row the first degrees(i) slots of node(:, i) / val(:, i) -- the same stream a CSR matrix
+    with exactly these rows yields (cs_graphs.f90 cursor), which is all incomplete_ldu_sparsity_pattern (ldu_solvers.f90:397-440)
+    and the fill loop of sparse_static_pattern_ldu_factorization (:306-321) see of A.  Returned as that CsrMatrix."""
+    deg = np.asarray(E.degrees, np.int64)
+    ptr = np.concatenate([[1], 1 + np.cumsum(deg)]).astype(I4)
+    keep = np.arange(E.max_d)[None, :] < deg[:, None]
+    return CsrMatrix(E.n, E.m, ptr, np.ascontiguousarray(E.node[keep], I4), np.ascontiguousarray(E.val[keep], F8))
+
+
 class Ildu:
-    """sparse_ldu_solver, ILDU(0) (ldu_solvers.f90:95-176); CSR input only, like the
-    reference tests."""
+    """sparse_ldu_solver, ILDU(0) (ldu_solvers.f90:95-176) of a CSR matrix, or of an ELLPACK matrix through its edge stream."""
     kind = 2
 
     def __init__(self, A):
-        assert A.fmt == 1
+        if A.fmt == 2:
+            A = ell_real_entries(A)
         n = self.n = A.n
         self.Lptr = np.zeros(n + 1, I4)
         self.Uptr = np.zeros(n + 1, I4)

@@ -1031,10 +1031,25 @@ int sgm_ell_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts, 
         SGM_HIP(hipStreamSynchronize(g_rt.stream));
     }
     for (int32_t i = 0; i <= n; ++i) hptr[i] = 1 + i * max_d;
+    // degrees(i), recovered from the padding the reference keeps (k_ell_degrees, sgm_mat.hip): what an ILDU(0) setup on these
+    // rows goes by -- the reference's pattern pass and fill read the real entries only (ellpack_graphs.f90:310-369)
+    std::vector<int32_t> hdeg((size_t)std::max(n, 1), 0);
+    for (int32_t i = 0; i < n && max_d; ++i) {
+        const int32_t *row = hnode.data() + (size_t)i * max_d;
+        const int32_t last = row[max_d - 1];
+        int32_t d = 0;
+        if (last != 0)
+            for (d = 1; d < max_d && row[d - 1] != last; ++d) {}
+        hdeg[i] = d;
+    }
     for (int32_t i = 0; i < n; ++i)
         for (int32_t k = 0; k < max_d; ++k)
             if (hnode[(size_t)i * max_d + k] <= 0) hnode[(size_t)i * max_d + k] = (int32_t)(r0 + i + 1);
-    return sgm_csr_create_dist(out, comm, row_starts, nnz, hptr.data(), hnode.data(), hval.data(), SGM_HOST);
+    SGM_TRY(sgm_csr_create_dist(out, comm, row_starts, nnz, hptr.data(), hnode.data(), hval.data(), SGM_HOST));
+    Part &p = (*out)->parts[0];
+    SGM_TRY(dalloc(&p.edeg, (size_t)std::max(n, 1)));
+    SGM_HIP(hipMemcpy(p.edeg, hdeg.data(), (size_t)std::max(n, 1) * 4, hipMemcpyHostToDevice));
+    return SGM_OK;
 }
 
 }  // extern "C"

@@ -313,6 +313,22 @@ int sgm_csr_set_values(sgm_mat A, const double *val, int where)
     return SGM_OK;
 }
 
+// degrees(i) of an ELLPACK row as the reference holds it (ellpack_graphs.f90:14-21): add_edge / graph_build set the whole rest
+// of the row to the neighbour just added (`g%node(d+1:, i) = j`, :164,:394-397) and never store a neighbour twice, so the last
+// slot holds the last real neighbour and its FIRST occurrence is slot degrees(i); an empty row keeps node(:, i) = 0.
+__global__ void k_ell_degrees(int32_t n, int32_t max_d, const int32_t *__restrict__ node /* (max_d, n) as handed over, 1-based */,
+                              int32_t *__restrict__ deg)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t *row = node + (int64_t)i * max_d;
+    const int32_t last = row[max_d - 1];
+    int32_t d = 0;
+    if (last != 0)
+        for (d = 1; d < max_d && row[d - 1] != last; ++d) {}
+    deg[i] = d;
+}
+
 int sgm_ell_create(sgm_mat *out, int32_t nrow, int32_t ncol, int32_t max_d, const int32_t *node,
                    const double *val, int where)
 {
@@ -349,6 +365,10 @@ int sgm_ell_create(sgm_mat *out, int32_t nrow, int32_t ncol, int32_t max_d, cons
     }
     hipLaunchKernelGGL(k_ell_transpose, dim3(vec_grid(total)), dim3(kBlock), 0, g_rt.stream, src, (const double *)nullptr, p.ecol,
                        p.eval, nrow, max_d, ncol, bad);
+    // degrees(n): not an argument (the product never reads it, ellpack_matrices.f90:640-665), but what the reference's edge
+    // cursor and get_value go by (ellpack_graphs.f90:310-369) -- recovered from the padding the reference keeps
+    SGM_TRY(dalloc(&p.edeg, (size_t)nrow));
+    hipLaunchKernelGGL(k_ell_degrees, dim3((nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, g_rt.stream, nrow, max_d, src, p.edeg);
     SGM_HIP(hipMemcpyAsync(&hbad, bad, sizeof hbad, hipMemcpyDeviceToHost, g_rt.stream));
     SGM_HIP(hipStreamSynchronize(g_rt.stream));
     dfree(tn);

@@ -130,6 +130,11 @@ __global__ void k_perm_lengths(int32_t n, const int32_t *__restrict__ rowptr, co
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) len2[p1[i] - 1] = rowptr[i + 1] - rowptr[i];
 }
+__global__ void k_perm_degrees(int32_t n, const int32_t *__restrict__ deg, const int32_t *__restrict__ p1, int32_t *__restrict__ deg2)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) deg2[p1[i] - 1] = deg[i];
+}
 // one wave per row: the row's entries move to the new row's segment in stored order
 __global__ void k_perm_rows(int32_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ p1,
                             const int32_t *__restrict__ rowptr2, const int32_t *__restrict__ col,
@@ -565,6 +570,10 @@ int permuted_part(const Part &p, const int32_t *p1, Part &q)
                               q.col, q.val);
     if (p.nnz) hipLaunchKernelGGL(k_perm_cols_own, dim3(vec_grid(p.nnz)), dim3(kBlock), 0, st, p.nnz, p.n_halo == 0 ? INT32_MAX : p.ncol_own,
                                   q.col, p1);
+    if (p.edeg) {                  // ELLPACK rows over ranks: the degrees follow their rows (the entries of a row keep their stored order)
+        SGM_TRY(dalloc(&q.edeg, (size_t)std::max(n, 1)));
+        if (n) hipLaunchKernelGGL(k_perm_degrees, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, (const int32_t *)p.edeg, p1, q.edeg);
+    }
     SGM_HIP(hipGetLastError());
     SGM_HIP(hipStreamSynchronize(st));
     SGM_TRY(rebuild_csr_formats(q));

@@ -2373,6 +2373,61 @@ int grid_factor_order(IlduState *S, int32_t n, int32_t w, int32_t h)
 }
 
 // The factors' patterns on the device (0-based) from the part's CSR-order arrays ...
+// The real entries of an ELLPACK part -- the first degrees(i) slots of every row, in slot order: what the reference's cursor
+// hands out (ellpack_graphs.f90:310-369) -- as 0-based CSR arrays.  Padding slots (the last neighbour repeated, value 0) and
+// empty rows' node = 0 never appear.  ELL = false: the rows are fixed-length CSR rows (an ELLPACK matrix over ranks,
+// sgm_ell_create_dist, whose padding slots are stored entries for the product's sake) and the same first degrees(i) are taken.
+template <bool ELL>
+__global__ void k_real_entries(int32_t n, const int32_t *__restrict__ src_ptr, const int32_t *__restrict__ scol, const double *__restrict__ sval,
+                               const int32_t *__restrict__ rowptr, int32_t *__restrict__ col, double *__restrict__ val)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t b = rowptr[i], d = rowptr[i + 1] - b;
+    const int64_t s0 = ELL ? i : src_ptr[i];
+    for (int32_t k = 0; k < d; ++k) {
+        const int64_t s = ELL ? (int64_t)k * n + s0 : s0 + k;
+        col[b + k] = scol[s];
+        val[b + k] = sval[s];
+    }
+}
+int real_entries_as_csr(const Part &p, bool ell, Part &v)
+{
+    hipStream_t st = g_rt.stream;
+    const int32_t n = p.n;
+    if (!p.edeg && n && (!ell || p.max_d)) return fail(SGM_ERR_UNSUPPORTED, "ILDU(0) on an ELLPACK matrix needs its degrees (this handle has none)");
+    v.n = n;
+    v.ncol_own = p.ncol_own;
+    v.n_halo = p.n_halo;
+    v.lean = false;
+    SGM_TRY(dalloc(&v.rowptr, (size_t)n + 1));
+    SGM_HIP(hipMemsetAsync(v.rowptr, 0, ((size_t)n + 1) * 4, st));
+    if (n && p.edeg) SGM_HIP(hipMemcpyAsync(v.rowptr, p.edeg, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+    size_t tb = 0;
+    void *tmp = nullptr;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, v.rowptr, v.rowptr, n + 1, st);
+    SGM_HIP(hipMalloc(&tmp, std::max<size_t>(tb, 16)));
+    struct Tmp { void *t; ~Tmp() { (void)hipFree(t); } } guard{tmp};
+    SGM_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, v.rowptr, v.rowptr, n + 1, st));
+    int32_t total = 0;
+    SGM_HIP(hipMemcpyAsync(&total, v.rowptr + n, 4, hipMemcpyDeviceToHost, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    v.nnz = total;
+    SGM_TRY(dalloc(&v.col, (size_t)total + 4));
+    SGM_TRY(dalloc(&v.val, (size_t)total + 2));
+    SGM_HIP(hipMemsetAsync(v.col + total, 0, 4 * sizeof(int32_t), st));
+    SGM_HIP(hipMemsetAsync(v.val + total, 0, 2 * sizeof(double), st));
+    const dim3 grid((n + kBlock - 1) / kBlock);
+    if (n && ell)
+        hipLaunchKernelGGL(k_real_entries<true>, grid, dim3(kBlock), 0, st, n, (const int32_t *)nullptr, (const int32_t *)p.ecol,
+                           (const double *)p.eval, (const int32_t *)v.rowptr, v.col, v.val);
+    else if (n)
+        hipLaunchKernelGGL(k_real_entries<false>, grid, dim3(kBlock), 0, st, n, (const int32_t *)p.rowptr, (const int32_t *)p.col,
+                           (const double *)p.val, (const int32_t *)v.rowptr, v.col, v.val);
+    SGM_HIP(hipGetLastError());
+    return SGM_OK;
+}
+
 int ildu_pattern(IlduState *S, const Part &P, int32_t own)
 {
     const int32_t n = P.n;
@@ -2748,9 +2803,14 @@ static int pc_setup_ordered(sgm_pc pc, sgm_mat A)
         return finish();
     }
     // ILDU(0); on a row partition: of every part's diagonal block (block-Jacobi ILDU -- exact
-    // parity with the reference holds for one part, more parts change the iteration counts)
-    if (A->fmt != SGM_FMT_CSR)
-        return fail(SGM_ERR_UNSUPPORTED, "ILDU(0) needs a CSR matrix");
+    // parity with the reference holds for one part, more parts change the iteration counts).
+    // An ELLPACK operand: sparse_ldu_setup takes any sparse_matrix_interface (ldu_solvers.f90:95-130); the pattern pass reads A
+    // through its get_edges cursor (:397-440) and the fill through get_entries (:306-321), and the ELLPACK cursor yields row
+    // after row the first degrees(i) slots of node(:, i) / val(:, i) (ellpack_graphs.f90:310-369) -- never the padding.  That
+    // edge stream is a CSR matrix's: the rows' real entries in slot order are laid out as one (real_entries_as_csr) for the
+    // length of this setup, and everything below runs on it statement for statement.
+    if (A->fmt != SGM_FMT_CSR && A->fmt != SGM_FMT_ELL)
+        return fail(SGM_ERR_UNSUPPORTED, "ILDU(0) needs a CSR or ELLPACK matrix");
     if (!pc->abort_sticky) SGM_TRY(dalloc(&pc->abort_sticky, 1));
     SGM_HIP(hipMemsetAsync(pc->abort_sticky, 0, sizeof(int32_t), g_rt.stream));
     if (pc->ild.size() != A->parts.size()) {
@@ -2761,7 +2821,17 @@ static int pc_setup_ordered(sgm_pc pc, sgm_mat A)
     pc->n = A->nrow;
     for (size_t ip = 0; ip < A->parts.size(); ++ip) {
         IlduState *S = &pc->ild[ip];
-        const Part &P = A->parts[ip];
+        Part ellview;
+        struct EllView { Part &v; ~EllView() { dfree(v.rowptr); dfree(v.col); dfree(v.val); v.rowptr = nullptr; v.col = nullptr; v.val = nullptr; } } ellguard{ellview};
+        const bool trim = A->fmt == SGM_FMT_ELL || A->parts[ip].edeg;     // (edeg on a CSR part: ELLPACK rows over ranks, sgm_ell_create_dist)
+        if (trim) {
+            const Part &src = A->parts[ip];
+            if (A->fmt == SGM_FMT_CSR) SGM_TRY(csr_need_arrays(src));
+            const int rc = real_entries_as_csr(src, A->fmt == SGM_FMT_ELL, ellview);
+            if (A->fmt == SGM_FMT_CSR) csr_release_arrays(src);
+            SGM_TRY(rc);
+        }
+        const Part &P = trim ? ellview : A->parts[ip];
         static const bool timing = getenv("SGM_PC_TIMING") != nullptr;       // phase times of the setup on stderr (tuning aid)
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto t_prev = now();

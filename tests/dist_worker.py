@@ -195,6 +195,21 @@ def run(rank, world, port, case, res):
         tea = ye0[e0:e1].copy()
         He.matvec_t_add(xe_full[e0:e1].copy(), tea)
         assert np.array_equal(tea, E.matvec_t_add(xe_full, ye0.copy())[e0:e1])
+        # ... and ldu() on these rows: block-Jacobi ILDU(0) of every rank's diagonal block of the REAL entries (the reference's
+        # pattern pass and fill go by the edge cursor, ellpack_graphs.f90:310-369: the first degrees(i) slots, never the padding,
+        # which is stored here for the product's sake and would otherwise overwrite the last neighbour's value with 0.0)
+        Ec = orc.ell_real_entries(E)
+        rowsE = np.repeat(np.arange(ne), np.diff(Ec.ptr))
+        blkE = np.searchsorted(es, np.arange(ne), side="right") - 1
+        keepE = blkE[rowsE] == blkE[Ec.node - 1]
+        cntE = np.bincount(rowsE[keepE], minlength=ne)
+        EbD = orc.CsrMatrix(ne, ne, np.concatenate([[1], 1 + np.cumsum(cntE)]).astype(np.int32), Ec.node[keepE].copy(), Ec.val[keepE].copy())
+        pcE = sg.ldu()
+        pcE.setup(He)
+        zE = np.zeros(e1 - e0)
+        pcE.solve(He, zE, xe_full[e0:e1].copy())
+        assert np.array_equal(zE, orc.Ildu(EbD).solve(xe_full)[e0:e1], equal_nan=True), "ILDU(0) of distributed ELLPACK rows saw the padding"
+        pcE.destroy()
         He.destroy()
 
         # ---- Krylov loops with all-reduced dots

@@ -1419,6 +1419,77 @@ def test_device_factorisation_statement_for_statement(orc, case):
     same_factors(orc.Ildu(A2))
 
 
+@pytest.mark.parametrize("kind", ["random_spd_padded", "grid_full_rows", "band_with_empty_rows", "one_slot"])
+def test_ildu_on_ellpack_operands_vs_oracle(orc, kind, dot_order_1):
+    """sparse_ldu_setup takes any sparse_matrix_interface (ldu_solvers.f90:95-130): on an ellpack_matrix the pattern pass and
+    the fill read the rows' REAL entries through the edge cursor (ellpack_graphs.f90:310-369) -- the first degrees(i) slots,
+    never the padding (the last neighbour repeated with value 0, which a naive read would take for a second (i, j) entry whose
+    0.0 overwrites the real one).  The handle is given node / val only (sgm_ell_create has no degrees argument) and recovers
+    the degrees from the padding.  L, D, U and their index arrays np.array_equal to the oracle's, the apply bit for bit, a
+    second setup after a value change, and PCG / PBiCGStab in the reference's dot order the oracle's solve bit for bit.
+    """
+    rs = np.random.RandomState(31)
+    if kind == "random_spd_padded":
+        n = 3000
+        E = orc.EllMatrix.from_edges(n, n, *P.random_spd_edges(n, seed=9, skew=False))
+    elif kind == "grid_full_rows":
+        nx, ny = 70, 45
+        n = nx * ny
+        E = orc.EllMatrix.from_edges(n, n, *P.poisson2d_edges(nx, ny))
+    elif kind == "one_slot":
+        n = 500                       # max_d = 1: the diagonal only
+        E = orc.EllMatrix.from_edges(n, n, np.arange(1, n + 1), np.arange(1, n + 1), rs.uniform(1.0, 2.0, n))
+    else:
+        n = 2400                      # a band whose every 7th row has no entry at all (node(:, i) = 0, degrees(i) = 0)
+        i = np.repeat(np.arange(n), 3)
+        j = np.clip(i + np.tile([-5, 0, 5], n), 0, n - 1)
+        keep = (i % 7 != 3) & ~((j != i) & (j % 7 == 3))
+        i, j = i[keep], j[keep]
+        key, first = np.unique(i.astype(np.int64) * n + j, return_index=True)
+        i, j = i[np.sort(first)], j[np.sort(first)]
+        E = orc.EllMatrix.from_edges(n, n, i + 1, j + 1, np.where(i == j, 4.0, -1.0) * rs.uniform(0.5, 1.0, i.size))
+    assert kind == "grid_full_rows" or kind == "one_slot" or int(E.degrees.min()) < E.max_d
+    H = hip_from_oracle(E)
+    assert np.array_equal(H.get("degrees", np.int32), E.degrees)        # recovered from the padding at create
+    ref = orc.Ildu(E)
+    pc = sg.ldu()
+    pc.setup(H)
+
+    def same_factors(ref):
+        for nm, dt, want in (("Lptr", np.int32, ref.Lptr), ("Lnode", np.int32, ref.Lnode), ("Uptr", np.int32, ref.Uptr),
+                             ("Unode", np.int32, ref.Unode)):
+            assert np.array_equal(pc.get(nm, dt), want), nm
+        for nm, want in (("Lval", ref.Lval), ("Uval", ref.Uval), ("D", ref.D)):
+            got = pc.get(nm, np.float64)
+            assert np.array_equal(got, want[:got.size], equal_nan=True), nm
+    same_factors(ref)
+    b = P.test_vector(n)
+    z = np.zeros(n)
+    pc.solve(H, z, b)
+    assert np.array_equal(z, ref.solve(b), equal_nan=True)
+    if kind != "band_with_empty_rows":                                   # (a zero row: no system to solve)
+        for mk, oref, tol in ((sg.cg, orc.cg, 1e-12), (sg.bicgstab, orc.bicgstab, 1e-11)):
+            s = mk(tol)
+            s.setup(H)
+            u = np.zeros(n)
+            s.solve(H, u, b, pc)
+            ur, itr = oref(E, b, tol=tol, pc=ref)[:2]
+            assert s.iterations == itr and np.array_equal(u, ur), (kind, mk.__name__, s.iterations, itr)
+            s.destroy()
+    v2 = E.val * (1.0 + 0.25 * np.sin(np.arange(E.val.size)).reshape(E.val.shape))
+    H.set_values(v2)
+    pc.setup(H)
+    same_factors(orc.Ildu(orc.EllMatrix(n, n, E.max_d, E.node, v2, E.degrees)))
+    # ... and through the A%solve facade (linear_operator_interface.f90:213-280)
+    if kind == "grid_full_rows":
+        H.set_values(E.val)
+        H.set_solver(sg.cg(1e-12))
+        H.set_preconditioner(sg.ldu())
+        u = np.zeros(n)
+        H.solve(u, b)
+        assert np.array_equal(u, orc.cg(E, b, tol=1e-12, pc=ref)[0])
+
+
 def test_ildu_apply_many_levels_vs_oracle(orc):
     """5-point grid 300x200: 499 dependency levels, wide and narrow level runs."""
     ptr, node, val = P.poisson2d_csr(300, 200)
@@ -2298,7 +2369,7 @@ def test_tolerance_is_live_on_an_existing_handle(golden, orc, kind, small):
     (sgm_solver_set_tolerance.)"""
     g = golden("poisson2d_32x24")
     A = hip_matrix(g)
-    Ao = orc.CsrMatrix(int(g["n"]), int(g["n"]), g["ptr"], g["node"], g["val"])
+    Ao = orc.CsrMatrix(int(g["n"]), int(g["n"]), g["ref_ptr"], g["ref_node"], g["ref_val"])
     n, b = int(g["n"]), g["b"]
     mk = {"cg": sg.cg, "cg_jacobi": sg.cg, "bicgstab": sg.bicgstab, "gmres": sg.gmres}[kind]
     for order in (1, 0):
