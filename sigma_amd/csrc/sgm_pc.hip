@@ -126,6 +126,7 @@ struct GridTri {
 
 struct PartPC {
     double *idiag = nullptr;
+    int32_t n = 0;                   // rows of the part (on a matrix distributed over ranks: this rank's, not the global count)
 };
 
 }  // namespace
@@ -2770,6 +2771,7 @@ static int pc_setup_ordered(sgm_pc pc, sgm_mat A)
             pc->parts.assign(1, PartPC());
         }
         pc->n = A->nrow;
+        pc->parts[0].n = A->nrow;
         if (!pc->parts[0].idiag) SGM_TRY(dalloc(&pc->parts[0].idiag, (size_t)A->nrow + 2));
         const int nrb = (int)A->blk_row_ptr.size() - 1, ncb = (int)A->blk_col_ptr.size() - 1;
         for (int it = 0; it < nrb; ++it)
@@ -2797,6 +2799,7 @@ static int pc_setup_ordered(sgm_pc pc, sgm_mat A)
         for (size_t ip = 0; ip < A->parts.size(); ++ip) {
             const Part &p = A->parts[ip];
             if (!pc->parts[ip].idiag) SGM_TRY(dalloc(&pc->parts[ip].idiag, (size_t)p.n + 2));
+            pc->parts[ip].n = p.n;
             jacobi_rows(p, A->fmt, 0, p.n, 0, pc->parts[ip].idiag);
         }
         SGM_HIP(hipGetLastError());
@@ -3099,27 +3102,29 @@ int sgm_pc_apply(sgm_pc pc, const double *r, double *z, int where)
     if (!pc || !r || !z) return fail(SGM_ERR_BAD_ARG, "sgm_pc_apply: null argument");
     if (pc->kind == SGM_PC_JACOBI && pc->parts.size() != 1)
         return fail(SGM_ERR_UNSUPPORTED, "sgm_pc_apply: stand-alone apply needs a single-part matrix");
+    // the vectors hold THIS process's rows: all of them on one GPU or an in-process partition, this rank's block when the
+    // matrix is distributed over ranks (pc->n is the global count there)
+    int64_t nloc = 0;
+    if (pc->kind == SGM_PC_ILDU0) for (const auto &S : pc->ild) nloc += S.n;
+    else nloc = pc->parts.empty() ? 0 : pc->parts[0].n;
     Staged sr, sz;
-    SGM_TRY(stage_in(sr, r, pc->n, where, true));
-    SGM_TRY(stage_in(sz, z, pc->n, where, false));
+    SGM_TRY(stage_in(sr, r, nloc, where, true));
+    SGM_TRY(stage_in(sz, z, nloc, where, false));
     // a throw-away matrix view with the right part count for pc_apply_parts (block-Jacobi ILDU on an in-process partition:
     // the caller's vectors are global, part k's slice starts where the rows of the parts before it end)
     const size_t NP = pc->kind == SGM_PC_ILDU0 ? std::max<size_t>(pc->ild.size(), 1) : 1;
     sgm_mat_s view;
     view.parts.resize(NP);
-    if (NP == 1) view.parts[0].n = pc->n;
-    else {
-        int64_t tot = 0;
-        for (size_t ip = 0; ip < NP; ++ip) { view.parts[ip].n = pc->ild[ip].n; tot += pc->ild[ip].n; }
-        if (tot != pc->n) return fail(SGM_ERR_UNSUPPORTED, "sgm_pc_apply: stand-alone apply of a preconditioner set up on a matrix distributed over ranks");
-    }
+    if (NP == 1) view.parts[0].n = (int32_t)nloc;
+    else
+        for (size_t ip = 0; ip < NP; ++ip) view.parts[ip].n = pc->ild[ip].n;
     // in-place apply (r == z on the device) through a pipelined sweep: a sweep that gives up has scattered its "not yet
     // written" patterns over z = r by the time anyone notices, so the redo below needs a right-hand side of its own
     Staged rkeep;
     if (sr.dev == sz.dev && pc_abort_word(pc)) {
-        SGM_TRY(dalloc(&rkeep.dev, (size_t)pc->n));
+        SGM_TRY(dalloc(&rkeep.dev, (size_t)nloc));
         rkeep.owned = true;
-        SGM_HIP(hipMemcpyAsync(rkeep.dev, sr.dev, (size_t)pc->n * sizeof(double), hipMemcpyDeviceToDevice, g_rt.stream));
+        SGM_HIP(hipMemcpyAsync(rkeep.dev, sr.dev, (size_t)nloc * sizeof(double), hipMemcpyDeviceToDevice, g_rt.stream));
     }
     std::vector<const double *> rsv(NP);
     std::vector<double *> zsv(NP);
@@ -3138,7 +3143,7 @@ int sgm_pc_apply(sgm_pc pc, const double *r, double *z, int where)
             SGM_TRY(pc_apply_parts(pc, &view, rs, zs, nullptr));
         }
     }
-    SGM_TRY(stage_out(sz, z, pc->n, where));
+    SGM_TRY(stage_out(sz, z, nloc, where));
     return finish();
 }
 

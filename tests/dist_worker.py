@@ -16,6 +16,8 @@ sys.path.insert(0, ROOT)
 
 
 def main():
+    import faulthandler
+    faulthandler.enable()          # a crash inside the library names the Python line that called it (the log of this rank)
     rank, world, port, case, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     res = {"rank": rank, "ok": False}
     try:

@@ -1474,7 +1474,8 @@ def test_ildu_on_ellpack_operands_vs_oracle(orc, kind, dot_order_1):
             u = np.zeros(n)
             s.solve(H, u, b, pc)
             ur, itr = oref(E, b, tol=tol, pc=ref)[:2]
-            assert s.iterations == itr and np.array_equal(u, ur), (kind, mk.__name__, s.iterations, itr)
+            # (equal_nan: BiCGStab on a system its preconditioner solves exactly ends in 0 / 0 -- in the reference's loop too)
+            assert s.iterations == itr and np.array_equal(u, ur, equal_nan=True), (kind, mk.__name__, s.iterations, itr)
             s.destroy()
     v2 = E.val * (1.0 + 0.25 * np.sin(np.arange(E.val.size)).reshape(E.val.shape))
     H.set_values(v2)
