@@ -10,6 +10,7 @@
 // RCCL is bound at run time with dlopen("librccl.so.1") so that the single-GPU path has
 // no link-time dependency on it and a process that already loaded torch's RCCL shares it.
 #include "sgm_internal.hpp"
+#include "sgm_plan_host.hpp"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -327,97 +328,10 @@ int seq_chain_share(sgm_mat A, double *run)
 }
 
 // ------------------------------------------------------------------ host planning
-// Everything in this section is host-only index work (no HIP call): it is exported so that the
-// CPU test suite drives the SAME code the RCCL path runs (tests/test_dist_cpu.py, world_size-2
-// gloo), and sgm_csr_create_partitioned / sgm_csr_create_dist are both built on it.
-
-// Sorted unique list of the non-owned columns + renumbering to [owned | halo].
-static void halo_plan(int32_t n_own, int64_t col_begin, int64_t nnz, const int32_t *node,
-                      int32_t *node_local, std::vector<int32_t> &halo)
-{
-    const int64_t lo = col_begin + 1, hi = col_begin + n_own;     // owned 1-based range
-    halo.clear();
-    for (int64_t k = 0; k < nnz; ++k) {
-        const int64_t c = node[k];
-        if (c < lo || c > hi) halo.push_back((int32_t)c);
-    }
-    std::sort(halo.begin(), halo.end());
-    halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
-    for (int64_t k = 0; k < nnz; ++k) {
-        const int64_t c = node[k];
-        if (c >= lo && c <= hi) {
-            node_local[k] = (int32_t)(c - col_begin);
-        } else {
-            const auto it = std::lower_bound(halo.begin(), halo.end(), (int32_t)c);
-            node_local[k] = n_own + 1 + (int32_t)(it - halo.begin());
-        }
-    }
-}
-
-static int owner_of(const int64_t *row_starts, int nparts, int64_t col0 /*0-based*/)
-{
-    const int64_t *it = std::upper_bound(row_starts, row_starts + nparts + 1, col0);
-    return (int)(it - row_starts) - 1;
-}
-
-// What one rank asks of the others: want[q] = how many of my halo entries rank q owns (the halo
-// list is sorted, owners are contiguous row blocks, so those entries are the run
-// [want_off[q], want_off[q+1]) of the halo), req[t] = index of halo entry t in ITS OWNER's
-// local numbering (0-based) -- the list the owner gathers from when it sends to me.
-static int dist_plan(int rank, int nranks, const int64_t *row_starts, const std::vector<int32_t> &halo,
-                     std::vector<int32_t> &want, std::vector<int32_t> &want_off, std::vector<int32_t> &req)
-{
-    want.assign((size_t)nranks, 0);
-    want_off.assign((size_t)nranks + 1, 0);
-    req.resize(halo.size());
-    const int64_t ntot = row_starts[nranks];
-    for (size_t t = 0; t < halo.size(); ++t) {
-        const int64_t c0 = (int64_t)halo[t] - 1;
-        if (c0 < 0 || c0 >= ntot) return fail(SGM_ERR_BAD_ARG, "column %lld outside 1..%lld", (long long)halo[t], (long long)ntot);
-        const int q = owner_of(row_starts, nranks, c0);
-        if (q == rank) return fail(SGM_ERR_BAD_ARG, "halo entry %lld is owned by this rank", (long long)halo[t]);
-        want[q]++;
-        req[t] = (int32_t)(c0 - row_starts[q]);
-    }
-    for (int q = 0; q < nranks; ++q) want_off[q + 1] = want_off[q] + want[q];
-    return SGM_OK;
-}
-
-struct NbrPlan { int peer; int32_t send_count, recv_count, recv_offset; };
-// Neighbour table of `rank` from the all-gathered want matrix (row q = rank q's want[]).
-static void dist_neighbors(int rank, int nranks, const int32_t *want_all, std::vector<NbrPlan> &out)
-{
-    out.clear();
-    int32_t off = 0;
-    for (int q = 0; q < nranks; ++q) {
-        const int32_t i_want = want_all[(size_t)rank * nranks + q];       // I receive this many from q
-        const int32_t they_want = want_all[(size_t)q * nranks + rank];    // q receives this many of mine
-        if (q != rank && (i_want || they_want)) out.push_back(NbrPlan{q, they_want, i_want, off});
-        off += i_want;
-    }
-}
-
-// All links of an in-process partition: the same dist_plan, run for every receiver.
-struct Link { int sender, receiver; int32_t recv_offset; std::vector<int32_t> idx; };
-static int partition_links(int nparts, const int64_t *row_starts, const std::vector<std::vector<int32_t>> &halos,
-                           std::vector<Link> &links)
-{
-    links.clear();
-    std::vector<int32_t> want, want_off, req;
-    for (int ip = 0; ip < nparts; ++ip) {
-        SGM_TRY(dist_plan(ip, nparts, row_starts, halos[ip], want, want_off, req));
-        for (int q = 0; q < nparts; ++q) {
-            if (!want[q]) continue;
-            Link l;
-            l.sender = q;
-            l.receiver = ip;
-            l.recv_offset = want_off[q];
-            l.idx.assign(req.begin() + want_off[q], req.begin() + want_off[q + 1]);
-            links.push_back(std::move(l));
-        }
-    }
-    return SGM_OK;
-}
+// The host-only index work (sorted unique halo lists, renumbering, request lists, neighbour tables, links of an in-process
+// partition, the nnz-balanced row split) lives in sgm_plan_host.hpp: plain C++ without a HIP call, exported through the C ABI
+// so that the CPU test suite drives the SAME code the RCCL path runs (tests/test_dist_cpu.py, world_size-2 gloo) -- also under
+// AddressSanitizer / UBSan (tools/asan) -- and sgm_csr_create_partitioned / sgm_csr_create_dist are both built on it.
 
 // frees a half-built matrix (and scratch device buffers) on every early return
 struct MatGuard {
@@ -440,99 +354,28 @@ extern "C" {
 int sgm_halo_plan_host(int32_t n_own, int64_t col_begin, int64_t nnz, const int32_t *node,
                        int32_t *node_local, int32_t *halo_cols, int32_t *n_halo)
 {
-    if (n_own < 0 || nnz < 0 || (nnz && (!node || !node_local)) || !n_halo)
-        return fail(SGM_ERR_BAD_ARG, "sgm_halo_plan_host: bad argument");
-    std::vector<int32_t> halo;
-    halo_plan(n_own, col_begin, nnz, node, node_local, halo);
-    *n_halo = (int32_t)halo.size();
-    if (halo_cols) std::copy(halo.begin(), halo.end(), halo_cols);
-    return SGM_OK;
+    return host_halo_plan_host(n_own, col_begin, nnz, node, node_local, halo_cols, n_halo);
 }
-
 int sgm_dist_plan_host(int32_t rank, int32_t nranks, const int64_t *row_starts, int32_t n_halo,
                        const int32_t *halo_cols, int32_t *want, int32_t *want_off, int32_t *req)
 {
-    if (nranks < 1 || rank < 0 || rank >= nranks || !row_starts || n_halo < 0 || (n_halo && !halo_cols) || !want || !want_off)
-        return fail(SGM_ERR_BAD_ARG, "sgm_dist_plan_host: bad argument");
-    std::vector<int32_t> halo(halo_cols, halo_cols + n_halo), w, wo, r;
-    SGM_TRY(dist_plan(rank, nranks, row_starts, halo, w, wo, r));
-    std::copy(w.begin(), w.end(), want);
-    std::copy(wo.begin(), wo.end(), want_off);
-    if (req) std::copy(r.begin(), r.end(), req);
-    return SGM_OK;
+    return host_dist_plan_host(rank, nranks, row_starts, n_halo, halo_cols, want, want_off, req);
 }
-
 int sgm_dist_neighbors_host(int32_t rank, int32_t nranks, const int32_t *want_all, int32_t *peer,
                             int32_t *send_count, int32_t *recv_count, int32_t *recv_offset, int32_t *n_nbrs)
 {
-    if (nranks < 1 || rank < 0 || rank >= nranks || !want_all || !n_nbrs)
-        return fail(SGM_ERR_BAD_ARG, "sgm_dist_neighbors_host: bad argument");
-    std::vector<NbrPlan> nb;
-    dist_neighbors(rank, nranks, want_all, nb);
-    *n_nbrs = (int32_t)nb.size();
-    for (size_t i = 0; i < nb.size(); ++i) {
-        if (peer) peer[i] = nb[i].peer;
-        if (send_count) send_count[i] = nb[i].send_count;
-        if (recv_count) recv_count[i] = nb[i].recv_count;
-        if (recv_offset) recv_offset[i] = nb[i].recv_offset;
-    }
-    return SGM_OK;
+    return host_dist_neighbors_host(rank, nranks, want_all, peer, send_count, recv_count, recv_offset, n_nbrs);
 }
-
 int sgm_partition_links_host(int32_t nparts, const int64_t *row_starts, const int32_t *ptr, const int32_t *node,
                              int32_t *n_links, int32_t *sender, int32_t *receiver, int32_t *recv_offset,
                              int32_t *count, int32_t *idx_concat, int64_t idx_capacity, int64_t *idx_needed)
 {
-    if (nparts < 1 || !row_starts || !ptr || !n_links) return fail(SGM_ERR_BAD_ARG, "sgm_partition_links_host: bad argument");
-    std::vector<std::vector<int32_t>> halos((size_t)nparts);
-    for (int ip = 0; ip < nparts; ++ip) {
-        const int64_t r0 = row_starts[ip], r1 = row_starts[ip + 1];
-        const int64_t k0 = ptr[r0] - 1, k1 = ptr[r1] - 1;
-        std::vector<int32_t> lnode((size_t)std::max<int64_t>(k1 - k0, 1));
-        halo_plan((int32_t)(r1 - r0), r0, k1 - k0, node + k0, lnode.data(), halos[ip]);
-    }
-    std::vector<Link> links;
-    SGM_TRY(partition_links(nparts, row_starts, halos, links));
-    int64_t total = 0;
-    for (auto &l : links) total += (int64_t)l.idx.size();
-    *n_links = (int32_t)links.size();
-    if (idx_needed) *idx_needed = total;
-    if (!sender) return SGM_OK;                       // sizing call
-    if (idx_concat && idx_capacity < total) return fail(SGM_ERR_BAD_ARG, "sgm_partition_links_host: idx buffer too small");
-    int64_t off = 0;
-    for (size_t i = 0; i < links.size(); ++i) {
-        sender[i] = links[i].sender;
-        if (receiver) receiver[i] = links[i].receiver;
-        if (recv_offset) recv_offset[i] = links[i].recv_offset;
-        if (count) count[i] = (int32_t)links[i].idx.size();
-        if (idx_concat) std::copy(links[i].idx.begin(), links[i].idx.end(), idx_concat + off);
-        off += (int64_t)links[i].idx.size();
-    }
-    return SGM_OK;
+    return host_partition_links_host(nparts, row_starts, ptr, node, n_links, sender, receiver, recv_offset, count, idx_concat,
+                                     idx_capacity, idx_needed);
 }
-
 int sgm_partition_rows_by_nnz(int32_t nrow, const int32_t *ptr, int32_t nparts, int32_t align, int64_t *row_starts)
 {
-    if (nrow < 0 || !ptr || nparts < 1 || !row_starts) return fail(SGM_ERR_BAD_ARG, "sgm_partition_rows_by_nnz: bad argument");
-    if (align < 2) align = 2;                         // 16-byte vector accesses need even row boundaries
-    if (align & 1) align += 1;
-    // weight of the rows [0, r): the bytes of B_csr they account for (12 per entry, 20 per row)
-    auto weight = [&](int64_t r) { return 12 * ((int64_t)ptr[r] - 1) + 20 * r; };
-    const int64_t total = weight(nrow);
-    row_starts[0] = 0;
-    for (int p = 1; p < nparts; ++p) {
-        const int64_t target = total / nparts * p + total % nparts * p / nparts;
-        int64_t lo = row_starts[p - 1], hi = nrow;        // first row whose prefix weight reaches the target
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) / 2;
-            if (weight(mid) < target) lo = mid + 1; else hi = mid;
-        }
-        int64_t r = (lo + align / 2) / align * align;      // nearest multiple of `align`
-        r = std::max<int64_t>(r, row_starts[p - 1]);
-        row_starts[p] = std::min<int64_t>(r, nrow);
-    }
-    row_starts[nparts] = nrow;
-    return SGM_OK;
+    return host_partition_rows_by_nnz(nrow, ptr, nparts, align, row_starts);
 }
 
 int sgm_csr_create_partitioned(sgm_mat *out, int32_t nparts, const int64_t *row_starts, int32_t nrow,

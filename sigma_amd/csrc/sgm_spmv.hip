@@ -25,6 +25,7 @@
 // The x gather is served by L2 (the workgroup -> row-block / slice maps keep neighbouring rows on one
 // XCD).  Algorithmic bytes per SpMV on the reference layout: 12*nnz + 4*(n+1) + 8*m + 8*n.
 #include "sgm_spmv_select.hpp"
+#include "sgm_plan_host.hpp"
 
 namespace sgm {
 
@@ -1309,57 +1310,12 @@ int resident_per_cu(bool dict, int block, int v, int cw)
 }
 
 // ---- slice schedule ---------------------------------------------------------------------------------
-// A 3-D grid's rows reference x a whole plane away (offset +-D, D >> one slice).  With slices handed out round-robin or
-// block-cyclic, the slices D rows apart -- which read the same x lines -- run on different XCDs, so every x line enters
-// three L2s (464^3: slice s and s + 420.5 land 4 XCDs apart).  The schedule cuts the period D into NB bands (NB a multiple
-// of 8, bands of about `slice_sched_band` slices); band(s) = floor(NB * frac((512 s + 256) / D)), XCD x walks bands
-// x, x + 8, ... one after the other, each in ascending slice order: a slice and its +-D neighbours sit one band width apart
-// in the SAME XCD's sequence, inside or next to the window of slices that XCD has in flight.  Workgroup b (XCD b % 8,
-// the hardware's round-robin) takes positions b / 8, b / 8 + grid / 8, ... of its XCD's sequence: tab[it * grid + b].
-// Only the ORDER of whole slices changes: every row is still summed by one lane in stored order.
-static void slice_sched_table(int64_t nsl, int64_t period_rows, int grid, int band_slices, std::vector<int32_t> &tab, int &iters)
-{
-    const double P = (double)period_rows / kSlRows;
-    const int NB = 8 * std::max(1, (int)std::ceil(P / (8.0 * std::max(1, band_slices))));
-    std::vector<int32_t> band((size_t)nsl);
-    std::vector<int64_t> cnt((size_t)NB + 1, 0);
-    for (int64_t sl = 0; sl < nsl; ++sl) {
-        const double t = ((double)sl * kSlRows + kSlRows / 2) / (double)period_rows;
-        int b = (int)((t - std::floor(t)) * NB);
-        b = std::min(std::max(b, 0), NB - 1);
-        band[(size_t)sl] = b;
-        ++cnt[(size_t)b + 1];
-    }
-    // XCD x's sequence = bands x, x + 8, ... end to end; start[b] = position of band b's first slice inside it
-    std::vector<int64_t> start((size_t)NB, 0), len(8, 0);
-    for (int x = 0; x < 8; ++x)
-        for (int b = x; b < NB; b += 8) { start[(size_t)b] = len[x]; len[x] += cnt[(size_t)b + 1]; }
-    const int64_t L = grid / 8;
-    const int64_t longest = *std::max_element(len.begin(), len.end());
-    iters = (int)((longest + L - 1) / L);
-    tab.assign((size_t)iters * grid, -1);
-    for (int64_t sl = 0; sl < nsl; ++sl) {
-        const int b = band[(size_t)sl], x = b & 7;
-        const int64_t q = start[(size_t)b]++;
-        tab[(size_t)((q / L) * grid + (q % L) * 8 + x)] = (int32_t)sl;
-    }
-}
-
+// slice_sched_table (what the schedule is and why: sgm_plan_host.hpp) is host-only index work and lives with the other planners.
+static_assert(kPlanSliceRows == kSlRows, "sgm_plan_host.hpp keeps its own copy of the slice height");
 extern "C" int sgm_slice_sched_host(int64_t n_slices, int64_t period_rows, int32_t grid, int32_t band_slices,
                                     int32_t *tab_out, int64_t capacity, int32_t *iters_out)
 {
-    if (n_slices < 1 || n_slices > INT32_MAX || period_rows < 1 || grid < 8 || grid % 8 || !iters_out)
-        return fail(SGM_ERR_BAD_ARG, "sgm_slice_sched_host: n_slices %lld, period %lld, grid %d (a multiple of 8)",
-                    (long long)n_slices, (long long)period_rows, grid);
-    std::vector<int32_t> tab;
-    int iters = 0;
-    slice_sched_table(n_slices, period_rows, grid, band_slices, tab, iters);
-    *iters_out = iters;
-    if (tab_out) {
-        if (capacity < (int64_t)tab.size()) return fail(SGM_ERR_BAD_ARG, "sgm_slice_sched_host: capacity %lld < %zu", (long long)capacity, tab.size());
-        memcpy(tab_out, tab.data(), tab.size() * sizeof(int32_t));
-    }
-    return SGM_OK;
+    return host_slice_sched_host(n_slices, period_rows, grid, band_slices, tab_out, capacity, iters_out);
 }
 
 // the schedule of one row range of a part (built and uploaded on first use), or null: no far offset, option off,

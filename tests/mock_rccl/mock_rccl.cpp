@@ -16,6 +16,25 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+// The few device operations the transport needs, in one place.  -DMOCK_RCCL_HOST_ONLY (tools/asan: the AddressSanitizer /
+// UBSan build, run on a CPU box by tests/test_asan_cpu.py) makes "device" buffers plain host memory, so that the rings, the
+// barrier and the collectives -- the index work of this file -- run as several processes without a GPU.
+#ifdef MOCK_RCCL_HOST_ONLY
+#include <cstdlib>
+#include <cstring>
+static inline hipError_t dev_sync(hipStream_t) { return hipSuccess; }
+static inline hipError_t dev_copy(void *dst, const void *src, size_t n, hipMemcpyKind) { memcpy(dst, src, n); return hipSuccess; }
+static inline hipError_t dev_copy_async(void *dst, const void *src, size_t n, hipMemcpyKind, hipStream_t) { memcpy(dst, src, n); return hipSuccess; }
+static inline hipError_t pinned_alloc(void **p, size_t n) { *p = malloc(n); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline void pinned_free(void *p) { free(p); }
+#else
+static inline hipError_t dev_sync(hipStream_t st) { return hipStreamSynchronize(st); }
+static inline hipError_t dev_copy(void *dst, const void *src, size_t n, hipMemcpyKind k) { return hipMemcpy(dst, src, n, k); }
+static inline hipError_t dev_copy_async(void *dst, const void *src, size_t n, hipMemcpyKind k, hipStream_t st) { return hipMemcpyAsync(dst, src, n, k, st); }
+static inline hipError_t pinned_alloc(void **p, size_t n) { return hipHostMalloc(p, n); }
+static inline void pinned_free(void *p) { (void)hipHostFree(p); }
+#endif
+
 #include <fcntl.h>
 #include <sched.h>
 #include <sys/mman.h>
@@ -34,16 +53,16 @@ constexpr size_t kColl = 1u << 16;       // bytes per rank for all-reduce / all-
 constexpr int kMaxRanks = 16;
 constexpr double kTimeoutS = 120.0;
 
-struct Ring {
+struct alignas(64) Ring {
     std::atomic<uint64_t> head, tail;    // bytes written / read so far
-    char buf[kRing];
+    alignas(64) char buf[kRing];
 };
 struct Shared {
     std::atomic<int> attached;
     std::atomic<int> bar_count, bar_gen;
-    char pad[64];
-    char coll[kMaxRanks][kColl];
-    Ring ring[1];                        // nranks * nranks
+    // (64-byte aligned: the reduction reads these slots as doubles -- UBSan found them at offset 76 of the segment, tools/asan)
+    alignas(64) char coll[kMaxRanks][kColl];
+    alignas(64) Ring ring[1];            // nranks * nranks
 };
 
 struct Comm {
@@ -74,7 +93,7 @@ double now()
 
 void reap()
 {
-    for (auto &g : g_graveyard) { (void)hipStreamSynchronize(g.st); (void)hipHostFree(g.p); }
+    for (auto &g : g_graveyard) { (void)dev_sync(g.st); pinned_free(g.p); }
     g_graveyard.clear();
 }
 
@@ -125,10 +144,10 @@ ncclResult_t run_ops()
     if (g_ops.empty()) return ncclSuccess;
     maybe_stall(g_ops[0].c->rank);
     reap();
-    for (auto &o : g_ops) if (hipStreamSynchronize(o.st) != hipSuccess) return ncclUnhandledCudaError;
+    for (auto &o : g_ops) if (dev_sync(o.st) != hipSuccess) return ncclUnhandledCudaError;
     for (auto &o : g_ops) {
-        if (hipHostMalloc((void **)&o.host, o.bytes ? o.bytes : 1) != hipSuccess) return ncclSystemError;
-        if (o.send && o.bytes && hipMemcpy(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+        if (pinned_alloc((void **)&o.host, o.bytes ? o.bytes : 1) != hipSuccess) return ncclSystemError;
+        if (o.send && o.bytes && dev_copy(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
     }
     const double t0 = now();
     for (;;) {
@@ -165,7 +184,7 @@ ncclResult_t run_ops()
         }
     }
     for (auto &o : g_ops) {
-        if (!o.send && o.bytes && hipMemcpyAsync(o.dev, o.host, o.bytes, hipMemcpyHostToDevice, o.st) != hipSuccess)
+        if (!o.send && o.bytes && dev_copy_async(o.dev, o.host, o.bytes, hipMemcpyHostToDevice, o.st) != hipSuccess)
             return ncclUnhandledCudaError;
         g_graveyard.push_back(Pinned{o.host, o.st});
     }
@@ -269,12 +288,12 @@ static ncclResult_t collective(const void *send, void *recv, size_t bytes_each, 
 {
     if (bytes_each > kColl || (reduce_f64 && bytes_each % 8)) return ncclInvalidArgument;
     reap();
-    if (hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;
-    if (bytes_each && hipMemcpy(c->sh->coll[c->rank], send, bytes_each, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+    if (dev_sync(st) != hipSuccess) return ncclUnhandledCudaError;
+    if (bytes_each && dev_copy(c->sh->coll[c->rank], send, bytes_each, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
     if (!barrier(c)) return ncclSystemError;
     const size_t out_bytes = reduce_f64 ? bytes_each : bytes_each * c->n;
     char *host = nullptr;
-    if (hipHostMalloc((void **)&host, out_bytes ? out_bytes : 1) != hipSuccess) return ncclSystemError;
+    if (pinned_alloc((void **)&host, out_bytes ? out_bytes : 1) != hipSuccess) return ncclSystemError;
     if (reduce_f64) {
         double *o = (double *)host;
         for (size_t i = 0; i < bytes_each / 8; ++i) {
@@ -286,7 +305,7 @@ static ncclResult_t collective(const void *send, void *recv, size_t bytes_each, 
         for (int r = 0; r < c->n; ++r) memcpy(host + (size_t)r * bytes_each, c->sh->coll[r], bytes_each);
     }
     if (!barrier(c)) return ncclSystemError;        // nobody overwrites a slot that is still being read
-    if (out_bytes && hipMemcpyAsync(recv, host, out_bytes, hipMemcpyHostToDevice, st) != hipSuccess) return ncclUnhandledCudaError;
+    if (out_bytes && dev_copy_async(recv, host, out_bytes, hipMemcpyHostToDevice, st) != hipSuccess) return ncclUnhandledCudaError;
     g_graveyard.push_back(Pinned{host, st});
     return ncclSuccess;
 }
