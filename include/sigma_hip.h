@@ -88,8 +88,9 @@ int sgm_synchronize(void);
  *                          LDS read, instead of one 128-byte line moved L2 -> L1 per 8-byte gather; 0 = gathers from L2
  *   "csr_lean" (1)         a matrix served by the sliced / SELL form keeps ONLY that form (+ row pointers) in HBM (C2: 0.48
  *                          instead of 1.13 GB); its CSR-order arrays are rebuilt on the device for whoever reads them
- *   "ell_colblock" (1)     ELLPACK matrices whose columns have no locality (x >= 16 MB, >= 8 slots per row): column-blocked
- *                          two-phase product (products through LDS-resident x blocks, then ordered row sums); 0 never, 2 always
+ *   "ell_colblock" (1)     ELLPACK matrices -- and CSR matrices with rows of similar length -- whose columns have no locality
+ *                          (x >= 7 MiB, >= 8 slots per row, no offset dictionary): column-blocked two-phase product (products
+ *                          through LDS-resident x blocks, then ordered row sums); 0 never, 2 always
  *   "ell_colblock_cols" (16384 = 128 KiB of LDS, the maximum)  x entries per block
  *   "ell_colblock_rows" (0 = automatic; 256 or 512)  rows per tile of the second phase
  *   "coloring_pass" (0)    sgm_graph_greedy_coloring / _greedy_color_order on this matrix's graph: 0 = the fastest pass that
@@ -254,8 +255,10 @@ int sgm_mat_info(sgm_mat A, int32_t *nrow, int32_t *ncol, int64_t *nnz, int32_t 
  *                              fails where the reference would index out of bounds (a vertex
  *                              not reachable from vertex 1)
  * Outputs are HOST arrays of nrow int32 (1-based values, like the reference's).  The
- * breadth-first numbering runs on the device (level-synchronous, same FIFO order); the colouring
- * is order- and tally-dependent and runs on the host over a copy of the index arrays.
+ * breadth-first numbering runs on the device (level-synchronous, same FIFO order); so does the
+ * colouring (option "coloring_pass": parities by union-find for a bipartite graph, else a level sweep
+ * that reproduces the sequential pass's order- and tally-dependent choices; the reference's own
+ * sequential pass on the host is the last resort and the checker) -- the same colours whichever.
  * sgm_mat_left_permute(A, p)   A%left_permute(p)   cs_matrices.f90:471-478: row i -> row p(i)
  * sgm_mat_right_permute(A, p)  A%right_permute(p)  cs_matrices.f90:483-490: column j -> p(j)
  *                              (ELLPACK handles too: ellpack_matrices.f90:601-632)
@@ -320,8 +323,10 @@ int sgm_pc_destroy(sgm_pc pc);
 /* ---- solvers ------------------------------------------------------------------------ *
  * sgm_cg_create       <- cg(tolerance)            src/solver/cg_solvers.f90:36-47
  * sgm_bicgstab_create <- bicgstab(tolerance)      src/solver/bicgstab_solvers.f90:37-48
- * sgm_gmres_create    <- NO reference counterpart; GMRES(restart), MGS Arnoldi,
- *                        same tolerance / iterations conventions as cg
+ * sgm_gmres_create    <- NO reference counterpart; GMRES(restart), Arnoldi by low-synchronisation
+ *                        classical Gram-Schmidt with re-orthogonalisation (CGS-2: the basis read twice, two
+ *                        reductions per step; option "gmres_cgs2" = 0: modified Gram-Schmidt), Givens
+ *                        rotations; same tolerance / iterations conventions as cg
  * sgm_solver_setup    <- solver%setup(A): square check, work vectors, iterations = 0
  *                        cg_solvers.f90:52-90
  * sgm_solver_solve    <- solver%solve(A,x,b[,pc]): cg_solve :116-150, cg_solve_pc :155-194,

@@ -16,6 +16,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <mutex>
 #include <chrono>
 
 namespace sgm {
@@ -215,11 +216,20 @@ int g_force_collectives = 0;
 // In-process parts: the device table of the parts' slot pointers, one per distinct set of pointers (a solver's slot arrays
 // never move while it lives, so a solve uploads each of its few tables once and no call waits for the host afterwards).
 // A table is found again only by EXACTLY the pointers it holds, so a recycled address can never name a stale table.
+// While the launch stream is being captured (GraphBatch::ensure) nothing here may allocate, copy or synchronise: a table that
+// is not there yet is refused (the capture is given up and the solve stays on the launch loop -- in practice the 64+ launched
+// iterations in front of the first capture have uploaded every table a replay needs), and the cache is never flushed.
 static int slot_table(double *const *slot_ptrs, size_t P, double ***out)
 {
+    static std::mutex mu;
     static std::vector<std::pair<std::vector<double *>, double **>> tabs;
+    std::lock_guard<std::mutex> lock(mu);
     for (auto &t : tabs)
         if (t.first.size() == P && std::equal(t.first.begin(), t.first.end(), slot_ptrs)) { *out = t.second; return SGM_OK; }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(g_rt.stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    if (cs != hipStreamCaptureStatusNone)
+        return fail(SGM_ERR_UNSUPPORTED, "slot_table: a table of %zu slot pointers is missing while the stream is being captured", P);
     if (tabs.size() >= 256) {                    // (solvers come and go: start over rather than grow without bound)
         SGM_HIP(hipStreamSynchronize(g_rt.stream));
         for (auto &t : tabs) dfree(t.second);

@@ -2906,7 +2906,8 @@ static int pc_setup_ordered(sgm_pc pc, sgm_mat A)
             // factored on the HOST instead, one after the other in natural order (row i reads rows k < i only: the reference's own
             // loop order), by the very statements of k_ildu_factor_level, and the values go back: two copies and ~0.1 us per row.
             const size_t nlev = flp.size() - 1;
-            host_factor = nlev > 4096 && (int64_t)nlev * 8 > (int64_t)n;
+            // (short rows only -- the host loop is O(len^3) per row and single-threaded: a chain of WIDE rows stays on the device)
+            host_factor = nlev > 4096 && (int64_t)nlev * 8 > (int64_t)n && S->maxL + S->maxU <= 16;
             if (host_factor) {
                 std::vector<int32_t> hLp((size_t)n + 1), hUp((size_t)n + 1), hLn((size_t)std::max(S->nnzL, 1)), hUn((size_t)std::max(S->nnzU, 1));
                 std::vector<double> hLv((size_t)std::max(S->nnzL, 1)), hUv((size_t)std::max(S->nnzU, 1)), hD((size_t)n);

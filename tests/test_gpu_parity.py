@@ -1491,6 +1491,38 @@ def test_ildu_on_ellpack_operands_vs_oracle(orc, kind, dot_order_1):
         assert np.array_equal(u, orc.cg(E, b, tol=1e-12, pc=ref)[0])
 
 
+@pytest.mark.parametrize("offsets", [(1,), (1, 7), (1, 2, 3, 4), tuple(range(1, 13))])
+def test_chain_factors_host_and_device_paths_agree_with_the_oracle(orc, offsets):
+    """A factor that is one dependency chain (a band with its first off-diagonal: thousands of levels of one row) is factored
+    row by row on the HOST when its rows are short (maxL + maxU <= 16), by one launch per level on the device otherwise -- two
+    implementations of sparse_static_pattern_ldu_factorization (ldu_solvers.f90:275-387) beside the register variant for rows
+    <= 4 + 4.  All of them against the oracle's, np.array_equal: (1,) and (1, 7) take the host loop, (1..4) the host loop with
+    longer rows, (1..12) the device's general kernel on 5000 levels.  (host / device agreement.)"""
+    n = 5000
+    rs = np.random.RandomState(len(offsets))
+    i = np.concatenate([np.arange(n - o) for o in offsets] + [np.arange(o, n) for o in offsets] + [np.arange(n)])
+    j = np.concatenate([np.arange(o, n) for o in offsets] + [np.arange(n - o) for o in offsets] + [np.arange(n)])
+    v = np.where(i == j, 2.0 * len(offsets) + 1.0, -1.0) * rs.uniform(0.9, 1.1, i.size)
+    o = np.lexsort((j, i))
+    i, j, v = i[o], j[o], v[o]
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(i, minlength=n))]).astype(np.int32) + 1
+    A = orc.CsrMatrix(n, n, ptr, (j + 1).astype(np.int32), v)
+    ref = orc.Ildu(A)
+    H = hip_from_oracle(A)
+    pc = sg.ldu()
+    pc.setup(H)
+    assert pc.info()["levels"][0] == n
+    for nm, dt, want in (("Lptr", np.int32, ref.Lptr), ("Lnode", np.int32, ref.Lnode), ("Uptr", np.int32, ref.Uptr),
+                         ("Unode", np.int32, ref.Unode), ("Lval", np.float64, ref.Lval), ("Uval", np.float64, ref.Uval),
+                         ("D", np.float64, ref.D)):
+        got = pc.get(nm, dt)
+        assert np.array_equal(got, want[:got.size]), (offsets, nm)
+    b = P.test_vector(n)
+    z = np.zeros(n)
+    pc.solve(H, z, b)
+    assert np.array_equal(z, ref.solve(b))
+
+
 def test_ildu_apply_many_levels_vs_oracle(orc):
     """5-point grid 300x200: 499 dependency levels, wide and narrow level runs."""
     ptr, node, val = P.poisson2d_csr(300, 200)
