@@ -3243,9 +3243,17 @@ def test_partitioned_overlap_split_bit_exact(orc, dict_opt):
         sg.set_option("csr_offset_dict", 1)
 
 
-def test_rccl_single_rank(orc):
-    """RCCL binding with a 1-rank communicator: bootstrap, distributed create, matvec, CG."""
+@pytest.fixture(scope="module")
+def one_rank_comm():
+    """ONE communicator of the real librccl (one rank) for the tests of this module that need the RCCL code path."""
     comm = sg.Comm(0, 1, sg.Comm.unique_id())
+    yield comm
+    comm.destroy()
+
+
+def test_rccl_single_rank(orc, one_rank_comm):
+    """RCCL binding with a 1-rank communicator: bootstrap, distributed create, matvec, CG."""
+    comm = one_rank_comm
     ptr, node, val = P.poisson2d_csr(48, 40)
     n = 1920
     A = orc.CsrMatrix(n, n, ptr, node, val)
@@ -3268,7 +3276,47 @@ def test_rccl_single_rank(orc):
     got, summed, us = comm.group_selftest()
     assert got == 42.0 and summed == 1.0, (got, summed)
     print(f"librccl: group of send / recv + all-reduce on one rank: {us:.1f} us")
-    comm.destroy()
+
+
+@pytest.mark.parametrize("solver,pck", [("cg", "none"), ("cg", "jacobi"), ("bicgstab", "none")])
+def test_one_gpu_solve_equals_the_rccl_path_with_one_rank_bit_for_bit(orc, solver, pck, one_rank_comm):
+    """From n = 2^21 rows on, a one-GPU CG / BiCGStab keeps every dot as ONE reduced scalar made by a one-block launch
+    (k_reduce_set) and replays captured groups of iterations; the RCCL code path with one rank collapses the same partial sums
+    with k_reduce (+ an all-reduce one rank skips), forms p's halo locally and never replays.  Same system through both:
+    residual history and solution BIT FOR BIT over 112 iterations.  (Also the A/B harness of round 6's rejected "last workgroup
+    collapses the partials" variant, profiles/r06/tail_collapse_ab.txt: it left these bits and lost 2-3 % of the iterations/s.)"""
+    nx = ny = 1500
+    n = nx * ny
+    assert n >= 1 << 21
+    ptr, node, val = P.poisson2d_csr(nx, ny)
+    if solver == "bicgstab":                      # a nonsymmetric perturbation of the stencil
+        rows = np.repeat(np.arange(1, n + 1), np.diff(ptr))
+        val = val + 0.05 * np.sign(node - rows)
+    b = P.test_vector(n)
+    comm = one_rank_comm
+    mats = {"one_gpu": sg.csr_matrix(n, n, ptr, node, val), "rccl_one_rank": sg.dist_csr_matrix(comm, np.array([0, n]), ptr, node, val)}
+    got = {}
+    for name, H in mats.items():
+        assert "k_csr_sl<W=5>" in H.kernel
+        s = (sg.cg if solver == "cg" else sg.bicgstab)(1e-300)
+        s.set_max_iter(112)
+        s.set_history(200)
+        s.setup(H)
+        pc = None
+        if pck == "jacobi":
+            pc = sg.jacobi()
+            pc.setup(H)
+        u = np.zeros(n)
+        s.solve(H, u, b, pc, check=False)
+        got[name] = (u, np.array(s.history), s.res2, s.last_iterations)
+        s.destroy()
+        if pc is not None:
+            pc.destroy()
+        H.destroy()
+    (ua, ha, ra, ia), (ub, hb, rb, ib) = got["one_gpu"], got["rccl_one_rank"]
+    assert ia == ib == 112 and len(ha) == 112
+    assert np.array_equal(ha, hb) and ra == rb and np.array_equal(ua, ub), float(np.abs(ha - hb).max())
+    assert np.all(np.isfinite(ha)) and ha[-1] < ha[0]
 
 
 # ------------------------------------------------------- full benchmark size (BASELINE C2)
