@@ -455,6 +455,13 @@ int sgm_solver_solve(sgm_solver s, sgm_mat A, double *x, const double *b, sgm_pc
     }
     SGM_TRY(stage_out(sx, x, nvec, where));
     SGM_TRY(finish());
+    // SGM_TRACE: a CG solve past n / 2 iterations is in the regime where the ORDER of the dot products decides the count (the
+    // short recurrence has lost its orthogonality to rounding: INTEGRATION.md, "Which parity gate each dot order meets") --
+    // say which switch reproduces the CPU build's count before anyone compares the two numbers
+    if (trace_on() && s->kind == SGM_SOLVER_CG && !s->seq && s->last_iterations > (int64_t)s->nn / 2)
+        fprintf(stderr, "[sigma_hip] cg: %lld iterations on %d rows (> n / 2) with tree-order dot products; validation against the CPU "
+                        "build's iteration count: option dot_order = 1 (the reference's summation order, bit-identical iterates)\n",
+                (long long)s->last_iterations, (int)s->nn);
     if (s->max_iter > 0 && !s->converged) {
         if (s->res2 != s->res2) fail(SGM_ERR_NOT_CONVERGED, "solver broke down after %lld iterations (res2 is NaN)", (long long)s->last_iterations);
         else fail(SGM_ERR_NOT_CONVERGED, "solver stopped at max_iter=%lld with sqrt(res2)=%g > %g",
