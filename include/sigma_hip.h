@@ -314,7 +314,8 @@ int sgm_pc_get(sgm_pc pc, const char *name, void *out_host, size_t bytes, size_t
  * correct, the reference's semantics, and 50-100 x below the HBM roofline.  This says so BEFORE the solve:
  *   out4[0], out4[1]  dependency levels of L, of U        out4[2]  path: 0 diagonal scaling, 1 row-space sweeps (bandwidth-
  *   bound), 2 strip pipeline, 3 slab pipeline, 4 level walkers        out4[3]  colours of the ordering (0 = A's own order)
- *   est_us  estimated microseconds per apply               path_name  e.g. "strip pipeline, 6323 levels", "row space, 2 levels"
+ *   est_us  estimated microseconds per apply               path_name  e.g. "strip pipeline, 6323 levels", "row space, 2 levels";
+ *   with a colour ordering, followed by "; product of the ordered part: k_csr_sl<W=5>" -- the SpMV kernel of the permuted copy
  * With SGM_TRACE set every sgm_pc_setup prints the same line on stderr.  The remedy for a chain: ldu(reorder = "colour")
  * (option "ildu_reorder"), INTEGRATION.md. */
 int sgm_pc_info(sgm_pc pc, int32_t part, int32_t *out4, double *est_us, char *path_name, int len);

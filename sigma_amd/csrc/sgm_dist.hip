@@ -317,6 +317,44 @@ int halo_exchange_allreduce(sgm_mat A, double *const *uext, double *const *slot_
     return SGM_OK;
 }
 
+// ------------------------------------------------------------------ re-ordered halo slots (colour-ordered parts, sgm_pc.hip)
+// A receiver that re-orders the slots of its halo (halo_attach_order) tells every sender where entry j of their link goes:
+// out[k][j] = new position (relative to the link's first slot) of entry j this rank sends to nbrs[k].peer.  One grouped
+// send / recv of int32 lists over the communicator the halo itself travels on; collective over the ranks (every rank sets its
+// preconditioner up).
+int exchange_halo_orders(sgm_mat A, const std::vector<int32_t> &mine, std::vector<int32_t *> &out)
+{
+    Part &p = A->parts[0];
+    out.assign(p.nbrs.size(), nullptr);
+    if (!A->comm || p.nbrs.empty()) return SGM_OK;
+    hipStream_t st = g_rt.stream;
+    ncclComm_t comm = (ncclComm_t)(A->comm->nccl_halo ? A->comm->nccl_halo : A->comm->nccl);
+    std::vector<int32_t *> give(p.nbrs.size(), nullptr);
+    struct Tmp { std::vector<int32_t *> &v; ~Tmp() { for (int32_t *q : v) dfree(q); } } tmp{give};
+    for (size_t k = 0; k < p.nbrs.size(); ++k) {
+        const HaloNbr &nb = p.nbrs[k];
+        if (nb.recv_count) {
+            std::vector<int32_t> rel((size_t)nb.recv_count);
+            for (int32_t t = 0; t < nb.recv_count; ++t) rel[(size_t)t] = mine[(size_t)nb.recv_offset + t] - nb.recv_offset;
+            SGM_TRY(dalloc(&give[k], (size_t)nb.recv_count));
+            SGM_HIP(hipMemcpy(give[k], rel.data(), (size_t)nb.recv_count * 4, hipMemcpyHostToDevice));
+        }
+        if (nb.send_count) SGM_TRY(dalloc(&out[k], (size_t)nb.send_count));
+    }
+    const int hb_prev = g_hb.phase;
+    hb_phase(HB_HALO_POST);
+    SGM_NCCL(g_nccl.GroupStart());
+    for (size_t k = 0; k < p.nbrs.size(); ++k) {
+        const HaloNbr &nb = p.nbrs[k];
+        if (nb.recv_count) SGM_NCCL(g_nccl.Send(give[k], (size_t)nb.recv_count, ncclInt32, nb.peer, comm, st));
+        if (nb.send_count) SGM_NCCL(g_nccl.Recv(out[k], (size_t)nb.send_count, ncclInt32, nb.peer, comm, st));
+    }
+    SGM_NCCL(g_nccl.GroupEnd());
+    SGM_HIP(hipStreamSynchronize(st));
+    hb_phase(hb_prev);
+    return SGM_OK;
+}
+
 // ------------------------------------------------------------------ dot_order = 1 across ranks
 int seq_chain_recv(sgm_mat A, double *run)
 {

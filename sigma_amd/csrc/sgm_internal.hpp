@@ -9,6 +9,7 @@
 #include <cstring>
 #include <string>
 #include <atomic>
+#include <utility>
 #include <vector>
 
 #include "../../include/sigma_hip.h"
@@ -326,7 +327,16 @@ int diag_block_plain(const Part &p, sgm_mat *out);
 // (sgm_order.hip) q = the row block p with row i moved to row p1(i), its owned columns renumbered by p1 (1-based, device) and
 // its halo columns as they are; stored order inside the rows kept; p's kernel forms (options) and halo links (the sender's
 // row numbers mapped through p1).  No interior range: a product on q runs after its halo has arrived.
-int permuted_part(const Part &p, const int32_t *p1_dev, Part &q);
+void part_kernel_name(const Part &p, int fmt, char *name, size_t len);       // (sgm_mat.hip) the SpMV kernel a part runs with
+int permuted_part(const Part &p, const int32_t *p1_dev, Part &q, const int32_t *hmap_dev = nullptr,
+                  const std::vector<int32_t *> *send_order = nullptr);
+// (sgm_order.hip) hmap: old halo slot -> new, the slots of every neighbour's segment (offset, count) ordered by the permuted index
+// of the row they attach to; send_order[k] (device, one per entry of p.nbrs): where entry j of that link goes in the receiver's halo
+int halo_attach_order(const Part &p, const int32_t *p1_dev, const std::vector<std::pair<int32_t, int32_t>> &segments,
+                      std::vector<int32_t> &hmap_host);
+// (sgm_dist.hip) ranks: every receiver tells each sender the order it wants that link's entries in (one grouped send / recv of
+// int32 lists); `mine` = this rank's hmap (host); out[k] = device list for nbrs[k] (null where nothing is sent)
+int exchange_halo_orders(sgm_mat A, const std::vector<int32_t> &mine, std::vector<int32_t *> &out);
 int spmv_grid(const Part &p, bool whole = false);      // whole: the product launched with halo_ready (one range)
 int matvec_plain(sgm_mat A, const double *x, double *y);     // device vectors, sgm_mat_matvec's layout, stream-ordered
 // "csr_lean": the CSR-order arrays of a part that kept only its sliced form, on demand (no-op otherwise)

@@ -610,29 +610,36 @@ int sgm_mat_info(sgm_mat A, int32_t *nrow, int32_t *ncol, int64_t *nnz, int32_t 
     return SGM_OK;
 }
 
+}  // extern "C"
+namespace sgm {
+// name of the SpMV kernel one part of a CSR / ELLPACK matrix runs with under its current options
+void part_kernel_name(const Part &p, int fmt, char *name, size_t len)
+{
+    if (fmt == SGM_FMT_ELL) {
+        if (use_ell_colblock(p)) snprintf(name, len, "k_ellcb<cols=%d,R=%d>", p.cb_cols, p.cb_R);
+        else if (use_sliced_ell(p)) snprintf(name, len, "k_csr_sl<W=%d>", p.sw);
+        else if (p.ecode && p.opt.ell_offset_dict) snprintf(name, len, "k_ell_do<MDP=%d>", p.emdp);
+        else snprintf(name, len, "k_ell_spmv");
+    } else if (use_ell_colblock(p)) snprintf(name, len, "k_ellcb<cols=%d,R=%d,csr>", p.cb_cols, p.cb_R);
+    else if (use_sliced(p)) snprintf(name, len, "k_csr_sl<W=%d>", p.sw);
+    else if (use_slicedb(p)) snprintf(name, len, "k_csr_slb<W=%d>", p.sw);
+    else if (use_sliced32(p)) snprintf(name, len, "k_csr_sl32<W=%d>", p.sw);
+    else if (use_sell(p)) snprintf(name, len, p.sl_win0 && p.opt.csr_xwindow ? "k_csr_sell<pad=%.3f,xw=%dx%d>" : "k_csr_sell<pad=%.3f>",
+                                   p.nnz ? (double)p.sl_total / (double)p.nnz : 1.0, p.sl_span, p.sl_gs);
+    else if (use_offset_dict(p)) snprintf(name, len, "k_csr_do<256,%d,CW=1>", do_tile_for(p));
+    else if (use_row_owner(p)) snprintf(name, len, "k_csr_do<256,%d,CW=4>", do_tile_for(p));
+    else if (use_row_lines(p)) snprintf(name, len, "k_csr_rl");
+    else snprintf(name, len, "k_csr_spmv");
+}
+}  // namespace sgm
+extern "C" {
+
 int sgm_mat_kernel(sgm_mat A, char *buf, int len)
 {
     if (!A || !buf || len < 1) return fail(SGM_ERR_BAD_ARG, "sgm_mat_kernel: bad argument");
     char name[64];
     if (A->fmt == SGM_FMT_COMPOSITE) snprintf(name, sizeof name, "composite");
-    else {
-        const Part &p = A->parts[0];
-        if (A->fmt == SGM_FMT_ELL) {
-            if (use_ell_colblock(p)) snprintf(name, sizeof name, "k_ellcb<cols=%d,R=%d>", p.cb_cols, p.cb_R);
-            else if (use_sliced_ell(p)) snprintf(name, sizeof name, "k_csr_sl<W=%d>", p.sw);
-            else if (p.ecode && p.opt.ell_offset_dict) snprintf(name, sizeof name, "k_ell_do<MDP=%d>", p.emdp);
-            else snprintf(name, sizeof name, "k_ell_spmv");
-        } else if (use_ell_colblock(p)) snprintf(name, sizeof name, "k_ellcb<cols=%d,R=%d,csr>", p.cb_cols, p.cb_R);
-        else if (use_sliced(p)) snprintf(name, sizeof name, "k_csr_sl<W=%d>", p.sw);
-        else if (use_slicedb(p)) snprintf(name, sizeof name, "k_csr_slb<W=%d>", p.sw);
-        else if (use_sliced32(p)) snprintf(name, sizeof name, "k_csr_sl32<W=%d>", p.sw);
-        else if (use_sell(p)) snprintf(name, sizeof name, p.sl_win0 && p.opt.csr_xwindow ? "k_csr_sell<pad=%.3f,xw=%dx%d>" : "k_csr_sell<pad=%.3f>",
-                                       p.nnz ? (double)p.sl_total / (double)p.nnz : 1.0, p.sl_span, p.sl_gs);
-        else if (use_offset_dict(p)) snprintf(name, sizeof name, "k_csr_do<256,%d,CW=1>", do_tile_for(p));
-        else if (use_row_owner(p)) snprintf(name, sizeof name, "k_csr_do<256,%d,CW=4>", do_tile_for(p));
-        else if (use_row_lines(p)) snprintf(name, sizeof name, "k_csr_rl");
-        else snprintf(name, sizeof name, "k_csr_spmv");
-    }
+    else part_kernel_name(A->parts[0], A->fmt, name, sizeof name);
     snprintf(buf, (size_t)len, "%s", name);
     return SGM_OK;
 }

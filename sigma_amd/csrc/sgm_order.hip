@@ -491,6 +491,30 @@ __global__ void k_map_idx(int32_t count, const int32_t *__restrict__ src, const 
     const int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < count) dst[j] = p1[src[j]] - 1;
 }
+// ... into the slot the receiver's re-ordered halo gives entry j of the link (order[j], halo_attach_order below)
+__global__ void k_map_idx_ordered(int32_t count, const int32_t *__restrict__ src, const int32_t *__restrict__ p1,
+                                  const int32_t *__restrict__ order, int32_t *__restrict__ dst)
+{
+    const int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < count) dst[order[j]] = p1[src[j]] - 1;
+}
+// halo columns of a permuted part renumbered: slot h -> hmap[h]
+__global__ void k_remap_halo_cols(int64_t nnz, int32_t own, int32_t *__restrict__ col, const int32_t *__restrict__ hmap)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; k < nnz; k += stride) { const int32_t c = col[k]; if (c >= own) col[k] = own + hmap[c - own]; }
+}
+// key[h] = the smallest PERMUTED index of a row that references halo slot h (INT32_MAX: no row does)
+__global__ void k_halo_attach_key(int32_t n, int32_t own, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                  const int32_t *__restrict__ p1, int32_t *__restrict__ key)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = p1[i] - 1;
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
+        if (col[k] >= own) atomicMin(key + (col[k] - own), r);
+}
 // exclusive scan of n + 1 int32 counts in place
 int scan_counts(int32_t *a, int32_t n1)
 {
@@ -543,7 +567,7 @@ int diag_block_plain(const Part &p, sgm_mat *out)
     return SGM_OK;
 }
 
-int permuted_part(const Part &p, const int32_t *p1, Part &q)
+int permuted_part(const Part &p, const int32_t *p1, Part &q, const int32_t *hmap, const std::vector<int32_t *> *send_order)
 {
     SGM_TRY(csr_need_arrays(p));
     struct Release { const Part &p; ~Release() { csr_release_arrays(p); } } rel{p};
@@ -570,6 +594,9 @@ int permuted_part(const Part &p, const int32_t *p1, Part &q)
                               q.col, q.val);
     if (p.nnz) hipLaunchKernelGGL(k_perm_cols_own, dim3(vec_grid(p.nnz)), dim3(kBlock), 0, st, p.nnz, p.n_halo == 0 ? INT32_MAX : p.ncol_own,
                                   q.col, p1);
+    // the halo slots in the order of the permuted rows they attach to (halo_attach_order): a stencil's halo columns are then a
+    // constant offset away from their rows again, and the part keeps the 4-bit dictionary form in the permuted order
+    if (hmap && p.n_halo > 0 && p.nnz) hipLaunchKernelGGL(k_remap_halo_cols, dim3(vec_grid(p.nnz)), dim3(kBlock), 0, st, p.nnz, p.ncol_own, q.col, hmap);
     if (p.edeg) {                  // ELLPACK rows over ranks: the degrees follow their rows (the entries of a row keep their stored order)
         SGM_TRY(dalloc(&q.edeg, (size_t)std::max(n, 1)));
         if (n) hipLaunchKernelGGL(k_perm_degrees, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, (const int32_t *)p.edeg, p1, q.edeg);
@@ -578,20 +605,61 @@ int permuted_part(const Part &p, const int32_t *p1, Part &q)
     SGM_HIP(hipStreamSynchronize(st));
     SGM_TRY(rebuild_csr_formats(q));
     if (p.xext) SGM_TRY(dalloc(&q.xext, (size_t)q.xlen()));
+    size_t inb = 0;
     for (const HaloNbr &nb : p.nbrs) {
         HaloNbr m = nb;
         m.send_idx = nullptr; m.send_buf = nullptr;
         q.nbrs.push_back(m);                              // (owned by q from here on: free_part releases what follows)
         HaloNbr &o = q.nbrs.back();
+        const int32_t *ord = send_order && inb < send_order->size() ? (*send_order)[inb] : nullptr;
+        ++inb;
         if (nb.send_idx) {
             SGM_TRY(dalloc(&o.send_idx, (size_t)std::max(nb.send_count, 1)));
-            if (nb.send_count) hipLaunchKernelGGL(k_map_idx, dim3((nb.send_count + kBlock - 1) / kBlock), dim3(kBlock), 0, st, nb.send_count,
-                                                  (const int32_t *)nb.send_idx, p1, o.send_idx);
+            const dim3 g((nb.send_count + kBlock - 1) / kBlock);
+            if (nb.send_count && ord)        // the receiver re-ordered its halo: entry j of the link goes to its slot ord[j]
+                hipLaunchKernelGGL(k_map_idx_ordered, g, dim3(kBlock), 0, st, nb.send_count, (const int32_t *)nb.send_idx, p1, ord, o.send_idx);
+            else if (nb.send_count)
+                hipLaunchKernelGGL(k_map_idx, g, dim3(kBlock), 0, st, nb.send_count, (const int32_t *)nb.send_idx, p1, o.send_idx);
         }
         if (nb.send_buf) SGM_TRY(dalloc(&o.send_buf, (size_t)std::max(nb.send_count, 1)));
     }
     SGM_HIP(hipGetLastError());
     SGM_HIP(hipStreamSynchronize(st));
+    return SGM_OK;
+}
+
+// The order a permuted part wants its halo slots in: inside every neighbour's segment [off, off + count) of the halo, by the
+// permuted index of the first row that references the slot (ties and unreferenced slots: as they were).  hmap_host[h] = the new
+// slot of old slot h.  Index work only: the VALUES a slot receives and the order a row adds its entries in do not change, so
+// every product on the part keeps its bits.
+int halo_attach_order(const Part &p, const int32_t *p1, const std::vector<std::pair<int32_t, int32_t>> &segments,
+                      std::vector<int32_t> &hmap_host)
+{
+    const int32_t nh = p.n_halo;
+    hmap_host.resize((size_t)nh);
+    for (int32_t h = 0; h < nh; ++h) hmap_host[(size_t)h] = h;
+    if (nh == 0 || p.n == 0) return SGM_OK;
+    SGM_TRY(csr_need_arrays(p));
+    struct Release { const Part &p; ~Release() { csr_release_arrays(p); } } rel{p};
+    hipStream_t st = g_rt.stream;
+    int32_t *key = nullptr;
+    SGM_TRY(dalloc(&key, (size_t)nh));
+    struct Tmp { int32_t *&a; ~Tmp() { dfree(a); } } tmp{key};
+    SGM_HIP(hipMemsetAsync(key, 0x7f, (size_t)nh * 4, st));          // 0x7f7f7f7f: beyond every row index
+    hipLaunchKernelGGL(k_halo_attach_key, dim3((p.n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, p.n, p.ncol_own, (const int32_t *)p.rowptr,
+                       (const int32_t *)p.col, p1, key);
+    std::vector<int32_t> hk((size_t)nh);
+    SGM_HIP(hipMemcpyAsync(hk.data(), key, (size_t)nh * 4, hipMemcpyDeviceToHost, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    std::vector<int32_t> idx;
+    for (const auto &sg : segments) {
+        const int32_t off = sg.first, cnt = sg.second;
+        if (off < 0 || cnt < 0 || (int64_t)off + cnt > nh) return fail(SGM_ERR_BAD_ARG, "halo_attach_order: a segment lies outside the halo");
+        idx.resize((size_t)cnt);
+        for (int32_t t = 0; t < cnt; ++t) idx[(size_t)t] = off + t;
+        std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return hk[(size_t)a] < hk[(size_t)b]; });
+        for (int32_t t = 0; t < cnt; ++t) hmap_host[(size_t)idx[(size_t)t]] = off + t;
+    }
     return SGM_OK;
 }
 

@@ -185,7 +185,12 @@ struct sgm_pc_s {
     // option "ildu_reorder": the factors are those of P A P^T -- on a row partition of P_k A_kk P_k^T for every part k, each
     // part ordering its own diagonal block (no communication; halo columns keep their numbers).  perm = p (1-based, local:
     // row i of the part is row p(i) of the permuted part), rp / zp = right-hand side and result in the permuted order
-    struct Reorder { int32_t *perm = nullptr; double *rp = nullptr, *zp = nullptr; int32_t n = 0, colors = 0; };
+    // hmap (device, n_halo entries; null: the halo keeps its order) = the part's halo slots re-ordered by the permuted rows they
+    // attach to; send_order[k] (device) = where entry j this part sends over its k-th link goes in the RECEIVER's re-ordered halo
+    struct Reorder {
+        int32_t *perm = nullptr; double *rp = nullptr, *zp = nullptr; int32_t n = 0, colors = 0;
+        int32_t *hmap = nullptr; std::vector<int32_t> hmap_host; std::vector<int32_t *> send_order;
+    };
     std::vector<Reorder> ro;            // one per part; empty = natural order
     uint64_t ro_serial = 0, ro_pattern = 0;     // the matrix (serial number, pattern version) the orderings were found for
     double reorder_ms[3] = {0, 0, 0};  // last setup: ordering, permuted copy, (factorisation is in the regular phases)
@@ -2673,7 +2678,7 @@ static void trace_setup(sgm_pc pc)
 
 static void free_reorder(sgm_pc pc)
 {
-    for (auto &R : pc->ro) { dfree(R.perm); dfree(R.rp); dfree(R.zp); }
+    for (auto &R : pc->ro) { dfree(R.perm); dfree(R.rp); dfree(R.zp); dfree(R.hmap); for (int32_t *q : R.send_order) dfree(q); }
     pc->ro.clear();
 }
 
@@ -2718,6 +2723,42 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             SGM_TRY(dalloc(&pc->ro[ip].rp, (size_t)pc->ro[ip].n + 2));
             SGM_TRY(dalloc(&pc->ro[ip].zp, (size_t)pc->ro[ip].n + 2));
         }
+        // Halo slots in the order of the permuted rows they attach to (index work, once per pattern): in the colour order a
+        // grid part's halo columns would otherwise sit at a different offset from every row -- the 15-entry offset dictionary
+        // overflows and the product falls from k_csr_sl (8.5 B per slot) to k_csr_sl32 (12 B).  Every receiver orders the
+        // slots of each neighbour's segment and the senders permute their lists to match (ranks: one exchange of int32 lists).
+        for (size_t ip = 0; ip < P; ++ip) {
+            std::vector<std::pair<int32_t, int32_t>> seg;
+            if (A->comm) {
+                for (const HaloNbr &nb : A->parts[ip].nbrs)
+                    if (nb.recv_count) seg.emplace_back(nb.recv_offset, nb.recv_count);
+            } else {
+                for (size_t is = 0; is < P; ++is)
+                    for (const HaloNbr &nb : A->parts[is].nbrs)
+                        if ((size_t)nb.peer == ip && nb.send_count) seg.emplace_back(nb.recv_offset, nb.send_count);
+            }
+            auto &R = pc->ro[ip];
+            SGM_TRY(halo_attach_order(A->parts[ip], R.perm, seg, R.hmap_host));
+            if (!R.hmap_host.empty()) {
+                SGM_TRY(dalloc(&R.hmap, R.hmap_host.size()));
+                SGM_HIP(hipMemcpy(R.hmap, R.hmap_host.data(), R.hmap_host.size() * 4, hipMemcpyHostToDevice));
+            }
+        }
+        if (A->comm) SGM_TRY(exchange_halo_orders(A, pc->ro[0].hmap_host, pc->ro[0].send_order));
+        else
+            for (size_t is = 0; is < P; ++is) {
+                auto &S = pc->ro[is];
+                S.send_order.assign(A->parts[is].nbrs.size(), nullptr);
+                for (size_t k = 0; k < A->parts[is].nbrs.size(); ++k) {
+                    const HaloNbr &nb = A->parts[is].nbrs[k];
+                    if (!nb.send_count) continue;
+                    const std::vector<int32_t> &hm = pc->ro[(size_t)nb.peer].hmap_host;
+                    std::vector<int32_t> rel((size_t)nb.send_count);
+                    for (int32_t t = 0; t < nb.send_count; ++t) rel[(size_t)t] = hm[(size_t)nb.recv_offset + t] - nb.recv_offset;
+                    SGM_TRY(dalloc(&S.send_order[k], (size_t)nb.send_count));
+                    SGM_HIP(hipMemcpy(S.send_order[k], rel.data(), (size_t)nb.send_count * 4, hipMemcpyHostToDevice));
+                }
+            }
         undo.armed = false;
         pc->ro_serial = A->serial;
         pc->ro_pattern = A->pattern_version;
@@ -2730,7 +2771,10 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
     Ap->comm = A->comm; Ap->row_starts = A->row_starts; Ap->col_starts = A->col_starts; Ap->halo_cols = A->halo_cols;
     Ap->parts.resize(P);
     int rc = SGM_OK;
-    for (size_t ip = 0; rc == SGM_OK && ip < P; ++ip) rc = permuted_part(A->parts[ip], pc->ro[ip].perm, Ap->parts[ip]);
+    for (size_t ip = 0; rc == SGM_OK && ip < P; ++ip)
+        rc = permuted_part(A->parts[ip], pc->ro[ip].perm, Ap->parts[ip], pc->ro[ip].hmap, &pc->ro[ip].send_order);
+    if (A->comm && !Ap->halo_cols.empty() && pc->ro[0].hmap_host.size() == Ap->halo_cols.size())      // (global column of every halo slot, in the new order)
+        for (size_t h = 0; h < pc->ro[0].hmap_host.size(); ++h) Ap->halo_cols[(size_t)pc->ro[0].hmap_host[h]] = A->halo_cols[h];
     pc->reorder_ms[1] = ms_since(t0);
     t0 = std::chrono::steady_clock::now();
     if (rc == SGM_OK) rc = pc_setup_ordered(pc, Ap);
@@ -3303,6 +3347,13 @@ int sgm_pc_info(sgm_pc pc, int32_t part, int32_t *out4, double *est_us, char *pa
                 snprintf(nm, sizeof nm, "level walkers, %d levels", std::max(o[0], o[1]));
             }
         }
+    }
+    // a colour-ordered part: the kernel the PRODUCT on the permuted copy runs with (the solvers iterate on that copy)
+    if (pc->kind == SGM_PC_ILDU0 && pc->Ap && (size_t)part < pc->Ap->parts.size() && (size_t)part < pc->ro.size() && pc->ro[(size_t)part].colors) {
+        char kn[64];
+        part_kernel_name(pc->Ap->parts[(size_t)part], pc->Ap->fmt, kn, sizeof kn);
+        const size_t used = strlen(nm);
+        snprintf(nm + used, sizeof nm - used, "; product of the ordered part: %s", kn);
     }
     if (out4) memcpy(out4, o, sizeof o);
     if (est_us) *est_us = us;

@@ -3170,6 +3170,51 @@ def test_partitioned_block_jacobi_ildu_of_the_colour_ordered_blocks(orc, nparts)
         assert np.array_equal(z, opc2.solve(rp)[p - 1])
 
 
+@pytest.mark.parametrize("nparts", [2, 4, 8])
+def test_colour_ordered_parts_keep_the_four_bit_dictionary_kernel(orc, nparts, dot_order_1):
+    """In the colour order a grid part's halo columns used to sit at a different offset from every row: the 15-entry offset
+    dictionary overflowed and the product of a permuted part fell from k_csr_sl (8.5 bytes per slot) to k_csr_sl32 (12).  The
+    halo slots of every neighbour's segment are now ordered by the permuted index of the row they attach to, and the senders'
+    lists follow: every part of the permuted copy reads k_csr_sl<W=5> again.  Index work only -- no row
+    adds its entries in another order: in the reference's dot order PCG on the partition is the oracle's solve of the permuted
+    system with block-Jacobi ILDU(0), bit for bit (reorder_solve 2 and 1: the solve runs in the permuted order)."""
+    nx, ny = 256, 64 * nparts
+    n = nx * ny
+    ptr, node, val = P.poisson2d_csr(nx, ny)
+    rows = np.repeat(np.arange(1, n + 1), np.diff(ptr))
+    val = val * (1.0 + 0.05 * np.cos(0.3 * (rows + node)))
+    A = orc.CsrMatrix(n, n, ptr, node, val)
+    starts = (np.arange(nparts + 1) * (ny // nparts) * nx).astype(np.int64)          # whole grid lines per part
+    H = sg.partitioned_csr_matrix(n, n, ptr, node, val, starts)
+    pc = sg.ldu(reorder="colour")
+    pc.setup(H)
+    for ip in range(nparts):
+        info = pc.info(ip)
+        assert info["colours"] == 2 and info["name"].endswith("product of the ordered part: k_csr_sl<W=5>"), (ip, info)
+    p, colours = _blockwise_colour_order(orc, A, starts)
+    Ap = orc.permuted(A, p, p)
+    opc = orc.Ildu(_block_diagonal(orc, Ap, starts))
+    b = P.test_vector(n)
+    bp = np.empty(n); bp[p - 1] = b
+    ur, itr, _, _ = orc.cg(Ap, bp, tol=1e-10, pc=opc)
+    for mode in (2, 1, 0):
+        s = sg.cg(1e-10)
+        s.set_option("reorder_solve", mode)
+        s.setup(H)
+        u = np.zeros(n)
+        s.solve(H, u, b, pc)
+        if mode:         # the solve runs in the permuted order: the oracle's sequence of dot products, bit for bit
+            assert s.iterations == itr and np.array_equal(u, ur[p - 1]), (nparts, mode, s.iterations, itr)
+        else:            # (mode 0 iterates in A's own order -- other dot products -- and permutes r, z around every apply)
+            assert abs(s.iterations - itr) <= 1 and np.abs(u - ur[p - 1]).max() <= 1e-8 * np.abs(ur).max(), (nparts, s.iterations, itr)
+        s.destroy()
+    # the product on the partition itself is untouched (natural order, k_csr_sl as before)
+    x = P.test_vector(n)
+    y = np.zeros(n)
+    H.matvec(x, y)
+    assert np.array_equal(y, A.matvec(x))
+
+
 @pytest.mark.parametrize("nparts", [2, 3, 8])
 def test_partitioned_cg_forms_p_halo_locally_bit_identical_to_exchanging_it(orc, nparts):
     """Option dist_halo_fused (default 1): on a row partition the boundary rows of r (z with a preconditioner) travel beside

@@ -238,7 +238,8 @@ def test_pc_info_names_the_chain_and_the_remedy_at_c2_size():
     import json
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("INFO ")][0][5:])
     assert d["natural"]["name"] == "strip pipeline, 6323 levels" and d["natural"]["path"] == 2 and d["natural"]["colours"] == 0, d["natural"]
-    assert d["colour"]["name"] == "row space, 2 levels" and d["colour"]["path"] == 1 and d["colour"]["colours"] == 2, d["colour"]
+    assert d["colour"]["name"] == "row space, 2 levels; product of the ordered part: k_csr_sl<W=5>", d["colour"]
+    assert d["colour"]["path"] == 1 and d["colour"]["colours"] == 2, d["colour"]
     assert d["colour"]["levels"] == [2, 2] and d["natural"]["levels"] == [6323, 6323]
     # the estimates are what tells a caller which one to take: the chain is several times the two bandwidth-bound sweeps
     assert d["natural"]["est_us"] > 4 * d["colour"]["est_us"] > 0, (d["natural"]["est_us"], d["colour"]["est_us"])
