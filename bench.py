@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
-PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"
 
 
 def spmv_bytes(n, m, nnz):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense gpurun_out/prof_round (tools/profile_round.sh) into profiles/<tag>/."""
 import csv, glob, hashlib, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", "prof_round"), os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)

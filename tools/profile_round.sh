@@ -53,7 +53,7 @@ grep -h '^{' $OUT/c3_lowsync.log $OUT/c3_mgs.log $OUT/configs.log > $OUT/configs
 cat $OUT/bench.json | cut -c1-600
 # the bench line once more, now that this round's PMC passes exist: condense them on the box (profiles/r03/pmc_hbm_traffic.json
 # with the fingerprint of the sources that just ran) so that `roofline.traffic` of the line is this run's own figure
-python tools/collect_profiles.py ${TAG:-r05} > /dev/null 2>&1
+python tools/collect_profiles.py ${TAG:-r06} > /dev/null 2>&1
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo bench_with_traffic=$?
 # what travels back is capped at 64 MiB: the per-dispatch traces are not needed once the stats exist
 find $OUT -name "*kernel_trace.csv" -delete
