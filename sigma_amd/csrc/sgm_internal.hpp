@@ -130,6 +130,15 @@ int dalloc(T **p, size_t count)
     hipError_t e = hipMalloc((void **)p, count * sizeof(T));
     if (e != hipSuccess)
         return fail(SGM_ERR_ALLOC, "hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
+#ifdef SGM_POISON_ALLOC
+    // debugging build (`make -C sigma_amd/csrc POISON=1`, tools/poison_visit.sh): every allocation starts as 0xFF bytes -- NaN
+    // doubles, -1 indices -- so that a read of memory nothing has written yet shows in the first result instead of depending on
+    // what the allocator handed back (a fresh GPU box hands back zeros; a busy one does not)
+    // (hipMemset on the null stream is not ordered against the library's non-blocking stream: wait for it, or the poison lands
+    //  on top of what is written next)
+    (void)hipMemset(*p, 0xFF, count * sizeof(T));
+    (void)hipDeviceSynchronize();
+#endif
     return SGM_OK;
 }
 inline void dfree(void *p) { if (p) (void)hipFree(p); }

@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r06
+timeout 3300 python -m pytest tests -q -m gpu --durations=15 --timeout=900 > gpurun_out/r06/gpu_tests.log 2>&1; echo gputests=$?
+tail -30 gpurun_out/r06/gpu_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
