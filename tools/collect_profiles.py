@@ -25,7 +25,8 @@ for name, to in (("pmc_colour_ildu.txt", "pmc_colour_ildu.txt"), ("cg_small_coop
                  ("cg_small_launch_loop.jsonl", "cg_per_iteration_launch_loop.jsonl"), ("bicgstab_small.jsonl", "bicgstab_per_iteration.jsonl"),
                  ("coop_probe.jsonl", "cg_coop_phase_timers.jsonl"), ("wave_sum_probe.txt", "wave_sum_probe.txt"),
                  ("scattered_csr.json", "scattered_csr.json"), ("ildu_colour_parts_kernel_sums.txt", "ildu_colour_parts_kernel_sums.txt"),
-                 ("stream_ceilings.txt", "stream_ceilings.txt"), ("c5_counters.txt", "c5_product_counters.txt")):
+                 ("stream_ceilings.txt", "stream_ceilings.txt"), ("c5_counters.txt", "c5_product_counters.txt"),
+                 ("fuzz_campaigns.txt", "fuzz_campaigns.txt"), ("bench_wall.txt", "bench_wall.txt")):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, to))
 if os.path.exists(os.path.join(src, "configs.jsonl")):

@@ -47,6 +47,9 @@ cp gpurun_out/r05_parts/summary.txt $OUT/ildu_colour_parts_kernel_sums.txt
 # the streaming ceilings and the counter passes of the C5 product (tools/probes/ceilings_r05.sh)
 bash tools/probes/ceilings_r05.sh > /dev/null 2>&1
 cp gpurun_out/r05_ceilings/stream_ceilings.txt gpurun_out/r05_ceilings/c5_counters.txt $OUT/
+# short campaigns of the fuzzers on this tree (the solver fuzzer holds every seventh one-part system in ELLPACK since round 6)
+{ echo "== tests/fuzz_solvers.py 240 s from seed 600000"; timeout 400 python tests/fuzz_solvers.py 240 600000 2>&1 | tail -4;
+  echo "== tests/fuzz_formats.py 120 s from seed 610000"; timeout 300 python tests/fuzz_formats.py 120 610000 2>&1 | tail -4; } > $OUT/fuzz_campaigns.txt 2>&1
 # C4 / C5: per-kernel times
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_configs -- python3 tools/bench_configs.py --configs c4,c5 > $OUT/configs.log 2>&1
 grep -h '^{' $OUT/c3_lowsync.log $OUT/c3_mgs.log $OUT/configs.log > $OUT/configs.jsonl
