@@ -86,6 +86,29 @@ int g_depth = 0;
 struct Pinned { void *p; hipStream_t st; };
 std::vector<Pinned> g_graveyard;
 
+// MOCK_RCCL_TRACE=<directory>: every rank appends one line per operation to <directory>/rank<r>.trace -- collectives with their
+// first inputs / outputs as hex floats, point-to-point messages with a checksum of their payload -- so that a wrong result of a
+// multi-rank test can be told apart: the transport delivered something else than was sent (compare the files), or the library
+// computed something else from the same messages.  tests/test_gpu_multirank.py keeps the files of a failed attempt.
+FILE *g_trace = nullptr;
+long g_trace_seq = 0;
+void trace_open(int rank)
+{
+    if (g_trace) return;
+    const char *d = getenv("MOCK_RCCL_TRACE");
+    if (!d) return;
+    char path[512];
+    snprintf(path, sizeof path, "%s/rank%d.trace", d, rank);
+    g_trace = fopen(path, "a");
+}
+uint64_t checksum(const void *p, size_t bytes)
+{
+    uint64_t h = 1469598103934665603ull;
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t i = 0; i < bytes; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+
 double now()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -183,6 +206,12 @@ ncclResult_t run_ops()
             if (now() - t0 > kTimeoutS) { fprintf(stderr, "[mock_rccl] send/recv timed out\n"); return ncclSystemError; }
         }
     }
+    if (g_trace) {
+        for (auto &o : g_ops)
+            fprintf(g_trace, "%ld %s peer %d bytes %zu sum %016llx\n", ++g_trace_seq, o.send ? "send" : "recv", o.peer, o.bytes,
+                    (unsigned long long)checksum(o.host, o.bytes));
+        fflush(g_trace);
+    }
     for (auto &o : g_ops) {
         if (!o.send && o.bytes && dev_copy_async(o.dev, o.host, o.bytes, hipMemcpyHostToDevice, o.st) != hipSuccess)
             return ncclUnhandledCudaError;
@@ -226,6 +255,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
         if (now() - t0 > kTimeoutS) { delete c; return ncclSystemError; }
     }
     if (!barrier(c)) { delete c; return ncclSystemError; }
+    trace_open(rank);
     if (rank == 0) shm_unlink(name);            // the mappings keep it alive; nothing is left in /dev/shm
     *comm = (ncclComm_t)c;
     return ncclSuccess;
@@ -303,6 +333,14 @@ static ncclResult_t collective(const void *send, void *recv, size_t bytes_each, 
         }
     } else {
         for (int r = 0; r < c->n; ++r) memcpy(host + (size_t)r * bytes_each, c->sh->coll[r], bytes_each);
+    }
+    if (g_trace) {
+        const double *in = (const double *)c->sh->coll[c->rank], *out = (const double *)host;
+        if (reduce_f64) fprintf(g_trace, "%ld allreduce count %zu in %a out %a insum %016llx outsum %016llx\n", ++g_trace_seq, bytes_each / 8,
+                                bytes_each ? in[0] : 0.0, bytes_each ? out[0] : 0.0, (unsigned long long)checksum(in, bytes_each),
+                                (unsigned long long)checksum(out, out_bytes));
+        else fprintf(g_trace, "%ld allgather bytes %zu outsum %016llx\n", ++g_trace_seq, bytes_each, (unsigned long long)checksum(host, out_bytes));
+        fflush(g_trace);
     }
     if (!barrier(c)) return ncclSystemError;        // nobody overwrites a slot that is still being read
     if (out_bytes && dev_copy_async(recv, host, out_bytes, hipMemcpyHostToDevice, st) != hipSuccess) return ncclUnhandledCudaError;

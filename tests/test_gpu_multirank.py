@@ -68,6 +68,8 @@ def _run_ranks_once(world, case, tmp_path, mock, extra_env=None):
     env.update(extra_env or {})
     if mock:
         env["SGM_RCCL_LIB"] = MOCK
+        if world >= 8:      # (what every rank sent, received and reduced: kept when the attempt fails -- see _run_ranks)
+            env["MOCK_RCCL_TRACE"] = str(tmp_path)
     else:
         env.pop("SGM_RCCL_LIB", None)
     outs = [str(tmp_path / f"rank{r}.json") for r in range(world)]
@@ -86,12 +88,25 @@ def _run_ranks_once(world, case, tmp_path, mock, extra_env=None):
         f.close()
     logs = [open(str(tmp_path / f"rank{r}.log"), "rb").read().decode(errors="replace")[-3000:] for r in range(world)]
     results = []
-    for r in range(world):
-        assert os.path.exists(outs[r]), f"rank {r} wrote no result (rc {procs[r].returncode}):\n{logs[r]}"
-        results.append(json.load(open(outs[r])))
-    for r, res in enumerate(results):
-        assert res["ok"], f"rank {r}: {res.get('error')}\n{logs[r]}"
-        assert res["n_halo"] > 0
+    try:
+        for r in range(world):
+            assert os.path.exists(outs[r]), f"rank {r} wrote no result (rc {procs[r].returncode}):\n{logs[r]}"
+            results.append(json.load(open(outs[r])))
+        for r, res in enumerate(results):
+            assert res["ok"], f"rank {r}: {res.get('error')}\n{logs[r]}"
+            assert res["n_halo"] > 0
+    except AssertionError:
+        try:                    # keep every rank's result, log and transport trace of the failed attempt
+            import shutil
+            d = os.path.join(ROOT, "gpurun_out", "rank_retries", f"{world}_{case.replace(':', '_')}_{int(time.time())}")
+            os.makedirs(d, exist_ok=True)
+            for f in os.listdir(str(tmp_path)):
+                src = os.path.join(str(tmp_path), f)
+                if os.path.isfile(src) and os.path.getsize(src) < (8 << 20):
+                    shutil.copy(src, d)
+        except OSError:
+            pass
+        raise
     return results
 
 
