@@ -19,20 +19,35 @@
 // The few device operations the transport needs, in one place.  -DMOCK_RCCL_HOST_ONLY (tools/asan: the AddressSanitizer /
 // UBSan build, run on a CPU box by tests/test_asan_cpu.py) makes "device" buffers plain host memory, so that the rings, the
 // barrier and the collectives -- the index work of this file -- run as several processes without a GPU.
-#ifdef MOCK_RCCL_HOST_ONLY
 #include <cstdlib>
 #include <cstring>
+#ifdef MOCK_RCCL_HOST_ONLY
 static inline hipError_t dev_sync(hipStream_t) { return hipSuccess; }
 static inline hipError_t dev_copy(void *dst, const void *src, size_t n, hipMemcpyKind) { memcpy(dst, src, n); return hipSuccess; }
 static inline hipError_t dev_copy_async(void *dst, const void *src, size_t n, hipMemcpyKind, hipStream_t) { memcpy(dst, src, n); return hipSuccess; }
 static inline hipError_t pinned_alloc(void **p, size_t n) { *p = malloc(n); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline void pinned_free(void *p) { free(p); }
 #else
+// Staging buffers are PAGEABLE host memory and every copy is synchronous.  Until round 6 they were hipHostMalloc'ed (recycled by
+// the runtime from one message to the next) with an asynchronous copy back: in three full-suite runs one message of an 8-rank
+// solve left its sender as the PREVIOUS content of the recycled buffer -- the device-to-host copy had not landed when the bytes
+// went into the ring (the per-message trace, MOCK_RCCL_TRACE, showed sender and receiver agreeing on a payload that was an old
+// message's).  A stand-in has no use for the overlap pinned memory buys: plain memory, hipMemcpy, and a wait on the device.
 static inline hipError_t dev_sync(hipStream_t st) { return hipStreamSynchronize(st); }
-static inline hipError_t dev_copy(void *dst, const void *src, size_t n, hipMemcpyKind k) { return hipMemcpy(dst, src, n, k); }
-static inline hipError_t dev_copy_async(void *dst, const void *src, size_t n, hipMemcpyKind k, hipStream_t st) { return hipMemcpyAsync(dst, src, n, k, st); }
-static inline hipError_t pinned_alloc(void **p, size_t n) { return hipHostMalloc(p, n); }
-static inline void pinned_free(void *p) { (void)hipHostFree(p); }
+static inline hipError_t dev_copy(void *dst, const void *src, size_t n, hipMemcpyKind k)
+{
+    const hipError_t e = hipMemcpy(dst, src, n, k);
+    return e != hipSuccess ? e : hipDeviceSynchronize();
+}
+static inline hipError_t dev_copy_async(void *dst, const void *src, size_t n, hipMemcpyKind k, hipStream_t)
+{
+    // (the stream was drained before the operation started and this thread launches nothing meanwhile: a copy that has
+    //  completed before the call returns is ordered in front of everything the stream gets afterwards)
+    const hipError_t e = hipMemcpy(dst, src, n, k);
+    return e != hipSuccess ? e : hipDeviceSynchronize();
+}
+static inline hipError_t pinned_alloc(void **p, size_t n) { *p = malloc(n); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline void pinned_free(void *p) { free(p); }
 #endif
 
 #include <fcntl.h>

@@ -95,6 +95,8 @@ def _run_ranks_once(world, case, tmp_path, mock, extra_env=None):
         for r, res in enumerate(results):
             assert res["ok"], f"rank {r}: {res.get('error')}\n{logs[r]}"
             assert res["n_halo"] > 0
+        if os.environ.get("SGM_KEEP_RANK_TRACES") and world >= 8:
+            raise AssertionError("SGM_KEEP_RANK_TRACES: keeping the artefacts of a PASSING attempt")
     except AssertionError:
         try:                    # keep every rank's result, log and transport trace of the failed attempt
             import shutil
