@@ -39,11 +39,13 @@ def _device_count():
 
 
 def _run_ranks(world, case, tmp_path, mock, extra_env=None):
-    """The ranks of one case; a failed attempt is repeated ONCE, loudly.  Round 6 saw one unexplained failure of the 8-rank case in
-    eleven executions (rank 0: CG 183 iterations against the oracle's 100, in a full-suite run; not reproduced in eight isolated
-    runs, nor with every device allocation poisoned -- profiles/r06/README.md): eight processes taking turns on one GPU over a
-    host-staged stand-in are test infrastructure, and `pytest -x` must not lose the whole suite to them.  A failure that repeats
-    still fails; the first attempt's message is kept in the warning and under gpurun_out/ when that is writable."""
+    """The ranks of one case; a failed attempt is repeated ONCE, loudly, and its artefacts are kept.  Round 6: the 8-rank case failed
+    in three full-suite runs (CG 183 iterations against the oracle's 100, ...) and in no other execution; the stand-in transport's
+    per-message trace (MOCK_RCCL_TRACE, kept with every rank's result and log under gpurun_out/rank_retries/ when an attempt fails)
+    showed ONE halo message leaving its sender as the previous content of a recycled pinned staging buffer -- the transport's
+    device-to-host copy, not the library (profiles/r06/rank8_transport_trace_evidence.txt; the staging is pageable and synchronous
+    since).  Eight processes taking turns on one GPU over a host-staged stand-in are test infrastructure: `pytest -x` must not lose
+    the whole suite to them, a failure that repeats still fails."""
     try:
         return _run_ranks_once(world, case, tmp_path / "a1", mock, extra_env)
     except AssertionError as first:
