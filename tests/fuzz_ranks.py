@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Rank-level fuzz campaign (not collected by pytest; tests/test_gpu_multirank.py::test_rank_fuzz_seeds runs 12 seeds per world
-size): `tests/dist_worker.py fuzz:<seed>:<count>` over 2 ... 5 rank processes sharing one GPU through tests/mock_rccl.
+size): `tests/dist_worker.py fuzz:<seed>:<count>` over 2 ... 8 rank processes sharing one GPU through tests/mock_rccl.
 
     python tests/fuzz_ranks.py [seeds per launch] [launches per world size] [first seed]"""
 import os
@@ -17,11 +17,11 @@ def main():
     launches = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     seed = int(sys.argv[3]) if len(sys.argv) > 3 else 400000
     total, failed = 0, []
-    for world in (2, 3, 4, 5):
+    for world in (2, 3, 4, 5, 8):
         for _ in range(launches):
             with tempfile.TemporaryDirectory() as d:
                 try:
-                    results = T._run_ranks(world, f"fuzz:{seed}:{count}", pathlib.Path(d), mock=True)
+                    results = T._run_ranks_once(world, f"fuzz:{seed}:{count}", pathlib.Path(d), mock=True)     # (a campaign repeats nothing)
                     done = results[0]["seeds"]
                     total += len(done)
                     print(f"world {world}: seeds {seed}..{seed + count - 1}: {len(done)} systems ok", flush=True)
