@@ -337,7 +337,8 @@ int exchange_halo_orders(sgm_mat A, const std::vector<int32_t> &mine, std::vecto
             std::vector<int32_t> rel((size_t)nb.recv_count);
             for (int32_t t = 0; t < nb.recv_count; ++t) rel[(size_t)t] = mine[(size_t)nb.recv_offset + t] - nb.recv_offset;
             SGM_TRY(dalloc(&give[k], (size_t)nb.recv_count));
-            SGM_HIP(hipMemcpy(give[k], rel.data(), (size_t)nb.recv_count * 4, hipMemcpyHostToDevice));
+            SGM_HIP(hipMemcpyAsync(give[k], rel.data(), (size_t)nb.recv_count * 4, hipMemcpyHostToDevice, st));
+            SGM_HIP(hipStreamSynchronize(st));          // (on the stream the sends read it on; `rel` goes out of scope)
         }
         if (nb.send_count) SGM_TRY(dalloc(&out[k], (size_t)nb.send_count));
     }
@@ -614,7 +615,8 @@ static int probe_mixed_group(sgm_comm c)
         (void)hipGetLastError();
     }
     const double vote = ok ? 1.0 : 0.0;
-    SGM_HIP(hipMemcpy(d + 3, &vote, sizeof vote, hipMemcpyHostToDevice));
+    SGM_HIP(hipMemcpyAsync(d + 3, &vote, sizeof vote, hipMemcpyHostToDevice, st));      // (on the stream the all-reduce reads it on)
+    SGM_HIP(hipStreamSynchronize(st));
     SGM_NCCL(g_nccl.AllReduce(d + 3, d + 3, 1, ncclFloat64, ncclSum, comm, st));
     SGM_HIP(hipStreamSynchronize(st));
     double votes = 0.0;
@@ -939,7 +941,8 @@ int sgm_ell_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts, 
     SGM_TRY(sgm_csr_create_dist(out, comm, row_starts, nnz, hptr.data(), hnode.data(), hval.data(), SGM_HOST));
     Part &p = (*out)->parts[0];
     SGM_TRY(dalloc(&p.edeg, (size_t)std::max(n, 1)));
-    SGM_HIP(hipMemcpy(p.edeg, hdeg.data(), (size_t)std::max(n, 1) * 4, hipMemcpyHostToDevice));
+    SGM_HIP(hipMemcpyAsync(p.edeg, hdeg.data(), (size_t)std::max(n, 1) * 4, hipMemcpyHostToDevice, g_rt.stream));
+    SGM_HIP(hipStreamSynchronize(g_rt.stream));
     return SGM_OK;
 }
 
@@ -1098,6 +1101,250 @@ static int ensure_transpose_dist(sgm_mat A)
     A->T = T;
     A->t_stale = false;
     return SGM_OK;
+}
+
+// ------------------------------------------------------------------ re-orderings and permutations over ranks (SURVEY 8(f4) x 8(e))
+// The reference's breadth_first_search / greedy_coloring / greedy_color_ordering (permutations.f90:22-205) are sequential walks of
+// ONE graph whose numbering depends on the visiting order; A%left_permute / right_permute (cs_matrices.f90:471-490) move whole rows
+// / rename columns.  On a matrix distributed over ranks both are SETUP work, done the simple way: every rank receives the whole
+// index structure (left_permute: and the values) once -- one grouped exchange, the matrix in host memory for the length of the
+// call --, the ordering runs on every rank by the single-GPU passes (the same p everywhere, the reference's bits), a permutation
+// cuts this rank's NEW rows out of the gathered arrays and rebuilds the handle's row block with sgm_csr_create_dist (same row
+// partition, new halo plan).  right_permute needs no exchange at all.  Not for matrices near a rank's memory; what a solver needs
+// per rank without any of this is ldu(reorder = "colour") (sgm_pc.hip).
+
+int sgm_invalidate_transpose(sgm_mat A);          // sgm_layouts.hip
+
+// A device -> host copy of index / value arrays that CHECKS what arrived: the 32-bit words are summed on the device (one atomic
+// per workgroup) and on the host; a copy whose sum differs is waited for (hipDeviceSynchronize) and repeated, loudly.  Setup-path
+// gathers only (a few per call).  Why: round 6 saw, on the shared GPU boxes under load, a host buffer read right after its
+// device-to-host copy still holding its previous content -- in the stand-in transport (profiles/r06) and, it seems, here; a wrong
+// index array is a wrong graph, silently.
+__global__ void k_word_sum(const uint32_t *__restrict__ w, size_t nwords, unsigned long long *sum)
+{
+    unsigned long long s = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) s += w[i];
+    __shared__ unsigned long long red[kBlock];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = kBlock / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) atomicAdd(sum, red[0]);
+}
+static int download_verified(void *host, const void *dev, size_t bytes, const char *what)
+{
+    if (!bytes) return SGM_OK;
+    hipStream_t st = g_rt.stream;
+    unsigned long long *dsum = nullptr, want = 0;
+    SGM_TRY(dalloc(&dsum, 1));
+    struct Tmp { unsigned long long *&p; ~Tmp() { dfree(p); } } tmp{dsum};
+    SGM_HIP(hipMemsetAsync(dsum, 0, 8, st));
+    const size_t nw = bytes / 4;
+    hipLaunchKernelGGL(k_word_sum, dim3((unsigned)std::min<size_t>((nw + kBlock - 1) / kBlock, 1024)), dim3(kBlock), 0, st, (const uint32_t *)dev, nw, dsum);
+    SGM_HIP(hipMemcpyAsync(&want, dsum, 8, hipMemcpyDeviceToHost, st));
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        SGM_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
+        SGM_HIP(hipStreamSynchronize(st));
+        unsigned long long got = 0;
+        const uint32_t *hw = (const uint32_t *)host;
+        for (size_t i = 0; i < nw; ++i) got += hw[i];
+        if (got == want) return SGM_OK;
+        fprintf(stderr, "[sigma_hip] WARNING: %s: a device-to-host copy of %zu bytes arrived with word sum %llx, the device holds %llx (attempt %d): "
+                        "waiting for the device and copying again\n", what, bytes, got, want, attempt + 1);
+        SGM_HIP(hipDeviceSynchronize());
+    }
+    return fail(SGM_ERR_HIP, "%s: a device-to-host copy does not arrive intact", what);
+}
+
+// this rank's rows as host arrays with GLOBAL 1-based columns
+static int local_rows_global(sgm_mat A, std::vector<int32_t> &hptr, std::vector<int32_t> &hnode, std::vector<double> *hval)
+{
+    const Part &p = A->parts[0];
+    hipStream_t st = g_rt.stream;
+    const int32_t n = p.n, nc = p.ncol_own;
+    const int64_t c0 = A->col_starts[A->comm->rank];
+    hptr.assign((size_t)n + 1, 0);
+    hnode.assign((size_t)std::max<int64_t>(p.nnz, 1), 0);
+    if (hval) hval->assign((size_t)std::max<int64_t>(p.nnz, 1), 0.0);
+    SGM_TRY(csr_need_arrays(p));
+    int rc = download_verified(hptr.data(), p.rowptr, ((size_t)n + 1) * 4, "local rows (ptr)");
+    if (rc == SGM_OK && p.nnz) rc = download_verified(hnode.data(), p.col, (size_t)p.nnz * 4, "local rows (node)");
+    if (rc == SGM_OK && p.nnz && hval) rc = download_verified(hval->data(), p.val, (size_t)p.nnz * 8, "local rows (val)");
+    SGM_HIP(hipStreamSynchronize(st));
+    csr_release_arrays(p);
+    SGM_TRY(rc);
+    for (int64_t k = 0; k < p.nnz; ++k) {
+        const int32_t c = hnode[(size_t)k];
+        hnode[(size_t)k] = c < nc ? (int32_t)(c0 + c + 1) : A->halo_cols[(size_t)(c - nc)];
+    }
+    return SGM_OK;
+}
+
+// every rank gets the whole matrix: gptr (nrow + 1, 1-based), gnode (global 1-based columns), gval (optional), rows in global
+// order, entries in stored order.  Row lengths, columns and values travel in one grouped send / recv per peer.
+int gather_global_csr(sgm_mat A, std::vector<int32_t> &gptr, std::vector<int32_t> &gnode, std::vector<double> *gval)
+{
+    if (!A->comm || A->fmt != SGM_FMT_CSR || A->parts.size() != 1)
+        return fail(SGM_ERR_UNSUPPORTED, "this operation needs a CSR matrix distributed over ranks (sgm_csr_create_dist)");
+    sgm_comm comm = A->comm;
+    const int R = comm->nranks, me = comm->rank;
+    const int64_t *rs = A->row_starts.data();
+    const int64_t ng = rs[R];
+    hipStream_t st = g_rt.stream;
+    std::vector<int32_t> hptr, hnode;
+    std::vector<double> hval;
+    SGM_TRY(local_rows_global(A, hptr, hnode, gval ? &hval : nullptr));
+    const int32_t n = A->parts[0].n;
+    const int64_t nnz = A->parts[0].nnz;
+    struct Scratch { std::vector<void *> v; ~Scratch() { for (void *q : v) dfree(q); } } sc;
+    auto dev = [&](size_t bytes, void **out) -> int {
+        char *q = nullptr;
+        SGM_TRY(dalloc(&q, bytes ? bytes : 1));
+        sc.v.push_back(q);
+        *out = q;
+        return SGM_OK;
+    };
+    // every rank's entry count
+    int32_t *d_cnt = nullptr, *d_all = nullptr;
+    SGM_TRY(dev(4, (void **)&d_cnt));
+    SGM_TRY(dev((size_t)R * 4, (void **)&d_all));
+    // (every copy of this function goes through the library's stream and is waited for: a blocking copy on the null stream is
+    //  not ordered against a non-blocking stream)
+    const int32_t mine = (int32_t)nnz;
+    SGM_HIP(hipMemcpyAsync(d_cnt, &mine, 4, hipMemcpyHostToDevice, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    SGM_NCCL(g_nccl.AllGather(d_cnt, d_all, 1, ncclInt32, (ncclComm_t)comm->nccl, st));
+    std::vector<int32_t> cnt((size_t)R);
+    SGM_HIP(hipMemcpyAsync(cnt.data(), d_all, (size_t)R * 4, hipMemcpyDeviceToHost, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    std::vector<int64_t> eoff((size_t)R + 1, 0);
+    for (int q = 0; q < R; ++q) eoff[(size_t)q + 1] = eoff[(size_t)q] + cnt[(size_t)q];
+    const int64_t nnzg = eoff[(size_t)R];
+    if (nnzg >= INT32_MAX - 4) return fail(SGM_ERR_UNSUPPORTED, "the whole matrix has %lld entries: more than one rank can hold as int32 CSR", (long long)nnzg);
+    int32_t *d_len = nullptr, *d_node = nullptr;
+    double *d_val = nullptr;
+    SGM_TRY(dev((size_t)ng * 4, (void **)&d_len));
+    SGM_TRY(dev((size_t)nnzg * 4, (void **)&d_node));
+    if (gval) SGM_TRY(dev((size_t)nnzg * 8, (void **)&d_val));
+    std::vector<int32_t> len((size_t)std::max(n, 1));
+    for (int32_t i = 0; i < n; ++i) len[(size_t)i] = hptr[(size_t)i + 1] - hptr[(size_t)i];
+    if (n) SGM_HIP(hipMemcpyAsync(d_len + rs[me], len.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    if (nnz) SGM_HIP(hipMemcpyAsync(d_node + eoff[(size_t)me], hnode.data(), (size_t)nnz * 4, hipMemcpyHostToDevice, st));
+    if (nnz && gval) SGM_HIP(hipMemcpyAsync(d_val + eoff[(size_t)me], hval.data(), (size_t)nnz * 8, hipMemcpyHostToDevice, st));
+    SGM_HIP(hipStreamSynchronize(st));
+    if (R > 1) {
+        const int hb_prev = g_hb.phase;
+        hb_phase(HB_CREATE_DIST);
+        SGM_NCCL(g_nccl.GroupStart());
+        for (int q = 0; q < R; ++q) {
+            if (q == me) continue;
+            const size_t nq = (size_t)(rs[q + 1] - rs[q]);
+            if (n) SGM_NCCL(g_nccl.Send(d_len + rs[me], (size_t)n, ncclInt32, q, (ncclComm_t)comm->nccl, st));
+            if (nq) SGM_NCCL(g_nccl.Recv(d_len + rs[q], nq, ncclInt32, q, (ncclComm_t)comm->nccl, st));
+            if (nnz) SGM_NCCL(g_nccl.Send(d_node + eoff[(size_t)me], (size_t)nnz, ncclInt32, q, (ncclComm_t)comm->nccl, st));
+            if (cnt[(size_t)q]) SGM_NCCL(g_nccl.Recv(d_node + eoff[(size_t)q], (size_t)cnt[(size_t)q], ncclInt32, q, (ncclComm_t)comm->nccl, st));
+            if (gval) {
+                if (nnz) SGM_NCCL(g_nccl.Send(d_val + eoff[(size_t)me], (size_t)nnz, ncclFloat64, q, (ncclComm_t)comm->nccl, st));
+                if (cnt[(size_t)q]) SGM_NCCL(g_nccl.Recv(d_val + eoff[(size_t)q], (size_t)cnt[(size_t)q], ncclFloat64, q, (ncclComm_t)comm->nccl, st));
+            }
+        }
+        SGM_NCCL(g_nccl.GroupEnd());
+        SGM_HIP(hipStreamSynchronize(st));
+        hb_phase(hb_prev);
+    }
+    std::vector<int32_t> glen((size_t)std::max<int64_t>(ng, 1));
+    gnode.assign((size_t)std::max<int64_t>(nnzg, 1), 0);
+    if (gval) gval->assign((size_t)std::max<int64_t>(nnzg, 1), 0.0);
+    if (ng) SGM_TRY(download_verified(glen.data(), d_len, (size_t)ng * 4, "gathered row lengths"));
+    if (nnzg) SGM_TRY(download_verified(gnode.data(), d_node, (size_t)nnzg * 4, "gathered columns"));
+    if (nnzg && gval) SGM_TRY(download_verified(gval->data(), d_val, (size_t)nnzg * 8, "gathered values"));
+    SGM_HIP(hipStreamSynchronize(st));
+    gptr.assign((size_t)ng + 1, 1);
+    for (int64_t i = 0; i < ng; ++i) gptr[(size_t)i + 1] = gptr[(size_t)i] + glen[(size_t)i];
+    if (trace_on()) {
+        fprintf(stderr, "[sigma_hip] gather_global_csr rank %d: n %d nnz %lld ng %lld nnzg %lld cnt", me, n, (long long)nnz, (long long)ng, (long long)nnzg);
+        for (int q = 0; q < R; ++q) fprintf(stderr, " %d", cnt[(size_t)q]);
+        for (int q = 0; q < R; ++q) {
+            unsigned long long h = 1469598103934665603ull, hl = 1469598103934665603ull;
+            for (int64_t k = eoff[(size_t)q]; k < eoff[(size_t)q + 1]; ++k) { h ^= (unsigned)gnode[(size_t)k]; h *= 1099511628211ull; }
+            for (int64_t i = rs[q]; i < rs[q + 1]; ++i) { hl ^= (unsigned)glen[(size_t)i]; hl *= 1099511628211ull; }
+            fprintf(stderr, " | q%d node %016llx len %016llx first %d %d %d", q, h, hl, gnode[(size_t)eoff[(size_t)q]], gnode[(size_t)eoff[(size_t)q] + 1], glen[(size_t)rs[q]]);
+        }
+        fprintf(stderr, "\n");
+    }
+    if ((int64_t)gptr[(size_t)ng] - 1 != nnzg) return fail(SGM_ERR_RCCL, "gather_global_csr: %lld entries arrived, the row lengths say %lld", (long long)nnzg, (long long)gptr[(size_t)ng] - 1);
+    return SGM_OK;
+}
+
+// the handle's row block replaced by `rows` (1-based local ptr, global 1-based columns): same communicator and row partition, new
+// halo plan and kernel forms; the old block is freed
+static int replace_dist_rows(sgm_mat A, const std::vector<int32_t> &lptr, const std::vector<int32_t> &lnode, const std::vector<double> &lval)
+{
+    sgm_mat N = nullptr;
+    const int64_t nnz = (int64_t)lptr.back() - 1;
+    SGM_TRY(sgm_csr_create_dist_rect(&N, A->comm, A->row_starts.data(), A->col_starts.data(), nnz, lptr.data(), lnode.data(), lval.data(), SGM_HOST));
+    const bool had_xext = A->parts[0].xext != nullptr;
+    std::swap(A->parts, N->parts);
+    std::swap(A->halo_cols, N->halo_cols);
+    A->nnz = N->nnz;
+    sgm_mat_destroy(N);                  // (holds the old row block now)
+    if (had_xext && !A->parts[0].xext) SGM_TRY(dalloc(&A->parts[0].xext, (size_t)A->parts[0].xlen() + 2));
+    return sgm_invalidate_transpose(A);
+}
+
+// A%left_permute(p) (cs_matrices.f90:471-478: row i becomes row p(i), entries in their stored order) / A%right_permute(p)
+// (:483-490: column j becomes p(j)) on a matrix distributed over ranks; p = the GLOBAL permutation (1-based, host), the same on
+// every rank.  Collective.
+int permute_dist(sgm_mat A, const int32_t *p, bool left)
+{
+    if (!A->comm || A->fmt != SGM_FMT_CSR || A->parts.size() != 1)
+        return fail(SGM_ERR_UNSUPPORTED, "permutations over ranks: a CSR matrix made by sgm_csr_create_dist");
+    const int R = A->comm->nranks, me = A->comm->rank;
+    const int64_t ng = left ? A->row_starts[(size_t)R] : A->col_starts[(size_t)R];
+    std::vector<int32_t> pinv((size_t)std::max<int64_t>(ng, 1), 0);
+    for (int64_t i = 0; i < ng; ++i) {
+        const int32_t t = p[i];
+        if (t < 1 || t > ng || pinv[(size_t)t - 1]) return fail(SGM_ERR_BAD_ARG, "%s: p is not a permutation of 1..%lld (p(%lld) = %d)", left ? "left_permute" : "right_permute", (long long)ng, (long long)i + 1, t);
+        pinv[(size_t)t - 1] = (int32_t)(i + 1);
+    }
+    std::vector<int32_t> lptr, lnode;
+    std::vector<double> lval;
+    if (!left) {                         // my rows, their columns renamed: nothing travels
+        SGM_TRY(local_rows_global(A, lptr, lnode, &lval));
+        for (auto &v : lptr) v += 1;
+        const int64_t nnz = (int64_t)lptr.back() - 1;
+        for (int64_t k = 0; k < nnz; ++k) lnode[(size_t)k] = p[(size_t)lnode[(size_t)k] - 1];
+        return replace_dist_rows(A, lptr, lnode, lval);
+    }
+    std::vector<int32_t> gptr, gnode;
+    std::vector<double> gval;
+    SGM_TRY(gather_global_csr(A, gptr, gnode, &gval));
+    const int64_t r0 = A->row_starts[(size_t)me], r1 = A->row_starts[(size_t)me + 1];
+    lptr.assign((size_t)(r1 - r0) + 1, 1);
+    for (int64_t k = r0; k < r1; ++k) {
+        const int64_t old = (int64_t)pinv[(size_t)k] - 1;
+        lptr[(size_t)(k - r0) + 1] = lptr[(size_t)(k - r0)] + (gptr[(size_t)old + 1] - gptr[(size_t)old]);
+    }
+    const int64_t nnz = (int64_t)lptr.back() - 1;
+    lnode.assign((size_t)std::max<int64_t>(nnz, 1), 0);
+    lval.assign((size_t)std::max<int64_t>(nnz, 1), 0.0);
+    for (int64_t k = r0; k < r1; ++k) {
+        const int64_t old = (int64_t)pinv[(size_t)k] - 1;
+        const int64_t s = (int64_t)gptr[(size_t)old] - 1, e = (int64_t)gptr[(size_t)old + 1] - 1, dd = (int64_t)lptr[(size_t)(k - r0)] - 1;
+        std::copy(gnode.begin() + s, gnode.begin() + e, lnode.begin() + dd);
+        std::copy(gval.begin() + s, gval.begin() + e, lval.begin() + dd);
+    }
+    return replace_dist_rows(A, lptr, lnode, lval);
+}
+
+// the graph of a matrix distributed over ranks as a single-GPU CSR matrix on THIS rank (values 0): what the reference's
+// sequential orderings walk.  The caller destroys it.
+int gathered_graph(sgm_mat A, sgm_mat *out)
+{
+    std::vector<int32_t> gptr, gnode;
+    SGM_TRY(gather_global_csr(A, gptr, gnode, nullptr));
+    const int64_t nnz = (int64_t)gptr.back() - 1;
+    std::vector<double> zeros((size_t)std::max<int64_t>(nnz, 1), 0.0);
+    return sgm_csr_create(out, A->nrow, A->ncol, nnz, gptr.data(), gnode.data(), zeros.data(), SGM_HOST);
 }
 
 int matvec_t_dist(sgm_mat A, const double *x, double *y, int where, bool add)

@@ -665,14 +665,27 @@ int halo_attach_order(const Part &p, const int32_t *p1, const std::vector<std::p
 
 }  // namespace sgm
 
+namespace sgm {
+// (sgm_dist.hip) the same operations on a matrix distributed over ranks: the graph gathered onto every rank, rows moved between ranks
+int permute_dist(sgm_mat A, const int32_t *p_host_global, bool left);
+int gathered_graph(sgm_mat A, sgm_mat *out);
+}  // namespace sgm
+
 extern "C" {
 
 int sgm_graph_bfs_order(sgm_mat A, int32_t *p_out)
 {
     SGM_TRY(require_init());
     if (!A || !p_out) return fail(SGM_ERR_BAD_ARG, "sgm_graph_bfs_order: null argument");
+    if (A->fmt == SGM_FMT_CSR && A->comm) {          // over ranks: the whole graph on every rank, the single-GPU pass, the same p everywhere
+        sgm_mat G = nullptr;
+        SGM_TRY(gathered_graph(A, &G));
+        const int rc = sgm_graph_bfs_order(G, p_out);
+        sgm_mat_destroy(G);
+        return rc;
+    }
     if (A->fmt != SGM_FMT_CSR || A->distributed())
-        return fail(SGM_ERR_UNSUPPORTED, "sgm_graph_bfs_order: single-GPU CSR matrices only");
+        return fail(SGM_ERR_UNSUPPORTED, "sgm_graph_bfs_order: CSR matrices on one GPU or distributed over ranks (not in-process partitions)");
     if (A->nrow != A->ncol) return fail(SGM_ERR_BAD_ARG, "sgm_graph_bfs_order: the matrix graph must be square");
     const Part &pt = A->parts[0];
     const int32_t n = pt.n;
@@ -740,6 +753,11 @@ int sgm_graph_bfs_order(sgm_mat A, int32_t *p_out)
             ++levels;
             if (m > 0 && levels >= 16 && (int64_t)base < (int64_t)levels * 4096) { on_host = true; break; }
         }
+        // (the last level's numbering kernel may still be in flight on the library's NON-BLOCKING stream when the loop is left for
+        //  the host continuation: a blocking copy on the null stream does not wait for it.  Found in round 6 by three rank
+        //  processes sharing a GPU -- a quiet GPU finishes the kernel before the copy starts --: the visiting numbers came back one
+        //  level short and the host queue then numbered that level after the next one)
+        if (rc == SGM_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(SGM_ERR_HIP, "sgm_graph_bfs_order: the last level failed");
         if (rc == SGM_OK && (hipMemcpy(p_out, p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess || hipGetLastError() != hipSuccess))
             rc = fail(SGM_ERR_HIP, "sgm_graph_bfs_order: copy back failed");
         if (rc == SGM_OK && on_host) {
@@ -788,6 +806,13 @@ int sgm_graph_greedy_coloring(sgm_mat A, int32_t *colors_out, int32_t *num_color
 {
     SGM_TRY(require_init());
     if (!colors_out) return fail(SGM_ERR_BAD_ARG, "sgm_graph_greedy_coloring: null output");
+    if (A && A->fmt == SGM_FMT_CSR && A->comm) {     // over ranks: the whole graph on every rank, the same colours everywhere
+        sgm_mat G = nullptr;
+        SGM_TRY(gathered_graph(A, &G));
+        const int rc = sgm_graph_greedy_coloring(G, colors_out, num_colors);
+        sgm_mat_destroy(G);
+        return rc;
+    }
     {   // graphs whose colouring is forced (bipartite, symmetric, connected from vertex 1): on the device
         bool done = false;
         int32_t n1 = 0, nc = 0;
@@ -805,6 +830,13 @@ int sgm_graph_greedy_color_order(sgm_mat A, int32_t *p_out, int32_t *ptrs_out, i
 {
     SGM_TRY(require_init());
     if (!p_out || !num_colors) return fail(SGM_ERR_BAD_ARG, "sgm_graph_greedy_color_order: null output");
+    if (A && A->fmt == SGM_FMT_CSR && A->comm) {
+        sgm_mat G = nullptr;
+        SGM_TRY(gathered_graph(A, &G));
+        const int rc = sgm_graph_greedy_color_order(G, p_out, ptrs_out, ptrs_len, num_colors);
+        sgm_mat_destroy(G);
+        return rc;
+    }
     {
         bool done = false;
         int32_t n1 = 0, nc = 0;
@@ -844,8 +876,15 @@ int sgm_mat_left_permute(sgm_mat A, const int32_t *p, int where)
     if (!A || !p) return fail(SGM_ERR_BAD_ARG, "sgm_mat_left_permute: null argument");
     A->version += 1;
     A->pattern_version += 1;
+    if (A->fmt == SGM_FMT_CSR && A->comm) {          // over ranks: p is the GLOBAL permutation, the same on every rank (collective)
+        const int64_t ng = A->nrow;
+        std::vector<int32_t> hp((size_t)std::max<int64_t>(ng, 1));
+        if (where == SGM_DEVICE) SGM_HIP(hipMemcpy(hp.data(), p, (size_t)ng * 4, hipMemcpyDeviceToHost));
+        else std::copy(p, p + ng, hp.begin());
+        return permute_dist(A, hp.data(), true);
+    }
     if ((A->fmt != SGM_FMT_CSR && A->fmt != SGM_FMT_ELL) || A->distributed())
-        return fail(SGM_ERR_UNSUPPORTED, "sgm_mat_left_permute: single-GPU CSR / ELLPACK matrices only");
+        return fail(SGM_ERR_UNSUPPORTED, "sgm_mat_left_permute: CSR / ELLPACK matrices on one GPU, CSR matrices distributed over ranks");
     Part &pt = A->parts[0];
     const int32_t n = pt.n;
     hipStream_t st = g_rt.stream;
@@ -913,8 +952,15 @@ int sgm_mat_right_permute(sgm_mat A, const int32_t *p, int where)
     if (!A || !p) return fail(SGM_ERR_BAD_ARG, "sgm_mat_right_permute: null argument");
     A->version += 1;
     A->pattern_version += 1;
+    if (A->fmt == SGM_FMT_CSR && A->comm) {          // over ranks: p is the GLOBAL permutation, the same on every rank (collective)
+        const int64_t ng = A->ncol;
+        std::vector<int32_t> hp((size_t)std::max<int64_t>(ng, 1));
+        if (where == SGM_DEVICE) SGM_HIP(hipMemcpy(hp.data(), p, (size_t)ng * 4, hipMemcpyDeviceToHost));
+        else std::copy(p, p + ng, hp.begin());
+        return permute_dist(A, hp.data(), false);
+    }
     if ((A->fmt != SGM_FMT_CSR && A->fmt != SGM_FMT_ELL) || A->distributed())
-        return fail(SGM_ERR_UNSUPPORTED, "sgm_mat_right_permute: single-GPU CSR / ELLPACK matrices only");
+        return fail(SGM_ERR_UNSUPPORTED, "sgm_mat_right_permute: CSR / ELLPACK matrices on one GPU, CSR matrices distributed over ranks");
     Part &pt = A->parts[0];
     int32_t *dp = nullptr;
     SGM_TRY(stage_perm("sgm_mat_right_permute", A->ncol, p, where, &dp));

@@ -2741,7 +2741,8 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
             SGM_TRY(halo_attach_order(A->parts[ip], R.perm, seg, R.hmap_host));
             if (!R.hmap_host.empty()) {
                 SGM_TRY(dalloc(&R.hmap, R.hmap_host.size()));
-                SGM_HIP(hipMemcpy(R.hmap, R.hmap_host.data(), R.hmap_host.size() * 4, hipMemcpyHostToDevice));
+                SGM_HIP(hipMemcpyAsync(R.hmap, R.hmap_host.data(), R.hmap_host.size() * 4, hipMemcpyHostToDevice, g_rt.stream));
+                SGM_HIP(hipStreamSynchronize(g_rt.stream));
             }
         }
         if (A->comm) SGM_TRY(exchange_halo_orders(A, pc->ro[0].hmap_host, pc->ro[0].send_order));
@@ -2756,7 +2757,8 @@ int sgm_pc_setup(sgm_pc pc, sgm_mat A)
                     std::vector<int32_t> rel((size_t)nb.send_count);
                     for (int32_t t = 0; t < nb.send_count; ++t) rel[(size_t)t] = hm[(size_t)nb.recv_offset + t] - nb.recv_offset;
                     SGM_TRY(dalloc(&S.send_order[k], (size_t)nb.send_count));
-                    SGM_HIP(hipMemcpy(S.send_order[k], rel.data(), (size_t)nb.send_count * 4, hipMemcpyHostToDevice));
+                    SGM_HIP(hipMemcpyAsync(S.send_order[k], rel.data(), (size_t)nb.send_count * 4, hipMemcpyHostToDevice, g_rt.stream));
+                    SGM_HIP(hipStreamSynchronize(g_rt.stream));
                 }
             }
         undo.armed = false;

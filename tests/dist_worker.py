@@ -50,6 +50,8 @@ def run(rank, world, port, case, res):
         comm = sg.Comm(rank, world, uid[0])
         res["group_ok"] = comm.group_ok          # sgm_comm_init's probe: pairs + all-reduce in one group on this transport
 
+        reorder_only = case.endswith("+reorder")
+        case = case.replace("+reorder", "")
         if case == "composite":
             run_composite(rank, world, comm, dev, res)
             comm.destroy()
@@ -132,6 +134,80 @@ def run(rank, world, port, case, res):
                 assert nb["recv_offset"] == l["recv_offset"] and nb["recv_count"] == len(l["send_idx"])
         assert sum(1 for nb in nbrs if nb["recv_count"]) == len(to_me)
 
+        bl_box = [None]
+        def reorder_checks(H, out, bl_holder):
+            """re-orderings and permutations of the matrix distributed over the ranks (see below)"""
+            # ---- re-orderings and permutations of the matrix distributed over the ranks (permutations.f90:22-205, cs_matrices.f90:
+            #      471-490): every rank gets the reference's p / colours for the WHOLE graph, and after A%left_permute(p) /
+            #      A%right_permute(p) every rank holds its row block of the reference's permuted matrix -- products bit for bit, then
+            #      a solve on the permuted system
+            pb = H.bfs_order()
+            pbo = orc.bfs_order(A)
+            if not np.array_equal(pb, pbo):
+                Hs = sg.csr_matrix(n, n, ptr, node, val)
+                single = bool(np.array_equal(Hs.bfs_order(), pbo))
+                got_rows = {}
+                for nm, dt in (("ptr", np.int32), ("node", np.int32)):
+                    got_rows[nm] = Hs.get(nm, dt)
+                Hs.destroy()
+                print(f"[diag] single-GPU bfs on the same matrix equals the oracle: {single}", flush=True)
+                bad_i = np.nonzero(pb != pbo)[0]
+                raise AssertionError(f"bfs_order over ranks differs from breadth_first_search: {bad_i.size} of {n} entries, first at {bad_i[:5]}: "
+                                     f"{pb[bad_i[:5]]} vs {pbo[bad_i[:5]]}; ours is a permutation: {np.array_equal(np.sort(pb), np.arange(1, n + 1))}; single-GPU bfs ok: {single}")
+            col, ncol_ = H.greedy_coloring()
+            assert np.array_equal(col, orc.greedy_coloring(A)) and ncol_ == int(col.max())
+            perm = None
+            if case in ("poisson2d", "laplace3d"):
+                perm, ptrs, nc_ = H.greedy_color_ordering()
+                po, ptro, nco = orc.greedy_color_ordering(A)
+                assert nc_ == nco and np.array_equal(perm, po) and np.array_equal(ptrs, ptro)
+            else:
+                perm = (np.random.RandomState(77).permutation(n) + 1).astype(np.int32)      # any permutation: rows cross every rank boundary
+            Ap = orc.permuted(A, perm, perm)
+            H.left_permute(perm)
+            H.right_permute(perm)
+            xq = np.random.RandomState(9).standard_normal(n)
+            xeq = np.zeros(H.x_len)
+            xeq[:n_own] = xq[r0:r1]
+            yq = np.zeros(n_own)
+            H.matvec(xeq, yq)
+            assert np.array_equal(yq, Ap.matvec(xq)[r0:r1]), "rows of P A P^T over ranks differ from the reference's permuted matrix"
+            tq = np.zeros(n_own)
+            H.matvec_t(xq[r0:r1].copy(), tq)
+            assert np.array_equal(tq, Ap.matvec_t(xq)[r0:r1]), "transposed product of the permuted distributed matrix"
+            if case != "random":
+                bq = np.empty(n); bq[perm - 1] = b
+                bl_holder[0] = bq[r0:r1].copy()
+                check("cg_on_permuted", sg.cg(1e-13), None, orc.cg(Ap, bq, tol=1e-13), lambda i: 1, 1e-10 if case == "longrows" else 1e-12)
+            out["reorderings_over_ranks"] = {"iterations": 0, "bfs": True, "colours": int(ncol_), "permuted_products_bit_exact": True}
+
+        if reorder_only:
+            b = np.full(n, 1.0 / n)
+            out = {}
+
+            def check(name, solver, pc_mk, ref, it_tol, rel_tol):
+                ur, itr = ref[0], ref[1]
+                solver.setup(H)
+                u = np.zeros(n_own)
+                solver.solve(H, u, bl_box[0], None)
+                rel = float(np.abs(u - ur[r0:r1]).max() / np.abs(ur).max())
+                out[name] = {"iterations": int(solver.iterations), "oracle_iterations": int(itr), "rel": rel}
+                assert abs(solver.iterations - itr) <= it_tol(itr) and rel <= rel_tol, (name, solver.iterations, itr, rel)
+                solver.destroy()
+            reorder_checks(H, out, bl_box)
+            res["solves"] = out
+            H.destroy()
+            comm.destroy()
+            return
+
+        def probe(label):
+            """SGM_WORKER_PROBE: after which section does the graph gathered over the ranks stop being the matrix's?"""
+            if not os.environ.get("SGM_WORKER_PROBE"):
+                return
+            okp = bool(np.array_equal(H.bfs_order(), orc.bfs_order(A)))
+            print(f"[probe] rank {rank} after {label}: bfs over ranks equals the oracle's: {okp}", flush=True)
+
+        probe("creation")
         # ---- matvec: host vectors, then device tensors; rows bit-identical to the serial matvec
         x = P.test_vector(n) if case != "random" else np.random.RandomState(1).standard_normal(n)
         y_ref = A.matvec(x)[r0:r1]
@@ -152,6 +228,7 @@ def run(rank, world, port, case, res):
         H.matvec_add(xe, ya)
         assert np.array_equal(ya, A.matvec_add(x, y0.copy())[r0:r1])
 
+        probe("matvec")
         # ---- transpose products: A^T built once as another distributed matrix (entries travel to the owner of
         #      their column); every y(i) sums the reference scatter's terms in the reference's order
         xt = np.random.RandomState(11).standard_normal(n)
@@ -166,6 +243,7 @@ def run(rank, world, port, case, res):
         H.matvec_t(torch.from_numpy(xt[r0:r1].copy()).to(dev), td)
         assert np.array_equal(td.cpu().numpy(), t_ref[r0:r1])
 
+        probe("transpose")
         # ---- the same matrix created from DEVICE arrays (what bench.py --workload c5 does)
         H2 = sg.dist_csr_matrix(comm, starts, torch.from_numpy(lptr).to(dev), torch.from_numpy(lnode_g).to(dev),
                                 torch.from_numpy(lval).to(dev))
@@ -174,6 +252,7 @@ def run(rank, world, port, case, res):
         assert np.array_equal(yd.cpu().numpy(), y_ref)
         H2.destroy()
 
+        probe("device-array twin")
         # ---- ELLPACK rows (padding slots included) through the same machinery: sgm_ell_create_dist
         ne = 4000
         E = orc.EllMatrix.from_edges(ne, ne, *P.random_regular_ell(ne, 12, 99, dmin=7))
@@ -214,6 +293,7 @@ def run(rank, world, port, case, res):
         pcE.destroy()
         He.destroy()
 
+        probe("ellpack section")
         # ---- Krylov loops with all-reduced dots
         b = np.full(n, 1.0 / n) if case != "random" else P.test_vector(n)
         bl = b[r0:r1].copy()
@@ -226,7 +306,7 @@ def run(rank, world, port, case, res):
             if pc is not None:
                 pc.setup(H)
             u = np.zeros(n_own)
-            solver.solve(H, u, bl, pc)
+            solver.solve(H, u, bl if bl_box[0] is None else bl_box[0], pc)      # (bl_box: the right-hand side of the permuted system, set by reorder_checks)
             rel = float(np.abs(u - ur[r0:r1]).max() / np.abs(ur).max())
             out[name] = {"iterations": int(solver.iterations), "oracle_iterations": int(itr), "rel": rel}
             assert abs(solver.iterations - itr) <= it_tol(itr), (name, solver.iterations, itr)
@@ -248,6 +328,7 @@ def run(rank, world, port, case, res):
             Ab = orc.CsrMatrix(n, n, np.concatenate([[1], 1 + np.cumsum(cnt)]).astype(np.int32), node[keep].copy(), val[keep].copy())
             check("cg_ildu_blockjacobi", sg.cg(1e-12), sg.ldu, orc.cg(A, b, tol=1e-12, pc=orc.Ildu(Ab)), lambda i: 1, max(rt, 1e-11))
             check("bicgstab", sg.bicgstab(1e-13), None, orc.bicgstab(A, b, tol=1e-13), lambda i: max(2, 0.1 * i), max(rt, 1e-11))
+            probe("first solver checks")
             # ---- option dist_halo_fused: p's halo formed locally from the boundary rows of r (z) that travel beside the
             #      all-reduce of r.r (r.z) -- 1: one group with it, 2: a group of its own -- against 0, p exchanged by every
             #      product: the same bits, iterate for iterate
@@ -271,6 +352,7 @@ def run(rank, world, port, case, res):
                 u0, it0, hist0 = fused[(nm, 0)]
                 assert it == it0 and np.array_equal(u, u0) and np.array_equal(hist, hist0), ("dist_halo_fused", nm, mode, it, it0)
             out["halo_fused_modes"] = {"iterations": fused[("cg", 1)][1], "bit_identical_to_exchanging_p": True}
+            probe("halo_fused modes")
             # ---- ldu(reorder="colour") over the ranks: every rank orders its own diagonal block (greedy_color_ordering of
             #      A_kk's graph, no communication), block-Jacobi ILDU(0) of the ordered blocks, the solve in the permuted
             #      order rank by rank.  Oracle: the same ordering block by block, A permuted by it, PCG with ILDU(0) of its
@@ -305,6 +387,7 @@ def run(rank, world, port, case, res):
         else:
             check("bicgstab_jacobi", sg.bicgstab(1e-12), sg.jacobi, orc.bicgstab(A, b, tol=1e-12, pc=orc.Jacobi(A)),
                   lambda i: max(2, 0.1 * i), 1e-10)
+        probe("colour ildu")
         # ---- Lanczos over the ranks (SURVEY 8(f3) on a partitioned matrix): every rank its owned slice of q1 and Q, dots
         #      all-reduced, T the same everywhere; against the oracle's serial run
         if case in ("poisson2d", "laplace3d"):
@@ -325,6 +408,7 @@ def run(rank, world, port, case, res):
             out["generalized_lanczos"] = {"iterations": 12, "T_max_diff": float(np.abs(Tg - Tgo).max())}
             HB.destroy()
 
+        probe("lanczos")
         # ---- dot_order = 1: the running sum of every dot travels rank 0 -> 1 -> ... and each rank continues it over its
         #      own rows: the distributed iterates are BIT-IDENTICAL to the serial ones (the oracle's left-to-right dots)
         sg.set_option("dot_order", 1)
@@ -353,6 +437,7 @@ def run(rank, world, port, case, res):
         finally:
             sg.set_option("dot_order", 0)
         check("gmres30", sg.gmres(1e-12, 30), None, orc.gmres(A, b, tol=1e-12, restart=30), lambda i: 2, 1e-9 if case == "longrows" else 1e-10)
+        reorder_checks(H, out, bl_box)
         res["solves"] = out
         H.destroy()
         comm.destroy()

@@ -135,6 +135,17 @@ def test_a_transport_that_refuses_the_mixed_group_is_found_at_comm_init_and_work
     assert results[0]["solves"]["halo_fused_modes"]["bit_identical_to_exchanging_p"] is True
 
 
+@pytest.mark.parametrize("world,case", [(2, "poisson2d"), (3, "laplace3d"), (4, "poisson2d"), (3, "random"), (3, "longrows"), (8, "laplace3d")])
+def test_reorderings_and_permutations_over_ranks(world, case, tmp_path):
+    """breadth_first_search / greedy_coloring / greedy_color_ordering (permutations.f90:22-205) and A%left_permute / right_permute
+    (cs_matrices.f90:471-490) on a matrix distributed over ranks (VERDICT r05 missing #5): every rank gets the reference's p /
+    colours of the WHOLE graph; after the permutation every rank holds its row block of the reference's permuted matrix --
+    products and transposed products bit for bit, CG on the permuted system against the oracle.  (The same checks close every
+    run of the full worker; this is the quick form: creation + these.)"""
+    results = _run_ranks(world, case + "+reorder", tmp_path, mock=True)
+    assert all(r["solves"]["reorderings_over_ranks"]["permuted_products_bit_exact"] for r in results)
+
+
 @pytest.mark.parametrize("world,seed0", [(2, 300000), (3, 300100), (4, 300200), (8, 300300)])
 def test_rank_fuzz_seeds(world, seed0, tmp_path):
     """tests/dist_worker.py `fuzz:<seed>:<count>`: seeded systems of tests/fuzz_solvers.py's generator over ranks with RANDOM
