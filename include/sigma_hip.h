@@ -259,6 +259,12 @@ int sgm_mat_info(sgm_mat A, int32_t *nrow, int32_t *ncol, int64_t *nnz, int32_t 
  * colouring (option "coloring_pass": parities by union-find for a bipartite graph, else a level sweep
  * that reproduces the sequential pass's order- and tally-dependent choices; the reference's own
  * sequential pass on the host is the last resort and the checker) -- the same colours whichever.
+ * On a CSR matrix DISTRIBUTED OVER RANKS (sgm_csr_create_dist; round 6) the three orderings and the two permutations below are
+ * collective: the whole index structure is gathered onto every rank once (one grouped exchange, host memory for the length of the
+ * call), the orderings run by the single-GPU passes on every rank (the same p / colours everywhere, arrays of the GLOBAL nrow),
+ * left_permute cuts this rank's NEW rows out of the gathered matrix and rebuilds the handle's row block (same row partition, new halo
+ * plan), right_permute renames this rank's columns without any exchange; p is the global permutation, the same on every rank.  A
+ * setup path for matrices one rank can hold; in-process partitions are refused.
  * sgm_mat_left_permute(A, p)   A%left_permute(p)   cs_matrices.f90:471-478: row i -> row p(i)
  * sgm_mat_right_permute(A, p)  A%right_permute(p)  cs_matrices.f90:483-490: column j -> p(j)
  *                              (ELLPACK handles too: ellpack_matrices.f90:601-632)
