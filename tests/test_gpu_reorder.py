@@ -343,3 +343,34 @@ def test_graph_fuzzer_seeds(seed):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import fuzz_graphs
     assert fuzz_graphs.one(seed, verbose=False) == []
+
+
+def test_breadth_first_order_while_other_processes_keep_the_gpu_busy(orc):
+    """Regression for the stream race round 6 found in sgm_graph_bfs_order: when the level loop hands over to the host queue (grids:
+    after 16 levels), the blocking copy-back of the visiting numbers did not wait for the last level's numbering kernel on the
+    library's non-blocking stream.  A quiet GPU finishes the kernel first; with other processes taking the GPU's time the numbers
+    came back one level short (seen as `bfs_order` of one and the same graph flickering inside three rank processes).  Here two
+    child processes run matrix products for a few seconds while this one orders the 24 x 20 x 30 grid forty times: every result is
+    the oracle's."""
+    nx, ny, nz = 24, 20, 30
+    n = nx * ny * nz
+    ptr, node, val = P.laplace3d_csr(nx, ny, nz)
+    A = orc.CsrMatrix(n, n, ptr, node, val)
+    want = orc.bfs_order(A)
+    H = sg.csr_matrix(n, n, ptr, node, val)
+    busy = ("import torch, time\n"
+            "a = torch.randn(4096, 4096, device='cuda'); t0 = time.time()\n"
+            "while time.time() - t0 < 12.0:\n"
+            "    for _ in range(20): b = a @ a\n"
+            "    torch.cuda.synchronize()\n")
+    kids = [subprocess.Popen([sys.executable, "-c", busy], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for _ in range(2)]
+    try:
+        import time
+        time.sleep(3.0)                       # (their contexts are up and their kernels are queued)
+        wrong = [k for k in range(40) if not np.array_equal(H.bfs_order(), want)]
+        assert not wrong, f"bfs_order differed from breadth_first_search in runs {wrong} of 40"
+    finally:
+        for p in kids:                        # the exact PIDs started here
+            p.kill()
+            p.wait()
+    H.destroy()
