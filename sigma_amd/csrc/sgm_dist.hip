@@ -1260,17 +1260,13 @@ int gather_global_csr(sgm_mat A, std::vector<int32_t> &gptr, std::vector<int32_t
     SGM_HIP(hipStreamSynchronize(st));
     gptr.assign((size_t)ng + 1, 1);
     for (int64_t i = 0; i < ng; ++i) gptr[(size_t)i + 1] = gptr[(size_t)i] + glen[(size_t)i];
-    if (trace_on()) {
-        fprintf(stderr, "[sigma_hip] gather_global_csr rank %d: n %d nnz %lld ng %lld nnzg %lld cnt", me, n, (long long)nnz, (long long)ng, (long long)nnzg);
-        for (int q = 0; q < R; ++q) fprintf(stderr, " %d", cnt[(size_t)q]);
-        for (int q = 0; q < R; ++q) {
-            unsigned long long h = 1469598103934665603ull, hl = 1469598103934665603ull;
+    if (trace_on())          // (one line per gather and rank: what arrived, by rank of origin -- equal lines on every rank)
+        for (int q = 0; q < R && q < 8; ++q) {
+            unsigned long long h = 1469598103934665603ull;
             for (int64_t k = eoff[(size_t)q]; k < eoff[(size_t)q + 1]; ++k) { h ^= (unsigned)gnode[(size_t)k]; h *= 1099511628211ull; }
-            for (int64_t i = rs[q]; i < rs[q + 1]; ++i) { hl ^= (unsigned)glen[(size_t)i]; hl *= 1099511628211ull; }
-            fprintf(stderr, " | q%d node %016llx len %016llx first %d %d %d", q, h, hl, gnode[(size_t)eoff[(size_t)q]], gnode[(size_t)eoff[(size_t)q] + 1], glen[(size_t)rs[q]]);
+            fprintf(stderr, "[sigma_hip] gather_global_csr rank %d: rows %lld..%lld of rank %d, %d entries, columns' hash %016llx\n", me,
+                    (long long)rs[q], (long long)rs[q + 1], q, cnt[(size_t)q], h);
         }
-        fprintf(stderr, "\n");
-    }
     if ((int64_t)gptr[(size_t)ng] - 1 != nnzg) return fail(SGM_ERR_RCCL, "gather_global_csr: %lld entries arrived, the row lengths say %lld", (long long)nnzg, (long long)gptr[(size_t)ng] - 1);
     return SGM_OK;
 }

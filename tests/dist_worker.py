@@ -146,9 +146,6 @@ def run(rank, world, port, case, res):
             if not np.array_equal(pb, pbo):
                 Hs = sg.csr_matrix(n, n, ptr, node, val)
                 single = bool(np.array_equal(Hs.bfs_order(), pbo))
-                got_rows = {}
-                for nm, dt in (("ptr", np.int32), ("node", np.int32)):
-                    got_rows[nm] = Hs.get(nm, dt)
                 Hs.destroy()
                 print(f"[diag] single-GPU bfs on the same matrix equals the oracle: {single}", flush=True)
                 bad_i = np.nonzero(pb != pbo)[0]
