@@ -487,6 +487,17 @@ int sgm_partition_links_host(int32_t nparts, const int64_t *row_starts, const in
                              int64_t *idx_needed);
 int sgm_partition_rows_by_nnz(int32_t nrow, const int32_t *ptr_1based, int32_t nparts, int32_t align,
                               int64_t *row_starts_out);
+/* Two more pieces of host-only index work, exported like the planners above so that the CPU suite (and the sanitizer build,
+ * tools/asan) drives the statements the library runs:
+ * sgm_ell_degrees_host        degrees(n) of an ELLPACK graph recovered from the padding the reference keeps (ellpack_graphs.f90:164,
+ *                             :394-397: the rest of a row repeats the neighbour just added; a row of zeros is empty) -- what
+ *                             sgm_ell_create / sgm_ell_create_dist do, since the product's interface carries no degrees
+ * sgm_left_permute_rows_host  rows [r0, r1) (0-based) of A%left_permute(p) (cs_matrices.f90:471-478) cut out of the whole matrix:
+ *                             what a rank keeps of a permuted matrix distributed over ranks.  lnode == NULL: sizing call. */
+int sgm_ell_degrees_host(int32_t n, int32_t max_d, const int32_t *node_1based_colmajor, int32_t *degrees_out);
+int sgm_left_permute_rows_host(int32_t n, const int32_t *p_1based, const int32_t *ptr_1based, const int32_t *node_1based,
+                               const double *val, int64_t r0, int64_t r1, int32_t *lptr_out, int32_t *lnode_out,
+                               double *lval_out, int64_t capacity, int64_t *needed);
 int sgm_mat_halo_nbr(sgm_mat A, int32_t part, int32_t k, int32_t *n_nbrs, int32_t *peer, int32_t *send_count,
                      int32_t *recv_count, int32_t *recv_offset, int32_t *send_idx_host, int32_t capacity);
 

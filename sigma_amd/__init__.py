@@ -986,6 +986,35 @@ def partition_rows_by_nnz(ptr, nparts, align=512):
     return rs
 
 
+def ell_degrees_host(node):
+    """sgm_ell_degrees_host: degrees(n) of an ELLPACK graph (node as (n, max_d) = the reference's (max_d, n), 1-based) recovered
+    from the padding the reference keeps -- what sgm_ell_create does, since the product's interface carries no degrees."""
+    node = np.ascontiguousarray(node, np.int32)
+    n, md = node.shape
+    deg = np.zeros(max(n, 1), np.int32)
+    _ck(lib().sgm_ell_degrees_host(C.c_int32(n), C.c_int32(md), C.c_void_p(node.ctypes.data), C.c_void_p(deg.ctypes.data)))
+    return deg[:n]
+
+
+def left_permute_rows_host(p, ptr, node, val, r0, r1):
+    """sgm_left_permute_rows_host: rows [r0, r1) (0-based) of A%left_permute(p) cut out of the whole matrix (1-based ptr / node):
+    what a rank keeps of a permuted matrix distributed over ranks.  Returns (lptr, lnode, lval)."""
+    p = np.ascontiguousarray(p, np.int32)
+    ptr = np.ascontiguousarray(ptr, np.int32)
+    node = np.ascontiguousarray(node, np.int32)
+    val = np.ascontiguousarray(val, np.float64)
+    n = len(ptr) - 1
+    lptr = np.zeros(r1 - r0 + 1, np.int32)
+    need = C.c_int64(0)
+    args = (C.c_int32(n), C.c_void_p(p.ctypes.data), C.c_void_p(ptr.ctypes.data), C.c_void_p(node.ctypes.data),
+            C.c_void_p(val.ctypes.data), C.c_int64(r0), C.c_int64(r1), C.c_void_p(lptr.ctypes.data))
+    _ck(lib().sgm_left_permute_rows_host(*args, None, None, C.c_int64(0), C.byref(need)))
+    lnode = np.zeros(max(need.value, 1), np.int32)
+    lval = np.zeros(max(need.value, 1), np.float64)
+    _ck(lib().sgm_left_permute_rows_host(*args, C.c_void_p(lnode.ctypes.data), C.c_void_p(lval.ctypes.data), C.c_int64(need.value), None))
+    return lptr, lnode[:need.value], lval[:need.value]
+
+
 def slice_sched_host(n_slices, period_rows, grid, band_slices=64):
     """sgm_slice_sched_host: the order in which `grid` workgroups take the 512-row slices of a sliced
     matrix whose rows carry a far offset of `period_rows`; returns the (iters, grid) int32 table

@@ -426,6 +426,15 @@ int sgm_partition_rows_by_nnz(int32_t nrow, const int32_t *ptr, int32_t nparts, 
 {
     return host_partition_rows_by_nnz(nrow, ptr, nparts, align, row_starts);
 }
+int sgm_ell_degrees_host(int32_t n, int32_t max_d, const int32_t *node, int32_t *deg)
+{
+    return host_ell_degrees_host(n, max_d, node, deg);
+}
+int sgm_left_permute_rows_host(int32_t n, const int32_t *p, const int32_t *ptr, const int32_t *node, const double *val, int64_t r0,
+                               int64_t r1, int32_t *lptr, int32_t *lnode, double *lval, int64_t capacity, int64_t *needed)
+{
+    return host_left_permute_rows_host(n, p, ptr, node, val, r0, r1, lptr, lnode, lval, capacity, needed);
+}
 
 int sgm_csr_create_partitioned(sgm_mat *out, int32_t nparts, const int64_t *row_starts, int32_t nrow,
                                int32_t ncol, int64_t nnz, const int32_t *ptr, const int32_t *node,
@@ -927,14 +936,7 @@ int sgm_ell_create_dist(sgm_mat *out, sgm_comm comm, const int64_t *row_starts, 
     // degrees(i), recovered from the padding the reference keeps (k_ell_degrees, sgm_mat.hip): what an ILDU(0) setup on these
     // rows goes by -- the reference's pattern pass and fill read the real entries only (ellpack_graphs.f90:310-369)
     std::vector<int32_t> hdeg((size_t)std::max(n, 1), 0);
-    for (int32_t i = 0; i < n && max_d; ++i) {
-        const int32_t *row = hnode.data() + (size_t)i * max_d;
-        const int32_t last = row[max_d - 1];
-        int32_t d = 0;
-        if (last != 0)
-            for (d = 1; d < max_d && row[d - 1] != last; ++d) {}
-        hdeg[i] = d;
-    }
+    SGM_TRY(host_ell_degrees_host(n, max_d, hnode.data(), hdeg.data()));
     for (int32_t i = 0; i < n; ++i)
         for (int32_t k = 0; k < max_d; ++k)
             if (hnode[(size_t)i * max_d + k] <= 0) hnode[(size_t)i * max_d + k] = (int32_t)(r0 + i + 1);
@@ -1316,19 +1318,11 @@ int permute_dist(sgm_mat A, const int32_t *p, bool left)
     SGM_TRY(gather_global_csr(A, gptr, gnode, &gval));
     const int64_t r0 = A->row_starts[(size_t)me], r1 = A->row_starts[(size_t)me + 1];
     lptr.assign((size_t)(r1 - r0) + 1, 1);
-    for (int64_t k = r0; k < r1; ++k) {
-        const int64_t old = (int64_t)pinv[(size_t)k] - 1;
-        lptr[(size_t)(k - r0) + 1] = lptr[(size_t)(k - r0)] + (gptr[(size_t)old + 1] - gptr[(size_t)old]);
-    }
-    const int64_t nnz = (int64_t)lptr.back() - 1;
+    int64_t nnz = 0;
+    SGM_TRY(host_left_permute_rows_host((int32_t)ng, p, gptr.data(), gnode.data(), gval.data(), r0, r1, lptr.data(), nullptr, nullptr, 0, &nnz));
     lnode.assign((size_t)std::max<int64_t>(nnz, 1), 0);
     lval.assign((size_t)std::max<int64_t>(nnz, 1), 0.0);
-    for (int64_t k = r0; k < r1; ++k) {
-        const int64_t old = (int64_t)pinv[(size_t)k] - 1;
-        const int64_t s = (int64_t)gptr[(size_t)old] - 1, e = (int64_t)gptr[(size_t)old + 1] - 1, dd = (int64_t)lptr[(size_t)(k - r0)] - 1;
-        std::copy(gnode.begin() + s, gnode.begin() + e, lnode.begin() + dd);
-        std::copy(gval.begin() + s, gval.begin() + e, lval.begin() + dd);
-    }
+    SGM_TRY(host_left_permute_rows_host((int32_t)ng, p, gptr.data(), gnode.data(), gval.data(), r0, r1, lptr.data(), lnode.data(), lval.data(), nnz, nullptr));
     return replace_dist_rows(A, lptr, lnode, lval);
 }
 

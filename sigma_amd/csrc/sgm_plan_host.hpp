@@ -215,6 +215,58 @@ inline int host_partition_rows_by_nnz(int32_t nrow, const int32_t *ptr, int32_t 
 }
 
 
+// ------------------------------------------------------------------ ELLPACK degrees, rows of a permuted matrix
+// degrees(i) of an ELLPACK row as the reference holds it (ellpack_graphs.f90:14-21): add_edge / graph_build set the whole rest of
+// the row to the neighbour just added (`g%node(d+1:, i) = j`, :164,:394-397) and never store a neighbour twice, so the last slot
+// holds the last real neighbour and its FIRST occurrence is slot degrees(i); an empty row keeps node(:, i) = 0.  (The device twin
+// is k_ell_degrees, sgm_mat.hip.)  node: (max_d, n) as the Fortran holds it, 1-based.
+inline int host_ell_degrees_host(int32_t n, int32_t max_d, const int32_t *node, int32_t *deg)
+{
+    if (n < 0 || max_d < 0 || (n && max_d && !node) || (n && !deg)) return fail(SGM_ERR_BAD_ARG, "sgm_ell_degrees_host: bad argument");
+    for (int32_t i = 0; i < n; ++i) {
+        int32_t d = 0;
+        if (max_d) {
+            const int32_t *row = node + (size_t)i * max_d;
+            const int32_t last = row[max_d - 1];
+            if (last != 0)
+                for (d = 1; d < max_d && row[d - 1] != last; ++d) {}
+        }
+        deg[i] = d;
+    }
+    return SGM_OK;
+}
+// Rows [r0, r1) (0-based) of A%left_permute(p) (cs_matrices.f90:471-478: row i becomes row p(i), its entries in their stored
+// order) cut out of the whole matrix (1-based ptr / node as the reference holds them): what a rank keeps of a permuted matrix
+// distributed over ranks.  lptr: r1 - r0 + 1 entries, 1-based; lnode / lval: `capacity` entries; *needed = entries of the rows.
+inline int host_left_permute_rows_host(int32_t n, const int32_t *p, const int32_t *ptr, const int32_t *node, const double *val,
+                                       int64_t r0, int64_t r1, int32_t *lptr, int32_t *lnode, double *lval, int64_t capacity,
+                                       int64_t *needed)
+{
+    if (n < 0 || !p || !ptr || r0 < 0 || r1 < r0 || r1 > n || !lptr) return fail(SGM_ERR_BAD_ARG, "sgm_left_permute_rows_host: bad argument");
+    std::vector<int32_t> pinv((size_t)std::max(n, 1), 0);
+    for (int32_t i = 0; i < n; ++i) {
+        const int32_t t = p[i];
+        if (t < 1 || t > n || pinv[(size_t)t - 1]) return fail(SGM_ERR_BAD_ARG, "left_permute: p is not a permutation of 1..%d (p(%d) = %d)", n, i + 1, t);
+        pinv[(size_t)t - 1] = i + 1;
+    }
+    lptr[0] = 1;
+    for (int64_t k = r0; k < r1; ++k) {
+        const int64_t old = (int64_t)pinv[(size_t)k] - 1;
+        lptr[(size_t)(k - r0) + 1] = lptr[(size_t)(k - r0)] + (ptr[(size_t)old + 1] - ptr[(size_t)old]);
+    }
+    const int64_t nnz = (int64_t)lptr[(size_t)(r1 - r0)] - 1;
+    if (needed) *needed = nnz;
+    if (!lnode) return SGM_OK;                       // sizing call
+    if (capacity < nnz || (nnz && (!node || !val || !lval))) return fail(SGM_ERR_BAD_ARG, "sgm_left_permute_rows_host: %lld entries do not fit %lld", (long long)nnz, (long long)capacity);
+    for (int64_t k = r0; k < r1; ++k) {
+        const int64_t old = (int64_t)pinv[(size_t)k] - 1;
+        const int64_t s = (int64_t)ptr[(size_t)old] - 1, e = (int64_t)ptr[(size_t)old + 1] - 1, dd = (int64_t)lptr[(size_t)(k - r0)] - 1;
+        std::copy(node + s, node + e, lnode + dd);
+        std::copy(val + s, val + e, lval + dd);
+    }
+    return SGM_OK;
+}
+
 // ---- slice schedule ---------------------------------------------------------------------------------
 // A 3-D grid's rows reference x a whole plane away (offset +-D, D >> one slice).  With slices handed out round-robin or
 // block-cyclic, the slices D rows apart -- which read the same x lines -- run on different XCDs, so every x line enters

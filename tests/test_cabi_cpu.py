@@ -126,6 +126,8 @@ NOT_FOR_A_FORTRAN_HOST = {
     "sgm_partition_links_host": "same",
     "sgm_mat_halo_nbr": "reads the exchange plan of a built matrix back for the parity tests",
     "sgm_slice_sched_host": "the slice schedule as a host table, so that a CPU test can check it is a permutation",
+    "sgm_ell_degrees_host": "host-only index work (the degrees of an ELLPACK graph from its padding), exported for the CPU tests",
+    "sgm_left_permute_rows_host": "host-only index work (a rank's rows of a permuted matrix), exported for the CPU tests",
     "sgm_comm_group_ok": "reads back what sgm_comm_init's probe of the transport found, for the GPU tests and bench.py",
     "sgm_comm_group_selftest": "a transport probe (does this RCCL take a group of send / recv + all-reduce?) for the GPU tests",
 }

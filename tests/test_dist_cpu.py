@@ -247,3 +247,53 @@ def test_rectangular_leaf_planners_without_any_transport():
             xext = np.concatenate([x[c0:c0 + nc], x[halo - 1]])
             A_loc = orc.CsrMatrix(L.shape[0], nc + len(halo), (L.indptr + 1).astype(np.int32), lnode, L.data.copy())
             assert np.array_equal(A_loc.matvec(xext), y_ref[int(rs[r]):int(rs[r + 1])]), (world, r)
+
+
+def test_ell_degrees_recovered_from_the_padding_equal_the_graph_builds():
+    """sgm_ell_degrees_host (what sgm_ell_create / sgm_ell_create_dist run: the product's interface has no degrees argument)
+    against the degrees the oracle's restatement of ellpack_graph_build keeps (ellpack_graphs.f90:105-170): random graphs with
+    ragged rows (padding = the last neighbour repeated), full rows, rows without any edge (node(:, i) = 0), a one-slot graph."""
+    sys.path.insert(0, ROOT)
+    import oracle as orc
+    import sigma_amd as sg
+    from sigma_amd import problems as P
+    rs = np.random.RandomState(5)
+    cases = [P.random_regular_ell(700, 12, 99, dmin=3), P.random_regular_ell(300, 8, 7, dmin=None), P.poisson2d_edges(17, 9)]
+    n = 400
+    i = np.repeat(np.arange(n), 3)
+    j = np.clip(i + np.tile([-4, 0, 4], n), 0, n - 1)
+    keep = i % 5 != 2                       # every fifth row has no edge at all
+    key, first = np.unique(i[keep].astype(np.int64) * n + j[keep], return_index=True)
+    cases.append((i[keep][np.sort(first)] + 1, j[keep][np.sort(first)] + 1, rs.standard_normal(first.size)))
+    cases.append((np.arange(1, 51), np.arange(1, 51), np.ones(50)))
+    for ei, ej, ev in cases:
+        ne = int(max(np.max(ei), np.max(ej)))
+        E = orc.EllMatrix.from_edges(ne, ne, ei, ej, ev)
+        assert np.array_equal(sg.ell_degrees_host(E.node), E.degrees)
+    assert sg.ell_degrees_host(np.zeros((0, 3), np.int32)).size == 0
+
+
+@pytest.mark.parametrize("nparts", [1, 2, 3, 5])
+def test_rows_of_a_left_permuted_matrix_cut_for_every_rank(nparts):
+    """sgm_left_permute_rows_host (what A%left_permute(p) on a matrix distributed over ranks runs after the gather): for every
+    rank's row range the rows of the oracle's permuted matrix (cs_matrices.f90:471-478), entries in their stored order, values
+    with them; a p that is not a permutation is refused."""
+    sys.path.insert(0, ROOT)
+    import oracle as orc
+    import sigma_amd as sg
+    from sigma_amd import problems as P
+    n = 1200
+    A = orc.CsrMatrix.from_edges(n, n, *P.random_spd_edges(n, seed=5, skew=True))
+    p = (np.random.RandomState(3).permutation(n) + 1).astype(np.int32)
+    Ap = orc.permuted(A, p, None)
+    starts = sg.partition_rows_by_nnz(A.ptr, nparts, align=2)
+    for k in range(nparts):
+        r0, r1 = int(starts[k]), int(starts[k + 1])
+        lptr, lnode, lval = sg.left_permute_rows_host(p, A.ptr, A.node, A.val, r0, r1)
+        k0, k1 = Ap.ptr[r0] - 1, Ap.ptr[r1] - 1
+        assert np.array_equal(lptr, Ap.ptr[r0:r1 + 1] - k0)
+        assert np.array_equal(lnode, Ap.node[k0:k1]) and np.array_equal(lval, Ap.val[k0:k1])
+    bad = p.copy()
+    bad[5] = bad[6]
+    with pytest.raises(sg.SigmaError):
+        sg.left_permute_rows_host(bad, A.ptr, A.node, A.val, 0, 10)

@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE ONLY -- the sanitizer build of the library's host-only index work.
 // sigma_amd/csrc/sgm_plan_host.hpp (the halo / exchange planners of the row-partitioned path, the nnz-balanced row split, the
 // slice schedule: the statements libsigma_hip.so itself runs) compiled by g++ with -fsanitize=address,undefined behind the
-// same six C-ABI entry points, so that tests/test_dist_cpu.py and tests/test_cabi_cpu.py can be run against it
+// same C-ABI entry points, so that tests/test_dist_cpu.py and tests/test_cabi_cpu.py can be run against it
 // (tests/test_asan_cpu.py).  No HIP: nothing here touches a GPU, and nothing of it is shipped.
 #include "../../sigma_amd/csrc/sgm_plan_host.hpp"
 
@@ -54,6 +54,12 @@ int sgm_partition_links_host(int32_t nparts, const int64_t *row_starts, const in
 int sgm_partition_rows_by_nnz(int32_t nrow, const int32_t *ptr, int32_t nparts, int32_t align, int64_t *row_starts)
 {
     return host_partition_rows_by_nnz(nrow, ptr, nparts, align, row_starts);
+}
+int sgm_ell_degrees_host(int32_t n, int32_t max_d, const int32_t *node, int32_t *deg) { return host_ell_degrees_host(n, max_d, node, deg); }
+int sgm_left_permute_rows_host(int32_t n, const int32_t *p, const int32_t *ptr, const int32_t *node, const double *val, int64_t r0,
+                               int64_t r1, int32_t *lptr, int32_t *lnode, double *lval, int64_t capacity, int64_t *needed)
+{
+    return host_left_permute_rows_host(n, p, ptr, node, val, r0, r1, lptr, lnode, lval, capacity, needed);
 }
 int sgm_slice_sched_host(int64_t n_slices, int64_t period_rows, int32_t grid, int32_t band_slices, int32_t *tab_out,
                          int64_t capacity, int32_t *iters_out)
